@@ -1,0 +1,269 @@
+/*
+ * permon_hip.h -- C ABI of libpermonhip: an MI355X (gfx950) implementation of PERMON's QPS hot path.
+ *
+ * Drop-in boundary.  PERMON reaches its numerical kernels through three op tables and a handful of
+ * Mat implementations; every entry point below names the reference slot it replaces
+ * (file:line under /root/reference).  INTEGRATION.md shows the PETSc-side glue that binds them.
+ *
+ *   - all vector arguments are DEVICE pointers to fp64 (PetscScalar = double, real build);
+ *     index arrays handed to *_create functions are HOST pointers (copied to the device once);
+ *   - every function returns 0 (PETSC_SUCCESS) or a non-zero pmh error code; pmh_last_error()
+ *     returns the message.  Solver failure is NOT an error: it is reason < 0 (qps.c:551);
+ *   - no function falls back to a CPU path: without a usable HIP device pmh_init() fails.
+ *   - one pmh context per process = one GPU (one MPI rank <-> one GPU, matblockdiag.c:787-788).
+ */
+#ifndef PERMON_HIP_H
+#define PERMON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- errors ------------------------------------------------------------------------------------ */
+#define PMH_SUCCESS 0
+#define PMH_ERR_HIP 1       /* HIP runtime error (message has the hipError string) */
+#define PMH_ERR_ARG 2       /* bad argument (PETSC_ERR_ARG_*) */
+#define PMH_ERR_STATE 3     /* wrong state (PETSC_ERR_ARG_WRONGSTATE / PETSC_ERR_ORDER) */
+#define PMH_ERR_SUP 4       /* unsupported (PETSC_ERR_SUP) */
+#define PMH_ERR_NODEVICE 5  /* no gfx950 device / extension unusable */
+#define PMH_ERR_COMM 6      /* RCCL error */
+const char *pmh_last_error(void);
+
+/* KSPConvergedReason values the path produces (PETSc petscksp.h; qps.c:675-714, smalxe.c:610-692) */
+#define PMH_CONVERGED_ITERATING 0
+#define PMH_CONVERGED_RTOL 2
+#define PMH_CONVERGED_ATOL 3
+#define PMH_CONVERGED_ITS 4
+#define PMH_CONVERGED_HAPPY_BREAKDOWN 7
+#define PMH_DIVERGED_ITS (-3)
+#define PMH_DIVERGED_DTOL (-4)
+#define PMH_DIVERGED_BREAKDOWN (-5)
+#define PMH_DIVERGED_NANORINF (-9)
+#define PMH_DECIDE (-1.0) /* PETSC_DECIDE */
+
+/* ---- context, memory, multi-GPU communicator ----------------------------------------------------- */
+typedef struct pmh_ctx_s *pmh_ctx;
+
+int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; fails loudly without a GPU */
+int pmh_finalize(pmh_ctx ctx);
+int pmh_device_name(pmh_ctx ctx, char *buf, size_t len);
+int pmh_sync(pmh_ctx ctx);                  /* hipStreamSynchronize of the context's compute stream */
+void *pmh_stream(pmh_ctx ctx);              /* the hipStream_t kernels are launched on */
+
+int pmh_malloc(pmh_ctx ctx, size_t bytes, void **dptr);
+int pmh_free(pmh_ctx ctx, void *dptr);
+int pmh_memcpy_h2d(pmh_ctx ctx, void *dst, const void *src, size_t bytes);
+int pmh_memcpy_d2h(pmh_ctx ctx, void *dst, const void *src, size_t bytes);
+int pmh_memcpy_d2d(pmh_ctx ctx, void *dst, const void *src, size_t bytes);
+int pmh_memset(pmh_ctx ctx, void *dst, int value, size_t bytes);
+
+/* timing on the compute stream with HIP events (bench.py's roofline leg) */
+int pmh_timer_start(pmh_ctx ctx);
+int pmh_timer_stop(pmh_ctx ctx, double *milliseconds);
+
+/* RCCL communicator over xGMI: replaces the MPI_Allreduce / PetscSF / VecScatter call sites of SURVEY 2.4 */
+#define PMH_UNIQUE_ID_BYTES 128
+int pmh_comm_unique_id(void *id128);                                     /* rank 0, then broadcast out of band */
+int pmh_comm_init(pmh_ctx ctx, int rank, int size, const void *id128);  /* collective */
+int pmh_comm_rank(pmh_ctx ctx, int *rank, int *size);
+int pmh_comm_allreduce_sum(pmh_ctx ctx, double *dbuf, size_t count);    /* in place, device buffer */
+int pmh_comm_allreduce_min(pmh_ctx ctx, double *dbuf, size_t count);
+int pmh_comm_barrier(pmh_ctx ctx);
+
+/* ---- Mat: CSR (PETSc SeqAIJ role) ---------------------------------------------------------------- */
+/* replaces MatMult(A,..) at mpgp.c:500,537,578,606,624, mpgp.c:250, permonmatutils.c:487,
+   matblockdiag.c:197 (local block), extension.c:485,519 (condensed block) */
+typedef struct pmh_csr_s *pmh_csr;
+int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowptr, const int *col, const double *val, pmh_csr *A);
+int pmh_csr_destroy(pmh_csr A);
+int pmh_csr_sizes(pmh_csr A, int *nrows, int *ncols, long long *nnz);
+int pmh_csr_mult(pmh_csr A, const double *x, double *y);                       /* y = A x       */
+int pmh_csr_mult_add(pmh_csr A, const double *x, const double *y1, double *y);  /* y = y1 + A x  */
+int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y);             /* y = A' x      */
+int pmh_csr_algorithmic_bytes(pmh_csr A, double *bytes);                        /* 12 nnz + 20 nrows */
+
+/* ---- generic operator (PETSc Mat with a mult slot) ------------------------------------------------ */
+typedef struct pmh_op_s *pmh_op;
+typedef int (*pmh_shell_mult_fn)(void *user, const double *x_dev, double *y_dev);
+int pmh_op_create_csr(pmh_csr A, pmh_op *op);                           /* borrows A */
+int pmh_op_create_shell(pmh_ctx ctx, int n, pmh_shell_mult_fn f, void *user, pmh_op *op); /* MatCreateShellPermon, shell.c:5-31 */
+int pmh_op_destroy(pmh_op op);
+int pmh_op_size(pmh_op op, int *n);
+int pmh_op_mult(pmh_op op, const double *x, double *y);
+/* MatGetMaxEigenvalue, src/mat/interface/permonmatutils.c:442-522 (tol/maxits: PMH_DECIDE -> 1e-4 / 50) */
+int pmh_op_max_eigenvalue(pmh_op op, double tol, int maxits, double *lambda, int *its);
+
+/* ---- QPC box: struct _QPCOps slots (include/permon/private/qpcimpl.h:8-25) ------------------------- */
+/* lb / ub may be NULL (no bound of that kind).  n = local length of the constrained (sub)vector. */
+int pmh_qpc_box_project(pmh_ctx ctx, int n, const double *x, const double *lb, const double *ub, double *Px);     /* QPCProject_Box qpcbox.c:290-305 */
+int pmh_qpc_box_feas(pmh_ctx ctx, int n, const double *x, const double *d, const double *lb, const double *ub, double *alpha_host); /* QPCFeas_Box qpcbox.c:104-146 (+ MIN allreduce qpc.c:521 when a communicator is set) */
+int pmh_qpc_box_grads(pmh_ctx ctx, int n, const double *x, const double *g, const double *lb, const double *ub, double astol, double *gf, double *gc); /* QPCGrads qpc.c:540-569 + QPCGrads_Box qpcbox.c:21-64 */
+int pmh_qpc_box_gradreduced(pmh_ctx ctx, int n, const double *x, const double *gf, const double *lb, const double *ub, double alpha, double *gr); /* QPCGradReduced qpc.c:589-615 + _Box qpcbox.c:68-100 */
+/* expands an index-set restricted bound (qpc->is, qpc.c:416-437) to a full-length bound with -inf/+inf elsewhere */
+int pmh_qpc_box_expand_is(pmh_ctx ctx, int n, int nis, const int *is_host, const double *bound_sub, double fill, double *bound_full);
+
+/* ---- Vec kernels used by the path (PETSc VecAXPY/AYPX/WAXPY/Dot/Norm/Copy/Set/Scale) --------------- */
+int pmh_vec_axpy(pmh_ctx ctx, int n, double *y, double a, const double *x);                  /* y += a x */
+int pmh_vec_aypx(pmh_ctx ctx, int n, double *y, double a, const double *x);                  /* y = x + a y */
+int pmh_vec_waxpy(pmh_ctx ctx, int n, double *w, double a, const double *x, const double *y); /* w = a x + y */
+int pmh_vec_scale(pmh_ctx ctx, int n, double *x, double a);
+int pmh_vec_set(pmh_ctx ctx, int n, double *x, double a);
+int pmh_vec_copy(pmh_ctx ctx, int n, const double *x, double *y);
+int pmh_vec_dot(pmh_ctx ctx, int n, const double *x, const double *y, double *result_host);
+int pmh_vec_norm2(pmh_ctx ctx, int n, const double *x, double *result_host);
+
+/* ---- QPS MPGP: struct _QPSOps.solve / .setup  (src/qps/impls/mpgp/mpgp.c:359-650) ------------------- */
+enum { PMH_EXP_STD = 0, PMH_EXP_PROJCG, PMH_EXP_GF, PMH_EXP_G, PMH_EXP_GFGR, PMH_EXP_GGR };           /* QPSMPGPExpansionTypes, mpgp.c:3 */
+enum { PMH_EXPLEN_FIXED = 0, PMH_EXPLEN_OPT, PMH_EXPLEN_OPTAPPROX, PMH_EXPLEN_BB };                    /* QPSMPGPExpansionLengthTypes, mpgp.c:4 */
+
+typedef struct {
+  /* QPS tolerances: QPSCreate qps.c:73-76 */
+  double rtol, atol, divtol;
+  int    max_it;
+  /* QPS_MPGP: QPSCreate_MPGP mpgp.c:827-843 */
+  double alpha_user;   /* PMH_DECIDE -> 2.0 */
+  int    alpha_direct; /* QPS_ARG_DIRECT (1) / QPS_ARG_MULTIPLE (0) */
+  double gamma;
+  double maxeig;       /* PMH_DECIDE -> power method */
+  double maxeig_tol;
+  int    maxeig_iter;
+  double bchop_tol;
+  double astol;        /* qpc->astol, qpc.c:28: 10*eps */
+  int    exptype, explengthtype;
+  int    resetalpha, fallback, fallback2;
+  int    monitor;      /* record the QPSMonitorDefault_MPGP trace (mpgp.c:21-34) */
+  int    unfused;      /* 1: run the literal one-kernel-per-PETSc-call sequence (every variant supports it);
+                          0: std expansion + fixed length without fallback takes the fused kernels */
+} pmh_mpgp_opts;
+
+typedef struct {
+  int    iteration, reason;
+  double rnorm, gfnorm, gcnorm, alpha, maxeig;
+  int    nmv, ncg, nexp, nprop, nfinc, nfall;
+  double norm_rhs, ttol;
+  char   current_step_type;
+} pmh_mpgp_stats;
+
+typedef struct pmh_mpgp_s *pmh_mpgp;
+int pmh_mpgp_default_opts(pmh_mpgp_opts *o);
+/* QPSSetup_MPGP: work vectors, bound chop, power method, alpha. lb/ub full-length device vectors or NULL */
+int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x, const double *lb, const double *ub, const pmh_mpgp_opts *o, pmh_mpgp *s);
+int pmh_mpgp_destroy(pmh_mpgp s);
+int pmh_mpgp_solve(pmh_mpgp s);                                     /* QPSSolve_MPGP mpgp.c:438-650 */
+int pmh_mpgp_get_stats(pmh_mpgp s, pmh_mpgp_stats *st);
+/* qps->convergencetest (qps.c:675; called at mpgp.c:531 every iteration with rnorm / iteration current).
+   The callback sets *reason (0 = keep iterating); NULL restores QPSConvergedDefault.  This is the hook
+   SMALXE uses to inject QPSConverged_Inner_SMALXE (smalxe.c:874-875). */
+typedef int (*pmh_converged_fn)(void *user, int iteration, double rnorm, int *reason);
+int pmh_mpgp_set_convergence_test(pmh_mpgp s, pmh_converged_fn f, void *user);
+int pmh_mpgp_set_tolerances(pmh_mpgp s, double rtol, double atol, double divtol, int max_it); /* QPSSetTolerances */
+/* monitor trace: per iteration step type, ||gP||, ||gf||, ||gc||, alpha (arrays of length >= iteration+1) */
+int pmh_mpgp_get_trace(pmh_mpgp s, int cap, char *step, double *gp, double *gf, double *gc, double *alpha, int *len);
+int pmh_mpgp_get_work(pmh_mpgp s, int idx, const double **dptr);   /* work[0..6] = gP,gf,gc,g,p,Ap,gr (mpgp.c:6-17) */
+/* composed methods SMALXE needs from its inner solver (mpgp.c:858-869) */
+int pmh_mpgp_set_operator_max_eigenvalue(pmh_mpgp s, double maxeig);   /* "QPSMPGPSetOperatorMaxEigenvalue_MPGP_C" mpgp.c:107-115 */
+int pmh_mpgp_update_max_eigenvalue(pmh_mpgp s, double maxeig_update);  /* "QPSMPGPUpdateMaxEigenvalue_MPGP_C"      mpgp.c:119-143 */
+int pmh_mpgp_get_current_step_type(pmh_mpgp s, char *step);            /* "QPSMPGPGetCurrentStepType_MPGP_C"       mpgp.c:38-45  */
+int pmh_mpgp_reset_statistics(pmh_mpgp s);                             /* QPSResetStatistics_MPGP mpgp.c:654-664 */
+/* throughput mode for bench.py: run exactly `iters` iterations of the loop with the convergence test
+   evaluated but its verdict ignored (the work per iteration is unchanged) */
+int pmh_mpgp_run_fixed(pmh_mpgp s, int iters);
+
+/* ---- QPPF projector factory (src/qppf/interface/qppf.c) ----------------------------------------------- */
+typedef struct pmh_qppf_s *pmh_qppf;
+/* G: m x n CSR (device); GG' is formed and Cholesky-factored on the host once (QPPFSetUpGGt/GGtinv_Private
+   qppf.c:213-333, MATINV monolithic direct solve), the factor is applied redundantly on the device.
+   orthonormal != 0 <=> G_has_orthonormal_rows (GGtinv = NULL, qppf.c:225-229) */
+int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf *pf);
+int pmh_qppf_destroy(pmh_qppf pf);
+int pmh_qppf_apply_Q(pmh_qppf pf, const double *v, double *Qv);     /* QPPFApplyQ   qppf.c:454-503 */
+int pmh_qppf_apply_P(pmh_qppf pf, const double *v, double *Pv);     /* QPPFApplyP   qppf.c:563-575 */
+int pmh_qppf_apply_GtG(pmh_qppf pf, const double *v, double *y);    /* QPPFApplyGtG qppf.c:580-605 */
+int pmh_qppf_apply_CP(pmh_qppf pf, const double *x, double *y);     /* QPPFApplyCP  qppf.c:610-645: y = (GG')^{-1} x, length m */
+int pmh_qppf_apply_halfQ(pmh_qppf pf, const double *x, double *y);  /* QPPFApplyHalfQ qppf.c:507-527 */
+int pmh_qppf_apply_halfQ_transpose(pmh_qppf pf, const double *x, double *y); /* qppf.c:531-559 */
+int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv);     /* MatMult(cp->G,..) qppf.c:475 */
+
+/* ---- composed operators of the QP transform chain ------------------------------------------------------ */
+int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op *op);   /* MatCreatePenalized matpenalized.c:212-243; mult :12-22 */
+int pmh_op_penalized_set_penalty(pmh_op op, double rho);                      /* MatPenalizedSetPenalty */
+int pmh_op_penalized_get_penalty(pmh_op op, double *rho);
+int pmh_op_create_projected(pmh_op A, pmh_qppf pf, int symmetric, pmh_op *op); /* P*A*P (symmetric) or P*A: qptransform.c:273-284 */
+
+/* ---- FETI Mats ------------------------------------------------------------------------------------------ */
+/* MATGLUING (src/mat/impls/gluing/gluing.c): leaves (local primal dof, lambda index, sign).
+   mult: x = B' lambda (gluing.c:47-81); mult_transpose: lambda = B x (gluing.c:125-159); in a multi-GPU
+   run lambda is replicated and mult_transpose ends with an RCCL all-reduce (replaces PetscSFReduce :144-147). */
+typedef struct pmh_gluing_s *pmh_gluing;
+int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leaves, const int *leaves_row, const int *leaves_root, const double *leaves_sign, pmh_gluing *B);
+int pmh_gluing_destroy(pmh_gluing B);
+int pmh_gluing_mult(pmh_gluing B, const double *lambda, double *x);
+int pmh_gluing_mult_transpose(pmh_gluing B, const double *x, double *lambda);
+
+/* MATBLOCKDIAG (src/mat/impls/blockdiag/matblockdiag.c:190-201): the rank's sequential blocks.
+   Several subdomains per GPU (BASELINE configs[3]) are stored as ONE concatenated CSR + block offsets. */
+typedef struct pmh_blockdiag_s *pmh_blockdiag;
+int pmh_blockdiag_create(pmh_ctx ctx, int nblocks, const int *block_rowstart /* nblocks+1 */, pmh_csr Kcat, pmh_blockdiag *K);
+int pmh_blockdiag_destroy(pmh_blockdiag K);
+int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y);
+
+/* MATINV apply (src/mat/impls/inv/matinv.c:734-743) on the iterative path the reference takes for a
+   non-factorisable inner matrix (KSPCG + PCNONE/PCJACOBI per block, matinv.c:535-540): block-wise
+   (regularised) CG, every block with its own scalars.  rtol/max_it as KSP; regularisation is the
+   caller's (MatRegularize is set-up code). */
+typedef struct pmh_matinv_s *pmh_matinv;
+int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int max_it, int jacobi, pmh_matinv *Kplus);
+int pmh_matinv_destroy(pmh_matinv Kplus);
+int pmh_matinv_mult(pmh_matinv Kplus, const double *f, double *u);
+int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *total_spmv);
+
+/* F = B K^+ B' (QPTDualize qptransform.c:1103-1128; MatCreateProd matprod.c:42-48) */
+int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
+/* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */
+int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, double *y);
+
+/* ---- QPS SMALXE (src/qps/impls/smalxe/smalxe.c) -------------------------------------------------------- */
+typedef struct {
+  double rtol, atol, divtol;
+  int    max_it;             /* outer, default 100 (smalxe.c:1203) */
+  double M1_user;  int M1_direct;  double M1_update;
+  double rtol_E;
+  double rho_user; int rho_direct; double rho_update, rho_update_late;
+  double eta_user; int eta_direct;
+  double update_threshold;
+  double maxeig, maxeig_tol; int maxeig_iter;
+  int    inject_maxeig, inject_maxeig_set;
+  int    inner_iter_min, inner_no_gtol_stop;
+  pmh_mpgp_opts inner;       /* inner MPGP (prefix smalxe_) */
+} pmh_smalxe_opts;
+
+typedef struct {
+  int    iteration, reason, inner_iter_accu, state;
+  int    M1_hits, eta_hits, M1_updates, rho_updates;
+  double M1, rho, eta, normBu, enorm, rnorm, maxeig;
+  pmh_mpgp_stats inner;
+} pmh_smalxe_stats;
+
+typedef struct pmh_smalxe_s *pmh_smalxe;
+int pmh_smalxe_default_opts(pmh_smalxe_opts *o);
+/* QPSSetUp_SMALXE smalxe.c:772-888: A (outer Hessian, e.g. P F P), b, u, box, pf with BE = G, cE = 0 */
+int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double *u, const double *lb, const double *ub, pmh_qppf pf, const pmh_smalxe_opts *o, pmh_smalxe *s);
+int pmh_smalxe_destroy(pmh_smalxe s);
+int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve_SMALXE smalxe.c:893-997 */
+int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
+
+/* ---- QPS PCPG (src/qps/impls/pcpg/pcpg.c:51-134) -------------------------------------------------------- */
+typedef struct {
+  int    iteration, reason;
+  double rnorm;
+} pmh_pcpg_stats;
+/* pc: NULL (none) or an operator applied as z = M^{-1} w (PCApply), e.g. the lumped dual preconditioner */
+int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_qppf pf, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERMON_HIP_H */

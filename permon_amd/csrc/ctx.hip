@@ -1,0 +1,223 @@
+// Context, device memory, HIP-event timers and the RCCL communicator of libpermonhip.
+#include "pmh_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+int pmh_set_error(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char *pmh_last_error(void) { return g_err; }
+
+extern "C" int pmh_init(int device, pmh_ctx *out)
+{
+  PMH_ARG(out);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return pmh_set_error(PMH_ERR_NODEVICE, "pmh_init: no HIP device visible (libpermonhip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return pmh_set_error(PMH_ERR_ARG, "pmh_init: device %d out of range [0,%d)", device, ndev);
+  PMH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PMH_HIP(hipGetDeviceProperties(&prop, device));
+  if (!strstr(prop.gcnArchName, "gfx950")) return pmh_set_error(PMH_ERR_NODEVICE, "pmh_init: device %d is %s; libpermonhip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  pmh_ctx c  = new pmh_ctx_s();
+  c->device  = device;
+  c->num_cus = prop.multiProcessorCount;
+  c->comm    = nullptr;
+  c->rank    = 0;
+  c->size    = 1;
+  PMH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PMH_HIP(hipEventCreate(&c->ev0));
+  PMH_HIP(hipEventCreate(&c->ev1));
+  c->partials_cap = PMH_MAX_VEC_BLOCKS;
+  PMH_HIP(hipMalloc((void **)&c->d_partials, sizeof(double) * PMH_MAX_RED * c->partials_cap));
+  PMH_HIP(hipMalloc((void **)&c->d_scal, sizeof(double) * PMH_NSCAL));
+  PMH_HIP(hipMemset(c->d_scal, 0, sizeof(double) * PMH_NSCAL));
+  PMH_HIP(hipHostMalloc((void **)&c->h_scal, sizeof(double) * PMH_NSCAL, hipHostMallocMapped));
+  memset(c->h_scal, 0, sizeof(double) * PMH_NSCAL);
+  PMH_HIP(hipMalloc((void **)&c->d_commbuf, sizeof(double) * PMH_NSCAL));
+  *out = c;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_finalize(pmh_ctx c)
+{
+  if (!c) return PMH_SUCCESS;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  hipFree(c->d_partials);
+  hipFree(c->d_scal);
+  hipFree(c->d_commbuf);
+  hipHostFree(c->h_scal);
+  hipEventDestroy(c->ev0);
+  hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_device_name(pmh_ctx c, char *buf, size_t len)
+{
+  PMH_ARG(c && buf && len > 0);
+  hipDeviceProp_t prop;
+  PMH_HIP(hipGetDeviceProperties(&prop, c->device));
+  snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_sync(pmh_ctx c)
+{
+  PMH_ARG(c);
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" void *pmh_stream(pmh_ctx c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int pmh_malloc(pmh_ctx c, size_t bytes, void **dptr)
+{
+  PMH_ARG(c && dptr);
+  PMH_HIP(hipSetDevice(c->device));
+  PMH_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_free(pmh_ctx c, void *dptr)
+{
+  PMH_ARG(c);
+  if (dptr) {
+    PMH_HIP(hipStreamSynchronize(c->stream));
+    PMH_HIP(hipFree(dptr));
+  }
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_memcpy_h2d(pmh_ctx c, void *dst, const void *src, size_t bytes)
+{
+  PMH_ARG(c);
+  if (!bytes) return PMH_SUCCESS;
+  PMH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_memcpy_d2h(pmh_ctx c, void *dst, const void *src, size_t bytes)
+{
+  PMH_ARG(c);
+  if (!bytes) return PMH_SUCCESS;
+  PMH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_memcpy_d2d(pmh_ctx c, void *dst, const void *src, size_t bytes)
+{
+  PMH_ARG(c);
+  if (!bytes || dst == src) return PMH_SUCCESS;
+  PMH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_memset(pmh_ctx c, void *dst, int value, size_t bytes)
+{
+  PMH_ARG(c);
+  if (!bytes) return PMH_SUCCESS;
+  PMH_HIP(hipMemsetAsync(dst, value, bytes, c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_timer_start(pmh_ctx c)
+{
+  PMH_ARG(c);
+  PMH_HIP(hipEventRecord(c->ev0, c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_timer_stop(pmh_ctx c, double *ms)
+{
+  PMH_ARG(c && ms);
+  float f = 0.f;
+  PMH_HIP(hipEventRecord(c->ev1, c->stream));
+  PMH_HIP(hipEventSynchronize(c->ev1));
+  PMH_HIP(hipEventElapsedTime(&f, c->ev0, c->ev1));
+  *ms = (double)f;
+  return PMH_SUCCESS;
+}
+
+// ---- RCCL over xGMI ---------------------------------------------------------------------------------------
+extern "C" int pmh_comm_unique_id(void *id128)
+{
+  PMH_ARG(id128);
+  static_assert(sizeof(ncclUniqueId) <= PMH_UNIQUE_ID_BYTES, "ncclUniqueId larger than PMH_UNIQUE_ID_BYTES");
+  ncclUniqueId id;
+  PMH_NCCL(ncclGetUniqueId(&id));
+  memset(id128, 0, PMH_UNIQUE_ID_BYTES);
+  memcpy(id128, &id, sizeof(id));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_comm_init(pmh_ctx c, int rank, int size, const void *id128)
+{
+  PMH_ARG(c && id128 && size >= 1 && rank >= 0 && rank < size);
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  PMH_HIP(hipSetDevice(c->device));
+  PMH_NCCL(ncclCommInitRank(&c->comm, size, id, rank));
+  c->rank = rank;
+  c->size = size;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_comm_rank(pmh_ctx c, int *rank, int *size)
+{
+  PMH_ARG(c);
+  if (rank) *rank = c->rank;
+  if (size) *size = c->size;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_comm_allreduce_sum(pmh_ctx c, double *dbuf, size_t count)
+{
+  PMH_ARG(c);
+  if (c->size == 1 || !count) return PMH_SUCCESS;
+  PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, c->comm, c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_comm_allreduce_min(pmh_ctx c, double *dbuf, size_t count)
+{
+  PMH_ARG(c);
+  if (c->size == 1 || !count) return PMH_SUCCESS;
+  PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclMin, c->comm, c->stream));
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_comm_barrier(pmh_ctx c)
+{
+  PMH_ARG(c);
+  if (c->size > 1) {
+    PMH_NCCL(ncclAllReduce(c->d_commbuf, c->d_commbuf, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  }
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  return PMH_SUCCESS;
+}
+
+int pmh_scalar_allreduce(pmh_ctx c, int slot, int count, int op)
+{
+  if (c->size == 1) return PMH_SUCCESS;
+  PMH_NCCL(ncclAllReduce(c->d_scal + slot, c->d_scal + slot, count, ncclDouble, op == PMH_RED_MIN ? ncclMin : ncclSum, c->comm, c->stream));
+  PMH_HIP(hipMemcpyAsync(c->h_scal + slot, c->d_scal + slot, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  return PMH_SUCCESS;
+}
+
+int pmh_host_scalar(pmh_ctx c, int slot, double *v)
+{
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  *v = c->h_scal[slot];
+  return PMH_SUCCESS;
+}

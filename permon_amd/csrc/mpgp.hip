@@ -1,0 +1,847 @@
+// QPS MPGP on gfx950: QPSSetup_MPGP / QPSSolve_MPGP (src/qps/impls/mpgp/mpgp.c:359-650).
+//
+// Two drivers behind one entry point:
+//  * solve_unfused(): the reference's operation sequence, one device kernel per PETSc Vec/Mat/QPC call
+//    (every expansion type x step-length rule, fallback, fallback2).  It exists so that every variant of
+//    the reference is available and so that each op-table slot is exercised exactly as PERMON calls it.
+//  * solve_fused(): the default variant (std expansion, fixed length, no fallback): the ~25 passes of an
+//    iteration collapse into the phases of SURVEY 8d --
+//      P1  Ap = A p  with  p'Ap, g'p, QPCFeas fused into the SpMV epilogue          (B_spmv + 24 n bytes)
+//      P2  x -= a p, g -= a Ap, gradient split, Ap'gf, |gP|^2, |gc|^2, |gf|^2       (64 n bytes)
+//      P3  p = gf - beta p                                                            (24 n bytes)
+//    gP, gc, gr are never stored (gc / gr are recomputed inside the rare proportioning / expansion
+//    kernels).  Step lengths are read by the kernels from device scalars; the host only decides the step
+//    TYPE, and the next iteration's SpMV is enqueued speculatively before the host reads the scalars.
+// Both produce the same iterates up to reduction-order rounding; tests compare them with the CPU oracle.
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "pmh_internal.h"
+#include "reduce.h"
+
+#define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < (n); i += (long long)gridDim.x * PMH_BLOCK)
+
+// scalar slots
+#define S_PAP 8
+#define S_GP 9
+#define S_FEAS 10
+#define S_APGF 16
+#define S_GP2 17
+#define S_GC2 18
+#define S_GF2 19
+#define S_TMP 24
+
+struct pmh_mpgp_s {
+  pmh_ctx       ctx;
+  pmh_op        A;
+  pmh_csr       csr;
+  int           n;
+  const double *b;
+  double       *x;
+  const double *lb, *ub;
+  pmh_mpgp_opts o;
+  // QPS_MPGP state
+  double alpha, alpha_user, maxeig;
+  int    expproject;
+  double *work[10];
+  int     nwork;
+  // convergence
+  pmh_converged_fn cvg;
+  void            *cvg_user;
+  double           norm_rhs, ttol, norm_rhs_div;
+  int              cvg_setup;
+  // results
+  double rnorm, gfnorm, gcnorm;
+  int    iteration, reason;
+  int    nmv, ncg, nexp, nprop, nfinc, nfall;
+  char   step;
+  int    fallback_state;
+  // monitor
+  std::vector<char>   t_step;
+  std::vector<double> t_gp, t_gf, t_gc, t_alpha;
+  // throughput mode
+  int fixed_iters;
+};
+
+// --------------------------------------------------------------------------------------------------------------------
+// device helpers: the box predicates of qpcbox.c restated per element
+// --------------------------------------------------------------------------------------------------------------------
+// QPCGrads_Box qpcbox.c:41-55 (lower bound wins ties, `else if`)
+__device__ __forceinline__ void box_split(double xi, double gi, const double *lb, const double *ub, long long i, double astol, double &gf, double &gc)
+{
+  gf = gi;
+  gc = 0.0;
+  if (lb && fabs(xi - lb[i]) <= astol) {
+    gf = 0.0;
+    gc = (gi < 0.0) ? gi : 0.0;
+  } else if (ub && fabs(xi - ub[i]) <= astol) {
+    gf = 0.0;
+    gc = (gi > 0.0) ? gi : 0.0;
+  }
+}
+
+// QPCGradReduced_Box qpcbox.c:86-92
+__device__ __forceinline__ double box_reduced(double xi, double gf, const double *lb, const double *ub, long long i, double alpha)
+{
+  double r = gf;
+  if (lb && gf > 0.0) {
+    double t = (xi - lb[i]) / alpha;
+    r        = (gf < t) ? gf : t;
+  } else if (ub && gf < 0.0) {
+    double t = (xi - ub[i]) / alpha;
+    r        = (gf < t) ? t : gf;
+  }
+  return r;
+}
+
+template <int K>
+__device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld)
+{
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double r = pmh_block_reduce<PMH_RED_SUM>(v[k], lds);
+    if (threadIdx.x == 0) partials[(size_t)k * ld + blockIdx.x] = r;
+  }
+}
+
+// gradient split + norms (+ p = gf): after the initial gradient and after an expansion step
+// (MPGPGrads mpgp.c:198-223 + VecCopy(gf,p) :507/:615 + the three reductions of :514-521)
+__global__ __launch_bounds__(PMH_BLOCK) void k_split_setp(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ p, double *__restrict__ partials, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            acc[4] = {0.0, 0.0, 0.0, 0.0};
+  GRID_STRIDE(i, n)
+  {
+    double f, c;
+    box_split(x[i], g[i], lb, ub, i, astol, f, c);
+    gf[i]      = f;
+    p[i]       = f;
+    double gPi = f + c; // VecWAXPY(gP,1,gf,gc)
+    acc[1] += gPi * gPi;
+    acc[2] += c * c;
+    acc[3] += f * f;
+  }
+  write_partials<4>(acc, lds, partials, ld);
+}
+
+// P2: CG / proportioning update.  acg = (g'p)/(p'Ap) from device scalars (mpgp.c:541-543, :628-630);
+// x -= acg p; g -= acg Ap (:553-554 / :633-634); split (:555 / :635); Ap'gf for beta (:558); norms.
+template <bool SETP>
+__global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const double *__restrict__ scal, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            acg = scal[S_GP] / scal[S_PAP];
+  const double      ma  = -acg;
+  double            acc[4] = {0.0, 0.0, 0.0, 0.0};
+  GRID_STRIDE(i, n)
+  {
+    double api = Ap[i];
+    double xi  = x[i] + ma * p[i];
+    double gi  = g[i] + ma * api;
+    double f, c;
+    box_split(xi, gi, lb, ub, i, astol, f, c);
+    x[i]  = xi;
+    g[i]  = gi;
+    gf[i] = f;
+    if (SETP) p[i] = f;
+    double gPi = f + c;
+    acc[0] += api * f;
+    acc[1] += gPi * gPi;
+    acc[2] += c * c;
+    acc[3] += f * f;
+  }
+  write_partials<4>(acc, lds, partials, ld);
+}
+
+// P3: p = gf - bcg p, bcg = (Ap'gf)/(p'Ap) (mpgp.c:558-560: VecAYPX(p,-bcg,gf))
+__global__ __launch_bounds__(PMH_BLOCK) void k_dir_update(long long n, const double *__restrict__ scal, const double *__restrict__ gf, double *__restrict__ p)
+{
+  double       bcg = scal[S_APGF] / scal[S_PAP];
+  const double mb  = -bcg;
+  GRID_STRIDE(i, n) p[i] = gf[i] + mb * p[i];
+}
+
+// proportioning direction p = gc (mpgp.c:623), gc recomputed from x, g
+__global__ __launch_bounds__(PMH_BLOCK) void k_prop_dir(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ p)
+{
+  GRID_STRIDE(i, n)
+  {
+    double f, c;
+    box_split(x[i], g[i], lb, ub, i, astol, f, c);
+    p[i] = c;
+  }
+}
+
+// expansion (std direction, fixed length; MPGPExpansion_Std mpgp.c:299-323):
+// x -= afeas p; g -= afeas Ap; split; gr; x -= alpha gr.  g is not stored: it is recomputed as A x - b next.
+__global__ __launch_bounds__(PMH_BLOCK) void k_expansion_std(long long n, double afeas, double alpha, double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol)
+{
+  const double maf = -afeas, mal = -alpha;
+  GRID_STRIDE(i, n)
+  {
+    double xi = x[i] + maf * p[i];
+    double gi = g[i] + maf * Ap[i];
+    double f, c;
+    box_split(xi, gi, lb, ub, i, astol, f, c);
+    double r = box_reduced(xi, f, lb, ub, i, alpha);
+    x[i]     = xi + mal * r;
+  }
+}
+
+// p'Ap, g'p, QPCFeas for operators without a fused SpMV epilogue (shell operators: F, P F P, A + rho Q ...)
+__global__ __launch_bounds__(PMH_BLOCK) void k_p1_dots(long long n, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ g, const double *__restrict__ x, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ partials, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            s0 = 0.0, s1 = 0.0, m = INFINITY;
+  GRID_STRIDE(i, n)
+  {
+    double pi = p[i];
+    s0 += pi * Ap[i];
+    s1 += g[i] * pi;
+    if (pi > 0. && lb) {
+      double l = lb[i];
+      if (l > -INFINITY) m = fmin(m, (x[i] - l) / pi);
+    }
+    if (pi < 0. && ub) {
+      double u = ub[i];
+      if (u < INFINITY) m = fmin(m, (x[i] - u) / pi);
+    }
+  }
+  s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
+  s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
+  m  = pmh_block_reduce<PMH_RED_MIN>(m, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x]          = s0;
+    partials[ld + blockIdx.x]     = s1;
+    partials[2 * ld + blockIdx.x] = m;
+  }
+}
+
+// three squared norms in one pass (unfused driver: VecNorm(gP), VecDot(gc,gc), VecDot(gf,gf) mpgp.c:514-521)
+__global__ __launch_bounds__(PMH_BLOCK) void k_three_norms(long long n, const double *__restrict__ gP, const double *__restrict__ gc, const double *__restrict__ gf, double *__restrict__ partials, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            acc[4] = {0.0, 0.0, 0.0, 0.0};
+  GRID_STRIDE(i, n)
+  {
+    double a = gP[i], c = gc[i], f = gf[i];
+    acc[1] += a * a;
+    acc[2] += c * c;
+    acc[3] += f * f;
+  }
+  write_partials<4>(acc, lds, partials, ld);
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_filter(long long n, double *v, double tol)
+{
+  GRID_STRIDE(i, n) if (fabs(v[i]) < tol) v[i] = 0.0;
+}
+
+// objective from gradient f = 1/2 x'(g - b) (QPComputeObjectiveFromGradient qp.c:981-996)
+__global__ __launch_bounds__(PMH_BLOCK) void k_obj_from_grad(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ b, double *__restrict__ partials)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            s = 0.0;
+  GRID_STRIDE(i, n) s += x[i] * (-1.0 * b[i] + g[i]);
+  s = pmh_block_reduce<PMH_RED_SUM>(s, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+#define LAUNCH(kern, ...) \
+  do { \
+    if (s->n > 0) hipLaunchKernelGGL(kern, dim3(pmh_vec_grid(s->n)), dim3(PMH_BLOCK), 0, s->ctx->stream, (long long)s->n, __VA_ARGS__); \
+    PMH_HIP(hipGetLastError()); \
+  } while (0)
+
+// --------------------------------------------------------------------------------------------------------------------
+// set-up
+// --------------------------------------------------------------------------------------------------------------------
+extern "C" int pmh_mpgp_default_opts(pmh_mpgp_opts *o)
+{
+  PMH_ARG(o);
+  memset(o, 0, sizeof(*o));
+  o->rtol          = 1e-5; // QPSCreate qps.c:73-76
+  o->atol          = 1e-50;
+  o->divtol        = 1e4;
+  o->max_it        = 10000;
+  o->alpha_user    = PMH_DECIDE; // QPSCreate_MPGP mpgp.c:827-843
+  o->alpha_direct  = 0;
+  o->gamma         = 1.0;
+  o->maxeig        = PMH_DECIDE;
+  o->maxeig_tol    = PMH_DECIDE;
+  o->maxeig_iter   = -1;
+  o->bchop_tol     = 0.0;
+  o->astol         = 10 * 2.220446049250313e-16; // qpc.c:28
+  o->exptype       = PMH_EXP_STD;
+  o->explengthtype = PMH_EXPLEN_FIXED;
+  return PMH_SUCCESS;
+}
+
+static int ensure_work(pmh_mpgp s, int i)
+{
+  if (!s->work[i]) {
+    PMH_CHK(pmh_malloc(s->ctx, sizeof(double) * (size_t)s->n, (void **)&s->work[i]));
+    PMH_CHK(pmh_memset(s->ctx, s->work[i], 0, sizeof(double) * (size_t)s->n));
+  }
+  return PMH_SUCCESS;
+}
+
+static bool use_fused(pmh_mpgp s)
+{
+  return !s->o.unfused && s->o.exptype == PMH_EXP_STD && s->o.explengthtype == PMH_EXPLEN_FIXED && !s->o.fallback && !s->o.fallback2;
+}
+
+// QPSSetup_MPGP mpgp.c:359-428
+extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x, const double *lb, const double *ub, const pmh_mpgp_opts *o, pmh_mpgp *out)
+{
+  PMH_ARG(ctx && A && b && x && o && out);
+  PMH_ARG(o->exptype >= PMH_EXP_STD && o->exptype <= PMH_EXP_GGR);
+  PMH_ARG(o->explengthtype >= PMH_EXPLEN_FIXED && o->explengthtype <= PMH_EXPLEN_BB);
+  pmh_mpgp s = new pmh_mpgp_s();
+  s->ctx     = ctx;
+  s->A       = A;
+  s->csr     = A->as_csr();
+  s->n       = A->n;
+  s->b       = b;
+  s->x       = x;
+  s->lb      = lb;
+  s->ub      = ub;
+  s->o       = *o;
+  if (s->o.fallback2) s->o.fallback = 0; // mpgp.c:744
+  for (int i = 0; i < 10; i++) s->work[i] = nullptr;
+  s->nwork = 0;
+  s->cvg = nullptr, s->cvg_user = nullptr, s->cvg_setup = 0;
+  s->norm_rhs = s->ttol = s->norm_rhs_div = 0.0;
+  s->rnorm = s->gfnorm = s->gcnorm = 0.0;
+  s->iteration = 0, s->reason = 0;
+  s->nmv = s->ncg = s->nexp = s->nprop = s->nfinc = s->nfall = 0;
+  s->step           = ' ';
+  s->fixed_iters    = -1;
+  s->fallback_state = s->o.fallback;
+  if (s->o.bchop_tol) { // mpgp.c:379-382: VecFilter on the user's bound vectors, in place as in the reference
+    if (lb) LAUNCH(k_filter, (double *)lb, s->o.bchop_tol);
+    if (ub) LAUNCH(k_filter, (double *)ub, s->o.bchop_tol);
+  }
+  s->expproject = 1; // mpgp.c:839
+  if (s->o.exptype == PMH_EXP_STD && s->o.explengthtype == PMH_EXPLEN_FIXED) s->expproject = 0; // mpgp.c:388
+  s->maxeig     = s->o.maxeig;
+  s->alpha_user = s->o.alpha_user;
+  if (!s->o.alpha_direct) { // QPS_ARG_MULTIPLE mpgp.c:417-422
+    if (s->maxeig == PMH_DECIDE) {
+      int rc = pmh_op_max_eigenvalue(A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr);
+      if (rc) {
+        delete s;
+        return rc;
+      }
+    }
+    if (s->alpha_user == PMH_DECIDE) s->alpha_user = 2.0;
+    s->alpha = s->alpha_user / s->maxeig;
+  } else {
+    s->alpha = s->alpha_user;
+  }
+  *out = s;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_destroy(pmh_mpgp s)
+{
+  if (!s) return PMH_SUCCESS;
+  for (int i = 0; i < 10; i++)
+    if (s->work[i]) pmh_free(s->ctx, s->work[i]);
+  delete s;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_set_convergence_test(pmh_mpgp s, pmh_converged_fn f, void *user)
+{
+  PMH_ARG(s);
+  s->cvg      = f;
+  s->cvg_user = user;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_set_tolerances(pmh_mpgp s, double rtol, double atol, double divtol, int max_it)
+{
+  PMH_ARG(s);
+  s->o.rtol    = rtol;
+  s->o.atol    = atol;
+  s->o.divtol  = divtol;
+  s->o.max_it  = max_it;
+  s->cvg_setup = 0;
+  return PMH_SUCCESS;
+}
+
+// "QPSMPGPSetOperatorMaxEigenvalue_MPGP_C" mpgp.c:107-115 (then QPSSetup_MPGP recomputes alpha :417-422)
+extern "C" int pmh_mpgp_set_operator_max_eigenvalue(pmh_mpgp s, double maxeig)
+{
+  PMH_ARG(s && (maxeig >= 0 || maxeig == PMH_DECIDE));
+  s->maxeig = maxeig;
+  if (!s->o.alpha_direct) {
+    if (s->maxeig == PMH_DECIDE) PMH_CHK(pmh_op_max_eigenvalue(s->A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr));
+    s->alpha = s->alpha_user / s->maxeig;
+  }
+  return PMH_SUCCESS;
+}
+
+// "QPSMPGPUpdateMaxEigenvalue_MPGP_C" mpgp.c:119-143
+extern "C" int pmh_mpgp_update_max_eigenvalue(pmh_mpgp s, double maxeig_update)
+{
+  PMH_ARG(s);
+  if (maxeig_update == 1.0) return PMH_SUCCESS; // mpgp.c:1007
+  s->maxeig = s->maxeig * maxeig_update;
+  if (!s->o.alpha_direct) s->alpha = s->alpha / maxeig_update;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_get_current_step_type(pmh_mpgp s, char *step)
+{
+  PMH_ARG(s && step);
+  *step = s->step;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_reset_statistics(pmh_mpgp s)
+{
+  PMH_ARG(s);
+  s->ncg = s->nexp = s->nmv = s->nprop = 0; // mpgp.c:659-662 (nfinc/nfall are not reset there)
+  return PMH_SUCCESS;
+}
+
+// QPSConvergedDefault qps.c:675-714 + QPSConvergedDefaultSetUp :718-731
+static int converged_default(pmh_mpgp s)
+{
+  if (!s->cvg_setup) {
+    PMH_CHK(pmh_vec_norm2(s->ctx, s->n, s->b, &s->norm_rhs));
+    s->ttol         = fmax(s->o.rtol * s->norm_rhs, s->o.atol);
+    s->norm_rhs_div = s->norm_rhs;
+    s->cvg_setup    = 1;
+  }
+  s->reason = PMH_CONVERGED_ITERATING;
+  if (s->iteration > s->o.max_it) { // strict, qps.c:688
+    s->reason = PMH_DIVERGED_ITS;
+    return PMH_SUCCESS;
+  }
+  if (std::isnan(s->rnorm) || std::isinf(s->rnorm)) s->reason = PMH_DIVERGED_NANORINF;
+  else if (s->rnorm <= s->ttol) s->reason = (s->rnorm < s->o.atol) ? PMH_CONVERGED_ATOL : PMH_CONVERGED_RTOL;
+  else if (s->rnorm >= s->o.divtol * s->norm_rhs_div) s->reason = PMH_DIVERGED_DTOL;
+  return PMH_SUCCESS;
+}
+
+// monitor (mpgp.c:524-528) + convergence test (mpgp.c:531)
+static int test_convergence(pmh_mpgp s)
+{
+  if (s->o.monitor) {
+    s->t_step.push_back(s->step);
+    s->t_gp.push_back(s->rnorm);
+    s->t_gf.push_back(s->gfnorm);
+    s->t_gc.push_back(s->gcnorm);
+    s->t_alpha.push_back(s->alpha);
+  }
+  if (s->cvg) {
+    int reason = 0;
+    int rc     = s->cvg(s->cvg_user, s->iteration, s->rnorm, &reason);
+    if (rc) return pmh_set_error(PMH_ERR_ARG, "convergence test callback returned %d", rc);
+    s->reason = reason;
+  } else {
+    PMH_CHK(converged_default(s));
+  }
+  if (s->fixed_iters >= 0) s->reason = (s->iteration >= s->fixed_iters) ? PMH_CONVERGED_ITS : PMH_CONVERGED_ITERATING; // throughput mode
+  return PMH_SUCCESS;
+}
+
+static int finalize_vec4(pmh_mpgp s)
+{
+  const int ops[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
+  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 4, ops, S_APGF);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// unfused driver: QPSSolve_MPGP mpgp.c:438-650 call by call
+// --------------------------------------------------------------------------------------------------------------------
+static double *exp_direction(pmh_mpgp s)
+{
+  switch (s->o.exptype) { // mpgp.c:384-414
+  case PMH_EXP_STD: return s->work[6];
+  case PMH_EXP_GF: return s->work[1];
+  case PMH_EXP_G: return s->work[3];
+  case PMH_EXP_GFGR: return s->work[1];
+  case PMH_EXP_GGR: return s->work[3];
+  default: return s->work[1]; // projcg fallback vectors
+  }
+}
+static double *exp_lengthvec(pmh_mpgp s)
+{
+  switch (s->o.exptype) {
+  case PMH_EXP_STD: return s->work[6];
+  case PMH_EXP_GF: return s->work[1];
+  case PMH_EXP_G: return s->work[3];
+  case PMH_EXP_GFGR: return s->work[6];
+  case PMH_EXP_GGR: return s->work[6];
+  default: return s->work[1];
+  }
+}
+
+// MPGPGrads mpgp.c:198-223
+static int u_grads(pmh_mpgp s, const double *x, const double *g)
+{
+  PMH_CHK(pmh_qpc_box_grads(s->ctx, s->n, x, g, s->lb, s->ub, s->o.astol, s->work[1], s->work[2]));
+  PMH_CHK(pmh_qpc_box_gradreduced(s->ctx, s->n, x, s->work[1], s->lb, s->ub, s->alpha, s->work[6]));
+  return pmh_vec_waxpy(s->ctx, s->n, s->work[0], 1.0, s->work[1], s->work[2]);
+}
+
+// MPGPExpansionLength mpgp.c:233-287
+static int u_expansion_length(pmh_mpgp s, double *xold, double *explengthvecold)
+{
+  pmh_ctx ctx = s->ctx;
+  int     n   = s->n;
+  double *lv  = exp_lengthvec(s), dots[2];
+  switch (s->o.explengthtype) {
+  case PMH_EXPLEN_FIXED: break;
+  case PMH_EXPLEN_OPT:
+    PMH_CHK(s->A->mult(lv, s->work[5]));
+    s->nmv++;
+    PMH_CHK(pmh_vec_dot(ctx, n, lv, s->work[3], &dots[0]));
+    PMH_CHK(pmh_vec_dot(ctx, n, lv, s->work[5], &dots[1]));
+    if (dots[1] == .0 && s->o.resetalpha) s->alpha = s->alpha / s->maxeig;
+    else s->alpha = s->alpha_user * (dots[0] / dots[1]);
+    break;
+  case PMH_EXPLEN_OPTAPPROX:
+    if (s->work[3] != lv) {
+      PMH_CHK(pmh_vec_dot(ctx, n, lv, s->work[3], &dots[0]));
+      PMH_CHK(pmh_vec_dot(ctx, n, lv, lv, &dots[1]));
+      s->alpha = s->alpha_user * (dots[0] / dots[1]);
+    } else {
+      s->alpha = s->alpha_user;
+    }
+    s->alpha = s->alpha / s->maxeig;
+    break;
+  case PMH_EXPLEN_BB:
+    PMH_CHK(pmh_vec_aypx(ctx, n, explengthvecold, -1.0, lv));
+    PMH_CHK(pmh_vec_aypx(ctx, n, xold, -1.0, s->x));
+    PMH_CHK(pmh_vec_dot(ctx, n, explengthvecold, explengthvecold, &dots[0]));
+    PMH_CHK(pmh_vec_dot(ctx, n, explengthvecold, xold, &dots[1]));
+    if (dots[1] == .0 && s->o.resetalpha) s->alpha = s->alpha / s->maxeig;
+    else s->alpha = s->alpha_user * (dots[0] / dots[1]);
+    break;
+  }
+  return PMH_SUCCESS;
+}
+
+// MPGPExpansion_Std mpgp.c:299-323
+static int u_expansion_std(pmh_mpgp s, double afeas, double *xold, double *explengthvecold)
+{
+  pmh_ctx ctx = s->ctx;
+  int     n   = s->n;
+  PMH_CHK(pmh_vec_axpy(ctx, n, s->x, -afeas, s->work[4]));
+  PMH_CHK(pmh_vec_axpy(ctx, n, s->work[3], -afeas, s->work[5]));
+  PMH_CHK(u_grads(s, s->x, s->work[3]));
+  PMH_CHK(u_expansion_length(s, xold, explengthvecold));
+  return pmh_vec_axpy(ctx, n, s->x, -s->alpha, exp_direction(s));
+}
+
+static int u_objective_from_gradient(pmh_mpgp s, const double *x, const double *g, double *f)
+{
+  const int ops[1] = {PMH_RED_SUM};
+  LAUNCH(k_obj_from_grad, x, g, s->b, s->ctx->d_partials);
+  PMH_CHK(pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 1, ops, S_TMP));
+  double v;
+  PMH_CHK(pmh_host_scalar(s->ctx, S_TMP, &v));
+  *f = .5 * v;
+  return PMH_SUCCESS;
+}
+
+static int solve_unfused(pmh_mpgp s)
+{
+  pmh_ctx ctx = s->ctx;
+  int     n   = s->n;
+  int     nw  = 7;
+  if (s->o.fallback || s->o.fallback2) nw = (s->o.explengthtype != PMH_EXPLEN_BB) ? 9 : 10; // mpgp.c:366-376
+  else if (s->o.explengthtype == PMH_EXPLEN_BB) nw = 9;
+  for (int i = 0; i < nw; i++) PMH_CHK(ensure_work(s, i));
+  double *gP = s->work[0], *gf = s->work[1], *gc = s->work[2], *g = s->work[3], *p = s->work[4], *Ap = s->work[5];
+  double *gold = nullptr, *xold = nullptr, *explengthvecold = nullptr;
+  if (s->o.explengthtype == PMH_EXPLEN_BB) { // mpgp.c:479-486
+    explengthvecold = s->work[7];
+    xold            = s->work[8];
+    if (s->o.fallback || s->o.fallback2) gold = s->work[9];
+  } else if (s->o.fallback || s->o.fallback2) {
+    xold = s->work[7];
+    gold = s->work[8];
+  }
+  const double gamma2 = s->o.gamma * s->o.gamma;
+  double       acg, bcg, afeas, pAp, gcTgc, gfTgf, f, fold;
+  int          nmv = 0, ncg = 0, nprop = 0, nexp = 0, nfinc = 0, nfall = 0;
+  int          fallback = s->fallback_state;
+  double      *x = s->x;
+
+  PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
+  PMH_CHK(s->A->mult(x, g));
+  nmv++;
+  PMH_CHK(pmh_vec_axpy(ctx, n, g, -1.0, s->b));
+  PMH_CHK(u_grads(s, x, g));
+  PMH_CHK(pmh_vec_copy(ctx, n, gf, p));
+  s->step      = ' ';
+  s->iteration = 0;
+  while (1) {
+    LAUNCH(k_three_norms, (const double *)gP, (const double *)gc, (const double *)gf, ctx->d_partials, ctx->partials_cap);
+    PMH_CHK(finalize_vec4(s));
+    PMH_CHK(pmh_sync(ctx));
+    s->rnorm  = sqrt(ctx->h_scal[S_GP2]);
+    gcTgc     = ctx->h_scal[S_GC2];
+    gfTgf     = ctx->h_scal[S_GF2];
+    s->gfnorm = sqrt(gfTgf);
+    s->gcnorm = sqrt(gcTgc);
+    PMH_CHK(test_convergence(s));
+    if (s->reason != PMH_CONVERGED_ITERATING) break;
+
+    if (gcTgc <= gamma2 * gfTgf) {
+      PMH_CHK(s->A->mult(p, Ap));
+      nmv++;
+      PMH_CHK(pmh_vec_dot(ctx, n, p, Ap, &pAp));
+      PMH_CHK(pmh_vec_dot(ctx, n, g, p, &acg));
+      acg = acg / pAp;
+      PMH_CHK(pmh_qpc_box_feas(ctx, n, x, p, s->lb, s->ub, &afeas));
+      if (acg <= afeas) {
+        ncg++;
+        s->step = 'c';
+        PMH_CHK(pmh_vec_axpy(ctx, n, x, -acg, p));
+        PMH_CHK(pmh_vec_axpy(ctx, n, g, -acg, Ap));
+        PMH_CHK(u_grads(s, x, g));
+        PMH_CHK(pmh_vec_dot(ctx, n, Ap, gf, &bcg));
+        bcg = bcg / pAp;
+        PMH_CHK(pmh_vec_aypx(ctx, n, p, -bcg, gf));
+      } else {
+        nexp++;
+        s->step = 'e';
+        if (s->o.explengthtype == PMH_EXPLEN_BB || fallback || s->o.fallback2) {
+          PMH_CHK(pmh_vec_copy(ctx, n, x, xold));
+          if (s->o.explengthtype == PMH_EXPLEN_BB) PMH_CHK(pmh_vec_copy(ctx, n, exp_lengthvec(s), explengthvecold));
+        }
+        if (s->o.exptype == PMH_EXP_PROJCG) PMH_CHK(pmh_vec_axpy(ctx, n, x, -acg, p)); // MPGPExpansion_ProjCG mpgp.c:335-349
+        else PMH_CHK(u_expansion_std(s, afeas, xold, explengthvecold));
+        if (s->expproject) PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x));
+        if (fallback || s->o.fallback2) PMH_CHK(pmh_vec_copy(ctx, n, g, gold));
+        PMH_CHK(s->A->mult(x, g));
+        nmv++;
+        PMH_CHK(pmh_vec_axpy(ctx, n, g, -1.0, s->b));
+        if (fallback || s->o.fallback2) {
+          PMH_CHK(u_objective_from_gradient(s, xold, gold, &fold));
+          PMH_CHK(u_objective_from_gradient(s, x, g, &f));
+          if (f > fold) {
+            nfinc++;
+            if (s->o.fallback2) {
+              PMH_CHK(u_grads(s, x, g));
+              PMH_CHK(pmh_vec_dot(ctx, n, gc, gc, &gcTgc));
+              PMH_CHK(pmh_vec_dot(ctx, n, gf, gf, &gfTgf));
+              fallback = (gcTgc <= gamma2 * gfTgf) ? 0 : 1;
+            }
+            if (fallback) {
+              nfall++;
+              s->step = 'f';
+              PMH_CHK(pmh_vec_copy(ctx, n, xold, x));
+              PMH_CHK(pmh_vec_copy(ctx, n, gold, g));
+              if (s->o.fallback2) PMH_CHK(u_grads(s, xold, gold));
+              PMH_CHK(u_expansion_std(s, afeas, xold, explengthvecold));
+              PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x));
+              PMH_CHK(s->A->mult(x, g));
+              nmv++;
+              PMH_CHK(pmh_vec_axpy(ctx, n, g, -1.0, s->b));
+            }
+          }
+        }
+        PMH_CHK(u_grads(s, x, g));
+        PMH_CHK(pmh_vec_copy(ctx, n, gf, p));
+      }
+    } else {
+      nprop++;
+      s->step = 'p';
+      PMH_CHK(pmh_vec_copy(ctx, n, gc, p));
+      PMH_CHK(s->A->mult(p, Ap));
+      nmv++;
+      PMH_CHK(pmh_vec_dot(ctx, n, p, Ap, &pAp));
+      PMH_CHK(pmh_vec_dot(ctx, n, g, p, &acg));
+      acg = acg / pAp;
+      PMH_CHK(pmh_vec_axpy(ctx, n, x, -acg, p));
+      PMH_CHK(pmh_vec_axpy(ctx, n, g, -acg, Ap));
+      PMH_CHK(u_grads(s, x, g));
+      PMH_CHK(pmh_vec_copy(ctx, n, gf, p));
+    }
+    s->iteration++;
+  }
+  s->fallback_state = fallback;
+  s->ncg += ncg, s->nexp += nexp, s->nmv += nmv, s->nprop += nprop, s->nfinc += nfinc, s->nfall += nfall;
+  return PMH_SUCCESS;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// fused driver (std expansion, fixed step length, no fallback)
+// --------------------------------------------------------------------------------------------------------------------
+// P1: Ap = A p and the three reductions into d_scal/h_scal[S_PAP..S_FEAS]
+static int f_apply_p1(pmh_mpgp s)
+{
+  double *g = s->work[3], *p = s->work[4], *Ap = s->work[5];
+  if (s->csr) {
+    pmh_spmv_epi e;
+    memset(&e, 0, sizeof(e));
+    e.kind      = PMH_EPI_MPGP;
+    e.g         = g;
+    e.xx        = s->x;
+    e.lb        = s->lb;
+    e.ub        = s->ub;
+    e.scal_base = S_PAP;
+    return pmh_csr_spmv_launch(s->csr, p, Ap, e);
+  }
+  PMH_CHK(s->A->mult(p, Ap));
+  const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
+  LAUNCH(k_p1_dots, (const double *)p, (const double *)Ap, (const double *)g, (const double *)s->x, s->lb, s->ub, s->ctx->d_partials, s->ctx->partials_cap);
+  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 3, ops, S_PAP);
+}
+
+// g = A x - b (mpgp.c:500-502, :578-580)
+static int f_gradient(pmh_mpgp s)
+{
+  double *g = s->work[3];
+  if (s->csr) {
+    pmh_spmv_epi e;
+    memset(&e, 0, sizeof(e));
+    e.kind = PMH_EPI_SUB;
+    e.y1   = s->b;
+    return pmh_csr_spmv_launch(s->csr, s->x, g, e);
+  }
+  PMH_CHK(s->A->mult(s->x, g));
+  return pmh_vec_axpy(s->ctx, s->n, g, -1.0, s->b);
+}
+
+static int solve_fused(pmh_mpgp s)
+{
+  pmh_ctx ctx = s->ctx;
+  int     n   = s->n;
+  PMH_CHK(ensure_work(s, 1));
+  PMH_CHK(ensure_work(s, 3));
+  PMH_CHK(ensure_work(s, 4));
+  PMH_CHK(ensure_work(s, 5));
+  double      *gf = s->work[1], *g = s->work[3], *p = s->work[4], *Ap = s->work[5], *x = s->x;
+  const double gamma2 = s->o.gamma * s->o.gamma, astol = s->o.astol;
+  int          nmv = 0, ncg = 0, nprop = 0, nexp = 0;
+  bool         spec = false; // P1 for the current p already enqueued
+
+  PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
+  PMH_CHK(f_gradient(s));                                   // :500-502
+  nmv++;
+  LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap); // :504-507
+  PMH_CHK(finalize_vec4(s));
+  s->step      = ' ';
+  s->iteration = 0;
+  while (1) {
+    PMH_CHK(pmh_sync(ctx));
+    s->rnorm           = sqrt(ctx->h_scal[S_GP2]);
+    const double gcTgc = ctx->h_scal[S_GC2], gfTgf = ctx->h_scal[S_GF2];
+    s->gfnorm = sqrt(gfTgf);
+    s->gcnorm = sqrt(gcTgc);
+    PMH_CHK(test_convergence(s));
+    if (s->reason != PMH_CONVERGED_ITERATING) break;
+
+    if (gcTgc <= gamma2 * gfTgf) { // proportional (mpgp.c:535)
+      if (!spec) {
+        PMH_CHK(f_apply_p1(s));
+        PMH_CHK(pmh_sync(ctx));
+      }
+      spec = false;
+      nmv++;
+      const double pAp = ctx->h_scal[S_PAP], acg = ctx->h_scal[S_GP] / pAp, afeas = ctx->h_scal[S_FEAS];
+      if (acg <= afeas) { // CG step (mpgp.c:547-560)
+        ncg++;
+        s->step = 'c';
+        LAUNCH(k_step_update<false>, (const double *)ctx->d_scal, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+        PMH_CHK(finalize_vec4(s));
+        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const double *)gf, p);
+      } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
+        nexp++;
+        s->step = 'e';
+        LAUNCH(k_expansion_std, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol);
+        PMH_CHK(f_gradient(s));
+        nmv++;
+        LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap);
+        PMH_CHK(finalize_vec4(s));
+      }
+    } else { // proportioning (mpgp.c:617-639)
+      nprop++;
+      s->step = 'p';
+      spec    = false; // a speculative P1 (if any) used the wrong direction; it is simply not counted
+      LAUNCH(k_prop_dir, (const double *)x, (const double *)g, s->lb, s->ub, astol, p);
+      PMH_CHK(f_apply_p1(s));
+      nmv++;
+      LAUNCH(k_step_update<true>, (const double *)ctx->d_scal, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+      PMH_CHK(finalize_vec4(s));
+    }
+    // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p
+    PMH_CHK(f_apply_p1(s));
+    spec = true;
+    s->iteration++;
+  }
+  s->ncg += ncg, s->nexp += nexp, s->nmv += nmv, s->nprop += nprop;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_solve(pmh_mpgp s)
+{
+  PMH_ARG(s);
+  s->t_step.clear(), s->t_gp.clear(), s->t_gf.clear(), s->t_gc.clear(), s->t_alpha.clear();
+  return use_fused(s) ? solve_fused(s) : solve_unfused(s);
+}
+
+extern "C" int pmh_mpgp_run_fixed(pmh_mpgp s, int iters)
+{
+  PMH_ARG(s && iters >= 0);
+  s->fixed_iters = iters;
+  int rc         = pmh_mpgp_solve(s);
+  s->fixed_iters = -1;
+  return rc;
+}
+
+extern "C" int pmh_mpgp_get_stats(pmh_mpgp s, pmh_mpgp_stats *st)
+{
+  PMH_ARG(s && st);
+  memset(st, 0, sizeof(*st));
+  st->iteration = s->iteration, st->reason = s->reason;
+  st->rnorm = s->rnorm, st->gfnorm = s->gfnorm, st->gcnorm = s->gcnorm, st->alpha = s->alpha, st->maxeig = s->maxeig;
+  st->nmv = s->nmv, st->ncg = s->ncg, st->nexp = s->nexp, st->nprop = s->nprop, st->nfinc = s->nfinc, st->nfall = s->nfall;
+  st->norm_rhs = s->norm_rhs, st->ttol = s->ttol;
+  st->current_step_type = s->step;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_mpgp_get_trace(pmh_mpgp s, int cap, char *step, double *gp, double *gf, double *gc, double *alpha, int *len)
+{
+  PMH_ARG(s && len);
+  int m = (int)s->t_step.size();
+  *len  = m;
+  if (m > cap) m = cap;
+  for (int i = 0; i < m; i++) {
+    if (step) step[i] = s->t_step[i];
+    if (gp) gp[i] = s->t_gp[i];
+    if (gf) gf[i] = s->t_gf[i];
+    if (gc) gc[i] = s->t_gc[i];
+    if (alpha) alpha[i] = s->t_alpha[i];
+  }
+  return PMH_SUCCESS;
+}
+
+// work[0..6] = gP, gf, gc, g, p, Ap, gr (mpgp.c:6-17).  The fused driver does not keep gP, gc, gr:
+// they are recomputed here from the final x, g (MPGPGrads) so that callers see the reference's work vectors.
+extern "C" int pmh_mpgp_get_work(pmh_mpgp s, int idx, const double **dptr)
+{
+  PMH_ARG(s && dptr && idx >= 0 && idx < 10);
+  if (use_fused(s) && (idx == 0 || idx == 2 || idx == 6)) {
+    PMH_ARG(s->work[3]);
+    PMH_CHK(ensure_work(s, 0));
+    PMH_CHK(ensure_work(s, 2));
+    PMH_CHK(ensure_work(s, 6));
+    PMH_CHK(ensure_work(s, 1));
+    PMH_CHK(u_grads(s, s->x, s->work[3]));
+  }
+  PMH_ARG(s->work[idx]);
+  *dptr = s->work[idx];
+  return PMH_SUCCESS;
+}

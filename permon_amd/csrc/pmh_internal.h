@@ -1,0 +1,101 @@
+// Internal declarations of libpermonhip (gfx950 only).  Public ABI: include/permon_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "permon_hip.h"
+
+#define PMH_BLOCK 256          // threads per workgroup (4 wavefronts of 64)
+#define PMH_MAX_VEC_BLOCKS 2048 // 256 CUs x 8 resident workgroups: grid cap of the streaming kernels
+#define PMH_MAX_RED 8          // reductions finalised per pass
+#define PMH_NSCAL 64           // scalar slots (device + pinned host mirror)
+
+int pmh_set_error(int code, const char *fmt, ...);
+
+#define PMH_HIP(call) \
+  do { \
+    hipError_t e_ = (call); \
+    if (e_ != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+#define PMH_CHK(call) \
+  do { \
+    int rc_ = (call); \
+    if (rc_) return rc_; \
+  } while (0)
+#define PMH_NCCL(call) \
+  do { \
+    ncclResult_t r_ = (call); \
+    if (r_ != ncclSuccess) return pmh_set_error(PMH_ERR_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+  } while (0)
+#define PMH_ARG(cond) \
+  do { \
+    if (!(cond)) return pmh_set_error(PMH_ERR_ARG, "%s:%d argument check failed: %s", __FILE__, __LINE__, #cond); \
+  } while (0)
+
+struct pmh_ctx_s {
+  int         device;
+  int         num_cus;
+  hipStream_t stream;
+  hipEvent_t  ev0, ev1;
+  double     *d_partials; // [PMH_MAX_RED][partials_cap] block partials of the streaming kernels
+  int         partials_cap;
+  double     *d_scal; // finalised reductions (device copy), consumed by follow-up kernels
+  double     *h_scal; // pinned host mirror written by the finalise kernel
+  // multi-GPU
+  ncclComm_t comm;
+  int        rank, size;
+  double    *d_commbuf; // small staging buffer for scalar allreduces
+};
+
+// ---- CSR -----------------------------------------------------------------------------------------------
+enum { PMH_SPMV_STREAM = 0, PMH_SPMV_VECTOR = 1 };
+struct pmh_csr_s {
+  pmh_ctx   ctx;
+  int       nrows, ncols;
+  long long nnz;
+  int      *d_rowptr, *d_col;
+  double   *d_val;
+  int       kind;          // PMH_SPMV_STREAM (row-blocked, LDS staged) or PMH_SPMV_VECTOR (sub-wave per row)
+  int       lanes_per_row; // VECTOR kind
+  int      *d_rowblocks;   // STREAM kind: row block boundaries [n_rowblocks+1]
+  int       n_rowblocks;
+  double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue
+  int       n_launch_blocks;
+  pmh_csr   transpose;     // built lazily for mult_transpose
+};
+
+// epilogues of the SpMV kernels
+enum { PMH_EPI_NONE = 0, PMH_EPI_ADD = 1, PMH_EPI_SUB = 2, PMH_EPI_MPGP = 3 };
+struct pmh_spmv_epi {
+  int           kind;
+  const double *y1;             // ADD: y = y1 + A x ; SUB: y = A x - y1
+  const double *g, *xx, *lb, *ub; // MPGP: partials p'Ap, g'p, min feasible step (p is the SpMV input)
+  int           scal_base;      // MPGP: d_scal slots [base..base+2] receive pAp, gp, afeas
+};
+int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
+
+// ---- operators -------------------------------------------------------------------------------------------
+struct pmh_op_s {
+  pmh_ctx ctx;
+  int     n;
+  virtual ~pmh_op_s() {}
+  virtual int     mult(const double *x, double *y) = 0;
+  virtual pmh_csr as_csr() { return nullptr; }
+};
+
+// ---- reductions ---------------------------------------------------------------------------------------------
+enum { PMH_RED_SUM = 0, PMH_RED_MIN = 1 };
+// finalise K block-partial arrays (stride = ld) into d_scal[base+k] and h_scal[base+k]
+int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base);
+int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (function of n only)
+
+// vec kernels needed across translation units (device pointers, enqueue only)
+int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
+int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
+int pmh_scalar_allreduce(pmh_ctx ctx, int slot, int count, int op);                     // RCCL on d_scal (no-op for size 1)

@@ -1,0 +1,323 @@
+// CSR SpMV for gfx950 (fp64 values, int32 indices) -- the MatMult_SeqAIJ role of the PERMON QPS path.
+//
+// Two kernels, chosen per matrix at pmh_csr_create:
+//  * STREAM (short rows, e.g. the 5-point Laplacian of BASELINE configs[1]): row-blocked.  A workgroup
+//    owns a contiguous block of rows whose non-zeros fit PMH_NNZ_PER_BLOCK; it streams val/col with
+//    fully coalesced loads, stages the products val*x[col] in LDS, then one lane per row sums that row's
+//    products from LDS LEFT TO RIGHT -- the same order as PETSc's MatMult_SeqAIJ row loop, so y is
+//    bit-identical to the CPU path.  Rows longer than a block are reduced by the whole workgroup.
+//  * VECTOR (long rows, e.g. 81 nnz/row Q1 elasticity blocks K_i): LPR lanes of a 64-wide wavefront
+//    per row, shuffle-tree reduction.
+// Both map workgroups to rows XCD-aware: the dispatcher deals workgroups round-robin over the 8 XCDs, so
+// workgroup b is given the row block (b%8)*chunk + b/8; each XCD then walks a contiguous slab of rows and
+// the gathered x entries of neighbouring row blocks hit that XCD's own L2 (placement only affects speed).
+// Epilogues fuse the row-local follow-up work of the MPGP iteration into the SpMV (SURVEY 8d phase P1).
+//
+// Algorithmic bytes per SpMV: 12*nnz + 20*nrows (8 B value + 4 B column per non-zero; 4 B row pointer,
+// 8 B y write, 8 B compulsory x read per row).
+#include "pmh_internal.h"
+#include "reduce.h"
+
+#define PMH_NNZ_PER_BLOCK 2048
+#define PMH_ITEMS (PMH_NNZ_PER_BLOCK / PMH_BLOCK)
+
+struct EpiArgs {
+  const double *y1;
+  const double *g, *xx, *lb, *ub;
+};
+
+template <int EPI>
+__device__ __forceinline__ void epi_row(int r, double sum, const double *__restrict__ xin, double *__restrict__ y, const EpiArgs &a, double &s0, double &s1, double &m)
+{
+  if (EPI == PMH_EPI_NONE) {
+    y[r] = sum;
+  } else if (EPI == PMH_EPI_ADD) {
+    y[r] = a.y1[r] + sum;
+  } else if (EPI == PMH_EPI_SUB) {
+    y[r] = sum - a.y1[r];
+  } else { // PMH_EPI_MPGP: Ap = A p with p'Ap, g'p and QPCFeas_Box(x,p) accumulated (mpgp.c:537-544)
+    y[r]     = sum;
+    double p = xin[r];
+    s0 += p * sum;
+    s1 += a.g[r] * p;
+    if (p > 0. && a.lb) {
+      double l = a.lb[r];
+      if (l > -INFINITY) m = fmin(m, (a.xx[r] - l) / p);
+    }
+    if (p < 0. && a.ub) {
+      double u = a.ub[r];
+      if (u < INFINITY) m = fmin(m, (a.xx[r] - u) / p);
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_finish(double s0, double s1, double m, double *lds, double *__restrict__ part, int ld, int slot)
+{
+  if (EPI == PMH_EPI_MPGP) {
+    s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
+    s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
+    m  = pmh_block_reduce<PMH_RED_MIN>(m, lds);
+    if (threadIdx.x == 0) {
+      part[slot]          = s0;
+      part[ld + slot]     = s1;
+      part[2 * ld + slot] = m;
+    }
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nlaunch)
+{
+  const int chunk = nlaunch >> 3;
+  return (bid & 7) * chunk + (bid >> 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict__ rowblocks, int nrb, int nlaunch, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
+{
+  __shared__ double prod[PMH_NNZ_PER_BLOCK];
+  __shared__ double red[PMH_BLOCK / 64];
+  const int         b = xcd_remap(blockIdx.x, nlaunch);
+  if (b >= nrb) return; // whole workgroup exits together
+  const int r0 = rowblocks[b], r1 = rowblocks[b + 1];
+  const int s0 = rowptr[r0], s1 = rowptr[r1];
+  const int tid = threadIdx.x;
+  double    acc0 = 0.0, acc1 = 0.0, amin = INFINITY;
+
+  if (s1 - s0 <= PMH_NNZ_PER_BLOCK) {
+    // coalesced stream of the block's non-zeros: all loads issued before first use
+    int    c[PMH_ITEMS];
+    double v[PMH_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PMH_ITEMS; j++) {
+      const int k = s0 + tid + j * PMH_BLOCK;
+      c[j]        = (k < s1) ? col[k] : -1;
+      v[j]        = (k < s1) ? val[k] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PMH_ITEMS; j++) {
+      const int k = tid + j * PMH_BLOCK;
+      if (c[j] >= 0) prod[k] = v[j] * x[c[j]];
+    }
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += PMH_BLOCK) {
+      const int k0 = rowptr[r] - s0, k1 = rowptr[r + 1] - s0;
+      double    sum = 0.0;
+      for (int k = k0; k < k1; k++) sum += prod[k];
+      epi_row<EPI>(r, sum, x, y, a, acc0, acc1, amin);
+    }
+  } else {
+    // a single row longer than the LDS tile: whole workgroup strides over it
+    double sum = 0.0;
+    for (int k = s0 + tid; k < s1; k += PMH_BLOCK) sum += val[k] * x[col[k]];
+    sum = pmh_block_reduce<PMH_RED_SUM>(sum, red);
+    if (tid == 0) epi_row<EPI>(r0, sum, x, y, a, acc0, acc1, amin);
+  }
+  epi_finish<EPI>(acc0, acc1, amin, red, part, ld, b);
+}
+
+template <int EPI, int LPR>
+__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, int nlaunch, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
+{
+  __shared__ double red[PMH_BLOCK / 64];
+  const int         b = xcd_remap(blockIdx.x, nlaunch);
+  if (b >= nblk) return;
+  constexpr int RPB  = PMH_BLOCK / LPR;
+  const int     sub  = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+  const int     r    = b * RPB + sub;
+  double        acc0 = 0.0, acc1 = 0.0, amin = INFINITY;
+  double        sum = 0.0;
+  if (r < nrows) {
+    const int k0 = rowptr[r], k1 = rowptr[r + 1];
+    for (int k = k0 + lane; k < k1; k += LPR) sum += val[k] * x[col[k]];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LPR);
+  if (r < nrows && lane == 0) epi_row<EPI>(r, sum, x, y, a, acc0, acc1, amin);
+  epi_finish<EPI>(acc0, acc1, amin, red, part, ld, b);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int build_rowblocks(int nrows, const int *rowptr, std::vector<int> &rb)
+{
+  rb.clear();
+  rb.push_back(0);
+  int r = 0;
+  while (r < nrows) {
+    int start = r;
+    int base  = rowptr[r];
+    while (r < nrows && rowptr[r + 1] - base <= PMH_NNZ_PER_BLOCK) r++;
+    if (r == start) r++; // single row longer than a tile
+    rb.push_back(r);
+  }
+  return (int)rb.size() - 1;
+}
+
+extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowptr, const int *col, const double *val, pmh_csr *out)
+{
+  PMH_ARG(ctx && out && nrows >= 0 && ncols >= 0 && rowptr);
+  PMH_ARG(rowptr[0] == 0);
+  for (int i = 0; i < nrows; i++)
+    if (rowptr[i + 1] < rowptr[i]) return pmh_set_error(PMH_ERR_ARG, "pmh_csr_create: rowptr not monotone at row %d", i);
+  const long long nnz = rowptr[nrows];
+  PMH_ARG(nnz == 0 || (col && val));
+  for (long long k = 0; k < nnz; k++)
+    if (col[k] < 0 || col[k] >= ncols) return pmh_set_error(PMH_ERR_ARG, "pmh_csr_create: column index %d out of range [0,%d) at nnz %lld", col[k], ncols, k);
+  PMH_HIP(hipSetDevice(ctx->device));
+  pmh_csr A = new pmh_csr_s();
+  memset(A, 0, sizeof(*A));
+  A->ctx   = ctx;
+  A->nrows = nrows;
+  A->ncols = ncols;
+  A->nnz   = nnz;
+  PMH_HIP(hipMalloc((void **)&A->d_rowptr, sizeof(int) * ((size_t)nrows + 1)));
+  PMH_HIP(hipMalloc((void **)&A->d_col, sizeof(int) * (size_t)(nnz ? nnz : 1)));
+  PMH_HIP(hipMalloc((void **)&A->d_val, sizeof(double) * (size_t)(nnz ? nnz : 1)));
+  PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowptr, rowptr, sizeof(int) * ((size_t)nrows + 1)));
+  PMH_CHK(pmh_memcpy_h2d(ctx, A->d_col, col, sizeof(int) * (size_t)nnz));
+  PMH_CHK(pmh_memcpy_h2d(ctx, A->d_val, val, sizeof(double) * (size_t)nnz));
+
+  const double avg = nrows ? (double)nnz / nrows : 0.0;
+  if (avg <= 24.0) {
+    A->kind = PMH_SPMV_STREAM;
+    std::vector<int> rb;
+    A->n_rowblocks = build_rowblocks(nrows, rowptr, rb);
+    PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowblocks, rb.data(), sizeof(int) * rb.size()));
+    A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
+  } else {
+    A->kind          = PMH_SPMV_VECTOR;
+    A->lanes_per_row = (avg <= 48.0) ? 8 : (avg <= 160.0 ? 16 : (avg <= 512.0 ? 32 : 64));
+    const int rpb    = PMH_BLOCK / A->lanes_per_row;
+    A->n_rowblocks   = (nrows + rpb - 1) / rpb;
+    A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
+  }
+  PMH_HIP(hipMalloc((void **)&A->d_blockpart, sizeof(double) * 3 * (size_t)(A->n_launch_blocks ? A->n_launch_blocks : 8)));
+  *out = A;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_csr_destroy(pmh_csr A)
+{
+  if (!A) return PMH_SUCCESS;
+  hipStreamSynchronize(A->ctx->stream);
+  if (A->transpose) pmh_csr_destroy(A->transpose);
+  hipFree(A->d_rowptr);
+  hipFree(A->d_col);
+  hipFree(A->d_val);
+  hipFree(A->d_rowblocks);
+  hipFree(A->d_blockpart);
+  delete A;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_csr_sizes(pmh_csr A, int *nrows, int *ncols, long long *nnz)
+{
+  PMH_ARG(A);
+  if (nrows) *nrows = A->nrows;
+  if (ncols) *ncols = A->ncols;
+  if (nnz) *nnz = A->nnz;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_csr_algorithmic_bytes(pmh_csr A, double *bytes)
+{
+  PMH_ARG(A && bytes);
+  *bytes = 12.0 * (double)A->nnz + 20.0 * (double)A->nrows;
+  return PMH_SUCCESS;
+}
+
+template <int EPI>
+static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
+{
+  pmh_ctx   ctx = A->ctx;
+  const int nl  = A->n_launch_blocks;
+  if (A->nrows == 0) return PMH_SUCCESS;
+  if (A->kind == PMH_SPMV_STREAM) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl);
+  } else {
+#define VEC_CASE(L) \
+  case L: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_vector<EPI, L>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl); break;
+    switch (A->lanes_per_row) {
+      VEC_CASE(8)
+      VEC_CASE(16)
+      VEC_CASE(32)
+      VEC_CASE(64)
+    default: return pmh_set_error(PMH_ERR_STATE, "bad lanes_per_row %d", A->lanes_per_row);
+    }
+  }
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &e)
+{
+  EpiArgs a;
+  a.y1 = e.y1;
+  a.g  = e.g;
+  a.xx = e.xx;
+  a.lb = e.lb;
+  a.ub = e.ub;
+  switch (e.kind) {
+  case PMH_EPI_NONE: return launch<PMH_EPI_NONE>(A, x, y, a);
+  case PMH_EPI_ADD: return launch<PMH_EPI_ADD>(A, x, y, a);
+  case PMH_EPI_SUB: return launch<PMH_EPI_SUB>(A, x, y, a);
+  case PMH_EPI_MPGP: {
+    PMH_CHK(launch<PMH_EPI_MPGP>(A, x, y, a));
+    const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
+    return pmh_finalize_partials(A->ctx, A->d_blockpart, A->n_launch_blocks, A->n_rowblocks, 3, ops, e.scal_base);
+  }
+  }
+  return pmh_set_error(PMH_ERR_ARG, "unknown SpMV epilogue %d", e.kind);
+}
+
+extern "C" int pmh_csr_mult(pmh_csr A, const double *x, double *y)
+{
+  PMH_ARG(A && (x || !A->ncols) && (y || !A->nrows));
+  PMH_ARG((const void *)x != (const void *)y);
+  pmh_spmv_epi e;
+  memset(&e, 0, sizeof(e));
+  e.kind = PMH_EPI_NONE;
+  return pmh_csr_spmv_launch(A, x, y, e);
+}
+
+extern "C" int pmh_csr_mult_add(pmh_csr A, const double *x, const double *y1, double *y)
+{
+  PMH_ARG(A && y1);
+  PMH_ARG((const void *)x != (const void *)y);
+  pmh_spmv_epi e;
+  memset(&e, 0, sizeof(e));
+  e.kind = PMH_EPI_ADD;
+  e.y1   = y1;
+  return pmh_csr_spmv_launch(A, x, y, e);
+}
+
+// A' is built once on the host (counting sort; columns of each row of A' ascending = PETSc MatTranspose layout)
+static int build_transpose(pmh_csr A)
+{
+  pmh_ctx             ctx = A->ctx;
+  std::vector<int>    rp((size_t)A->nrows + 1), ci((size_t)A->nnz);
+  std::vector<double> va((size_t)A->nnz);
+  PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), A->d_rowptr, sizeof(int) * rp.size()));
+  PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), A->d_col, sizeof(int) * ci.size()));
+  PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), A->d_val, sizeof(double) * va.size()));
+  std::vector<int> trp((size_t)A->ncols + 1, 0), tci((size_t)A->nnz);
+  std::vector<double> tva((size_t)A->nnz);
+  for (long long k = 0; k < A->nnz; k++) trp[ci[k] + 1]++;
+  for (int j = 0; j < A->ncols; j++) trp[j + 1] += trp[j];
+  std::vector<int> pos(trp.begin(), trp.end() - 1);
+  for (int i = 0; i < A->nrows; i++)
+    for (int k = rp[i]; k < rp[i + 1]; k++) {
+      int p  = pos[ci[k]]++;
+      tci[p] = i;
+      tva[p] = va[k];
+    }
+  return pmh_csr_create(ctx, A->ncols, A->nrows, trp.data(), tci.data(), tva.data(), &A->transpose);
+}
+
+extern "C" int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y)
+{
+  PMH_ARG(A);
+  if (!A->transpose) PMH_CHK(build_transpose(A));
+  return pmh_csr_mult(A->transpose, x, y);
+}

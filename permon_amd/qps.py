@@ -1,0 +1,231 @@
+"""Host-side mirror of PERMON's QP / QPS interface for the hot path (same names, argument meaning and
+error behaviour as include/permonqp.h, include/permonqps.h), over the C ABI of libpermonhip.
+
+    qp  = QP(ctx);  qp.SetOperator(A); qp.SetRhs(b); qp.SetInitialVector(x); qp.SetBox(None, lb, ub)
+    qps = QPS(ctx); qps.SetQP(qp); qps.SetType("mpgp"); qps.SetTolerances(rtol=1e-6); qps.Solve()
+
+reads like src/tutorials/ex1.c:110-146.  Solver failure is not an exception: it is reason < 0 (qps.c:551).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .core import Op, Vec, _ptr
+
+QPSMPGPExpansionTypes = ("std", "projcg", "gf", "g", "gfgr", "ggr")  # mpgp.c:3
+QPSMPGPExpansionLengthTypes = ("fixed", "opt", "optapprox", "bb")  # mpgp.c:4
+
+KSP_CONVERGED_RTOL, KSP_CONVERGED_ATOL, KSP_CONVERGED_ITS, KSP_CONVERGED_HAPPY_BREAKDOWN = 2, 3, 4, 7
+KSP_DIVERGED_ITS, KSP_DIVERGED_DTOL, KSP_DIVERGED_BREAKDOWN, KSP_DIVERGED_NANORINF = -3, -4, -5, -9
+
+
+class QP:
+    """The slice of the QP object the solvers read (qps->solQP: A, b, x, qpc/box, BE via pf, pc)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.A = self.b = self.x = self.lb = self.ub = None
+        self.pf = None  # QPPF holding BE = G (cE must be homogenised away: QPTHomogenizeEq)
+        self.pc = None
+        self._keep = []
+
+    def SetOperator(self, A):  # QPSetOperator
+        self.A = A
+
+    def SetRhs(self, b):  # QPSetRhs
+        self.b = b
+
+    def SetInitialVector(self, x):  # QPSetInitialVector (qp.c:1964): x also receives the solution
+        self.x = x
+
+    def SetBox(self, is_, lb, ub):  # QPSetBox (qp.c:1842)
+        """is_: None or an int array selecting the constrained sub-vector (lb/ub then have len(is_))."""
+        n = self.A.n
+        if is_ is not None:
+            is_ = np.ascontiguousarray(is_, dtype=np.int32)
+            full = []
+            for bound, fill in ((lb, -np.inf), (ub, np.inf)):
+                if bound is None:
+                    full.append(None)
+                    continue
+                v = Vec(self.ctx, n, zero=False)
+                check(self.ctx.L.pmh_qpc_box_expand_is(self.ctx.h, n, is_.size, is_.ctypes.data_as(C.c_void_p), bound.p, fill, v.p))
+                full.append(v)
+            lb, ub = full
+        self.lb, self.ub = lb, ub
+
+    def SetEq(self, pf):  # QPSetEq + QPSetQPPF: BE = G lives in the projector factory
+        self.pf = pf
+
+    def GetSolutionVector(self):
+        return self.x
+
+
+class QPS:
+    """QPS front end: SetType("mpgp" | "smalxe" | "pcpg"), tolerances, Solve, statistics."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = ctx.L
+        self.type = None
+        self.qp = None
+        self.rtol, self.atol, self.divtol, self.max_it = 1e-5, 1e-50, 1e4, 10000  # qps.c:73-76
+        self._max_it_set = False
+        self.mpgp_opts = _lib.MpgpOpts()
+        check(self.L.pmh_mpgp_default_opts(C.byref(self.mpgp_opts)))
+        self.smalxe_opts = None
+        self.h = None
+        self.stats = None
+        self._cb = None
+
+    # ---- set-up -------------------------------------------------------------------------------------
+    def SetQP(self, qp):
+        self.qp = qp
+
+    def SetType(self, t):
+        if t not in ("mpgp", "smalxe", "pcpg"):
+            raise ValueError("unknown QPS type %r" % t)  # QPSSetType: PETSC_ERR_ARG_UNKNOWN_TYPE
+        self.type = t
+        if t == "smalxe" and self.smalxe_opts is None:
+            self.smalxe_opts = _lib.SmalxeOpts()
+            check(self.L.pmh_smalxe_default_opts(C.byref(self.smalxe_opts)))
+            if not self._max_it_set:
+                self.max_it = self.smalxe_opts.max_it  # 100, smalxe.c:1203
+
+    def SetDefaultType(self):  # QPSSetDefaultType qps.c:422-455
+        if self.qp.pf is not None:
+            self.SetType("smalxe")
+        elif self.qp.lb is not None or self.qp.ub is not None:
+            self.SetType("mpgp")
+        else:
+            raise ValueError("unconstrained QP: QPSKSP is out of scope; use pcpg")
+
+    def SetTolerances(self, rtol=None, atol=None, divtol=None, max_it=None):  # QPSSetTolerances
+        if rtol is not None:
+            self.rtol = float(rtol)
+        if atol is not None:
+            self.atol = float(atol)
+        if divtol is not None:
+            self.divtol = float(divtol)
+        if max_it is not None:
+            self.max_it = int(max_it)
+            self._max_it_set = True
+
+    # MPGP options (QPSSetFromOptions_MPGP keys, mpgp.c:723-745)
+    def MPGPSetAlpha(self, alpha, direct=False):
+        self._mo().alpha_user, self._mo().alpha_direct = float(alpha), int(bool(direct))
+
+    def MPGPSetGamma(self, gamma):
+        self._mo().gamma = float(gamma)
+
+    def MPGPSetOperatorMaxEigenvalue(self, maxeig):
+        if not (maxeig >= 0 or maxeig == -1.0):
+            raise ValueError("Argument must be nonnegative")  # mpgp.c:995
+        self._mo().maxeig = float(maxeig)
+
+    def MPGPSetOperatorMaxEigenvalueTolerance(self, tol):
+        self._mo().maxeig_tol = float(tol)
+
+    def MPGPSetOperatorMaxEigenvalueIterations(self, numit):
+        if not numit > 1:
+            raise ValueError("Argument must be > 1")  # mpgp.c:1088
+        self._mo().maxeig_iter = int(numit)
+
+    def MPGPSetExpansionType(self, exptype, lengthtype="fixed"):
+        self._mo().exptype = QPSMPGPExpansionTypes.index(exptype)
+        self._mo().explengthtype = QPSMPGPExpansionLengthTypes.index(lengthtype)
+
+    def MPGPSetFallback(self, fallback=False, fallback2=False):
+        self._mo().fallback, self._mo().fallback2 = int(fallback), int(fallback2)
+
+    def MPGPSetUnfused(self, flag=True):
+        self._mo().unfused = int(flag)
+
+    def MonitorSet(self, flag=True):  # QPSMonitorSet(qps, QPSMonitorDefault, ...)
+        self._mo().monitor = int(flag)
+
+    def _mo(self):
+        return self.smalxe_opts.inner if self.type == "smalxe" else self.mpgp_opts
+
+    # ---- solve --------------------------------------------------------------------------------------
+    def SetUp(self):  # QPSSetUp qps.c:198-221
+        if self.h is not None:
+            return
+        qp = self.qp
+        if self.type is None:
+            self.SetDefaultType()
+        h = C.c_void_p()
+        if self.type == "mpgp":
+            if qp.pf is not None:
+                raise ValueError("QPS solver mpgp is not compatible with its attached QP")  # QPSIsQPCompatible_MPGP
+            o = self.mpgp_opts
+            o.rtol, o.atol, o.divtol, o.max_it = self.rtol, self.atol, self.divtol, self.max_it
+            check(self.L.pmh_mpgp_create(self.ctx.h, qp.A.h, qp.b.p, qp.x.p, _ptr(qp.lb), _ptr(qp.ub), C.byref(o), C.byref(h)))
+        elif self.type == "smalxe":
+            o = self.smalxe_opts
+            o.rtol, o.atol, o.divtol, o.max_it = self.rtol, self.atol, self.divtol, self.max_it
+            check(self.L.pmh_smalxe_create(self.ctx.h, qp.A.h, qp.b.p, qp.x.p, _ptr(qp.lb), _ptr(qp.ub), qp.pf.h, C.byref(o), C.byref(h)))
+        self.h = h
+
+    def Solve(self):  # QPSSolve qps.c:537-555
+        self.SetUp()
+        qp = self.qp
+        if self.type == "mpgp":
+            check(self.L.pmh_mpgp_solve(self.h))
+            st = _lib.MpgpStats()
+            check(self.L.pmh_mpgp_get_stats(self.h, C.byref(st)))
+        elif self.type == "smalxe":
+            check(self.L.pmh_smalxe_solve(self.h))
+            st = _lib.SmalxeStats()
+            check(self.L.pmh_smalxe_get_stats(self.h, C.byref(st)))
+        else:
+            st = _lib.PcpgStats()
+            check(self.L.pmh_pcpg_solve(self.ctx.h, qp.A.h, qp.b.p, qp.x.p, qp.pf.h, qp.pc.h if qp.pc is not None else None,
+                                        self.rtol, self.atol, self.divtol, self.max_it, C.byref(st)))
+        self.stats = st
+        return st
+
+    def RunFixed(self, iters):
+        """Throughput mode (bench.py): exactly `iters` MPGP iterations, verdict of the convergence test ignored."""
+        self.SetUp()
+        check(self.L.pmh_mpgp_run_fixed(self.h, int(iters)))
+        st = _lib.MpgpStats()
+        check(self.L.pmh_mpgp_get_stats(self.h, C.byref(st)))
+        self.stats = st
+        return st
+
+    def GetIterationNumber(self):
+        return self.stats.iteration
+
+    def GetConvergedReason(self):
+        return self.stats.reason
+
+    def GetResidualNorm(self):
+        return self.stats.rnorm
+
+    def MPGPGetTrace(self):
+        """The QPSMonitorDefault_MPGP lines (mpgp.c:21-34) as (steps, gp, gf, gc, alpha)."""
+        cap = self.stats.iteration + 2 if self.type == "mpgp" else 1 << 20
+        step = C.create_string_buffer(cap + 1)
+        arrs = [np.zeros(cap) for _ in range(4)]
+        ln = C.c_int()
+        check(self.L.pmh_mpgp_get_trace(self.h, cap, step, *[a.ctypes.data_as(_lib.c_double_p) for a in arrs], C.byref(ln)))
+        m = min(ln.value, cap)
+        return (step.raw[:m].decode(),) + tuple(a[:m] for a in arrs)
+
+    def MPGPGetWork(self, idx):
+        p = C.c_void_p()
+        check(self.L.pmh_mpgp_get_work(self.h, int(idx), C.byref(p)))
+        a = np.empty(self.qp.A.n)
+        check(self.L.pmh_memcpy_d2h(self.ctx.h, a.ctypes.data_as(C.c_void_p), p, 8 * a.size))
+        return a
+
+    def Destroy(self):
+        if self.h is not None:
+            if self.type == "mpgp":
+                self.L.pmh_mpgp_destroy(self.h)
+            elif self.type == "smalxe":
+                self.L.pmh_smalxe_destroy(self.h)
+            self.h = None
