@@ -84,6 +84,10 @@ int pmh_csr_mult(pmh_csr A, const double *x, double *y);                       /
 int pmh_csr_mult_add(pmh_csr A, const double *x, const double *y1, double *y);  /* y = y1 + A x  */
 int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y);             /* y = A' x      */
 int pmh_csr_algorithmic_bytes(pmh_csr A, double *bytes);                        /* 12 nnz + 20 nrows */
+/* per-launch kernel timing with HIP events on the launch stream (bench.py's roofline leg): every SpMV launch of A
+   is bracketed by an event pair while enabled; `epilogue` selects 0 plain, 1 mult-add, 2 fused "-b", 3 fused MPGP phase P1 */
+int pmh_csr_timing_enable(pmh_csr A, int max_launches);
+int pmh_csr_timing_get(pmh_csr A, int epilogue, int *launches, double *total_ms);
 
 /* ---- generic operator (PETSc Mat with a mult slot) ------------------------------------------------ */
 typedef struct pmh_op_s *pmh_op;

@@ -95,6 +95,8 @@ _PROTOS = {
     "pmh_csr_mult_add": [vp, vp, vp, vp],
     "pmh_csr_mult_transpose": [vp, vp, vp],
     "pmh_csr_algorithmic_bytes": [vp, c_double_p],
+    "pmh_csr_timing_enable": [vp, C.c_int],
+    "pmh_csr_timing_get": [vp, C.c_int, c_int_p, c_double_p],
     "pmh_op_create_csr": [vp, C.POINTER(vp)],
     "pmh_op_create_shell": [vp, C.c_int, SHELL_MULT_FN, vp, C.POINTER(vp)],
     "pmh_op_destroy": [vp],

@@ -168,6 +168,15 @@ class CsrMat:
         check(self.ctx.L.pmh_csr_algorithmic_bytes(self.h, C.byref(b)))
         return b.value
 
+    def timing_enable(self, max_launches):
+        check(self.ctx.L.pmh_csr_timing_enable(self.h, int(max_launches)))
+
+    def timing_get(self, epilogue):
+        """(launches, total milliseconds) of the SpMV launches with the given epilogue since timing_enable."""
+        n, ms = C.c_int(), C.c_double()
+        check(self.ctx.L.pmh_csr_timing_get(self.h, int(epilogue), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def destroy(self):
         if self.h:
             self.ctx.L.pmh_csr_destroy(self.h)

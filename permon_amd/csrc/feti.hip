@@ -1,0 +1,427 @@
+// FETI operators on gfx950: MATGLUING (B, B'), MATBLOCKDIAG (K), MATINV apply (K^+), the dual operator
+// F = B K^+ B' and the lumped dual preconditioner B K B'.
+//
+// Layout in HBM.  A rank's subdomain blocks K_i are ONE concatenated CSR (block-diagonal by construction,
+// matblockdiag.c:787-801) plus the block row offsets, so one SpMV launch covers every subdomain the GPU
+// owns (BASELINE configs[3]: 8 per GPU) and primal vectors are plain contiguous arrays.  The signed Boolean
+// gluing is stored twice as CSR: B (n_lambda x n_primal, <= a few entries per row) and B' (n_primal x
+// n_lambda, empty rows for interior dofs); both use the stream SpMV and, because each row is summed left to
+// right in leaf order, reproduce MatMult(Transpose)_Gluing's accumulation order (gluing.c:67-75,142-150).
+// Dual vectors are replicated on every GPU: B' lambda is local, B u ends with one RCCL all-reduce.
+//
+// K^+ follows the reference's iterative MATINV path (KSPCG per block, matinv.c:535-540): block-wise
+// (Jacobi-)preconditioned CG in which every subdomain block carries its own alpha/beta/residual and stops
+// on its own; all per-block scalars live on the device, the host only polls the number of active blocks.
+#include <algorithm>
+#include <cmath>
+
+#include "pmh_internal.h"
+#include "reduce.h"
+
+// ---- MATGLUING -----------------------------------------------------------------------------------------------------
+struct pmh_gluing_s {
+  pmh_ctx ctx;
+  int     n_x, n_lambda, n_leaves;
+  pmh_csr B, Bt;
+};
+
+extern "C" int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leaves, const int *leaves_row, const int *leaves_root, const double *leaves_sign, pmh_gluing *out)
+{
+  PMH_ARG(ctx && out && n_x >= 0 && n_lambda >= 0 && n_leaves >= 0);
+  PMH_ARG(n_leaves == 0 || (leaves_row && leaves_root && leaves_sign));
+  for (int i = 0; i < n_leaves; i++) {
+    if (leaves_row[i] < 0 || leaves_row[i] >= n_x) return pmh_set_error(PMH_ERR_ARG, "pmh_gluing_create: leaf %d row %d out of [0,%d)", i, leaves_row[i], n_x);
+    if (leaves_root[i] < 0 || leaves_root[i] >= n_lambda) return pmh_set_error(PMH_ERR_ARG, "pmh_gluing_create: leaf %d root %d out of [0,%d)", i, leaves_root[i], n_lambda);
+  }
+  // stable counting sorts keep leaf order inside every row
+  auto build = [&](int nrows, int ncols, const int *rows, const int *cols, pmh_csr *M) -> int {
+    std::vector<int>    rp((size_t)nrows + 1, 0), ci((size_t)n_leaves);
+    std::vector<double> va((size_t)n_leaves);
+    for (int i = 0; i < n_leaves; i++) rp[rows[i] + 1]++;
+    for (int r = 0; r < nrows; r++) rp[r + 1] += rp[r];
+    std::vector<int> pos(rp.begin(), rp.end() - 1);
+    for (int i = 0; i < n_leaves; i++) {
+      int p = pos[rows[i]]++;
+      ci[p] = cols[i];
+      va[p] = leaves_sign[i];
+    }
+    return pmh_csr_create(ctx, nrows, ncols, rp.data(), ci.data(), va.data(), M);
+  };
+  pmh_gluing g = new pmh_gluing_s();
+  g->ctx = ctx, g->n_x = n_x, g->n_lambda = n_lambda, g->n_leaves = n_leaves;
+  g->B = g->Bt = nullptr;
+  PMH_CHK(build(n_lambda, n_x, leaves_root, leaves_row, &g->B));
+  PMH_CHK(build(n_x, n_lambda, leaves_row, leaves_root, &g->Bt));
+  *out = g;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_gluing_destroy(pmh_gluing g)
+{
+  if (!g) return PMH_SUCCESS;
+  pmh_csr_destroy(g->B);
+  pmh_csr_destroy(g->Bt);
+  delete g;
+  return PMH_SUCCESS;
+}
+
+// MatMult_Gluing gluing.c:47-81: x = B' lambda (VecZeroEntries + signed scatter-add)
+extern "C" int pmh_gluing_mult(pmh_gluing g, const double *lambda, double *x)
+{
+  PMH_ARG(g);
+  return pmh_csr_mult(g->Bt, lambda, x);
+}
+
+// MatMultTranspose_Gluing gluing.c:125-159: lambda = B x; PetscSFReduce(SUM) -> ncclAllReduce on the replicated lambda
+extern "C" int pmh_gluing_mult_transpose(pmh_gluing g, const double *x, double *lambda)
+{
+  PMH_ARG(g);
+  PMH_CHK(pmh_csr_mult(g->B, x, lambda));
+  return pmh_comm_allreduce_sum(g->ctx, lambda, (size_t)g->n_lambda);
+}
+
+// ---- MATBLOCKDIAG ---------------------------------------------------------------------------------------------------
+struct pmh_blockdiag_s {
+  pmh_ctx          ctx;
+  int              nblocks, n;
+  std::vector<int> rowstart;
+  int             *d_rowstart;
+  pmh_csr          K;
+};
+
+extern "C" int pmh_blockdiag_create(pmh_ctx ctx, int nblocks, const int *block_rowstart, pmh_csr Kcat, pmh_blockdiag *out)
+{
+  PMH_ARG(ctx && out && Kcat && nblocks >= 1 && block_rowstart);
+  PMH_ARG(Kcat->nrows == Kcat->ncols);
+  PMH_ARG(block_rowstart[0] == 0 && block_rowstart[nblocks] == Kcat->nrows);
+  for (int b = 0; b < nblocks; b++) PMH_ARG(block_rowstart[b + 1] >= block_rowstart[b]);
+  pmh_blockdiag K = new pmh_blockdiag_s();
+  K->ctx = ctx, K->nblocks = nblocks, K->n = Kcat->nrows, K->K = Kcat;
+  K->rowstart.assign(block_rowstart, block_rowstart + nblocks + 1);
+  PMH_HIP(hipMalloc((void **)&K->d_rowstart, sizeof(int) * (size_t)(nblocks + 1)));
+  PMH_CHK(pmh_memcpy_h2d(ctx, K->d_rowstart, block_rowstart, sizeof(int) * (size_t)(nblocks + 1)));
+  *out = K;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_blockdiag_destroy(pmh_blockdiag K)
+{
+  if (!K) return PMH_SUCCESS;
+  hipFree(K->d_rowstart);
+  delete K;
+  return PMH_SUCCESS;
+}
+
+// MatMult_BlockDiag matblockdiag.c:190-201
+extern "C" int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y)
+{
+  PMH_ARG(K);
+  return pmh_csr_mult(K->K, x, y);
+}
+
+// ---- MATINV: block-wise CG -------------------------------------------------------------------------------------------
+// per-block scalar slots (doubles)
+enum { BS_RZ = 0, BS_PAP, BS_RZNEW, BS_RR, BS_ALPHA, BS_BETA, BS_TOL, BS_NSLOT };
+// per-block int slots
+enum { BI_ACTIVE = 0, BI_ITS, BI_NSLOT };
+
+struct pmh_matinv_s {
+  pmh_blockdiag K;
+  pmh_ctx       ctx;
+  int           n, nblocks, wgs; // wgs = workgroups per block in the segmented kernels
+  double        rtol, atol;
+  int           max_it, jacobi;
+  double       *dinv, *r, *z, *p, *Ap;
+  double       *d_part; // [2][nblocks*wgs]
+  double       *d_bs;   // [nblocks][BS_NSLOT]
+  int          *d_bi;   // [nblocks][BI_NSLOT]
+  int          *d_nactive, *h_nactive;
+  int           last_max_its;
+  long long     total_spmv;
+};
+
+#define SEG_LOOP(i, b, rs, wgs) \
+  const int b = blockIdx.x / (wgs), w_ = blockIdx.x % (wgs); \
+  const int lo_ = (rs)[b], hi_ = (rs)[b + 1]; \
+  for (int i = lo_ + w_ * PMH_BLOCK + (int)threadIdx.x; i < hi_; i += (wgs)*PMH_BLOCK)
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_extract_dinv(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int jacobi, double *__restrict__ dinv)
+{
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
+    double d = 1.0;
+    if (jacobi) {
+      d = 0.0;
+      for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+        if (col[k] == i) d = val[k];
+      d = (d != 0.0) ? 1.0 / d : 1.0;
+    }
+    dinv[i] = d;
+  }
+}
+
+// start: u = 0, r = f, z = Dinv r, p = z; partials r.z and r.r
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ rs, int wgs, const double *__restrict__ f, const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, double *__restrict__ part, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            s0 = 0.0, s1 = 0.0;
+  SEG_LOOP(i, b, rs, wgs)
+  {
+    double ri = f[i], zi = dinv[i] * ri;
+    u[i] = 0.0;
+    r[i] = ri;
+    z[i] = zi;
+    p[i] = zi;
+    s0 += ri * zi;
+    s1 += ri * ri;
+  }
+  s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
+  s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x]      = s0;
+    part[ld + blockIdx.x] = s1;
+  }
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_seg_dot(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  if (*nactive == 0) return;
+  double s = 0.0;
+  SEG_LOOP(i, b, rs, wgs) s += x[i] * y[i];
+  s = pmh_block_reduce<PMH_RED_SUM>(s, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// u += alpha_b p; r -= alpha_b Ap; z = Dinv r; partials r.z, r.r
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ part, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  if (*nactive == 0) return;
+  double       s0 = 0.0, s1 = 0.0;
+  const int    bb     = blockIdx.x / wgs;
+  const bool   active = bi[bb * BI_NSLOT + BI_ACTIVE] != 0;
+  const double alpha  = bs[bb * BS_NSLOT + BS_ALPHA];
+  if (active) {
+    SEG_LOOP(i, b, rs, wgs)
+    {
+      double ri = r[i] - alpha * Ap[i];
+      double zi = dinv[i] * ri;
+      u[i] += alpha * p[i];
+      r[i] = ri;
+      z[i] = zi;
+      s0 += ri * zi;
+      s1 += ri * ri;
+    }
+  }
+  s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
+  s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x]      = s0;
+    part[ld + blockIdx.x] = s1;
+  }
+}
+
+// p = z + beta_b p
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_p(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ z, double *__restrict__ p)
+{
+  if (*nactive == 0) return;
+  const int bb = blockIdx.x / wgs;
+  if (!bi[bb * BI_NSLOT + BI_ACTIVE]) return;
+  const double beta = bs[bb * BS_NSLOT + BS_BETA];
+  SEG_LOOP(i, b, rs, wgs) p[i] = z[i] + beta * p[i];
+}
+
+// one workgroup per block: reduce the block's partials in fixed order and run the scalar recurrences
+// phase 0: start (rz, rr -> tol, active); phase 1: pAp -> alpha; phase 2: rznew, rr -> beta, convergence
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_scalars(int phase, int wgs, int ld, const double *__restrict__ part, double *__restrict__ bs, int *__restrict__ bi, int *__restrict__ nactive, int *__restrict__ h_nactive, double rtol, double atol, int it, int max_it)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  const int         b = blockIdx.x;
+  if (phase != 0 && *nactive == 0) return;
+  double v0 = 0.0, v1 = 0.0;
+  for (int i = threadIdx.x; i < wgs; i += PMH_BLOCK) {
+    v0 += part[b * wgs + i];
+    if (phase != 1) v1 += part[ld + b * wgs + i];
+  }
+  v0 = pmh_block_reduce<PMH_RED_SUM>(v0, lds);
+  v1 = pmh_block_reduce<PMH_RED_SUM>(v1, lds);
+  if (threadIdx.x != 0) return;
+  double *s = bs + b * BS_NSLOT;
+  int    *q = bi + b * BI_NSLOT;
+  if (phase == 0) {
+    s[BS_RZ]     = v0;
+    s[BS_RR]     = v1;
+    s[BS_TOL]    = fmax(rtol * sqrt(v1), atol); // KSPConvergedDefault: rnorm <= max(rtol*||b||, atol), zero initial guess
+    q[BI_ITS]    = 0;
+    const int a  = (sqrt(v1) > s[BS_TOL]) ? 1 : 0;
+    q[BI_ACTIVE] = a;
+    if (a) {
+      int old = atomicAdd(nactive, 1);
+      (void)old;
+    }
+  } else if (phase == 1) {
+    if (q[BI_ACTIVE]) {
+      s[BS_PAP]   = v0;
+      s[BS_ALPHA] = s[BS_RZ] / v0;
+    }
+  } else {
+    if (q[BI_ACTIVE]) {
+      s[BS_RZNEW] = v0;
+      s[BS_RR]    = v1;
+      s[BS_BETA]  = v0 / s[BS_RZ];
+      s[BS_RZ]    = v0;
+      q[BI_ITS]   = it + 1;
+      if (sqrt(v1) <= s[BS_TOL] || it + 1 >= max_it || !(v1 == v1)) {
+        q[BI_ACTIVE] = 0;
+        atomicSub(nactive, 1);
+      }
+    }
+  }
+}
+
+__global__ void k_publish_int(const int *d, int *h) { *h = *d; }
+
+extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int max_it, int jacobi, pmh_matinv *out)
+{
+  PMH_ARG(K && out && max_it > 0);
+  pmh_ctx    ctx = K->ctx;
+  pmh_matinv M   = new pmh_matinv_s();
+  M->K = K, M->ctx = ctx, M->n = K->n, M->nblocks = K->nblocks;
+  M->rtol = rtol, M->atol = atol, M->max_it = max_it, M->jacobi = jacobi;
+  M->wgs          = std::max(1, std::min(256, PMH_MAX_VEC_BLOCKS / K->nblocks));
+  M->last_max_its = 0;
+  M->total_spmv   = 0;
+  const size_t nb = sizeof(double) * (size_t)(M->n ? M->n : 1);
+  PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->dinv));
+  PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->r));
+  PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->z));
+  PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->p));
+  PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->Ap));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 2 * (size_t)M->nblocks * M->wgs, (void **)&M->d_part));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)M->nblocks * BS_NSLOT, (void **)&M->d_bs));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)M->nblocks * BI_NSLOT, (void **)&M->d_bi));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_nactive));
+  PMH_HIP(hipHostMalloc((void **)&M->h_nactive, sizeof(int), hipHostMallocMapped));
+  if (M->n > 0) {
+    hipLaunchKernelGGL(k_extract_dinv, dim3(pmh_vec_grid(M->n)), dim3(PMH_BLOCK), 0, ctx->stream, M->n, K->K->d_rowptr, K->K->d_col, K->K->d_val, jacobi, M->dinv);
+    PMH_HIP(hipGetLastError());
+  }
+  *out = M;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_matinv_destroy(pmh_matinv M)
+{
+  if (!M) return PMH_SUCCESS;
+  pmh_ctx ctx = M->ctx;
+  pmh_free(ctx, M->dinv);
+  pmh_free(ctx, M->r);
+  pmh_free(ctx, M->z);
+  pmh_free(ctx, M->p);
+  pmh_free(ctx, M->Ap);
+  pmh_free(ctx, M->d_part);
+  pmh_free(ctx, M->d_bs);
+  pmh_free(ctx, M->d_bi);
+  pmh_free(ctx, M->d_nactive);
+  hipHostFree(M->h_nactive);
+  delete M;
+  return PMH_SUCCESS;
+}
+
+// MatMult_Inv matinv.c:734-743: u = K^+ f by block-wise CG from a zero initial guess
+extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
+{
+  PMH_ARG(M && f && u && (const void *)f != (const void *)u);
+  pmh_ctx   ctx  = M->ctx;
+  const int nb   = M->nblocks, wgs = M->wgs, grid = nb * wgs, ld = nb * wgs;
+  const int *rs  = M->K->d_rowstart;
+  hipStream_t st = ctx->stream;
+  if (M->n == 0) return PMH_SUCCESS;
+  PMH_HIP(hipMemsetAsync(M->d_nactive, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
+  hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 0, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, 0, M->max_it);
+  PMH_HIP(hipGetLastError());
+  int it = 0, next_check = (M->last_max_its > 8) ? (M->last_max_its - 2) : 4;
+  while (it < M->max_it) {
+    PMH_CHK(pmh_csr_mult(M->K->K, M->p, M->Ap));
+    M->total_spmv++;
+    hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->p, (const double *)M->Ap, M->d_part);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 1, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, it, M->max_it);
+    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_part, ld);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 2, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, it, M->max_it);
+    hipLaunchKernelGGL(k_cg_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->z, M->p);
+    PMH_HIP(hipGetLastError());
+    it++;
+    if (it >= next_check || it >= M->max_it) {
+      hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, st, (const int *)M->d_nactive, M->h_nactive);
+      PMH_HIP(hipStreamSynchronize(st));
+      if (*M->h_nactive == 0) break;
+      next_check = it + 2;
+    }
+  }
+  // iteration counts per block
+  std::vector<int> bi((size_t)nb * BI_NSLOT);
+  PMH_CHK(pmh_memcpy_d2h(ctx, bi.data(), M->d_bi, sizeof(int) * bi.size()));
+  int mx = 0;
+  for (int b = 0; b < nb; b++) mx = std::max(mx, bi[(size_t)b * BI_NSLOT + BI_ITS]);
+  M->last_max_its = mx;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_matinv_last_iterations(pmh_matinv M, int *max_block_its, long long *total_spmv)
+{
+  PMH_ARG(M);
+  if (max_block_its) *max_block_its = M->last_max_its;
+  if (total_spmv) *total_spmv = M->total_spmv;
+  return PMH_SUCCESS;
+}
+
+// ---- F = B K^+ B' and the lumped preconditioner ------------------------------------------------------------------------
+struct FetiDualOp : pmh_op_s {
+  pmh_gluing B;
+  pmh_matinv Kplus;
+  double    *t1, *t2;
+  ~FetiDualOp() override
+  {
+    pmh_free(ctx, t1);
+    pmh_free(ctx, t2);
+  }
+  // MatCreateProd(Bt, Kplus, B) applied right to left: qptransform.c:1103-1128, matprod.c:42-48
+  int mult(const double *x, double *y) override
+  {
+    PMH_CHK(pmh_gluing_mult(B, x, t1));
+    PMH_CHK(pmh_matinv_mult(Kplus, t1, t2));
+    return pmh_gluing_mult_transpose(B, t2, y);
+  }
+};
+
+extern "C" int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F)
+{
+  PMH_ARG(B && Kplus && F);
+  PMH_ARG(B->n_x == Kplus->n);
+  FetiDualOp *o = new FetiDualOp();
+  o->ctx        = B->ctx;
+  o->n          = B->n_lambda;
+  o->B          = B;
+  o->Kplus      = Kplus;
+  PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)(B->n_x ? B->n_x : 1), (void **)&o->t1));
+  PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)(B->n_x ? B->n_x : 1), (void **)&o->t2));
+  *F = o;
+  return PMH_SUCCESS;
+}
+
+// PCApply_Dual (lumped) pcdual.c:63-78: xwork = B' x; ywork = K xwork; y = B ywork
+extern "C" int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, double *y)
+{
+  PMH_ARG(B && K && B->n_x == K->n);
+  pmh_ctx ctx = B->ctx;
+  double *xw, *yw;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(K->n ? K->n : 1), (void **)&xw));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(K->n ? K->n : 1), (void **)&yw));
+  int rc = pmh_gluing_mult(B, x, xw);
+  if (!rc) rc = pmh_blockdiag_mult(K, xw, yw);
+  if (!rc) rc = pmh_gluing_mult_transpose(B, yw, y);
+  pmh_free(ctx, xw);
+  pmh_free(ctx, yw);
+  return rc;
+}

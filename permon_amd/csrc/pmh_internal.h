@@ -68,6 +68,10 @@ struct pmh_csr_s {
   double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue
   int       n_launch_blocks;
   pmh_csr   transpose;     // built lazily for mult_transpose
+  // optional per-launch timing (HIP event pairs recorded on the launch stream)
+  std::vector<hipEvent_t> *ev;
+  std::vector<int>        *ev_kind;
+  int                      ev_used;
 };
 
 // epilogues of the SpMV kernels
@@ -87,6 +91,18 @@ struct pmh_op_s {
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
   virtual pmh_csr as_csr() { return nullptr; }
+};
+
+// ---- projector factory -------------------------------------------------------------------------------------
+struct pmh_qppf_s {
+  pmh_ctx ctx;
+  pmh_csr G;
+  int     m, n;
+  int     orthonormal;
+  double *d_inv; // (GG')^{-1}, m x m row-major
+  double *G_left, *Gt_right;
+  // QPPFApplyQ's (v,state) -> Qv cache (qppf.c:464-467,495-498) is realised structurally: the penalised
+  // operator over a projected operator computes Q x once and reuses it (see PenalizedOp::mult).
 };
 
 // ---- reductions ---------------------------------------------------------------------------------------------

@@ -1,0 +1,286 @@
+// QPPF projector factory on gfx950: Q = G'(GG')^{-1}G, P = I - Q (src/qppf/interface/qppf.c) and the two
+// shell operators of the QP transform chain built on it: A + rho*G'G (src/qp/utils/matpenalized.c) and
+// P*A*P / P*A (QPTEnforceEqByProjector, src/qp/interface/qptransform.c:215-316).
+//
+// G (m x n, m = 6 * #subdomains rigid-body rows, each dense over one subdomain's interface) is an explicit
+// CSR in HBM; G v uses the long-row path of the SpMV (one workgroup per row), G' w the short-row stream
+// path on the transposed CSR.  The coarse problem (GG')^{-1} is small and dense: GG' is assembled and
+// inverted on the host once (the reference's QPPFSetUpGGt_Private / -qppf_explicit_inv path, qppf.c:213-333)
+// and applied as a dense GEMV, redundantly on every GPU (mirrors -qppf_redundancy, qppf.c:182,305).
+#include "pmh_internal.h"
+#include "reduce.h"
+
+
+// y = M x, M dense m x m row-major; one 64-lane wavefront per row
+__global__ __launch_bounds__(PMH_BLOCK) void k_dense_gemv(int m, const double *__restrict__ M, const double *__restrict__ x, double *__restrict__ y)
+{
+  const int row = blockIdx.x * (PMH_BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  double s = 0.0;
+  for (int j = lane; j < m; j += 64) s += M[(size_t)row * m + j] * x[j];
+  s = pmh_wave_sum(s);
+  if (lane == 0) y[row] = s;
+}
+
+static int host_cholesky_inverse(int m, std::vector<double> &a)
+{
+  // in-place lower Cholesky, then inverse via forward/back substitution against the identity
+  for (int j = 0; j < m; j++) {
+    double d = a[(size_t)j * m + j];
+    for (int k = 0; k < j; k++) d -= a[(size_t)j * m + k] * a[(size_t)j * m + k];
+    if (!(d > 0.0)) return 1;
+    d                    = sqrt(d);
+    a[(size_t)j * m + j] = d;
+    for (int i = j + 1; i < m; i++) {
+      double s = a[(size_t)i * m + j];
+      for (int k = 0; k < j; k++) s -= a[(size_t)i * m + k] * a[(size_t)j * m + k];
+      a[(size_t)i * m + j] = s / d;
+    }
+  }
+  std::vector<double> inv((size_t)m * m, 0.0), col(m);
+  for (int c = 0; c < m; c++) {
+    for (int i = 0; i < m; i++) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; k++) s -= a[(size_t)i * m + k] * col[k];
+      col[i] = s / a[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; i--) {
+      double s = col[i];
+      for (int k = i + 1; k < m; k++) s -= a[(size_t)k * m + i] * col[k];
+      col[i] = s / a[(size_t)i * m + i];
+    }
+    for (int i = 0; i < m; i++) inv[(size_t)i * m + c] = col[i];
+  }
+  a.swap(inv);
+  return 0;
+}
+
+extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf *out)
+{
+  PMH_ARG(ctx && G && out);
+  pmh_qppf pf    = new pmh_qppf_s();
+  pf->ctx        = ctx;
+  pf->G          = G;
+  pf->m          = G->nrows;
+  pf->n          = G->ncols;
+  pf->orthonormal = orthonormal ? 1 : 0;
+  pf->d_inv      = nullptr;
+  const int m    = pf->m;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->G_left));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->Gt_right));
+  if (!pf->orthonormal && m > 0) {
+    // GG' on the host (QPPFSetUpGGt_Private qppf.c:213-278), column-wise accumulation over G'
+    std::vector<int>    rp((size_t)m + 1), ci((size_t)G->nnz);
+    std::vector<double> va((size_t)G->nnz);
+    PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), G->d_rowptr, sizeof(int) * rp.size()));
+    PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), G->d_col, sizeof(int) * ci.size()));
+    PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), G->d_val, sizeof(double) * va.size()));
+    std::vector<int> cp((size_t)pf->n + 1, 0), cr((size_t)G->nnz);
+    std::vector<double> cv((size_t)G->nnz);
+    for (long long k = 0; k < G->nnz; k++) cp[ci[k] + 1]++;
+    for (int j = 0; j < pf->n; j++) cp[j + 1] += cp[j];
+    std::vector<int> pos(cp.begin(), cp.end() - 1);
+    for (int i = 0; i < m; i++)
+      for (int k = rp[i]; k < rp[i + 1]; k++) {
+        int p = pos[ci[k]]++;
+        cr[p] = i;
+        cv[p] = va[k];
+      }
+    std::vector<double> ggt((size_t)m * m, 0.0);
+    for (int j = 0; j < pf->n; j++)
+      for (int a = cp[j]; a < cp[j + 1]; a++)
+        for (int b = cp[j]; b < cp[j + 1]; b++) ggt[(size_t)cr[a] * m + cr[b]] += cv[a] * cv[b];
+    if (host_cholesky_inverse(m, ggt)) {
+      pmh_free(ctx, pf->G_left);
+      pmh_free(ctx, pf->Gt_right);
+      delete pf;
+      return pmh_set_error(PMH_ERR_ARG, "pmh_qppf_create: G G' is not positive definite (G must have full row rank)");
+    }
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)m * m, (void **)&pf->d_inv));
+    PMH_CHK(pmh_memcpy_h2d(ctx, pf->d_inv, ggt.data(), sizeof(double) * (size_t)m * m));
+  }
+  *out = pf;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_qppf_destroy(pmh_qppf pf)
+{
+  if (!pf) return PMH_SUCCESS;
+  pmh_free(pf->ctx, pf->G_left);
+  pmh_free(pf->ctx, pf->Gt_right);
+  if (pf->d_inv) pmh_free(pf->ctx, pf->d_inv);
+  delete pf;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv)
+{
+  PMH_ARG(pf);
+  if (pf->m == 0) return PMH_SUCCESS;
+  return pmh_csr_mult(pf->G, v, Gv);
+}
+
+// QPPFApplyCP qppf.c:610-645
+extern "C" int pmh_qppf_apply_CP(pmh_qppf pf, const double *x, double *y)
+{
+  PMH_ARG(pf);
+  if (pf->m == 0) return PMH_SUCCESS;
+  if (!pf->d_inv) return pmh_vec_copy(pf->ctx, pf->m, x, y);
+  hipLaunchKernelGGL(k_dense_gemv, dim3((pf->m + 3) / 4), dim3(PMH_BLOCK), 0, pf->ctx->stream, pf->m, pf->d_inv, x, y);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+// QPPFApplyQ qppf.c:454-503
+extern "C" int pmh_qppf_apply_Q(pmh_qppf pf, const double *v, double *Qv)
+{
+  PMH_ARG(pf && (const void *)v != (const void *)Qv);
+  if (pf->m == 0) return pmh_vec_set(pf->ctx, pf->n, Qv, 0.0);
+  PMH_CHK(pmh_csr_mult(pf->G, v, pf->G_left));
+  if (pf->d_inv) {
+    PMH_CHK(pmh_qppf_apply_CP(pf, pf->G_left, pf->Gt_right));
+    return pmh_csr_mult_transpose(pf->G, pf->Gt_right, Qv);
+  }
+  return pmh_csr_mult_transpose(pf->G, pf->G_left, Qv);
+}
+
+// QPPFApplyP qppf.c:563-575: Pv = v - Qv  (VecAYPX(Pv,-1,v))
+extern "C" int pmh_qppf_apply_P(pmh_qppf pf, const double *v, double *Pv)
+{
+  PMH_CHK(pmh_qppf_apply_Q(pf, v, Pv));
+  return pmh_vec_aypx(pf->ctx, pf->n, Pv, -1.0, v);
+}
+
+// QPPFApplyGtG qppf.c:580-605
+extern "C" int pmh_qppf_apply_GtG(pmh_qppf pf, const double *v, double *y)
+{
+  PMH_ARG(pf);
+  if (pf->orthonormal) return pmh_qppf_apply_Q(pf, v, y);
+  if (pf->m == 0) return pmh_vec_set(pf->ctx, pf->n, y, 0.0);
+  PMH_CHK(pmh_csr_mult(pf->G, v, pf->G_left));
+  return pmh_csr_mult_transpose(pf->G, pf->G_left, y);
+}
+
+// QPPFApplyHalfQ qppf.c:507-527: y = (GG')^{-1} G x  (length m)
+extern "C" int pmh_qppf_apply_halfQ(pmh_qppf pf, const double *x, double *y)
+{
+  PMH_ARG(pf);
+  if (pf->m == 0) return PMH_SUCCESS;
+  PMH_CHK(pmh_csr_mult(pf->G, x, pf->G_left));
+  return pmh_qppf_apply_CP(pf, pf->G_left, y);
+}
+
+// QPPFApplyHalfQTranspose qppf.c:531-559: y = G'(GG')^{-1} x
+extern "C" int pmh_qppf_apply_halfQ_transpose(pmh_qppf pf, const double *x, double *y)
+{
+  PMH_ARG(pf);
+  if (pf->m == 0) return pmh_vec_set(pf->ctx, pf->n, y, 0.0);
+  if (pf->d_inv) {
+    PMH_CHK(pmh_qppf_apply_CP(pf, x, pf->Gt_right));
+    return pmh_csr_mult_transpose(pf->G, pf->Gt_right, y);
+  }
+  return pmh_csr_mult_transpose(pf->G, x, y);
+}
+
+// ---- shell operators of the transform chain ------------------------------------------------------------------------
+struct ProjectedOp : pmh_op_s {
+  pmh_op   A;
+  pmh_qppf pf;
+  int      symmetric;
+  double  *w1, *w2;
+  ~ProjectedOp() override
+  {
+    pmh_free(ctx, w1);
+    pmh_free(ctx, w2);
+  }
+  // MatCreateProd(P,A,P) / (P,A): qptransform.c:273-284, matprod.c:42-48
+  int mult(const double *x, double *y) override
+  {
+    if (symmetric) {
+      PMH_CHK(pmh_qppf_apply_P(pf, x, w1));
+      PMH_CHK(A->mult(w1, w2));
+    } else {
+      PMH_CHK(A->mult(x, w2));
+    }
+    return pmh_qppf_apply_P(pf, w2, y);
+  }
+  // same, with Q x supplied by the caller (the QPPFApplyQ cache hit of qppf.c:464-467)
+  int mult_with_Qx(const double *x, const double *Qx, double *y)
+  {
+    if (symmetric) {
+      PMH_CHK(pmh_vec_waxpy(ctx, n, w1, -1.0, Qx, x)); // P x = x - Q x
+      PMH_CHK(A->mult(w1, w2));
+    } else {
+      PMH_CHK(A->mult(x, w2));
+    }
+    return pmh_qppf_apply_P(pf, w2, y);
+  }
+};
+
+struct PenalizedOp : pmh_op_s {
+  pmh_op   A;
+  pmh_qppf pf;
+  double   rho;
+  double  *t;
+  ~PenalizedOp() override { pmh_free(ctx, t); }
+  // MatMult_Penalized matpenalized.c:12-22: y = BtB x; y *= rho; y = y + A x
+  int mult(const double *x, double *y) override
+  {
+    PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));
+    ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
+    if (pa && pa->pf == pf && pa->symmetric && pf->orthonormal) {
+      PMH_CHK(pa->mult_with_Qx(x, y, t)); // y currently holds Q x: reuse it before scaling
+    } else {
+      PMH_CHK(A->mult(x, t));
+    }
+    PMH_CHK(pmh_vec_scale(ctx, n, y, rho));
+    return pmh_vec_axpy(ctx, n, y, 1.0, t);
+  }
+};
+
+extern "C" int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op *op)
+{
+  PMH_ARG(A && pf && op && rho >= 0);
+  PMH_ARG(A->n == pf->n);
+  PenalizedOp *o = new PenalizedOp();
+  o->ctx         = A->ctx;
+  o->n           = A->n;
+  o->A           = A;
+  o->pf          = pf;
+  o->rho         = rho;
+  PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)o->n, (void **)&o->t));
+  *op = o;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_op_penalized_set_penalty(pmh_op op, double rho)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && rho >= 0);
+  o->rho = rho;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_op_penalized_get_penalty(pmh_op op, double *rho)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && rho);
+  *rho = o->rho;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_op_create_projected(pmh_op A, pmh_qppf pf, int symmetric, pmh_op *op)
+{
+  PMH_ARG(A && pf && op);
+  PMH_ARG(A->n == pf->n);
+  ProjectedOp *o = new ProjectedOp();
+  o->ctx         = A->ctx;
+  o->n           = A->n;
+  o->A           = A;
+  o->pf          = pf;
+  o->symmetric   = symmetric ? 1 : 0;
+  PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)o->n, (void **)&o->w1));
+  PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)o->n, (void **)&o->w2));
+  *op = o;
+  return PMH_SUCCESS;
+}

@@ -1,0 +1,376 @@
+// QPS SMALXE (src/qps/impls/smalxe/smalxe.c) and QPS PCPG (src/qps/impls/pcpg/pcpg.c) on gfx950.
+// Outer loops are host logic over device-resident vectors; all arithmetic is in the kernels of vec.hip,
+// spmv.hip, qppf.hip and the inner MPGP driver (mpgp.hip).
+#include <cmath>
+
+#include "pmh_internal.h"
+
+struct pmh_smalxe_s {
+  pmh_ctx         ctx;
+  pmh_op          A;
+  const double   *b;
+  double         *u;
+  const double   *lb, *ub;
+  pmh_qppf        pf;
+  pmh_smalxe_opts o;
+  int             n;
+  // QPS_SMALXE state (smalxeimpl.h:13-67)
+  double M1, M1_initial, eta, maxeig;
+  int    M1_updates, M1_hits, eta_hits, rho_updates;
+  int    state, inner_iter_accu;
+  double normBu, normBu_old, enorm;
+  double rnorm;
+  int    iteration, reason;
+  // inner solver + penalised QP
+  pmh_op   A_inner;
+  pmh_mpgp inner;
+  double  *Btmu, *b_inner, *BtBu, *Bu, *xwork;
+  // QPSConvergedCtx_Inner_SMALXE + outer QPSConvergedDefaultCtx
+  double gtol, ttol_outer, norm_rhs_outer, MNormBu;
+  double outer_norm_rhs, outer_ttol, outer_norm_rhs_div;
+  int    outer_cvg_setup;
+  double inner_atol;
+  int    inner_reason, inner_max_it;
+  double inner_rnorm;
+};
+
+// QPSCreate_SMALXE defaults smalxe.c:1159-1207
+extern "C" int pmh_smalxe_default_opts(pmh_smalxe_opts *o)
+{
+  PMH_ARG(o);
+  memset(o, 0, sizeof(*o));
+  o->rtol               = 1e-5;
+  o->atol               = 1e-50;
+  o->divtol             = 1e4;
+  o->max_it             = 100;
+  o->M1_user            = 1e2;
+  o->M1_direct          = 0;
+  o->M1_update          = 2.0;
+  o->rtol_E             = 1e-0;
+  o->rho_user           = 1.1;
+  o->rho_direct         = 0;
+  o->rho_update         = 1.0;
+  o->rho_update_late    = 2.0;
+  o->eta_user           = 1e-1;
+  o->eta_direct         = 0;
+  o->update_threshold   = 0.0;
+  o->maxeig             = PMH_DECIDE;
+  o->maxeig_tol         = PMH_DECIDE;
+  o->maxeig_iter        = -1;
+  o->inject_maxeig      = 0;
+  o->inject_maxeig_set  = 0;
+  o->inner_iter_min     = 1;
+  o->inner_no_gtol_stop = 0;
+  return pmh_mpgp_default_opts(&o->inner);
+}
+
+// QPSSMALXEUpdateNormBu_SMALXE smalxe.c:247-261 (cE is homogenised away before SMALXE, smalxe.c:782-787)
+static int update_normBu(pmh_smalxe s, const double *u, double *normBu, double *enorm)
+{
+  if (s->pf->m > 0) {
+    PMH_CHK(pmh_qppf_apply_G(s->pf, u, s->Bu));
+    PMH_CHK(pmh_vec_norm2(s->ctx, s->pf->m, s->Bu, normBu));
+  } else {
+    *normBu = 0.0;
+  }
+  *enorm = *normBu / s->o.rtol_E;
+  return PMH_SUCCESS;
+}
+
+// the outer solver's QPSConvergedDefault (qps.c:675-714)
+static int outer_converged(pmh_smalxe s, int *reason)
+{
+  if (!s->outer_cvg_setup) {
+    PMH_CHK(pmh_vec_norm2(s->ctx, s->n, s->b, &s->outer_norm_rhs));
+    s->outer_ttol         = fmax(s->o.rtol * s->outer_norm_rhs, s->o.atol);
+    s->outer_norm_rhs_div = s->outer_norm_rhs;
+    s->outer_cvg_setup    = 1;
+  }
+  *reason = PMH_CONVERGED_ITERATING;
+  if (s->iteration > s->o.max_it) {
+    *reason = PMH_DIVERGED_ITS;
+    return PMH_SUCCESS;
+  }
+  if (std::isnan(s->rnorm) || std::isinf(s->rnorm)) *reason = PMH_DIVERGED_NANORINF;
+  else if (s->rnorm <= s->outer_ttol) *reason = (s->rnorm < s->o.atol) ? PMH_CONVERGED_ATOL : PMH_CONVERGED_RTOL;
+  else if (s->rnorm >= s->o.divtol * s->outer_norm_rhs_div) *reason = PMH_DIVERGED_DTOL;
+  return PMH_SUCCESS;
+}
+
+// QPSConverged_Inner_SMALXE smalxe.c:610-692, injected into the inner MPGP (smalxe.c:874-875)
+static int inner_converged(void *user, int i, double gnorm, int *reason)
+{
+  pmh_smalxe s = (pmh_smalxe)user;
+  *reason      = PMH_CONVERGED_ITERATING;
+  s->inner_rnorm = gnorm;
+  if (update_normBu(s, s->u, &s->normBu, &s->enorm)) return 1;
+  s->rnorm      = fmax(s->enorm, gnorm);
+  s->MNormBu    = s->M1 * s->normBu;
+  s->inner_atol = fmin(s->MNormBu, s->eta);
+
+  if (i > s->inner_max_it - s->inner_iter_accu) {
+    *reason   = PMH_DIVERGED_ITS;
+    s->reason = PMH_DIVERGED_BREAKDOWN;
+    return 0;
+  }
+  if (std::isnan(gnorm) || std::isinf(gnorm)) {
+    *reason   = PMH_DIVERGED_NANORINF;
+    s->reason = PMH_DIVERGED_BREAKDOWN;
+    return 0;
+  }
+  if (outer_converged(s, &s->reason)) return 1;
+  if (s->reason) {
+    *reason = (s->reason > 0) ? PMH_CONVERGED_HAPPY_BREAKDOWN : PMH_DIVERGED_BREAKDOWN;
+    return 0;
+  }
+  if (gnorm < s->inner_atol) {
+    *reason = PMH_CONVERGED_ATOL;
+    if (s->MNormBu < s->eta) s->M1_hits++;
+    else s->eta_hits++;
+    return 0;
+  }
+  if (s->state == 3 && (i < s->o.inner_iter_min || s->o.inner_no_gtol_stop)) return 0;
+  if (gnorm <= s->gtol) {
+    if (gnorm > s->enorm) {
+      // skipping gtol criterion because G > E (smalxe.c:675-676)
+    } else {
+      if (s->o.inner_no_gtol_stop < 2) *reason = PMH_CONVERGED_RTOL;
+      if (s->state != 3) s->state = 3;
+    }
+  }
+  return 0;
+}
+
+// QPSSetUp_SMALXE smalxe.c:772-888
+extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double *u, const double *lb, const double *ub, pmh_qppf pf, const pmh_smalxe_opts *o, pmh_smalxe *out)
+{
+  PMH_ARG(ctx && A && b && u && pf && o && out);
+  PMH_ARG(pf->n == A->n);
+  pmh_smalxe s = new pmh_smalxe_s();
+  memset((void *)s, 0, sizeof(*s));
+  s->ctx = ctx, s->A = A, s->b = b, s->u = u, s->lb = lb, s->ub = ub, s->pf = pf, s->o = *o, s->n = A->n;
+  s->state  = 1;
+  s->normBu = s->normBu_old = s->enorm = NAN;
+  const int n = s->n;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->BtBu));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->Btmu));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->b_inner));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->xwork));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(pf->m ? pf->m : 1), (void **)&s->Bu));
+  PMH_CHK(pmh_memset(ctx, s->Btmu, 0, sizeof(double) * (size_t)n));
+
+  s->eta = s->o.eta_user;
+  if (!s->o.eta_direct) {
+    double normb;
+    PMH_CHK(pmh_vec_norm2(ctx, n, b, &normb));
+    s->eta *= normb;
+  }
+  s->maxeig     = s->o.maxeig;
+  s->M1_initial = s->o.M1_user;
+  if (!s->o.M1_direct) {
+    if (s->maxeig == PMH_DECIDE) PMH_CHK(pmh_op_max_eigenvalue(A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr));
+    s->M1_initial *= s->maxeig;
+  }
+  double rho;
+  if (!s->o.rho_direct) {
+    if (s->maxeig == PMH_DECIDE) PMH_CHK(pmh_op_max_eigenvalue(A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr));
+    rho = s->o.rho_user * s->maxeig;
+  } else {
+    rho = s->o.rho_user;
+  }
+  // QPTEnforceEqByPenalty(qp, rho, PETSC_TRUE) qptransform.c:329-410: A_rho = A + rho*BE'*BE
+  PMH_CHK(pmh_op_create_penalized(A, pf, rho, &s->A_inner));
+  PMH_CHK(pmh_vec_copy(ctx, n, b, s->b_inner));
+
+  // inner MPGP inherits max(rho, maxeig) when G has orthonormal rows (smalxe.c:864-868)
+  pmh_mpgp_opts io       = s->o.inner;
+  s->inner_max_it        = io.max_it;
+  const double maxeig_in = fmax(rho, s->maxeig);
+  int          inject    = s->o.inject_maxeig_set ? s->o.inject_maxeig : pf->orthonormal;
+  if (inject) io.maxeig = maxeig_in;
+  PMH_CHK(pmh_mpgp_create(ctx, s->A_inner, s->b_inner, u, lb, ub, &io, &s->inner));
+  PMH_CHK(pmh_mpgp_set_convergence_test(s->inner, inner_converged, s));
+  *out = s;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_smalxe_destroy(pmh_smalxe s)
+{
+  if (!s) return PMH_SUCCESS;
+  pmh_mpgp_destroy(s->inner);
+  pmh_op_destroy(s->A_inner);
+  pmh_free(s->ctx, s->BtBu);
+  pmh_free(s->ctx, s->Btmu);
+  pmh_free(s->ctx, s->b_inner);
+  pmh_free(s->ctx, s->xwork);
+  pmh_free(s->ctx, s->Bu);
+  delete s;
+  return PMH_SUCCESS;
+}
+
+// QPComputeObjective qp.c:913-927 on the penalised QP: f = -u'(b_inner - 1/2 A_rho u)
+static int objective(pmh_smalxe s, double *f)
+{
+  PMH_CHK(s->A_inner->mult(s->u, s->xwork));
+  PMH_CHK(pmh_vec_aypx(s->ctx, s->n, s->xwork, -0.5, s->b_inner));
+  double dot;
+  PMH_CHK(pmh_vec_dot(s->ctx, s->n, s->u, s->xwork, &dot));
+  *f = -dot;
+  return PMH_SUCCESS;
+}
+
+// QPSSMALXEUpdate_SMALXE smalxe.c:439-488 + QPSSMALXEUpdateRho_SMALXE :373-398
+static int smalxe_update(pmh_smalxe s, double Lag_old, double Lag, double rho)
+{
+  double t    = 0.5 * rho * s->normBu * s->normBu;
+  double t2   = Lag - (Lag_old + t);
+  int    flag = (t2 < s->o.update_threshold);
+  if (flag && s->o.M1_update != 1.0) {
+    if (s->inner_reason == PMH_CONVERGED_ATOL) {
+      s->M1 = s->M1 / s->o.M1_update;
+      s->M1_updates++;
+    }
+  }
+  if (s->inner_rnorm > s->enorm) return PMH_SUCCESS;
+  double rho_update = s->o.rho_update;
+  if (s->state == 3) {
+    rho_update = s->o.rho_update_late;
+    flag       = 1;
+  }
+  if (!flag || rho_update == 1.0) return PMH_SUCCESS;
+  double r;
+  PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &r));
+  PMH_CHK(pmh_op_penalized_set_penalty(s->A_inner, r * rho_update)); // MatPenalizedUpdatePenalty
+  PMH_CHK(pmh_mpgp_update_max_eigenvalue(s->inner, rho_update));
+  s->rho_updates++;
+  return PMH_SUCCESS;
+}
+
+// QPSSolve_SMALXE smalxe.c:893-997
+extern "C" int pmh_smalxe_solve(pmh_smalxe s)
+{
+  PMH_ARG(s);
+  pmh_ctx ctx = s->ctx;
+  const int n = s->n, maxits = s->o.max_it;
+  double  Lag, Lag_old, rho;
+  int     i;
+
+  s->M1 = s->M1_initial;
+  PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
+  PMH_CHK(pmh_memset(ctx, s->Btmu, 0, sizeof(double) * (size_t)n));
+  PMH_CHK(objective(s, &Lag_old));
+  PMH_CHK(update_normBu(s, s->u, &s->normBu_old, &s->enorm));
+  s->iteration       = 0;
+  s->inner_iter_accu = 0;
+  s->reason          = PMH_CONVERGED_ITERATING;
+  PMH_CHK(pmh_mpgp_reset_statistics(s->inner));
+
+  for (i = 0; i < maxits; i++) {
+    // QPSSMALXEUpdateLambda_SMALXE smalxe.c:402-435: Btmu += rho * BtB u
+    PMH_CHK(pmh_qppf_apply_GtG(s->pf, s->u, s->BtBu));
+    PMH_CHK(pmh_vec_axpy(ctx, n, s->Btmu, rho, s->BtBu));
+    if (s->reason) break;
+    PMH_CHK(pmh_vec_waxpy(ctx, n, s->b_inner, -1.0, s->Btmu, s->b)); // b_inner = b - Btmu
+    // QPSConvergedSetUp_Inner_SMALXE smalxe.c:537-557
+    PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs_outer));
+    s->gtol       = s->o.rtol * s->norm_rhs_outer;
+    s->ttol_outer = fmax(s->o.rtol * s->norm_rhs_outer, s->o.atol);
+    PMH_CHK(pmh_vec_norm2(ctx, n, s->b_inner, &s->outer_norm_rhs_div));
+    PMH_CHK(pmh_mpgp_set_tolerances(s->inner, s->o.inner.rtol, s->o.inner.atol, s->o.divtol, s->inner_max_it));
+    PMH_CHK(pmh_mpgp_solve(s->inner));
+    pmh_mpgp_stats st;
+    PMH_CHK(pmh_mpgp_get_stats(s->inner, &st));
+    s->inner_reason = st.reason;
+    s->inner_rnorm  = st.rnorm;
+    s->inner_iter_accu += st.iteration;
+    s->iteration = i + 1;
+    PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
+    PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
+    PMH_CHK(objective(s, &Lag));
+    PMH_CHK(smalxe_update(s, Lag_old, Lag, rho));
+    Lag_old       = Lag;
+    s->normBu_old = s->normBu;
+  }
+  if (i == maxits && !s->reason) s->reason = PMH_DIVERGED_ITS;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st)
+{
+  PMH_ARG(s && st);
+  memset(st, 0, sizeof(*st));
+  st->iteration = s->iteration, st->reason = s->reason, st->inner_iter_accu = s->inner_iter_accu, st->state = s->state;
+  st->M1_hits = s->M1_hits, st->eta_hits = s->eta_hits, st->M1_updates = s->M1_updates, st->rho_updates = s->rho_updates;
+  st->M1 = s->M1, st->eta = s->eta, st->normBu = s->normBu, st->enorm = s->enorm, st->rnorm = s->rnorm, st->maxeig = s->maxeig;
+  pmh_op_penalized_get_penalty(s->A_inner, &st->rho);
+  return pmh_mpgp_get_stats(s->inner, &st->inner);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// QPSSolve_PCPG src/qps/impls/pcpg/pcpg.c:51-134: r = b - A x; loop { w = P r; test ||w||; z = M^-1 w; y = P z;
+// beta; p; Ap; alpha = (y,w)/(p,Ap); x += alpha p; r -= alpha Ap }
+// --------------------------------------------------------------------------------------------------------------------
+extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_qppf pf, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st)
+{
+  PMH_ARG(ctx && A && b && x && pf && st);
+  const int n = A->n;
+  double   *p, *r, *w, *z, *yb, *Ap, *y;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&p));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&r));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&w));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&z));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&yb));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&Ap));
+  double alpha, alpha1, beta, beta1 = 0, beta2, norm_rhs, ttol;
+  int    rc = PMH_SUCCESS;
+#define PC_CHK(call) \
+  if ((rc = (call))) break;
+  st->iteration = 0;
+  st->reason    = 0;
+  do {
+    PC_CHK(pmh_vec_norm2(ctx, n, b, &norm_rhs));
+    ttol = fmax(rtol * norm_rhs, atol);
+    PC_CHK(A->mult(x, r));
+    PC_CHK(pmh_vec_aypx(ctx, n, r, -1.0, b));
+    do {
+      PC_CHK(pmh_qppf_apply_P(pf, r, w));
+      PC_CHK(pmh_vec_norm2(ctx, n, w, &st->rnorm));
+      st->reason = PMH_CONVERGED_ITERATING; // QPSConvergedDefault
+      if (st->iteration > max_it) st->reason = PMH_DIVERGED_ITS;
+      else if (std::isnan(st->rnorm) || std::isinf(st->rnorm)) st->reason = PMH_DIVERGED_NANORINF;
+      else if (st->rnorm <= ttol) st->reason = (st->rnorm < atol) ? PMH_CONVERGED_ATOL : PMH_CONVERGED_RTOL;
+      else if (st->rnorm >= divtol * norm_rhs) st->reason = PMH_DIVERGED_DTOL;
+      if (st->reason) break;
+      if (!pc) {
+        y = w;
+      } else {
+        PC_CHK(pc->mult(w, z));
+        PC_CHK(pmh_qppf_apply_P(pf, z, yb));
+        y = yb;
+      }
+      beta2 = beta1;
+      PC_CHK(pmh_vec_dot(ctx, n, y, w, &beta1));
+      if (!st->iteration) {
+        beta = 0;
+        PC_CHK(pmh_vec_copy(ctx, n, y, p));
+      } else {
+        beta = beta1 / beta2;
+        PC_CHK(pmh_vec_aypx(ctx, n, p, beta, y));
+      }
+      PC_CHK(A->mult(p, Ap));
+      PC_CHK(pmh_vec_dot(ctx, n, p, Ap, &alpha1));
+      alpha = beta1 / alpha1;
+      PC_CHK(pmh_vec_axpy(ctx, n, x, alpha, p));
+      PC_CHK(pmh_vec_axpy(ctx, n, r, -alpha, Ap));
+      st->iteration++;
+    } while (st->iteration < max_it);
+  } while (0);
+  (void)beta;
+  pmh_free(ctx, p);
+  pmh_free(ctx, r);
+  pmh_free(ctx, w);
+  pmh_free(ctx, z);
+  pmh_free(ctx, yb);
+  pmh_free(ctx, Ap);
+  return rc;
+}

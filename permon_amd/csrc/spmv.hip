@@ -20,6 +20,7 @@
 
 #define PMH_NNZ_PER_BLOCK 2048
 #define PMH_ITEMS (PMH_NNZ_PER_BLOCK / PMH_BLOCK)
+#define PMH_MAX_ROWS_PER_BLOCK 1024 // bounds the per-row phase when rows are (nearly) empty, e.g. B' of MATGLUING
 
 struct EpiArgs {
   const double *y1;
@@ -146,7 +147,7 @@ static int build_rowblocks(int nrows, const int *rowptr, std::vector<int> &rb)
   while (r < nrows) {
     int start = r;
     int base  = rowptr[r];
-    while (r < nrows && rowptr[r + 1] - base <= PMH_NNZ_PER_BLOCK) r++;
+    while (r < nrows && r - start < PMH_MAX_ROWS_PER_BLOCK && rowptr[r + 1] - base <= PMH_NNZ_PER_BLOCK) r++;
     if (r == start) r++; // single row longer than a tile
     rb.push_back(r);
   }
@@ -178,7 +179,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_val, val, sizeof(double) * (size_t)nnz));
 
   const double avg = nrows ? (double)nnz / nrows : 0.0;
-  if (avg <= 24.0) {
+  if (avg <= 24.0 || avg > 1024.0) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
     A->kind = PMH_SPMV_STREAM;
     std::vector<int> rb;
     A->n_rowblocks = build_rowblocks(nrows, rowptr, rb);
@@ -202,6 +203,7 @@ extern "C" int pmh_csr_destroy(pmh_csr A)
   if (!A) return PMH_SUCCESS;
   hipStreamSynchronize(A->ctx->stream);
   if (A->transpose) pmh_csr_destroy(A->transpose);
+  if (A->ev) pmh_csr_timing_enable(A, 0);
   hipFree(A->d_rowptr);
   hipFree(A->d_col);
   hipFree(A->d_val);
@@ -250,7 +252,56 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   return PMH_SUCCESS;
 }
 
+static int spmv_dispatch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &e);
+
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &e)
+{
+  const bool timed = A->ev && (size_t)(2 * A->ev_used + 1) < A->ev->size();
+  if (timed) PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used], A->ctx->stream));
+  int rc = spmv_dispatch(A, x, y, e);
+  if (timed) {
+    PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used + 1], A->ctx->stream));
+    (*A->ev_kind)[A->ev_used++] = e.kind;
+  }
+  return rc;
+}
+
+extern "C" int pmh_csr_timing_enable(pmh_csr A, int max_launches)
+{
+  PMH_ARG(A && max_launches >= 0);
+  PMH_HIP(hipStreamSynchronize(A->ctx->stream));
+  if (A->ev) {
+    for (hipEvent_t e : *A->ev) hipEventDestroy(e);
+    delete A->ev;
+    delete A->ev_kind;
+    A->ev = nullptr, A->ev_kind = nullptr;
+  }
+  A->ev_used = 0;
+  if (max_launches > 0) {
+    A->ev      = new std::vector<hipEvent_t>(2 * (size_t)max_launches);
+    A->ev_kind = new std::vector<int>((size_t)max_launches, -1);
+    for (auto &e : *A->ev) PMH_HIP(hipEventCreate(&e));
+  }
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_csr_timing_get(pmh_csr A, int epilogue, int *launches, double *total_ms)
+{
+  PMH_ARG(A && launches && total_ms);
+  *launches = 0, *total_ms = 0.0;
+  if (!A->ev) return PMH_SUCCESS;
+  PMH_HIP(hipStreamSynchronize(A->ctx->stream));
+  for (int i = 0; i < A->ev_used; i++) {
+    if ((*A->ev_kind)[i] != epilogue) continue;
+    float ms = 0.f;
+    PMH_HIP(hipEventElapsedTime(&ms, (*A->ev)[2 * i], (*A->ev)[2 * i + 1]));
+    *total_ms += ms;
+    (*launches)++;
+  }
+  return PMH_SUCCESS;
+}
+
+static int spmv_dispatch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &e)
 {
   EpiArgs a;
   a.y1 = e.y1;
