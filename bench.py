@@ -110,6 +110,7 @@ def main():
     # warm-up: W untimed steps
     qps.RunFixed(a.warmup)
     x.set_numpy(p["x0"])
+    pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
     A.timing_enable(2 * a.steps + 8)
     barrier()
     t1 = time.perf_counter()

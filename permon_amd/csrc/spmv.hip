@@ -18,8 +18,6 @@
 #include "pmh_internal.h"
 #include "reduce.h"
 
-#define PMH_NNZ_PER_BLOCK 2048
-#define PMH_ITEMS (PMH_NNZ_PER_BLOCK / PMH_BLOCK)
 #define PMH_MAX_ROWS_PER_BLOCK 1024 // bounds the per-row phase when rows are (nearly) empty, e.g. B' of MATGLUING
 
 struct EpiArgs {
@@ -27,27 +25,40 @@ struct EpiArgs {
   const double *g, *xx, *lb, *ub;
 };
 
-template <int EPI>
+// streamed-once operands (y, y1, g, x, lb, ub) optionally bypass the caches with non-temporal accesses
+template <bool NT>
+__device__ __forceinline__ double ldg(const double *p)
+{
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void stg(double *p, double v)
+{
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <int EPI, bool NT = false>
 __device__ __forceinline__ void epi_row(int r, double sum, const double *__restrict__ xin, double *__restrict__ y, const EpiArgs &a, double &s0, double &s1, double &m)
 {
   if (EPI == PMH_EPI_NONE) {
-    y[r] = sum;
+    stg<NT>(&y[r], sum);
   } else if (EPI == PMH_EPI_ADD) {
-    y[r] = a.y1[r] + sum;
+    stg<NT>(&y[r], ldg<NT>(&a.y1[r]) + sum);
   } else if (EPI == PMH_EPI_SUB) {
-    y[r] = sum - a.y1[r];
+    stg<NT>(&y[r], sum - ldg<NT>(&a.y1[r]));
   } else { // PMH_EPI_MPGP: Ap = A p with p'Ap, g'p and QPCFeas_Box(x,p) accumulated (mpgp.c:537-544)
-    y[r]     = sum;
+    stg<NT>(&y[r], sum);
     double p = xin[r];
     s0 += p * sum;
-    s1 += a.g[r] * p;
+    s1 += ldg<NT>(&a.g[r]) * p;
     if (p > 0. && a.lb) {
-      double l = a.lb[r];
-      if (l > -INFINITY) m = fmin(m, (a.xx[r] - l) / p);
+      double l = ldg<NT>(&a.lb[r]);
+      if (l > -INFINITY) m = fmin(m, (ldg<NT>(&a.xx[r]) - l) / p);
     }
     if (p < 0. && a.ub) {
-      double u = a.ub[r];
-      if (u < INFINITY) m = fmin(m, (a.xx[r] - u) / p);
+      double u = ldg<NT>(&a.ub[r]);
+      if (u < INFINITY) m = fmin(m, (ldg<NT>(&a.xx[r]) - u) / p);
     }
   }
 }
@@ -73,48 +84,91 @@ __device__ __forceinline__ int xcd_remap(int bid, int nlaunch)
   return (bid & 7) * chunk + (bid >> 3);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict__ rowblocks, int nrb, int nlaunch, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
+// Row-block stream kernel.  MODE 0: one row block per workgroup (grid = #row blocks, XCD-remapped).
+// MODE 1/2: persistent grid of 8*W workgroups (W <= 256 per XCD, all resident); XCD x owns the contiguous
+// slab of row blocks [x*chunk,(x+1)*chunk) and its W workgroups walk it with stride W, so one XCD works on a
+// window of W consecutive row blocks at a time (x stays in its L2) and only 8*W partials reach the finalise
+// kernel.  MODE 1 double-buffers the LDS tile (one barrier per row block, 2 tiles of LDS), MODE 2 keeps one
+// tile (two barriers).  The next row block's val/col stream is issued before the current per-row phase.
+// NT: val/col are read exactly once per SpMV -> non-temporal loads keep them from evicting x out of L2.
+template <int EPI, int NNZB, int MODE, bool NT, bool NT2>
+__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict__ rowblocks, int nrb, int chunk, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
 {
-  __shared__ double prod[PMH_NNZ_PER_BLOCK];
+  constexpr int     ITEMS = NNZB / PMH_BLOCK;
+  constexpr int     NBUF  = (MODE == 1) ? 2 : 1;
+  __shared__ double prod[NBUF][NNZB];
   __shared__ double red[PMH_BLOCK / 64];
-  const int         b = xcd_remap(blockIdx.x, nlaunch);
-  if (b >= nrb) return; // whole workgroup exits together
-  const int r0 = rowblocks[b], r1 = rowblocks[b + 1];
-  const int s0 = rowptr[r0], s1 = rowptr[r1];
-  const int tid = threadIdx.x;
-  double    acc0 = 0.0, acc1 = 0.0, amin = INFINITY;
-
-  if (s1 - s0 <= PMH_NNZ_PER_BLOCK) {
-    // coalesced stream of the block's non-zeros: all loads issued before first use
-    int    c[PMH_ITEMS];
-    double v[PMH_ITEMS];
-#pragma unroll
-    for (int j = 0; j < PMH_ITEMS; j++) {
-      const int k = s0 + tid + j * PMH_BLOCK;
-      c[j]        = (k < s1) ? col[k] : -1;
-      v[j]        = (k < s1) ? val[k] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < PMH_ITEMS; j++) {
-      const int k = tid + j * PMH_BLOCK;
-      if (c[j] >= 0) prod[k] = v[j] * x[c[j]];
-    }
-    __syncthreads();
-    for (int r = r0 + tid; r < r1; r += PMH_BLOCK) {
-      const int k0 = rowptr[r] - s0, k1 = rowptr[r + 1] - s0;
-      double    sum = 0.0;
-      for (int k = k0; k < k1; k++) sum += prod[k];
-      epi_row<EPI>(r, sum, x, y, a, acc0, acc1, amin);
-    }
+  const int         tid = threadIdx.x;
+  int               b, end, W;
+  if (MODE == 0) {
+    b   = xcd_remap(blockIdx.x, gridDim.x);
+    end = (b < nrb) ? b + 1 : b;
+    W   = 1;
   } else {
-    // a single row longer than the LDS tile: whole workgroup strides over it
-    double sum = 0.0;
-    for (int k = s0 + tid; k < s1; k += PMH_BLOCK) sum += val[k] * x[col[k]];
-    sum = pmh_block_reduce<PMH_RED_SUM>(sum, red);
-    if (tid == 0) epi_row<EPI>(r0, sum, x, y, a, acc0, acc1, amin);
+    W             = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    b             = xcd * chunk + (blockIdx.x >> 3);
+    end           = min(nrb, (xcd + 1) * chunk);
   }
-  epi_finish<EPI>(acc0, acc1, amin, red, part, ld, b);
+  double acc0 = 0.0, acc1 = 0.0, amin = INFINITY;
+  int    c[ITEMS];
+  double v[ITEMS];
+  int    r0 = 0, r1 = 0, s0 = 0, s1 = 0;
+
+  auto prefetch = [&](int bb) {
+    r0 = rowblocks[bb], r1 = rowblocks[bb + 1];
+    s0 = rowptr[r0], s1 = rowptr[r1];
+    if (s1 - s0 <= NNZB) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++) {
+        const int k = s0 + tid + j * PMH_BLOCK;
+        if (NT) {
+          c[j] = (k < s1) ? __builtin_nontemporal_load(&col[k]) : -1;
+          v[j] = (k < s1) ? __builtin_nontemporal_load(&val[k]) : 0.0;
+        } else {
+          c[j] = (k < s1) ? col[k] : -1;
+          v[j] = (k < s1) ? val[k] : 0.0;
+        }
+      }
+    }
+  };
+
+  if (b < end) prefetch(b);
+  int buf = 0;
+  while (b < end) {
+    const int cr0 = r0, cr1 = r1, cs0 = s0, cs1 = s1;
+    const int nb  = b + W;
+    if (cs1 - cs0 <= NNZB) {
+      double *pr = prod[buf];
+      if (MODE == 2) __syncthreads(); // previous row phase done before the tile is overwritten
+#pragma unroll
+      for (int j = 0; j < ITEMS; j++)
+        if (c[j] >= 0) pr[tid + j * PMH_BLOCK] = v[j] * x[c[j]];
+      if (MODE != 0 && nb < end) prefetch(nb); // next block's stream in flight during this block's row phase
+      __syncthreads();
+      for (int r = cr0 + tid; r < cr1; r += PMH_BLOCK) {
+        const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
+        double    sum = 0.0;
+        for (int k = k0; k < k1; k++) sum += pr[k];
+        epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+      }
+      if (MODE == 1) buf ^= 1;
+    } else {
+      // a single row longer than the LDS tile: the whole workgroup strides over it
+      double sum = 0.0;
+      for (int k = cs0 + tid; k < cs1; k += PMH_BLOCK) sum += val[k] * x[col[k]];
+      sum = pmh_block_reduce<PMH_RED_SUM>(sum, red);
+      if (tid == 0) epi_row<EPI>(cr0, sum, x, y, a, acc0, acc1, amin);
+      if (MODE != 0 && nb < end) prefetch(nb);
+    }
+    b = nb;
+  }
+  if (MODE == 0) {
+    const int lb_ = xcd_remap(blockIdx.x, gridDim.x);
+    if (lb_ < nrb) epi_finish<EPI>(acc0, acc1, amin, red, part, ld, lb_);
+  } else {
+    epi_finish<EPI>(acc0, acc1, amin, red, part, ld, blockIdx.x);
+  }
 }
 
 template <int EPI, int LPR>
@@ -139,7 +193,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-static int build_rowblocks(int nrows, const int *rowptr, std::vector<int> &rb)
+static int build_rowblocks(int nrows, const int *rowptr, int nnzb, std::vector<int> &rb)
 {
   rb.clear();
   rb.push_back(0);
@@ -147,7 +201,7 @@ static int build_rowblocks(int nrows, const int *rowptr, std::vector<int> &rb)
   while (r < nrows) {
     int start = r;
     int base  = rowptr[r];
-    while (r < nrows && r - start < PMH_MAX_ROWS_PER_BLOCK && rowptr[r + 1] - base <= PMH_NNZ_PER_BLOCK) r++;
+    while (r < nrows && r - start < PMH_MAX_ROWS_PER_BLOCK && rowptr[r + 1] - base <= nnzb) r++;
     if (r == start) r++; // single row longer than a tile
     rb.push_back(r);
   }
@@ -181,11 +235,23 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   const double avg = nrows ? (double)nnz / nrows : 0.0;
   if (avg <= 24.0 || avg > 1024.0) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
     A->kind = PMH_SPMV_STREAM;
+    // tuning knobs (defaults chosen from measurements on MI355X, see profiles/): PMH_SPMV_TUNE="nnzb,mode,nt"
+    A->st_nnzb = 1024, A->st_mode = 2, A->st_nt = 1;
+    if (const char *t = getenv("PMH_SPMV_TUNE")) sscanf(t, "%d,%d,%d", &A->st_nnzb, &A->st_mode, &A->st_nt);
+    if (A->st_nnzb != 512 && A->st_nnzb != 1024 && A->st_nnzb != 2048 && A->st_nnzb != 4096) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: nnzb must be 512, 1024, 2048 or 4096");
+    if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0, 1 or 2");
     std::vector<int> rb;
-    A->n_rowblocks = build_rowblocks(nrows, rowptr, rb);
+    A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb, rb);
     PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowblocks, rb.data(), sizeof(int) * rb.size()));
-    A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
+    const int chunk = (A->n_rowblocks + 7) / 8; // row blocks per XCD
+    if (A->st_mode == 0) {
+      A->n_launch_blocks = 8 * (chunk > 0 ? chunk : 1);
+    } else {
+      const int wcap     = (A->st_mode == 1 || A->st_nnzb == 4096) ? 128 : 256; // resident workgroups per XCD (LDS bound)
+      const int W        = chunk < wcap ? (chunk > 0 ? chunk : 1) : wcap;
+      A->n_launch_blocks = 8 * W;
+    }
   } else {
     A->kind          = PMH_SPMV_VECTOR;
     A->lanes_per_row = (avg <= 48.0) ? 8 : (avg <= 160.0 ? 16 : (avg <= 512.0 ? 32 : 64));
@@ -236,7 +302,27 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   const int nl  = A->n_launch_blocks;
   if (A->nrows == 0) return PMH_SUCCESS;
   if (A->kind == PMH_SPMV_STREAM) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl);
+#define ST_LAUNCH(NNZB, MODE, NT) \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, ((NT)&2) != 0>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl)
+#define ST_MODE(NNZB) \
+  switch (A->st_mode * 4 + (A->st_nt & 3)) { \
+  case 0: ST_LAUNCH(NNZB, 0, 0); break; \
+  case 1: ST_LAUNCH(NNZB, 0, 1); break; \
+  case 3: ST_LAUNCH(NNZB, 0, 3); break; \
+  case 8: ST_LAUNCH(NNZB, 2, 0); break; \
+  case 9: ST_LAUNCH(NNZB, 2, 1); break; \
+  case 11: ST_LAUNCH(NNZB, 2, 3); break; \
+  default: return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: unsupported mode/nt combination"); \
+  }
+    if (A->st_nnzb == 512) {
+      ST_MODE(512)
+    } else if (A->st_nnzb == 1024) {
+      ST_MODE(1024)
+    } else if (A->st_nnzb == 2048) {
+      ST_MODE(2048)
+    } else {
+      ST_MODE(4096)
+    }
   } else {
 #define VEC_CASE(L) \
   case L: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_vector<EPI, L>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl); break;
@@ -257,10 +343,14 @@ static int spmv_dispatch(pmh_csr A, const double *x, double *y, const pmh_spmv_e
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &e)
 {
   const bool timed = A->ev && (size_t)(2 * A->ev_used + 1) < A->ev->size();
-  if (timed) PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used], A->ctx->stream));
+  if (timed) {
+    PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used], A->ctx->stream));
+    A->ev_pending = 1;
+  }
   int rc = spmv_dispatch(A, x, y, e);
   if (timed) {
-    PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used + 1], A->ctx->stream));
+    if (A->ev_pending) PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used + 1], A->ctx->stream));
+    A->ev_pending                = 0;
     (*A->ev_kind)[A->ev_used++] = e.kind;
   }
   return rc;
@@ -315,8 +405,12 @@ static int spmv_dispatch(pmh_csr A, const double *x, double *y, const pmh_spmv_e
   case PMH_EPI_SUB: return launch<PMH_EPI_SUB>(A, x, y, a);
   case PMH_EPI_MPGP: {
     PMH_CHK(launch<PMH_EPI_MPGP>(A, x, y, a));
+    if (A->ev_pending) { // close the timing bracket before the (separately launched) finalise kernel
+      PMH_HIP(hipEventRecord((*A->ev)[2 * A->ev_used + 1], A->ctx->stream));
+      A->ev_pending = 0;
+    }
     const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
-    return pmh_finalize_partials(A->ctx, A->d_blockpart, A->n_launch_blocks, A->n_rowblocks, 3, ops, e.scal_base);
+    return pmh_finalize_partials(A->ctx, A->d_blockpart, A->n_launch_blocks, (A->kind == PMH_SPMV_STREAM && A->st_mode != 0) ? A->n_launch_blocks : A->n_rowblocks, 3, ops, e.scal_base);
   }
   }
   return pmh_set_error(PMH_ERR_ARG, "unknown SpMV epilogue %d", e.kind);

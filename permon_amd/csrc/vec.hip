@@ -20,23 +20,33 @@ struct pmh_ops8 {
 
 __global__ __launch_bounds__(PMH_BLOCK) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base)
 {
-  __shared__ double lds[PMH_BLOCK / 64];
-  for (int k = 0; k < K; k++) {
-    const double *p = partials + (size_t)k * ld;
-    double        v;
-    if (ops.op[k] == PMH_RED_SUM) {
-      v = 0.0;
-      for (int i = threadIdx.x; i < nblocks; i += PMH_BLOCK) v += p[i];
-      v = pmh_block_reduce<PMH_RED_SUM>(v, lds);
-    } else {
-      v = INFINITY;
-      for (int i = threadIdx.x; i < nblocks; i += PMH_BLOCK) v = fmin(v, p[i]);
-      v = pmh_block_reduce<PMH_RED_MIN>(v, lds);
+  __shared__ double lds[PMH_MAX_RED][PMH_BLOCK / 64];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double            v[PMH_MAX_RED];
+  // all K strided partial sums are accumulated together: their loads overlap (one latency, not K)
+#pragma unroll
+  for (int k = 0; k < PMH_MAX_RED; k++) v[k] = (ops.op[k] == PMH_RED_SUM) ? 0.0 : INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += PMH_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < PMH_MAX_RED; k++)
+      if (k < K) {
+        const double p = partials[(size_t)k * ld + i];
+        v[k]           = (ops.op[k] == PMH_RED_SUM) ? (v[k] + p) : fmin(v[k], p);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < PMH_MAX_RED; k++)
+    if (k < K) {
+      v[k] = (ops.op[k] == PMH_RED_SUM) ? pmh_wave_sum(v[k]) : pmh_wave_min(v[k]);
+      if (lane == 0) lds[k][wave] = v[k];
     }
-    if (threadIdx.x == 0) {
-      d_scal[base + k] = v;
-      h_scal[base + k] = v;
-    }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    double    r = lds[k][0];
+    for (int w = 1; w < PMH_BLOCK / 64; w++) r = (ops.op[k] == PMH_RED_SUM) ? (r + lds[k][w]) : fmin(r, lds[k][w]);
+    d_scal[base + k] = r;
+    h_scal[base + k] = r;
   }
 }
 
