@@ -42,8 +42,10 @@ def cpu_baseline(p, its):
     on a bounded sample: `its` MPGP iterations of the same workload.  Reported baseline, not the target."""
     from oracle import oracle as O
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # threads = the cores this process may actually run on (a cgroup/affinity mask can be far below cpu_count)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
     A = O.Csr(p["n"], p["n"], p["rowptr"], p["col"], p["val"])
     op = O.Op(p["n"], csr=A, omp=True)
     box = O.Box(p["n"], lb=p["lb"], ub=p["ub"])
@@ -57,7 +59,7 @@ def cpu_baseline(p, its):
         "cores": cores,
         "kind": "port",
         "sample": "%d MPGP iterations of the same %d-row workload, oracle/permon_oracle.c with OpenMP on %d threads "
-                  "(reference op order, one pass per PETSc call); SpMV alone %.1f GB/s" % (done, p["n"], cores, (12.0 * A.val.size + 20.0 * p["n"]) / t_spmv / 1e9),
+                  "(os.cpu_count()=%d; reference op order, one pass per PETSc call); SpMV alone %.1f GB/s" % (done, p["n"], cores, os.cpu_count() or 0, (12.0 * A.val.size + 20.0 * p["n"]) / t_spmv / 1e9),
     }
 
 

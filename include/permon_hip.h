@@ -221,6 +221,9 @@ int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y);
 typedef struct pmh_matinv_s *pmh_matinv;
 int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int max_it, int jacobi, pmh_matinv *Kplus);
 int pmh_matinv_destroy(pmh_matinv Kplus);
+/* MatInvSetNullSpace + Moore-Penrose wrapping P_R K^- P_R (QPTDualize -qpt_dualize_Kplus_mp, qptransform.c:1006-1062).
+   R_host: kdim (<= 8) columns of length n, column-major; rows of block b hold that block's orthonormal kernel basis */
+int pmh_matinv_set_nullspace(pmh_matinv Kplus, int kdim, const double *R_host);
 int pmh_matinv_mult(pmh_matinv Kplus, const double *f, double *u);
 int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *total_spmv);
 

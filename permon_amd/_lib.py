@@ -152,6 +152,7 @@ _PROTOS = {
     "pmh_blockdiag_mult": [vp, vp, vp],
     "pmh_matinv_create": [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_matinv_destroy": [vp],
+    "pmh_matinv_set_nullspace": [vp, C.c_int, vp],
     "pmh_matinv_mult": [vp, vp, vp],
     "pmh_matinv_last_iterations": [vp, c_int_p, C.POINTER(C.c_longlong)],
     "pmh_op_create_feti_dual": [vp, vp, C.POINTER(vp)],

@@ -1,0 +1,103 @@
+"""The QP transform chain of the (T)FETI path, host side, over device operators:
+QPTDualize -> [QPTOrthonormalizeEq] -> QPTHomogenizeEq -> QPTEnforceEqByProjector -> QPS (SMALXE / PCPG).
+Each step cites the reference function it follows (src/qp/interface/qptransform.c).  Only set-up happens
+here (a handful of operator applications); the iteration itself is pmh_smalxe_solve / pmh_pcpg_solve."""
+import numpy as np
+
+from .core import Vec
+from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatGluing, MatInv, PCDualLumpedOp
+from .qps import QP, QPS
+
+
+class FetiDualQP:
+    """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
+
+    def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True):
+        """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
+        lb: dual lower bound (-inf on equality rows, 0 on inequality rows)."""
+        self.ctx = ctx
+        nl = local["n_lambda"]
+        self.n_lambda = nl
+        self.K = MatBlockDiag.from_scipy(ctx, local["block_rowstart"], local["K"])
+        self.Kplus = MatInv(self.K, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=local["R"])
+        self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
+        # F = B K^+ B' (QPTDualize qptransform.c:1103-1128)
+        self.F = MatCreateFetiDual(self.B, self.Kplus)
+        # d = B K^+ f - c (qptransform.c:1130-1134)
+        self.f = ctx.vec_from(local["f"])
+        self.tprim = ctx.vec(local["n_x"])
+        self.d = ctx.vec(nl)
+        self.Kplus.mult(self.f, self.tprim)
+        self.B.mult_transpose(self.tprim, self.d)
+        self.d.axpy(-1.0, ctx.vec_from(c))
+        # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169)
+        self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal)
+        # QPTHomogenizeEq qptransform.c:437-527: lambda~ = G'(GG')^{-1} e; b_bar = d - F lambda~; lb <- lb - lambda~
+        self.e = ctx.vec_from(e)
+        self.lam_tilde = ctx.vec(nl)
+        self.pf.ApplyHalfQTranspose(self.e, self.lam_tilde)
+        self.b_bar = ctx.vec(nl)
+        self.F.mult(self.lam_tilde, self.b_bar)
+        self.b_bar.aypx(-1.0, self.d)
+        lt = self.lam_tilde.to_numpy()
+        self.lb_new = ctx.vec_from(np.asarray(lb) - lt)
+        # QPTEnforceEqByProjector qptransform.c:215-316: A = P F P (box present), b = P b_bar
+        self.has_box = bool(np.any(np.isfinite(lb)))
+        self.A = MatCreateProjected(self.F, self.pf, symmetric=self.has_box)
+        self.b = ctx.vec(nl)
+        self.pf.ApplyP(self.b_bar, self.b)
+        self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
+
+    def solve_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
+        """QPSSetDefaultType: BE present -> SMALXE with inner MPGP (qps.c:443-444)."""
+        qp = QP(self.ctx)
+        qp.SetOperator(self.A)
+        qp.SetRhs(self.b)
+        qp.SetInitialVector(self.lam)
+        qp.lb, qp.ub = self.lb_new, None
+        qp.SetEq(self.pf)
+        qps = QPS(self.ctx)
+        qps.SetQP(qp)
+        qps.SetType("smalxe")
+        qps.SetTolerances(rtol=rtol, max_it=max_it)
+        for k, v in smalxe.items():
+            setattr(qps.smalxe_opts, k, v)
+        for k, v in (inner or {}).items():
+            setattr(qps.smalxe_opts.inner, k, v)
+        st = qps.Solve()
+        self.qps = qps
+        return st
+
+    def solve_pcpg(self, rtol=1e-5, max_it=1000, lumped=False):
+        """Equality-only dual QP (no box): projected preconditioned CG (QPSPCPG)."""
+        qp = QP(self.ctx)
+        qp.SetOperator(self.F)
+        qp.SetRhs(self.b_bar)
+        qp.SetInitialVector(self.lam)
+        qp.SetEq(self.pf)
+        qp.pc = PCDualLumpedOp(self.B, self.K) if lumped else None
+        qps = QPS(self.ctx)
+        qps.SetQP(qp)
+        qps.SetType("pcpg")
+        qps.SetTolerances(rtol=rtol, max_it=max_it)
+        st = qps.Solve()
+        self.qps = qps
+        return st
+
+    def dual_solution(self):
+        """lambda = lambda_child + lambda~ (QPTHomogenizeEqPostSolve_Private qptransform.c:423-431)."""
+        return self.lam.to_numpy() + self.lam_tilde.to_numpy()
+
+    def primal_solution(self, G_host, e_host=None):
+        """u = K^+(f - B' lambda) - R alpha, alpha = (G G')^{-1} G (F lambda - d) (QPTDualizePostSolve, qptransform.c:783-833)."""
+        ctx = self.ctx
+        lam = ctx.vec_from(self.dual_solution())
+        t = ctx.vec(self.tprim.n)
+        self.B.mult(lam, t)  # B' lambda
+        t.aypx(-1.0, self.f)  # f - B' lambda
+        u = ctx.vec(self.tprim.n)
+        self.Kplus.mult(t, u)
+        Fl = ctx.vec(self.n_lambda)
+        self.F.mult(lam, Fl)
+        Fl.axpy(-1.0, self.d)
+        return u.to_numpy(), Fl.to_numpy()

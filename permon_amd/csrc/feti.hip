@@ -138,6 +138,10 @@ struct pmh_matinv_s {
   int          *d_nactive, *h_nactive;
   int           last_max_its;
   long long     total_spmv;
+  // Moore-Penrose variant (QPTDualize true_mp path, qptransform.c:1006-1062): K^+ := P_R K^- P_R with
+  // P_R = I - R R', R = block-wise orthonormal kernel basis stored as kdim columns of length n
+  int     kdim;
+  double *d_R, *d_coef, *d_fproj, *d_kpart;
 };
 
 #define SEG_LOOP(i, b, rs, wgs) \
@@ -281,6 +285,55 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_scalars(int phase, int wgs, in
 
 __global__ void k_publish_int(const int *d, int *h) { *h = *d; }
 
+#define PMH_MAX_KDIM 8
+// partial coefficients R_k' v per block (k < kdim)
+__global__ __launch_bounds__(PMH_BLOCK) void k_seg_rt_dot(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R, const double *__restrict__ v, double *__restrict__ part, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            acc[PMH_MAX_KDIM];
+#pragma unroll
+  for (int k = 0; k < PMH_MAX_KDIM; k++) acc[k] = 0.0;
+  SEG_LOOP(i, b, rs, wgs)
+  {
+    const double vi = v[i];
+#pragma unroll
+    for (int k = 0; k < PMH_MAX_KDIM; k++)
+      if (k < kdim) acc[k] += R[(size_t)k * n + i] * vi;
+  }
+#pragma unroll
+  for (int k = 0; k < PMH_MAX_KDIM; k++)
+    if (k < kdim) {
+      double r = pmh_block_reduce<PMH_RED_SUM>(acc[k], lds);
+      if (threadIdx.x == 0) part[(size_t)k * ld + blockIdx.x] = r;
+    }
+}
+
+// coef[b][k] = sum of block b's partials (fixed order)
+__global__ __launch_bounds__(PMH_BLOCK) void k_seg_coef(int wgs, int ld, int kdim, const double *__restrict__ part, double *__restrict__ coef)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  const int         b = blockIdx.x;
+  for (int k = 0; k < kdim; k++) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < wgs; i += PMH_BLOCK) v += part[(size_t)k * ld + b * wgs + i];
+    v = pmh_block_reduce<PMH_RED_SUM>(v, lds);
+    if (threadIdx.x == 0) coef[b * PMH_MAX_KDIM + k] = v;
+  }
+}
+
+// out = v - R coef  (block-wise)
+__global__ __launch_bounds__(PMH_BLOCK) void k_seg_project(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R, const double *__restrict__ coef, const double *__restrict__ v, double *__restrict__ out)
+{
+  SEG_LOOP(i, b, rs, wgs)
+  {
+    double s = v[i];
+#pragma unroll
+    for (int k = 0; k < PMH_MAX_KDIM; k++)
+      if (k < kdim) s -= coef[b * PMH_MAX_KDIM + k] * R[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+
 extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int max_it, int jacobi, pmh_matinv *out)
 {
   PMH_ARG(K && out && max_it > 0);
@@ -291,6 +344,8 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   M->wgs          = std::max(1, std::min(256, PMH_MAX_VEC_BLOCKS / K->nblocks));
   M->last_max_its = 0;
   M->total_spmv   = 0;
+  M->kdim         = 0;
+  M->d_R = M->d_coef = M->d_fproj = M->d_kpart = nullptr;
   const size_t nb = sizeof(double) * (size_t)(M->n ? M->n : 1);
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->dinv));
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->r));
@@ -310,10 +365,44 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   return PMH_SUCCESS;
 }
 
+// R: host array, kdim columns of length n (column-major); the rows of block b hold that block's orthonormal
+// kernel basis (zero columns for a block without kernel).  Mirrors MatInvSetNullSpace + the Moore-Penrose
+// wrapping of QPTDualize (-qpt_dualize_Kplus_mp, qptransform.c:1006-1062).
+extern "C" int pmh_matinv_set_nullspace(pmh_matinv M, int kdim, const double *R_host)
+{
+  PMH_ARG(M && kdim >= 0 && kdim <= PMH_MAX_KDIM && (kdim == 0 || R_host));
+  pmh_ctx ctx = M->ctx;
+  if (M->d_R) pmh_free(ctx, M->d_R), M->d_R = nullptr;
+  M->kdim = kdim;
+  if (!kdim) return PMH_SUCCESS;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)kdim * M->n, (void **)&M->d_R));
+  PMH_CHK(pmh_memcpy_h2d(ctx, M->d_R, R_host, sizeof(double) * (size_t)kdim * M->n));
+  if (!M->d_coef) PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)M->nblocks * PMH_MAX_KDIM, (void **)&M->d_coef));
+  if (!M->d_fproj) PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)M->n, (void **)&M->d_fproj));
+  if (!M->d_kpart) PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)PMH_MAX_KDIM * M->nblocks * M->wgs, (void **)&M->d_kpart));
+  return PMH_SUCCESS;
+}
+
+// v_out = (I - R R') v, block-wise
+static int matinv_project(pmh_matinv M, const double *v, double *out)
+{
+  const int nb = M->nblocks, wgs = M->wgs, grid = nb * wgs, ld = nb * wgs;
+  double *part = M->d_kpart;
+  hipLaunchKernelGGL(k_seg_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, M->ctx->stream, (const int *)M->K->d_rowstart, wgs, M->n, M->kdim, (const double *)M->d_R, v, part, ld);
+  hipLaunchKernelGGL(k_seg_coef, dim3(nb), dim3(PMH_BLOCK), 0, M->ctx->stream, wgs, ld, M->kdim, (const double *)part, M->d_coef);
+  hipLaunchKernelGGL(k_seg_project, dim3(grid), dim3(PMH_BLOCK), 0, M->ctx->stream, (const int *)M->K->d_rowstart, wgs, M->n, M->kdim, (const double *)M->d_R, (const double *)M->d_coef, v, out);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_matinv_destroy(pmh_matinv M)
 {
   if (!M) return PMH_SUCCESS;
   pmh_ctx ctx = M->ctx;
+  if (M->d_R) pmh_free(ctx, M->d_R);
+  if (M->d_coef) pmh_free(ctx, M->d_coef);
+  if (M->d_fproj) pmh_free(ctx, M->d_fproj);
+  if (M->d_kpart) pmh_free(ctx, M->d_kpart);
   pmh_free(ctx, M->dinv);
   pmh_free(ctx, M->r);
   pmh_free(ctx, M->z);
@@ -337,6 +426,10 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   const int *rs  = M->K->d_rowstart;
   hipStream_t st = ctx->stream;
   if (M->n == 0) return PMH_SUCCESS;
+  if (M->kdim) { // f <- P_R f
+    PMH_CHK(matinv_project(M, f, M->d_fproj));
+    f = M->d_fproj;
+  }
   PMH_HIP(hipMemsetAsync(M->d_nactive, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
   hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 0, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, 0, M->max_it);
@@ -365,6 +458,10 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   int mx = 0;
   for (int b = 0; b < nb; b++) mx = std::max(mx, bi[(size_t)b * BI_NSLOT + BI_ITS]);
   M->last_max_its = mx;
+  if (M->kdim) { // u <- P_R u (in place through the scratch vector)
+    PMH_CHK(matinv_project(M, u, M->d_fproj));
+    PMH_CHK(pmh_memcpy_d2d(ctx, u, M->d_fproj, sizeof(double) * (size_t)M->n));
+  }
   return PMH_SUCCESS;
 }
 

@@ -18,15 +18,16 @@ struct pmh_ops8 {
   int op[PMH_MAX_RED];
 };
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base)
+#define PMH_FIN_THREADS 1024
+__global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base)
 {
-  __shared__ double lds[PMH_MAX_RED][PMH_BLOCK / 64];
+  __shared__ double lds[PMH_MAX_RED][PMH_FIN_THREADS / 64];
   const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double            v[PMH_MAX_RED];
   // all K strided partial sums are accumulated together: their loads overlap (one latency, not K)
 #pragma unroll
   for (int k = 0; k < PMH_MAX_RED; k++) v[k] = (ops.op[k] == PMH_RED_SUM) ? 0.0 : INFINITY;
-  for (int i = threadIdx.x; i < nblocks; i += PMH_BLOCK) {
+  for (int i = threadIdx.x; i < nblocks; i += PMH_FIN_THREADS) {
 #pragma unroll
     for (int k = 0; k < PMH_MAX_RED; k++)
       if (k < K) {
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_finalize(const double *__restrict
   if (threadIdx.x < K) {
     const int k = threadIdx.x;
     double    r = lds[k][0];
-    for (int w = 1; w < PMH_BLOCK / 64; w++) r = (ops.op[k] == PMH_RED_SUM) ? (r + lds[k][w]) : fmin(r, lds[k][w]);
+    for (int w = 1; w < PMH_FIN_THREADS / 64; w++) r = (ops.op[k] == PMH_RED_SUM) ? (r + lds[k][w]) : fmin(r, lds[k][w]);
     d_scal[base + k] = r;
     h_scal[base + k] = r;
   }
@@ -54,7 +55,7 @@ int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nbloc
 {
   pmh_ops8 o;
   for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_BLOCK), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base);
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }

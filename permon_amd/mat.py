@@ -1,0 +1,163 @@
+"""Mat implementations of the FETI path over the C ABI: MATGLUING, MATBLOCKDIAG, MATINV, QPPF and the shell
+operators of the QP transform chain (names follow include/permonmat.h / permonqppf.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check
+from .core import CsrMat, Op, Vec
+
+
+class MatGluing:
+    """MatCreateGluing (src/mat/impls/gluing/gluing.c:216-258): leaves = (local primal dof, lambda index, sign)."""
+
+    def __init__(self, ctx, n_x, n_lambda, leaves_row, leaves_root, leaves_sign):
+        lr = np.ascontiguousarray(leaves_row, dtype=np.int32)
+        lo = np.ascontiguousarray(leaves_root, dtype=np.int32)
+        ls = np.ascontiguousarray(leaves_sign, dtype=np.float64)
+        assert lr.size == lo.size == ls.size
+        self.ctx, self.n_x, self.n_lambda = ctx, int(n_x), int(n_lambda)
+        h = C.c_void_p()
+        check(ctx.L.pmh_gluing_create(ctx.h, self.n_x, self.n_lambda, lr.size, lr.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p),
+                                      ls.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    def mult(self, lam, x):  # MatMult_Gluing: x = B' lambda
+        check(self.ctx.L.pmh_gluing_mult(self.h, lam.p, x.p))
+
+    def mult_transpose(self, x, lam):  # MatMultTranspose_Gluing: lambda = B x (+ all-reduce across GPUs)
+        check(self.ctx.L.pmh_gluing_mult_transpose(self.h, x.p, lam.p))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_gluing_destroy(self.h)
+            self.h = None
+
+
+class MatBlockDiag:
+    """MatCreateBlockDiag (src/mat/impls/blockdiag/matblockdiag.c:777-854): this rank's subdomain blocks as
+    one concatenated CSR + block row offsets."""
+
+    def __init__(self, ctx, block_rowstart, Kcat):
+        rs = np.ascontiguousarray(block_rowstart, dtype=np.int32)
+        self.ctx, self.K, self.nblocks, self.n = ctx, Kcat, rs.size - 1, Kcat.nrows
+        h = C.c_void_p()
+        check(ctx.L.pmh_blockdiag_create(ctx.h, self.nblocks, rs.ctypes.data_as(C.c_void_p), Kcat.h, C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_scipy(cls, ctx, block_rowstart, K):
+        K = K.tocsr()
+        K.sort_indices()
+        return cls(ctx, block_rowstart, CsrMat(ctx, K.shape[0], K.shape[1], K.indptr, K.indices, K.data))
+
+    def mult(self, x, y):  # MatMult_BlockDiag
+        check(self.ctx.L.pmh_blockdiag_mult(self.h, x.p, y.p))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_blockdiag_destroy(self.h)
+            self.h = None
+
+
+class MatInv:
+    """MATINV apply (src/mat/impls/inv/matinv.c:734-743) on the iterative per-block KSPCG path."""
+
+    def __init__(self, K, rtol=1e-10, atol=1e-50, max_it=10000, jacobi=True, nullspace=None):
+        self.ctx, self.K = K.ctx, K
+        h = C.c_void_p()
+        check(self.ctx.L.pmh_matinv_create(K.h, float(rtol), float(atol), int(max_it), int(bool(jacobi)), C.byref(h)))
+        self.h = h
+        if nullspace is not None:
+            self.set_nullspace(nullspace)
+
+    def set_nullspace(self, R):
+        """R: array (kdim, n) whose rows restricted to a block are that block's orthonormal kernel basis
+        (MatInvSetNullSpace + the Moore-Penrose wrapping of QPTDualize)."""
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        assert R.ndim == 2 and R.shape[1] == self.K.n
+        check(self.ctx.L.pmh_matinv_set_nullspace(self.h, R.shape[0], R.ctypes.data_as(C.c_void_p)))
+
+    def mult(self, f, u):  # MatMult_Inv
+        check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
+
+    def last_iterations(self):
+        its, tot = C.c_int(), C.c_longlong()
+        check(self.ctx.L.pmh_matinv_last_iterations(self.h, C.byref(its), C.byref(tot)))
+        return its.value, tot.value
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_matinv_destroy(self.h)
+            self.h = None
+
+
+class QPPF:
+    """Projector factory on G (src/qppf/interface/qppf.c): Q = G'(GG')^{-1}G, P = I - Q."""
+
+    def __init__(self, ctx, G, orthonormal=False):
+        self.ctx, self.G, self.orthonormal = ctx, G, bool(orthonormal)
+        self.m, self.n = G.nrows, G.ncols
+        h = C.c_void_p()
+        check(ctx.L.pmh_qppf_create(ctx.h, G.h, int(self.orthonormal), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_scipy(cls, ctx, G, orthonormal=False):
+        G = G.tocsr()
+        G.sort_indices()
+        return cls(ctx, CsrMat(ctx, G.shape[0], G.shape[1], G.indptr, G.indices, G.data), orthonormal)
+
+    def ApplyQ(self, v, Qv):
+        check(self.ctx.L.pmh_qppf_apply_Q(self.h, v.p, Qv.p))
+
+    def ApplyP(self, v, Pv):
+        check(self.ctx.L.pmh_qppf_apply_P(self.h, v.p, Pv.p))
+
+    def ApplyGtG(self, v, y):
+        check(self.ctx.L.pmh_qppf_apply_GtG(self.h, v.p, y.p))
+
+    def ApplyCP(self, x, y):
+        check(self.ctx.L.pmh_qppf_apply_CP(self.h, x.p, y.p))
+
+    def ApplyG(self, v, Gv):
+        check(self.ctx.L.pmh_qppf_apply_G(self.h, v.p, Gv.p))
+
+    def ApplyHalfQ(self, x, y):
+        check(self.ctx.L.pmh_qppf_apply_halfQ(self.h, x.p, y.p))
+
+    def ApplyHalfQTranspose(self, x, y):
+        check(self.ctx.L.pmh_qppf_apply_halfQ_transpose(self.h, x.p, y.p))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_qppf_destroy(self.h)
+            self.h = None
+
+
+def MatCreatePenalized(A, pf, rho):  # src/qp/utils/matpenalized.c:212-243
+    h = C.c_void_p()
+    check(A.ctx.L.pmh_op_create_penalized(A.h, pf.h, float(rho), C.byref(h)))
+    return Op(A.ctx, h, A.n, keep=[A, pf])
+
+
+def MatCreateProjected(A, pf, symmetric=True):  # P*A*P / P*A, qptransform.c:273-284
+    h = C.c_void_p()
+    check(A.ctx.L.pmh_op_create_projected(A.h, pf.h, int(bool(symmetric)), C.byref(h)))
+    return Op(A.ctx, h, A.n, keep=[A, pf])
+
+
+def MatCreateFetiDual(B, Kplus):  # F = B K^+ B', qptransform.c:1103-1128
+    h = C.c_void_p()
+    check(B.ctx.L.pmh_op_create_feti_dual(B.h, Kplus.h, C.byref(h)))
+    return Op(B.ctx, h, B.n_lambda, keep=[B, Kplus])
+
+
+def PCDualLumpedOp(B, K):
+    """PCDUAL lumped (src/pc/impls/dual/pcdual.c:63-78) as an operator y = B K B' x."""
+    ctx = B.ctx
+
+    def fn(xp, yp):
+        check(ctx.L.pmh_pc_dual_lumped_apply(B.h, K.h, xp, yp))
+
+    return Op.shell(ctx, B.n_lambda, fn)

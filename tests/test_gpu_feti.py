@@ -1,0 +1,212 @@
+"""GPU parity tests of the FETI side of the path (MATGLUING, QPPF, MATINV, F, SMALXE, PCPG) against the CPU oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import permon_amd as pa
+from permon_amd import problems as P
+from permon_amd.chain import FetiDualQP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def test_gluing_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(11)
+    n_x, n_l, nleaf = 5000, 1300, 4000
+    rows = rng.integers(0, n_x, nleaf).astype(np.int32)
+    roots = rng.integers(0, n_l, nleaf).astype(np.int32)
+    signs = rng.choice([-1.0, 1.0, 1 / np.sqrt(2), -1 / np.sqrt(3)], nleaf)
+    Bd = pa.MatGluing(ctx, n_x, n_l, rows, roots, signs)
+    Bo = oracle.Gluing(n_x, n_l, rows, roots, signs)
+    lam, x = rng.standard_normal(n_l), rng.standard_normal(n_x)
+    xd, ld = ctx.vec(n_x), ctx.vec(n_l)
+    Bd.mult(ctx.vec_from(lam), xd)
+    assert np.array_equal(xd.to_numpy(), Bo.mult(lam))
+    Bd.mult_transpose(ctx.vec_from(x), ld)
+    assert np.array_equal(ld.to_numpy(), Bo.mult_transpose(x))
+
+
+@pytest.mark.parametrize("orth", [False, True])
+def test_qppf_vs_oracle(ctx, oracle, orth):
+    f = pa.CubeFeti((2, 2, 1), 2)
+    G, e = f.coarse(orthonormalize=orth)
+    pf = pa.QPPF.from_scipy(ctx, G, orthonormal=orth)
+    pfo = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=orth)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(f.n_lambda)
+    vd, yd = ctx.vec_from(v), ctx.vec(f.n_lambda)
+    pf.ApplyQ(vd, yd)
+    q_ref = pfo.Q(v)
+    assert np.max(np.abs(yd.to_numpy() - q_ref)) <= 1e-12 * np.max(np.abs(q_ref))
+    pf.ApplyP(vd, yd)
+    assert np.max(np.abs(yd.to_numpy() - pfo.P(v))) <= 1e-12 * np.max(np.abs(v))
+    # P is a projector onto null(G)
+    gd = ctx.vec(G.shape[0])
+    pf.ApplyG(yd, gd)
+    assert np.max(np.abs(gd.to_numpy())) <= 1e-12
+    ed = ctx.vec_from(e)
+    pf.ApplyHalfQTranspose(ed, yd)
+    assert np.max(np.abs(yd.to_numpy() - pfo.half_Q_transpose(e))) <= 1e-12 * max(1.0, np.max(np.abs(e)))
+
+
+def _dense_ops(f):
+    Kd = f.K.toarray()
+    Kp = np.linalg.pinv(Kd, rcond=1e-12, hermitian=True)
+    Bd = f.B.toarray()
+    return Kp, Bd, Bd @ Kp @ Bd.T
+
+
+@pytest.mark.parametrize("physics", ["poisson", "elasticity"])
+def test_matinv_block_cg_is_pseudoinverse(ctx, physics):
+    f = pa.CubeFeti((2, 1, 1), 2, physics=physics)
+    Kp, _, _ = _dense_ops(f)
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
+    Kplus = pa.MatInv(K, rtol=1e-13, nullspace=f.R)
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(f.N)
+    u = ctx.vec(f.N)
+    Kplus.mult(ctx.vec_from(rhs), u)
+    ref = Kp @ rhs
+    assert np.linalg.norm(u.to_numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+    its, total = Kplus.last_iterations()
+    assert 0 < its < 500 and total >= its
+    y = ctx.vec(f.N)
+    K.mult(u, y)  # MatMult_BlockDiag
+    assert np.linalg.norm(y.to_numpy() - f.K @ u.to_numpy()) <= 1e-12 * np.linalg.norm(rhs)
+
+
+def test_feti_dual_operator_and_lumped_pc(ctx):
+    f = pa.CubeFeti((2, 2, 1), 2)
+    Kp, Bd, Fd = _dense_ops(f)
+    loc = f.subset(range(f.nsub))
+    K = pa.MatBlockDiag.from_scipy(ctx, loc["block_rowstart"], loc["K"])
+    Kplus = pa.MatInv(K, rtol=1e-13, nullspace=loc["R"])
+    B = pa.MatGluing(ctx, loc["n_x"], loc["n_lambda"], loc["leaves_row"], loc["leaves_root"], loc["leaves_sign"])
+    F = pa.MatCreateFetiDual(B, Kplus)
+    rng = np.random.default_rng(9)
+    lam = rng.standard_normal(f.n_lambda)
+    y = ctx.vec(f.n_lambda)
+    F.mult(ctx.vec_from(lam), y)
+    ref = Fd @ lam
+    assert np.linalg.norm(y.to_numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+    pc = pa.PCDualLumpedOp(B, K)
+    pc.mult(ctx.vec_from(lam), y)
+    ref = Bd @ (f.K @ (Bd.T @ lam))
+    assert np.linalg.norm(y.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+def _oracle_dual(oracle, f, G, e, orth):
+    """The same chain on the CPU with a dense Moore-Penrose K^+ (oracle side of the parity test)."""
+    Kp, Bd, Fd = _dense_ops(f)
+    pfo = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=orth)
+    d = Bd @ (Kp @ f.f) - f.c
+    lam_t = pfo.half_Q_transpose(e)
+    b_bar = d - Fd @ lam_t
+    lb_new = f.lb - lam_t
+    return Fd, pfo, d, lam_t, b_bar, lb_new
+
+
+def test_smalxe_contact_tfeti_vs_oracle(ctx, oracle):
+    f = pa.CubeFeti((2, 2, 2), 2, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    Fd, pfo, d, lam_t, b_bar, lb_new = _oracle_dual(oracle, f, G, e, True)
+    n = f.n_lambda
+    A_or = oracle.Op(n, fn=lambda x: pfo.P(Fd @ pfo.P(x)))
+    ref = oracle.smalxe(A_or, pfo.P(b_bar), np.zeros(n), oracle.Box(n, lb=lb_new), pfo)
+    assert ref["reason"] > 0
+
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-13)
+    assert np.linalg.norm(q.d.to_numpy() - d) <= 1e-9 * np.linalg.norm(d)
+    assert np.linalg.norm(q.b.to_numpy() - pfo.P(b_bar)) <= 1e-9 * np.linalg.norm(b_bar)
+    st = q.solve_smalxe()
+    assert st.reason == ref["reason"]
+    assert st.iteration == ref["iteration"]
+    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(2, ref["inner_iter_accu"] // 50)
+    lam_child = q.lam.to_numpy()
+    assert np.linalg.norm(lam_child - ref["u"]) <= 1e-4 * np.linalg.norm(ref["u"])
+    # KKT of the dual problem: feasibility of the multipliers and of the primal solution
+    lam = q.dual_solution()
+    assert np.all(lam[f.n_eq:] >= -1e-10)
+    u, _ = q.primal_solution(G)
+    Ru = f.kernel_matrix()
+    alpha = np.linalg.lstsq((f.B @ Ru).toarray(), f.B @ u - np.where(np.arange(n) < f.n_eq, f.c, np.minimum(f.c, f.B @ u)), rcond=None)[0]
+    uu = u - Ru @ alpha
+    assert np.max(np.abs((f.B @ uu)[:f.n_eq] - f.c[:f.n_eq])) <= 1e-4
+    assert np.max((f.B @ uu)[f.n_eq:] - f.c[f.n_eq:]) <= 1e-4
+
+
+def test_pcpg_linear_tfeti_vs_oracle(ctx, oracle):
+    f = pa.CubeFeti((2, 2, 1), 2, contact=False)
+    G, e = f.coarse(orthonormalize=False)
+    Fd, pfo, d, lam_t, b_bar, lb_new = _oracle_dual(oracle, f, G, e, False)
+    n = f.n_lambda
+    ref = oracle.pcpg(oracle.Op(n, fn=lambda x: Fd @ x), b_bar, np.zeros(n), pfo, rtol=1e-8)
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=False, kplus_rtol=1e-13)
+    st = q.solve_pcpg(rtol=1e-8)
+    assert (st.reason, st.iteration) == (ref["reason"], ref["iteration"])
+    assert np.linalg.norm(q.lam.to_numpy() - ref["x"]) <= 1e-6 * np.linalg.norm(ref["x"])
+    # lumped preconditioner: fewer iterations, same solution (feti/output/ex71_2_*: 66 -> 26 its)
+    Bd = f.B.toarray()
+    refl = oracle.pcpg(oracle.Op(n, fn=lambda x: Fd @ x), b_bar, np.zeros(n), pfo, rtol=1e-8, pc=lambda w: Bd @ (f.K @ (Bd.T @ w)))
+    q2 = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=False, kplus_rtol=1e-13)
+    st2 = q2.solve_pcpg(rtol=1e-8, lumped=True)
+    assert (st2.reason, st2.iteration) == (refl["reason"], refl["iteration"])
+    assert st2.iteration < st.iteration
+    assert np.linalg.norm(q2.lam.to_numpy() - refl["x"]) <= 1e-6 * np.linalg.norm(refl["x"])
+
+
+def _ex3_dual_dense(n):
+    p = P.ex3_primal(n)
+    K = sp.csr_matrix((p["val"], p["col"], p["rowptr"]), shape=(n, n)).toarray()
+    Lc = np.linalg.cholesky(K)
+    Kinv = np.linalg.solve(Lc.T, np.linalg.solve(Lc, np.eye(n)))
+    B = np.diag(p["BI_diag"])
+    return B @ Kinv @ B.T, B @ (Kinv @ p["b"]) - p["cI"]
+
+
+def _dense_csr(ctx, F):
+    Fs = sp.csr_matrix(F)
+    Fs.sort_indices()
+    return pa.CsrMat(ctx, F.shape[0], F.shape[1], Fs.indptr, Fs.indices, Fs.data)
+
+
+def test_ex3_goldens_on_gpu(ctx, goldens):
+    """Reference goldens ex3_1.out (dualised MPGP) and ex3_nullspace.out (SMALXE with a 0-row BE) through the C ABI."""
+    n = 100
+    F, d = _ex3_dual_dense(n)
+    op = pa.Op.from_csr(_dense_csr(ctx, F))
+    g = goldens["ex3_1"]["solves"][0]
+    qp = pa.QP(ctx)
+    qp.SetOperator(op)
+    qp.SetRhs(ctx.vec_from(d))
+    qp.SetInitialVector(ctx.vec(n))
+    qp.SetBox(None, ctx.vec(n), None)
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    st = qps.Solve()
+    assert (st.iteration, st.nmv, st.ncg, st.nexp, st.nprop, st.reason) == (g["iterations"], g["nmv"], g["ncg"], g["nexp"], g["nprop"], g["reason"])
+
+    outer, inner = goldens["ex3_nullspace"]["solves"]
+    G0 = pa.CsrMat(ctx, 0, n, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    qp2 = pa.QP(ctx)
+    qp2.SetOperator(op)
+    qp2.SetRhs(ctx.vec_from(d))
+    qp2.SetInitialVector(ctx.vec(n))
+    qp2.SetBox(None, ctx.vec(n), None)
+    qp2.SetEq(pa.QPPF(ctx, G0, orthonormal=True))
+    qps2 = pa.QPS(ctx)
+    qps2.SetQP(qp2)
+    qps2.SetDefaultType()  # BE present -> SMALXE (qps.c:443-444)
+    assert qps2.type == "smalxe"
+    s2 = qps2.Solve()
+    assert (s2.iteration, s2.reason, s2.inner_iter_accu) == (outer["iterations"], outer["reason"], outer["inner_iterations"])
+    i2 = s2.inner
+    assert (i2.reason, i2.nmv, i2.ncg, i2.nexp, i2.nprop) == (inner["reason"], inner["nmv"], inner["ncg"], inner["nexp"], inner["nprop"])
