@@ -44,6 +44,12 @@ def cpu_baseline(p, its):
 
     # threads = the cores this process may actually run on (a cgroup/affinity mask can be far below cpu_count)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota (the GPU box: cpu.max = 1600000 100000 -> 16 CPUs of a 2 x 64-core EPYC 9575F)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     A = O.Csr(p["n"], p["n"], p["rowptr"], p["col"], p["val"])

@@ -62,6 +62,9 @@ struct pmh_mpgp_s {
   std::vector<double> t_gp, t_gf, t_gc, t_alpha;
   // throughput mode
   int fixed_iters;
+  // speculative device-side CG chain
+  int    *d_ctl, *h_ctl;
+  double *d_ring, *h_ring;
 };
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -125,15 +128,49 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_split_setp(long long n, const dou
   write_partials<4>(acc, lds, partials, ld);
 }
 
+// device control words of the speculative CG chain
+enum { CTL_HALT = 0, CTL_ITER, CTL_NCG, CTL_BASE, CTL_NWORDS };
+
+struct pmh_spec_args { // constants of one solve, passed by value
+  int    *ctl;   // device: [halt, iteration, ncg, base]
+  double *ring;  // device: per device-side iteration (|gP|^2, |gf|^2, |gc|^2) for the monitor trace
+  int     ring_cap;
+  int     max_it, fixed_iters;
+  double  ttol, divtol_rhs, gamma2;
+};
+
 // P2: CG / proportioning update.  acg = (g'p)/(p'Ap) from device scalars (mpgp.c:541-543, :628-630);
 // x -= acg p; g -= acg Ap (:553-554 / :633-634); split (:555 / :635); Ap'gf for beta (:558); norms.
-template <bool SETP>
-__global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const double *__restrict__ scal, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld)
+// SPEC: the kernel first evaluates, from the device scalars alone, everything the host loop would check
+// at the top of this iteration -- QPSConvergedDefault (qps.c:688-712), proportionality (mpgp.c:535) and
+// acg <= afeas (mpgp.c:547).  If this is a plain CG step it is taken without any host round trip; otherwise
+// the chain halts with the state untouched and the host driver takes this iteration.
+template <bool SETP, bool SPEC>
+__global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const double *__restrict__ scal, pmh_spec_args sa, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld)
 {
   __shared__ double lds[PMH_BLOCK / 64];
   double            acg = scal[S_GP] / scal[S_PAP];
-  const double      ma  = -acg;
-  double            acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (SPEC) {
+    if (sa.ctl[CTL_HALT]) return;
+    const int    it  = sa.ctl[CTL_ITER];
+    const double gP2 = scal[S_GP2], gc2 = scal[S_GC2], gf2 = scal[S_GF2], rnorm = sqrt(gP2);
+    bool         go;
+    if (sa.fixed_iters >= 0) go = it < sa.fixed_iters;
+    else go = (it <= sa.max_it) && (rnorm > sa.ttol) && (rnorm < sa.divtol_rhs); // NaN fails every comparison -> halt
+    go = go && (gc2 <= sa.gamma2 * gf2) && (acg <= scal[S_FEAS]) && (it - sa.ctl[CTL_BASE] < sa.ring_cap);
+    if (!go) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) sa.ctl[CTL_HALT] = 1; // every workgroup reaches the same verdict
+      return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int k        = it - sa.ctl[CTL_BASE];
+      sa.ring[3 * k]     = gP2;
+      sa.ring[3 * k + 1] = gf2;
+      sa.ring[3 * k + 2] = gc2;
+    }
+  }
+  const double ma     = -acg;
+  double       acc[4] = {0.0, 0.0, 0.0, 0.0};
   GRID_STRIDE(i, n)
   {
     double api = Ap[i];
@@ -155,8 +192,9 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const do
 }
 
 // P3: p = gf - bcg p, bcg = (Ap'gf)/(p'Ap) (mpgp.c:558-560: VecAYPX(p,-bcg,gf))
-__global__ __launch_bounds__(PMH_BLOCK) void k_dir_update(long long n, const double *__restrict__ scal, const double *__restrict__ gf, double *__restrict__ p)
+__global__ __launch_bounds__(PMH_BLOCK) void k_dir_update(long long n, const double *__restrict__ scal, const int *__restrict__ halt, const double *__restrict__ gf, double *__restrict__ p)
 {
+  if (halt && *halt) return;
   double       bcg = scal[S_APGF] / scal[S_PAP];
   const double mb  = -bcg;
   GRID_STRIDE(i, n) p[i] = gf[i] + mb * p[i];
@@ -319,6 +357,8 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->step           = ' ';
   s->fixed_iters    = -1;
   s->fallback_state = s->o.fallback;
+  s->d_ctl = s->h_ctl = nullptr;
+  s->d_ring = s->h_ring = nullptr;
   if (s->o.bchop_tol) { // mpgp.c:379-382: VecFilter on the user's bound vectors, in place as in the reference
     if (lb) LAUNCH(k_filter, (double *)lb, s->o.bchop_tol);
     if (ub) LAUNCH(k_filter, (double *)ub, s->o.bchop_tol);
@@ -349,6 +389,10 @@ extern "C" int pmh_mpgp_destroy(pmh_mpgp s)
   if (!s) return PMH_SUCCESS;
   for (int i = 0; i < 10; i++)
     if (s->work[i]) pmh_free(s->ctx, s->work[i]);
+  if (s->d_ctl) pmh_free(s->ctx, s->d_ctl);
+  if (s->d_ring) pmh_free(s->ctx, s->d_ring);
+  if (s->h_ctl) hipHostFree(s->h_ctl);
+  if (s->h_ring) hipHostFree(s->h_ring);
   delete s;
   return PMH_SUCCESS;
 }
@@ -450,10 +494,10 @@ static int test_convergence(pmh_mpgp s)
   return PMH_SUCCESS;
 }
 
-static int finalize_vec4(pmh_mpgp s)
+static int finalize_vec4(pmh_mpgp s, const int *halt = nullptr, int *post = nullptr)
 {
   const int ops[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
-  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 4, ops, S_APGF);
+  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 4, ops, S_APGF, halt, post);
 }
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -678,7 +722,7 @@ static int solve_unfused(pmh_mpgp s)
 // fused driver (std expansion, fixed step length, no fallback)
 // --------------------------------------------------------------------------------------------------------------------
 // P1: Ap = A p and the three reductions into d_scal/h_scal[S_PAP..S_FEAS]
-static int f_apply_p1(pmh_mpgp s)
+static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr)
 {
   double *g = s->work[3], *p = s->work[4], *Ap = s->work[5];
   if (s->csr) {
@@ -690,8 +734,10 @@ static int f_apply_p1(pmh_mpgp s)
     e.lb        = s->lb;
     e.ub        = s->ub;
     e.scal_base = S_PAP;
+    e.halt      = halt;
     return pmh_csr_spmv_launch(s->csr, p, Ap, e);
   }
+  if (halt) return pmh_set_error(PMH_ERR_STATE, "speculative chain needs a CSR operator");
   PMH_CHK(s->A->mult(p, Ap));
   const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
   LAUNCH(k_p1_dots, (const double *)p, (const double *)Ap, (const double *)g, (const double *)s->x, s->lb, s->ub, s->ctx->d_partials, s->ctx->partials_cap);
@@ -733,7 +779,62 @@ static int solve_fused(pmh_mpgp s)
   PMH_CHK(finalize_vec4(s));
   s->step      = ' ';
   s->iteration = 0;
+  pmh_spec_args nosa;
+  memset(&nosa, 0, sizeof(nosa));
+  auto k_cg_spec = k_step_update<false, true>;
+  auto k_cg_host = k_step_update<false, false>;
+  auto k_prop_host = k_step_update<true, false>;
+  // the device-side CG chain needs the default convergence test (its constants go to the kernels) and a CSR operator
+  const int SPEC_BATCH = 16;
+  bool      can_spec   = s->csr && !s->cvg && !getenv("PMH_MPGP_NO_SPEC");
+  pmh_spec_args sa     = nosa;
+  if (can_spec) {
+    if (!s->d_ctl) {
+      PMH_CHK(pmh_malloc(ctx, sizeof(int) * CTL_NWORDS, (void **)&s->d_ctl));
+      PMH_CHK(pmh_malloc(ctx, sizeof(double) * 3 * SPEC_BATCH, (void **)&s->d_ring));
+      PMH_HIP(hipHostMalloc((void **)&s->h_ctl, sizeof(int) * CTL_NWORDS, hipHostMallocMapped));
+      PMH_HIP(hipHostMalloc((void **)&s->h_ring, sizeof(double) * 3 * SPEC_BATCH, hipHostMallocMapped));
+    }
+    if (!s->cvg_setup) { // QPSConvergedDefaultSetUp qps.c:718-731
+      PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs));
+      s->ttol         = fmax(s->o.rtol * s->norm_rhs, s->o.atol);
+      s->norm_rhs_div = s->norm_rhs;
+      s->cvg_setup    = 1;
+    }
+    sa.ctl = s->d_ctl, sa.ring = s->d_ring, sa.ring_cap = SPEC_BATCH;
+    sa.max_it = s->o.max_it, sa.fixed_iters = s->fixed_iters;
+    sa.ttol = s->ttol, sa.divtol_rhs = s->o.divtol * s->norm_rhs_div, sa.gamma2 = gamma2;
+  }
   while (1) {
+    if (can_spec && spec) {
+      // a batch of CG steps decided on the device: no host round trip between them
+      s->h_ctl[CTL_HALT] = 0, s->h_ctl[CTL_ITER] = s->iteration, s->h_ctl[CTL_NCG] = 0, s->h_ctl[CTL_BASE] = s->iteration;
+      PMH_HIP(hipMemcpyAsync(s->d_ctl, s->h_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyHostToDevice, ctx->stream));
+      for (int j = 0; j < SPEC_BATCH; j++) {
+        LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+        PMH_CHK(finalize_vec4(s, s->d_ctl + CTL_HALT, s->d_ctl + CTL_ITER));
+        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p);
+        PMH_CHK(f_apply_p1(s, s->d_ctl + CTL_HALT));
+      }
+      PMH_HIP(hipMemcpyAsync(s->h_ctl, s->d_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyDeviceToHost, ctx->stream));
+      PMH_HIP(hipMemcpyAsync(s->h_ring, s->d_ring, sizeof(double) * 3 * SPEC_BATCH, hipMemcpyDeviceToHost, ctx->stream));
+      PMH_CHK(pmh_sync(ctx));
+      const int ndev = s->h_ctl[CTL_ITER] - s->iteration;
+      for (int j = 0; j < ndev; j++) {
+        if (s->o.monitor) { // QPSMonitorDefault_MPGP line of iteration s->iteration + j
+          s->t_step.push_back(s->step);
+          s->t_gp.push_back(sqrt(s->h_ring[3 * j]));
+          s->t_gf.push_back(sqrt(s->h_ring[3 * j + 1]));
+          s->t_gc.push_back(sqrt(s->h_ring[3 * j + 2]));
+          s->t_alpha.push_back(s->alpha);
+        }
+        s->step = 'c';
+      }
+      s->iteration += ndev;
+      ncg += ndev;
+      nmv += ndev;
+      if (!s->h_ctl[CTL_HALT]) continue; // whole batch were CG steps
+    }
     PMH_CHK(pmh_sync(ctx));
     s->rnorm           = sqrt(ctx->h_scal[S_GP2]);
     const double gcTgc = ctx->h_scal[S_GC2], gfTgf = ctx->h_scal[S_GF2];
@@ -753,9 +854,9 @@ static int solve_fused(pmh_mpgp s)
       if (acg <= afeas) { // CG step (mpgp.c:547-560)
         ncg++;
         s->step = 'c';
-        LAUNCH(k_step_update<false>, (const double *)ctx->d_scal, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+        LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
         PMH_CHK(finalize_vec4(s));
-        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const double *)gf, p);
+        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p);
       } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
         nexp++;
         s->step = 'e';
@@ -772,7 +873,7 @@ static int solve_fused(pmh_mpgp s)
       LAUNCH(k_prop_dir, (const double *)x, (const double *)g, s->lb, s->ub, astol, p);
       PMH_CHK(f_apply_p1(s));
       nmv++;
-      LAUNCH(k_step_update<true>, (const double *)ctx->d_scal, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+      LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
       PMH_CHK(finalize_vec4(s));
     }
     // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p

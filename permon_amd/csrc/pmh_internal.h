@@ -82,6 +82,7 @@ struct pmh_spmv_epi {
   const double *y1;             // ADD: y = y1 + A x ; SUB: y = A x - y1
   const double *g, *xx, *lb, *ub; // MPGP: partials p'Ap, g'p, min feasible step (p is the SpMV input)
   int           scal_base;      // MPGP: d_scal slots [base..base+2] receive pAp, gp, afeas
+  const int    *halt;           // optional device flag: when set the launch (and its finalise) is a no-op
 };
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
 
@@ -109,7 +110,7 @@ struct pmh_qppf_s {
 // ---- reductions ---------------------------------------------------------------------------------------------
 enum { PMH_RED_SUM = 0, PMH_RED_MIN = 1 };
 // finalise K block-partial arrays (stride = ld) into d_scal[base+k] and h_scal[base+k]
-int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base);
+int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base, const int *halt = nullptr, int *post_inc = nullptr);
 int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (function of n only)
 
 // vec kernels needed across translation units (device pointers, enqueue only)

@@ -19,9 +19,10 @@ struct pmh_ops8 {
 };
 
 #define PMH_FIN_THREADS 1024
-__global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base)
+__global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base, const int *__restrict__ halt, int *__restrict__ post_inc)
 {
   __shared__ double lds[PMH_MAX_RED][PMH_FIN_THREADS / 64];
+  if (halt && *halt) return; // speculative chain stopped: keep the scalars of the last valid state
   const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double            v[PMH_MAX_RED];
   // all K strided partial sums are accumulated together: their loads overlap (one latency, not K)
@@ -49,13 +50,17 @@ __global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__re
     d_scal[base + k] = r;
     h_scal[base + k] = r;
   }
+  if (post_inc && threadIdx.x == 0) { // device-side iteration / CG-step counters of the speculative chain
+    post_inc[0]++;
+    post_inc[1]++;
+  }
 }
 
-int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base)
+int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base, const int *halt, int *post_inc)
 {
   pmh_ops8 o;
   for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base, halt, post_inc);
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
