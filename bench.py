@@ -143,6 +143,17 @@ def main():
     alg_bytes = st.ncg * b_cg + st.nprop * b_prop + st.nexp * b_exp
     achieved = b_p1 / (ms_p1 / n_p1 * 1e-3) / 1e9 if n_p1 else 0.0
 
+    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    # collected by scripts/gpu_pmc.sh with this very command and committed under profiles/
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for k, v in pmc.items():
+            if k.startswith("void k_spmv_stream<3,") and a.grid == 3162 and a.variant == "obstacle":
+                traffic = v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {
         "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)",
         "value": world * a.steps / dt,
@@ -169,7 +180,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": b_p1,
             "launches_timed": n_p1,
             "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
