@@ -92,7 +92,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nlaunch)
 // kernel.  MODE 1 double-buffers the LDS tile (one barrier per row block, 2 tiles of LDS), MODE 2 keeps one
 // tile (two barriers).  The next row block's val/col stream is issued before the current per-row phase.
 // NT: val/col are read exactly once per SpMV -> non-temporal loads keep them from evicting x out of L2.
-template <int EPI, int NNZB, int MODE, bool NT, bool NT2>
+template <int EPI, int NNZB, int MODE, bool NT, bool NT2, int RL>
 __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict__ rowblocks, int nrb, int chunk, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
 {
   if (a.halt && *a.halt) return; // uniform: every workgroup reads the same flag
@@ -148,11 +148,28 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
         if (c[j] >= 0) pr[tid + j * PMH_BLOCK] = v[j] * x[c[j]];
       if (MODE != 0 && nb < end) prefetch(nb); // next block's stream in flight during this block's row phase
       __syncthreads();
-      for (int r = cr0 + tid; r < cr1; r += PMH_BLOCK) {
-        const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
-        double    sum = 0.0;
-        for (int k = k0; k < k1; k++) sum += pr[k];
-        epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+      if (RL == 1) {
+        // short rows: one lane per row, left-to-right sum (bit-identical to MatMult_SeqAIJ)
+        for (int r = cr0 + tid; r < cr1; r += PMH_BLOCK) {
+          const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
+          double    sum = 0.0;
+          for (int k = k0; k < k1; k++) sum += pr[k];
+          epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+        }
+      } else {
+        // medium rows (e.g. 81 nnz/row elasticity blocks): RL lanes per row over the LDS tile + shuffle tree
+        const int sub = tid / RL, lane = tid % RL;
+        for (int rb = cr0; rb < cr1; rb += PMH_BLOCK / RL) { // uniform trip count for the shuffles
+          const int r   = rb + sub;
+          double    sum = 0.0;
+          if (r < cr1) {
+            const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
+            for (int k = k0 + lane; k < k1; k += RL) sum += pr[k];
+          }
+#pragma unroll
+          for (int o = RL / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, RL);
+          if (r < cr1 && lane == 0) epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+        }
       }
       if (MODE == 1) buf ^= 1;
     } else {
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
   }
 }
 
-template <int EPI, int LPR>
+template <int EPI, int LPR, bool NT>
 __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, int nlaunch, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
 {
   __shared__ double red[PMH_BLOCK / 64];
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, 
   double        sum = 0.0;
   if (r < nrows) {
     const int k0 = rowptr[r], k1 = rowptr[r + 1];
-    for (int k = k0 + lane; k < k1; k += LPR) sum += val[k] * x[col[k]];
+    for (int k = k0 + lane; k < k1; k += LPR) sum += (NT ? __builtin_nontemporal_load(&val[k]) : val[k]) * x[NT ? __builtin_nontemporal_load(&col[k]) : col[k]];
   }
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LPR);
@@ -236,11 +253,17 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_val, val, sizeof(double) * (size_t)nnz));
 
   const double avg = nrows ? (double)nnz / nrows : 0.0;
-  if (avg <= 24.0 || avg > 1024.0) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
+  int medium_stream = 1, m_nnzb = 2048, m_mode = 0, m_nt = 1; // measured best on 81 nnz/row K_i: 5.0 TB/s (profiles/)
+  if (const char *t = getenv("PMH_SPMV_MTUNE")) sscanf(t, "%d,%d,%d,%d", &medium_stream, &m_nnzb, &m_mode, &m_nt); // medium-row tuning knob
+  const bool medium = avg > 24.0 && avg <= 256.0 && medium_stream;
+  if (avg <= 24.0 || avg > 1024.0 || medium) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
     A->kind = PMH_SPMV_STREAM;
     // tuning knobs (defaults chosen from measurements on MI355X, see profiles/): PMH_SPMV_TUNE="nnzb,mode,nt"
-    A->st_nnzb = 1024, A->st_mode = 2, A->st_nt = 1;
-    if (const char *t = getenv("PMH_SPMV_TUNE")) sscanf(t, "%d,%d,%d", &A->st_nnzb, &A->st_mode, &A->st_nt);
+    A->st_nnzb = 1024, A->st_mode = 2, A->st_nt = 1, A->st_rl = 1;
+    if (medium) A->st_nnzb = m_nnzb, A->st_mode = m_mode, A->st_nt = m_nt, A->st_rl = 8;
+    if (const char *t = getenv("PMH_SPMV_TUNE")) {
+      if (!medium) sscanf(t, "%d,%d,%d", &A->st_nnzb, &A->st_mode, &A->st_nt);
+    }
     if (A->st_nnzb != 512 && A->st_nnzb != 1024 && A->st_nnzb != 2048 && A->st_nnzb != 4096) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: nnzb must be 512, 1024, 2048 or 4096");
     if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0, 1 or 2");
     std::vector<int> rb;
@@ -258,6 +281,8 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   } else {
     A->kind          = PMH_SPMV_VECTOR;
     A->lanes_per_row = (avg <= 48.0) ? 8 : (avg <= 160.0 ? 16 : (avg <= 512.0 ? 32 : 64));
+    A->st_nt         = 1;
+    if (const char *t = getenv("PMH_SPMV_VTUNE")) sscanf(t, "%d,%d", &A->lanes_per_row, &A->st_nt); // tuning knob: "lanes,nt"
     const int rpb    = PMH_BLOCK / A->lanes_per_row;
     A->n_rowblocks   = (nrows + rpb - 1) / rpb;
     A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
@@ -306,8 +331,16 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   if (A->nrows == 0) return PMH_SUCCESS;
   if (A->kind == PMH_SPMV_STREAM) {
 #define ST_LAUNCH(NNZB, MODE, NT) \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, ((NT)&2) != 0>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl)
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, ((NT)&2) != 0, RLV>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl)
 #define ST_MODE(NNZB) \
+  if (A->st_rl == 8) { \
+    constexpr int RLV = 8; \
+    ST_MODE_(NNZB) \
+  } else { \
+    constexpr int RLV = 1; \
+    ST_MODE_(NNZB) \
+  }
+#define ST_MODE_(NNZB) \
   switch (A->st_mode * 4 + (A->st_nt & 3)) { \
   case 0: ST_LAUNCH(NNZB, 0, 0); break; \
   case 1: ST_LAUNCH(NNZB, 0, 1); break; \
@@ -328,7 +361,10 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
     }
   } else {
 #define VEC_CASE(L) \
-  case L: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_vector<EPI, L>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl); break;
+  case L: \
+    if (A->st_nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_vector<EPI, L, true>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_vector<EPI, L, false>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, A->n_rowblocks, nl, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl); \
+    break;
     switch (A->lanes_per_row) {
       VEC_CASE(8)
       VEC_CASE(16)

@@ -109,8 +109,7 @@ class CubeFeti:
         Ki.sum_duplicates()
         Ki.sort_indices()
         self.Ki = Ki
-        self.K = sp.block_diag([Ki] * self.nsub, format="csr")
-        self.K.sort_indices()
+        self._K = None
 
         # body force: constant `load` in the last component (z for elasticity), consistent Q1 load vector
         fe = np.zeros(nloc)
@@ -199,6 +198,14 @@ class CubeFeti:
         self.B = sp.csr_matrix((self.leaves_sign, (self.leaves_root, self.leaves_row)), shape=(self.n_lambda, self.N))
         # dual bounds: lb(E) = -inf, lb(I) = 0 (qptransform.c:1136-1162)
         self.lb = np.concatenate([np.full(self.n_eq, -np.inf), np.zeros(self.n_ineq)])
+
+    @property
+    def K(self):
+        """blockdiag(K_i) of all subdomains (built on demand: 158 M non-zeros at configs[2] size)."""
+        if self._K is None:
+            self._K = sp.block_diag([self.Ki] * self.nsub, format="csr")
+            self._K.sort_indices()
+        return self._K
 
     # ---- coarse space -----------------------------------------------------------------------------------
     def kernel_matrix(self):
