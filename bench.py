@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the PERMON QPS hot path on MI355X.
 
-Metric (BASELINE.json): QPS iterations/sec + CSR SpMV GB/s (% of HBM roofline).
-Workload at N=1 (BASELINE.json configs[1]): synthetic SPD CSR, 5-point Laplacian on a 3162 x 3162 grid
-(n = 9 998 244 rows, nnz = 49 978 572), box-constrained, MPGP, fp64, one MI355X.
-A "step" is one MPGP iteration (one pass of the hot loop, src/qps/impls/mpgp/mpgp.c:511-641).
+Metric (BASELINE.json): QPS iterations/sec + CSR SpMV GB/s (% of HBM roofline), 1/2/4/8 MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N=1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+Workloads
+  feti (default, every N): BASELINE.json configs[2] -- 3-D elasticity TFETI, 2x2x2 cubic subdomains of 43^3 Q1
+      elements (N = 2 044 416 primal dof, K_i: 255 552 rows / 19.77 M nnz each, n_lambda = 102 268 incl. 7 744
+      contact rows), rigid obstacle, SMALXE + MPGP on the dual QP with F = B K^+ B'.  The 8 subdomain blocks
+      are sharded over the N GPUs (8/N per GPU, STRONG scaling: the north-star's own scaling target); dual
+      vectors are replicated, B u is summed with one RCCL all-reduce per F apply.  This is the configuration the
+      north-star quotes both of its targets on (>= 60 % HBM roofline on the FETI dual SpMV at 1 GPU, >= 6x
+      iterations/s at 8 GPUs); it fits one GPU (2.2 GB).
+      A "step" = one inner MPGP iteration of SMALXE (mpgp.c:511-641) on A_rho = P F P + rho Q, i.e. one F apply
+      (block-wise CG K^+ on every subdomain), two projector applies, the ||G u|| of the injected convergence test
+      and the fused vector phases.
+  c2: BASELINE.json configs[1] -- 5-pt Laplacian 3162^2 (n = 9 998 244, nnz = 49 978 572) box QP, MPGP, one GPU.
+      At N = 1 it is ALSO run and reported in the same JSON line under "configs1" (with its own roofline object).
+
+  python bench.py --gpus N --steps K --warmup W                    (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region starts.
 """
@@ -28,45 +39,220 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--grid", type=int, default=3162, help="nx = ny of the 5-pt Laplacian (3162 -> configs[1])")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="feti", choices=["feti", "c2"])
+    ap.add_argument("--grid", type=int, default=3162, help="c2: nx = ny of the 5-pt Laplacian")
     ap.add_argument("--variant", default="obstacle", choices=["obstacle", "twosided"])
+    ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
+    ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-its", type=int, default=24, help="MPGP iterations of the bounded CPU-baseline sample")
+    ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
+    ap.add_argument("--cpu-its", type=int, default=24, help="c2: MPGP iterations of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(p, its):
-    """The oracle (a port of the reference's unfused op sequence, OpenMP over rows) timed on the host cores
-    on a bounded sample: `its` MPGP iterations of the same workload.  Reported baseline, not the target."""
-    from oracle import oracle as O
-
-    # threads = the cores this process may actually run on (a cgroup/affinity mask can be far below cpu_count)
+def host_threads():
+    """Threads the CPU baseline may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:  # cgroup v2 CPU quota (the GPU box: cpu.max = 1600000 100000 -> 16 CPUs of a 2 x 64-core EPYC 9575F)
+    try:  # cgroup v2 quota (the GPU box: cpu.max = 1600000 100000 -> 16 CPUs of a 2 x 64-core EPYC 9575F)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def pmc_traffic(prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/, scripts/gpu_pmc.sh)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for k, v in pmc.items():
+            if k.startswith(prefix):
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[1]: single CSR, MPGP
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_c2(p, its):
+    """The oracle (a port of the reference's unfused op sequence, OpenMP over rows) timed on the host cores on a
+    bounded sample: `its` MPGP iterations of the same workload.  Reported baseline, not the target."""
+    from oracle import oracle as O
+
+    cores = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     A = O.Csr(p["n"], p["n"], p["rowptr"], p["col"], p["val"])
     op = O.Op(p["n"], csr=A, omp=True)
     box = O.Box(p["n"], lb=p["lb"], ub=p["ub"])
-    # maxeig supplied => no power method inside the timed call; max_it bounds the sample
-    lam, _ = O.max_eigenvalue(op, omp=True)
+    lam, _ = O.max_eigenvalue(op, omp=True)  # maxeig supplied => no power method inside the timed call
     t, done = O.time_mpgp(op, p["b"], p["x0"], box, reps=1, omp=True, maxeig=lam, max_it=its - 1)
     t_spmv = O.time_spmv(A, p["b"], reps=3, omp=True)
     return {
-        "value": done / t,
-        "unit": "QPS iterations/s",
-        "cores": cores,
-        "kind": "port",
+        "value": done / t, "unit": "QPS iterations/s", "cores": cores, "kind": "port",
         "sample": "%d MPGP iterations of the same %d-row workload, oracle/permon_oracle.c with OpenMP on %d threads "
-                  "(os.cpu_count()=%d; reference op order, one pass per PETSc call); SpMV alone %.1f GB/s" % (done, p["n"], cores, os.cpu_count() or 0, (12.0 * A.val.size + 20.0 * p["n"]) / t_spmv / 1e9),
+                  "(os.cpu_count()=%d, cgroup quota honoured; reference op order, one pass per PETSc call); SpMV alone %.1f GB/s"
+                  % (done, p["n"], cores, os.cpu_count() or 0, (12.0 * A.val.size + 20.0 * p["n"]) / t_spmv / 1e9),
     }
+
+
+def run_c2(ctx, a, steps, warmup, cpu=True):
+    import permon_amd as pa
+    from permon_amd import problems as P
+
+    t0 = time.time()
+    p = P.laplace2d_box(a.grid, a.grid, variant=a.variant)
+    n, nnz = p["n"], int(p["val"].size)
+    A = pa.CsrMat(ctx, n, n, p["rowptr"], p["col"], p["val"])
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(A))
+    qp.SetRhs(ctx.vec_from(p["b"]))
+    x = ctx.vec_from(p["x0"])
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec_from(p["lb"]), ctx.vec_from(p["ub"]) if p["ub"] is not None else None)
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    qps.SetUp()  # power method (<= 50 SpMV), alpha = 2/lambda_max: set-up, outside the timed region
+    t_setup = time.time() - t0
+    qps.RunFixed(warmup)
+    x.set_numpy(p["x0"])
+    pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
+    A.timing_enable(2 * steps + 64)
+    ctx.sync()
+    t1 = time.perf_counter()
+    st = qps.RunFixed(steps)
+    ctx.sync()
+    dt = time.perf_counter() - t1
+    assert st.iteration == steps, (st.iteration, steps)
+    n_p1, ms_p1 = A.timing_get(3)  # fused MPGP phase-P1 SpMV launches (the dominant kernel)
+    has_ub = p["ub"] is not None
+    b_spmv = 12.0 * nnz + 20.0 * n
+    b_p1 = b_spmv + (32.0 if has_ub else 24.0) * n  # + reads of g, x, lb (ub) in the fused epilogue
+    ve = 16.0 * n if has_ub else 0.0
+    alg = st.ncg * (b_spmv + 112.0 * n + ve) + st.nprop * (b_spmv + 104.0 * n + ve) + st.nexp * (2 * b_spmv + 112.0 * n + ve)
+    achieved = b_p1 / (ms_p1 / n_p1 * 1e-3) / 1e9 if n_p1 else 0.0
+    res = {
+        "value": steps / dt, "unit": "QPS iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "workload": "configs[1]: 5-pt Laplacian %dx%d (n=%d, nnz=%d) MPGP box QP (%s), fp64, CSR int32" % (a.grid, a.grid, n, nnz, a.variant),
+        "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
+        "setup_seconds": round(t_setup, 2),
+        "roofline": {
+            "bound": "hbm", "kernel": "k_spmv_stream<MPGP epilogue> (Ap = A p fused with p'Ap, g'p, QPCFeas)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("void k_spmv_stream<3,") if (a.grid == 3162 and a.variant == "obstacle") else None,
+            "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
+            "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+        },
+    }
+    A.timing_enable(0)
+    if cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline_c2(p, a.cpu_its)
+        except Exception as e:  # noqa: BLE001 - the baseline leg must not kill the GPU number
+            res["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": host_threads(), "kind": "port", "sample": "failed: %r" % (e,)}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2]: TFETI contact problem, SMALXE + MPGP on the dual QP, subdomain blocks sharded over the GPUs
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol):
+    """Same dual operator on the host cores: the oracle's MPGP (C, reference op order) on A_rho = P F P + rho Q with
+    F = B K^+ B', K^+ = per-block Jacobi-CG in C with OpenMP row-parallel CSR SpMV (oracle/permon_oracle.c).
+    Bounded sample: `steps` MPGP iterations from the same right-hand side / bounds the GPU run uses."""
+    from oracle import oracle as O
+
+    cores = host_threads()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    K = O.Csr.from_scipy(f.K)
+    Kplus = O.MatInv(K, f.block_rowstart, f.R, rtol=rtol, omp=True)
+    pfo = O.Qppf(O.Csr.from_scipy(G), orthonormal=True)
+    B = O.Gluing(f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
+    A_or = O.FetiOp(B, Kplus, pfo, rho=1.0, which=1, omp=True)  # any positive penalty: cost per iteration is the same
+    n = f.n_lambda
+    t0 = time.perf_counter()
+    ref = O.mpgp(A_or.op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), omp=True, maxeig=1.0, max_it=steps - 1)
+    dt = time.perf_counter() - t0
+    return {
+        "value": ref["iteration"] / dt, "unit": "QPS iterations/s", "cores": cores, "kind": "port",
+        "sample": "%d inner MPGP iteration(s) of the same TFETI dual QP: oracle/permon_oracle.c (reference op order), F = B K^+ B' with "
+                  "per-block Jacobi-CG K^+ rtol %.0e, OpenMP row-parallel CSR SpMV on %d threads (cgroup quota of the box), %d K SpMVs in the sample"
+                  % (ref["iteration"], rtol, cores, Kplus.spmv_count()),
+    }
+
+
+def run_feti(ctx, a, steps, warmup, rank, world, dist):
+    import permon_amd as pa
+    from permon_amd.chain import FetiDualQP
+
+    t0 = time.time()
+    f = pa.CubeFeti((2, 2, 2), a.nel, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    if 8 % world:
+        raise SystemExit("feti workload: the 8 subdomains must divide over the ranks (N in 1,2,4,8)")
+    per = 8 // world
+    local = f.subset(range(rank * per, (rank + 1) * per))
+    t_gen = time.time() - t0
+    t0 = time.time()
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol)
+    qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
+    t_setup = time.time() - t0
+    Kcsr = q.K.K
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    qps.RunFixed(warmup)
+    q.lam.set(0.0)
+    Kcsr.timing_enable(60000)
+    _, spmv1 = q.Kplus.last_iterations()
+    barrier()
+    t1 = time.perf_counter()
+    st = qps.RunFixed(steps)
+    barrier()
+    dt = time.perf_counter() - t1
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert st.iteration == steps, (st.iteration, steps)
+    kits, spmv2 = q.Kplus.last_iterations()
+    n_k, ms_k = Kcsr.timing_get(0)
+    b_k = 12.0 * Kcsr.nnz + 20.0 * Kcsr.nrows
+    achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+    res = {
+        "value": steps / dt, "ms_per_step": dt / steps * 1e3,
+        "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
+                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise Jacobi-CG K^+ (rtol %.0e)"
+                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, a.kplus_rtol),
+        "parallelism": "%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world),
+        "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
+        "kplus": {"spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "last_block_cg_iterations": kits},
+        "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
+        "roofline": {
+            "bound": "hbm", "kernel": "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("void k_spmv_stream<0, 2048,") if (a.nel == 43 and world == 1) else None,
+            "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
+            "share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
+        },
+    }
+    Kcsr.timing_enable(0)
+    return res, f, G, q.b.to_numpy(), q.lb_new.to_numpy()
 
 
 def main():
@@ -74,9 +260,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
     dist = None
     if world > 1:
         import torch
@@ -87,115 +272,57 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import permon_amd as pa
-    from permon_amd import problems as P
 
     ctx = pa.Context(local_rank)
-    t0 = time.time()
-    p = P.laplace2d_box(a.grid, a.grid, variant=a.variant)
-    n, nnz = p["n"], int(p["val"].size)
-    A = pa.CsrMat(ctx, n, n, p["rowptr"], p["col"], p["val"])
-    op = pa.Op.from_csr(A)
-    qp = pa.QP(ctx)
-    qp.SetOperator(op)
-    qp.SetRhs(ctx.vec_from(p["b"]))
-    x = ctx.vec_from(p["x0"])
-    qp.SetInitialVector(x)
-    qp.SetBox(None, ctx.vec_from(p["lb"]), ctx.vec_from(p["ub"]) if p["ub"] is not None else None)
-    qps = pa.QPS(ctx)
-    qps.SetQP(qp)
-    qps.SetType("mpgp")
-    qps.SetUp()  # power method (<= 50 SpMV), alpha = 2/lambda_max: set-up, outside the timed region
-    t_setup = time.time() - t0
+    if world > 1:
+        import torch
 
-    def barrier():
-        ctx.sync()
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.tensor(list(ctx.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        ctx.comm_init(rank, world, bytes(idt.cpu().tolist()))
+
+    if a.workload == "c2":
+        steps, warmup = a.steps or 300, a.warmup if a.warmup is not None else 30
+        r = run_c2(ctx, a, steps, warmup, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline))
         if dist is not None:
             import torch
 
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # warm-up: W untimed steps
-    qps.RunFixed(a.warmup)
-    x.set_numpy(p["x0"])
-    pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
-    A.timing_enable(2 * a.steps + 8)
-    barrier()
-    t1 = time.perf_counter()
-    st = qps.RunFixed(a.steps)
-    barrier()
-    dt = time.perf_counter() - t1
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    assert st.iteration == a.steps, (st.iteration, a.steps)
-    n_p1, ms_p1 = A.timing_get(3)  # fused MPGP phase-P1 SpMV launches (the dominant kernel)
-    n_sub, ms_sub = A.timing_get(2)
-    has_ub = p["ub"] is not None
-    b_spmv = 12.0 * nnz + 20.0 * n
-    b_p1 = b_spmv + (32.0 if has_ub else 24.0) * n  # + reads of g, x, lb (ub) in the fused epilogue
-    vec_extra = 16.0 * n if has_ub else 0.0
-    b_cg, b_prop, b_exp = b_spmv + 112.0 * n + vec_extra, b_spmv + 104.0 * n + vec_extra, 2 * b_spmv + 112.0 * n + vec_extra
-    alg_bytes = st.ncg * b_cg + st.nprop * b_prop + st.nexp * b_exp
-    achieved = b_p1 / (ms_p1 / n_p1 * 1e-3) / 1e9 if n_p1 else 0.0
-
-    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-    # collected by scripts/gpu_pmc.sh with this very command and committed under profiles/
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for k, v in pmc.items():
-            if k.startswith("void k_spmv_stream<3,") and a.grid == 3162 and a.variant == "obstacle":
-                traffic = v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-
-    out = {
-        "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)",
-        "value": world * a.steps / dt,
-        "unit": "QPS iterations/s",
-        "n_gpus": world,
-        "steps": a.steps,
-        "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": "configs[1]: 5-pt Laplacian %dx%d (n=%d, nnz=%d) MPGP box QP (%s), fp64, CSR int32" % (a.grid, a.grid, n, nnz, a.variant),
-            "parallelism": "1 GPU" if world == 1 else "%d independent replicas (configs[1] is a single-GPU config; replicas only)" % world,
-            "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
-            "setup_seconds": round(t_setup, 2),
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_spmv_stream<MPGP epilogue> (Ap = A p fused with p'Ap, g'p, QPCFeas)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": b_p1,
-            "launches_timed": n_p1,
-            "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
-            "spmv_only_GBs": b_spmv / (ms_p1 / n_p1 * 1e-3) / 1e9 if n_p1 else None,
-            "whole_iteration_GBs": alg_bytes / dt / 1e9,
-            "whole_iteration_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
-        },
-    }
-    if n_sub:
-        out["roofline"]["gradient_spmv_avg_ms"] = ms_sub / n_sub
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(p, a.cpu_its)
-        except Exception as e:  # noqa: BLE001 - the baseline leg must not kill the GPU number
-            out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            r["ms_per_step"] = float(tt.item())
+            r["value"] = 1e3 / r["ms_per_step"]
+        out = {
+            "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": world * r["value"], "unit": "QPS iterations/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": r["workload"], "parallelism": "1 GPU" if world == 1 else "%d independent replicas (configs[1] is a single-CSR, single-GPU config: replicas only)" % world,
+                       "steps_by_type": r["steps_by_type"], "setup_seconds": r["setup_seconds"]},
+            "roofline": r["roofline"],
+        }
+        if "cpu_baseline" in r:
+            out["cpu_baseline"] = r["cpu_baseline"]
+    else:
+        steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 2
+        r, f, G, b_dual, lb_dual = run_feti(ctx, a, steps, warmup, rank, world, dist)
+        out = {
+            "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"],
+                       "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
+            "roofline": r["roofline"],
+        }
+        if rank == 0 and world == 1:
+            if not a.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline_feti(f, G, b_dual, lb_dual, 1, a.kplus_rtol)
+                except Exception as ex:  # noqa: BLE001
+                    out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+            if not a.no_c2:
+                del f, G
+                out["configs1"] = run_c2(ctx, a, 300, 30, cpu=not a.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -261,6 +261,7 @@ int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double *u, const d
 int pmh_smalxe_destroy(pmh_smalxe s);
 int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve_SMALXE smalxe.c:893-997 */
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
+int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
 /* ---- QPS PCPG (src/qps/impls/pcpg/pcpg.c:51-134) -------------------------------------------------------- */
 typedef struct {

@@ -369,6 +369,39 @@ class Gluing:
         return lam
 
 
+class MatInv:
+    """MATINV apply on the reference's iterative path: per-block Jacobi-CG, Moore-Penrose wrapped (orc_matinv_mult)."""
+
+    def __init__(self, K, rowstart, R=None, rtol=1e-10, atol=1e-50, max_it=20000, omp=False):
+        self.L = lib(omp)
+        self.L.orc_matinv_new.restype = C.c_void_p
+        self.L.orc_matinv_spmv_count.restype = C.c_longlong
+        self.K, self.rowstart = K, _i32(rowstart)
+        self.R = _f64(R) if R is not None else None
+        kdim = self.R.shape[0] if self.R is not None else 0
+        self.h = self.L.orc_matinv_new(C.byref(K.c), len(self.rowstart) - 1, _p(self.rowstart), kdim, _p(self.R), C.c_double(rtol), C.c_double(atol), C.c_int(max_it))
+
+    def mult(self, f):
+        u = np.empty(self.K.nrows)
+        self.L.orc_matinv_mult(C.c_void_p(self.h), _dp(_f64(f)), _dp(u))
+        return u
+
+    def spmv_count(self):
+        return int(self.L.orc_matinv_spmv_count(C.c_void_p(self.h)))
+
+
+class FetiOp:
+    """Native operators of the FETI dual QP: F = B K^+ B' (which=0) or A_rho = P F P + rho Q (which=1)."""
+
+    def __init__(self, B, Kplus, pf, rho=0.0, which=0, omp=False):
+        L = lib(omp)
+        L.orc_feti_new.restype = C.c_void_p
+        L.orc_feti_fn.restype = C.c_void_p
+        self._keep = (B, Kplus, pf)
+        self.h = L.orc_feti_new(C.byref(B.c), C.c_void_p(Kplus.h), C.byref(pf.c) if pf is not None else None, C.c_double(rho))
+        self.op = Op(B.n_lambda, native=(L.orc_feti_fn(C.c_int(which)), C.c_void_p(self.h), self), omp=omp)
+
+
 def kkt_box(op, b, x, lb):
     """The four 'r =' lines of QPViewKKT + QPCViewKKT_Box for a lower-bound-only QP
     (src/qp/interface/qp.c:245-369, src/qpc/impls/box/qpcbox.c:333-427, multipliers qp.c:828-893)."""

@@ -179,3 +179,29 @@ double orc_time_spmv(const orc_csr *A, const double *x, double *y, int reps)
   for (r = 0; r < reps; r++) orc_csr_mult((void *)A, x, y);
   return orc_now() - t0;
 }
+
+orc_matinv *orc_matinv_new(const orc_csr *K, int nblocks, const int *rowstart, int kdim, const double *R, double rtol, double atol, int max_it)
+{
+  orc_matinv *M = (orc_matinv *)calloc(1, sizeof(orc_matinv));
+  M->K = K, M->nblocks = nblocks, M->rowstart = rowstart, M->kdim = kdim, M->R = R, M->rtol = rtol, M->atol = atol, M->max_it = max_it;
+  return M;
+}
+long long orc_matinv_spmv_count(orc_matinv *M) { return M->spmv_count; }
+int       orc_matinv_last_its(orc_matinv *M) { return M->last_max_its; }
+void      orc_matinv_delete(orc_matinv *M) { free(M); }
+
+orc_feti *orc_feti_new(const orc_gluing *B, orc_matinv *Kplus, const orc_qppf *pf, double rho)
+{
+  orc_feti *F = (orc_feti *)calloc(1, sizeof(orc_feti));
+  F->B = B, F->Kplus = Kplus, F->pf = pf, F->rho = rho;
+  F->t1 = (double *)calloc((size_t)B->n_x + 1, sizeof(double));
+  F->t2 = (double *)calloc((size_t)B->n_x + 1, sizeof(double));
+  F->w1 = (double *)calloc((size_t)B->n_lambda + 1, sizeof(double));
+  F->w2 = (double *)calloc((size_t)B->n_lambda + 1, sizeof(double));
+  return F;
+}
+void orc_feti_delete(orc_feti *F)
+{
+  free(F->t1), free(F->t2), free(F->w1), free(F->w2), free(F);
+}
+orc_mult_fn orc_feti_fn(int which) { return which ? orc_feti_penalized_mult : orc_feti_dual_mult; }

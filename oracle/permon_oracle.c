@@ -1018,3 +1018,99 @@ void orc_gluing_mult_transpose(const orc_gluing *B, const double *x, double *lam
   for (i = 0; i < B->n_lambda; i++) lambda[i] = 0.0;
   for (i = 0; i < B->n_leaves; i++) lambda[B->leaves_root[i]] += x[B->leaves_row[i]] * B->leaves_sign[i];
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* MatMult_Inv matinv.c:734-743 on the KSPCG/PCJACOBI per-block path (matinv.c:535-540)         */
+/* ------------------------------------------------------------------------------------------ */
+static void matinv_project(const orc_matinv *M, const double *v, double *out)
+{
+  int b, k, i;
+  v_copy(M->K->nrows, v, out);
+  for (b = 0; b < M->nblocks; b++) {
+    int lo = M->rowstart[b], hi = M->rowstart[b + 1];
+    for (k = 0; k < M->kdim; k++) {
+      const double *Rk = M->R + (size_t)k * M->K->nrows;
+      double        c  = v_dot(hi - lo, Rk + lo, v + lo);
+      for (i = lo; i < hi; i++) out[i] -= c * Rk[i];
+    }
+  }
+}
+
+void orc_matinv_mult(orc_matinv *M, const double *f, double *u)
+{
+  int     n = M->K->nrows, nb = M->nblocks, b, i, it, nactive = 0, mx = 0;
+  double *r = orc_vec(n), *z = orc_vec(n), *p = orc_vec(n), *Ap = orc_vec(n), *dinv = orc_vec(n), *t = orc_vec(n);
+  double *rz = orc_vec(nb), *tol = orc_vec(nb);
+  int    *active = (int *)calloc((size_t)nb, sizeof(int));
+  for (i = 0; i < n; i++) {
+    int    k;
+    double d = 1.0;
+    for (k = M->K->rowptr[i]; k < M->K->rowptr[i + 1]; k++)
+      if (M->K->col[k] == i) d = M->K->val[k];
+    dinv[i] = 1.0 / d;
+  }
+  if (M->kdim) matinv_project(M, f, r);
+  else v_copy(n, f, r);
+  for (i = 0; i < n; i++) {
+    u[i] = 0.0;
+    z[i] = dinv[i] * r[i];
+    p[i] = z[i];
+  }
+  for (b = 0; b < nb; b++) {
+    int    lo = M->rowstart[b], m = M->rowstart[b + 1] - lo;
+    double rr = v_dot(m, r + lo, r + lo);
+    rz[b]     = v_dot(m, r + lo, z + lo);
+    tol[b]    = fmax(M->rtol * sqrt(rr), M->atol);
+    active[b] = sqrt(rr) > tol[b];
+    nactive += active[b];
+  }
+  for (it = 0; it < M->max_it && nactive; it++) {
+    orc_csr_mult((void *)M->K, p, Ap);
+    M->spmv_count++;
+    for (b = 0; b < nb; b++) {
+      int    lo = M->rowstart[b], m = M->rowstart[b + 1] - lo;
+      double alpha, rzn, rr, beta;
+      if (!active[b]) continue;
+      alpha = rz[b] / v_dot(m, p + lo, Ap + lo);
+      v_axpy(m, u + lo, alpha, p + lo);
+      v_axpy(m, r + lo, -alpha, Ap + lo);
+      for (i = lo; i < lo + m; i++) z[i] = dinv[i] * r[i];
+      rzn   = v_dot(m, r + lo, z + lo);
+      rr    = v_dot(m, r + lo, r + lo);
+      beta  = rzn / rz[b];
+      rz[b] = rzn;
+      mx    = it + 1;
+      if (sqrt(rr) <= tol[b]) {
+        active[b] = 0;
+        nactive--;
+      } else {
+        v_aypx(m, p + lo, beta, z + lo);
+      }
+    }
+  }
+  M->last_max_its = mx;
+  if (M->kdim) {
+    matinv_project(M, u, t);
+    v_copy(n, t, u);
+  }
+  free(r), free(z), free(p), free(Ap), free(dinv), free(t), free(rz), free(tol), free(active);
+}
+
+void orc_feti_dual_mult(void *ctx, const double *x, double *y)
+{
+  orc_feti *F = (orc_feti *)ctx;
+  orc_gluing_mult(F->B, x, F->t1);
+  orc_matinv_mult(F->Kplus, F->t1, F->t2);
+  orc_gluing_mult_transpose(F->B, F->t2, y);
+}
+
+void orc_feti_penalized_mult(void *ctx, const double *x, double *y)
+{
+  orc_feti *F = (orc_feti *)ctx;
+  int       n = F->B->n_lambda, i;
+  orc_qppf_apply_Q(F->pf, x, y); /* Q x (orthonormal G: BtB = Q) */
+  for (i = 0; i < n; i++) F->w1[i] = x[i] - y[i]; /* P x */
+  orc_feti_dual_mult(ctx, F->w1, F->w2);
+  orc_qppf_apply_P(F->pf, F->w2, F->w1);
+  for (i = 0; i < n; i++) y[i] = F->rho * y[i] + F->w1[i];
+}

@@ -240,6 +240,33 @@ typedef struct {
 void orc_gluing_mult(const orc_gluing *B, const double *lambda, double *x);           /* x = B' lambda */
 void orc_gluing_mult_transpose(const orc_gluing *B, const double *x, double *lambda); /* lambda = B x */
 
+/* MATINV apply on the reference's iterative path (KSPCG + PCJACOBI per block, matinv.c:535-540) wrapped as the
+   Moore-Penrose inverse P_R K^- P_R (QPTDualize -qpt_dualize_Kplus_mp, qptransform.c:1006-1062); blocks = contiguous
+   row ranges of the block-diagonal CSR K; R = kdim columns of length n (column-major), block-wise orthonormal */
+typedef struct {
+  const orc_csr *K;
+  int            nblocks;
+  const int     *rowstart;
+  int            kdim;
+  const double  *R;
+  double         rtol, atol;
+  int            max_it;
+  long long      spmv_count;
+  int            last_max_its;
+} orc_matinv;
+void orc_matinv_mult(orc_matinv *M, const double *f, double *u);
+
+/* F = B K^+ B' (qptransform.c:1103-1128) and the SMALXE inner operator A_rho = P F P + rho Q as native callbacks */
+typedef struct {
+  const orc_gluing *B;
+  orc_matinv       *Kplus;
+  const orc_qppf   *pf;
+  double            rho;
+  double           *t1, *t2, *w1, *w2; /* work: n_x, n_x, n_lambda, n_lambda */
+} orc_feti;
+void orc_feti_dual_mult(void *ctx, const double *x, double *y);     /* y = F x */
+void orc_feti_penalized_mult(void *ctx, const double *x, double *y); /* y = P F P x + rho Q x */
+
 /* unfused reference-order CG step timing helper for the CPU baseline: runs `iters` MPGP iterations
    without convergence test on a fixed problem; returns elapsed seconds */
 double orc_now(void);

@@ -162,6 +162,7 @@ _PROTOS = {
     "pmh_smalxe_destroy": [vp],
     "pmh_smalxe_solve": [vp],
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
+    "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

@@ -48,8 +48,8 @@ class FetiDualQP:
         self.pf.ApplyP(self.b_bar, self.b)
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
-    def solve_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
-        """QPSSetDefaultType: BE present -> SMALXE with inner MPGP (qps.c:443-444)."""
+    def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
+        """QPS of type SMALXE on the projected dual QP, set up but not solved."""
         qp = QP(self.ctx)
         qp.SetOperator(self.A)
         qp.SetRhs(self.b)
@@ -64,9 +64,13 @@ class FetiDualQP:
             setattr(qps.smalxe_opts, k, v)
         for k, v in (inner or {}).items():
             setattr(qps.smalxe_opts.inner, k, v)
-        st = qps.Solve()
+        qps.SetUp()
         self.qps = qps
-        return st
+        return qps
+
+    def solve_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
+        """QPSSetDefaultType: BE present -> SMALXE with inner MPGP (qps.c:443-444)."""
+        return self.make_smalxe(rtol=rtol, max_it=max_it, inner=inner, **smalxe).Solve()
 
     def solve_pcpg(self, rtol=1e-5, max_it=1000, lumped=False):
         """Equality-only dual QP (no box): projected preconditioned CG (QPSPCPG)."""

@@ -295,6 +295,13 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
   return PMH_SUCCESS;
 }
 
+extern "C" int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner)
+{
+  PMH_ARG(s && inner);
+  *inner = s->inner;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st)
 {
   PMH_ARG(s && st);

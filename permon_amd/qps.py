@@ -187,12 +187,21 @@ class QPS:
         self.stats = st
         return st
 
+    def _mpgp_handle(self):
+        if self.type == "smalxe":  # QPSSMALXEGetInnerQPS
+            h = C.c_void_p()
+            check(self.L.pmh_smalxe_get_inner(self.h, C.byref(h)))
+            return h
+        return self.h
+
     def RunFixed(self, iters):
-        """Throughput mode (bench.py): exactly `iters` MPGP iterations, verdict of the convergence test ignored."""
+        """Throughput mode (bench.py): exactly `iters` MPGP iterations (for SMALXE: of its inner MPGP on the
+        penalised operator, injected convergence test still evaluated), verdict of the test ignored."""
         self.SetUp()
-        check(self.L.pmh_mpgp_run_fixed(self.h, int(iters)))
+        h = self._mpgp_handle()
+        check(self.L.pmh_mpgp_run_fixed(h, int(iters)))
         st = _lib.MpgpStats()
-        check(self.L.pmh_mpgp_get_stats(self.h, C.byref(st)))
+        check(self.L.pmh_mpgp_get_stats(h, C.byref(st)))
         self.stats = st
         return st
 
