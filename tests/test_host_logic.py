@@ -1,0 +1,84 @@
+"""CPU tests of the host-side producers (problem generators, FETI set-up data) and of the oracle's FETI pieces."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from permon_amd import problems as P
+from permon_amd.feti import CubeFeti, q1_elasticity_element, q1_poisson_element
+
+
+def test_ex1_matrix_shape_matches_tutorial():
+    p = P.ex1(1000)  # BASELINE.json configs[0]
+    assert p["col"].size == 2994  # nnz quoted in SURVEY section 8 (C1)
+    A = sp.csr_matrix((p["val"], p["col"], p["rowptr"]), shape=(1000, 1000))
+    assert abs(A - A.T).max() == 0
+    assert A[0, 0] == 1 and A[0, 1] == 0 and A[1, 0] == 0 and A[1, 1] == 2
+    assert p["lb"][0] == 0 and p["lb"][-1] == 0 and p["b"][0] == 0
+
+
+def test_laplace2d_config1_counts():
+    rp, ci, va = P.laplace2d_csr(50, 40)
+    n = 2000
+    assert rp[-1] == 5 * n - 2 * 50 - 2 * 40
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    assert abs(A - A.T).max() == 0 and np.all(np.diff(ci[rp[7]:rp[8]]) > 0)
+    # configs[1]: 3162^2 -> n = 9 998 244, nnz = 49 978 572 (formula, without building it)
+    g = 3162
+    assert g * g == 9998244 and 5 * g * g - 4 * g == 49978572
+
+
+def test_q1_elements():
+    Ke = q1_elasticity_element(0.5)
+    assert np.allclose(Ke, Ke.T) and Ke.shape == (24, 24)
+    ev = np.linalg.eigvalsh(Ke)
+    assert np.sum(np.abs(ev) < 1e-12) == 6 and ev.min() > -1e-12  # six rigid-body modes
+    Kp = q1_poisson_element(0.25)
+    assert np.allclose(Kp.sum(axis=1), 0) and np.linalg.eigvalsh(Kp).min() > -1e-14
+
+
+@pytest.mark.parametrize("physics,kdim", [("elasticity", 6), ("poisson", 1)])
+def test_cube_feti_invariants(physics, kdim):
+    f = CubeFeti((2, 2, 1), 2, physics=physics, gluing="full")
+    assert f.R.shape == (kdim, f.N)
+    assert abs(f.K @ f.R.T).max() < 1e-13  # R spans ker K block-wise
+    for s in range(f.nsub):
+        Rs = f.R[:, s * f.n_i:(s + 1) * f.n_i]
+        assert np.allclose(Rs @ Rs.T, np.eye(kdim))
+    # gluing rows: two entries +-1/sqrt(multiplicity); Dirichlet / contact rows: one entry
+    B = f.B.tocsr()
+    nnz_row = np.diff(B.indptr)
+    assert np.all(nnz_row[:f.n_dirichlet] == 1) and np.all(nnz_row[f.n_dirichlet:f.n_eq] == 2) and np.all(nnz_row[f.n_eq:] == 1)
+    assert np.allclose(B[f.n_dirichlet:f.n_eq].sum(axis=1), 0)
+    G, e = f.coarse(orthonormalize=True)
+    assert np.allclose((G @ G.T).toarray(), np.eye(G.shape[0]), atol=1e-12)
+    # subsets partition the leaves
+    a, b = f.subset([0, 1]), f.subset([2, 3])
+    assert len(a["leaves_row"]) + len(b["leaves_row"]) == len(f.leaves_row)
+    assert f.lb[:f.n_eq].max() == -np.inf and np.all(f.lb[f.n_eq:] == 0)
+
+
+def test_config2_sizes_formula():
+    """BASELINE.json configs[2] at full size without assembling: 2x2x2 cubes of 44^3 nodes x 3 dof."""
+    nn1 = 44
+    assert nn1 ** 3 * 3 == 255552 and 8 * 255552 == 2044416
+    f = CubeFeti((2, 2, 2), 3)
+    # structure check of the row count formulas on a small instance: Dirichlet = dofs on x=0 of the 4 left cubes
+    assert f.n_dirichlet == 4 * (3 + 1) ** 2 * 3
+
+
+def test_oracle_matinv_and_feti_operator(oracle):
+    f = CubeFeti((2, 1, 1), 2)
+    K = oracle.Csr.from_scipy(f.K)
+    M = oracle.MatInv(K, f.block_rowstart, f.R, rtol=1e-13)
+    rhs = np.random.default_rng(0).standard_normal(f.N)
+    Kp = np.linalg.pinv(f.K.toarray(), rcond=1e-12, hermitian=True)
+    assert np.linalg.norm(M.mult(rhs) - Kp @ rhs) <= 1e-10 * np.linalg.norm(Kp @ rhs)
+    G, e = f.coarse()
+    pf = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=True)
+    B = oracle.Gluing(f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
+    Fo = oracle.FetiOp(B, M, pf, rho=0.7, which=1)
+    x = np.random.default_rng(1).standard_normal(f.n_lambda)
+    Bd = f.B.toarray()
+    Fd = Bd @ Kp @ Bd.T
+    ref = pf.P(Fd @ pf.P(x)) + 0.7 * pf.Q(x)
+    assert np.linalg.norm(Fo.op(x) - ref) <= 1e-10 * np.linalg.norm(ref)
