@@ -132,10 +132,10 @@ struct pmh_matinv_s {
   double        rtol, atol;
   int           max_it, jacobi;
   double       *dinv, *r, *z, *p, *Ap;
-  double       *d_part; // [2][nblocks*wgs]
-  double       *d_bs;   // [nblocks][BS_NSLOT]
-  int          *d_bi;   // [nblocks][BI_NSLOT]
-  int          *d_nactive, *h_nactive;
+  double       *d_part, *d_partB; // [2][nblocks*wgs] each
+  double       *d_bs;             // [2 parities][nblocks][rz, tol]
+  int          *d_bi;             // [2 parities][nblocks][active, its]
+  int          *d_nactive, *d_done, *h_nactive;
   int           last_max_its;
   long long     total_spmv;
   // Moore-Penrose variant (QPTDualize true_mp path, qptransform.c:1006-1062): K^+ := P_R K^- P_R with
@@ -163,6 +163,22 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_extract_dinv(int n, const int *__
   }
 }
 
+// block-wide sum of `wgs` (<= PMH_BLOCK) partials, result broadcast to every thread; identical in every workgroup
+__device__ __forceinline__ double seg_total(const double *__restrict__ part, int wgs, double *lds)
+{
+  double v = ((int)threadIdx.x < wgs) ? part[threadIdx.x] : 0.0;
+  v        = pmh_block_reduce<PMH_RED_SUM>(v, lds);
+  __shared__ double bc;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = v;
+  __syncthreads();
+  return bc;
+}
+
+// per-block state, double buffered by iteration parity q: doubles {rz, tol}, ints {active, its}
+#define BSQ(bs, q, b, k) (bs)[((q)*nb + (b)) * 2 + (k)]
+#define BIQ(bi, q, b, k) (bi)[((q)*nb + (b)) * 2 + (k)]
+
 // start: u = 0, r = f, z = Dinv r, p = z; partials r.z and r.r
 __global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ rs, int wgs, const double *__restrict__ f, const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, double *__restrict__ part, int ld)
 {
@@ -186,100 +202,92 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_seg_dot(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part)
+// one workgroup per block: rz, tolerance (KSPConvergedDefault: ||r|| <= max(rtol ||b||, atol), zero initial guess), active set
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_init(int nb, int wgs, int ld, const double *__restrict__ part, double *__restrict__ bs, int *__restrict__ bi, int *__restrict__ nactive, int *__restrict__ done, double rtol, double atol)
 {
   __shared__ double lds[PMH_BLOCK / 64];
-  if (*nactive == 0) return;
+  const int         b  = blockIdx.x;
+  const double      rz = seg_total(part + b * wgs, wgs, lds);
+  const double      rr = seg_total(part + ld + b * wgs, wgs, lds);
+  if (threadIdx.x == 0) {
+    const double tol = fmax(rtol * sqrt(rr), atol);
+    const int    act = (sqrt(rr) > tol) ? 1 : 0;
+    BSQ(bs, 0, b, 0) = rz, BSQ(bs, 0, b, 1) = tol;
+    BSQ(bs, 1, b, 0) = rz, BSQ(bs, 1, b, 1) = tol;
+    BIQ(bi, 0, b, 0) = act, BIQ(bi, 0, b, 1) = 0;
+    BIQ(bi, 1, b, 0) = act, BIQ(bi, 1, b, 1) = 0;
+    if (act) atomicAdd(nactive, 1);
+  }
+}
+// done = (nactive == 0) after k_cg_init
+__global__ void k_cg_init_done(const int *nactive, int *done) { *done = (*nactive == 0) ? 1 : 0; }
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_seg_dot(const int *__restrict__ rs, int nb, int wgs, int q, const int *__restrict__ done, const int *__restrict__ bi, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  if (*done) return;
   double s = 0.0;
-  SEG_LOOP(i, b, rs, wgs) s += x[i] * y[i];
+  if (BIQ(bi, q, blockIdx.x / wgs, 0)) {
+    SEG_LOOP(i, b, rs, wgs) s += x[i] * y[i];
+  }
   s = pmh_block_reduce<PMH_RED_SUM>(s, lds);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// alpha_b = rz_b / (p'Ap)_b (every workgroup re-sums its block's partials in the same fixed order);
 // u += alpha_b p; r -= alpha_b Ap; z = Dinv r; partials r.z, r.r
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ part, int ld)
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int nb, int wgs, int q, const int *__restrict__ done, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, int ld)
 {
   __shared__ double lds[PMH_BLOCK / 64];
-  if (*nactive == 0) return;
+  if (*done) return;
+  const int bb = blockIdx.x / wgs;
+  if (!BIQ(bi, q, bb, 0)) return; // converged block: frozen
+  const double pAp   = seg_total(partA + bb * wgs, wgs, lds);
+  const double alpha = BSQ(bs, q, bb, 0) / pAp;
   double       s0 = 0.0, s1 = 0.0;
-  const int    bb     = blockIdx.x / wgs;
-  const bool   active = bi[bb * BI_NSLOT + BI_ACTIVE] != 0;
-  const double alpha  = bs[bb * BS_NSLOT + BS_ALPHA];
-  if (active) {
-    SEG_LOOP(i, b, rs, wgs)
-    {
-      double ri = r[i] - alpha * Ap[i];
-      double zi = dinv[i] * ri;
-      u[i] += alpha * p[i];
-      r[i] = ri;
-      z[i] = zi;
-      s0 += ri * zi;
-      s1 += ri * ri;
-    }
+  SEG_LOOP(i, b, rs, wgs)
+  {
+    double ri = r[i] - alpha * Ap[i];
+    double zi = dinv[i] * ri;
+    u[i] += alpha * p[i];
+    r[i] = ri;
+    z[i] = zi;
+    s0 += ri * zi;
+    s1 += ri * ri;
   }
   s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
   s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
   if (threadIdx.x == 0) {
-    part[blockIdx.x]      = s0;
-    part[ld + blockIdx.x] = s1;
+    partB[blockIdx.x]      = s0;
+    partB[ld + blockIdx.x] = s1;
   }
 }
 
-// p = z + beta_b p
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_p(const int *__restrict__ rs, int wgs, const int *__restrict__ nactive, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ z, double *__restrict__ p)
-{
-  if (*nactive == 0) return;
-  const int bb = blockIdx.x / wgs;
-  if (!bi[bb * BI_NSLOT + BI_ACTIVE]) return;
-  const double beta = bs[bb * BS_NSLOT + BS_BETA];
-  SEG_LOOP(i, b, rs, wgs) p[i] = z[i] + beta * p[i];
-}
-
-// one workgroup per block: reduce the block's partials in fixed order and run the scalar recurrences
-// phase 0: start (rz, rr -> tol, active); phase 1: pAp -> alpha; phase 2: rznew, rr -> beta, convergence
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_scalars(int phase, int wgs, int ld, const double *__restrict__ part, double *__restrict__ bs, int *__restrict__ bi, int *__restrict__ nactive, int *__restrict__ h_nactive, double rtol, double atol, int it, int max_it)
+// beta_b = rz_new / rz; convergence of block b; p = z + beta_b p; the block's first workgroup publishes the next state
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_p(const int *__restrict__ rs, int nb, int wgs, int q, int it, int max_it, double *__restrict__ bs, int *__restrict__ bi, int *__restrict__ nactive, int *__restrict__ done, const double *__restrict__ partB, int ld, const double *__restrict__ z, double *__restrict__ p)
 {
   __shared__ double lds[PMH_BLOCK / 64];
-  const int         b = blockIdx.x;
-  if (phase != 0 && *nactive == 0) return;
-  double v0 = 0.0, v1 = 0.0;
-  for (int i = threadIdx.x; i < wgs; i += PMH_BLOCK) {
-    v0 += part[b * wgs + i];
-    if (phase != 1) v1 += part[ld + b * wgs + i];
+  const int         bb = blockIdx.x / wgs, w = blockIdx.x % wgs;
+  if (!BIQ(bi, q, bb, 0)) {
+    if (w == 0 && threadIdx.x == 0) { // carry the frozen state to the other parity
+      BSQ(bs, q ^ 1, bb, 0) = BSQ(bs, q, bb, 0);
+      BIQ(bi, q ^ 1, bb, 0) = 0;
+      BIQ(bi, q ^ 1, bb, 1) = BIQ(bi, q, bb, 1);
+    }
+    return;
   }
-  v0 = pmh_block_reduce<PMH_RED_SUM>(v0, lds);
-  v1 = pmh_block_reduce<PMH_RED_SUM>(v1, lds);
-  if (threadIdx.x != 0) return;
-  double *s = bs + b * BS_NSLOT;
-  int    *q = bi + b * BI_NSLOT;
-  if (phase == 0) {
-    s[BS_RZ]     = v0;
-    s[BS_RR]     = v1;
-    s[BS_TOL]    = fmax(rtol * sqrt(v1), atol); // KSPConvergedDefault: rnorm <= max(rtol*||b||, atol), zero initial guess
-    q[BI_ITS]    = 0;
-    const int a  = (sqrt(v1) > s[BS_TOL]) ? 1 : 0;
-    q[BI_ACTIVE] = a;
-    if (a) {
-      int old = atomicAdd(nactive, 1);
-      (void)old;
-    }
-  } else if (phase == 1) {
-    if (q[BI_ACTIVE]) {
-      s[BS_PAP]   = v0;
-      s[BS_ALPHA] = s[BS_RZ] / v0;
-    }
-  } else {
-    if (q[BI_ACTIVE]) {
-      s[BS_RZNEW] = v0;
-      s[BS_RR]    = v1;
-      s[BS_BETA]  = v0 / s[BS_RZ];
-      s[BS_RZ]    = v0;
-      q[BI_ITS]   = it + 1;
-      if (sqrt(v1) <= s[BS_TOL] || it + 1 >= max_it || !(v1 == v1)) {
-        q[BI_ACTIVE] = 0;
-        atomicSub(nactive, 1);
-      }
-    }
+  const double rzn  = seg_total(partB + bb * wgs, wgs, lds);
+  const double rr   = seg_total(partB + ld + bb * wgs, wgs, lds);
+  const double beta = rzn / BSQ(bs, q, bb, 0);
+  const bool   conv = (sqrt(rr) <= BSQ(bs, q, bb, 1)) || (it + 1 >= max_it) || !(rr == rr);
+  if (!conv) {
+    SEG_LOOP(i, b, rs, wgs) p[i] = z[i] + beta * p[i];
+  }
+  if (w == 0 && threadIdx.x == 0) {
+    BSQ(bs, q ^ 1, bb, 0) = rzn;
+    BIQ(bi, q ^ 1, bb, 0) = conv ? 0 : 1;
+    BIQ(bi, q ^ 1, bb, 1) = it + 1;
+    if (conv && atomicSub(nactive, 1) == 1) *done = 1; // last active block: later launches of this solve are no-ops
   }
 }
 
@@ -341,7 +349,10 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   pmh_matinv M   = new pmh_matinv_s();
   M->K = K, M->ctx = ctx, M->n = K->n, M->nblocks = K->nblocks;
   M->rtol = rtol, M->atol = atol, M->max_it = max_it, M->jacobi = jacobi;
-  M->wgs          = std::max(1, std::min(256, PMH_MAX_VEC_BLOCKS / K->nblocks));
+  int maxrows = 0;
+  for (int b = 0; b < K->nblocks; b++) maxrows = std::max(maxrows, K->rowstart[b + 1] - K->rowstart[b]);
+  // >= 4 rows per lane, at most 256 partials per block, at most the resident-grid cap over all blocks
+  M->wgs = std::max(1, std::min(std::min(256, PMH_MAX_VEC_BLOCKS / K->nblocks), (maxrows + 1023) / 1024));
   M->last_max_its = 0;
   M->total_spmv   = 0;
   M->kdim         = 0;
@@ -353,9 +364,11 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->p));
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->Ap));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * 2 * (size_t)M->nblocks * M->wgs, (void **)&M->d_part));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)M->nblocks * BS_NSLOT, (void **)&M->d_bs));
-  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)M->nblocks * BI_NSLOT, (void **)&M->d_bi));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 2 * (size_t)M->nblocks * M->wgs, (void **)&M->d_partB));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 4 * (size_t)M->nblocks, (void **)&M->d_bs));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * 4 * (size_t)M->nblocks, (void **)&M->d_bi));
   PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_nactive));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_done));
   PMH_HIP(hipHostMalloc((void **)&M->h_nactive, sizeof(int), hipHostMallocMapped));
   if (M->n > 0) {
     hipLaunchKernelGGL(k_extract_dinv, dim3(pmh_vec_grid(M->n)), dim3(PMH_BLOCK), 0, ctx->stream, M->n, K->K->d_rowptr, K->K->d_col, K->K->d_val, jacobi, M->dinv);
@@ -409,6 +422,8 @@ extern "C" int pmh_matinv_destroy(pmh_matinv M)
   pmh_free(ctx, M->p);
   pmh_free(ctx, M->Ap);
   pmh_free(ctx, M->d_part);
+  pmh_free(ctx, M->d_partB);
+  pmh_free(ctx, M->d_done);
   pmh_free(ctx, M->d_bs);
   pmh_free(ctx, M->d_bi);
   pmh_free(ctx, M->d_nactive);
@@ -432,17 +447,21 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   }
   PMH_HIP(hipMemsetAsync(M->d_nactive, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
-  hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 0, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, 0, M->max_it);
+  hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(PMH_BLOCK), 0, st, nb, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->d_done, M->rtol, M->atol);
+  hipLaunchKernelGGL(k_cg_init_done, dim3(1), dim3(1), 0, st, (const int *)M->d_nactive, M->d_done);
   PMH_HIP(hipGetLastError());
+  pmh_spmv_epi epi;
+  memset(&epi, 0, sizeof(epi));
+  epi.kind = PMH_EPI_NONE;
+  epi.halt = M->d_done; // once every block has converged the remaining enqueued launches return at once
   int it = 0, next_check = (M->last_max_its > 8) ? (M->last_max_its - 2) : 4;
   while (it < M->max_it) {
-    PMH_CHK(pmh_csr_mult(M->K->K, M->p, M->Ap));
+    const int q = it & 1;
+    PMH_CHK(pmh_csr_spmv_launch(M->K->K, M->p, M->Ap, epi));
     M->total_spmv++;
-    hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->p, (const double *)M->Ap, M->d_part);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 1, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, it, M->max_it);
-    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_part, ld);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(nb), dim3(PMH_BLOCK), 0, st, 2, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->h_nactive, M->rtol, M->atol, it, M->max_it);
-    hipLaunchKernelGGL(k_cg_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)M->d_nactive, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->z, M->p);
+    hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->p, (const double *)M->Ap, M->d_part);
+    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld);
+    hipLaunchKernelGGL(k_cg_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, it, M->max_it, M->d_bs, M->d_bi, M->d_nactive, M->d_done, (const double *)M->d_partB, ld, (const double *)M->z, M->p);
     PMH_HIP(hipGetLastError());
     it++;
     if (it >= next_check || it >= M->max_it) {
@@ -453,10 +472,10 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     }
   }
   // iteration counts per block
-  std::vector<int> bi((size_t)nb * BI_NSLOT);
+  std::vector<int> bi((size_t)4 * nb);
   PMH_CHK(pmh_memcpy_d2h(ctx, bi.data(), M->d_bi, sizeof(int) * bi.size()));
   int mx = 0;
-  for (int b = 0; b < nb; b++) mx = std::max(mx, bi[(size_t)b * BI_NSLOT + BI_ITS]);
+  for (int b = 0; b < nb; b++) mx = std::max(mx, std::max(bi[(size_t)(0 * nb + b) * 2 + 1], bi[(size_t)(1 * nb + b) * 2 + 1]));
   M->last_max_its = mx;
   if (M->kdim) { // u <- P_R u (in place through the scratch vector)
     PMH_CHK(matinv_project(M, u, M->d_fproj));
