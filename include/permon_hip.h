@@ -103,7 +103,7 @@ int pmh_op_max_eigenvalue(pmh_op op, double tol, int maxits, double *lambda, int
 /* ---- QPC box: struct _QPCOps slots (include/permon/private/qpcimpl.h:8-25) ------------------------- */
 /* lb / ub may be NULL (no bound of that kind).  n = local length of the constrained (sub)vector. */
 int pmh_qpc_box_project(pmh_ctx ctx, int n, const double *x, const double *lb, const double *ub, double *Px);     /* QPCProject_Box qpcbox.c:290-305 */
-int pmh_qpc_box_feas(pmh_ctx ctx, int n, const double *x, const double *d, const double *lb, const double *ub, double *alpha_host); /* QPCFeas_Box qpcbox.c:104-146 (+ MIN allreduce qpc.c:521 when a communicator is set) */
+int pmh_qpc_box_feas(pmh_ctx ctx, int n, const double *x, const double *d, const double *lb, const double *ub, double *alpha_host); /* QPCFeas_Box qpcbox.c:104-146; the MIN all-reduce of qpc.c:521 has no counterpart: constrained vectors are replicated */
 int pmh_qpc_box_grads(pmh_ctx ctx, int n, const double *x, const double *g, const double *lb, const double *ub, double astol, double *gf, double *gc); /* QPCGrads qpc.c:540-569 + QPCGrads_Box qpcbox.c:21-64 */
 int pmh_qpc_box_gradreduced(pmh_ctx ctx, int n, const double *x, const double *gf, const double *lb, const double *ub, double alpha, double *gr); /* QPCGradReduced qpc.c:589-615 + _Box qpcbox.c:68-100 */
 /* expands an index-set restricted bound (qpc->is, qpc.c:416-437) to a full-length bound with -inf/+inf elsewhere */

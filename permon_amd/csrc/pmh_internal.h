@@ -49,7 +49,7 @@ struct pmh_ctx_s {
   double     *h_scal; // pinned host mirror written by the finalise kernel
   // multi-GPU
   ncclComm_t comm;
-  int        rank, size;
+  int        rank, size, force_comm;
   double    *d_commbuf; // small staging buffer for scalar allreduces
 };
 
@@ -116,4 +116,3 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
-int pmh_scalar_allreduce(pmh_ctx ctx, int slot, int count, int op);                     // RCCL on d_scal (no-op for size 1)

@@ -151,11 +151,12 @@ int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int
   return PMH_SUCCESS;
 }
 
+// Vectors at this tier are either rank-local (primal blocks) or REPLICATED on every GPU (dual space): a dot product
+// is therefore complete locally and identical on every rank -- no MPI_Allreduce counterpart.
 extern "C" int pmh_vec_dot(pmh_ctx ctx, int n, const double *x, const double *y, double *result_host)
 {
   PMH_ARG(ctx && n >= 0 && result_host);
   PMH_CHK(pmh_k_dot_partials(ctx, n, x, y, 0));
-  PMH_CHK(pmh_scalar_allreduce(ctx, 0, 1, PMH_RED_SUM)); // VecDot's MPI_Allreduce (row-distributed vectors)
   return pmh_host_scalar(ctx, 0, result_host);
 }
 
@@ -264,7 +265,6 @@ extern "C" int pmh_qpc_box_feas(pmh_ctx ctx, int n, const double *x, const doubl
     nb = 0;
   }
   PMH_CHK(pmh_finalize_partials(ctx, ctx->d_partials, ctx->partials_cap, nb, 1, ops, 0));
-  PMH_CHK(pmh_scalar_allreduce(ctx, 0, 1, PMH_RED_MIN)); // qpc.c:521 MPI_Allreduce(MIN)
   return pmh_host_scalar(ctx, 0, alpha_host);
 }
 
