@@ -218,3 +218,27 @@ def test_ex3_goldens_on_gpu(ctx, goldens):
     assert (s2.iteration, s2.reason, s2.inner_iter_accu) == (outer["iterations"], outer["reason"], outer["inner_iterations"])
     i2 = s2.inner
     assert (i2.reason, i2.nmv, i2.ncg, i2.nexp, i2.nprop) == (inner["reason"], inner["nmv"], inner["ncg"], inner["nexp"], inner["nprop"])
+
+
+def test_config3_shape_64_subdomains_dense_coarse_solve(ctx, oracle):
+    """BASELINE configs[3] in miniature: 4x4x4 = 64 subdomains packed on one GPU (one concatenated block-diagonal CSR,
+    64 independent block-CG solves per K^+ apply), G NOT orthonormalised => the coarse problem is the dense 384 x 384
+    (GG')^{-1} applied on the device, SMALXE penalty term rho*G'G, inner MPGP with its own power method."""
+    f = pa.CubeFeti((4, 4, 4), 1, contact=True)
+    assert f.nsub == 64
+    G, e = f.coarse(orthonormalize=False)
+    assert G.shape[0] == 384
+    Fd, pfo, d, lam_t, b_bar, lb_new = _oracle_dual(oracle, f, G, e, False)
+    n = f.n_lambda
+    A_or = oracle.Op(n, fn=lambda x: pfo.P(Fd @ pfo.P(x)))
+    ref = oracle.smalxe(A_or, pfo.P(b_bar), np.zeros(n), oracle.Box(n, lb=lb_new), pfo)
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=False, kplus_rtol=1e-13)
+    st = q.solve_smalxe()
+    assert st.reason == ref["reason"] and st.reason > 0
+    assert st.iteration == ref["iteration"]
+    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(3, ref["inner_iter_accu"] // 25)
+    # two solutions of an ill-conditioned dual QP, each converged to rtol 1e-5: they agree to a few 1e-3
+    assert np.linalg.norm(q.lam.to_numpy() - ref["u"]) <= 5e-3 * np.linalg.norm(ref["u"])
+    # G lambda = e to the solver tolerance (equality constraint of the dual QP)
+    lam = q.dual_solution()
+    assert np.linalg.norm(G @ lam - e) <= 1e-4 * max(1.0, np.linalg.norm(e))
