@@ -141,6 +141,9 @@ typedef struct {
   int    monitor;      /* record the QPSMonitorDefault_MPGP trace (mpgp.c:21-34) */
   int    unfused;      /* 1: run the literal one-kernel-per-PETSc-call sequence (every variant supports it);
                           0: std expansion + fixed length without fallback takes the fused kernels */
+  int    distributed;  /* 1: x, b, lb, ub are ROW-DISTRIBUTED over the ranks of the communicator (PETSc MPI Vec layout):
+                          every dot / norm / min is completed with an RCCL all-reduce of the device scalars, replacing
+                          VecDot's and QPCFeas' MPI_Allreduce.  0: vectors are rank-local or replicated */
 } pmh_mpgp_opts;
 
 typedef struct {
@@ -231,6 +234,11 @@ int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *
 int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
 /* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */
 int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, double *y);
+
+/* ---- dense-row SVM dual Hessian (BASELINE configs[4]) ---------------------------------------------------- */
+/* H = diag(y) X X' diag(y), X: n_local x d row-major in HBM (d <= 256), applied as two GEMV passes; with a
+   communicator the samples are sharded by rows and w = X'(y o a) is all-reduced (d doubles) between the passes */
+int pmh_op_create_svm_dual(pmh_ctx ctx, int n_local, int d, const double *X_dev, const double *y_dev, pmh_op *op);
 
 /* ---- QPS SMALXE (src/qps/impls/smalxe/smalxe.c) -------------------------------------------------------- */
 typedef struct {

@@ -23,7 +23,7 @@ class MpgpOpts(C.Structure):
         ("bchop_tol", C.c_double), ("astol", C.c_double),
         ("exptype", C.c_int), ("explengthtype", C.c_int),
         ("resetalpha", C.c_int), ("fallback", C.c_int), ("fallback2", C.c_int),
-        ("monitor", C.c_int), ("unfused", C.c_int),
+        ("monitor", C.c_int), ("unfused", C.c_int), ("distributed", C.c_int),
     ]
 
 
@@ -157,6 +157,7 @@ _PROTOS = {
     "pmh_matinv_last_iterations": [vp, c_int_p, C.POINTER(C.c_longlong)],
     "pmh_op_create_feti_dual": [vp, vp, C.POINTER(vp)],
     "pmh_pc_dual_lumped_apply": [vp, vp, vp, vp],
+    "pmh_op_create_svm_dual": [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
     "pmh_smalxe_default_opts": [C.POINTER(SmalxeOpts)],
     "pmh_smalxe_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(SmalxeOpts), C.POINTER(vp)],
     "pmh_smalxe_destroy": [vp],

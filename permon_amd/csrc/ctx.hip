@@ -30,6 +30,7 @@ extern "C" int pmh_init(int device, pmh_ctx *out)
   c->comm    = nullptr;
   c->rank    = 0;
   c->size    = 1;
+  c->dist_scalars = 0;
   c->force_comm = getenv("PMH_COMM_FORCE") ? 1 : 0; // testing: keep the RCCL calls on a 1-rank communicator
   PMH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PMH_HIP(hipEventCreate(&c->ev0));

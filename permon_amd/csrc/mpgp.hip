@@ -369,7 +369,9 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->alpha_user = s->o.alpha_user;
   if (!s->o.alpha_direct) { // QPS_ARG_MULTIPLE mpgp.c:417-422
     if (s->maxeig == PMH_DECIDE) {
-      int rc = pmh_op_max_eigenvalue(A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr);
+      ctx->dist_scalars = s->o.distributed;
+      int rc            = pmh_op_max_eigenvalue(A, s->o.maxeig_tol, s->o.maxeig_iter, &s->maxeig, nullptr);
+      ctx->dist_scalars = 0;
       if (rc) {
         delete s;
         return rc;
@@ -786,7 +788,7 @@ static int solve_fused(pmh_mpgp s)
   auto k_prop_host = k_step_update<true, false>;
   // the device-side CG chain needs the default convergence test (its constants go to the kernels) and a CSR operator
   const int SPEC_BATCH = 16;
-  bool      can_spec   = s->csr && !s->cvg && !getenv("PMH_MPGP_NO_SPEC");
+  bool      can_spec   = s->csr && !s->cvg && !s->o.distributed && !getenv("PMH_MPGP_NO_SPEC");
   pmh_spec_args sa     = nosa;
   if (can_spec) {
     if (!s->d_ctl) {
@@ -889,7 +891,10 @@ extern "C" int pmh_mpgp_solve(pmh_mpgp s)
 {
   PMH_ARG(s);
   s->t_step.clear(), s->t_gp.clear(), s->t_gf.clear(), s->t_gc.clear(), s->t_alpha.clear();
-  return use_fused(s) ? solve_fused(s) : solve_unfused(s);
+  s->ctx->dist_scalars = s->o.distributed;
+  int rc               = use_fused(s) ? solve_fused(s) : solve_unfused(s);
+  s->ctx->dist_scalars = 0;
+  return rc;
 }
 
 extern "C" int pmh_mpgp_run_fixed(pmh_mpgp s, int iters)

@@ -51,6 +51,7 @@ struct pmh_ctx_s {
   ncclComm_t comm;
   int        rank, size, force_comm;
   double    *d_commbuf; // small staging buffer for scalar allreduces
+  int        dist_scalars; // set while a solver with row-distributed vectors runs: finalised scalars are all-reduced
 };
 
 // ---- CSR -----------------------------------------------------------------------------------------------

@@ -62,6 +62,16 @@ int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nbloc
   for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base, halt, post_inc);
   PMH_HIP(hipGetLastError());
+  if (ctx->dist_scalars && ctx->comm && (ctx->size > 1 || ctx->force_comm)) {
+    // row-distributed vectors: complete the reductions across ranks (VecDot / VecNorm / QPCFeas MPI_Allreduce)
+    // as ONE grouped RCCL launch over the K device scalars, then refresh the pinned host mirror
+    if (halt) return pmh_set_error(PMH_ERR_STATE, "the speculative device-side chain is not available with row-distributed vectors");
+    PMH_NCCL(ncclGroupStart());
+    for (int k = 0; k < K; k++)
+      PMH_NCCL(ncclAllReduce(ctx->d_scal + scal_base + k, ctx->d_scal + scal_base + k, 1, ncclDouble, ops[k] == PMH_RED_MIN ? ncclMin : ncclSum, ctx->comm, ctx->stream));
+    PMH_NCCL(ncclGroupEnd());
+    PMH_HIP(hipMemcpyAsync(ctx->h_scal + scal_base, ctx->d_scal + scal_base, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+  }
   return PMH_SUCCESS;
 }
 

@@ -161,3 +161,14 @@ def PCDualLumpedOp(B, K):
         check(ctx.L.pmh_pc_dual_lumped_apply(B.h, K.h, xp, yp))
 
     return Op.shell(ctx, B.n_lambda, fn)
+
+
+def MatCreateSVMDual(ctx, X, y):
+    """Matrix-free H = diag(y) X X' diag(y) of the hinge-loss SVM dual (BASELINE configs[4]); X: (n_local, d) row-major."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    Xd = Vec.from_numpy(ctx, X.ravel())
+    yd = Vec.from_numpy(ctx, y)
+    h = C.c_void_p()
+    check(ctx.L.pmh_op_create_svm_dual(ctx.h, n, d, Xd.p, yd.p, C.byref(h)))
+    return Op(ctx, h, n, keep=[Xd, yd])

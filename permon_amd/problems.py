@@ -6,7 +6,7 @@ CSR arrays (int32 indices, fp64 values) + vectors.  No solver code lives here.
 """
 import numpy as np
 
-__all__ = ["ex1", "ex2", "ex3_primal", "jbearing2", "laplace2d_box", "laplace2d_csr"]
+__all__ = ["ex1", "ex2", "ex3_primal", "jbearing2", "laplace2d_box", "laplace2d_csr", "svm_dual"]
 
 
 def _fobst(i, n):
@@ -198,3 +198,15 @@ def laplace2d_box(nx, ny, variant="obstacle", seed=20260515):
     else:
         raise ValueError(variant)
     return dict(n=n, rowptr=rowptr, col=col, val=val, b=b, lb=lb, ub=ub, x0=np.zeros(n))
+
+
+def svm_dual(N, d=64, C=1.0, seed_x=7, seed_w=8):
+    """BASELINE.json configs[4]: PermonSVM-style hinge-loss dual without bias term,
+    min 1/2 a'Ha - 1'a, 0 <= a <= C, H = diag(y) X X' diag(y) applied matrix-free.
+    X in R^{N x d} i.i.d. N(0,1) (default_rng(seed_x)), w* ~ N(0,1) (default_rng(seed_w)), y = sign(X w* + 0.1 N(0,1))."""
+    rng = np.random.default_rng(seed_x)
+    X = rng.standard_normal((N, d))
+    w = np.random.default_rng(seed_w).standard_normal(d)
+    y = np.sign(X @ w + 0.1 * rng.standard_normal(N))
+    y[y == 0] = 1.0
+    return dict(n=N, d=d, X=X, y=y, b=np.ones(N), lb=np.zeros(N), ub=np.full(N, float(C)), x0=np.zeros(N))

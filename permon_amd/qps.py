@@ -143,6 +143,10 @@ class QPS:
     def MPGPSetUnfused(self, flag=True):
         self._mo().unfused = int(flag)
 
+    def MPGPSetDistributed(self, flag=True):
+        """x, b, lb, ub are row-distributed over the communicator's ranks (PETSc MPI Vec layout)."""
+        self._mo().distributed = int(flag)
+
     def MonitorSet(self, flag=True):  # QPSMonitorSet(qps, QPSMonitorDefault, ...)
         self._mo().monitor = int(flag)
 
