@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="feti", choices=["feti", "c2"])
+    ap.add_argument("--workload", default="feti", choices=["feti", "c2", "svm"])
+    ap.add_argument("--svm-n", type=int, default=5000000, help="svm: total number of samples (configs[4]: 5 M x 64)")
     ap.add_argument("--grid", type=int, default=3162, help="c2: nx = ny of the 5-pt Laplacian")
     ap.add_argument("--variant", default="obstacle", choices=["obstacle", "twosided"])
     ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
@@ -157,6 +158,82 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
         except Exception as e:  # noqa: BLE001 - the baseline leg must not kill the GPU number
             res["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": host_threads(), "kind": "port", "sample": "failed: %r" % (e,)}
     return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[4]: PermonSVM-style hinge-loss dual, dense-row Hessian, samples sharded by rows over the GPUs
+# ------------------------------------------------------------------------------------------------------------------
+def run_svm(ctx, a, steps, warmup, rank, world, dist):
+    import permon_amd as pa
+    from permon_amd import problems as P
+
+    t0 = time.time()
+    N, d = a.svm_n, 64
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    # every rank draws the same stream and keeps its row slice (chunked to bound host memory)
+    rng = np.random.default_rng(7)
+    w_true = np.random.default_rng(8).standard_normal(d)
+    X = np.empty((hi - lo, d))
+    y = np.empty(hi - lo)
+    chunk = 500000
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        Xc = rng.standard_normal((e - s, d))
+        yc = np.sign(Xc @ w_true + 0.1 * rng.standard_normal(e - s))
+        a0, a1 = max(s, lo), min(e, hi)
+        if a1 > a0:
+            X[a0 - lo:a1 - lo] = Xc[a0 - s:a1 - s]
+            y[a0 - lo:a1 - lo] = yc[a0 - s:a1 - s]
+    y[y == 0] = 1.0
+    n = hi - lo
+    H = pa.MatCreateSVMDual(ctx, X, y)
+    del X
+    qp = pa.QP(ctx)
+    qp.SetOperator(H)
+    qp.SetRhs(ctx.vec_from(np.ones(n)))
+    x = ctx.vec(n)
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec(n), ctx.vec_from(np.ones(n)))
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    qps.MPGPSetDistributed(world > 1)
+    qps.SetUp()
+    t_setup = time.time() - t0
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    qps.RunFixed(warmup)
+    x.set(0.0)
+    pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
+    barrier()
+    t1 = time.perf_counter()
+    st = qps.RunFixed(steps)
+    barrier()
+    dt = time.perf_counter() - t1
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    b_H = 2.0 * 8 * n * d + 40.0 * n
+    return {
+        "value": steps / dt, "ms_per_step": dt / steps * 1e3,
+        "workload": "configs[4]: PermonSVM-style hinge-loss dual, N=%d samples x d=%d dense fp64 (%.2f GB), H = diag(y) X X' diag(y) matrix-free, MPGP box 0<=a<=1" % (N, d, N * d * 8 / 1e9),
+        "parallelism": "samples sharded by rows over %d GPU(s); w all-reduce (d doubles) per Hessian apply; scalar all-reduces for the MPGP reductions" % world,
+        "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
+        "setup_seconds": round(t_setup, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_svm_xt + k_svm_x (two GEMV passes over X)", "achieved": st.nmv * b_H / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": st.nmv * b_H / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_H,
+                     "note": "achieved = Hessian-apply bytes (2*8*N*d + 40*N per apply, local rows) x applies / WHOLE step time (vector phases included)"},
+    }
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -303,6 +380,16 @@ def main():
         }
         if "cpu_baseline" in r:
             out["cpu_baseline"] = r["cpu_baseline"]
+    elif a.workload == "svm":
+        steps, warmup = a.steps or 100, a.warmup if a.warmup is not None else 10
+        r = run_svm(ctx, a, steps, warmup, rank, world, dist)
+        out = {
+            "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "setup_seconds": r["setup_seconds"]},
+            "roofline": r["roofline"],
+        }
     else:
         steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 2
         r, f, G, b_dual, lb_dual = run_feti(ctx, a, steps, warmup, rank, world, dist)

@@ -1,0 +1,190 @@
+"""Edge cases the reference's semantics imply, and size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import permon_amd as pa
+from permon_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def _mpgp(ctx, A, b, x0, lb, ub, unfused=False, monitor=False, **tol):
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(A))
+    qp.SetRhs(ctx.vec_from(b))
+    x = ctx.vec_from(x0)
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec_from(lb) if lb is not None else None, ctx.vec_from(ub) if ub is not None else None)
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    qps.SetTolerances(**tol)
+    qps.MPGPSetUnfused(unfused)
+    qps.MonitorSet(monitor)
+    st = qps.Solve()
+    return qps, st, x.to_numpy()
+
+
+def _oracle_mpgp(oracle, M, b, x0, lb, ub, **opts):
+    A = oracle.Csr.from_scipy(M)
+    return oracle.mpgp(oracle.Op(M.shape[0], csr=A), b, x0, oracle.Box(M.shape[0], lb=lb, ub=ub), **opts)
+
+
+def _csr(ctx, M):
+    M = M.tocsr()
+    M.sort_indices()
+    return pa.CsrMat(ctx, M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+
+
+@pytest.mark.parametrize("unfused", [False, True])
+def test_tiny_and_degenerate_problems(ctx, oracle, unfused):
+    # n = 1
+    M = sp.csr_matrix(np.array([[2.0]]))
+    for b, lb in ((np.array([1.0]), np.array([-5.0])), (np.array([-3.0]), np.array([0.0]))):
+        qps, st, x = _mpgp(ctx, _csr(ctx, M), b, np.zeros(1), lb, None, unfused=unfused)
+        ref = _oracle_mpgp(oracle, M, b, np.zeros(1), lb, None)
+        assert (st.iteration, st.reason, st.nmv) == (ref["iteration"], ref["reason"], ref["nmv"])
+        assert np.allclose(x, ref["x"], atol=1e-14)
+    # zero right-hand side, x0 = 0 feasible: converged at iteration 0 by the absolute tolerance (qps.c:697-699)
+    n = 50
+    M = sp.diags([-1, 2.5, -1], [-1, 0, 1], shape=(n, n)).tocsr()
+    qps, st, x = _mpgp(ctx, _csr(ctx, M), np.zeros(n), np.zeros(n), -np.ones(n), np.ones(n), unfused=unfused)
+    assert st.iteration == 0 and st.reason == 3 and st.nmv == 1 and not x.any()
+    # infeasible initial guess is projected first (mpgp.c:497).  lb = ub: the reference tests the LOWER bound first
+    # (`else if`, qpcbox.c:42-47), so a pinned unknown with g < 0 is released upwards -- the quirk is reproduced, not
+    # fixed (hard part 3): the HIP path must do exactly what the restated reference does.
+    lb = np.linspace(-1, 1, n)
+    qps, st, x = _mpgp(ctx, _csr(ctx, M), np.ones(n), 10 * np.ones(n), lb, lb.copy(), unfused=unfused, max_it=200)
+    ref = _oracle_mpgp(oracle, M, np.ones(n), 10 * np.ones(n), lb, lb.copy(), max_it=200)
+    assert (st.reason, st.iteration, st.nmv, st.ncg, st.nexp, st.nprop) == (ref["reason"], ref["iteration"], ref["nmv"], ref["ncg"], ref["nexp"], ref["nprop"])
+    assert np.max(np.abs(x - ref["x"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["x"])))
+    # a genuinely pinned problem (g > 0 everywhere at the bound) stays on the bound
+    qps, st, x = _mpgp(ctx, _csr(ctx, M), -np.ones(n), 10 * np.ones(n), np.ones(n), np.ones(n), unfused=unfused)
+    ref = _oracle_mpgp(oracle, M, -np.ones(n), 10 * np.ones(n), np.ones(n), np.ones(n))
+    assert np.array_equal(x, np.ones(n)) and np.array_equal(ref["x"], np.ones(n)) and st.iteration == ref["iteration"]
+
+
+def test_empty_rows_and_ragged_matrix(ctx, oracle):
+    """CSR with empty rows, a dense row longer than the LDS tile and rows of very different lengths."""
+    rng = np.random.default_rng(4)
+    n = 6000
+    M = sp.random(n, n, density=0.0008, random_state=5, format="lil")
+    M[17, :] = rng.standard_normal(n)  # one row of 6000 > 2048-nnz tile
+    M[100:140, :] = 0  # empty rows
+    M = M.tocsr()
+    M.eliminate_zeros()
+    M.sort_indices()
+    x = rng.standard_normal(n)
+    A = _csr(ctx, M)
+    y = ctx.vec(n)
+    A.mult(ctx.vec_from(x), y)
+    ref = oracle.spmv(oracle.Csr.from_scipy(M), x)
+    assert np.max(np.abs(y.to_numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert not y.to_numpy()[100:140].any()
+    A.mult_transpose(ctx.vec_from(x), y)
+    ref = oracle.spmv_transpose(oracle.Csr.from_scipy(M), x)
+    assert np.max(np.abs(y.to_numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    z = rng.standard_normal(n)
+    A.mult_add(ctx.vec_from(x), ctx.vec_from(z), y)
+    assert np.max(np.abs(y.to_numpy() - (z + oracle.spmv(oracle.Csr.from_scipy(M), x)))) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_bad_inputs_fail_loudly(ctx):
+    with pytest.raises(pa.PermonHipError):
+        pa.CsrMat(ctx, 3, 3, [0, 1, 2, 3], [0, 1, 7], [1.0, 1.0, 1.0])  # column index out of range
+    with pytest.raises(pa.PermonHipError):
+        pa.CsrMat(ctx, 3, 3, [0, 2, 1, 3], [0, 1, 2], [1.0, 1.0, 1.0])  # rowptr not monotone
+    with pytest.raises(pa.PermonHipError):
+        pa.MatGluing(ctx, 4, 2, [0, 5], [0, 1], [1.0, -1.0])  # leaf row out of range
+    qps = pa.QPS(ctx)
+    with pytest.raises(ValueError):
+        qps.SetType("nonsense")
+    with pytest.raises(ValueError):
+        qps.MPGPSetOperatorMaxEigenvalueIterations(1)  # mpgp.c:1088 "Argument must be > 1"
+
+
+@pytest.mark.parametrize("exp,length", [("gf", "fixed"), ("g", "fixed"), ("gfgr", "opt"), ("ggr", "optapprox"), ("std", "bb"), ("projcg", "fixed")])
+def test_expansion_variants_two_sided_vs_oracle(ctx, oracle, exp, length):
+    p = P.jbearing2(12, 14)
+    M = sp.csr_matrix((p["val"], p["col"], p["rowptr"]), shape=(p["n"], p["n"]))
+    ub = np.full(p["n"], 0.05)  # tight upper bound so both bound kinds become active
+    A = _csr(ctx, M)
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(A))
+    qp.SetRhs(ctx.vec_from(p["b"]))
+    x = ctx.vec_from(p["x0"])
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec_from(p["lb"]), ctx.vec_from(ub))
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    qps.SetTolerances(rtol=1e-7)
+    qps.MPGPSetExpansionType(exp, length)
+    st = qps.Solve()
+    ref = _oracle_mpgp(oracle, M, p["b"], p["x0"], p["lb"], ub, rtol=1e-7, exptype=exp, explengthtype=length)
+    assert (st.iteration, st.nmv, st.ncg, st.nexp, st.nprop, st.reason) == (ref["iteration"], ref["nmv"], ref["ncg"], ref["nexp"], ref["nprop"], ref["reason"])
+    assert np.max(np.abs(x.to_numpy() - ref["x"])) <= 1e-10
+    assert np.any(np.abs(ref["x"] - ub) <= 1e-14) and np.any(np.abs(ref["x"] - p["lb"]) <= 1e-14)
+
+
+@pytest.mark.parametrize("fallback2", [False, True])
+def test_fallback_options_vs_oracle(ctx, oracle, fallback2):
+    p = P.ex1(100)
+    M = sp.csr_matrix((p["val"], p["col"], p["rowptr"]), shape=(100, 100))
+    A = _csr(ctx, M)
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(A))
+    qp.SetRhs(ctx.vec_from(p["b"]))
+    x = ctx.vec_from(p["x0"])
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec_from(p["lb"]), None)
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("mpgp")
+    qps.MPGPSetExpansionType("gf", "opt")
+    qps.MPGPSetFallback(fallback=not fallback2, fallback2=fallback2)
+    st = qps.Solve()
+    ref = _oracle_mpgp(oracle, M, p["b"], p["x0"], p["lb"], None, exptype="gf", explengthtype="opt", fallback=int(not fallback2), fallback2=int(fallback2))
+    assert (st.iteration, st.nmv, st.ncg, st.nexp, st.nprop, st.nfinc, st.nfall, st.reason) == (
+        ref["iteration"], ref["nmv"], ref["ncg"], ref["nexp"], ref["nprop"], ref["nfinc"], ref["nfall"], ref["reason"])
+
+
+def test_full_size_config1_properties(ctx):
+    """BASELINE configs[1] at full size (10 M rows, 50 M nnz): properties that need no oracle run.
+    SpMV symmetry x'(Ay) = y'(Ax), linearity; fused and unfused MPGP drivers take the same steps and agree."""
+    g = 3162
+    p = P.laplace2d_box(g, g, variant="twosided")
+    n = p["n"]
+    A = pa.CsrMat(ctx, n, n, p["rowptr"], p["col"], p["val"])
+    assert (n, A.nnz) == (9998244, 49978572)
+    rng = np.random.default_rng(0)
+    xv, yv = ctx.vec_from(rng.standard_normal(n)), ctx.vec_from(rng.standard_normal(n))
+    Ax, Ay, Axy = ctx.vec(n), ctx.vec(n), ctx.vec(n)
+    A.mult(xv, Ax)
+    A.mult(yv, Ay)
+    assert xv.dot(Ay) == pytest.approx(yv.dot(Ax), rel=1e-12)
+    s = xv.copy()
+    s.axpy(2.5, yv)
+    A.mult(s, Axy)
+    Axy.axpy(-1.0, Ax)
+    Axy.axpy(-2.5, Ay)
+    assert Axy.norm() <= 1e-12 * (Ax.norm() + 2.5 * Ay.norm())
+    res = {}
+    for unfused in (False, True):
+        qps, st, x = _mpgp(ctx, A, p["b"], p["x0"], p["lb"], p["ub"], unfused=unfused, monitor=True, max_it=40, rtol=1e-30)
+        steps, gp, gf, gc, alpha = qps.MPGPGetTrace()
+        res[unfused] = (steps, gp, x)
+        assert st.reason == -3 and st.iteration == 41  # DIVERGED_ITS at i > max_it (strict, qps.c:688)
+        assert x.min() >= -1.0 - 1e-14 and x.max() <= 1.0 + 1e-14  # iterates stay feasible
+        assert st.nmv == 1 + st.ncg + 2 * st.nexp + st.nprop
+    assert res[False][0] == res[True][0]
+    assert np.allclose(res[False][1], res[True][1], rtol=1e-9)
+    assert np.linalg.norm(res[False][2] - res[True][2]) <= 1e-9 * np.linalg.norm(res[True][2])
