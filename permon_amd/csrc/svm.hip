@@ -84,8 +84,81 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x(int n, int d, const double 
   }
 }
 
+// ---- d == 64 fast path: 16-byte loads, two rows per wave-instruction (lanes 0-31 row r, lanes 32-63 row r+1), 4-fold unroll ----
+#define SVM_UNR 4
+typedef double dbl2 __attribute__((ext_vector_type(2))); // native 16-byte vector: accepted by the non-temporal builtins
+__global__ __launch_bounds__(PMH_BLOCK) void k_svm_xt64(int n, const double *__restrict__ X, const double *__restrict__ y, const double *__restrict__ a, double *__restrict__ part)
+{
+  __shared__ double lds[PMH_BLOCK / 64][64];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l2 = lane & 31;
+  const long long   gw = (long long)blockIdx.x * (PMH_BLOCK / 64) + wave, nw = (long long)gridDim.x * (PMH_BLOCK / 64);
+  double            a0 = 0.0, a1 = 0.0;
+  for (long long r0 = gw * 2 * SVM_UNR; r0 < n; r0 += nw * 2 * SVM_UNR) {
+    dbl2   v[SVM_UNR];
+    double s[SVM_UNR];
+#pragma unroll
+    for (int u = 0; u < SVM_UNR; u++) {
+      const long long i = r0 + 2 * u + half;
+      const bool      ok = i < n;
+      v[u] = ok ? __builtin_nontemporal_load((const dbl2 *)(X + (size_t)i * 64) + l2) : dbl2{0.0, 0.0};
+      s[u] = ok ? y[i] * a[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < SVM_UNR; u++) {
+      a0 += s[u] * v[u].x;
+      a1 += s[u] * v[u].y;
+    }
+  }
+  // lanes l and l+32 hold the same two columns (2*l2, 2*l2+1) of different rows: fold, then across the 4 waves in order
+  a0 += __shfl_down(a0, 32, 64);
+  a1 += __shfl_down(a1, 32, 64);
+  if (half == 0) {
+    lds[wave][2 * l2]     = a0;
+    lds[wave][2 * l2 + 1] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double v = lds[0][threadIdx.x];
+#pragma unroll
+    for (int wv = 1; wv < PMH_BLOCK / 64; wv++) v += lds[wv][threadIdx.x];
+    part[(size_t)blockIdx.x * 64 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64(int n, const double *__restrict__ X, const double *__restrict__ y, const double *__restrict__ w, double *__restrict__ Ha)
+{
+  const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l2 = lane & 31;
+  const long long gw = (long long)blockIdx.x * (PMH_BLOCK / 64) + wave, nw = (long long)gridDim.x * (PMH_BLOCK / 64);
+  const dbl2      wr = ((const dbl2 *)w)[l2];
+  for (long long r0 = gw * 2 * SVM_UNR; r0 < n; r0 += nw * 2 * SVM_UNR) {
+    dbl2 v[SVM_UNR];
+#pragma unroll
+    for (int u = 0; u < SVM_UNR; u++) {
+      const long long i = r0 + 2 * u + half;
+      v[u] = (i < n) ? __builtin_nontemporal_load((const dbl2 *)(X + (size_t)i * 64) + l2) : dbl2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < SVM_UNR; u++) {
+      const long long i = r0 + 2 * u + half;
+      double          s = v[u].x * wr.x + v[u].y * wr.y;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_down(s, o, 32);
+      if (l2 == 0 && i < n) Ha[i] = y[i] * s;
+    }
+  }
+}
+
 int SvmDualOp::mult(const double *a, double *Ha)
 {
+  if (d == 64 && n > 0) {
+    hipLaunchKernelGGL(k_svm_xt64, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, a, part);
+    hipLaunchKernelGGL(k_svm_colsum, dim3((d + 3) / 4), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
+    PMH_HIP(hipGetLastError());
+    PMH_CHK(pmh_comm_allreduce_sum(ctx, w, (size_t)d));
+    hipLaunchKernelGGL(k_svm_x64, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, (const double *)w, Ha);
+    PMH_HIP(hipGetLastError());
+    return PMH_SUCCESS;
+  }
   if (n == 0) return PMH_SUCCESS;
   hipLaunchKernelGGL(k_svm_xt, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, d, X, y, a, part);
   hipLaunchKernelGGL(k_svm_colsum, dim3((d + 3) / 4), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
