@@ -53,8 +53,15 @@ def parse():
     return ap.parse_args()
 
 
+_HOST_THREADS = None
+
+
 def host_threads():
-    """Threads the CPU baseline may really use: affinity mask capped by the cgroup CPU quota."""
+    """Threads the CPU baseline may really use: affinity mask capped by the cgroup CPU quota.  Evaluated once, before
+    any OpenMP runtime is loaded (libgomp reads OMP_NUM_THREADS at load time and may re-bind the main thread)."""
+    global _HOST_THREADS
+    if _HOST_THREADS is not None:
+        return _HOST_THREADS
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 quota (the GPU box: cpu.max = 1600000 100000 -> 16 CPUs of a 2 x 64-core EPYC 9575F)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -62,6 +69,8 @@ def host_threads():
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    _HOST_THREADS = cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     return cores
 
 
@@ -86,8 +95,6 @@ def cpu_baseline_c2(p, its):
     from oracle import oracle as O
 
     cores = host_threads()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
     A = O.Csr(p["n"], p["n"], p["rowptr"], p["col"], p["val"])
     op = O.Op(p["n"], csr=A, omp=True)
     box = O.Box(p["n"], lb=p["lb"], ub=p["ub"])
@@ -246,8 +253,6 @@ def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol):
     from oracle import oracle as O
 
     cores = host_threads()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
     K = O.Csr.from_scipy(f.K)
     Kplus = O.MatInv(K, f.block_rowstart, f.R, rtol=rtol, omp=True)
     pfo = O.Qppf(O.Csr.from_scipy(G), orthonormal=True)
@@ -334,6 +339,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
 
 def main():
     a = parse()
+    host_threads()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

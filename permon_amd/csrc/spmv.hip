@@ -92,7 +92,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nlaunch)
 // kernel.  MODE 1 double-buffers the LDS tile (one barrier per row block, 2 tiles of LDS), MODE 2 keeps one
 // tile (two barriers).  The next row block's val/col stream is issued before the current per-row phase.
 // NT: val/col are read exactly once per SpMV -> non-temporal loads keep them from evicting x out of L2.
-template <int EPI, int NNZB, int MODE, bool NT, bool NT2, int RL>
+template <int EPI, int NNZB, int MODE, bool NT, bool VL2, int RL>
 __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict__ rowblocks, int nrb, int chunk, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, EpiArgs a, double *__restrict__ part, int ld)
 {
   if (a.halt && *a.halt) return; // uniform: every workgroup reads the same flag
@@ -117,19 +117,40 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
   double v[ITEMS];
   int    r0 = 0, r1 = 0, s0 = 0, s1 = 0;
 
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef int    int2v __attribute__((ext_vector_type(2)));
   auto prefetch = [&](int bb) {
     r0 = rowblocks[bb], r1 = rowblocks[bb + 1];
     s0 = rowptr[r0], s1 = rowptr[r1];
-    if (s1 - s0 <= NNZB) {
+    if (s1 - s0 <= NNZB - (VL2 ? 1 : 0)) {
+      if (VL2) {
+        // 16-byte val / 8-byte col loads: start at the even index below s0 (arrays are padded by 2 entries)
+        const int s0a = s0 & ~1;
 #pragma unroll
-      for (int j = 0; j < ITEMS; j++) {
-        const int k = s0 + tid + j * PMH_BLOCK;
-        if (NT) {
-          c[j] = (k < s1) ? __builtin_nontemporal_load(&col[k]) : -1;
-          v[j] = (k < s1) ? __builtin_nontemporal_load(&val[k]) : 0.0;
-        } else {
-          c[j] = (k < s1) ? col[k] : -1;
-          v[j] = (k < s1) ? val[k] : 0.0;
+        for (int j = 0; j < ITEMS / 2; j++) {
+          const int k  = s0a + 2 * (tid + j * PMH_BLOCK);
+          dbl2      vv = {0.0, 0.0};
+          int2v     cc = {-1, -1};
+          if (k < s1) {
+            vv = NT ? __builtin_nontemporal_load((const dbl2 *)(val + k)) : *(const dbl2 *)(val + k);
+            cc = NT ? __builtin_nontemporal_load((const int2v *)(col + k)) : *(const int2v *)(col + k);
+          }
+          c[2 * j]     = (k >= s0 && k < s1) ? cc.x : -1;
+          c[2 * j + 1] = (k + 1 < s1) ? cc.y : -1;
+          v[2 * j]     = vv.x;
+          v[2 * j + 1] = vv.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+          const int k = s0 + tid + j * PMH_BLOCK;
+          if (NT) {
+            c[j] = (k < s1) ? __builtin_nontemporal_load(&col[k]) : -1;
+            v[j] = (k < s1) ? __builtin_nontemporal_load(&val[k]) : 0.0;
+          } else {
+            c[j] = (k < s1) ? col[k] : -1;
+            v[j] = (k < s1) ? val[k] : 0.0;
+          }
         }
       }
     }
@@ -140,12 +161,22 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
   while (b < end) {
     const int cr0 = r0, cr1 = r1, cs0 = s0, cs1 = s1;
     const int nb  = b + W;
-    if (cs1 - cs0 <= NNZB) {
+    if (cs1 - cs0 <= NNZB - (VL2 ? 1 : 0)) {
       double *pr = prod[buf];
       if (MODE == 2) __syncthreads(); // previous row phase done before the tile is overwritten
+      if (VL2) {
+        const int sh = (cs0 & ~1) - cs0; // 0 or -1
 #pragma unroll
-      for (int j = 0; j < ITEMS; j++)
-        if (c[j] >= 0) pr[tid + j * PMH_BLOCK] = v[j] * x[c[j]];
+        for (int j = 0; j < ITEMS / 2; j++) {
+          const int k = sh + 2 * (tid + j * PMH_BLOCK);
+          if (c[2 * j] >= 0) pr[k] = v[2 * j] * x[c[2 * j]];
+          if (c[2 * j + 1] >= 0) pr[k + 1] = v[2 * j + 1] * x[c[2 * j + 1]];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++)
+          if (c[j] >= 0) pr[tid + j * PMH_BLOCK] = v[j] * x[c[j]];
+      }
       if (MODE != 0 && nb < end) prefetch(nb); // next block's stream in flight during this block's row phase
       __syncthreads();
       if (RL == 1) {
@@ -154,7 +185,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
           const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
           double    sum = 0.0;
           for (int k = k0; k < k1; k++) sum += pr[k];
-          epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+          epi_row<EPI, false>(r, sum, x, y, a, acc0, acc1, amin);
         }
       } else {
         // medium rows (e.g. 81 nnz/row elasticity blocks): RL lanes per row over the LDS tile + shuffle tree
@@ -168,7 +199,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
           }
 #pragma unroll
           for (int o = RL / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, RL);
-          if (r < cr1 && lane == 0) epi_row<EPI, (NT2)>(r, sum, x, y, a, acc0, acc1, amin);
+          if (r < cr1 && lane == 0) epi_row<EPI, false>(r, sum, x, y, a, acc0, acc1, amin);
         }
       }
       if (MODE == 1) buf ^= 1;
@@ -246,8 +277,10 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   A->ncols = ncols;
   A->nnz   = nnz;
   PMH_HIP(hipMalloc((void **)&A->d_rowptr, sizeof(int) * ((size_t)nrows + 1)));
-  PMH_HIP(hipMalloc((void **)&A->d_col, sizeof(int) * (size_t)(nnz ? nnz : 1)));
-  PMH_HIP(hipMalloc((void **)&A->d_val, sizeof(double) * (size_t)(nnz ? nnz : 1)));
+  PMH_HIP(hipMalloc((void **)&A->d_col, sizeof(int) * (size_t)(nnz + 2)));    // +2: the vector-load variant may touch one entry past the end
+  PMH_HIP(hipMalloc((void **)&A->d_val, sizeof(double) * (size_t)(nnz + 2)));
+  PMH_HIP(hipMemsetAsync(A->d_col + nnz, 0, sizeof(int) * 2, ctx->stream));
+  PMH_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * 2, ctx->stream));
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowptr, rowptr, sizeof(int) * ((size_t)nrows + 1)));
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_col, col, sizeof(int) * (size_t)nnz));
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_val, val, sizeof(double) * (size_t)nnz));
@@ -267,7 +300,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
     if (A->st_nnzb != 512 && A->st_nnzb != 1024 && A->st_nnzb != 2048 && A->st_nnzb != 4096) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: nnzb must be 512, 1024, 2048 or 4096");
     if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0, 1 or 2");
     std::vector<int> rb;
-    A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb, rb);
+    A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb - 1, rb); // -1: room for the aligned-down start of the 16-byte load variant
     PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowblocks, rb.data(), sizeof(int) * rb.size()));
     const int chunk = (A->n_rowblocks + 7) / 8; // row blocks per XCD

@@ -13,7 +13,7 @@ x = ctx.vec_from(np.random.default_rng(0).standard_normal(n))
 y = ctx.vec(n)
 bytes_ = 12.0 * va.size + 20.0 * n
 ref = None
-for nnzb, mode, nt in [(512,0,1),(512,2,1),(512,2,3),(1024,0,1),(1024,0,3),(1024,2,1),(1024,2,3),(2048,0,3),(2048,2,3)]:
+for nnzb, mode, nt in [(1024,2,1),(1024,2,3),(1024,0,1),(1024,0,3),(2048,0,1),(2048,0,3),(2048,2,3),(4096,0,3),(4096,2,3)]:
     os.environ["PMH_SPMV_TUNE"] = "%d,%d,%d" % (nnzb, mode, nt)
     try:
         A = pa.CsrMat(ctx, n, n, rp, ci, va)
