@@ -109,6 +109,14 @@ int pmh_qpc_box_gradreduced(pmh_ctx ctx, int n, const double *x, const double *g
 /* expands an index-set restricted bound (qpc->is, qpc.c:416-437) to a full-length bound with -inf/+inf elsewhere */
 int pmh_qpc_box_expand_is(pmh_ctx ctx, int n, int nis, const int *is_host, const double *bound_sub, double fill, double *bound_full);
 
+/* ---- post-solve: KKT residuals of a box-constrained QP -------------------------------------------------------- */
+/* QPComputeMissingBoxMultipliers (qp.c:828-893: lambda_lb = A x - b, lambda_ub = -(A x - b), both clipped at 0 when both
+   bounds exist) + the `r = ...` lines of QPViewKKT (qp.c:245-369) and QPCViewKKT_Box (qpcbox.c:333-427).
+   out[0] = ||A x - b - lambda_lb + lambda_ub||, out[1] = ||min(x-lb,0)||, out[2] = ||min(lambda_lb,0)||,
+   out[3] = |lambda_lb'(lb-x)|, out[4] = ||max(x-ub,0)||, out[5] = ||min(lambda_ub,0)||, out[6] = |lambda_ub'(x-ub)|,
+   out[7] = ||b||  (entries of an absent bound are 0).  work: device scratch of length n. */
+int pmh_qp_kkt_box(pmh_op A, const double *b, const double *x, const double *lb, const double *ub, double *work, double out_host[8]);
+
 /* ---- Vec kernels used by the path (PETSc VecAXPY/AYPX/WAXPY/Dot/Norm/Copy/Set/Scale) --------------- */
 int pmh_vec_axpy(pmh_ctx ctx, int n, double *y, double a, const double *x);                  /* y += a x */
 int pmh_vec_aypx(pmh_ctx ctx, int n, double *y, double a, const double *x);                  /* y = x + a y */

@@ -108,6 +108,7 @@ _PROTOS = {
     "pmh_qpc_box_grads": [vp, C.c_int, vp, vp, vp, vp, C.c_double, vp, vp],
     "pmh_qpc_box_gradreduced": [vp, C.c_int, vp, vp, vp, vp, C.c_double, vp],
     "pmh_qpc_box_expand_is": [vp, C.c_int, C.c_int, vp, vp, C.c_double, vp],
+    "pmh_qp_kkt_box": [vp, vp, vp, vp, vp, vp, c_double_p],
     "pmh_vec_axpy": [vp, C.c_int, vp, C.c_double, vp],
     "pmh_vec_aypx": [vp, C.c_int, vp, C.c_double, vp],
     "pmh_vec_waxpy": [vp, C.c_int, vp, C.c_double, vp, vp],

@@ -1,5 +1,6 @@
 // Generic operators (the PETSc Mat "mult slot" of the QP chain) and MatGetMaxEigenvalue.
 #include "pmh_internal.h"
+#include "reduce.h"
 
 struct CsrOp : pmh_op_s {
   pmh_csr A;
@@ -97,5 +98,62 @@ extern "C" int pmh_op_max_eigenvalue(pmh_op op, double tol, int maxits, double *
   if (rc) return rc;
   *lambda_out = lambda;
   if (its_out) *its_out = i;
+  return PMH_SUCCESS;
+}
+
+// ---- post-solve KKT residuals (QPViewKKT qp.c:245-369, QPCViewKKT_Box qpcbox.c:333-427, multipliers qp.c:828-893) ----
+__global__ __launch_bounds__(PMH_BLOCK) void k_kkt_box(long long n, const double *__restrict__ Ax, const double *__restrict__ b, const double *__restrict__ x, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ partials, int ld)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * PMH_BLOCK) {
+    const double bi = b[i], xi = x[i], r = Ax[i] - bi; // QPComputeLagrangianGradient without the box part
+    double       llb = 0.0, lub = 0.0;
+    if (lb) llb = r;
+    if (ub) lub = -r;
+    if (lb && ub) { // qp.c:874-881: VecPointwiseMax(.,0)
+      llb = (llb > 0.0) ? llb : 0.0;
+      lub = (lub > 0.0) ? lub : 0.0;
+    }
+    const double lg = r - llb + lub;
+    acc[0] += lg * lg;
+    if (lb) {
+      const double l = lb[i], d0 = xi - l, m0 = (d0 < 0.0) ? d0 : 0.0, m1 = (llb < 0.0) ? llb : 0.0;
+      acc[1] += m0 * m0;
+      acc[2] += m1 * m1;
+      acc[3] += llb * ((l <= -INFINITY) ? -1.0 : (l - xi)); // qpcbox.c:371-379
+    }
+    if (ub) {
+      const double u = ub[i], d0 = xi - u, m0 = (d0 > 0.0) ? d0 : 0.0, m1 = (lub < 0.0) ? lub : 0.0;
+      acc[4] += m0 * m0;
+      acc[5] += m1 * m1;
+      acc[6] += lub * ((u >= INFINITY) ? 1.0 : (xi - u)); // qpcbox.c:411-419
+    }
+    acc[7] += bi * bi;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    double r = pmh_block_reduce<PMH_RED_SUM>(acc[k], lds);
+    if (threadIdx.x == 0) partials[(size_t)k * ld + blockIdx.x] = r;
+  }
+}
+
+extern "C" int pmh_qp_kkt_box(pmh_op A, const double *b, const double *x, const double *lb, const double *ub, double *work, double out_host[8])
+{
+  PMH_ARG(A && b && x && work && out_host);
+  pmh_ctx   ctx = A->ctx;
+  const int n   = A->n;
+  PMH_CHK(A->mult(x, work));
+  const int ops[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int nb     = n > 0 ? pmh_vec_grid(n) : 0;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_kkt_box, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, (long long)n, (const double *)work, b, x, lb, ub, ctx->d_partials, ctx->partials_cap);
+    PMH_HIP(hipGetLastError());
+  }
+  PMH_CHK(pmh_finalize_partials(ctx, ctx->d_partials, ctx->partials_cap, nb, 8, ops, 32));
+  PMH_CHK(pmh_sync(ctx));
+  const double *s = ctx->h_scal + 32;
+  out_host[0] = sqrt(s[0]), out_host[1] = sqrt(s[1]), out_host[2] = sqrt(s[2]), out_host[3] = fabs(s[3]);
+  out_host[4] = sqrt(s[4]), out_host[5] = sqrt(s[5]), out_host[6] = fabs(s[6]), out_host[7] = sqrt(s[7]);
   return PMH_SUCCESS;
 }

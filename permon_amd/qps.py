@@ -209,6 +209,27 @@ class QPS:
         self.stats = st
         return st
 
+    def ViewKKT(self):
+        """The `r = ...` lines of -qp_chain_view_kkt for a box-constrained QP (QPViewKKT qp.c:245-369 + QPCViewKKT_Box
+        qpcbox.c:333-427), formatted exactly as the reference prints them."""
+        qp = self.qp
+        out = (C.c_double * 8)()
+        work = Vec(self.ctx, qp.A.n, zero=False)
+        check(self.L.pmh_qp_kkt_box(qp.A.h, qp.b.p, qp.x.p, _ptr(qp.lb), _ptr(qp.ub), work.p, out))
+        work.free()
+        r, normb = list(out)[:7], out[7]
+        name = "A*x - b" + (" - lambda_lb" if qp.lb is not None else "") + (" + lambda_ub" if qp.ub is not None else "")
+        lines = ["r = ||%s|| = %.2e    rO/||b|| = %.2e" % (name, r[0], r[0] / normb)]
+        if qp.lb is not None:
+            lines.append("r = ||min(x-lb,0)||      = %.2e    r/||b|| = %.2e" % (r[1], r[1] / normb))
+            lines.append("r = ||min(lambda_lb,0)|| = %.2e    r/||b|| = %.2e" % (r[2], r[2] / normb))
+            lines.append("r = |lambda_lb'*(lb-x)|  = %.2e    r/||b|| = %.2e" % (r[3], r[3] / normb))
+        if qp.ub is not None:
+            lines.append("r = ||max(x-ub,0)||      = %.2e    r/||b|| = %.2e" % (r[4], r[4] / normb))
+            lines.append("r = ||min(lambda_ub,0)|| = %.2e    r/||b|| = %.2e" % (r[5], r[5] / normb))
+            lines.append("r = |lambda_ub'*(x-ub)|  = %.2e    r/||b|| = %.2e" % (r[6], r[6] / normb))
+        return lines
+
     def GetIterationNumber(self):
         return self.stats.iteration
 

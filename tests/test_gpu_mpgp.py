@@ -187,3 +187,45 @@ def test_medium_laplace_fused_vs_oracle(ctx, oracle):
     astol = 10 * np.finfo(float).eps
     act = lambda v: (np.abs(v - p["lb"]) <= astol).astype(int) - (np.abs(v - p["ub"]) <= astol).astype(int)
     assert np.mean(act(x) != act(ref["x"])) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["ex1_1", "ex1_opt", "ex1_optapprox", "ex1_bb", "ex1_projcg"])
+def test_kkt_lines_match_reference_golden(ctx, goldens, case):
+    """End to end through the product: solve, then the post-solve KKT report (-qp_chain_view_kkt) must print the
+    numbers of the reference's golden file (src/tutorials/output/ex1_*.out)."""
+    import re
+
+    g = goldens[case]
+    o = g["args"]["opts"]
+    p = P.ex1(100)
+    qps, st, x = _solve(ctx, p, expansion=(o["exptype"], o.get("explengthtype", "fixed")) if o else None)
+    lines = qps.ViewKKT()
+    assert len(lines) == len(g["kkt"]) == 4
+    for line, ref in zip(lines, g["kkt"]):
+        assert line.startswith("r = " + ref["name"])
+        m = re.match(r"r = (.*?)\s*= (\S+)\s+rO?/\|\|b\|\| = (\S+)", line)
+        if float(ref["r"]) < 1e-15:
+            assert float(m.group(2)) < 1e-12  # 0.00e+00 in the golden: rounding-level here as well
+        else:
+            assert (m.group(2), m.group(3)) == (ref["r"], ref["r_rel"])
+
+
+def test_kkt_two_sided_vs_numpy(ctx):
+    p = P.jbearing2(10, 16)
+    ub = np.full(p["n"], 0.05)
+    p2 = dict(p, ub=ub)
+    qps, st, x = _solve(ctx, p2, opts=dict(rtol=1e-8))
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((p["val"], p["col"], p["rowptr"]), shape=(p["n"], p["n"]))
+    r = A @ x - p["b"]
+    llb, lub = np.maximum(r, 0), np.maximum(-r, 0)
+    normb = np.linalg.norm(p["b"])
+    exp = [np.linalg.norm(r - llb + lub), np.linalg.norm(np.minimum(x - p["lb"], 0)), np.linalg.norm(np.minimum(llb, 0)), abs(llb @ (p["lb"] - x)),
+           np.linalg.norm(np.maximum(x - ub, 0)), np.linalg.norm(np.minimum(lub, 0)), abs(lub @ (x - ub))]
+    lines = qps.ViewKKT()
+    assert len(lines) == 7 and "- lambda_lb + lambda_ub" in lines[0]
+    for line, e in zip(lines, exp):
+        got = float(line.split("=")[2].split()[0])
+        assert got == pytest.approx(e, rel=1e-2, abs=1e-15)
+    assert exp[3] / normb < 1e-6 and exp[6] / normb < 1e-6  # complementarity at the solution
