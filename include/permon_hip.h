@@ -218,6 +218,17 @@ int pmh_gluing_destroy(pmh_gluing B);
 int pmh_gluing_mult(pmh_gluing B, const double *lambda, double *x);
 int pmh_gluing_mult_transpose(pmh_gluing B, const double *x, double *lambda);
 
+/* MATEXTENSION (src/mat/impls/extension/extension.c, the reference's DEFAULT gluing matrix type, qpfeti.c:825-831):
+   TA = scatter(ris) * A * gather(cis) with a condensed local CSR A (n_ris x n_cis).
+   mult (extension.c:476-489):           r = 0; r[ris] += A * c[cis]
+   mult_transpose (extension.c:510-523): c = 0; c[cis] += A' * r[ris]
+   ris / cis are host index arrays (each without repeats: they are index sets); n_r, n_c are the lengths of r and c. */
+typedef struct pmh_extension_s *pmh_extension;
+int pmh_extension_create(pmh_ctx ctx, int n_r, int n_c, pmh_csr A, const int *ris, const int *cis, pmh_extension *TA);
+int pmh_extension_destroy(pmh_extension TA);
+int pmh_extension_mult(pmh_extension TA, const double *c, double *r);
+int pmh_extension_mult_transpose(pmh_extension TA, const double *r, double *c);
+
 /* MATBLOCKDIAG (src/mat/impls/blockdiag/matblockdiag.c:190-201): the rank's sequential blocks.
    Several subdomains per GPU (BASELINE configs[3]) are stored as ONE concatenated CSR + block offsets. */
 typedef struct pmh_blockdiag_s *pmh_blockdiag;

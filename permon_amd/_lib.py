@@ -148,6 +148,10 @@ _PROTOS = {
     "pmh_gluing_destroy": [vp],
     "pmh_gluing_mult": [vp, vp, vp],
     "pmh_gluing_mult_transpose": [vp, vp, vp],
+    "pmh_extension_create": [vp, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)],
+    "pmh_extension_destroy": [vp],
+    "pmh_extension_mult": [vp, vp, vp],
+    "pmh_extension_mult_transpose": [vp, vp, vp],
     "pmh_blockdiag_create": [vp, C.c_int, vp, vp, C.POINTER(vp)],
     "pmh_blockdiag_destroy": [vp],
     "pmh_blockdiag_mult": [vp, vp, vp],

@@ -80,6 +80,91 @@ extern "C" int pmh_gluing_mult_transpose(pmh_gluing g, const double *x, double *
   return pmh_comm_allreduce_sum(g->ctx, lambda, (size_t)g->n_lambda);
 }
 
+// ---- MATEXTENSION ----------------------------------------------------------------------------------------------------
+struct pmh_extension_s {
+  pmh_ctx ctx;
+  int     n_r, n_c, nr_loc, nc_loc;
+  pmh_csr A;
+  int    *d_ris, *d_cis;
+  double *cwork, *rwork;
+};
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_gather(int m, const int *__restrict__ idx, const double *__restrict__ v, double *__restrict__ w)
+{
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < m; i += gridDim.x * PMH_BLOCK) w[i] = v[idx[i]];
+}
+// ADD_VALUES scatter; the index set has no repeats (checked at create), so plain stores are race free and deterministic
+__global__ __launch_bounds__(PMH_BLOCK) void k_scatter_add(int m, const int *__restrict__ idx, const double *__restrict__ w, double *__restrict__ v)
+{
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < m; i += gridDim.x * PMH_BLOCK) v[idx[i]] += w[i];
+}
+
+static int check_index_set(const int *is, int m, int n, const char *name)
+{
+  std::vector<char> seen((size_t)n, 0);
+  for (int i = 0; i < m; i++) {
+    if (is[i] < 0 || is[i] >= n) return pmh_set_error(PMH_ERR_ARG, "pmh_extension_create: %s[%d] = %d out of [0,%d)", name, i, is[i], n);
+    if (seen[is[i]]) return pmh_set_error(PMH_ERR_ARG, "pmh_extension_create: %s has the repeated index %d", name, is[i]);
+    seen[is[i]] = 1;
+  }
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_extension_create(pmh_ctx ctx, int n_r, int n_c, pmh_csr A, const int *ris, const int *cis, pmh_extension *out)
+{
+  PMH_ARG(ctx && A && ris && cis && out && n_r >= 0 && n_c >= 0);
+  PMH_CHK(check_index_set(ris, A->nrows, n_r, "ris"));
+  PMH_CHK(check_index_set(cis, A->ncols, n_c, "cis"));
+  pmh_extension T = new pmh_extension_s();
+  T->ctx = ctx, T->n_r = n_r, T->n_c = n_c, T->nr_loc = A->nrows, T->nc_loc = A->ncols, T->A = A;
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(A->nrows + 1), (void **)&T->d_ris));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(A->ncols + 1), (void **)&T->d_cis));
+  PMH_CHK(pmh_memcpy_h2d(ctx, T->d_ris, ris, sizeof(int) * (size_t)A->nrows));
+  PMH_CHK(pmh_memcpy_h2d(ctx, T->d_cis, cis, sizeof(int) * (size_t)A->ncols));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(A->ncols + 1), (void **)&T->cwork));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(A->nrows + 1), (void **)&T->rwork));
+  *out = T;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_extension_destroy(pmh_extension T)
+{
+  if (!T) return PMH_SUCCESS;
+  pmh_free(T->ctx, T->d_ris);
+  pmh_free(T->ctx, T->d_cis);
+  pmh_free(T->ctx, T->cwork);
+  pmh_free(T->ctx, T->rwork);
+  delete T;
+  return PMH_SUCCESS;
+}
+
+#define EXT_GRID(m) dim3((unsigned)std::max(1, std::min(PMH_MAX_VEC_BLOCKS, ((m) + PMH_BLOCK - 1) / PMH_BLOCK)))
+// MatMult_Extension extension.c:476-489
+extern "C" int pmh_extension_mult(pmh_extension T, const double *c, double *r)
+{
+  PMH_ARG(T);
+  hipStream_t st = T->ctx->stream;
+  PMH_CHK(pmh_memset(T->ctx, r, 0, sizeof(double) * (size_t)T->n_r));
+  if (T->nc_loc) hipLaunchKernelGGL(k_gather, EXT_GRID(T->nc_loc), dim3(PMH_BLOCK), 0, st, T->nc_loc, (const int *)T->d_cis, c, T->cwork);
+  PMH_CHK(pmh_csr_mult(T->A, T->cwork, T->rwork));
+  if (T->nr_loc) hipLaunchKernelGGL(k_scatter_add, EXT_GRID(T->nr_loc), dim3(PMH_BLOCK), 0, st, T->nr_loc, (const int *)T->d_ris, (const double *)T->rwork, r);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+// MatMultTranspose_Extension extension.c:510-523
+extern "C" int pmh_extension_mult_transpose(pmh_extension T, const double *r, double *c)
+{
+  PMH_ARG(T);
+  hipStream_t st = T->ctx->stream;
+  PMH_CHK(pmh_memset(T->ctx, c, 0, sizeof(double) * (size_t)T->n_c));
+  if (T->nr_loc) hipLaunchKernelGGL(k_gather, EXT_GRID(T->nr_loc), dim3(PMH_BLOCK), 0, st, T->nr_loc, (const int *)T->d_ris, r, T->rwork);
+  PMH_CHK(pmh_csr_mult_transpose(T->A, T->rwork, T->cwork));
+  if (T->nc_loc) hipLaunchKernelGGL(k_scatter_add, EXT_GRID(T->nc_loc), dim3(PMH_BLOCK), 0, st, T->nc_loc, (const int *)T->d_cis, (const double *)T->cwork, c);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
 // ---- MATBLOCKDIAG ---------------------------------------------------------------------------------------------------
 struct pmh_blockdiag_s {
   pmh_ctx          ctx;

@@ -34,6 +34,30 @@ class MatGluing:
             self.h = None
 
 
+class MatExtension:
+    """MatCreateExtension (src/mat/impls/extension/extension.c): TA = scatter(ris) * A * gather(cis), A condensed CSR."""
+
+    def __init__(self, ctx, n_r, n_c, A, ris, cis):
+        ris = np.ascontiguousarray(ris, dtype=np.int32)
+        cis = np.ascontiguousarray(cis, dtype=np.int32)
+        assert ris.size == A.nrows and cis.size == A.ncols
+        self.ctx, self.A, self.n_r, self.n_c = ctx, A, int(n_r), int(n_c)
+        h = C.c_void_p()
+        check(ctx.L.pmh_extension_create(ctx.h, self.n_r, self.n_c, A.h, ris.ctypes.data_as(C.c_void_p), cis.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    def mult(self, c, r):  # MatMult_Extension
+        check(self.ctx.L.pmh_extension_mult(self.h, c.p, r.p))
+
+    def mult_transpose(self, r, c):  # MatMultTranspose_Extension
+        check(self.ctx.L.pmh_extension_mult_transpose(self.h, r.p, c.p))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_extension_destroy(self.h)
+            self.h = None
+
+
 class MatBlockDiag:
     """MatCreateBlockDiag (src/mat/impls/blockdiag/matblockdiag.c:777-854): this rank's subdomain blocks as
     one concatenated CSR + block row offsets."""

@@ -242,3 +242,31 @@ def test_config3_shape_64_subdomains_dense_coarse_solve(ctx, oracle):
     # G lambda = e to the solver tolerance (equality constraint of the dual QP)
     lam = q.dual_solution()
     assert np.linalg.norm(G @ lam - e) <= 1e-4 * max(1.0, np.linalg.norm(e))
+
+
+def test_extension_matches_gluing_and_dense(ctx):
+    """MATEXTENSION (the reference's default B type): B' lambda and B u through the condensed CSR + index sets must equal
+    MATGLUING's result on the same constraints (both compute the same B' lambda / B u)."""
+    f = pa.CubeFeti((2, 2, 1), 2, contact=True)
+    Bt = f.B.T.tocsr()  # N x n_lambda: rows = primal dofs; condensed to the interface rows
+    ris = np.flatnonzero(np.diff(Bt.indptr) > 0).astype(np.int32)
+    cis = np.arange(f.n_lambda, dtype=np.int32)
+    Acond = Bt[ris].tocsr()
+    Acond.sort_indices()
+    A = pa.CsrMat(ctx, Acond.shape[0], Acond.shape[1], Acond.indptr, Acond.indices, Acond.data)
+    TA = pa.MatExtension(ctx, f.N, f.n_lambda, A, ris, cis)
+    Bg = pa.MatGluing(ctx, f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
+    rng = np.random.default_rng(2)
+    lam, u = rng.standard_normal(f.n_lambda), rng.standard_normal(f.N)
+    x1, x2 = ctx.vec(f.N), ctx.vec(f.N)
+    TA.mult(ctx.vec_from(lam), x1)
+    Bg.mult(ctx.vec_from(lam), x2)
+    assert np.array_equal(x1.to_numpy(), x2.to_numpy())
+    assert np.allclose(x1.to_numpy(), f.B.T @ lam, rtol=1e-14, atol=1e-14)
+    l1, l2 = ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    TA.mult_transpose(ctx.vec_from(u), l1)
+    Bg.mult_transpose(ctx.vec_from(u), l2)
+    assert np.allclose(l1.to_numpy(), l2.to_numpy(), rtol=1e-14, atol=1e-14)
+    assert np.allclose(l1.to_numpy(), f.B @ u, rtol=1e-13, atol=1e-14)
+    with pytest.raises(pa.PermonHipError):
+        pa.MatExtension(ctx, f.N, f.n_lambda, A, np.zeros_like(ris), cis)  # repeated row index
