@@ -205,10 +205,6 @@ extern "C" int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y)
 }
 
 // ---- MATINV: block-wise CG -------------------------------------------------------------------------------------------
-// per-block scalar slots (doubles)
-enum { BS_RZ = 0, BS_PAP, BS_RZNEW, BS_RR, BS_ALPHA, BS_BETA, BS_TOL, BS_NSLOT };
-// per-block int slots
-enum { BI_ACTIVE = 0, BI_ITS, BI_NSLOT };
 
 struct pmh_matinv_s {
   pmh_blockdiag K;

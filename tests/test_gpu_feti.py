@@ -270,3 +270,30 @@ def test_extension_matches_gluing_and_dense(ctx):
     assert np.allclose(l1.to_numpy(), f.B @ u, rtol=1e-13, atol=1e-14)
     with pytest.raises(pa.PermonHipError):
         pa.MatExtension(ctx, f.N, f.n_lambda, A, np.zeros_like(ris), cis)  # repeated row index
+
+
+def test_contact_tfeti_end_to_end_properties(ctx):
+    """Whole chain at a size the oracle cannot follow (222 k dof, n_lambda = 23 700; the 2.04 M-dof configs[2] run of the
+    same script is recorded in profiles/r01_solve_configs2_smalxe.jsonl): dualise -> homogenise -> project -> SMALXE+MPGP,
+    then size-independent properties of the solution -- dual feasibility, G lambda = e, and primal feasibility / contact
+    complementarity after the rigid-body recovery."""
+    f = pa.CubeFeti((2, 2, 2), 20, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    q = FetiDualQP(ctx, f.subset(range(8)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-9)
+    st = q.solve_smalxe(rtol=1e-5)
+    assert st.reason == 2 and st.iteration < 100 and st.inner.nmv == st.inner.ncg + 2 * st.inner.nexp + st.inner.nprop + st.iteration
+    lam = q.dual_solution()
+    n = f.n_lambda
+    assert lam[f.n_eq:].min() >= -1e-12  # lambda_I >= 0
+    assert np.linalg.norm(G @ lam - e) <= 1e-5 * max(1.0, np.linalg.norm(e))
+    u, Fl_minus_d = q.primal_solution(G)
+    Ru = f.kernel_matrix()
+    tight = (np.arange(n) < f.n_eq) | (lam > 1e-8 * np.abs(lam).max())
+    alpha = np.linalg.lstsq((f.B @ Ru).toarray()[tight], Fl_minus_d[tight], rcond=None)[0]
+    uu = u + Ru @ alpha
+    Bu, scale = f.B @ uu, np.abs(uu).max()
+    assert np.abs(Bu[:f.n_eq] - f.c[:f.n_eq]).max() <= 1e-3 * scale  # glued + Dirichlet
+    assert (Bu[f.n_eq:] - f.c[f.n_eq:]).max() <= 1e-3 * scale  # no penetration
+    gap = f.c[f.n_eq:] - Bu[f.n_eq:]
+    assert np.abs(lam[f.n_eq:] * gap).max() <= 1e-3 * scale * np.abs(lam).max()  # complementarity
+    assert (lam[f.n_eq:] > 0).sum() > 100  # a genuine contact zone
