@@ -86,6 +86,27 @@ def pmc_traffic(prefix):
     return None
 
 
+def measured_ceiling(ctx, n=1 << 26, reps=10):
+    """On-box HBM ceiling (SURVEY 8d asks for it next to the 8 TB/s spec): device copy (read n, write n) and the
+    VecWAXPY triad (read 2n, write n) on 512 MiB vectors, HIP-event timed on the launch stream."""
+    x, y, w = ctx.vec(n), ctx.vec(n), ctx.vec(n)
+    x.set(1.0)
+    y.set(2.0)
+    res = {}
+    for name, fn, nbytes in (("copy_GBs", lambda: ctx.L.pmh_vec_copy(ctx.h, n, x.p, w.p), 16.0 * n), ("triad_GBs", lambda: w.waxpy(0.5, x, y), 24.0 * n)):
+        for _ in range(2):
+            fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        res[name] = nbytes / ms / 1e6
+    for v in (x, y, w):
+        v.free()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # configs[1]: single CSR, MPGP
 # ------------------------------------------------------------------------------------------------------------------
@@ -417,6 +438,11 @@ def main():
                 del f, G
                 out["configs1"] = run_c2(ctx, a, 300, 30, cpu=not a.no_cpu_baseline)
     if rank == 0:
+        try:
+            out["roofline"]["measured_ceiling"] = measured_ceiling(ctx)
+            out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / out["roofline"]["measured_ceiling"]["copy_GBs"]
+        except Exception as ex:  # noqa: BLE001
+            out["roofline"]["measured_ceiling"] = "failed: %r" % (ex,)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

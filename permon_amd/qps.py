@@ -230,6 +230,29 @@ class QPS:
             lines.append("r = |lambda_ub'*(x-ub)|  = %.2e    r/||b|| = %.2e" % (r[6], r[6] / normb))
         return lines
 
+    def ViewConvergence(self):
+        """The -qps_view_convergence lines (QPSViewConvergence qps.c:968 + _MPGP mpgp.c:751-770 + _SMALXE smalxe.c:1001-1018)
+        in the reference's wording, so that golden files can be compared as text."""
+        names = {2: "CONVERGED_RTOL", 3: "CONVERGED_ATOL", 4: "CONVERGED_ITS", 7: "CONVERGED_HAPPY_BREAKDOWN", -3: "DIVERGED_ITS",
+                 -4: "DIVERGED_DTOL", -5: "DIVERGED_BREAKDOWN", -9: "DIVERGED_NANORINF"}
+
+        def head(st):
+            return "last QPSSolve %s due to %s, KSPReason=%d, required %d iterations" % (
+                "CONVERGED" if st.reason > 0 else "DIVERGED", names.get(st.reason, str(st.reason)), st.reason, st.iteration)
+
+        def mpgp(st):
+            return ["number of Hessian multiplications %d" % st.nmv, "number of CG steps %d" % st.ncg,
+                    "number of expansion steps %d" % st.nexp, "number of proportioning steps %d" % st.nprop]
+
+        st = self.stats
+        if self.type == "mpgp":
+            return [head(st)] + mpgp(st)
+        if self.type == "smalxe":
+            return [head(st), "Total number of inner iterations %d" % st.inner_iter_accu,
+                    "#hits    of M1, eta: %3d, %3d" % (st.M1_hits, st.eta_hits), "#updates of M1, rho: %3d, %3d" % (st.M1_updates, st.rho_updates),
+                    head(st.inner)] + mpgp(st.inner)
+        return [head(st)]
+
     def GetIterationNumber(self):
         return self.stats.iteration
 

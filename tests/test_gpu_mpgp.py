@@ -229,3 +229,15 @@ def test_kkt_two_sided_vs_numpy(ctx):
         got = float(line.split("=")[2].split()[0])
         assert got == pytest.approx(e, rel=1e-2, abs=1e-15)
     assert exp[3] / normb < 1e-6 and exp[6] / normb < 1e-6  # complementarity at the solution
+
+
+def test_view_convergence_text_matches_golden(ctx):
+    """-qps_view_convergence output, line by line against src/tutorials/output/ex1_1.out (filter: CONVERGED | number)."""
+    qps, st, x = _solve(ctx, P.ex1(100))
+    assert qps.ViewConvergence() == [
+        "last QPSSolve CONVERGED due to CONVERGED_RTOL, KSPReason=2, required 181 iterations",
+        "number of Hessian multiplications 200",
+        "number of CG steps 156",
+        "number of expansion steps 18",
+        "number of proportioning steps 7",
+    ]
