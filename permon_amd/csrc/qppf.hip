@@ -22,6 +22,82 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_dense_gemv(int m, const double *_
   if (lane == 0) y[row] = s;
 }
 
+// ---- GG' assembly on the matrix cores (the one GEMM-shaped item of the path, SURVEY 2.3 K20: the reference builds the
+// 6x6 blocks of GG' with BLASgemm("N","T"), extension.c:961) -----------------------------------------------------------
+// G is densified TRANSPOSED (Gt: n x Mp row-major, Mp = m rounded up to 16) so that the MFMA operand loads are
+// contiguous: for v_mfma_f64_16x16x4_f64 lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; with C = G G'
+// both come from row (k0 + (l>>4)) of Gt, columns i0 + (l&15) and j0 + (l&15).  C/D: col = l&15, row = (l>>4) + 4*reg.
+// Every workgroup owns one 16x16 output tile and one K chunk; its 4 wavefronts split the chunk, partial tiles are summed
+// in wave order through LDS, and the per-chunk partials are added in chunk order by k_ggt_reduce (deterministic).
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define GGT_KCHUNK 8192
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_densify_gt(int m, int Mp, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double *__restrict__ Gt)
+{
+  const int row = blockIdx.x;
+  if (row >= m) return;
+  for (int k = rowptr[row] + (int)threadIdx.x; k < rowptr[row + 1]; k += PMH_BLOCK) Gt[(size_t)col[k] * Mp + row] = val[k];
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_ggt_mfma(int n, int Mp, const double *__restrict__ Gt, double *__restrict__ part)
+{
+  __shared__ double lds[PMH_BLOCK / 64][256];
+  const int         nt = Mp / 16, ti = blockIdx.x / nt, tj = blockIdx.x % nt, chunk = blockIdx.y;
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int         k_lo = chunk * GGT_KCHUNK + wave * (GGT_KCHUNK / 4);
+  const int         k_hi = min(n, k_lo + GGT_KCHUNK / 4);
+  v4f64             acc  = {0.0, 0.0, 0.0, 0.0};
+  const int         kk = lane >> 4, ij = lane & 15;
+  for (int k = k_lo; k < k_hi; k += 4) {
+    const int  kr = k + kk;
+    const bool ok = kr < k_hi;
+    const double a = ok ? Gt[(size_t)kr * Mp + ti * 16 + ij] : 0.0;
+    const double b = ok ? Gt[(size_t)kr * Mp + tj * 16 + ij] : 0.0;
+    acc            = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) lds[wave][((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  const int t = threadIdx.x; // 256 threads = 256 tile entries
+  double    v = lds[0][t];
+#pragma unroll
+  for (int w = 1; w < PMH_BLOCK / 64; w++) v += lds[w][t];
+  part[((size_t)chunk * nt * nt + blockIdx.x) * 256 + t] = v;
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_ggt_reduce(int nchunks, int Mp, const double *__restrict__ part, double *__restrict__ GGt)
+{
+  const int nt = Mp / 16, tile = blockIdx.x, ti = tile / nt, tj = tile % nt, t = threadIdx.x;
+  double    v = 0.0;
+  for (int c = 0; c < nchunks; c++) v += part[((size_t)c * nt * nt + tile) * 256 + t];
+  GGt[(size_t)(ti * 16 + t / 16) * Mp + tj * 16 + (t % 16)] = v;
+}
+
+// device GG' (m x m, row-major, returned on the host)
+static int device_ggt(pmh_ctx ctx, pmh_csr G, std::vector<double> &ggt)
+{
+  const int m = G->nrows, n = G->ncols, Mp = ((m + 15) / 16) * 16, nt = Mp / 16;
+  const int nchunks = (n + GGT_KCHUNK - 1) / GGT_KCHUNK;
+  double   *Gt = nullptr, *part = nullptr, *dggt = nullptr;
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n * Mp, (void **)&Gt));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)nchunks * nt * nt * 256, (void **)&part));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)Mp * Mp, (void **)&dggt));
+  PMH_CHK(pmh_memset(ctx, Gt, 0, sizeof(double) * (size_t)n * Mp));
+  hipLaunchKernelGGL(k_densify_gt, dim3(m), dim3(PMH_BLOCK), 0, ctx->stream, m, Mp, (const int *)G->d_rowptr, (const int *)G->d_col, (const double *)G->d_val, Gt);
+  hipLaunchKernelGGL(k_ggt_mfma, dim3(nt * nt, nchunks), dim3(PMH_BLOCK), 0, ctx->stream, n, Mp, (const double *)Gt, part);
+  hipLaunchKernelGGL(k_ggt_reduce, dim3(nt * nt), dim3(PMH_BLOCK), 0, ctx->stream, nchunks, Mp, (const double *)part, dggt);
+  PMH_HIP(hipGetLastError());
+  std::vector<double> full((size_t)Mp * Mp);
+  PMH_CHK(pmh_memcpy_d2h(ctx, full.data(), dggt, sizeof(double) * full.size()));
+  ggt.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < m; j++) ggt[(size_t)i * m + j] = full[(size_t)i * Mp + j];
+  pmh_free(ctx, Gt);
+  pmh_free(ctx, part);
+  pmh_free(ctx, dggt);
+  return PMH_SUCCESS;
+}
+
 static int host_cholesky_inverse(int m, std::vector<double> &a)
 {
   // in-place lower Cholesky, then inverse via forward/back substitution against the identity
@@ -69,27 +145,9 @@ extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->G_left));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->Gt_right));
   if (!pf->orthonormal && m > 0) {
-    // GG' on the host (QPPFSetUpGGt_Private qppf.c:213-278), column-wise accumulation over G'
-    std::vector<int>    rp((size_t)m + 1), ci((size_t)G->nnz);
-    std::vector<double> va((size_t)G->nnz);
-    PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), G->d_rowptr, sizeof(int) * rp.size()));
-    PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), G->d_col, sizeof(int) * ci.size()));
-    PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), G->d_val, sizeof(double) * va.size()));
-    std::vector<int> cp((size_t)pf->n + 1, 0), cr((size_t)G->nnz);
-    std::vector<double> cv((size_t)G->nnz);
-    for (long long k = 0; k < G->nnz; k++) cp[ci[k] + 1]++;
-    for (int j = 0; j < pf->n; j++) cp[j + 1] += cp[j];
-    std::vector<int> pos(cp.begin(), cp.end() - 1);
-    for (int i = 0; i < m; i++)
-      for (int k = rp[i]; k < rp[i + 1]; k++) {
-        int p = pos[ci[k]]++;
-        cr[p] = i;
-        cv[p] = va[k];
-      }
-    std::vector<double> ggt((size_t)m * m, 0.0);
-    for (int j = 0; j < pf->n; j++)
-      for (int a = cp[j]; a < cp[j + 1]; a++)
-        for (int b = cp[j]; b < cp[j + 1]; b++) ggt[(size_t)cr[a] * m + cr[b]] += cv[a] * cv[b];
+    // GG' on the device with fp64 MFMA (QPPFSetUpGGt_Private qppf.c:213-278); the small dense factorisation stays on the host
+    std::vector<double> ggt;
+    PMH_CHK(device_ggt(ctx, G, ggt));
     if (host_cholesky_inverse(m, ggt)) {
       pmh_free(ctx, pf->G_left);
       pmh_free(ctx, pf->Gt_right);

@@ -51,6 +51,13 @@ def test_qppf_vs_oracle(ctx, oracle, orth):
     gd = ctx.vec(G.shape[0])
     pf.ApplyG(yd, gd)
     assert np.max(np.abs(gd.to_numpy())) <= 1e-12
+    if not orth:
+        # coarse solve: GG' assembled by the fp64-MFMA kernel (k_ggt_mfma), inverted on the host, applied as a dense GEMV
+        xm = rng.standard_normal(G.shape[0])
+        ym = ctx.vec(G.shape[0])
+        pf.ApplyCP(ctx.vec_from(xm), ym)
+        ref_cp = np.linalg.solve((G @ G.T).toarray(), xm)
+        assert np.linalg.norm(ym.to_numpy() - ref_cp) <= 1e-10 * np.linalg.norm(ref_cp)
     ed = ctx.vec_from(e)
     pf.ApplyHalfQTranspose(ed, yd)
     assert np.max(np.abs(yd.to_numpy() - pfo.half_Q_transpose(e))) <= 1e-12 * max(1.0, np.max(np.abs(e)))
