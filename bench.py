@@ -367,7 +367,8 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("PMH_BENCH_FORCE_DIST"))  # exercise the N>1 code path on a single rank (testing)
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist_
 
@@ -378,7 +379,7 @@ def main():
     import permon_amd as pa
 
     ctx = pa.Context(local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch
 
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
