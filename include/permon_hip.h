@@ -298,6 +298,12 @@ typedef struct {
 /* pc: NULL (none) or an operator applied as z = M^{-1} w (PCApply), e.g. the lumped dual preconditioner */
 int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_qppf pf, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st);
 
+/* ---- QPS KSP (src/qps/impls/ksp/qpsksp.c:127-143): the solver QPSSetDefaultType picks for a QP without box or
+ * equality constraints (qps.c:437-449), e.g. the projected dual of a linear TFETI problem or the FETI-1 dual.
+ * The KSP is the one QPSCreate_KSP sets up (qpsksp.c:244-250): CG, unpreconditioned residual norm, x as initial
+ * guess, pc NULL = PCNONE; stopping test QPSKSPConverged_KSP -> QPSConvergedDefault. */
+int pmh_ksp_cg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,11 +324,12 @@ def smalxe(op, b, u0, box, pf, omp=False, inner_opts=None, trace_cap=0, **opts):
 
 
 def pcpg(op, b, x0, pf, rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, pc=None):
-    """QPSSolve_PCPG restatement; pc is an optional python callable y = M^{-1} x."""
+    """QPSSolve_PCPG restatement; pc is an optional python callable y = M^{-1} x.
+    pf=None: no equality constraint, i.e. the CG that QPSKSP runs (qpsksp.c:244-250)."""
     L = lib()
     b = _f64(b)
     x = _f64(x0).copy()
-    s = L.orc_pcpg_new(C.byref(op.c), _dp(b), _dp(x), C.byref(pf.c), C.c_double(rtol), C.c_double(atol), C.c_double(divtol), C.c_int(max_it))
+    s = L.orc_pcpg_new(C.byref(op.c), _dp(b), _dp(x), C.byref(pf.c) if pf is not None else None, C.c_double(rtol), C.c_double(atol), C.c_double(divtol), C.c_int(max_it))
     keep = None
     try:
         if pc is not None:

@@ -960,7 +960,8 @@ int orc_pcpg_solve(orc_pcpg *s)
   v_aypx(n, r, -1.0, s->b);
   s->iteration = 0;
   do {
-    orc_qppf_apply_P(s->pf, r, w);
+    if (s->pf) orc_qppf_apply_P(s->pf, r, w);
+    else v_copy(n, r, w); /* no eq. constraints: KSPCG as set up by QPSKSP (qpsksp.c:244-250), unpreconditioned norm */
     s->rnorm = v_norm2(n, w);
     /* QPSConvergedDefault */
     s->reason = ORC_CONVERGED_ITERATING;
@@ -973,7 +974,8 @@ int orc_pcpg_solve(orc_pcpg *s)
       y = w;
     } else {
       s->pc(s->pc_ctx, w, z);
-      orc_qppf_apply_P(s->pf, z, yb);
+      if (s->pf) orc_qppf_apply_P(s->pf, z, yb);
+      else v_copy(n, z, yb);
       y = yb;
     }
     beta2 = beta1;

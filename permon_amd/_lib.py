@@ -170,6 +170,7 @@ _PROTOS = {
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
+    "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 
 #: every symbol include/permon_hip.h declares

@@ -30,22 +30,28 @@ class FetiDualQP:
         self.Kplus.mult(self.f, self.tprim)
         self.B.mult_transpose(self.tprim, self.d)
         self.d.axpy(-1.0, ctx.vec_from(c))
-        # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169)
-        self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal)
-        # QPTHomogenizeEq qptransform.c:437-527: lambda~ = G'(GG')^{-1} e; b_bar = d - F lambda~; lb <- lb - lambda~
-        self.e = ctx.vec_from(e)
-        self.lam_tilde = ctx.vec(nl)
-        self.pf.ApplyHalfQTranspose(self.e, self.lam_tilde)
-        self.b_bar = ctx.vec(nl)
-        self.F.mult(self.lam_tilde, self.b_bar)
-        self.b_bar.aypx(-1.0, self.d)
-        lt = self.lam_tilde.to_numpy()
-        self.lb_new = ctx.vec_from(np.asarray(lb) - lt)
-        # QPTEnforceEqByProjector qptransform.c:215-316: A = P F P (box present), b = P b_bar
         self.has_box = bool(np.any(np.isfinite(lb)))
-        self.A = MatCreateProjected(self.F, self.pf, symmetric=self.has_box)
-        self.b = ctx.vec(nl)
-        self.pf.ApplyP(self.b_bar, self.b)
+        if G is None:
+            # no floating subdomain: R has no columns, the dual QP has no equality constraint (qptransform.c:1092-1101)
+            self.pf, self.e, self.lam_tilde = None, None, ctx.vec(nl)
+            self.b_bar, self.b, self.A = self.d, self.d, self.F
+            self.lb_new = ctx.vec_from(np.asarray(lb, dtype=np.float64))
+        else:
+            # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169)
+            self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal)
+            # QPTHomogenizeEq qptransform.c:437-527: lambda~ = G'(GG')^{-1} e; b_bar = d - F lambda~; lb <- lb - lambda~
+            self.e = ctx.vec_from(e)
+            self.lam_tilde = ctx.vec(nl)
+            self.pf.ApplyHalfQTranspose(self.e, self.lam_tilde)
+            self.b_bar = ctx.vec(nl)
+            self.F.mult(self.lam_tilde, self.b_bar)
+            self.b_bar.aypx(-1.0, self.d)
+            lt = self.lam_tilde.to_numpy()
+            self.lb_new = ctx.vec_from(np.asarray(lb) - lt)
+            # QPTEnforceEqByProjector qptransform.c:215-316: A = P F P (box present) or P F (eq. only), b = P b_bar
+            self.A = MatCreateProjected(self.F, self.pf, symmetric=self.has_box)
+            self.b = ctx.vec(nl)
+            self.pf.ApplyP(self.b_bar, self.b)
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
     def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
@@ -83,6 +89,25 @@ class FetiDualQP:
         qps = QPS(self.ctx)
         qps.SetQP(qp)
         qps.SetType("pcpg")
+        qps.SetTolerances(rtol=rtol, max_it=max_it)
+        st = qps.Solve()
+        self.qps = qps
+        return st
+
+    def solve_ksp(self, rtol=1e-5, max_it=10000, lumped=False):
+        """The reference's default for a dual QP without box: after QPTEnforceEqByProjector the child QP has operator
+        P F, rhs P b_bar, preconditioner P M^{-1} (qptransform.c:272-308) and no constraint left, so QPSSetDefaultType
+        picks QPSKSP = CG (qps.c:448); without floating subdomains it is CG on F lambda = d."""
+        qp = QP(self.ctx)
+        qp.SetOperator(self.A)
+        qp.SetRhs(self.b)
+        qp.SetInitialVector(self.lam)
+        if lumped:
+            self._lumped = PCDualLumpedOp(self.B, self.K)
+            qp.pc = MatCreateProjected(self._lumped, self.pf, symmetric=False) if self.pf is not None else self._lumped
+        qps = QPS(self.ctx)
+        qps.SetQP(qp)
+        qps.SetType("ksp")
         qps.SetTolerances(rtol=rtol, max_it=max_it)
         st = qps.Solve()
         self.qps = qps

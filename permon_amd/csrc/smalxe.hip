@@ -319,7 +319,7 @@ extern "C" int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st)
 // --------------------------------------------------------------------------------------------------------------------
 extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_qppf pf, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st)
 {
-  PMH_ARG(ctx && A && b && x && pf && st);
+  PMH_ARG(ctx && A && b && x && st); // pf == NULL: no equality constraints, P = I (the QPSKSP/KSPCG path)
   const int n = A->n;
   double   *p, *r, *w, *z, *yb, *Ap, *y;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&p));
@@ -340,7 +340,11 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
     PC_CHK(A->mult(x, r));
     PC_CHK(pmh_vec_aypx(ctx, n, r, -1.0, b));
     do {
-      PC_CHK(pmh_qppf_apply_P(pf, r, w));
+      if (pf) {
+        PC_CHK(pmh_qppf_apply_P(pf, r, w));
+      } else {
+        PC_CHK(pmh_vec_copy(ctx, n, r, w));
+      }
       PC_CHK(pmh_vec_norm2(ctx, n, w, &st->rnorm));
       st->reason = PMH_CONVERGED_ITERATING; // QPSConvergedDefault
       if (st->iteration > max_it) st->reason = PMH_DIVERGED_ITS;
@@ -352,8 +356,12 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
         y = w;
       } else {
         PC_CHK(pc->mult(w, z));
-        PC_CHK(pmh_qppf_apply_P(pf, z, yb));
-        y = yb;
+        if (pf) {
+          PC_CHK(pmh_qppf_apply_P(pf, z, yb));
+          y = yb;
+        } else {
+          y = z;
+        }
       }
       beta2 = beta1;
       PC_CHK(pmh_vec_dot(ctx, n, y, w, &beta1));
@@ -380,4 +388,12 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
   pmh_free(ctx, yb);
   pmh_free(ctx, Ap);
   return rc;
+}
+
+// QPSSolve_KSP src/qps/impls/ksp/qpsksp.c:127-143 with the KSP that QPSCreate_KSP configures (:244-250: KSPCG,
+// KSP_NORM_UNPRECONDITIONED, nonzero initial guess, PCNONE unless the QP carries a PC) and QPSKSPConverged_KSP ->
+// QPSConvergedDefault as the stopping test: this is PCPG with P = I, so the same driver serves it.
+extern "C" int pmh_ksp_cg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st)
+{
+  return pmh_pcpg_solve(ctx, A, b, x, nullptr, pc, rtol, atol, divtol, max_it, st);
 }

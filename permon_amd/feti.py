@@ -11,7 +11,7 @@ Everything here is set-up; the iteration runs in libpermonhip.
 import numpy as np
 import scipy.sparse as sp
 
-__all__ = ["q1_elasticity_element", "q1_poisson_element", "CubeFeti"]
+__all__ = ["q1_elasticity_element", "q1_poisson_element", "gluing_links", "CubeFeti", "DmdaFeti"]
 
 
 def _gauss_q1():
@@ -69,13 +69,38 @@ def q1_elasticity_element(h, E=1.0, nu=0.3):
     return 0.5 * (Ke + Ke.T)
 
 
+def gluing_links(m, gtype="full", scale=True):
+    """Links (dual rows) that glue the m copies of one interface dof, copies ordered by rank: a list of
+    [(copy, value), ...] rows as QPFetiGetBgtSF assembles them (src/qp/impls/feti/qpfeti.c).
+
+    nonred  m-1 links, copy 0 against copy k (star around the lowest rank, :643-648); full  all m(m-1)/2 pairs
+    (i, k>i) (:650-657); both +1 on the lower rank, -1 on the highest rank of the link, times 1/sqrt(m) with
+    -SCALE_ON, the default (:786-806).  orth  m-1 orthonormal links, link k couples copies 0..d-1 (value 1/d)
+    with copy d = m-1-k (value -1), all divided by sqrt(1/d + 1) (:659-667, :700-716, :807-817)."""
+    if m < 2:
+        return []
+    if gtype == "orth":
+        rows = []
+        for k in range(m - 1):
+            d = m - 1 - k
+            x = np.sqrt(1.0 / d + 1.0)
+            rows.append([(t, 1.0 / d / x) for t in range(d)] + [(d, -1.0 / x)])
+        return rows
+    sc = 1.0 / np.sqrt(m) if scale else 1.0
+    if gtype == "nonred":
+        return [[(0, sc), (k, -sc)] for k in range(1, m)]
+    if gtype == "full":
+        return [[(i, sc), (k, -sc)] for i in range(m - 1) for k in range(i + 1, m)]
+    raise ValueError("unknown FETI gluing type %r" % gtype)  # qpfeti.c:561
+
+
 class CubeFeti:
     """TFETI data for sx x sy x sz unit cubes of nel^3 Q1 elements each.
 
     physics 'elasticity' (3 dof/node, 6 rigid-body modes per cube) or 'poisson' (1 dof/node, 1 mode).
     Dirichlet u = 0 on the global x = 0 face enforced by B (TFETI: every subdomain floats,
     KSPFETISetDirichlet(..., FETI_LOCAL, PETSC_TRUE) as in src/tutorials/feti/ex1.c:89-90);
-    gluing 'nonred' or 'full' with -SCALE_ON values +-1/sqrt(multiplicity) (qpfeti.c:789-806);
+    gluing 'nonred' | 'full' | 'orth' as gluing_links();
     contact=True adds the rigid obstacle below the global z = 0 face: -u_z <= gap (inequality rows).
     Dual rows are ordered [Dirichlet | gluing | contact]; the first n_eq are equalities.
     """
@@ -168,13 +193,13 @@ class CubeFeti:
             m = len(cp)
             if m < 2:
                 continue
-            sc = 1.0 / np.sqrt(m) if scale else 1.0
-            pairs = [(cp[i], cp[i + 1]) for i in range(m - 1)] if gluing == "nonred" else [(cp[i], cp[j]) for i in range(m) for j in range(i + 1, m)]
-            for (sa, la), (sb, lb_) in pairs:
+            for link in gluing_links(m, gluing, scale):
                 for c in range(nd):
-                    rows_l += [sa * nloc + la * nd + c, sb * nloc + lb_ * nd + c]
-                    roots_l += [nrow, nrow]
-                    vals_l += [sc, -sc]  # the copy on the higher rank carries -1 (qpfeti.c:791-795)
+                    for t, v in link:
+                        sa, la = cp[t]
+                        rows_l.append(sa * nloc + la * nd + c)
+                        roots_l.append(nrow)
+                        vals_l.append(v)
                     c_rhs.append(0.0)
                     nrow += 1
         self.n_eq = nrow
@@ -246,3 +271,161 @@ class CubeFeti:
             K=sp.block_diag([self.Ki] * len(blocks), format="csr"), f=self.f[keep], R=self.R[:, keep],
             leaves_row=newidx[self.leaves_row[sel]].astype(np.int32), leaves_root=self.leaves_root[sel], leaves_sign=self.leaves_sign[sel],
             n_x=len(blocks) * nloc, n_lambda=self.n_lambda)
+
+
+def _dmda_partition3(M, N, P, size):
+    """Process grid DMDACreate3d picks for PETSC_DECIDE (the 'squarish' rule of DMSetUp_DA_3D)."""
+    n = max(int(0.5 + ((N * N) * size / (P * M)) ** (1.0 / 3.0)), 1)
+    while n > 0:
+        pm = size // n
+        if n * pm == size:
+            break
+        n -= 1
+    n = max(n, 1)
+    m = max(int(0.5 + np.sqrt(M * size / (P * n))), 1)
+    p = 1
+    while m > 0:
+        p = size // (m * n)
+        if m * n * p == size:
+            break
+        m -= 1
+    if M > P and m < p:
+        m, p = p, m
+    return m, n, p
+
+
+def _dmda_node_ranges(M, m):
+    """Node range (inclusive) of each of the m element slabs along one direction: rank i owns M/m + (M%m > i)
+    nodes and the elements whose upper node it owns (DMDAGetElements)."""
+    own = [M // m + (1 if (M % m) > i else 0) for i in range(m)]
+    s = np.cumsum([0] + own)
+    return [((s[i] - 1 if i > 0 else 0), s[i + 1] - 1) for i in range(m)]
+
+
+class DmdaFeti:
+    """The problem of the reference's DMDA tutorial, src/tutorials/feti/ex71.c, as FETI hot-path inputs:
+    Q1 Poisson / elasticity (lambda = mu = 1, the tabulated element matrices :16-126 recomputed by quadrature)
+    on [0,cx] x [0,cy] x [0,cz] with unit cells, decomposed the way DMDACreate3d does for `size` ranks, x = 0 face
+    fixed IN the subdomain matrices (MatZeroRowsColumnsIS, diagonal 1/multiplicity, :305-349), b = 1 split by
+    multiplicity (QPTMatISToBlockDiag, qptransform.c:2095-2113), gluing by QPFetiGetBgtSF (gluing_links).
+    Subdomains touching x = 0 are non-singular; the others float (1 or 6 kernel vectors)."""
+
+    def __init__(self, cells=(7, 8, 9), size=6, physics="poisson", gluing="full", scale=True):
+        M, N, P = (c + 1 for c in cells)
+        self.physics, self.gluing = physics, gluing
+        nd = self.ndof = 3 if physics == "elasticity" else 1
+        kd = 6 if physics == "elasticity" else 1
+        self.procs = _dmda_partition3(M, N, P, size)
+        m, n, p = self.procs
+        rx, ry, rz = _dmda_node_ranges(M, m), _dmda_node_ranges(N, n), _dmda_node_ranges(P, p)
+        Ke = q1_elasticity_element(1.0, E=2.5, nu=0.25) if physics == "elasticity" else q1_poisson_element(1.0)
+        lex = [(a, b, c) for c in (0, 1) for b in (0, 1) for a in (0, 1)]
+        self.nsub = size
+        Ks, gids, Rs, coords = [], [], [], []
+        for kz in range(p):
+            for jy in range(n):
+                for ix in range(m):
+                    (x0, x1), (y0, y1), (z0, z1) = rx[ix], ry[jy], rz[kz]
+                    nx, ny, nz = x1 - x0 + 1, y1 - y0 + 1, z1 - z0 + 1
+                    kk, jj, ii = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+                    ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
+                    gids.append(((kk + z0) * N + (jj + y0)) * M + (ii + x0))
+                    coords.append(np.stack([ii + x0, jj + y0, kk + z0], axis=1).astype(float))
+                    ek, ej, ei = np.meshgrid(np.arange(nz - 1), np.arange(ny - 1), np.arange(nx - 1), indexing="ij")
+                    e0 = (ek.ravel() * ny + ej.ravel()) * nx + ei.ravel()
+                    offs = np.array([(c * ny + b) * nx + a for (a, b, c) in lex])
+                    en = e0[:, None] + offs[None, :]
+                    ed = (en[:, :, None] * nd + np.arange(nd)[None, None, :]).reshape(len(e0), 8 * nd)
+                    Ki = sp.coo_matrix((np.tile(Ke.ravel(), len(e0)), (np.repeat(ed, 8 * nd, axis=1).ravel(), np.tile(ed, (1, 8 * nd)).ravel())),
+                                       shape=(nx * ny * nz * nd,) * 2).tocsr()
+                    Ks.append(Ki)
+        mult = np.zeros(M * N * P, dtype=np.int64)
+        for g in gids:
+            mult[g] += 1
+        fs = []
+        for s, (Ki, g, X) in enumerate(zip(Ks, gids, coords)):
+            nl = len(g)
+            dn = np.nonzero(g % M == 0)[0]
+            if len(dn):
+                dd = (dn[:, None] * nd + np.arange(nd)[None, :]).ravel()
+                keep = np.ones(nl * nd)
+                keep[dd] = 0.0
+                Dk = sp.diags(keep)
+                fix = np.zeros(nl * nd)
+                fix[dd] = 1.0 / np.repeat(mult[g[dn]], nd)
+                Ki = (Dk @ Ki @ Dk + sp.diags(fix)).tocsr()
+                Rs.append(np.zeros((0, nl * nd)))
+            else:
+                if nd == 1:
+                    R = np.ones((nl, 1))
+                else:
+                    R = np.zeros((nl * 3, 6))
+                    R[0::3, 0] = R[1::3, 1] = R[2::3, 2] = 1.0
+                    R[0::3, 3], R[1::3, 3] = -X[:, 1], X[:, 0]
+                    R[1::3, 4], R[2::3, 4] = -X[:, 2], X[:, 1]
+                    R[0::3, 5], R[2::3, 5] = X[:, 2], -X[:, 0]
+                Q, _ = np.linalg.qr(R)
+                Rs.append(Q.T[:kd])
+            Ki.sum_duplicates()
+            Ki.eliminate_zeros()
+            Ki.sort_indices()
+            Ks[s] = Ki
+            fs.append(np.repeat(1.0 / mult[g], nd))
+        self.blocks, self.gids, self.Rblocks = Ks, gids, Rs
+        self.block_rowstart = np.concatenate([[0], np.cumsum([K.shape[0] for K in Ks])]).astype(np.int32)
+        self.N = int(self.block_rowstart[-1])
+        self.f = np.concatenate(fs)
+        copies = {}
+        for s, g in enumerate(gids):
+            for ln, gg in enumerate(g):
+                copies.setdefault(int(gg), []).append((s, ln))
+        rows_l, roots_l, vals_l = [], [], []
+        nrow = 0
+        for gg in sorted(copies):
+            cp = copies[gg]
+            for c in range(nd):  # the reference numbers the dofs node-major, so the links of one node are interleaved by component
+                for link in gluing_links(len(cp), gluing, scale):
+                    for t, v in link:
+                        sa, la = cp[t]
+                        rows_l.append(int(self.block_rowstart[sa]) + la * nd + c)
+                        roots_l.append(nrow)
+                        vals_l.append(v)
+                    nrow += 1
+        self.n_lambda = self.n_eq = nrow
+        self.leaves_row = np.asarray(rows_l, dtype=np.int32)
+        self.leaves_root = np.asarray(roots_l, dtype=np.int32)
+        self.leaves_sign = np.asarray(vals_l, dtype=np.float64)
+        self.B = sp.csr_matrix((self.leaves_sign, (self.leaves_root, self.leaves_row)), shape=(self.n_lambda, self.N))
+        self.c = np.zeros(self.n_lambda)
+        self.lb = np.full(self.n_lambda, -np.inf)
+        self.kdim = max(R.shape[0] for R in Rs)
+        # kernel as a dense (kdim x N) array, zero columns over the non-singular blocks (MatInv / MP projection input)
+        self.R = np.zeros((self.kdim, self.N))
+        for s, R in enumerate(Rs):
+            self.R[:R.shape[0], self.block_rowstart[s]:self.block_rowstart[s + 1]] = R
+
+    @property
+    def K(self):
+        K = sp.block_diag(self.blocks, format="csr")
+        K.sort_indices()
+        return K
+
+    def coarse(self):
+        """G = R'B' over the floating subdomains only (no zero rows), e = R'f; None, None if nothing floats."""
+        rows = []
+        for s, R in enumerate(self.Rblocks):
+            for k in range(R.shape[0]):
+                v = np.zeros(self.N)
+                v[self.block_rowstart[s]:self.block_rowstart[s + 1]] = R[k]
+                rows.append(v)
+        if not rows:
+            return None, None
+        Rm = sp.csr_matrix(np.array(rows))
+        G = (Rm @ self.B.T).tocsr()
+        G.sort_indices()
+        return G, Rm @ self.f
+
+    def local(self):
+        """All blocks on one rank, in the layout FetiDualQP consumes (CubeFeti.subset)."""
+        return dict(nblocks=self.nsub, block_rowstart=self.block_rowstart, K=self.K, f=self.f, R=self.R if self.kdim and np.any(self.R) else None,
+                    leaves_row=self.leaves_row, leaves_root=self.leaves_root, leaves_sign=self.leaves_sign, n_x=self.N, n_lambda=self.n_lambda)

@@ -64,7 +64,7 @@ class QP:
 
 
 class QPS:
-    """QPS front end: SetType("mpgp" | "smalxe" | "pcpg"), tolerances, Solve, statistics."""
+    """QPS front end: SetType("mpgp" | "smalxe" | "pcpg" | "ksp"), tolerances, Solve, statistics."""
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -85,7 +85,7 @@ class QPS:
         self.qp = qp
 
     def SetType(self, t):
-        if t not in ("mpgp", "smalxe", "pcpg"):
+        if t not in ("mpgp", "smalxe", "pcpg", "ksp"):
             raise ValueError("unknown QPS type %r" % t)  # QPSSetType: PETSC_ERR_ARG_UNKNOWN_TYPE
         self.type = t
         if t == "smalxe" and self.smalxe_opts is None:
@@ -100,7 +100,7 @@ class QPS:
         elif self.qp.lb is not None or self.qp.ub is not None:
             self.SetType("mpgp")
         else:
-            raise ValueError("unconstrained QP: QPSKSP is out of scope; use pcpg")
+            self.SetType("ksp")  # QPSKSP with KSPCG (qps.c:448, qpsksp.c:244)
 
     def SetTolerances(self, rtol=None, atol=None, divtol=None, max_it=None):  # QPSSetTolerances
         if rtol is not None:
@@ -184,6 +184,10 @@ class QPS:
             check(self.L.pmh_smalxe_solve(self.h))
             st = _lib.SmalxeStats()
             check(self.L.pmh_smalxe_get_stats(self.h, C.byref(st)))
+        elif self.type == "ksp":
+            st = _lib.PcpgStats()
+            check(self.L.pmh_ksp_cg_solve(self.ctx.h, qp.A.h, qp.b.p, qp.x.p, qp.pc.h if qp.pc is not None else None,
+                                          self.rtol, self.atol, self.divtol, self.max_it, C.byref(st)))
         else:
             st = _lib.PcpgStats()
             check(self.L.pmh_pcpg_solve(self.ctx.h, qp.A.h, qp.b.p, qp.x.p, qp.pf.h, qp.pc.h if qp.pc is not None else None,
