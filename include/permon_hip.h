@@ -290,6 +290,22 @@ int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
 int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
+/* ---- PC for the inner KSP of MATINV: multigrid V-cycle (PCMG semantics) ----------------------------------------
+ * The reference's iterative MATINV applies K^+ with a PETSc KSP whose PC is chosen by -mat_inv_pc_type
+ * (src/mat/impls/inv/matinv.c, MatInvGetKSP / MatInvSetUp).  pmh_mg is that PC on the device for PCMG-like set-ups:
+ * A[0] is the fine operator (the same CSR the MATBLOCKDIAG holds), A[l+1] = P[l]' A[l] P[l] are handed over by the
+ * caller, P[l] is n_l x n_{l+1}.  Smoother: Chebyshev of the given degree on D^-1 A over
+ * [lo_frac, hi_frac] x lambda_max[l] (PETSc's PCMG/GAMG default is 0.1, 1.1), applied before and after the coarse
+ * correction; the coarsest level is solved block-wise by the dense (pseudo-)inverses in coarse_pinv (row-major blocks
+ * of sizes coarse_rowstart[b+1]-coarse_rowstart[b], concatenated).  The CSR handles stay owned by the caller. */
+typedef struct pmh_mg_s *pmh_mg;
+int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
+                  const double *coarse_pinv_host, pmh_mg *mg);
+int pmh_mg_apply(pmh_mg mg, const double *b_dev, double *x_dev); /* x = V(b), zero initial guess (PCApply) */
+int pmh_mg_stats(pmh_mg mg, long long *fine_spmv);
+int pmh_mg_destroy(pmh_mg mg);
+int pmh_matinv_set_pc_mg(pmh_matinv Kplus, pmh_mg mg); /* NULL: back to Jacobi / none */
+
 /* ---- QPS PCPG (src/qps/impls/pcpg/pcpg.c:51-134) -------------------------------------------------------- */
 typedef struct {
   int    iteration, reason;

@@ -170,6 +170,11 @@ _PROTOS = {
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
+    "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(vp)],
+    "pmh_mg_apply": [vp, vp, vp],
+    "pmh_mg_stats": [vp, C.POINTER(C.c_longlong)],
+    "pmh_mg_destroy": [vp],
+    "pmh_matinv_set_pc_mg": [vp, vp],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

@@ -118,7 +118,9 @@ class FetiDualQP:
         return self.lam.to_numpy() + self.lam_tilde.to_numpy()
 
     def primal_solution(self, G_host, e_host=None):
-        """u = K^+(f - B' lambda) - R alpha, alpha = (G G')^{-1} G (F lambda - d) (QPTDualizePostSolve, qptransform.c:783-833)."""
+        """The two device-side pieces of QPTDualizePostSolve_Private (qptransform.c:783-833): returns
+        (K^+(f - B' lambda), F lambda - d).  The caller finishes on the host with the small coarse solve:
+        u = K^+(f - B' lambda) - R alpha,  G' alpha = d - F lambda, i.e. alpha = -(G G')^{-1} G (F lambda - d)."""
         ctx = self.ctx
         lam = ctx.vec_from(self.dual_solution())
         t = ctx.vec(self.tprim.n)

@@ -223,6 +223,7 @@ struct pmh_matinv_s {
   // P_R = I - R R', R = block-wise orthonormal kernel basis stored as kdim columns of length n
   int     kdim;
   double *d_R, *d_coef, *d_fproj, *d_kpart;
+  pmh_mg  mg; // optional V-cycle preconditioner (pmh_matinv_set_pc_mg); NULL: Jacobi / none
 };
 
 #define SEG_LOOP(i, b, rs, wgs) \
@@ -261,18 +262,22 @@ __device__ __forceinline__ double seg_total(const double *__restrict__ part, int
 #define BIQ(bi, q, b, k) (bi)[((q)*nb + (b)) * 2 + (k)]
 
 // start: u = 0, r = f, z = Dinv r, p = z; partials r.z and r.r
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ rs, int wgs, const double *__restrict__ f, const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, double *__restrict__ part, int ld)
+// extpc: z comes from an external preconditioner afterwards (k_cg_start_pz completes the start)
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ rs, int wgs, int extpc, const double *__restrict__ f, const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, double *__restrict__ part, int ld)
 {
   __shared__ double lds[PMH_BLOCK / 64];
   double            s0 = 0.0, s1 = 0.0;
   SEG_LOOP(i, b, rs, wgs)
   {
-    double ri = f[i], zi = dinv[i] * ri;
+    double ri = f[i];
     u[i] = 0.0;
     r[i] = ri;
-    z[i] = zi;
-    p[i] = zi;
-    s0 += ri * zi;
+    if (!extpc) {
+      const double zi = dinv[i] * ri;
+      z[i] = zi;
+      p[i] = zi;
+      s0 += ri * zi;
+    }
     s1 += ri * ri;
   }
   s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
@@ -281,6 +286,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_start(const int *__restrict__ 
     part[blockIdx.x]      = s0;
     part[ld + blockIdx.x] = s1;
   }
+}
+
+// external preconditioner: p = z, partial r.z
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_start_pz(const int *__restrict__ rs, int wgs, const double *__restrict__ r, const double *__restrict__ z, double *__restrict__ p, double *__restrict__ part)
+{
+  __shared__ double lds[PMH_BLOCK / 64];
+  double            s0 = 0.0;
+  SEG_LOOP(i, b, rs, wgs)
+  {
+    const double zi = z[i];
+    p[i] = zi;
+    s0 += r[i] * zi;
+  }
+  s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = s0;
 }
 
 // one workgroup per block: rz, tolerance (KSPConvergedDefault: ||r|| <= max(rtol ||b||, atol), zero initial guess), active set
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_seg_dot(const int *__restrict__ r
 
 // alpha_b = rz_b / (p'Ap)_b (every workgroup re-sums its block's partials in the same fixed order);
 // u += alpha_b p; r -= alpha_b Ap; z = Dinv r; partials r.z, r.r
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int nb, int wgs, int q, const int *__restrict__ done, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, int ld)
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int nb, int wgs, int q, int extpc, const int *__restrict__ done, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, int ld)
 {
   __shared__ double lds[PMH_BLOCK / 64];
   if (*done) return;
@@ -329,17 +349,19 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restric
   SEG_LOOP(i, b, rs, wgs)
   {
     double ri = r[i] - alpha * Ap[i];
-    double zi = dinv[i] * ri;
     u[i] += alpha * p[i];
     r[i] = ri;
-    z[i] = zi;
-    s0 += ri * zi;
+    if (!extpc) {
+      const double zi = dinv[i] * ri;
+      z[i] = zi;
+      s0 += ri * zi;
+    }
     s1 += ri * ri;
   }
   s0 = pmh_block_reduce<PMH_RED_SUM>(s0, lds);
   s1 = pmh_block_reduce<PMH_RED_SUM>(s1, lds);
   if (threadIdx.x == 0) {
-    partB[blockIdx.x]      = s0;
+    if (!extpc) partB[blockIdx.x] = s0; // external preconditioner: k_seg_dot(r, z) fills this half afterwards
     partB[ld + blockIdx.x] = s1;
   }
 }
@@ -438,6 +460,7 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   M->total_spmv   = 0;
   M->kdim         = 0;
   M->d_R = M->d_coef = M->d_fproj = M->d_kpart = nullptr;
+  M->mg  = nullptr;
   const size_t nb = sizeof(double) * (size_t)(M->n ? M->n : 1);
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->dinv));
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->r));
@@ -527,7 +550,12 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     f = M->d_fproj;
   }
   PMH_HIP(hipMemsetAsync(M->d_nactive, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
+  const int extpc = M->mg ? 1 : 0;
+  hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, extpc, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
+  if (extpc) {
+    PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, nullptr));
+    hipLaunchKernelGGL(k_cg_start_pz, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const double *)M->r, (const double *)M->z, M->p, M->d_part);
+  }
   hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(PMH_BLOCK), 0, st, nb, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->d_done, M->rtol, M->atol);
   hipLaunchKernelGGL(k_cg_init_done, dim3(1), dim3(1), 0, st, (const int *)M->d_nactive, M->d_done);
   PMH_HIP(hipGetLastError());
@@ -536,12 +564,17 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   epi.kind = PMH_EPI_NONE;
   epi.halt = M->d_done; // once every block has converged the remaining enqueued launches return at once
   int it = 0, next_check = (M->last_max_its > 8) ? (M->last_max_its - 2) : 4;
+  if (extpc) next_check = (M->last_max_its > 2) ? (M->last_max_its - 1) : 1; // few, expensive iterations: do not overshoot
   while (it < M->max_it) {
     const int q = it & 1;
     PMH_CHK(pmh_csr_spmv_launch(M->K->K, M->p, M->Ap, epi));
     M->total_spmv++;
     hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->p, (const double *)M->Ap, M->d_part);
-    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld);
+    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, extpc, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld);
+    if (extpc) { // z = V(r) over all blocks (converged blocks ignore it), then the per-block r.z
+      PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, M->d_done));
+      hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->r, (const double *)M->z, M->d_partB);
+    }
     hipLaunchKernelGGL(k_cg_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, it, M->max_it, M->d_bs, M->d_bi, M->d_nactive, M->d_done, (const double *)M->d_partB, ld, (const double *)M->z, M->p);
     PMH_HIP(hipGetLastError());
     it++;
@@ -549,7 +582,7 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
       hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, st, (const int *)M->d_nactive, M->h_nactive);
       PMH_HIP(hipStreamSynchronize(st));
       if (*M->h_nactive == 0) break;
-      next_check = it + 2;
+      next_check = it + (extpc ? 1 : 2);
     }
   }
   // iteration counts per block
@@ -562,6 +595,14 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     PMH_CHK(matinv_project(M, u, M->d_fproj));
     PMH_CHK(pmh_memcpy_d2d(ctx, u, M->d_fproj, sizeof(double) * (size_t)M->n));
   }
+  return PMH_SUCCESS;
+}
+
+// PC of the inner KSP (matinv.c: -mat_inv_pc_type): a V-cycle built by pmh_mg_create on this matrix (level 0 = K)
+extern "C" int pmh_matinv_set_pc_mg(pmh_matinv M, pmh_mg mg)
+{
+  PMH_ARG(M);
+  M->mg = mg; // NULL restores Jacobi / none
   return PMH_SUCCESS;
 }
 

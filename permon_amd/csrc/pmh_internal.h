@@ -117,3 +117,6 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
+
+// ---- multigrid preconditioner (mg.hip) -------------------------------------------------------------------------
+int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt); // halt: device flag turning the launches into no-ops

@@ -11,7 +11,7 @@ Everything here is set-up; the iteration runs in libpermonhip.
 import numpy as np
 import scipy.sparse as sp
 
-__all__ = ["q1_elasticity_element", "q1_poisson_element", "gluing_links", "CubeFeti", "DmdaFeti"]
+__all__ = ["q1_elasticity_element", "q1_poisson_element", "gluing_links", "CubeFeti", "DmdaFeti", "box_mg_hierarchy"]
 
 
 def _gauss_q1():
@@ -429,3 +429,86 @@ class DmdaFeti:
         """All blocks on one rank, in the layout FetiDualQP consumes (CubeFeti.subset)."""
         return dict(nblocks=self.nsub, block_rowstart=self.block_rowstart, K=self.K, f=self.f, R=self.R if self.kdim and np.any(self.R) else None,
                     leaves_row=self.leaves_row, leaves_root=self.leaves_root, leaves_sign=self.leaves_sign, n_x=self.N, n_lambda=self.n_lambda)
+
+
+# ---- multigrid hierarchy for structured box blocks (input of pmh_mg_create) -------------------------------------
+def _interp1d(n):
+    """Linear interpolation onto n grid nodes from the coarse nodes {0,2,4,...} U {n-1}: (n x nc) CSR, exact for
+    linear functions also when the last coarse interval is short (n even)."""
+    c = list(range(0, n, 2))
+    if c[-1] != n - 1:
+        c.append(n - 1)
+    if len(c) == n:
+        return sp.identity(n, format="csr")
+    rows, cols, vals = [], [], []
+    for j in range(len(c) - 1):
+        a, b = c[j], c[j + 1]
+        for i in range(a, b):
+            t = (i - a) / float(b - a)
+            rows.append(i), cols.append(j), vals.append(1.0 - t)
+            if t > 0.0:
+                rows.append(i), cols.append(j + 1), vals.append(t)
+    rows.append(n - 1), cols.append(len(c) - 1), vals.append(1.0)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n, len(c)))
+
+
+def _lambda_max_dinv_a(A, its=20, seed=0):
+    """Power-method estimate of lambda_max(D^-1 A) (what KSPChebyshev's eigen-estimate provides)."""
+    d = A.diagonal()
+    dinv = np.where(d != 0.0, 1.0 / np.where(d != 0.0, d, 1.0), 1.0)
+    v = np.random.default_rng(seed).standard_normal(A.shape[0])
+    lam = 1.0
+    for _ in range(its):
+        w = dinv * (A @ v)
+        lam = np.linalg.norm(w) / max(np.linalg.norm(v), 1e-300)
+        v = w / max(np.linalg.norm(w), 1e-300)
+    return float(lam)
+
+
+def box_mg_hierarchy(blocks, dims, ndof, min_nodes=27, max_levels=12):
+    """Geometric multigrid hierarchy for a block-diagonal matrix whose blocks are Q1 discretisations on
+    nx x ny x nz node boxes (node-major dof numbering, x fastest): trilinear prolongation P_l (x) I_ndof, Galerkin
+    coarse operators A_{l+1} = P_l' A_l P_l.  Trilinear interpolation reproduces constants and rigid-body modes, so
+    floating blocks stay consistently singular down to the coarsest level, where a dense pseudo-inverse is used.
+    blocks: list of scipy matrices; dims: list of (nx, ny, nz); congruent blocks (same object) are processed once.
+    Returns dict(A=[...], P=[...], lambda_max=[...], coarse_rowstart, coarse_pinv) with block-concatenated matrices."""
+    cache = {}
+    per_block = []
+    for Kb, dm in zip(blocks, dims):
+        key = (id(Kb), tuple(dm))
+        if key not in cache:
+            A, P, lam = [Kb.tocsr()], [], []
+            d = tuple(int(v) for v in dm)
+            while len(A) < max_levels and d[0] * d[1] * d[2] > min_nodes and max(d) > 2:
+                P1 = [_interp1d(n) for n in d]
+                Pn = sp.kron(P1[2], sp.kron(P1[1], P1[0], format="csr"), format="csr")
+                Pl = sp.kron(Pn, sp.identity(ndof, format="csr"), format="csr") if ndof > 1 else Pn
+                Ac = (Pl.T @ A[-1] @ Pl).tocsr()
+                Ac = 0.5 * (Ac + Ac.T)
+                Ac.sort_indices()
+                lam.append(_lambda_max_dinv_a(A[-1]))
+                P.append(Pl)
+                A.append(Ac.tocsr())
+                d = tuple(p.shape[1] for p in P1)
+            pinv = np.linalg.pinv(A[-1].toarray(), rcond=1e-10, hermitian=True)
+            cache[key] = (A, P, lam, pinv)
+        per_block.append(cache[key])
+    nlev = min(len(pb[0]) for pb in per_block)
+    out = dict(A=[], P=[], lambda_max=[])
+    for l in range(nlev):
+        # a block with a deeper private hierarchy is cut at the common depth: its level-l operator is re-inverted densely below
+        Al = sp.block_diag([pb[0][l] for pb in per_block], format="csr")
+        Al.sort_indices()
+        out["A"].append(Al)
+        if l + 1 < nlev:
+            Pl = sp.block_diag([pb[1][l] for pb in per_block], format="csr")
+            Pl.sort_indices()
+            out["P"].append(Pl)
+            out["lambda_max"].append(max(pb[2][l] for pb in per_block))
+    sizes = [pb[0][nlev - 1].shape[0] for pb in per_block]
+    out["coarse_rowstart"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pinvs = []
+    for pb in per_block:
+        pinvs.append(pb[3] if len(pb[0]) == nlev else np.linalg.pinv(pb[0][nlev - 1].toarray(), rcond=1e-10, hermitian=True))
+    out["coarse_pinv"] = np.concatenate([p.ravel() for p in pinvs]) if pinvs else np.zeros(0)
+    return out

@@ -102,6 +102,13 @@ class MatInv:
         assert R.ndim == 2 and R.shape[1] == self.K.n
         check(self.ctx.L.pmh_matinv_set_nullspace(self.h, R.shape[0], R.ctypes.data_as(C.c_void_p)))
 
+    def set_pc_mg(self, hier, degree=2, lo=0.1, hi=1.1):
+        """PCMG-like V-cycle as the PC of the inner CG (-mat_inv_pc_type mg): hier is box_mg_hierarchy()'s dict whose
+        level 0 is this matrix (the resident CSR of the MATBLOCKDIAG is reused, not uploaded twice)."""
+        self.mg = MG(self.ctx, hier, degree=degree, lo=lo, hi=hi, fine=self.K.K)
+        check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, self.mg.h))
+        return self.mg
+
     def mult(self, f, u):  # MatMult_Inv
         check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
 
@@ -113,6 +120,47 @@ class MatInv:
     def destroy(self):
         if self.h:
             self.ctx.L.pmh_matinv_destroy(self.h)
+            self.h = None
+
+
+class MG:
+    """pmh_mg: Galerkin multigrid V-cycle with Chebyshev/Jacobi smoothing and dense coarse pseudo-inverses (PCMG role)."""
+
+    def __init__(self, ctx, hier, degree=2, lo=0.1, hi=1.1, fine=None):
+        self.ctx = ctx
+        A, P = hier["A"], hier["P"]
+        self.nlevels = len(A)
+
+        def up(M):
+            M = M.tocsr()
+            M.sort_indices()
+            return CsrMat(ctx, M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+
+        self.A = [fine if fine is not None else up(A[0])] + [up(a) for a in A[1:]]
+        self.P = [up(p) for p in P]
+        if self.A[0].nrows != A[0].shape[0]:
+            raise ValueError("fine operator size does not match the hierarchy")
+        Ah = (C.c_void_p * self.nlevels)(*[a.h for a in self.A])
+        Ph = (C.c_void_p * max(1, len(self.P)))(*[p.h for p in self.P])
+        lam = np.ascontiguousarray(hier["lambda_max"] if len(self.P) else [1.0], dtype=np.float64)
+        crs = np.ascontiguousarray(hier["coarse_rowstart"], dtype=np.int32)
+        cpinv = np.ascontiguousarray(hier["coarse_pinv"], dtype=np.float64)
+        h = C.c_void_p()
+        check(ctx.L.pmh_mg_create(ctx.h, self.nlevels, Ah, Ph, int(degree), lam.ctypes.data_as(C.c_void_p), float(lo), float(hi), crs.size - 1,
+                                  crs.ctypes.data_as(C.c_void_p), cpinv.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    def apply(self, b, x):  # PCApply
+        check(self.ctx.L.pmh_mg_apply(self.h, b.p, x.p))
+
+    def fine_spmv(self):
+        n = C.c_longlong()
+        check(self.ctx.L.pmh_mg_stats(self.h, C.byref(n)))
+        return n.value
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_mg_destroy(self.h)
             self.h = None
 
 

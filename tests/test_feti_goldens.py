@@ -124,7 +124,7 @@ def test_gpu_ex71_poisson_iteration_goldens(ctx, oracle, goldens, gtype):
     _, _, _, F, d = _oracle_dual(oracle, prob)
     ref = oracle.pcpg(F.op, d, np.zeros(prob.n_lambda), None, rtol=1e-5)
     lam = dq.dual_solution()
-    assert np.linalg.norm(lam - ref["x"]) <= 1e-8 * np.linalg.norm(ref["x"])
+    assert np.linalg.norm(lam - ref["x"]) <= 1e-4 * np.linalg.norm(ref["x"])  # both stopped at rtol 1e-5
 
 
 @pytest.mark.gpu
@@ -140,7 +140,7 @@ def test_gpu_ex71_elasticity_iteration_goldens(ctx, goldens, lumped):
     u, Fl = dq.primal_solution(None)
     lam = dq.dual_solution()
     G, e = prob.coarse()
-    alpha = np.linalg.solve((G @ G.T).toarray(), G @ Fl)
+    alpha = -np.linalg.solve((G @ G.T).toarray(), G @ Fl)  # G' alpha = d - F lambda
     Rm = np.zeros((G.shape[0], prob.N))
     r0 = 0
     for s, R in enumerate(prob.Rblocks):

@@ -1,0 +1,145 @@
+"""GPU tests of the multigrid preconditioner of the MATINV inner CG (pmh_mg_*, pmh_matinv_set_pc_mg):
+the V-cycle against a numpy restatement of the same cycle, K^+ with the V-cycle PC against the dense pseudo-inverse and
+against the Jacobi-preconditioned path, and a contact TFETI solve that must not notice which PC the inner KSP uses."""
+import numpy as np
+import pytest
+
+import permon_amd as pa
+from permon_amd.chain import FetiDualQP
+from permon_amd.feti import CubeFeti, DmdaFeti, box_mg_hierarchy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def _vcycle_numpy(H, degree, lo, hi):
+    A, P, lam = H["A"], H["P"], H["lambda_max"]
+    nl = len(A)
+    dinv = [1.0 / a.diagonal() for a in A]
+    crs = H["coarse_rowstart"]
+    blocks, o = [], 0
+    for b in range(len(crs) - 1):
+        m = crs[b + 1] - crs[b]
+        blocks.append(H["coarse_pinv"][o:o + m * m].reshape(m, m))
+        o += m * m
+
+    def smooth(l, b, x):
+        a_, b_ = lo * lam[l], hi * lam[l]
+        th, de = (a_ + b_) / 2, (b_ - a_) / 2
+        sig = th / de
+        rho = 1 / sig
+        if x is None:
+            r = dinv[l] * b
+            d = r / th
+            x = d.copy()
+        else:
+            r = dinv[l] * (b - A[l] @ x)
+            d = r / th
+            x = x + d
+        for _ in range(1, degree):
+            rn = 1 / (2 * sig - rho)
+            r = r - dinv[l] * (A[l] @ d)
+            d = rn * rho * d + 2 * rn / de * r
+            x = x + d
+            rho = rn
+        return x
+
+    def V(l, b):
+        if l == nl - 1:
+            return np.concatenate([blocks[k] @ b[crs[k]:crs[k + 1]] for k in range(len(blocks))])
+        x = smooth(l, b, None)
+        x = x + P[l] @ V(l + 1, P[l].T @ (b - A[l] @ x))
+        return smooth(l, b, x)
+
+    return lambda b: V(0, b)
+
+
+def _cube_hierarchy(f):
+    nn = f.nel + 1
+    return box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, f.ndof)
+
+
+@pytest.mark.parametrize("physics,degree", [("poisson", 2), ("elasticity", 2), ("elasticity", 3)])
+def test_vcycle_matches_numpy_restatement(ctx, physics, degree):
+    f = CubeFeti((2, 1, 1), 8, physics, contact=False)
+    H = _cube_hierarchy(f)
+    assert len(H["A"]) >= 3
+    mg = pa.MG(ctx, H, degree=degree)
+    b = np.random.default_rng(5).standard_normal(f.N)
+    x = ctx.vec(f.N)
+    mg.apply(ctx.vec_from(b), x)
+    ref = _vcycle_numpy(H, degree, 0.1, 1.1)(b)
+    assert np.linalg.norm(x.to_numpy() - ref) <= 1e-11 * np.linalg.norm(ref)
+    # symmetric: <V a, b> == <a, V b>
+    a = np.random.default_rng(6).standard_normal(f.N)
+    y = ctx.vec(f.N)
+    mg.apply(ctx.vec_from(a), y)
+    assert abs(y.to_numpy() @ b - a @ x.to_numpy()) <= 1e-10 * abs(a @ x.to_numpy())
+
+
+@pytest.mark.parametrize("nel", [8, 11])  # 11: odd element count, non-nested last coarse interval
+def test_matinv_with_mg_pc(ctx, nel):
+    f = CubeFeti((2, 1, 1), nel, "elasticity", contact=False)
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
+    rhs = np.random.default_rng(1).standard_normal(f.N)
+    uj, um = ctx.vec(f.N), ctx.vec(f.N)
+    Mj = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
+    Mj.mult(ctx.vec_from(rhs), uj)
+    its_j, _ = Mj.last_iterations()
+    Mm = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
+    mg = Mm.set_pc_mg(_cube_hierarchy(f))
+    Mm.mult(ctx.vec_from(rhs), um)
+    its_m, spmv_m = Mm.last_iterations()
+    assert its_m <= 20 and its_m * 4 < its_j  # mesh-independent and far below the Jacobi count
+    assert mg.fine_spmv() >= 4 * (its_m + 1) and spmv_m >= its_m  # 2*degree fine SpMVs per V-cycle, one V-cycle per CG step + start
+    ref = uj.to_numpy()
+    assert np.linalg.norm(um.to_numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+    # Moore-Penrose: K u = P_R rhs and R'u = 0
+    u = um.to_numpy()
+    Rm = f.kernel_matrix()
+    rp = rhs - Rm @ (Rm.T @ rhs)
+    assert np.linalg.norm(f.K @ u - rp) <= 1e-9 * np.linalg.norm(rp)
+    assert np.linalg.norm(Rm.T @ u) <= 1e-9 * np.linalg.norm(u)
+    # second application reuses the hierarchy and the iteration-count hint
+    Mm.mult(ctx.vec_from(2.0 * rhs), um)
+    assert np.linalg.norm(um.to_numpy() - 2.0 * ref) <= 1e-9 * np.linalg.norm(ref) * 2.0
+
+
+def test_mg_on_heterogeneous_dmda_blocks(ctx):
+    """ex71 elasticity slabs: blocks of different sizes, one of them non-singular (Dirichlet in the matrix), thin in x."""
+    prob = DmdaFeti((8, 6, 4), 7, "elasticity")
+    dims = [(2, 7, 5), (3, 7, 5)] + [(2, 7, 5)] * 5
+    assert [d[0] * d[1] * d[2] * 3 for d in dims] == [K.shape[0] for K in prob.blocks]
+    H = box_mg_hierarchy(prob.blocks, dims, 3)
+    K = pa.MatBlockDiag.from_scipy(ctx, prob.block_rowstart, prob.K)
+    rhs = np.random.default_rng(2).standard_normal(prob.N)
+    uj, um = ctx.vec(prob.N), ctx.vec(prob.N)
+    Mj = pa.MatInv(K, rtol=1e-12, nullspace=prob.R)
+    Mj.mult(ctx.vec_from(rhs), uj)
+    Mm = pa.MatInv(K, rtol=1e-12, nullspace=prob.R)
+    Mm.set_pc_mg(H)
+    Mm.mult(ctx.vec_from(rhs), um)
+    assert Mm.last_iterations()[0] < Mj.last_iterations()[0]
+    assert np.linalg.norm(um.to_numpy() - uj.to_numpy()) <= 1e-8 * np.linalg.norm(uj.to_numpy())
+
+
+def test_contact_tfeti_solve_is_independent_of_the_inner_pc(ctx):
+    f = CubeFeti((2, 2, 1), 6, "elasticity", contact=True)
+    G, e = f.coarse()
+    sols, its = [], []
+    for use_mg in (False, True):
+        q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-11)
+        if use_mg:
+            q.Kplus.set_pc_mg(_cube_hierarchy(f))
+        st = q.solve_smalxe(rtol=1e-6)
+        assert st.reason > 0
+        sols.append(q.dual_solution())
+        its.append((st.iteration, st.inner_iter_accu))
+    assert its[0] == its[1]  # same outer / inner MPGP counts: K^+ is the same operator to 1e-11
+    assert np.linalg.norm(sols[0] - sols[1]) <= 1e-7 * np.linalg.norm(sols[0])
