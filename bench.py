@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--variant", default="obstacle", choices=["obstacle", "twosided"])
     ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
+    ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
+    ap.add_argument("--mg-precision", choices=["fp32", "fp64"], default="fp32", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
+    ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
     ap.add_argument("--cpu-its", type=int, default=24, help="c2: MPGP iterations of the bounded CPU-baseline sample")
@@ -304,7 +307,11 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     local = f.subset(range(rank * per, (rank + 1) * per))
     t_gen = time.time() - t0
     t0 = time.time()
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol)
+    hier = None
+    if a.kplus_pc == "mg":  # Galerkin hierarchy of the congruent cubes (host set-up, seconds)
+        nn = a.nel + 1
+        hier = pa.box_mg_hierarchy([f.Ki] * per, [(nn, nn, nn)] * per, 3)
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_precision=a.mg_precision, bsr3=not a.no_bsr3)
     qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
     t_setup = time.time() - t0
     Kcsr = q.K.K
@@ -319,8 +326,11 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
 
     qps.RunFixed(warmup)
     q.lam.set(0.0)
-    Kcsr.timing_enable(60000)
+    q.Kplus.timing_enable(60000)
+    if hier is not None:
+        q.Kplus.mg.timing_enable(60000)
     _, spmv1 = q.Kplus.last_iterations()
+    mgs1 = q.Kplus.mg.fine_spmv() if hier is not None else 0
     barrier()
     t1 = time.perf_counter()
     st = qps.RunFixed(steps)
@@ -334,27 +344,45 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         dt = float(tt.item())
     assert st.iteration == steps, (st.iteration, steps)
     kits, spmv2 = q.Kplus.last_iterations()
-    n_k, ms_k = Kcsr.timing_get(0)
-    b_k = 12.0 * Kcsr.nnz + 20.0 * Kcsr.nrows
+    mgs2 = q.Kplus.mg.fine_spmv() if hier is not None else 0
+    # dominant kernel: the K x product.  With the V-cycle PC most of them are the cycle's fine-level launches
+    # (3x3-block kernel, fp32 or fp64); without it they are the CG's own products.
+    n_cg, ms_cg, b_cg = q.Kplus.timing_get()
+    if hier is not None:
+        n_k, ms_k, b_k = q.Kplus.mg.timing_get()
+        kname = "k_bsr3<%s>: fine-level K x of the V-cycle (3x3 blocks, %s B per non-zero)" % (("float", "4.44") if a.mg_precision == "fp32" else ("double", "8.44"))
+        kpat = "void k_bsr3<float" if a.mg_precision == "fp32" else "void k_bsr3<double"
+    else:
+        n_k, ms_k, b_k = n_cg, ms_cg, b_cg
+        kname = ("k_bsr3<double>: K x of the block CG (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
+                 else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
+        kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
+    ms_all = ms_k + (ms_cg if hier is not None else 0.0)
     achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+    pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(2)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision)) if hier is not None else "Jacobi-CG"
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
-                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise Jacobi-CG K^+ (rtol %.0e)"
-                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, a.kplus_rtol),
+                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+ (rtol %.0e)"
+                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, pc_text, a.kplus_rtol),
         "parallelism": "%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world),
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
-        "kplus": {"spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "last_block_cg_iterations": kits},
+        "kplus": {"pc": a.kplus_pc, "cg_spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(steps, 1),
+                  "last_block_cg_iterations": kits},
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "roofline": {
-            "bound": "hbm", "kernel": "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+",
+            "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("void k_spmv_stream<0, 2048,") if (a.nel == 43 and world == 1) else None,
+            "traffic": pmc_traffic(kpat) if (a.nel == 43 and world == 1) else None,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
             "share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
+            "all_fine_K_products": {"launches": n_k + (n_cg if hier is not None else 0), "share_of_step_time": (ms_all * 1e-3) / dt if n_k else None,
+                                    "cg_product_GBps": (b_cg / (ms_cg / n_cg * 1e-3) / 1e9) if n_cg else None},
         },
     }
-    Kcsr.timing_enable(0)
+    q.Kplus.timing_enable(0)
+    if hier is not None:
+        q.Kplus.mg.timing_enable(0)
     return res, f, G, q.b.to_numpy(), q.lb_new.to_numpy()
 
 

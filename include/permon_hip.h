@@ -297,14 +297,25 @@ int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALX
  * caller, P[l] is n_l x n_{l+1}.  Smoother: Chebyshev of the given degree on D^-1 A over
  * [lo_frac, hi_frac] x lambda_max[l] (PETSc's PCMG/GAMG default is 0.1, 1.1), applied before and after the coarse
  * correction; the coarsest level is solved block-wise by the dense (pseudo-)inverses in coarse_pinv (row-major blocks
- * of sizes coarse_rowstart[b+1]-coarse_rowstart[b], concatenated).  The CSR handles stay owned by the caller. */
+ * of sizes coarse_rowstart[b+1]-coarse_rowstart[b], concatenated).  The CSR handles stay owned by the caller.
+ * precision: PMH_MG_FP64, or PMH_MG_FP32 = the cycle (operators, vectors, coarse inverses) in single precision -- it only
+ * preconditions the fp64 CG; needs 3x3-block operators (elasticity, PETSc's BAIJ bs=3 case) on every smoothed level. */
+#define PMH_MG_FP64 0
+#define PMH_MG_FP32 1
 typedef struct pmh_mg_s *pmh_mg;
 int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
-                  const double *coarse_pinv_host, pmh_mg *mg);
+                  const double *coarse_pinv_host, int precision, pmh_mg *mg);
 int pmh_mg_apply(pmh_mg mg, const double *b_dev, double *x_dev); /* x = V(b), zero initial guess (PCApply) */
 int pmh_mg_stats(pmh_mg mg, long long *fine_spmv);
+int pmh_mg_timing_enable(pmh_mg mg, int max_launches); /* HIP-event pairs around the fine-level operator launches */
+int pmh_mg_timing_get(pmh_mg mg, int *launches, double *total_ms, double *bytes_per_launch);
 int pmh_mg_destroy(pmh_mg mg);
 int pmh_matinv_set_pc_mg(pmh_matinv Kplus, pmh_mg mg); /* NULL: back to Jacobi / none */
+/* MATINV's own K x product on the 3x3-block kernel (PETSc MATSEQBAIJ role: 8.44 instead of 12 bytes per non-zero);
+ * returns PMH_ERR_SUP if K has no 3x3 block structure.  Timing as pmh_csr_timing_*. */
+int pmh_matinv_enable_bsr3(pmh_matinv Kplus);
+int pmh_matinv_timing_enable(pmh_matinv Kplus, int max_launches);
+int pmh_matinv_timing_get(pmh_matinv Kplus, int *launches, double *total_ms, double *bytes_per_launch);
 
 /* ---- QPS PCPG (src/qps/impls/pcpg/pcpg.c:51-134) -------------------------------------------------------- */
 typedef struct {

@@ -170,7 +170,12 @@ _PROTOS = {
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
-    "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(vp)],
+    "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
+    "pmh_mg_timing_enable": [vp, C.c_int],
+    "pmh_mg_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "pmh_matinv_enable_bsr3": [vp],
+    "pmh_matinv_timing_enable": [vp, C.c_int],
+    "pmh_matinv_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_mg_apply": [vp, vp, vp],
     "pmh_mg_stats": [vp, C.POINTER(C.c_longlong)],
     "pmh_mg_destroy": [vp],

@@ -12,7 +12,7 @@ from .qps import QP, QPS
 class FetiDualQP:
     """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
 
-    def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True):
+    def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False):
         """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
         lb: dual lower bound (-inf on equality rows, 0 on inequality rows)."""
         self.ctx = ctx
@@ -20,6 +20,10 @@ class FetiDualQP:
         self.n_lambda = nl
         self.K = MatBlockDiag.from_scipy(ctx, local["block_rowstart"], local["K"])
         self.Kplus = MatInv(self.K, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=local["R"])
+        if bsr3:  # K x of the inner CG on the 3x3-block kernel (BAIJ bs=3)
+            self.Kplus.enable_bsr3()
+        if mg_hierarchy is not None:  # -mat_inv_pc_type mg: V-cycle PC for the inner CG (feti.box_mg_hierarchy)
+            self.Kplus.set_pc_mg(mg_hierarchy, degree=mg_degree, precision=mg_precision)
         self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
         # F = B K^+ B' (QPTDualize qptransform.c:1103-1128)
         self.F = MatCreateFetiDual(self.B, self.Kplus)

@@ -224,6 +224,7 @@ struct pmh_matinv_s {
   int     kdim;
   double *d_R, *d_coef, *d_fproj, *d_kpart;
   pmh_mg  mg; // optional V-cycle preconditioner (pmh_matinv_set_pc_mg); NULL: Jacobi / none
+  pmh_bsr3 Kb; // optional 3x3-block copy of K for the CG's own product (pmh_matinv_enable_bsr3)
 };
 
 #define SEG_LOOP(i, b, rs, wgs) \
@@ -461,6 +462,7 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   M->kdim         = 0;
   M->d_R = M->d_coef = M->d_fproj = M->d_kpart = nullptr;
   M->mg  = nullptr;
+  M->Kb  = nullptr;
   const size_t nb = sizeof(double) * (size_t)(M->n ? M->n : 1);
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->dinv));
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->r));
@@ -520,6 +522,7 @@ extern "C" int pmh_matinv_destroy(pmh_matinv M)
   if (M->d_coef) pmh_free(ctx, M->d_coef);
   if (M->d_fproj) pmh_free(ctx, M->d_fproj);
   if (M->d_kpart) pmh_free(ctx, M->d_kpart);
+  pmh_bsr3_destroy(M->Kb);
   pmh_free(ctx, M->dinv);
   pmh_free(ctx, M->r);
   pmh_free(ctx, M->z);
@@ -567,7 +570,11 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   if (extpc) next_check = (M->last_max_its > 2) ? (M->last_max_its - 1) : 1; // few, expensive iterations: do not overshoot
   while (it < M->max_it) {
     const int q = it & 1;
-    PMH_CHK(pmh_csr_spmv_launch(M->K->K, M->p, M->Ap, epi));
+    if (M->Kb) {
+      PMH_CHK(pmh_bsr3_spmv_f64(M->Kb, M->p, M->Ap, PMH_EPI_NONE, nullptr, M->d_done));
+    } else {
+      PMH_CHK(pmh_csr_spmv_launch(M->K->K, M->p, M->Ap, epi));
+    }
     M->total_spmv++;
     hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->p, (const double *)M->Ap, M->d_part);
     hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, extpc, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld);
@@ -604,6 +611,33 @@ extern "C" int pmh_matinv_set_pc_mg(pmh_matinv M, pmh_mg mg)
   PMH_ARG(M);
   M->mg = mg; // NULL restores Jacobi / none
   return PMH_SUCCESS;
+}
+
+extern "C" int pmh_matinv_enable_bsr3(pmh_matinv M)
+{
+  PMH_ARG(M);
+  if (M->Kb) return PMH_SUCCESS;
+  PMH_CHK(pmh_bsr3_from_csr(M->K->K, 0, &M->Kb));
+  if (!M->Kb) return pmh_set_error(PMH_ERR_SUP, "pmh_matinv_enable_bsr3: K (n = %d) has no usable 3x3 block structure", M->n);
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_matinv_timing_enable(pmh_matinv M, int max_launches)
+{
+  PMH_ARG(M);
+  if (M->Kb) return pmh_bsr3_timing_enable(M->Kb, max_launches);
+  return pmh_csr_timing_enable(M->K->K, max_launches);
+}
+
+extern "C" int pmh_matinv_timing_get(pmh_matinv M, int *launches, double *total_ms, double *bytes_per_launch)
+{
+  PMH_ARG(M && launches && total_ms);
+  if (M->Kb) {
+    if (bytes_per_launch) *bytes_per_launch = pmh_bsr3_bytes(M->Kb);
+    return pmh_bsr3_timing_get(M->Kb, launches, total_ms);
+  }
+  if (bytes_per_launch) PMH_CHK(pmh_csr_algorithmic_bytes(M->K->K, bytes_per_launch));
+  return pmh_csr_timing_get(M->K->K, PMH_EPI_NONE, launches, total_ms);
 }
 
 extern "C" int pmh_matinv_last_iterations(pmh_matinv M, int *max_block_its, long long *total_spmv)

@@ -1,50 +1,56 @@
 // Multigrid V-cycle preconditioner for the block CG inside MATINV.
 // The reference's iterative MATINV path is a PETSc KSP whose PC is whatever -mat_inv_pc_type names
 // (src/mat/impls/inv/matinv.c: MatInvGetKSP / MatInvSetUp); for the 3-D elasticity blocks of BASELINE configs[2] the
-// Jacobi default needs ~1000 CG iterations per K^+ application.  This is the PCMG equivalent on the device:
+// Jacobi default needs ~450-1000 CG iterations per K^+ application.  This is the PCMG equivalent on the device:
 // Galerkin hierarchy A_{l+1} = P_l' A_l P_l handed over as CSR (built by the caller), Chebyshev/Jacobi smoothing with
 // PETSc's eigenvalue window [lo, hi] x lambda_max(D^-1 A) (KSPCHEBYSHEV as PCMG/PCGAMG configure it), and block-wise
 // dense pseudo-inverses on the coarsest level (floating subdomains stay singular down the hierarchy: the prolongation
 // reproduces the rigid-body modes).  Pre- and post-smoother are the same polynomial, so the cycle is symmetric positive
-// (semi-)definite and valid inside CG.  Every kernel is HBM bound; the SpMVs are the tuned pmh_csr kernels.
+// (semi-)definite and valid inside CG.
+// Every kernel is HBM bound, so the cycle is built to move few bytes: level operators with 3x3 block structure run on the
+// block kernel of bsr.hip (one column index per block), and with precision = PMH_MG_FP32 the whole cycle (operators and
+// vectors) is single precision -- it only preconditions the fp64 CG, whose residual and solution stay fp64.
 #include "pmh_internal.h"
 
 struct mg_level {
-  pmh_csr A, P;                  // P: n_l x n_{l+1} (NULL on the coarsest level)
-  int     n;
-  double *dinv, *x, *b, *r, *d, *t; // x, b are borrowed on level 0
-  double  theta, delta;
-  std::vector<double> c1, c2;    // Chebyshev recurrence coefficients of steps 1..degree-1
+  pmh_csr  A, P;          // P: n_l x n_{l+1} (NULL on the coarsest level); A is used directly only if Ab == NULL
+  pmh_bsr3 Ab;            // 3x3-block copy of A in the cycle's precision, or NULL
+  int      n;
+  void    *dinv, *x, *b, *r, *d, *t; // vectors in the cycle's precision; in fp64 x and b of level 0 are the caller's
+  double   theta, delta;
+  std::vector<double> c1, c2; // Chebyshev recurrence coefficients of steps 1..degree-1
 };
 
 struct pmh_mg_s {
   pmh_ctx               ctx;
-  int                   nlevels, degree;
+  int                   nlevels, degree, is_float;
   std::vector<mg_level> L;
   int                   nb_coarse;
   int                  *d_crs;   // coarse block row starts [nb_coarse+1]
   long long            *d_cofs;  // offsets of the dense blocks [nb_coarse]
-  double               *d_cpinv; // concatenated dense pseudo-inverses, row-major
+  void                 *d_cpinv; // concatenated dense pseudo-inverses, row-major, cycle precision
   const int            *halt;
   long long             fine_spmv; // fine-level SpMVs issued (statistics)
 };
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_dinv(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double *__restrict__ dinv)
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_dinv(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, TV *__restrict__ dinv)
 {
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
     double d = 0.0;
     for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
       if (col[k] == i) d = val[k];
-    dinv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+    dinv[i] = (TV)((d != 0.0) ? 1.0 / d : 1.0);
   }
 }
 
 // first Chebyshev step from a zero guess: r = D^-1 b, d = r/theta, x = d
-__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first_zero(int n, const int *__restrict__ halt, const double *__restrict__ dinv, const double *__restrict__ b, double itheta, double *__restrict__ r, double *__restrict__ d, double *__restrict__ x)
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first_zero(int n, const int *__restrict__ halt, const TV *__restrict__ dinv, const TV *__restrict__ b, TV itheta, TV *__restrict__ r, TV *__restrict__ d, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    const double ri = dinv[i] * b[i], di = ri * itheta;
+    const TV ri = dinv[i] * b[i], di = ri * itheta;
     r[i] = ri;
     d[i] = di;
     x[i] = di;
@@ -52,11 +58,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first_zero(int n, const int 
 }
 
 // first step from the current x (t = A x): r = D^-1 (b - t), d = r/theta, x += d
-__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first(int n, const int *__restrict__ halt, const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ t, double itheta, double *__restrict__ r, double *__restrict__ d, double *__restrict__ x)
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first(int n, const int *__restrict__ halt, const TV *__restrict__ dinv, const TV *__restrict__ b, const TV *__restrict__ t, TV itheta, TV *__restrict__ r, TV *__restrict__ d, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    const double ri = dinv[i] * (b[i] - t[i]), di = ri * itheta;
+    const TV ri = dinv[i] * (b[i] - t[i]), di = ri * itheta;
     r[i] = ri;
     d[i] = di;
     x[i] += di;
@@ -64,26 +71,45 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first(int n, const int *__re
 }
 
 // later steps (t = A d): r -= D^-1 t, d = c1 d + c2 r, x += d
-__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_step(int n, const int *__restrict__ halt, const double *__restrict__ dinv, const double *__restrict__ t, double c1, double c2, double *__restrict__ r, double *__restrict__ d, double *__restrict__ x)
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_step(int n, const int *__restrict__ halt, const TV *__restrict__ dinv, const TV *__restrict__ t, TV c1, TV c2, TV *__restrict__ r, TV *__restrict__ d, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    const double ri = r[i] - dinv[i] * t[i], di = c1 * d[i] + c2 * ri;
+    const TV ri = r[i] - dinv[i] * t[i], di = c1 * d[i] + c2 * ri;
     r[i] = ri;
     d[i] = di;
     x[i] += di;
   }
 }
 
-// x += t
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_add(int n, const int *__restrict__ halt, const double *__restrict__ t, double *__restrict__ x)
+// restriction b_c = R t with R = P' as CSR (<= 27 x ndof entries per row), one thread per coarse row
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc)
 {
   if (halt && *halt) return;
-  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) x[i] += t[i];
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < nc; i += gridDim.x * PMH_BLOCK) {
+    TV s = (TV)0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += (TV)val[k] * t[col[k]];
+    bc[i] = s;
+  }
+}
+
+// coarse-grid correction x -= P x_c (<= 8 entries per row of P), one thread per fine row
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
+{
+  if (halt && *halt) return;
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
+    TV s = (TV)0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += (TV)val[k] * xc[col[k]];
+    x[i] -= s;
+  }
 }
 
 // coarsest level: x_b = pinv_b b_b, one wavefront per row, lanes stride the row of the dense block (fixed order)
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const double *__restrict__ pinv, const double *__restrict__ b, double *__restrict__ x)
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const TV *__restrict__ pinv, const TV *__restrict__ b, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   const int lane = threadIdx.x & 63;
@@ -95,13 +121,20 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const in
     if (rs[mid] <= row) lo = mid;
     else hi = mid;
   }
-  const int     r0 = rs[lo], m = rs[lo + 1] - r0;
-  const double *a  = pinv + ofs[lo] + (size_t)(row - r0) * m;
-  double        s  = 0.0;
+  const int r0 = rs[lo], m = rs[lo + 1] - r0;
+  const TV *a  = pinv + ofs[lo] + (size_t)(row - r0) * m;
+  TV        s  = (TV)0;
   for (int j = lane; j < m; j += 64) s += a[j] * b[r0 + j];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if (lane == 0) x[row] = s;
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_convert(int n, const int *__restrict__ halt, const TA *__restrict__ a, TB *__restrict__ b)
+{
+  if (halt && *halt) return;
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) b[i] = (TB)a[i];
 }
 
 static inline dim3 mg_grid(int n)
@@ -110,67 +143,82 @@ static inline dim3 mg_grid(int n)
   return dim3((unsigned)(g < 1 ? 1 : (g > PMH_MAX_VEC_BLOCKS ? PMH_MAX_VEC_BLOCKS : g)));
 }
 
-static int mg_spmv(pmh_mg mg, int l, pmh_csr A, const double *x, double *y)
+// y = A_l x (NONE) or A_l x - y1 (SUB)
+static int mg_spmv(pmh_mg mg, int l, const void *x, void *y, int epi_kind, const void *y1)
 {
+  mg_level &Lv = mg->L[l];
+  if (l == 0) mg->fine_spmv++;
+  if (Lv.Ab) {
+    if (mg->is_float) return pmh_bsr3_spmv_f32(Lv.Ab, (const float *)x, (float *)y, epi_kind, (const float *)y1, mg->halt);
+    return pmh_bsr3_spmv_f64(Lv.Ab, (const double *)x, (double *)y, epi_kind, (const double *)y1, mg->halt);
+  }
   pmh_spmv_epi epi;
   memset(&epi, 0, sizeof(epi));
-  epi.kind = PMH_EPI_NONE;
+  epi.kind = epi_kind;
+  epi.y1   = (const double *)y1;
   epi.halt = mg->halt;
-  if (l == 0) mg->fine_spmv++;
-  return pmh_csr_spmv_launch(A, x, y, epi);
+  return pmh_csr_spmv_launch(Lv.A, (const double *)x, (double *)y, epi);
 }
 
 // degree-k Chebyshev/Jacobi smoothing of A x = b on level l; zero: x is taken as 0 on entry
-static int mg_smooth(pmh_mg mg, int l, const double *b, double *x, bool zero)
+template <typename TV>
+static int mg_smooth(pmh_mg mg, int l, const TV *b, TV *x, bool zero)
 {
   mg_level   &Lv = mg->L[l];
   hipStream_t st = mg->ctx->stream;
-  const dim3  g  = mg_grid(Lv.n);
+  const dim3  g  = mg_grid(Lv.n), blk(PMH_BLOCK);
+  TV         *r = (TV *)Lv.r, *d = (TV *)Lv.d, *t = (TV *)Lv.t;
+  const TV   *dinv = (const TV *)Lv.dinv;
   if (zero) {
-    hipLaunchKernelGGL(k_cheb_first_zero, g, dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const double *)Lv.dinv, b, 1.0 / Lv.theta, Lv.r, Lv.d, x);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_first_zero<TV>), g, blk, 0, st, Lv.n, mg->halt, dinv, b, (TV)(1.0 / Lv.theta), r, d, x);
   } else {
-    PMH_CHK(mg_spmv(mg, l, Lv.A, x, Lv.t));
-    hipLaunchKernelGGL(k_cheb_first, g, dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const double *)Lv.dinv, b, (const double *)Lv.t, 1.0 / Lv.theta, Lv.r, Lv.d, x);
+    PMH_CHK(mg_spmv(mg, l, x, t, PMH_EPI_NONE, nullptr));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_first<TV>), g, blk, 0, st, Lv.n, mg->halt, dinv, b, (const TV *)t, (TV)(1.0 / Lv.theta), r, d, x);
   }
   for (int j = 1; j < mg->degree; j++) {
-    PMH_CHK(mg_spmv(mg, l, Lv.A, Lv.d, Lv.t));
-    hipLaunchKernelGGL(k_cheb_step, g, dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const double *)Lv.dinv, (const double *)Lv.t, Lv.c1[j], Lv.c2[j], Lv.r, Lv.d, x);
+    PMH_CHK(mg_spmv(mg, l, d, t, PMH_EPI_NONE, nullptr));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_step<TV>), g, blk, 0, st, Lv.n, mg->halt, dinv, (const TV *)t, (TV)Lv.c1[j], (TV)Lv.c2[j], r, d, x);
   }
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
 
-static int mg_cycle(pmh_mg mg, int l, const double *b, double *x)
+template <typename TV>
+static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x)
 {
   mg_level   &Lv = mg->L[l];
   hipStream_t st = mg->ctx->stream;
+  const dim3  blk(PMH_BLOCK);
   if (l == mg->nlevels - 1) {
-    hipLaunchKernelGGL(k_mg_coarse, dim3((Lv.n + 3) / 4), dim3(PMH_BLOCK), 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const double *)mg->d_cpinv, b, x);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_coarse<TV>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const TV *)mg->d_cpinv, b, x);
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
   mg_level &Lc = mg->L[l + 1];
-  PMH_CHK(mg_smooth(mg, l, b, x, true));
-  // residual and restriction: b_{l+1} = P'(b - A x)
-  pmh_spmv_epi epi;
-  memset(&epi, 0, sizeof(epi));
-  epi.kind = PMH_EPI_SUB; // t = A x - b
-  epi.y1   = b;
-  epi.halt = mg->halt;
-  if (l == 0) mg->fine_spmv++;
-  PMH_CHK(pmh_csr_spmv_launch(Lv.A, x, Lv.t, epi));
-  PMH_CHK(pmh_csr_mult_transpose(Lv.P, Lv.t, Lc.b)); // = -P'(b - A x): the sign is undone when the correction is added
-  PMH_CHK(mg_cycle(mg, l + 1, Lc.b, Lc.x));
-  // x -= P x_{l+1}  (x_{l+1} solves A_{l+1} x_{l+1} = -restricted residual)
-  PMH_CHK(pmh_csr_mult(Lv.P, Lc.x, Lv.t));
-  PMH_CHK(pmh_vec_axpy(mg->ctx, Lv.n, x, -1.0, Lv.t));
-  return mg_smooth(mg, l, b, x, false);
+  PMH_CHK(mg_smooth<TV>(mg, l, b, x, true));
+  // t = A x - b; b_{l+1} = P' t = -P'(b - A x); the coarse solve is linear, so the sign is undone by subtracting P x_{l+1}
+  PMH_CHK(mg_spmv(mg, l, x, Lv.t, PMH_EPI_SUB, b));
+  pmh_csr R = Lv.P->transpose;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b);
+  PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, x);
+  PMH_HIP(hipGetLastError());
+  return mg_smooth<TV>(mg, l, b, x, false);
 }
 
 int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt)
 {
   mg->halt = halt;
-  int rc   = mg_cycle(mg, 0, b, x);
+  int rc;
+  if (mg->is_float) {
+    mg_level   &L0 = mg->L[0];
+    hipStream_t st = mg->ctx->stream;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_convert<double, float>), mg_grid(L0.n), dim3(PMH_BLOCK), 0, st, L0.n, halt, b, (float *)L0.b);
+    rc = mg_cycle<float>(mg, 0, (const float *)L0.b, (float *)L0.x);
+    if (!rc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_convert<float, double>), mg_grid(L0.n), dim3(PMH_BLOCK), 0, st, L0.n, halt, (const float *)L0.x, x);
+  } else {
+    rc = mg_cycle<double>(mg, 0, b, x);
+  }
   mg->halt = nullptr;
   return rc;
 }
@@ -182,39 +230,51 @@ extern "C" int pmh_mg_apply(pmh_mg mg, const double *b, double *x)
 }
 
 extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
-                             const double *coarse_pinv_host, pmh_mg *out)
+                             const double *coarse_pinv_host, int precision, pmh_mg *out)
 {
   PMH_ARG(ctx && out && A && nlevels >= 1 && degree >= 1 && nb_coarse >= 1 && coarse_rowstart && coarse_pinv_host);
   PMH_ARG(nlevels == 1 || (P && lambda_max));
   PMH_ARG(hi_frac > lo_frac && lo_frac > 0.0);
+  PMH_ARG(precision == PMH_MG_FP64 || precision == PMH_MG_FP32);
   for (int l = 0; l < nlevels; l++) {
     PMH_ARG(A[l] && A[l]->nrows == A[l]->ncols);
     if (l + 1 < nlevels) PMH_ARG(P[l] && P[l]->nrows == A[l]->nrows && P[l]->ncols == A[l + 1]->nrows && lambda_max[l] > 0.0);
   }
   PMH_ARG(coarse_rowstart[0] == 0 && coarse_rowstart[nb_coarse] == A[nlevels - 1]->nrows);
-  pmh_mg mg   = new pmh_mg_s();
-  mg->ctx     = ctx;
-  mg->nlevels = nlevels;
-  mg->degree  = degree;
-  mg->halt    = nullptr;
+  const int    fl = precision == PMH_MG_FP32;
+  const size_t w  = fl ? sizeof(float) : sizeof(double);
+  pmh_mg mg     = new pmh_mg_s();
+  mg->ctx       = ctx;
+  mg->nlevels   = nlevels;
+  mg->degree    = degree;
+  mg->is_float  = fl;
+  mg->halt      = nullptr;
   mg->fine_spmv = 0;
   mg->L.resize(nlevels);
+  const bool no_bsr = getenv("PMH_MG_NO_BSR") != nullptr; // testing knob: keep the CSR kernels (fp64 only)
   for (int l = 0; l < nlevels; l++) {
     mg_level &Lv = mg->L[l];
-    Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows;
+    Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows, Lv.Ab = nullptr;
     Lv.dinv = Lv.x = Lv.b = Lv.r = Lv.d = Lv.t = nullptr;
-    const size_t nbytes = sizeof(double) * (size_t)(Lv.n ? Lv.n : 1);
-    if (l > 0) {
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.x));
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.b));
+    const size_t nbytes = w * (size_t)(Lv.n ? Lv.n : 1);
+    if (l > 0 || fl) {
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.x));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.b));
     }
     if (l + 1 < nlevels) {
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.dinv));
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.r));
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.d));
-      PMH_CHK(pmh_malloc(ctx, nbytes, (void **)&Lv.t));
+      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], fl, &Lv.Ab));
+      if (fl && !Lv.Ab) {
+        pmh_mg_destroy(mg);
+        return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
+      }
+      PMH_CHK(pmh_csr_ensure_transpose(P[l]));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.dinv));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.r));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.d));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.t));
       if (Lv.n > 0) {
-        hipLaunchKernelGGL(k_mg_dinv, mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, Lv.dinv);
+        if (fl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<float>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (float *)Lv.dinv);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
         PMH_HIP(hipGetLastError());
       }
       // KSPChebyshev recurrence on the window [lo, hi] x lambda_max
@@ -240,10 +300,16 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   }
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(nb_coarse + 1), (void **)&mg->d_crs));
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * (size_t)nb_coarse, (void **)&mg->d_cofs));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(tot ? tot : 1), (void **)&mg->d_cpinv));
+  PMH_CHK(pmh_malloc(ctx, w * (size_t)(tot ? tot : 1), &mg->d_cpinv));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_crs, coarse_rowstart, sizeof(int) * (size_t)(nb_coarse + 1)));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cofs, ofs.data(), sizeof(long long) * (size_t)nb_coarse));
-  PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cpinv, coarse_pinv_host, sizeof(double) * (size_t)tot));
+  if (fl) {
+    std::vector<float> pf((size_t)tot);
+    for (long long i = 0; i < tot; i++) pf[i] = (float)coarse_pinv_host[i];
+    PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cpinv, pf.data(), sizeof(float) * (size_t)tot));
+  } else {
+    PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cpinv, coarse_pinv_host, sizeof(double) * (size_t)tot));
+  }
   *out = mg;
   return PMH_SUCCESS;
 }
@@ -259,6 +325,7 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.t);
     pmh_free(ctx, Lv.x);
     pmh_free(ctx, Lv.b);
+    pmh_bsr3_destroy(Lv.Ab);
   }
   pmh_free(ctx, mg->d_crs);
   pmh_free(ctx, mg->d_cofs);
@@ -272,4 +339,19 @@ extern "C" int pmh_mg_stats(pmh_mg mg, long long *fine_spmv)
   PMH_ARG(mg);
   if (fine_spmv) *fine_spmv = mg->fine_spmv;
   return PMH_SUCCESS;
+}
+
+// HIP-event timing of the fine-level operator launches of the cycle (block kernel only; the CSR kernel has its own)
+extern "C" int pmh_mg_timing_enable(pmh_mg mg, int max_launches)
+{
+  PMH_ARG(mg);
+  if (!mg->L[0].Ab) return max_launches ? pmh_set_error(PMH_ERR_SUP, "pmh_mg_timing_enable: the fine level runs on the CSR kernel; use pmh_csr_timing_enable") : PMH_SUCCESS;
+  return pmh_bsr3_timing_enable(mg->L[0].Ab, max_launches);
+}
+
+extern "C" int pmh_mg_timing_get(pmh_mg mg, int *launches, double *total_ms, double *bytes_per_launch)
+{
+  PMH_ARG(mg && mg->L[0].Ab);
+  if (bytes_per_launch) *bytes_per_launch = pmh_bsr3_bytes(mg->L[0].Ab);
+  return pmh_bsr3_timing_get(mg->L[0].Ab, launches, total_ms);
 }

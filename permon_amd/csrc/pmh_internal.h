@@ -118,5 +118,25 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
 
+// ---- 3x3-block SpMV (bsr.hip) -------------------------------------------------------------------------------------
+struct pmh_bsr3_s {
+  pmh_ctx   ctx;
+  int       n, nbr, ntiles, is_float;
+  long long nblocks;
+  int      *d_tile_br, *d_browptr, *d_bcol;
+  void     *d_val;
+  std::vector<hipEvent_t> ev; // optional per-launch timing (event pairs on the launch stream)
+  int                     ev_used, ev_on;
+};
+typedef pmh_bsr3_s *pmh_bsr3;
+int    pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out); // *out = NULL (no error) if A has no usable 3x3 block structure
+int    pmh_bsr3_destroy(pmh_bsr3 B);
+double pmh_bsr3_bytes(pmh_bsr3 B);
+int    pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt);
+int    pmh_bsr3_spmv_f32(pmh_bsr3 B, const float *x, float *y, int epi, const float *y1, const int *halt);
+int    pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches);
+int    pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms);
+int    pmh_csr_ensure_transpose(pmh_csr A); // builds A->transpose if missing
+
 // ---- multigrid preconditioner (mg.hip) -------------------------------------------------------------------------
 int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt); // halt: device flag turning the launches into no-ops

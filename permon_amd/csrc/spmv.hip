@@ -542,6 +542,13 @@ static int build_transpose(pmh_csr A)
   return pmh_csr_create(ctx, A->ncols, A->nrows, trp.data(), tci.data(), tva.data(), &A->transpose);
 }
 
+int pmh_csr_ensure_transpose(pmh_csr A)
+{
+  PMH_ARG(A);
+  if (!A->transpose) PMH_CHK(build_transpose(A));
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y)
 {
   PMH_ARG(A);

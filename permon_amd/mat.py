@@ -102,12 +102,26 @@ class MatInv:
         assert R.ndim == 2 and R.shape[1] == self.K.n
         check(self.ctx.L.pmh_matinv_set_nullspace(self.h, R.shape[0], R.ctypes.data_as(C.c_void_p)))
 
-    def set_pc_mg(self, hier, degree=2, lo=0.1, hi=1.1):
+    def set_pc_mg(self, hier, degree=2, lo=0.1, hi=1.1, precision="fp64"):
         """PCMG-like V-cycle as the PC of the inner CG (-mat_inv_pc_type mg): hier is box_mg_hierarchy()'s dict whose
-        level 0 is this matrix (the resident CSR of the MATBLOCKDIAG is reused, not uploaded twice)."""
-        self.mg = MG(self.ctx, hier, degree=degree, lo=lo, hi=hi, fine=self.K.K)
+        level 0 is this matrix (the resident CSR of the MATBLOCKDIAG is reused, not uploaded twice).
+        precision "fp32": single-precision cycle (3x3-block operators only)."""
+        self.mg = MG(self.ctx, hier, degree=degree, lo=lo, hi=hi, fine=self.K.K, precision=precision)
         check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, self.mg.h))
         return self.mg
+
+    def enable_bsr3(self):
+        """K x of the CG on the 3x3-block kernel (MATSEQBAIJ bs=3 role)."""
+        check(self.ctx.L.pmh_matinv_enable_bsr3(self.h))
+
+    def timing_enable(self, max_launches):
+        check(self.ctx.L.pmh_matinv_timing_enable(self.h, int(max_launches)))
+
+    def timing_get(self):
+        """(launches, total ms, algorithmic bytes per launch) of the CG's K x products since timing_enable."""
+        n, ms, b = C.c_int(), C.c_double(), C.c_double()
+        check(self.ctx.L.pmh_matinv_timing_get(self.h, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value
 
     def mult(self, f, u):  # MatMult_Inv
         check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
@@ -126,8 +140,9 @@ class MatInv:
 class MG:
     """pmh_mg: Galerkin multigrid V-cycle with Chebyshev/Jacobi smoothing and dense coarse pseudo-inverses (PCMG role)."""
 
-    def __init__(self, ctx, hier, degree=2, lo=0.1, hi=1.1, fine=None):
+    def __init__(self, ctx, hier, degree=2, lo=0.1, hi=1.1, fine=None, precision="fp64"):
         self.ctx = ctx
+        self.precision = precision
         A, P = hier["A"], hier["P"]
         self.nlevels = len(A)
 
@@ -147,11 +162,20 @@ class MG:
         cpinv = np.ascontiguousarray(hier["coarse_pinv"], dtype=np.float64)
         h = C.c_void_p()
         check(ctx.L.pmh_mg_create(ctx.h, self.nlevels, Ah, Ph, int(degree), lam.ctypes.data_as(C.c_void_p), float(lo), float(hi), crs.size - 1,
-                                  crs.ctypes.data_as(C.c_void_p), cpinv.ctypes.data_as(C.c_void_p), C.byref(h)))
+                                  crs.ctypes.data_as(C.c_void_p), cpinv.ctypes.data_as(C.c_void_p), {"fp64": 0, "fp32": 1}[precision], C.byref(h)))
         self.h = h
 
     def apply(self, b, x):  # PCApply
         check(self.ctx.L.pmh_mg_apply(self.h, b.p, x.p))
+
+    def timing_enable(self, max_launches):
+        check(self.ctx.L.pmh_mg_timing_enable(self.h, int(max_launches)))
+
+    def timing_get(self):
+        """(launches, total ms, algorithmic bytes per launch) of the fine-level operator launches of the cycle."""
+        n, ms, b = C.c_int(), C.c_double(), C.c_double()
+        check(self.ctx.L.pmh_mg_timing_get(self.h, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value
 
     def fine_spmv(self):
         n = C.c_longlong()

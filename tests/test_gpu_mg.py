@@ -65,11 +65,14 @@ def _cube_hierarchy(f):
     return box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, f.ndof)
 
 
-@pytest.mark.parametrize("physics,degree", [("poisson", 2), ("elasticity", 2), ("elasticity", 3)])
-def test_vcycle_matches_numpy_restatement(ctx, physics, degree):
+@pytest.mark.parametrize("physics,degree,csr_only", [("poisson", 2, False), ("elasticity", 2, False), ("elasticity", 3, False), ("elasticity", 2, True)])
+def test_vcycle_matches_numpy_restatement(ctx, physics, degree, csr_only, monkeypatch):
+    """fp64 cycle: the elasticity levels run on the 3x3-block kernel (bsr.hip) unless csr_only, Poisson on the CSR kernel."""
     f = CubeFeti((2, 1, 1), 8, physics, contact=False)
     H = _cube_hierarchy(f)
     assert len(H["A"]) >= 3
+    if csr_only:
+        monkeypatch.setenv("PMH_MG_NO_BSR", "1")
     mg = pa.MG(ctx, H, degree=degree)
     b = np.random.default_rng(5).standard_normal(f.N)
     x = ctx.vec(f.N)
@@ -83,8 +86,47 @@ def test_vcycle_matches_numpy_restatement(ctx, physics, degree):
     assert abs(y.to_numpy() @ b - a @ x.to_numpy()) <= 1e-10 * abs(a @ x.to_numpy())
 
 
-@pytest.mark.parametrize("nel", [8, 11])  # 11: odd element count, non-nested last coarse interval
-def test_matinv_with_mg_pc(ctx, nel):
+def test_fp32_cycle_is_a_close_copy_of_the_fp64_cycle(ctx):
+    f = CubeFeti((2, 1, 1), 8, "elasticity", contact=False)
+    H = _cube_hierarchy(f)
+    b = np.random.default_rng(7).standard_normal(f.N)
+    out = []
+    for prec in ("fp64", "fp32"):
+        mg = pa.MG(ctx, H, precision=prec)
+        x = ctx.vec(f.N)
+        mg.apply(ctx.vec_from(b), x)
+        out.append(x.to_numpy())
+    assert np.linalg.norm(out[1] - out[0]) <= 2e-5 * np.linalg.norm(out[0])
+    with pytest.raises(pa.PermonHipError):  # Poisson blocks have no 3x3 structure
+        g = CubeFeti((2, 1, 1), 8, "poisson", contact=False)
+        pa.MG(ctx, _cube_hierarchy(g), precision="fp32")
+
+
+def test_matinv_bsr3_product_matches_csr(ctx):
+    f = CubeFeti((2, 1, 1), 7, "elasticity", contact=False)
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
+    rhs = np.random.default_rng(4).standard_normal(f.N)
+    u0, u1 = ctx.vec(f.N), ctx.vec(f.N)
+    M0 = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
+    M0.mult(ctx.vec_from(rhs), u0)
+    M1 = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
+    M1.enable_bsr3()
+    M1.timing_enable(4000)
+    M1.mult(ctx.vec_from(rhs), u1)
+    assert abs(M1.last_iterations()[0] - M0.last_iterations()[0]) <= 2
+    assert np.linalg.norm(u1.to_numpy() - u0.to_numpy()) <= 1e-10 * np.linalg.norm(u0.to_numpy())
+    n, ms, nbytes = M1.timing_get()
+    assert n >= M1.last_iterations()[0] and ms > 0
+    assert abs(nbytes - (f.K.nnz // 9 * 76 + 4 * (f.N // 3 + 1) + 16 * f.N)) <= 76 * 64  # 8.44 B per non-zero
+    # a Poisson K has no 3x3 blocks: refused loudly
+    g = CubeFeti((2, 1, 1), 4, "poisson", contact=False)
+    Kg = pa.MatBlockDiag.from_scipy(ctx, g.block_rowstart, g.K)
+    with pytest.raises(pa.PermonHipError):
+        pa.MatInv(Kg).enable_bsr3()
+
+
+@pytest.mark.parametrize("nel,prec", [(8, "fp64"), (11, "fp64"), (8, "fp32"), (11, "fp32")])  # 11: odd element count, non-nested last coarse interval
+def test_matinv_with_mg_pc(ctx, nel, prec):
     f = CubeFeti((2, 1, 1), nel, "elasticity", contact=False)
     K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
     rhs = np.random.default_rng(1).standard_normal(f.N)
@@ -93,7 +135,9 @@ def test_matinv_with_mg_pc(ctx, nel):
     Mj.mult(ctx.vec_from(rhs), uj)
     its_j, _ = Mj.last_iterations()
     Mm = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
-    mg = Mm.set_pc_mg(_cube_hierarchy(f))
+    if prec == "fp32":
+        Mm.enable_bsr3()
+    mg = Mm.set_pc_mg(_cube_hierarchy(f), precision=prec)
     Mm.mult(ctx.vec_from(rhs), um)
     its_m, spmv_m = Mm.last_iterations()
     assert its_m <= 20 and its_m * 4 < its_j  # mesh-independent and far below the Jacobi count
@@ -135,8 +179,9 @@ def test_contact_tfeti_solve_is_independent_of_the_inner_pc(ctx):
     sols, its = [], []
     for use_mg in (False, True):
         q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-11)
-        if use_mg:
-            q.Kplus.set_pc_mg(_cube_hierarchy(f))
+        if use_mg:  # the production configuration: fp32 V-cycle + block-kernel K x in the CG
+            q.Kplus.enable_bsr3()
+            q.Kplus.set_pc_mg(_cube_hierarchy(f), precision="fp32")
         st = q.solve_smalxe(rtol=1e-6)
         assert st.reason > 0
         sols.append(q.dual_solution())
