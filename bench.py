@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
     ap.add_argument("--mg-precision", choices=["fp32", "fp64"], default="fp32", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
+    ap.add_argument("--mg-degree", type=int, default=2, help="feti: Chebyshev degree of the V-cycle smoother")
     ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
@@ -311,7 +312,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     if a.kplus_pc == "mg":  # Galerkin hierarchy of the congruent cubes (host set-up, seconds)
         nn = a.nel + 1
         hier = pa.box_mg_hierarchy([f.Ki] * per, [(nn, nn, nn)] * per, 3)
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_precision=a.mg_precision, bsr3=not a.no_bsr3)
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3)
     qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
     t_setup = time.time() - t0
     Kcsr = q.K.K
@@ -359,7 +360,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
     ms_all = ms_k + (ms_cg if hier is not None else 0.0)
     achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
-    pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(2)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision)) if hier is not None else "Jacobi-CG"
+    pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "

@@ -3,7 +3,7 @@
 // per 3x3 block it is 8.44 (fp64) or 4.44 (fp32, used only inside the multigrid preconditioner) -- the kernel is HBM bound,
 // so the byte count is the run time.
 //
-// Layout: block rows are grouped into tiles of at most BSR_TB blocks (whole block rows per tile); inside a tile the nine
+// Layout: block rows are grouped into tiles of at most 512 (fp64) / 1024 (fp32) blocks (whole block rows per tile); inside a tile the nine
 // entries of the blocks are stored as nine planes of length nbt (structure of arrays), so that thread j reads entry k of
 // block j at plane k, offset j: every load of the value stream is lane-contiguous.  One workgroup per tile: each thread
 // multiplies its blocks with the three x entries of the block column, writes the three partial products to LDS, then four
@@ -12,9 +12,9 @@
 
 #include <algorithm>
 
-#define BSR_TB 512 // blocks per tile (2 per thread)
+#define BSR_TB_MAX 1024 // largest tile (blocks); a tile is BSR_TB = 512 or 1024 blocks (2 or 4 per thread)
 
-template <typename T, int EPI>
+template <typename T, int EPI, int BSR_TB>
 __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile_br, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
                                                      const T *__restrict__ y1, const int *__restrict__ halt)
 {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile
 }
 
 // Build from a resident CSR (downloaded once); *out = NULL without error when the matrix has no 3x3 block structure that
-// fits the tile (n not a multiple of 3, or a block row with more than BSR_TB blocks).
+// fits the tile (n not a multiple of 3, or a block row with more blocks than a tile holds).
 int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
 {
   PMH_ARG(A && out);
@@ -71,6 +71,9 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
   pmh_ctx ctx = A->ctx;
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
   const int        n = A->nrows, nbr = n / 3;
+  int              tb = 512; // measured on MI355X (profiles/): 512 beats 1024 for both precisions
+  if (const char *e = getenv("PMH_BSR_TB")) tb = atoi(e); // tuning knob
+  if (tb != 512 && tb != 1024) return pmh_set_error(PMH_ERR_ARG, "PMH_BSR_TB must be 512 or 1024");
   std::vector<int> rp((size_t)n + 1), ci((size_t)A->nnz);
   std::vector<double> va((size_t)A->nnz);
   PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), A->d_rowptr, sizeof(int) * rp.size()));
@@ -88,7 +91,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
       for (int k = rp[3 * br + r]; k < rp[3 * br + r + 1]; k++) tmp.push_back(ci[k] / 3);
     std::sort(tmp.begin(), tmp.end());
     tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    if ((int)tmp.size() > BSR_TB) return PMH_SUCCESS;
+    if ((int)tmp.size() > tb) return PMH_SUCCESS;
     bcol.insert(bcol.end(), tmp.begin(), tmp.end());
     if (bcol.size() > (size_t)0x7fffff00) return PMH_SUCCESS;
     browptr[br + 1] = (int)bcol.size();
@@ -98,7 +101,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
   // tiles of whole block rows
   std::vector<int> tile_br(1, 0);
   for (int br = 0, start = 0; br < nbr; br++) {
-    if (browptr[br + 1] - browptr[start] > BSR_TB) {
+    if (browptr[br + 1] - browptr[start] > tb) {
       tile_br.push_back(br);
       start = br;
     }
@@ -123,7 +126,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
     }
   }
   pmh_bsr3 B = new pmh_bsr3_s();
-  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->is_float = is_float;
+  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->is_float = is_float, B->tb = tb;
   B->ev_used = 0, B->ev_on = 0;
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * tile_br.size(), (void **)&B->d_tile_br));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * browptr.size(), (void **)&B->d_browptr));
@@ -172,9 +175,15 @@ static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const T *y1, const
   if (timed) PMH_HIP(hipEventRecord(B->ev[B->ev_used], st));
   const int *tb = B->d_tile_br, *bp = B->d_browptr, *bc = B->d_bcol;
   const T   *v  = (const T *)B->d_val;
-  if (epi == PMH_EPI_NONE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<T, PMH_EPI_NONE>), grid, blk, 0, st, tb, B->ntiles, bp, bc, v, x, y, y1, halt);
-  else if (epi == PMH_EPI_ADD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<T, PMH_EPI_ADD>), grid, blk, 0, st, tb, B->ntiles, bp, bc, v, x, y, y1, halt);
-  else if (epi == PMH_EPI_SUB) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<T, PMH_EPI_SUB>), grid, blk, 0, st, tb, B->ntiles, bp, bc, v, x, y, y1, halt);
+#define BSR_LAUNCH(EPI, TB) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<T, EPI, TB>), grid, blk, 0, st, tb, B->ntiles, bp, bc, v, x, y, y1, halt)
+#define BSR_LAUNCH_TB(EPI) \
+  do { \
+    if (B->tb == 512) BSR_LAUNCH(EPI, 512); \
+    else BSR_LAUNCH(EPI, 1024); \
+  } while (0)
+  if (epi == PMH_EPI_NONE) BSR_LAUNCH_TB(PMH_EPI_NONE);
+  else if (epi == PMH_EPI_ADD) BSR_LAUNCH_TB(PMH_EPI_ADD);
+  else if (epi == PMH_EPI_SUB) BSR_LAUNCH_TB(PMH_EPI_SUB);
   else return pmh_set_error(PMH_ERR_ARG, "bsr3: unsupported epilogue %d", epi);
   PMH_HIP(hipGetLastError());
   if (timed) {

@@ -83,15 +83,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_step(int n, const int *__res
   }
 }
 
-// restriction b_c = R t with R = P' as CSR (<= 27 x ndof entries per row), one thread per coarse row
+// restriction b_c = R t with R = P' as CSR (<= 27 entries per row): 8 lanes per coarse row, shuffle-tree sum (fixed order)
 template <typename TV>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc)
 {
   if (halt && *halt) return;
-  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < nc; i += gridDim.x * PMH_BLOCK) {
-    TV s = (TV)0;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += (TV)val[k] * t[col[k]];
-    bc[i] = s;
+  const int lane = threadIdx.x & 7;
+  for (int i0 = blockIdx.x * (PMH_BLOCK / 8); i0 < nc; i0 += gridDim.x * (PMH_BLOCK / 8)) { // uniform trip count per workgroup
+    const int i = i0 + (threadIdx.x >> 3);
+    TV        s = (TV)0;
+    if (i < nc)
+      for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 8) s += (TV)val[k] * t[col[k]];
+    s += __shfl_down(s, 4, 8);
+    s += __shfl_down(s, 2, 8);
+    s += __shfl_down(s, 1, 8);
+    if (i < nc && lane == 0) bc[i] = s;
   }
 }
 
@@ -199,7 +205,7 @@ static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x)
   // t = A x - b; b_{l+1} = P' t = -P'(b - A x); the coarse solve is linear, so the sign is undone by subtracting P x_{l+1}
   PMH_CHK(mg_spmv(mg, l, x, Lv.t, PMH_EPI_SUB, b));
   pmh_csr R = Lv.P->transpose;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, x);
   PMH_HIP(hipGetLastError());

@@ -121,7 +121,7 @@ int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                          
 // ---- 3x3-block SpMV (bsr.hip) -------------------------------------------------------------------------------------
 struct pmh_bsr3_s {
   pmh_ctx   ctx;
-  int       n, nbr, ntiles, is_float;
+  int       n, nbr, ntiles, is_float, tb;
   long long nblocks;
   int      *d_tile_br, *d_browptr, *d_bcol;
   void     *d_val;
