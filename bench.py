@@ -327,9 +327,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
 
     qps.RunFixed(warmup)
     q.lam.set(0.0)
-    q.Kplus.timing_enable(60000)
-    if hier is not None:
-        q.Kplus.mg.timing_enable(60000)
+    if not os.environ.get("PMH_BENCH_NO_TIMING"):
+        q.Kplus.timing_enable(60000)
+        if hier is not None:
+            q.Kplus.mg.timing_enable(60000)
     _, spmv1 = q.Kplus.last_iterations()
     mgs1 = q.Kplus.mg.fine_spmv() if hier is not None else 0
     barrier()

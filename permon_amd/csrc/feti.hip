@@ -556,7 +556,8 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   const int extpc = M->mg ? 1 : 0;
   hipLaunchKernelGGL(k_cg_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, extpc, f, (const double *)M->dinv, u, M->r, M->z, M->p, M->d_part, ld);
   if (extpc) {
-    PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, nullptr));
+    PMH_HIP(hipMemsetAsync(M->d_done, 0, sizeof(int), st)); // same (r, z, done) triple as in the loop: one cached graph
+    PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, M->d_done));
     hipLaunchKernelGGL(k_cg_start_pz, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const double *)M->r, (const double *)M->z, M->p, M->d_part);
   }
   hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(PMH_BLOCK), 0, st, nb, wgs, ld, (const double *)M->d_part, M->d_bs, M->d_bi, M->d_nactive, M->d_done, M->rtol, M->atol);

@@ -31,6 +31,16 @@ struct pmh_mg_s {
   void                 *d_cpinv; // concatenated dense pseudo-inverses, row-major, cycle precision
   const int            *halt;
   long long             fine_spmv; // fine-level SpMVs issued (statistics)
+  // the cycle is a fixed launch sequence: it is captured once per (b, x, halt) triple into a hipGraph and replayed
+  struct cached_graph {
+    const double   *b;
+    double         *x;
+    const int      *halt;
+    hipGraphExec_t  exec;
+    long long       fine_spmv;
+  };
+  std::vector<cached_graph> graphs;
+  int                       use_graph, timing_on;
 };
 
 template <typename TV>
@@ -212,7 +222,36 @@ static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x)
   return mg_smooth<TV>(mg, l, b, x, false);
 }
 
+static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt);
+
 int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt)
+{
+  if (!mg->use_graph || mg->timing_on) return mg_apply_body(mg, b, x, halt);
+  hipStream_t st = mg->ctx->stream;
+  for (auto &g : mg->graphs)
+    if (g.b == b && g.x == x && g.halt == halt) {
+      PMH_HIP(hipGraphLaunch(g.exec, st));
+      mg->fine_spmv += g.fine_spmv;
+      return PMH_SUCCESS;
+    }
+  if (mg->graphs.size() >= 8) return mg_apply_body(mg, b, x, halt); // callers with ever-changing vectors: plain launches
+  const long long f0 = mg->fine_spmv;
+  hipGraph_t      graph;
+  PMH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = mg_apply_body(mg, b, x, halt);
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_mg: stream capture of the V-cycle failed: %s", hipGetErrorString(e));
+  pmh_mg_s::cached_graph g;
+  g.b = b, g.x = x, g.halt = halt, g.fine_spmv = mg->fine_spmv - f0;
+  PMH_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+  PMH_HIP(hipGraphDestroy(graph));
+  mg->graphs.push_back(g);
+  PMH_HIP(hipGraphLaunch(g.exec, st)); // the capture recorded the launches without running them
+  return PMH_SUCCESS;
+}
+
+static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt)
 {
   mg->halt = halt;
   int rc;
@@ -256,6 +295,9 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   mg->is_float  = fl;
   mg->halt      = nullptr;
   mg->fine_spmv = 0;
+  mg->timing_on = 0;
+  mg->use_graph = 1;
+  if (const char *e = getenv("PMH_MG_GRAPH")) mg->use_graph = atoi(e);
   mg->L.resize(nlevels);
   const bool no_bsr = getenv("PMH_MG_NO_BSR") != nullptr; // testing knob: keep the CSR kernels (fp64 only)
   for (int l = 0; l < nlevels; l++) {
@@ -273,6 +315,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         pmh_mg_destroy(mg);
         return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
       }
+      if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.dinv));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.r));
@@ -333,6 +376,7 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.b);
     pmh_bsr3_destroy(Lv.Ab);
   }
+  for (auto &g : mg->graphs) (void)hipGraphExecDestroy(g.exec);
   pmh_free(ctx, mg->d_crs);
   pmh_free(ctx, mg->d_cofs);
   pmh_free(ctx, mg->d_cpinv);
@@ -352,6 +396,7 @@ extern "C" int pmh_mg_timing_enable(pmh_mg mg, int max_launches)
 {
   PMH_ARG(mg);
   if (!mg->L[0].Ab) return max_launches ? pmh_set_error(PMH_ERR_SUP, "pmh_mg_timing_enable: the fine level runs on the CSR kernel; use pmh_csr_timing_enable") : PMH_SUCCESS;
+  mg->timing_on = max_launches > 0; // event pairs cannot be replayed from a graph: timed applications use plain launches
   return pmh_bsr3_timing_enable(mg->L[0].Ab, max_launches);
 }
 

@@ -465,11 +465,13 @@ def _lambda_max_dinv_a(A, its=20, seed=0):
     return float(lam)
 
 
-def box_mg_hierarchy(blocks, dims, ndof, min_nodes=27, max_levels=12):
+def box_mg_hierarchy(blocks, dims, ndof, min_nodes=400, max_levels=12):
     """Geometric multigrid hierarchy for a block-diagonal matrix whose blocks are Q1 discretisations on
     nx x ny x nz node boxes (node-major dof numbering, x fastest): trilinear prolongation P_l (x) I_ndof, Galerkin
     coarse operators A_{l+1} = P_l' A_l P_l.  Trilinear interpolation reproduces constants and rigid-body modes, so
     floating blocks stay consistently singular down to the coarsest level, where a dense pseudo-inverse is used.
+    Coarsening stops at <= min_nodes nodes per block: a ~1000-dof dense coarse solve costs one small GEMV, whereas
+    every further smoothed level costs ~11 latency-bound launches per cycle.
     blocks: list of scipy matrices; dims: list of (nx, ny, nz); congruent blocks (same object) are processed once.
     Returns dict(A=[...], P=[...], lambda_max=[...], coarse_rowstart, coarse_pinv) with block-concatenated matrices."""
     cache = {}

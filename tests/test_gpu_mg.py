@@ -60,9 +60,10 @@ def _vcycle_numpy(H, degree, lo, hi):
     return lambda b: V(0, b)
 
 
-def _cube_hierarchy(f):
+def _cube_hierarchy(f, min_nodes=27):
+    """min_nodes=27 forces the deepest hierarchy on these small cubes (the default stops at <= 400 nodes per block)."""
     nn = f.nel + 1
-    return box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, f.ndof)
+    return box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, f.ndof, min_nodes=min_nodes)
 
 
 @pytest.mark.parametrize("physics,degree,csr_only", [("poisson", 2, False), ("elasticity", 2, False), ("elasticity", 3, False), ("elasticity", 2, True)])
@@ -160,7 +161,7 @@ def test_mg_on_heterogeneous_dmda_blocks(ctx):
     prob = DmdaFeti((8, 6, 4), 7, "elasticity")
     dims = [(2, 7, 5), (3, 7, 5)] + [(2, 7, 5)] * 5
     assert [d[0] * d[1] * d[2] * 3 for d in dims] == [K.shape[0] for K in prob.blocks]
-    H = box_mg_hierarchy(prob.blocks, dims, 3)
+    H = box_mg_hierarchy(prob.blocks, dims, 3, min_nodes=27)
     K = pa.MatBlockDiag.from_scipy(ctx, prob.block_rowstart, prob.K)
     rhs = np.random.default_rng(2).standard_normal(prob.N)
     uj, um = ctx.vec(prob.N), ctx.vec(prob.N)
@@ -181,7 +182,7 @@ def test_contact_tfeti_solve_is_independent_of_the_inner_pc(ctx):
         q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-11)
         if use_mg:  # the production configuration: fp32 V-cycle + block-kernel K x in the CG
             q.Kplus.enable_bsr3()
-            q.Kplus.set_pc_mg(_cube_hierarchy(f), precision="fp32")
+            q.Kplus.set_pc_mg(_cube_hierarchy(f, min_nodes=400), precision="fp32")  # default depth: 2 levels here
         st = q.solve_smalxe(rtol=1e-6)
         assert st.reason > 0
         sols.append(q.dual_solution())
