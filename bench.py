@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
-    ap.add_argument("--mg-precision", choices=["fp32", "fp64"], default="fp32", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
+    ap.add_argument("--mg-precision", choices=["fp16", "fp32", "fp64"], default="fp16", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
     ap.add_argument("--mg-degree", type=int, default=2, help="feti: Chebyshev degree of the V-cycle smoother")
     ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -352,8 +352,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     n_cg, ms_cg, b_cg = q.Kplus.timing_get()
     if hier is not None:
         n_k, ms_k, b_k = q.Kplus.mg.timing_get()
-        kname = "k_bsr3<%s>: fine-level K x of the V-cycle (3x3 blocks, %s B per non-zero)" % (("float", "4.44") if a.mg_precision == "fp32" else ("double", "8.44"))
-        kpat = "void k_bsr3<float" if a.mg_precision == "fp32" else "void k_bsr3<double"
+        kname = "k_bsr3<%s>: fine-level K x of the V-cycle (3x3 blocks, %s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[a.mg_precision]
+        kpat = {"fp16": "void k_bsr3<_Float16", "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[a.mg_precision]
     else:
         n_k, ms_k, b_k = n_cg, ms_cg, b_cg
         kname = ("k_bsr3<double>: K x of the block CG (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3

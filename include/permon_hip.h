@@ -302,6 +302,7 @@ int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALX
  * preconditions the fp64 CG; needs 3x3-block operators (elasticity, PETSc's BAIJ bs=3 case) on every smoothed level. */
 #define PMH_MG_FP64 0
 #define PMH_MG_FP32 1
+#define PMH_MG_FP16 2 /* as FP32, the fine-level operator stored as (scaled) fp16 entries */
 typedef struct pmh_mg_s *pmh_mg;
 int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
                   const double *coarse_pinv_host, int precision, pmh_mg *mg);

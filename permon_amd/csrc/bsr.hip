@@ -1,44 +1,73 @@
 // 3x3-block sparse matrix-vector product for the elasticity blocks K_i (PETSc's SeqBAIJ role, bs = 3) in a
 // device-private layout.  A CSR row of K_i costs 12 bytes per non-zero (fp64 value + int32 column); with one column index
-// per 3x3 block it is 8.44 (fp64) or 4.44 (fp32, used only inside the multigrid preconditioner) -- the kernel is HBM bound,
-// so the byte count is the run time.
+// per 3x3 block it is 8.44 (fp64 values), 4.44 (fp32) or 2.44 (fp16 values, fp32 arithmetic) -- the reduced precisions are
+// used only inside the multigrid preconditioner.  The kernel is HBM bound, so the byte count is the run time.
 //
-// Layout: block rows are grouped into tiles of at most 512 (fp64) / 1024 (fp32) blocks (whole block rows per tile); inside a tile the nine
-// entries of the blocks are stored as nine planes of length nbt (structure of arrays), so that thread j reads entry k of
-// block j at plane k, offset j: every load of the value stream is lane-contiguous.  One workgroup per tile: each thread
-// multiplies its blocks with the three x entries of the block column, writes the three partial products to LDS, then four
-// lanes per scalar row add the row's partials in a fixed order (deterministic, no atomics).
+// Layout: block rows are grouped into tiles of at most BSR_TB blocks (whole block rows per tile, block count padded to a
+// multiple of the load width W with zero blocks); inside a tile the nine entries of the blocks are stored as nine planes of
+// length nbp (structure of arrays), so that a thread reads entry k of its W adjacent blocks with one W-wide load at plane k:
+// every load of the value stream is lane-contiguous.  One workgroup per tile: each thread multiplies its blocks with the
+// three x entries of the block column, writes the three partial products to LDS, then four lanes per scalar row add the
+// row's partials in a fixed order (deterministic, no atomics).
 #include "pmh_internal.h"
 
 #include <algorithm>
 
-#define BSR_TB_MAX 1024 // largest tile (blocks); a tile is BSR_TB = 512 or 1024 blocks (2 or 4 per thread)
+#define BSR_TB 512 // blocks per tile; 1024 measured slower (profiles/)
 
-template <typename T, int EPI, int BSR_TB>
-__global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile_br, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                     const T *__restrict__ y1, const int *__restrict__ halt)
+template <typename TM, int W> struct vecw { typedef TM type __attribute__((ext_vector_type(W))); };
+template <typename TM> struct vecw<TM, 1> { typedef TM type; };
+template <int W> struct ivecw { typedef int type __attribute__((ext_vector_type(W))); };
+template <> struct ivecw<1> { typedef int type; };
+template <typename V, int W> struct lane_of {
+  template <typename S> static __device__ __forceinline__ S get(const V &v, int w) { return (S)v[w]; }
+};
+template <typename V> struct lane_of<V, 1> {
+  template <typename S> static __device__ __forceinline__ S get(const V &v, int) { return (S)v; }
+};
+
+// Epilogues.  Besides y = A x (+/- y1) the kernel can finish a Chebyshev/Jacobi smoothing step of the V-cycle on the row it
+// has just summed, which removes the separate vector kernels (and their launches) from the cycle.  All fused variants write
+// to vectors that no workgroup gathers from during the same launch.
+//   PRE   (x = d0 gathered):  y = c0 d0 + c2 dinv (b - A d0)                      second step of the zero-guess pre-smoother
+//   POST1 (x gathered):       r = dinv (b - A x); d = c0 r; y = x + d             first step of the post-smoother
+//   POST2 (x = d gathered):   y += c1 d + c2 (r - dinv A d); optional fp64 copy   second step of the post-smoother
+// TM: storage type of the matrix entries, T: arithmetic / vector type, W: adjacent blocks per thread-load.
+template <typename TM, typename T, int EPI, int W>
+__global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile_br, const long long *__restrict__ tile_off, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const TM *__restrict__ val, T scale,
+                                                     const T *__restrict__ x, T *__restrict__ y, pmh_bsr3_epi<T> e, const int *__restrict__ halt)
 {
   if (halt && *halt) return;
+  typedef typename vecw<TM, W>::type VM;
+  typedef typename ivecw<W>::type    VI;
   __shared__ T prod[3][BSR_TB];
   const int    tid   = threadIdx.x;
   const int    chunk = gridDim.x >> 3; // XCD-aware: XCD x works on a contiguous slab of tiles (x stays in its L2)
   const int    t     = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (t >= ntiles) return;
-  const int br0 = tile_br[t], br1 = tile_br[t + 1];
-  const int s0 = browptr[br0], nbt = browptr[br1] - s0;
-  const T  *v = val + (size_t)s0 * 9;
+  const int       br0 = tile_br[t], br1 = tile_br[t + 1];
+  const int       s0 = browptr[br0], nbt = browptr[br1] - s0, nbp = (nbt + W - 1) / W * W;
+  const long long off = tile_off[t];
+  const TM       *v  = val + off * 9;
+  const int      *bc = bcol + off;
 #pragma unroll
-  for (int jj = 0; jj < BSR_TB / PMH_BLOCK; jj++) {
-    const int j = tid + jj * PMH_BLOCK;
-    if (j < nbt) {
-      const int c = __builtin_nontemporal_load(&bcol[s0 + j]);
-      T         a[9];
+  for (int jj = 0; jj < (BSR_TB / (PMH_BLOCK * W) > 0 ? BSR_TB / (PMH_BLOCK * W) : 1); jj++) {
+    const int j0 = (tid + jj * PMH_BLOCK) * W;
+    if (j0 < nbp) {
+      const VI c = __builtin_nontemporal_load((const VI *)(bc + j0));
+      VM       a[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) a[k] = __builtin_nontemporal_load(&v[(size_t)k * nbt + j]);
-      const T x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-      prod[0][j] = a[0] * x0 + a[1] * x1 + a[2] * x2;
-      prod[1][j] = a[3] * x0 + a[4] * x1 + a[5] * x2;
-      prod[2][j] = a[6] * x0 + a[7] * x1 + a[8] * x2;
+      for (int k = 0; k < 9; k++) a[k] = __builtin_nontemporal_load((const VM *)(v + (size_t)k * nbp + j0));
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        const int cw = lane_of<VI, W>::template get<int>(c, w);
+        const T   x0 = x[3 * cw], x1 = x[3 * cw + 1], x2 = x[3 * cw + 2];
+#define A_(k) lane_of<VM, W>::template get<T>(a[k], w)
+        prod[0][j0 + w] = A_(0) * x0 + A_(1) * x1 + A_(2) * x2;
+        prod[1][j0 + w] = A_(3) * x0 + A_(4) * x1 + A_(5) * x2;
+        prod[2][j0 + w] = A_(6) * x0 + A_(7) * x1 + A_(8) * x2;
+#undef A_
+      }
     }
   }
   __syncthreads();
@@ -55,25 +84,47 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile
     sum += __shfl_down(sum, 1, 4);
     if (q < nrows && lane == 0) {
       const int row = 3 * br0 + q;
-      if (EPI == PMH_EPI_ADD) sum = y1[row] + sum;
-      if (EPI == PMH_EPI_SUB) sum = sum - y1[row];
-      y[row] = sum;
+      if (sizeof(TM) == 2) sum *= scale; // fp16 storage keeps A / scale
+      if (EPI == PMH_EPI_NONE) y[row] = sum;
+      if (EPI == PMH_EPI_ADD) y[row] = e.y1[row] + sum;
+      if (EPI == PMH_EPI_SUB) y[row] = sum - e.y1[row];
+      if (EPI == PMH_BSR_EPI_PRE) y[row] = e.c0 * x[row] + e.c2 * e.dinv[row] * (e.y1[row] - sum);
+      if (EPI == PMH_BSR_EPI_POST1) {
+        const T rr = e.dinv[row] * (e.y1[row] - sum), dd = e.c0 * rr;
+        e.r[row] = rr;
+        e.d[row] = dd;
+        y[row]   = x[row] + dd;
+      }
+      if (EPI == PMH_BSR_EPI_POST2) {
+        const T vv = y[row] + e.c1 * x[row] + e.c2 * (e.r[row] - e.dinv[row] * sum);
+        y[row] = vv;
+        if (e.z64) e.z64[row] = (double)vv;
+      }
     }
   }
 }
 
+static int bsr_width(int storage)
+{
+  int w = (storage == PMH_BSR_F64) ? 1 : 2;
+  if (const char *e = getenv("PMH_BSR_W")) { // tuning knob: "w64,w32,w16"
+    int w64 = 1, w32 = 2, w16 = 2;
+    sscanf(e, "%d,%d,%d", &w64, &w32, &w16);
+    w = (storage == PMH_BSR_F64) ? w64 : (storage == PMH_BSR_F32 ? w32 : w16);
+  }
+  return (w == 1 || w == 2 || w == 4) ? w : 1;
+}
+
 // Build from a resident CSR (downloaded once); *out = NULL without error when the matrix has no 3x3 block structure that
 // fits the tile (n not a multiple of 3, or a block row with more blocks than a tile holds).
-int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
+int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out)
 {
-  PMH_ARG(A && out);
+  PMH_ARG(A && out && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
   *out        = nullptr;
   pmh_ctx ctx = A->ctx;
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
   const int        n = A->nrows, nbr = n / 3;
-  int              tb = 512; // measured on MI355X (profiles/): 512 beats 1024 for both precisions
-  if (const char *e = getenv("PMH_BSR_TB")) tb = atoi(e); // tuning knob
-  if (tb != 512 && tb != 1024) return pmh_set_error(PMH_ERR_ARG, "PMH_BSR_TB must be 512 or 1024");
+  const int        tb = BSR_TB, W = bsr_width(storage);
   std::vector<int> rp((size_t)n + 1), ci((size_t)A->nnz);
   std::vector<double> va((size_t)A->nnz);
   PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), A->d_rowptr, sizeof(int) * rp.size()));
@@ -107,12 +158,21 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
     }
     if (br == nbr - 1) tile_br.push_back(nbr);
   }
-  const int ntiles = (int)tile_br.size() - 1;
-  // values, tile-wise structure of arrays
-  std::vector<double> bv((size_t)nblocks * 9, 0.0);
+  const int              ntiles = (int)tile_br.size() - 1;
+  std::vector<long long> tile_off((size_t)ntiles + 1, 0); // padded block offsets
   for (int t = 0; t < ntiles; t++) {
-    const int    s0 = browptr[tile_br[t]], nbt = browptr[tile_br[t + 1]] - s0;
-    double      *v  = bv.data() + (size_t)s0 * 9;
+    const int nbt   = browptr[tile_br[t + 1]] - browptr[tile_br[t]];
+    tile_off[t + 1] = tile_off[t] + (nbt + W - 1) / W * W;
+  }
+  const long long npad = tile_off[ntiles];
+  // values, tile-wise structure of arrays; padding blocks are zero and point at block column 0
+  std::vector<double> bv((size_t)npad * 9, 0.0);
+  std::vector<int>    bcp((size_t)npad, 0);
+  double              amax = 0.0;
+  for (int t = 0; t < ntiles; t++) {
+    const int s0 = browptr[tile_br[t]], nbt = browptr[tile_br[t + 1]] - s0, nbp = (nbt + W - 1) / W * W;
+    double   *v  = bv.data() + (size_t)tile_off[t] * 9;
+    std::copy(bcol.begin() + s0, bcol.begin() + s0 + nbt, bcp.begin() + tile_off[t]);
     for (int br = tile_br[t]; br < tile_br[t + 1]; br++) {
       const int *bc = bcol.data() + browptr[br];
       const int  nb = browptr[br + 1] - browptr[br];
@@ -121,26 +181,39 @@ int pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out)
           const int  c = ci[k] / 3, cc = ci[k] % 3;
           const int *p = std::lower_bound(bc, bc + nb, c);
           const int  j = (int)(p - bc) + browptr[br] - s0;
-          v[(size_t)(3 * r + cc) * nbt + j] += va[k];
+          v[(size_t)(3 * r + cc) * nbp + j] += va[k];
+          amax = std::max(amax, fabs(va[k]));
         }
     }
   }
   pmh_bsr3 B = new pmh_bsr3_s();
-  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->is_float = is_float, B->tb = tb;
+  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W;
+  B->scale   = 1.0;
   B->ev_used = 0, B->ev_on = 0;
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * tile_br.size(), (void **)&B->d_tile_br));
+  PMH_CHK(pmh_malloc(ctx, sizeof(long long) * tile_off.size(), (void **)&B->d_tile_off));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * browptr.size(), (void **)&B->d_browptr));
-  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(nblocks + 1), (void **)&B->d_bcol));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(npad + 2), (void **)&B->d_bcol));
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_br, tile_br.data(), sizeof(int) * tile_br.size()));
+  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_off, tile_off.data(), sizeof(long long) * tile_off.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_browptr, browptr.data(), sizeof(int) * browptr.size()));
-  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_bcol, bcol.data(), sizeof(int) * (size_t)nblocks));
-  if (is_float) {
+  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_bcol, bcp.data(), sizeof(int) * (size_t)npad));
+  if (storage == PMH_BSR_F32) {
     std::vector<float> bf(bv.size());
     for (size_t i = 0; i < bv.size(); i++) bf[i] = (float)bv[i];
-    PMH_CHK(pmh_malloc(ctx, sizeof(float) * (bf.size() + 1), &B->d_val));
+    PMH_CHK(pmh_malloc(ctx, sizeof(float) * (bf.size() + 2), &B->d_val));
     PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bf.data(), sizeof(float) * bf.size()));
+  } else if (storage == PMH_BSR_F16) {
+    // power-of-two scale that brings the largest entry to [1, 2): entries below 2^-24 of it flush to zero
+    int ex = 0;
+    if (amax > 0.0) frexp(amax, &ex);
+    B->scale = ldexp(1.0, ex - 1);
+    std::vector<_Float16> bh(bv.size());
+    for (size_t i = 0; i < bv.size(); i++) bh[i] = (_Float16)(float)(bv[i] / B->scale);
+    PMH_CHK(pmh_malloc(ctx, sizeof(_Float16) * (bh.size() + 4), &B->d_val));
+    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bh.data(), sizeof(_Float16) * bh.size()));
   } else {
-    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (bv.size() + 1), &B->d_val));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (bv.size() + 2), &B->d_val));
     PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bv.data(), sizeof(double) * bv.size()));
   }
   *out = B;
@@ -151,6 +224,7 @@ int pmh_bsr3_destroy(pmh_bsr3 B)
 {
   if (!B) return PMH_SUCCESS;
   pmh_free(B->ctx, B->d_tile_br);
+  pmh_free(B->ctx, B->d_tile_off);
   pmh_free(B->ctx, B->d_browptr);
   pmh_free(B->ctx, B->d_bcol);
   pmh_free(B->ctx, B->d_val);
@@ -162,30 +236,43 @@ int pmh_bsr3_destroy(pmh_bsr3 B)
 // algorithmic bytes of one launch: values + one index per block, block-row pointers, x read once, y written once
 double pmh_bsr3_bytes(pmh_bsr3 B)
 {
-  const double w = B->is_float ? 4.0 : 8.0;
-  return (double)B->nblocks * (9.0 * w + 4.0) + 4.0 * (B->nbr + 1) + 2.0 * w * B->n;
+  const double wm = (B->storage == PMH_BSR_F64) ? 8.0 : (B->storage == PMH_BSR_F32 ? 4.0 : 2.0);
+  const double wv = (B->storage == PMH_BSR_F64) ? 8.0 : 4.0;
+  return (double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1) + 2.0 * wv * B->n;
 }
 
-template <typename T>
-static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const T *y1, const int *halt)
+template <typename TM, typename T, int W>
+static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)
 {
-  const dim3 grid((unsigned)(((B->ntiles + 7) / 8) * 8)), blk(PMH_BLOCK);
-  hipStream_t st = B->ctx->stream;
+  const dim3       grid((unsigned)(((B->ntiles + 7) / 8) * 8)), blk(PMH_BLOCK);
+  hipStream_t      st = B->ctx->stream;
+  const int       *tb = B->d_tile_br, *bp = B->d_browptr, *bc = B->d_bcol;
+  const long long *to = B->d_tile_off;
+  const TM        *v  = (const TM *)B->d_val;
+  const T          sc = (T)B->scale;
+#define BSR_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<TM, T, EPI, W>), grid, blk, 0, st, tb, to, B->ntiles, bp, bc, v, sc, x, y, e, halt)
+  switch (epi) {
+  case PMH_EPI_NONE: BSR_LAUNCH(PMH_EPI_NONE); break;
+  case PMH_EPI_ADD: BSR_LAUNCH(PMH_EPI_ADD); break;
+  case PMH_EPI_SUB: BSR_LAUNCH(PMH_EPI_SUB); break;
+  case PMH_BSR_EPI_PRE: BSR_LAUNCH(PMH_BSR_EPI_PRE); break;
+  case PMH_BSR_EPI_POST1: BSR_LAUNCH(PMH_BSR_EPI_POST1); break;
+  case PMH_BSR_EPI_POST2: BSR_LAUNCH(PMH_BSR_EPI_POST2); break;
+  default: return pmh_set_error(PMH_ERR_ARG, "bsr3: unsupported epilogue %d", epi);
+  }
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+template <typename TM, typename T>
+static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)
+{
+  hipStream_t st    = B->ctx->stream;
   const bool  timed = B->ev_on && (size_t)(B->ev_used + 2) <= B->ev.size();
   if (timed) PMH_HIP(hipEventRecord(B->ev[B->ev_used], st));
-  const int *tb = B->d_tile_br, *bp = B->d_browptr, *bc = B->d_bcol;
-  const T   *v  = (const T *)B->d_val;
-#define BSR_LAUNCH(EPI, TB) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<T, EPI, TB>), grid, blk, 0, st, tb, B->ntiles, bp, bc, v, x, y, y1, halt)
-#define BSR_LAUNCH_TB(EPI) \
-  do { \
-    if (B->tb == 512) BSR_LAUNCH(EPI, 512); \
-    else BSR_LAUNCH(EPI, 1024); \
-  } while (0)
-  if (epi == PMH_EPI_NONE) BSR_LAUNCH_TB(PMH_EPI_NONE);
-  else if (epi == PMH_EPI_ADD) BSR_LAUNCH_TB(PMH_EPI_ADD);
-  else if (epi == PMH_EPI_SUB) BSR_LAUNCH_TB(PMH_EPI_SUB);
-  else return pmh_set_error(PMH_ERR_ARG, "bsr3: unsupported epilogue %d", epi);
-  PMH_HIP(hipGetLastError());
+  if (B->W == 4) PMH_CHK((bsr3_launch_w<TM, T, 4>(B, x, y, epi, e, halt)));
+  else if (B->W == 2) PMH_CHK((bsr3_launch_w<TM, T, 2>(B, x, y, epi, e, halt)));
+  else PMH_CHK((bsr3_launch_w<TM, T, 1>(B, x, y, epi, e, halt)));
   if (timed) {
     PMH_HIP(hipEventRecord(B->ev[B->ev_used + 1], st));
     B->ev_used += 2;
@@ -193,16 +280,33 @@ static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const T *y1, const
   return PMH_SUCCESS;
 }
 
+int pmh_bsr3_spmv_epi_f64(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt)
+{
+  PMH_ARG(B && B->storage == PMH_BSR_F64);
+  return bsr3_launch<double, double>(B, x, y, epi, e, halt);
+}
+
+int pmh_bsr3_spmv_epi_f32(pmh_bsr3 B, const float *x, float *y, int epi, const pmh_bsr3_epi<float> &e, const int *halt)
+{
+  PMH_ARG(B && B->storage != PMH_BSR_F64);
+  if (B->storage == PMH_BSR_F16) return bsr3_launch<_Float16, float>(B, x, y, epi, e, halt);
+  return bsr3_launch<float, float>(B, x, y, epi, e, halt);
+}
+
 int pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt)
 {
-  PMH_ARG(B && !B->is_float);
-  return bsr3_launch<double>(B, x, y, epi, y1, halt);
+  pmh_bsr3_epi<double> e;
+  memset(&e, 0, sizeof(e));
+  e.y1 = y1;
+  return pmh_bsr3_spmv_epi_f64(B, x, y, epi, e, halt);
 }
 
 int pmh_bsr3_spmv_f32(pmh_bsr3 B, const float *x, float *y, int epi, const float *y1, const int *halt)
 {
-  PMH_ARG(B && B->is_float);
-  return bsr3_launch<float>(B, x, y, epi, y1, halt);
+  pmh_bsr3_epi<float> e;
+  memset(&e, 0, sizeof(e));
+  e.y1 = y1;
+  return pmh_bsr3_spmv_epi_f32(B, x, y, epi, e, halt);
 }
 
 int pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches)

@@ -16,7 +16,7 @@ struct mg_level {
   pmh_csr  A, P;          // P: n_l x n_{l+1} (NULL on the coarsest level); A is used directly only if Ab == NULL
   pmh_bsr3 Ab;            // 3x3-block copy of A in the cycle's precision, or NULL
   int      n;
-  void    *dinv, *x, *b, *r, *d, *t; // vectors in the cycle's precision; in fp64 x and b of level 0 are the caller's
+  void    *dinv, *x, *b, *r, *d, *t, *xa; // vectors in the cycle's precision; in fp64 x and b of level 0 are the caller's
   double   theta, delta;
   std::vector<double> c1, c2; // Chebyshev recurrence coefficients of steps 1..degree-1
 };
@@ -41,6 +41,7 @@ struct pmh_mg_s {
   };
   std::vector<cached_graph> graphs;
   int                       use_graph, timing_on;
+  int                       fused; // degree 2 + block operators: smoothing steps finished inside the operator kernel
 };
 
 template <typename TV>
@@ -64,6 +65,19 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_first_zero(int n, const int 
     r[i] = ri;
     d[i] = di;
     x[i] = di;
+  }
+}
+
+// fused cycle: d0 = D^-1 b / theta (the first pre-smoothing direction); on the fine level of the fp32 cycle b arrives in
+// fp64 and its fp32 copy is produced on the way
+template <typename TV, typename TB>
+__global__ __launch_bounds__(PMH_BLOCK) void k_cheb_d0(int n, const int *__restrict__ halt, const TV *__restrict__ dinv, const TB *__restrict__ b, TV itheta, TV *__restrict__ d, TV *__restrict__ bcopy)
+{
+  if (halt && *halt) return;
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
+    const TV bi = (TV)b[i];
+    d[i] = dinv[i] * bi * itheta;
+    if (bcopy) bcopy[i] = bi;
   }
 }
 
@@ -199,12 +213,52 @@ static int mg_smooth(pmh_mg mg, int l, const TV *b, TV *x, bool zero)
   return PMH_SUCCESS;
 }
 
+template <typename TV> static int bsr_epi_launch(pmh_bsr3 B, const TV *x, TV *y, int epi, const pmh_bsr3_epi<TV> &e, const int *halt);
+template <> int bsr_epi_launch<double>(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt) { return pmh_bsr3_spmv_epi_f64(B, x, y, epi, e, halt); }
+template <> int bsr_epi_launch<float>(pmh_bsr3 B, const float *x, float *y, int epi, const pmh_bsr3_epi<float> &e, const int *halt) { return pmh_bsr3_spmv_epi_f32(B, x, y, epi, e, halt); }
+
+template <typename TV> static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64 = nullptr, double *z64 = nullptr);
+
+// One smoothed level with the degree-2 Chebyshev steps finished inside the operator kernel (7 launches instead of 10):
+//   d0 = D^-1 b/theta | xa = (1+c1) d0 + c2 D^-1 (b - A d0) | t = A xa - b | b_c = P't | ... | xa -= P x_c |
+//   r, d, x = xa + d from A xa | x += c1 d + c2 (r - D^-1 A d)
+// b64 / z64: fp64 input / output of the fp32 cycle's fine level (the conversions ride on the first and last kernel).
 template <typename TV>
-static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x)
+static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64)
+{
+  mg_level   &Lv = mg->L[l], &Lc = mg->L[l + 1];
+  hipStream_t st = mg->ctx->stream;
+  const dim3  g = mg_grid(Lv.n), blk(PMH_BLOCK);
+  TV         *r = (TV *)Lv.r, *d = (TV *)Lv.d, *t = (TV *)Lv.t, *xa = (TV *)Lv.xa;
+  const TV   *dinv = (const TV *)Lv.dinv;
+  const TV    itheta = (TV)(1.0 / Lv.theta), c1 = (TV)Lv.c1[1], c2 = (TV)Lv.c2[1];
+  if (b64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_d0<TV, double>), g, blk, 0, st, Lv.n, mg->halt, dinv, b64, itheta, d, (TV *)b);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_d0<TV, TV>), g, blk, 0, st, Lv.n, mg->halt, dinv, b, itheta, d, (TV *)nullptr);
+  pmh_bsr3_epi<TV> e;
+  memset(&e, 0, sizeof(e));
+  e.y1 = b, e.dinv = dinv, e.r = r, e.d = d;
+  e.c0 = (TV)1 + c1, e.c1 = c1, e.c2 = c2;
+  if (l == 0) mg->fine_spmv += 4;
+  PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, d, xa, PMH_BSR_EPI_PRE, e, mg->halt));
+  PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, t, PMH_EPI_SUB, e, mg->halt));
+  pmh_csr R = Lv.P->transpose;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)t, (TV *)Lc.b);
+  PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), g, blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, xa);
+  PMH_HIP(hipGetLastError());
+  e.c0 = itheta;
+  PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, x, PMH_BSR_EPI_POST1, e, mg->halt));
+  e.z64 = z64;
+  return bsr_epi_launch<TV>(Lv.Ab, d, x, PMH_BSR_EPI_POST2, e, mg->halt);
+}
+
+template <typename TV>
+static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64)
 {
   mg_level   &Lv = mg->L[l];
   hipStream_t st = mg->ctx->stream;
   const dim3  blk(PMH_BLOCK);
+  if (l < mg->nlevels - 1 && mg->fused && Lv.Ab) return mg_level_fused<TV>(mg, l, b, x, b64, z64);
   if (l == mg->nlevels - 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_coarse<TV>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const TV *)mg->d_cpinv, b, x);
     PMH_HIP(hipGetLastError());
@@ -255,7 +309,10 @@ static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt)
 {
   mg->halt = halt;
   int rc;
-  if (mg->is_float) {
+  if (mg->is_float && mg->fused && mg->nlevels > 1) {
+    mg_level &L0 = mg->L[0];
+    rc = mg_cycle<float>(mg, 0, (const float *)L0.b, (float *)L0.x, b, x); // conversions fused into the first / last kernel
+  } else if (mg->is_float) {
     mg_level   &L0 = mg->L[0];
     hipStream_t st = mg->ctx->stream;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_convert<double, float>), mg_grid(L0.n), dim3(PMH_BLOCK), 0, st, L0.n, halt, b, (float *)L0.b);
@@ -280,13 +337,13 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   PMH_ARG(ctx && out && A && nlevels >= 1 && degree >= 1 && nb_coarse >= 1 && coarse_rowstart && coarse_pinv_host);
   PMH_ARG(nlevels == 1 || (P && lambda_max));
   PMH_ARG(hi_frac > lo_frac && lo_frac > 0.0);
-  PMH_ARG(precision == PMH_MG_FP64 || precision == PMH_MG_FP32);
+  PMH_ARG(precision == PMH_MG_FP64 || precision == PMH_MG_FP32 || precision == PMH_MG_FP16);
   for (int l = 0; l < nlevels; l++) {
     PMH_ARG(A[l] && A[l]->nrows == A[l]->ncols);
     if (l + 1 < nlevels) PMH_ARG(P[l] && P[l]->nrows == A[l]->nrows && P[l]->ncols == A[l + 1]->nrows && lambda_max[l] > 0.0);
   }
   PMH_ARG(coarse_rowstart[0] == 0 && coarse_rowstart[nb_coarse] == A[nlevels - 1]->nrows);
-  const int    fl = precision == PMH_MG_FP32;
+  const int    fl = precision != PMH_MG_FP64;
   const size_t w  = fl ? sizeof(float) : sizeof(double);
   pmh_mg mg     = new pmh_mg_s();
   mg->ctx       = ctx;
@@ -298,22 +355,26 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   mg->timing_on = 0;
   mg->use_graph = 1;
   if (const char *e = getenv("PMH_MG_GRAPH")) mg->use_graph = atoi(e);
+  mg->fused = (degree == 2);
+  if (const char *e = getenv("PMH_MG_FUSED")) mg->fused = mg->fused && atoi(e); // testing knob: 0 = separate smoothing kernels
   mg->L.resize(nlevels);
   const bool no_bsr = getenv("PMH_MG_NO_BSR") != nullptr; // testing knob: keep the CSR kernels (fp64 only)
   for (int l = 0; l < nlevels; l++) {
     mg_level &Lv = mg->L[l];
     Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows, Lv.Ab = nullptr;
-    Lv.dinv = Lv.x = Lv.b = Lv.r = Lv.d = Lv.t = nullptr;
+    Lv.dinv = Lv.x = Lv.b = Lv.r = Lv.d = Lv.t = Lv.xa = nullptr;
     const size_t nbytes = w * (size_t)(Lv.n ? Lv.n : 1);
     if (l > 0 || fl) {
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.x));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.b));
     }
     if (l + 1 < nlevels) {
-      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], fl, &Lv.Ab));
+      // FP16: the fine-level operator (almost all of the cycle's bytes) stores fp16 entries; arithmetic and vectors stay fp32
+      const int storage = !fl ? PMH_BSR_F64 : ((precision == PMH_MG_FP16 && l == 0) ? PMH_BSR_F16 : PMH_BSR_F32);
+      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab));
       if (fl && !Lv.Ab) {
         pmh_mg_destroy(mg);
-        return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
+        return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32/FP16 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
       }
       if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
@@ -321,6 +382,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.r));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.d));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.t));
+      PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.xa));
       if (Lv.n > 0) {
         if (fl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<float>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (float *)Lv.dinv);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
@@ -372,6 +434,7 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.r);
     pmh_free(ctx, Lv.d);
     pmh_free(ctx, Lv.t);
+    pmh_free(ctx, Lv.xa);
     pmh_free(ctx, Lv.x);
     pmh_free(ctx, Lv.b);
     pmh_bsr3_destroy(Lv.Ab);

@@ -121,19 +121,33 @@ int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                          
 // ---- 3x3-block SpMV (bsr.hip) -------------------------------------------------------------------------------------
 struct pmh_bsr3_s {
   pmh_ctx   ctx;
-  int       n, nbr, ntiles, is_float, tb;
-  long long nblocks;
+  int       n, nbr, ntiles, storage, W; // storage: PMH_BSR_F64 / F32 / F16 (matrix entries); W: blocks per load
+  long long nblocks, npad;
+  double    scale; // F16: the stored entries are A / scale
   int      *d_tile_br, *d_browptr, *d_bcol;
+  long long *d_tile_off;
   void     *d_val;
   std::vector<hipEvent_t> ev; // optional per-launch timing (event pairs on the launch stream)
   int                     ev_used, ev_on;
 };
 typedef pmh_bsr3_s *pmh_bsr3;
-int    pmh_bsr3_from_csr(pmh_csr A, int is_float, pmh_bsr3 *out); // *out = NULL (no error) if A has no usable 3x3 block structure
+enum { PMH_BSR_F64 = 0, PMH_BSR_F32 = 1, PMH_BSR_F16 = 2 };
+// fused epilogues of the block kernel (continuing the PMH_EPI_* numbering): see bsr.hip
+enum { PMH_BSR_EPI_PRE = 10, PMH_BSR_EPI_POST1 = 11, PMH_BSR_EPI_POST2 = 12 };
+template <typename T> struct pmh_bsr3_epi {
+  const T *y1;   // ADD / SUB operand; b of the smoothing steps
+  const T *dinv; // Jacobi scaling
+  T       *r, *d; // POST1 outputs; r is a POST2 input
+  double  *z64;  // POST2: optional fp64 copy of the result
+  T        c0, c1, c2;
+};
+int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out); // *out = NULL (no error) if A has no usable 3x3 block structure
 int    pmh_bsr3_destroy(pmh_bsr3 B);
 double pmh_bsr3_bytes(pmh_bsr3 B);
 int    pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt);
 int    pmh_bsr3_spmv_f32(pmh_bsr3 B, const float *x, float *y, int epi, const float *y1, const int *halt);
+int    pmh_bsr3_spmv_epi_f64(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt);
+int    pmh_bsr3_spmv_epi_f32(pmh_bsr3 B, const float *x, float *y, int epi, const pmh_bsr3_epi<float> &e, const int *halt);
 int    pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches);
 int    pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms);
 int    pmh_csr_ensure_transpose(pmh_csr A); // builds A->transpose if missing

@@ -162,7 +162,7 @@ class MG:
         cpinv = np.ascontiguousarray(hier["coarse_pinv"], dtype=np.float64)
         h = C.c_void_p()
         check(ctx.L.pmh_mg_create(ctx.h, self.nlevels, Ah, Ph, int(degree), lam.ctypes.data_as(C.c_void_p), float(lo), float(hi), crs.size - 1,
-                                  crs.ctypes.data_as(C.c_void_p), cpinv.ctypes.data_as(C.c_void_p), {"fp64": 0, "fp32": 1}[precision], C.byref(h)))
+                                  crs.ctypes.data_as(C.c_void_p), cpinv.ctypes.data_as(C.c_void_p), {"fp64": 0, "fp32": 1, "fp16": 2}[precision], C.byref(h)))
         self.h = h
 
     def apply(self, b, x):  # PCApply

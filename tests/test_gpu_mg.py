@@ -66,9 +66,13 @@ def _cube_hierarchy(f, min_nodes=27):
     return box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, f.ndof, min_nodes=min_nodes)
 
 
-@pytest.mark.parametrize("physics,degree,csr_only", [("poisson", 2, False), ("elasticity", 2, False), ("elasticity", 3, False), ("elasticity", 2, True)])
+@pytest.mark.parametrize("physics,degree,csr_only", [("poisson", 2, False), ("elasticity", 2, False), ("elasticity", 3, False), ("elasticity", 2, True), ("elasticity", 2, "unfused")])
 def test_vcycle_matches_numpy_restatement(ctx, physics, degree, csr_only, monkeypatch):
-    """fp64 cycle: the elasticity levels run on the 3x3-block kernel (bsr.hip) unless csr_only, Poisson on the CSR kernel."""
+    """fp64 cycle: the elasticity levels run on the 3x3-block kernel (bsr.hip) unless csr_only, Poisson on the CSR kernel.
+    Degree 2 on block operators finishes the smoothing steps inside the operator kernel ("unfused" switches that off)."""
+    if csr_only == "unfused":
+        monkeypatch.setenv("PMH_MG_FUSED", "0")
+        csr_only = False
     f = CubeFeti((2, 1, 1), 8, physics, contact=False)
     H = _cube_hierarchy(f)
     assert len(H["A"]) >= 3
@@ -92,12 +96,13 @@ def test_fp32_cycle_is_a_close_copy_of_the_fp64_cycle(ctx):
     H = _cube_hierarchy(f)
     b = np.random.default_rng(7).standard_normal(f.N)
     out = []
-    for prec in ("fp64", "fp32"):
+    for prec in ("fp64", "fp32", "fp16"):
         mg = pa.MG(ctx, H, precision=prec)
         x = ctx.vec(f.N)
         mg.apply(ctx.vec_from(b), x)
         out.append(x.to_numpy())
     assert np.linalg.norm(out[1] - out[0]) <= 2e-5 * np.linalg.norm(out[0])
+    assert np.linalg.norm(out[2] - out[0]) <= 5e-3 * np.linalg.norm(out[0])  # fp16 entries: 2^-11 relative perturbation of K
     with pytest.raises(pa.PermonHipError):  # Poisson blocks have no 3x3 structure
         g = CubeFeti((2, 1, 1), 8, "poisson", contact=False)
         pa.MG(ctx, _cube_hierarchy(g), precision="fp32")
@@ -126,7 +131,7 @@ def test_matinv_bsr3_product_matches_csr(ctx):
         pa.MatInv(Kg).enable_bsr3()
 
 
-@pytest.mark.parametrize("nel,prec", [(8, "fp64"), (11, "fp64"), (8, "fp32"), (11, "fp32")])  # 11: odd element count, non-nested last coarse interval
+@pytest.mark.parametrize("nel,prec", [(8, "fp64"), (11, "fp64"), (8, "fp32"), (11, "fp32"), (11, "fp16")])  # 11: odd element count, non-nested last coarse interval
 def test_matinv_with_mg_pc(ctx, nel, prec):
     f = CubeFeti((2, 1, 1), nel, "elasticity", contact=False)
     K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
@@ -136,7 +141,7 @@ def test_matinv_with_mg_pc(ctx, nel, prec):
     Mj.mult(ctx.vec_from(rhs), uj)
     its_j, _ = Mj.last_iterations()
     Mm = pa.MatInv(K, rtol=1e-12, nullspace=f.R)
-    if prec == "fp32":
+    if prec != "fp64":
         Mm.enable_bsr3()
     mg = Mm.set_pc_mg(_cube_hierarchy(f), precision=prec)
     Mm.mult(ctx.vec_from(rhs), um)
