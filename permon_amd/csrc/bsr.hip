@@ -13,7 +13,7 @@
 
 #include <algorithm>
 
-#define BSR_TB 512 // blocks per tile; 1024 measured slower (profiles/)
+#define BSR_TB_MAX 2048 // largest tile (blocks)
 
 template <typename TM, int W> struct vecw { typedef TM type __attribute__((ext_vector_type(W))); };
 template <typename TM> struct vecw<TM, 1> { typedef TM type; };
@@ -33,7 +33,7 @@ template <typename V> struct lane_of<V, 1> {
 //   POST1 (x gathered):       r = dinv (b - A x); d = c0 r; y = x + d             first step of the post-smoother
 //   POST2 (x = d gathered):   y += c1 d + c2 (r - dinv A d); optional fp64 copy   second step of the post-smoother
 // TM: storage type of the matrix entries, T: arithmetic / vector type, W: adjacent blocks per thread-load.
-template <typename TM, typename T, int EPI, int W>
+template <typename TM, typename T, int EPI, int W, int BSR_TB>
 __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile_br, const long long *__restrict__ tile_off, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const TM *__restrict__ val, T scale,
                                                      const T *__restrict__ x, T *__restrict__ y, pmh_bsr3_epi<T> e, const int *__restrict__ halt)
 {
@@ -104,15 +104,26 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile
   }
 }
 
+static int bsr_tile(int storage)
+{
+  int tb = 1024; // measured on MI355X (profiles/r01_bsr3_tune.txt)
+  if (const char *e = getenv("PMH_BSR_TB")) { // tuning knob: "tb64,tb32,tb16"
+    int t64 = 1024, t32 = 1024, t16 = 1024;
+    sscanf(e, "%d,%d,%d", &t64, &t32, &t16);
+    tb = (storage == PMH_BSR_F64) ? t64 : (storage == PMH_BSR_F32 ? t32 : t16);
+  }
+  return (tb == 512 || tb == 1024 || tb == 2048) ? tb : 512;
+}
+
 static int bsr_width(int storage)
 {
-  int w = (storage == PMH_BSR_F64) ? 1 : 2;
+  int w = (storage == PMH_BSR_F64) ? 2 : 4; // 16-byte loads for fp64 / fp32, 8-byte for fp16
   if (const char *e = getenv("PMH_BSR_W")) { // tuning knob: "w64,w32,w16"
-    int w64 = 1, w32 = 2, w16 = 2;
+    int w64 = 2, w32 = 4, w16 = 4;
     sscanf(e, "%d,%d,%d", &w64, &w32, &w16);
     w = (storage == PMH_BSR_F64) ? w64 : (storage == PMH_BSR_F32 ? w32 : w16);
   }
-  return (w == 1 || w == 2 || w == 4) ? w : 1;
+  return (w == 1 || w == 2 || w == 4 || (w == 8 && storage == PMH_BSR_F16)) ? w : 1;
 }
 
 // Build from a resident CSR (downloaded once); *out = NULL without error when the matrix has no 3x3 block structure that
@@ -124,7 +135,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out)
   pmh_ctx ctx = A->ctx;
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
   const int        n = A->nrows, nbr = n / 3;
-  const int        tb = BSR_TB, W = bsr_width(storage);
+  const int        tb = bsr_tile(storage), W = bsr_width(storage);
   std::vector<int> rp((size_t)n + 1), ci((size_t)A->nnz);
   std::vector<double> va((size_t)A->nnz);
   PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), A->d_rowptr, sizeof(int) * rp.size()));
@@ -187,7 +198,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out)
     }
   }
   pmh_bsr3 B = new pmh_bsr3_s();
-  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W;
+  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
   B->scale   = 1.0;
   B->ev_used = 0, B->ev_on = 0;
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * tile_br.size(), (void **)&B->d_tile_br));
@@ -241,7 +252,7 @@ double pmh_bsr3_bytes(pmh_bsr3 B)
   return (double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1) + 2.0 * wv * B->n;
 }
 
-template <typename TM, typename T, int W>
+template <typename TM, typename T, int W, int TB>
 static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)
 {
   const dim3       grid((unsigned)(((B->ntiles + 7) / 8) * 8)), blk(PMH_BLOCK);
@@ -250,7 +261,7 @@ static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_e
   const long long *to = B->d_tile_off;
   const TM        *v  = (const TM *)B->d_val;
   const T          sc = (T)B->scale;
-#define BSR_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<TM, T, EPI, W>), grid, blk, 0, st, tb, to, B->ntiles, bp, bc, v, sc, x, y, e, halt)
+#define BSR_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<TM, T, EPI, W, TB>), grid, blk, 0, st, tb, to, B->ntiles, bp, bc, v, sc, x, y, e, halt)
   switch (epi) {
   case PMH_EPI_NONE: BSR_LAUNCH(PMH_EPI_NONE); break;
   case PMH_EPI_ADD: BSR_LAUNCH(PMH_EPI_ADD); break;
@@ -270,9 +281,16 @@ static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi
   hipStream_t st    = B->ctx->stream;
   const bool  timed = B->ev_on && (size_t)(B->ev_used + 2) <= B->ev.size();
   if (timed) PMH_HIP(hipEventRecord(B->ev[B->ev_used], st));
-  if (B->W == 4) PMH_CHK((bsr3_launch_w<TM, T, 4>(B, x, y, epi, e, halt)));
-  else if (B->W == 2) PMH_CHK((bsr3_launch_w<TM, T, 2>(B, x, y, epi, e, halt)));
-  else PMH_CHK((bsr3_launch_w<TM, T, 1>(B, x, y, epi, e, halt)));
+#define BSR_W(TBV) \
+  do { \
+    if (B->W == 8 && sizeof(TM) == 2) PMH_CHK((bsr3_launch_w<TM, T, (sizeof(TM) == 2 ? 8 : 4), TBV>(B, x, y, epi, e, halt))); \
+    else if (B->W == 4) PMH_CHK((bsr3_launch_w<TM, T, 4, TBV>(B, x, y, epi, e, halt))); \
+    else if (B->W == 2) PMH_CHK((bsr3_launch_w<TM, T, 2, TBV>(B, x, y, epi, e, halt))); \
+    else PMH_CHK((bsr3_launch_w<TM, T, 1, TBV>(B, x, y, epi, e, halt))); \
+  } while (0)
+  if (B->tb == 2048) BSR_W(2048);
+  else if (B->tb == 1024) BSR_W(1024);
+  else BSR_W(512);
   if (timed) {
     PMH_HIP(hipEventRecord(B->ev[B->ev_used + 1], st));
     B->ev_used += 2;

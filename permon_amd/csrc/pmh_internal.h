@@ -121,7 +121,7 @@ int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                          
 // ---- 3x3-block SpMV (bsr.hip) -------------------------------------------------------------------------------------
 struct pmh_bsr3_s {
   pmh_ctx   ctx;
-  int       n, nbr, ntiles, storage, W; // storage: PMH_BSR_F64 / F32 / F16 (matrix entries); W: blocks per load
+  int       n, nbr, ntiles, storage, W, tb; // storage: PMH_BSR_F64 / F32 / F16 (matrix entries); W: blocks per load
   long long nblocks, npad;
   double    scale; // F16: the stored entries are A / scale
   int      *d_tile_br, *d_browptr, *d_bcol;
