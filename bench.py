@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
+    ap.add_argument("--sim-world", type=int, default=0, help="feti, testing: this single process takes the share rank 0 would have in a run on SIM_WORLD GPUs (8/SIM_WORLD blocks, no collective): per-GPU launch-latency rehearsal of the strong-scaling run")
     ap.add_argument("--cpu-its", type=int, default=24, help="c2: MPGP iterations of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -305,6 +306,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     if 8 % world:
         raise SystemExit("feti workload: the 8 subdomains must divide over the ranks (N in 1,2,4,8)")
     per = 8 // world
+    if a.sim_world and world == 1:
+        if 8 % a.sim_world:
+            raise SystemExit("--sim-world must divide 8")
+        per = 8 // a.sim_world
     local = f.subset(range(rank * per, (rank + 1) * per))
     t_gen = time.time() - t0
     t0 = time.time()
@@ -367,7 +372,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
                     "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+ (rtol %.0e)"
                     % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, pc_text, a.kplus_rtol),
-        "parallelism": "%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world),
+        "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
+                       + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
         "kplus": {"pc": a.kplus_pc, "cg_spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(steps, 1),
                   "last_block_cg_iterations": kits},

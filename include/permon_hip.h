@@ -249,6 +249,19 @@ int pmh_matinv_set_nullspace(pmh_matinv Kplus, int kdim, const double *R_host);
 int pmh_matinv_mult(pmh_matinv Kplus, const double *f, double *u);
 int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *total_spmv);
 
+/* MatRegularize (src/mat/interface/permonmatregularize.c:198-287), the set-up step of the reference's default FETI path
+   (-regularize 1 -> MAT_REG_EXPLICIT, qptransform.c:2215,2231; MATINV then factors / iterates on K_reg, matinv.c:449-459).
+   Host routines (they run once per block on host CSR / dense R; the per-iteration work stays in pmh_matinv_mult):
+   _pivots = MatRegularize_GetPivots_Private (:6-116): the d "fixing" DOFs picked from the p x d column-major kernel basis
+             R_loc by complete pivoting from the last column backwards -- index bookkeeping, reproduced exactly;
+   _Q      = MatRegularize_GetRegularization_Private (:118-160): RI (RI'RI)^{-1} RI' filtered at 10 eps (d x d row-major);
+   _csr    = K_reg = K + rho (rho Q) on the union pattern (rho enters twice, :256,265, kept); rho is the caller's
+             pmh_op_max_eigenvalue(K, 1.0, 20, ...) (:254).  Output arrays hold rowptr[n] + d*d entries. */
+int pmh_mat_regularize_pivots(int p, int d, const double *R_host, int *pivots_out /* d, ascending */);
+int pmh_mat_regularization_Q(int p, int d, const double *R_host, const int *pivots, double *Q_out, int *keep_out);
+int pmh_mat_regularize_csr(int n, const int *rowptr, const int *col, const double *val, int d, const double *R_host, double rho, int *pivots_out, int *rowptr_out, int *col_out,
+                           double *val_out, long long *nnz_out);
+
 /* F = B K^+ B' (QPTDualize qptransform.c:1103-1128; MatCreateProd matprod.c:42-48) */
 int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
 /* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */

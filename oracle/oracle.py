@@ -193,6 +193,32 @@ def max_eigenvalue(op, tol=-1.0, maxits=-1, omp=False):
     return lam, its.value
 
 
+def regularize_pivots(R):
+    """MatRegularize_GetPivots_Private; R: (d, p) array = the p x d kernel basis stored column-major."""
+    R = _f64(R)
+    d, p = R.shape
+    piv = np.zeros(d, dtype=np.int32)
+    lib().orc_regularize_pivots(C.c_int(p), C.c_int(d), _dp(R), _p(piv))
+    return piv
+
+
+def regularize_csr(csr, R, rho):
+    """MatRegularize (MAT_REG_EXPLICIT) of one block: returns (rowptr, col, val, pivots) of K + rho^2 Q."""
+    R = _f64(R)
+    d = R.shape[0] if R.size else 0
+    nnz = int(csr.rowptr[-1])
+    rp = np.zeros(csr.nrows + 1, dtype=np.int32)
+    ci = np.zeros(nnz + d * d, dtype=np.int32)
+    va = np.zeros(nnz + d * d)
+    piv = np.zeros(max(d, 1), dtype=np.int32)
+    L = lib()
+    L.orc_regularize_csr.restype = C.c_int
+    n = L.orc_regularize_csr(C.byref(csr.c), C.c_int(d), _dp(R) if d else None, C.c_double(rho), _p(piv), _p(rp), _p(ci), _dp(va))
+    if n < 0:
+        raise ValueError("R(pivots,:) is rank deficient")
+    return rp, ci[:n].copy(), va[:n].copy(), piv[:d]
+
+
 def _qps_results(L, q, x, trace):
     keys = ["iteration", "reason", "rnorm", "gfnorm", "gcnorm", "nmv", "ncg", "nexp", "nprop", "nfinc", "nfall", "alpha", "maxeig", "norm_rhs", "ttol"]
     res = {k: L.orc_qps_get(C.c_void_p(q), k.encode()) for k in keys}

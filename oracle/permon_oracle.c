@@ -196,7 +196,11 @@ void orc_box_gradreduced(const orc_box *qpc, const double *x, const double *gf, 
 /* ------------------------------------------------------------------------------------------ */
 /* MatGetMaxEigenvalue, src/mat/interface/permonmatutils.c:442-522 (v = 1 start, tol 1e-4,       */
 /* <= 50 its, v = Av/sqrt(v'v) quirk kept).  The lambda < eps random-restart branch (:491-499)   */
-/* needs PETSc's RAND48 stream and is not restated: it is reported by returning NaN.             */
+/* replaces A*v by PETSc's RAND48 stream: PetscRandomCreate seeds 0x12345678 (+76543*rank, rank   */
+/* 0 here), PetscRandomSeed_Rand48 = srand48(seed), VecSetRandom_Seq = drand48() per entry in     */
+/* index order (PETSc src/sys/classes/random/impls/rand48/rand48.c, un-vendored: restated from    */
+/* its published source; no golden of the reference exercises this branch => parity unpinned).    */
+/* lambda keeps its (< eps) value in that iteration, exactly as in the reference.                 */
 /* ------------------------------------------------------------------------------------------ */
 double orc_max_eigenvalue(const orc_op *A, double tol, int maxits, int *its_out)
 {
@@ -204,6 +208,7 @@ double orc_max_eigenvalue(const orc_op *A, double tol, int maxits, int *its_out)
   double *v = (double *)malloc((size_t)n * sizeof(double));
   double *Av = (double *)malloc((size_t)n * sizeof(double));
   double  lambda = 0.0, lambda0, err, relerr, vAv, vv;
+  int     rand_seeded = 0;
   if (tol == ORC_DECIDE || tol == -2.0) tol = 1e-4;
   if (maxits == -1 || maxits == -2) maxits = 50;
   v_set(n, v, 1.0);
@@ -213,9 +218,14 @@ double orc_max_eigenvalue(const orc_op *A, double tol, int maxits, int *its_out)
     vAv    = v_dot(n, v, Av); /* VecMDot(v,2,{Av,v}) */
     vv     = v_dot(n, v, v);
     lambda = vAv / vv;
-    if (lambda < ORC_EPS) {
-      lambda = NAN;
-      break;
+    if (lambda < ORC_EPS) { /* :491-499 */
+      int k;
+      if (!rand_seeded) {
+        srand48(0x12345678L);
+        rand_seeded = 1;
+      }
+      for (k = 0; k < n; k++) Av[k] = drand48();
+      vAv = v_dot(n, v, Av); /* VecDot(v,Av,&vAv_vv[0]): lambda itself is NOT recomputed */
     }
     err    = fabs(lambda - lambda0);
     relerr = err / fabs(lambda);
@@ -223,6 +233,7 @@ double orc_max_eigenvalue(const orc_op *A, double tol, int maxits, int *its_out)
     v_copy(n, Av, v);
     v_scale(n, v, 1.0 / sqrt(vv));
   }
+  (void)vAv;
   if (its_out) *its_out = i;
   free(v);
   free(Av);
@@ -1115,4 +1126,155 @@ void orc_feti_penalized_mult(void *ctx, const double *x, double *y)
   orc_feti_dual_mult(ctx, F->w1, F->w2);
   orc_qppf_apply_P(F->pf, F->w2, F->w1);
   for (i = 0; i < n; i++) y[i] = F->rho * y[i] + F->w1[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MatRegularize, src/mat/interface/permonmatregularize.c (TFETI "fixing DOFs" regularisation   */
+/* of a singular subdomain stiffness matrix; default of QPTFromOptions: -regularize 1,          */
+/* qptransform.c:2215,2231 -> MAT_REG_EXPLICIT).                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* MatRegularize_GetPivots_Private :6-116.  R: p x d column-major (R_loc, the kernel basis of the block).
+   Complete pivoting from the last column / row backwards; the search is column-outer, row-inner with a strict
+   '>' (first maximum wins); rows are swapped only in columns 0..J, columns only in rows 0..II; the remaining
+   columns are combined so that row II vanishes (columns whose entry is < eps are skipped).  pivots = the last d
+   entries of the row permutation, sorted ascending (ISSort). */
+void orc_regularize_pivots(int p, int d, const double *R, int *pivots)
+{
+  double *W = (double *)malloc(sizeof(double) * (size_t)p * (size_t)(d > 0 ? d : 1));
+  int    *perm = (int *)malloc(sizeof(int) * (size_t)(p > 0 ? p : 1));
+  int     i, j, J, II, ipivot = 0, jpivot = 0, t;
+  memcpy(W, R, sizeof(double) * (size_t)p * (size_t)d);
+  for (i = 0; i < p; i++) perm[i] = i;
+#define RW(i, j) W[(size_t)(j) * (size_t)p + (size_t)(i)]
+  for (J = d - 1, II = p - 1; J >= 0; J--, II--) {
+    double vpivot = 0.0;
+    for (j = 0; j <= J; j++)
+      for (i = 0; i <= II; i++)
+        if (fabs(RW(i, j)) > fabs(vpivot)) {
+          ipivot = i;
+          jpivot = j;
+          vpivot = RW(i, j);
+        }
+    for (j = 0; j <= J; j++) { /* swap rows ipivot and II */
+      double a = RW(ipivot, j);
+      RW(ipivot, j) = RW(II, j);
+      RW(II, j)     = a;
+    }
+    t            = perm[ipivot];
+    perm[ipivot] = perm[II];
+    perm[II]     = t;
+    for (i = 0; i <= II; i++) { /* swap columns jpivot and J */
+      double a = RW(i, jpivot);
+      RW(i, jpivot) = RW(i, J);
+      RW(i, J)      = a;
+    }
+    for (j = 0; j <= J - 1; j++) { /* v2 = -(vpivot/v2(II)) * v2 + v1, v1 = the pivot column (now column J) */
+      double alpha;
+      if (fabs(RW(II, j)) < ORC_EPS) continue;
+      alpha = -vpivot / RW(II, j);
+      for (i = 0; i <= II; i++) {
+        double v = RW(i, j);
+        v *= alpha;
+        v += RW(i, J);
+        RW(i, j) = v;
+      }
+    }
+  }
+#undef RW
+  for (i = 0; i < d; i++) pivots[i] = perm[p - d + i];
+  for (i = 1; i < d; i++) { /* ISSort */
+    int v = pivots[i];
+    for (j = i - 1; j >= 0 && pivots[j] > v; j--) pivots[j + 1] = pivots[j];
+    pivots[j + 1] = v;
+  }
+  free(W), free(perm);
+}
+
+/* MatRegularize_GetRegularization_Private :118-160: Q_loc_condensed = RI (RI' RI)^{-1} RI' with RI = R(pivots,:),
+   then MatFilterZeros(.,10 eps) (entries with |q| <= 10 eps are dropped, permonmatutils.c:547).  Q: d x d row-major,
+   dropped entries are exact zeros and keep[] (d*d) flags the stored ones.  (RI'RI)^{-1} is the reference's
+   MatInvExplicitly of a dense SPD matrix (a PETSc factorisation, third party): restated with a Cholesky solve, so
+   values agree to rounding only.  Returns non-zero if RI'RI is not positive definite. */
+int orc_regularization_Q(int p, int d, const double *R, const int *pivots, double *Q, int *keep)
+{
+  double *RI = (double *)malloc(sizeof(double) * (size_t)(d * d + 1)), *M = (double *)malloc(sizeof(double) * (size_t)(d * d + 1));
+  double *Minv = (double *)malloc(sizeof(double) * (size_t)(d * d + 1)), *T = (double *)malloc(sizeof(double) * (size_t)(d * d + 1));
+  double *e = (double *)malloc(sizeof(double) * (size_t)(d + 1)), *c = (double *)malloc(sizeof(double) * (size_t)(d + 1));
+  int     i, j, k, rc;
+  for (i = 0; i < d; i++)
+    for (j = 0; j < d; j++) RI[i * d + j] = R[(size_t)j * (size_t)p + (size_t)pivots[i]];
+  for (i = 0; i < d; i++) /* RItRI = RIt * RI */
+    for (j = 0; j < d; j++) {
+      double s = 0.0;
+      for (k = 0; k < d; k++) s += RI[k * d + i] * RI[k * d + j];
+      M[i * d + j] = s;
+    }
+  rc = orc_dense_cholesky(d, M);
+  if (!rc) {
+    for (j = 0; j < d; j++) { /* explicit inverse, column by column */
+      for (i = 0; i < d; i++) e[i] = (i == j) ? 1.0 : 0.0;
+      orc_dense_chol_solve(d, M, e, c);
+      for (i = 0; i < d; i++) Minv[i * d + j] = c[i];
+    }
+    for (i = 0; i < d; i++) /* RI_invRItRI = RI * invRItRI */
+      for (j = 0; j < d; j++) {
+        double s = 0.0;
+        for (k = 0; k < d; k++) s += RI[i * d + k] * Minv[k * d + j];
+        T[i * d + j] = s;
+      }
+    for (i = 0; i < d; i++) /* Q = RI_invRItRI * RIt */
+      for (j = 0; j < d; j++) {
+        double s = 0.0;
+        for (k = 0; k < d; k++) s += T[i * d + k] * RI[j * d + k];
+        keep[i * d + j] = fabs(s) > 10.0 * ORC_EPS;
+        Q[i * d + j]    = keep[i * d + j] ? s : 0.0;
+      }
+  }
+  free(RI), free(M), free(Minv), free(T), free(e), free(c);
+  return rc;
+}
+
+/* MatRegularize :198-287, MAT_REG_EXPLICIT: Kreg_loc = K_loc + rho * (rho * Q_loc) -- MatScale(Q_loc,rho) followed by
+   MatAXPY(Kreg_loc,rho,Q_loc,DIFFERENT_NONZERO_PATTERN): the regulariser is scaled by rho TWICE (:256,265; kept).
+   rho is the caller's MatGetMaxEigenvalue(K_loc,NULL,&rho,1,20) (:254).  Output CSR = union pattern, sorted columns;
+   arrays sized nnz(K) + d*d.  Returns the number of stored entries, or -1 if RI'RI is not positive definite. */
+int orc_regularize_csr(const orc_csr *K, int d, const double *R, double rho, int *pivots, int *rowptr_out, int *col_out, double *val_out)
+{
+  int     n = K->nrows, i, j, k, nnz = 0;
+  double *Q    = (double *)malloc(sizeof(double) * (size_t)(d * d + 1));
+  int    *keep = (int *)malloc(sizeof(int) * (size_t)(d * d + 1));
+  int    *prow = (int *)malloc(sizeof(int) * (size_t)(n + 1)); /* row -> index in pivots or -1 */
+  for (i = 0; i < n; i++) prow[i] = -1;
+  if (d > 0) {
+    orc_regularize_pivots(n, d, R, pivots);
+    if (orc_regularization_Q(n, d, R, pivots, Q, keep)) {
+      free(Q), free(keep), free(prow);
+      return -1;
+    }
+    for (i = 0; i < d; i++) prow[pivots[i]] = i;
+  }
+  rowptr_out[0] = 0;
+  for (i = 0; i < n; i++) {
+    int a = K->rowptr[i], b = K->rowptr[i + 1], pi = prow[i];
+    j = 0; /* merge the sorted row of K with the (sorted) pivot columns of row pi of Q */
+    for (k = a; k < b || (pi >= 0 && j < d);) {
+      int cq = (pi >= 0 && j < d) ? pivots[j] : 0x7fffffff;
+      int ck = (k < b) ? K->col[k] : 0x7fffffff;
+      if (pi >= 0 && j < d && !keep[pi * d + j]) {
+        j++;
+        continue;
+      }
+      if (ck < cq) {
+        col_out[nnz] = ck, val_out[nnz] = K->val[k], k++;
+      } else if (ck == cq) {
+        col_out[nnz] = ck, val_out[nnz] = K->val[k] + rho * (Q[pi * d + j] * rho), k++, j++;
+      } else {
+        col_out[nnz] = cq, val_out[nnz] = rho * (Q[pi * d + j] * rho), j++;
+      }
+      nnz++;
+    }
+    rowptr_out[i + 1] = nnz;
+  }
+  free(Q), free(keep), free(prow);
+  return nnz;
 }

@@ -267,6 +267,11 @@ typedef struct {
 void orc_feti_dual_mult(void *ctx, const double *x, double *y);     /* y = F x */
 void orc_feti_penalized_mult(void *ctx, const double *x, double *y); /* y = P F P x + rho Q x */
 
+/* MatRegularize (src/mat/interface/permonmatregularize.c): fixing-DOF regularisation of a singular block, see the .c file */
+void orc_regularize_pivots(int p, int d, const double *R /* p x d column-major */, int *pivots /* d, ascending */);
+int  orc_regularization_Q(int p, int d, const double *R, const int *pivots, double *Q /* d x d */, int *keep /* d x d */);
+int  orc_regularize_csr(const orc_csr *K, int d, const double *R, double rho, int *pivots, int *rowptr_out, int *col_out, double *val_out);
+
 /* unfused reference-order CG step timing helper for the CPU baseline: runs `iters` MPGP iterations
    without convergence test on a fixed problem; returns elapsed seconds */
 double orc_now(void);

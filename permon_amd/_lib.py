@@ -160,6 +160,9 @@ _PROTOS = {
     "pmh_matinv_set_nullspace": [vp, C.c_int, vp],
     "pmh_matinv_mult": [vp, vp, vp],
     "pmh_matinv_last_iterations": [vp, c_int_p, C.POINTER(C.c_longlong)],
+    "pmh_mat_regularize_pivots": [C.c_int, C.c_int, vp, vp],
+    "pmh_mat_regularization_Q": [C.c_int, C.c_int, vp, vp, vp, vp],
+    "pmh_mat_regularize_csr": [C.c_int, vp, vp, vp, C.c_int, vp, C.c_double, vp, vp, vp, vp, C.POINTER(C.c_longlong)],
     "pmh_op_create_feti_dual": [vp, vp, C.POINTER(vp)],
     "pmh_pc_dual_lumped_apply": [vp, vp, vp, vp],
     "pmh_op_create_svm_dual": [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],

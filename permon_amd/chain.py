@@ -5,21 +5,58 @@ here (a handful of operator applications); the iteration itself is pmh_smalxe_so
 import numpy as np
 
 from .core import Vec
-from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatGluing, MatInv, PCDualLumpedOp
+from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatGluing, MatInv, MatRegularize, PCDualLumpedOp
 from .qps import QP, QPS
+
+
+def regularize_blocks(ctx, local):
+    """MatRegularize on a MATBLOCKDIAG (permonmatregularize.c:241-266 works on the rank's diagonal block; with several
+    subdomains per GPU every block is treated as its own 'rank'): returns (blockdiag(K_reg,i) as scipy CSR, pivots per
+    block, rho per block).  Congruent blocks (same K_i and R_i objects' values) are regularised once."""
+    import scipy.sparse as sp
+
+    rs = np.asarray(local["block_rowstart"])
+    K = local["K"].tocsr()
+    R = np.asarray(local["R"]) if local.get("R") is not None else np.zeros((0, K.shape[0]))
+    blocks, pivots, rhos, cache = [], [], [], []
+    for b in range(len(rs) - 1):
+        lo, hi = int(rs[b]), int(rs[b + 1])
+        Kb = K[lo:hi, lo:hi].tocsr()
+        Rb = R[:, lo:hi]
+        Rb = Rb[np.any(Rb != 0.0, axis=1)]  # a block without kernel has zero columns in R (d_loc = 0)
+        hit = None
+        for (Kc, Rc, out) in cache:
+            if Kc.shape == Kb.shape and Kc.nnz == Kb.nnz and Rc.shape == Rb.shape and np.array_equal(Kc.indices, Kb.indices) and np.array_equal(Kc.data, Kb.data) and np.array_equal(Rc, Rb):
+                hit = out
+                break
+        if hit is None:
+            hit = MatRegularize(ctx, Kb, Rb)
+            cache.append((Kb, Rb, hit))
+        blocks.append(hit[0]), pivots.append(hit[1]), rhos.append(hit[2])
+    return sp.block_diag(blocks, format="csr"), pivots, rhos
 
 
 class FetiDualQP:
     """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
 
-    def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False):
+    def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False,
+                 regularize=False):
         """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
-        lb: dual lower bound (-inf on equality rows, 0 on inequality rows)."""
+        lb: dual lower bound (-inf on equality rows, 0 on inequality rows).
+        regularize: the reference's default (-regularize 1, QPTDualize -> MatInvSetRegularizationType(MAT_REG_EXPLICIT),
+        qptransform.c:1012): MATINV works on K_reg = MatRegularize(K, R) and K^+ = K_reg^{-1} without projections;
+        False: -regularize 0 with the Moore-Penrose wrapping P_R K^- P_R (-qpt_dualize_Kplus_mp, qptransform.c:1020-1062).
+        With regularize=True a multigrid hierarchy, if given, must have been built on the regularised blocks."""
         self.ctx = ctx
         nl = local["n_lambda"]
         self.n_lambda = nl
         self.K = MatBlockDiag.from_scipy(ctx, local["block_rowstart"], local["K"])
-        self.Kplus = MatInv(self.K, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=local["R"])
+        if regularize:
+            Kreg = local["Kreg"] if "Kreg" in local else regularize_blocks(ctx, local)[0]
+            self.Kreg = MatBlockDiag.from_scipy(ctx, local["block_rowstart"], Kreg)
+            self.Kplus = MatInv(self.Kreg, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=None)
+        else:
+            self.Kplus = MatInv(self.K, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=local["R"])
         if bsr3:  # K x of the inner CG on the 3x3-block kernel (BAIJ bs=3)
             self.Kplus.enable_bsr3()
         if mg_hierarchy is not None:  # -mat_inv_pc_type mg: V-cycle PC for the inner CG (feti.box_mg_hierarchy)

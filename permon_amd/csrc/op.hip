@@ -78,15 +78,22 @@ extern "C" int pmh_op_max_eigenvalue(pmh_op op, double tol, int maxits, double *
   PMH_CHK(pmh_vec_set(ctx, n, v, 1.0));
   double lambda = 0.0, lambda0, vAv, vv;
   int    i, rc = PMH_SUCCESS;
+  bool   seeded = false;
   for (i = 1; i <= maxits; i++) {
     lambda0 = lambda;
     if ((rc = op->mult(v, Av))) break;
     if ((rc = pmh_vec_dot(ctx, n, v, Av, &vAv))) break;
     if ((rc = pmh_vec_dot(ctx, n, v, v, &vv))) break;
     lambda = vAv / vv;
-    if (lambda < 2.220446049250313e-16) { // permonmatutils.c:491: null-space hit; the RAND48 restart is not restated
-      rc = pmh_set_error(PMH_ERR_SUP, "pmh_op_max_eigenvalue: hit the null space of A (lambda=%g) at iteration %d", lambda, i);
-      break;
+    if (lambda < 2.220446049250313e-16) {
+      // permonmatutils.c:491-499: v hit the null space of A (e.g. v = 1 and a floating elasticity block): A v is replaced by a
+      // random vector and only v'Av is recomputed -- lambda keeps its value in this iteration.  PETSc's RAND48 stream:
+      // PetscRandomCreate seeds 0x12345678 (+ 76543 rank), srand48(seed), one drand48() per entry in index order.
+      if (!seeded) srand48(0x12345678L), seeded = true;
+      std::vector<double> h((size_t)n);
+      for (int k = 0; k < n; k++) h[k] = drand48();
+      if ((rc = pmh_memcpy_h2d(ctx, Av, h.data(), sizeof(double) * (size_t)n))) break;
+      if ((rc = pmh_vec_dot(ctx, n, v, Av, &vAv))) break;
     }
     double err = fabs(lambda - lambda0), relerr = err / fabs(lambda);
     if (relerr < tol) break;

@@ -70,6 +70,10 @@ struct pmh_csr_s {
   double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue
   int       n_launch_blocks;
   pmh_csr   transpose;     // built lazily for mult_transpose
+  // very long rows (G of the coarse problem: a few dozen rows of ~10^4 non-zeros): rows split into chunks, see spmv.hip
+  int      *d_lchunks, *d_lrow; // [3*l_nchunks] (row, k0, k1) and [nrows+1] first chunk of each row
+  double   *d_lpart;            // [l_nchunks] chunk sums
+  int       l_nchunks;
   // optional per-launch timing (HIP event pairs recorded on the launch stream)
   std::vector<hipEvent_t> *ev;
   std::vector<int>        *ev_kind;

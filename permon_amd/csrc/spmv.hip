@@ -243,6 +243,43 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, 
   epi_finish<EPI>(acc0, acc1, amin, red, part, ld, b);
 }
 
+// Very long rows (G = R'B' of the FETI coarse problem: 6 rows per subdomain, ~10^4 non-zeros each; QPPFApplyQ/P/GtG and the
+// ||G u|| of the SMALXE convergence test apply it ~5 times per MPGP step).  One workgroup per row leaves 48 workgroups
+// striding 25 000 non-zeros each (182 us measured); here every row is cut into chunks of PMH_LONG_CHUNK non-zeros, one
+// workgroup per chunk (fixed-tree block reduction), and a second small kernel adds the chunk sums of a row in chunk order
+// and applies the epilogue -- deterministic, ~2 x 5 us.
+#define PMH_LONG_CHUNK 4096
+__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_part(const int *__restrict__ chunks, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, const int *__restrict__ halt, double *__restrict__ part)
+{
+  __shared__ double red[PMH_BLOCK / 64];
+  if (halt && *halt) return;
+  const int k0 = chunks[3 * blockIdx.x + 1], k1 = chunks[3 * blockIdx.x + 2];
+  double    s[4] = {0.0, 0.0, 0.0, 0.0};
+  int       k    = k0 + (int)threadIdx.x;
+  for (; k + 3 * PMH_BLOCK < k1; k += 4 * PMH_BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) s[j] += __builtin_nontemporal_load(&val[k + j * PMH_BLOCK]) * x[__builtin_nontemporal_load(&col[k + j * PMH_BLOCK])];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) { // at most three strides are left
+    const int kk = k + j * PMH_BLOCK;
+    if (kk < k1) s[j] += val[kk] * x[col[kk]];
+  }
+  const double t = pmh_block_reduce<PMH_RED_SUM>((s[0] + s[1]) + (s[2] + s[3]), red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_fin(int nrows, const int *__restrict__ lrow, const double *__restrict__ part, const double *__restrict__ x, double *__restrict__ y, EpiArgs a)
+{
+  if (a.halt && *a.halt) return;
+  const int r = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (r >= nrows) return;
+  double sum = 0.0, d0 = 0.0, d1 = 0.0, dm = 0.0;
+  for (int c = lrow[r]; c < lrow[r + 1]; c++) sum += part[c];
+  epi_row<EPI>(r, sum, x, y, a, d0, d1, dm);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int build_rowblocks(int nrows, const int *rowptr, int nnzb, std::vector<int> &rb)
 {
@@ -321,6 +358,23 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
     A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
   }
   PMH_HIP(hipMalloc((void **)&A->d_blockpart, sizeof(double) * 3 * (size_t)(A->n_launch_blocks ? A->n_launch_blocks : 8)));
+  if (avg > 1024.0 && !getenv("PMH_SPMV_NO_LONG")) { // chunk table of the long-row kernels (plain / ADD / SUB epilogues)
+    std::vector<int> ch, lrow((size_t)nrows + 1, 0);
+    for (int r = 0; r < nrows; r++) {
+      for (int k = rowptr[r]; k < rowptr[r + 1]; k += PMH_LONG_CHUNK) {
+        ch.push_back(r), ch.push_back(k), ch.push_back(std::min(k + PMH_LONG_CHUNK, rowptr[r + 1]));
+      }
+      lrow[r + 1] = (int)(ch.size() / 3);
+    }
+    A->l_nchunks = (int)(ch.size() / 3);
+    if (A->l_nchunks) {
+      PMH_HIP(hipMalloc((void **)&A->d_lchunks, sizeof(int) * ch.size()));
+      PMH_HIP(hipMalloc((void **)&A->d_lrow, sizeof(int) * lrow.size()));
+      PMH_HIP(hipMalloc((void **)&A->d_lpart, sizeof(double) * (size_t)A->l_nchunks));
+      PMH_CHK(pmh_memcpy_h2d(ctx, A->d_lchunks, ch.data(), sizeof(int) * ch.size()));
+      PMH_CHK(pmh_memcpy_h2d(ctx, A->d_lrow, lrow.data(), sizeof(int) * lrow.size()));
+    }
+  }
   *out = A;
   return PMH_SUCCESS;
 }
@@ -336,6 +390,9 @@ extern "C" int pmh_csr_destroy(pmh_csr A)
   hipFree(A->d_val);
   hipFree(A->d_rowblocks);
   hipFree(A->d_blockpart);
+  if (A->d_lchunks) hipFree(A->d_lchunks);
+  if (A->d_lrow) hipFree(A->d_lrow);
+  if (A->d_lpart) hipFree(A->d_lpart);
   delete A;
   return PMH_SUCCESS;
 }
@@ -362,6 +419,12 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   pmh_ctx   ctx = A->ctx;
   const int nl  = A->n_launch_blocks;
   if (A->nrows == 0) return PMH_SUCCESS;
+  if (A->l_nchunks && EPI != PMH_EPI_MPGP) {
+    hipLaunchKernelGGL(k_spmv_long_part, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_long_fin<EPI>), dim3((A->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, x, y, a);
+    PMH_HIP(hipGetLastError());
+    return PMH_SUCCESS;
+  }
   if (A->kind == PMH_SPMV_STREAM) {
 #define ST_LAUNCH(NNZB, MODE, NT) \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, ((NT)&2) != 0, RLV>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl)

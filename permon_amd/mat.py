@@ -84,6 +84,37 @@ class MatBlockDiag:
             self.h = None
 
 
+def MatRegularize(ctx, K, R, rho=None):
+    """MatRegularize(K, R, MAT_REG_EXPLICIT) for ONE sequential block (src/mat/interface/permonmatregularize.c:198-287):
+    K scipy CSR (p x p), R (d, p) array whose rows span the kernel of K.  Returns (K_reg as scipy CSR, pivots, rho):
+    K_reg = K + rho^2 Q with Q the filtered RI (RI'RI)^{-1} RI' on the d fixing DOFs picked by the reference's pivot
+    search; rho = MatGetMaxEigenvalue(K, NULL, &rho, 1, 20) on the device unless given."""
+    import scipy.sparse as sp
+
+    K = K.tocsr()
+    K.sort_indices()
+    p = K.shape[0]
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(-1, p) if np.size(R) else np.zeros((0, p))
+    d = R.shape[0]
+    if rho is None:
+        Kd = CsrMat(ctx, p, p, K.indptr, K.indices, K.data)
+        op = Op.from_csr(Kd)
+        rho, _ = op.max_eigenvalue(tol=1.0, maxits=20)
+        op.destroy()
+        Kd.destroy()
+    rp = np.zeros(p + 1, dtype=np.int32)
+    ci = np.zeros(K.nnz + d * d, dtype=np.int32)
+    va = np.zeros(K.nnz + d * d)
+    piv = np.zeros(max(d, 1), dtype=np.int32)
+    nnz = C.c_longlong()
+    ip, cp, vp_ = (np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64))
+    check(ctx.L.pmh_mat_regularize_csr(p, ip.ctypes.data_as(C.c_void_p), cp.ctypes.data_as(C.c_void_p), vp_.ctypes.data_as(C.c_void_p), d,
+                                       R.ctypes.data_as(C.c_void_p) if d else None, float(rho), piv.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p),
+                                       ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(nnz)))
+    Kreg = sp.csr_matrix((va[:nnz.value], ci[:nnz.value], rp), shape=(p, p))
+    return Kreg, piv[:d].copy(), float(rho)
+
+
 class MatInv:
     """MATINV apply (src/mat/impls/inv/matinv.c:734-743) on the iterative per-block KSPCG path."""
 

@@ -188,3 +188,37 @@ def test_full_size_config1_properties(ctx):
     assert res[False][0] == res[True][0]
     assert np.allclose(res[False][1], res[True][1], rtol=1e-9)
     assert np.linalg.norm(res[False][2] - res[True][2]) <= 1e-9 * np.linalg.norm(res[True][2])
+
+
+def test_very_long_rows_chunked_kernel(ctx, oracle, monkeypatch):
+    """G = R'B' of the coarse problem: a few dozen rows of ~10^4 non-zeros (avg > 1024 per row) run on the chunked long-row
+    kernels (k_spmv_long_part / _fin); ragged lengths incl. an empty row, a row of exactly one chunk and one of a chunk + 1."""
+    rng = np.random.default_rng(77)
+    ncols = 60000
+    lens = [25000, 0, 4096, 4097, 1, 31000, 8191, 12288, 20000, 17]
+    rows = []
+    for m in lens:
+        c = np.sort(rng.choice(ncols, m, replace=False))
+        rows.append((c, rng.standard_normal(m)))
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([r[0] for r in rows]).astype(np.int32)
+    val = np.concatenate([r[1] for r in rows])
+    A = pa.CsrMat(ctx, len(lens), ncols, rowptr, col, val)
+    x, y1 = rng.standard_normal(ncols), rng.standard_normal(len(lens))
+    ref = oracle.spmv(oracle.Csr(len(lens), ncols, rowptr, col, val), x)
+    yd = ctx.vec(len(lens))
+    A.mult(ctx.vec_from(x), yd)
+    scale = np.abs(ref).max()
+    assert np.abs(yd.to_numpy() - ref).max() <= 1e-13 * scale * 200  # ~sqrt(n) rounding of a 30 000-term sum in another order
+    assert yd.to_numpy()[1] == 0.0
+    A.mult_add(ctx.vec_from(x), ctx.vec_from(y1), yd)
+    assert np.abs(yd.to_numpy() - (y1 + ref)).max() <= 1e-13 * scale * 200
+    # deterministic: two launches give identical bits; and the pre-existing one-workgroup-per-row path agrees
+    y2 = ctx.vec(len(lens))
+    A.mult(ctx.vec_from(x), y2)
+    A.mult(ctx.vec_from(x), yd)
+    assert np.array_equal(y2.to_numpy(), yd.to_numpy())
+    monkeypatch.setenv("PMH_SPMV_NO_LONG", "1")
+    A0 = pa.CsrMat(ctx, len(lens), ncols, rowptr, col, val)
+    A0.mult(ctx.vec_from(x), y2)
+    assert np.abs(y2.to_numpy() - yd.to_numpy()).max() <= 1e-13 * scale * 200
