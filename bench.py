@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
     ap.add_argument("--mg-precision", choices=["fp16", "fp32", "fp64"], default="fp16", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
     ap.add_argument("--mg-degree", type=int, default=2, help="feti: Chebyshev degree of the V-cycle smoother")
+    ap.add_argument("--regularize", action="store_true", help="feti: K^+ = K_reg^{-1} with K_reg = MatRegularize(K, R) (the reference's default, -regularize 1) instead of the Moore-Penrose wrapping "
+                    "P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp); identical on the projected dual problem, the V-cycle hierarchy is then built per block on K_reg")
     ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
@@ -314,10 +316,17 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     t_gen = time.time() - t0
     t0 = time.time()
     hier = None
+    blocks = [f.Ki] * per
+    if a.regularize:  # MatRegularize per block (the kernel bases, hence the fixing DOFs, differ from block to block)
+        from permon_amd.chain import regularize_blocks
+
+        local["Kreg"] = regularize_blocks(ctx, local)[0]
+        blocks = [local["Kreg"][i * f.n_i:(i + 1) * f.n_i, i * f.n_i:(i + 1) * f.n_i].tocsr() for i in range(per)]
     if a.kplus_pc == "mg":  # Galerkin hierarchy of the congruent cubes (host set-up, seconds)
         nn = a.nel + 1
-        hier = pa.box_mg_hierarchy([f.Ki] * per, [(nn, nn, nn)] * per, 3)
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3)
+        hier = pa.box_mg_hierarchy(blocks, [(nn, nn, nn)] * per, 3)
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
+                   regularize=a.regularize)
     qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
     t_setup = time.time() - t0
     Kcsr = q.K.K
@@ -366,12 +375,13 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
     ms_all = ms_k + (ms_cg if hier is not None else 0.0)
     achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+    kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
     pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
-                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+ (rtol %.0e)"
-                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, pc_text, a.kplus_rtol),
+                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+%s (rtol %.0e)"
+                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, pc_text, kreg_text, a.kplus_rtol),
         "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},

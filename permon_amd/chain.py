@@ -9,10 +9,13 @@ from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatG
 from .qps import QP, QPS
 
 
-def regularize_blocks(ctx, local):
+def regularize_blocks(ctx, local, rho=None):
     """MatRegularize on a MATBLOCKDIAG (permonmatregularize.c:241-266 works on the rank's diagonal block; with several
     subdomains per GPU every block is treated as its own 'rank'): returns (blockdiag(K_reg,i) as scipy CSR, pivots per
-    block, rho per block).  Congruent blocks (same K_i and R_i objects' values) are regularised once."""
+    block, rho per block).  Congruent blocks (same K_i and R_i objects' values) are regularised once.
+    rho: None = MatGetMaxEigenvalue(K_loc, NULL, &rho, 1, 20) per block as the reference does (:254; it stops after 2 or 3
+    power iterations from a RAND48 restart depending on the SIGN of a rounding-noise Rayleigh quotient, so it is not
+    reproducible to more than its order of magnitude), or a given positive value for every block."""
     import scipy.sparse as sp
 
     rs = np.asarray(local["block_rowstart"])
@@ -30,7 +33,7 @@ def regularize_blocks(ctx, local):
                 hit = out
                 break
         if hit is None:
-            hit = MatRegularize(ctx, Kb, Rb)
+            hit = MatRegularize(ctx, Kb, Rb, rho=rho)
             cache.append((Kb, Rb, hit))
         blocks.append(hit[0]), pivots.append(hit[1]), rhos.append(hit[2])
     return sp.block_diag(blocks, format="csr"), pivots, rhos
