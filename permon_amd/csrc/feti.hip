@@ -338,8 +338,11 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_seg_dot(const int *__restrict__ r
 
 // alpha_b = rz_b / (p'Ap)_b (every workgroup re-sums its block's partials in the same fixed order);
 // u += alpha_b p; r -= alpha_b Ap; z = Dinv r; partials r.z, r.r
-__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int nb, int wgs, int q, int extpc, const int *__restrict__ done, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, int ld)
+__global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restrict__ rs, int nb, int wgs, int q, int extpc, const int *__restrict__ done, const double *__restrict__ bs, const int *__restrict__ bi, const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, int ld,
+                                                          const float *__restrict__ mg_dinv, float mg_itheta, float *__restrict__ mg_d0, float *__restrict__ mg_b32)
 {
+  // mg_dinv != NULL: the V-cycle that follows starts from d0 = D^-1 r / theta and the fp32 copy of r (k_cheb_d0 of mg.hip):
+  // both are written here, where r is produced (one launch less per CG iteration)
   __shared__ double lds[PMH_BLOCK / 64];
   if (*done) return;
   const int bb = blockIdx.x / wgs;
@@ -356,6 +359,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_ur(const int *__restric
       const double zi = dinv[i] * ri;
       z[i] = zi;
       s0 += ri * zi;
+    } else if (mg_dinv) {
+      const float rf = (float)ri;
+      mg_b32[i] = rf;
+      mg_d0[i]  = mg_dinv[i] * rf * mg_itheta;
     }
     s1 += ri * ri;
   }
@@ -567,6 +574,9 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   memset(&epi, 0, sizeof(epi));
   epi.kind = PMH_EPI_NONE;
   epi.halt = M->d_done; // once every block has converged the remaining enqueued launches return at once
+  const float *mg_dinv = nullptr;
+  float        mg_itheta = 0.f, *mg_d0 = nullptr, *mg_b32 = nullptr;
+  const bool   d0_fused = extpc && !getenv("PMH_MG_NO_D0_FUSION") && pmh_mg_fine_d0_slots(M->mg, &mg_dinv, &mg_itheta, &mg_d0, &mg_b32);
   int it = 0, next_check = (M->last_max_its > 8) ? (M->last_max_its - 2) : 4;
   if (extpc) next_check = (M->last_max_its > 2) ? (M->last_max_its - 1) : 1; // few, expensive iterations: do not overshoot
   while (it < M->max_it) {
@@ -578,9 +588,10 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     }
     M->total_spmv++;
     hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->p, (const double *)M->Ap, M->d_part);
-    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, extpc, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld);
+    hipLaunchKernelGGL(k_cg_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, extpc, (const int *)M->d_done, (const double *)M->d_bs, (const int *)M->d_bi, (const double *)M->d_part, (const double *)M->dinv, (const double *)M->p, (const double *)M->Ap, u, M->r, M->z, M->d_partB, ld,
+                       mg_dinv, mg_itheta, mg_d0, mg_b32);
     if (extpc) { // z = V(r) over all blocks (converged blocks ignore it), then the per-block r.z
-      PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, M->d_done));
+      PMH_CHK(pmh_mg_apply_halt(M->mg, M->r, M->z, M->d_done, d0_fused));
       hipLaunchKernelGGL(k_seg_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, (const int *)M->d_done, (const int *)M->d_bi, (const double *)M->r, (const double *)M->z, M->d_partB);
     }
     hipLaunchKernelGGL(k_cg_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, nb, wgs, q, it, M->max_it, M->d_bs, M->d_bi, M->d_nactive, M->d_done, (const double *)M->d_partB, ld, (const double *)M->z, M->p);

@@ -28,7 +28,9 @@ struct pmh_mg_s {
   int                   nb_coarse;
   int                  *d_crs;   // coarse block row starts [nb_coarse+1]
   long long            *d_cofs;  // offsets of the dense blocks [nb_coarse]
-  void                 *d_cpinv; // concatenated dense pseudo-inverses, row-major, cycle precision
+  void                 *d_cpinv; // concatenated dense pseudo-inverses, row-major, cycle precision (fp16 entries / cp_scale with PMH_MG_FP16)
+  int                   cp_half;
+  double                cp_scale;
   const int            *halt;
   long long             fine_spmv; // fine-level SpMVs issued (statistics)
   // the cycle is a fixed launch sequence: it is captured once per (b, x, halt) triple into a hipGraph and replayed
@@ -36,6 +38,7 @@ struct pmh_mg_s {
     const double   *b;
     double         *x;
     const int      *halt;
+    bool            d0_ready;
     hipGraphExec_t  exec;
     long long       fine_spmv;
   };
@@ -107,9 +110,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_step(int n, const int *__res
   }
 }
 
-// restriction b_c = R t with R = P' as CSR (<= 27 entries per row): 8 lanes per coarse row, shuffle-tree sum (fixed order)
+// restriction b_c = R t with R = P' as CSR (<= 27 entries per row): 8 lanes per coarse row, shuffle-tree sum (fixed order).
+// dinv_c != NULL: the first smoothing direction of the coarse level, d_c = D_c^-1 b_c / theta_c, is written on the way
+// (saves the k_cheb_d0 launch of every smoothed coarse level: these levels are launch-latency bound).
 template <typename TV>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
+                                                         const TV *__restrict__ dinv_c, TV itheta_c, TV *__restrict__ d_c)
 {
   if (halt && *halt) return;
   const int lane = threadIdx.x & 7;
@@ -121,7 +127,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__
     s += __shfl_down(s, 4, 8);
     s += __shfl_down(s, 2, 8);
     s += __shfl_down(s, 1, 8);
-    if (i < nc && lane == 0) bc[i] = s;
+    if (i < nc && lane == 0) {
+      bc[i] = s;
+      if (dinv_c) d_c[i] = dinv_c[i] * s * itheta_c;
+    }
   }
 }
 
@@ -137,9 +146,11 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *
   }
 }
 
-// coarsest level: x_b = pinv_b b_b, one wavefront per row, lanes stride the row of the dense block (fixed order)
-template <typename TV>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const TV *__restrict__ pinv, const TV *__restrict__ b, TV *__restrict__ x)
+// coarsest level: x_b = pinv_b b_b, one wavefront per row, lanes stride the row of the dense block (fixed order).
+// TP = storage type of the pseudo-inverse: TV, or _Float16 (PMH_MG_FP16: entries / scale, fp32 arithmetic) -- with one or two
+// blocks per GPU the hierarchy stops at a ~5000-dof level whose dense solve is a pure HBM stream (2 B per entry).
+template <typename TV, typename TP>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const TP *__restrict__ pinv, TV scale, const TV *__restrict__ b, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   const int lane = threadIdx.x & 63;
@@ -152,12 +163,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_coarse(int nb, int n, const in
     else hi = mid;
   }
   const int r0 = rs[lo], m = rs[lo + 1] - r0;
-  const TV *a  = pinv + ofs[lo] + (size_t)(row - r0) * m;
-  TV        s  = (TV)0;
-  for (int j = lane; j < m; j += 64) s += a[j] * b[r0 + j];
+  const TP *a  = pinv + ofs[lo] + (size_t)(row - r0) * m;
+  const TV *bb = b + r0;
+  TV        s0 = (TV)0, s1 = (TV)0, s2 = (TV)0, s3 = (TV)0;
+  int       j  = lane;
+  for (; j + 192 < m; j += 256) { // four independent streams per lane
+    s0 += (TV)__builtin_nontemporal_load(&a[j]) * bb[j];
+    s1 += (TV)__builtin_nontemporal_load(&a[j + 64]) * bb[j + 64];
+    s2 += (TV)__builtin_nontemporal_load(&a[j + 128]) * bb[j + 128];
+    s3 += (TV)__builtin_nontemporal_load(&a[j + 192]) * bb[j + 192];
+  }
+  for (; j < m; j += 64) s0 += (TV)a[j] * bb[j];
+  TV s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-  if (lane == 0) x[row] = s;
+  if (lane == 0) x[row] = (sizeof(TP) == 2) ? s * scale : s;
 }
 
 template <typename TA, typename TB>
@@ -217,14 +237,17 @@ template <typename TV> static int bsr_epi_launch(pmh_bsr3 B, const TV *x, TV *y,
 template <> int bsr_epi_launch<double>(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt) { return pmh_bsr3_spmv_epi_f64(B, x, y, epi, e, halt); }
 template <> int bsr_epi_launch<float>(pmh_bsr3 B, const float *x, float *y, int epi, const pmh_bsr3_epi<float> &e, const int *halt) { return pmh_bsr3_spmv_epi_f32(B, x, y, epi, e, halt); }
 
-template <typename TV> static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64 = nullptr, double *z64 = nullptr);
+template <typename TV> static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64 = nullptr, double *z64 = nullptr, bool d0_ready = false);
+
+// does level l run mg_level_fused (its first smoothing direction can then be produced by the kernel that makes its b)?
+static inline bool mg_fused_level(pmh_mg mg, int l) { return l < mg->nlevels - 1 && mg->fused && mg->L[l].Ab; }
 
 // One smoothed level with the degree-2 Chebyshev steps finished inside the operator kernel (7 launches instead of 10):
 //   d0 = D^-1 b/theta | xa = (1+c1) d0 + c2 D^-1 (b - A d0) | t = A xa - b | b_c = P't | ... | xa -= P x_c |
 //   r, d, x = xa + d from A xa | x += c1 d + c2 (r - D^-1 A d)
 // b64 / z64: fp64 input / output of the fp32 cycle's fine level (the conversions ride on the first and last kernel).
 template <typename TV>
-static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64)
+static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64, bool d0_ready)
 {
   mg_level   &Lv = mg->L[l], &Lc = mg->L[l + 1];
   hipStream_t st = mg->ctx->stream;
@@ -232,7 +255,8 @@ static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b6
   TV         *r = (TV *)Lv.r, *d = (TV *)Lv.d, *t = (TV *)Lv.t, *xa = (TV *)Lv.xa;
   const TV   *dinv = (const TV *)Lv.dinv;
   const TV    itheta = (TV)(1.0 / Lv.theta), c1 = (TV)Lv.c1[1], c2 = (TV)Lv.c2[1];
-  if (b64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_d0<TV, double>), g, blk, 0, st, Lv.n, mg->halt, dinv, b64, itheta, d, (TV *)b);
+  if (d0_ready) { // d (and the cycle-precision copy of b) were written by the producer of b
+  } else if (b64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_d0<TV, double>), g, blk, 0, st, Lv.n, mg->halt, dinv, b64, itheta, d, (TV *)b);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cheb_d0<TV, TV>), g, blk, 0, st, Lv.n, mg->halt, dinv, b, itheta, d, (TV *)nullptr);
   pmh_bsr3_epi<TV> e;
   memset(&e, 0, sizeof(e));
@@ -241,9 +265,11 @@ static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b6
   if (l == 0) mg->fine_spmv += 4;
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, d, xa, PMH_BSR_EPI_PRE, e, mg->halt));
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, t, PMH_EPI_SUB, e, mg->halt));
-  pmh_csr R = Lv.P->transpose;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)t, (TV *)Lc.b);
-  PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
+  pmh_csr    R  = Lv.P->transpose;
+  const bool cf = mg_fused_level(mg, l + 1); // the coarse level's d0 rides on the restriction
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)t, (TV *)Lc.b,
+                     cf ? (const TV *)Lc.dinv : (const TV *)nullptr, cf ? (TV)(1.0 / Lc.theta) : (TV)0, cf ? (TV *)Lc.d : (TV *)nullptr);
+  PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x, nullptr, nullptr, cf));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), g, blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
@@ -253,14 +279,15 @@ static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b6
 }
 
 template <typename TV>
-static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64)
+static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, double *z64, bool d0_ready)
 {
   mg_level   &Lv = mg->L[l];
   hipStream_t st = mg->ctx->stream;
   const dim3  blk(PMH_BLOCK);
-  if (l < mg->nlevels - 1 && mg->fused && Lv.Ab) return mg_level_fused<TV>(mg, l, b, x, b64, z64);
+  if (mg_fused_level(mg, l)) return mg_level_fused<TV>(mg, l, b, x, b64, z64, d0_ready);
   if (l == mg->nlevels - 1) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_coarse<TV>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const TV *)mg->d_cpinv, b, x);
+    if (mg->cp_half) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_coarse<TV, _Float16>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (TV)mg->cp_scale, b, x);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_coarse<TV, TV>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, mg->halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const TV *)mg->d_cpinv, (TV)1, b, x);
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
@@ -269,35 +296,46 @@ static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, dou
   // t = A x - b; b_{l+1} = P' t = -P'(b - A x); the coarse solve is linear, so the sign is undone by subtracting P x_{l+1}
   PMH_CHK(mg_spmv(mg, l, x, Lv.t, PMH_EPI_SUB, b));
   pmh_csr R = Lv.P->transpose;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b,
+                     (const TV *)nullptr, (TV)0, (TV *)nullptr);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, x);
   PMH_HIP(hipGetLastError());
   return mg_smooth<TV>(mg, l, b, x, false);
 }
 
-static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt);
+static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready = false);
 
-int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt)
+// The caller's kernel that produces the residual b can write the fine level's first smoothing direction itself
+// (d0 = D^-1 b / theta in fp32, plus the fp32 copy of b): slots and constants for it; returns 0 if the cycle has no such slot.
+int pmh_mg_fine_d0_slots(pmh_mg mg, const float **dinv, float *itheta, float **d0, float **b32)
 {
-  if (!mg->use_graph || mg->timing_on) return mg_apply_body(mg, b, x, halt);
+  if (!(mg->is_float && mg->fused && mg->nlevels > 1 && mg_fused_level(mg, 0))) return 0;
+  mg_level &L0 = mg->L[0];
+  *dinv = (const float *)L0.dinv, *itheta = (float)(1.0 / L0.theta), *d0 = (float *)L0.d, *b32 = (float *)L0.b;
+  return 1;
+}
+
+int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready)
+{
+  if (!mg->use_graph || mg->timing_on) return mg_apply_body(mg, b, x, halt, d0_ready);
   hipStream_t st = mg->ctx->stream;
   for (auto &g : mg->graphs)
-    if (g.b == b && g.x == x && g.halt == halt) {
+    if (g.b == b && g.x == x && g.halt == halt && g.d0_ready == d0_ready) {
       PMH_HIP(hipGraphLaunch(g.exec, st));
       mg->fine_spmv += g.fine_spmv;
       return PMH_SUCCESS;
     }
-  if (mg->graphs.size() >= 8) return mg_apply_body(mg, b, x, halt); // callers with ever-changing vectors: plain launches
+  if (mg->graphs.size() >= 8) return mg_apply_body(mg, b, x, halt, d0_ready); // callers with ever-changing vectors: plain launches
   const long long f0 = mg->fine_spmv;
   hipGraph_t      graph;
   PMH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = mg_apply_body(mg, b, x, halt);
+  int rc = mg_apply_body(mg, b, x, halt, d0_ready);
   hipError_t e = hipStreamEndCapture(st, &graph);
   if (rc) return rc;
   if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_mg: stream capture of the V-cycle failed: %s", hipGetErrorString(e));
   pmh_mg_s::cached_graph g;
-  g.b = b, g.x = x, g.halt = halt, g.fine_spmv = mg->fine_spmv - f0;
+  g.b = b, g.x = x, g.halt = halt, g.d0_ready = d0_ready, g.fine_spmv = mg->fine_spmv - f0;
   PMH_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
   PMH_HIP(hipGraphDestroy(graph));
   mg->graphs.push_back(g);
@@ -305,13 +343,13 @@ int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt)
   return PMH_SUCCESS;
 }
 
-static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt)
+static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready)
 {
   mg->halt = halt;
   int rc;
   if (mg->is_float && mg->fused && mg->nlevels > 1) {
     mg_level &L0 = mg->L[0];
-    rc = mg_cycle<float>(mg, 0, (const float *)L0.b, (float *)L0.x, b, x); // conversions fused into the first / last kernel
+    rc = mg_cycle<float>(mg, 0, (const float *)L0.b, (float *)L0.x, b, x, d0_ready); // conversions fused into the first / last kernel
   } else if (mg->is_float) {
     mg_level   &L0 = mg->L[0];
     hipStream_t st = mg->ctx->stream;
@@ -353,9 +391,11 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   mg->halt      = nullptr;
   mg->fine_spmv = 0;
   mg->timing_on = 0;
-  // hipGraph replay of the cycle is opt-in: measured gain is nil at configs[2] size (the host runs far ahead of the GPU) and
-  // ~8 % on 10^3-element blocks, and rocprofv3's kernel tracing crashes on graph launches on this ROCm
-  mg->use_graph = 0;
+  // hipGraph replay of the cycle (rocprofv3's kernel tracing crashes on graph launches on this ROCm: profile with PMH_MG_GRAPH=0).
+  // Default: replay for small fine levels only.  With one or two subdomain blocks per GPU (the 8-GPU strong-scaling share) the
+  // ~15 launches of a cycle take ~5 us each and the host's launch rate, not the GPU, bounds the step (measured: 4.4 ms of
+  // kernels in a 5.6 ms step); at 8 blocks per GPU the host runs far ahead and replay gains nothing.
+  mg->use_graph = A[0]->nrows <= 600000;
   if (const char *e = getenv("PMH_MG_GRAPH")) mg->use_graph = atoi(e);
   mg->fused = (degree == 2);
   if (const char *e = getenv("PMH_MG_FUSED")) mg->fused = mg->fused && atoi(e); // testing knob: 0 = separate smoothing kernels
@@ -413,10 +453,23 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   }
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(nb_coarse + 1), (void **)&mg->d_crs));
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * (size_t)nb_coarse, (void **)&mg->d_cofs));
-  PMH_CHK(pmh_malloc(ctx, w * (size_t)(tot ? tot : 1), &mg->d_cpinv));
+  mg->cp_half  = (precision == PMH_MG_FP16 && nlevels > 1) ? 1 : 0;
+  mg->cp_scale = 1.0;
+  if (const char *e = getenv("PMH_MG_COARSE_HALF")) mg->cp_half = mg->cp_half && atoi(e); // testing knob
+  PMH_CHK(pmh_malloc(ctx, (mg->cp_half ? 2 : w) * (size_t)(tot ? tot : 1), &mg->d_cpinv));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_crs, coarse_rowstart, sizeof(int) * (size_t)(nb_coarse + 1)));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cofs, ofs.data(), sizeof(long long) * (size_t)nb_coarse));
-  if (fl) {
+  if (mg->cp_half) {
+    // power-of-two scale that brings the largest entry to [1, 2) (as the fp16 fine-level operator, bsr.hip)
+    double amax = 0.0;
+    for (long long i = 0; i < tot; i++) amax = std::max(amax, fabs(coarse_pinv_host[i]));
+    int ex = 0;
+    if (amax > 0.0) frexp(amax, &ex);
+    mg->cp_scale = ldexp(1.0, ex - 1);
+    std::vector<_Float16> ph((size_t)tot);
+    for (long long i = 0; i < tot; i++) ph[i] = (_Float16)(float)(coarse_pinv_host[i] / mg->cp_scale);
+    PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cpinv, ph.data(), sizeof(_Float16) * (size_t)tot));
+  } else if (fl) {
     std::vector<float> pf((size_t)tot);
     for (long long i = 0; i < tot; i++) pf[i] = (float)coarse_pinv_host[i];
     PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cpinv, pf.data(), sizeof(float) * (size_t)tot));

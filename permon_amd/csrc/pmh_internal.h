@@ -157,4 +157,5 @@ int    pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms);
 int    pmh_csr_ensure_transpose(pmh_csr A); // builds A->transpose if missing
 
 // ---- multigrid preconditioner (mg.hip) -------------------------------------------------------------------------
-int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt); // halt: device flag turning the launches into no-ops
+int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready = false); // halt: device flag turning the launches into no-ops
+int pmh_mg_fine_d0_slots(pmh_mg mg, const float **dinv, float *itheta, float **d0, float **b32); // see mg.hip
