@@ -352,6 +352,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     timing_in_region = want_timing and world == 1 and not a.sim_world
 
     def timing_on():
+        os.environ.setdefault("PMH_TIMING_STRIDE", "5")  # event pairs around every 5th K x launch (each pair costs stream time; 5 is coprime to the 4 fine-level launches of a cycle, so all four kernel variants are sampled)
         q.Kplus.timing_enable(60000)
         if hier is not None:
             q.Kplus.mg.timing_enable(60000)
@@ -410,6 +411,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(kpat) if (a.nel == 43 and world == 1) else None,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
+            "timing_stride": int(os.environ.get("PMH_TIMING_STRIDE", "1")),
             "timed_over": "the timed region" if timing_in_region else "a separate 2-step pass after the timed region (hipGraph replay inside it)",
             "share_of_step_time": ((ms_k * 1e-3) / dt if n_k else None) if timing_in_region else None,
             "all_fine_K_products": {"launches": n_k + (n_cg if hier is not None else 0), "share_of_step_time": ((ms_all * 1e-3) / dt if n_k else None) if timing_in_region else None,

@@ -200,7 +200,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out)
   pmh_bsr3 B = new pmh_bsr3_s();
   B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
   B->scale   = 1.0;
-  B->ev_used = 0, B->ev_on = 0;
+  B->ev_used = 0, B->ev_on = 0, B->ev_seen = 0, B->ev_stride = 1;
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * tile_br.size(), (void **)&B->d_tile_br));
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * tile_off.size(), (void **)&B->d_tile_off));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * browptr.size(), (void **)&B->d_browptr));
@@ -279,7 +279,9 @@ template <typename TM, typename T>
 static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)
 {
   hipStream_t st    = B->ctx->stream;
-  const bool  timed = B->ev_on && (size_t)(B->ev_used + 2) <= B->ev.size();
+  // event pairs on every ev_stride-th launch (PMH_TIMING_STRIDE, default 1): each pair costs ~4 us of stream time, which a
+  // benchmark's timed region should not pay on all of its ~130 launches per step
+  const bool  timed = B->ev_on && (B->ev_seen++ % B->ev_stride == 0) && (size_t)(B->ev_used + 2) <= B->ev.size();
   if (timed) PMH_HIP(hipEventRecord(B->ev[B->ev_used], st));
 #define BSR_W(TBV) \
   do { \
@@ -336,7 +338,8 @@ int pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches)
     PMH_HIP(hipEventCreate(&e));
     B->ev.push_back(e);
   }
-  B->ev_used = 0;
+  B->ev_used = 0, B->ev_seen = 0, B->ev_stride = 1;
+  if (const char *e = getenv("PMH_TIMING_STRIDE")) B->ev_stride = std::max(1, atoi(e));
   B->ev_on   = max_launches > 0;
   return PMH_SUCCESS;
 }

@@ -17,6 +17,9 @@ struct mg_level {
   pmh_bsr3 Ab;            // 3x3-block copy of A in the cycle's precision, or NULL
   int      n;
   void    *dinv, *x, *b, *r, *d, *t, *xa; // vectors in the cycle's precision; in fp64 x and b of level 0 are the caller's
+  void    *pv, *rv;       // values of P and P' in the cycle's precision (fp32 copies: 8 instead of 12 bytes per entry; the
+                          // trilinear weights 1, 1/2, 1/4, 1/8 are exact in any precision), or the CSR's own fp64 arrays
+  bool     pv_owned;
   double   theta, delta;
   std::vector<double> c1, c2; // Chebyshev recurrence coefficients of steps 1..degree-1
 };
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cheb_step(int n, const int *__res
 // dinv_c != NULL: the first smoothing direction of the coarse level, d_c = D_c^-1 b_c / theta_c, is written on the way
 // (saves the k_cheb_d0 launch of every smoothed coarse level: these levels are launch-latency bound).
 template <typename TV>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
                                                          const TV *__restrict__ dinv_c, TV itheta_c, TV *__restrict__ d_c)
 {
   if (halt && *halt) return;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__
 
 // coarse-grid correction x -= P x_c (<= 8 entries per row of P), one thread per fine row
 template <typename TV>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
 {
   if (halt && *halt) return;
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
@@ -267,10 +270,10 @@ static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b6
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, t, PMH_EPI_SUB, e, mg->halt));
   pmh_csr    R  = Lv.P->transpose;
   const bool cf = mg_fused_level(mg, l + 1); // the coarse level's d0 rides on the restriction
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)t, (TV *)Lc.b,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, (const TV *)t, (TV *)Lc.b,
                      cf ? (const TV *)Lc.dinv : (const TV *)nullptr, cf ? (TV)(1.0 / Lc.theta) : (TV)0, cf ? (TV *)Lc.d : (TV *)nullptr);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x, nullptr, nullptr, cf));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), g, blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, xa);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), g, blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, x, PMH_BSR_EPI_POST1, e, mg->halt));
@@ -296,10 +299,10 @@ static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, dou
   // t = A x - b; b_{l+1} = P' t = -P'(b - A x); the coarse solve is linear, so the sign is undone by subtracting P x_{l+1}
   PMH_CHK(mg_spmv(mg, l, x, Lv.t, PMH_EPI_SUB, b));
   pmh_csr R = Lv.P->transpose;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const double *)R->d_val, (const TV *)Lv.t, (TV *)Lc.b,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, (const TV *)Lv.t, (TV *)Lc.b,
                      (const TV *)nullptr, (TV)0, (TV *)nullptr);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const double *)Lv.P->d_val, (const TV *)Lc.x, x);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, x);
   PMH_HIP(hipGetLastError());
   return mg_smooth<TV>(mg, l, b, x, false);
 }
@@ -391,11 +394,11 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   mg->halt      = nullptr;
   mg->fine_spmv = 0;
   mg->timing_on = 0;
-  // hipGraph replay of the cycle (rocprofv3's kernel tracing crashes on graph launches on this ROCm: profile with PMH_MG_GRAPH=0).
-  // Default: replay for small fine levels only.  With one or two subdomain blocks per GPU (the 8-GPU strong-scaling share) the
-  // ~15 launches of a cycle take ~5 us each and the host's launch rate, not the GPU, bounds the step (measured: 4.4 ms of
-  // kernels in a 5.6 ms step); at 8 blocks per GPU the host runs far ahead and replay gains nothing.
-  mg->use_graph = A[0]->nrows <= 600000;
+  // hipGraph replay of the cycle is opt-in (PMH_MG_GRAPH=1).  Measured: nil at 8 blocks per GPU (the host runs far ahead of the
+  // GPU), and nil at 1 block per GPU too once the bench stopped recording event pairs inside the timed region (4.85 ms/step with
+  // replay, 4.71 without): the ~5 us floor of the small launches is GPU-side (dependent loads), not host launch overhead.
+  // rocprofv3's kernel tracing crashes on graph launches on this ROCm.
+  mg->use_graph = 0;
   if (const char *e = getenv("PMH_MG_GRAPH")) mg->use_graph = atoi(e);
   mg->fused = (degree == 2);
   if (const char *e = getenv("PMH_MG_FUSED")) mg->fused = mg->fused && atoi(e); // testing knob: 0 = separate smoothing kernels
@@ -405,6 +408,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
     mg_level &Lv = mg->L[l];
     Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows, Lv.Ab = nullptr;
     Lv.dinv = Lv.x = Lv.b = Lv.r = Lv.d = Lv.t = Lv.xa = nullptr;
+    Lv.pv = Lv.rv = nullptr, Lv.pv_owned = false;
     const size_t nbytes = w * (size_t)(Lv.n ? Lv.n : 1);
     if (l > 0 || fl) {
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.x));
@@ -420,6 +424,16 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       }
       if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches only
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
+      Lv.pv = P[l]->d_val, Lv.rv = P[l]->transpose->d_val;
+      if (fl && P[l]->nnz > 0) {
+        const int nz = (int)P[l]->nnz;
+        PMH_CHK(pmh_malloc(ctx, sizeof(float) * (size_t)nz, &Lv.pv));
+        PMH_CHK(pmh_malloc(ctx, sizeof(float) * (size_t)nz, &Lv.rv));
+        Lv.pv_owned = true;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_convert<double, float>), mg_grid(nz), dim3(PMH_BLOCK), 0, ctx->stream, nz, (const int *)nullptr, (const double *)P[l]->d_val, (float *)Lv.pv);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_convert<double, float>), mg_grid(nz), dim3(PMH_BLOCK), 0, ctx->stream, nz, (const int *)nullptr, (const double *)P[l]->transpose->d_val, (float *)Lv.rv);
+        PMH_HIP(hipGetLastError());
+      }
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.dinv));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.r));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.d));
@@ -492,6 +506,7 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.xa);
     pmh_free(ctx, Lv.x);
     pmh_free(ctx, Lv.b);
+    if (Lv.pv_owned) pmh_free(ctx, Lv.pv), pmh_free(ctx, Lv.rv);
     pmh_bsr3_destroy(Lv.Ab);
   }
   for (auto &g : mg->graphs) (void)hipGraphExecDestroy(g.exec);

@@ -132,7 +132,7 @@ struct pmh_bsr3_s {
   long long *d_tile_off;
   void     *d_val;
   std::vector<hipEvent_t> ev; // optional per-launch timing (event pairs on the launch stream)
-  int                     ev_used, ev_on;
+  int                     ev_used, ev_on, ev_seen, ev_stride;
 };
 typedef pmh_bsr3_s *pmh_bsr3;
 enum { PMH_BSR_F64 = 0, PMH_BSR_F32 = 1, PMH_BSR_F16 = 2 };
