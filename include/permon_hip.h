@@ -303,6 +303,20 @@ int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
 int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
+/* ---- options front end (QPSSetFromOptions qps.c:860-900, _MPGP mpgp.c:712-745, _SMALXE smalxe.c:696-766) ----------
+ * The reference is configured from PETSc's options database; this parses the same keys out of a PETSc-style option string
+ * (command line / permonrc contents) into the option structs, with the argument checks of the reference's setters.
+ * prefix: options prefix of the QPS object ("" for the top solver); SMALXE's inner MPGP reads <prefix>smalxe_qps_* (smalxe.c:500-502).
+ * unknown: optional buffer for the keys nobody consumed (PETSc's -options_left), space separated. */
+typedef struct {
+  char   type[16];           /* -qps_type: "mpgp" | "smalxe" | "pcpg" | "ksp"; "" = QPSSetDefaultType decides (qps.c:422-455) */
+  double rtol, atol, divtol; /* -qps_rtol / -qps_atol / -qps_divtol (QPSSetTolerances qps.c:905-930) */
+  int    max_it, max_it_set; /* -qps_max_it */
+  int    monitor, monitor_cost, view, view_convergence, auto_post_solve;
+} pmh_qps_opts;
+int pmh_qps_default_opts(pmh_qps_opts *q);
+int pmh_qps_set_from_options(const char *options, const char *prefix, pmh_qps_opts *q, pmh_mpgp_opts *m, pmh_smalxe_opts *s /* or NULL */, char *unknown, int unknown_cap);
+
 /* ---- PC for the inner KSP of MATINV: multigrid V-cycle (PCMG semantics) ----------------------------------------
  * The reference's iterative MATINV applies K^+ with a PETSc KSP whose PC is chosen by -mat_inv_pc_type
  * (src/mat/impls/inv/matinv.c, MatInvGetKSP / MatInvSetUp).  pmh_mg is that PC on the device for PCMG-like set-ups:

@@ -62,6 +62,13 @@ class SmalxeStats(C.Structure):
     ]
 
 
+class QpsOpts(C.Structure):
+    _fields_ = [
+        ("type", C.c_char * 16), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int), ("max_it_set", C.c_int),
+        ("monitor", C.c_int), ("monitor_cost", C.c_int), ("view", C.c_int), ("view_convergence", C.c_int), ("auto_post_solve", C.c_int),
+    ]
+
+
 class PcpgStats(C.Structure):
     _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double)]
 
@@ -183,6 +190,8 @@ _PROTOS = {
     "pmh_mg_stats": [vp, C.POINTER(C.c_longlong)],
     "pmh_mg_destroy": [vp],
     "pmh_matinv_set_pc_mg": [vp, vp],
+    "pmh_qps_default_opts": [C.POINTER(QpsOpts)],
+    "pmh_qps_set_from_options": [C.c_char_p, C.c_char_p, C.POINTER(QpsOpts), C.POINTER(MpgpOpts), C.POINTER(SmalxeOpts), C.c_char_p, C.c_int],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

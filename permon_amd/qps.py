@@ -76,6 +76,7 @@ class QPS:
         self.mpgp_opts = _lib.MpgpOpts()
         check(self.L.pmh_mpgp_default_opts(C.byref(self.mpgp_opts)))
         self.smalxe_opts = None
+        self.view_convergence = False
         self.h = None
         self.stats = None
         self._cb = None
@@ -112,6 +113,36 @@ class QPS:
         if max_it is not None:
             self.max_it = int(max_it)
             self._max_it_set = True
+
+    def SetFromOptions(self, options="", prefix=""):
+        """QPSSetFromOptions (qps.c:860-900) over a PETSc-style option string, e.g. the args of the reference's TEST blocks:
+        "-qps_type mpgp -qps_rtol 1e-6 -qps_mpgp_expansion_type gf -qps_mpgp_expansion_length_type opt".  Parsed by
+        pmh_qps_set_from_options (C++, csrc/options.hip) with the reference's key names and argument checks; SMALXE's inner
+        MPGP reads <prefix>smalxe_qps_*.  Returns the list of keys nobody consumed (PETSc's -options_left)."""
+        q = _lib.QpsOpts()
+        check(self.L.pmh_qps_default_opts(C.byref(q)))
+        q.rtol, q.atol, q.divtol, q.max_it = self.rtol, self.atol, self.divtol, self.max_it
+        sm = self.smalxe_opts
+        if sm is None:
+            sm = _lib.SmalxeOpts()
+            check(self.L.pmh_smalxe_default_opts(C.byref(sm)))
+        left = C.create_string_buffer(4096)
+        check(self.L.pmh_qps_set_from_options(options.encode(), prefix.encode(), C.byref(q), C.byref(self.mpgp_opts), C.byref(sm), left, len(left)))
+        t = q.type.decode()
+        if t:
+            self.smalxe_opts = sm if t == "smalxe" else self.smalxe_opts
+            self.SetType(t)
+        elif self.type is None and self.qp is not None:  # QPSSetDefaultTypeIfNotSpecified
+            if self.qp.pf is not None:
+                self.smalxe_opts = sm
+            self.SetDefaultType()
+        elif self.type == "smalxe":
+            self.smalxe_opts = sm
+        self.SetTolerances(rtol=q.rtol, atol=q.atol, divtol=q.divtol, max_it=q.max_it if q.max_it_set else None)
+        if q.monitor:
+            self.MonitorSet(True)
+        self.view_convergence = bool(q.view_convergence)
+        return [k for k in left.value.decode().split() if k]
 
     # MPGP options (QPSSetFromOptions_MPGP keys, mpgp.c:723-745)
     def MPGPSetAlpha(self, alpha, direct=False):

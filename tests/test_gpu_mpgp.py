@@ -241,3 +241,40 @@ def test_view_convergence_text_matches_golden(ctx):
         "number of expansion steps 18",
         "number of proportioning steps 7",
     ]
+
+
+# the args lines of the reference's own TEST blocks (src/tutorials/ex1.c:165-184), fed verbatim to QPSSetFromOptions
+_EX1_TEST_BLOCKS = {
+    "ex1_1": "-n 100 -qps_view_convergence -qp_chain_view_kkt",
+    "ex1_opt": "-n 100 -qps_view_convergence -qp_chain_view_kkt -qps_mpgp_expansion_type gf -qps_mpgp_expansion_length_type opt",
+    "ex1_optapprox": "-n 100 -qps_view_convergence -qp_chain_view_kkt -qps_mpgp_expansion_type g -qps_mpgp_expansion_length_type optapprox",
+    "ex1_bb": "-n 100 -qps_view_convergence -qp_chain_view_kkt -qps_mpgp_expansion_type gfgr -qps_mpgp_expansion_length_type bb",
+    "ex1_projcg": "-n 100 -qps_view_convergence -qp_chain_view_kkt -qps_mpgp_expansion_type projcg",
+}
+
+
+@pytest.mark.parametrize("case", sorted(_EX1_TEST_BLOCKS))
+def test_ex1_goldens_from_the_reference_command_lines(ctx, goldens, case):
+    """QPSSetFromOptions on the reference's command line -> the golden's -qps_view_convergence text and KKT lines."""
+    g = goldens[case]
+    p = P.ex1(100)
+    A = pa.CsrMat(ctx, p["n"], p["n"], p["rowptr"], p["col"], p["val"])
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(A))
+    qp.SetRhs(ctx.vec_from(p["b"]))
+    qp.SetInitialVector(ctx.vec_from(p["x0"]))
+    qp.SetBox(None, ctx.vec_from(p["lb"]), None)
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    left = qps.SetFromOptions(_EX1_TEST_BLOCKS[case])
+    assert left == ["-n", "-qp_chain_view_kkt"]  # the example's own keys, not the solver's
+    assert qps.type == "mpgp" and qps.view_convergence  # QPSSetDefaultTypeIfNotSpecified: box only -> MPGP (qps.c:445)
+    st = qps.Solve()
+    assert _counts(st) == _gold(g["solves"][0]) and st.reason == g["solves"][0]["reason"]
+    text = qps.ViewConvergence()
+    assert text[0].endswith("required %d iterations" % g["solves"][0]["iterations"]) and "CONVERGED_RTOL" in text[0]
+    assert text[1:] == ["number of Hessian multiplications %d" % g["solves"][0]["nmv"], "number of CG steps %d" % g["solves"][0]["ncg"],
+                        "number of expansion steps %d" % g["solves"][0]["nexp"], "number of proportioning steps %d" % g["solves"][0]["nprop"]]
+    kkt = qps.ViewKKT()
+    for line, gl in zip(kkt[1:], g["kkt"][1:]):  # r = ||min(x-lb,0)||, ||min(lambda_lb,0)||, |lambda_lb'(lb-x)|
+        assert line.split("=")[-2].split()[0] == gl["r"]
