@@ -267,6 +267,19 @@ int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
 /* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */
 int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, double *y);
 
+/* ---- QP transform chain of the (T)FETI path, data part (src/qp/interface/qptransform.c) -------------------------------
+   QPTDualize (:1102-1174: F = B K^+ B', d = B K^+ f - c) -> QPTHomogenizeEq (:437-527: lambda~ = G'(GG')^{-1} e,
+   b_bar = d - F lambda~, lb <- lb - lambda~) -> QPTEnforceEqByProjector (:215-316: A = P F P with a box, P F without;
+   b = P b_bar).  f: n_x, c / lb: n_lambda (lb NULL = no box, -inf on equality rows otherwise), e: rows of G; pf NULL = no
+   equality constraint (no floating subdomain).  The handles stay owned by the caller, the chain owns what it creates. */
+typedef struct pmh_feti_chain_s *pmh_feti_chain;
+int pmh_qpt_feti_chain_create(pmh_gluing B, pmh_matinv Kplus, const double *f, const double *c, pmh_qppf pf, const double *e, const double *lb, pmh_feti_chain *ch);
+int pmh_qpt_feti_chain_get(pmh_feti_chain ch, pmh_op *F, pmh_op *A, double **d, double **b_bar, double **b, double **lb_new, double **lambda_tilde); /* borrowed */
+/* QPTHomogenizeEqPostSolve_Private (:423-431) + the operator part of QPTDualizePostSolve_Private (:783-833):
+   lambda = lambda_child + lambda~; u0 = K^+(f - B' lambda); r = F lambda - d (u0, r optional) */
+int pmh_qpt_feti_chain_post_solve(pmh_feti_chain ch, const double *lambda_child, double *lambda, double *u0, double *r);
+int pmh_qpt_feti_chain_destroy(pmh_feti_chain ch);
+
 /* ---- dense-row SVM dual Hessian (BASELINE configs[4]) ---------------------------------------------------- */
 /* H = diag(y) X X' diag(y), X: n_local x d row-major in HBM (d <= 256), applied as two GEMV passes; with a
    communicator the samples are sharded by rows and w = X'(y o a) is all-reduced (d doubles) between the passes */

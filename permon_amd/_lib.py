@@ -172,6 +172,10 @@ _PROTOS = {
     "pmh_mat_regularize_csr": [C.c_int, vp, vp, vp, C.c_int, vp, C.c_double, vp, vp, vp, vp, C.POINTER(C.c_longlong)],
     "pmh_op_create_feti_dual": [vp, vp, C.POINTER(vp)],
     "pmh_pc_dual_lumped_apply": [vp, vp, vp, vp],
+    "pmh_qpt_feti_chain_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
+    "pmh_qpt_feti_chain_get": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+    "pmh_qpt_feti_chain_post_solve": [vp, vp, vp, vp, vp],
+    "pmh_qpt_feti_chain_destroy": [vp],
     "pmh_op_create_svm_dual": [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
     "pmh_smalxe_default_opts": [C.POINTER(SmalxeOpts)],
     "pmh_smalxe_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(SmalxeOpts), C.POINTER(vp)],

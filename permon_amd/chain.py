@@ -2,9 +2,12 @@
 QPTDualize -> [QPTOrthonormalizeEq] -> QPTHomogenizeEq -> QPTEnforceEqByProjector -> QPS (SMALXE / PCPG).
 Each step cites the reference function it follows (src/qp/interface/qptransform.c).  Only set-up happens
 here (a handful of operator applications); the iteration itself is pmh_smalxe_solve / pmh_pcpg_solve."""
+import ctypes as C
+
 import numpy as np
 
-from .core import Vec
+from ._lib import check
+from .core import Op, Vec
 from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatGluing, MatInv, MatRegularize, PCDualLumpedOp
 from .qps import QP, QPS
 
@@ -65,37 +68,28 @@ class FetiDualQP:
         if mg_hierarchy is not None:  # -mat_inv_pc_type mg: V-cycle PC for the inner CG (feti.box_mg_hierarchy)
             self.Kplus.set_pc_mg(mg_hierarchy, degree=mg_degree, precision=mg_precision)
         self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
-        # F = B K^+ B' (QPTDualize qptransform.c:1103-1128)
-        self.F = MatCreateFetiDual(self.B, self.Kplus)
-        # d = B K^+ f - c (qptransform.c:1130-1134)
-        self.f = ctx.vec_from(local["f"])
-        self.tprim = ctx.vec(local["n_x"])
-        self.d = ctx.vec(nl)
-        self.Kplus.mult(self.f, self.tprim)
-        self.B.mult_transpose(self.tprim, self.d)
-        self.d.axpy(-1.0, ctx.vec_from(c))
         self.has_box = bool(np.any(np.isfinite(lb)))
-        if G is None:
-            # no floating subdomain: R has no columns, the dual QP has no equality constraint (qptransform.c:1092-1101)
-            self.pf, self.e, self.lam_tilde = None, None, ctx.vec(nl)
-            self.b_bar, self.b, self.A = self.d, self.d, self.F
-            self.lb_new = ctx.vec_from(np.asarray(lb, dtype=np.float64))
-        else:
-            # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169)
-            self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal)
-            # QPTHomogenizeEq qptransform.c:437-527: lambda~ = G'(GG')^{-1} e; b_bar = d - F lambda~; lb <- lb - lambda~
-            self.e = ctx.vec_from(e)
-            self.lam_tilde = ctx.vec(nl)
-            self.pf.ApplyHalfQTranspose(self.e, self.lam_tilde)
-            self.b_bar = ctx.vec(nl)
-            self.F.mult(self.lam_tilde, self.b_bar)
-            self.b_bar.aypx(-1.0, self.d)
-            lt = self.lam_tilde.to_numpy()
-            self.lb_new = ctx.vec_from(np.asarray(lb) - lt)
-            # QPTEnforceEqByProjector qptransform.c:215-316: A = P F P (box present) or P F (eq. only), b = P b_bar
-            self.A = MatCreateProjected(self.F, self.pf, symmetric=self.has_box)
-            self.b = ctx.vec(nl)
-            self.pf.ApplyP(self.b_bar, self.b)
+        self.f = ctx.vec_from(local["f"])
+        # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169); G None: no floating subdomain, no equality constraint
+        self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal) if G is not None else None
+        self.e = ctx.vec_from(e) if G is not None else None
+        # QPTDualize -> QPTHomogenizeEq -> QPTEnforceEqByProjector on the device (pmh_qpt_feti_chain_create, csrc/feti.hip):
+        # F = B K^+ B', d = B K^+ f - c, lambda~ = G'(GG')^{-1} e, b_bar = d - F lambda~, lb <- lb - lambda~, A = P F P | P F, b = P b_bar
+        cv = ctx.vec_from(c)
+        lbv = ctx.vec_from(np.asarray(lb, dtype=np.float64))  # dual box of QPTDualize (:1136-1162); all -inf = no box => A = P F
+        h = C.c_void_p()
+        check(ctx.L.pmh_qpt_feti_chain_create(self.B.h, self.Kplus.h, self.f.p, cv.p, self.pf.h if self.pf is not None else None,
+                                              self.e.p if self.e is not None else None, lbv.p if self.has_box else None, C.byref(h)))
+        self.h = h
+        cv.free()
+        lbv.free()
+        ptr = [C.c_void_p() for _ in range(7)]
+        check(ctx.L.pmh_qpt_feti_chain_get(h, *[C.byref(p) for p in ptr]))
+        self.F = Op(ctx, ptr[0], nl, keep=[self.B, self.Kplus])
+        self.A = self.F if ptr[1].value == ptr[0].value else Op(ctx, ptr[1], nl, keep=[self.F, self.pf])
+        self.F.destroy = self.A.destroy = lambda: None  # owned by the chain
+        self.d, self.b_bar, self.b, self.lb_new, self.lam_tilde = (Vec.borrowed(ctx, p, nl) if p.value else None for p in ptr[2:7])
+        self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
     def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
@@ -159,20 +153,20 @@ class FetiDualQP:
 
     def dual_solution(self):
         """lambda = lambda_child + lambda~ (QPTHomogenizeEqPostSolve_Private qptransform.c:423-431)."""
-        return self.lam.to_numpy() + self.lam_tilde.to_numpy()
+        lam = self.ctx.vec(self.n_lambda)
+        check(self.ctx.L.pmh_qpt_feti_chain_post_solve(self.h, self.lam.p, lam.p, None, None))
+        out = lam.to_numpy()
+        lam.free()
+        return out
 
     def primal_solution(self, G_host, e_host=None):
         """The two device-side pieces of QPTDualizePostSolve_Private (qptransform.c:783-833): returns
         (K^+(f - B' lambda), F lambda - d).  The caller finishes on the host with the small coarse solve:
         u = K^+(f - B' lambda) - R alpha,  G' alpha = d - F lambda, i.e. alpha = -(G G')^{-1} G (F lambda - d)."""
         ctx = self.ctx
-        lam = ctx.vec_from(self.dual_solution())
-        t = ctx.vec(self.tprim.n)
-        self.B.mult(lam, t)  # B' lambda
-        t.aypx(-1.0, self.f)  # f - B' lambda
-        u = ctx.vec(self.tprim.n)
-        self.Kplus.mult(t, u)
-        Fl = ctx.vec(self.n_lambda)
-        self.F.mult(lam, Fl)
-        Fl.axpy(-1.0, self.d)
-        return u.to_numpy(), Fl.to_numpy()
+        lam, u, Fl = ctx.vec(self.n_lambda), ctx.vec(self.tprim.n), ctx.vec(self.n_lambda)
+        check(ctx.L.pmh_qpt_feti_chain_post_solve(self.h, self.lam.p, lam.p, u.p, Fl.p))
+        out = (u.to_numpy(), Fl.to_numpy())
+        for v in (lam, u, Fl):
+            v.free()
+        return out

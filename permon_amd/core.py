@@ -80,6 +80,13 @@ class Vec:
             check(ctx.L.pmh_memset(ctx.h, self.p, 0, 8 * self.n))
 
     @classmethod
+    def borrowed(cls, ctx, p, n):
+        """View of device memory owned by a library object (never freed from here)."""
+        v = cls.__new__(cls)
+        v.ctx, v.n, v.p, v._borrowed = ctx, int(n), C.c_void_p(p) if not isinstance(p, C.c_void_p) else p, True
+        return v
+
+    @classmethod
     def from_numpy(cls, ctx, a):
         a = np.ascontiguousarray(a, dtype=np.float64)
         v = cls(ctx, a.size, zero=False)
@@ -102,9 +109,9 @@ class Vec:
         return v
 
     def free(self):
-        if self.p:
+        if self.p and not getattr(self, "_borrowed", False):
             self.ctx.L.pmh_free(self.ctx.h, self.p)
-            self.p = None
+        self.p = None
 
     # PETSc Vec ops used by the path
     def axpy(self, a, x):

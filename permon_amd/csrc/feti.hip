@@ -709,3 +709,110 @@ extern "C" int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const dou
   pmh_free(ctx, yw);
   return rc;
 }
+
+// ---- the QP transform chain of the (T)FETI path, data part, on the device -------------------------------------------------
+// QPTDualize (src/qp/interface/qptransform.c:1102-1174: F = B K^+ B', d = B K^+ f - c, child QP with BE = G, cE = e and the
+// dual box) -> QPTHomogenizeEq (:437-527: lambda~ = G'(GG')^{-1} e, b_bar = d - F lambda~, lb <- lb - lambda~) ->
+// QPTEnforceEqByProjector (:215-316: A = P F P with a box / P F without, b = P b_bar).  The reference builds these with a
+// handful of MatMult / VecAXPY calls at set-up time; the same calls here, behind one entry point, produce the operator and
+// the vectors the QPS solvers (pmh_smalxe_* / pmh_pcpg_solve / pmh_ksp_cg_solve) consume.
+struct pmh_feti_chain_s {
+  pmh_ctx    ctx;
+  pmh_gluing B;
+  pmh_matinv Kplus;
+  pmh_qppf   pf;
+  int        n_x, n_lambda, has_box;
+  pmh_op     F, A; // A == F when there is no equality constraint
+  double    *f, *d, *b_bar, *b, *lb_new, *lam_tilde, *t_x, *t_l; // b_bar == b == d and lam_tilde = 0 without pf
+};
+
+extern "C" int pmh_qpt_feti_chain_create(pmh_gluing B, pmh_matinv Kplus, const double *f, const double *c, pmh_qppf pf, const double *e, const double *lb, pmh_feti_chain *out)
+{
+  PMH_ARG(B && Kplus && f && c && out && (!pf || e));
+  PMH_ARG(B->n_x == Kplus->n && (!pf || pf->n == B->n_lambda));
+  pmh_ctx          ctx = B->ctx;
+  const int        nl = B->n_lambda, nx = B->n_x;
+  pmh_feti_chain   ch = new pmh_feti_chain_s();
+  memset(ch, 0, sizeof(*ch));
+  ch->ctx = ctx, ch->B = B, ch->Kplus = Kplus, ch->pf = pf, ch->n_x = nx, ch->n_lambda = nl, ch->has_box = lb ? 1 : 0;
+  const size_t bl = sizeof(double) * (size_t)(nl ? nl : 1), bx = sizeof(double) * (size_t)(nx ? nx : 1);
+  PMH_CHK(pmh_malloc(ctx, bx, (void **)&ch->f));
+  PMH_CHK(pmh_malloc(ctx, bx, (void **)&ch->t_x));
+  PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->d));
+  PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->t_l));
+  PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->lam_tilde));
+  PMH_CHK(pmh_memcpy_d2d(ctx, ch->f, f, bx));
+  PMH_CHK(pmh_op_create_feti_dual(B, Kplus, &ch->F)); // qptransform.c:1103-1128
+  // d = B K^+ f - c (:1130-1134)
+  PMH_CHK(pmh_matinv_mult(Kplus, ch->f, ch->t_x));
+  PMH_CHK(pmh_gluing_mult_transpose(B, ch->t_x, ch->d));
+  PMH_CHK(pmh_vec_axpy(ctx, nl, ch->d, -1.0, c));
+  if (lb) {
+    PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->lb_new));
+    PMH_CHK(pmh_memcpy_d2d(ctx, ch->lb_new, lb, bl));
+  }
+  if (!pf) { // no floating subdomain: the dual QP has no equality constraint (:1092-1101)
+    PMH_CHK(pmh_memset(ctx, ch->lam_tilde, 0, bl));
+    ch->b_bar = ch->b = ch->d;
+    ch->A     = ch->F;
+  } else {
+    PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->b_bar));
+    PMH_CHK(pmh_malloc(ctx, bl, (void **)&ch->b));
+    // QPTHomogenizeEq: lambda~ = G'(GG')^{-1} e (:464-476); b_bar = d - F lambda~ (:487-494); lb <- lb - lambda~ (:497-512)
+    PMH_CHK(pmh_qppf_apply_halfQ_transpose(pf, e, ch->lam_tilde));
+    PMH_CHK(ch->F->mult(ch->lam_tilde, ch->b_bar));
+    PMH_CHK(pmh_vec_aypx(ctx, nl, ch->b_bar, -1.0, ch->d));
+    if (lb) PMH_CHK(pmh_vec_axpy(ctx, nl, ch->lb_new, -1.0, ch->lam_tilde)); // -inf stays -inf
+    // QPTEnforceEqByProjector: A = P F P (box present, :278-283) or P F (:273-277); b = P b_bar (:285-288)
+    PMH_CHK(pmh_op_create_projected(ch->F, pf, ch->has_box, &ch->A));
+    PMH_CHK(pmh_qppf_apply_P(pf, ch->b_bar, ch->b));
+  }
+  *out = ch;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_qpt_feti_chain_get(pmh_feti_chain ch, pmh_op *F, pmh_op *A, double **d, double **b_bar, double **b, double **lb_new, double **lambda_tilde)
+{
+  PMH_ARG(ch);
+  if (F) *F = ch->F;
+  if (A) *A = ch->A;
+  if (d) *d = ch->d;
+  if (b_bar) *b_bar = ch->b_bar;
+  if (b) *b = ch->b;
+  if (lb_new) *lb_new = ch->lb_new;
+  if (lambda_tilde) *lambda_tilde = ch->lam_tilde;
+  return PMH_SUCCESS;
+}
+
+// Post-solve, device part: lambda = lambda_child + lambda~ (QPTHomogenizeEqPostSolve_Private :423-431); then the two pieces of
+// QPTDualizePostSolve_Private (:783-833) that need the big operators: u0 = K^+(f - B' lambda) and r = F lambda - d.  The caller
+// finishes with the small coarse solve u = u0 - R alpha, G' alpha = d - F lambda.  u0 / r may be NULL.
+extern "C" int pmh_qpt_feti_chain_post_solve(pmh_feti_chain ch, const double *lambda_child, double *lambda, double *u0, double *r)
+{
+  PMH_ARG(ch && lambda_child && lambda);
+  pmh_ctx ctx = ch->ctx;
+  PMH_CHK(pmh_vec_waxpy(ctx, ch->n_lambda, lambda, 1.0, lambda_child, ch->lam_tilde));
+  if (u0) {
+    PMH_CHK(pmh_gluing_mult(ch->B, lambda, ch->t_x)); // B' lambda
+    PMH_CHK(pmh_vec_aypx(ctx, ch->n_x, ch->t_x, -1.0, ch->f)); // f - B' lambda
+    PMH_CHK(pmh_matinv_mult(ch->Kplus, ch->t_x, u0));
+  }
+  if (r) {
+    PMH_CHK(ch->F->mult(lambda, r));
+    PMH_CHK(pmh_vec_axpy(ctx, ch->n_lambda, r, -1.0, ch->d));
+  }
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_qpt_feti_chain_destroy(pmh_feti_chain ch)
+{
+  if (!ch) return PMH_SUCCESS;
+  pmh_ctx ctx = ch->ctx;
+  if (ch->A && ch->A != ch->F) pmh_op_destroy(ch->A);
+  if (ch->F) pmh_op_destroy(ch->F);
+  if (ch->b_bar != ch->d) pmh_free(ctx, ch->b_bar);
+  if (ch->b != ch->d) pmh_free(ctx, ch->b);
+  pmh_free(ctx, ch->f), pmh_free(ctx, ch->d), pmh_free(ctx, ch->lb_new), pmh_free(ctx, ch->lam_tilde), pmh_free(ctx, ch->t_x), pmh_free(ctx, ch->t_l);
+  delete ch;
+  return PMH_SUCCESS;
+}
