@@ -34,10 +34,9 @@ template <typename V> struct lane_of<V, 1> {
 //   POST2 (x = d gathered):   y += c1 d + c2 (r - dinv A d); optional fp64 copy   second step of the post-smoother
 // TM: storage type of the matrix entries, T: arithmetic / vector type, W: adjacent blocks per thread-load.
 template <typename TM, typename T, int EPI, int W, int BSR_TB>
-__global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile_br, const long long *__restrict__ tile_off, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const TM *__restrict__ val, T scale,
+__global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int4 *__restrict__ tile_meta, const long long *__restrict__ tile_off, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const TM *__restrict__ val, T scale,
                                                      const T *__restrict__ x, T *__restrict__ y, pmh_bsr3_epi<T> e, const int *__restrict__ halt)
 {
-  if (halt && *halt) return;
   typedef typename vecw<TM, W>::type VM;
   typedef typename ivecw<W>::type    VI;
   __shared__ T prod[3][BSR_TB];
@@ -45,9 +44,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int *__restrict__ tile
   const int    chunk = gridDim.x >> 3; // XCD-aware: XCD x works on a contiguous slab of tiles (x stays in its L2)
   const int    t     = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (t >= ntiles) return;
-  const int       br0 = tile_br[t], br1 = tile_br[t + 1];
-  const int       s0 = browptr[br0], nbt = browptr[br1] - s0, nbp = (nbt + W - 1) / W * W;
+  // the halt flag, the tile descriptor {first block row, end block row, first block, block count} and the tile's offset are
+  // fetched together: one memory round trip instead of three dependent ones (the coarse-level launches are latency bound)
+  const int       hlt = halt ? *halt : 0;
+  const int4      tm  = tile_meta[t];
   const long long off = tile_off[t];
+  if (hlt) return;
+  const int br0 = tm.x, br1 = tm.y, s0 = tm.z, nbt = tm.w, nbp = (nbt + W - 1) / W * W;
   const TM       *v  = val + off * 9;
   const int      *bc = bcol + off;
 #pragma unroll
@@ -201,11 +204,16 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out)
   B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
   B->scale   = 1.0;
   B->ev_used = 0, B->ev_on = 0, B->ev_seen = 0, B->ev_stride = 1;
-  PMH_CHK(pmh_malloc(ctx, sizeof(int) * tile_br.size(), (void **)&B->d_tile_br));
+  std::vector<int> tmeta((size_t)4 * ntiles);
+  for (int t = 0; t < ntiles; t++) {
+    tmeta[4 * t] = tile_br[t], tmeta[4 * t + 1] = tile_br[t + 1];
+    tmeta[4 * t + 2] = browptr[tile_br[t]], tmeta[4 * t + 3] = browptr[tile_br[t + 1]] - browptr[tile_br[t]];
+  }
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (tmeta.size() ? tmeta.size() : 4), (void **)&B->d_tile_br));
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * tile_off.size(), (void **)&B->d_tile_off));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * browptr.size(), (void **)&B->d_browptr));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(npad + 2), (void **)&B->d_bcol));
-  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_br, tile_br.data(), sizeof(int) * tile_br.size()));
+  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_br, tmeta.data(), sizeof(int) * tmeta.size())); // int4 per tile
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_off, tile_off.data(), sizeof(long long) * tile_off.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_browptr, browptr.data(), sizeof(int) * browptr.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_bcol, bcp.data(), sizeof(int) * (size_t)npad));
@@ -257,7 +265,8 @@ static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_e
 {
   const dim3       grid((unsigned)(((B->ntiles + 7) / 8) * 8)), blk(PMH_BLOCK);
   hipStream_t      st = B->ctx->stream;
-  const int       *tb = B->d_tile_br, *bp = B->d_browptr, *bc = B->d_bcol;
+  const int4      *tb = (const int4 *)B->d_tile_br;
+  const int       *bp = B->d_browptr, *bc = B->d_bcol;
   const long long *to = B->d_tile_off;
   const TM        *v  = (const TM *)B->d_val;
   const T          sc = (T)B->scale;

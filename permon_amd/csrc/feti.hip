@@ -402,7 +402,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_update_p(const int *__restrict
   }
 }
 
-__global__ void k_publish_int(const int *d, int *h) { *h = *d; }
+// number of still active blocks and the largest per-block iteration count, to pinned host memory (one sync serves both)
+__global__ void k_publish_state(int nb, const int *__restrict__ bi, const int *nactive, int *h)
+{
+  int mx = 0;
+  for (int b = 0; b < nb; b++) {
+    const int a = bi[(size_t)(0 * nb + b) * 2 + 1], c = bi[(size_t)(1 * nb + b) * 2 + 1];
+    mx = max(mx, max(a, c));
+  }
+  h[1] = mx;
+  h[0] = *nactive;
+}
 
 #define PMH_MAX_KDIM 8
 // partial coefficients R_k' v per block (k < kdim)
@@ -482,7 +492,7 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * 4 * (size_t)M->nblocks, (void **)&M->d_bi));
   PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_nactive));
   PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_done));
-  PMH_HIP(hipHostMalloc((void **)&M->h_nactive, sizeof(int), hipHostMallocMapped));
+  PMH_HIP(hipHostMalloc((void **)&M->h_nactive, 2 * sizeof(int), hipHostMallocMapped));
   if (M->n > 0) {
     hipLaunchKernelGGL(k_extract_dinv, dim3(pmh_vec_grid(M->n)), dim3(PMH_BLOCK), 0, ctx->stream, M->n, K->K->d_rowptr, K->K->d_col, K->K->d_val, jacobi, M->dinv);
     PMH_HIP(hipGetLastError());
@@ -577,8 +587,11 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   const float *mg_dinv = nullptr;
   float        mg_itheta = 0.f, *mg_d0 = nullptr, *mg_b32 = nullptr;
   const bool   d0_fused = extpc && !getenv("PMH_MG_NO_D0_FUSION") && pmh_mg_fine_d0_slots(M->mg, &mg_dinv, &mg_itheta, &mg_d0, &mg_b32);
-  int it = 0, next_check = (M->last_max_its > 8) ? (M->last_max_its - 2) : 4;
-  if (extpc) next_check = (M->last_max_its > 2) ? (M->last_max_its - 1) : 1; // few, expensive iterations: do not overshoot
+  // The host enqueues iterations without waiting and looks at the device state only where it expects the solve to end: the
+  // iteration count of the previous application (successive right-hand sides of the dual iteration need the same number, give
+  // or take one).  Launches enqueued past convergence are no-ops (done flag).  One synchronisation per application in the
+  // common case -- each one drains the stream, which costs more than an idle iteration once the blocks are spread over 8 GPUs.
+  int it = 0, next_check = (M->last_max_its > 0) ? M->last_max_its : (extpc ? 1 : 4);
   while (it < M->max_it) {
     const int q = it & 1;
     if (M->Kb) {
@@ -598,18 +611,17 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     PMH_HIP(hipGetLastError());
     it++;
     if (it >= next_check || it >= M->max_it) {
-      hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, st, (const int *)M->d_nactive, M->h_nactive);
+      hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(1), 0, st, nb, (const int *)M->d_bi, (const int *)M->d_nactive, M->h_nactive);
       PMH_HIP(hipStreamSynchronize(st));
-      if (*M->h_nactive == 0) break;
+      if (M->h_nactive[0] == 0) break;
       next_check = it + (extpc ? 1 : 2);
     }
   }
-  // iteration counts per block
-  std::vector<int> bi((size_t)4 * nb);
-  PMH_CHK(pmh_memcpy_d2h(ctx, bi.data(), M->d_bi, sizeof(int) * bi.size()));
-  int mx = 0;
-  for (int b = 0; b < nb; b++) mx = std::max(mx, std::max(bi[(size_t)(0 * nb + b) * 2 + 1], bi[(size_t)(1 * nb + b) * 2 + 1]));
-  M->last_max_its = mx;
+  if (it == 0) { // max_it reached before the first check cannot happen (max_it > 0); zero right-hand side: publish once
+    hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(1), 0, st, nb, (const int *)M->d_bi, (const int *)M->d_nactive, M->h_nactive);
+    PMH_HIP(hipStreamSynchronize(st));
+  }
+  M->last_max_its = M->h_nactive[1]; // largest per-block iteration count
   if (M->kdim) { // u <- P_R u (in place through the scratch vector)
     PMH_CHK(matinv_project(M, u, M->d_fproj));
     PMH_CHK(pmh_memcpy_d2d(ctx, u, M->d_fproj, sizeof(double) * (size_t)M->n));

@@ -120,13 +120,18 @@ template <typename TV>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
                                                          const TV *__restrict__ dinv_c, TV itheta_c, TV *__restrict__ d_c)
 {
-  if (halt && *halt) return;
+  const int hlt  = halt ? *halt : 0; // fetched together with the first row pointers: one round trip less on a latency-bound launch
   const int lane = threadIdx.x & 7;
+  bool      first = true;
   for (int i0 = blockIdx.x * (PMH_BLOCK / 8); i0 < nc; i0 += gridDim.x * (PMH_BLOCK / 8)) { // uniform trip count per workgroup
     const int i = i0 + (threadIdx.x >> 3);
     TV        s = (TV)0;
-    if (i < nc)
-      for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 8) s += (TV)val[k] * t[col[k]];
+    const int k0 = (i < nc) ? rowptr[i] : 0, k1 = (i < nc) ? rowptr[i + 1] : 0;
+    if (first) {
+      if (hlt) return;
+      first = false;
+    }
+    for (int k = k0 + lane; k < k1; k += 8) s += (TV)val[k] * t[col[k]];
     s += __shfl_down(s, 4, 8);
     s += __shfl_down(s, 2, 8);
     s += __shfl_down(s, 1, 8);
@@ -141,12 +146,20 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict(int nc, const int *__
 template <typename TV>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
 {
-  if (halt && *halt) return;
+  const int hlt   = halt ? *halt : 0; // as in k_mg_restrict
+  bool      first = true;
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    TV s = (TV)0;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += (TV)val[k] * xc[col[k]];
-    x[i] -= s;
+    TV        s  = (TV)0;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    const TV  xi = x[i];
+    if (first) {
+      if (hlt) return;
+      first = false;
+    }
+    for (int k = k0; k < k1; k++) s += (TV)val[k] * xc[col[k]];
+    x[i] = xi - s;
   }
+  if (first && hlt) return;
 }
 
 // coarsest level: x_b = pinv_b b_b, one wavefront per row, lanes stride the row of the dense block (fixed order).
