@@ -218,6 +218,37 @@ static PetscErrorCode MatMult_GluingHIP(Mat mat, Vec right, Vec left) /* replace
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * MatRegularize for one sequential block (replaces the body of MatRegularize, permonmatregularize.c:241-266, for
+ * MAT_REG_EXPLICIT): K_loc (SeqAIJ) and R_loc (SeqDense, p x d, column-major with lda = p) stay host objects at set-up
+ * time; rho = MatGetMaxEigenvalue(K_loc,NULL,&rho,1,20) is the caller's (pmh_op_max_eigenvalue on the device copy).
+ * --------------------------------------------------------------------------------------------------- */
+PERMON_EXTERN PetscErrorCode MatRegularizeLocal_HIP(Mat K_loc, Mat R_loc, PetscReal rho, Mat *Kreg_loc)
+{
+  PetscInt           p, d, nz;
+  const PetscInt    *ia, *ja;
+  const PetscScalar *a, *r;
+  PetscBool          done;
+  PetscInt          *pivots, *ia_new, *ja_new;
+  PetscScalar       *a_new;
+  long long          nnz;
+  PetscFunctionBegin;
+  PetscCall(MatGetSize(R_loc, &p, &d));
+  PetscCall(MatGetRowIJ(K_loc, 0, PETSC_FALSE, PETSC_FALSE, &p, &ia, &ja, &done));
+  PetscCheck(done, PETSC_COMM_SELF, PETSC_ERR_SUP, "K_loc must be MATSEQAIJ");
+  PetscCall(MatSeqAIJGetArrayRead(K_loc, &a));
+  PetscCall(MatDenseGetArrayRead(R_loc, &r));
+  nz = ia[p];
+  PetscCall(PetscMalloc4(d, &pivots, p + 1, &ia_new, nz + d * d, &ja_new, nz + d * d, &a_new));
+  /* PetscInt must be 32 bit (the library's index type), as for pmh_csr_create */
+  PMHCall(pmh_mat_regularize_csr((int)p, (const int *)ia, (const int *)ja, a, (int)d, r, rho, (int *)pivots, (int *)ia_new, (int *)ja_new, a_new, &nnz));
+  PetscCall(MatCreateSeqAIJWithArrays(PETSC_COMM_SELF, p, p, ia_new, ja_new, a_new, Kreg_loc)); /* ownership of the arrays: see MatSeqAIJ docs */
+  PetscCall(MatDenseRestoreArrayRead(R_loc, &r));
+  PetscCall(MatSeqAIJRestoreArrayRead(K_loc, &a));
+  PetscCall(MatRestoreRowIJ(K_loc, 0, PETSC_FALSE, PETSC_FALSE, &p, &ia, &ja, &done));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 /* registration: called from PermonInitialize next to QPSRegisterAll (src/sys/permoninit.c:86-88) */
 PERMON_EXTERN PetscErrorCode PermonHipRegisterAll(void)
 {
