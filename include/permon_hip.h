@@ -83,6 +83,7 @@ int pmh_csr_sizes(pmh_csr A, int *nrows, int *ncols, long long *nnz);
 int pmh_csr_mult(pmh_csr A, const double *x, double *y);                       /* y = A x       */
 int pmh_csr_mult_add(pmh_csr A, const double *x, const double *y1, double *y);  /* y = y1 + A x  */
 int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y);             /* y = A' x      */
+int pmh_csr_mult_transpose_add(pmh_csr A, const double *x, const double *y1, double *y); /* y = y1 + A' x */
 int pmh_csr_algorithmic_bytes(pmh_csr A, double *bytes);                        /* 12 nnz + 20 nrows */
 /* per-launch kernel timing with HIP events on the launch stream (bench.py's roofline leg): every SpMV launch of A
    is bracketed by an event pair while enabled; `epilogue` selects 0 plain, 1 mult-add, 2 fused "-b", 3 fused MPGP phase P1 */
@@ -217,6 +218,8 @@ int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leaves, const in
 int pmh_gluing_destroy(pmh_gluing B);
 int pmh_gluing_mult(pmh_gluing B, const double *lambda, double *x);
 int pmh_gluing_mult_transpose(pmh_gluing B, const double *x, double *lambda);
+int pmh_gluing_mult_add(pmh_gluing B, const double *lambda, const double *x1, double *x);                 /* MatMultAdd_Gluing gluing.c:85-123 */
+int pmh_gluing_mult_transpose_add(pmh_gluing B, const double *x, const double *lambda1, double *lambda); /* MatMultTransposeAdd_Gluing :163-199 */
 
 /* MATEXTENSION (src/mat/impls/extension/extension.c, the reference's DEFAULT gluing matrix type, qpfeti.c:825-831):
    TA = scatter(ris) * A * gather(cis) with a condensed local CSR A (n_ris x n_cis).
@@ -228,6 +231,8 @@ int pmh_extension_create(pmh_ctx ctx, int n_r, int n_c, pmh_csr A, const int *ri
 int pmh_extension_destroy(pmh_extension TA);
 int pmh_extension_mult(pmh_extension TA, const double *c, double *r);
 int pmh_extension_mult_transpose(pmh_extension TA, const double *r, double *c);
+int pmh_extension_mult_add(pmh_extension TA, const double *c, const double *r1, double *r);           /* MatMultAdd_Extension extension.c:493-506 */
+int pmh_extension_mult_transpose_add(pmh_extension TA, const double *r, const double *c1, double *c); /* MatMultTransposeAdd_Extension :527-540 */
 
 /* MATBLOCKDIAG (src/mat/impls/blockdiag/matblockdiag.c:190-201): the rank's sequential blocks.
    Several subdomains per GPU (BASELINE configs[3]) are stored as ONE concatenated CSR + block offsets. */
@@ -235,6 +240,9 @@ typedef struct pmh_blockdiag_s *pmh_blockdiag;
 int pmh_blockdiag_create(pmh_ctx ctx, int nblocks, const int *block_rowstart /* nblocks+1 */, pmh_csr Kcat, pmh_blockdiag *K);
 int pmh_blockdiag_destroy(pmh_blockdiag K);
 int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y);
+int pmh_blockdiag_mult_transpose(pmh_blockdiag K, const double *x, double *y);                        /* matblockdiag.c:205-216 */
+int pmh_blockdiag_mult_add(pmh_blockdiag K, const double *x, const double *y1, double *y);            /* :220-233, y1 may be y */
+int pmh_blockdiag_mult_transpose_add(pmh_blockdiag K, const double *x, const double *y1, double *y);  /* :237-250 */
 
 /* MATINV apply (src/mat/impls/inv/matinv.c:734-743) on the iterative path the reference takes for a
    non-factorisable inner matrix (KSPCG + PCNONE/PCJACOBI per block, matinv.c:535-540): block-wise

@@ -101,6 +101,7 @@ _PROTOS = {
     "pmh_csr_mult": [vp, vp, vp],
     "pmh_csr_mult_add": [vp, vp, vp, vp],
     "pmh_csr_mult_transpose": [vp, vp, vp],
+    "pmh_csr_mult_transpose_add": [vp, vp, vp, vp],
     "pmh_csr_algorithmic_bytes": [vp, c_double_p],
     "pmh_csr_timing_enable": [vp, C.c_int],
     "pmh_csr_timing_get": [vp, C.c_int, c_int_p, c_double_p],
@@ -155,13 +156,20 @@ _PROTOS = {
     "pmh_gluing_destroy": [vp],
     "pmh_gluing_mult": [vp, vp, vp],
     "pmh_gluing_mult_transpose": [vp, vp, vp],
+    "pmh_gluing_mult_add": [vp, vp, vp, vp],
+    "pmh_gluing_mult_transpose_add": [vp, vp, vp, vp],
     "pmh_extension_create": [vp, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)],
     "pmh_extension_destroy": [vp],
     "pmh_extension_mult": [vp, vp, vp],
     "pmh_extension_mult_transpose": [vp, vp, vp],
+    "pmh_extension_mult_add": [vp, vp, vp, vp],
+    "pmh_extension_mult_transpose_add": [vp, vp, vp, vp],
     "pmh_blockdiag_create": [vp, C.c_int, vp, vp, C.POINTER(vp)],
     "pmh_blockdiag_destroy": [vp],
     "pmh_blockdiag_mult": [vp, vp, vp],
+    "pmh_blockdiag_mult_transpose": [vp, vp, vp],
+    "pmh_blockdiag_mult_add": [vp, vp, vp, vp],
+    "pmh_blockdiag_mult_transpose_add": [vp, vp, vp, vp],
     "pmh_matinv_create": [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_matinv_destroy": [vp],
     "pmh_matinv_set_nullspace": [vp, C.c_int, vp],

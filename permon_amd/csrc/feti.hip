@@ -23,6 +23,7 @@ struct pmh_gluing_s {
   pmh_ctx ctx;
   int     n_x, n_lambda, n_leaves;
   pmh_csr B, Bt;
+  double *d_tmp; // n_lambda scratch of mult_transpose_add on several GPUs (lazy)
 };
 
 extern "C" int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leaves, const int *leaves_row, const int *leaves_root, const double *leaves_sign, pmh_gluing *out)
@@ -49,7 +50,7 @@ extern "C" int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leave
   };
   pmh_gluing g = new pmh_gluing_s();
   g->ctx = ctx, g->n_x = n_x, g->n_lambda = n_lambda, g->n_leaves = n_leaves;
-  g->B = g->Bt = nullptr;
+  g->B = g->Bt = nullptr, g->d_tmp = nullptr;
   PMH_CHK(build(n_lambda, n_x, leaves_root, leaves_row, &g->B));
   PMH_CHK(build(n_x, n_lambda, leaves_row, leaves_root, &g->Bt));
   *out = g;
@@ -61,6 +62,7 @@ extern "C" int pmh_gluing_destroy(pmh_gluing g)
   if (!g) return PMH_SUCCESS;
   pmh_csr_destroy(g->B);
   pmh_csr_destroy(g->Bt);
+  if (g->d_tmp) pmh_free(g->ctx, g->d_tmp);
   delete g;
   return PMH_SUCCESS;
 }
@@ -78,6 +80,26 @@ extern "C" int pmh_gluing_mult_transpose(pmh_gluing g, const double *x, double *
   PMH_ARG(g);
   PMH_CHK(pmh_csr_mult(g->B, x, lambda));
   return pmh_comm_allreduce_sum(g->ctx, lambda, (size_t)g->n_lambda);
+}
+
+// MatMultAdd_Gluing gluing.c:85-123: x = x1 + B' lambda (the reference forms B' lambda, then VecAXPY(left,1,add))
+extern "C" int pmh_gluing_mult_add(pmh_gluing g, const double *lambda, const double *x1, double *x)
+{
+  PMH_ARG(g && x1);
+  return pmh_csr_mult_add(g->Bt, lambda, x1, x);
+}
+
+// MatMultTransposeAdd_Gluing gluing.c:163-199: lambda = lambda1 + B x; with several GPUs only the B x part is summed over the ranks
+extern "C" int pmh_gluing_mult_transpose_add(pmh_gluing g, const double *x, const double *lambda1, double *lambda)
+{
+  PMH_ARG(g && lambda1);
+  int rank = 0, size = 1;
+  PMH_CHK(pmh_comm_rank(g->ctx, &rank, &size));
+  if (size == 1) return pmh_csr_mult_add(g->B, x, lambda1, lambda);
+  if (!g->d_tmp) PMH_CHK(pmh_malloc(g->ctx, sizeof(double) * (size_t)(g->n_lambda ? g->n_lambda : 1), (void **)&g->d_tmp));
+  PMH_CHK(pmh_csr_mult(g->B, x, g->d_tmp));
+  PMH_CHK(pmh_comm_allreduce_sum(g->ctx, g->d_tmp, (size_t)g->n_lambda));
+  return pmh_vec_waxpy(g->ctx, g->n_lambda, lambda, 1.0, g->d_tmp, lambda1);
 }
 
 // ---- MATEXTENSION ----------------------------------------------------------------------------------------------------
@@ -165,6 +187,32 @@ extern "C" int pmh_extension_mult_transpose(pmh_extension T, const double *r, do
   return PMH_SUCCESS;
 }
 
+// MatMultAdd_Extension extension.c:493-506: r = r1 + TA c (VecCopy(r1,r) then the same gather / mult / scatter-add)
+extern "C" int pmh_extension_mult_add(pmh_extension T, const double *c, const double *r1, double *r)
+{
+  PMH_ARG(T && r1);
+  hipStream_t st = T->ctx->stream;
+  if (r1 != r) PMH_CHK(pmh_memcpy_d2d(T->ctx, r, r1, sizeof(double) * (size_t)T->n_r));
+  if (T->nc_loc) hipLaunchKernelGGL(k_gather, EXT_GRID(T->nc_loc), dim3(PMH_BLOCK), 0, st, T->nc_loc, (const int *)T->d_cis, c, T->cwork);
+  PMH_CHK(pmh_csr_mult(T->A, T->cwork, T->rwork));
+  if (T->nr_loc) hipLaunchKernelGGL(k_scatter_add, EXT_GRID(T->nr_loc), dim3(PMH_BLOCK), 0, st, T->nr_loc, (const int *)T->d_ris, (const double *)T->rwork, r);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+// MatMultTransposeAdd_Extension extension.c:527-540: c = c1 + TA' r
+extern "C" int pmh_extension_mult_transpose_add(pmh_extension T, const double *r, const double *c1, double *c)
+{
+  PMH_ARG(T && c1);
+  hipStream_t st = T->ctx->stream;
+  if (c1 != c) PMH_CHK(pmh_memcpy_d2d(T->ctx, c, c1, sizeof(double) * (size_t)T->n_c));
+  if (T->nr_loc) hipLaunchKernelGGL(k_gather, EXT_GRID(T->nr_loc), dim3(PMH_BLOCK), 0, st, T->nr_loc, (const int *)T->d_ris, r, T->rwork);
+  PMH_CHK(pmh_csr_mult_transpose(T->A, T->rwork, T->cwork));
+  if (T->nc_loc) hipLaunchKernelGGL(k_scatter_add, EXT_GRID(T->nc_loc), dim3(PMH_BLOCK), 0, st, T->nc_loc, (const int *)T->d_cis, (const double *)T->cwork, c);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
 // ---- MATBLOCKDIAG ---------------------------------------------------------------------------------------------------
 struct pmh_blockdiag_s {
   pmh_ctx          ctx;
@@ -202,6 +250,25 @@ extern "C" int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y)
 {
   PMH_ARG(K);
   return pmh_csr_mult(K->K, x, y);
+}
+
+// MatMultTranspose_BlockDiag :205-216, MatMultAdd_BlockDiag :220-233 (y1 may be y), MatMultTransposeAdd_BlockDiag :237-250
+extern "C" int pmh_blockdiag_mult_transpose(pmh_blockdiag K, const double *x, double *y)
+{
+  PMH_ARG(K);
+  return pmh_csr_mult_transpose(K->K, x, y);
+}
+
+extern "C" int pmh_blockdiag_mult_add(pmh_blockdiag K, const double *x, const double *y1, double *y)
+{
+  PMH_ARG(K);
+  return pmh_csr_mult_add(K->K, x, y1, y);
+}
+
+extern "C" int pmh_blockdiag_mult_transpose_add(pmh_blockdiag K, const double *x, const double *y1, double *y)
+{
+  PMH_ARG(K);
+  return pmh_csr_mult_transpose_add(K->K, x, y1, y);
 }
 
 // ---- MATINV: block-wise CG -------------------------------------------------------------------------------------------

@@ -618,3 +618,11 @@ extern "C" int pmh_csr_mult_transpose(pmh_csr A, const double *x, double *y)
   if (!A->transpose) PMH_CHK(build_transpose(A));
   return pmh_csr_mult(A->transpose, x, y);
 }
+
+// MatMultTransposeAdd: y = y1 + A' x (y1 may be y)
+extern "C" int pmh_csr_mult_transpose_add(pmh_csr A, const double *x, const double *y1, double *y)
+{
+  PMH_ARG(A);
+  if (!A->transpose) PMH_CHK(build_transpose(A));
+  return pmh_csr_mult_add(A->transpose, x, y1, y);
+}

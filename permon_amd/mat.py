@@ -28,6 +28,12 @@ class MatGluing:
     def mult_transpose(self, x, lam):  # MatMultTranspose_Gluing: lambda = B x (+ all-reduce across GPUs)
         check(self.ctx.L.pmh_gluing_mult_transpose(self.h, x.p, lam.p))
 
+    def mult_add(self, lam, x1, x):  # MatMultAdd_Gluing: x = x1 + B' lambda
+        check(self.ctx.L.pmh_gluing_mult_add(self.h, lam.p, x1.p, x.p))
+
+    def mult_transpose_add(self, x, lam1, lam):  # MatMultTransposeAdd_Gluing: lambda = lambda1 + B x
+        check(self.ctx.L.pmh_gluing_mult_transpose_add(self.h, x.p, lam1.p, lam.p))
+
     def destroy(self):
         if self.h:
             self.ctx.L.pmh_gluing_destroy(self.h)
@@ -51,6 +57,12 @@ class MatExtension:
 
     def mult_transpose(self, r, c):  # MatMultTranspose_Extension
         check(self.ctx.L.pmh_extension_mult_transpose(self.h, r.p, c.p))
+
+    def mult_add(self, c, r1, r):  # MatMultAdd_Extension: r = r1 + TA c
+        check(self.ctx.L.pmh_extension_mult_add(self.h, c.p, r1.p, r.p))
+
+    def mult_transpose_add(self, r, c1, c):  # MatMultTransposeAdd_Extension: c = c1 + TA' r
+        check(self.ctx.L.pmh_extension_mult_transpose_add(self.h, r.p, c1.p, c.p))
 
     def destroy(self):
         if self.h:
@@ -77,6 +89,15 @@ class MatBlockDiag:
 
     def mult(self, x, y):  # MatMult_BlockDiag
         check(self.ctx.L.pmh_blockdiag_mult(self.h, x.p, y.p))
+
+    def mult_transpose(self, x, y):  # MatMultTranspose_BlockDiag
+        check(self.ctx.L.pmh_blockdiag_mult_transpose(self.h, x.p, y.p))
+
+    def mult_add(self, x, y1, y):  # MatMultAdd_BlockDiag (y1 may be y)
+        check(self.ctx.L.pmh_blockdiag_mult_add(self.h, x.p, y1.p, y.p))
+
+    def mult_transpose_add(self, x, y1, y):  # MatMultTransposeAdd_BlockDiag
+        check(self.ctx.L.pmh_blockdiag_mult_transpose_add(self.h, x.p, y1.p, y.p))
 
     def destroy(self):
         if self.h:

@@ -304,3 +304,48 @@ def test_contact_tfeti_end_to_end_properties(ctx):
     gap = f.c[f.n_eq:] - Bu[f.n_eq:]
     assert np.abs(lam[f.n_eq:] * gap).max() <= 1e-3 * scale * np.abs(lam).max()  # complementarity
     assert (lam[f.n_eq:] > 0).sum() > 100  # a genuine contact zone
+
+
+def test_mat_add_and_transpose_slots(ctx):
+    """The remaining Mat op slots the reference fills (multadd / multtranspose / multtransposeadd of MATBLOCKDIAG
+    matblockdiag.c:743-746, MATGLUING gluing.c:281-284, MATEXTENSION extension.c:1115-1118), incl. the in-place form."""
+    rng = np.random.default_rng(21)
+    f = pa.CubeFeti((2, 2, 1), 2, contact=True)
+    N, nl = f.N, f.n_lambda
+    # a non-symmetric block-diagonal matrix so that the transpose slots are really exercised
+    blocks = [sp.random(f.n_i, f.n_i, density=0.05, random_state=5 + s, format="csr") + sp.identity(f.n_i) for s in range(f.nsub)]
+    Kd = sp.block_diag(blocks, format="csr")
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Kd)
+    x, y1 = rng.standard_normal(N), rng.standard_normal(N)
+    xd, y1d, yd = ctx.vec_from(x), ctx.vec_from(y1), ctx.vec(N)
+    K.mult_transpose(xd, yd)
+    assert np.allclose(yd.to_numpy(), Kd.T @ x, rtol=1e-13, atol=1e-13)
+    K.mult_add(xd, y1d, yd)
+    assert np.allclose(yd.to_numpy(), y1 + Kd @ x, rtol=1e-13, atol=1e-13)
+    K.mult_transpose_add(xd, y1d, yd)
+    assert np.allclose(yd.to_numpy(), y1 + Kd.T @ x, rtol=1e-13, atol=1e-13)
+    yin = ctx.vec_from(y1)
+    K.mult_add(xd, yin, yin)  # v2 can be the same as v3 (matblockdiag.c:227)
+    assert np.allclose(yin.to_numpy(), y1 + Kd @ x, rtol=1e-13, atol=1e-13)
+    # gluing
+    Bg = pa.MatGluing(ctx, N, nl, f.leaves_row, f.leaves_root, f.leaves_sign)
+    lam, l1 = rng.standard_normal(nl), rng.standard_normal(nl)
+    out_x, out_l = ctx.vec(N), ctx.vec(nl)
+    Bg.mult_add(ctx.vec_from(lam), y1d, out_x)
+    assert np.allclose(out_x.to_numpy(), y1 + f.B.T @ lam, rtol=1e-13, atol=1e-13)
+    Bg.mult_transpose_add(xd, ctx.vec_from(l1), out_l)
+    assert np.allclose(out_l.to_numpy(), l1 + f.B @ x, rtol=1e-13, atol=1e-13)
+    # extension: same operator through the condensed CSR + index sets
+    Bt = f.B.T.tocsr()
+    ris = np.flatnonzero(np.diff(Bt.indptr) > 0).astype(np.int32)
+    Acond = Bt[ris].tocsr()
+    Acond.sort_indices()
+    A = pa.CsrMat(ctx, Acond.shape[0], Acond.shape[1], Acond.indptr, Acond.indices, Acond.data)
+    TA = pa.MatExtension(ctx, N, nl, A, ris, np.arange(nl, dtype=np.int32))
+    TA.mult_add(ctx.vec_from(lam), y1d, out_x)
+    assert np.allclose(out_x.to_numpy(), y1 + f.B.T @ lam, rtol=1e-13, atol=1e-13)
+    TA.mult_transpose_add(xd, ctx.vec_from(l1), out_l)
+    assert np.allclose(out_l.to_numpy(), l1 + f.B @ x, rtol=1e-13, atol=1e-13)
+    xin = ctx.vec_from(y1)
+    TA.mult_add(ctx.vec_from(lam), xin, xin)
+    assert np.allclose(xin.to_numpy(), y1 + f.B.T @ lam, rtol=1e-13, atol=1e-13)
