@@ -304,6 +304,16 @@ static int bsr3_launch(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi
   else BSR_W(512);
   if (timed) {
     PMH_HIP(hipEventRecord(B->ev[B->ev_used + 1], st));
+    // operands of the fused epilogue beyond y = A x (one vector = n entries of the arithmetic type):
+    // ADD/SUB read y1; PRE reads dinv, b; POST1 reads dinv, b and writes r, d; POST2 re-reads y, reads r, dinv (+ the fp64 copy)
+    const double vec = (double)sizeof(T) * B->n;
+    double       ex  = 0.0;
+    if (epi == PMH_EPI_ADD || epi == PMH_EPI_SUB) ex = vec;
+    else if (epi == PMH_BSR_EPI_PRE) ex = 2.0 * vec;
+    else if (epi == PMH_BSR_EPI_POST1) ex = 4.0 * vec;
+    else if (epi == PMH_BSR_EPI_POST2) ex = 3.0 * vec + (e.z64 ? 8.0 * B->n : 0.0);
+    if (B->ev_extra.size() < B->ev.size() / 2) B->ev_extra.resize(B->ev.size() / 2, 0.0);
+    B->ev_extra[B->ev_used / 2] = ex;
     B->ev_used += 2;
   }
   return PMH_SUCCESS;
@@ -354,7 +364,7 @@ int pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches)
 }
 
 // launches whose duration is below a quarter of the longest are halted no-ops and are not counted
-int pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms)
+int pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms, double *epilogue_bytes)
 {
   PMH_ARG(B && launches && total_ms);
   PMH_HIP(hipStreamSynchronize(B->ctx->stream));
@@ -365,7 +375,9 @@ int pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms)
     mx = std::max(mx, ms[i]);
   }
   *launches = 0, *total_ms = 0.0;
-  for (float m : ms)
-    if (m >= 0.25f * mx) (*launches)++, *total_ms += m;
+  double ex = 0.0;
+  for (size_t i = 0; i < ms.size(); i++)
+    if (ms[i] >= 0.25f * mx) (*launches)++, *total_ms += ms[i], ex += (i < B->ev_extra.size() ? B->ev_extra[i] : 0.0);
+  if (epilogue_bytes) *epilogue_bytes = ex; // summed over the counted launches
   return PMH_SUCCESS;
 }

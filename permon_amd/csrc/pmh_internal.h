@@ -132,6 +132,7 @@ struct pmh_bsr3_s {
   long long *d_tile_off;
   void     *d_val;
   std::vector<hipEvent_t> ev; // optional per-launch timing (event pairs on the launch stream)
+  std::vector<double>     ev_extra; // bytes of the fused epilogue's own operands of every timed launch
   int                     ev_used, ev_on, ev_seen, ev_stride;
 };
 typedef pmh_bsr3_s *pmh_bsr3;
@@ -153,7 +154,7 @@ int    pmh_bsr3_spmv_f32(pmh_bsr3 B, const float *x, float *y, int epi, const fl
 int    pmh_bsr3_spmv_epi_f64(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt);
 int    pmh_bsr3_spmv_epi_f32(pmh_bsr3 B, const float *x, float *y, int epi, const pmh_bsr3_epi<float> &e, const int *halt);
 int    pmh_bsr3_timing_enable(pmh_bsr3 B, int max_launches);
-int    pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms);
+int    pmh_bsr3_timing_get(pmh_bsr3 B, int *launches, double *total_ms, double *epilogue_bytes = nullptr);
 int    pmh_csr_ensure_transpose(pmh_csr A); // builds A->transpose if missing
 
 // ---- multigrid preconditioner (mg.hip) -------------------------------------------------------------------------
