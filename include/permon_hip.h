@@ -270,6 +270,15 @@ int pmh_mat_regularization_Q(int p, int d, const double *R_host, const int *pivo
 int pmh_mat_regularize_csr(int n, const int *rowptr, const int *col, const double *val, int d, const double *R_host, double rho, int *pivots_out, int *rowptr_out, int *col_out,
                            double *val_out, long long *nnz_out);
 
+/* QPFetiGetBgtSF (src/qp/impls/feti/qpfeti.c:465-925): the signed gluing matrix of a decomposition from the subdomains' local-to-
+   global dof maps (concatenated; l2g_start[nsub+1]).  type 0 nonred / 1 full / 2 orth (FetiGluingType), scale = -SCALE_ON
+   (qpfeti.c:757-758), exclude = sorted global dofs left out (-feti_gluing_exclude_dirichlet).  Copies are ordered by subdomain
+   index, links by ascending global dof; the leaves come out grouped by link in the summation order of MatMultTranspose_Gluing and
+   feed pmh_gluing_create directly (leaves_row = position in the concatenated local numbering).  Host routine (integer set-up,
+   runs once).  leaves_* NULL: counts only. */
+int pmh_feti_gluing_from_l2g(int nsub, const int *l2g_start, const int *l2g, int type, int scale, int n_exclude, const int *exclude, int *n_lambda, int *n_leaves, int *leaves_row,
+                             int *leaves_root, double *leaves_val);
+
 /* F = B K^+ B' (QPTDualize qptransform.c:1103-1128; MatCreateProd matprod.c:42-48) */
 int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
 /* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */

@@ -178,6 +178,7 @@ _PROTOS = {
     "pmh_mat_regularize_pivots": [C.c_int, C.c_int, vp, vp],
     "pmh_mat_regularization_Q": [C.c_int, C.c_int, vp, vp, vp, vp],
     "pmh_mat_regularize_csr": [C.c_int, vp, vp, vp, C.c_int, vp, C.c_double, vp, vp, vp, vp, C.POINTER(C.c_longlong)],
+    "pmh_feti_gluing_from_l2g": [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, c_int_p, c_int_p, vp, vp, vp],
     "pmh_op_create_feti_dual": [vp, vp, C.POINTER(vp)],
     "pmh_pc_dual_lumped_apply": [vp, vp, vp, vp],
     "pmh_qpt_feti_chain_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],

@@ -183,3 +183,72 @@ extern "C" int pmh_mat_regularize_csr(int n, const int *rowptr, const int *col, 
   *nnz_out = nz;
   return PMH_SUCCESS;
 }
+
+// ---- QPFetiGetBgtSF (src/qp/impls/feti/qpfeti.c:465-925): the signed gluing matrix B_g of a decomposition ----------------------
+// Input: the local-to-global dof maps of the nsub subdomains ("ranks" of the reference: one sequential block per rank,
+// matblockdiag.c:787-788), concatenated; a global dof that appears in m >= 2 subdomains has m copies, ordered by subdomain index
+// (PetscSFSetRankOrder :507,598).  Links (rows of B_g, the dual unknowns) are numbered root by root in ascending global dof
+// (:636-688 with the sorted i2g of qptransform.c:2118), within a root in the order the reference assigns them:
+//   nonred (:643-648)  m-1 links, copy 0 against copy k;          full (:650-657)  the m(m-1)/2 pairs (i, k > i), i outer;
+//   both: +1 on the lower, -1 on the highest rank of the link (:786-806), times 1/sqrt(m) with -SCALE_ON (the default);
+//   orth (:659-667, :700-716, :807-817)  m-1 orthonormal links: link k couples copies 0..d-1 (value 1/d) with copy d = m-1-k
+//   (value -1), all divided by sqrt(1/d + 1).
+// Output: the leaves (local dof in the concatenated numbering, link, value) grouped by link, copies in rank order -- the order
+// MatMultTranspose_Gluing's PetscSFReduce sums them in.  exclude: sorted global dofs left out (-feti_gluing_exclude_dirichlet,
+// qpfeti.c:423-431).  leaves_* may be NULL: only the counts are returned (first of two calls).
+extern "C" int pmh_feti_gluing_from_l2g(int nsub, const int *l2g_start, const int *l2g, int type, int scale, int n_exclude, const int *exclude, int *n_lambda, int *n_leaves, int *leaves_row,
+                                        int *leaves_root, double *leaves_val)
+{
+  PMH_ARG(nsub >= 1 && l2g_start && n_lambda && n_leaves && (type >= 0 && type <= 2) && (n_exclude == 0 || exclude));
+  PMH_ARG(l2g_start[0] == 0 && (l2g_start[nsub] == 0 || l2g));
+  if (type < 0 || type > 2) return pmh_set_error(PMH_ERR_ARG, "Unknown FETI gluing type"); // qpfeti.c:561
+  const int ntot = l2g_start[nsub];
+  // (global dof, subdomain, local position) sorted by global dof, then subdomain: the copies of every root in rank order
+  struct Copy {
+    int g, s, loc;
+  };
+  std::vector<Copy> cp;
+  cp.reserve((size_t)ntot);
+  for (int s = 0; s < nsub; s++) {
+    PMH_ARG(l2g_start[s + 1] >= l2g_start[s]);
+    for (int i = l2g_start[s]; i < l2g_start[s + 1]; i++) {
+      if (l2g[i] < 0) return pmh_set_error(PMH_ERR_ARG, "pmh_feti_gluing_from_l2g: negative global index at position %d", i);
+      cp.push_back({l2g[i], s, i});
+    }
+  }
+  std::stable_sort(cp.begin(), cp.end(), [](const Copy &a, const Copy &b) { return a.g != b.g ? a.g < b.g : a.s < b.s; });
+  for (size_t i = 1; i < cp.size(); i++)
+    if (cp[i].g == cp[i - 1].g && cp[i].s == cp[i - 1].s) return pmh_set_error(PMH_ERR_ARG, "pmh_feti_gluing_from_l2g: global dof %d appears twice in subdomain %d", cp[i].g, cp[i].s);
+  for (int i = 1; i < n_exclude; i++) PMH_ARG(exclude[i] > exclude[i - 1]);
+  long long nl = 0, nleaf = 0;
+  const bool fill = leaves_row && leaves_root && leaves_val;
+  auto emit = [&](int row, long long link, double v) {
+    if (fill) leaves_row[nleaf] = row, leaves_root[nleaf] = (int)link, leaves_val[nleaf] = v;
+    nleaf++;
+  };
+  for (size_t a = 0; a < cp.size();) {
+    size_t b = a;
+    while (b < cp.size() && cp[b].g == cp[a].g) b++;
+    const int m = (int)(b - a);
+    if (m >= 2 && !(n_exclude && std::binary_search(exclude, exclude + n_exclude, cp[a].g))) {
+      const double sc = scale ? 1.0 / sqrt((double)m) : 1.0;
+      if (type == 0) {
+        for (int k = 1; k < m; k++, nl++) emit(cp[a].loc, nl, sc), emit(cp[a + k].loc, nl, -sc);
+      } else if (type == 1) {
+        for (int i = 0; i < m - 1; i++)
+          for (int k = i + 1; k < m; k++, nl++) emit(cp[a + i].loc, nl, sc), emit(cp[a + k].loc, nl, -sc);
+      } else {
+        for (int k = 0; k < m - 1; k++, nl++) {
+          const int    d = m - 1 - k;
+          const double x = sqrt(1.0 / d + 1.0);
+          for (int t = 0; t < d; t++) emit(cp[a + t].loc, nl, 1.0 / d / x);
+          emit(cp[a + d].loc, nl, -1.0 / x);
+        }
+      }
+    }
+    a = b;
+  }
+  if (nl > 0x7fffffffLL || nleaf > 0x7fffffffLL) return pmh_set_error(PMH_ERR_SUP, "pmh_feti_gluing_from_l2g: more than 2^31-1 links or leaves");
+  *n_lambda = (int)nl, *n_leaves = (int)nleaf;
+  return PMH_SUCCESS;
+}

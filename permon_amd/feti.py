@@ -94,6 +94,29 @@ def gluing_links(m, gtype="full", scale=True):
     raise ValueError("unknown FETI gluing type %r" % gtype)  # qpfeti.c:561
 
 
+def gluing_from_l2g(l2g_list, gtype="full", scale=True, exclude=None):
+    """QPFetiGetBgtSF (src/qp/impls/feti/qpfeti.c:465-925) for a decomposition given by the subdomains' local-to-global dof maps:
+    returns (leaves_row, leaves_root, leaves_val, n_lambda) with leaves_row indexing the concatenated local numbering.
+    Thin wrapper of pmh_feti_gluing_from_l2g (csrc/regularize.hip); exclude: global dofs left out of the gluing."""
+    import ctypes as C
+
+    from . import _lib
+
+    L = _lib.load()
+    tcode = {"nonred": 0, "full": 1, "orth": 2}
+    if gtype not in tcode:
+        raise ValueError("unknown FETI gluing type %r" % gtype)  # qpfeti.c:561
+    start = np.concatenate([[0], np.cumsum([len(g) for g in l2g_list])]).astype(np.int32)
+    cat = np.ascontiguousarray(np.concatenate(l2g_list) if len(l2g_list) else np.zeros(0), dtype=np.int32)
+    ex = np.ascontiguousarray(np.unique(exclude), dtype=np.int32) if exclude is not None and len(exclude) else np.zeros(0, dtype=np.int32)
+    nl, nleaf = C.c_int(), C.c_int()
+    args = (len(l2g_list), start.ctypes.data_as(C.c_void_p), cat.ctypes.data_as(C.c_void_p), tcode[gtype], int(bool(scale)), ex.size, ex.ctypes.data_as(C.c_void_p) if ex.size else None)
+    _lib.check(L.pmh_feti_gluing_from_l2g(*args, C.byref(nl), C.byref(nleaf), None, None, None))
+    rows, roots, vals = np.zeros(nleaf.value, dtype=np.int32), np.zeros(nleaf.value, dtype=np.int32), np.zeros(nleaf.value)
+    _lib.check(L.pmh_feti_gluing_from_l2g(*args, C.byref(nl), C.byref(nleaf), rows.ctypes.data_as(C.c_void_p), roots.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p)))
+    return rows, roots, vals, nl.value
+
+
 class CubeFeti:
     """TFETI data for sx x sy x sz unit cubes of nel^3 Q1 elements each.
 
@@ -375,22 +398,9 @@ class DmdaFeti:
         self.block_rowstart = np.concatenate([[0], np.cumsum([K.shape[0] for K in Ks])]).astype(np.int32)
         self.N = int(self.block_rowstart[-1])
         self.f = np.concatenate(fs)
-        copies = {}
-        for s, g in enumerate(gids):
-            for ln, gg in enumerate(g):
-                copies.setdefault(int(gg), []).append((s, ln))
-        rows_l, roots_l, vals_l = [], [], []
-        nrow = 0
-        for gg in sorted(copies):
-            cp = copies[gg]
-            for c in range(nd):  # the reference numbers the dofs node-major, so the links of one node are interleaved by component
-                for link in gluing_links(len(cp), gluing, scale):
-                    for t, v in link:
-                        sa, la = cp[t]
-                        rows_l.append(int(self.block_rowstart[sa]) + la * nd + c)
-                        roots_l.append(nrow)
-                        vals_l.append(v)
-                    nrow += 1
+        # gluing: QPFetiGetBgtSF on the dof-level local-to-global maps (node-major dofs), pmh_feti_gluing_from_l2g (C++)
+        l2g = [(np.asarray(g)[:, None] * nd + np.arange(nd)[None, :]).ravel() for g in gids]
+        rows_l, roots_l, vals_l, nrow = gluing_from_l2g(l2g, gluing, scale)
         self.n_lambda = self.n_eq = nrow
         self.leaves_row = np.asarray(rows_l, dtype=np.int32)
         self.leaves_root = np.asarray(roots_l, dtype=np.int32)

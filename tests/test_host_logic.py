@@ -82,3 +82,46 @@ def test_oracle_matinv_and_feti_operator(oracle):
     Fd = Bd @ Kp @ Bd.T
     ref = pf.P(Fd @ pf.P(x)) + 0.7 * pf.Q(x)
     assert np.linalg.norm(Fo.op(x) - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_gluing_from_l2g_matches_the_link_rules():
+    """pmh_feti_gluing_from_l2g (C++, QPFetiGetBgtSF) against an independent statement of the same rules (gluing_links applied node
+    by node in ascending global dof): random partitions with dofs shared by up to 6 subdomains, all three gluing types, with and
+    without -SCALE_ON and with excluded (Dirichlet) dofs.  Index bookkeeping: exact."""
+    import numpy as np
+
+    from permon_amd.feti import gluing_from_l2g, gluing_links
+
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        nsub, nglob = int(rng.integers(2, 7)), int(rng.integers(20, 60))
+        l2g = []
+        for s in range(nsub):
+            g = np.flatnonzero(rng.random(nglob) < 0.55)
+            rng.shuffle(g)  # local numbering is not monotone in the global one (as for a DMDA's ghosted numbering)
+            l2g.append(g.astype(np.int32))
+        start = np.concatenate([[0], np.cumsum([len(g) for g in l2g])])
+        exclude = rng.choice(nglob, 4, replace=False) if trial % 2 else None
+        for gtype in ("nonred", "full", "orth"):
+            for scale in (True, False):
+                rows, roots, vals, nl = gluing_from_l2g(l2g, gtype, scale, exclude)
+                exp_rows, exp_roots, exp_vals, link = [], [], [], 0
+                for gg in range(nglob):
+                    if exclude is not None and gg in exclude:
+                        continue
+                    cp = [(s, int(np.flatnonzero(l2g[s] == gg)[0])) for s in range(nsub) if gg in l2g[s]]
+                    for lk in gluing_links(len(cp), gtype, scale):
+                        for t, v in lk:
+                            exp_rows.append(start[cp[t][0]] + cp[t][1]), exp_roots.append(link), exp_vals.append(v)
+                        link += 1
+                assert nl == link and rows.tolist() == exp_rows and roots.tolist() == exp_roots
+                assert np.array_equal(vals, np.asarray(exp_vals))
+    # a dof listed twice in one subdomain is an input error, reported
+    import pytest
+
+    from permon_amd import PermonHipError
+
+    with pytest.raises(PermonHipError):
+        gluing_from_l2g([np.array([0, 1, 1], dtype=np.int32), np.array([1, 2], dtype=np.int32)], "full")
+    with pytest.raises(ValueError):
+        gluing_from_l2g([np.array([0, 1], dtype=np.int32)], "bogus")
