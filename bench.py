@@ -82,14 +82,18 @@ def host_threads():
     return cores
 
 
-def pmc_traffic(prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/, scripts/gpu_pmc.sh)."""
+def pmc_traffic(prefix, fname="r01_pmc_traffic.json"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/, scripts/gpu_pmc*.sh): launch-weighted
+    mean over every kernel instantiation whose name starts with the prefix (e.g. the four epilogue variants of the V-cycle's
+    fine-level operator, which the live event timing samples in equal shares)."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for k, v in pmc.items():
-            if k.startswith(prefix):
-                return v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
+        hits = [v for k, v in pmc.items() if k.startswith(prefixes)]
+        if hits:
+            n = sum(v["launches"] for v in hits)
+            return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
         pass
     return None
 
@@ -385,13 +389,14 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     if hier is not None:
         n_k, ms_k, b_k = q.Kplus.mg.timing_get()
         kname = "k_bsr3<%s>: fine-level K x of the V-cycle (3x3 blocks, %s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[a.mg_precision]
-        kpat = {"fp16": "void k_bsr3<_Float16", "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[a.mg_precision]
+        kpat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[a.mg_precision]  # rocprofv3 leaves the _Float16 instantiations mangled
     else:
         n_k, ms_k, b_k = n_cg, ms_cg, b_cg
         kname = ("k_bsr3<double>: K x of the block CG (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
                  else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
     ms_all = ms_k + (ms_cg if hier is not None else 0.0)
+    stride = int(os.environ.get("PMH_TIMING_STRIDE", "1"))
     achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
     kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
     pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
@@ -409,12 +414,12 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "roofline": {
             "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(kpat) if (a.nel == 43 and world == 1) else None,
+            "traffic": pmc_traffic(kpat, "r01_h_pmc_traffic_feti.json") if (a.nel == 43 and world == 1 and not a.sim_world) else None,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
             "timing_stride": int(os.environ.get("PMH_TIMING_STRIDE", "1")),
             "timed_over": "the timed region" if timing_in_region else "a separate 2-step pass after the timed region (hipGraph replay inside it)",
-            "share_of_step_time": ((ms_k * 1e-3) / dt if n_k else None) if timing_in_region else None,
-            "all_fine_K_products": {"launches": n_k + (n_cg if hier is not None else 0), "share_of_step_time": ((ms_all * 1e-3) / dt if n_k else None) if timing_in_region else None,
+            "share_of_step_time": ((ms_k * 1e-3) * stride / dt if n_k else None) if timing_in_region else None,  # every stride-th launch is timed
+            "all_fine_K_products": {"launches_timed": n_k + (n_cg if hier is not None else 0), "share_of_step_time": ((ms_all * 1e-3) * stride / dt if n_k else None) if timing_in_region else None,
                                     "cg_product_GBps": (b_cg / (ms_cg / n_cg * 1e-3) / 1e9) if n_cg else None},
         },
     }

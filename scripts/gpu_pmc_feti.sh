@@ -8,7 +8,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 mkdir -p $R/gpurun_out/pmcf && rm -rf $R/gpurun_out/pmcf/pmc_FETCH_SIZE $R/gpurun_out/pmcf/pmc_WRITE_SIZE
 mv $R/gpurun_out/pmcf_FETCH_SIZE $R/gpurun_out/pmcf/pmc_FETCH_SIZE; mv $R/gpurun_out/pmcf_WRITE_SIZE $R/gpurun_out/pmcf/pmc_WRITE_SIZE
-python3 $R/scripts/pmc_parse.py $R/gpurun_out/pmcf
+python3 $R/scripts/pmc_parse.py $R/gpurun_out/pmcf && cp $R/gpurun_out/pmcf/pmc_traffic.json $R/gpurun_out/pmc_traffic_feti.json
 # keep only the summary (the per-dispatch CSVs are tens of MB)
 rm -rf $R/gpurun_out/pmcf/pmc_FETCH_SIZE $R/gpurun_out/pmcf/pmc_WRITE_SIZE
 # torch-first import check: libpermonhip must work on torch's bundled HIP runtime + RCCL (the N>1 launch path)
