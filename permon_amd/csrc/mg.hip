@@ -431,7 +431,10 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       // FP16: the fine-level operator (almost all of the cycle's bytes) stores fp16 entries; arithmetic and vectors stay fp32
       static const int f16_levels = getenv("PMH_MG_FP16_LEVELS") ? atoi(getenv("PMH_MG_FP16_LEVELS")) : 2; // fp16 entries on the two finest levels (measured: 22.2 -> 20.6 ms per step, same CG count; a third level gains nothing)
       const int storage = !fl ? PMH_BSR_F64 : ((precision == PMH_MG_FP16 && l < f16_levels) ? PMH_BSR_F16 : PMH_BSR_F32);
-      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab));
+      // coarser levels use 512-block tiles: twice the workgroups on operators that are too small to fill the chip, and a kernel
+      // instantiation of their own, so that profiler averages of the fine-level operator are not mixed with the coarse launches
+      static const int coarse_tile = getenv("PMH_MG_COARSE_TILE") ? atoi(getenv("PMH_MG_COARSE_TILE")) : 512;
+      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab, l == 0 ? 0 : coarse_tile));
       if (fl && !Lv.Ab) {
         pmh_mg_destroy(mg);
         return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32/FP16 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);

@@ -146,7 +146,7 @@ template <typename T> struct pmh_bsr3_epi {
   double  *z64;  // POST2: optional fp64 copy of the result
   T        c0, c1, c2;
 };
-int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out); // *out = NULL (no error) if A has no usable 3x3 block structure
+int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0); // *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default
 int    pmh_bsr3_destroy(pmh_bsr3 B);
 double pmh_bsr3_bytes(pmh_bsr3 B);
 int    pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt);

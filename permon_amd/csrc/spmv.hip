@@ -15,6 +15,8 @@
 //
 // Algorithmic bytes per SpMV: 12*nnz + 20*nrows (8 B value + 4 B column per non-zero; 4 B row pointer,
 // 8 B y write, 8 B compulsory x read per row).
+#include <algorithm>
+
 #include "pmh_internal.h"
 #include "reduce.h"
 
@@ -523,10 +525,15 @@ extern "C" int pmh_csr_timing_get(pmh_csr A, int epilogue, int *launches, double
     float ms = 0.f;
     PMH_HIP(hipEventElapsedTime(&ms, (*A->ev)[2 * i], (*A->ev)[2 * i + 1]));
     d.push_back(ms);
-    if (ms > mx) mx = ms;
+  }
+  if (!d.empty()) {
+    std::vector<float> srt(d);
+    std::sort(srt.begin(), srt.end());
+    mx = srt[(size_t)(0.75 * (double)(srt.size() - 1))];
   }
   // launches of a halted speculative chain return at once (no work, no bytes): they are not SpMVs and are
-  // left out of the average (anything below a quarter of the longest launch)
+  // left out of the average (anything below a quarter of the upper-quartile launch; not of the longest one: the first
+  // launch of a kernel in a process pays the code-object load)
   for (float ms : d)
     if (ms >= 0.25f * mx) {
       *total_ms += ms;
