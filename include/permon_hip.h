@@ -389,6 +389,33 @@ int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_qppf p
  * guess, pc NULL = PCNONE; stopping test QPSKSPConverged_KSP -> QPSConvergedDefault. */
 int pmh_ksp_cg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x, pmh_op pc, double rtol, double atol, double divtol, int max_it, pmh_pcpg_stats *st);
 
+/* ---- KSPFETI (src/ksp/impls/feti/feti.c): KSPFETISetUp (:71-94) + KSPSolve_FETI (:144-156) for a decomposed linear problem ----
+ * Input = what the reference holds after QPTMatISToBlockDiag (qptransform.c:2007-2150): the block-diagonal K (host CSR, blocks
+ * given by block_rowstart), f split among the copies of shared dofs, l2g (global dof of every local dof), the Dirichlet dofs to be
+ * enforced by B (local indices, KSPFETISetDirichlet(..., FETI_LOCAL, PETSC_TRUE); none if they are eliminated in K), and the
+ * kernel vectors R (kdim rows of length N, zero over non-floating blocks; orthonormalised internally).
+ * Builds B = [B_d; B_g] (QPFetiAssembleDirichlet, QPFetiGetBgtSF), K^+ (MatRegularize + MATINV, or the Moore-Penrose wrapping),
+ * G = R'B', the dual QP chain, solves it with the QPS the reference's QPSSetDefaultType picks (CG on P F, optional lumped PC) and
+ * recovers u.  One call per solve; everything it creates is released before it returns. */
+typedef struct {
+  int    gluing_type;        /* -feti_gluing_type: 0 nonred, 1 full (default, qpfeti.c:322), 2 orth */
+  int    scale;              /* -SCALE_ON (default 1) */
+  int    exclude_dirichlet;  /* -feti_gluing_exclude_dirichlet (default 0) */
+  int    regularize;         /* -regularize (default 1, qptransform.c:2215); 0: -qpt_dualize_Kplus_mp */
+  int    lumped_pc;          /* -dual_pc_dual_type lumped (default none) */
+  double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */
+  double rtol, atol, divtol; int max_it; /* -qps_rtol ... of the dual solve (qps.c:73-76) */
+} pmh_kspfeti_opts;
+typedef struct {
+  int    iteration, reason;
+  double rnorm;              /* ||P (F lambda - d)|| at exit */
+  int    n_lambda, n_dirichlet_rows, coarse_dim;
+} pmh_kspfeti_stats;
+int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o);
+int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
+                      const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host /* or NULL */, int lambda_cap,
+                      pmh_kspfeti_stats *st);
+
 #ifdef __cplusplus
 }
 #endif

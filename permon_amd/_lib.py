@@ -69,6 +69,15 @@ class QpsOpts(C.Structure):
     ]
 
 
+class KspFetiOpts(C.Structure):
+    _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int),
+                ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int)]
+
+
+class KspFetiStats(C.Structure):
+    _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("n_lambda", C.c_int), ("n_dirichlet_rows", C.c_int), ("coarse_dim", C.c_int)]
+
+
 class PcpgStats(C.Structure):
     _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double)]
 
@@ -205,6 +214,8 @@ _PROTOS = {
     "pmh_matinv_set_pc_mg": [vp, vp],
     "pmh_qps_default_opts": [C.POINTER(QpsOpts)],
     "pmh_qps_set_from_options": [C.c_char_p, C.c_char_p, C.POINTER(QpsOpts), C.POINTER(MpgpOpts), C.POINTER(SmalxeOpts), C.c_char_p, C.c_int],
+    "pmh_kspfeti_default_opts": [C.POINTER(KspFetiOpts)],
+    "pmh_kspfeti_solve": [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.POINTER(KspFetiOpts), vp, vp, C.c_int, C.POINTER(KspFetiStats)],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

@@ -170,3 +170,35 @@ class FetiDualQP:
         for v in (lam, u, Fl):
             v.free()
         return out
+
+
+def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, gluing="full", scale=True, exclude_dirichlet=False, regularize=True, lumped=False,
+                 rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000):
+    """KSPFETI (src/ksp/impls/feti/feti.c:71-156) for a decomposed linear problem, one call into pmh_kspfeti_solve (C++):
+    K block-diagonal scipy CSR, f split among copies, l2g global dof of every local dof, dirichlet_local = local dofs enforced
+    by B (TFETI) or None, R = (kdim, N) kernel vectors (zero over non-floating blocks) or None.
+    Returns (u, lambda, stats) with stats = (iteration, reason, rnorm, n_lambda, n_dirichlet_rows, coarse_dim)."""
+    from . import _lib
+
+    K = K.tocsr()
+    K.sort_indices()
+    N = K.shape[0]
+    rs = np.ascontiguousarray(block_rowstart, dtype=np.int32)
+    ip, ci, va = (np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64))
+    fv = np.ascontiguousarray(f, dtype=np.float64)
+    lg = np.ascontiguousarray(l2g, dtype=np.int32)
+    dl = np.ascontiguousarray(dirichlet_local if dirichlet_local is not None else [], dtype=np.int32)
+    Rm = np.ascontiguousarray(R, dtype=np.float64) if R is not None and np.size(R) else np.zeros((0, N))
+    assert fv.size == N and lg.size == N and Rm.shape[1] == N
+    o = _lib.KspFetiOpts()
+    check(ctx.L.pmh_kspfeti_default_opts(C.byref(o)))
+    o.gluing_type, o.scale, o.exclude_dirichlet = {"nonred": 0, "full": 1, "orth": 2}[gluing], int(bool(scale)), int(bool(exclude_dirichlet))
+    o.regularize, o.lumped_pc = int(bool(regularize)), int(bool(lumped))
+    o.kplus_rtol, o.kplus_max_it, o.rtol, o.atol, o.divtol, o.max_it = kplus_rtol, kplus_max_it, rtol, atol, divtol, max_it
+    st = _lib.KspFetiStats()
+    u = np.zeros(N)
+    cap = int(dl.size + 8 * N)
+    lam = np.zeros(cap)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+    check(ctx.L.pmh_kspfeti_solve(ctx.h, rs.size - 1, p(rs), p(ip), p(ci), p(va), p(fv), p(lg), dl.size, p(dl), Rm.shape[0], p(Rm), C.byref(o), p(u), p(lam), cap, C.byref(st)))
+    return u, lam[:st.n_lambda].copy(), st

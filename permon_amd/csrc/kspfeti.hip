@@ -1,0 +1,245 @@
+// KSPFETI (src/ksp/impls/feti/feti.c): the reference's KSP facade that solves a decomposed linear problem K u = f by (T)FETI --
+// KSPFETISetUp (:71-94: QPTMatISToBlockDiag -> QPFetiSetDirichlet -> QPFetiSetUp -> QPTFromOptions "-feti" = dualize + project)
+// and KSPSolve_FETI (:144-156: QPSSolve on the last QP of the chain, then the post-solve chain).  This is the same driver over
+// the pieces of this library, for the input the reference has AFTER QPTMatISToBlockDiag: the subdomain blocks K_i, the right-hand
+// side already split among the copies of shared dofs, the local-to-global dof map, the Dirichlet dofs and the kernel bases R_i.
+//   B  = [B_d ; B_g]: one row per Dirichlet dof copy with a single 1 (QPFetiAssembleDirichlet qpfeti.c:153-312, enforce_by_B), then
+//        the gluing rows of QPFetiGetBgtSF (pmh_feti_gluing_from_l2g);
+//   K^+: MATINV on K_reg = MatRegularize(K, R) (-regularize 1, the default) or P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp);
+//   G  = R'B' (explicit, qptransform.c:838), e = R'f;  chain: pmh_qpt_feti_chain_create (dualize, homogenize, project);
+//   QPS: the dual QP has no box, so QPSSetDefaultType picks QPSKSP = CG on P F (qps.c:448) with PC none or P (B K B') (PCDUAL lumped);
+//   post-solve: lambda = lambda_child + lambda~, u = K^+(f - B' lambda) - R alpha with G' alpha = d - F lambda (qptransform.c:783-833).
+// Host orchestration in C++; every operator application runs on the device.
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+#include "pmh_internal.h"
+
+namespace {
+struct LumpedOp : pmh_op_s { // PCApply_Dual lumped (pcdual.c:63-78) as an operator
+  pmh_gluing    B;
+  pmh_blockdiag K;
+  int           mult(const double *x, double *y) override { return pmh_pc_dual_lumped_apply(B, K, x, y); }
+};
+} // namespace
+
+extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
+{
+  PMH_ARG(o);
+  memset(o, 0, sizeof(*o));
+  o->gluing_type = 1;   // FETI_GLUING_FULL, qpfeti.c:322
+  o->scale       = 1;   // -SCALE_ON, qpfeti.c:757
+  o->regularize  = 1;   // QPTFromOptions qptransform.c:2215
+  o->kplus_rtol = 1e-12, o->kplus_max_it = 20000; // a stand-in for "direct": the reference factorises K_reg
+  o->rtol = 1e-5, o->atol = 1e-50, o->divtol = 1e4, o->max_it = 10000; // QPSCreate qps.c:73-76
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
+                                 const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host, int lambda_cap, pmh_kspfeti_stats *st)
+{
+  PMH_ARG(ctx && nsub >= 1 && block_rowstart && rowptr && f && l2g && o && u_host && st && kdim >= 0 && kdim <= 8 && (kdim == 0 || R) && (n_dir == 0 || dir_local));
+  const int N = block_rowstart[nsub];
+  PMH_ARG(block_rowstart[0] == 0 && N >= 0 && (rowptr[N] == 0 || (col && val)));
+  memset(st, 0, sizeof(*st));
+  auto block_of = [&](int i) { return (int)(std::upper_bound(block_rowstart, block_rowstart + nsub + 1, i) - block_rowstart) - 1; };
+
+  // ---- kernel bases: block-wise Gram-Schmidt (QPTDualize orthonormalises a computed R, qptransform.c:1001); which blocks float
+  std::vector<double> Rn((size_t)kdim * N, 0.0); // row k = k-th kernel vector over all blocks (layout of pmh_matinv_set_nullspace)
+  std::vector<int>    bdim(nsub, 0);             // kernel dimension per block (leading non-zero vectors)
+  for (int s = 0; s < nsub; s++) {
+    const int lo = block_rowstart[s], hi = block_rowstart[s + 1];
+    int       d  = 0;
+    for (int k = 0; k < kdim; k++) {
+      std::vector<double> v(R + (size_t)k * N + lo, R + (size_t)k * N + hi);
+      double              nrm0 = 0.0;
+      for (double x : v) nrm0 += x * x;
+      if (nrm0 == 0.0) continue;
+      for (int pass = 0; pass < 2; pass++) // twice is enough
+        for (int j = 0; j < d; j++) {
+          const double *q = &Rn[(size_t)j * N + lo];
+          double        t = 0.0;
+          for (int i = 0; i < hi - lo; i++) t += q[i] * v[i];
+          for (int i = 0; i < hi - lo; i++) v[i] -= t * q[i];
+        }
+      double nrm = 0.0;
+      for (double x : v) nrm += x * x;
+      if (nrm <= 1e-24 * nrm0) return pmh_set_error(PMH_ERR_ARG, "pmh_kspfeti_solve: the kernel vectors of block %d are linearly dependent", s);
+      nrm = std::sqrt(nrm);
+      for (int i = 0; i < hi - lo; i++) Rn[(size_t)d * N + lo + i] = v[i] / nrm;
+      d++;
+    }
+    bdim[s] = d;
+  }
+
+  // ---- B = [B_d ; B_g] as leaves
+  std::vector<int>    lrow, lroot;
+  std::vector<double> lval;
+  for (int i = 0; i < n_dir; i++) {
+    PMH_ARG(dir_local[i] >= 0 && dir_local[i] < N);
+    lrow.push_back(dir_local[i]), lroot.push_back(i), lval.push_back(1.0);
+  }
+  std::vector<int> excl;
+  if (o->exclude_dirichlet) { // -feti_gluing_exclude_dirichlet (qpfeti.c:423-431): the global dofs of the Dirichlet set
+    for (int i = 0; i < n_dir; i++) excl.push_back(l2g[dir_local[i]]);
+    std::sort(excl.begin(), excl.end());
+    excl.erase(std::unique(excl.begin(), excl.end()), excl.end());
+  }
+  int ng = 0, nleaf = 0;
+  PMH_CHK(pmh_feti_gluing_from_l2g(nsub, block_rowstart, l2g, o->gluing_type, o->scale, (int)excl.size(), excl.data(), &ng, &nleaf, nullptr, nullptr, nullptr));
+  {
+    std::vector<int>    r((size_t)nleaf), t((size_t)nleaf);
+    std::vector<double> v((size_t)nleaf);
+    PMH_CHK(pmh_feti_gluing_from_l2g(nsub, block_rowstart, l2g, o->gluing_type, o->scale, (int)excl.size(), excl.data(), &ng, &nleaf, r.data(), t.data(), v.data()));
+    for (int i = 0; i < nleaf; i++) lrow.push_back(r[i]), lroot.push_back(n_dir + t[i]), lval.push_back(v[i]);
+  }
+  const int nl = n_dir + ng;
+  st->n_lambda = nl, st->n_dirichlet_rows = n_dir;
+  if (lambda_host) PMH_ARG(lambda_cap >= nl);
+
+  // ---- device objects
+  pmh_csr        Kc = nullptr, Kregc = nullptr, Gc = nullptr;
+  pmh_blockdiag  Kb = nullptr, Kregb = nullptr;
+  pmh_matinv     Kp = nullptr;
+  pmh_gluing     B  = nullptr;
+  pmh_qppf       pf = nullptr;
+  pmh_feti_chain ch = nullptr;
+  LumpedOp      *lump = nullptr;
+  pmh_op         pc = nullptr;
+  double        *d_f = nullptr, *d_c = nullptr, *d_e = nullptr, *d_x = nullptr, *d_lam = nullptr, *d_u0 = nullptr, *d_r = nullptr, *d_alpha = nullptr;
+  int            rc = PMH_SUCCESS;
+#define GO(call) \
+  do { \
+    if ((rc = (call))) goto done; \
+  } while (0)
+  {
+    GO(pmh_csr_create(ctx, N, N, rowptr, col, val, &Kc));
+    GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kc, &Kb));
+    const bool any_kernel = std::any_of(bdim.begin(), bdim.end(), [](int d) { return d > 0; });
+    if (o->regularize && any_kernel) {
+      // MatRegularize block by block (permonmatregularize.c:241-266 works on the rank's diagonal block)
+      std::vector<int>    rp((size_t)N + 1, 0), ci;
+      std::vector<double> va;
+      ci.reserve((size_t)rowptr[N] + 64 * nsub), va.reserve((size_t)rowptr[N] + 64 * nsub);
+      for (int s = 0; s < nsub; s++) {
+        const int lo = block_rowstart[s], hi = block_rowstart[s + 1], p = hi - lo, d = bdim[s], z0 = rowptr[lo], nz = rowptr[hi] - z0;
+        std::vector<int>    brp((size_t)p + 1), bci((size_t)nz), orp((size_t)p + 1), oci((size_t)nz + d * d), piv((size_t)std::max(d, 1));
+        std::vector<double> ova((size_t)nz + d * d), Rb((size_t)d * p);
+        for (int i = 0; i <= p; i++) brp[i] = rowptr[lo + i] - z0;
+        for (int k = 0; k < nz; k++) {
+          bci[k] = col[z0 + k] - lo;
+          if (bci[k] < 0 || bci[k] >= p) {
+            rc = pmh_set_error(PMH_ERR_ARG, "pmh_kspfeti_solve: K is not block diagonal (row block %d)", s);
+            goto done;
+          }
+        }
+        for (int k = 0; k < d; k++) std::copy(&Rn[(size_t)k * N + lo], &Rn[(size_t)k * N + hi], &Rb[(size_t)k * p]);
+        double rho = 0.0;
+        if (d) { // rho = MatGetMaxEigenvalue(K_loc, NULL, &rho, 1, 20) (:254)
+          pmh_csr Kblk = nullptr;
+          pmh_op  op   = nullptr;
+          GO(pmh_csr_create(ctx, p, p, brp.data(), bci.data(), val + z0, &Kblk));
+          rc = pmh_op_create_csr(Kblk, &op);
+          if (!rc) rc = pmh_op_max_eigenvalue(op, 1.0, 20, &rho, nullptr);
+          pmh_op_destroy(op), pmh_csr_destroy(Kblk);
+          if (rc) goto done;
+        }
+        long long onz = 0;
+        GO(pmh_mat_regularize_csr(p, brp.data(), bci.data(), val + z0, d, Rb.data(), rho, piv.data(), orp.data(), oci.data(), ova.data(), &onz));
+        for (int i = 0; i < p; i++) rp[lo + i + 1] = rp[lo + i] + (orp[i + 1] - orp[i]);
+        for (long long k = 0; k < onz; k++) ci.push_back(oci[k] + lo), va.push_back(ova[k]);
+      }
+      GO(pmh_csr_create(ctx, N, N, rp.data(), ci.data(), va.data(), &Kregc));
+      GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kregc, &Kregb));
+      GO(pmh_matinv_create(Kregb, o->kplus_rtol, 1e-50, o->kplus_max_it, 1, &Kp));
+    } else {
+      GO(pmh_matinv_create(Kb, o->kplus_rtol, 1e-50, o->kplus_max_it, 1, &Kp));
+      if (any_kernel) GO(pmh_matinv_set_nullspace(Kp, kdim, Rn.data()));
+    }
+    GO(pmh_gluing_create(ctx, N, nl, (int)lrow.size(), lrow.data(), lroot.data(), lval.data(), &B));
+
+    // ---- G = R'B' (rows: the kernel vectors of the floating blocks), e = R'f
+    std::vector<int> grow0(nsub + 1, 0);
+    for (int s = 0; s < nsub; s++) grow0[s + 1] = grow0[s] + bdim[s];
+    const int m = grow0[nsub];
+    st->coarse_dim = m;
+    std::vector<double> e((size_t)std::max(m, 1), 0.0);
+    if (m) {
+      std::vector<std::map<int, double>> rows((size_t)m);
+      for (size_t q = 0; q < lrow.size(); q++) {
+        const int s = block_of(lrow[q]);
+        for (int k = 0; k < bdim[s]; k++) {
+          const double w = Rn[(size_t)k * N + lrow[q]] * lval[q];
+          if (w != 0.0) rows[grow0[s] + k][lroot[q]] += w;
+        }
+      }
+      std::vector<int>    grp((size_t)m + 1, 0), gci;
+      std::vector<double> gva;
+      for (int r = 0; r < m; r++) {
+        for (auto &kv : rows[r]) gci.push_back(kv.first), gva.push_back(kv.second);
+        grp[r + 1] = (int)gci.size();
+      }
+      for (int s = 0; s < nsub; s++)
+        for (int k = 0; k < bdim[s]; k++) {
+          double t = 0.0;
+          for (int i = block_rowstart[s]; i < block_rowstart[s + 1]; i++) t += Rn[(size_t)k * N + i] * f[i];
+          e[grow0[s] + k] = t;
+        }
+      GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
+      GO(pmh_qppf_create(ctx, Gc, 0, &pf));
+    }
+
+    // ---- chain, solve, post-solve
+    const size_t bl = sizeof(double) * (size_t)std::max(nl, 1), bx = sizeof(double) * (size_t)std::max(N, 1);
+    GO(pmh_malloc(ctx, bx, (void **)&d_f));
+    GO(pmh_malloc(ctx, bl, (void **)&d_c));
+    GO(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(m, 1), (void **)&d_e));
+    GO(pmh_malloc(ctx, bl, (void **)&d_x));
+    GO(pmh_malloc(ctx, bl, (void **)&d_lam));
+    GO(pmh_malloc(ctx, bx, (void **)&d_u0));
+    GO(pmh_malloc(ctx, bl, (void **)&d_r));
+    GO(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(m, 1), (void **)&d_alpha));
+    GO(pmh_memcpy_h2d(ctx, d_f, f, sizeof(double) * (size_t)N));
+    GO(pmh_memset(ctx, d_c, 0, bl)); // c = B x0 with x0 = 0 (qpfeti.c:268-270)
+    GO(pmh_memset(ctx, d_x, 0, bl));
+    if (m) GO(pmh_memcpy_h2d(ctx, d_e, e.data(), sizeof(double) * (size_t)m));
+    GO(pmh_qpt_feti_chain_create(B, Kp, d_f, d_c, pf, m ? d_e : nullptr, nullptr, &ch));
+    pmh_op  A;
+    double *b;
+    GO(pmh_qpt_feti_chain_get(ch, nullptr, &A, nullptr, nullptr, &b, nullptr, nullptr));
+    if (o->lumped_pc) { // PCDUAL lumped, projected as qptransform.c:301-309 does for an equality-only QP
+      lump      = new LumpedOp();
+      lump->ctx = ctx, lump->n = nl, lump->B = B, lump->K = Kb;
+      if (pf) GO(pmh_op_create_projected(lump, pf, 0, &pc));
+    }
+    pmh_pcpg_stats ks;
+    GO(pmh_ksp_cg_solve(ctx, A, b, d_x, o->lumped_pc ? (pc ? pc : (pmh_op)lump) : nullptr, o->rtol, o->atol, o->divtol, o->max_it, &ks));
+    st->iteration = ks.iteration, st->reason = ks.reason, st->rnorm = ks.rnorm;
+    GO(pmh_qpt_feti_chain_post_solve(ch, d_x, d_lam, d_u0, d_r));
+    GO(pmh_memcpy_d2h(ctx, u_host, d_u0, sizeof(double) * (size_t)N));
+    if (lambda_host) GO(pmh_memcpy_d2h(ctx, lambda_host, d_lam, sizeof(double) * (size_t)nl));
+    if (m) { // u = u0 - R alpha, G' alpha = d - F lambda  =>  alpha = -(G G')^{-1} G (F lambda - d)
+      std::vector<double> alpha((size_t)m);
+      GO(pmh_qppf_apply_halfQ(pf, d_r, d_alpha));
+      GO(pmh_memcpy_d2h(ctx, alpha.data(), d_alpha, sizeof(double) * (size_t)m));
+      for (int s = 0; s < nsub; s++)
+        for (int k = 0; k < bdim[s]; k++) {
+          const double a = -alpha[grow0[s] + k];
+          for (int i = block_rowstart[s]; i < block_rowstart[s + 1]; i++) u_host[i] -= Rn[(size_t)k * N + i] * a;
+        }
+    }
+  }
+done:
+#undef GO
+  pmh_free(ctx, d_f), pmh_free(ctx, d_c), pmh_free(ctx, d_e), pmh_free(ctx, d_x), pmh_free(ctx, d_lam), pmh_free(ctx, d_u0), pmh_free(ctx, d_r), pmh_free(ctx, d_alpha);
+  if (pc) pmh_op_destroy(pc);
+  if (lump) delete lump;
+  pmh_qpt_feti_chain_destroy(ch);
+  pmh_qppf_destroy(pf);
+  pmh_gluing_destroy(B);
+  pmh_matinv_destroy(Kp);
+  pmh_blockdiag_destroy(Kregb), pmh_blockdiag_destroy(Kb);
+  pmh_csr_destroy(Gc), pmh_csr_destroy(Kregc), pmh_csr_destroy(Kc);
+  return rc;
+}
