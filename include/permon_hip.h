@@ -411,6 +411,10 @@ typedef struct {
   double rnorm;              /* ||P (F lambda - d)|| at exit */
   int    n_lambda, n_dirichlet_rows, coarse_dim;
 } pmh_kspfeti_stats;
+/* vector part of QPTMatISToBlockDiag (qptransform.c:2095-2113: assembled rhs -> copies, interface values divided by their
+   multiplicity) and of its post-solve (:1945-1949: INSERT_VALUES assembly of the solution, no averaging); host routines */
+int pmh_qpt_matis_split_rhs(int N, const int *l2g, int n_global, const double *b_global, double *f_local);
+int pmh_qpt_matis_assemble_solution(int N, const int *l2g, const double *u_local, int n_global, double *x_global);
 int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o);
 int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
                       const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host /* or NULL */, int lambda_cap,

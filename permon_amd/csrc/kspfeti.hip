@@ -243,3 +243,32 @@ done:
   pmh_csr_destroy(Gc), pmh_csr_destroy(Kregc), pmh_csr_destroy(Kc);
   return rc;
 }
+
+// ---- QPTMatISToBlockDiag, vector part (src/qp/interface/qptransform.c:2007-2150 and its post-solve :1905-1982) -----------------
+// Decomposing the assembled right-hand side: every interface dof's value is divided by the number of subdomains it belongs to
+// (the scaling "matrix" D = 1/counter, :2095-2104) and then copied to all its copies (:2105-2113).  Host routine.
+extern "C" int pmh_qpt_matis_split_rhs(int N, const int *l2g, int n_global, const double *b_global, double *f_local)
+{
+  PMH_ARG(N >= 0 && n_global >= 0 && (N == 0 || (l2g && b_global && f_local)));
+  std::vector<int> mult((size_t)n_global, 0);
+  for (int i = 0; i < N; i++) {
+    if (l2g[i] < 0 || l2g[i] >= n_global) return pmh_set_error(PMH_ERR_ARG, "pmh_qpt_matis_split_rhs: l2g[%d] = %d out of [0,%d)", i, l2g[i], n_global);
+    mult[l2g[i]]++;
+  }
+  for (int i = 0; i < N; i++) f_local[i] = b_global[l2g[i]] / (double)mult[l2g[i]];
+  return PMH_SUCCESS;
+}
+
+// QPTPostSolve_QPTMatISToBlockDiag (:1945-1949): the global solution is assembled from the local ones by a reverse scatter with
+// INSERT_VALUES -- one copy of every shared dof wins (here: the one in the highest-numbered subdomain, what a rank-ordered
+// scatter delivers last), nothing is averaged.  Pinned by the last KKT line of the ex71 goldens (tests/test_feti_goldens.py).
+extern "C" int pmh_qpt_matis_assemble_solution(int N, const int *l2g, const double *u_local, int n_global, double *x_global)
+{
+  PMH_ARG(N >= 0 && n_global >= 0 && (N == 0 || (l2g && u_local)) && (n_global == 0 || x_global));
+  for (int g = 0; g < n_global; g++) x_global[g] = 0.0;
+  for (int i = 0; i < N; i++) {
+    if (l2g[i] < 0 || l2g[i] >= n_global) return pmh_set_error(PMH_ERR_ARG, "pmh_qpt_matis_assemble_solution: l2g[%d] = %d out of [0,%d)", i, l2g[i], n_global);
+    x_global[l2g[i]] = u_local[i];
+  }
+  return PMH_SUCCESS;
+}

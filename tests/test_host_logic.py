@@ -125,3 +125,26 @@ def test_gluing_from_l2g_matches_the_link_rules():
         gluing_from_l2g([np.array([0, 1, 1], dtype=np.int32), np.array([1, 2], dtype=np.int32)], "full")
     with pytest.raises(ValueError):
         gluing_from_l2g([np.array([0, 1], dtype=np.int32)], "bogus")
+
+
+def test_matis_rhs_split_and_solution_assembly():
+    """QPTMatISToBlockDiag's vector part (qptransform.c:2095-2113, post-solve :1945-1949) as host routines of the C ABI."""
+    import ctypes as C
+
+    import numpy as np
+
+    from permon_amd import _lib
+
+    L = _lib.load()
+    l2g = np.array([0, 1, 2, 2, 3, 1, 4, 2], dtype=np.int32)  # dof 1 twice, dof 2 three times
+    b = np.array([1.0, 4.0, 9.0, 5.0, 7.0])
+    f = np.zeros(l2g.size)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _lib.check(L.pmh_qpt_matis_split_rhs(l2g.size, p(l2g), b.size, p(b), p(f)))
+    assert f.tolist() == [1.0, 2.0, 3.0, 3.0, 5.0, 2.0, 7.0, 3.0]
+    assert np.allclose(np.bincount(l2g, weights=f, minlength=5), b)  # the copies sum up to the assembled load
+    u = np.arange(10.0, 18.0)
+    x = np.zeros(5)
+    _lib.check(L.pmh_qpt_matis_assemble_solution(l2g.size, p(l2g), p(u), x.size, p(x)))
+    assert x.tolist() == [10.0, 15.0, 17.0, 14.0, 16.0]  # INSERT_VALUES: the last copy wins, nothing is averaged
+    assert L.pmh_qpt_matis_split_rhs(l2g.size, p(l2g), 3, p(b), p(f)) != 0  # l2g out of range: reported
