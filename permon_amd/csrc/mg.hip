@@ -20,6 +20,9 @@ struct mg_level {
   void    *pv, *rv;       // values of P and P' in the cycle's precision (fp32 copies: 8 instead of 12 bytes per entry; the
                           // trilinear weights 1, 1/2, 1/4, 1/8 are exact in any precision), or the CSR's own fp64 arrays
   bool     pv_owned;
+  // node-level copies of P and P' when P = P_node (x) I_3 (cycle precision values), else NULL
+  int     *pn_rowptr, *pn_col, *rn_rowptr, *rn_col;
+  void    *pn_val, *rn_val;
   double   theta, delta;
   std::vector<double> c1, c2; // Chebyshev recurrence coefficients of steps 1..degree-1
 };
@@ -162,6 +165,67 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *
   if (first && hlt) return;
 }
 
+// P = P_node (x) I_3 (nodal prolongation of a 3-dof-per-node problem, e.g. trilinear interpolation of elasticity blocks): one
+// node-level CSR entry serves the three components, so the transfer operators move a third of the index / value bytes.
+// Detected at pmh_mg_create from the entries of P; any other P runs on the scalar kernels above.
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict3(int ncn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
+                                                          const TV *__restrict__ dinv_c, TV itheta_c, TV *__restrict__ d_c)
+{
+  const int hlt  = halt ? *halt : 0;
+  const int lane = threadIdx.x & 7;
+  bool      first = true;
+  for (int i0 = blockIdx.x * (PMH_BLOCK / 8); i0 < ncn; i0 += gridDim.x * (PMH_BLOCK / 8)) { // uniform trip count per workgroup
+    const int i  = i0 + (threadIdx.x >> 3);
+    TV        s0 = (TV)0, s1 = (TV)0, s2 = (TV)0;
+    const int k0 = (i < ncn) ? rowptr[i] : 0, k1 = (i < ncn) ? rowptr[i + 1] : 0;
+    if (first) {
+      if (hlt) return;
+      first = false;
+    }
+    for (int k = k0 + lane; k < k1; k += 8) {
+      const TV  w = val[k];
+      const TV *p = t + 3 * (size_t)col[k];
+      s0 += w * p[0], s1 += w * p[1], s2 += w * p[2];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) s0 += __shfl_down(s0, o, 8), s1 += __shfl_down(s1, o, 8), s2 += __shfl_down(s2, o, 8);
+    if (i < ncn && lane == 0) {
+      TV *o = bc + 3 * (size_t)i;
+      o[0] = s0, o[1] = s1, o[2] = s2;
+      if (dinv_c) {
+        const TV *di = dinv_c + 3 * (size_t)i;
+        TV       *dd = d_c + 3 * (size_t)i;
+        dd[0] = di[0] * s0 * itheta_c, dd[1] = di[1] * s1 * itheta_c, dd[2] = di[2] * s2 * itheta_c;
+      }
+    }
+  }
+}
+
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub3(int nn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
+{
+  const int hlt   = halt ? *halt : 0;
+  bool      first = true;
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < nn; i += gridDim.x * PMH_BLOCK) {
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    TV       *xi = x + 3 * (size_t)i;
+    const TV  a0 = xi[0], a1 = xi[1], a2 = xi[2];
+    if (first) {
+      if (hlt) return;
+      first = false;
+    }
+    TV s0 = (TV)0, s1 = (TV)0, s2 = (TV)0;
+    for (int k = k0; k < k1; k++) {
+      const TV  w = val[k];
+      const TV *p = xc + 3 * (size_t)col[k];
+      s0 += w * p[0], s1 += w * p[1], s2 += w * p[2];
+    }
+    xi[0] = a0 - s0, xi[1] = a1 - s1, xi[2] = a2 - s2;
+  }
+  if (first && hlt) return;
+}
+
 // coarsest level: x_b = pinv_b b_b, one wavefront per row, lanes stride the row of the dense block (fixed order).
 // TP = storage type of the pseudo-inverse: TV, or _Float16 (PMH_MG_FP16: entries / scale, fp32 arithmetic) -- with one or two
 // blocks per GPU the hierarchy stops at a ~5000-dof level whose dense solve is a pure HBM stream (2 B per entry).
@@ -258,6 +322,36 @@ template <typename TV> static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x,
 // does level l run mg_level_fused (its first smoothing direction can then be produced by the kernel that makes its b)?
 static inline bool mg_fused_level(pmh_mg mg, int l) { return l < mg->nlevels - 1 && mg->fused && mg->L[l].Ab; }
 
+// b_c = P' t (+ the coarse level's d0) and x -= P x_c: node-level kernels when P = P_node (x) I_3, scalar CSR kernels otherwise
+template <typename TV>
+static void mg_restrict(pmh_mg mg, int l, const TV *t, bool with_d0)
+{
+  mg_level   &Lv = mg->L[l], &Lc = mg->L[l + 1];
+  hipStream_t st = mg->ctx->stream;
+  const TV   *dv = with_d0 ? (const TV *)Lc.dinv : (const TV *)nullptr;
+  const TV    it = with_d0 ? (TV)(1.0 / Lc.theta) : (TV)0;
+  TV         *dc = with_d0 ? (TV *)Lc.d : (TV *)nullptr;
+  if (Lv.rn_rowptr) {
+    const int ncn = Lc.n / 3;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict3<TV>), mg_grid(8 * ncn), dim3(PMH_BLOCK), 0, st, ncn, mg->halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col, (const TV *)Lv.rn_val, t, (TV *)Lc.b, dv, it, dc);
+  } else {
+    pmh_csr R = Lv.P->transpose;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), dim3(PMH_BLOCK), 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, t,
+                       (TV *)Lc.b, dv, it, dc);
+  }
+}
+
+template <typename TV>
+static void mg_prolong_sub(pmh_mg mg, int l, TV *x)
+{
+  mg_level   &Lv = mg->L[l], &Lc = mg->L[l + 1];
+  hipStream_t st = mg->ctx->stream;
+  if (Lv.pn_rowptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub3<TV>), mg_grid(Lv.n / 3), dim3(PMH_BLOCK), 0, st, Lv.n / 3, mg->halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const TV *)Lv.pn_val, (const TV *)Lc.x, x);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, x);
+}
+
 // One smoothed level with the degree-2 Chebyshev steps finished inside the operator kernel (7 launches instead of 10):
 //   d0 = D^-1 b/theta | xa = (1+c1) d0 + c2 D^-1 (b - A d0) | t = A xa - b | b_c = P't | ... | xa -= P x_c |
 //   r, d, x = xa + d from A xa | x += c1 d + c2 (r - D^-1 A d)
@@ -281,12 +375,10 @@ static int mg_level_fused(pmh_mg mg, int l, const TV *b, TV *x, const double *b6
   if (l == 0) mg->fine_spmv += 4;
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, d, xa, PMH_BSR_EPI_PRE, e, mg->halt));
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, t, PMH_EPI_SUB, e, mg->halt));
-  pmh_csr    R  = Lv.P->transpose;
   const bool cf = mg_fused_level(mg, l + 1); // the coarse level's d0 rides on the restriction
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, (const TV *)t, (TV *)Lc.b,
-                     cf ? (const TV *)Lc.dinv : (const TV *)nullptr, cf ? (TV)(1.0 / Lc.theta) : (TV)0, cf ? (TV *)Lc.d : (TV *)nullptr);
+  mg_restrict<TV>(mg, l, (const TV *)t, cf);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x, nullptr, nullptr, cf));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), g, blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, xa);
+  mg_prolong_sub<TV>(mg, l, xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
   PMH_CHK(bsr_epi_launch<TV>(Lv.Ab, xa, x, PMH_BSR_EPI_POST1, e, mg->halt));
@@ -311,11 +403,9 @@ static int mg_cycle(pmh_mg mg, int l, const TV *b, TV *x, const double *b64, dou
   PMH_CHK(mg_smooth<TV>(mg, l, b, x, true));
   // t = A x - b; b_{l+1} = P' t = -P'(b - A x); the coarse solve is linear, so the sign is undone by subtracting P x_{l+1}
   PMH_CHK(mg_spmv(mg, l, x, Lv.t, PMH_EPI_SUB, b));
-  pmh_csr R = Lv.P->transpose;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), blk, 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, (const TV *)Lv.t, (TV *)Lc.b,
-                     (const TV *)nullptr, (TV)0, (TV *)nullptr);
+  mg_restrict<TV>(mg, l, (const TV *)Lv.t, false);
   PMH_CHK(mg_cycle<TV>(mg, l + 1, (const TV *)Lc.b, (TV *)Lc.x));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), blk, 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, x);
+  mg_prolong_sub<TV>(mg, l, x);
   PMH_HIP(hipGetLastError());
   return mg_smooth<TV>(mg, l, b, x, false);
 }
@@ -385,6 +475,69 @@ extern "C" int pmh_mg_apply(pmh_mg mg, const double *b, double *x)
   return pmh_mg_apply_halt(mg, b, x, nullptr);
 }
 
+// P = P_node (x) I_3 ?  Rows 3i+c of P must hold the columns 3j+c with the same value for c = 0,1,2.  If so, node-level CSR
+// copies of P and of P' (values in the cycle's precision) are built for the three-components-per-entry kernels.
+static int mg_build_nodal_transfer(pmh_mg mg, int l, int fl)
+{
+  mg_level &Lv = mg->L[l];
+  pmh_csr   P  = Lv.P;
+  pmh_ctx   ctx = mg->ctx;
+  if (P->nrows % 3 || P->ncols % 3 || P->nrows == 0 || P->nnz % 3) return PMH_SUCCESS;
+  const int           n = P->nrows, nn = n / 3, ncn = P->ncols / 3;
+  std::vector<int>    rp((size_t)n + 1), ci((size_t)P->nnz);
+  std::vector<double> va((size_t)P->nnz);
+  PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), P->d_rowptr, sizeof(int) * rp.size()));
+  PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), P->d_col, sizeof(int) * ci.size()));
+  PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), P->d_val, sizeof(double) * va.size()));
+  std::vector<int>    nrp((size_t)nn + 1, 0), nci;
+  std::vector<double> nva;
+  nci.reserve((size_t)P->nnz / 3), nva.reserve((size_t)P->nnz / 3);
+  for (int i = 0; i < nn; i++) {
+    const int k0 = rp[3 * i], m = rp[3 * i + 1] - k0;
+    if (rp[3 * i + 2] - rp[3 * i + 1] != m || rp[3 * i + 3] - rp[3 * i + 2] != m) return PMH_SUCCESS;
+    for (int q = 0; q < m; q++) {
+      const int    j = ci[k0 + q];
+      const double w = va[k0 + q];
+      if (j % 3 != 0) return PMH_SUCCESS;
+      for (int c = 1; c < 3; c++)
+        if (ci[rp[3 * i + c] + q] != j + c || va[rp[3 * i + c] + q] != w) return PMH_SUCCESS;
+      nci.push_back(j / 3), nva.push_back(w);
+    }
+    nrp[i + 1] = (int)nci.size();
+  }
+  // node-level transpose (counting sort: columns of every row of P' ascending, the order of the scalar P')
+  std::vector<int>    trp((size_t)ncn + 1, 0), tci(nci.size());
+  std::vector<double> tva(nva.size());
+  for (int c : nci) trp[c + 1]++;
+  for (int j = 0; j < ncn; j++) trp[j + 1] += trp[j];
+  {
+    std::vector<int> pos(trp.begin(), trp.end() - 1);
+    for (int i = 0; i < nn; i++)
+      for (int k = nrp[i]; k < nrp[i + 1]; k++) {
+        const int p = pos[nci[k]]++;
+        tci[p] = i, tva[p] = nva[k];
+      }
+  }
+  auto upload = [&](const std::vector<int> &r, const std::vector<int> &c, const std::vector<double> &v, int **dr, int **dc, void **dv) -> int {
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * r.size(), (void **)dr));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * (c.size() ? c.size() : 1), (void **)dc));
+    PMH_CHK(pmh_memcpy_h2d(ctx, *dr, r.data(), sizeof(int) * r.size()));
+    if (!c.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, *dc, c.data(), sizeof(int) * c.size()));
+    if (fl) {
+      std::vector<float> vf(v.begin(), v.end());
+      PMH_CHK(pmh_malloc(ctx, sizeof(float) * (vf.size() ? vf.size() : 1), dv));
+      if (!vf.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, *dv, vf.data(), sizeof(float) * vf.size()));
+    } else {
+      PMH_CHK(pmh_malloc(ctx, sizeof(double) * (v.size() ? v.size() : 1), dv));
+      if (!v.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, *dv, v.data(), sizeof(double) * v.size()));
+    }
+    return PMH_SUCCESS;
+  };
+  PMH_CHK(upload(nrp, nci, nva, &Lv.pn_rowptr, &Lv.pn_col, &Lv.pn_val));
+  PMH_CHK(upload(trp, tci, tva, &Lv.rn_rowptr, &Lv.rn_col, &Lv.rn_val));
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
                              const double *coarse_pinv_host, int precision, pmh_mg *out)
 {
@@ -422,6 +575,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
     Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows, Lv.Ab = nullptr;
     Lv.dinv = Lv.x = Lv.b = Lv.r = Lv.d = Lv.t = Lv.xa = nullptr;
     Lv.pv = Lv.rv = nullptr, Lv.pv_owned = false;
+    Lv.pn_rowptr = Lv.pn_col = Lv.rn_rowptr = Lv.rn_col = nullptr, Lv.pn_val = Lv.rn_val = nullptr;
     const size_t nbytes = w * (size_t)(Lv.n ? Lv.n : 1);
     if (l > 0 || fl) {
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.x));
@@ -461,6 +615,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
         PMH_HIP(hipGetLastError());
       }
+      if (!getenv("PMH_MG_NO_NODAL_P")) PMH_CHK(mg_build_nodal_transfer(mg, l, fl));
       // KSPChebyshev recurrence on the window [lo, hi] x lambda_max
       const double a = lo_frac * lambda_max[l], b = hi_frac * lambda_max[l];
       Lv.theta = 0.5 * (a + b), Lv.delta = 0.5 * (b - a);
@@ -524,6 +679,7 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.x);
     pmh_free(ctx, Lv.b);
     if (Lv.pv_owned) pmh_free(ctx, Lv.pv), pmh_free(ctx, Lv.rv);
+    pmh_free(ctx, Lv.pn_rowptr), pmh_free(ctx, Lv.pn_col), pmh_free(ctx, Lv.pn_val), pmh_free(ctx, Lv.rn_rowptr), pmh_free(ctx, Lv.rn_col), pmh_free(ctx, Lv.rn_val);
     pmh_bsr3_destroy(Lv.Ab);
   }
   for (auto &g : mg->graphs) (void)hipGraphExecDestroy(g.exec);
