@@ -684,10 +684,6 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
       next_check = it + (extpc ? 1 : 2);
     }
   }
-  if (it == 0) { // max_it reached before the first check cannot happen (max_it > 0); zero right-hand side: publish once
-    hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(1), 0, st, nb, (const int *)M->d_bi, (const int *)M->d_nactive, M->h_nactive);
-    PMH_HIP(hipStreamSynchronize(st));
-  }
   M->last_max_its = M->h_nactive[1]; // largest per-block iteration count
   if (M->kdim) { // u <- P_R u (in place through the scratch vector)
     PMH_CHK(matinv_project(M, u, M->d_fproj));
