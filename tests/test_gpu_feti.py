@@ -349,3 +349,23 @@ def test_mat_add_and_transpose_slots(ctx):
     xin = ctx.vec_from(y1)
     TA.mult_add(ctx.vec_from(lam), xin, xin)
     assert np.allclose(xin.to_numpy(), y1 + f.B.T @ lam, rtol=1e-13, atol=1e-13)
+
+
+def test_replicated_dual_arithmetic_is_bitwise_reproducible(ctx):
+    """The multi-GPU design replicates the dual-space MPGP / SMALXE arithmetic on every rank and relies on it being
+    deterministic (fixed reduction trees, no atomics on the data path): two independent set-ups + solves of the same contact
+    problem on one GPU must agree bit for bit -- multipliers, counters and the final residual -- although the number of
+    enqueued no-op launches differs between them (the K^+ driver adapts its look-ahead to the previous iteration counts)."""
+    f = pa.CubeFeti((2, 2, 2), 3, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    runs = []
+    for rep in range(2):
+        q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-10)
+        if rep:  # perturb the driver's look-ahead state: a different number of idle launches, same arithmetic
+            w = ctx.vec(f.N)
+            q.Kplus.mult(ctx.vec_from(np.ones(f.N)), w)
+        st = q.solve_smalxe()
+        runs.append((q.lam.to_numpy(), st.iteration, st.inner_iter_accu, st.inner.nmv, st.rnorm))
+    a, b = runs
+    assert a[1:4] == b[1:4] and a[4] == b[4]
+    assert np.array_equal(a[0], b[0])
