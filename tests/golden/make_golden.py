@@ -24,6 +24,7 @@ KEYS = {"Hessian multiplications": "nmv", "CG steps": "ncg", "expansion steps": 
 
 def parse(path):
     d = {"source": os.path.relpath(path, "/root/reference"), "solves": [], "kkt": [], "trace": []}
+    d["text"] = [ln.rstrip("\n") for ln in open(path)]  # the expected output itself (what the reference's harness diffs against)
     for line in open(path):
         m = RE_SOLVE.search(line)
         if m:
