@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the ABI / host-logic tests load the in-tree extension: build it (hipcc cross-compiles without a GPU) if a fresh checkout
+    # has not run __graft_entry__.build() yet.  Nothing falls back to a CPU path when the build fails: the tests then fail loudly.
+    so = os.path.join(ROOT, "permon_amd", "libpermonhip.so")
+    if not os.path.exists(so):
+        import subprocess
+
+        subprocess.call(["make", "-C", os.path.join(ROOT, "permon_amd", "csrc"), "-j8", "-s", "all"])
 
 
 @pytest.fixture(scope="session")
