@@ -416,6 +416,9 @@ typedef struct {
 int pmh_qpt_matis_split_rhs(int N, const int *l2g, int n_global, const double *b_global, double *f_local);
 int pmh_qpt_matis_assemble_solution(int N, const int *l2g, const double *u_local, int n_global, double *x_global);
 int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o);
+/* the options-database keys of the FETI chain (-feti_gluing_type, -feti_gluing_exclude_dirichlet, -SCALE_ON, -regularize,
+   -qpt_dualize_Kplus_mp, -dual_pc_dual_type, -qps_rtol/-qps_atol/-qps_divtol/-qps_max_it, -dual_mat_inv_ksp_rtol/_max_it) */
+int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opts *o, char *unknown, int unknown_cap);
 int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
                       const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host /* or NULL */, int lambda_cap,
                       pmh_kspfeti_stats *st);

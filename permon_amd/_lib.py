@@ -217,6 +217,7 @@ _PROTOS = {
     "pmh_qpt_matis_split_rhs": [C.c_int, vp, C.c_int, vp, vp],
     "pmh_qpt_matis_assemble_solution": [C.c_int, vp, vp, C.c_int, vp],
     "pmh_kspfeti_default_opts": [C.POINTER(KspFetiOpts)],
+    "pmh_kspfeti_set_from_options": [C.c_char_p, C.POINTER(KspFetiOpts), C.c_char_p, C.c_int],
     "pmh_kspfeti_solve": [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.POINTER(KspFetiOpts), vp, vp, C.c_int, C.POINTER(KspFetiStats)],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }

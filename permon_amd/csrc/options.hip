@@ -321,3 +321,39 @@ extern "C" int pmh_qps_default_opts(pmh_qps_opts *q)
   q->auto_post_solve = 1;
   return PMH_SUCCESS;
 }
+
+// Options of the FETI driver: the keys KSPFETI's chain reads from the options database -- QPFetiSetUp (qpfeti.c:340-341:
+// -feti_gluing_type, -feti_gluing_exclude_dirichlet), QPFetiGetBgtSF (:757-758: -SCALE_ON), QPTFromOptions (qptransform.c:2220-2231:
+// -regularize), QPTDualize (:1019: -qpt_dualize_Kplus_mp), PCDUAL with the dual QP's prefix (pcdual.c:170: -dual_pc_dual_type), the
+// outer QPS tolerances (-qps_rtol ...) and the inner KSP of MATINV (-dual_mat_inv_ksp_rtol / _max_it) -- parsed into
+// pmh_kspfeti_opts, so the reference's ex71 TEST blocks ("-feti_gluing_type orth", "-qps_rtol 1e-6 -dual_pc_dual_type lumped")
+// configure pmh_kspfeti_solve verbatim.  Unknown keys are returned, not rejected (PETSc's -options_left).
+extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opts *o, char *unknown, int unknown_cap)
+{
+  PMH_ARG(options && o);
+  std::vector<Token> toks;
+  PMH_CHK(tokenize(options, toks));
+  static const char *const gtypes[] = {"nonred", "full", "orth"};    // FetiGluingTypes
+  static const char *const pctypes[] = {"none", "lumped"};           // PCDualTypes (pcdual.c)
+  std::string left;
+  for (const Token &t : toks) {
+    const std::string &k = t.key;
+    int                rc = 1, b = 0;
+    if (k == "feti_gluing_type") rc = get_enum(t, gtypes, 3, &o->gluing_type) ? -1 : 1;
+    else if (k == "feti_gluing_exclude_dirichlet") rc = get_bool(t, &o->exclude_dirichlet) ? -1 : 1;
+    else if (k == "SCALE_ON") rc = get_bool(t, &o->scale) ? -1 : 1;
+    else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1;
+    else if (k == "qpt_dualize_Kplus_mp") {
+      rc = get_bool(t, &b) ? -1 : 1;
+      if (rc == 1 && b) o->regularize = 0; // the Moore-Penrose wrapping is this library's -regularize 0 path
+    } else if (k == "dual_pc_dual_type") rc = get_enum(t, pctypes, 2, &o->lumped_pc) ? -1 : 1;
+    else if (k == "dual_mat_inv_ksp_rtol") rc = get_real(t, &o->kplus_rtol) ? -1 : 1;
+    else if (k == "dual_mat_inv_ksp_max_it") rc = get_int(t, &o->kplus_max_it) ? -1 : 1;
+    else if (k == "feti") rc = get_bool(t, &b) ? -1 : 1; // the combination this driver always performs
+    else rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
+    if (rc < 0) return PMH_ERR_ARG;
+    if (!rc) left += (left.empty() ? "-" : " -") + k;
+  }
+  if (unknown && unknown_cap > 0) snprintf(unknown, (size_t)unknown_cap, "%s", left.c_str());
+  return PMH_SUCCESS;
+}

@@ -34,7 +34,9 @@ def _assembled(prob, l2g):
 def test_ex71_poisson_goldens_through_the_driver(ctx, goldens, gtype, its):
     prob = DmdaFeti((7, 8, 9), 6, "poisson", gtype)
     l2g = _dmda_l2g(prob)
-    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, gluing=gtype)  # Dirichlet is in K, nothing floats
+    # configured by the reference's own command line (feti/ex71.c:433-438)
+    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g,  # Dirichlet is in K, nothing floats
+                                 options="-qps_view_convergence -qp_chain_view_kkt -pde_type Poisson -cells 7,8,9 -dim 3 -feti_gluing_type %s" % gtype)
     assert (st.reason, st.iteration) == (2, its) and st.iteration == goldens["feti_ex71_1_" + gtype]["solves"][0]["iterations"]
     assert st.coarse_dim == 0 and st.n_dirichlet_rows == 0 and st.n_lambda == prob.n_lambda
     if gtype != "nonred":
@@ -53,7 +55,8 @@ def test_ex71_elasticity_floating_slabs(ctx, goldens, regularize, lumped):
     golden counts 66 / 26 are reproduced within the +-5 the ill-conditioned slab decomposition allows (tests/test_feti_goldens.py)."""
     prob = DmdaFeti((8, 6, 4), 7, "elasticity")
     l2g = _dmda_l2g(prob)
-    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, regularize=regularize, lumped=lumped, rtol=1e-6, kplus_rtol=1e-13)
+    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, regularize=regularize, kplus_rtol=1e-13,
+                                 options="-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type %s" % ("lumped" if lumped else "none"))  # feti/ex71.c:442
     gold = goldens["feti_ex71_2_lumped" if lumped else "feti_ex71_2_none"]["solves"][0]["iterations"]
     assert st.reason == 2 and abs(st.iteration - gold) <= 5 and st.coarse_dim == 36
     Rg, A, b = _assembled(prob, l2g)

@@ -72,3 +72,27 @@ def test_value_syntax_and_prefixes():
 def test_argument_checks_of_the_reference_setters(opts, msg):
     rc, q, m, s, left, err = _parse(opts)
     assert rc != 0 and msg in err
+
+
+def test_feti_driver_options():
+    """pmh_kspfeti_set_from_options: the keys of QPFetiSetUp / QPFetiGetBgtSF / QPTFromOptions / QPTDualize / PCDUAL
+    (qpfeti.c:340-341,757-758, qptransform.c:1019,2231, pcdual.c:170) as the ex71 TEST blocks use them (feti/ex71.c:438-442)."""
+    L = _lib.load()
+
+    def parse(opts):
+        o = _lib.KspFetiOpts()
+        _lib.check(L.pmh_kspfeti_default_opts(C.byref(o)))
+        left = C.create_string_buffer(512)
+        rc = L.pmh_kspfeti_set_from_options(opts.encode(), C.byref(o), left, len(left))
+        return rc, o, left.value.decode().split()
+
+    rc, o, left = parse("-pde_type Poisson -cells 7,8,9 -dim 3 -feti_gluing_type orth -qps_view_convergence -qp_chain_view_kkt")
+    assert rc == 0 and o.gluing_type == 2 and (o.scale, o.regularize, o.lumped_pc, o.rtol) == (1, 1, 0, 1e-5)
+    assert left == ["-pde_type", "-cells", "-dim", "-qps_view_convergence", "-qp_chain_view_kkt"]
+    rc, o, left = parse("-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type lumped")
+    assert rc == 0 and o.lumped_pc == 1 and o.rtol == 1e-6 and o.gluing_type == 1
+    rc, o, left = parse("-feti_gluing_type NONRED -SCALE_ON 0 -feti_gluing_exclude_dirichlet -regularize false -dual_mat_inv_ksp_rtol 1e-10 -qps_max_it 50")
+    assert rc == 0 and (o.gluing_type, o.scale, o.exclude_dirichlet, o.regularize, o.kplus_rtol, o.max_it) == (0, 0, 1, 0, 1e-10, 50) and not left
+    rc, o, left = parse("-qpt_dualize_Kplus_mp")
+    assert rc == 0 and o.regularize == 0
+    assert parse("-feti_gluing_type sideways")[0] != 0 and parse("-qps_rtol 2")[0] != 0
