@@ -403,6 +403,7 @@ typedef struct {
   int    exclude_dirichlet;  /* -feti_gluing_exclude_dirichlet (default 0) */
   int    regularize;         /* -regularize (default 1, qptransform.c:2215); 0: -qpt_dualize_Kplus_mp */
   int    lumped_pc;          /* -dual_pc_dual_type lumped (default none) */
+  double regularize_rho;     /* > 0: the rho of MatRegularize for every block; 0 (default): the reference's power-method estimate */
   double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */
   double rtol, atol, divtol; int max_it; /* -qps_rtol ... of the dual solve (qps.c:73-76) */
 } pmh_kspfeti_opts;

@@ -70,7 +70,7 @@ class QpsOpts(C.Structure):
 
 
 class KspFetiOpts(C.Structure):
-    _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int),
+    _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
                 ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int)]
 
 

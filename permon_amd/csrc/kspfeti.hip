@@ -135,8 +135,8 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
           }
         }
         for (int k = 0; k < d; k++) std::copy(&Rn[(size_t)k * N + lo], &Rn[(size_t)k * N + hi], &Rb[(size_t)k * p]);
-        double rho = 0.0;
-        if (d) { // rho = MatGetMaxEigenvalue(K_loc, NULL, &rho, 1, 20) (:254)
+        double rho = o->regularize_rho;
+        if (d && !(rho > 0.0)) { // rho = MatGetMaxEigenvalue(K_loc, NULL, &rho, 1, 20) (:254)
           pmh_csr Kblk = nullptr;
           pmh_op  op   = nullptr;
           GO(pmh_csr_create(ctx, p, p, brp.data(), bci.data(), val + z0, &Kblk));

@@ -51,14 +51,16 @@ def test_ex71_poisson_goldens_through_the_driver(ctx, goldens, gtype, its):
 @pytest.mark.parametrize("regularize", [True, False])
 @pytest.mark.parametrize("lumped", [False, True])
 def test_ex71_elasticity_floating_slabs(ctx, goldens, regularize, lumped):
-    """7 slabs, 6 of them floating (coarse problem of 36): K^+ on K_reg (the reference's default) or Moore-Penrose wrapped; the
-    golden counts 66 / 26 are reproduced within the +-5 the ill-conditioned slab decomposition allows (tests/test_feti_goldens.py)."""
+    """7 slabs, 6 of them floating (coarse problem of 36).  With K^+ = K_reg^{-1} -- the reference's default chain -- the golden
+    counts 66 / 26 are reproduced within +-2 for any regularisation scale rho (measured 65-68 / 27 for rho from 1 to 13,
+    scripts/ex71_elasticity_counts.py); the Moore-Penrose wrapped K^+ is less stable on this one-element-thick slab decomposition
+    (67-87 / 29-35 depending on the inner tolerance) and keeps the +-5 margin of tests/test_feti_goldens.py."""
     prob = DmdaFeti((8, 6, 4), 7, "elasticity")
     l2g = _dmda_l2g(prob)
-    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, regularize=regularize, kplus_rtol=1e-13,
+    u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, regularize=regularize, kplus_rtol=1e-14 if regularize else 1e-13,
                                  options="-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type %s" % ("lumped" if lumped else "none"))  # feti/ex71.c:442
     gold = goldens["feti_ex71_2_lumped" if lumped else "feti_ex71_2_none"]["solves"][0]["iterations"]
-    assert st.reason == 2 and abs(st.iteration - gold) <= 5 and st.coarse_dim == 36
+    assert st.reason == 2 and abs(st.iteration - gold) <= (2 if regularize else 5) and st.coarse_dim == 36
     Rg, A, b = _assembled(prob, l2g)
     x = spla.spsolve(A, b)
     assert np.linalg.norm(u - Rg @ x) <= 1e-3 * np.linalg.norm(x)
