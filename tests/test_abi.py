@@ -57,7 +57,8 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "permon_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(pmh_mpgp_opts), sizeof(pmh_mpgp_stats), sizeof(pmh_smalxe_opts), sizeof(pmh_smalxe_stats), sizeof(pmh_pcpg_stats)); return 0; }
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pmh_mpgp_opts), sizeof(pmh_mpgp_stats), sizeof(pmh_smalxe_opts), sizeof(pmh_smalxe_stats), sizeof(pmh_pcpg_stats),
+  sizeof(pmh_qps_opts), sizeof(pmh_kspfeti_opts), sizeof(pmh_kspfeti_stats)); return 0; }
 '''
     import tempfile
 
@@ -67,5 +68,5 @@ int main(void){ printf("%zu %zu %zu %zu %zu\n", sizeof(pmh_mpgp_opts), sizeof(pm
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = list(map(int, subprocess.check_output([exe]).split()))
-    got = [ctypes.sizeof(t) for t in (_lib.MpgpOpts, _lib.MpgpStats, _lib.SmalxeOpts, _lib.SmalxeStats, _lib.PcpgStats)]
+    got = [ctypes.sizeof(t) for t in (_lib.MpgpOpts, _lib.MpgpStats, _lib.SmalxeOpts, _lib.SmalxeStats, _lib.PcpgStats, _lib.QpsOpts, _lib.KspFetiOpts, _lib.KspFetiStats)]
     assert got == sizes
