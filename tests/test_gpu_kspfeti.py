@@ -107,3 +107,61 @@ def test_tfeti_dirichlet_rows_in_B(ctx, gtype):
     u2, _, st2 = pa.KSPFETISolve(ctx, f.block_rowstart, f.K, fsplit, l2g, dirichlet_local=dirl, R=f.R, gluing=gtype, regularize=False, exclude_dirichlet=True, rtol=1e-10, kplus_rtol=1e-13)
     assert st2.reason == 2 and st2.n_lambda < st.n_lambda
     assert np.linalg.norm(u2 - Rg @ x) <= 1e-7 * np.linalg.norm(x)
+
+
+@pytest.mark.parametrize("dir_in_hess", [False, True])
+def test_feti_ex1_tutorial_one_iteration(ctx, goldens, dir_in_hess):
+    """src/tutorials/feti/ex1.c (-ne 7, 4 subdomains of a 1-D bar, -u'' = sin(pi u)): the goldens ex1_1.out / ex1_2.out say
+    'PERMON FETI CONVERGED_RTOL in 1 iteration'.  MATIS input: local element matrices, ASSEMBLED right-hand side split by
+    pmh_qpt_matis_split_rhs, Dirichlet ends by rows of B (default) or eliminated in the blocks (-dir_in_hess)."""
+    import ctypes as C
+
+    from permon_amd import _lib
+
+    ns, ne_l = 4, 7
+    nl, ng = ne_l + 1, ns * ne_l + 1
+    h = 1.0 / (ns * ne_l)
+    Ke = np.array([[1.0, -1.0], [-1.0, 1.0]])
+    blocks, l2g = [], []
+    b = np.zeros(ng)
+    for r in range(ns):
+        Ki = np.zeros((nl, nl))
+        for i in range(ne_l):
+            Ki[i:i + 2, i:i + 2] += Ke
+            v = np.sin((r * ne_l + i + 0.5) * h * 3.14159) * 0.5 * h * h
+            b[r * ne_l + i] += v
+            b[r * ne_l + i + 1] += v
+        blocks.append(Ki)
+        l2g.append(r * ne_l + np.arange(nl))
+    l2g = np.concatenate(l2g).astype(np.int32)
+    N = l2g.size
+    f = np.zeros(N)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _lib.check(ctx.L.pmh_qpt_matis_split_rhs(N, p(l2g), ng, p(b), p(f)))
+    rs = np.arange(ns + 1, dtype=np.int32) * nl
+    dirl = [0, N - 1]  # global dofs 0 and ng-1 live in the first and the last subdomain only
+    R = np.zeros((1, N))
+    if dir_in_hess:  # MatZeroRowsColumns with diag = max |diag| (qpfeti.c:296-303): the two end subdomains no longer float
+        for blk, i in ((0, 0), (ns - 1, nl - 1)):
+            blocks[blk][i, :] = 0.0
+            blocks[blk][:, i] = 0.0
+            blocks[blk][i, i] = 2.0
+        f[dirl] = 0.0
+        R[0, nl:N - nl] = 1.0
+    else:
+        R[0, :] = 1.0
+    K = sp.block_diag(blocks, format="csr")
+    u, lam, st = pa.KSPFETISolve(ctx, rs, K, f, l2g, dirichlet_local=None if dir_in_hess else dirl, R=R, rtol=1e-5, kplus_rtol=1e-14)
+    g = goldens["feti_ex1_2" if dir_in_hess else "feti_ex1_1"]
+    assert st.reason == 2 and st.iteration == 1  # "PERMON FETI CONVERGED_RTOL in 1 iteration"
+    assert st.coarse_dim == (ns - 2 if dir_in_hess else ns) and st.n_dirichlet_rows == (0 if dir_in_hess else 2)
+    assert g["kkt"][-1]["name"] == "||A*x - b||"
+    # the solution of the assembled problem with u(0) = u(1) = 0
+    A = np.zeros((ng, ng))
+    for e in range(ns * ne_l):
+        A[e:e + 2, e:e + 2] += Ke
+    x = np.zeros(ng)
+    x[1:-1] = np.linalg.solve(A[1:-1, 1:-1], b[1:-1])
+    xg = np.zeros(ng)
+    _lib.check(ctx.L.pmh_qpt_matis_assemble_solution(N, p(l2g), p(np.ascontiguousarray(u)), ng, p(xg)))
+    assert np.linalg.norm(xg - x) <= 1e-10 * np.linalg.norm(x)
