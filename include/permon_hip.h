@@ -49,6 +49,7 @@ typedef struct pmh_ctx_s *pmh_ctx;
 
 int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; fails loudly without a GPU */
 int pmh_finalize(pmh_ctx ctx);
+int pmh_mem_info(pmh_ctx ctx, size_t *free_bytes, size_t *total_bytes); /* HBM of the context's device */
 int pmh_device_name(pmh_ctx ctx, char *buf, size_t len);
 int pmh_sync(pmh_ctx ctx);                  /* hipStreamSynchronize of the context's compute stream */
 void *pmh_stream(pmh_ctx ctx);              /* the hipStream_t kernels are launched on */

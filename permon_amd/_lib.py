@@ -90,6 +90,7 @@ _PROTOS = {
     "pmh_finalize": [vp],
     "pmh_device_name": [vp, C.c_char_p, C.c_size_t],
     "pmh_sync": [vp],
+    "pmh_mem_info": [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "pmh_malloc": [vp, C.c_size_t, C.POINTER(vp)],
     "pmh_free": [vp, vp],
     "pmh_memcpy_h2d": [vp, vp, vp, C.c_size_t],

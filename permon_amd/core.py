@@ -38,6 +38,12 @@ class Context:
     def sync(self):
         check(self.L.pmh_sync(self.h))
 
+    def mem_info(self):
+        """(free, total) bytes of the device's HBM."""
+        f, t = C.c_size_t(), C.c_size_t()
+        check(self.L.pmh_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def timer_start(self):
         check(self.L.pmh_timer_start(self.h))
 

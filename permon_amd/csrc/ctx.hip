@@ -72,6 +72,16 @@ extern "C" int pmh_device_name(pmh_ctx c, char *buf, size_t len)
   return PMH_SUCCESS;
 }
 
+// free / total bytes of the device's HBM (hipMemGetInfo): sizing against the 288 GB, leak checks in the tests
+extern "C" int pmh_mem_info(pmh_ctx c, size_t *free_bytes, size_t *total_bytes)
+{
+  PMH_ARG(c && free_bytes && total_bytes);
+  PMH_HIP(hipSetDevice(c->device));
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  PMH_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_sync(pmh_ctx c)
 {
   PMH_ARG(c);

@@ -165,3 +165,22 @@ def test_feti_ex1_tutorial_one_iteration(ctx, goldens, dir_in_hess):
     xg = np.zeros(ng)
     _lib.check(ctx.L.pmh_qpt_matis_assemble_solution(N, p(l2g), p(np.ascontiguousarray(u)), ng, p(xg)))
     assert np.linalg.norm(xg - x) <= 1e-10 * np.linalg.norm(x)
+
+
+def test_driver_and_chain_release_their_device_memory(ctx):
+    """Every object pmh_kspfeti_solve creates (CSR copies, K_reg, MATINV work vectors, gluing, projector, chain) is released:
+    repeated solves do not grow the HBM footprint (hipMemGetInfo through pmh_mem_info)."""
+    prob = DmdaFeti((8, 6, 4), 7, "elasticity")
+    l2g = _dmda_l2g(prob)
+
+    def once():
+        pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6)
+        pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, regularize=False, lumped=True)
+
+    once()
+    free0, total = ctx.mem_info()
+    assert total > 250e9  # an MI355X: 288 GB
+    for _ in range(5):
+        once()
+    free1, _ = ctx.mem_info()
+    assert free0 - free1 <= 8 << 20, (free0, free1)
