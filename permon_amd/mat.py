@@ -197,6 +197,10 @@ class MG:
         self.precision = precision
         A, P = hier["A"], hier["P"]
         self.nlevels = len(A)
+        import os
+
+        if os.environ.get("PMH_MG_WINDOW"):  # tuning knob: "lo,hi" fractions of lambda_max(D^-1 A) of the Chebyshev window
+            lo, hi = (float(v) for v in os.environ["PMH_MG_WINDOW"].split(","))
 
         def up(M):
             M = M.tocsr()
