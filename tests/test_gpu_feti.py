@@ -208,6 +208,28 @@ def test_ex3_goldens_on_gpu(ctx, goldens):
     qps.SetType("mpgp")
     st = qps.Solve()
     assert (st.iteration, st.nmv, st.ncg, st.nexp, st.nprop, st.reason) == (g["iterations"], g["nmv"], g["ncg"], g["nexp"], g["nprop"], g["reason"])
+    # -qp_chain_view_kkt of ex3_1.out: four lines of the dual (box) QP, then four of the primal QP after QPTDualizePostSolve
+    kk = goldens["ex3_1"]["kkt"]
+    assert len(kk) == 8
+
+    def same(val, printed):
+        return ("%.2e" % val) == printed or (float(printed) < 1e-12 and abs(val) < 1e-12)
+
+    import re
+
+    for line, ref in zip(qps.ViewKKT(), kk[:4]):
+        m = re.match(r"r = (.*?)\s*= (\S+)\s+rO?/\|\|b\|\| = (\S+)", line)
+        assert line.startswith("r = " + ref["name"]) and same(float(m.group(2)), ref["r"]) and same(float(m.group(3)), ref["r_rel"]), (line, ref)
+    p3 = P.ex3_primal(n)
+    Kd = sp.csr_matrix((p3["val"], p3["col"], p3["rowptr"]), shape=(n, n)).toarray()
+    BI, lam = np.diag(p3["BI_diag"]), qp.x.to_numpy()
+    xp = np.linalg.solve(Kd, p3["b"] - BI.T @ lam)  # u = K^+(f - B' lambda), qptransform.c:812-815 (K regular here)
+    nb = np.linalg.norm(p3["b"])
+    gap = BI @ xp - p3["cI"]
+    vals = [np.linalg.norm(Kd @ xp - p3["b"] + BI.T @ lam), np.linalg.norm(np.maximum(gap, 0.0)), np.linalg.norm(np.minimum(lam, 0.0)), abs(lam @ gap)]
+    assert vals[0] <= 1e-13 and float(kk[4]["r"]) <= 1e-13  # rounding level on both sides
+    for v, ref in zip(vals[1:], kk[5:]):
+        assert same(v, ref["r"]) and same(v / nb, ref["r_rel"]), (v, v / nb, ref)
 
     outer, inner = goldens["ex3_nullspace"]["solves"]
     G0 = pa.CsrMat(ctx, 0, n, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
