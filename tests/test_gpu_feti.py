@@ -247,6 +247,25 @@ def test_ex3_goldens_on_gpu(ctx, goldens):
     assert (s2.iteration, s2.reason, s2.inner_iter_accu) == (outer["iterations"], outer["reason"], outer["inner_iterations"])
     i2 = s2.inner
     assert (i2.reason, i2.nmv, i2.ncg, i2.nexp, i2.nprop) == (inner["reason"], inner["nmv"], inner["ncg"], inner["nexp"], inner["nprop"])
+    # ex3_nullspace.out prints 13 KKT lines: the penalised QP, the dual QP with its (empty) equality constraint, the primal QP.
+    # Entries of rounding size (1.08e-19 in the golden: a multiplier that is -1e-19 instead of 0) are compared by magnitude.
+    kn = goldens["ex3_nullspace"]["kkt"]
+    lam2 = qp2.x.to_numpy()
+    box = qps2.ViewKKT()  # the dual QP's box lines (same numbers on lines 0-3 and 6-8 of the golden)
+    for line, ref in zip(box, kn[:4]):
+        m = re.match(r"r = (.*?)\s*= (\S+)\s+rO?/\|\|b\|\| = (\S+)", line)
+        assert line.startswith("r = " + ref["name"])
+        if float(ref["r"]) < 1e-15:
+            assert float(m.group(2)) < 1e-12
+        else:
+            assert (m.group(2), m.group(3)) == (ref["r"], ref["r_rel"]), (line, ref)
+    assert [k["r"] for k in kn[6:9]] == [k["r"] for k in kn[1:4]]
+    xp2 = np.linalg.solve(Kd, p3["b"] - BI.T @ lam2)
+    gap2 = BI @ xp2 - p3["cI"]
+    v2 = [np.linalg.norm(np.maximum(gap2, 0.0)), abs(lam2 @ gap2)]
+    for v, ref in zip(v2, (kn[10], kn[12])):
+        assert same(v, ref["r"]) and same(v / nb, ref["r_rel"]), (v, v / nb, ref)
+    assert np.linalg.norm(Kd @ xp2 - p3["b"] + BI.T @ lam2) <= 1e-13 and np.linalg.norm(np.minimum(lam2, 0.0)) <= 1e-15
 
 
 def test_config3_shape_64_subdomains_dense_coarse_solve(ctx, oracle):
