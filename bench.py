@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=3162, help="c2: nx = ny of the 5-pt Laplacian")
     ap.add_argument("--variant", default="obstacle", choices=["obstacle", "twosided"])
     ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
+    ap.add_argument("--sub", default="2,2,2", help="feti: subdomain grid sx,sy,sz (2,2,2 -> configs[2]; 4,4,4 with --nel 21 --dense-coarse -> the shape of configs[3]: 64 subdomains, 8 per GPU at N = 8, 384 x 384 coarse problem)")
+    ap.add_argument("--dense-coarse", action="store_true", help="feti: keep G as it comes (no QPTOrthonormalizeEq): the projector applies the dense (GG')^{-1} (GG' assembled by the fp64-MFMA kernel)")
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
     ap.add_argument("--mg-precision", choices=["fp16", "fp32", "fp64"], default="fp16", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
@@ -279,7 +281,7 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[2]: TFETI contact problem, SMALXE + MPGP on the dual QP, subdomain blocks sharded over the GPUs
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol):
+def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol, orth=True):
     """Same dual operator on the host cores: the oracle's MPGP (C, reference op order) on A_rho = P F P + rho Q with
     F = B K^+ B', K^+ = per-block Jacobi-CG in C with OpenMP row-parallel CSR SpMV (oracle/permon_oracle.c).
     Bounded sample: `steps` MPGP iterations from the same right-hand side / bounds the GPU run uses."""
@@ -288,7 +290,7 @@ def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol):
     cores = host_threads()
     K = O.Csr.from_scipy(f.K)
     Kplus = O.MatInv(K, f.block_rowstart, f.R, rtol=rtol, omp=True)
-    pfo = O.Qppf(O.Csr.from_scipy(G), orthonormal=True)
+    pfo = O.Qppf(O.Csr.from_scipy(G), orthonormal=orth)
     B = O.Gluing(f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
     A_or = O.FetiOp(B, Kplus, pfo, rho=1.0, which=1, omp=True)  # any positive penalty: cost per iteration is the same
     n = f.n_lambda
@@ -308,15 +310,18 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     from permon_amd.chain import FetiDualQP
 
     t0 = time.time()
-    f = pa.CubeFeti((2, 2, 2), a.nel, contact=True)
-    G, e = f.coarse(orthonormalize=True)
-    if 8 % world:
-        raise SystemExit("feti workload: the 8 subdomains must divide over the ranks (N in 1,2,4,8)")
-    per = 8 // world
+    sub = tuple(int(v) for v in a.sub.split(","))
+    nsub = sub[0] * sub[1] * sub[2]
+    orth = not a.dense_coarse
+    f = pa.CubeFeti(sub, a.nel, contact=True)
+    G, e = f.coarse(orthonormalize=orth)
+    if nsub % world:
+        raise SystemExit("feti workload: the %d subdomains must divide over the ranks" % nsub)
+    per = nsub // world
     if a.sim_world and world == 1:
-        if 8 % a.sim_world:
-            raise SystemExit("--sim-world must divide 8")
-        per = 8 // a.sim_world
+        if nsub % a.sim_world:
+            raise SystemExit("--sim-world must divide the number of subdomains")
+        per = nsub // a.sim_world
     local = f.subset(range(rank * per, (rank + 1) * per))
     t_gen = time.time() - t0
     t0 = time.time()
@@ -333,7 +338,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         # (dense block pseudo-inverse at ~5000 dof, one HBM-streaming launch instead of a smoothed level's seven) -- measured, profiles/
         auto_nodes = 2000 if per <= (4 if a.mg_precision == "fp16" else 1) else 400
         hier = pa.box_mg_hierarchy(blocks, [(nn, nn, nn)] * per, 3, min_nodes=a.mg_min_nodes or auto_nodes)
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=True, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
                    regularize=a.regularize)
     qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
     t_setup = time.time() - t0
@@ -402,9 +407,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
-        "workload": "configs[2]: 3-D elasticity TFETI, 2x2x2 cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
-                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+%s (rtol %.0e)"
-                    % (a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq, pc_text, kreg_text, a.kplus_rtol),
+        "workload": "%s: 3-D elasticity TFETI, %dx%dx%d cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
+                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+%s (rtol %.0e)%s"
+                    % ("configs[2]" if (sub == (2, 2, 2) and orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like", sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
+                       pc_text, kreg_text, a.kplus_rtol, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
         "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
@@ -417,7 +423,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "roofline": {
             "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(kpat, "r01_h_pmc_traffic_feti.json") if (a.nel == 43 and world == 1 and not a.sim_world) else None,
+            "traffic": pmc_traffic(kpat, "r01_h_pmc_traffic_feti.json") if (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world) else None,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
             "timing_stride": int(os.environ.get("PMH_TIMING_STRIDE", "1")),
             "timed_over": "the timed region" if timing_in_region else "a separate 2-step pass after the timed region (hipGraph replay inside it)",
@@ -429,7 +435,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     q.Kplus.timing_enable(0)
     if hier is not None:
         q.Kplus.mg.timing_enable(0)
-    return res, f, G, q.b.to_numpy(), q.lb_new.to_numpy()
+    return res, f, G, q.b.to_numpy(), q.lb_new.to_numpy()  # (the CPU baseline leg re-uses the generated problem)
 
 
 def main():
@@ -506,7 +512,7 @@ def main():
         if rank == 0 and world == 1:
             if not a.no_cpu_baseline:
                 try:
-                    out["cpu_baseline"] = cpu_baseline_feti(f, G, b_dual, lb_dual, 1, a.kplus_rtol)
+                    out["cpu_baseline"] = cpu_baseline_feti(f, G, b_dual, lb_dual, 1, a.kplus_rtol, orth=not a.dense_coarse)
                 except Exception as ex:  # noqa: BLE001
                     out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
             if not a.no_c2:
