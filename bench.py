@@ -420,6 +420,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "kplus": {"pc": a.kplus_pc, "cg_spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(steps, 1),
                   "last_block_cg_iterations": kits},
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
+        "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
+                                      "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": True},
         "roofline": {
             "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -505,7 +507,7 @@ def main():
             "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"],
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"],
                        "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
             "roofline": r["roofline"],
         }

@@ -196,6 +196,8 @@ typedef struct pmh_qppf_s *pmh_qppf;
    orthonormal != 0 <=> G_has_orthonormal_rows (GGtinv = NULL, qppf.c:225-229) */
 int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf *pf);
 int pmh_qppf_destroy(pmh_qppf pf);
+/* set-up cost of the coarse problem: GG' assembly on the matrix cores (ms, flops = 2 Mp^2 n) and the host Cholesky + inverse (ms) */
+int pmh_qppf_setup_stats(pmh_qppf pf, double *ggt_mfma_ms, double *ggt_flops, double *host_inverse_ms);
 int pmh_qppf_apply_Q(pmh_qppf pf, const double *v, double *Qv);     /* QPPFApplyQ   qppf.c:454-503 */
 int pmh_qppf_apply_P(pmh_qppf pf, const double *v, double *Pv);     /* QPPFApplyP   qppf.c:563-575 */
 int pmh_qppf_apply_GtG(pmh_qppf pf, const double *v, double *y);    /* QPPFApplyGtG qppf.c:580-605 */

@@ -108,6 +108,7 @@ struct pmh_qppf_s {
   int     orthonormal;
   double *d_inv; // (GG')^{-1}, m x m row-major
   double *G_left, *Gt_right;
+  double  ggt_mfma_ms, host_inverse_ms; // set-up timings (pmh_qppf_setup_stats)
   // QPPFApplyQ's (v,state) -> Qv cache (qppf.c:464-467,495-498) is realised structurally: the penalised
   // operator over a projected operator computes Q x once and reuses it (see PenalizedOp::mult).
 };

@@ -7,6 +7,8 @@
 // path on the transposed CSR.  The coarse problem (GG')^{-1} is small and dense: GG' is assembled and
 // inverted on the host once (the reference's QPPFSetUpGGt_Private / -qppf_explicit_inv path, qppf.c:213-333)
 // and applied as a dense GEMV, redundantly on every GPU (mirrors -qppf_redundancy, qppf.c:182,305).
+#include <chrono>
+
 #include "pmh_internal.h"
 #include "reduce.h"
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_ggt_reduce(int nchunks, int Mp, c
 }
 
 // device GG' (m x m, row-major, returned on the host)
-static int device_ggt(pmh_ctx ctx, pmh_csr G, std::vector<double> &ggt)
+static int device_ggt(pmh_ctx ctx, pmh_csr G, std::vector<double> &ggt, double *mfma_ms)
 {
   const int m = G->nrows, n = G->ncols, Mp = ((m + 15) / 16) * 16, nt = Mp / 16;
   const int nchunks = (n + GGT_KCHUNK - 1) / GGT_KCHUNK;
@@ -84,9 +86,15 @@ static int device_ggt(pmh_ctx ctx, pmh_csr G, std::vector<double> &ggt)
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)Mp * Mp, (void **)&dggt));
   PMH_CHK(pmh_memset(ctx, Gt, 0, sizeof(double) * (size_t)n * Mp));
   hipLaunchKernelGGL(k_densify_gt, dim3(m), dim3(PMH_BLOCK), 0, ctx->stream, m, Mp, (const int *)G->d_rowptr, (const int *)G->d_col, (const double *)G->d_val, Gt);
+  PMH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_ggt_mfma, dim3(nt * nt, nchunks), dim3(PMH_BLOCK), 0, ctx->stream, n, Mp, (const double *)Gt, part);
   hipLaunchKernelGGL(k_ggt_reduce, dim3(nt * nt), dim3(PMH_BLOCK), 0, ctx->stream, nchunks, Mp, (const double *)part, dggt);
+  PMH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   PMH_HIP(hipGetLastError());
+  PMH_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PMH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (mfma_ms) *mfma_ms = ms;
   std::vector<double> full((size_t)Mp * Mp);
   PMH_CHK(pmh_memcpy_d2h(ctx, full.data(), dggt, sizeof(double) * full.size()));
   ggt.assign((size_t)m * m, 0.0);
@@ -141,14 +149,18 @@ extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf
   pf->n          = G->ncols;
   pf->orthonormal = orthonormal ? 1 : 0;
   pf->d_inv      = nullptr;
+  pf->ggt_mfma_ms = pf->host_inverse_ms = 0.0;
   const int m    = pf->m;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->G_left));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&pf->Gt_right));
   if (!pf->orthonormal && m > 0) {
     // GG' on the device with fp64 MFMA (QPPFSetUpGGt_Private qppf.c:213-278); the small dense factorisation stays on the host
     std::vector<double> ggt;
-    PMH_CHK(device_ggt(ctx, G, ggt));
-    if (host_cholesky_inverse(m, ggt)) {
+    PMH_CHK(device_ggt(ctx, G, ggt, &pf->ggt_mfma_ms));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int  bad = host_cholesky_inverse(m, ggt);
+    pf->host_inverse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bad) {
       pmh_free(ctx, pf->G_left);
       pmh_free(ctx, pf->Gt_right);
       delete pf;
@@ -158,6 +170,18 @@ extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf
     PMH_CHK(pmh_memcpy_h2d(ctx, pf->d_inv, ggt.data(), sizeof(double) * (size_t)m * m));
   }
   *out = pf;
+  return PMH_SUCCESS;
+}
+
+// set-up cost of the coarse problem (SURVEY 8d asks for them separately): the GG' assembly on the matrix cores
+// (k_ggt_mfma + its fixed-order reduction; 2 Mp^2 n flops with Mp = m rounded up to 16) and the host Cholesky + inverse
+extern "C" int pmh_qppf_setup_stats(pmh_qppf pf, double *ggt_mfma_ms, double *ggt_flops, double *host_inverse_ms)
+{
+  PMH_ARG(pf);
+  const double Mp = (double)(((pf->m + 15) / 16) * 16);
+  if (ggt_mfma_ms) *ggt_mfma_ms = pf->ggt_mfma_ms;
+  if (ggt_flops) *ggt_flops = pf->orthonormal ? 0.0 : 2.0 * Mp * Mp * (double)pf->n;
+  if (host_inverse_ms) *host_inverse_ms = pf->host_inverse_ms;
   return PMH_SUCCESS;
 }
 

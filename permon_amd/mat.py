@@ -260,6 +260,12 @@ class QPPF:
         G.sort_indices()
         return cls(ctx, CsrMat(ctx, G.shape[0], G.shape[1], G.indptr, G.indices, G.data), orthonormal)
 
+    def setup_stats(self):
+        """(GG' assembly ms on the matrix cores, its flops, host Cholesky + inverse ms)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(self.ctx.L.pmh_qppf_setup_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def ApplyQ(self, v, Qv):
         check(self.ctx.L.pmh_qppf_apply_Q(self.h, v.p, Qv.p))
 
