@@ -362,9 +362,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
 
     def timing_on():
         os.environ.setdefault("PMH_TIMING_STRIDE", "5")  # event pairs around every 5th K x launch (each pair costs stream time; 5 is coprime to the 4 fine-level launches of a cycle, so all four kernel variants are sampled)
-        q.Kplus.timing_enable(60000)
+        q.Kplus.timing_enable(8000)
         if hier is not None:
-            q.Kplus.mg.timing_enable(60000)
+            q.Kplus.mg.timing_enable(8000)
 
     if timing_in_region:
         timing_on()
