@@ -337,6 +337,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         # depth of the hierarchy by blocks per GPU: with 1-2 blocks the cycle is launch-latency bound, so it stops one level earlier
         # (dense block pseudo-inverse at ~5000 dof, one HBM-streaming launch instead of a smoothed level's seven) -- measured, profiles/
         auto_nodes = 2000 if per <= (4 if a.mg_precision == "fp16" else 1) else 400
+        auto_nodes = min(auto_nodes, nn ** 3 // 8)  # tiny test problems: at least one smoothed level
         hier = pa.box_mg_hierarchy(blocks, [(nn, nn, nn)] * per, 3, min_nodes=a.mg_min_nodes or auto_nodes)
     q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
                    regularize=a.regularize)

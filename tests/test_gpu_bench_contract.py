@@ -1,0 +1,48 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys (small problem sizes here; the real sizes are the
+defaults).  Also the CPU-baseline leg and the secondary configs[1] block on a reduced grid."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_workload_line_small():
+    d = _run("--nel", "7", "--steps", "3", "--warmup", "1", "--grid", "300", "--cpu-its", "3")
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "QPS iterations/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "strong"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    c1 = d["configs1"]
+    assert ROOF <= set(c1["roofline"]) and c1["value"] > 0 and c1["cpu_baseline"]["value"] > 0
+
+
+def test_rehearsal_and_other_workloads_small():
+    d = _run("--nel", "7", "--steps", "2", "--warmup", "1", "--sim-world", "4", "--no-cpu-baseline", "--no-c2")
+    assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["timed_over"].startswith("a separate")
+    d = _run("--workload", "c2", "--grid", "400", "--steps", "20", "--warmup", "2", "--no-cpu-baseline")
+    assert KEYS <= set(d) and d["scaling"] == "weak" and d["config"]["workload"].startswith("configs[1]")
+    d = _run("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2")
+    assert KEYS <= set(d) and d["config"]["workload"].startswith("configs[4]")
+    d = _run("--sub", "2,2,1", "--nel", "5", "--dense-coarse", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c2")
+    assert d["config"]["coarse_problem"]["m"] == 24 and d["config"]["coarse_problem"]["GGt_mfma_ms"] > 0
