@@ -287,6 +287,38 @@ int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F);
 /* PCApply_Dual lumped: y = B K B' x (src/pc/impls/dual/pcdual.c:63-78) */
 int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, double *y);
 
+/* ---- explicit local dual operators: the exact K^+ path of F ------------------------------------------------
+ * The reference forms an inverse explicitly column by column with its inner KSP (MatInvExplicitly_Inv, src/mat/impls/inv/
+ * matinv.c:670-730, _Private :640-665: one KSPSolve per column of the identity); it applies K^+ inside F = B K^+ B'
+ * (qptransform.c:1103-1128) by a per-block factorisation (matinv.c:435-590).  pmh_fexplicit is that explicit inverse restricted
+ * to what F can see: for every block b of the rank the dense symmetric W_b = (K_b^+)[Gamma_b, Gamma_b], Gamma_b = the primal
+ * dofs of the block that B touches.  F lambda = Bhat blockdiag(W_b) Bhat' lambda: two CSR launches + ONE dense fp64 GEMV that
+ * streams 8 n_Gamma_b^2 bytes per block (HBM roofline; SURVEY 8d "dense path"), instead of an inner Krylov solve.
+ * _assemble: the columns come from K^+ applications of `solver`, a MATINV whose nslots blocks are solved at once, one unit
+ * right-hand side each, at tolerance rtol (1e-12: F exact to that).  block_class[b] / slot_class[s] name classes of identical
+ * matrices (pmh_csr_block_classes): blocks of one class share their columns and any slot of the class may produce them; NULL, NULL
+ * = slot s solves for block s (solver = the operator's own K^+).  Set-up cost: one K^+ application per
+ * ceil(|union of the class's Gamma| / slots of the class). */
+typedef struct pmh_fexplicit_s *pmh_fexplicit;
+int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
+int pmh_fexplicit_destroy(pmh_fexplicit E);
+int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);
+int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
+int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds);
+int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *W_host /* n_Gamma_b^2 row-major or NULL */, int *gamma_host /* or NULL */);
+int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double *y);              /* y = F lambda (MatMult of the product) */
+int pmh_fexplicit_compressed_size(pmh_fexplicit E, int *ntot, int *gstart /* [nblocks+1] or NULL */);
+int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xhat, double *yhat);        /* the dense kernel alone, compressed vectors */
+int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, int stride);         /* HIP-event pairs around the GEMV launches */
+int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms);
+/* F = B K^+ B' built on this MATINV (pmh_op_create_feti_dual, the FETI chain) applies through E from now on (E built from the
+   same B; NULL detaches).  K^+ f for a general f (d = B K^+ f - c, primal recovery) stays on the inner KSP. */
+int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E);
+int pmh_matinv_set_tolerances(pmh_matinv Kplus, double rtol, double atol, int max_it);  /* KSPSetTolerances of MatInvGetKSP's KSP */
+int pmh_matinv_get_tolerances(pmh_matinv Kplus, double *rtol, double *atol, int *max_it);
+/* classes of bit-identical diagonal blocks of a block-diagonal host CSR (congruent subdomains): block_class[b] in [0, nclasses) */
+int pmh_csr_block_classes(int nblocks, const int *block_rowstart, const int *rowptr, const int *col, const double *val, int *block_class, int *nclasses);
+
 /* ---- QP transform chain of the (T)FETI path, data part (src/qp/interface/qptransform.c) -------------------------------
    QPTDualize (:1102-1174: F = B K^+ B', d = B K^+ f - c) -> QPTHomogenizeEq (:437-527: lambda~ = G'(GG')^{-1} e,
    b_bar = d - F lambda~, lb <- lb - lambda~) -> QPTEnforceEqByProjector (:215-316: A = P F P with a box, P F without;
@@ -317,6 +349,12 @@ typedef struct {
   double maxeig, maxeig_tol; int maxeig_iter;
   int    inject_maxeig, inject_maxeig_set;
   int    inner_iter_min, inner_no_gtol_stop;
+  /* ||Bu|| update (smalxe.c:878-886): be_implicit = BE has no mult slot, only B'B is available -> QPSSMALXEUpdateNormBu_SMALXEON
+     (:265-285, ||Bu|| = sqrt(u'B'Bu), BtBu reused by the lambda update), with lag_enabled (-qps_smalxe_norm_update_lag) the lagged
+     variant (:289-370; offset / Jstart / Jstep / Jend / lower / upper as :757-762, defaults :1190-1200) */
+  int    be_implicit, lag_enabled, lag_offset, lag_start, lag_step, lag_end;
+  double lag_lower, lag_upper;
+  int    knoll;              /* -qps_smalxe_knoll (smalxe.c:764,938-943): u0 = P b */
   pmh_mpgp_opts inner;       /* inner MPGP (prefix smalxe_) */
 } pmh_smalxe_opts;
 
@@ -334,6 +372,9 @@ int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double *u, const d
 int pmh_smalxe_destroy(pmh_smalxe s);
 int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve_SMALXE smalxe.c:893-997 */
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
+/* throughput mode for bench.py: the real solver loop for exactly `inner_iters` inner MPGP iterations in total (a solve that
+   converges earlier restarts from u = 0; counts accumulate over the restarts) */
+int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv);
 int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
 /* ---- options front end (QPSSetFromOptions qps.c:860-900, _MPGP mpgp.c:712-745, _SMALXE smalxe.c:696-766) ----------

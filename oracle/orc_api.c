@@ -120,7 +120,7 @@ int orc_smalxe_set(orc_smalxe *s, const char *key, double v)
 {
   SSETD(rtol) SSETD(atol) SSETD(divtol) SSETI(max_it) SSETD(M1_user) SSETI(M1_direct) SSETD(M1_update) SSETD(rtol_E) SSETD(rho_user) SSETI(rho_direct)
     SSETD(rho_update) SSETD(rho_update_late) SSETD(eta_user) SSETI(eta_direct) SSETD(update_threshold) SSETD(maxeig) SSETD(maxeig_tol) SSETI(maxeig_iter)
-      SSETI(inject_maxeig) SSETI(inject_maxeig_set) SSETI(inner_iter_min) SSETI(inner_no_gtol_stop) SSETI(inner_max_it) return 1;
+      SSETI(inject_maxeig) SSETI(inject_maxeig_set) SSETI(inner_iter_min) SSETI(inner_no_gtol_stop) SSETI(inner_max_it) SSETI(norm_update) SSETI(lag_offset) SSETI(Jstart) SSETI(Jstep) SSETI(Jend) SSETD(lower) SSETD(upper) SSETI(knoll) return 1;
 }
 
 #define SGET(name) \
@@ -128,7 +128,7 @@ int orc_smalxe_set(orc_smalxe *s, const char *key, double v)
 double orc_smalxe_get(orc_smalxe *s, const char *key)
 {
   SGET(M1) SGET(M1_initial) SGET(eta) SGET(rho) SGET(M1_updates) SGET(M1_hits) SGET(eta_hits) SGET(rho_updates) SGET(state) SGET(inner_iter_accu)
-    SGET(normBu) SGET(enorm) SGET(rnorm) SGET(iteration) SGET(reason) SGET(maxeig) SGET(gtol) if (!strcmp(key, "rho_current")) return s->pen.rho;
+    SGET(normBu) SGET(enorm) SGET(rnorm) SGET(iteration) SGET(reason) SGET(maxeig) SGET(gtol) SGET(lag_neval) SGET(lag_niter) if (!strcmp(key, "rho_current")) return s->pen.rho;
   return -12345.678;
 }
 

@@ -748,17 +748,84 @@ void orc_smalxe_init(orc_smalxe *s)
   s->inner_iter_min     = 1;
   s->inner_no_gtol_stop = 0;
   s->inner_max_it       = 10000;
+  s->norm_update        = 0;
+  s->lag_offset         = 0; /* never assigned in QPSCreate_SMALXE: PetscNew zero */
+  s->Jstart             = 10;
+  s->Jstep              = 5;
+  s->Jend               = 20;
+  s->lower              = 0.1;
+  s->upper              = 1.1;
+  s->knoll              = 0;
   s->state              = 1;
   s->normBu = s->normBu_old = s->enorm = NAN;
   orc_qps_init(&s->inner);
 }
 
 /* QPSSMALXEUpdateNormBu_SMALXE smalxe.c:247-261 (cE == NULL after homogenisation) */
-static void smalxe_update_normBu(orc_smalxe *s, const double *u, double *normBu, double *enorm)
+static void smalxe_update_normBu_std(orc_smalxe *s, const double *u, double *normBu, double *enorm)
 {
   orc_csr_mult((void *)s->pf->G, u, s->Bu);
   *normBu = v_norm2(s->pf->m, s->Bu);
   *enorm  = *normBu / s->rtol_E;
+}
+
+/* QPSSMALXEUpdateNormBu_SMALXEON smalxe.c:265-285: ||Bu|| = sqrt(u'B'Bu) from the penalised term alone */
+static void smalxe_update_normBu_on(orc_smalxe *s, const double *u, double *normBu, double *enorm)
+{
+  double dot;
+  orc_qppf_apply_GtG(s->pf, s->G_orthonormal, u, s->BtBu);
+  dot     = v_dot(s->A->n, u, s->BtBu);
+  *normBu = sqrt(dot);
+  *enorm  = *normBu / s->rtol_E;
+}
+
+/* QPSSMALXEUpdateNormBu_Lag_SMALXEON smalxe.c:289-370: the exact norm every J-th inner iteration only, J growing from Jstart
+   to Jend by Jstep while the norm stays within [lower, upper) of the last exact one */
+static void smalxe_update_normBu_lag(orc_smalxe *s, const double *u, double *normBu, double *enorm)
+{
+  double normBu_approx, normBu_exact, enorm_exact, rdiff;
+  if (s->inner.iteration <= s->lag_offset) {
+    smalxe_update_normBu_on(s, u, &normBu_exact, &enorm_exact);
+    s->lag_neval++;
+    s->lag_normBu0 = normBu_exact;
+    normBu_approx  = s->lag_normBu0;
+    s->lag_J       = s->Jstart;
+    s->lag_II      = 0;
+  } else {
+    if (s->lag_II == 0) {
+      smalxe_update_normBu_on(s, u, &normBu_exact, &enorm_exact);
+      s->lag_neval++;
+      rdiff = fabs(normBu_exact / s->lag_normBu0);
+      if (rdiff >= s->upper) {
+        s->lag_II = 0;
+        s->lag_J  = s->Jstart;
+      } else if (rdiff < s->lower) {
+        s->lag_II = 0;
+        s->lag_J  = s->Jstart;
+      } else {
+        s->lag_II++;
+      }
+      s->lag_normBu0 = normBu_exact;
+    } else {
+      s->lag_II++;
+    }
+    normBu_approx = s->lag_normBu0;
+  }
+  s->lag_niter++;
+  if (s->lag_II == s->lag_J) {
+    s->lag_II = 0;
+    if (s->lag_J < s->Jend) s->lag_J += s->Jstep;
+  }
+  *normBu = normBu_approx;
+  *enorm  = *normBu / s->rtol_E;
+}
+
+/* smalxe->updateNormBu, chosen in QPSSetUp_SMALXE smalxe.c:878-886 */
+static void smalxe_update_normBu(orc_smalxe *s, const double *u, double *normBu, double *enorm)
+{
+  if (s->norm_update == 2) smalxe_update_normBu_lag(s, u, normBu, enorm);
+  else if (s->norm_update == 1) smalxe_update_normBu_on(s, u, normBu, enorm);
+  else smalxe_update_normBu_std(s, u, normBu, enorm);
 }
 
 /* outer QPSConvergedDefault (qps.c:675-714) evaluated on the outer solver's fields */
@@ -912,6 +979,7 @@ int orc_smalxe_solve(orc_smalxe *s)
   s->M1 = s->M1_initial;
   rho   = s->pen.rho;
   v_set(n, s->Btmu, 0.0);
+  if (s->knoll) orc_qppf_apply_P(s->pf, s->b, s->u); /* the Knoll trick smalxe.c:938-943: u = P b */
   Lag_old = orc_objective(&s->A_inner, s->b_inner, s->u, s->xwork);
   smalxe_update_normBu(s, s->u, &s->normBu_old, &s->enorm);
 

@@ -189,6 +189,14 @@ typedef struct {
   int    inject_maxeig, inject_maxeig_set;
   int    inner_iter_min, inner_no_gtol_stop;
   int    inner_max_it;
+  /* ||Bu|| update variant (smalxe.c:878-886): 0 = _SMALXE (:247-261, BE has a mult slot), 1 = _SMALXEON (:265-285, only B'B),
+     2 = _Lag_SMALXEON (:289-370, -qps_smalxe_norm_update_lag); lag parameters :1190-1200 (norm_update_lag_offset is zero-initialised) */
+  int    norm_update, lag_offset, Jstart, Jstep, Jend;
+  double lower, upper;
+  int    knoll; /* -qps_smalxe_knoll smalxe.c:938-943 */
+  /* the function-static state of the lagged update (:291-293) */
+  double lag_normBu0;
+  int    lag_II, lag_J, lag_neval, lag_niter;
   /* state / results */
   double M1, M1_initial, eta, rho;
   int    M1_updates, M1_hits, eta_hits, rho_updates;

@@ -48,6 +48,8 @@ class SmalxeOpts(C.Structure):
         ("maxeig", C.c_double), ("maxeig_tol", C.c_double), ("maxeig_iter", C.c_int),
         ("inject_maxeig", C.c_int), ("inject_maxeig_set", C.c_int),
         ("inner_iter_min", C.c_int), ("inner_no_gtol_stop", C.c_int),
+        ("be_implicit", C.c_int), ("lag_enabled", C.c_int), ("lag_offset", C.c_int), ("lag_start", C.c_int), ("lag_step", C.c_int), ("lag_end", C.c_int),
+        ("lag_lower", C.c_double), ("lag_upper", C.c_double), ("knoll", C.c_int),
         ("inner", MpgpOpts),
     ]
 
@@ -203,6 +205,7 @@ _PROTOS = {
     "pmh_smalxe_solve": [vp],
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
+    "pmh_smalxe_run_fixed": [vp, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
     "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_mg_timing_enable": [vp, C.c_int],
@@ -221,6 +224,21 @@ _PROTOS = {
     "pmh_kspfeti_default_opts": [C.POINTER(KspFetiOpts)],
     "pmh_kspfeti_set_from_options": [C.c_char_p, C.POINTER(KspFetiOpts), C.c_char_p, C.c_int],
     "pmh_kspfeti_solve": [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.POINTER(KspFetiOpts), vp, vp, C.c_int, C.POINTER(KspFetiStats)],
+    "pmh_fexplicit_create": [vp, vp, C.POINTER(vp)],
+    "pmh_fexplicit_destroy": [vp],
+    "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
+    "pmh_fexplicit_assemble": [vp, vp, C.c_int, vp, vp, C.c_double, C.c_int],
+    "pmh_fexplicit_assemble_stats": [vp, C.POINTER(C.c_longlong), c_double_p],
+    "pmh_fexplicit_get_block": [vp, C.c_int, vp, vp],
+    "pmh_fexplicit_mult": [vp, vp, vp],
+    "pmh_fexplicit_compressed_size": [vp, c_int_p, vp],
+    "pmh_fexplicit_dense_mult": [vp, vp, vp],
+    "pmh_fexplicit_timing_enable": [vp, C.c_int, C.c_int],
+    "pmh_fexplicit_timing_get": [vp, c_int_p, c_double_p],
+    "pmh_matinv_attach_explicit": [vp, vp],
+    "pmh_matinv_set_tolerances": [vp, C.c_double, C.c_double, C.c_int],
+    "pmh_matinv_get_tolerances": [vp, c_double_p, c_double_p, c_int_p],
+    "pmh_csr_block_classes": [C.c_int, vp, vp, vp, vp, vp, c_int_p],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

@@ -8,7 +8,7 @@ import numpy as np
 
 from ._lib import check
 from .core import Op, Vec
-from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatGluing, MatInv, MatRegularize, PCDualLumpedOp
+from .mat import QPPF, MatBlockDiag, MatCreateFetiDual, MatCreateProjected, MatExplicitDual, MatGluing, MatInv, MatRegularize, PCDualLumpedOp, csr_block_classes
 from .qps import QP, QPS
 
 
@@ -46,13 +46,16 @@ class FetiDualQP:
     """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
 
     def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False,
-                 regularize=False):
+                 regularize=False, explicit=None):
         """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
         lb: dual lower bound (-inf on equality rows, 0 on inequality rows).
         regularize: the reference's default (-regularize 1, QPTDualize -> MatInvSetRegularizationType(MAT_REG_EXPLICIT),
         qptransform.c:1012): MATINV works on K_reg = MatRegularize(K, R) and K^+ = K_reg^{-1} without projections;
         False: -regularize 0 with the Moore-Penrose wrapping P_R K^- P_R (-qpt_dualize_Kplus_mp, qptransform.c:1020-1062).
-        With regularize=True a multigrid hierarchy, if given, must have been built on the regularised blocks."""
+        With regularize=True a multigrid hierarchy, if given, must have been built on the regularised blocks.
+        explicit: None, or a dict -- F applies through the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b]
+        (pmh_fexplicit, the exact K^+ path): rtol (1e-12) of the set-up solves; min_slots: a rank with fewer blocks than this
+        assembles with a replica solver built by solver_factory(nslots) -> MatInv whose slots all hold the class matrix."""
         self.ctx = ctx
         nl = local["n_lambda"]
         self.n_lambda = nl
@@ -60,14 +63,19 @@ class FetiDualQP:
         if regularize:
             Kreg = local["Kreg"] if "Kreg" in local else regularize_blocks(ctx, local)[0]
             self.Kreg = MatBlockDiag.from_scipy(ctx, local["block_rowstart"], Kreg)
+            self._Kinv_sp = Kreg
             self.Kplus = MatInv(self.Kreg, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=None)
         else:
             self.Kplus = MatInv(self.K, rtol=kplus_rtol, max_it=kplus_max_it, jacobi=jacobi, nullspace=local["R"])
+            self._Kinv_sp = local["K"]
         if bsr3:  # K x of the inner CG on the 3x3-block kernel (BAIJ bs=3)
             self.Kplus.enable_bsr3()
         if mg_hierarchy is not None:  # -mat_inv_pc_type mg: V-cycle PC for the inner CG (feti.box_mg_hierarchy)
             self.Kplus.set_pc_mg(mg_hierarchy, degree=mg_degree, precision=mg_precision)
         self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
+        self.E = None
+        if explicit is not None:
+            self.E = self.assemble_explicit(local, **explicit)
         self.has_box = bool(np.any(np.isfinite(lb)))
         self.f = ctx.vec_from(local["f"])
         # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169); G None: no floating subdomain, no equality constraint
@@ -91,6 +99,24 @@ class FetiDualQP:
         self.d, self.b_bar, self.b, self.lb_new, self.lam_tilde = (Vec.borrowed(ctx, p, nl) if p.value else None for p in ptr[2:7])
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
+
+    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True):
+        """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
+        right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
+        has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit."""
+        Kmat = self.Kreg if hasattr(self, "Kreg") else self.K
+        E = MatExplicitDual(self.B, Kmat)
+        rs = np.asarray(local["block_rowstart"])
+        nb = len(rs) - 1
+        cls = csr_block_classes(rs, self._Kinv_sp) if share_congruent else np.arange(nb, dtype=np.int32)
+        if solver_factory is not None and nb < min_slots and int(cls.max()) == 0:
+            solver = solver_factory(int(min_slots))
+            E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=cls, rtol=rtol, max_it=max_it)
+            self._replica_solver = solver
+        else:
+            E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it)
+        self.Kplus.attach_explicit(E)
+        return E
 
     def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):
         """QPS of type SMALXE on the projected dual QP, set up but not solved."""

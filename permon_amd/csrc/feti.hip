@@ -16,15 +16,10 @@
 #include <cmath>
 
 #include "pmh_internal.h"
+#include "feti_internal.h"
 #include "reduce.h"
 
 // ---- MATGLUING -----------------------------------------------------------------------------------------------------
-struct pmh_gluing_s {
-  pmh_ctx ctx;
-  int     n_x, n_lambda, n_leaves;
-  pmh_csr B, Bt;
-  double *d_tmp; // n_lambda scratch of mult_transpose_add on several GPUs (lazy)
-};
 
 extern "C" int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leaves, const int *leaves_row, const int *leaves_root, const double *leaves_sign, pmh_gluing *out)
 {
@@ -51,6 +46,7 @@ extern "C" int pmh_gluing_create(pmh_ctx ctx, int n_x, int n_lambda, int n_leave
   pmh_gluing g = new pmh_gluing_s();
   g->ctx = ctx, g->n_x = n_x, g->n_lambda = n_lambda, g->n_leaves = n_leaves;
   g->B = g->Bt = nullptr, g->d_tmp = nullptr;
+  g->h_row.assign(leaves_row, leaves_row + n_leaves), g->h_root.assign(leaves_root, leaves_root + n_leaves), g->h_sign.assign(leaves_sign, leaves_sign + n_leaves);
   PMH_CHK(build(n_lambda, n_x, leaves_root, leaves_row, &g->B));
   PMH_CHK(build(n_x, n_lambda, leaves_row, leaves_root, &g->Bt));
   *out = g;
@@ -214,13 +210,6 @@ extern "C" int pmh_extension_mult_transpose_add(pmh_extension T, const double *r
 }
 
 // ---- MATBLOCKDIAG ---------------------------------------------------------------------------------------------------
-struct pmh_blockdiag_s {
-  pmh_ctx          ctx;
-  int              nblocks, n;
-  std::vector<int> rowstart;
-  int             *d_rowstart;
-  pmh_csr          K;
-};
 
 extern "C" int pmh_blockdiag_create(pmh_ctx ctx, int nblocks, const int *block_rowstart, pmh_csr Kcat, pmh_blockdiag *out)
 {
@@ -273,26 +262,6 @@ extern "C" int pmh_blockdiag_mult_transpose_add(pmh_blockdiag K, const double *x
 
 // ---- MATINV: block-wise CG -------------------------------------------------------------------------------------------
 
-struct pmh_matinv_s {
-  pmh_blockdiag K;
-  pmh_ctx       ctx;
-  int           n, nblocks, wgs; // wgs = workgroups per block in the segmented kernels
-  double        rtol, atol;
-  int           max_it, jacobi;
-  double       *dinv, *r, *z, *p, *Ap;
-  double       *d_part, *d_partB; // [2][nblocks*wgs] each
-  double       *d_bs;             // [2 parities][nblocks][rz, tol]
-  int          *d_bi;             // [2 parities][nblocks][active, its]
-  int          *d_nactive, *d_done, *h_nactive;
-  int           last_max_its;
-  long long     total_spmv;
-  // Moore-Penrose variant (QPTDualize true_mp path, qptransform.c:1006-1062): K^+ := P_R K^- P_R with
-  // P_R = I - R R', R = block-wise orthonormal kernel basis stored as kdim columns of length n
-  int     kdim;
-  double *d_R, *d_coef, *d_fproj, *d_kpart;
-  pmh_mg  mg; // optional V-cycle preconditioner (pmh_matinv_set_pc_mg); NULL: Jacobi / none
-  pmh_bsr3 Kb; // optional 3x3-block copy of K for the CG's own product (pmh_matinv_enable_bsr3)
-};
 
 #define SEG_LOOP(i, b, rs, wgs) \
   const int b = blockIdx.x / (wgs), w_ = blockIdx.x % (wgs); \
@@ -547,6 +516,7 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   M->d_R = M->d_coef = M->d_fproj = M->d_kpart = nullptr;
   M->mg  = nullptr;
   M->Kb  = nullptr;
+  M->E   = nullptr;
   const size_t nb = sizeof(double) * (size_t)(M->n ? M->n : 1);
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->dinv));
   PMH_CHK(pmh_malloc(ctx, nb, (void **)&M->r));
@@ -700,6 +670,24 @@ extern "C" int pmh_matinv_set_pc_mg(pmh_matinv M, pmh_mg mg)
   return PMH_SUCCESS;
 }
 
+// KSPSetTolerances of the inner KSP (MatInvGetKSP, matinv.c): the explicit assembly tightens it for its own solves
+extern "C" int pmh_matinv_set_tolerances(pmh_matinv M, double rtol, double atol, int max_it)
+{
+  PMH_ARG(M && max_it > 0);
+  M->rtol = rtol, M->atol = atol, M->max_it = max_it;
+  M->last_max_its = 0;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_matinv_get_tolerances(pmh_matinv M, double *rtol, double *atol, int *max_it)
+{
+  PMH_ARG(M);
+  if (rtol) *rtol = M->rtol;
+  if (atol) *atol = M->atol;
+  if (max_it) *max_it = M->max_it;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_matinv_enable_bsr3(pmh_matinv M)
 {
   PMH_ARG(M);
@@ -748,6 +736,7 @@ struct FetiDualOp : pmh_op_s {
   // MatCreateProd(Bt, Kplus, B) applied right to left: qptransform.c:1103-1128, matprod.c:42-48
   int mult(const double *x, double *y) override
   {
+    if (Kplus->E && pmh_fexplicit_matches(Kplus->E, B)) return pmh_fexplicit_apply(Kplus->E, x, y); // explicit local dual operators
     PMH_CHK(pmh_gluing_mult(B, x, t1));
     PMH_CHK(pmh_matinv_mult(Kplus, t1, t2));
     return pmh_gluing_mult_transpose(B, t2, y);

@@ -1,0 +1,494 @@
+// Explicit local dual operators on gfx950: the exact K^+ path of the FETI dual operator.
+//
+// The reference applies K^+ by a per-block factorisation (matinv.c:435-590) and can form an inverse explicitly, column by
+// column with its inner KSP (MatInvExplicitly_Inv, matinv.c:670-730: KSPSolve on the columns of the identity).  F = B K^+ B'
+// (qptransform.c:1103-1128) only ever sees the entries of K_b^+ on Gamma_b = the primal dofs of block b that B touches
+// (interface, Dirichlet and contact dofs), so the same construction restricted to those columns and rows,
+//
+//     W_b = (K_b^+)[Gamma_b, Gamma_b]        (dense, symmetric, n_Gamma_b ~ 17-25 k for a 44^3-node elasticity cube),
+//
+// gives F = sum_b Bhat_b W_b Bhat_b' EXACTLY (to the tolerance of the set-up solves, 1e-12), with Bhat the gluing over the
+// compressed numbering [Gamma_0 | Gamma_1 | ...].  One F apply is then three launches -- Bhat' lambda (CSR), one dense GEMV over
+// all blocks of the rank, Bhat (CSR, + the all-reduce on several GPUs) -- instead of ~340 launches of a 12-iteration
+// multigrid-CG, and it streams 8 n_Gamma^2 bytes per block once: a pure HBM-bandwidth kernel (SURVEY 8d "dense path").
+//
+// Layout in HBM: W_b row-major with leading dimension ld_b (n_Gamma_b rounded up to 2, rows 16-byte aligned), all blocks of the
+// rank in one allocation (configs[2]: 28 GB for the 8 blocks, ~5 GB the largest; far inside 288 GB).  The compressed vectors pad every
+// block to an even offset so a lane's 16-byte load never straddles two blocks.
+//
+// Assembly.  Columns come from K^+ applications of a `solver` (a pmh_matinv whose blocks are "slots"): each application solves
+// one unit right-hand side per slot at once.  Blocks with identical matrices form a class and share their columns (the 8
+// congruent cubes of configs[2] need the 33 k boundary columns once, spread over 8 slots, instead of 8 x 17-25 k); a rank that
+// owns a single block hands over a solver with several replica slots of it.  Rows are written (row j = column j, K^+ symmetric).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <map>
+
+#include "feti_internal.h"
+#include "pmh_internal.h"
+#include "reduce.h"
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+struct pmh_fexplicit_s {
+  pmh_ctx       ctx;
+  pmh_gluing    B;    // the gluing it was built from (borrowed)
+  pmh_blockdiag K;    // block structure (borrowed)
+  pmh_gluing    Bhat; // gluing over the compressed numbering (owned)
+  int           nb, ntot; // blocks, padded length of the compressed vectors
+  std::vector<int> gstart; // [nb+1] padded (even) offsets of the blocks in the compressed numbering
+  std::vector<int> ngam;   // [nb] n_Gamma_b
+  std::vector<int> gamma;  // [sum ngam] primal dof (rank-local concatenated numbering) of every compressed dof, ascending per block
+  std::vector<size_t> goff; // [nb+1] offsets into gamma
+  std::vector<int> ld;
+  std::vector<double *> W; // device pointer of every block inside the single allocation Wbase
+  double  *Wbase;
+  std::vector<long long> woff; // [nb] offset (doubles) of block b in Wbase
+  long long *d_woff;
+  int     *d_gamma_rel;    // [sum ngam] gamma relative to its block's first row
+  int     *d_ld, *d_gstart, *d_ngam;
+  int     *d_wg_block, *d_wg_row0;
+  int      nwg, rw;        // GEMV launch table: workgroup -> (block, first row); rows per wave
+  double  *xh, *yh;        // compressed work vectors
+  int      assembled;
+  long long n_solves;
+  double   assemble_seconds;
+  std::vector<hipEvent_t> ev;
+  int      ev_used, ev_on, ev_seen, ev_stride;
+};
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------
+
+// y_b = W_b x_b for every block of the rank in one launch.  A workgroup owns 4*RW consecutive rows of one block (wave w the rows
+// row0 + w*RW ...), every lane streams its 16-byte column pairs of the RW rows (non-temporal: each byte is used once) against the
+// matching pair of x (served by L2: x_b is 0.2 MB), per-lane partial sums in column order, one shuffle tree per row at the end.
+// Fixed summation order => bitwise reproducible; -ffp-contract=off keeps the two products of a pair separate.
+template <int RW>
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_gemv(const int *__restrict__ wg_block, const int *__restrict__ wg_row0, const int *__restrict__ gstart, const int *__restrict__ ngam, const int *__restrict__ ldv,
+                                                      const long long *__restrict__ woff, const double *__restrict__ Wbase, const double *__restrict__ xh, double *__restrict__ yh)
+{
+  const int b = wg_block[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = ngam[b], ld = ldv[b];
+  const int row0 = wg_row0[blockIdx.x] + wave * RW;
+  if (row0 >= n) return;
+  const double *__restrict__ A = Wbase + woff[b]; // one allocation for all blocks: the row pointers stay in the global address space
+  const double *__restrict__ x = xh + gstart[b];
+  const double *rp[RW];
+#pragma unroll
+  for (int r = 0; r < RW; r++) rp[r] = A + (size_t)min(row0 + r, n - 1) * ld; // rows past the end re-read the last row, result dropped
+  double acc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; r++) acc[r] = 0.0;
+  int c = lane * 2;
+  // two 128-column chunks per trip: 2*RW 16-byte loads in flight per lane before the first use
+  for (; c + 128 < ld; c += 256) {
+    const dbl2 x0 = *(const dbl2 *)(x + c), x1 = *(const dbl2 *)(x + c + 128);
+    dbl2       a0[RW], a1[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) a0[r] = __builtin_nontemporal_load((const dbl2 *)(rp[r] + c));
+#pragma unroll
+    for (int r = 0; r < RW; r++) a1[r] = __builtin_nontemporal_load((const dbl2 *)(rp[r] + c + 128));
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+      acc[r] += a0[r].x * x0.x;
+      acc[r] += a0[r].y * x0.y;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+      acc[r] += a1[r].x * x1.x;
+      acc[r] += a1[r].y * x1.y;
+    }
+  }
+  if (c < ld) {
+    const dbl2 x0 = *(const dbl2 *)(x + c);
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+      const dbl2 a = __builtin_nontemporal_load((const dbl2 *)(rp[r] + c));
+      acc[r] += a.x * x0.x;
+      acc[r] += a.y * x0.y;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const double s = pmh_wave_sum(acc[r]);
+    if (lane == 0 && row0 + r < n) yh[gstart[b] + row0 + r] = s;
+  }
+}
+
+// unit right-hand sides of one assembly batch: rhs[idx[s]] = val for the slots of the batch (idx < 0: slot idle)
+__global__ void k_fx_set_entries(int m, const int *__restrict__ idx, double val, double *__restrict__ rhs)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < m && idx[s] >= 0) rhs[idx[s]] = val;
+}
+
+// one row of W_b: wrow[i] = u[gamma_rel[i]] (u = the slot's solution), i < n; the pad entry stays 0
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract(int n, const int *__restrict__ gamma_rel, const double *__restrict__ u, double *__restrict__ wrow)
+{
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) wrow[i] = u[gamma_rel[i]];
+}
+
+// ---- create / destroy ---------------------------------------------------------------------------------------------------
+
+extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit *out)
+{
+  PMH_ARG(B && K && out);
+  PMH_ARG(B->n_x == K->n);
+  pmh_ctx       ctx = B->ctx;
+  pmh_fexplicit E   = new pmh_fexplicit_s();
+  E->ctx = ctx, E->B = B, E->K = K, E->Bhat = nullptr, E->nb = K->nblocks;
+  E->d_gamma_rel = nullptr, E->Wbase = nullptr, E->d_woff = nullptr, E->d_ld = E->d_gstart = E->d_ngam = E->d_wg_block = E->d_wg_row0 = nullptr;
+  E->xh = E->yh = nullptr, E->assembled = 0, E->n_solves = 0, E->assemble_seconds = 0.0;
+  E->ev_used = E->ev_on = E->ev_seen = 0, E->ev_stride = 1;
+  const int nb = E->nb;
+  // Gamma_b: the primal dofs with at least one leaf, ascending inside every block
+  std::vector<char> touched((size_t)std::max(1, B->n_x), 0);
+  for (int i = 0; i < B->n_leaves; i++) touched[B->h_row[i]] = 1;
+  std::vector<int> newidx((size_t)std::max(1, B->n_x), -1);
+  E->gstart.assign(nb + 1, 0), E->ngam.assign(nb, 0), E->goff.assign(nb + 1, 0), E->ld.assign(nb, 0);
+  int off = 0;
+  for (int b = 0; b < nb; b++) {
+    E->gstart[b] = off;
+    E->goff[b]   = E->gamma.size();
+    int cnt = 0;
+    for (int i = K->rowstart[b]; i < K->rowstart[b + 1]; i++)
+      if (touched[i]) {
+        newidx[i] = off + cnt++;
+        E->gamma.push_back(i);
+      }
+    E->ngam[b] = cnt;
+    E->ld[b]   = (cnt + 1) & ~1;
+    off += E->ld[b]; // even offsets: a lane's 16-byte load of x never straddles two blocks, the pad entry is an empty row of Bhat'
+  }
+  E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
+  // Bhat: same leaves (same order => same summation order as B), primal index remapped
+  std::vector<int> rows((size_t)std::max(1, B->n_leaves));
+  for (int i = 0; i < B->n_leaves; i++) rows[i] = newidx[B->h_row[i]];
+  PMH_CHK(pmh_gluing_create(ctx, E->ntot, B->n_lambda, B->n_leaves, rows.data(), B->h_root.data(), B->h_sign.data(), &E->Bhat));
+  // dense blocks in one allocation (block offsets 256-byte aligned), zero-initialised (the pad column must stay 0)
+  E->W.assign(nb, nullptr), E->woff.assign(nb, 0);
+  long long wtot = 0;
+  for (int b = 0; b < nb; b++) {
+    E->woff[b] = wtot;
+    wtot += (((long long)std::max(1, E->ngam[b]) * std::max(2, E->ld[b])) + 31) & ~31LL;
+  }
+  {
+    const size_t bytes = sizeof(double) * (size_t)std::max(32LL, wtot);
+    hipError_t   e     = hipMalloc((void **)&E->Wbase, bytes);
+    if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_create: %.2f GB for the explicit blocks: %s", bytes / 1e9, hipGetErrorString(e));
+    PMH_HIP(hipMemsetAsync(E->Wbase, 0, bytes, ctx->stream));
+  }
+  for (int b = 0; b < nb; b++) E->W[b] = E->Wbase + E->woff[b];
+  std::vector<int> grel(E->gamma.size() + 1);
+  for (int b = 0; b < nb; b++)
+    for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++) grel[k] = E->gamma[k] - K->rowstart[b];
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * grel.size(), (void **)&E->d_gamma_rel));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_gamma_rel, grel.data(), sizeof(int) * grel.size()));
+  PMH_CHK(pmh_malloc(ctx, sizeof(long long) * nb, (void **)&E->d_woff));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_woff, E->woff.data(), sizeof(long long) * nb));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * nb, (void **)&E->d_ld));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_ld, E->ld.data(), sizeof(int) * nb));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (nb + 1), (void **)&E->d_gstart));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_gstart, E->gstart.data(), sizeof(int) * (nb + 1)));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * nb, (void **)&E->d_ngam));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_ngam, E->ngam.data(), sizeof(int) * nb));
+  // GEMV launch table
+  E->rw = 4;
+  if (const char *s = getenv("PMH_FX_RW")) E->rw = (atoi(s) == 8) ? 8 : (atoi(s) == 2 ? 2 : 4);
+  const int        rows_per_wg = 4 * E->rw;
+  std::vector<int> wb, wr;
+  for (int b = 0; b < nb; b++)
+    for (int r = 0; r < E->ngam[b]; r += rows_per_wg) wb.push_back(b), wr.push_back(r);
+  E->nwg = (int)wb.size();
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max(1, E->nwg), (void **)&E->d_wg_block));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max(1, E->nwg), (void **)&E->d_wg_row0));
+  if (E->nwg) {
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_block, wb.data(), sizeof(int) * E->nwg));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_row0, wr.data(), sizeof(int) * E->nwg));
+  }
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->xh));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->yh));
+  PMH_CHK(pmh_memset(ctx, E->xh, 0, sizeof(double) * (size_t)std::max(2, E->ntot)));
+  PMH_CHK(pmh_memset(ctx, E->yh, 0, sizeof(double) * (size_t)std::max(2, E->ntot)));
+  *out = E;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
+{
+  if (!E) return PMH_SUCCESS;
+  pmh_ctx ctx = E->ctx;
+  if (E->Wbase) hipFree(E->Wbase);
+  pmh_gluing_destroy(E->Bhat);
+  pmh_free(ctx, E->d_gamma_rel), pmh_free(ctx, E->d_woff), pmh_free(ctx, E->d_ld), pmh_free(ctx, E->d_gstart), pmh_free(ctx, E->d_ngam);
+  pmh_free(ctx, E->d_wg_block), pmh_free(ctx, E->d_wg_row0), pmh_free(ctx, E->xh), pmh_free(ctx, E->yh);
+  for (hipEvent_t e : E->ev) hipEventDestroy(e);
+  delete E;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma, long long *dense_bytes, double *gemv_bytes)
+{
+  PMH_ARG(E);
+  if (nblocks) *nblocks = E->nb;
+  long long tot = 0;
+  double    alg = 0.0;
+  for (int b = 0; b < E->nb; b++) {
+    if (n_gamma) n_gamma[b] = E->ngam[b];
+    tot += (long long)sizeof(double) * E->ngam[b] * E->ld[b];
+    alg += 8.0 * (double)E->ngam[b] * E->ngam[b] + 16.0 * E->ngam[b]; // the matrix once + x read + y written
+  }
+  if (dense_bytes) *dense_bytes = tot;
+  if (gemv_bytes) *gemv_bytes = alg;
+  return PMH_SUCCESS;
+}
+
+// host helper: classes of identical diagonal blocks of a block-diagonal CSR (same size, pattern and values, bit for bit)
+extern "C" int pmh_csr_block_classes(int nblocks, const int *rowstart, const int *rowptr, const int *col, const double *val, int *block_class, int *nclasses)
+{
+  PMH_ARG(nblocks >= 0 && rowstart && rowptr && col && val && block_class);
+  std::vector<int> reps;
+  for (int b = 0; b < nblocks; b++) {
+    const int r0 = rowstart[b], n = rowstart[b + 1] - r0, k0 = rowptr[r0], nnz = rowptr[r0 + n] - k0;
+    int       cls = -1;
+    for (size_t c = 0; c < reps.size() && cls < 0; c++) {
+      const int a = reps[c], q0 = rowstart[a], m = rowstart[a + 1] - q0, j0 = rowptr[q0];
+      if (m != n || rowptr[q0 + m] - j0 != nnz) continue;
+      bool same = true;
+      for (int i = 0; i <= n && same; i++) same = (rowptr[r0 + i] - k0) == (rowptr[q0 + i] - j0);
+      for (int k = 0; k < nnz && same; k++) same = (col[k0 + k] - r0) == (col[j0 + k] - q0);
+      if (same) same = memcmp(val + k0, val + j0, sizeof(double) * (size_t)nnz) == 0;
+      if (same) cls = (int)c;
+    }
+    if (cls < 0) {
+      cls = (int)reps.size();
+      reps.push_back(b);
+    }
+    block_class[b] = cls;
+  }
+  if (nclasses) *nclasses = (int)reps.size();
+  return PMH_SUCCESS;
+}
+
+// ---- assembly -------------------------------------------------------------------------------------------------------------
+// MatInvExplicitly_Private (matinv.c:640-665: KSPSolve on the columns of the identity, one row of the explicit matrix per solve),
+// restricted to the columns / rows in Gamma and batched over the slots of `solver`.
+// slot_class[s]: class of the matrix in slot s of the solver; block_class[b]: class of block b of this operator (blocks of one
+// class have identical K_b, so K_b^+ e_j serves all of them).  NULL, NULL: slot s <-> block s (the solver is the operator's own K^+).
+extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it)
+{
+  PMH_ARG(E && solver && nslots >= 1 && solver->nblocks == nslots);
+  PMH_ARG((slot_class && block_class) || (!slot_class && !block_class && nslots == E->nb));
+  pmh_ctx   ctx = E->ctx;
+  const int nb  = E->nb;
+  auto      t0  = std::chrono::steady_clock::now();
+  std::vector<int> sc(nslots), bc(nb);
+  for (int s = 0; s < nslots; s++) sc[s] = slot_class ? slot_class[s] : s;
+  for (int b = 0; b < nb; b++) bc[b] = block_class ? block_class[b] : b;
+  int ncls = 0;
+  for (int b = 0; b < nb; b++) ncls = std::max(ncls, bc[b] + 1);
+  const std::vector<int> &srs = solver->K->rowstart;
+  // per class: its slots, its blocks, the union of the blocks' relative Gamma indices
+  std::vector<std::vector<int>> cslots(ncls), cblocks(ncls), cunion(ncls);
+  for (int s = 0; s < nslots; s++)
+    if (sc[s] >= 0 && sc[s] < ncls) cslots[sc[s]].push_back(s);
+  for (int b = 0; b < nb; b++) {
+    PMH_ARG(bc[b] >= 0);
+    cblocks[bc[b]].push_back(b);
+  }
+  for (int c = 0; c < ncls; c++) {
+    if (cblocks[c].empty()) continue;
+    if (cslots[c].empty()) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: no solver slot for block class %d", c);
+    const int nloc = E->K->rowstart[cblocks[c][0] + 1] - E->K->rowstart[cblocks[c][0]];
+    for (int b : cblocks[c])
+      if (E->K->rowstart[b + 1] - E->K->rowstart[b] != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: blocks of class %d differ in size", c);
+    for (int s : cslots[c])
+      if (srs[s + 1] - srs[s] != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, nloc);
+    std::vector<char> in((size_t)std::max(1, nloc), 0);
+    for (int b : cblocks[c])
+      for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++) in[E->gamma[k] - E->K->rowstart[b]] = 1;
+    for (int i = 0; i < nloc; i++)
+      if (in[i]) cunion[c].push_back(i);
+  }
+  // position of a relative dof inside Gamma_b (-1: not in it)
+  std::vector<std::vector<int>> pos(nb);
+  for (int b = 0; b < nb; b++) {
+    pos[b].assign((size_t)std::max(1, E->K->rowstart[b + 1] - E->K->rowstart[b]), -1);
+    for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++) pos[b][E->gamma[k] - E->K->rowstart[b]] = (int)(k - E->goff[b]);
+  }
+  int nbatch = 0;
+  for (int c = 0; c < ncls; c++)
+    if (!cblocks[c].empty()) nbatch = std::max(nbatch, (int)((cunion[c].size() + cslots[c].size() - 1) / cslots[c].size()));
+  double *rhs, *sol;
+  int    *d_idx, *h_idx;
+  const size_t nsol = (size_t)std::max(1, solver->n);
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&rhs));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&sol));
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * nslots, (void **)&d_idx));
+  PMH_HIP(hipHostMalloc((void **)&h_idx, sizeof(int) * nslots * 2, hipHostMallocDefault));
+  PMH_CHK(pmh_memset(ctx, rhs, 0, sizeof(double) * nsol));
+  double old_rtol, old_atol;
+  int    old_maxit;
+  PMH_CHK(pmh_matinv_get_tolerances(solver, &old_rtol, &old_atol, &old_maxit));
+  PMH_CHK(pmh_matinv_set_tolerances(solver, rtol, 1e-300, max_it > 0 ? max_it : old_maxit));
+  int        rc = PMH_SUCCESS;
+  std::vector<int> col(nslots);
+  for (int k = 0; k < nbatch && !rc; k++) {
+    int *hh = h_idx + (k & 1) * nslots; // pinned staging, alternating halves (every K^+ application synchronises the stream at least once)
+    for (int s = 0; s < nslots; s++) hh[s] = -1, col[s] = -1;
+    for (int c = 0; c < ncls; c++) {
+      if (cblocks[c].empty()) continue;
+      for (size_t t = 0; t < cslots[c].size(); t++) {
+        const size_t j = (size_t)k * cslots[c].size() + t;
+        if (j < cunion[c].size()) {
+          const int s = cslots[c][t];
+          col[s]      = cunion[c][j];
+          hh[s]       = srs[s] + col[s];
+        }
+      }
+    }
+    if (hipMemcpyAsync(d_idx, hh, sizeof(int) * nslots, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: index upload failed");
+      break;
+    }
+    hipLaunchKernelGGL(k_fx_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
+    if ((rc = pmh_matinv_mult(solver, rhs, sol))) break;
+    hipLaunchKernelGGL(k_fx_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 0.0, rhs);
+    for (int s = 0; s < nslots; s++) {
+      if (col[s] < 0) continue;
+      E->n_solves++;
+      for (int b : cblocks[sc[s]]) {
+        const int p = pos[b][col[s]];
+        if (p < 0) continue;
+        const int n = E->ngam[b];
+        hipLaunchKernelGGL(k_fx_extract, dim3(std::max(1, std::min(64, (n + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]),
+                           (const double *)(sol + srs[s]), E->W[b] + (size_t)p * E->ld[b]);
+      }
+    }
+    if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);
+  }
+  if (!rc) rc = pmh_sync(ctx);
+  pmh_matinv_set_tolerances(solver, old_rtol, old_atol, old_maxit);
+  pmh_free(ctx, rhs), pmh_free(ctx, sol), pmh_free(ctx, d_idx);
+  hipHostFree(h_idx);
+  if (rc) return rc;
+  E->assembled = 1;
+  E->assemble_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds)
+{
+  PMH_ARG(E);
+  if (n_solves) *n_solves = E->n_solves;
+  if (seconds) *seconds = E->assemble_seconds;
+  return PMH_SUCCESS;
+}
+
+// copies W_b to the host (tests, post-processing): out is n_Gamma_b x n_Gamma_b row-major
+extern "C" int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *out_host, int *gamma_host)
+{
+  PMH_ARG(E && b >= 0 && b < E->nb);
+  const int n = E->ngam[b];
+  if (out_host && n) PMH_HIP(hipMemcpy2D(out_host, sizeof(double) * n, E->W[b], sizeof(double) * E->ld[b], sizeof(double) * n, n, hipMemcpyDeviceToHost));
+  if (gamma_host)
+    for (int i = 0; i < n; i++) gamma_host[i] = E->gamma[E->goff[b] + i];
+  return PMH_SUCCESS;
+}
+
+// ---- apply ----------------------------------------------------------------------------------------------------------------
+
+static int fx_gemv(pmh_fexplicit E)
+{
+  if (!E->nwg) return PMH_SUCCESS;
+  hipStream_t st    = E->ctx->stream;
+  bool        timed = false;
+  if (E->ev_on && (E->ev_seen++ % E->ev_stride) == 0 && (size_t)(2 * E->ev_used + 2) <= E->ev.size()) {
+    timed = true;
+    PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used], st));
+  }
+#define FX_LAUNCH(RW) hipLaunchKernelGGL(k_fx_gemv<RW>, dim3(E->nwg), dim3(PMH_BLOCK), 0, st, (const int *)E->d_wg_block, (const int *)E->d_wg_row0, (const int *)E->d_gstart, (const int *)E->d_ngam, (const int *)E->d_ld, (const long long *)E->d_woff, (const double *)E->Wbase, (const double *)E->xh, E->yh)
+  if (E->rw == 8) FX_LAUNCH(8);
+  else if (E->rw == 2) FX_LAUNCH(2);
+  else FX_LAUNCH(4);
+#undef FX_LAUNCH
+  if (timed) {
+    PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used + 1], st));
+    E->ev_used++;
+  }
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B) { return E && E->B == B && E->assembled; }
+
+// y = F lambda = Bhat W Bhat' lambda (MatMult of the product F = B K^+ B', qptransform.c:1103-1128, with K^+ explicit)
+int pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y)
+{
+  PMH_CHK(pmh_gluing_mult(E->Bhat, lambda, E->xh));
+  PMH_CHK(fx_gemv(E));
+  return pmh_gluing_mult_transpose(E->Bhat, E->yh, y); // ends with the all-reduce on several GPUs
+}
+
+extern "C" int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double *y)
+{
+  PMH_ARG(E && lambda && y);
+  if (!E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_mult: the explicit blocks are not assembled yet");
+  return pmh_fexplicit_apply(E, lambda, y);
+}
+
+// the dense kernel alone on the compressed vectors (tests, bench): yh = blockdiag(W_b) xh, both of length n_compressed
+extern "C" int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xh, double *yh)
+{
+  PMH_ARG(E && xh && yh);
+  PMH_CHK(pmh_memcpy_d2d(E->ctx, E->xh, xh, sizeof(double) * (size_t)E->ntot));
+  PMH_CHK(fx_gemv(E));
+  return pmh_memcpy_d2d(E->ctx, yh, E->yh, sizeof(double) * (size_t)E->ntot);
+}
+
+extern "C" int pmh_fexplicit_compressed_size(pmh_fexplicit E, int *ntot, int *gstart /* [nblocks+1] or NULL */)
+{
+  PMH_ARG(E);
+  if (ntot) *ntot = E->ntot;
+  if (gstart)
+    for (int b = 0; b <= E->nb; b++) gstart[b] = E->gstart[b];
+  return PMH_SUCCESS;
+}
+
+// MATINV with an explicit inverse attached: F = B K^+ B' built on this K^+ (pmh_op_create_feti_dual) applies through E
+// whenever E was built from the same B; NULL detaches.  K^+ f for a general f (d = B K^+ f - c, the primal recovery) stays iterative.
+extern "C" int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E)
+{
+  PMH_ARG(Kplus);
+  if (E && !E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_matinv_attach_explicit: assemble the explicit blocks first");
+  if (E && E->K->n != Kplus->n) return pmh_set_error(PMH_ERR_ARG, "pmh_matinv_attach_explicit: size mismatch (%d vs %d)", E->K->n, Kplus->n);
+  Kplus->E = E;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, int stride)
+{
+  PMH_ARG(E && max_launches >= 0);
+  while ((int)E->ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    PMH_HIP(hipEventCreate(&e));
+    E->ev.push_back(e);
+  }
+  E->ev_on = max_launches > 0, E->ev_used = 0, E->ev_seen = 0, E->ev_stride = std::max(1, stride);
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms)
+{
+  PMH_ARG(E && launches && total_ms);
+  PMH_CHK(pmh_sync(E->ctx));
+  double tot = 0.0;
+  for (int i = 0; i < E->ev_used; i++) {
+    float ms = 0.f;
+    PMH_HIP(hipEventElapsedTime(&ms, E->ev[2 * i], E->ev[2 * i + 1]));
+    tot += ms;
+  }
+  *launches = E->ev_used, *total_ms = tot;
+  return PMH_SUCCESS;
+}

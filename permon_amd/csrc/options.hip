@@ -241,6 +241,22 @@ int smalxe_key(const Token &t, const std::string &k, pmh_smalxe_opts *s)
     ERR(get_int(t, &s->inner_no_gtol_stop));
   } else if (k == "qps_smalxe_update_threshold") {
     ERR(get_real(t, &s->update_threshold));
+  } else if (k == "qps_smalxe_norm_update_lag") { // smalxe.c:754-762
+    ERR(get_bool(t, &s->lag_enabled));
+  } else if (k == "qps_smalxe_norm_update_lag_offset") {
+    ERR(get_int(t, &s->lag_offset));
+  } else if (k == "qps_smalxe_norm_update_lag_start") {
+    ERR(get_int(t, &s->lag_start));
+  } else if (k == "qps_smalxe_norm_update_lag_step") {
+    ERR(get_int(t, &s->lag_step));
+  } else if (k == "qps_smalxe_norm_update_lag_end") {
+    ERR(get_int(t, &s->lag_end));
+  } else if (k == "qps_smalxe_norm_update_lag_lower") {
+    ERR(get_real(t, &s->lag_lower));
+  } else if (k == "qps_smalxe_norm_update_lag_upper") {
+    ERR(get_real(t, &s->lag_upper));
+  } else if (k == "qps_smalxe_knoll") { // smalxe.c:764
+    ERR(get_bool(t, &s->knoll));
   } else {
     return 0;
   }

@@ -32,6 +32,13 @@ struct pmh_smalxe_s {
   double inner_atol;
   int    inner_reason, inner_max_it;
   double inner_rnorm;
+  // ||Bu|| update variants (smalxe.c:265-370): BtBu reuse flag (QPSWorkVecStateChanged, smalxe.c:421-430), the inner solver's
+  // current iteration (qps_inner->iteration as the lagged update reads it) and the function-static state of the lagged update
+  int    BtBu_valid, inner_it_now;
+  double lag_normBu0;
+  int    lag_II, lag_J, lag_neval, lag_niter;
+  // throughput mode (pmh_smalxe_run_fixed): budget of inner iterations left, -1 = off
+  long long fixed_left;
 };
 
 // QPSCreate_SMALXE defaults smalxe.c:1159-1207
@@ -61,11 +68,20 @@ extern "C" int pmh_smalxe_default_opts(pmh_smalxe_opts *o)
   o->inject_maxeig_set  = 0;
   o->inner_iter_min     = 1;
   o->inner_no_gtol_stop = 0;
+  o->be_implicit        = 0;   // BE has a mult slot (smalxe.c:878-879)
+  o->lag_enabled        = 0;   // smalxe.c:1192
+  o->lag_offset         = 0;   // norm_update_lag_offset is never assigned in QPSCreate_SMALXE (PetscNew zero)
+  o->lag_start          = 10;  // Jstart, Jstep, Jend, lower, upper: smalxe.c:1196-1200
+  o->lag_step           = 5;
+  o->lag_end            = 20;
+  o->lag_lower          = 0.1;
+  o->lag_upper          = 1.1;
+  o->knoll              = 0;   // smalxe.c:1202
   return pmh_mpgp_default_opts(&o->inner);
 }
 
 // QPSSMALXEUpdateNormBu_SMALXE smalxe.c:247-261 (cE is homogenised away before SMALXE, smalxe.c:782-787)
-static int update_normBu(pmh_smalxe s, const double *u, double *normBu, double *enorm)
+static int update_normBu_std(pmh_smalxe s, const double *u, double *normBu, double *enorm)
 {
   if (s->pf->m > 0) {
     PMH_CHK(pmh_qppf_apply_G(s->pf, u, s->Bu));
@@ -75,6 +91,65 @@ static int update_normBu(pmh_smalxe s, const double *u, double *normBu, double *
   }
   *enorm = *normBu / s->o.rtol_E;
   return PMH_SUCCESS;
+}
+
+// QPSSMALXEUpdateNormBu_SMALXEON smalxe.c:265-285: only the penalised term B'B is available; ||Bu|| = sqrt(u'B'Bu).
+// BtBu stays valid for this u (QPSWorkVecStateUpdate :278-279) and is reused by the next lambda update.
+static int update_normBu_on(pmh_smalxe s, const double *u, double *normBu, double *enorm)
+{
+  double dot;
+  PMH_CHK(pmh_qppf_apply_GtG(s->pf, u, s->BtBu));
+  s->BtBu_valid = (u == s->u);
+  PMH_CHK(pmh_vec_dot(s->ctx, s->n, u, s->BtBu, &dot));
+  *normBu = sqrt(dot);
+  *enorm  = *normBu / s->o.rtol_E;
+  return PMH_SUCCESS;
+}
+
+// QPSSMALXEUpdateNormBu_Lag_SMALXEON smalxe.c:289-370 (-qps_smalxe_norm_update_lag): the exact norm every J-th inner
+// iteration only; J grows from lag_start to lag_end by lag_step while the norm stays within [lower, upper) of the last exact one
+static int update_normBu_lag(pmh_smalxe s, const double *u, double *normBu, double *enorm)
+{
+  double normBu_approx, normBu_exact, enorm_exact;
+  if (s->inner_it_now <= s->o.lag_offset) {
+    PMH_CHK(update_normBu_on(s, u, &normBu_exact, &enorm_exact));
+    s->lag_neval++;
+    s->lag_normBu0 = normBu_exact;
+    normBu_approx  = s->lag_normBu0;
+    s->lag_J       = s->o.lag_start;
+    s->lag_II      = 0;
+  } else {
+    if (s->lag_II == 0) {
+      PMH_CHK(update_normBu_on(s, u, &normBu_exact, &enorm_exact));
+      s->lag_neval++;
+      const double rdiff = fabs(normBu_exact / s->lag_normBu0);
+      if (rdiff >= s->o.lag_upper || rdiff < s->o.lag_lower) {
+        s->lag_II = 0;
+        s->lag_J  = s->o.lag_start;
+      } else {
+        s->lag_II++;
+      }
+      s->lag_normBu0 = normBu_exact;
+    } else {
+      s->lag_II++;
+    }
+    normBu_approx = s->lag_normBu0;
+  }
+  s->lag_niter++;
+  if (s->lag_II == s->lag_J) {
+    s->lag_II = 0;
+    if (s->lag_J < s->o.lag_end) s->lag_J += s->o.lag_step;
+  }
+  *normBu = normBu_approx;
+  *enorm  = *normBu / s->o.rtol_E;
+  return PMH_SUCCESS;
+}
+
+// smalxe->updateNormBu as QPSSetUp_SMALXE picks it (smalxe.c:878-886)
+static int update_normBu(pmh_smalxe s, const double *u, double *normBu, double *enorm)
+{
+  if (!s->o.be_implicit || s->pf->m == 0) return update_normBu_std(s, u, normBu, enorm);
+  return s->o.lag_enabled ? update_normBu_lag(s, u, normBu, enorm) : update_normBu_on(s, u, normBu, enorm);
 }
 
 // the outer solver's QPSConvergedDefault (qps.c:675-714)
@@ -103,7 +178,13 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
   pmh_smalxe s = (pmh_smalxe)user;
   *reason      = PMH_CONVERGED_ITERATING;
   s->inner_rnorm = gnorm;
+  s->inner_it_now = i;
+  s->BtBu_valid   = 0; // the inner solver has moved u
   if (update_normBu(s, s->u, &s->normBu, &s->enorm)) return 1;
+  if (s->fixed_left >= 0 && (long long)i >= s->fixed_left) { // throughput mode: the iteration budget ends this inner solve
+    *reason = PMH_CONVERGED_ITS;
+    return 0;
+  }
   s->rnorm      = fmax(s->enorm, gnorm);
   s->MNormBu    = s->M1 * s->normBu;
   s->inner_atol = fmin(s->MNormBu, s->eta);
@@ -151,6 +232,7 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   s->ctx = ctx, s->A = A, s->b = b, s->u = u, s->lb = lb, s->ub = ub, s->pf = pf, s->o = *o, s->n = A->n;
   s->state  = 1;
   s->normBu = s->normBu_old = s->enorm = NAN;
+  s->fixed_left = -1;
   const int n = s->n;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->BtBu));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->Btmu));
@@ -258,6 +340,8 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
   s->M1 = s->M1_initial;
   PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
   PMH_CHK(pmh_memset(ctx, s->Btmu, 0, sizeof(double) * (size_t)n));
+  s->BtBu_valid = 0;
+  if (s->o.knoll) PMH_CHK(pmh_qppf_apply_P(s->pf, s->b, s->u)); // the Knoll trick smalxe.c:938-943: projected rhs as initial guess
   PMH_CHK(objective(s, &Lag_old));
   PMH_CHK(update_normBu(s, s->u, &s->normBu_old, &s->enorm));
   s->iteration       = 0;
@@ -267,7 +351,8 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
 
   for (i = 0; i < maxits; i++) {
     // QPSSMALXEUpdateLambda_SMALXE smalxe.c:402-435: Btmu += rho * BtB u
-    PMH_CHK(pmh_qppf_apply_GtG(s->pf, s->u, s->BtBu));
+    if (!s->BtBu_valid) PMH_CHK(pmh_qppf_apply_GtG(s->pf, s->u, s->BtBu)); // "BtBu reused" otherwise (smalxe.c:421-430)
+    s->BtBu_valid = 1;
     PMH_CHK(pmh_vec_axpy(ctx, n, s->Btmu, rho, s->BtBu));
     if (s->reason) break;
     PMH_CHK(pmh_vec_waxpy(ctx, n, s->b_inner, -1.0, s->Btmu, s->b)); // b_inner = b - Btmu
@@ -283,7 +368,13 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->inner_reason = st.reason;
     s->inner_rnorm  = st.rnorm;
     s->inner_iter_accu += st.iteration;
+    s->inner_it_now = st.iteration;
+    s->BtBu_valid   = 0;
     s->iteration = i + 1;
+    if (s->fixed_left >= 0) {
+      s->fixed_left -= st.iteration;
+      if (s->fixed_left <= 0) break;
+    }
     PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
     PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
     PMH_CHK(objective(s, &Lag));
@@ -292,6 +383,37 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->normBu_old = s->normBu;
   }
   if (i == maxits && !s->reason) s->reason = PMH_DIVERGED_ITS;
+  return PMH_SUCCESS;
+}
+
+// Throughput mode of bench.py: the REAL solver loop (outer updates of lambda, M1, rho and the inner stopping rule included) for
+// exactly `inner_iters` inner MPGP iterations in total; a solve that converges earlier is restarted from u = 0 (the statistics
+// of the restarts accumulate in *cg / *exp / *prop / *mv), the last one is cut when the budget is spent.
+extern "C" int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv)
+{
+  PMH_ARG(s && inner_iters >= 0);
+  long long left = inner_iters;
+  int       ns = 0, no = 0, cg = 0, ex = 0, pr = 0, mv = 0;
+  while (left > 0) {
+    PMH_CHK(pmh_memset(s->ctx, s->u, 0, sizeof(double) * (size_t)s->n));
+    s->state      = 1;
+    s->fixed_left = left;
+    int rc        = pmh_smalxe_solve(s);
+    s->fixed_left = -1;
+    if (rc) return rc;
+    pmh_mpgp_stats st;
+    PMH_CHK(pmh_mpgp_get_stats(s->inner, &st));
+    cg += st.ncg, ex += st.nexp, pr += st.nprop, mv += st.nmv;
+    ns++, no += s->iteration;
+    if (s->inner_iter_accu <= 0) return pmh_set_error(PMH_ERR_STATE, "pmh_smalxe_run_fixed: the solve made no inner iteration");
+    left -= s->inner_iter_accu;
+  }
+  if (solves) *solves = ns;
+  if (outer_iters) *outer_iters = no;
+  if (ncg) *ncg = cg;
+  if (nexp) *nexp = ex;
+  if (nprop) *nprop = pr;
+  if (nmv) *nmv = mv;
   return PMH_SUCCESS;
 }
 

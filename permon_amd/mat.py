@@ -178,6 +178,14 @@ class MatInv:
     def mult(self, f, u):  # MatMult_Inv
         check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
 
+    def set_tolerances(self, rtol, atol=1e-50, max_it=10000):  # KSPSetTolerances of the inner KSP
+        check(self.ctx.L.pmh_matinv_set_tolerances(self.h, float(rtol), float(atol), int(max_it)))
+
+    def attach_explicit(self, E):
+        """F = B K^+ B' built on this MATINV applies through the explicit local dual operators E (None detaches)."""
+        check(self.ctx.L.pmh_matinv_attach_explicit(self.h, E.h if E is not None else None))
+        self.explicit = E
+
     def last_iterations(self):
         its, tot = C.c_int(), C.c_longlong()
         check(self.ctx.L.pmh_matinv_last_iterations(self.h, C.byref(its), C.byref(tot)))
@@ -186,6 +194,83 @@ class MatInv:
     def destroy(self):
         if self.h:
             self.ctx.L.pmh_matinv_destroy(self.h)
+            self.h = None
+
+
+def csr_block_classes(block_rowstart, K):
+    """Classes of bit-identical diagonal blocks of a block-diagonal scipy CSR (congruent subdomains): array of class ids."""
+    from . import _lib
+
+    K = K.tocsr()
+    K.sort_indices()
+    rs = np.ascontiguousarray(block_rowstart, dtype=np.int32)
+    ip, ci, va = np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64)
+    cls = np.zeros(rs.size - 1, dtype=np.int32)
+    ncls = C.c_int()
+    check(_lib.load().pmh_csr_block_classes(rs.size - 1, rs.ctypes.data_as(C.c_void_p), ip.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p),
+                                            cls.ctypes.data_as(C.c_void_p), C.byref(ncls)))
+    return cls
+
+
+class MatExplicitDual:
+    """Explicit local dual operators (pmh_fexplicit): W_b = (K_b^+)[Gamma_b, Gamma_b] dense per block, F = Bhat W Bhat'.
+    The exact-K^+ path (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:670-730, restricted to the dofs B touches)."""
+
+    def __init__(self, B, K):
+        self.ctx, self.B, self.K = B.ctx, B, K
+        h = C.c_void_p()
+        check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, C.byref(h)))
+        self.h = h
+        nb = C.c_int()
+        check(self.ctx.L.pmh_fexplicit_sizes(h, C.byref(nb), None, None, None))
+        self.nblocks = nb.value
+        ng = np.zeros(self.nblocks, dtype=np.int32)
+        db, gb = C.c_longlong(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_sizes(h, None, ng.ctypes.data_as(C.c_void_p), C.byref(db), C.byref(gb)))
+        self.n_gamma, self.dense_bytes, self.gemv_bytes = ng, db.value, gb.value
+
+    def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
+        """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
+        sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None
+        bc = np.ascontiguousarray(block_class, dtype=np.int32) if block_class is not None else None
+        check(self.ctx.L.pmh_fexplicit_assemble(self.h, solver.h, solver.K.nblocks, sc.ctypes.data_as(C.c_void_p) if sc is not None else None,
+                                                bc.ctypes.data_as(C.c_void_p) if bc is not None else None, float(rtol), int(max_it)))
+
+    def assemble_stats(self):
+        n, t = C.c_longlong(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_assemble_stats(self.h, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def block(self, b):
+        """(W_b as a numpy array, Gamma_b as rank-local primal indices)."""
+        n = int(self.n_gamma[b])
+        W, g = np.zeros((n, n)), np.zeros(n, dtype=np.int32)
+        check(self.ctx.L.pmh_fexplicit_get_block(self.h, int(b), W.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p)))
+        return W, g
+
+    def mult(self, lam, y):  # y = F lambda
+        check(self.ctx.L.pmh_fexplicit_mult(self.h, lam.p, y.p))
+
+    def compressed_size(self):
+        n = C.c_int()
+        gs = np.zeros(self.nblocks + 1, dtype=np.int32)
+        check(self.ctx.L.pmh_fexplicit_compressed_size(self.h, C.byref(n), gs.ctypes.data_as(C.c_void_p)))
+        return n.value, gs
+
+    def dense_mult(self, xh, yh):
+        check(self.ctx.L.pmh_fexplicit_dense_mult(self.h, xh.p, yh.p))
+
+    def timing_enable(self, max_launches, stride=1):
+        check(self.ctx.L.pmh_fexplicit_timing_enable(self.h, int(max_launches), int(stride)))
+
+    def timing_get(self):
+        n, ms = C.c_int(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_timing_get(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value, self.gemv_bytes
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.pmh_fexplicit_destroy(self.h)
             self.h = None
 
 
