@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--sub", default="2,2,2", help="feti: subdomain grid sx,sy,sz (2,2,2 -> configs[2]; 4,4,4 with --nel 21 --dense-coarse -> the shape of configs[3]: 64 subdomains, 8 per GPU at N = 8, 384 x 384 coarse problem)")
     ap.add_argument("--dense-coarse", action="store_true", help="feti: keep G as it comes (no QPTOrthonormalizeEq): the projector applies the dense (GG')^{-1} (GG' assembled by the fp64-MFMA kernel)")
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
+    ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
+                    "(assembled once by K^+ solves, then ONE fp64 GEMV per apply; the exact path and the faster one at every N), iterative = an inner block-wise Krylov solve per apply")
+    ap.add_argument("--explicit-rtol", type=float, default=1e-12, help="feti: tolerance of the set-up solves of the explicit operators")
+    ap.add_argument("--explicit-slots", type=int, default=8, help="feti: a rank with fewer (congruent) blocks than this assembles with a replica solver of this many slots")
+    ap.add_argument("--no-iterative", action="store_true", help="feti at N=1: skip the secondary passes on the inner-Krylov K^+ (fp16-PC and strict fp64)")
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
     ap.add_argument("--mg-precision", choices=["fp16", "fp32", "fp64"], default="fp16", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
     ap.add_argument("--mg-min-nodes", type=int, default=0, help="feti: the hierarchy stops coarsening at <= this many nodes per block (dense block pseudo-inverse there); 0 = by blocks per GPU")
@@ -60,6 +65,7 @@ def parse():
     ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
     ap.add_argument("--sim-world", type=int, default=0, help="feti, testing: this single process takes the share rank 0 would have in a run on SIM_WORLD GPUs (8/SIM_WORLD blocks, no collective): per-GPU launch-latency rehearsal of the strong-scaling run")
     ap.add_argument("--cpu-its", type=int, default=24, help="c2: MPGP iterations of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-its-feti", type=int, default=5, help="feti: MPGP iterations of the bounded CPU-baseline sample (median of their times; cut at ~45 s)")
     return ap.parse_args()
 
 
@@ -82,22 +88,6 @@ def host_threads():
     _HOST_THREADS = cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
     return cores
-
-
-def pmc_traffic(prefix, fname="r01_pmc_traffic.json"):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/, scripts/gpu_pmc*.sh): launch-weighted
-    mean over every kernel instantiation whose name starts with the prefix (e.g. the four epilogue variants of the V-cycle's
-    fine-level operator, which the live event timing samples in equal shares)."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
-        prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
-        hits = [v for k, v in pmc.items() if k.startswith(prefixes)]
-        if hits:
-            n = sum(v["launches"] for v in hits)
-            return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
-    except (OSError, ValueError, KeyError, ZeroDivisionError):
-        pass
-    return None
 
 
 def measured_ceiling(ctx, n=1 << 26, reps=10):
@@ -188,7 +178,7 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv_stream<MPGP epilogue> (Ap = A p fused with p'Ap, g'p, QPCFeas)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("void k_spmv_stream<3,") if (a.grid == 3162 and a.variant == "obstacle") else None,
+            **dict(zip(("traffic", "traffic_source"), pmc_lookup("void k_spmv_stream<3,", "r02_pmc_traffic_c2.json") if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
             "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
             "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
         },
@@ -281,31 +271,96 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[2]: TFETI contact problem, SMALXE + MPGP on the dual QP, subdomain blocks sharded over the GPUs
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_feti(f, G, b_dual, lb_dual, steps, rtol, orth=True):
-    """Same dual operator on the host cores: the oracle's MPGP (C, reference op order) on A_rho = P F P + rho Q with
-    F = B K^+ B', K^+ = per-block Jacobi-CG in C with OpenMP row-parallel CSR SpMV (oracle/permon_oracle.c).
-    Bounded sample: `steps` MPGP iterations from the same right-hand side / bounds the GPU run uses."""
+def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_s=45.0):
+    """The same algorithm as the GPU's ITERATIVE K^+ path on the host cores: the oracle's MPGP (C, reference op order) on
+    A_rho = P F P + rho Q, F = B K^+ B', K^+ = block-wise V-cycle-preconditioned CG (oracle/mg_host.py: same hierarchy, Chebyshev(2)/
+    Jacobi smoothing, dense coarse pseudo-inverses, fp64 throughout, Moore-Penrose wrapped), sparse products by the OpenMP CSR
+    kernel of oracle/permon_oracle.c, vectors in numpy.  (The reference's own K^+ is a sparse Cholesky fwd/bwd solve; no sparse
+    direct solver exists on this image, so the closest like-for-like host path is the GPU's own algorithm.)
+    Bounded sample: `its` MPGP iterations (fewer if one application is too slow for the time budget); every Hessian application
+    is timed, the median x applications per iteration is reported."""
     from oracle import oracle as O
+    from oracle.mg_host import KplusMG
 
     cores = host_threads()
-    K = O.Csr.from_scipy(f.K)
-    Kplus = O.MatInv(K, f.block_rowstart, f.R, rtol=rtol, omp=True)
-    pfo = O.Qppf(O.Csr.from_scipy(G), orthonormal=orth)
-    B = O.Gluing(f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
-    A_or = O.FetiOp(B, Kplus, pfo, rho=1.0, which=1, omp=True)  # any positive penalty: cost per iteration is the same
+    L = O.lib(True)
+    import ctypes as C
+
+    A = [O.Csr.from_scipy(a) for a in hier["A"]]
+    P = [O.Csr.from_scipy(p) for p in hier["P"]]
+    Pt = [O.Csr.from_scipy(p.T.tocsr()) for p in hier["P"]]
+
+    def spmv(tag, l, x):
+        M = A[l] if tag == "A" else P[l] if tag == "P" else Pt[l]
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(M.nrows)
+        L.orc_csr_mult(C.byref(M.c), x.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double)))
+        return y
+
+    Kp = KplusMG(hier["A"][0], f.block_rowstart, hier, R=f.R, rtol=rtol, spmv=spmv)
+    B, Gs = f.B.tocsr(), G.tocsr()
+    Bt, Gt = B.T.tocsr(), Gs.T.tocsr()
+    GGt_inv = None if orth else np.linalg.inv((Gs @ Gt).toarray())
+    rho = 1.0  # any positive penalty: the cost per iteration is the same
+    stamps = []
+
+    def Q(v):
+        w = Gs @ v
+        return Gt @ (w if orth else GGt_inv @ w)
+
+    def A_rho(v):
+        pv = v - Q(v)
+        y = B @ Kp(Bt @ pv)
+        y = y - Q(y)
+        y = y + rho * (Gt @ (Gs @ v))
+        stamps.append(time.perf_counter())
+        return y
+
     n = f.n_lambda
+    op = O.Op(n, fn=A_rho)
+    # size the sample: one probe application of A_rho, then as many MPGP iterations (<= its, >= 2) as fit the time budget
     t0 = time.perf_counter()
-    ref = O.mpgp(A_or.op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), omp=True, maxeig=1.0, max_it=steps - 1)
-    dt = time.perf_counter() - t0
+    A_rho(b_dual)
+    t_probe = time.perf_counter() - t0
+    its = int(max(2, min(its, budget_s / (2.1 * t_probe))))
+    del stamps[:]
+    ref = O.mpgp(op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), maxeig=1.0 + rho, max_it=its - 1)
+    # the first application is the initial gradient (set-up of the solve); the iterations own the rest
+    per_apply = np.diff(np.asarray(stamps))
+    applies_per_it = len(per_apply) / max(1, ref["iteration"])
+    med = float(np.median(per_apply)) * applies_per_it
     return {
-        "value": ref["iteration"] / dt, "unit": "QPS iterations/s", "cores": cores, "kind": "port",
-        "sample": "%d inner MPGP iteration(s) of the same TFETI dual QP: oracle/permon_oracle.c (reference op order), F = B K^+ B' with "
-                  "per-block Jacobi-CG K^+ rtol %.0e, OpenMP row-parallel CSR SpMV on %d threads (cgroup quota of the box), %d K SpMVs in the sample"
-                  % (ref["iteration"], rtol, cores, Kplus.spmv_count()),
+        "value": 1.0 / med, "unit": "QPS iterations/s", "cores": cores, "kind": "port",
+        "sample": "%d MPGP iterations (oracle/permon_oracle.c, the reference's op order; %.2f Hessian applications each, median application %.2f s => %.1f s per iteration) of the same TFETI dual QP on the host: "
+                  "F = B K^+ B' with the GPU's own ITERATIVE K^+ restated on the CPU (oracle/mg_host.py: block-wise CG preconditioned by the same %d-level V-cycle, "
+                  "fp64, rtol %.0e, %d CG iterations per application), sparse products by the OpenMP CSR kernel on %d threads (cgroup quota of the box), vectors in numpy; "
+                  "%d K products in the sample.  The reference's own K^+ (sparse Cholesky) cannot be built here (no sparse direct solver on the image)"
+                  % (ref["iteration"], applies_per_it, float(np.median(per_apply)), med, len(hier["A"]), rtol, Kp.last_its, cores, Kp.n_spmv),
     }
 
 
+def pmc_lookup(prefix, fname):
+    """(HBM bytes per launch, provenance) of a kernel from a committed rocprofv3 PMC pass (profiles/<fname>, written by
+    scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
+    carries no traffic figure rather than a stale one."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        pmc = json.load(open(path))
+    except (OSError, ValueError) as ex:
+        return None, "no PMC pass: %r" % (ex,)
+    prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
+    hits = [v for k, v in pmc.items() if not k.startswith("_") and k.startswith(prefixes)]
+    if not hits:
+        return None, "kernel %r not in profiles/%s" % (prefixes, fname)
+    n = sum(v["launches"] for v in hits)
+    meta = pmc.get("_meta", {})
+    return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n,
+            "profiles/%s @ %s (%s)" % (fname, meta.get("git", "git state not recorded"), meta.get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled")))
+
+
 def run_feti(ctx, a, steps, warmup, rank, world, dist):
+    import scipy.sparse as sp
+
     import permon_amd as pa
     from permon_amd.chain import FetiDualQP
 
@@ -325,25 +380,49 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     local = f.subset(range(rank * per, (rank + 1) * per))
     t_gen = time.time() - t0
     t0 = time.time()
-    hier = None
+    nn = a.nel + 1
     blocks = [f.Ki] * per
     if a.regularize:  # MatRegularize per block (the kernel bases, hence the fixing DOFs, differ from block to block)
         from permon_amd.chain import regularize_blocks
 
         local["Kreg"] = regularize_blocks(ctx, local)[0]
         blocks = [local["Kreg"][i * f.n_i:(i + 1) * f.n_i, i * f.n_i:(i + 1) * f.n_i].tocsr() for i in range(per)]
-    if a.kplus_pc == "mg":  # Galerkin hierarchy of the congruent cubes (host set-up, seconds)
-        nn = a.nel + 1
-        # depth of the hierarchy by blocks per GPU: with 1-2 blocks the cycle is launch-latency bound, so it stops one level earlier
-        # (dense block pseudo-inverse at ~5000 dof, one HBM-streaming launch instead of a smoothed level's seven) -- measured, profiles/
-        auto_nodes = 2000 if per <= (4 if a.mg_precision == "fp16" else 1) else 400
+
+    def make_hier(blks, nper):  # Galerkin hierarchy of the congruent cubes (host set-up, seconds)
+        # depth by blocks per GPU: with 1-4 blocks the cycle is launch-latency bound, so it stops one level earlier (dense block
+        # pseudo-inverse at ~5000 dof, one HBM-streaming launch instead of a smoothed level's seven) -- measured, profiles/
+        auto_nodes = 2000 if nper <= (4 if a.mg_precision == "fp16" else 1) else 400
         auto_nodes = min(auto_nodes, nn ** 3 // 8)  # tiny test problems: at least one smoothed level
-        hier = pa.box_mg_hierarchy(blocks, [(nn, nn, nn)] * per, 3, min_nodes=a.mg_min_nodes or auto_nodes)
+        return pa.box_mg_hierarchy(blks, [(nn, nn, nn)] * len(blks), 3, min_nodes=a.mg_min_nodes or auto_nodes)
+
+    hier = make_hier(blocks, per) if a.kplus_pc == "mg" else None
+    explicit = None
+    replica = {}
+    if a.kplus == "explicit":
+        def solver_factory(nslots):
+            """A K^+ over `nslots` replicas of this rank's (congruent) block: the set-up solves of the explicit operators fill the GPU
+            although the rank owns fewer blocks (1 at N = 8)."""
+            Kb = pa.MatBlockDiag.from_scipy(ctx, np.arange(nslots + 1, dtype=np.int32) * f.n_i, sp.block_diag([f.Ki] * nslots, format="csr"))
+            Rb = np.tile(local["R"][:, :f.n_i], (1, nslots))
+            M = pa.MatInv(Kb, rtol=a.explicit_rtol, max_it=20000, jacobi=True, nullspace=Rb)
+            if not a.no_bsr3:
+                M.enable_bsr3()
+            if a.kplus_pc == "mg":
+                M.set_pc_mg(make_hier([f.Ki] * nslots, nslots), degree=a.mg_degree, precision=a.mg_precision)
+            replica["M"], replica["K"] = M, Kb
+            return M
+
+        explicit = dict(rtol=a.explicit_rtol, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
     q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
-                   regularize=a.regularize)
+                   regularize=a.regularize, explicit=explicit)
+    if replica:  # the replica solver is set-up scaffolding: release it
+        if getattr(replica["M"], "mg", None) is not None:
+            replica["M"].mg.destroy()
+        replica["M"].destroy()
+        replica["K"].destroy()
+        replica["K"].K.destroy()
     qps = q.make_smalxe()  # QPSSetUp_SMALXE: lambda_max(PFP) by the power method, rho, M1, inner MPGP
     t_setup = time.time() - t0
-    Kcsr = q.K.K
 
     def barrier():
         ctx.sync()
@@ -353,92 +432,132 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             dist.barrier()
             torch.cuda.synchronize()
 
-    qps.RunFixed(warmup)
-    q.lam.set(0.0)
-    # HIP-event pairs around the K x launches: over the timed region at N = 1; at N > 1 (1-4 blocks per GPU) the V-cycle is replayed
-    # as a hipGraph inside the timed region, which cannot carry event pairs, so the kernel durations of the roofline object come
-    # from a separate 2-step pass right after it (same state, same kernels; "timed_over" says which)
+    def timed_pass(nsteps, nwarm):
+        """W untimed + exactly K timed inner MPGP iterations of the real SMALXE solver loop (restarting from lambda = 0 whenever the
+        solve converges: configs[2] takes 108 iterations), bracketed by barriers; max over ranks."""
+        if nwarm:
+            qps.RunFixedSolve(nwarm)
+        barrier()
+        t1 = time.perf_counter()
+        cnt = qps.RunFixedSolve(nsteps)
+        barrier()
+        dt = time.perf_counter() - t1
+        if dist is not None:
+            import torch
+
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, cnt
+
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
-    timing_in_region = want_timing and world == 1 and not a.sim_world
-
-    def timing_on():
-        os.environ.setdefault("PMH_TIMING_STRIDE", "5")  # event pairs around every 5th K x launch (each pair costs stream time; 5 is coprime to the 4 fine-level launches of a cycle, so all four kernel variants are sampled)
-        q.Kplus.timing_enable(8000)
-        if hier is not None:
-            q.Kplus.mg.timing_enable(8000)
-
-    if timing_in_region:
-        timing_on()
-    _, spmv1 = q.Kplus.last_iterations()
-    mgs1 = q.Kplus.mg.fine_spmv() if hier is not None else 0
-    barrier()
-    t1 = time.perf_counter()
-    st = qps.RunFixed(steps)
-    barrier()
-    dt = time.perf_counter() - t1
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert st.iteration == steps, (st.iteration, steps)
-    kits, spmv2 = q.Kplus.last_iterations()
-    mgs2 = q.Kplus.mg.fine_spmv() if hier is not None else 0
-    if want_timing and not timing_in_region:
-        timing_on()
-        qps.RunFixed(2)
-        ctx.sync()
-    # dominant kernel: the K x product.  With the V-cycle PC most of them are the cycle's fine-level launches
-    # (3x3-block kernel, fp32 or fp64); without it they are the CG's own products.
-    n_cg, ms_cg, b_cg = q.Kplus.timing_get()
-    if hier is not None:
-        n_k, ms_k, b_k = q.Kplus.mg.timing_get()
-        kname = "k_bsr3<%s>: fine-level K x of the V-cycle (3x3 blocks, %s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[a.mg_precision]
-        kpat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[a.mg_precision]  # rocprofv3 leaves the _Float16 instantiations mangled
-    else:
-        n_k, ms_k, b_k = n_cg, ms_cg, b_cg
-        kname = ("k_bsr3<double>: K x of the block CG (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
-                 else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
-        kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
-    ms_all = ms_k + (ms_cg if hier is not None else 0.0)
-    stride = int(os.environ.get("PMH_TIMING_STRIDE", "1"))
-    achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+    full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world)
     kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
     pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
+
+    def iterative_pass(nsteps, nwarm, precision):
+        """The inner-Krylov K^+ (the reference's iterative MATINV path): block-wise CG with the V-cycle PC in `precision`."""
+        os.environ.setdefault("PMH_TIMING_STRIDE", "5")  # event pairs around every 5th K x launch (coprime to the 4 fine-level launches of a cycle)
+        if want_timing:
+            q.Kplus.timing_enable(8000)
+            if hier is not None:
+                q.Kplus.mg.timing_enable(8000)
+        _, spmv1 = q.Kplus.last_iterations()
+        mgs1 = q.Kplus.mg.fine_spmv() if hier is not None else 0
+        dt, cnt = timed_pass(nsteps, nwarm)
+        kits, spmv2 = q.Kplus.last_iterations()
+        mgs2 = q.Kplus.mg.fine_spmv() if hier is not None else 0
+        stride = int(os.environ.get("PMH_TIMING_STRIDE", "1"))
+        n_cg, ms_cg, b_cg = q.Kplus.timing_get() if want_timing else (0, 0.0, 0.0)
+        cg_GBs = b_cg / (ms_cg / n_cg * 1e-3) / 1e9 if n_cg else 0.0
+        kname = ("k_bsr3<double>: the fp64 K x of the block CG inside K^+ = the FETI dual SpMV (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
+                 else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
+        kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
+        traffic, tsrc = pmc_lookup(kpat, "r02_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        roof = {"bound": "hbm", "kernel": kname, "achieved": cg_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_GBs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": b_cg, "launches_timed": n_cg, "avg_launch_ms": ms_cg / n_cg if n_cg else None, "timing_stride": stride,
+                "share_of_step_time": (ms_cg * 1e-3) * stride / dt if n_cg else None}
+        if hier is not None and want_timing:
+            n_k, ms_k, b_k = q.Kplus.mg.timing_get()
+            pk = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+            ppat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[precision]
+            ptraffic, ptsrc = pmc_lookup(ppat, "r02_pmc_traffic_feti_iterative.json") if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
+            roof["preconditioner"] = {"kernel": "k_bsr3<%s>: fine-level K x of the V-cycle (%s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[precision],
+                                      "achieved": pk, "frac": pk / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
+                                      "share_of_step_time": (ms_k * 1e-3) * stride / dt if n_k else None, "traffic": ptraffic, "traffic_source": ptsrc}
+        q.Kplus.timing_enable(0)
+        if hier is not None:
+            q.Kplus.mg.timing_enable(0)
+        return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "steps": nsteps, "warmup": nwarm, "steps_by_type": cnt,
+                "kplus": "block-wise %s%s (rtol %.0e)" % (pc_text.replace(a.mg_precision, precision), kreg_text, a.kplus_rtol),
+                "cg_spmv_per_step": (spmv2 - spmv1) / max(nsteps + nwarm, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(nsteps + nwarm, 1), "last_block_cg_iterations": kits,
+                "roofline": roof}
+
+    extra = {}
+    if a.kplus == "explicit":
+        E = q.E
+        if want_timing:
+            E.timing_enable(4 * (steps + warmup) + 256, 1)
+        dt, cnt = timed_pass(steps, warmup)
+        n_k, ms_k, b_k = E.timing_get() if want_timing else (0, 0.0, E.gemv_bytes)
+        E.timing_enable(0)
+        achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
+        n_solves, asm_s = E.assemble_stats()
+        traffic, tsrc = pmc_lookup("void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        roofline = {
+            "bound": "hbm", "kernel": "k_fx_gemv: y_b = W_b x_b, the dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] of all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None, "timing_stride": 1,
+            "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt * (steps / max(1, steps + warmup)) if n_k else None,
+        }
+        kplus_cfg = {"path": "explicit", "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
+                     "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text
+                     if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
+        kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
+            int(E.n_gamma.min()), int(E.n_gamma.max()), E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
+        precision_note = "fp64 throughout: the dense blocks, the GEMV and everything in the dual space are fp64; reduced precision exists only inside the V-cycle that preconditions the SET-UP solves (their CG, residual test at rtol %.0e and solutions are fp64)" % a.explicit_rtol
+        if world == 1 and not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and strict fp64
+            q.Kplus.attach_explicit(None)
+            extra["iterative"] = iterative_pass(min(steps, 108), 4, a.mg_precision)
+            if hier is not None and a.mg_precision != "fp64":
+                old = q.Kplus.mg
+                q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
+                old.destroy()
+                extra["strict_fp64"] = iterative_pass(min(steps, 54), 2, "fp64")
+                extra["strict_fp64"]["note"] = "every operator, vector and the V-cycle in fp64 (the reference's arithmetic throughout)"
+            q.Kplus.attach_explicit(E)
+    else:
+        r = iterative_pass(steps, warmup, a.mg_precision)
+        dt, cnt = r["ms_per_step"] * steps / 1e3, r["steps_by_type"]
+        roofline = r["roofline"]
+        roofline["timed_over"] = "the timed region"
+        kplus_cfg = {"path": "iterative", "pc": a.kplus_pc, "cg_spmv_per_step": r["cg_spmv_per_step"], "vcycle_fine_spmv_per_step": r["vcycle_fine_spmv_per_step"], "last_block_cg_iterations": r["last_block_cg_iterations"]}
+        kplus_text = "block-wise %s K^+%s (rtol %.0e)" % (pc_text, kreg_text, a.kplus_rtol)
+        precision_note = ("the reduced precision (%s) lives ONLY in the V-cycle that preconditions the block CG of K^+: that CG's operator, residual, stopping test (rtol %.0e) and solution "
+                          "are fp64, as is everything in the dual space" % (a.mg_precision, a.kplus_rtol)) if hier is not None else "fp64 throughout"
+        if world == 1 and not a.sim_world and hier is not None and a.mg_precision != "fp64" and not a.no_iterative:
+            old = q.Kplus.mg
+            q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
+            old.destroy()
+            extra["strict_fp64"] = iterative_pass(min(steps, 54), 2, "fp64")
+    comm_rank, comm_size = ctx.comm_rank()
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "%s: 3-D elasticity TFETI, %dx%dx%d cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
-                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP, F = B K^+ B' with block-wise %s K^+%s (rtol %.0e)%s"
+                    "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP (the real solver loop, restarted when it converges), F = B K^+ B' through %s%s"
                     % ("configs[2]" if (sub == (2, 2, 2) and orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like", sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
-                       pc_text, kreg_text, a.kplus_rtol, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
+                       kplus_text, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
         "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
-        "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
-        "precision_note": ("the reduced precision (%s) lives ONLY in the V-cycle that preconditions the block CG of K^+: that CG's operator, residual, "
-                           "stopping test (rtol %.0e) and solution are fp64, as is everything in the dual space; --mg-precision fp64 runs the cycle in fp64 "
-                           "(same CG count; 39.8 vs 20.1 ms/step measured, profiles/)" % (a.mg_precision, a.kplus_rtol)) if hier is not None else "fp64 throughout",
-        "kplus": {"pc": a.kplus_pc, "cg_spmv_per_step": (spmv2 - spmv1) / max(steps, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(steps, 1),
-                  "last_block_cg_iterations": kits},
+        "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None,
+        "steps_by_type": cnt, "precision_note": precision_note, "kplus": kplus_cfg,
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
                                       "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": True},
-        "roofline": {
-            "bound": "hbm", "kernel": kname,
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(kpat, "r01_h_pmc_traffic_feti.json") if (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world) else None,
-            "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
-            "timing_stride": int(os.environ.get("PMH_TIMING_STRIDE", "1")),
-            "timed_over": "the timed region" if timing_in_region else "a separate 2-step pass after the timed region (hipGraph replay inside it)",
-            "share_of_step_time": ((ms_k * 1e-3) * stride / dt if n_k else None) if timing_in_region else None,  # every stride-th launch is timed
-            "all_fine_K_products": {"launches_timed": n_k + (n_cg if hier is not None else 0), "share_of_step_time": ((ms_all * 1e-3) * stride / dt if n_k else None) if timing_in_region else None,
-                                    "cg_product_GBps": (b_cg / (ms_cg / n_cg * 1e-3) / 1e9) if n_cg else None},
-        },
+        "roofline": roofline,
     }
-    q.Kplus.timing_enable(0)
-    if hier is not None:
-        q.Kplus.mg.timing_enable(0)
-    return res, f, G, q.b.to_numpy(), q.lb_new.to_numpy()  # (the CPU baseline leg re-uses the generated problem)
+    res.update(extra)
+    return res, f, G, hier, q.b.to_numpy(), q.lb_new.to_numpy()  # (the CPU baseline leg re-uses the generated problem)
 
 
 def main():
@@ -502,20 +621,23 @@ def main():
             "roofline": r["roofline"],
         }
     else:
-        steps, warmup = a.steps or 20, a.warmup if a.warmup is not None else 2
-        r, f, G, b_dual, lb_dual = run_feti(ctx, a, steps, warmup, rank, world, dist)
+        steps, warmup = a.steps or 216, a.warmup if a.warmup is not None else 8  # 216 = two full configs[2] solves (108 inner iterations each)
+        r, f, G, hier, b_dual, lb_dual = run_feti(ctx, a, steps, warmup, rank, world, dist)
         out = {
             "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"],
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "rccl_ranks": r["rccl_ranks"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"],
                        "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
             "roofline": r["roofline"],
         }
+        for k in ("iterative", "strict_fp64"):
+            if k in r:
+                out[k] = r[k]
         if rank == 0 and world == 1:
-            if not a.no_cpu_baseline:
+            if not a.no_cpu_baseline and hier is not None and not a.regularize:
                 try:
-                    out["cpu_baseline"] = cpu_baseline_feti(f, G, b_dual, lb_dual, 1, a.kplus_rtol, orth=not a.dense_coarse)
+                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=not a.dense_coarse)
                 except Exception as ex:  # noqa: BLE001
                     out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
             if not a.no_c2:

@@ -99,6 +99,7 @@ int pmh_op_create_shell(pmh_ctx ctx, int n, pmh_shell_mult_fn f, void *user, pmh
 int pmh_op_destroy(pmh_op op);
 int pmh_op_size(pmh_op op, int *n);
 int pmh_op_mult(pmh_op op, const double *x, double *y);
+int pmh_op_mult_transpose(pmh_op op, const double *x, double *y); /* MatMultTranspose; PMH_ERR_SUP for a shell without the slot */
 /* MatGetMaxEigenvalue, src/mat/interface/permonmatutils.c:442-522 (tol/maxits: PMH_DECIDE -> 1e-4 / 50) */
 int pmh_op_max_eigenvalue(pmh_op op, double tol, int maxits, double *lambda, int *its);
 
@@ -208,6 +209,14 @@ int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv);     /* MatMult(c
 
 /* ---- composed operators of the QP transform chain ------------------------------------------------------ */
 int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op *op);   /* MatCreatePenalized matpenalized.c:212-243; mult :12-22 */
+/* the other three op slots MatCreatePenalized registers (matpenalized.c:232-235): MatMultTranspose_Penalized :26-36,
+   MatMultAdd_Penalized :40-57 (y = x2 + A_rho x; x2 may be y), MatMultTransposeAdd_Penalized :61-78 */
+int pmh_op_penalized_mult_add(pmh_op op, const double *x, const double *x2, double *y);
+int pmh_op_penalized_mult_transpose_add(pmh_op op, const double *x, const double *x2, double *y);
+/* the other three op slots MatCreatePenalized registers (matpenalized.c:232-235): MatMultTranspose_Penalized :26-36 (through
+   pmh_op_mult_transpose), MatMultAdd_Penalized :40-57 (y = x2 + A_rho x; x2 may be y), MatMultTransposeAdd_Penalized :61-78 */
+int pmh_op_penalized_mult_add(pmh_op op, const double *x, const double *x2, double *y);
+int pmh_op_penalized_mult_transpose_add(pmh_op op, const double *x, const double *x2, double *y);
 int pmh_op_penalized_set_penalty(pmh_op op, double rho);                      /* MatPenalizedSetPenalty */
 int pmh_op_penalized_get_penalty(pmh_op op, double *rho);
 int pmh_op_create_projected(pmh_op A, pmh_qppf pf, int symmetric, pmh_op *op); /* P*A*P (symmetric) or P*A: qptransform.c:273-284 */

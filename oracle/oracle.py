@@ -338,9 +338,9 @@ def smalxe(op, b, u0, box, pf, omp=False, inner_opts=None, trace_cap=0, **opts):
             L.orc_qps_enable_trace(C.c_void_p(inner), C.c_int(trace_cap))
         L.orc_smalxe_setup(C.c_void_p(s))
         L.orc_smalxe_solve(C.c_void_p(s))
-        keys = ["M1", "M1_initial", "eta", "rho", "rho_current", "M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "normBu", "enorm", "rnorm", "iteration", "reason", "maxeig", "gtol"]
+        keys = ["M1", "M1_initial", "eta", "rho", "rho_current", "M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "normBu", "enorm", "rnorm", "iteration", "reason", "maxeig", "gtol", "lag_neval", "lag_niter"]
         res = {k: L.orc_smalxe_get(C.c_void_p(s), k.encode()) for k in keys}
-        for k in ("M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "iteration", "reason"):
+        for k in ("M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "iteration", "reason", "lag_neval", "lag_niter"):
             res[k] = int(res[k])
         res["inner"] = _qps_results(L, inner, u, trace_cap)
         res["u"] = u

@@ -122,6 +122,9 @@ _PROTOS = {
     "pmh_op_destroy": [vp],
     "pmh_op_size": [vp, c_int_p],
     "pmh_op_mult": [vp, vp, vp],
+    "pmh_op_mult_transpose": [vp, vp, vp],
+    "pmh_op_penalized_mult_add": [vp, vp, vp, vp],
+    "pmh_op_penalized_mult_transpose_add": [vp, vp, vp, vp],
     "pmh_op_max_eigenvalue": [vp, C.c_double, C.c_int, c_double_p, c_int_p],
     "pmh_qpc_box_project": [vp, C.c_int, vp, vp, vp, vp],
     "pmh_qpc_box_feas": [vp, C.c_int, vp, vp, vp, vp, c_double_p],

@@ -63,6 +63,12 @@ class Context:
         check(self.L.pmh_comm_init(self.h, int(rank), int(size), buf))
         self.rank, self.size = int(rank), int(size)
 
+    def comm_rank(self):
+        """(rank, size) of the RCCL communicator (pmh_comm_rank); (0, 1) without one."""
+        r, n = C.c_int(), C.c_int()
+        check(self.L.pmh_comm_rank(self.h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def barrier(self):
         check(self.L.pmh_comm_barrier(self.h))
 

@@ -741,6 +741,7 @@ struct FetiDualOp : pmh_op_s {
     PMH_CHK(pmh_matinv_mult(Kplus, t1, t2));
     return pmh_gluing_mult_transpose(B, t2, y);
   }
+  int mult_transpose(const double *x, double *y) override { return mult(x, y); } // F = B K^+ B' is symmetric
 };
 
 extern "C" int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F)

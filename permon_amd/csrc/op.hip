@@ -5,6 +5,7 @@
 struct CsrOp : pmh_op_s {
   pmh_csr A;
   int     mult(const double *x, double *y) override { return pmh_csr_mult(A, x, y); }
+  int     mult_transpose(const double *x, double *y) override { return pmh_csr_mult_transpose(A, x, y); }
   pmh_csr as_csr() override { return A; }
 };
 
@@ -60,6 +61,12 @@ extern "C" int pmh_op_mult(pmh_op op, const double *x, double *y)
 {
   PMH_ARG(op);
   return op->mult(x, y);
+}
+
+extern "C" int pmh_op_mult_transpose(pmh_op op, const double *x, double *y)
+{
+  PMH_ARG(op);
+  return op->mult_transpose(x, y);
 }
 
 // MatGetMaxEigenvalue, src/mat/interface/permonmatutils.c:442-522: v = 1; <= maxits power iterations

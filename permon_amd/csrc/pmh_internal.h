@@ -97,6 +97,8 @@ struct pmh_op_s {
   int     n;
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
+  // MatMultTranspose slot; operators that are symmetric by construction forward to mult
+  virtual int     mult_transpose(const double *, double *) { return pmh_set_error(PMH_ERR_SUP, "this operator has no MatMultTranspose slot"); }
   virtual pmh_csr as_csr() { return nullptr; }
 };
 

@@ -286,6 +286,16 @@ struct ProjectedOp : pmh_op_s {
     }
     return pmh_qppf_apply_P(pf, w2, y);
   }
+  // (P A P)' = P A' P; (P A)' = A' P
+  int mult_transpose(const double *x, double *y) override
+  {
+    PMH_CHK(pmh_qppf_apply_P(pf, x, w1));
+    if (symmetric) {
+      PMH_CHK(A->mult_transpose(w1, w2));
+      return pmh_qppf_apply_P(pf, w2, y);
+    }
+    return A->mult_transpose(w1, y);
+  }
   // same, with Q x supplied by the caller (the QPPFApplyQ cache hit of qppf.c:464-467)
   int mult_with_Qx(const double *x, const double *Qx, double *y)
   {
@@ -303,8 +313,12 @@ struct PenalizedOp : pmh_op_s {
   pmh_op   A;
   pmh_qppf pf;
   double   rho;
-  double  *t;
-  ~PenalizedOp() override { pmh_free(ctx, t); }
+  double  *t, *xwork = nullptr;
+  ~PenalizedOp() override
+  {
+    pmh_free(ctx, t);
+    if (xwork) pmh_free(ctx, xwork);
+  }
   // MatMult_Penalized matpenalized.c:12-22: y = BtB x; y *= rho; y = y + A x
   int mult(const double *x, double *y) override
   {
@@ -316,6 +330,30 @@ struct PenalizedOp : pmh_op_s {
       PMH_CHK(A->mult(x, t));
     }
     PMH_CHK(pmh_vec_scale(ctx, n, y, rho));
+    return pmh_vec_axpy(ctx, n, y, 1.0, t);
+  }
+  // MatMultTranspose_Penalized matpenalized.c:26-36: y = BtB x; y *= rho; y = y + A' x
+  int mult_transpose(const double *x, double *y) override
+  {
+    PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));
+    PMH_CHK(A->mult_transpose(x, t));
+    PMH_CHK(pmh_vec_scale(ctx, n, y, rho));
+    return pmh_vec_axpy(ctx, n, y, 1.0, t);
+  }
+  // MatMultAdd_Penalized / MatMultTransposeAdd_Penalized matpenalized.c:40-78: x2 != y: y = BtB x; y = rho y + x2;
+  // x2 == y: xwork = BtB x; xwork *= rho; y += xwork.  Then y = y + A x (resp. A' x).
+  int mult_add(const double *x, const double *x2, double *y, bool transpose)
+  {
+    if (x2 != y) {
+      PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));
+      PMH_CHK(pmh_vec_aypx(ctx, n, y, rho, x2));
+    } else {
+      if (!xwork) PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&xwork));
+      PMH_CHK(pmh_qppf_apply_GtG(pf, x, xwork));
+      PMH_CHK(pmh_vec_scale(ctx, n, xwork, rho));
+      PMH_CHK(pmh_vec_axpy(ctx, n, y, 1.0, xwork));
+    }
+    PMH_CHK(transpose ? A->mult_transpose(x, t) : A->mult(x, t));
     return pmh_vec_axpy(ctx, n, y, 1.0, t);
   }
 };
@@ -333,6 +371,20 @@ extern "C" int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op
   PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)o->n, (void **)&o->t));
   *op = o;
   return PMH_SUCCESS;
+}
+
+extern "C" int pmh_op_penalized_mult_add(pmh_op op, const double *x, const double *x2, double *y)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && x && x2 && y);
+  return o->mult_add(x, x2, y, false);
+}
+
+extern "C" int pmh_op_penalized_mult_transpose_add(pmh_op op, const double *x, const double *x2, double *y)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && x && x2 && y);
+  return o->mult_add(x, x2, y, true);
 }
 
 extern "C" int pmh_op_penalized_set_penalty(pmh_op op, double rho)

@@ -244,6 +244,18 @@ class QPS:
         self.stats = st
         return st
 
+    def RunFixedSolve(self, iters):
+        """Throughput mode of a SMALXE solver (bench.py): the REAL solver loop -- outer multiplier / M1 / rho updates and the inner
+        stopping rule included -- for exactly `iters` inner MPGP iterations in total; a solve that converges earlier restarts from
+        the zero initial guess.  Returns the counts accumulated over the restarts."""
+        if self.type != "smalxe":
+            raise ValueError("RunFixedSolve is for QPS of type smalxe")
+        self.SetUp()
+        v = [C.c_int() for _ in range(6)]
+        check(self.L.pmh_smalxe_run_fixed(self.h, int(iters), *[C.byref(x) for x in v]))
+        keys = ("solves", "outer", "cg", "expansion", "proportioning", "hessian_mults")
+        return dict(zip(keys, (x.value for x in v)))
+
     def ViewKKT(self):
         """The `r = ...` lines of -qp_chain_view_kkt for a box-constrained QP (QPViewKKT qp.c:245-369 + QPCViewKKT_Box
         qpcbox.c:333-427), formatted exactly as the reference prints them."""

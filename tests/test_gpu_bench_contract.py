@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
-ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
 
 
 def _run(*args):
@@ -23,14 +23,21 @@ def _run(*args):
 
 
 def test_default_workload_line_small():
-    d = _run("--nel", "7", "--steps", "3", "--warmup", "1", "--grid", "300", "--cpu-its", "3")
+    d = _run("--nel", "7", "--steps", "30", "--warmup", "3", "--grid", "300", "--cpu-its", "3", "--cpu-its-feti", "3")
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "QPS iterations/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "strong"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the headline path: explicit local dual operators (fp64 GEMV); the inner-Krylov path and its strict-fp64 variant ride along
+    assert d["config"]["kplus"]["path"] == "explicit" and "k_fx_gemv" in r["kernel"] and r["launches_timed"] > 0
+    st = d["config"]["steps_by_type"]
+    assert st["cg"] + st["expansion"] + st["proportioning"] == 30 and st["solves"] >= 1
+    for k in ("iterative", "strict_fp64"):
+        assert d[k]["value"] > 0 and ROOF <= set(d[k]["roofline"]) and "k_bsr3<double>" in d[k]["roofline"]["kernel"]
+    assert d["config"]["rccl_ranks"] is None
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     c1 = d["configs1"]
@@ -39,7 +46,9 @@ def test_default_workload_line_small():
 
 def test_rehearsal_and_other_workloads_small():
     d = _run("--nel", "7", "--steps", "2", "--warmup", "1", "--sim-world", "4", "--no-cpu-baseline", "--no-c2")
-    assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["timed_over"].startswith("a separate")
+    assert "REHEARSAL" in d["config"]["parallelism"] and "iterative" not in d
+    d = _run("--nel", "7", "--steps", "4", "--warmup", "1", "--kplus", "iterative", "--no-cpu-baseline", "--no-c2")
+    assert d["config"]["kplus"]["path"] == "iterative" and "strict_fp64" in d and "k_bsr3<double>" in d["roofline"]["kernel"]
     d = _run("--workload", "c2", "--grid", "400", "--steps", "20", "--warmup", "2", "--no-cpu-baseline")
     assert KEYS <= set(d) and d["scaling"] == "weak" and d["config"]["workload"].startswith("configs[1]")
     d = _run("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2")

@@ -19,45 +19,9 @@ def ctx():
 
 
 def _vcycle_numpy(H, degree, lo, hi):
-    A, P, lam = H["A"], H["P"], H["lambda_max"]
-    nl = len(A)
-    dinv = [1.0 / a.diagonal() for a in A]
-    crs = H["coarse_rowstart"]
-    blocks, o = [], 0
-    for b in range(len(crs) - 1):
-        m = crs[b + 1] - crs[b]
-        blocks.append(H["coarse_pinv"][o:o + m * m].reshape(m, m))
-        o += m * m
+    from oracle.mg_host import vcycle  # the CPU restatement of the cycle (test infrastructure)
 
-    def smooth(l, b, x):
-        a_, b_ = lo * lam[l], hi * lam[l]
-        th, de = (a_ + b_) / 2, (b_ - a_) / 2
-        sig = th / de
-        rho = 1 / sig
-        if x is None:
-            r = dinv[l] * b
-            d = r / th
-            x = d.copy()
-        else:
-            r = dinv[l] * (b - A[l] @ x)
-            d = r / th
-            x = x + d
-        for _ in range(1, degree):
-            rn = 1 / (2 * sig - rho)
-            r = r - dinv[l] * (A[l] @ d)
-            d = rn * rho * d + 2 * rn / de * r
-            x = x + d
-            rho = rn
-        return x
-
-    def V(l, b):
-        if l == nl - 1:
-            return np.concatenate([blocks[k] @ b[crs[k]:crs[k + 1]] for k in range(len(blocks))])
-        x = smooth(l, b, None)
-        x = x + P[l] @ V(l + 1, P[l].T @ (b - A[l] @ x))
-        return smooth(l, b, x)
-
-    return lambda b: V(0, b)
+    return vcycle(H, degree, lo, hi)
 
 
 def _cube_hierarchy(f, min_nodes=27):

@@ -1,0 +1,119 @@
+"""the ||Bu|| update variants of SMALXE (QPSSMALXEUpdateNormBu_SMALXEON smalxe.c:265-285, the lagged update :289-370),
+-qps_smalxe_knoll (:938-943) and the remaining op slots of the penalised operator (matpenalized.c:26-78) against the CPU oracle."""
+import numpy as np
+import pytest
+
+import permon_amd as pa
+from permon_amd._lib import check
+from permon_amd.chain import FetiDualQP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def problem(ctx):
+    f = pa.CubeFeti((2, 2, 2), 3, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-13, explicit=dict(rtol=1e-13))
+    return f, G, q
+
+
+def _oracle_problem(oracle, f, G, q):
+    """The same projected dual QP on the CPU: F from the product's explicit blocks (pinned against numpy pinv in test_gpu_explicit)."""
+    Kp = np.linalg.pinv(f.Ki.toarray(), rcond=1e-10, hermitian=True)
+    B = f.B.toarray()
+    F = sum(B[:, s * f.n_i:(s + 1) * f.n_i] @ Kp @ B[:, s * f.n_i:(s + 1) * f.n_i].T for s in range(f.nsub))
+    pfo = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=True)
+    n = f.n_lambda
+    A_or = oracle.Op(n, fn=lambda x: pfo.P(F @ pfo.P(x)))
+    return A_or, pfo, q.b.to_numpy(), q.lb_new.to_numpy()
+
+
+@pytest.mark.parametrize("name,prod,orc", [
+    ("on", dict(be_implicit=1), dict(norm_update=1)),
+    ("lag", dict(be_implicit=1, lag_enabled=1), dict(norm_update=2)),
+    ("lag_short", dict(be_implicit=1, lag_enabled=1, lag_start=2, lag_step=1, lag_end=4, lag_offset=1), dict(norm_update=2, Jstart=2, Jstep=1, Jend=4, lag_offset=1)),
+    ("knoll", dict(knoll=1), dict(knoll=1)),
+    ("knoll_on", dict(knoll=1, be_implicit=1), dict(knoll=1, norm_update=1)),
+])
+def test_smalxe_variant_vs_oracle(ctx, oracle, problem, name, prod, orc):
+    f, G, q = problem
+    A_or, pfo, b, lb = _oracle_problem(oracle, f, G, q)
+    n = f.n_lambda
+    ref = oracle.smalxe(A_or, b, np.zeros(n), oracle.Box(n, lb=lb), pfo, **orc)
+    base = oracle.smalxe(A_or, b, np.zeros(n), oracle.Box(n, lb=lb), pfo)
+    assert ref["reason"] > 0
+    q.lam.set(0.0)
+    st = q.solve_smalxe(**prod)
+    q.qps.Destroy()
+    assert st.reason == ref["reason"] and st.iteration == ref["iteration"]
+    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(2, ref["inner_iter_accu"] // 50)
+    assert (st.M1_updates, st.rho_updates) == (ref["M1_updates"], ref["rho_updates"])
+    assert np.linalg.norm(q.lam.to_numpy() - ref["u"]) <= 1e-4 * np.linalg.norm(ref["u"])
+    # the variant still solves the same QP as the default update
+    assert np.linalg.norm(ref["u"] - base["u"]) <= 5e-3 * np.linalg.norm(base["u"])
+    if name.startswith("lag"):  # the lag really skips evaluations of the exact norm
+        assert ref["lag_neval"] < ref["lag_niter"]
+
+
+def test_smalxe_options_keys(ctx):
+    from permon_amd import _lib
+    import ctypes as C
+
+    L = _lib.load()
+    qo, mo, so = _lib.QpsOpts(), _lib.MpgpOpts(), _lib.SmalxeOpts()
+    check(L.pmh_qps_default_opts(C.byref(qo))), check(L.pmh_mpgp_default_opts(C.byref(mo))), check(L.pmh_smalxe_default_opts(C.byref(so)))
+    assert (so.lag_enabled, so.lag_offset, so.lag_start, so.lag_step, so.lag_end, so.lag_lower, so.lag_upper, so.knoll) == (0, 0, 10, 5, 20, 0.1, 1.1, 0)
+    left = C.create_string_buffer(256)
+    check(L.pmh_qps_set_from_options(b"-qps_smalxe_knoll -qps_smalxe_norm_update_lag 1 -qps_smalxe_norm_update_lag_start 3 -qps_smalxe_norm_update_lag_step 2 "
+                                     b"-qps_smalxe_norm_update_lag_end 9 -qps_smalxe_norm_update_lag_lower 0.2 -qps_smalxe_norm_update_lag_upper 1.5 -qps_smalxe_norm_update_lag_offset 4",
+                                     b"", C.byref(qo), C.byref(mo), C.byref(so), left, 256))
+    assert (so.lag_enabled, so.lag_offset, so.lag_start, so.lag_step, so.lag_end, so.lag_lower, so.lag_upper, so.knoll) == (1, 4, 3, 2, 9, 0.2, 1.5, 1)
+    assert left.value == b""
+
+
+def test_penalized_op_slots(ctx, problem):
+    """MatMult / MatMultTranspose / MatMultAdd / MatMultTransposeAdd of A_rho = A + rho B'B (matpenalized.c:12-78), A = P F P and a CSR A."""
+    f, G, q = problem
+    n = f.n_lambda
+    rng = np.random.default_rng(4)
+    Gd = G.toarray()
+    x, x2 = rng.standard_normal(n), rng.standard_normal(n)
+    xd, x2d, yd = ctx.vec_from(x), ctx.vec_from(x2), ctx.vec(n)
+    Ap = pa.MatCreatePenalized(q.A, q.pf, 2.5)
+    check(ctx.L.pmh_op_mult(Ap.h, xd.p, yd.p))
+    y0 = yd.to_numpy()
+    check(ctx.L.pmh_op_mult_transpose(Ap.h, xd.p, yd.p))  # P F P + rho G'G is symmetric
+    assert np.linalg.norm(yd.to_numpy() - y0) <= 1e-12 * np.linalg.norm(y0)
+    check(ctx.L.pmh_op_penalized_mult_add(Ap.h, xd.p, x2d.p, yd.p))
+    assert np.linalg.norm(yd.to_numpy() - (x2 + y0)) <= 1e-12 * np.linalg.norm(y0)
+    yd.set_numpy(x2)  # x2 == y branch (xwork)
+    check(ctx.L.pmh_op_penalized_mult_transpose_add(Ap.h, xd.p, yd.p, yd.p))
+    assert np.linalg.norm(yd.to_numpy() - (x2 + y0)) <= 1e-12 * np.linalg.norm(y0)
+    # a non-symmetric CSR A makes the transpose slots distinguishable
+    import scipy.sparse as sp
+
+    A = (sp.random(n, n, density=5.0 / n, random_state=3) + sp.identity(n)).tocsr()
+    A.sort_indices()
+    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+    Ap2 = pa.MatCreatePenalized(pa.Op.from_csr(Ad), q.pf, 0.75)
+    gtg = Gd.T @ (Gd @ x)
+    check(ctx.L.pmh_op_mult_transpose(Ap2.h, xd.p, yd.p))
+    ref = A.T @ x + 0.75 * gtg
+    assert np.linalg.norm(yd.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
+    check(ctx.L.pmh_op_penalized_mult_transpose_add(Ap2.h, xd.p, x2d.p, yd.p))
+    assert np.linalg.norm(yd.to_numpy() - (x2 + ref)) <= 1e-12 * np.linalg.norm(ref)
+    check(ctx.L.pmh_op_penalized_mult_add(Ap2.h, xd.p, x2d.p, yd.p))
+    ref = x2 + A @ x + 0.75 * gtg
+    assert np.linalg.norm(yd.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
+    # a shell without the slot refuses loudly
+    sh = pa.Op.shell(ctx, n, lambda xp, yp: None)
+    with pytest.raises(pa.PermonHipError):
+        check(ctx.L.pmh_op_mult_transpose(sh.h, xd.p, yd.p))

@@ -148,3 +148,20 @@ def test_matis_rhs_split_and_solution_assembly():
     _lib.check(L.pmh_qpt_matis_assemble_solution(l2g.size, p(l2g), p(u), x.size, p(x)))
     assert x.tolist() == [10.0, 15.0, 17.0, 14.0, 16.0]  # INSERT_VALUES: the last copy wins, nothing is averaged
     assert L.pmh_qpt_matis_split_rhs(l2g.size, p(l2g), 3, p(b), p(f)) != 0  # l2g out of range: reported
+
+
+def test_host_kplus_mg_restatement_vs_pinv():
+    """oracle/mg_host.py (the CPU baseline's K^+: block-wise V-cycle-preconditioned CG, Moore-Penrose wrapped) against numpy pinv."""
+    import permon_amd as pa
+    from oracle.mg_host import KplusMG
+
+    f = pa.CubeFeti((2, 1, 1), 4, contact=False)
+    nn = f.nel + 1
+    H = pa.box_mg_hierarchy([f.Ki] * 2, [(nn, nn, nn)] * 2, 3, min_nodes=27)
+    Kp = KplusMG(f.K, f.block_rowstart, H, R=f.R, rtol=1e-12)
+    rhs = np.random.default_rng(2).standard_normal(f.N)
+    u = Kp(rhs)
+    ref1 = np.linalg.pinv(f.Ki.toarray(), rcond=1e-10, hermitian=True)
+    ref = np.concatenate([ref1 @ rhs[:f.n_i], ref1 @ rhs[f.n_i:]])
+    assert np.linalg.norm(u - ref) <= 1e-9 * np.linalg.norm(ref)
+    assert 0 < Kp.last_its < 40
