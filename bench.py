@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
                     "(assembled once by K^+ solves, then ONE fp64 GEMV per apply; the exact path and the faster one at every N), iterative = an inner block-wise Krylov solve per apply")
+    ap.add_argument("--explicit-storage", choices=["sym", "full"], default="sym", help="feti: the dense local dual operators as their lower block-triangle (SYMV, 4 n^2 bytes per apply) or in full (GEMV, 8 n^2)")
     ap.add_argument("--explicit-rtol", type=float, default=1e-12, help="feti: tolerance of the set-up solves of the explicit operators")
     ap.add_argument("--explicit-slots", type=int, default=8, help="feti: a rank with fewer (congruent) blocks than this assembles with a replica solver of this many slots")
     ap.add_argument("--no-iterative", action="store_true", help="feti at N=1: skip the secondary passes on the inner-Krylov K^+ (fp16-PC and strict fp64)")
@@ -271,7 +272,7 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[2]: TFETI contact problem, SMALXE + MPGP on the dual QP, subdomain blocks sharded over the GPUs
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_s=45.0):
+def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_s=60.0):
     """The same algorithm as the GPU's ITERATIVE K^+ path on the host cores: the oracle's MPGP (C, reference op order) on
     A_rho = P F P + rho Q, F = B K^+ B', K^+ = block-wise V-cycle-preconditioned CG (oracle/mg_host.py: same hierarchy, Chebyshev(2)/
     Jacobi smoothing, dense coarse pseudo-inverses, fp64 throughout, Moore-Penrose wrapped), sparse products by the OpenMP CSR
@@ -319,10 +320,11 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     n = f.n_lambda
     op = O.Op(n, fn=A_rho)
     # size the sample: one probe application of A_rho, then as many MPGP iterations (<= its, >= 2) as fit the time budget
+    A_rho(b_dual)  # warm-up (page faults, thread pool)
     t0 = time.perf_counter()
     A_rho(b_dual)
     t_probe = time.perf_counter() - t0
-    its = int(max(2, min(its, budget_s / (2.1 * t_probe))))
+    its = int(max(3, min(its, budget_s / (2.1 * t_probe))))
     del stamps[:]
     ref = O.mpgp(op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), maxeig=1.0 + rho, max_it=its - 1)
     # the first application is the initial gradient (set-up of the solve); the iterations own the rest
@@ -412,7 +414,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             replica["M"], replica["K"] = M, Kb
             return M
 
-        explicit = dict(rtol=a.explicit_rtol, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
+        explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
     q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
                    regularize=a.regularize, explicit=explicit)
     if replica:  # the replica solver is set-up scaffolding: release it
@@ -503,14 +505,16 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         E.timing_enable(0)
         achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
         n_solves, asm_s = E.assemble_stats()
-        traffic, tsrc = pmc_lookup("void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        traffic, tsrc = pmc_lookup(("k_fx_symv(", "k_fx_symv") if a.explicit_storage == "sym" else "void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json") if full_size else (None, "not the configuration of the committed PMC pass")
         roofline = {
-            "bound": "hbm", "kernel": "k_fx_gemv: y_b = W_b x_b, the dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] of all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)",
+            "bound": "hbm", "kernel": ("k_fx_symv (+ k_fx_symv_fin): y_b = W_b x_b on the lower block-triangle of the symmetric dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b], every stored byte read once, "
+                                       "all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)" if a.explicit_storage == "sym" else
+                                       "k_fx_gemv: y_b = W_b x_b, the dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] of all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None, "timing_stride": 1,
             "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt * (steps / max(1, steps + warmup)) if n_k else None,
         }
-        kplus_cfg = {"path": "explicit", "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
+        kplus_cfg = {"path": "explicit", "storage": a.explicit_storage, "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
@@ -523,7 +527,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                 old = q.Kplus.mg
                 q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
                 old.destroy()
-                extra["strict_fp64"] = iterative_pass(min(steps, 54), 2, "fp64")
+                extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
                 extra["strict_fp64"]["note"] = "every operator, vector and the V-cycle in fp64 (the reference's arithmetic throughout)"
             q.Kplus.attach_explicit(E)
     else:
@@ -539,7 +543,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             old = q.Kplus.mg
             q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
             old.destroy()
-            extra["strict_fp64"] = iterative_pass(min(steps, 54), 2, "fp64")
+            extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
     comm_rank, comm_size = ctx.comm_rank()
     res = {
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,

@@ -309,7 +309,9 @@ int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, dou
  * = slot s solves for block s (solver = the operator's own K^+).  Set-up cost: one K^+ application per
  * ceil(|union of the class's Gamma| / slots of the class). */
 typedef struct pmh_fexplicit_s *pmh_fexplicit;
-int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
+#define PMH_FX_FULL 0 /* W_b as a full row-major matrix: one GEMV, 8 n^2 bytes per block and apply */
+#define PMH_FX_SYM 1  /* W_b = W_b' kept as its lower block-triangle (bands of 32 rows): a deterministic two-launch SYMV, 4 n^2 bytes */
+int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);

@@ -227,7 +227,7 @@ _PROTOS = {
     "pmh_kspfeti_default_opts": [C.POINTER(KspFetiOpts)],
     "pmh_kspfeti_set_from_options": [C.c_char_p, C.POINTER(KspFetiOpts), C.c_char_p, C.c_int],
     "pmh_kspfeti_solve": [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.POINTER(KspFetiOpts), vp, vp, C.c_int, C.POINTER(KspFetiStats)],
-    "pmh_fexplicit_create": [vp, vp, C.POINTER(vp)],
+    "pmh_fexplicit_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_assemble": [vp, vp, C.c_int, vp, vp, C.c_double, C.c_int],

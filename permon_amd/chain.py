@@ -100,12 +100,12 @@ class FetiDualQP:
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
-    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True):
+    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym"):
         """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
         right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
         has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit."""
         Kmat = self.Kreg if hasattr(self, "Kreg") else self.K
-        E = MatExplicitDual(self.B, Kmat)
+        E = MatExplicitDual(self.B, Kmat, storage=storage)
         rs = np.asarray(local["block_rowstart"])
         nb = len(rs) - 1
         cls = csr_block_classes(rs, self._Kinv_sp) if share_congruent else np.arange(nb, dtype=np.int32)

@@ -50,6 +50,12 @@ struct pmh_fexplicit_s {
   int     *d_ld, *d_gstart, *d_ngam;
   int     *d_wg_block, *d_wg_row0;
   int      nwg, rw;        // GEMV launch table: workgroup -> (block, first row); rows per wave
+  int      storage;        // PMH_FX_FULL: n x ld row-major; PMH_FX_SYM: lower block-triangle in bands of 32 rows (see k_fx_symv)
+  double  *partial, *ydir; // SYM: transposed-product partials [block][band][npad] and the direct products
+  long long *d_poff;       // SYM: offset of block b in `partial`
+  int     *d_sw_block, *d_sw_band; // SYM launch table: workgroup -> (block, band), longest bands first
+  int      nsw;
+  double   sym_bytes;      // SYM: algorithmic bytes of one apply
   double  *xh, *yh;        // compressed work vectors
   int      assembled;
   long long n_solves;
@@ -116,6 +122,84 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_gemv(const int *__restrict__ w
   }
 }
 
+// Symmetric storage (PMH_FX_SYM): W_b = W_b' is kept as its lower block-triangle in BANDS of FX_RB = 32 rows.  Band k holds the
+// rows 32k .. 32k+31 and the columns 0 .. 32(k+1)-1 (the diagonal 32 x 32 tile in full), row-major with leading dimension
+// 32(k+1); bands are concatenated, so row j starts at 512 k(k+1) + (j - 32k) 32(k+1), k = j / 32.  n is padded to a multiple of 32
+// (zero rows / columns), which removes every bounds check.  One workgroup per band; wave w owns the 128-column chunks w, w+4, ...
+// and streams ALL 32 rows of a chunk (32 16-byte non-temporal loads per lane, two batches of 16 in flight):
+//   direct     y_band[r] += a[r][c] x[c]      per-lane partial sums in column order, one shuffle tree per row at the end of the band,
+//                                             the four waves' results combined through LDS in wave order;
+//   transposed z[c]      += a[r][c] x_band[r] for the columns left of the diagonal tile: the lane owns column pair c for all 32 rows,
+//                                             so z is complete for the band without any exchange and goes to partial[band][c].
+// k_fx_symv_fin then adds, for every c, the direct product and the partials of the bands below c's band in band order.  Every
+// matrix byte is read once (half of the GEMV's bytes), the partials add 2 x n^2/64 x 8 bytes (6 %); fixed summation order.
+#define FX_RB 32
+__host__ __device__ __forceinline__ long long fx_band_off(int k) { return 512LL * k * (k + 1); }
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ sw_block, const int *__restrict__ sw_band, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ woff,
+                                                      const long long *__restrict__ poff, const double *__restrict__ Wbase, const double *__restrict__ xh, double *__restrict__ ydir, double *__restrict__ partial)
+{
+  __shared__ double red[PMH_BLOCK / 64][FX_RB];
+  const int b = __builtin_amdgcn_readfirstlane(sw_block[blockIdx.x]), k = __builtin_amdgcn_readfirstlane(sw_band[blockIdx.x]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npad = ldv[b], row0 = k * FX_RB, ldk = FX_RB * (k + 1);
+  const double *__restrict__ A = Wbase + woff[b] + fx_band_off(k);
+  const double *__restrict__ x = xh + gstart[b];
+  double *__restrict__ prow    = partial + poff[b] + (long long)k * npad;
+  double xr[FX_RB]; // x over the band's rows: uniform across the wave (scalar loads)
+#pragma unroll
+  for (int r = 0; r < FX_RB; r++) xr[r] = x[row0 + r];
+  double acc[FX_RB];
+#pragma unroll
+  for (int r = 0; r < FX_RB; r++) acc[r] = 0.0;
+  for (int c = wave * 128 + lane * 2; c < ldk; c += 4 * 128) {
+    const dbl2   xc = *(const dbl2 *)(x + c);
+    const double *ap = A + c;
+    dbl2         z  = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < FX_RB; h += 16) {
+      dbl2 a[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a[r] = __builtin_nontemporal_load((const dbl2 *)(ap + (size_t)(h + r) * ldk));
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        acc[h + r] += a[r].x * xc.x;
+        acc[h + r] += a[r].y * xc.y;
+        z.x += a[r].x * xr[h + r];
+        z.y += a[r].y * xr[h + r];
+      }
+    }
+    if (c < row0) *(dbl2 *)(prow + c) = z; // columns inside the diagonal tile are covered by the tile's own rows (direct product)
+  }
+#pragma unroll
+  for (int r = 0; r < FX_RB; r++) {
+    const double sm = pmh_wave_sum(acc[r]);
+    if (lane == 0) red[wave][r] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x < FX_RB) {
+    double sm = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < PMH_BLOCK / 64; w++) sm += red[w][threadIdx.x];
+    ydir[gstart[b] + row0 + threadIdx.x] = sm;
+  }
+}
+
+// y[c] = ydir[c] + sum over the bands k below c's band of partial[k][c], in band order
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv_fin(int nb, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ poff, const double *__restrict__ ydir,
+                                                          const double *__restrict__ partial, double *__restrict__ yh)
+{
+  const int i = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (i >= gstart[nb]) return;
+  int b = 0;
+  while (i >= gstart[b + 1]) b++;
+  const int     c = i - gstart[b], npad = ldv[b], nbk = npad / FX_RB;
+  const double *p = partial + poff[b] + c;
+  double        s = ydir[i];
+  for (int k = c / FX_RB + 1; k < nbk; k++) s += p[(long long)k * npad];
+  yh[i] = s;
+}
+
 // unit right-hand sides of one assembly batch: rhs[idx[s]] = val for the slots of the batch (idx < 0: slot idle)
 __global__ void k_fx_set_entries(int m, const int *__restrict__ idx, double val, double *__restrict__ rhs)
 {
@@ -131,9 +215,9 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract(int n, const int *__re
 
 // ---- create / destroy ---------------------------------------------------------------------------------------------------
 
-extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit *out)
+extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *out)
 {
-  PMH_ARG(B && K && out);
+  PMH_ARG(B && K && out && (storage == PMH_FX_FULL || storage == PMH_FX_SYM));
   PMH_ARG(B->n_x == K->n);
   pmh_ctx       ctx = B->ctx;
   pmh_fexplicit E   = new pmh_fexplicit_s();
@@ -141,6 +225,7 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit
   E->d_gamma_rel = nullptr, E->Wbase = nullptr, E->d_woff = nullptr, E->d_ld = E->d_gstart = E->d_ngam = E->d_wg_block = E->d_wg_row0 = nullptr;
   E->xh = E->yh = nullptr, E->assembled = 0, E->n_solves = 0, E->assemble_seconds = 0.0;
   E->ev_used = E->ev_on = E->ev_seen = 0, E->ev_stride = 1;
+  E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = nullptr, E->d_sw_block = E->d_sw_band = nullptr, E->nsw = 0, E->sym_bytes = 0.0;
   const int nb = E->nb;
   // Gamma_b: the primal dofs with at least one leaf, ascending inside every block
   std::vector<char> touched((size_t)std::max(1, B->n_x), 0);
@@ -158,8 +243,8 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit
         E->gamma.push_back(i);
       }
     E->ngam[b] = cnt;
-    E->ld[b]   = (cnt + 1) & ~1;
-    off += E->ld[b]; // even offsets: a lane's 16-byte load of x never straddles two blocks, the pad entry is an empty row of Bhat'
+    E->ld[b]   = (cnt + FX_RB - 1) / FX_RB * FX_RB;
+    off += E->ld[b]; // every block padded to a multiple of 32: aligned 16-byte loads, whole bands; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
   // Bhat: same leaves (same order => same summation order as B), primal index remapped
@@ -171,7 +256,8 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit
   long long wtot = 0;
   for (int b = 0; b < nb; b++) {
     E->woff[b] = wtot;
-    wtot += (((long long)std::max(1, E->ngam[b]) * std::max(2, E->ld[b])) + 31) & ~31LL;
+    const long long nbk = E->ld[b] / FX_RB;
+    wtot += (storage == PMH_FX_SYM) ? fx_band_off((int)nbk) : (long long)E->ld[b] * E->ld[b];
   }
   {
     const size_t bytes = sizeof(double) * (size_t)std::max(32LL, wtot);
@@ -207,6 +293,31 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, pmh_fexplicit
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_block, wb.data(), sizeof(int) * E->nwg));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_row0, wr.data(), sizeof(int) * E->nwg));
   }
+  if (storage == PMH_FX_SYM) { // partial / direct-product buffers and the band launch table (longest bands first over all blocks)
+    std::vector<long long> poff(nb);
+    long long              ptot = 0;
+    std::vector<std::pair<int, int>> bands;
+    for (int b = 0; b < nb; b++) {
+      const int nbk = E->ld[b] / FX_RB;
+      poff[b]       = ptot;
+      ptot += (long long)nbk * E->ld[b];
+      for (int k = 0; k < nbk; k++) bands.push_back({k, b});
+      E->sym_bytes += 8.0 * (double)fx_band_off(nbk) + 8.0 * (double)E->ld[b] * (nbk - 1) + 32.0 * E->ld[b]; // matrix once + partials written and read (triangle) + x, ydir, y
+    }
+    std::sort(bands.begin(), bands.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &c) { return a.first != c.first ? a.first > c.first : a.second < c.second; });
+    std::vector<int> swb(bands.size() + 1), swk(bands.size() + 1);
+    for (size_t i = 0; i < bands.size(); i++) swk[i] = bands[i].first, swb[i] = bands[i].second;
+    E->nsw = (int)bands.size();
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(1LL, ptot), (void **)&E->partial));
+    PMH_CHK(pmh_memset(ctx, E->partial, 0, sizeof(double) * (size_t)std::max(1LL, ptot)));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->ydir));
+    PMH_CHK(pmh_malloc(ctx, sizeof(long long) * nb, (void **)&E->d_poff));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_poff, poff.data(), sizeof(long long) * nb));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swb.size(), (void **)&E->d_sw_block));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swk.size(), (void **)&E->d_sw_band));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
+  }
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->xh));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->yh));
   PMH_CHK(pmh_memset(ctx, E->xh, 0, sizeof(double) * (size_t)std::max(2, E->ntot)));
@@ -223,6 +334,11 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
   pmh_gluing_destroy(E->Bhat);
   pmh_free(ctx, E->d_gamma_rel), pmh_free(ctx, E->d_woff), pmh_free(ctx, E->d_ld), pmh_free(ctx, E->d_gstart), pmh_free(ctx, E->d_ngam);
   pmh_free(ctx, E->d_wg_block), pmh_free(ctx, E->d_wg_row0), pmh_free(ctx, E->xh), pmh_free(ctx, E->yh);
+  if (E->partial) pmh_free(ctx, E->partial);
+  if (E->ydir) pmh_free(ctx, E->ydir);
+  if (E->d_poff) pmh_free(ctx, E->d_poff);
+  if (E->d_sw_block) pmh_free(ctx, E->d_sw_block);
+  if (E->d_sw_band) pmh_free(ctx, E->d_sw_band);
   for (hipEvent_t e : E->ev) hipEventDestroy(e);
   delete E;
   return PMH_SUCCESS;
@@ -236,11 +352,11 @@ extern "C" int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma, 
   double    alg = 0.0;
   for (int b = 0; b < E->nb; b++) {
     if (n_gamma) n_gamma[b] = E->ngam[b];
-    tot += (long long)sizeof(double) * E->ngam[b] * E->ld[b];
-    alg += 8.0 * (double)E->ngam[b] * E->ngam[b] + 16.0 * E->ngam[b]; // the matrix once + x read + y written
+    tot += (long long)sizeof(double) * (E->storage == PMH_FX_SYM ? fx_band_off(E->ld[b] / FX_RB) : (long long)E->ld[b] * E->ld[b]);
+    alg += 8.0 * (double)E->ngam[b] * E->ngam[b] + 16.0 * E->ngam[b]; // FULL: the matrix once + x read + y written
   }
   if (dense_bytes) *dense_bytes = tot;
-  if (gemv_bytes) *gemv_bytes = alg;
+  if (gemv_bytes) *gemv_bytes = (E->storage == PMH_FX_SYM) ? E->sym_bytes : alg;
   return PMH_SUCCESS;
 }
 
@@ -361,9 +477,12 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
       for (int b : cblocks[sc[s]]) {
         const int p = pos[b][col[s]];
         if (p < 0) continue;
-        const int n = E->ngam[b];
+        // row p of W_b: FULL all n_Gamma columns; SYM the columns of its band (0 .. 32(k+1)-1, capped at n_Gamma: the rest is padding)
+        const int       kb   = p / FX_RB;
+        const int       n    = (E->storage == PMH_FX_SYM) ? std::min(E->ngam[b], FX_RB * (kb + 1)) : E->ngam[b];
+        const long long roff = (E->storage == PMH_FX_SYM) ? fx_band_off(kb) + (long long)(p - FX_RB * kb) * FX_RB * (kb + 1) : (long long)p * E->ld[b];
         hipLaunchKernelGGL(k_fx_extract, dim3(std::max(1, std::min(64, (n + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]),
-                           (const double *)(sol + srs[s]), E->W[b] + (size_t)p * E->ld[b]);
+                           (const double *)(sol + srs[s]), E->W[b] + roff);
       }
     }
     if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);
@@ -391,7 +510,25 @@ extern "C" int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *out_host,
 {
   PMH_ARG(E && b >= 0 && b < E->nb);
   const int n = E->ngam[b];
-  if (out_host && n) PMH_HIP(hipMemcpy2D(out_host, sizeof(double) * n, E->W[b], sizeof(double) * E->ld[b], sizeof(double) * n, n, hipMemcpyDeviceToHost));
+  if (out_host && n) {
+    if (E->storage == PMH_FX_FULL) {
+      PMH_HIP(hipMemcpy2D(out_host, sizeof(double) * n, E->W[b], sizeof(double) * E->ld[b], sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    } else { // unpack the lower block-triangle band by band, mirror it (the diagonal tile is stored in full)
+      std::vector<double> band;
+      for (int k = 0; k * FX_RB < n; k++) {
+        const int ldk = FX_RB * (k + 1), rows = std::min(FX_RB, n - k * FX_RB);
+        band.resize((size_t)FX_RB * ldk);
+        PMH_HIP(hipMemcpy(band.data(), E->W[b] + fx_band_off(k), sizeof(double) * (size_t)rows * ldk, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; r++) {
+          const int j = k * FX_RB + r;
+          for (int c = 0; c < std::min(ldk, n); c++) {
+            out_host[(size_t)j * n + c] = band[(size_t)r * ldk + c];
+            if (c < k * FX_RB) out_host[(size_t)c * n + j] = band[(size_t)r * ldk + c];
+          }
+        }
+      }
+    }
+  }
   if (gamma_host)
     for (int i = 0; i < n; i++) gamma_host[i] = E->gamma[E->goff[b] + i];
   return PMH_SUCCESS;
@@ -402,6 +539,24 @@ extern "C" int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *out_host,
 static int fx_gemv(pmh_fexplicit E)
 {
   if (!E->nwg) return PMH_SUCCESS;
+  if (E->storage == PMH_FX_SYM) {
+    hipStream_t st    = E->ctx->stream;
+    bool        timed = false;
+    if (E->ev_on && (E->ev_seen++ % E->ev_stride) == 0 && (size_t)(2 * E->ev_used + 2) <= E->ev.size()) {
+      timed = true;
+      PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used], st));
+    }
+    hipLaunchKernelGGL(k_fx_symv, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff,
+                       (const long long *)E->d_poff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial);
+    hipLaunchKernelGGL(k_fx_symv_fin, dim3((E->ntot + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, E->nb, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_poff,
+                       (const double *)E->ydir, (const double *)E->partial, E->yh);
+    if (timed) {
+      PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used + 1], st));
+      E->ev_used++;
+    }
+    PMH_HIP(hipGetLastError());
+    return PMH_SUCCESS;
+  }
   hipStream_t st    = E->ctx->stream;
   bool        timed = false;
   if (E->ev_on && (E->ev_seen++ % E->ev_stride) == 0 && (size_t)(2 * E->ev_used + 2) <= E->ev.size()) {

@@ -216,10 +216,11 @@ class MatExplicitDual:
     """Explicit local dual operators (pmh_fexplicit): W_b = (K_b^+)[Gamma_b, Gamma_b] dense per block, F = Bhat W Bhat'.
     The exact-K^+ path (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:670-730, restricted to the dofs B touches)."""
 
-    def __init__(self, B, K):
-        self.ctx, self.B, self.K = B.ctx, B, K
+    def __init__(self, B, K, storage="sym"):
+        """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV."""
+        self.ctx, self.B, self.K, self.storage = B.ctx, B, K, storage
         h = C.c_void_p()
-        check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, C.byref(h)))
+        check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, {"full": 0, "sym": 1}[storage], C.byref(h)))
         self.h = h
         nb = C.c_int()
         check(self.ctx.L.pmh_fexplicit_sizes(h, C.byref(nb), None, None, None))

@@ -21,7 +21,7 @@ nn = nel + 1
 hier = pa.box_mg_hierarchy([f.Ki] * 8, [(nn, nn, nn)] * 8, 3, min_nodes=min(400, nn ** 3 // 8))
 print("generate + hierarchy %.1f s" % (time.time() - t0), flush=True)
 t0 = time.time()
-q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-9, mg_hierarchy=hier, mg_precision="fp16", bsr3=True, explicit=dict(rtol=float(os.environ.get("FX_RTOL", "1e-12"))))
+q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-9, mg_hierarchy=hier, mg_precision="fp16", bsr3=True, explicit=dict(rtol=float(os.environ.get("FX_RTOL", "1e-12")), storage=os.environ.get("FX_STORAGE", "sym")))
 ctx.sync()
 ns, secs = q.E.assemble_stats()
 out = {"nel": nel, "n_gamma": q.E.n_gamma.tolist(), "dense_GB": q.E.dense_bytes / 1e9, "assemble_solves": ns, "assemble_seconds": secs, "setup_seconds": time.time() - t0}

@@ -35,12 +35,12 @@ def test_block_classes_host():
     assert cls.tolist() == [0, 0, 1, 0]
 
 
-@pytest.mark.parametrize("share", [True, False])
-def test_explicit_blocks_vs_pinv(ctx, share):
+@pytest.mark.parametrize("share,storage", [(True, "sym"), (False, "sym"), (True, "full")])
+def test_explicit_blocks_vs_pinv(ctx, share, storage):
     """nel = 2: every W_b equals the dense pseudo-inverse of K_b on Gamma_b; F through the explicit path equals B pinv(K) B'."""
     f = pa.CubeFeti((2, 2, 1), 2, contact=True)
     G, e = f.coarse()
-    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, share_congruent=share))
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, share_congruent=share, storage=storage))
     Fref, Kp = _dense_F(f)
     n_solves, secs = q.E.assemble_stats()
     if share:  # the four congruent cubes share the union of their Gamma sets
@@ -64,13 +64,15 @@ def test_explicit_blocks_vs_pinv(ctx, share):
     assert np.array_equal(y.to_numpy(), y2.to_numpy())
 
 
-def test_explicit_vs_iterative_F(ctx):
-    """2x2x2 cubes, nel = 6: F_dense lambda vs the iterative B K^+ B' lambda (rtol 1e-13) <= 1e-10; GEMV kernel vs numpy."""
+@pytest.mark.parametrize("storage", ["sym", "full"])
+def test_explicit_vs_iterative_F(ctx, storage):
+    """2x2x2 cubes, nel = 6: F_dense lambda vs the iterative B K^+ B' lambda (rtol 1e-13) <= 1e-10; the dense kernel (SYMV on the
+    lower block-triangle / GEMV on the full matrix) vs numpy, and bitwise reproducible."""
     f = pa.CubeFeti((2, 2, 2), 6, contact=True)
     G, e = f.coarse()
     loc = f.subset(range(f.nsub))
     q_it = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
-    q_ex = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13))
+    q_ex = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage=storage))
     rng = np.random.default_rng(9)
     for _ in range(3):
         lam = rng.standard_normal(f.n_lambda)
@@ -86,8 +88,10 @@ def test_explicit_vs_iterative_F(ctx):
     xh = rng.standard_normal(ntot)
     for b in range(f.nsub):  # pad entries (odd n_Gamma) must be zero in x
         xh[gs[b] + q_ex.E.n_gamma[b]:gs[b + 1]] = 0.0
-    yh = ctx.vec(ntot)
+    yh, yh2 = ctx.vec(ntot), ctx.vec(ntot)
     q_ex.E.dense_mult(ctx.vec_from(xh), yh)
+    q_ex.E.dense_mult(ctx.vec_from(xh), yh2)
+    assert np.array_equal(yh.to_numpy(), yh2.to_numpy())  # fixed summation order
     yh = yh.to_numpy()
     for b in range(f.nsub):
         W, _ = q_ex.E.block(b)
