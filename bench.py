@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
                     "(assembled once by K^+ solves, then ONE fp64 GEMV per apply; the exact path and the faster one at every N), iterative = an inner block-wise Krylov solve per apply")
     ap.add_argument("--explicit-storage", choices=["sym", "full"], default="sym", help="feti: the dense local dual operators as their lower block-triangle (SYMV, 4 n^2 bytes per apply) or in full (GEMV, 8 n^2)")
+    ap.add_argument("--no-stripe", action="store_true", help="feti at N > 1: every rank keeps the explicit operators of its OWN blocks instead of an even share of 128-row stripes of all blocks")
     ap.add_argument("--explicit-rtol", type=float, default=1e-12, help="feti: tolerance of the set-up solves of the explicit operators")
     ap.add_argument("--explicit-slots", type=int, default=8, help="feti: a rank with fewer (congruent) blocks than this assembles with a replica solver of this many slots")
     ap.add_argument("--no-iterative", action="store_true", help="feti at N=1: skip the secondary passes on the inner-Krylov K^+ (fp16-PC and strict fp64)")
@@ -415,6 +416,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             return M
 
         explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
+        nshare = world if world > 1 else a.sim_world
+        if nshare > 1 and a.explicit_storage == "sym" and not a.regularize and not a.no_stripe:
+            # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
+            explicit["stripe"] = (rank, nshare, dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign))
     q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
                    regularize=a.regularize, explicit=explicit)
     if replica:  # the replica solver is set-up scaffolding: release it
@@ -551,7 +556,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                     "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP (the real solver loop, restarted when it converges), F = B K^+ B' through %s%s"
                     % ("configs[2]" if (sub == (2, 2, 2) and orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like", sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
                        kplus_text, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
-        "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
+        "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s) (K_i, K^+, the set-up solves); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
+                       + ("; the dense local dual operators are applied in 128-row stripes dealt evenly over the GPUs (the cubes are congruent: every rank assembles its stripes of every W_b with its own K^+)" if (explicit and "stripe" in explicit) else "")
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None,
         "steps_by_type": cnt, "precision_note": precision_note, "kplus": kplus_cfg,

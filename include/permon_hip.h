@@ -314,14 +314,19 @@ typedef struct pmh_fexplicit_s *pmh_fexplicit;
 int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);
+/* several GPUs, congruent blocks: E built over ALL blocks (B = the global gluing, K = the global block structure); this rank
+   assembles and applies the 128-row stripes idx = rank (mod size) of the size-ordered list -- an even share of the dense bytes; the
+   all-reduce that ends B u completes F lambda.  PMH_FX_SYM only; before the assembly. */
+int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size);
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
+int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte); /* tuning helper: byte pattern instead of the assembly (not F afterwards) */
 int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds);
 int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *W_host /* n_Gamma_b^2 row-major or NULL */, int *gamma_host /* or NULL */);
 int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double *y);              /* y = F lambda (MatMult of the product) */
 int pmh_fexplicit_compressed_size(pmh_fexplicit E, int *ntot, int *gstart /* [nblocks+1] or NULL */);
 int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xhat, double *yhat);        /* the dense kernel alone, compressed vectors */
 int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, int stride);         /* HIP-event pairs around the GEMV launches */
-int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms);
+int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms, double *first_kernel_ms /* SYM: k_fx_symv alone; or NULL */);
 /* F = B K^+ B' built on this MATINV (pmh_op_create_feti_dual, the FETI chain) applies through E from now on (E built from the
    same B; NULL detaches).  K^+ f for a general f (d = B K^+ f - c, primal recovery) stays on the inner KSP. */
 int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E);

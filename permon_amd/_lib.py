@@ -230,14 +230,16 @@ _PROTOS = {
     "pmh_fexplicit_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
+    "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],
     "pmh_fexplicit_assemble": [vp, vp, C.c_int, vp, vp, C.c_double, C.c_int],
+    "pmh_fexplicit_fill_pattern": [vp, C.c_int],
     "pmh_fexplicit_assemble_stats": [vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_get_block": [vp, C.c_int, vp, vp],
     "pmh_fexplicit_mult": [vp, vp, vp],
     "pmh_fexplicit_compressed_size": [vp, c_int_p, vp],
     "pmh_fexplicit_dense_mult": [vp, vp, vp],
     "pmh_fexplicit_timing_enable": [vp, C.c_int, C.c_int],
-    "pmh_fexplicit_timing_get": [vp, c_int_p, c_double_p],
+    "pmh_fexplicit_timing_get": [vp, c_int_p, c_double_p, c_double_p],
     "pmh_matinv_attach_explicit": [vp, vp],
     "pmh_matinv_set_tolerances": [vp, C.c_double, C.c_double, C.c_int],
     "pmh_matinv_get_tolerances": [vp, c_double_p, c_double_p, c_int_p],

@@ -100,19 +100,37 @@ class FetiDualQP:
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
-    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym"):
+    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None):
         """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
         right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
-        has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit."""
-        Kmat = self.Kreg if hasattr(self, "Kreg") else self.K
-        E = MatExplicitDual(self.B, Kmat, storage=storage)
+        has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit.
+        stripe = (rank, size, glob): several GPUs and ALL blocks of the decomposition congruent -- the operator spans every block
+        (glob: dict n_x, block_rowstart, leaves_row / _root / _sign of the whole decomposition) and this rank assembles and applies
+        an even share of 128-row stripes of every W_b instead of its own blocks (pmh_fexplicit_set_stripe)."""
+        import scipy.sparse as sp
+
         rs = np.asarray(local["block_rowstart"])
         nb = len(rs) - 1
         cls = csr_block_classes(rs, self._Kinv_sp) if share_congruent else np.arange(nb, dtype=np.int32)
-        if solver_factory is not None and nb < min_slots and int(cls.max()) == 0:
+        one_class = int(cls.max()) == 0
+        if stripe is not None:
+            rank, size, glob = stripe
+            if not one_class:
+                raise ValueError("striped explicit operators need congruent blocks")
+            self._Bglob = MatGluing(self.ctx, glob["n_x"], self.n_lambda, glob["leaves_row"], glob["leaves_root"], glob["leaves_sign"])
+            self._Kglob = MatBlockDiag.from_scipy(self.ctx, glob["block_rowstart"], sp.identity(glob["n_x"], format="csr"))  # block structure only
+            E = MatExplicitDual(self._Bglob, self._Kglob, storage="sym")
+            E.set_stripe(rank, size)
+            ngl = len(glob["block_rowstart"]) - 1
+        else:
+            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage)
+            ngl = nb
+        if solver_factory is not None and nb < min_slots and one_class:
             solver = solver_factory(int(min_slots))
-            E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=cls, rtol=rtol, max_it=max_it)
+            E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
             self._replica_solver = solver
+        elif stripe is not None:
+            E.assemble(self.Kplus, slot_class=np.zeros(nb, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
         else:
             E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it)
         self.Kplus.attach_explicit(E)

@@ -51,16 +51,19 @@ struct pmh_fexplicit_s {
   int     *d_wg_block, *d_wg_row0;
   int      nwg, rw;        // GEMV launch table: workgroup -> (block, first row); rows per wave
   int      storage;        // PMH_FX_FULL: n x ld row-major; PMH_FX_SYM: lower block-triangle in bands of 32 rows (see k_fx_symv)
-  double  *partial, *ydir; // SYM: transposed-product partials [block][band][npad] and the direct products
-  long long *d_poff;       // SYM: offset of block b in `partial`
-  int     *d_sw_block, *d_sw_band; // SYM launch table: workgroup -> (block, band), longest bands first
-  int      nsw;
+  double  *partial, *ydir; // SYM: transposed-product partials [block][super band][npad] and the direct products [block][segment][npad]
+  long long *d_poff, *d_doff; // SYM: offset of block b in `partial` / in `ydir`
+  int     *d_sw_block, *d_sw_band, *d_sw_seg; // SYM launch table: workgroup -> (block, super band, column segment)
+  int     *d_fw_block, *d_fw_col0; // SYM second launch: workgroup -> (block, first of its 128 columns)
+  int      nsw, nfw;
   double   sym_bytes;      // SYM: algorithmic bytes of one apply
   double  *xh, *yh;        // compressed work vectors
   int      assembled;
+  int      stripe_rank, stripe_size; // > 0: this rank applies / assembles only the super bands idx % size == rank (see pmh_fexplicit_set_stripe)
+  std::vector<std::vector<char>> owned; // [block][super band]
   long long n_solves;
   double   assemble_seconds;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev, ev_mid; // pairs around the dense launch(es); SYM: a third event between k_fx_symv and k_fx_symv_fin
   int      ev_used, ev_on, ev_seen, ev_stride;
 };
 
@@ -123,10 +126,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_gemv(const int *__restrict__ w
 }
 
 // Symmetric storage (PMH_FX_SYM): W_b = W_b' is kept as its lower block-triangle in BANDS of FX_RB = 32 rows.  Band k holds the
-// rows 32k .. 32k+31 and the columns 0 .. 32(k+1)-1 (the diagonal 32 x 32 tile in full), row-major with leading dimension
-// 32(k+1); bands are concatenated, so row j starts at 512 k(k+1) + (j - 32k) 32(k+1), k = j / 32.  n is padded to a multiple of 32
-// (zero rows / columns), which removes every bounds check.  One workgroup per band; wave w owns the 128-column chunks w, w+4, ...
-// and streams ALL 32 rows of a chunk (32 16-byte non-temporal loads per lane, two batches of 16 in flight):
+// rows 32k .. 32k+31 and the columns 0 .. 32(k+1)-1 (the diagonal 32 x 32 tile in full), cut into TILES of 32 rows x 128 columns
+// that are stored contiguously (32 KB each, tile-major, row-major inside a tile; the last tile of a band is zero padded): one trip
+// of a wave reads one contiguous 32 KB tile, whatever the band's length -- no large strides, no channel aliasing between the rows.
+// Band k has ceil((k+1)/4) tiles and starts at tile T(k) = (q+1)(2q+r), k = 4q+r.  n is padded to a multiple of 128 (zero rows /
+// columns), which removes every bounds check.  One workgroup per band; wave w owns the tiles w, w+4, ... and streams ALL 32 rows
+// of a tile (32 16-byte non-temporal loads per lane in flight):
 //   direct     y_band[r] += a[r][c] x[c]      per-lane partial sums in column order, one shuffle tree per row at the end of the band,
 //                                             the four waves' results combined through LDS in wave order;
 //   transposed z[c]      += a[r][c] x_band[r] for the columns left of the diagonal tile: the lane owns column pair c for all 32 rows,
@@ -134,33 +139,49 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_gemv(const int *__restrict__ w
 // k_fx_symv_fin then adds, for every c, the direct product and the partials of the bands below c's band in band order.  Every
 // matrix byte is read once (half of the GEMV's bytes), the partials add 2 x n^2/64 x 8 bytes (6 %); fixed summation order.
 #define FX_RB 32
-__host__ __device__ __forceinline__ long long fx_band_off(int k) { return 512LL * k * (k + 1); }
+#define FX_TC 128                 // columns per tile
+#define FX_TILE (FX_RB * FX_TC)   // doubles per tile
+__host__ __device__ __forceinline__ long long fx_band_tiles(int k) { return (long long)(k / 4 + 1) * (2 * (k / 4) + (k & 3)); } // tiles before band k
+__host__ __device__ __forceinline__ long long fx_band_off(int k) { return (long long)FX_TILE * fx_band_tiles(k); }
+// doubles of the SYM storage of a block padded to npad (multiple of 128) rows
+__host__ __device__ __forceinline__ long long fx_sym_size(int npad) { return fx_band_off(npad / FX_RB); }
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ sw_block, const int *__restrict__ sw_band, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ woff,
-                                                      const long long *__restrict__ poff, const double *__restrict__ Wbase, const double *__restrict__ xh, double *__restrict__ ydir, double *__restrict__ partial)
+// Work decomposition: a workgroup owns (super band s = 4 bands = 128 rows) x (segment j = FX_SEG tile columns = 2048 columns);
+// its wave w streams band 4s+w through the segment, one 32 KB tile per trip, the four waves in step.  Per tile column the four
+// transposed partial sums z_w (the lane owns its column pair for the 32 rows of the band) are added in wave order through LDS and
+// written ONCE per 128 rows (partial[s][c]: n^2/256 entries, 1.6 % of the matrix bytes -- written per band they cost 22 % of the
+// kernel time, measured); the direct sums stay in registers across the segment and end in ydseg[j][row].  Every workgroup moves
+// the same 2 MB (except the last segment of a super band), so the grid balances at any block count.
+#define FX_SEG 16
+template <int VAR>
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ sw_block, const int *__restrict__ sw_sband, const int *__restrict__ sw_seg, const int *__restrict__ gstart, const int *__restrict__ ldv,
+                                                      const long long *__restrict__ woff, const long long *__restrict__ poff, const long long *__restrict__ doff, const double *__restrict__ Wbase,
+                                                      const double *__restrict__ xh, double *__restrict__ ydseg, double *__restrict__ partial)
 {
-  __shared__ double red[PMH_BLOCK / 64][FX_RB];
-  const int b = __builtin_amdgcn_readfirstlane(sw_block[blockIdx.x]), k = __builtin_amdgcn_readfirstlane(sw_band[blockIdx.x]);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int npad = ldv[b], row0 = k * FX_RB, ldk = FX_RB * (k + 1);
+  __shared__ dbl2 zred[2][PMH_BLOCK / 64][64];
+  const int b = __builtin_amdgcn_readfirstlane(sw_block[blockIdx.x]), sb = __builtin_amdgcn_readfirstlane(sw_sband[blockIdx.x]), seg = __builtin_amdgcn_readfirstlane(sw_seg[blockIdx.x]);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int npad = ldv[b], k = 4 * sb + wave, row0 = k * FX_RB;
+  const int t0 = seg * FX_SEG, t1 = min(t0 + FX_SEG, sb + 1); // every band of the super band has sb + 1 tiles
   const double *__restrict__ A = Wbase + woff[b] + fx_band_off(k);
   const double *__restrict__ x = xh + gstart[b];
-  double *__restrict__ prow    = partial + poff[b] + (long long)k * npad;
+  double *__restrict__ prow    = partial + poff[b] + (long long)sb * npad;
   double xr[FX_RB]; // x over the band's rows: uniform across the wave (scalar loads)
 #pragma unroll
   for (int r = 0; r < FX_RB; r++) xr[r] = x[row0 + r];
   double acc[FX_RB];
 #pragma unroll
   for (int r = 0; r < FX_RB; r++) acc[r] = 0.0;
-  for (int c = wave * 128 + lane * 2; c < ldk; c += 4 * 128) {
-    const dbl2   xc = *(const dbl2 *)(x + c);
-    const double *ap = A + c;
-    dbl2         z  = {0.0, 0.0};
+  for (int t = t0; t < t1; t++) {
+    const int     c  = t * FX_TC + lane * 2;
+    const dbl2    xc = *(const dbl2 *)(x + c);
+    const double *ap = A + (long long)t * FX_TILE + lane * 2;
+    dbl2          z  = {0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < FX_RB; h += 16) {
       dbl2 a[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) a[r] = __builtin_nontemporal_load((const dbl2 *)(ap + (size_t)(h + r) * ldk));
+      for (int r = 0; r < 16; r++) a[r] = (VAR == 1) ? *(const dbl2 *)(ap + (h + r) * FX_TC) : __builtin_nontemporal_load((const dbl2 *)(ap + (h + r) * FX_TC));
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         acc[h + r] += a[r].x * xc.x;
@@ -169,35 +190,62 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ s
         z.y += a[r].y * xr[h + r];
       }
     }
-    if (c < row0) *(dbl2 *)(prow + c) = z; // columns inside the diagonal tile are covered by the tile's own rows (direct product)
+    if (c >= row0) z = dbl2{0.0, 0.0}; // columns inside the band's diagonal tile are covered by the tile's own rows (direct product)
+    const int q = t & 1;               // double-buffered: one barrier per tile column
+    zred[q][wave][lane] = z;
+    __syncthreads();
+    if (wave == (t & 3)) {
+      dbl2 zs = zred[q][0][lane];
+      zs += zred[q][1][lane];
+      zs += zred[q][2][lane];
+      zs += zred[q][3][lane];
+      *(dbl2 *)(prow + c) = zs;
+    }
   }
+  double *__restrict__ yd = ydseg + doff[b] + (long long)seg * npad + row0;
 #pragma unroll
   for (int r = 0; r < FX_RB; r++) {
     const double sm = pmh_wave_sum(acc[r]);
-    if (lane == 0) red[wave][r] = sm;
-  }
-  __syncthreads();
-  if (threadIdx.x < FX_RB) {
-    double sm = red[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < PMH_BLOCK / 64; w++) sm += red[w][threadIdx.x];
-    ydir[gstart[b] + row0 + threadIdx.x] = sm;
+    if (lane == 0) yd[r] = sm;
   }
 }
 
-// y[c] = ydir[c] + sum over the bands k below c's band of partial[k][c], in band order
-__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv_fin(int nb, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ poff, const double *__restrict__ ydir,
-                                                          const double *__restrict__ partial, double *__restrict__ yh)
+// y[c] = sum over the segments j of ydseg[j][c] (segment order) + sum over the super bands s >= c / 128 of partial[s][c] (wave w
+// takes s = w (mod 4) in ascending order, eight 16-byte loads in flight per lane; the four waves' sums are added in wave order).
+// One workgroup per 128 columns of a block.
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv_fin(const int *__restrict__ fw_block, const int *__restrict__ fw_col0, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ poff,
+                                                          const long long *__restrict__ doff, const double *__restrict__ ydseg, const double *__restrict__ partial, double *__restrict__ yh)
 {
-  const int i = blockIdx.x * PMH_BLOCK + threadIdx.x;
-  if (i >= gstart[nb]) return;
-  int b = 0;
-  while (i >= gstart[b + 1]) b++;
-  const int     c = i - gstart[b], npad = ldv[b], nbk = npad / FX_RB;
-  const double *p = partial + poff[b] + c;
-  double        s = ydir[i];
-  for (int k = c / FX_RB + 1; k < nbk; k++) s += p[(long long)k * npad];
-  yh[i] = s;
+  __shared__ dbl2 red[PMH_BLOCK / 64][64];
+  const int b = fw_block[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npad = ldv[b], nsb = npad / FX_TC;
+  const int c    = fw_col0[blockIdx.x] + lane * 2; // npad is a multiple of 128: always inside the block
+  const int sc   = c / FX_TC;                      // the column's own super band: its diagonal tile column holds the in-super-band transposed terms
+  dbl2      s    = {0.0, 0.0};
+  {
+    const double *p = partial + poff[b] + c;
+    int           k = sc;
+    k += (wave - (k & 3)) & 3; // first super band >= sc with k = wave (mod 4)
+    for (; k < nsb; k += 32) {
+      dbl2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = (k + 4 * u < nsb) ? *(const dbl2 *)(p + (long long)(k + 4 * u) * npad) : dbl2{0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    dbl2          t  = red[0][lane];
+    t += red[1][lane];
+    t += red[2][lane];
+    t += red[3][lane];
+    const int     nseg = sc / FX_SEG + 1; // segments of the row's super band (sc + 1 tile columns)
+    const double *yd   = ydseg + doff[b] + c;
+    for (int j = 0; j < nseg; j++) t += *(const dbl2 *)(yd + (long long)j * npad);
+    *(dbl2 *)(yh + gstart[b] + c) = t;
+  }
 }
 
 // unit right-hand sides of one assembly batch: rhs[idx[s]] = val for the slots of the batch (idx < 0: slot idle)
@@ -213,6 +261,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract(int n, const int *__re
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) wrow[i] = u[gamma_rel[i]];
 }
 
+// SYM: the part of row j = 32 k + r that lies in its band, into the band's tiles: element (r, i) at (i / 128) tiles + r * 128 + i % 128
+__global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract_tiled(int n, const int *__restrict__ gamma_rel, const double *__restrict__ u, double *__restrict__ band, int r)
+{
+  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) band[(long long)(i / FX_TC) * FX_TILE + r * FX_TC + (i % FX_TC)] = u[gamma_rel[i]];
+}
+
 // ---- create / destroy ---------------------------------------------------------------------------------------------------
 
 extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *out)
@@ -224,8 +278,9 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
   E->ctx = ctx, E->B = B, E->K = K, E->Bhat = nullptr, E->nb = K->nblocks;
   E->d_gamma_rel = nullptr, E->Wbase = nullptr, E->d_woff = nullptr, E->d_ld = E->d_gstart = E->d_ngam = E->d_wg_block = E->d_wg_row0 = nullptr;
   E->xh = E->yh = nullptr, E->assembled = 0, E->n_solves = 0, E->assemble_seconds = 0.0;
+  E->stripe_rank = 0, E->stripe_size = 0;
   E->ev_used = E->ev_on = E->ev_seen = 0, E->ev_stride = 1;
-  E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = nullptr, E->d_sw_block = E->d_sw_band = nullptr, E->nsw = 0, E->sym_bytes = 0.0;
+  E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = E->d_doff = nullptr, E->d_sw_block = E->d_sw_band = E->d_sw_seg = E->d_fw_block = E->d_fw_col0 = nullptr, E->nsw = E->nfw = 0, E->sym_bytes = 0.0;
   const int nb = E->nb;
   // Gamma_b: the primal dofs with at least one leaf, ascending inside every block
   std::vector<char> touched((size_t)std::max(1, B->n_x), 0);
@@ -243,8 +298,8 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
         E->gamma.push_back(i);
       }
     E->ngam[b] = cnt;
-    E->ld[b]   = (cnt + FX_RB - 1) / FX_RB * FX_RB;
-    off += E->ld[b]; // every block padded to a multiple of 32: aligned 16-byte loads, whole bands; the pad entries are empty rows of Bhat'
+    E->ld[b]   = (cnt + FX_TC - 1) / FX_TC * FX_TC;
+    off += E->ld[b]; // every block padded to a multiple of 128: aligned 16-byte loads, whole bands and tiles; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
   // Bhat: same leaves (same order => same summation order as B), primal index remapped
@@ -256,8 +311,7 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
   long long wtot = 0;
   for (int b = 0; b < nb; b++) {
     E->woff[b] = wtot;
-    const long long nbk = E->ld[b] / FX_RB;
-    wtot += (storage == PMH_FX_SYM) ? fx_band_off((int)nbk) : (long long)E->ld[b] * E->ld[b];
+    wtot += (storage == PMH_FX_SYM) ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b];
   }
   {
     const size_t bytes = sizeof(double) * (size_t)std::max(32LL, wtot);
@@ -293,30 +347,51 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_block, wb.data(), sizeof(int) * E->nwg));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_row0, wr.data(), sizeof(int) * E->nwg));
   }
-  if (storage == PMH_FX_SYM) { // partial / direct-product buffers and the band launch table (longest bands first over all blocks)
-    std::vector<long long> poff(nb);
-    long long              ptot = 0;
-    std::vector<std::pair<int, int>> bands;
+  if (storage == PMH_FX_SYM) { // partial / direct-product buffers and the launch table (super band, segment), largest super bands first
+    std::vector<long long> poff(nb), doff(nb);
+    long long              ptot = 0, dtot = 0;
+    std::vector<int>       swb, swk, swj;
+    int                    maxsb = 0;
+    for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
     for (int b = 0; b < nb; b++) {
-      const int nbk = E->ld[b] / FX_RB;
-      poff[b]       = ptot;
-      ptot += (long long)nbk * E->ld[b];
-      for (int k = 0; k < nbk; k++) bands.push_back({k, b});
-      E->sym_bytes += 8.0 * (double)fx_band_off(nbk) + 8.0 * (double)E->ld[b] * (nbk - 1) + 32.0 * E->ld[b]; // matrix once + partials written and read (triangle) + x, ydir, y
+      const int nsb = E->ld[b] / FX_TC, nsegmax = (nsb + FX_SEG - 1) / FX_SEG;
+      poff[b] = ptot, doff[b] = dtot;
+      ptot += (long long)nsb * E->ld[b];
+      dtot += (long long)nsegmax * E->ld[b];
+      // stored matrix once + partials written and read (triangle of 128-column rows) + direct sums written and read + x, y
+      E->sym_bytes += 8.0 * (double)fx_sym_size(E->ld[b]) + 2.0 * 8.0 * FX_TC * 0.5 * (double)nsb * (nsb + 1) + 2.0 * 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b];
     }
-    std::sort(bands.begin(), bands.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &c) { return a.first != c.first ? a.first > c.first : a.second < c.second; });
-    std::vector<int> swb(bands.size() + 1), swk(bands.size() + 1);
-    for (size_t i = 0; i < bands.size(); i++) swk[i] = bands[i].first, swb[i] = bands[i].second;
-    E->nsw = (int)bands.size();
+    E->owned.assign(nb, std::vector<char>());
+    for (int b = 0; b < nb; b++) E->owned[b].assign(E->ld[b] / FX_TC, 1);
+    for (int sb = maxsb - 1; sb >= 0; sb--)
+      for (int b = 0; b < nb; b++)
+        if (sb < E->ld[b] / FX_TC)
+          for (int j = 0; j * FX_SEG < sb + 1; j++) swb.push_back(b), swk.push_back(sb), swj.push_back(j);
+    E->nsw = (int)swb.size();
+    swb.push_back(0), swk.push_back(0), swj.push_back(0);
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(1LL, ptot), (void **)&E->partial));
     PMH_CHK(pmh_memset(ctx, E->partial, 0, sizeof(double) * (size_t)std::max(1LL, ptot)));
-    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->ydir));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(1LL, dtot), (void **)&E->ydir));
+    PMH_CHK(pmh_memset(ctx, E->ydir, 0, sizeof(double) * (size_t)std::max(1LL, dtot)));
     PMH_CHK(pmh_malloc(ctx, sizeof(long long) * nb, (void **)&E->d_poff));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_poff, poff.data(), sizeof(long long) * nb));
+    PMH_CHK(pmh_malloc(ctx, sizeof(long long) * nb, (void **)&E->d_doff));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_doff, doff.data(), sizeof(long long) * nb));
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * swb.size(), (void **)&E->d_sw_block));
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * swk.size(), (void **)&E->d_sw_band));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swj.size(), (void **)&E->d_sw_seg));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+    std::vector<int> fwb, fwc;
+    for (int b = 0; b < nb; b++)
+      for (int c0 = 0; c0 < E->ld[b]; c0 += 128) fwb.push_back(b), fwc.push_back(c0);
+    E->nfw = (int)fwb.size();
+    fwb.push_back(0), fwc.push_back(0);
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * fwb.size(), (void **)&E->d_fw_block));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * fwc.size(), (void **)&E->d_fw_col0));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_fw_block, fwb.data(), sizeof(int) * fwb.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_fw_col0, fwc.data(), sizeof(int) * fwc.size()));
   }
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->xh));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(2, E->ntot), (void **)&E->yh));
@@ -339,7 +414,12 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
   if (E->d_poff) pmh_free(ctx, E->d_poff);
   if (E->d_sw_block) pmh_free(ctx, E->d_sw_block);
   if (E->d_sw_band) pmh_free(ctx, E->d_sw_band);
+  if (E->d_sw_seg) pmh_free(ctx, E->d_sw_seg);
+  if (E->d_doff) pmh_free(ctx, E->d_doff);
+  if (E->d_fw_block) pmh_free(ctx, E->d_fw_block);
+  if (E->d_fw_col0) pmh_free(ctx, E->d_fw_col0);
   for (hipEvent_t e : E->ev) hipEventDestroy(e);
+  for (hipEvent_t e : E->ev_mid) hipEventDestroy(e);
   delete E;
   return PMH_SUCCESS;
 }
@@ -352,11 +432,53 @@ extern "C" int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma, 
   double    alg = 0.0;
   for (int b = 0; b < E->nb; b++) {
     if (n_gamma) n_gamma[b] = E->ngam[b];
-    tot += (long long)sizeof(double) * (E->storage == PMH_FX_SYM ? fx_band_off(E->ld[b] / FX_RB) : (long long)E->ld[b] * E->ld[b]);
+    tot += (long long)sizeof(double) * (E->storage == PMH_FX_SYM ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b]);
     alg += 8.0 * (double)E->ngam[b] * E->ngam[b] + 16.0 * E->ngam[b]; // FULL: the matrix once + x read + y written
   }
   if (dense_bytes) *dense_bytes = tot;
   if (gemv_bytes) *gemv_bytes = (E->storage == PMH_FX_SYM) ? E->sym_bytes : alg;
+  return PMH_SUCCESS;
+}
+
+// Several GPUs, congruent blocks: E is built over ALL blocks of the decomposition (B = the global gluing) and every rank takes
+// the super bands (128-row stripes) number idx = rank (mod size) of the size-ordered list -- an even share of the dense bytes whatever
+// the blocks' sizes (one block per rank would leave a 1.36 x imbalance on configs[2]: n_Gamma 17 031 ... 24 384).  lambda is replicated
+// and B u is all-reduced anyway, so a rank may apply any rows of any W_b: y_rank = Bhat (rows it owns of blockdiag(W_b)) Bhat' lambda
+// and the all-reduce of pmh_gluing_mult_transpose completes F lambda.  Call before the assembly; the storage of the other ranks'
+// stripes stays allocated (zero) so that no index changes (14 GB of 288 at configs[2]).
+extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
+{
+  PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);
+  if (E->storage != PMH_FX_SYM) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_stripe: striping needs the symmetric storage");
+  if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_stripe: call before the assembly");
+  pmh_ctx   ctx = E->ctx;
+  const int nb  = E->nb;
+  int       maxsb = 0;
+  for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
+  std::vector<int> swb, swk, swj;
+  int              idx = 0;
+  for (int sb = maxsb - 1; sb >= 0; sb--)
+    for (int b = 0; b < nb; b++)
+      if (sb < E->ld[b] / FX_TC) {
+        const bool mine  = (idx++ % size) == rank;
+        E->owned[b][sb]  = mine ? 1 : 0;
+        if (mine)
+          for (int j = 0; j * FX_SEG < sb + 1; j++) swb.push_back(b), swk.push_back(sb), swj.push_back(j);
+      }
+  E->nsw = (int)swb.size();
+  swb.push_back(0), swk.push_back(0), swj.push_back(0);
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size())); // the tables were sized for all super bands
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
+  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+  E->stripe_rank = rank, E->stripe_size = size;
+  // algorithmic bytes of this rank's share
+  E->sym_bytes = 0.0;
+  for (int b = 0; b < nb; b++) {
+    const int nsb = E->ld[b] / FX_TC, nsegmax = (nsb + FX_SEG - 1) / FX_SEG;
+    for (int sb = 0; sb < nsb; sb++)
+      if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 8.0 * FX_TC * (sb + 1); // its tiles + its partial row written
+    E->sym_bytes += 8.0 * FX_TC * 0.5 * (double)nsb * (nsb + 1) + 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b]; // the finishing pass reads every partial row
+  }
   return PMH_SUCCESS;
 }
 
@@ -386,6 +508,9 @@ extern "C" int pmh_csr_block_classes(int nblocks, const int *rowstart, const int
   if (nclasses) *nclasses = (int)reps.size();
   return PMH_SUCCESS;
 }
+
+// row p of block b belongs to this rank's stripe (always, without striping)
+static inline bool fx_owns_row(pmh_fexplicit E, int b, int p) { return E->stripe_size <= 1 || E->storage != PMH_FX_SYM || E->owned[b][p / FX_TC]; }
 
 // ---- assembly -------------------------------------------------------------------------------------------------------------
 // MatInvExplicitly_Private (matinv.c:640-665: KSPSolve on the columns of the identity, one row of the explicit matrix per solve),
@@ -423,7 +548,8 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
       if (srs[s + 1] - srs[s] != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, nloc);
     std::vector<char> in((size_t)std::max(1, nloc), 0);
     for (int b : cblocks[c])
-      for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++) in[E->gamma[k] - E->K->rowstart[b]] = 1;
+      for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++)
+        if (fx_owns_row(E, b, (int)(k - E->goff[b]))) in[E->gamma[k] - E->K->rowstart[b]] = 1;
     for (int i = 0; i < nloc; i++)
       if (in[i]) cunion[c].push_back(i);
   }
@@ -476,13 +602,15 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
       E->n_solves++;
       for (int b : cblocks[sc[s]]) {
         const int p = pos[b][col[s]];
-        if (p < 0) continue;
+        if (p < 0 || !fx_owns_row(E, b, p)) continue;
         // row p of W_b: FULL all n_Gamma columns; SYM the columns of its band (0 .. 32(k+1)-1, capped at n_Gamma: the rest is padding)
         const int       kb   = p / FX_RB;
         const int       n    = (E->storage == PMH_FX_SYM) ? std::min(E->ngam[b], FX_RB * (kb + 1)) : E->ngam[b];
-        const long long roff = (E->storage == PMH_FX_SYM) ? fx_band_off(kb) + (long long)(p - FX_RB * kb) * FX_RB * (kb + 1) : (long long)p * E->ld[b];
-        hipLaunchKernelGGL(k_fx_extract, dim3(std::max(1, std::min(64, (n + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]),
-                           (const double *)(sol + srs[s]), E->W[b] + roff);
+        const dim3      grid(std::max(1, std::min(64, (n + PMH_BLOCK - 1) / PMH_BLOCK)));
+        if (E->storage == PMH_FX_SYM)
+          hipLaunchKernelGGL(k_fx_extract_tiled, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), (const double *)(sol + srs[s]), E->W[b] + fx_band_off(kb), p - FX_RB * kb);
+        else
+          hipLaunchKernelGGL(k_fx_extract, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), (const double *)(sol + srs[s]), E->W[b] + (long long)p * E->ld[b]);
       }
     }
     if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);
@@ -495,6 +623,18 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   E->assembled = 1;
   E->assemble_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return PMH_SUCCESS;
+}
+
+// kernel-tuning helper (scripts/symv_tune.py): fills the dense storage with a byte pattern instead of assembling it, so that the
+// apply kernels can be timed at full size without the set-up solves.  The operator is NOT F afterwards.
+extern "C" int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte)
+{
+  PMH_ARG(E);
+  long long tot = 0;
+  for (int b = 0; b < E->nb; b++) tot += (E->storage == PMH_FX_SYM) ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b];
+  PMH_HIP(hipMemsetAsync(E->Wbase, byte, sizeof(double) * (size_t)tot, E->ctx->stream));
+  E->assembled = 1;
+  return pmh_sync(E->ctx);
 }
 
 extern "C" int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds)
@@ -516,14 +656,15 @@ extern "C" int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *out_host,
     } else { // unpack the lower block-triangle band by band, mirror it (the diagonal tile is stored in full)
       std::vector<double> band;
       for (int k = 0; k * FX_RB < n; k++) {
-        const int ldk = FX_RB * (k + 1), rows = std::min(FX_RB, n - k * FX_RB);
-        band.resize((size_t)FX_RB * ldk);
-        PMH_HIP(hipMemcpy(band.data(), E->W[b] + fx_band_off(k), sizeof(double) * (size_t)rows * ldk, hipMemcpyDeviceToHost));
+        const int ntile = k / 4 + 1, rows = std::min(FX_RB, n - k * FX_RB), ncol = std::min(FX_RB * (k + 1), n);
+        band.resize((size_t)FX_TILE * ntile);
+        PMH_HIP(hipMemcpy(band.data(), E->W[b] + fx_band_off(k), sizeof(double) * band.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < rows; r++) {
           const int j = k * FX_RB + r;
-          for (int c = 0; c < std::min(ldk, n); c++) {
-            out_host[(size_t)j * n + c] = band[(size_t)r * ldk + c];
-            if (c < k * FX_RB) out_host[(size_t)c * n + j] = band[(size_t)r * ldk + c];
+          for (int c = 0; c < ncol; c++) {
+            const double v = band[(size_t)(c / FX_TC) * FX_TILE + (size_t)r * FX_TC + (c % FX_TC)];
+            out_host[(size_t)j * n + c] = v;
+            if (c < k * FX_RB) out_host[(size_t)c * n + j] = v;
           }
         }
       }
@@ -542,14 +683,19 @@ static int fx_gemv(pmh_fexplicit E)
   if (E->storage == PMH_FX_SYM) {
     hipStream_t st    = E->ctx->stream;
     bool        timed = false;
-    if (E->ev_on && (E->ev_seen++ % E->ev_stride) == 0 && (size_t)(2 * E->ev_used + 2) <= E->ev.size()) {
+    if (E->ev_on && (E->ev_seen++ % E->ev_stride) == 0 && (size_t)(2 * E->ev_used + 2) <= E->ev.size() && (size_t)E->ev_used < E->ev_mid.size()) {
       timed = true;
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used], st));
     }
-    hipLaunchKernelGGL(k_fx_symv, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff,
-                       (const long long *)E->d_poff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial);
-    hipLaunchKernelGGL(k_fx_symv_fin, dim3((E->ntot + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, E->nb, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_poff,
-                       (const double *)E->ydir, (const double *)E->partial, E->yh);
+    static const int var = getenv("PMH_FX_SYMV_VARIANT") ? atoi(getenv("PMH_FX_SYMV_VARIANT")) : 0;
+#define SYMV_LAUNCH(V) hipLaunchKernelGGL(k_fx_symv<V>, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_sw_seg, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff, (const long long *)E->d_poff, (const long long *)E->d_doff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial)
+    if (var == 1) SYMV_LAUNCH(1);
+    else SYMV_LAUNCH(0);
+#undef SYMV_LAUNCH
+    if (timed) PMH_HIP(hipEventRecord(E->ev_mid[E->ev_used], st));
+    if (E->nfw)
+      hipLaunchKernelGGL(k_fx_symv_fin, dim3(E->nfw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_fw_block, (const int *)E->d_fw_col0, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_poff,
+                         (const long long *)E->d_doff, (const double *)E->ydir, (const double *)E->partial, E->yh);
     if (timed) {
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used + 1], st));
       E->ev_used++;
@@ -576,7 +722,8 @@ static int fx_gemv(pmh_fexplicit E)
   return PMH_SUCCESS;
 }
 
-bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B) { return E && E->B == B && E->assembled; }
+// E serves F = B K^+ B' when it was built from B itself, or -- striped over several GPUs -- from the global gluing with the same dual space
+bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B) { return E && E->assembled && (E->B == B || (E->stripe_size >= 1 && E->B->n_lambda == B->n_lambda)); }
 
 // y = F lambda = Bhat W Bhat' lambda (MatMult of the product F = B K^+ B', qptransform.c:1103-1128, with K^+ explicit)
 int pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y)
@@ -617,7 +764,7 @@ extern "C" int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E)
 {
   PMH_ARG(Kplus);
   if (E && !E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_matinv_attach_explicit: assemble the explicit blocks first");
-  if (E && E->K->n != Kplus->n) return pmh_set_error(PMH_ERR_ARG, "pmh_matinv_attach_explicit: size mismatch (%d vs %d)", E->K->n, Kplus->n);
+  if (E && E->stripe_size < 1 && E->K->n != Kplus->n) return pmh_set_error(PMH_ERR_ARG, "pmh_matinv_attach_explicit: size mismatch (%d vs %d)", E->K->n, Kplus->n);
   Kplus->E = E;
   return PMH_SUCCESS;
 }
@@ -630,20 +777,30 @@ extern "C" int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, in
     PMH_HIP(hipEventCreate(&e));
     E->ev.push_back(e);
   }
+  while ((int)E->ev_mid.size() < max_launches) {
+    hipEvent_t e;
+    PMH_HIP(hipEventCreate(&e));
+    E->ev_mid.push_back(e);
+  }
   E->ev_on = max_launches > 0, E->ev_used = 0, E->ev_seen = 0, E->ev_stride = std::max(1, stride);
   return PMH_SUCCESS;
 }
 
-extern "C" int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms)
+extern "C" int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms, double *first_kernel_ms)
 {
   PMH_ARG(E && launches && total_ms);
   PMH_CHK(pmh_sync(E->ctx));
-  double tot = 0.0;
+  double tot = 0.0, first = 0.0;
   for (int i = 0; i < E->ev_used; i++) {
     float ms = 0.f;
     PMH_HIP(hipEventElapsedTime(&ms, E->ev[2 * i], E->ev[2 * i + 1]));
     tot += ms;
+    if (E->storage == PMH_FX_SYM) {
+      PMH_HIP(hipEventElapsedTime(&ms, E->ev[2 * i], E->ev_mid[i]));
+      first += ms;
+    }
   }
   *launches = E->ev_used, *total_ms = tot;
+  if (first_kernel_ms) *first_kernel_ms = (E->storage == PMH_FX_SYM) ? first : tot; // SYM: k_fx_symv alone (the rest is k_fx_symv_fin)
   return PMH_SUCCESS;
 }

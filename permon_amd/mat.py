@@ -230,6 +230,13 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_sizes(h, None, ng.ctypes.data_as(C.c_void_p), C.byref(db), C.byref(gb)))
         self.n_gamma, self.dense_bytes, self.gemv_bytes = ng, db.value, gb.value
 
+    def set_stripe(self, rank, size):
+        """Several GPUs, congruent blocks: this object spans all blocks; the rank keeps the 128-row stripes idx = rank (mod size)."""
+        check(self.ctx.L.pmh_fexplicit_set_stripe(self.h, int(rank), int(size)))
+        gb = C.c_double()
+        check(self.ctx.L.pmh_fexplicit_sizes(self.h, None, None, None, C.byref(gb)))
+        self.gemv_bytes = gb.value
+
     def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
         """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
         sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None
@@ -265,8 +272,9 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_timing_enable(self.h, int(max_launches), int(stride)))
 
     def timing_get(self):
-        n, ms = C.c_int(), C.c_double()
-        check(self.ctx.L.pmh_fexplicit_timing_get(self.h, C.byref(n), C.byref(ms)))
+        n, ms, ms1 = C.c_int(), C.c_double(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_timing_get(self.h, C.byref(n), C.byref(ms), C.byref(ms1)))
+        self.first_kernel_ms = ms1.value  # "sym": k_fx_symv alone, the rest of ms is k_fx_symv_fin
         return n.value, ms.value, self.gemv_bytes
 
     def destroy(self):

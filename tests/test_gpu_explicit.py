@@ -136,3 +136,33 @@ def test_explicit_replica_solver(ctx):
     assert np.max(np.abs(W - ref)) <= 1e-10 * np.max(np.abs(ref))
     n_solves, _ = q.E.assemble_stats()
     assert n_solves == q.E.n_gamma[0]
+
+
+def test_striped_shares_sum_to_F(ctx):
+    """Several GPUs rehearsed on one: the operator spans all blocks, rank r of 3 keeps the 128-row stripes idx = r (mod 3); the sum of
+    the three ranks' applies (the all-reduce) equals F lambda of the unstriped operator, each share is bitwise reproducible, and the
+    shares split the set-up solves."""
+    f = pa.CubeFeti((2, 2, 1), 8, contact=True)  # n_Gamma > 128: several stripes per block
+    G, e = f.coarse()
+    loc = f.subset(range(f.nsub))
+    q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13))
+    assert q0.E.n_gamma.min() > 256
+    lam = np.random.default_rng(2).standard_normal(f.n_lambda)
+    lv, y0 = ctx.vec_from(lam), ctx.vec(f.n_lambda)
+    q0.F.mult(lv, y0)
+    glob = dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign)
+    tot, solves = np.zeros(f.n_lambda), []
+    for r in range(3):
+        # rank r owns blocks [r] only (a 1-block K^+), but applies its stripes of ALL four W_b
+        lr = f.subset([r])
+        q = FetiDualQP(ctx, lr, G, e, f.c, f.lb, kplus_rtol=1e-13)
+        E = q.assemble_explicit(lr, rtol=1e-13, stripe=(r, 3, glob))
+        y, y2 = ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+        q.F.mult(lv, y)
+        q.F.mult(lv, y2)
+        assert np.array_equal(y.to_numpy(), y2.to_numpy())
+        tot += y.to_numpy()
+        solves.append(E.assemble_stats()[0])
+    ref = y0.to_numpy()
+    assert np.linalg.norm(tot - ref) <= 1e-10 * np.linalg.norm(ref)
+    assert max(solves) < q0.E.assemble_stats()[0] and sum(solves) >= q0.E.assemble_stats()[0]
