@@ -505,9 +505,15 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         E = q.E
         if want_timing:
             E.timing_enable(4 * (steps + warmup) + 256, 1)
-        dt, cnt = timed_pass(steps, warmup)
+        if warmup:
+            qps.RunFixedSolve(warmup)
+        n_w, ms_w, _ = E.timing_get() if want_timing else (0, 0.0, 0.0)
+        dt, cnt = timed_pass(steps, 0)
         n_k, ms_k, b_k = E.timing_get() if want_timing else (0, 0.0, E.gemv_bytes)
+        n_k, ms_k = n_k - n_w, ms_k - ms_w  # the timed region only
         E.timing_enable(0)
+        cnt["operator_applies"] = n_k  # F applies of the timed region: the inner Hessian multiplications + SMALXE's objective evaluation per outer iteration
+        cnt["ms_per_operator_apply"] = dt * 1e3 / n_k if n_k else None
         achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
         n_solves, asm_s = E.assemble_stats()
         traffic, tsrc = pmc_lookup(("k_fx_symv(", "k_fx_symv") if a.explicit_storage == "sym" else "void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json") if full_size else (None, "not the configuration of the committed PMC pass")
@@ -517,7 +523,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                                        "k_fx_gemv: y_b = W_b x_b, the dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] of all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None, "timing_stride": 1,
-            "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt * (steps / max(1, steps + warmup)) if n_k else None,
+            "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
         }
         kplus_cfg = {"path": "explicit", "storage": a.explicit_storage, "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text

@@ -423,6 +423,13 @@ int pmh_qps_set_from_options(const char *options, const char *prefix, pmh_qps_op
 typedef struct pmh_mg_s *pmh_mg;
 int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, int degree, const double *lambda_max, double lo_frac, double hi_frac, int nb_coarse, const int *coarse_rowstart,
                   const double *coarse_pinv_host, int precision, pmh_mg *mg);
+/* The same PC with the hierarchy built HERE (host C++, runs once) for a block-diagonal A_fine whose blocks are Q1 discretisations on
+ * boxes of dims[3 b .. 3 b + 2] nodes (x fastest, node-major dofs, ndof per node): trilinear prolongations (x) I_ndof (exact for rigid-body
+ * modes), Galerkin operators, lambda_max(D^-1 A) by the power method, dense pseudo-inverses of the coarsest blocks
+ * (A + Q Q')^{-1} - Q Q' with Q the kernel basis injected from R_host (kdim x n, zero over non-singular blocks; NULL if none floats).
+ * Coarsening stops at <= min_nodes nodes per block; congruent blocks are processed once.  rowptr / col / val: host copy of A_fine. */
+int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_rowstart, const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int kdim,
+                      const double *R_host, int min_nodes, int degree, int precision, pmh_mg *mg);
 int pmh_mg_apply(pmh_mg mg, const double *b_dev, double *x_dev); /* x = V(b), zero initial guess (PCApply) */
 int pmh_mg_stats(pmh_mg mg, long long *fine_spmv);
 int pmh_mg_timing_enable(pmh_mg mg, int max_launches); /* HIP-event pairs around the fine-level operator launches */
@@ -483,6 +490,31 @@ int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opts *o, char 
 int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
                       const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host /* or NULL */, int lambda_cap,
                       pmh_kspfeti_stats *st);
+
+/* ---- TFETI contact problem in one call (QPTFromOptions / QPTAllInOne, src/qp/interface/qptransform.c:2152-2237: dualize ->
+ * orthonormalize -> homogenize -> project; QPSSetDefaultType -> SMALXE + MPGP; the post-solve chain) ----------------------------------
+ * Input = the decomposed QP: block-diagonal K (host CSR), f, the constraint matrix B as leaves (local primal dof, dual row, value) with
+ * the n_eq equality rows (gluing, Dirichlet) first and the inequality rows (B_I u <= c_I, e.g. non-penetration) after them, c, the
+ * kernel vectors R (kdim x N; every block floats in TFETI), optionally the blocks' node boxes (dims: nsub x 3, x fastest, node-major
+ * dofs) for the multigrid PC of K^+.  K^+ = P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp); with explicit_dual the explicit local dual
+ * operators carry F (exact, one dense SYMV per apply).  Output: u (N, host), lambda (n_lambda, host, optional), the solver's statistics. */
+typedef struct {
+  pmh_smalxe_opts smalxe;           /* outer tolerances + SMALXE / inner MPGP parameters (pmh_smalxe_default_opts) */
+  double kplus_rtol; int kplus_max_it;
+  int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
+  int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
+  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL) */
+  int    orthonormalize;            /* QPTOrthonormalizeEq: G <- L^{-1} G */
+} pmh_feti_contact_opts;
+typedef struct {
+  pmh_smalxe_stats smalxe;
+  int    n_lambda, n_eq, coarse_dim, n_active, explicit_solves;
+  double setup_seconds, solve_seconds, explicit_seconds, norm_Glambda_minus_e;
+} pmh_feti_contact_stats;
+int pmh_feti_contact_default_opts(pmh_feti_contact_opts *o);
+int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, int n_lambda, int n_eq, int n_leaves,
+                           const int *leaves_row, const int *leaves_root, const double *leaves_val, const double *c, int kdim, const double *R, const int *dims /* or NULL */, int ndof,
+                           const pmh_feti_contact_opts *o, double *u_host, double *lambda_host /* or NULL */, pmh_feti_contact_stats *st);
 
 #ifdef __cplusplus
 }

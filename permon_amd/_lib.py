@@ -80,6 +80,16 @@ class KspFetiStats(C.Structure):
     _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("n_lambda", C.c_int), ("n_dirichlet_rows", C.c_int), ("coarse_dim", C.c_int)]
 
 
+class FetiContactOpts(C.Structure):
+    _fields_ = [("smalxe", SmalxeOpts), ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("mg", C.c_int), ("mg_min_nodes", C.c_int), ("mg_degree", C.c_int), ("mg_precision", C.c_int),
+                ("bsr3", C.c_int), ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("explicit_storage", C.c_int), ("orthonormalize", C.c_int)]
+
+
+class FetiContactStats(C.Structure):
+    _fields_ = [("smalxe", SmalxeStats), ("n_lambda", C.c_int), ("n_eq", C.c_int), ("coarse_dim", C.c_int), ("n_active", C.c_int), ("explicit_solves", C.c_int),
+                ("setup_seconds", C.c_double), ("solve_seconds", C.c_double), ("explicit_seconds", C.c_double), ("norm_Glambda_minus_e", C.c_double)]
+
+
 class PcpgStats(C.Structure):
     _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double)]
 
@@ -211,6 +221,7 @@ _PROTOS = {
     "pmh_smalxe_run_fixed": [vp, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
     "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
+    "pmh_mg_create_box": [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_mg_timing_enable": [vp, C.c_int],
     "pmh_mg_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_matinv_enable_bsr3": [vp],
@@ -244,6 +255,8 @@ _PROTOS = {
     "pmh_matinv_set_tolerances": [vp, C.c_double, C.c_double, C.c_int],
     "pmh_matinv_get_tolerances": [vp, c_double_p, c_double_p, c_int_p],
     "pmh_csr_block_classes": [C.c_int, vp, vp, vp, vp, vp, c_int_p],
+    "pmh_feti_contact_default_opts": [C.POINTER(FetiContactOpts)],
+    "pmh_feti_contact_solve": [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(FetiContactOpts), vp, vp, C.POINTER(FetiContactStats)],
     "pmh_ksp_cg_solve": [vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
 }
 

@@ -55,6 +55,7 @@ struct pmh_fexplicit_s {
   long long *d_poff, *d_doff; // SYM: offset of block b in `partial` / in `ydir`
   int     *d_sw_block, *d_sw_band, *d_sw_seg; // SYM launch table: workgroup -> (block, super band, column segment)
   int     *d_fw_block, *d_fw_col0; // SYM second launch: workgroup -> (block, first of its 128 columns)
+  int     *d_own_ptr, *d_own_list; // SYM: per block the ascending list of the super bands this rank owns
   int      nsw, nfw;
   double   sym_bytes;      // SYM: algorithmic bytes of one apply
   double  *xh, *yh;        // compressed work vectors
@@ -210,26 +211,34 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ s
   }
 }
 
-// y[c] = sum over the segments j of ydseg[j][c] (segment order) + sum over the super bands s >= c / 128 of partial[s][c] (wave w
-// takes s = w (mod 4) in ascending order, eight 16-byte loads in flight per lane; the four waves' sums are added in wave order).
+// y[c] = sum over the segments j of ydseg[j][c] (segment order) + sum over the OWNED super bands s >= c / 128 of partial[s][c] (wave w
+// takes every 4th of them in ascending order, eight 16-byte loads in flight per lane; the four waves' sums are added in wave order).
 // One workgroup per 128 columns of a block.
 __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv_fin(const int *__restrict__ fw_block, const int *__restrict__ fw_col0, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ poff,
-                                                          const long long *__restrict__ doff, const double *__restrict__ ydseg, const double *__restrict__ partial, double *__restrict__ yh)
+                                                          const long long *__restrict__ doff, const int *__restrict__ own_ptr, const int *__restrict__ own_list, const double *__restrict__ ydseg,
+                                                          const double *__restrict__ partial, double *__restrict__ yh)
 {
   __shared__ dbl2 red[PMH_BLOCK / 64][64];
   const int b = fw_block[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int npad = ldv[b], nsb = npad / FX_TC;
+  const int npad = ldv[b];
   const int c    = fw_col0[blockIdx.x] + lane * 2; // npad is a multiple of 128: always inside the block
   const int sc   = c / FX_TC;                      // the column's own super band: its diagonal tile column holds the in-super-band transposed terms
   dbl2      s    = {0.0, 0.0};
   {
+    // the super bands this rank owns (all of them without striping), ascending; start at the first one >= sc
+    const int *own = own_list + own_ptr[b];
+    const int  cnt = own_ptr[b + 1] - own_ptr[b];
+    int        lo = 0, hi = cnt;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (own[mid] < sc) lo = mid + 1;
+      else hi = mid;
+    }
     const double *p = partial + poff[b] + c;
-    int           k = sc;
-    k += (wave - (k & 3)) & 3; // first super band >= sc with k = wave (mod 4)
-    for (; k < nsb; k += 32) {
+    for (int q = lo + wave; q < cnt; q += 32) { // wave w takes the list positions lo + w (mod 4), eight loads in flight
       dbl2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = (k + 4 * u < nsb) ? *(const dbl2 *)(p + (long long)(k + 4 * u) * npad) : dbl2{0.0, 0.0};
+      for (int u = 0; u < 8; u++) v[u] = (q + 4 * u < cnt) ? *(const dbl2 *)(p + (long long)own[q + 4 * u] * npad) : dbl2{0.0, 0.0};
 #pragma unroll
       for (int u = 0; u < 8; u++) s += v[u];
     }
@@ -261,6 +270,26 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract(int n, const int *__re
   for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) wrow[i] = u[gamma_rel[i]];
 }
 
+// per block the ascending list of owned super bands (E->owned) -> device
+static int fx_upload_owned(pmh_fexplicit E)
+{
+  std::vector<int> ptr(E->nb + 1, 0), lst;
+  for (int b = 0; b < E->nb; b++) {
+    for (int sb = 0; sb < (int)E->owned[b].size(); sb++)
+      if (E->owned[b][sb]) lst.push_back(sb);
+    ptr[b + 1] = (int)lst.size();
+  }
+  int tot = 0;
+  for (int b = 0; b < E->nb; b++) tot += (int)E->owned[b].size();
+  if (!E->d_own_ptr) {
+    PMH_CHK(pmh_malloc(E->ctx, sizeof(int) * (E->nb + 1), (void **)&E->d_own_ptr));
+    PMH_CHK(pmh_malloc(E->ctx, sizeof(int) * (size_t)std::max(1, tot), (void **)&E->d_own_list));
+  }
+  lst.push_back(0);
+  PMH_CHK(pmh_memcpy_h2d(E->ctx, E->d_own_ptr, ptr.data(), sizeof(int) * (E->nb + 1)));
+  return pmh_memcpy_h2d(E->ctx, E->d_own_list, lst.data(), sizeof(int) * std::max<size_t>(1, lst.size() - 1));
+}
+
 // SYM: the part of row j = 32 k + r that lies in its band, into the band's tiles: element (r, i) at (i / 128) tiles + r * 128 + i % 128
 __global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract_tiled(int n, const int *__restrict__ gamma_rel, const double *__restrict__ u, double *__restrict__ band, int r)
 {
@@ -280,7 +309,7 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
   E->xh = E->yh = nullptr, E->assembled = 0, E->n_solves = 0, E->assemble_seconds = 0.0;
   E->stripe_rank = 0, E->stripe_size = 0;
   E->ev_used = E->ev_on = E->ev_seen = 0, E->ev_stride = 1;
-  E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = E->d_doff = nullptr, E->d_sw_block = E->d_sw_band = E->d_sw_seg = E->d_fw_block = E->d_fw_col0 = nullptr, E->nsw = E->nfw = 0, E->sym_bytes = 0.0;
+  E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = E->d_doff = nullptr, E->d_sw_block = E->d_sw_band = E->d_sw_seg = E->d_fw_block = E->d_fw_col0 = E->d_own_ptr = E->d_own_list = nullptr, E->nsw = E->nfw = 0, E->sym_bytes = 0.0;
   const int nb = E->nb;
   // Gamma_b: the primal dofs with at least one leaf, ascending inside every block
   std::vector<char> touched((size_t)std::max(1, B->n_x), 0);
@@ -383,6 +412,7 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+    PMH_CHK(fx_upload_owned(E));
     std::vector<int> fwb, fwc;
     for (int b = 0; b < nb; b++)
       for (int c0 = 0; c0 < E->ld[b]; c0 += 128) fwb.push_back(b), fwc.push_back(c0);
@@ -418,6 +448,8 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
   if (E->d_doff) pmh_free(ctx, E->d_doff);
   if (E->d_fw_block) pmh_free(ctx, E->d_fw_block);
   if (E->d_fw_col0) pmh_free(ctx, E->d_fw_col0);
+  if (E->d_own_ptr) pmh_free(ctx, E->d_own_ptr);
+  if (E->d_own_list) pmh_free(ctx, E->d_own_list);
   for (hipEvent_t e : E->ev) hipEventDestroy(e);
   for (hipEvent_t e : E->ev_mid) hipEventDestroy(e);
   delete E;
@@ -471,13 +503,16 @@ extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
   PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
   E->stripe_rank = rank, E->stripe_size = size;
+  PMH_CHK(fx_upload_owned(E));
   // algorithmic bytes of this rank's share
   E->sym_bytes = 0.0;
   for (int b = 0; b < nb; b++) {
     const int nsb = E->ld[b] / FX_TC, nsegmax = (nsb + FX_SEG - 1) / FX_SEG;
     for (int sb = 0; sb < nsb; sb++)
       if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 8.0 * FX_TC * (sb + 1); // its tiles + its partial row written
-    E->sym_bytes += 8.0 * FX_TC * 0.5 * (double)nsb * (nsb + 1) + 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b]; // the finishing pass reads every partial row
+    for (int sb = 0; sb < nsb; sb++)
+      if (E->owned[b][sb]) E->sym_bytes += 8.0 * FX_TC * (sb + 1); // ... and read back by the finishing pass
+    E->sym_bytes += 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b];
   }
   return PMH_SUCCESS;
 }
@@ -695,7 +730,7 @@ static int fx_gemv(pmh_fexplicit E)
     if (timed) PMH_HIP(hipEventRecord(E->ev_mid[E->ev_used], st));
     if (E->nfw)
       hipLaunchKernelGGL(k_fx_symv_fin, dim3(E->nfw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_fw_block, (const int *)E->d_fw_col0, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_poff,
-                         (const long long *)E->d_doff, (const double *)E->ydir, (const double *)E->partial, E->yh);
+                         (const long long *)E->d_doff, (const int *)E->d_own_ptr, (const int *)E->d_own_list, (const double *)E->ydir, (const double *)E->partial, E->yh);
     if (timed) {
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used + 1], st));
       E->ev_used++;

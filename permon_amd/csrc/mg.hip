@@ -51,6 +51,7 @@ struct pmh_mg_s {
   std::vector<cached_graph> graphs;
   int                       use_graph, timing_on;
   int                       fused; // degree 2 + block operators: smoothing steps finished inside the operator kernel
+  std::vector<pmh_csr>      owned; // CSR handles created for this hierarchy by pmh_mg_create_box (destroyed with it)
 };
 
 template <typename TV>
@@ -666,10 +667,18 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   return PMH_SUCCESS;
 }
 
+int pmh_mg_adopt_csr(pmh_mg mg, pmh_csr A)
+{
+  PMH_ARG(mg && A);
+  mg->owned.push_back(A);
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_mg_destroy(pmh_mg mg)
 {
   if (!mg) return PMH_SUCCESS;
   pmh_ctx ctx = mg->ctx;
+  for (pmh_csr a : mg->owned) pmh_csr_destroy(a);
   for (auto &Lv : mg->L) {
     pmh_free(ctx, Lv.dinv);
     pmh_free(ctx, Lv.r);

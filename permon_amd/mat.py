@@ -77,6 +77,7 @@ class MatBlockDiag:
     def __init__(self, ctx, block_rowstart, Kcat):
         rs = np.ascontiguousarray(block_rowstart, dtype=np.int32)
         self.ctx, self.K, self.nblocks, self.n = ctx, Kcat, rs.size - 1, Kcat.nrows
+        self.block_rowstart = rs
         h = C.c_void_p()
         check(ctx.L.pmh_blockdiag_create(ctx.h, self.nblocks, rs.ctypes.data_as(C.c_void_p), Kcat.h, C.byref(h)))
         self.h = h
@@ -161,6 +162,28 @@ class MatInv:
         self.mg = MG(self.ctx, hier, degree=degree, lo=lo, hi=hi, fine=self.K.K, precision=precision)
         check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, self.mg.h))
         return self.mg
+
+    def set_pc_mg_box(self, K, dims, ndof, R=None, min_nodes=400, degree=2, precision="fp64"):
+        """The same V-cycle PC with the hierarchy built inside libpermonhip (pmh_mg_create_box, host C++): K = the scipy CSR this
+        MATINV works on (the host copy of the resident matrix), dims = [(nx, ny, nz)] node boxes of the blocks, R = (kdim, n) kernel
+        vectors (zero over non-singular blocks) or None."""
+        K = K.tocsr()
+        K.sort_indices()
+        ip, ci, va = np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64)
+        rs = np.ascontiguousarray(self._rowstart(), dtype=np.int32)
+        dm = np.ascontiguousarray(dims, dtype=np.int32).reshape(-1, 3)
+        Rm = np.ascontiguousarray(R, dtype=np.float64) if R is not None and np.size(R) else None
+        h = C.c_void_p()
+        check(self.ctx.L.pmh_mg_create_box(self.ctx.h, self.K.K.h, rs.size - 1, rs.ctypes.data_as(C.c_void_p), dm.ctypes.data_as(C.c_void_p), int(ndof), ip.ctypes.data_as(C.c_void_p),
+                                           ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), Rm.shape[0] if Rm is not None else 0, Rm.ctypes.data_as(C.c_void_p) if Rm is not None else None,
+                                           int(min_nodes), int(degree), {"fp64": 0, "fp32": 1, "fp16": 2}[precision], C.byref(h)))
+        self.mg = MG.__new__(MG)
+        self.mg.ctx, self.mg.h, self.mg.precision = self.ctx, h, precision
+        check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, h))
+        return self.mg
+
+    def _rowstart(self):
+        return self.K.block_rowstart
 
     def enable_bsr3(self):
         """K x of the CG on the 3x3-block kernel (MATSEQBAIJ bs=3 role)."""

@@ -210,3 +210,19 @@ def svm_dual(N, d=64, C=1.0, seed_x=7, seed_w=8):
     y = np.sign(X @ w + 0.1 * rng.standard_normal(N))
     y[y == 0] = 1.0
     return dict(n=N, d=d, X=X, y=y, b=np.ones(N), lb=np.zeros(N), ub=np.full(N, float(C)), x0=np.zeros(N))
+
+
+def write_contact_problem(path, f):
+    """A CubeFeti contact problem (permon_amd.feti.CubeFeti) in the binary layout examples/contact_tfeti.c reads:
+    everything pmh_feti_contact_solve takes -- block-diagonal K, f, B as leaves (equality rows first), c, R, the node boxes."""
+    K = f.K.tocsr()
+    K.sort_indices()
+    nn = f.nel + 1
+    with open(path, "wb") as fh:
+        np.array([0x504D4831, f.nsub, f.N, K.nnz, f.n_lambda, f.n_eq, f.leaves_row.size, f.kdim], dtype=np.int32).tofile(fh)
+        np.array([f.ndof], dtype=np.int32).tofile(fh)
+        np.array([nn, nn, nn] * f.nsub, dtype=np.int32).tofile(fh)
+        for a in (f.block_rowstart, K.indptr, K.indices, f.leaves_row, f.leaves_root):
+            np.ascontiguousarray(a, dtype=np.int32).tofile(fh)
+        for a in (K.data, f.f, f.leaves_sign, f.c, f.R):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(fh)

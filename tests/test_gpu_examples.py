@@ -2,6 +2,8 @@
 the command lines of the reference's TEST blocks (src/tutorials/ex1.c:165-184); its stdout must equal the reference's golden
 output files line for line (what PETSc's test harness diffs: -qps_view_convergence and -qp_chain_view_kkt text)."""
 import os
+
+import numpy as np
 import subprocess
 
 import pytest
@@ -48,3 +50,42 @@ def test_example_output_equals_the_reference_golden_file(goldens, case):
     got = [ln.rstrip() for ln in out.stdout.splitlines() if ln.strip()]
     exp = [ln.rstrip() for ln in goldens[case]["text"] if ln.strip()]
     assert got == exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [1, 0])
+def test_contact_example_reproduces_the_python_chain(tmp_path, explicit):
+    """examples/contact_tfeti.c = pmh_feti_contact_solve from plain C (hierarchy built by pmh_mg_create_box, explicit dual operators,
+    SMALXE + MPGP, rigid-body recovery, no Python in the solve) against the Python-orchestrated chain on the same problem: identical
+    outer / inner / Hessian-multiplication / step-type counts, a feasible solution."""
+    import re
+
+    import permon_amd as pa
+    from permon_amd import problems as P
+    from permon_amd.chain import FetiDualQP
+
+    _build()
+    f = pa.CubeFeti((2, 2, 2), 8, contact=True)
+    path = str(tmp_path / "contact.bin")
+    P.write_contact_problem(path, f)
+    out = subprocess.run([os.path.join(ROOT, "examples", "contact_tfeti"), path, str(explicit), "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    ctx = pa.Context(0)
+    G, e = f.coarse(orthonormalize=True)
+    nn = f.nel + 1
+    hier = pa.box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, 3, min_nodes=400)
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, kplus_rtol=1e-9, mg_hierarchy=hier, mg_precision="fp16", bsr3=True, explicit=dict(rtol=1e-12) if explicit else None)
+    st = q.solve_smalxe(rtol=1e-5)
+    want = q.qps.ViewConvergence()
+    # the C program prints the same block (its first line without the reason's name)
+    assert lines[0] == "last QPSSolve CONVERGED, KSPReason=%d, required %d iterations" % (st.reason, st.iteration)
+    assert lines[1:4] == want[1:4]  # inner iterations, hits, updates
+    assert lines[4:8] == want[5:9]  # Hessian multiplications, CG / expansion / proportioning steps
+    m = re.search(r"\|\|G lambda - e\|\| = (\S+)\s+max\|B_E u - c_E\| / max\|u\| = (\S+)\s+max\(B_I u - c_I\) / max\|u\| = (\S+)\s+min lambda_I = (\S+)", lines[-1])
+    gle, eqv, pen, lmin = (float(v) for v in m.groups())
+    assert gle <= 1e-5 and eqv <= 1e-3 and pen <= 1e-3 and lmin >= -1e-12
+    act = int(re.search(r"active contact rows (\d+)", lines[-2]).group(1))
+    lam = q.dual_solution()
+    assert act == int((lam[f.n_eq:] > 1e-8 * np.abs(lam).max()).sum())
+    ctx.close()

@@ -158,3 +158,46 @@ def test_contact_tfeti_solve_is_independent_of_the_inner_pc(ctx):
         its.append((st.iteration, st.inner_iter_accu))
     assert its[0] == its[1]  # same outer / inner MPGP counts: K^+ is the same operator to 1e-11
     assert np.linalg.norm(sols[0] - sols[1]) <= 1e-7 * np.linalg.norm(sols[0])
+
+
+@pytest.mark.parametrize("case", ["floating", "regularized", "odd_box"])
+def test_box_hierarchy_built_in_c(ctx, case):
+    """pmh_mg_create_box (host C++ inside libpermonhip: trilinear prolongation (x) I3, Galerkin products, coarse pseudo-inverses from the
+    injected kernel) against the scipy builder of permon_amd.feti: same K^+ to 1e-9 and the same CG iteration count (+-2)."""
+    if case == "odd_box":
+        f = CubeFeti((2, 1, 1), 9, "elasticity", contact=False)  # 10 nodes per edge: short last coarse interval
+    else:
+        f = CubeFeti((2, 1, 1), 8, "elasticity", contact=False)
+    nn = f.nel + 1
+    local = f.subset(range(f.nsub))
+    if case == "regularized":
+        from permon_amd.chain import regularize_blocks
+
+        Ksp = regularize_blocks(ctx, local)[0]
+        R = None
+    else:
+        Ksp, R = f.K, f.R
+    blocks = [Ksp[i * f.n_i:(i + 1) * f.n_i, i * f.n_i:(i + 1) * f.n_i].tocsr() for i in range(f.nsub)]
+    H = box_mg_hierarchy(blocks, [(nn, nn, nn)] * f.nsub, 3, min_nodes=27)
+    rhs = np.random.default_rng(8).standard_normal(f.N)
+    out = []
+    for builder in ("python", "c"):
+        K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Ksp)
+        M = pa.MatInv(K, rtol=1e-11, nullspace=R)
+        if builder == "python":
+            M.set_pc_mg(H, degree=2)
+        else:
+            M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=R, min_nodes=27, degree=2)
+        u = ctx.vec(f.N)
+        M.mult(ctx.vec_from(rhs), u)
+        out.append((u.to_numpy(), M.last_iterations()[0]))
+    (ua, ia), (ub, ib) = out
+    assert np.linalg.norm(ua - ub) <= 1e-9 * np.linalg.norm(ua) and abs(ia - ib) <= 2 and ib < 30
+    # and against the dense (pseudo-)inverse
+    Kd = blocks[0].toarray()
+    ref1 = np.linalg.pinv(Kd, rcond=1e-10, hermitian=True) if case != "regularized" else None
+    if ref1 is not None:
+        ref = np.concatenate([ref1 @ rhs[:f.n_i], ref1 @ rhs[f.n_i:]])
+        assert np.linalg.norm(ub - ref) <= 1e-8 * np.linalg.norm(ref)
+    else:
+        assert np.linalg.norm(Ksp @ ub - rhs) <= 1e-9 * np.linalg.norm(rhs)
