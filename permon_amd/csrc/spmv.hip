@@ -179,11 +179,42 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_stream(const int *__restrict
         for (int j = 0; j < ITEMS; j++)
           if (c[j] >= 0) pr[tid + j * PMH_BLOCK] = v[j] * x[c[j]];
       }
+      // short rows: the lane's first row of this block and the operands of its epilogue (row pointers, p, g, x, lb / ub, y1) are
+      // requested BEFORE the barrier, so that their latency runs under the barrier and the LDS phase instead of after it
+      int    fr = cr0 + tid, fk0 = 0, fk1 = 0;
+      double fp = 0.0, fg = 0.0, fx = 0.0, fl = -INFINITY, fu = INFINITY, fy1 = 0.0;
+      if (RL == 1 && fr < cr1) {
+        fk0 = rowptr[fr] - cs0, fk1 = rowptr[fr + 1] - cs0;
+        if (EPI == PMH_EPI_MPGP) {
+          fp = x[fr], fg = a.g[fr], fx = a.xx[fr];
+          if (a.lb) fl = a.lb[fr];
+          if (a.ub) fu = a.ub[fr];
+        } else if (EPI == PMH_EPI_ADD || EPI == PMH_EPI_SUB) {
+          fy1 = a.y1[fr];
+        }
+      }
       if (MODE != 0 && nb < end) prefetch(nb); // next block's stream in flight during this block's row phase
       __syncthreads();
       if (RL == 1) {
-        // short rows: one lane per row, left-to-right sum (bit-identical to MatMult_SeqAIJ)
-        for (int r = cr0 + tid; r < cr1; r += PMH_BLOCK) {
+        // one lane per row, left-to-right sum (bit-identical to MatMult_SeqAIJ)
+        if (fr < cr1) {
+          double sum = 0.0;
+          for (int k = fk0; k < fk1; k++) sum += pr[k];
+          if (EPI == PMH_EPI_NONE) {
+            y[fr] = sum;
+          } else if (EPI == PMH_EPI_ADD) {
+            y[fr] = fy1 + sum;
+          } else if (EPI == PMH_EPI_SUB) {
+            y[fr] = sum - fy1;
+          } else { // PMH_EPI_MPGP: same arithmetic as epi_row
+            y[fr] = sum;
+            acc0 += fp * sum;
+            acc1 += fg * fp;
+            if (fp > 0. && fl > -INFINITY) amin = fmin(amin, (fx - fl) / fp);
+            if (fp < 0. && fu < INFINITY) amin = fmin(amin, (fx - fu) / fp);
+          }
+        }
+        for (int r = fr + PMH_BLOCK; r < cr1; r += PMH_BLOCK) { // (nearly) empty rows: more rows than lanes in a block
           const int k0 = rowptr[r] - cs0, k1 = rowptr[r + 1] - cs0;
           double    sum = 0.0;
           for (int k = k0; k < k1; k++) sum += pr[k];
