@@ -258,7 +258,9 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     b_H = 2.0 * 8 * n * d + 40.0 * n
+    comm_rank, comm_size = ctx.comm_rank()
     return {
+        "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None, "checksum": {"norm_x_after_last_step": repr(float(x.norm()))},
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "configs[4]: PermonSVM-style hinge-loss dual, N=%d samples x d=%d dense fp64 (%.2f GB), H = diag(y) X X' diag(y) matrix-free, MPGP box 0<=a<=1" % (N, d, N * d * 8 / 1e9),
         "parallelism": "samples sharded by rows over %d GPU(s); w all-reduce (d doubles) per Hessian apply; scalar all-reduces for the MPGP reductions" % world,
@@ -439,16 +441,28 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def roctx(resume):
+        """PMH_BENCH_ROCTX=1 under `rocprofv3 --selected-regions`: only the timed region is traced (the set-up solves of the explicit
+        operators alone are ~11 M launches)."""
+        if not os.environ.get("PMH_BENCH_ROCTX"):
+            return
+        import ctypes
+
+        lib = ctypes.CDLL("/opt/rocm/lib/librocprofiler-sdk-roctx.so")
+        (lib.roctxProfilerResume if resume else lib.roctxProfilerPause)(ctypes.c_uint64(0))
+
     def timed_pass(nsteps, nwarm):
         """W untimed + exactly K timed inner MPGP iterations of the real SMALXE solver loop (restarting from lambda = 0 whenever the
         solve converges: configs[2] takes 108 iterations), bracketed by barriers; max over ranks."""
         if nwarm:
             qps.RunFixedSolve(nwarm)
         barrier()
+        roctx(True)
         t1 = time.perf_counter()
         cnt = qps.RunFixedSolve(nsteps)
         barrier()
         dt = time.perf_counter() - t1
+        roctx(False)
         if dist is not None:
             import torch
 
@@ -567,6 +581,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None,
         "steps_by_type": cnt, "precision_note": precision_note, "kplus": kplus_cfg,
+        "checksum": {"norm_lambda_child_after_last_step": repr(float(q.lam.norm()))},  # bitwise comparable between runs (deterministic reductions)
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
                                       "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": True},
@@ -633,7 +648,7 @@ def main():
             "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "steps_by_type": r["steps_by_type"], "setup_seconds": r["setup_seconds"]},
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "rccl_ranks": r["rccl_ranks"], "steps_by_type": r["steps_by_type"], "setup_seconds": r["setup_seconds"], "checksum": r["checksum"]},
             "roofline": r["roofline"],
         }
     else:
@@ -643,7 +658,7 @@ def main():
             "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": r["value"], "unit": "QPS iterations/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "rccl_ranks": r["rccl_ranks"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"],
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"], "rccl_ranks": r["rccl_ranks"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"], "checksum": r["checksum"],
                        "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
             "roofline": r["roofline"],
         }

@@ -483,6 +483,12 @@ typedef struct {
    multiplicity) and of its post-solve (:1945-1949: INSERT_VALUES assembly of the solution, no averaging); host routines */
 int pmh_qpt_matis_split_rhs(int N, const int *l2g, int n_global, const double *b_global, double *f_local);
 int pmh_qpt_matis_assemble_solution(int N, const int *l2g, const double *u_local, int n_global, double *x_global);
+/* matrix side of QPTMatISToBlockDiag (qptransform.c:2007-2150): MATIS = per-subdomain local matrices + l2g  ->  the MATBLOCKDIAG of the child QP
+   (MatCreateBlockDiag(comm, matis->A)) in the concatenated local numbering, matis->counter (dof multiplicities: D = 1/counter), the interface
+   flags of the local dofs and i2g = the sorted global interface dofs (QPFetiSetInterfaceToGlobalMapping); host routine.  loc_rowptr: the
+   subdomains' row pointers one after the other (n_s + 1 entries each, each starting at 0); col / val / counter / is_interface / i2g may be NULL */
+int pmh_qpt_matis_to_blockdiag(int nsub, const int *l2g_start, const int *l2g, int n_global, const int *loc_rowptr, const int *loc_col, const double *loc_val, int *block_rowstart,
+                               int *rowptr, int *col, double *val, int *counter, int *is_interface, int *n_i2g, int *i2g);
 int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o);
 /* the options-database keys of the FETI chain (-feti_gluing_type, -feti_gluing_exclude_dirichlet, -SCALE_ON, -regularize,
    -qpt_dualize_Kplus_mp, -dual_pc_dual_type, -qps_rtol/-qps_atol/-qps_divtol/-qps_max_it, -dual_mat_inv_ksp_rtol/_max_it) */

@@ -234,6 +234,7 @@ _PROTOS = {
     "pmh_qps_default_opts": [C.POINTER(QpsOpts)],
     "pmh_qps_set_from_options": [C.c_char_p, C.c_char_p, C.POINTER(QpsOpts), C.POINTER(MpgpOpts), C.POINTER(SmalxeOpts), C.c_char_p, C.c_int],
     "pmh_qpt_matis_split_rhs": [C.c_int, vp, C.c_int, vp, vp],
+    "pmh_qpt_matis_to_blockdiag": [C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int_p, vp],
     "pmh_qpt_matis_assemble_solution": [C.c_int, vp, vp, C.c_int, vp],
     "pmh_kspfeti_default_opts": [C.POINTER(KspFetiOpts)],
     "pmh_kspfeti_set_from_options": [C.c_char_p, C.POINTER(KspFetiOpts), C.c_char_p, C.c_int],

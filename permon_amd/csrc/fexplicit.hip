@@ -56,7 +56,7 @@ struct pmh_fexplicit_s {
   int     *d_sw_block, *d_sw_band, *d_sw_seg; // SYM launch table: workgroup -> (block, super band, column segment)
   int     *d_fw_block, *d_fw_col0; // SYM second launch: workgroup -> (block, first of its 128 columns)
   int     *d_own_ptr, *d_own_list; // SYM: per block the ascending list of the super bands this rank owns
-  int      nsw, nfw;
+  int      nsw, nfw, seg; // seg: tile columns per workgroup of k_fx_symv
   double   sym_bytes;      // SYM: algorithmic bytes of one apply
   double  *xh, *yh;        // compressed work vectors
   int      assembled;
@@ -153,11 +153,12 @@ __host__ __device__ __forceinline__ long long fx_sym_size(int npad) { return fx_
 // written ONCE per 128 rows (partial[s][c]: n^2/256 entries, 1.6 % of the matrix bytes -- written per band they cost 22 % of the
 // kernel time, measured); the direct sums stay in registers across the segment and end in ydseg[j][row].  Every workgroup moves
 // the same 2 MB (except the last segment of a super band), so the grid balances at any block count.
-#define FX_SEG 16
+#define FX_SEG_MIN 2
+#define FX_SEG_MAX 16 // tile columns per workgroup: 16, or fewer when the rank's share is small (see fx_pick_seg)
 template <int VAR>
 __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ sw_block, const int *__restrict__ sw_sband, const int *__restrict__ sw_seg, const int *__restrict__ gstart, const int *__restrict__ ldv,
                                                       const long long *__restrict__ woff, const long long *__restrict__ poff, const long long *__restrict__ doff, const double *__restrict__ Wbase,
-                                                      const double *__restrict__ xh, double *__restrict__ ydseg, double *__restrict__ partial)
+                                                      const double *__restrict__ xh, double *__restrict__ ydseg, double *__restrict__ partial, int FX_SEG)
 {
   __shared__ dbl2 zred[2][PMH_BLOCK / 64][64];
   const int b = __builtin_amdgcn_readfirstlane(sw_block[blockIdx.x]), sb = __builtin_amdgcn_readfirstlane(sw_sband[blockIdx.x]), seg = __builtin_amdgcn_readfirstlane(sw_seg[blockIdx.x]);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ s
 // One workgroup per 128 columns of a block.
 __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv_fin(const int *__restrict__ fw_block, const int *__restrict__ fw_col0, const int *__restrict__ gstart, const int *__restrict__ ldv, const long long *__restrict__ poff,
                                                           const long long *__restrict__ doff, const int *__restrict__ own_ptr, const int *__restrict__ own_list, const double *__restrict__ ydseg,
-                                                          const double *__restrict__ partial, double *__restrict__ yh)
+                                                          const double *__restrict__ partial, double *__restrict__ yh, int FX_SEG)
 {
   __shared__ dbl2 red[PMH_BLOCK / 64][64];
   const int b = fw_block[blockIdx.x], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -288,6 +289,47 @@ static int fx_upload_owned(pmh_fexplicit E)
   lst.push_back(0);
   PMH_CHK(pmh_memcpy_h2d(E->ctx, E->d_own_ptr, ptr.data(), sizeof(int) * (E->nb + 1)));
   return pmh_memcpy_h2d(E->ctx, E->d_own_list, lst.data(), sizeof(int) * std::max<size_t>(1, lst.size() - 1));
+}
+
+// launch table of k_fx_symv for the super bands this rank owns, largest first; picks the segment length (tile columns per workgroup):
+// 16 unless that leaves fewer than ~6 rounds of workgroups on the chip (256 CUs x 2 resident), then 8, 4 or 2 -- a rank's 1/8 share
+// of configs[2] would otherwise run 2.2 rounds of equal 2 MB workgroups, i.e. a third of the last round idle.  Also the algorithmic
+// bytes of one apply of this rank's share.
+static int fx_build_launch(pmh_fexplicit E)
+{
+  const int nb = E->nb;
+  int       maxsb = 0;
+  for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
+  int seg = FX_SEG_MAX;
+  if (const char *e = getenv("PMH_FX_SEG")) seg = std::max(FX_SEG_MIN, std::min(FX_SEG_MAX, atoi(e)));
+  else
+    for (; seg > FX_SEG_MIN; seg /= 2) {
+      long long n = 0;
+      for (int b = 0; b < nb; b++)
+        for (int sb = 0; sb < E->ld[b] / FX_TC; sb++)
+          if (E->owned[b][sb]) n += (sb + seg) / seg;
+      if (n >= 6 * 512) break;
+    }
+  E->seg = seg;
+  std::vector<int> swb, swk, swj;
+  for (int sb = maxsb - 1; sb >= 0; sb--)
+    for (int b = 0; b < nb; b++)
+      if (sb < E->ld[b] / FX_TC && E->owned[b][sb])
+        for (int j = 0; j * seg < sb + 1; j++) swb.push_back(b), swk.push_back(sb), swj.push_back(j);
+  E->nsw = (int)swb.size();
+  swb.push_back(0), swk.push_back(0), swj.push_back(0);
+  PMH_CHK(pmh_memcpy_h2d(E->ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size()));
+  PMH_CHK(pmh_memcpy_h2d(E->ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
+  PMH_CHK(pmh_memcpy_h2d(E->ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+  PMH_CHK(fx_upload_owned(E));
+  E->sym_bytes = 0.0;
+  for (int b = 0; b < nb; b++) {
+    const int nsb = E->ld[b] / FX_TC;
+    for (int sb = 0; sb < nsb; sb++)
+      if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 2.0 * 8.0 * FX_TC * (sb + 1) + 2.0 * 8.0 * 128.0 * ((sb + seg) / seg); // its tiles, its partial row and its direct sums written + read back
+    E->sym_bytes += 16.0 * E->ld[b]; // x read, y written
+  }
+  return PMH_SUCCESS;
 }
 
 // SYM: the part of row j = 32 k + r that lies in its band, into the band's tiles: element (r, i) at (i / 128) tiles + r * 128 + i % 128
@@ -376,28 +418,18 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_block, wb.data(), sizeof(int) * E->nwg));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_wg_row0, wr.data(), sizeof(int) * E->nwg));
   }
-  if (storage == PMH_FX_SYM) { // partial / direct-product buffers and the launch table (super band, segment), largest super bands first
+  if (storage == PMH_FX_SYM) { // partial / direct-product buffers (sized for the shortest segments) and the launch table
     std::vector<long long> poff(nb), doff(nb);
-    long long              ptot = 0, dtot = 0;
-    std::vector<int>       swb, swk, swj;
-    int                    maxsb = 0;
-    for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
+    long long              ptot = 0, dtot = 0, wgmax = 0;
     for (int b = 0; b < nb; b++) {
-      const int nsb = E->ld[b] / FX_TC, nsegmax = (nsb + FX_SEG - 1) / FX_SEG;
+      const int nsb = E->ld[b] / FX_TC;
       poff[b] = ptot, doff[b] = dtot;
       ptot += (long long)nsb * E->ld[b];
-      dtot += (long long)nsegmax * E->ld[b];
-      // stored matrix once + partials written and read (triangle of 128-column rows) + direct sums written and read + x, y
-      E->sym_bytes += 8.0 * (double)fx_sym_size(E->ld[b]) + 2.0 * 8.0 * FX_TC * 0.5 * (double)nsb * (nsb + 1) + 2.0 * 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b];
+      dtot += (long long)((nsb + FX_SEG_MIN - 1) / FX_SEG_MIN) * E->ld[b];
+      for (int sb = 0; sb < nsb; sb++) wgmax += (sb + FX_SEG_MIN) / FX_SEG_MIN;
     }
     E->owned.assign(nb, std::vector<char>());
     for (int b = 0; b < nb; b++) E->owned[b].assign(E->ld[b] / FX_TC, 1);
-    for (int sb = maxsb - 1; sb >= 0; sb--)
-      for (int b = 0; b < nb; b++)
-        if (sb < E->ld[b] / FX_TC)
-          for (int j = 0; j * FX_SEG < sb + 1; j++) swb.push_back(b), swk.push_back(sb), swj.push_back(j);
-    E->nsw = (int)swb.size();
-    swb.push_back(0), swk.push_back(0), swj.push_back(0);
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(1LL, ptot), (void **)&E->partial));
     PMH_CHK(pmh_memset(ctx, E->partial, 0, sizeof(double) * (size_t)std::max(1LL, ptot)));
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(1LL, dtot), (void **)&E->ydir));
@@ -406,12 +438,10 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_poff, poff.data(), sizeof(long long) * nb));
     PMH_CHK(pmh_malloc(ctx, sizeof(long long) * nb, (void **)&E->d_doff));
     PMH_CHK(pmh_memcpy_h2d(ctx, E->d_doff, doff.data(), sizeof(long long) * nb));
-    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swb.size(), (void **)&E->d_sw_block));
-    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swk.size(), (void **)&E->d_sw_band));
-    PMH_CHK(pmh_malloc(ctx, sizeof(int) * swj.size(), (void **)&E->d_sw_seg));
-    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size()));
-    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
-    PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(wgmax + 1), (void **)&E->d_sw_block));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(wgmax + 1), (void **)&E->d_sw_band));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(wgmax + 1), (void **)&E->d_sw_seg));
+    PMH_CHK(fx_build_launch(E));
     PMH_CHK(fx_upload_owned(E));
     std::vector<int> fwb, fwc;
     for (int b = 0; b < nb; b++)
@@ -487,34 +517,13 @@ extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
   const int nb  = E->nb;
   int       maxsb = 0;
   for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
-  std::vector<int> swb, swk, swj;
-  int              idx = 0;
+  int idx = 0;
   for (int sb = maxsb - 1; sb >= 0; sb--)
     for (int b = 0; b < nb; b++)
-      if (sb < E->ld[b] / FX_TC) {
-        const bool mine  = (idx++ % size) == rank;
-        E->owned[b][sb]  = mine ? 1 : 0;
-        if (mine)
-          for (int j = 0; j * FX_SEG < sb + 1; j++) swb.push_back(b), swk.push_back(sb), swj.push_back(j);
-      }
-  E->nsw = (int)swb.size();
-  swb.push_back(0), swk.push_back(0), swj.push_back(0);
-  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_block, swb.data(), sizeof(int) * swb.size())); // the tables were sized for all super bands
-  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_band, swk.data(), sizeof(int) * swk.size()));
-  PMH_CHK(pmh_memcpy_h2d(ctx, E->d_sw_seg, swj.data(), sizeof(int) * swj.size()));
+      if (sb < E->ld[b] / FX_TC) E->owned[b][sb] = ((idx++ % size) == rank) ? 1 : 0;
   E->stripe_rank = rank, E->stripe_size = size;
-  PMH_CHK(fx_upload_owned(E));
-  // algorithmic bytes of this rank's share
-  E->sym_bytes = 0.0;
-  for (int b = 0; b < nb; b++) {
-    const int nsb = E->ld[b] / FX_TC, nsegmax = (nsb + FX_SEG - 1) / FX_SEG;
-    for (int sb = 0; sb < nsb; sb++)
-      if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 8.0 * FX_TC * (sb + 1); // its tiles + its partial row written
-    for (int sb = 0; sb < nsb; sb++)
-      if (E->owned[b][sb]) E->sym_bytes += 8.0 * FX_TC * (sb + 1); // ... and read back by the finishing pass
-    E->sym_bytes += 8.0 * E->ld[b] * (0.5 * (nsegmax + 1)) + 16.0 * E->ld[b];
-  }
-  return PMH_SUCCESS;
+  (void)ctx;
+  return fx_build_launch(E);
 }
 
 // host helper: classes of identical diagonal blocks of a block-diagonal CSR (same size, pattern and values, bit for bit)
@@ -723,14 +732,14 @@ static int fx_gemv(pmh_fexplicit E)
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used], st));
     }
     static const int var = getenv("PMH_FX_SYMV_VARIANT") ? atoi(getenv("PMH_FX_SYMV_VARIANT")) : 0;
-#define SYMV_LAUNCH(V) hipLaunchKernelGGL(k_fx_symv<V>, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_sw_seg, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff, (const long long *)E->d_poff, (const long long *)E->d_doff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial)
+#define SYMV_LAUNCH(V) hipLaunchKernelGGL(k_fx_symv<V>, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_sw_seg, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff, (const long long *)E->d_poff, (const long long *)E->d_doff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial, E->seg)
     if (var == 1) SYMV_LAUNCH(1);
     else SYMV_LAUNCH(0);
 #undef SYMV_LAUNCH
     if (timed) PMH_HIP(hipEventRecord(E->ev_mid[E->ev_used], st));
     if (E->nfw)
       hipLaunchKernelGGL(k_fx_symv_fin, dim3(E->nfw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_fw_block, (const int *)E->d_fw_col0, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_poff,
-                         (const long long *)E->d_doff, (const int *)E->d_own_ptr, (const int *)E->d_own_list, (const double *)E->ydir, (const double *)E->partial, E->yh);
+                         (const long long *)E->d_doff, (const int *)E->d_own_ptr, (const int *)E->d_own_list, (const double *)E->ydir, (const double *)E->partial, E->yh, E->seg);
     if (timed) {
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used + 1], st));
       E->ev_used++;

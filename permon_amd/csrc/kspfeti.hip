@@ -272,3 +272,55 @@ extern "C" int pmh_qpt_matis_assemble_solution(int N, const int *l2g, const doub
   }
   return PMH_SUCCESS;
 }
+
+// QPTMatISToBlockDiag, matrix side (qptransform.c:2007-2150): the MATIS operator -- one unassembled local matrix per subdomain plus its
+// local-to-global map -- becomes the MATBLOCKDIAG of the child QP (MatCreateBlockDiag(comm, matis->A), :2044-2046), and the mapping
+// yields what the rest of the transform needs: matis->counter (how many subdomains share a dof: the scaling D = 1/counter of the
+// right-hand side, :2095-2104), the interface / interior split of the local dofs (PetscBT over the shared nodes, :2057-2071) and
+// i2g, the sorted global numbers of the interface dofs (:2123-2125, QPFetiSetInterfaceToGlobalMapping).  Host routine (set-up, integers).
+// loc_rowptr: the subdomains' CSR row pointers one after the other (n_s + 1 entries each, every block starting at 0), loc_col local
+// column indices, loc_val values; out: the block-diagonal CSR in the concatenated local numbering (rowptr N + 1, col / val nnz).
+extern "C" int pmh_qpt_matis_to_blockdiag(int nsub, const int *l2g_start, const int *l2g, int n_global, const int *loc_rowptr, const int *loc_col, const double *loc_val, int *block_rowstart,
+                                          int *rowptr, int *col, double *val, int *counter, int *is_interface, int *n_i2g, int *i2g)
+{
+  PMH_ARG(nsub >= 1 && l2g_start && l2g && n_global >= 0 && loc_rowptr && block_rowstart && rowptr && n_i2g);
+  const int N = l2g_start[nsub];
+  PMH_ARG(l2g_start[0] == 0);
+  std::vector<int> mult((size_t)std::max(1, n_global), 0);
+  for (int i = 0; i < N; i++) {
+    if (l2g[i] < 0 || l2g[i] >= n_global) return pmh_set_error(PMH_ERR_ARG, "pmh_qpt_matis_to_blockdiag: l2g[%d] = %d out of [0,%d)", i, l2g[i], n_global);
+    mult[l2g[i]]++;
+  }
+  long long knz = 0; // running non-zero offset of the block diagonal
+  int       rp0 = 0; // running offset into loc_rowptr
+  rowptr[0] = 0;
+  for (int s = 0; s < nsub; s++) {
+    const int lo = l2g_start[s], n = l2g_start[s + 1] - lo;
+    block_rowstart[s] = lo;
+    const int *rp = loc_rowptr + rp0;
+    if (rp[0] != 0) return pmh_set_error(PMH_ERR_ARG, "pmh_qpt_matis_to_blockdiag: the row pointers of subdomain %d do not start at 0", s);
+    for (int i = 0; i < n; i++) {
+      for (int k = rp[i]; k < rp[i + 1]; k++) {
+        const int c = loc_col[knz + k - 0];
+        if (c < 0 || c >= n) return pmh_set_error(PMH_ERR_ARG, "pmh_qpt_matis_to_blockdiag: subdomain %d, row %d: column %d out of [0,%d)", s, i, c, n);
+        if (col) col[knz + k] = c + lo;
+        if (val) val[knz + k] = loc_val[knz + k];
+      }
+      rowptr[lo + i + 1] = (int)(knz + rp[i + 1]);
+    }
+    knz += rp[n];
+    rp0 += n + 1;
+  }
+  block_rowstart[nsub] = N;
+  std::vector<int> inter;
+  for (int i = 0; i < N; i++) {
+    const int m = mult[l2g[i]];
+    if (counter) counter[i] = m;
+    if (is_interface) is_interface[i] = m > 1;
+  }
+  for (int g = 0; g < n_global; g++)
+    if (mult[g] > 1) inter.push_back(g);
+  *n_i2g = (int)inter.size();
+  if (i2g) std::copy(inter.begin(), inter.end(), i2g);
+  return PMH_SUCCESS;
+}

@@ -55,3 +55,26 @@ def test_rehearsal_and_other_workloads_small():
     assert KEYS <= set(d) and d["config"]["workload"].startswith("configs[4]")
     d = _run("--sub", "2,2,1", "--nel", "5", "--dense-coarse", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c2")
     assert d["config"]["coarse_problem"]["m"] == 24 and d["config"]["coarse_problem"]["GGt_mfma_ms"] > 0
+
+
+def test_forced_distributed_path_on_one_rank():
+    """The N > 1 code path of bench.py on ONE rank (no 8-GPU node is available to the builder): torch.distributed rendezvous over
+    RCCL, ncclUniqueId broadcast, pmh_comm_init, and -- with PMH_COMM_FORCE=1 -- every all-reduce of the data path really issued on
+    the 1-rank communicator (B u in pmh_gluing_mult_transpose; the grouped scalar all-reduces and w of the SVM workload).  The line
+    must carry rccl_ranks and the same checksum, bit for bit, as the local mode."""
+    env = dict(os.environ, PMH_BENCH_FORCE_DIST="1", PMH_COMM_FORCE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+
+    def run(envv, *args):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900, env=envv)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+
+    for args in (("--nel", "7", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"),
+                 ("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"),
+                 ("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2")):
+        loc = run(dict(os.environ), *args)
+        dst = run(env, *args)
+        assert loc["config"]["rccl_ranks"] is None and dst["config"]["rccl_ranks"] == 1
+        assert loc["config"]["checksum"] == dst["config"]["checksum"], (loc["config"]["checksum"], dst["config"]["checksum"])
+        for k in ("cg", "expansion", "proportioning", "hessian_mults"):
+            assert loc["config"]["steps_by_type"][k] == dst["config"]["steps_by_type"][k]

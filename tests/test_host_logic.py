@@ -165,3 +165,43 @@ def test_host_kplus_mg_restatement_vs_pinv():
     ref = np.concatenate([ref1 @ rhs[:f.n_i], ref1 @ rhs[f.n_i:]])
     assert np.linalg.norm(u - ref) <= 1e-9 * np.linalg.norm(ref)
     assert 0 < Kp.last_its < 40
+
+
+def test_matis_to_blockdiag_matrix_side():
+    """QPTMatISToBlockDiag, matrix side (qptransform.c:2007-2150): local matrices + l2g -> block-diagonal CSR, matis->counter,
+    interface flags and the sorted i2g, against scipy / numpy on the ex71 decomposition (host routine: no GPU needed)."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+
+    import permon_amd as pa
+
+    L = pa.load()
+    f = pa.DmdaFeti(cells=(5, 4, 3), size=4, physics="elasticity")
+    blocks = [b.tocsr() for b in f.blocks]
+    for b in blocks:
+        b.sort_indices()
+    nd = f.ndof
+    l2g = [(np.asarray(g)[:, None] * nd + np.arange(nd)[None, :]).ravel() for g in f.gids]
+    start = np.concatenate([[0], np.cumsum([len(g) for g in l2g])]).astype(np.int32)
+    cat = np.concatenate(l2g).astype(np.int32)
+    ng = int(cat.max()) + 1
+    lrp = np.concatenate([b.indptr for b in blocks]).astype(np.int32)
+    lci = np.concatenate([b.indices for b in blocks]).astype(np.int32)
+    lva = np.concatenate([b.data for b in blocks])
+    N, nnz = int(start[-1]), lva.size
+    brs, rp, ci, va = np.zeros(len(blocks) + 1, np.int32), np.zeros(N + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+    cnt, isb, i2g, n_i2g = np.zeros(N, np.int32), np.zeros(N, np.int32), np.zeros(ng, np.int32), C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    pa._lib.check(L.pmh_qpt_matis_to_blockdiag(len(blocks), p(start), p(cat), ng, p(lrp), p(lci), p(lva), p(brs), p(rp), p(ci), p(va), p(cnt), p(isb), C.byref(n_i2g), p(i2g)))
+    K = sp.csr_matrix((va, ci, rp), shape=(N, N))
+    ref = sp.block_diag(blocks, format="csr")
+    assert (K != ref).nnz == 0 and np.array_equal(brs, start)
+    mult = np.bincount(cat, minlength=ng)
+    assert np.array_equal(cnt, mult[cat]) and np.array_equal(isb, (mult[cat] > 1).astype(np.int32))
+    assert np.array_equal(i2g[:n_i2g.value], np.nonzero(mult > 1)[0])
+    # the vector part uses the same counter: b_local = b_global / counter
+    bg = np.random.default_rng(0).standard_normal(ng)
+    fl = np.zeros(N)
+    pa._lib.check(L.pmh_qpt_matis_split_rhs(N, p(cat), ng, p(bg), p(fl)))
+    assert np.allclose(fl, bg[cat] / cnt)
