@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--kplus-pc", choices=["mg", "jacobi"], default="mg", help="feti: PC of the inner CG of K^+ (-mat_inv_pc_type): multigrid V-cycle or Jacobi")
     ap.add_argument("--mg-precision", choices=["fp16", "fp32", "fp64"], default="fp16", help="feti: precision of the V-cycle (it only preconditions the fp64 CG)")
     ap.add_argument("--mg-min-nodes", type=int, default=0, help="feti: the hierarchy stops coarsening at <= this many nodes per block (dense block pseudo-inverse there); 0 = by blocks per GPU")
+    ap.add_argument("--mg-builder", choices=["c", "python"], default="c", help="feti: who builds the V-cycle hierarchy of the GPU solver: pmh_mg_create_box inside the library, or permon_amd.feti.box_mg_hierarchy (scipy)")
     ap.add_argument("--mg-degree", type=int, default=2, help="feti: Chebyshev degree of the V-cycle smoother")
     ap.add_argument("--regularize", action="store_true", help="feti: K^+ = K_reg^{-1} with K_reg = MatRegularize(K, R) (the reference's default, -regularize 1) instead of the Moore-Penrose wrapping "
                     "P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp); identical on the projected dual problem, the V-cycle hierarchy is then built per block on K_reg")
@@ -400,7 +401,15 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         auto_nodes = min(auto_nodes, nn ** 3 // 8)  # tiny test problems: at least one smoothed level
         return pa.box_mg_hierarchy(blks, [(nn, nn, nn)] * len(blks), 3, min_nodes=a.mg_min_nodes or auto_nodes)
 
-    hier = make_hier(blocks, per) if a.kplus_pc == "mg" else None
+    # the V-cycle hierarchy of the GPU solver is built inside the library (pmh_mg_create_box, host C++); the scipy builder is only
+    # run where its output is needed on the host: the CPU baseline leg (rank 0 at N = 1) and --mg-builder python
+    need_py_hier = a.kplus_pc == "mg" and (a.mg_builder == "python" or a.regularize or (world == 1 and not a.sim_world and not a.no_cpu_baseline))
+    hier = make_hier(blocks, per) if need_py_hier else None
+    use_c_builder = a.kplus_pc == "mg" and a.mg_builder == "c" and not a.regularize
+
+    def mg_box(nblk):
+        auto_nodes = 2000 if nblk <= (4 if a.mg_precision == "fp16" else 1) else 400
+        return dict(dims=[(nn, nn, nn)] * nblk, ndof=3, min_nodes=a.mg_min_nodes or min(auto_nodes, nn ** 3 // 8))
     explicit = None
     replica = {}
     if a.kplus == "explicit":
@@ -412,7 +421,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             M = pa.MatInv(Kb, rtol=a.explicit_rtol, max_it=20000, jacobi=True, nullspace=Rb)
             if not a.no_bsr3:
                 M.enable_bsr3()
-            if a.kplus_pc == "mg":
+            if use_c_builder:
+                mb = mg_box(nslots)
+                M.set_pc_mg_box(sp.block_diag([f.Ki] * nslots, format="csr"), mb["dims"], 3, R=Rb, min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=a.mg_precision)
+            elif a.kplus_pc == "mg":
                 M.set_pc_mg(make_hier([f.Ki] * nslots, nslots), degree=a.mg_degree, precision=a.mg_precision)
             replica["M"], replica["K"] = M, Kb
             return M
@@ -422,8 +434,19 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if nshare > 1 and a.explicit_storage == "sym" and not a.regularize and not a.no_stripe:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
             explicit["stripe"] = (rank, nshare, dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign))
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=hier, mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3,
-                   regularize=a.regularize, explicit=explicit)
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if use_c_builder else None,
+                   mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3, regularize=a.regularize, explicit=explicit)
+    has_mg = a.kplus_pc == "mg"
+
+    def switch_mg(precision):
+        """Replace the V-cycle of the inner KSP by one in another precision (same hierarchy, same builder)."""
+        old = q.Kplus.mg
+        if use_c_builder:
+            mb = mg_box(per)
+            q.Kplus.set_pc_mg_box(local["K"], mb["dims"], 3, R=local["R"], min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=precision)
+        else:
+            q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision=precision)
+        old.destroy()
     if replica:  # the replica solver is set-up scaffolding: release it
         if getattr(replica["M"], "mg", None) is not None:
             replica["M"].mg.destroy()
@@ -474,20 +497,21 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
     full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world)
     kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
-    pc_text = ("multigrid-preconditioned CG (%d-level Galerkin V-cycle in %s, Chebyshev(%d)/Jacobi smoothing)" % (len(hier["A"]), a.mg_precision, a.mg_degree)) if hier is not None else "Jacobi-CG"
+    pc_text = ("multigrid-preconditioned CG (Galerkin V-cycle in %s built by %s, dense coarse solve at <= %d nodes per block, Chebyshev(%d)/Jacobi smoothing)"
+               % (a.mg_precision, "pmh_mg_create_box" if use_c_builder else "permon_amd.feti.box_mg_hierarchy", mg_box(per)["min_nodes"], a.mg_degree)) if has_mg else "Jacobi-CG"
 
     def iterative_pass(nsteps, nwarm, precision):
         """The inner-Krylov K^+ (the reference's iterative MATINV path): block-wise CG with the V-cycle PC in `precision`."""
         os.environ.setdefault("PMH_TIMING_STRIDE", "5")  # event pairs around every 5th K x launch (coprime to the 4 fine-level launches of a cycle)
         if want_timing:
             q.Kplus.timing_enable(8000)
-            if hier is not None:
+            if has_mg:
                 q.Kplus.mg.timing_enable(8000)
         _, spmv1 = q.Kplus.last_iterations()
-        mgs1 = q.Kplus.mg.fine_spmv() if hier is not None else 0
+        mgs1 = q.Kplus.mg.fine_spmv() if has_mg else 0
         dt, cnt = timed_pass(nsteps, nwarm)
         kits, spmv2 = q.Kplus.last_iterations()
-        mgs2 = q.Kplus.mg.fine_spmv() if hier is not None else 0
+        mgs2 = q.Kplus.mg.fine_spmv() if has_mg else 0
         stride = int(os.environ.get("PMH_TIMING_STRIDE", "1"))
         n_cg, ms_cg, b_cg = q.Kplus.timing_get() if want_timing else (0, 0.0, 0.0)
         cg_GBs = b_cg / (ms_cg / n_cg * 1e-3) / 1e9 if n_cg else 0.0
@@ -498,7 +522,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         roof = {"bound": "hbm", "kernel": kname, "achieved": cg_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_GBs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": b_cg, "launches_timed": n_cg, "avg_launch_ms": ms_cg / n_cg if n_cg else None, "timing_stride": stride,
                 "share_of_step_time": (ms_cg * 1e-3) * stride / dt if n_cg else None}
-        if hier is not None and want_timing:
+        if has_mg and want_timing:
             n_k, ms_k, b_k = q.Kplus.mg.timing_get()
             pk = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
             ppat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[precision]
@@ -507,7 +531,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                                       "achieved": pk, "frac": pk / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
                                       "share_of_step_time": (ms_k * 1e-3) * stride / dt if n_k else None, "traffic": ptraffic, "traffic_source": ptsrc}
         q.Kplus.timing_enable(0)
-        if hier is not None:
+        if has_mg:
             q.Kplus.mg.timing_enable(0)
         return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "steps": nsteps, "warmup": nwarm, "steps_by_type": cnt,
                 "kplus": "block-wise %s%s (rtol %.0e)" % (pc_text.replace(a.mg_precision, precision), kreg_text, a.kplus_rtol),
@@ -548,10 +572,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if world == 1 and not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and strict fp64
             q.Kplus.attach_explicit(None)
             extra["iterative"] = iterative_pass(min(steps, 108), 4, a.mg_precision)
-            if hier is not None and a.mg_precision != "fp64":
-                old = q.Kplus.mg
-                q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
-                old.destroy()
+            if has_mg and a.mg_precision != "fp64":
+                switch_mg("fp64")
                 extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
                 extra["strict_fp64"]["note"] = "every operator, vector and the V-cycle in fp64 (the reference's arithmetic throughout)"
             q.Kplus.attach_explicit(E)
@@ -563,11 +585,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kplus_cfg = {"path": "iterative", "pc": a.kplus_pc, "cg_spmv_per_step": r["cg_spmv_per_step"], "vcycle_fine_spmv_per_step": r["vcycle_fine_spmv_per_step"], "last_block_cg_iterations": r["last_block_cg_iterations"]}
         kplus_text = "block-wise %s K^+%s (rtol %.0e)" % (pc_text, kreg_text, a.kplus_rtol)
         precision_note = ("the reduced precision (%s) lives ONLY in the V-cycle that preconditions the block CG of K^+: that CG's operator, residual, stopping test (rtol %.0e) and solution "
-                          "are fp64, as is everything in the dual space" % (a.mg_precision, a.kplus_rtol)) if hier is not None else "fp64 throughout"
-        if world == 1 and not a.sim_world and hier is not None and a.mg_precision != "fp64" and not a.no_iterative:
-            old = q.Kplus.mg
-            q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision="fp64")
-            old.destroy()
+                          "are fp64, as is everything in the dual space" % (a.mg_precision, a.kplus_rtol)) if has_mg else "fp64 throughout"
+        if world == 1 and not a.sim_world and has_mg and a.mg_precision != "fp64" and not a.no_iterative:
+            switch_mg("fp64")
             extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
     comm_rank, comm_size = ctx.comm_rank()
     res = {

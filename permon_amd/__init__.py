@@ -8,4 +8,4 @@ from .core import Context, CsrMat, Op, Vec  # noqa: F401
 from .qps import QP, QPS  # noqa: F401
 from .mat import MG, MatBlockDiag, MatExplicitDual, csr_block_classes, MatCreateFetiDual, MatCreatePenalized, MatCreateProjected, MatCreateSVMDual, MatExtension, MatGluing, MatInv, MatRegularize, PCDualLumpedOp, QPPF  # noqa: F401,E402
 from .feti import CubeFeti, DmdaFeti, box_mg_hierarchy, gluing_from_l2g, gluing_links  # noqa: F401,E402
-from .chain import FetiDualQP, KSPFETISolve, regularize_blocks  # noqa: F401,E402
+from .chain import FetiDualQP, FETIContactSolve, KSPFETISolve, regularize_blocks  # noqa: F401,E402

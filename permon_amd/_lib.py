@@ -73,7 +73,8 @@ class QpsOpts(C.Structure):
 
 class KspFetiOpts(C.Structure):
     _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
-                ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int)]
+                ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int),
+                ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double)]
 
 
 class KspFetiStats(C.Structure):
@@ -243,6 +244,7 @@ _PROTOS = {
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],
+    "pmh_fexplicit_stripe_bytes": [C.c_int, vp, C.c_int, c_double_p],
     "pmh_fexplicit_assemble": [vp, vp, C.c_int, vp, vp, C.c_double, C.c_int],
     "pmh_fexplicit_fill_pattern": [vp, C.c_int],
     "pmh_fexplicit_assemble_stats": [vp, C.POINTER(C.c_longlong), c_double_p],

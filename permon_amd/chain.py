@@ -46,7 +46,7 @@ class FetiDualQP:
     """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
 
     def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False,
-                 regularize=False, explicit=None):
+                 regularize=False, explicit=None, mg_box=None):
         """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
         lb: dual lower bound (-inf on equality rows, 0 on inequality rows).
         regularize: the reference's default (-regularize 1, QPTDualize -> MatInvSetRegularizationType(MAT_REG_EXPLICIT),
@@ -72,6 +72,9 @@ class FetiDualQP:
             self.Kplus.enable_bsr3()
         if mg_hierarchy is not None:  # -mat_inv_pc_type mg: V-cycle PC for the inner CG (feti.box_mg_hierarchy)
             self.Kplus.set_pc_mg(mg_hierarchy, degree=mg_degree, precision=mg_precision)
+        elif mg_box is not None:  # the same PC, hierarchy built inside the library (pmh_mg_create_box): dict(dims=[(nx, ny, nz)], ndof, min_nodes)
+            self.Kplus.set_pc_mg_box(self._Kinv_sp, mg_box["dims"], mg_box["ndof"], R=None if regularize else local["R"], min_nodes=mg_box.get("min_nodes", 400),
+                                     degree=mg_degree, precision=mg_precision)
         self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
         self.E = None
         if explicit is not None:
@@ -217,7 +220,7 @@ class FetiDualQP:
 
 
 def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, gluing="full", scale=True, exclude_dirichlet=False, regularize=True, lumped=False,
-                 rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000, options=None, regularize_rho=0.0):
+                 rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000, options=None, regularize_rho=0.0, explicit=False):
     """KSPFETI (src/ksp/impls/feti/feti.c:71-156) for a decomposed linear problem, one call into pmh_kspfeti_solve (C++):
     K block-diagonal scipy CSR, f split among copies, l2g global dof of every local dof, dirichlet_local = local dofs enforced
     by B (TFETI) or None, R = (kdim, N) kernel vectors (zero over non-floating blocks) or None.
@@ -239,6 +242,7 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     o.gluing_type, o.scale, o.exclude_dirichlet = {"nonred": 0, "full": 1, "orth": 2}[gluing], int(bool(scale)), int(bool(exclude_dirichlet))
     o.regularize, o.lumped_pc, o.regularize_rho = int(bool(regularize)), int(bool(lumped)), float(regularize_rho)
     o.kplus_rtol, o.kplus_max_it, o.rtol, o.atol, o.divtol, o.max_it = kplus_rtol, kplus_max_it, rtol, atol, divtol, max_it
+    o.explicit_dual = int(bool(explicit))  # F through the explicit local dual operators (pmh_fexplicit_*)
     if options:  # the reference's command line on top of the keyword arguments (pmh_kspfeti_set_from_options)
         left = C.create_string_buffer(2048)
         check(ctx.L.pmh_kspfeti_set_from_options(options.encode(), C.byref(o), left, len(left)))
@@ -249,3 +253,28 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
     check(ctx.L.pmh_kspfeti_solve(ctx.h, rs.size - 1, p(rs), p(ip), p(ci), p(va), p(fv), p(lg), dl.size, p(dl), Rm.shape[0], p(Rm), C.byref(o), p(u), p(lam), cap, C.byref(st)))
     return u, lam[:st.n_lambda].copy(), st
+
+
+def FETIContactSolve(ctx, f, explicit=True, mg_precision="fp16", rtol=1e-5, kplus_rtol=1e-9, explicit_rtol=1e-12, mg_min_nodes=400, dims=None):
+    """pmh_feti_contact_solve (contact.hip): the whole contact TFETI solve in ONE library call -- QPTFromOptions / QPTAllInOne
+    (qptransform.c:2152-2237) + QPSSolve + the post-solve chain; f: a CubeFeti-like problem (K, f, leaves, c, R, n_eq).
+    Returns (u, lambda, stats: _lib.FetiContactStats)."""
+    from . import _lib
+
+    K = f.K.tocsr()
+    K.sort_indices()
+    o, st = _lib.FetiContactOpts(), _lib.FetiContactStats()
+    check(ctx.L.pmh_feti_contact_default_opts(C.byref(o)))
+    o.smalxe.rtol, o.kplus_rtol, o.explicit_dual, o.explicit_rtol = rtol, kplus_rtol, int(bool(explicit)), explicit_rtol
+    o.mg_precision, o.mg_min_nodes = {"fp64": 0, "fp32": 1, "fp16": 2}[mg_precision], int(mg_min_nodes)
+    if dims is None and hasattr(f, "nel"):
+        dims = [(f.nel + 1,) * 3] * f.nsub
+    a32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    a64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    arrs = dict(rs=a32(f.block_rowstart), ip=a32(K.indptr), ci=a32(K.indices), va=a64(K.data), ff=a64(f.f), lr=a32(f.leaves_row), lo=a32(f.leaves_root), ls=a64(f.leaves_sign),
+                cc=a64(f.c), R=a64(f.R), dm=a32(dims) if dims is not None else None)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    u, lam = np.zeros(f.N), np.zeros(f.n_lambda)
+    check(ctx.L.pmh_feti_contact_solve(ctx.h, f.nsub, p(arrs["rs"]), p(arrs["ip"]), p(arrs["ci"]), p(arrs["va"]), p(arrs["ff"]), f.n_lambda, f.n_eq, arrs["lr"].size, p(arrs["lr"]), p(arrs["lo"]),
+                                       p(arrs["ls"]), p(arrs["cc"]), arrs["R"].shape[0], p(arrs["R"]), p(arrs["dm"]), f.ndof, C.byref(o), p(u), p(lam), C.byref(st)))
+    return u, lam, st

@@ -508,6 +508,39 @@ extern "C" int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma, 
 // and B u is all-reduced anyway, so a rank may apply any rows of any W_b: y_rank = Bhat (rows it owns of blockdiag(W_b)) Bhat' lambda
 // and the all-reduce of pmh_gluing_mult_transpose completes F lambda.  Call before the assembly; the storage of the other ranks'
 // stripes stays allocated (zero) so that no index changes (14 GB of 288 at configs[2]).
+// the dealing rule, host only: super band sb of block b (n_Gamma padded to 128) goes to rank idx % size, idx counting the super bands
+// of all blocks from the largest down (ties by block number).  owner[b][sb] and the dense bytes every rank ends up with.
+static void fx_stripe_plan(int nb, const int *npad, int size, std::vector<std::vector<int>> &owner, std::vector<double> &bytes)
+{
+  int maxsb = 0;
+  for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, npad[b] / FX_TC);
+  owner.assign(nb, std::vector<int>());
+  for (int b = 0; b < nb; b++) owner[b].assign(npad[b] / FX_TC, -1);
+  bytes.assign(size, 0.0);
+  int idx = 0;
+  for (int sb = maxsb - 1; sb >= 0; sb--)
+    for (int b = 0; b < nb; b++)
+      if (sb < npad[b] / FX_TC) {
+        const int r  = idx++ % size;
+        owner[b][sb] = r;
+        bytes[r] += 8.0 * 4.0 * FX_TILE * (sb + 1);
+      }
+}
+
+// host helper (no device): dense bytes per rank under pmh_fexplicit_set_stripe for blocks with the given n_Gamma -- the load balance
+// of a multi-GPU run can be inspected (and tested) without a GPU
+extern "C" int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int size, double *bytes_per_rank)
+{
+  PMH_ARG(nblocks >= 1 && n_gamma && size >= 1 && bytes_per_rank);
+  std::vector<int> npad(nblocks);
+  for (int b = 0; b < nblocks; b++) npad[b] = (n_gamma[b] + FX_TC - 1) / FX_TC * FX_TC;
+  std::vector<std::vector<int>> owner;
+  std::vector<double>           bytes;
+  fx_stripe_plan(nblocks, npad.data(), size, owner, bytes);
+  for (int r = 0; r < size; r++) bytes_per_rank[r] = bytes[r];
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
 {
   PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);
@@ -515,12 +548,11 @@ extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
   if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_stripe: call before the assembly");
   pmh_ctx   ctx = E->ctx;
   const int nb  = E->nb;
-  int       maxsb = 0;
-  for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
-  int idx = 0;
-  for (int sb = maxsb - 1; sb >= 0; sb--)
-    for (int b = 0; b < nb; b++)
-      if (sb < E->ld[b] / FX_TC) E->owned[b][sb] = ((idx++ % size) == rank) ? 1 : 0;
+  std::vector<std::vector<int>> owner;
+  std::vector<double>           bytes;
+  fx_stripe_plan(nb, E->ld.data(), size, owner, bytes);
+  for (int b = 0; b < nb; b++)
+    for (size_t sb = 0; sb < owner[b].size(); sb++) E->owned[b][sb] = owner[b][sb] == rank ? 1 : 0;
   E->stripe_rank = rank, E->stripe_size = size;
   (void)ctx;
   return fx_build_launch(E);

@@ -33,6 +33,7 @@ extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
   o->regularize  = 1;   // QPTFromOptions qptransform.c:2215
   o->kplus_rtol = 1e-12, o->kplus_max_it = 20000; // a stand-in for "direct": the reference factorises K_reg
   o->rtol = 1e-5, o->atol = 1e-50, o->divtol = 1e4, o->max_it = 10000; // QPSCreate qps.c:73-76
+  o->explicit_dual = 0, o->explicit_rtol = 1e-13;
   return PMH_SUCCESS;
 }
 
@@ -105,6 +106,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
   pmh_gluing     B  = nullptr;
   pmh_qppf       pf = nullptr;
   pmh_feti_chain ch = nullptr;
+  pmh_fexplicit  E  = nullptr;
   LumpedOp      *lump = nullptr;
   pmh_op         pc = nullptr;
   double        *d_f = nullptr, *d_c = nullptr, *d_e = nullptr, *d_x = nullptr, *d_lam = nullptr, *d_u0 = nullptr, *d_r = nullptr, *d_alpha = nullptr;
@@ -158,6 +160,11 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
       if (any_kernel) GO(pmh_matinv_set_nullspace(Kp, kdim, Rn.data()));
     }
     GO(pmh_gluing_create(ctx, N, nl, (int)lrow.size(), lrow.data(), lroot.data(), lval.data(), &B));
+    if (o->explicit_dual) { // the exact K^+ path: W_b = (K_b^+)[Gamma_b, Gamma_b] by one K^+ solve per column, then F = Bhat W Bhat'
+      GO(pmh_fexplicit_create(B, Kregb ? Kregb : Kb, PMH_FX_SYM, &E));
+      GO(pmh_fexplicit_assemble(E, Kp, nsub, nullptr, nullptr, o->explicit_rtol, 0));
+      GO(pmh_matinv_attach_explicit(Kp, E));
+    }
 
     // ---- G = R'B' (rows: the kernel vectors of the floating blocks), e = R'f
     std::vector<int> grow0(nsub + 1, 0);
@@ -236,6 +243,8 @@ done:
   if (pc) pmh_op_destroy(pc);
   if (lump) delete lump;
   pmh_qpt_feti_chain_destroy(ch);
+  if (Kp && E) pmh_matinv_attach_explicit(Kp, nullptr);
+  pmh_fexplicit_destroy(E);
   pmh_qppf_destroy(pf);
   pmh_gluing_destroy(B);
   pmh_matinv_destroy(Kp);
