@@ -345,7 +345,7 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     }
 
 
-def pmc_lookup(prefix, fname):
+def pmc_lookup(prefix, fname, combine="mean"):
     """(HBM bytes per launch, provenance) of a kernel from a committed rocprofv3 PMC pass (profiles/<fname>, written by
     scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
     carries no traffic figure rather than a stale one."""
@@ -360,7 +360,9 @@ def pmc_lookup(prefix, fname):
         return None, "kernel %r not in profiles/%s" % (prefixes, fname)
     n = sum(v["launches"] for v in hits)
     meta = pmc.get("_meta", {})
-    return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n,
+    # "mean": launch-weighted mean over the instantiations of one kernel; "sum": the kernels of one operation launched once each
+    total = sum(v["hbm_bytes_per_launch"] for v in hits) if combine == "sum" else sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+    return (total,
             "profiles/%s @ %s (%s)" % (fname, meta.get("git", "git state not recorded"), meta.get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled")))
 
 
@@ -554,7 +556,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         cnt["ms_per_operator_apply"] = dt * 1e3 / n_k if n_k else None
         achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
         n_solves, asm_s = E.assemble_stats()
-        traffic, tsrc = pmc_lookup(("k_fx_symv(", "k_fx_symv") if a.explicit_storage == "sym" else "void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        traffic, tsrc = pmc_lookup(("void k_fx_symv<", "k_fx_symv_fin") if a.explicit_storage == "sym" else "void k_fx_gemv<", "r02_pmc_traffic_feti_explicit.json", combine="sum") if full_size else (None, "not the configuration of the committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fx_symv (+ k_fx_symv_fin): y_b = W_b x_b on the lower block-triangle of the symmetric dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b], every stored byte read once, "
                                        "all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)" if a.explicit_storage == "sym" else
