@@ -368,7 +368,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
       if (!medium) sscanf(t, "%d,%d,%d", &A->st_nnzb, &A->st_mode, &A->st_nt);
     }
     if (A->st_nnzb != 512 && A->st_nnzb != 1024 && A->st_nnzb != 2048 && A->st_nnzb != 4096) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: nnzb must be 512, 1024, 2048 or 4096");
-    if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0, 1 or 2");
+    if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0 (one row block per workgroup) or 2 (persistent grid); the double-buffered mode 1 was measured slower and is not instantiated");
     std::vector<int> rb;
     A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb - 1, rb); // -1: room for the aligned-down start of the 16-byte load variant
     PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));

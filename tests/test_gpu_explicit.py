@@ -166,3 +166,22 @@ def test_striped_shares_sum_to_F(ctx):
     ref = y0.to_numpy()
     assert np.linalg.norm(tot - ref) <= 1e-10 * np.linalg.norm(ref)
     assert max(solves) < q0.E.assemble_stats()[0] and sum(solves) >= q0.E.assemble_stats()[0]
+
+
+def test_contact_solve_one_call(ctx):
+    """pmh_feti_contact_solve through its Python binding (the C example runs the same entry from plain C): counts of the Python-orchestrated
+    chain, a feasible primal solution with glued interfaces, and the non-explicit path of the same call."""
+    f = pa.CubeFeti((2, 2, 1), 6, contact=True)
+    G, e = f.coarse()
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, kplus_rtol=1e-9, mg_box=dict(dims=[(7, 7, 7)] * f.nsub, ndof=3, min_nodes=400), mg_precision="fp16", bsr3=True,
+                   explicit=dict(rtol=1e-12))
+    ref = q.solve_smalxe(rtol=1e-5)
+    for explicit in (True, False):
+        u, lam, st = pa.FETIContactSolve(ctx, f, explicit=explicit)
+        s = st.smalxe
+        assert (s.reason, s.iteration, s.inner_iter_accu, s.inner.nmv, s.inner.ncg, s.inner.nexp) == (ref.reason, ref.iteration, ref.inner_iter_accu, ref.inner.nmv, ref.inner.ncg, ref.inner.nexp)
+        assert st.coarse_dim == 6 * f.nsub and st.norm_Glambda_minus_e <= 1e-5 and (st.explicit_solves > 0) == explicit
+        Bu, scale = f.B @ u, np.abs(u).max()
+        assert np.abs(Bu[:f.n_eq] - f.c[:f.n_eq]).max() <= 1e-3 * scale and (Bu[f.n_eq:] - f.c[f.n_eq:]).max() <= 1e-3 * scale
+        assert lam[f.n_eq:].min() >= -1e-12 and np.linalg.norm(lam - q.dual_solution()) <= 1e-6 * np.linalg.norm(lam)
+        assert np.linalg.norm(f.K @ u - (f.f - f.B.T @ lam)) <= 1e-4 * np.linalg.norm(f.f)  # equilibrium
