@@ -244,6 +244,7 @@ _PROTOS = {
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],
+    "pmh_fexplicit_stripe_owner": [C.c_int, vp, C.c_int, vp],
     "pmh_fexplicit_stripe_bytes": [C.c_int, vp, C.c_int, c_double_p],
     "pmh_fexplicit_assemble": [vp, vp, C.c_int, vp, vp, C.c_double, C.c_int],
     "pmh_fexplicit_fill_pattern": [vp, C.c_int],

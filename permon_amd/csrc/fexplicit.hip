@@ -541,6 +541,21 @@ extern "C" int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int s
   return PMH_SUCCESS;
 }
 
+// host helper (no device): the owner rank of every 128-row stripe, block after block (ceil(n_Gamma_b / 128) entries per block)
+extern "C" int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int size, int *owner_out)
+{
+  PMH_ARG(nblocks >= 1 && n_gamma && size >= 1 && owner_out);
+  std::vector<int> npad(nblocks);
+  for (int b = 0; b < nblocks; b++) npad[b] = (n_gamma[b] + FX_TC - 1) / FX_TC * FX_TC;
+  std::vector<std::vector<int>> owner;
+  std::vector<double>           bytes;
+  fx_stripe_plan(nblocks, npad.data(), size, owner, bytes);
+  int k = 0;
+  for (int b = 0; b < nblocks; b++)
+    for (int o : owner[b]) owner_out[k++] = o;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
 {
   PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);

@@ -51,6 +51,41 @@ def main():
     lst = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(lst, chk)
     assert all(torch.equal(lst[0], v) for v in lst)
+    # ---- the striped explicit operators (pmh_fexplicit_set_stripe): every rank applies the 128-row stripes the library's dealing rule gives it
+    # -- of ALL blocks -- and the same all-reduce completes F lambda.  The plan comes from libpermonhip's host helper (no GPU needed);
+    # W_b = pinv(K_b)[Gamma_b, Gamma_b] by numpy stands in for the assembled blocks.
+    import ctypes as C
+
+    import permon_amd as pa
+
+    L = pa.load()
+    g = CubeFeti((2, 1, 1), 7, contact=True)  # n_Gamma > 128: several stripes per block
+    Kp = np.linalg.pinv(g.Ki.toarray(), rcond=1e-10, hermitian=True)
+    Bd = g.B.toarray()
+    gam = [np.nonzero(np.abs(Bd[:, s * g.n_i:(s + 1) * g.n_i]).sum(axis=0))[0] for s in range(g.nsub)]
+    ng = np.array([len(x) for x in gam], dtype=np.int32)
+    assert ng.min() > 128
+    nst = [int(-(-n // 128)) for n in ng]
+    owner = np.zeros(sum(nst), dtype=np.int32)
+    pa._lib.check(L.pmh_fexplicit_stripe_owner(g.nsub, ng.ctypes.data_as(C.c_void_p), world, owner.ctypes.data_as(C.c_void_p)))
+    assert set(owner.tolist()) == set(range(world))  # every rank gets stripes
+    lam2 = np.random.default_rng(9).standard_normal(g.n_lambda)
+    part2, o = np.zeros(g.n_lambda), 0
+    for s in range(g.nsub):
+        Bs = Bd[:, s * g.n_i:(s + 1) * g.n_i][:, gam[s]]  # Bhat_s
+        W = Kp[np.ix_(gam[s], gam[s])]
+        xh = Bs.T @ lam2
+        yh = np.zeros(ng[s])
+        for k in range(nst[s]):
+            if owner[o + k] == rank:
+                yh[128 * k:128 * (k + 1)] = W[128 * k:128 * (k + 1)] @ xh  # the rows of this stripe
+        o += nst[s]
+        part2 += Bs @ yh
+    t2 = torch.from_numpy(part2.copy())
+    dist.all_reduce(t2)
+    if rank == 0:
+        Fd = sum(Bd[:, s * g.n_i:(s + 1) * g.n_i] @ Kp @ Bd[:, s * g.n_i:(s + 1) * g.n_i].T for s in range(g.nsub))
+        assert np.linalg.norm(t2.numpy() - Fd @ lam2) <= 1e-11 * np.linalg.norm(Fd @ lam2)
     # 128-byte communicator id broadcast (what bench.py does with the ncclUniqueId)
     idt = torch.arange(128, dtype=torch.uint8) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
     dist.broadcast(idt, 0)
