@@ -330,7 +330,7 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     t_probe = time.perf_counter() - t0
     its = int(max(3, min(its, budget_s / (2.1 * t_probe))))
     del stamps[:]
-    ref = O.mpgp(op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), maxeig=1.0 + rho, max_it=its - 1)
+    ref = O.mpgp(op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), maxeig=1.0 + rho, max_it=its)  # stops once iteration > max_it - 1 ... `its` iterations
     # the first application is the initial gradient (set-up of the solve); the iterations own the rest
     per_apply = np.diff(np.asarray(stamps))
     applies_per_it = len(per_apply) / max(1, ref["iteration"])

@@ -31,6 +31,6 @@ runtune() {
 }
 runtune
 echo "explicit done"
-run feti_iterative "k_bsr3" --no-cpu-baseline --no-c2 --no-iterative --kplus iterative --steps 20 --warmup 2
+run feti_iterative "bsr3" --no-cpu-baseline --no-c2 --no-iterative --kplus iterative --steps 20 --warmup 2
 echo "iterative done"
 run c2 "k_spmv_stream|k_step_update|k_dir_update" --workload c2 --no-cpu-baseline --steps 50 --warmup 5
