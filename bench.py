@@ -355,7 +355,7 @@ def pmc_lookup(prefix, fname, combine="mean"):
     except (OSError, ValueError) as ex:
         return None, "no PMC pass: %r" % (ex,)
     prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
-    hits = [v for k, v in pmc.items() if not k.startswith("_") and k.startswith(prefixes)]
+    hits = [v for k, v in pmc.items() if k != "_meta" and k.startswith(prefixes)]
     if not hits:
         return None, "kernel %r not in profiles/%s" % (prefixes, fname)
     n = sum(v["launches"] for v in hits)

@@ -25,5 +25,5 @@ for k in out["FETCH_SIZE"]:
 if len(sys.argv) > 2:  # provenance: the commit measured and the command (bench.py quotes it as roofline.traffic_source)
     res["_meta"] = {"git": sys.argv[2], "command": sys.argv[3] if len(sys.argv) > 3 else ""}
 json.dump(res, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
-for k, v in sorted(((k, v) for k, v in res.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
+for k, v in sorted(((k, v) for k, v in res.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
     print("%-60s launches=%5d  fetch(x2)=%8.1f MB  write=%8.1f MB  total=%8.1f MB" % (k[:60], v["launches"], v["fetch_bytes_corrected"] / 1e6, v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
