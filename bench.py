@@ -345,7 +345,7 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     }
 
 
-def pmc_lookup(prefix, fname, combine="mean"):
+def pmc_lookup(prefix, fname, combine="mean", contains=None):
     """(HBM bytes per launch, provenance) of a kernel from a committed rocprofv3 PMC pass (profiles/<fname>, written by
     scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
     carries no traffic figure rather than a stale one."""
@@ -355,7 +355,7 @@ def pmc_lookup(prefix, fname, combine="mean"):
     except (OSError, ValueError) as ex:
         return None, "no PMC pass: %r" % (ex,)
     prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
-    hits = [v for k, v in pmc.items() if k != "_meta" and k.startswith(prefixes)]
+    hits = [v for k, v in pmc.items() if k != "_meta" and k.startswith(prefixes) and (contains is None or any(c in k for c in contains))]
     if not hits:
         return None, "kernel %r not in profiles/%s" % (prefixes, fname)
     n = sum(v["launches"] for v in hits)
@@ -528,7 +528,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             n_k, ms_k, b_k = q.Kplus.mg.timing_get()
             pk = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
             ppat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[precision]
-            ptraffic, ptsrc = pmc_lookup(ppat, "r02_pmc_traffic_feti_iterative.json") if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
+            # the fine-level instantiations only (tile size 1024; the second level runs the 512 ones)
+            ptraffic, ptsrc = pmc_lookup(ppat, "r02_pmc_traffic_feti_iterative.json", contains=("Li1024E", ", 1024>")) if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
             roof["preconditioner"] = {"kernel": "k_bsr3<%s>: fine-level K x of the V-cycle (%s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[precision],
                                       "achieved": pk, "frac": pk / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
                                       "share_of_step_time": (ms_k * 1e-3) * stride / dt if n_k else None, "traffic": ptraffic, "traffic_source": ptsrc}
