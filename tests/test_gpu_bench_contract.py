@@ -71,6 +71,7 @@ def test_forced_distributed_path_on_one_rank():
 
     for args in (("--nel", "7", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"),
                  ("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"),
+                 ("--nel", "9", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--sim-world", "2"),  # striped operators + replica solver + the all-reduce
                  ("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2")):
         loc = run(dict(os.environ), *args)
         dst = run(env, *args)
