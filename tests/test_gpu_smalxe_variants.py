@@ -117,3 +117,25 @@ def test_penalized_op_slots(ctx, problem):
     sh = pa.Op.shell(ctx, n, lambda xp, yp: None)
     with pytest.raises(pa.PermonHipError):
         check(ctx.L.pmh_op_mult_transpose(sh.h, xd.p, yd.p))
+
+
+def test_fused_projector_epilogues_are_bit_identical(ctx, problem, monkeypatch):
+    """A_rho x = rho Q x + P F P x with the projector's G' products fused with their vector epilogues (k_gt_fused: 10 launches instead
+    of 15) against the unfused sequence of MatMult_Penalized / QPPFApplyP calls: the same bits."""
+    f, G, q = problem
+    n = f.n_lambda
+    assert G.shape[0] >= 24  # enough rigid-body rows per dual row for the 8-lanes-per-row case the fusion covers
+    Ap = pa.MatCreatePenalized(q.A, q.pf, 3.25)
+    x = np.random.default_rng(11).standard_normal(n)
+    xd, y1, y2 = ctx.vec_from(x), ctx.vec(n), ctx.vec(n)
+    check(ctx.L.pmh_op_mult(Ap.h, xd.p, y1.p))
+    monkeypatch.setenv("PMH_NO_GT_FUSION", "1")
+    check(ctx.L.pmh_op_mult(Ap.h, xd.p, y2.p))
+    monkeypatch.delenv("PMH_NO_GT_FUSION")
+    assert np.array_equal(y1.to_numpy(), y2.to_numpy())
+    Gd = G.toarray()
+    P = lambda v: v - Gd.T @ (Gd @ v)  # noqa: E731
+    Fx = ctx.vec(n)
+    q.F.mult(ctx.vec_from(P(x)), Fx)
+    ref = 3.25 * (Gd.T @ (Gd @ x)) + P(Fx.to_numpy())
+    assert np.linalg.norm(y1.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
