@@ -465,7 +465,7 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
 {
   if (!E) return PMH_SUCCESS;
   pmh_ctx ctx = E->ctx;
-  if (E->Wbase) hipFree(E->Wbase);
+  if (E->Wbase) (void)hipFree(E->Wbase);
   pmh_gluing_destroy(E->Bhat);
   pmh_free(ctx, E->d_gamma_rel), pmh_free(ctx, E->d_woff), pmh_free(ctx, E->d_ld), pmh_free(ctx, E->d_gstart), pmh_free(ctx, E->d_ngam);
   pmh_free(ctx, E->d_wg_block), pmh_free(ctx, E->d_wg_row0), pmh_free(ctx, E->xh), pmh_free(ctx, E->yh);
@@ -480,8 +480,8 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
   if (E->d_fw_col0) pmh_free(ctx, E->d_fw_col0);
   if (E->d_own_ptr) pmh_free(ctx, E->d_own_ptr);
   if (E->d_own_list) pmh_free(ctx, E->d_own_list);
-  for (hipEvent_t e : E->ev) hipEventDestroy(e);
-  for (hipEvent_t e : E->ev_mid) hipEventDestroy(e);
+  for (hipEvent_t e : E->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : E->ev_mid) (void)hipEventDestroy(e);
   delete E;
   return PMH_SUCCESS;
 }
@@ -687,6 +687,10 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
     }
     hipLaunchKernelGGL(k_fx_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
     if ((rc = pmh_matinv_mult(solver, rhs, sol))) break;
+    if (solver->last_max_its >= solver->max_it) { // a column that is not converged would silently make F inexact
+      rc = pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_assemble: a set-up solve of batch %d did not reach rtol %.1e within %d iterations of the inner KSP", k, rtol, solver->max_it);
+      break;
+    }
     hipLaunchKernelGGL(k_fx_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 0.0, rhs);
     for (int s = 0; s < nslots; s++) {
       if (col[s] < 0) continue;
@@ -709,7 +713,7 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   if (!rc) rc = pmh_sync(ctx);
   pmh_matinv_set_tolerances(solver, old_rtol, old_atol, old_maxit);
   pmh_free(ctx, rhs), pmh_free(ctx, sol), pmh_free(ctx, d_idx);
-  hipHostFree(h_idx);
+  (void)hipHostFree(h_idx);
   if (rc) return rc;
   E->assembled = 1;
   E->assemble_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
