@@ -185,3 +185,42 @@ def test_contact_solve_one_call(ctx):
         assert np.abs(Bu[:f.n_eq] - f.c[:f.n_eq]).max() <= 1e-3 * scale and (Bu[f.n_eq:] - f.c[f.n_eq:]).max() <= 1e-3 * scale
         assert lam[f.n_eq:].min() >= -1e-12 and np.linalg.norm(lam - q.dual_solution()) <= 1e-6 * np.linalg.norm(lam)
         assert np.linalg.norm(f.K @ u - (f.f - f.B.T @ lam)) <= 1e-4 * np.linalg.norm(f.f)  # equilibrium
+
+
+def test_explicit_edge_cases(ctx):
+    """A block that B does not touch at all (n_Gamma = 0), a block with a single touched dof, non-congruent blocks, n_Gamma around the
+    32 / 128 padding boundaries -- F through the explicit operators against the iterative F; striping refuses the full storage."""
+    rng = np.random.default_rng(21)
+    for ntouch in ((0, 1, 33), (127, 128, 129), (5, 0, 260)):
+        f = pa.CubeFeti((3, 1, 1), 4, contact=False)  # three 5^3-node cubes: 375 dofs each
+        K = sp.block_diag([f.Ki, 1.5 * f.Ki, f.Ki], format="csr")  # block 1 is not congruent with the others
+        rows, roots, vals = [], [], []
+        nl = 0
+        for b, nt in enumerate(ntouch):
+            dofs = np.sort(rng.choice(f.n_i, size=nt, replace=False)) + b * f.n_i
+            for d in dofs:  # one or two dual rows per touched dof
+                for _ in range(1 + int(rng.integers(0, 2))):
+                    rows.append(d), roots.append(int(rng.integers(0, 40))), vals.append(float(rng.choice([-1.0, 1.0, 0.5])))
+        nl = 40
+        Kd = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, K)
+        Kp = pa.MatInv(Kd, rtol=1e-13, max_it=5000, nullspace=f.R)
+        B = pa.MatGluing(ctx, f.N, nl, np.array(rows, dtype=np.int32), np.array(roots, dtype=np.int32), np.array(vals))
+        F_it = pa.MatCreateFetiDual(B, Kp)
+        lam = rng.standard_normal(nl)
+        y_it, y_ex = ctx.vec(nl), ctx.vec(nl)
+        F_it.mult(ctx.vec_from(lam), y_it)
+        for storage in ("sym", "full"):
+            E = pa.MatExplicitDual(B, Kd, storage=storage)
+            assert E.n_gamma.tolist() == list(ntouch)
+            cls = pa.csr_block_classes(f.block_rowstart, K)
+            assert cls.tolist() == [0, 1, 0]
+            E.assemble(Kp, slot_class=cls, block_class=cls, rtol=1e-13)
+            Kp.attach_explicit(E)
+            F_it.mult(ctx.vec_from(lam), y_ex)  # the same operator object now applies through E
+            Kp.attach_explicit(None)
+            ref = y_it.to_numpy()
+            assert np.linalg.norm(y_ex.to_numpy() - ref) <= 1e-9 * max(np.linalg.norm(ref), 1e-300)
+            if storage == "full":
+                with pytest.raises(pa.PermonHipError):
+                    E.set_stripe(0, 2)
+            E.destroy()
