@@ -311,7 +311,10 @@ int pmh_pc_dual_lumped_apply(pmh_gluing B, pmh_blockdiag K, const double *x, dou
 typedef struct pmh_fexplicit_s *pmh_fexplicit;
 #define PMH_FX_FULL 0 /* W_b as a full row-major matrix: one GEMV, 8 n^2 bytes per block and apply */
 #define PMH_FX_SYM 1  /* W_b = W_b' kept as its lower block-triangle (bands of 32 rows): a deterministic two-launch SYMV, 4 n^2 bytes */
+#define PMH_FX_CLASS 2 /* pmh_fexplicit_create_shared: congruent blocks share ONE full matrix W_c = (K^+)[U_c, U_c] per class (U_c = union of their
+                          Gamma_b) applied to the blocks' vectors together, 8 right-hand sides per pass: 8 n_c^2 bytes for the whole class */
 int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
+int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);
 /* several GPUs, congruent blocks: E built over ALL blocks (B = the global gluing, K = the global block structure); this rank
@@ -512,7 +515,7 @@ typedef struct {
   double kplus_rtol; int kplus_max_it;
   int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
-  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL) */
+  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS) */
   int    orthonormalize;            /* QPTOrthonormalizeEq: G <- L^{-1} G */
 } pmh_feti_contact_opts;
 typedef struct {

@@ -116,17 +116,34 @@ class FetiDualQP:
         nb = len(rs) - 1
         cls = csr_block_classes(rs, self._Kinv_sp) if share_congruent else np.arange(nb, dtype=np.int32)
         one_class = int(cls.max()) == 0
+        if storage == "auto":
+            # congruent blocks: ONE full matrix per class applied to 8 blocks' vectors per pass ("class": ceil(|c| / 8) 8 n_c^2 bytes) when
+            # that moves fewer bytes than one symmetric matrix per block ("sym": sum_b 4 n_b^2)
+            src = stripe[2] if stripe is not None else dict(block_rowstart=rs, leaves_row=local["leaves_row"])
+            grs = np.asarray(src["block_rowstart"])
+            tr = np.unique(np.asarray(src["leaves_row"]))
+            blk = np.searchsorted(grs, tr, side="right") - 1
+            n_b = np.bincount(blk, minlength=len(grs) - 1).astype(float)
+            gcls = np.zeros(len(grs) - 1, dtype=np.int64) if stripe is not None else cls
+            b_sym = 4.0 * float(np.sum(n_b ** 2))
+            b_cls = 0.0
+            for c in np.unique(gcls):
+                members = np.nonzero(gcls == c)[0]
+                union = np.unique(np.concatenate([tr[blk == m] - grs[m] for m in members])).size
+                b_cls += np.ceil(len(members) / 8.0) * 8.0 * float(union) ** 2
+            storage = "class" if b_cls < b_sym else "sym"
+        self.explicit_storage = storage
         if stripe is not None:
             rank, size, glob = stripe
             if not one_class:
                 raise ValueError("striped explicit operators need congruent blocks")
             self._Bglob = MatGluing(self.ctx, glob["n_x"], self.n_lambda, glob["leaves_row"], glob["leaves_root"], glob["leaves_sign"])
             self._Kglob = MatBlockDiag.from_scipy(self.ctx, glob["block_rowstart"], sp.identity(glob["n_x"], format="csr"))  # block structure only
-            E = MatExplicitDual(self._Bglob, self._Kglob, storage="sym")
-            E.set_stripe(rank, size)
             ngl = len(glob["block_rowstart"]) - 1
+            E = MatExplicitDual(self._Bglob, self._Kglob, storage="class" if storage == "class" else "sym", block_class=np.zeros(ngl, dtype=np.int32))
+            E.set_stripe(rank, size)
         else:
-            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage)
+            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)
             ngl = nb
         if solver_factory is not None and nb < min_slots and one_class:
             solver = solver_factory(int(min_slots))

@@ -26,6 +26,7 @@
 #include <map>
 
 #include "feti_internal.h"
+#include "fshared.h"
 #include "pmh_internal.h"
 #include "reduce.h"
 
@@ -50,6 +51,7 @@ struct pmh_fexplicit_s {
   int     *d_ld, *d_gstart, *d_ngam;
   int     *d_wg_block, *d_wg_row0;
   int      nwg, rw;        // GEMV launch table: workgroup -> (block, first row); rows per wave
+  fx_shared *sh;           // PMH_FX_CLASS: congruent blocks share one full matrix per class (fshared.hip); everything dense lives there
   int      storage;        // PMH_FX_FULL: n x ld row-major; PMH_FX_SYM: lower block-triangle in bands of 32 rows (see k_fx_symv)
   double  *partial, *ydir; // SYM: transposed-product partials [block][super band][npad] and the direct products [block][segment][npad]
   long long *d_poff, *d_doff; // SYM: offset of block b in `partial` / in `ydir`
@@ -186,10 +188,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_symv(const int *__restrict__ s
       for (int r = 0; r < 16; r++) a[r] = (VAR == 1) ? *(const dbl2 *)(ap + (h + r) * FX_TC) : __builtin_nontemporal_load((const dbl2 *)(ap + (h + r) * FX_TC));
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        acc[h + r] += a[r].x * xc.x;
-        acc[h + r] += a[r].y * xc.y;
-        z.x += a[r].x * xr[h + r];
-        z.y += a[r].y * xr[h + r];
+        acc[h + r] = __builtin_fma(a[r].x, xc.x, acc[h + r]); // fused multiply-adds: the dense product has no reference summation order to
+        acc[h + r] = __builtin_fma(a[r].y, xc.y, acc[h + r]); // reproduce (W is K^+ data), the order stays fixed
+        z.x        = __builtin_fma(a[r].x, xr[h + r], z.x);
+        z.y        = __builtin_fma(a[r].y, xr[h + r], z.y);
       }
     }
     if (c >= row0) z = dbl2{0.0, 0.0}; // columns inside the band's diagonal tile are covered by the tile's own rows (direct product)
@@ -340,16 +342,32 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fx_extract_tiled(int n, const int
 
 // ---- create / destroy ---------------------------------------------------------------------------------------------------
 
+static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *block_class, pmh_fexplicit *out);
+
 extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *out)
 {
-  PMH_ARG(B && K && out && (storage == PMH_FX_FULL || storage == PMH_FX_SYM));
+  PMH_ARG(storage == PMH_FX_FULL || storage == PMH_FX_SYM);
+  return fx_create(B, K, storage, nullptr, out);
+}
+
+// congruent blocks (block_class from pmh_csr_block_classes) share ONE full dense matrix per class, applied to the blocks' vectors
+// together, eight right-hand sides per pass (fshared.hip)
+extern "C" int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *out)
+{
+  PMH_ARG(block_class);
+  return fx_create(B, K, PMH_FX_CLASS, block_class, out);
+}
+
+static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *block_class, pmh_fexplicit *out)
+{
+  PMH_ARG(B && K && out);
   PMH_ARG(B->n_x == K->n);
   pmh_ctx       ctx = B->ctx;
   pmh_fexplicit E   = new pmh_fexplicit_s();
   E->ctx = ctx, E->B = B, E->K = K, E->Bhat = nullptr, E->nb = K->nblocks;
   E->d_gamma_rel = nullptr, E->Wbase = nullptr, E->d_woff = nullptr, E->d_ld = E->d_gstart = E->d_ngam = E->d_wg_block = E->d_wg_row0 = nullptr;
   E->xh = E->yh = nullptr, E->assembled = 0, E->n_solves = 0, E->assemble_seconds = 0.0;
-  E->stripe_rank = 0, E->stripe_size = 0;
+  E->stripe_rank = 0, E->stripe_size = 0, E->sh = nullptr;
   E->ev_used = E->ev_on = E->ev_seen = 0, E->ev_stride = 1;
   E->storage = storage, E->partial = E->ydir = nullptr, E->d_poff = E->d_doff = nullptr, E->d_sw_block = E->d_sw_band = E->d_sw_seg = E->d_fw_block = E->d_fw_col0 = E->d_own_ptr = E->d_own_list = nullptr, E->nsw = E->nfw = 0, E->sym_bytes = 0.0;
   const int nb = E->nb;
@@ -373,6 +391,12 @@ extern "C" int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, 
     off += E->ld[b]; // every block padded to a multiple of 128: aligned 16-byte loads, whole bands and tiles; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
+  if (storage == PMH_FX_CLASS) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
+    E->W.assign(nb, nullptr), E->woff.assign(nb, 0);
+    PMH_CHK(fxs_create(B, K, block_class, &E->sh));
+    *out = E;
+    return PMH_SUCCESS;
+  }
   // Bhat: same leaves (same order => same summation order as B), primal index remapped
   std::vector<int> rows((size_t)std::max(1, B->n_leaves));
   for (int i = 0; i < B->n_leaves; i++) rows[i] = newidx[B->h_row[i]];
@@ -465,6 +489,11 @@ extern "C" int pmh_fexplicit_destroy(pmh_fexplicit E)
 {
   if (!E) return PMH_SUCCESS;
   pmh_ctx ctx = E->ctx;
+  if (E->sh) {
+    fxs_destroy(E->sh);
+    delete E;
+    return PMH_SUCCESS;
+  }
   if (E->Wbase) (void)hipFree(E->Wbase);
   pmh_gluing_destroy(E->Bhat);
   pmh_free(ctx, E->d_gamma_rel), pmh_free(ctx, E->d_woff), pmh_free(ctx, E->d_ld), pmh_free(ctx, E->d_gstart), pmh_free(ctx, E->d_ngam);
@@ -494,9 +523,10 @@ extern "C" int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma, 
   double    alg = 0.0;
   for (int b = 0; b < E->nb; b++) {
     if (n_gamma) n_gamma[b] = E->ngam[b];
-    tot += (long long)sizeof(double) * (E->storage == PMH_FX_SYM ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b]);
+    if (!E->sh) tot += (long long)sizeof(double) * (E->storage == PMH_FX_SYM ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b]);
     alg += 8.0 * (double)E->ngam[b] * E->ngam[b] + 16.0 * E->ngam[b]; // FULL: the matrix once + x read + y written
   }
+  if (E->sh) tot = fxs_dense_bytes(E->sh), alg = fxs_apply_bytes(E->sh);
   if (dense_bytes) *dense_bytes = tot;
   if (gemv_bytes) *gemv_bytes = (E->storage == PMH_FX_SYM) ? E->sym_bytes : alg;
   return PMH_SUCCESS;
@@ -559,8 +589,12 @@ extern "C" int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int s
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
 {
   PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);
-  if (E->storage != PMH_FX_SYM) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_stripe: striping needs the symmetric storage");
   if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_stripe: call before the assembly");
+  if (E->sh) { // class-shared storage: contiguous row ranges of every W_c
+    E->stripe_rank = rank, E->stripe_size = size;
+    return fxs_set_stripe(E->sh, rank, size);
+  }
+  if (E->storage != PMH_FX_SYM) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_stripe: striping needs the symmetric or the class-shared storage");
   pmh_ctx   ctx = E->ctx;
   const int nb  = E->nb;
   std::vector<std::vector<int>> owner;
@@ -612,6 +646,14 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
 {
   PMH_ARG(E && solver && nslots >= 1 && solver->nblocks == nslots);
   PMH_ARG((slot_class && block_class) || (!slot_class && !block_class && nslots == E->nb));
+  if (E->sh) { // class-shared storage: one full row of W_c per solve (the classes are those given at creation)
+    PMH_ARG(slot_class);
+    auto t0s = std::chrono::steady_clock::now();
+    PMH_CHK(fxs_assemble(E->sh, solver, nslots, slot_class, rtol, max_it, &E->n_solves));
+    E->assembled = 1;
+    E->assemble_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0s).count();
+    return PMH_SUCCESS;
+  }
   pmh_ctx   ctx = E->ctx;
   const int nb  = E->nb;
   auto      t0  = std::chrono::steady_clock::now();
@@ -725,6 +767,10 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
 extern "C" int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte)
 {
   PMH_ARG(E);
+  if (E->sh) {
+    E->assembled = 1;
+    return fxs_fill_pattern(E->sh, byte);
+  }
   long long tot = 0;
   for (int b = 0; b < E->nb; b++) tot += (E->storage == PMH_FX_SYM) ? fx_sym_size(E->ld[b]) : (long long)E->ld[b] * E->ld[b];
   PMH_HIP(hipMemsetAsync(E->Wbase, byte, sizeof(double) * (size_t)tot, E->ctx->stream));
@@ -745,7 +791,9 @@ extern "C" int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *out_host,
 {
   PMH_ARG(E && b >= 0 && b < E->nb);
   const int n = E->ngam[b];
-  if (out_host && n) {
+  if (out_host && n && E->sh) {
+    PMH_CHK(fxs_get_block(E->sh, b, n, &E->gamma[E->goff[b]], out_host));
+  } else if (out_host && n) {
     if (E->storage == PMH_FX_FULL) {
       PMH_HIP(hipMemcpy2D(out_host, sizeof(double) * n, E->W[b], sizeof(double) * E->ld[b], sizeof(double) * n, n, hipMemcpyDeviceToHost));
     } else { // unpack the lower block-triangle band by band, mirror it (the diagonal tile is stored in full)
@@ -823,6 +871,7 @@ bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B) { return E && E->as
 // y = F lambda = Bhat W Bhat' lambda (MatMult of the product F = B K^+ B', qptransform.c:1103-1128, with K^+ explicit)
 int pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y)
 {
+  if (E->sh) return fxs_apply(E->sh, lambda, y);
   PMH_CHK(pmh_gluing_mult(E->Bhat, lambda, E->xh));
   PMH_CHK(fx_gemv(E));
   return pmh_gluing_mult_transpose(E->Bhat, E->yh, y); // ends with the all-reduce on several GPUs
@@ -839,6 +888,12 @@ extern "C" int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double 
 extern "C" int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xh, double *yh)
 {
   PMH_ARG(E && xh && yh);
+  if (E->sh) { // vectors in the multivector numbering (pmh_fexplicit_compressed_size)
+    const size_t nbytes = sizeof(double) * (size_t)fxs_multivector_length(E->sh);
+    PMH_CHK(pmh_memcpy_d2d(E->ctx, fxs_X(E->sh), xh, nbytes));
+    PMH_CHK(fxs_dense(E->sh));
+    return pmh_memcpy_d2d(E->ctx, yh, fxs_Y(E->sh), nbytes);
+  }
   PMH_CHK(pmh_memcpy_d2d(E->ctx, E->xh, xh, sizeof(double) * (size_t)E->ntot));
   PMH_CHK(fx_gemv(E));
   return pmh_memcpy_d2d(E->ctx, yh, E->yh, sizeof(double) * (size_t)E->ntot);
@@ -847,6 +902,12 @@ extern "C" int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xh, doubl
 extern "C" int pmh_fexplicit_compressed_size(pmh_fexplicit E, int *ntot, int *gstart /* [nblocks+1] or NULL */)
 {
   PMH_ARG(E);
+  if (E->sh) {
+    if (ntot) *ntot = (int)fxs_multivector_length(E->sh);
+    if (gstart)
+      for (int b = 0; b <= E->nb; b++) gstart[b] = -1; // no per-block layout in the multivector numbering
+    return PMH_SUCCESS;
+  }
   if (ntot) *ntot = E->ntot;
   if (gstart)
     for (int b = 0; b <= E->nb; b++) gstart[b] = E->gstart[b];
@@ -867,6 +928,7 @@ extern "C" int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E)
 extern "C" int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, int stride)
 {
   PMH_ARG(E && max_launches >= 0);
+  if (E->sh) return fxs_timing_enable(E->sh, max_launches);
   while ((int)E->ev.size() < 2 * max_launches) {
     hipEvent_t e;
     PMH_HIP(hipEventCreate(&e));
@@ -884,6 +946,11 @@ extern "C" int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, in
 extern "C" int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms, double *first_kernel_ms)
 {
   PMH_ARG(E && launches && total_ms);
+  if (E->sh) {
+    PMH_CHK(fxs_timing_get(E->sh, launches, total_ms));
+    if (first_kernel_ms) *first_kernel_ms = *total_ms;
+    return PMH_SUCCESS;
+  }
   PMH_CHK(pmh_sync(E->ctx));
   double tot = 0.0, first = 0.0;
   for (int i = 0; i < E->ev_used; i++) {

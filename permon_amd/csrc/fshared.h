@@ -1,0 +1,20 @@
+// Class-shared explicit local dual operators (fshared.hip), the PMH_FX_CLASS storage of pmh_fexplicit (internal)
+#pragma once
+#include "feti_internal.h"
+
+struct fx_shared;
+int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, fx_shared **out);
+void      fxs_destroy(fx_shared *S);
+int       fxs_set_stripe(fx_shared *S, int rank, int size);
+long long fxs_dense_bytes(fx_shared *S);
+double    fxs_apply_bytes(fx_shared *S);
+int       fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves);
+int       fxs_apply(fx_shared *S, const double *lambda, double *y);
+int       fxs_dense(fx_shared *S);
+long long fxs_multivector_length(fx_shared *S);
+double   *fxs_X(fx_shared *S);
+double   *fxs_Y(fx_shared *S);
+int       fxs_fill_pattern(fx_shared *S, int byte);
+int       fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host);
+int       fxs_timing_enable(fx_shared *S, int max_launches);
+int       fxs_timing_get(fx_shared *S, int *launches, double *total_ms);

@@ -239,11 +239,17 @@ class MatExplicitDual:
     """Explicit local dual operators (pmh_fexplicit): W_b = (K_b^+)[Gamma_b, Gamma_b] dense per block, F = Bhat W Bhat'.
     The exact-K^+ path (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:670-730, restricted to the dofs B touches)."""
 
-    def __init__(self, B, K, storage="sym"):
-        """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV."""
+    def __init__(self, B, K, storage="sym", block_class=None):
+        """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV; "class": congruent blocks
+        (block_class from csr_block_classes) share ONE full matrix per class, applied to their vectors together (8 per pass)."""
         self.ctx, self.B, self.K, self.storage = B.ctx, B, K, storage
         h = C.c_void_p()
-        check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, {"full": 0, "sym": 1}[storage], C.byref(h)))
+        if storage == "class":
+            bc = np.ascontiguousarray(block_class, dtype=np.int32)
+            assert bc.size == K.nblocks
+            check(self.ctx.L.pmh_fexplicit_create_shared(B.h, K.h, bc.ctypes.data_as(C.c_void_p), C.byref(h)))
+        else:
+            check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, {"full": 0, "sym": 1}[storage], C.byref(h)))
         self.h = h
         nb = C.c_int()
         check(self.ctx.L.pmh_fexplicit_sizes(h, C.byref(nb), None, None, None))
@@ -258,7 +264,7 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_set_stripe(self.h, int(rank), int(size)))
         gb = C.c_double()
         check(self.ctx.L.pmh_fexplicit_sizes(self.h, None, None, None, C.byref(gb)))
-        self.gemv_bytes = gb.value
+        self.gemv_bytes = gb.value  # this rank's share
 
     def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
         """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""

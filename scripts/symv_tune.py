@@ -1,5 +1,5 @@
 """Times the dense apply kernels of the explicit local dual operators at configs[2] size without the set-up solves (the storage is
-filled with a byte pattern).  usage: python scripts/symv_tune.py [sym|full] [nel] [blocks]"""
+filled with a byte pattern).  usage: python scripts/symv_tune.py [sym|full|class] [nel] [blocks] [share of N]"""
 import os
 import sys
 
@@ -20,7 +20,9 @@ import scipy.sparse as sp  # noqa: E402
 # the explicit operator only needs the block structure: a diagonal stand-in for K keeps the upload small
 K = pa.MatBlockDiag.from_scipy(ctx, loc["block_rowstart"], sp.identity(loc["n_x"], format="csr"))
 B = pa.MatGluing(ctx, loc["n_x"], f.n_lambda, loc["leaves_row"], loc["leaves_root"], loc["leaves_sign"])
-E = pa.MatExplicitDual(B, K, storage=storage)
+E = pa.MatExplicitDual(B, K, storage=storage, block_class=np.zeros(nblk, dtype=np.int32))  # "class": the cubes are congruent
+if len(sys.argv) > 4:  # rank 0's share of an N-GPU run
+    E.set_stripe(0, int(sys.argv[4]))
 check(ctx.L.pmh_fexplicit_fill_pattern(E.h, 0x3C))
 ntot, gs = E.compressed_size()
 x, y = ctx.vec_from(np.random.default_rng(0).standard_normal(ntot)), ctx.vec(ntot)

@@ -53,8 +53,8 @@ def test_example_output_equals_the_reference_golden_file(goldens, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("explicit", [1, 0])
-def test_contact_example_reproduces_the_python_chain(tmp_path, explicit):
+@pytest.mark.parametrize("explicit,storage", [(1, 1), (1, 2), (0, 1)])
+def test_contact_example_reproduces_the_python_chain(tmp_path, explicit, storage):
     """examples/contact_tfeti.c = pmh_feti_contact_solve from plain C (hierarchy built by pmh_mg_create_box, explicit dual operators,
     SMALXE + MPGP, rigid-body recovery, no Python in the solve) against the Python-orchestrated chain on the same problem: identical
     outer / inner / Hessian-multiplication / step-type counts, a feasible solution."""
@@ -68,7 +68,7 @@ def test_contact_example_reproduces_the_python_chain(tmp_path, explicit):
     f = pa.CubeFeti((2, 2, 2), 8, contact=True)
     path = str(tmp_path / "contact.bin")
     P.write_contact_problem(path, f)
-    out = subprocess.run([os.path.join(ROOT, "examples", "contact_tfeti"), path, str(explicit), "2"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([os.path.join(ROOT, "examples", "contact_tfeti"), path, str(explicit), "2", str(storage)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
     ctx = pa.Context(0)
