@@ -5,7 +5,7 @@ import csv, glob, json, os, sys, collections
 root = sys.argv[1]
 out = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(os.path.join(root, "pmc_" + C, "*", "*counter_collection.csv"))
+    files = glob.glob(os.path.join(root, "pmc_" + C, "**", "*counter_collection.csv"), recursive=True)
     vals = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
