@@ -51,9 +51,10 @@ def parse():
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
                     "(assembled once by K^+ solves, then ONE fp64 GEMV per apply; the exact path and the faster one at every N), iterative = an inner block-wise Krylov solve per apply")
-    ap.add_argument("--explicit-storage", choices=["auto", "class", "sym", "full"], default="auto",
+    ap.add_argument("--explicit-storage", choices=["auto", "class_sym", "class", "sym", "full"], default="auto",
                     help="feti: the dense local dual operators per block as their lower block-triangle (sym: SYMV, 4 n^2 bytes per apply) or in full (full: GEMV, 8 n^2), or ONE full matrix per class "
-                         "of congruent blocks applied to 8 blocks' vectors per pass (class: 8 n_c^2 for the whole class); auto = class when that moves fewer bytes, else sym")
+                         "of congruent blocks applied to 8 blocks' vectors per pass (class: 8 n_c^2 for the whole class; class_sym: its lower block-triangle in 16x16 tiles, 4 n_c^2, both products of a tile on the "
+                         "fp64 matrix instruction); auto = class_sym when that moves fewer bytes, else sym")
     ap.add_argument("--no-stripe", action="store_true", help="feti at N > 1: every rank keeps the explicit operators of its OWN blocks instead of an even share of 128-row stripes of all blocks")
     ap.add_argument("--explicit-rtol", type=float, default=1e-12, help="feti: tolerance of the set-up solves of the explicit operators")
     ap.add_argument("--explicit-slots", type=int, default=8, help="feti: a rank with fewer (congruent) blocks than this assembles with a replica solver of this many slots")
@@ -560,10 +561,13 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
         n_solves, asm_s = E.assemble_stats()
         storage_used = q.explicit_storage
-        ppref = {"class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
+        ppref = {"class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
         traffic, tsrc = pmc_lookup(ppref, "r02_pmc_traffic_feti_explicit.json", combine="sum") if full_size else (None, "not the configuration of the committed PMC pass")
         roofline = {
-            "bound": "hbm", "kernel": ("k_fxs_gemm8 (+ k_fxs_fin): Y = W_c X, ONE full dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks applied to the blocks' vectors together "
+            "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
+                                       "(every stored byte read once) and applied to the blocks' vectors together: 8 right-hand sides per pass, both products of a tile (W_IJ X_J and W_IJ' X_I) on the fp64 matrix "
+                                       "instruction v_mfma_f64_4x4x4_4b (4 flop per byte: 1/3 of the fp64 MFMA peak at the HBM rate, so still HBM-bound; the FETI dual operator apply, SURVEY 8d dense path)" if storage_used == "class_sym" else
+                                       "k_fxs_gemm8 (+ k_fxs_fin): Y = W_c X, ONE full dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks applied to the blocks' vectors together "
                                        "(8 right-hand sides per pass, the lane owns its output columns: no reduction across lanes; the FETI dual operator apply, SURVEY 8d dense path)" if storage_used == "class" else
                                        "k_fx_symv (+ k_fx_symv_fin): y_b = W_b x_b on the lower block-triangle of the symmetric dense fp64 local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b], every stored byte read once, "
                                        "all blocks of the rank in one launch (the FETI dual operator apply, SURVEY 8d dense path)" if storage_used == "sym" else
@@ -576,7 +580,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %s%.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
-            int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used == "class" else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
+            int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
         precision_note = "fp64 throughout: the dense blocks, the GEMV and everything in the dual space are fp64; reduced precision exists only inside the V-cycle that preconditions the SET-UP solves (their CG, residual test at rtol %.0e and solutions are fp64)" % a.explicit_rtol
         if world == 1 and not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and strict fp64
             q.Kplus.attach_explicit(None)

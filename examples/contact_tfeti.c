@@ -61,7 +61,7 @@ int main(int argc, char **argv)
   CHECK(pmh_feti_contact_default_opts(&o));
   if (argc > 2) o.explicit_dual = atoi(argv[2]);
   if (argc > 3) o.mg_precision = atoi(argv[3]);
-  if (argc > 4) o.explicit_storage = atoi(argv[4]); /* 1 PMH_FX_SYM (default), 0 PMH_FX_FULL, 2 PMH_FX_CLASS */
+  if (argc > 4) o.explicit_storage = atoi(argv[4]); /* 1 PMH_FX_SYM (default), 0 PMH_FX_FULL, 2 PMH_FX_CLASS, 3 PMH_FX_CLASS_SYM */
   double *u = (double *)malloc(sizeof(double) * N), *lam = (double *)malloc(sizeof(double) * nl);
   CHECK(pmh_feti_contact_solve(ctx, nsub, rs, rp, ci, va, f, nl, neq, nleaf, lrow, lroot, lval, c, kdim, R, dims, *ndof, &o, u, lam, &st));
 

@@ -314,12 +314,16 @@ typedef struct pmh_fexplicit_s *pmh_fexplicit;
 #define PMH_FX_CLASS 2 /* pmh_fexplicit_create_shared: congruent blocks share ONE full matrix W_c = (K^+)[U_c, U_c] per class (U_c = union of their
                           Gamma_b) applied to the blocks' vectors together, 8 right-hand sides per pass: 8 n_c^2 bytes for the whole class */
 int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
+#define PMH_FX_CLASS_SYM 3 /* pmh_fexplicit_create_shared_sym: the same W_c kept as its lower block-triangle in 16 x 16 tiles (4 n_c^2 bytes for the
+                              whole class); both products of a tile with the 8 right-hand sides run on the fp64 matrix instruction (4x4x4_4b) */
 int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS */
+int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_SYM */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);
 /* several GPUs, congruent blocks: E built over ALL blocks (B = the global gluing, K = the global block structure); this rank
    assembles and applies the 128-row stripes idx = rank (mod size) of the size-ordered list -- an even share of the dense bytes; the
-   all-reduce that ends B u completes F lambda.  PMH_FX_SYM only; before the assembly. */
+   all-reduce that ends B u completes F lambda (PMH_FX_CLASS: a contiguous range of the rows of W_c; PMH_FX_CLASS_SYM: whole 256-row super
+   bands dealt in snake order).  Not for PMH_FX_FULL; before the assembly. */
 int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size);
 int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int size, int *owner_out); /* host: owner rank of every 128-row stripe, block after block */
 int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int size, double *bytes_per_rank); /* host: dense bytes per rank under that rule */
@@ -515,7 +519,7 @@ typedef struct {
   double kplus_rtol; int kplus_max_it;
   int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
-  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS) */
+  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM) */
   int    orthonormalize;            /* QPTOrthonormalizeEq: G <- L^{-1} G */
 } pmh_feti_contact_opts;
 typedef struct {

@@ -242,6 +242,7 @@ _PROTOS = {
     "pmh_kspfeti_solve": [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.POINTER(KspFetiOpts), vp, vp, C.c_int, C.POINTER(KspFetiStats)],
     "pmh_fexplicit_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_fexplicit_create_shared": [vp, vp, vp, C.POINTER(vp)],
+    "pmh_fexplicit_create_shared_sym": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],

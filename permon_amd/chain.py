@@ -131,7 +131,7 @@ class FetiDualQP:
                 members = np.nonzero(gcls == c)[0]
                 union = np.unique(np.concatenate([tr[blk == m] - grs[m] for m in members])).size
                 b_cls += np.ceil(len(members) / 8.0) * 8.0 * float(union) ** 2
-            storage = "class" if b_cls < b_sym else "sym"
+            storage = "class_sym" if 0.5 * b_cls < b_sym else "sym"  # the class matrix in symmetric tiles: half of b_cls
         self.explicit_storage = storage
         if stripe is not None:
             rank, size, glob = stripe
@@ -140,7 +140,7 @@ class FetiDualQP:
             self._Bglob = MatGluing(self.ctx, glob["n_x"], self.n_lambda, glob["leaves_row"], glob["leaves_root"], glob["leaves_sign"])
             self._Kglob = MatBlockDiag.from_scipy(self.ctx, glob["block_rowstart"], sp.identity(glob["n_x"], format="csr"))  # block structure only
             ngl = len(glob["block_rowstart"]) - 1
-            E = MatExplicitDual(self._Bglob, self._Kglob, storage="class" if storage == "class" else "sym", block_class=np.zeros(ngl, dtype=np.int32))
+            E = MatExplicitDual(self._Bglob, self._Kglob, storage=storage if storage in ("class", "class_sym") else "sym", block_class=np.zeros(ngl, dtype=np.int32))
             E.set_stripe(rank, size)
         else:
             E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)

@@ -168,6 +168,7 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       GO(pmh_csr_block_classes(nsub, block_rowstart, rowptr, col, val, cls.data(), nullptr));
       // blocks of one class share K, hence K^+ (the Moore-Penrose inverse does not depend on the basis chosen for the kernel)
       if (o->explicit_storage == PMH_FX_CLASS) GO(pmh_fexplicit_create_shared(B, Kb, cls.data(), &E)); // congruent blocks share one matrix per class
+      else if (o->explicit_storage == PMH_FX_CLASS_SYM) GO(pmh_fexplicit_create_shared_sym(B, Kb, cls.data(), &E));
       else GO(pmh_fexplicit_create(B, Kb, o->explicit_storage, &E));
       GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));
       GO(pmh_matinv_attach_explicit(Kp, E));

@@ -358,6 +358,13 @@ extern "C" int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const 
   return fx_create(B, K, PMH_FX_CLASS, block_class, out);
 }
 
+// the same with W_c = W_c' kept as its lower block-triangle in 16 x 16 tiles (half the bytes; fp64 MFMA kernel k_fxs_symm8)
+extern "C" int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *out)
+{
+  PMH_ARG(block_class);
+  return fx_create(B, K, PMH_FX_CLASS_SYM, block_class, out);
+}
+
 static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *block_class, pmh_fexplicit *out)
 {
   PMH_ARG(B && K && out);
@@ -391,9 +398,9 @@ static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *bloc
     off += E->ld[b]; // every block padded to a multiple of 128: aligned 16-byte loads, whole bands and tiles; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
-  if (storage == PMH_FX_CLASS) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
+  if (storage == PMH_FX_CLASS || storage == PMH_FX_CLASS_SYM) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
     E->W.assign(nb, nullptr), E->woff.assign(nb, 0);
-    PMH_CHK(fxs_create(B, K, block_class, &E->sh));
+    PMH_CHK(fxs_create(B, K, block_class, storage == PMH_FX_CLASS_SYM, &E->sh));
     *out = E;
     return PMH_SUCCESS;
   }

@@ -3,7 +3,7 @@
 #include "feti_internal.h"
 
 struct fx_shared;
-int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, fx_shared **out);
+int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out); // sym: lower block-triangle in 16 x 16 tiles (PMH_FX_CLASS_SYM)
 void      fxs_destroy(fx_shared *S);
 int       fxs_set_stripe(fx_shared *S, int rank, int size);
 long long fxs_dense_bytes(fx_shared *S);

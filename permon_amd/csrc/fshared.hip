@@ -32,6 +32,11 @@ struct fxs_class {
   int              nloc = 0, nc = 0, ld = 0, ngroups = 0, r0 = 0, r1 = 0;
   long long        woff = 0, xoff = 0;
   int             *d_urel = nullptr;
+  // symmetric tile storage (fx_shared::sym): super bands of FXM_RS rows
+  int              nsb = 0;
+  std::vector<char> own;    // this rank applies / assembles super band sb
+  long long        ptoff = 0, ptsize = 0; // transposed partial sums: ptoff + group * ptsize + 2048 sb (sb + 1) / 2 + position * 8 + slot
+  int             *d_nseg = nullptr;      // segments of the direct sums per super band (0: not owned)
 };
 
 struct fx_shared {
@@ -53,6 +58,12 @@ struct fx_shared {
   double                 bytes = 0.0;
   std::vector<hipEvent_t> ev;
   int                    ev_used = 0, ev_on = 0;
+  // symmetric tile storage (PMH_FX_CLASS_SYM): the lower block-triangle of W_c in 16 x 16 tiles, k_fxs_symm8 (fp64 MFMA) + k_fxs_symfin
+  int                    sym = 0, segj = 0;
+  long long             *d_wgl = nullptr; // per workgroup: offset of its super band's tiles, offset of its transposed partial sums
+  double                *pt = nullptr;
+  long long              pt_tot = 0;
+  double                 owned_bytes = 0.0;
 };
 
 // Y = W_c X with 8 right-hand sides, W_c symmetric and stored in full: the product is taken as Y[c][s] = sum_r W[r][c] X[r][s], i.e.
@@ -147,8 +158,226 @@ __global__ void k_fxs_set_entries(int m, const int *__restrict__ idx, double val
   if (s < m && idx[s] >= 0) rhs[idx[s]] = val;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Symmetric tile storage (PMH_FX_CLASS_SYM): W_c = W_c' kept as its lower block-triangle, HALF the bytes of the full storage above.
+// With 8 right-hand sides every stored entry now feeds 16 multiply-adds (Y_I += W_IJ X_J and Y_J += W_IJ' X_I): 4 flop per byte, which a
+// kernel with per-lane accumulators cannot organise without a reduction across lanes for one of the two products.  The fp64 matrix
+// instruction v_mfma_f64_4x4x4_4b_f64 can: one instruction = four independent 4x4x4 products, i.e. 16 rows x 4 k x 4 right-hand sides,
+// at the full fp64 rate (measured 72 TFLOP/s, scripts/micro/mfma_f64.hip; the 16x16x4 shape would waste half of its 16 columns on 8
+// right-hand sides AND measured 44 TFLOP/s).  Operand maps (measured, same file): A lane l = A_b[i = l&3][k = l>>4] of block b = (l>>2)&3,
+// B lane l = B_b[k = l>>4][j = l&3], D lane l = D_b[i = l>>4][j = l&3].
+//
+// Layout: rows in super bands of 256 (16 row tiles); super band sb holds, for every column tile J = 0 .. 16 (sb + 1) - 1 and row tile
+// I = 0 .. 15, the 16 x 16 tile (sb, I, J) as 2 KB, column tile after column tile -- a wave streams 32 KB contiguous per column tile.
+// Inside the square diagonal block the tiles above the diagonal are zero and the diagonal tiles keep their strict lower triangle plus HALF
+// their diagonal, so that the kernel treats every tile alike (direct + transposed product) with no branch: L' X + L'' X = W X.
+// Element (r, c) of a tile sits at double index (q >> 1) * 128 + 2 * l + (q & 1) with q = r >> 2, l = 16 (r & 3) + c: two 16-byte loads per
+// lane give the four A operands of the transposed product (row group q, lane l <-> k = row & 3, column c) with no shuffling.  The direct
+// product needs the transposed lane map: the tile goes through a wave-private 2 KB LDS image (rotation-swizzled, conflict-free both ways).
+#define FXM_RT 16
+#define FXM_RS 256
+#define FXM_NB 8 // tiles in flight per wave (16 KB)
+static __device__ __forceinline__ double fxm_mfma_hw(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+#define fxm_mfma(a, b, c) (DBG == 3 ? (a) + (b) + (c) : fxm_mfma_hw(a, b, c))
+
+// workgroup = (class, group, super band, column tiles [jbeg, jend)); its 4 waves take a quarter of the column tiles each and walk down the
+// 16 row tiles of every column tile.  Per tile: 8 MFMA for Y_J += W_IJ' X_I (accumulated over the 16 row tiles in 2 registers, then stored
+// as the partial sum of (super band, J)), 8 MFMA for Y_I += W_IJ X_J (32 accumulators per lane for the 16 row tiles, kept for the whole
+// segment).  X of the super band's rows is staged in LDS once; X of the column tile is loaded from L2 one tile ahead.
+template <int DBG> // 0: the product; 1-3: tuning experiments (wrong results): no partial-sum stores / no LDS transposition / no MFMA
+__global__ __launch_bounds__(PMH_BLOCK, 2) void k_fxs_symm8(const int *__restrict__ wg, const long long *__restrict__ wgl, const int *__restrict__ c_ld, const long long *__restrict__ c_xoff,
+                                                           const double *__restrict__ Wbase, const double *__restrict__ X, double *__restrict__ pd, long long pd_stride, double *__restrict__ pt)
+{
+  __shared__ double xs[FXM_RS * FXS_S];
+  __shared__ double scr[PMH_BLOCK / 64][256];
+  __shared__ double xjst[PMH_BLOCK / 64][16 * FXS_S];
+  const int *w8 = wg + 8 * blockIdx.x;
+  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), g = __builtin_amdgcn_readfirstlane(w8[1]), sb = __builtin_amdgcn_readfirstlane(w8[2]);
+  const int  jbeg = __builtin_amdgcn_readfirstlane(w8[3]), jend = __builtin_amdgcn_readfirstlane(w8[4]), seg = __builtin_amdgcn_readfirstlane(w8[5]);
+  const int  lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int  ld = c_ld[c];
+  const long long xbase = c_xoff[c] + (long long)g * ld * FXS_S;
+  const double *__restrict__ x = X + xbase;
+  for (int i = threadIdx.x * 2; i < FXM_RS * FXS_S; i += 2 * PMH_BLOCK) *(dbl2 *)(xs + i) = *(const dbl2 *)(x + (long long)sb * FXM_RS * FXS_S + i);
+  __syncthreads();
+  const int nj = jend - jbeg, j0 = jbeg + (nj * wave) / 4, j1 = jbeg + (nj * (wave + 1)) / 4;
+  const int ntile = (j1 - j0) * FXM_RT;
+  const double *__restrict__ tp = Wbase + wgl[2 * blockIdx.x] + (long long)j0 * (FXM_RT * 256) + lane * 2;
+  double *__restrict__ ptp = pt + wgl[2 * blockIdx.x + 1];
+  const int kq = lane >> 4, r4 = lane & 3, a16 = lane & 15;
+  double dd[FXM_RT][2];
+#pragma unroll
+  for (int I = 0; I < FXM_RT; I++) dd[I][0] = dd[I][1] = 0.0;
+  if (ntile > 0) {
+    dbl2 ring[FXM_NB][2];
+#pragma unroll
+    for (int k = 0; k < FXM_NB; k++) {
+      const double *q = tp + (long long)min(k, ntile - 1) * 256;
+      ring[k][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[k][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
+    }
+    // operand of the products with X: lane l supplies X[row0 + 4 q + (l >> 4)][4 h + (l & 3)]
+    const int xo = kq * FXS_S + r4;
+    double   *sc = scr[wave], *xjs = xjst[wave];
+    // X of the 16 columns of a column tile = 1 KB contiguous: every lane fetches 16 bytes of it one column tile ahead (2 registers), the
+    // operands are read back from a wave-private LDS image
+    dbl2 xraw = *(const dbl2 *)(x + (long long)j0 * 16 * FXS_S + lane * 2);
+    // LDS image of a tile: element (r, c) at r * 16 + ((c + r) & 15)
+    int wofs[4], rofs[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wofs[q] = (4 * q + kq) * 16 + ((a16 + 4 * q + kq) & 15), rofs[q] = a16 * 16 + ((4 * q + kq + a16) & 15);
+    int t = 0;
+    for (int J = j0; J < j1; J++) {
+      *(dbl2 *)(xjs + lane * 2) = xraw;
+      double xj[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; q++) xj[q][0] = xjs[4 * q * FXS_S + xo], xj[q][1] = xjs[4 * q * FXS_S + xo + 4];
+      xraw = *(const dbl2 *)(x + (long long)min(J + 1, j1 - 1) * 16 * FXS_S + lane * 2);
+      double dt0 = 0.0, dt1 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+#pragma unroll
+      for (int I = 0; I < FXM_RT; I++, t++) {
+        const double t0 = ring[I % FXM_NB][0].x, t1 = ring[I % FXM_NB][0].y, t2 = ring[I % FXM_NB][1].x, t3 = ring[I % FXM_NB][1].y;
+        if (DBG != 2) sc[wofs[0]] = t0, sc[wofs[1]] = t1, sc[wofs[2]] = t2, sc[wofs[3]] = t3;
+        const double *xi = xs + (I * 16) * FXS_S + xo;
+        const double  xi00 = xi[0], xi01 = xi[4], xi10 = xi[4 * FXS_S], xi11 = xi[4 * FXS_S + 4], xi20 = xi[8 * FXS_S], xi21 = xi[8 * FXS_S + 4], xi30 = xi[12 * FXS_S], xi31 = xi[12 * FXS_S + 4];
+        if (I > 0) { // the direct product of the previous tile: its transposed image has arrived meanwhile
+          dd[I ? I - 1 : 0][0] = fxm_mfma(u0, xj[0][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u0, xj[0][1], dd[I ? I - 1 : 0][1]);
+          dd[I ? I - 1 : 0][0] = fxm_mfma(u1, xj[1][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u1, xj[1][1], dd[I ? I - 1 : 0][1]);
+          dd[I ? I - 1 : 0][0] = fxm_mfma(u2, xj[2][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u2, xj[2][1], dd[I ? I - 1 : 0][1]);
+          dd[I ? I - 1 : 0][0] = fxm_mfma(u3, xj[3][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u3, xj[3][1], dd[I ? I - 1 : 0][1]);
+        }
+        dt0 = fxm_mfma(t0, xi00, dt0), dt1 = fxm_mfma(t0, xi01, dt1);
+        dt0 = fxm_mfma(t1, xi10, dt0), dt1 = fxm_mfma(t1, xi11, dt1);
+        dt0 = fxm_mfma(t2, xi20, dt0), dt1 = fxm_mfma(t2, xi21, dt1);
+        dt0 = fxm_mfma(t3, xi30, dt0), dt1 = fxm_mfma(t3, xi31, dt1);
+        {
+          const double *q = tp + (long long)min(t + FXM_NB, ntile - 1) * 256;
+          ring[I % FXM_NB][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[I % FXM_NB][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
+        }
+        if (DBG != 2) u0 = sc[rofs[0]], u1 = sc[rofs[1]], u2 = sc[rofs[2]], u3 = sc[rofs[3]];
+        else u0 = t0, u1 = t1, u2 = t2, u3 = t3;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      dd[FXM_RT - 1][0] = fxm_mfma(u0, xj[0][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u0, xj[0][1], dd[FXM_RT - 1][1]);
+      dd[FXM_RT - 1][0] = fxm_mfma(u1, xj[1][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u1, xj[1][1], dd[FXM_RT - 1][1]);
+      dd[FXM_RT - 1][0] = fxm_mfma(u2, xj[2][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u2, xj[2][1], dd[FXM_RT - 1][1]);
+      dd[FXM_RT - 1][0] = fxm_mfma(u3, xj[3][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u3, xj[3][1], dd[FXM_RT - 1][1]);
+      // D lane l = (column 4 ((l >> 2) & 3) + (l >> 4) of the tile, right-hand side 4 h + (l & 3))
+      double *o = ptp + (long long)(J * 16 + 4 * ((lane >> 2) & 3) + kq) * FXS_S + r4;
+      if (DBG == 4) *(dbl2 *)(ptp + (long long)(J * 16) * FXS_S + lane * 2) = dbl2{dt0, dt1};
+      else if (DBG == 5) *(dbl2 *)(ptp + (long long)(j0 * 16) * FXS_S + lane * 2) = dbl2{dt0, dt1};
+      else if (DBG == 6) __builtin_nontemporal_store(dbl2{dt0, dt1}, (dbl2 *)(ptp + (long long)(J * 16) * FXS_S + lane * 2));
+      else if (DBG != 1) o[0] = dt0, o[4] = dt1;
+      else if (dt0 == 1.2345e-67) o[0] = dt1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // direct sums: the four waves' accumulators are added in wave order through LDS (the X stage is free now), the last wave writes the segment's sums
+  __syncthreads();
+  const int rowl = 4 * ((lane >> 2) & 3) + kq;
+  for (int w = 0; w < PMH_BLOCK / 64; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int I = 0; I < FXM_RT; I++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int    idx = (I * 2 + h) * 64 + lane;
+          const double v   = w ? xs[idx] + dd[I][h] : dd[I][h];
+          if (w < PMH_BLOCK / 64 - 1) xs[idx] = v;
+          else pd[(long long)seg * pd_stride + xbase + (long long)(sb * FXM_RS + I * 16 + rowl) * FXS_S + 4 * h + r4] = v;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// Y[position][slot] = the direct sums of the segments of the position's super band + the transposed partial sums of every owned super band from
+// that one on, in a fixed order.  grid (ld * 8 / 2 / 256, groups of the class)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nsb, const int *__restrict__ nseg_of, long long xbase0, long long pd_stride, const double *__restrict__ pd,
+                                                          long long ptoff, long long ptsize, const double *__restrict__ pt, double *__restrict__ Y)
+{
+  const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x);
+  if (i >= (long long)ld * FXS_S) return;
+  const int       g = blockIdx.y, sb0 = (int)(i / (FXM_RS * FXS_S));
+  const long long xb = xbase0 + (long long)g * ld * FXS_S;
+  dbl2            s = {0.0, 0.0};
+  const int       ns = nseg_of[sb0];
+  for (int j = 0; j < ns; j++) s += *(const dbl2 *)(pd + (long long)j * pd_stride + xb + i);
+  const double *__restrict__ p = pt + ptoff + (long long)g * ptsize + i;
+  for (int sb = sb0; sb < nsb; sb++)
+    if (nseg_of[sb]) s += *(const dbl2 *)(p + (long long)FXM_RS * FXS_S * ((long long)sb * (sb + 1) / 2));
+  *(dbl2 *)(Y + xb + i) = s;
+}
+
+// row p of W_c from a K^+ solve: the entries c <= p go to the tiles of p's row tile (the diagonal entry halved, see above)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_extract_sym(int p, const int *__restrict__ urel, const double *__restrict__ u, double *__restrict__ wsb)
+{
+  // wsb: first tile of p's super band
+  const int Il = (p % FXM_RS) / 16, r = p & 15, q = r >> 2;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c <= p; c += gridDim.x * PMH_BLOCK) {
+    const double v = u[urel[c]];
+    const int    l = 16 * (r & 3) + (c & 15);
+    wsb[((long long)(c >> 4) * FXM_RT + Il) * 256 + (q >> 1) * 128 + 2 * l + (q & 1)] = c == p ? 0.5 * v : v;
+  }
+}
+
 static int fxs_build_launch(fx_shared *S)
 {
+  if (S->sym) {
+    // work items = (super band, segment of column tiles), 32 KB per wave and column tile; the segment length gives >= ~8 rounds of
+    // 512 resident workgroups (2 per CU) but stays >= 16 column tiles (direct sums written per segment: 16 KB per 0.5 MB of tiles)
+    long long steps = 0;
+    for (auto &C : S->C)
+      for (int sb = 0; sb < C.nsb; sb++)
+        if (C.own[sb]) steps += (long long)C.ngroups * (sb + 1) * FXM_RT;
+    int segj = (int)std::max(16LL, std::min(128LL, steps / (8 * 512)));
+    segj     = (segj + 3) / 4 * 4;
+    if (const char *e = getenv("PMH_FXM_SEGJ")) segj = std::max(4, atoi(e) / 4 * 4);
+    S->segj = segj;
+    std::vector<int>       wg;
+    std::vector<long long> wgl;
+    int                    nsegmax = 1;
+    S->bytes = 0.0, S->owned_bytes = 0.0;
+    for (int c = 0; c < S->ncls; c++) {
+      fxs_class       &C = S->C[c];
+      std::vector<int> nseg_of((size_t)std::max(1, C.nsb), 0);
+      double           tiles = 0.0, parts = 0.0;
+      for (int sb = C.nsb - 1; sb >= 0; sb--) { // the long super bands first
+        if (!C.own[sb]) continue;
+        const int nj = (sb + 1) * FXM_RT, ns = (nj + segj - 1) / segj;
+        nseg_of[sb]  = ns, nsegmax = std::max(nsegmax, ns);
+        tiles += (double)nj * FXM_RT * 2048.0;
+        parts += (double)ns * FXM_RS * FXS_S * 8.0 + (double)nj * 16 * FXS_S * 8.0; // direct sums per segment + transposed sums per column
+        for (int g = 0; g < C.ngroups; g++)
+          for (int j = 0; j < ns; j++) {
+            wg.insert(wg.end(), {c, g, sb, j * segj, std::min(nj, (j + 1) * segj), j, 0, 0});
+            wgl.push_back(C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
+            wgl.push_back(C.ptoff + (long long)g * C.ptsize + (long long)FXM_RS * FXS_S * ((long long)sb * (sb + 1) / 2));
+          }
+      }
+      S->owned_bytes += tiles;
+      // the owned tiles once per group + X read (rows + columns) + the partial sums written and read back + Y written
+      S->bytes += (double)C.ngroups * (tiles + 2.0 * parts + 2.0 * 8.0 * FXS_S * C.ld);
+      if (!C.d_nseg) PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * nseg_of.size(), (void **)&C.d_nseg));
+      PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_nseg, nseg_of.data(), sizeof(int) * nseg_of.size()));
+    }
+    S->nwg = (int)(wg.size() / 8), S->nseg = nsegmax;
+    wg.insert(wg.end(), {0, 0, 0, 0, 0, 0, 0, 0});
+    wgl.insert(wgl.end(), {0, 0});
+    if (S->d_wg) pmh_free(S->ctx, S->d_wg);
+    if (S->d_wgl) pmh_free(S->ctx, S->d_wgl);
+    PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * wg.size(), (void **)&S->d_wg));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wg, wg.data(), sizeof(int) * wg.size()));
+    PMH_CHK(pmh_malloc(S->ctx, sizeof(long long) * wgl.size(), (void **)&S->d_wgl));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wgl, wgl.data(), sizeof(long long) * wgl.size()));
+    const long long need = (long long)nsegmax * std::max(16LL, S->nX);
+    if (need > S->part_cap) {
+      if (S->part) pmh_free(S->ctx, S->part);
+      PMH_CHK(pmh_malloc(S->ctx, sizeof(double) * (size_t)need, (void **)&S->part));
+      S->part_cap = need;
+    }
+    return PMH_SUCCESS; // k_fxs_symfin reads only what the segments of a super band wrote
+  }
   // segments of the rank's rows: enough of them to give the chip >= ~4000 waves (n_c / 128 column chunks each), at most 32
   int maxrows = 0, chunks = 0;
   for (auto &C : S->C) maxrows = std::max(maxrows, C.r1 - C.r0), chunks += C.ngroups * (C.ld / 128);
@@ -183,12 +412,12 @@ static int fxs_build_launch(fx_shared *S)
   return pmh_memset(S->ctx, S->part, 0, sizeof(double) * (size_t)need); // column chunks beyond a class's ld / empty segments stay zero
 }
 
-int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, fx_shared **out)
+int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out)
 {
   PMH_ARG(B && K && block_class && out && B->n_x == K->n);
   pmh_ctx    ctx = B->ctx;
   fx_shared *S   = new fx_shared();
-  S->ctx = ctx, S->B = B, S->K = K, S->nb = K->nblocks;
+  S->ctx = ctx, S->B = B, S->K = K, S->nb = K->nblocks, S->sym = sym;
   S->cls.assign(block_class, block_class + S->nb);
   S->ncls = 0;
   for (int b = 0; b < S->nb; b++) {
@@ -213,17 +442,25 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, fx_shared 
     lb[i] = block_of(B->h_row[i]);
     S->C[S->cls[lb[i]]].pos[B->h_row[i] - K->rowstart[lb[i]]] = 0;
   }
-  long long wtot = 0, xtot = 0;
+  long long wtot = 0, xtot = 0, pttot = 0;
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
     for (int i = 0; i < C.nloc; i++)
       if (C.pos[i] == 0) C.pos[i] = (int)C.urel.size(), C.urel.push_back(i);
     C.nc      = (int)C.urel.size();
-    C.ld      = (C.nc + FXS_PAD - 1) / FXS_PAD * FXS_PAD;
+    const int pad = sym ? FXM_RS : FXS_PAD;
+    C.ld      = (C.nc + pad - 1) / pad * pad;
     C.ngroups = ((int)C.blocks.size() + FXS_S - 1) / FXS_S;
     C.r0 = 0, C.r1 = C.ld;
     C.woff = wtot, C.xoff = xtot;
-    wtot += (long long)C.ld * C.ld;
+    if (sym) {
+      C.nsb = C.ld / FXM_RS;
+      C.own.assign((size_t)std::max(1, C.nsb), 1);
+      C.ptoff = pttot, C.ptsize = (long long)FXM_RS * FXS_S * ((long long)C.nsb * (C.nsb + 1) / 2);
+      pttot += C.ngroups * C.ptsize;
+      wtot += (long long)FXM_RS * FXM_RS * ((long long)C.nsb * (C.nsb + 1) / 2); // super band sb: (sb + 1) * 16 column tiles x 16 row tiles x 256 doubles
+    } else
+      wtot += (long long)C.ld * C.ld;
     xtot += (long long)C.ngroups * C.ld * FXS_S;
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)std::max(1, C.nc), (void **)&C.d_urel));
     if (C.nc) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_urel, C.urel.data(), sizeof(int) * (size_t)C.nc));
@@ -243,6 +480,10 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, fx_shared 
     hipError_t   e     = hipMalloc((void **)&S->Wbase, bytes);
     if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_create_shared: %.2f GB for the shared explicit operators: %s", bytes / 1e9, hipGetErrorString(e));
     PMH_HIP(hipMemsetAsync(S->Wbase, 0, bytes, ctx->stream));
+  }
+  if (sym) {
+    S->pt_tot = pttot;
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, pttot), (void **)&S->pt));
   }
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, xtot), (void **)&S->X));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, xtot), (void **)&S->Y));
@@ -266,8 +507,12 @@ void fxs_destroy(fx_shared *S)
 {
   if (!S) return;
   pmh_ctx ctx = S->ctx;
-  for (auto &C : S->C)
+  for (auto &C : S->C) {
     if (C.d_urel) pmh_free(ctx, C.d_urel);
+    if (C.d_nseg) pmh_free(ctx, C.d_nseg);
+  }
+  if (S->pt) pmh_free(ctx, S->pt);
+  if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   pmh_gluing_destroy(S->Bc);
   if (S->Wbase) (void)hipFree(S->Wbase);
   if (S->part) pmh_free(ctx, S->part);
@@ -279,6 +524,17 @@ void fxs_destroy(fx_shared *S)
 // several GPUs: rank r applies / assembles the rows [r0, r1) of every W_c, contiguous ranges of equal length (multiples of 32)
 int fxs_set_stripe(fx_shared *S, int rank, int size)
 {
+  if (S->sym) {
+    // whole super bands (a rank assembles exactly the rows it applies); super band sb costs sb + 1 column blocks: dealt from the longest
+    // down in snake order, so every rank gets the same number of long and short ones
+    for (auto &C : S->C) {
+      for (int i = 0; i < C.nsb; i++) {
+        const int sb = C.nsb - 1 - i, round = i / size, k = i % size;
+        C.own[sb]    = ((round & 1) ? size - 1 - k : k) == rank;
+      }
+    }
+    return fxs_build_launch(S);
+  }
   for (auto &C : S->C) {
     const int nrg = C.ld / 32; // row groups of 32
     C.r0 = (int)((long long)nrg * rank / size) * 32;
@@ -287,7 +543,7 @@ int fxs_set_stripe(fx_shared *S, int rank, int size)
   return fxs_build_launch(S);
 }
 
-long long fxs_dense_bytes(fx_shared *S) { return (long long)sizeof(double) * S->wtot; }
+long long fxs_dense_bytes(fx_shared *S) { return S->sym ? (long long)S->owned_bytes : (long long)sizeof(double) * S->wtot; }
 double    fxs_apply_bytes(fx_shared *S) { return S->bytes; }
 
 int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves)
@@ -305,7 +561,11 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
     if (cslots[c].empty()) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: no solver slot for block class %d", c);
     for (int s : cslots[c])
       if (srs[s + 1] - srs[s] != C.nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, C.nloc);
-    for (int p = C.r0; p < std::min(C.r1, C.nc); p++) todo[c].push_back(p); // the rows of this rank's stripe
+    if (S->sym) {
+      for (int p = 0; p < C.nc; p++)
+        if (C.own[p / FXM_RS]) todo[c].push_back(p); // the rows of this rank's super bands
+    } else
+      for (int p = C.r0; p < std::min(C.r1, C.nc); p++) todo[c].push_back(p); // the rows of this rank's stripe
     nbatch = std::max(nbatch, (int)((todo[c].size() + cslots[c].size() - 1) / cslots[c].size()));
   }
   double      *rhs, *sol;
@@ -349,6 +609,11 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (prow[s] < 0) continue;
       (*n_solves)++;
       const fxs_class &C = S->C[slot_class[s]];
+      if (S->sym) {
+        const int sb = prow[s] / FXM_RS;
+        hipLaunchKernelGGL(k_fxs_extract_sym, dim3(std::max(1, std::min(64, (prow[s] + PMH_BLOCK) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, prow[s], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+                           S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
+      } else
       hipLaunchKernelGGL(k_fxs_extract, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.nc, (const int *)C.d_urel, (const double *)(sol + srs[s]),
                          S->Wbase + C.woff + (long long)prow[s] * C.ld); // row p of W_c = column p (K^+ symmetric)
     }
@@ -368,9 +633,26 @@ static int fxs_gemm(fx_shared *S)
   const bool  timed = S->ev_on && (size_t)(2 * S->ev_used + 2) <= S->ev.size();
   if (timed) PMH_HIP(hipEventRecord(S->ev[2 * S->ev_used], st));
   const long long stride = std::max(16LL, S->nX);
+  if (S->sym) {
+    static const int dbg = getenv("PMH_FXM_DBG") ? atoi(getenv("PMH_FXM_DBG")) : 0;
+#define FXM_LAUNCH(D) \
+  hipLaunchKernelGGL(k_fxs_symm8<D>, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff, (const double *)S->Wbase, \
+                     (const double *)S->X, S->part, stride, S->pt)
+    if (dbg == 1) FXM_LAUNCH(1);
+    else if (dbg == 2) FXM_LAUNCH(2);
+    else if (dbg == 3) FXM_LAUNCH(3);
+    else if (dbg == 4) FXM_LAUNCH(4);
+    else if (dbg == 5) FXM_LAUNCH(5);
+    else if (dbg == 6) FXM_LAUNCH(6);
+    else FXM_LAUNCH(0);
+    for (auto &C : S->C)
+      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nsb, (const int *)C.d_nseg, C.xoff, stride,
+                         (const double *)S->part, C.ptoff, C.ptsize, (const double *)S->pt, S->Y);
+  } else {
   hipLaunchKernelGGL(k_fxs_gemm8, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const int *)S->d_ld, (const long long *)S->d_woff, (const long long *)S->d_xoff, (const double *)S->Wbase,
                      (const double *)S->X, S->part, stride);
   hipLaunchKernelGGL(k_fxs_fin, dim3((unsigned)((S->nX / 2 + PMH_BLOCK - 1) / PMH_BLOCK)), dim3(PMH_BLOCK), 0, st, S->nX, S->nseg, stride, (const double *)S->part, S->Y);
+  }
   if (timed) {
     PMH_HIP(hipEventRecord(S->ev[2 * S->ev_used + 1], st));
     S->ev_used++;
@@ -402,6 +684,20 @@ int fxs_fill_pattern(fx_shared *S, int byte)
 int fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host)
 {
   const fxs_class    &C = S->C[S->cls[b]];
+  if (S->sym) {
+    // the class's tiles on the host (tests: small classes), W[p][c] from the stored lower triangle
+    const long long     len = (long long)FXM_RS * FXM_RS * ((long long)C.nsb * (C.nsb + 1) / 2);
+    std::vector<double> T((size_t)len);
+    PMH_HIP(hipMemcpy(T.data(), S->Wbase + C.woff, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost));
+    auto at = [&](int p, int c) {
+      const int hi = std::max(p, c), lo = std::min(p, c), sb = hi / FXM_RS, Il = (hi % FXM_RS) / 16, r = hi & 15, q = r >> 2, l = 16 * (r & 3) + (lo & 15);
+      const double v = T[(size_t)((long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2) + ((long long)(lo >> 4) * FXM_RT + Il) * 256 + (q >> 1) * 128 + 2 * l + (q & 1))];
+      return hi == lo ? 2.0 * v : v;
+    };
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < n; k++) out_host[(size_t)i * n + k] = at(C.pos[gamma[i] - S->K->rowstart[b]], C.pos[gamma[k] - S->K->rowstart[b]]);
+    return PMH_SUCCESS;
+  }
   std::vector<double> row((size_t)std::max(1, C.ld));
   for (int i = 0; i < n; i++) {
     const int p = C.pos[gamma[i] - S->K->rowstart[b]];

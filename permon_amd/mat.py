@@ -241,13 +241,15 @@ class MatExplicitDual:
 
     def __init__(self, B, K, storage="sym", block_class=None):
         """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV; "class": congruent blocks
-        (block_class from csr_block_classes) share ONE full matrix per class, applied to their vectors together (8 per pass)."""
+        (block_class from csr_block_classes) share ONE full matrix per class, applied to their vectors together (8 per pass);
+        "class_sym": that matrix kept as its lower block-triangle in 16 x 16 tiles (half the bytes, fp64 MFMA kernel)."""
         self.ctx, self.B, self.K, self.storage = B.ctx, B, K, storage
         h = C.c_void_p()
-        if storage == "class":
+        if storage in ("class", "class_sym"):
             bc = np.ascontiguousarray(block_class, dtype=np.int32)
             assert bc.size == K.nblocks
-            check(self.ctx.L.pmh_fexplicit_create_shared(B.h, K.h, bc.ctypes.data_as(C.c_void_p), C.byref(h)))
+            create = self.ctx.L.pmh_fexplicit_create_shared if storage == "class" else self.ctx.L.pmh_fexplicit_create_shared_sym
+            check(create(B.h, K.h, bc.ctypes.data_as(C.c_void_p), C.byref(h)))
         else:
             check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, {"full": 0, "sym": 1}[storage], C.byref(h)))
         self.h = h

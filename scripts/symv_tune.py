@@ -1,5 +1,5 @@
 """Times the dense apply kernels of the explicit local dual operators at configs[2] size without the set-up solves (the storage is
-filled with a byte pattern).  usage: python scripts/symv_tune.py [sym|full|class] [nel] [blocks] [share of N]"""
+filled with a byte pattern).  usage: python scripts/symv_tune.py [sym|full|class|class_sym] [nel] [blocks] [share of N]"""
 import os
 import sys
 

@@ -35,7 +35,7 @@ def test_block_classes_host():
     assert cls.tolist() == [0, 0, 1, 0]
 
 
-@pytest.mark.parametrize("share,storage", [(True, "sym"), (False, "sym"), (True, "full"), (True, "class")])
+@pytest.mark.parametrize("share,storage", [(True, "sym"), (False, "sym"), (True, "full"), (True, "class"), (True, "class_sym")])
 def test_explicit_blocks_vs_pinv(ctx, share, storage):
     """nel = 2: every W_b equals the dense pseudo-inverse of K_b on Gamma_b; F through the explicit path equals B pinv(K) B'."""
     f = pa.CubeFeti((2, 2, 1), 2, contact=True)
@@ -64,7 +64,7 @@ def test_explicit_blocks_vs_pinv(ctx, share, storage):
     assert np.array_equal(y.to_numpy(), y2.to_numpy())
 
 
-@pytest.mark.parametrize("storage", ["sym", "full", "class"])
+@pytest.mark.parametrize("storage", ["sym", "full", "class", "class_sym"])
 def test_explicit_vs_iterative_F(ctx, storage):
     """2x2x2 cubes, nel = 6: F_dense lambda vs the iterative B K^+ B' lambda (rtol 1e-13) <= 1e-10; the dense kernel (SYMV on the
     lower block-triangle / GEMV on the full matrix) vs numpy, and bitwise reproducible."""
@@ -83,7 +83,7 @@ def test_explicit_vs_iterative_F(ctx, storage):
         assert np.linalg.norm(yb.to_numpy() - ref) <= 1e-10 * np.linalg.norm(ref)
     # chain vectors agree (d, b: computed with the respective F)
     assert np.linalg.norm(q_ex.b.to_numpy() - q_it.b.to_numpy()) <= 1e-9 * np.linalg.norm(q_it.b.to_numpy())
-    if storage == "class":  # multivector numbering: the dense kernel is covered through F above; reproducibility here
+    if storage in ("class", "class_sym"):  # multivector numbering: the dense kernel is covered through F above; reproducibility here
         ntot, _ = q_ex.E.compressed_size()
         xm = ctx.vec_from(rng.standard_normal(ntot))
         ya, yb = ctx.vec(ntot), ctx.vec(ntot)
@@ -149,7 +149,7 @@ def test_explicit_replica_solver(ctx):
     assert n_solves == q.E.n_gamma[0]
 
 
-@pytest.mark.parametrize("storage", ["sym", "class"])
+@pytest.mark.parametrize("storage", ["sym", "class", "class_sym"])
 def test_striped_shares_sum_to_F(ctx, storage):
     """Several GPUs rehearsed on one: the operator spans all blocks, rank r of 3 keeps the 128-row stripes idx = r (mod 3); the sum of
     the three ranks' applies (the all-reduce) equals F lambda of the unstriped operator, each share is bitwise reproducible, and the
