@@ -33,10 +33,12 @@ struct fxs_class {
   long long        woff = 0, xoff = 0;
   int             *d_urel = nullptr;
   // symmetric tile storage (fx_shared::sym): super bands of FXM_RS rows
-  int              nsb = 0;
-  std::vector<char> own;    // this rank applies / assembles super band sb
-  long long        ptoff = 0, ptsize = 0; // transposed partial sums: ptoff + group * ptsize + 2048 sb (sb + 1) / 2 + position * 8 + slot
-  int             *d_nseg = nullptr;      // segments of the direct sums per super band (0: not owned)
+  int              nsb = 0, nmb = 0; // mega bands of FXM_MB super bands
+  std::vector<char> own;    // this rank applies / assembles super band sb (whole mega bands)
+  long long        ptoff = 0, ptsize = 0; // transposed partial sums: ptoff + group * ptsize + ptm[mega band] + position * 8 + slot
+  std::vector<long long> ptm;
+  int             *d_nseg = nullptr;      // items (= segments of the direct sums) per (group, mega band) (0: not owned)
+  long long       *d_ptoff = nullptr;
 };
 
 struct fx_shared {
@@ -60,7 +62,8 @@ struct fx_shared {
   int                    ev_used = 0, ev_on = 0;
   // symmetric tile storage (PMH_FX_CLASS_SYM): the lower block-triangle of W_c in 16 x 16 tiles, k_fxs_symm8 (fp64 MFMA) + k_fxs_symfin
   int                    sym = 0, segj = 0;
-  long long             *d_wgl = nullptr; // per workgroup: offset of its super band's tiles, offset of its transposed partial sums
+  long long             *d_wgl = nullptr; // per item: offset of its class's tiles, offset of its transposed partial sums
+  int                   *d_items = nullptr;
   double                *pt = nullptr;
   long long              pt_tot = 0;
   double                 owned_bytes = 0.0;
@@ -178,134 +181,150 @@ __global__ void k_fxs_set_entries(int m, const int *__restrict__ idx, double val
 #define FXM_RT 16
 #define FXM_RS 256
 #define FXM_NB 8 // tiles in flight per wave (16 KB)
-static __device__ __forceinline__ double fxm_mfma_hw(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
-#define fxm_mfma(a, b, c) (DBG == 3 ? (a) + (b) + (c) : fxm_mfma_hw(a, b, c))
+#define FXM_MB 4 // super bands per mega band = per workgroup: the transposed sums of 1024 rows are combined on chip before they are written
+#define FXM_THREADS 512
+static __device__ __forceinline__ double fxm_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
-// workgroup = (class, group, super band, column tiles [jbeg, jend)); its 4 waves take a quarter of the column tiles each and walk down the
-// 16 row tiles of every column tile.  Per tile: 8 MFMA for Y_J += W_IJ' X_I (accumulated over the 16 row tiles in 2 registers, then stored
-// as the partial sum of (super band, J)), 8 MFMA for Y_I += W_IJ X_J (32 accumulators per lane for the 16 row tiles, kept for the whole
-// segment).  X of the super band's rows is staged in LDS once; X of the column tile is loaded from L2 one tile ahead.
-template <int DBG> // 0: the product; 1-3: tuning experiments (wrong results): no partial-sum stores / no LDS transposition / no MFMA
-__global__ __launch_bounds__(PMH_BLOCK, 2) void k_fxs_symm8(const int *__restrict__ wg, const long long *__restrict__ wgl, const int *__restrict__ c_ld, const long long *__restrict__ c_xoff,
-                                                           const double *__restrict__ Wbase, const double *__restrict__ X, double *__restrict__ pd, long long pd_stride, double *__restrict__ pt)
+// Persistent grid, one workgroup of 8 waves per CU, each with an equal run of work: items = (class, group, mega band m = super bands
+// 4m .. 4m+3, column tiles [jbeg, jend)).  Wave w works on super band 4m + (w >> 1) and the column tiles jbeg + (w & 1), + 2, ... -- the
+// eight waves walk the column tiles in lock step (one barrier per pair), each down the 16 row tiles of its super band.  Per tile: 8 MFMA
+// for Y_J += W_IJ' X_I (accumulated over the 16 row tiles in 2 registers; the four super bands' sums of a column tile are then added in
+// LDS, in super band order, and stored as ONE 1 KB partial sum per (mega band, column tile): measured, the HBM writes of these partial
+// sums are what limits the kernel -- with one per 256 rows 3 % of the bytes cost 10-18 % of the time) and 8 MFMA for Y_I += W_IJ X_J (32
+// accumulators per lane for the 16 row tiles, kept for the whole item and stored once per item).  X of the mega band's rows is staged in
+// LDS once per item; X of the column tile is fetched one tile ahead.  Every sum has a fixed order => bitwise reproducible.
+__global__ __launch_bounds__(FXM_THREADS, 1) void k_fxs_symm8(const int *__restrict__ wg_first, const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_ld,
+                                                              const long long *__restrict__ c_xoff, const double *__restrict__ Wbase, const double *__restrict__ X, double *__restrict__ pd,
+                                                              long long pd_stride, double *__restrict__ pt)
 {
-  __shared__ double xs[FXM_RS * FXS_S];
-  __shared__ double scr[PMH_BLOCK / 64][256];
-  __shared__ double xjst[PMH_BLOCK / 64][16 * FXS_S];
-  const int *w8 = wg + 8 * blockIdx.x;
-  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), g = __builtin_amdgcn_readfirstlane(w8[1]), sb = __builtin_amdgcn_readfirstlane(w8[2]);
-  const int  jbeg = __builtin_amdgcn_readfirstlane(w8[3]), jend = __builtin_amdgcn_readfirstlane(w8[4]), seg = __builtin_amdgcn_readfirstlane(w8[5]);
-  const int  lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int  ld = c_ld[c];
-  const long long xbase = c_xoff[c] + (long long)g * ld * FXS_S;
-  const double *__restrict__ x = X + xbase;
-  for (int i = threadIdx.x * 2; i < FXM_RS * FXS_S; i += 2 * PMH_BLOCK) *(dbl2 *)(xs + i) = *(const dbl2 *)(x + (long long)sb * FXM_RS * FXS_S + i);
-  __syncthreads();
-  const int nj = jend - jbeg, j0 = jbeg + (nj * wave) / 4, j1 = jbeg + (nj * (wave + 1)) / 4;
-  const int ntile = (j1 - j0) * FXM_RT;
-  const double *__restrict__ tp = Wbase + wgl[2 * blockIdx.x] + (long long)j0 * (FXM_RT * 256) + lane * 2;
-  double *__restrict__ ptp = pt + wgl[2 * blockIdx.x + 1];
-  const int kq = lane >> 4, r4 = lane & 3, a16 = lane & 15;
-  double dd[FXM_RT][2];
+  __shared__ double xs[FXM_MB][FXM_RS * FXS_S];      // 64 KB: X of the mega band's rows; after the item: the direct sums of the odd waves
+  __shared__ double scr[FXM_THREADS / 64][256];      // a tile's image per wave (transposition)
+  __shared__ double xjst[FXM_THREADS / 64][16 * FXS_S];
+  __shared__ double dtx[2][FXM_THREADS / 64][16 * FXS_S]; // transposed sums of a step, per wave
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sbq = wave >> 1, par = wave & 1;
+  const int kq = lane >> 4, r4 = lane & 3, a16 = lane & 15, cl = 4 * ((lane >> 2) & 3) + kq; // D lane l = (row / column cl of the tile, right-hand side 4 h + r4)
+  const int xo = kq * FXS_S + r4; // operand of the products with X: lane l supplies X[row0 + 4 q + (l >> 4)][4 h + (l & 3)]
+  double   *sc = scr[wave], *xjs = xjst[wave];
+  int       wofs[4], rofs[4]; // LDS image of a tile: element (r, c) at r * 16 + ((c + r) & 15)
 #pragma unroll
-  for (int I = 0; I < FXM_RT; I++) dd[I][0] = dd[I][1] = 0.0;
-  if (ntile > 0) {
-    dbl2 ring[FXM_NB][2];
-#pragma unroll
-    for (int k = 0; k < FXM_NB; k++) {
-      const double *q = tp + (long long)min(k, ntile - 1) * 256;
-      ring[k][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[k][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
+  for (int q = 0; q < 4; q++) wofs[q] = (4 * q + kq) * 16 + ((a16 + 4 * q + kq) & 15), rofs[q] = a16 * 16 + ((4 * q + kq + a16) & 15);
+  const int it1 = __builtin_amdgcn_readfirstlane(wg_first[blockIdx.x + 1]);
+  for (int it = __builtin_amdgcn_readfirstlane(wg_first[blockIdx.x]); it < it1; it++) {
+    const int *w8 = items + 8 * it;
+    const int  c = __builtin_amdgcn_readfirstlane(w8[0]), g = __builtin_amdgcn_readfirstlane(w8[1]), m = __builtin_amdgcn_readfirstlane(w8[2]);
+    const int  jbeg = __builtin_amdgcn_readfirstlane(w8[3]), jend = __builtin_amdgcn_readfirstlane(w8[4]), seg = __builtin_amdgcn_readfirstlane(w8[5]);
+    const int  ld = c_ld[c], nsb = ld / FXM_RS, sb = FXM_MB * m + sbq;
+    const long long xbase = c_xoff[c] + (long long)g * ld * FXS_S;
+    const double *__restrict__ x = X + xbase;
+    {
+      const int     n  = min(FXM_MB * FXM_RS, ld - m * FXM_MB * FXM_RS) * FXS_S;
+      const double *xm = x + (long long)m * FXM_MB * FXM_RS * FXS_S;
+      double       *xf = &xs[0][0];
+      for (int i = threadIdx.x * 2; i < n; i += 2 * FXM_THREADS) *(dbl2 *)(xf + i) = *(const dbl2 *)(xm + i);
     }
-    // operand of the products with X: lane l supplies X[row0 + 4 q + (l >> 4)][4 h + (l & 3)]
-    const int xo = kq * FXS_S + r4;
-    double   *sc = scr[wave], *xjs = xjst[wave];
-    // X of the 16 columns of a column tile = 1 KB contiguous: every lane fetches 16 bytes of it one column tile ahead (2 registers), the
-    // operands are read back from a wave-private LDS image
-    dbl2 xraw = *(const dbl2 *)(x + (long long)j0 * 16 * FXS_S + lane * 2);
-    // LDS image of a tile: element (r, c) at r * 16 + ((c + r) & 15)
-    int wofs[4], rofs[4];
+    __syncthreads();
+    // this wave's column tiles: J = jbeg + par, + 2, ... below jhi (a super band ends at its diagonal block)
+    const int jhi = sb < nsb ? min(jend, (sb + 1) * FXM_RT) : jbeg, nst = (jend - jbeg + 1) >> 1, myst = jhi > jbeg + par ? (jhi - jbeg - par + 1) >> 1 : 0;
+    const int ntile = myst * FXM_RT;
+    const double *__restrict__ tp = Wbase + iteml[2 * it] + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2) + (long long)(jbeg + par) * (FXM_RT * 256) + lane * 2;
+    double *__restrict__ ptp = pt + iteml[2 * it + 1];
+    double dd[FXM_RT][2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) wofs[q] = (4 * q + kq) * 16 + ((a16 + 4 * q + kq) & 15), rofs[q] = a16 * 16 + ((4 * q + kq + a16) & 15);
-    int t = 0;
-    for (int J = j0; J < j1; J++) {
-      *(dbl2 *)(xjs + lane * 2) = xraw;
-      double xj[4][2];
+    for (int I = 0; I < FXM_RT; I++) dd[I][0] = dd[I][1] = 0.0;
+    dbl2 ring[FXM_NB][2], xraw = {0.0, 0.0};
+    if (ntile > 0) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) xj[q][0] = xjs[4 * q * FXS_S + xo], xj[q][1] = xjs[4 * q * FXS_S + xo + 4];
-      xraw = *(const dbl2 *)(x + (long long)min(J + 1, j1 - 1) * 16 * FXS_S + lane * 2);
-      double dt0 = 0.0, dt1 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
-#pragma unroll
-      for (int I = 0; I < FXM_RT; I++, t++) {
-        const double t0 = ring[I % FXM_NB][0].x, t1 = ring[I % FXM_NB][0].y, t2 = ring[I % FXM_NB][1].x, t3 = ring[I % FXM_NB][1].y;
-        if (DBG != 2) sc[wofs[0]] = t0, sc[wofs[1]] = t1, sc[wofs[2]] = t2, sc[wofs[3]] = t3;
-        const double *xi = xs + (I * 16) * FXS_S + xo;
-        const double  xi00 = xi[0], xi01 = xi[4], xi10 = xi[4 * FXS_S], xi11 = xi[4 * FXS_S + 4], xi20 = xi[8 * FXS_S], xi21 = xi[8 * FXS_S + 4], xi30 = xi[12 * FXS_S], xi31 = xi[12 * FXS_S + 4];
-        if (I > 0) { // the direct product of the previous tile: its transposed image has arrived meanwhile
-          dd[I ? I - 1 : 0][0] = fxm_mfma(u0, xj[0][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u0, xj[0][1], dd[I ? I - 1 : 0][1]);
-          dd[I ? I - 1 : 0][0] = fxm_mfma(u1, xj[1][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u1, xj[1][1], dd[I ? I - 1 : 0][1]);
-          dd[I ? I - 1 : 0][0] = fxm_mfma(u2, xj[2][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u2, xj[2][1], dd[I ? I - 1 : 0][1]);
-          dd[I ? I - 1 : 0][0] = fxm_mfma(u3, xj[3][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u3, xj[3][1], dd[I ? I - 1 : 0][1]);
-        }
-        dt0 = fxm_mfma(t0, xi00, dt0), dt1 = fxm_mfma(t0, xi01, dt1);
-        dt0 = fxm_mfma(t1, xi10, dt0), dt1 = fxm_mfma(t1, xi11, dt1);
-        dt0 = fxm_mfma(t2, xi20, dt0), dt1 = fxm_mfma(t2, xi21, dt1);
-        dt0 = fxm_mfma(t3, xi30, dt0), dt1 = fxm_mfma(t3, xi31, dt1);
-        {
-          const double *q = tp + (long long)min(t + FXM_NB, ntile - 1) * 256;
-          ring[I % FXM_NB][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[I % FXM_NB][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
-        }
-        if (DBG != 2) u0 = sc[rofs[0]], u1 = sc[rofs[1]], u2 = sc[rofs[2]], u3 = sc[rofs[3]];
-        else u0 = t0, u1 = t1, u2 = t2, u3 = t3;
-        __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < FXM_NB; k++) { // tile t of the wave: step t >> 4 (column tile jbeg + par + 2 (t >> 4)), row tile t & 15
+        const int     tt = min(k, ntile - 1);
+        const double *q  = tp + (long long)(tt >> 4) * (2 * FXM_RT * 256) + (tt & 15) * 256;
+        ring[k][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[k][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
       }
-      dd[FXM_RT - 1][0] = fxm_mfma(u0, xj[0][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u0, xj[0][1], dd[FXM_RT - 1][1]);
-      dd[FXM_RT - 1][0] = fxm_mfma(u1, xj[1][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u1, xj[1][1], dd[FXM_RT - 1][1]);
-      dd[FXM_RT - 1][0] = fxm_mfma(u2, xj[2][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u2, xj[2][1], dd[FXM_RT - 1][1]);
-      dd[FXM_RT - 1][0] = fxm_mfma(u3, xj[3][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u3, xj[3][1], dd[FXM_RT - 1][1]);
-      // D lane l = (column 4 ((l >> 2) & 3) + (l >> 4) of the tile, right-hand side 4 h + (l & 3))
-      double *o = ptp + (long long)(J * 16 + 4 * ((lane >> 2) & 3) + kq) * FXS_S + r4;
-      if (DBG == 4) *(dbl2 *)(ptp + (long long)(J * 16) * FXS_S + lane * 2) = dbl2{dt0, dt1};
-      else if (DBG == 5) *(dbl2 *)(ptp + (long long)(j0 * 16) * FXS_S + lane * 2) = dbl2{dt0, dt1};
-      else if (DBG == 6) __builtin_nontemporal_store(dbl2{dt0, dt1}, (dbl2 *)(ptp + (long long)(J * 16) * FXS_S + lane * 2));
-      else if (DBG != 1) o[0] = dt0, o[4] = dt1;
-      else if (dt0 == 1.2345e-67) o[0] = dt1;
+      xraw = *(const dbl2 *)(x + (long long)(jbeg + par) * 16 * FXS_S + lane * 2);
+    }
+    const double *xsb = xs[sbq];
+    int           t   = 0;
+    for (int s = 0; s < nst; s++) {
+      double dt0 = 0.0, dt1 = 0.0;
+      if (s < myst) {
+        // X of the 16 columns of the column tile = 1 KB contiguous: every lane fetched 16 bytes of it one step ahead, the operands are read
+        // back from a wave-private LDS image
+        *(dbl2 *)(xjs + lane * 2) = xraw;
+        double xj[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) xj[q][0] = xjs[4 * q * FXS_S + xo], xj[q][1] = xjs[4 * q * FXS_S + xo + 4];
+        xraw = *(const dbl2 *)(x + (long long)(jbeg + par + 2 * min(s + 1, myst - 1)) * 16 * FXS_S + lane * 2);
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+#pragma unroll
+        for (int I = 0; I < FXM_RT; I++, t++) {
+          const double t0 = ring[I % FXM_NB][0].x, t1 = ring[I % FXM_NB][0].y, t2 = ring[I % FXM_NB][1].x, t3 = ring[I % FXM_NB][1].y;
+          sc[wofs[0]] = t0, sc[wofs[1]] = t1, sc[wofs[2]] = t2, sc[wofs[3]] = t3;
+          const double *xi = xsb + (I * 16) * FXS_S + xo;
+          const double  xi00 = xi[0], xi01 = xi[4], xi10 = xi[4 * FXS_S], xi11 = xi[4 * FXS_S + 4], xi20 = xi[8 * FXS_S], xi21 = xi[8 * FXS_S + 4], xi30 = xi[12 * FXS_S], xi31 = xi[12 * FXS_S + 4];
+          if (I > 0) { // the direct product of the previous tile: its transposed image has arrived meanwhile
+            dd[I ? I - 1 : 0][0] = fxm_mfma(u0, xj[0][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u0, xj[0][1], dd[I ? I - 1 : 0][1]);
+            dd[I ? I - 1 : 0][0] = fxm_mfma(u1, xj[1][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u1, xj[1][1], dd[I ? I - 1 : 0][1]);
+            dd[I ? I - 1 : 0][0] = fxm_mfma(u2, xj[2][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u2, xj[2][1], dd[I ? I - 1 : 0][1]);
+            dd[I ? I - 1 : 0][0] = fxm_mfma(u3, xj[3][0], dd[I ? I - 1 : 0][0]), dd[I ? I - 1 : 0][1] = fxm_mfma(u3, xj[3][1], dd[I ? I - 1 : 0][1]);
+          }
+          dt0 = fxm_mfma(t0, xi00, dt0), dt1 = fxm_mfma(t0, xi01, dt1);
+          dt0 = fxm_mfma(t1, xi10, dt0), dt1 = fxm_mfma(t1, xi11, dt1);
+          dt0 = fxm_mfma(t2, xi20, dt0), dt1 = fxm_mfma(t2, xi21, dt1);
+          dt0 = fxm_mfma(t3, xi30, dt0), dt1 = fxm_mfma(t3, xi31, dt1);
+          {
+            const int     tt = min(t + FXM_NB, ntile - 1);
+            const double *q  = tp + (long long)(tt >> 4) * (2 * FXM_RT * 256) + (tt & 15) * 256;
+            ring[I % FXM_NB][0] = __builtin_nontemporal_load((const dbl2 *)q), ring[I % FXM_NB][1] = __builtin_nontemporal_load((const dbl2 *)(q + 128));
+          }
+          u0 = sc[rofs[0]], u1 = sc[rofs[1]], u2 = sc[rofs[2]], u3 = sc[rofs[3]];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        dd[FXM_RT - 1][0] = fxm_mfma(u0, xj[0][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u0, xj[0][1], dd[FXM_RT - 1][1]);
+        dd[FXM_RT - 1][0] = fxm_mfma(u1, xj[1][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u1, xj[1][1], dd[FXM_RT - 1][1]);
+        dd[FXM_RT - 1][0] = fxm_mfma(u2, xj[2][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u2, xj[2][1], dd[FXM_RT - 1][1]);
+        dd[FXM_RT - 1][0] = fxm_mfma(u3, xj[3][0], dd[FXM_RT - 1][0]), dd[FXM_RT - 1][1] = fxm_mfma(u3, xj[3][1], dd[FXM_RT - 1][1]);
+      }
+      // the step's transposed sums: [column of the tile][right-hand side], added over the four super bands by waves 0 (even column tile) and 1
+      double *dx = dtx[s & 1][wave] + cl * FXS_S + r4;
+      dx[0] = dt0, dx[4] = dt1;
+      __syncthreads(); // the buffer of this parity is rewritten two steps on, i.e. after the next barrier, which the adding waves reach after their reads
+      if (wave < 2 && jbeg + 2 * s + wave < jend) {
+        dbl2 v = *(const dbl2 *)(dtx[s & 1][wave] + lane * 2);
+#pragma unroll
+        for (int k = 1; k < FXM_MB; k++) v += *(const dbl2 *)(dtx[s & 1][2 * k + wave] + lane * 2);
+        *(dbl2 *)(ptp + (long long)(jbeg + 2 * s + wave) * 16 * FXS_S + lane * 2) = v;
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  // direct sums: the four waves' accumulators are added in wave order through LDS (the X stage is free now), the last wave writes the segment's sums
-  __syncthreads();
-  const int rowl = 4 * ((lane >> 2) & 3) + kq;
-  for (int w = 0; w < PMH_BLOCK / 64; w++) {
-    if (wave == w) {
+    // direct sums: the odd wave's accumulators through LDS (the X stage is free now), the even wave adds its own and writes the item's sums
+    __syncthreads();
+    if (par) {
 #pragma unroll
-      for (int I = 0; I < FXM_RT; I++)
+      for (int I = 0; I < FXM_RT; I++) xs[sbq][(I * 2) * 64 + lane] = dd[I][0], xs[sbq][(I * 2 + 1) * 64 + lane] = dd[I][1];
+    }
+    __syncthreads();
+    if (!par && sb < nsb) {
+      double *o = pd + (long long)seg * pd_stride + xbase + (long long)(sb * FXM_RS + cl) * FXS_S + r4;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int    idx = (I * 2 + h) * 64 + lane;
-          const double v   = w ? xs[idx] + dd[I][h] : dd[I][h];
-          if (w < PMH_BLOCK / 64 - 1) xs[idx] = v;
-          else pd[(long long)seg * pd_stride + xbase + (long long)(sb * FXM_RS + I * 16 + rowl) * FXS_S + 4 * h + r4] = v;
-        }
+      for (int I = 0; I < FXM_RT; I++) o[(I * 16) * FXS_S] = dd[I][0] + xs[sbq][(I * 2) * 64 + lane], o[(I * 16) * FXS_S + 4] = dd[I][1] + xs[sbq][(I * 2 + 1) * 64 + lane];
     }
     __syncthreads();
   }
 }
 
-// Y[position][slot] = the direct sums of the segments of the position's super band + the transposed partial sums of every owned super band from
-// that one on, in a fixed order.  grid (ld * 8 / 2 / 256, groups of the class)
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nsb, const int *__restrict__ nseg_of, long long xbase0, long long pd_stride, const double *__restrict__ pd,
-                                                          long long ptoff, long long ptsize, const double *__restrict__ pt, double *__restrict__ Y)
+// Y[position][slot] = the direct sums of the items of the position's mega band + the transposed partial sums of every owned mega band from that
+// one on, in a fixed order.  grid (ld * 8 / 2 / 256, groups of the class); nseg_of[g * nmb + m] (0: not owned), ptoff_of[g * nmb + m]
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nmb, const int *__restrict__ nseg_of, const long long *__restrict__ ptoff_of, long long xbase0, long long pd_stride,
+                                                          const double *__restrict__ pd, const double *__restrict__ pt, double *__restrict__ Y)
 {
   const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x);
   if (i >= (long long)ld * FXS_S) return;
-  const int       g = blockIdx.y, sb0 = (int)(i / (FXM_RS * FXS_S));
+  const int       g = blockIdx.y, m0 = (int)(i / (FXM_MB * FXM_RS * FXS_S));
   const long long xb = xbase0 + (long long)g * ld * FXS_S;
   dbl2            s = {0.0, 0.0};
-  const int       ns = nseg_of[sb0];
+  const int       ns = nseg_of[g * nmb + m0];
   for (int j = 0; j < ns; j++) s += *(const dbl2 *)(pd + (long long)j * pd_stride + xb + i);
-  const double *__restrict__ p = pt + ptoff + (long long)g * ptsize + i;
-  for (int sb = sb0; sb < nsb; sb++)
-    if (nseg_of[sb]) s += *(const dbl2 *)(p + (long long)FXM_RS * FXS_S * ((long long)sb * (sb + 1) / 2));
+  for (int m = m0; m < nmb; m++)
+    if (nseg_of[g * nmb + m]) s += *(const dbl2 *)(pt + ptoff_of[g * nmb + m] + i);
   *(dbl2 *)(Y + xb + i) = s;
 }
 
@@ -324,59 +343,91 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_extract_sym(int p, const int 
 static int fxs_build_launch(fx_shared *S)
 {
   if (S->sym) {
-    // work items = (super band, segment of column tiles), 32 KB per wave and column tile; the segment length gives >= ~8 rounds of
-    // 512 resident workgroups (2 per CU) but stays >= 16 column tiles (direct sums written per segment: 16 KB per 0.5 MB of tiles)
-    long long steps = 0;
-    for (auto &C : S->C)
-      for (int sb = 0; sb < C.nsb; sb++)
-        if (C.own[sb]) steps += (long long)C.ngroups * (sb + 1) * FXM_RT;
-    int segj = (int)std::max(16LL, std::min(128LL, steps / (8 * 512)));
-    segj     = (segj + 3) / 4 * 4;
-    if (const char *e = getenv("PMH_FXM_SEGJ")) segj = std::max(4, atoi(e) / 4 * 4);
-    S->segj = segj;
-    std::vector<int>       wg;
-    std::vector<long long> wgl;
-    int                    nsegmax = 1;
+    // work = (class, group, owned mega band m) one after the other, the longest first, each a run of steps (pairs of column tiles, 128 KB
+    // when all four super bands reach that far); the run is cut into one equal share per CU
+    struct band { int c, g, m, nj; };
+    std::vector<band> bands;
+    long long         steps = 0;
+    for (int c = 0; c < S->ncls; c++) {
+      fxs_class &C = S->C[c];
+      for (int m = C.nmb - 1; m >= 0; m--) {
+        if (!C.own[FXM_MB * m]) continue;
+        for (int g = 0; g < C.ngroups; g++) {
+          const int nj = std::min(C.nsb, FXM_MB * (m + 1)) * FXM_RT;
+          bands.push_back({c, g, m, nj});
+          steps += (nj + 1) / 2;
+        }
+      }
+    }
+    int nwg = (int)std::max(1LL, std::min((long long)S->ctx->num_cus, steps));
+    if (const char *e = getenv("PMH_FXM_NWG")) nwg = std::max(1, atoi(e));
+    std::vector<int>       first(1, 0), items;
+    std::vector<long long> iteml;
+    std::vector<std::vector<int>> nseg_of(S->ncls);
+    for (int c = 0; c < S->ncls; c++) nseg_of[c].assign((size_t)std::max(1, S->C[c].ngroups * S->C[c].nmb), 0);
+    {
+      long long done = 0; // steps handed out so far
+      size_t    bi = 0;
+      long long boff = 0; // steps of band bi already handed out
+      for (int k = 0; k < nwg; k++) {
+        const long long upto = steps * (k + 1) / nwg;
+        while (done < upto && bi < bands.size()) {
+          const band     &b   = bands[bi];
+          const long long bst = (b.nj + 1) / 2, take = std::min(bst - boff, upto - done);
+          fxs_class      &C   = S->C[b.c];
+          int            &ns  = nseg_of[b.c][(size_t)b.g * C.nmb + b.m];
+          items.insert(items.end(), {b.c, b.g, b.m, (int)(2 * boff), (int)std::min<long long>(b.nj, 2 * (boff + take)), ns, 0, 0});
+          iteml.push_back(C.woff);
+          iteml.push_back(C.ptoff + (long long)b.g * C.ptsize + C.ptm[b.m]);
+          ns++, done += take, boff += take;
+          if (boff == bst) bi++, boff = 0;
+        }
+        first.push_back((int)(items.size() / 8));
+      }
+    }
+    int nsegmax = 1;
     S->bytes = 0.0, S->owned_bytes = 0.0;
     for (int c = 0; c < S->ncls; c++) {
-      fxs_class       &C = S->C[c];
-      std::vector<int> nseg_of((size_t)std::max(1, C.nsb), 0);
-      double           tiles = 0.0, parts = 0.0;
-      for (int sb = C.nsb - 1; sb >= 0; sb--) { // the long super bands first
-        if (!C.own[sb]) continue;
-        const int nj = (sb + 1) * FXM_RT, ns = (nj + segj - 1) / segj;
-        nseg_of[sb]  = ns, nsegmax = std::max(nsegmax, ns);
-        tiles += (double)nj * FXM_RT * 2048.0;
-        parts += (double)ns * FXM_RS * FXS_S * 8.0 + (double)nj * 16 * FXS_S * 8.0; // direct sums per segment + transposed sums per column
-        for (int g = 0; g < C.ngroups; g++)
-          for (int j = 0; j < ns; j++) {
-            wg.insert(wg.end(), {c, g, sb, j * segj, std::min(nj, (j + 1) * segj), j, 0, 0});
-            wgl.push_back(C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
-            wgl.push_back(C.ptoff + (long long)g * C.ptsize + (long long)FXM_RS * FXS_S * ((long long)sb * (sb + 1) / 2));
-          }
+      fxs_class &C     = S->C[c];
+      double     tiles = 0.0, parts = 0.0;
+      std::vector<long long> ptoff_of((size_t)std::max(1, C.ngroups * C.nmb), 0);
+      for (int m = 0; m < C.nmb; m++) {
+        for (int g = 0; g < C.ngroups; g++) ptoff_of[(size_t)g * C.nmb + m] = C.ptoff + (long long)g * C.ptsize + C.ptm[m];
+        if (!C.own[FXM_MB * m]) continue;
+        const int sb1 = std::min(C.nsb, FXM_MB * (m + 1));
+        for (int sb = FXM_MB * m; sb < sb1; sb++) tiles += (double)(sb + 1) * FXM_RT * FXM_RT * 2048.0;
+        int ns = 0;
+        for (int g = 0; g < C.ngroups; g++) ns = std::max(ns, nseg_of[c][(size_t)g * C.nmb + m]);
+        nsegmax = std::max(nsegmax, ns);
+        parts += (double)ns * (sb1 - FXM_MB * m) * FXM_RS * FXS_S * 8.0 + (double)sb1 * FXM_RS * FXS_S * 8.0; // direct sums per item + transposed sums per column
       }
       S->owned_bytes += tiles;
       // the owned tiles once per group + X read (rows + columns) + the partial sums written and read back + Y written
       S->bytes += (double)C.ngroups * (tiles + 2.0 * parts + 2.0 * 8.0 * FXS_S * C.ld);
-      if (!C.d_nseg) PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * nseg_of.size(), (void **)&C.d_nseg));
-      PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_nseg, nseg_of.data(), sizeof(int) * nseg_of.size()));
+      if (!C.d_nseg) PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * nseg_of[c].size(), (void **)&C.d_nseg));
+      PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_nseg, nseg_of[c].data(), sizeof(int) * nseg_of[c].size()));
+      if (!C.d_ptoff) PMH_CHK(pmh_malloc(S->ctx, sizeof(long long) * ptoff_of.size(), (void **)&C.d_ptoff));
+      PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_ptoff, ptoff_of.data(), sizeof(long long) * ptoff_of.size()));
     }
-    S->nwg = (int)(wg.size() / 8), S->nseg = nsegmax;
-    wg.insert(wg.end(), {0, 0, 0, 0, 0, 0, 0, 0});
-    wgl.insert(wgl.end(), {0, 0});
+    S->nwg = items.empty() ? 0 : nwg, S->nseg = nsegmax;
+    items.insert(items.end(), {0, 0, 0, 0, 0, 0, 0, 0});
+    iteml.insert(iteml.end(), {0, 0});
     if (S->d_wg) pmh_free(S->ctx, S->d_wg);
+    if (S->d_items) pmh_free(S->ctx, S->d_items);
     if (S->d_wgl) pmh_free(S->ctx, S->d_wgl);
-    PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * wg.size(), (void **)&S->d_wg));
-    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wg, wg.data(), sizeof(int) * wg.size()));
-    PMH_CHK(pmh_malloc(S->ctx, sizeof(long long) * wgl.size(), (void **)&S->d_wgl));
-    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wgl, wgl.data(), sizeof(long long) * wgl.size()));
+    PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * first.size(), (void **)&S->d_wg));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wg, first.data(), sizeof(int) * first.size()));
+    PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * items.size(), (void **)&S->d_items));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_items, items.data(), sizeof(int) * items.size()));
+    PMH_CHK(pmh_malloc(S->ctx, sizeof(long long) * iteml.size(), (void **)&S->d_wgl));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, S->d_wgl, iteml.data(), sizeof(long long) * iteml.size()));
     const long long need = (long long)nsegmax * std::max(16LL, S->nX);
     if (need > S->part_cap) {
       if (S->part) pmh_free(S->ctx, S->part);
       PMH_CHK(pmh_malloc(S->ctx, sizeof(double) * (size_t)need, (void **)&S->part));
       S->part_cap = need;
     }
-    return PMH_SUCCESS; // k_fxs_symfin reads only what the segments of a super band wrote
+    return PMH_SUCCESS; // k_fxs_symfin reads only what the items of a mega band wrote
   }
   // segments of the rank's rows: enough of them to give the chip >= ~4000 waves (n_c / 128 column chunks each), at most 32
   int maxrows = 0, chunks = 0;
@@ -454,9 +505,11 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     C.r0 = 0, C.r1 = C.ld;
     C.woff = wtot, C.xoff = xtot;
     if (sym) {
-      C.nsb = C.ld / FXM_RS;
+      C.nsb = C.ld / FXM_RS, C.nmb = (C.nsb + FXM_MB - 1) / FXM_MB;
       C.own.assign((size_t)std::max(1, C.nsb), 1);
-      C.ptoff = pttot, C.ptsize = (long long)FXM_RS * FXS_S * ((long long)C.nsb * (C.nsb + 1) / 2);
+      C.ptm.assign((size_t)C.nmb + 1, 0);
+      for (int m = 0; m < C.nmb; m++) C.ptm[m + 1] = C.ptm[m] + (long long)std::min(C.nsb, FXM_MB * (m + 1)) * FXM_RS * FXS_S;
+      C.ptoff = pttot, C.ptsize = C.ptm[C.nmb];
       pttot += C.ngroups * C.ptsize;
       wtot += (long long)FXM_RS * FXM_RS * ((long long)C.nsb * (C.nsb + 1) / 2); // super band sb: (sb + 1) * 16 column tiles x 16 row tiles x 256 doubles
     } else
@@ -510,9 +563,11 @@ void fxs_destroy(fx_shared *S)
   for (auto &C : S->C) {
     if (C.d_urel) pmh_free(ctx, C.d_urel);
     if (C.d_nseg) pmh_free(ctx, C.d_nseg);
+    if (C.d_ptoff) pmh_free(ctx, C.d_ptoff);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
+  if (S->d_items) pmh_free(ctx, S->d_items);
   pmh_gluing_destroy(S->Bc);
   if (S->Wbase) (void)hipFree(S->Wbase);
   if (S->part) pmh_free(ctx, S->part);
@@ -525,12 +580,13 @@ void fxs_destroy(fx_shared *S)
 int fxs_set_stripe(fx_shared *S, int rank, int size)
 {
   if (S->sym) {
-    // whole super bands (a rank assembles exactly the rows it applies); super band sb costs sb + 1 column blocks: dealt from the longest
-    // down in snake order, so every rank gets the same number of long and short ones
+    // whole mega bands of 1024 rows (a rank assembles exactly the rows it applies); mega band m costs ~ m + 1: dealt from the longest down in
+    // snake order, so every rank gets the same number of long and short ones
     for (auto &C : S->C) {
-      for (int i = 0; i < C.nsb; i++) {
-        const int sb = C.nsb - 1 - i, round = i / size, k = i % size;
-        C.own[sb]    = ((round & 1) ? size - 1 - k : k) == rank;
+      for (int i = 0; i < C.nmb; i++) {
+        const int  m = C.nmb - 1 - i, round = i / size, k = i % size;
+        const char o = ((round & 1) ? size - 1 - k : k) == rank;
+        for (int sb = FXM_MB * m; sb < std::min(C.nsb, FXM_MB * (m + 1)); sb++) C.own[sb] = o;
       }
     }
     return fxs_build_launch(S);
@@ -634,20 +690,11 @@ static int fxs_gemm(fx_shared *S)
   if (timed) PMH_HIP(hipEventRecord(S->ev[2 * S->ev_used], st));
   const long long stride = std::max(16LL, S->nX);
   if (S->sym) {
-    static const int dbg = getenv("PMH_FXM_DBG") ? atoi(getenv("PMH_FXM_DBG")) : 0;
-#define FXM_LAUNCH(D) \
-  hipLaunchKernelGGL(k_fxs_symm8<D>, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff, (const double *)S->Wbase, \
-                     (const double *)S->X, S->part, stride, S->pt)
-    if (dbg == 1) FXM_LAUNCH(1);
-    else if (dbg == 2) FXM_LAUNCH(2);
-    else if (dbg == 3) FXM_LAUNCH(3);
-    else if (dbg == 4) FXM_LAUNCH(4);
-    else if (dbg == 5) FXM_LAUNCH(5);
-    else if (dbg == 6) FXM_LAUNCH(6);
-    else FXM_LAUNCH(0);
+    hipLaunchKernelGGL(k_fxs_symm8, dim3(S->nwg), dim3(FXM_THREADS), 0, st, (const int *)S->d_wg, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff,
+                       (const double *)S->Wbase, (const double *)S->X, S->part, stride, S->pt);
     for (auto &C : S->C)
-      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nsb, (const int *)C.d_nseg, C.xoff, stride,
-                         (const double *)S->part, C.ptoff, C.ptsize, (const double *)S->pt, S->Y);
+      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nmb, (const int *)C.d_nseg, (const long long *)C.d_ptoff,
+                         C.xoff, stride, (const double *)S->part, (const double *)S->pt, S->Y);
   } else {
   hipLaunchKernelGGL(k_fxs_gemm8, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const int *)S->d_ld, (const long long *)S->d_woff, (const long long *)S->d_xoff, (const double *)S->Wbase,
                      (const double *)S->X, S->part, stride);

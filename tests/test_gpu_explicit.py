@@ -64,10 +64,13 @@ def test_explicit_blocks_vs_pinv(ctx, share, storage):
     assert np.array_equal(y.to_numpy(), y2.to_numpy())
 
 
-@pytest.mark.parametrize("storage", ["sym", "full", "class", "class_sym"])
-def test_explicit_vs_iterative_F(ctx, storage):
+@pytest.mark.parametrize("storage", ["sym", "full", "class", "class_sym", "class_sym/3"])
+def test_explicit_vs_iterative_F(ctx, storage, monkeypatch):
     """2x2x2 cubes, nel = 6: F_dense lambda vs the iterative B K^+ B' lambda (rtol 1e-13) <= 1e-10; the dense kernel (SYMV on the
     lower block-triangle / GEMV on the full matrix) vs numpy, and bitwise reproducible."""
+    if "/" in storage:  # the persistent grid of k_fxs_symm8 cut down to 3 workgroups: several items (mega band, column range) per workgroup
+        storage, nwg = storage.split("/")
+        monkeypatch.setenv("PMH_FXM_NWG", nwg)
     f = pa.CubeFeti((2, 2, 2), 6, contact=True)
     G, e = f.coarse()
     loc = f.subset(range(f.nsub))
@@ -154,7 +157,8 @@ def test_striped_shares_sum_to_F(ctx, storage):
     """Several GPUs rehearsed on one: the operator spans all blocks, rank r of 3 keeps the 128-row stripes idx = r (mod 3); the sum of
     the three ranks' applies (the all-reduce) equals F lambda of the unstriped operator, each share is bitwise reproducible, and the
     shares split the set-up solves."""
-    f = pa.CubeFeti((2, 2, 1), 8, contact=True)  # n_Gamma > 128: several stripes per block
+    # n_Gamma > 128: several stripes per block; "class_sym" deals whole mega bands of 1024 rows of W_c: n_c = 3 534 gives 4 of them
+    f = pa.CubeFeti((2, 2, 1), 14 if storage == "class_sym" else 8, contact=True)
     G, e = f.coarse()
     loc = f.subset(range(f.nsub))
     q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13))
