@@ -39,6 +39,7 @@ struct fxs_class {
   std::vector<long long> ptm;
   int             *d_nseg = nullptr;      // items (= segments of the direct sums) per (group, mega band) (0: not owned)
   long long       *d_ptoff = nullptr;
+  int             *d_ownfirst = nullptr, nown = 0;
 };
 
 struct fx_shared {
@@ -312,9 +313,10 @@ __global__ __launch_bounds__(FXM_THREADS, 1) void k_fxs_symm8(const int *__restr
 }
 
 // Y[position][slot] = the direct sums of the items of the position's mega band + the transposed partial sums of every owned mega band from that
-// one on, in a fixed order.  grid (ld * 8 / 2 / 256, groups of the class); nseg_of[g * nmb + m] (0: not owned), ptoff_of[g * nmb + m]
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nmb, const int *__restrict__ nseg_of, const long long *__restrict__ ptoff_of, long long xbase0, long long pd_stride,
-                                                          const double *__restrict__ pd, const double *__restrict__ pt, double *__restrict__ Y)
+// one on, in a fixed order.  grid (ld * 8 / 2 / 256, groups of the class); nseg_of[g * nmb + m] (0: not owned); the owned mega bands as a
+// compact ascending list: own_first[m] = index of the first owned one >= m, own_ptoff[g * nown + k] = offset of its transposed sums
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nmb, int nown, const int *__restrict__ nseg_of, const int *__restrict__ own_first, const long long *__restrict__ own_ptoff,
+                                                          long long xbase0, long long pd_stride, const double *__restrict__ pd, const double *__restrict__ pt, double *__restrict__ Y)
 {
   const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x);
   if (i >= (long long)ld * FXS_S) return;
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nmb, const
   dbl2            s = {0.0, 0.0};
   const int       ns = nseg_of[g * nmb + m0];
   for (int j = 0; j < ns; j++) s += *(const dbl2 *)(pd + (long long)j * pd_stride + xb + i);
-  for (int m = m0; m < nmb; m++)
-    if (nseg_of[g * nmb + m]) s += *(const dbl2 *)(pt + ptoff_of[g * nmb + m] + i);
+  const long long *__restrict__ po = own_ptoff + (long long)g * nown;
+  for (int k = own_first[m0]; k < nown; k++) s += *(const dbl2 *)(pt + po[k] + i);
   *(dbl2 *)(Y + xb + i) = s;
 }
 
@@ -390,9 +392,18 @@ static int fxs_build_launch(fx_shared *S)
     for (int c = 0; c < S->ncls; c++) {
       fxs_class &C     = S->C[c];
       double     tiles = 0.0, parts = 0.0;
-      std::vector<long long> ptoff_of((size_t)std::max(1, C.ngroups * C.nmb), 0);
+      std::vector<int> ownm, own_first((size_t)C.nmb + 1, 0);
       for (int m = 0; m < C.nmb; m++) {
-        for (int g = 0; g < C.ngroups; g++) ptoff_of[(size_t)g * C.nmb + m] = C.ptoff + (long long)g * C.ptsize + C.ptm[m];
+        own_first[m] = (int)ownm.size();
+        if (C.own[FXM_MB * m]) ownm.push_back(m);
+      }
+      C.nown = (int)ownm.size();
+      std::vector<long long> ptoff_of((size_t)std::max(1, C.ngroups * C.nown), 0);
+      for (int g = 0; g < C.ngroups; g++)
+        for (int k = 0; k < C.nown; k++) ptoff_of[(size_t)g * C.nown + k] = C.ptoff + (long long)g * C.ptsize + C.ptm[ownm[k]];
+      if (!C.d_ownfirst) PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * own_first.size(), (void **)&C.d_ownfirst));
+      PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_ownfirst, own_first.data(), sizeof(int) * own_first.size()));
+      for (int m = 0; m < C.nmb; m++) {
         if (!C.own[FXM_MB * m]) continue;
         const int sb1 = std::min(C.nsb, FXM_MB * (m + 1));
         for (int sb = FXM_MB * m; sb < sb1; sb++) tiles += (double)(sb + 1) * FXM_RT * FXM_RT * 2048.0;
@@ -406,6 +417,7 @@ static int fxs_build_launch(fx_shared *S)
       S->bytes += (double)C.ngroups * (tiles + 2.0 * parts + 2.0 * 8.0 * FXS_S * C.ld);
       if (!C.d_nseg) PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * nseg_of[c].size(), (void **)&C.d_nseg));
       PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_nseg, nseg_of[c].data(), sizeof(int) * nseg_of[c].size()));
+      if (C.d_ptoff) pmh_free(S->ctx, C.d_ptoff), C.d_ptoff = nullptr;
       if (!C.d_ptoff) PMH_CHK(pmh_malloc(S->ctx, sizeof(long long) * ptoff_of.size(), (void **)&C.d_ptoff));
       PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_ptoff, ptoff_of.data(), sizeof(long long) * ptoff_of.size()));
     }
@@ -564,6 +576,7 @@ void fxs_destroy(fx_shared *S)
     if (C.d_urel) pmh_free(ctx, C.d_urel);
     if (C.d_nseg) pmh_free(ctx, C.d_nseg);
     if (C.d_ptoff) pmh_free(ctx, C.d_ptoff);
+    if (C.d_ownfirst) pmh_free(ctx, C.d_ownfirst);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
@@ -693,8 +706,8 @@ static int fxs_gemm(fx_shared *S)
     hipLaunchKernelGGL(k_fxs_symm8, dim3(S->nwg), dim3(FXM_THREADS), 0, st, (const int *)S->d_wg, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff,
                        (const double *)S->Wbase, (const double *)S->X, S->part, stride, S->pt);
     for (auto &C : S->C)
-      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nmb, (const int *)C.d_nseg, (const long long *)C.d_ptoff,
-                         C.xoff, stride, (const double *)S->part, (const double *)S->pt, S->Y);
+      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nmb, C.nown, (const int *)C.d_nseg, (const int *)C.d_ownfirst,
+                         (const long long *)C.d_ptoff, C.xoff, stride, (const double *)S->part, (const double *)S->pt, S->Y);
   } else {
   hipLaunchKernelGGL(k_fxs_gemm8, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const int *)S->d_ld, (const long long *)S->d_woff, (const long long *)S->d_xoff, (const double *)S->Wbase,
                      (const double *)S->X, S->part, stride);

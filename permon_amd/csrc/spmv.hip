@@ -282,6 +282,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_vector(int nrows, int nblk, 
 // workgroup per chunk (fixed-tree block reduction), and a second small kernel adds the chunk sums of a row in chunk order
 // and applies the epilogue -- deterministic, ~2 x 5 us.
 #define PMH_LONG_CHUNK 4096
+template <bool NT>
 __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_part(const int *__restrict__ chunks, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x, const int *__restrict__ halt, double *__restrict__ part)
 {
   __shared__ double red[PMH_BLOCK / 64];
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_part(const int *__restr
   int       k    = k0 + (int)threadIdx.x;
   for (; k + 3 * PMH_BLOCK < k1; k += 4 * PMH_BLOCK) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) s[j] += __builtin_nontemporal_load(&val[k + j * PMH_BLOCK]) * x[__builtin_nontemporal_load(&col[k + j * PMH_BLOCK])];
+    for (int j = 0; j < 4; j++) s[j] += (NT ? __builtin_nontemporal_load(&val[k + j * PMH_BLOCK]) : val[k + j * PMH_BLOCK]) * x[NT ? __builtin_nontemporal_load(&col[k + j * PMH_BLOCK]) : col[k + j * PMH_BLOCK]];
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) { // at most three strides are left
@@ -393,9 +394,10 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   PMH_HIP(hipMalloc((void **)&A->d_blockpart, sizeof(double) * 3 * (size_t)(A->n_launch_blocks ? A->n_launch_blocks : 8)));
   if (avg > 1024.0 && !getenv("PMH_SPMV_NO_LONG")) { // chunk table of the long-row kernels (plain / ADD / SUB epilogues)
     std::vector<int> ch, lrow((size_t)nrows + 1, 0);
+    const int        long_chunk = getenv("PMH_LONG_CHUNK") ? std::max(256, atoi(getenv("PMH_LONG_CHUNK"))) : PMH_LONG_CHUNK;
     for (int r = 0; r < nrows; r++) {
-      for (int k = rowptr[r]; k < rowptr[r + 1]; k += PMH_LONG_CHUNK) {
-        ch.push_back(r), ch.push_back(k), ch.push_back(std::min(k + PMH_LONG_CHUNK, rowptr[r + 1]));
+      for (int k = rowptr[r]; k < rowptr[r + 1]; k += long_chunk) {
+        ch.push_back(r), ch.push_back(k), ch.push_back(std::min(k + long_chunk, rowptr[r + 1]));
       }
       lrow[r + 1] = (int)(ch.size() / 3);
     }
@@ -453,7 +455,9 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   const int nl  = A->n_launch_blocks;
   if (A->nrows == 0) return PMH_SUCCESS;
   if (A->l_nchunks && EPI != PMH_EPI_MPGP) {
-    hipLaunchKernelGGL(k_spmv_long_part, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
+    static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+    if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
+    else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_long_fin<EPI>), dim3((A->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, x, y, a);
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;

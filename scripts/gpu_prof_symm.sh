@@ -5,6 +5,3 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_symm 
 f=$(find $R/gpurun_out/prof_symm -name "*kernel_stats.csv" | head -n 1)
 cut -d, -f1-4 $f | cut -c1-150 | sed -n 1,8p
 find $R/gpurun_out/prof_symm -name "*kernel_trace.csv" -delete
-cd $R
-for s in 16 24 48 64 128; do echo "SEGJ $s"; PMH_FXM_SEGJ=$s python3 scripts/symv_tune.py class_sym | cut -c130-330; done
-python3 scripts/symv_tune.py class_sym 43 8 8 | cut -c130-330
