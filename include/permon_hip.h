@@ -327,6 +327,7 @@ int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks]
 int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size);
 int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int size, int *owner_out); /* host: owner rank of every 128-row stripe, block after block */
 int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int size, double *bytes_per_rank); /* host: dense bytes per rank under that rule */
+int pmh_fexplicit_class_sym_plan(int n_c, int size, int *megaband_owner /* [ceil(ceil(n_c / 256) / 4)] or NULL */, double *bytes_per_rank /* [size] or NULL */); /* host: PMH_FX_CLASS_SYM's rule */
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
 int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte); /* tuning helper: byte pattern instead of the assembly (not F afterwards) */
 int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds);

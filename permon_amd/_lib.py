@@ -243,6 +243,7 @@ _PROTOS = {
     "pmh_fexplicit_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_fexplicit_create_shared": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_create_shared_sym": [vp, vp, vp, C.POINTER(vp)],
+    "pmh_fexplicit_class_sym_plan": [C.c_int, C.c_int, vp, vp],
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],

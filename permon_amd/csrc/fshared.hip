@@ -589,6 +589,29 @@ void fxs_destroy(fx_shared *S)
   delete S;
 }
 
+// the dealing rule of the symmetric tile storage: mega band m of nmb (1024 rows; cost ~ m + 1) -> rank: from the longest down in snake order
+static inline int fxm_owner(int m, int nmb, int size)
+{
+  const int i = nmb - 1 - m, round = i / size, k = i % size;
+  return (round & 1) ? size - 1 - k : k;
+}
+
+// host helper (no device): the owner rank of every mega band of a class with n_c touched dofs and the tile bytes per rank under that rule
+extern "C" int pmh_fexplicit_class_sym_plan(int n_c, int size, int *owner_out, double *bytes_per_rank)
+{
+  PMH_ARG(n_c >= 1 && size >= 1);
+  const int nsb = (n_c + FXM_RS - 1) / FXM_RS, nmb = (nsb + FXM_MB - 1) / FXM_MB;
+  if (bytes_per_rank)
+    for (int r = 0; r < size; r++) bytes_per_rank[r] = 0.0;
+  for (int m = 0; m < nmb; m++) {
+    const int o = fxm_owner(m, nmb, size);
+    if (owner_out) owner_out[m] = o;
+    if (bytes_per_rank)
+      for (int sb = FXM_MB * m; sb < std::min(nsb, FXM_MB * (m + 1)); sb++) bytes_per_rank[o] += (double)(sb + 1) * FXM_RT * FXM_RT * 2048.0;
+  }
+  return PMH_SUCCESS;
+}
+
 // several GPUs: rank r applies / assembles the rows [r0, r1) of every W_c, contiguous ranges of equal length (multiples of 32)
 int fxs_set_stripe(fx_shared *S, int rank, int size)
 {
@@ -596,11 +619,8 @@ int fxs_set_stripe(fx_shared *S, int rank, int size)
     // whole mega bands of 1024 rows (a rank assembles exactly the rows it applies); mega band m costs ~ m + 1: dealt from the longest down in
     // snake order, so every rank gets the same number of long and short ones
     for (auto &C : S->C) {
-      for (int i = 0; i < C.nmb; i++) {
-        const int  m = C.nmb - 1 - i, round = i / size, k = i % size;
-        const char o = ((round & 1) ? size - 1 - k : k) == rank;
-        for (int sb = FXM_MB * m; sb < std::min(C.nsb, FXM_MB * (m + 1)); sb++) C.own[sb] = o;
-      }
+      for (int m = 0; m < C.nmb; m++)
+        for (int sb = FXM_MB * m; sb < std::min(C.nsb, FXM_MB * (m + 1)); sb++) C.own[sb] = fxm_owner(m, C.nmb, size) == rank;
     }
     return fxs_build_launch(S);
   }

@@ -86,6 +86,27 @@ def main():
     if rank == 0:
         Fd = sum(Bd[:, s * g.n_i:(s + 1) * g.n_i] @ Kp @ Bd[:, s * g.n_i:(s + 1) * g.n_i].T for s in range(g.nsub))
         assert np.linalg.norm(t2.numpy() - Fd @ lam2) <= 1e-11 * np.linalg.norm(Fd @ lam2)
+    # ---- the class-shared symmetric storage (PMH_FX_CLASS_SYM): ONE W_c for the congruent cubes; a rank owns whole mega bands of 1024 rows of
+    # its lower block-triangle and applies both products of every stored tile (rows of its band: direct; the columns they touch: transposed)
+    nc = 2600  # 3 mega bands
+    nmb = -(-(-(-nc // 256)) // 4)
+    own = np.zeros(nmb, dtype=np.int32)
+    pa._lib.check(L.pmh_fexplicit_class_sym_plan(nc, world, own.ctypes.data_as(C.c_void_p), None))
+    assert set(own.tolist()) == set(range(world))
+    rngc = np.random.default_rng(4)
+    Wc = rngc.standard_normal((nc, nc))
+    Wc = Wc + Wc.T
+    Xc = rngc.standard_normal((nc, 8))
+    Lw = np.tril(Wc, -1) + 0.5 * np.diag(np.diag(Wc))  # what the tiles hold: strict lower triangle + half the diagonal
+    Yc = np.zeros((nc, 8))
+    for m in range(nmb):
+        if own[m] == rank:
+            R = slice(1024 * m, min(nc, 1024 * (m + 1)))
+            Yc[R] += Lw[R] @ Xc  # direct sums of the band's rows
+            Yc += Lw[R].T @ Xc[R]  # transposed sums on the columns of the band's tiles
+    tc = torch.from_numpy(Yc.copy())
+    dist.all_reduce(tc)
+    assert np.linalg.norm(tc.numpy() - Wc @ Xc) <= 1e-12 * np.linalg.norm(Wc @ Xc)
     # 128-byte communicator id broadcast (what bench.py does with the ncclUniqueId)
     idt = torch.arange(128, dtype=torch.uint8) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
     dist.broadcast(idt, 0)

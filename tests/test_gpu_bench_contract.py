@@ -32,7 +32,7 @@ def test_default_workload_line_small():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # the headline path: explicit local dual operators (fp64 GEMV); the inner-Krylov path and its strict-fp64 variant ride along
-    assert d["config"]["kplus"]["path"] == "explicit" and ("k_fx_symv" in r["kernel"] or "k_fxs_gemm8" in r["kernel"]) and r["launches_timed"] > 0
+    assert d["config"]["kplus"]["path"] == "explicit" and any(k in r["kernel"] for k in ("k_fx_symv", "k_fxs_gemm8", "k_fxs_symm8")) and r["launches_timed"] > 0
     st = d["config"]["steps_by_type"]
     assert st["cg"] + st["expansion"] + st["proportioning"] == 30 and st["solves"] >= 1
     for k in ("iterative", "strict_fp64"):
