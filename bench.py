@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--variant", default="obstacle", choices=["obstacle", "twosided"])
     ap.add_argument("--nel", type=int, default=43, help="feti: Q1 elements per subdomain edge (43 -> configs[2])")
     ap.add_argument("--sub", default="2,2,2", help="feti: subdomain grid sx,sy,sz (2,2,2 -> configs[2]; 4,4,4 with --nel 21 --dense-coarse -> the shape of configs[3]: 64 subdomains, 8 per GPU at N = 8, 384 x 384 coarse problem)")
+    ap.add_argument("--orth-form", choices=["implicit", "explicit"], default="implicit",
+                    help="feti: QPTOrthonormalizeEq's form (-qp_E_orth_form; the reference's default is implicit, qptransform.c:647): implicit keeps G = R'B' as sparse as it is and applies "
+                         "the small dense T = chol(GG')^{-1} inside the finishing launch of G v; explicit hands the filled T G to the library (3.4 x the non-zeros for configs[2]). Same operator either way")
     ap.add_argument("--dense-coarse", action="store_true", help="feti: keep G as it comes (no QPTOrthonormalizeEq): the projector applies the dense (GG')^{-1} (GG' assembled by the fp64-MFMA kernel)")
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
@@ -380,7 +383,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     nsub = sub[0] * sub[1] * sub[2]
     orth = not a.dense_coarse
     f = pa.CubeFeti(sub, a.nel, contact=True)
-    G, e = f.coarse(orthonormalize=orth)
+    implicit = orth and a.orth_form == "implicit"
+    G, e = f.coarse(orthonormalize=orth and not implicit)  # implicit: G0 = R'B', e0; the library orthonormalises (pmh_qppf_create orthonormal = 2)
     if nsub % world:
         raise SystemExit("feti workload: the %d subdomains must divide over the ranks" % nsub)
     per = nsub // world
@@ -439,7 +443,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
             explicit["stripe"] = (rank, nshare, dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign))
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if use_c_builder else None,
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal="implicit" if implicit else orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if use_c_builder else None,
                    mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3, regularize=a.regularize, explicit=explicit)
     has_mg = a.kplus_pc == "mg"
 
@@ -617,7 +621,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "checksum": {"norm_lambda_child_after_last_step": repr(float(q.lam.norm()))},  # bitwise comparable between runs (deterministic reductions)
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
-                                      "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": True},
+                                      "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": "implicit: T G0 with T = chol(G0 G0')^{-1} applied in the finishing launch of G0 v, G0 kept sparse (%d non-zeros)" % G.nnz if implicit else True},
         "roofline": roofline,
     }
     res.update(extra)
@@ -701,7 +705,7 @@ def main():
         if rank == 0 and world == 1:
             if not a.no_cpu_baseline and hier is not None and not a.regularize:
                 try:
-                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=not a.dense_coarse)
+                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=orth and not implicit)  # implicit: G0 with the dense (G0 G0')^{-1} = the same projector
                 except Exception as ex:  # noqa: BLE001
                     out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
             if not a.no_c2:

@@ -194,8 +194,13 @@ int pmh_mpgp_run_fixed(pmh_mpgp s, int iters);
 typedef struct pmh_qppf_s *pmh_qppf;
 /* G: m x n CSR (device); GG' is formed and Cholesky-factored on the host once (QPPFSetUpGGt/GGtinv_Private
    qppf.c:213-333, MATINV monolithic direct solve), the factor is applied redundantly on the device.
-   orthonormal != 0 <=> G_has_orthonormal_rows (GGtinv = NULL, qppf.c:225-229) */
+   orthonormal == 1 <=> G_has_orthonormal_rows (GGtinv = NULL, qppf.c:225-229).
+   orthonormal == 2: G is NOT orthonormal and is orthonormalised IMPLICITLY (QPTOrthonormalizeEq with -qp_E_orth_form implicit, the reference's default
+   form, qptransform.c:647; MatOrthRows_Implicit_Default permonmatorth.c:176-205): the object behaves exactly as one created with the explicit
+   T G (GG' = L L', T = L^{-1}; orthonormal rows) but keeps G as sparse as it came and applies the small dense T / T'T inside the finishing launch
+   of G v.  The right-hand side of the constraint transforms with pmh_qppf_orth_rhs (e = T e0, host vectors of length m). */
 int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf *pf);
+int pmh_qppf_orth_rhs(pmh_qppf pf, const double *e0_host, double *e_host);
 int pmh_qppf_destroy(pmh_qppf pf);
 /* set-up cost of the coarse problem: GG' assembly on the matrix cores (ms, flops = 2 Mp^2 n) and the host Cholesky + inverse (ms) */
 int pmh_qppf_setup_stats(pmh_qppf pf, double *ggt_mfma_ms, double *ggt_flops, double *host_inverse_ms);
@@ -521,7 +526,7 @@ typedef struct {
   int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
   int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM) */
-  int    orthonormalize;            /* QPTOrthonormalizeEq: G <- L^{-1} G */
+  int    orthonormalize;            /* QPTOrthonormalizeEq: 1 G <- L^{-1} G formed explicitly, 2 implicitly (G stays sparse, -qp_E_orth_form implicit), 0 none */
 } pmh_feti_contact_opts;
 typedef struct {
   pmh_smalxe_stats smalxe;

@@ -167,6 +167,7 @@ _PROTOS = {
     "pmh_mpgp_run_fixed": [vp, C.c_int],
     "pmh_qppf_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_qppf_destroy": [vp],
+    "pmh_qppf_orth_rhs": [vp, vp, vp],
     "pmh_qppf_setup_stats": [vp, c_double_p, c_double_p, c_double_p],
     "pmh_qppf_apply_Q": [vp, vp, vp],
     "pmh_qppf_apply_P": [vp, vp, vp],

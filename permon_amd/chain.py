@@ -83,6 +83,8 @@ class FetiDualQP:
         self.f = ctx.vec_from(local["f"])
         # BE = G, cE = e (QPSetEq(child,G,e) qptransform.c:1169); G None: no floating subdomain, no equality constraint
         self.pf = QPPF.from_scipy(ctx, G, orthonormal=orthonormal) if G is not None else None
+        if G is not None and orthonormal == "implicit":  # G, e come un-orthonormalised: the constraint is (T G) lambda = T e
+            e = self.pf.orth_rhs(e)
         self.e = ctx.vec_from(e) if G is not None else None
         # QPTDualize -> QPTHomogenizeEq -> QPTEnforceEqByProjector on the device (pmh_qpt_feti_chain_create, csrc/feti.hip):
         # F = B K^+ B', d = B K^+ f - c, lambda~ = G'(GG')^{-1} e, b_bar = d - F lambda~, lb <- lb - lambda~, A = P F P | P F, b = P b_bar

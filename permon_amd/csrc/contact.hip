@@ -106,7 +106,7 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       e[grow0[s] + k] = t;
     }
   const std::vector<double> G0 = Gd; // the un-orthonormalised G serves the rigid-body recovery
-  if (o->orthonormalize) {
+  if (o->orthonormalize == 1) { // explicit form: the filled T G0 (2: implicit, the library keeps G0 sparse, see pmh_qppf_create)
     L.assign((size_t)m * m, 0.0);
     for (int i = 0; i < m; i++)
       for (int j = 0; j <= i; j++) {
@@ -162,7 +162,11 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     }
     GO(pmh_gluing_create(ctx, N, nl, n_leaves, leaves_row, leaves_root, leaves_val, &B));
     GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
-    GO(pmh_qppf_create(ctx, Gc, o->orthonormalize ? 1 : 0, &pf));
+    GO(pmh_qppf_create(ctx, Gc, o->orthonormalize, &pf));
+    if (o->orthonormalize == 2) { // the constraint becomes (T G0) lambda = T e0
+      std::vector<double> e0 = e;
+      GO(pmh_qppf_orth_rhs(pf, e0.data(), e.data()));
+    }
     if (o->explicit_dual) { // MatInvExplicitly restricted to the dofs B touches; congruent blocks share their columns
       std::vector<int> cls(nsub);
       GO(pmh_csr_block_classes(nsub, block_rowstart, rowptr, col, val, cls.data(), nullptr));

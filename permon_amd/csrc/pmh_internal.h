@@ -90,6 +90,7 @@ struct pmh_spmv_epi {
   const int    *halt;           // optional device flag: when set the launch (and its finalise) is a no-op
 };
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
+int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y); // y = M (A x), Mt = M' (m x m, device)
 
 // ---- operators -------------------------------------------------------------------------------------------
 struct pmh_op_s {
@@ -109,6 +110,11 @@ struct pmh_qppf_s {
   int     m, n;
   int     orthonormal;
   double *d_inv; // (GG')^{-1}, m x m row-major
+  // implicit orthonormalisation (pmh_qppf_create orthonormal = 2): G stays G0 as handed over, the orthonormal-row matrix is T G0 with GG' = LL',
+  // T = L^{-1}; d_Tt = T' (row-major) and d_S = T'T = (G0 G0')^{-1} (symmetric), both m x m
+  int     implicit_orth;
+  double *d_Tt, *d_S, *tmp_m;
+  std::vector<double> h_T;
   double *G_left, *Gt_right;
   double  ggt_mfma_ms, host_inverse_ms; // set-up timings (pmh_qppf_setup_stats)
   // QPPFApplyQ's (v,state) -> Qv cache (qppf.c:464-467,495-498) is realised structurally: the penalised

@@ -139,6 +139,38 @@ static int host_cholesky_inverse(int m, std::vector<double> &a)
   return 0;
 }
 
+// a = L L' (lower Cholesky, in place); T = L^{-1} (lower triangular, row-major), S = T'T = a^{-1} (symmetrised by construction)
+static int host_cholesky_T(int m, std::vector<double> &a, std::vector<double> &T, std::vector<double> &S)
+{
+  for (int j = 0; j < m; j++) {
+    double d = a[(size_t)j * m + j];
+    for (int k = 0; k < j; k++) d -= a[(size_t)j * m + k] * a[(size_t)j * m + k];
+    if (!(d > 0.0)) return 1;
+    d                    = sqrt(d);
+    a[(size_t)j * m + j] = d;
+    for (int i = j + 1; i < m; i++) {
+      double s = a[(size_t)i * m + j];
+      for (int k = 0; k < j; k++) s -= a[(size_t)i * m + k] * a[(size_t)j * m + k];
+      a[(size_t)i * m + j] = s / d;
+    }
+  }
+  T.assign((size_t)m * m, 0.0);
+  for (int c = 0; c < m; c++) // column c of L^{-1} by forward substitution against e_c
+    for (int i = c; i < m; i++) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; k++) s -= a[(size_t)i * m + k] * T[(size_t)k * m + c];
+      T[(size_t)i * m + c] = s / a[(size_t)i * m + i];
+    }
+  S.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = 0.0;
+      for (int k = i; k < m; k++) s += T[(size_t)k * m + i] * T[(size_t)k * m + j]; // (T'T)_ij = sum_k T_ki T_kj, k >= max(i, j) = i
+      S[(size_t)i * m + j] = S[(size_t)j * m + i] = s;
+    }
+  return 0;
+}
+
 extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf *out)
 {
   PMH_ARG(ctx && G && out);
@@ -148,6 +180,8 @@ extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf
   pf->m          = G->nrows;
   pf->n          = G->ncols;
   pf->orthonormal = orthonormal ? 1 : 0;
+  pf->implicit_orth = 0;
+  pf->d_Tt = pf->d_S = pf->tmp_m = nullptr;
   pf->d_inv      = nullptr;
   pf->ggt_mfma_ms = pf->host_inverse_ms = 0.0;
   const int m    = pf->m;
@@ -169,7 +203,49 @@ extern "C" int pmh_qppf_create(pmh_ctx ctx, pmh_csr G, int orthonormal, pmh_qppf
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)m * m, (void **)&pf->d_inv));
     PMH_CHK(pmh_memcpy_h2d(ctx, pf->d_inv, ggt.data(), sizeof(double) * (size_t)m * m));
   }
+  if (orthonormal == 2 && m > 0) {
+    // implicit orthonormalisation (the reference's -qp_E_orth_form implicit, qptransform.c:647, permonmatorth.c:176-205: the orthonormalised
+    // matrix is never formed): G stays as sparse as it came (an explicit T G0 fills every row of a subdomain's modes with the columns of all
+    // subdomains before it: 3.4 x the non-zeros for configs[2]); GG' = L L' on the device / host as above, T = L^{-1}, S = T'T = (GG')^{-1}
+    std::vector<double> ggt;
+    PMH_CHK(device_ggt(ctx, G, ggt, &pf->ggt_mfma_ms));
+    const auto          t0 = std::chrono::steady_clock::now();
+    std::vector<double> T, S;
+    const int           bad = host_cholesky_T(m, ggt, T, S);
+    pf->host_inverse_ms     = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bad) {
+      pmh_free(ctx, pf->G_left);
+      pmh_free(ctx, pf->Gt_right);
+      delete pf;
+      return pmh_set_error(PMH_ERR_ARG, "pmh_qppf_create: G G' is not positive definite (G must have full row rank)");
+    }
+    std::vector<double> Tt((size_t)m * m);
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < m; j++) Tt[(size_t)j * m + i] = T[(size_t)i * m + j];
+    const size_t bytes = sizeof(double) * (size_t)m * m;
+    PMH_CHK(pmh_malloc(ctx, bytes, (void **)&pf->d_Tt));
+    PMH_CHK(pmh_malloc(ctx, bytes, (void **)&pf->d_S));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)m, (void **)&pf->tmp_m));
+    PMH_CHK(pmh_memcpy_h2d(ctx, pf->d_Tt, Tt.data(), bytes));
+    PMH_CHK(pmh_memcpy_h2d(ctx, pf->d_S, S.data(), bytes)); // symmetric: its own transpose
+    pf->h_T           = T;
+    pf->implicit_orth = 1;
+  }
   *out = pf;
+  return PMH_SUCCESS;
+}
+
+// e = T e0: the right-hand side of the implicitly orthonormalised constraint (T G0) lambda = T e0 (host vectors of length m)
+extern "C" int pmh_qppf_orth_rhs(pmh_qppf pf, const double *e0, double *e)
+{
+  PMH_ARG(pf && e0 && e);
+  if (!pf->implicit_orth) return pmh_set_error(PMH_ERR_STATE, "pmh_qppf_orth_rhs: the projector was not created with implicit orthonormalisation");
+  const int m = pf->m;
+  for (int i = 0; i < m; i++) {
+    double s = 0.0;
+    for (int j = 0; j <= i; j++) s += pf->h_T[(size_t)i * m + j] * e0[j];
+    e[i] = s;
+  }
   return PMH_SUCCESS;
 }
 
@@ -191,6 +267,7 @@ extern "C" int pmh_qppf_destroy(pmh_qppf pf)
   pmh_free(pf->ctx, pf->G_left);
   pmh_free(pf->ctx, pf->Gt_right);
   if (pf->d_inv) pmh_free(pf->ctx, pf->d_inv);
+  if (pf->d_Tt) pmh_free(pf->ctx, pf->d_Tt), pmh_free(pf->ctx, pf->d_S), pmh_free(pf->ctx, pf->tmp_m);
   delete pf;
   return PMH_SUCCESS;
 }
@@ -199,7 +276,15 @@ extern "C" int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv)
 {
   PMH_ARG(pf);
   if (pf->m == 0) return PMH_SUCCESS;
+  if (pf->implicit_orth) return pmh_csr_mult_then_dense(pf->G, v, pf->d_Tt, pf->tmp_m, Gv); // (T G0) v
   return pmh_csr_mult(pf->G, v, Gv);
+}
+
+// G_left = what G' is applied to in Q v = G'(..): G v for orthonormal rows, S G0 v under implicit orthonormalisation
+static int qppf_left(pmh_qppf pf, const double *v)
+{
+  if (pf->implicit_orth) return pmh_csr_mult_then_dense(pf->G, v, pf->d_S, pf->tmp_m, pf->G_left);
+  return pmh_csr_mult(pf->G, v, pf->G_left);
 }
 
 // QPPFApplyCP qppf.c:610-645
@@ -218,7 +303,7 @@ extern "C" int pmh_qppf_apply_Q(pmh_qppf pf, const double *v, double *Qv)
 {
   PMH_ARG(pf && (const void *)v != (const void *)Qv);
   if (pf->m == 0) return pmh_vec_set(pf->ctx, pf->n, Qv, 0.0);
-  PMH_CHK(pmh_csr_mult(pf->G, v, pf->G_left));
+  PMH_CHK(qppf_left(pf, v));
   if (pf->d_inv) {
     PMH_CHK(pmh_qppf_apply_CP(pf, pf->G_left, pf->Gt_right));
     return pmh_csr_mult_transpose(pf->G, pf->Gt_right, Qv);
@@ -248,6 +333,7 @@ extern "C" int pmh_qppf_apply_halfQ(pmh_qppf pf, const double *x, double *y)
 {
   PMH_ARG(pf);
   if (pf->m == 0) return PMH_SUCCESS;
+  if (pf->implicit_orth) return pmh_csr_mult_then_dense(pf->G, x, pf->d_Tt, pf->tmp_m, y); // (GG')^{-1} = I for G = T G0: y = T G0 x
   PMH_CHK(pmh_csr_mult(pf->G, x, pf->G_left));
   return pmh_qppf_apply_CP(pf, pf->G_left, y);
 }
@@ -257,6 +343,11 @@ extern "C" int pmh_qppf_apply_halfQ_transpose(pmh_qppf pf, const double *x, doub
 {
   PMH_ARG(pf);
   if (pf->m == 0) return pmh_vec_set(pf->ctx, pf->n, y, 0.0);
+  if (pf->implicit_orth) { // (T G0)' x = G0' (T' x); k_dense_gemv takes a row-major matrix: T' row-major = d_Tt
+    hipLaunchKernelGGL(k_dense_gemv, dim3((pf->m + 3) / 4), dim3(PMH_BLOCK), 0, pf->ctx->stream, pf->m, (const double *)pf->d_Tt, x, pf->Gt_right);
+    PMH_HIP(hipGetLastError());
+    return pmh_csr_mult_transpose(pf->G, pf->Gt_right, y);
+  }
   if (pf->d_inv) {
     PMH_CHK(pmh_qppf_apply_CP(pf, x, pf->Gt_right));
     return pmh_csr_mult_transpose(pf->G, pf->Gt_right, y);
@@ -294,6 +385,24 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused(int n, const int *__rest
   }
 }
 
+// the same for short rows (the one-lane-per-row case of the stream kernel: a row is summed left to right by one thread), e.g. the <= 12
+// entries per row of an un-filled G0' under implicit orthonormalisation
+__global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ w, int mode,
+                                                        const double *__restrict__ x, double *__restrict__ y, double *__restrict__ z, double rho)
+{
+  const int r = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  double sum = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; k++) sum += val[k] * w[col[k]];
+  if (mode == 0) {
+    y[r] = sum;
+    z[r] = -1.0 * sum + x[r];
+  } else {
+    const double t = x[r] + -1.0 * sum;
+    y[r]           = y[r] * rho + t;
+  }
+}
+
 // the fused path applies when G' is the 8-lanes-per-row stream case (a few dozen entries per row: the rigid-body modes of the
 // subdomains a dual row touches), otherwise the callers keep the unfused sequence
 static bool gt_fusable(pmh_qppf pf)
@@ -301,12 +410,16 @@ static bool gt_fusable(pmh_qppf pf)
   if (!pf->orthonormal || pf->d_inv || pf->m == 0 || getenv("PMH_NO_GT_FUSION")) return false;
   if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
   const pmh_csr Gt = pf->G->transpose;
-  return Gt->kind == PMH_SPMV_STREAM && Gt->st_rl == 8 && Gt->l_nchunks == 0;
+  return Gt->kind == PMH_SPMV_STREAM && (Gt->st_rl == 8 || Gt->st_rl == 1) && Gt->l_nchunks == 0;
 }
 
 static int gt_fused(pmh_qppf pf, const double *w, int mode, const double *x, double *y, double *z, double rho)
 {
   const pmh_csr Gt = pf->G->transpose;
+  if (Gt->st_rl == 1)
+    hipLaunchKernelGGL(k_gt_fused1, dim3((Gt->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, pf->ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, w,
+                       mode, x, y, z, rho);
+  else
   hipLaunchKernelGGL(k_gt_fused, dim3((Gt->nrows + PMH_BLOCK / 8 - 1) / (PMH_BLOCK / 8)), dim3(PMH_BLOCK), 0, pf->ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col,
                      (const double *)Gt->d_val, w, mode, x, y, z, rho);
   PMH_HIP(hipGetLastError());
@@ -374,10 +487,10 @@ struct PenalizedOp : pmh_op_s {
     ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
     if (pa && pa->pf == pf && pa->symmetric && gt_fusable(pf)) {
       // A = P F P with the same orthonormal projector: y = rho Q x + P F (P x) in 10 launches (see k_gt_fused)
-      PMH_CHK(pmh_csr_mult(pf->G, x, pf->G_left));
+      PMH_CHK(qppf_left(pf, x));
       PMH_CHK(gt_fused(pf, pf->G_left, 0, x, y, pa->w1, 0.0)); // y = Q x, w1 = P x
       PMH_CHK(pa->A->mult(pa->w1, pa->w2));
-      PMH_CHK(pmh_csr_mult(pf->G, pa->w2, pf->G_left));
+      PMH_CHK(qppf_left(pf, pa->w2));
       return gt_fused(pf, pf->G_left, 1, pa->w2, y, nullptr, rho); // y = rho y + (w2 - Q w2)
     }
     PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));

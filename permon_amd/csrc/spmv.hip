@@ -314,6 +314,29 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_fin(int nrows, const in
   epi_row<EPI>(r, sum, x, y, a, d0, d1, dm);
 }
 
+// y = M (A x) for a matrix with few rows (the m = 48 ... 384 rows of G) and a small dense m x m matrix M handed over TRANSPOSED (Mt[c * m + r] =
+// M[r][c]: lane r reads contiguously): the chunk sums of k_spmv_long_part are added per row in chunk order into LDS, then every row of M is
+// applied by one thread, left to right -- the finishing launch of the long-row product and the dense product in ONE launch of one workgroup
+// (the implicitly orthonormalised G = T G0 of qppf.hip: G0 keeps its sparsity, T or T'T is applied here).  lrow == nullptr: `part` already
+// holds A x (the product of a short-row matrix).
+__global__ __launch_bounds__(PMH_BLOCK) void k_rows_then_dense(int m, const int *__restrict__ lrow, const double *__restrict__ part, const double *__restrict__ Mt, double *__restrict__ y)
+{
+  extern __shared__ double t0[];
+  for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
+    double sum = 0.0;
+    if (lrow)
+      for (int c = lrow[r]; c < lrow[r + 1]; c++) sum += part[c];
+    else sum = part[r];
+    t0[r] = sum;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
+    double s = 0.0;
+    for (int c = 0; c < m; c++) s += Mt[(size_t)c * m + r] * t0[c];
+    y[r] = s;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int build_rowblocks(int nrows, const int *rowptr, int nnzb, std::vector<int> &rb)
 {
@@ -611,6 +634,25 @@ extern "C" int pmh_csr_mult(pmh_csr A, const double *x, double *y)
   memset(&e, 0, sizeof(e));
   e.kind = PMH_EPI_NONE;
   return pmh_csr_spmv_launch(A, x, y, e);
+}
+
+// y = M (A x), M m x m dense given transposed on the device (see k_rows_then_dense); tmp: m doubles of device scratch (short-row matrices)
+int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y)
+{
+  PMH_ARG(A && x && Mt && tmp && y && A->nrows >= 1 && A->nrows <= 4096);
+  pmh_ctx      ctx = A->ctx;
+  const size_t lds = sizeof(double) * (size_t)A->nrows;
+  if (A->l_nchunks) {
+    static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+    if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
+    else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
+    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, Mt, y);
+  } else {
+    PMH_CHK(pmh_csr_mult(A, x, tmp));
+    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)nullptr, (const double *)tmp, Mt, y);
+  }
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
 }
 
 extern "C" int pmh_csr_mult_add(pmh_csr A, const double *x, const double *y1, double *y)

@@ -373,11 +373,21 @@ class QPPF:
     """Projector factory on G (src/qppf/interface/qppf.c): Q = G'(GG')^{-1}G, P = I - Q."""
 
     def __init__(self, ctx, G, orthonormal=False):
+        """orthonormal: False (G as it is, dense (GG')^{-1} in between), True (G has orthonormal rows), "implicit" (G is orthonormalised
+        implicitly: the object acts as T G with GG' = LL', T = L^{-1}, but G keeps its sparsity; the reference's -qp_E_orth_form implicit)."""
         self.ctx, self.G, self.orthonormal = ctx, G, bool(orthonormal)
+        self.implicit = orthonormal == "implicit"
         self.m, self.n = G.nrows, G.ncols
         h = C.c_void_p()
-        check(ctx.L.pmh_qppf_create(ctx.h, G.h, int(self.orthonormal), C.byref(h)))
+        check(ctx.L.pmh_qppf_create(ctx.h, G.h, 2 if self.implicit else int(self.orthonormal), C.byref(h)))
         self.h = h
+
+    def orth_rhs(self, e0):
+        """e = T e0: the right-hand side of the implicitly orthonormalised constraint."""
+        e0 = np.ascontiguousarray(e0, dtype=np.float64)
+        e = np.zeros_like(e0)
+        check(self.ctx.L.pmh_qppf_orth_rhs(self.h, e0.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p)))
+        return e
 
     @classmethod
     def from_scipy(cls, ctx, G, orthonormal=False):

@@ -63,6 +63,55 @@ def test_qppf_vs_oracle(ctx, oracle, orth):
     assert np.max(np.abs(yd.to_numpy() - pfo.half_Q_transpose(e))) <= 1e-12 * max(1.0, np.max(np.abs(e)))
 
 
+@pytest.mark.parametrize("size", [(2, 2, 1, 2), (2, 2, 2, 16)])
+def test_qppf_implicit_orthonormalisation(ctx, size, monkeypatch):
+    """pmh_qppf_create(orthonormal = 2): G0 = R'B' kept sparse, T = chol(G0 G0')^{-1} applied in the finishing launch of G0 v -- every slot acts as the
+    explicitly orthonormalised T G0 does (QPTOrthonormalizeEq, -qp_E_orth_form implicit vs explicit); the second size has long rows (the chunked
+    G v kernels) and short G0' rows (k_gt_fused1 of the penalised operator)."""
+    f = pa.CubeFeti(size[:3], size[3], contact=True)
+    G0, e0 = f.coarse(orthonormalize=False)
+    Ge, ee = f.coarse(orthonormalize=True)
+    assert Ge.nnz > 1.5 * G0.nnz  # what the implicit form saves
+    pi, pe = pa.QPPF.from_scipy(ctx, G0, orthonormal="implicit"), pa.QPPF.from_scipy(ctx, Ge, orthonormal=True)
+    assert np.linalg.norm(pi.orth_rhs(e0) - ee) <= 1e-11 * np.linalg.norm(ee)
+    rng = np.random.default_rng(8)
+    v, w = rng.standard_normal(f.n_lambda), rng.standard_normal(G0.shape[0])
+    vd, wd = ctx.vec_from(v), ctx.vec_from(w)
+    for name, arg, n_out in (("ApplyQ", vd, f.n_lambda), ("ApplyP", vd, f.n_lambda), ("ApplyGtG", vd, f.n_lambda), ("ApplyG", vd, G0.shape[0]), ("ApplyHalfQ", vd, G0.shape[0]),
+                             ("ApplyHalfQTranspose", wd, f.n_lambda), ("ApplyCP", wd, G0.shape[0])):
+        ya, yb = ctx.vec(n_out), ctx.vec(n_out)
+        getattr(pi, name)(arg, ya)
+        getattr(pe, name)(arg, yb)
+        ref = yb.to_numpy()
+        assert np.linalg.norm(ya.to_numpy() - ref) <= 1e-11 * max(np.linalg.norm(ref), 1e-3 * np.linalg.norm(v)), name
+    # the penalised projected operator rho Q x + P A P x (its fused G' epilogues against the unfused sequence: same bits; against the explicit form)
+    n = f.n_lambda
+    Dm = sp.diags(1.0 + rng.random(n)).tocsr()
+    D = pa.Op.from_csr(pa.CsrMat(ctx, n, n, Dm.indptr, Dm.indices, Dm.data))
+    out = []
+    for pf in (pi, pe):
+        Ap = pa.MatCreatePenalized(pa.MatCreateProjected(D, pf, symmetric=True), pf, 2.5)
+        y1, y2 = ctx.vec(n), ctx.vec(n)
+        pa._lib.check(ctx.L.pmh_op_mult(Ap.h, vd.p, y1.p))
+        monkeypatch.setenv("PMH_NO_GT_FUSION", "1")
+        pa._lib.check(ctx.L.pmh_op_mult(Ap.h, vd.p, y2.p))
+        monkeypatch.delenv("PMH_NO_GT_FUSION")
+        assert np.array_equal(y1.to_numpy(), y2.to_numpy())
+        out.append(y1.to_numpy())
+    assert np.linalg.norm(out[0] - out[1]) <= 1e-11 * np.linalg.norm(out[1])
+    if size[3] > 4:
+        return
+    # the whole dual chain and the contact solve: same counts, same solution
+    loc, res = f.subset(range(f.nsub)), []
+    for G, e, orth in ((G0, e0, "implicit"), (Ge, ee, True)):
+        q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, orthonormal=orth, kplus_rtol=1e-12)
+        st = q.solve_smalxe(rtol=1e-6)
+        res.append((st, q.dual_solution()))
+    (sa, la), (sb, lb_) = res
+    assert (sa.iteration, sa.inner_iter_accu, sa.reason, sa.inner.ncg, sa.inner.nexp, sa.inner.nprop) == (sb.iteration, sb.inner_iter_accu, sb.reason, sb.inner.ncg, sb.inner.nexp, sb.inner.nprop)
+    assert np.linalg.norm(la - lb_) <= 1e-8 * np.linalg.norm(la)
+
+
 def _dense_ops(f):
     Kd = f.K.toarray()
     Kp = np.linalg.pinv(Kd, rcond=1e-12, hermitian=True)
