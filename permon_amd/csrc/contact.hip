@@ -1,7 +1,7 @@
 // One C entry point for a TFETI CONTACT problem -- what QPTFromOptions / QPTAllInOne (src/qp/interface/qptransform.c:2152-2237) +
 // QPSSolve + the post-solve chain do for a decomposed QP with equality (gluing, Dirichlet) and inequality (non-penetration) rows:
 //   QPTDualize (:1102-1174)  F = B K^+ B', d = B K^+ f - c, G = R'B', e = R'f, dual box lambda_I >= 0 (:1136-1162)
-//   QPTOrthonormalizeEq      G <- L^{-1} G, e <- L^{-1} e with G G' = L L'   (optional, the bench default)
+//   QPTOrthonormalizeEq      G <- L^{-1} G, e <- L^{-1} e with G G' = L L'   (optional, the bench default; implicitly by default: pmh_qppf_create)
 //   QPTHomogenizeEq (:437-527), QPTEnforceEqByProjector (:215-316)          A = P F P, b = P (d - F lambda~)
 //   QPSSetDefaultType (qps.c:443-444): equality constraint present -> SMALXE with inner MPGP
 //   post-solve: lambda = lambda_child + lambda~ (:423-431); u = K^+(f - B' lambda) + R alpha (:783-833)
@@ -24,7 +24,7 @@ extern "C" int pmh_feti_contact_default_opts(pmh_feti_contact_opts *o)
   o->mg = 1, o->mg_min_nodes = 400, o->mg_degree = 2, o->mg_precision = PMH_MG_FP16;
   o->bsr3 = 1;
   o->explicit_dual = 1, o->explicit_rtol = 1e-12, o->explicit_storage = PMH_FX_SYM;
-  o->orthonormalize = 1;
+  o->orthonormalize = 2; // implicit form (the reference's default form): G = R'B' keeps its sparsity
   return PMH_SUCCESS;
 }
 
@@ -163,10 +163,8 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     GO(pmh_gluing_create(ctx, N, nl, n_leaves, leaves_row, leaves_root, leaves_val, &B));
     GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
     GO(pmh_qppf_create(ctx, Gc, o->orthonormalize, &pf));
-    if (o->orthonormalize == 2) { // the constraint becomes (T G0) lambda = T e0
-      std::vector<double> e0 = e;
-      GO(pmh_qppf_orth_rhs(pf, e0.data(), e.data()));
-    }
+    std::vector<double> e_raw = e; // pairs with Gd = G0 in the diagnostic below
+    if (o->orthonormalize == 2) GO(pmh_qppf_orth_rhs(pf, e_raw.data(), e.data())); // the constraint becomes (T G0) lambda = T e0
     if (o->explicit_dual) { // MatInvExplicitly restricted to the dofs B touches; congruent blocks share their columns
       std::vector<int> cls(nsub);
       GO(pmh_csr_block_classes(nsub, block_rowstart, rowptr, col, val, cls.data(), nullptr));
@@ -217,11 +215,11 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     GO(pmh_memcpy_d2h(ctx, r.data(), d_r, bl));
     GO(pmh_memcpy_d2h(ctx, u_host, d_u0, bx));
     if (lambda_host) memcpy(lambda_host, lam.data(), bl);
-    // G lambda = e (the equality constraint of the dual QP), measured with the G the solver used
+    // G lambda = e (the equality constraint of the dual QP), measured with the G the solver was handed (implicit form: G0 lambda = e0)
     {
       double t2 = 0.0;
       for (int i = 0; i < m; i++) {
-        double t = -e[i];
+        double t = -(o->orthonormalize == 2 ? e_raw[i] : e[i]);
         for (int q = 0; q < nl; q++) t += Gd[(size_t)i * nl + q] * lam[q];
         t2 += t * t;
       }

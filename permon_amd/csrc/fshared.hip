@@ -318,16 +318,24 @@ __global__ __launch_bounds__(FXM_THREADS, 1) void k_fxs_symm8(const int *__restr
 __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_symfin(int ld, int nmb, int nown, const int *__restrict__ nseg_of, const int *__restrict__ own_first, const long long *__restrict__ own_ptoff,
                                                           long long xbase0, long long pd_stride, const double *__restrict__ pd, const double *__restrict__ pt, double *__restrict__ Y)
 {
-  const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x);
-  if (i >= (long long)ld * FXS_S) return;
-  const int       g = blockIdx.y, m0 = (int)(i / (FXM_MB * FXM_RS * FXS_S));
-  const long long xb = xbase0 + (long long)g * ld * FXS_S;
+  // 8 lanes per pair of entries: lane `sub` adds the partial sums j = sub, sub + 8, ... (a small share of W_c cuts a mega band into > 100 items:
+  // one thread per entry would walk them one load latency after the other), then a fixed shuffle tree -- still one summation order
+  const long long t = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x, i = 2 * (t >> 3);
+  const int       sub = threadIdx.x & 7;
   dbl2            s = {0.0, 0.0};
-  const int       ns = nseg_of[g * nmb + m0];
-  for (int j = 0; j < ns; j++) s += *(const dbl2 *)(pd + (long long)j * pd_stride + xb + i);
-  const long long *__restrict__ po = own_ptoff + (long long)g * nown;
-  for (int k = own_first[m0]; k < nown; k++) s += *(const dbl2 *)(pt + po[k] + i);
-  *(dbl2 *)(Y + xb + i) = s;
+  const bool      in = i < (long long)ld * FXS_S;
+  const int       g = blockIdx.y;
+  const long long xb = xbase0 + (long long)g * ld * FXS_S;
+  if (in) {
+    const int m0 = (int)(i / (FXM_MB * FXM_RS * FXS_S));
+    const int ns = nseg_of[g * nmb + m0];
+    for (int j = sub; j < ns; j += 8) s += *(const dbl2 *)(pd + (long long)j * pd_stride + xb + i);
+    const long long *__restrict__ po = own_ptoff + (long long)g * nown;
+    for (int k = own_first[m0] + sub; k < nown; k += 8) s += *(const dbl2 *)(pt + po[k] + i);
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) s.x += __shfl_down(s.x, o, 8), s.y += __shfl_down(s.y, o, 8);
+  if (in && sub == 0) *(dbl2 *)(Y + xb + i) = s;
 }
 
 // row p of W_c from a K^+ solve: the entries c <= p go to the tiles of p's row tile (the diagonal entry halved, see above)
@@ -726,7 +734,7 @@ static int fxs_gemm(fx_shared *S)
     hipLaunchKernelGGL(k_fxs_symm8, dim3(S->nwg), dim3(FXM_THREADS), 0, st, (const int *)S->d_wg, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff,
                        (const double *)S->Wbase, (const double *)S->X, S->part, stride, S->pt);
     for (auto &C : S->C)
-      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nmb, C.nown, (const int *)C.d_nseg, (const int *)C.d_ownfirst,
+      hipLaunchKernelGGL(k_fxs_symfin, dim3((unsigned)(((long long)C.ld * FXS_S / 2 * 8 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.ld, C.nmb, C.nown, (const int *)C.d_nseg, (const int *)C.d_ownfirst,
                          (const long long *)C.d_ptoff, C.xoff, stride, (const double *)S->part, (const double *)S->pt, S->Y);
   } else {
   hipLaunchKernelGGL(k_fxs_gemm8, dim3(S->nwg), dim3(PMH_BLOCK), 0, st, (const int *)S->d_wg, (const int *)S->d_ld, (const long long *)S->d_woff, (const long long *)S->d_xoff, (const double *)S->Wbase,

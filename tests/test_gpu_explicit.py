@@ -188,8 +188,8 @@ def test_contact_solve_one_call(ctx):
     """pmh_feti_contact_solve through its Python binding (the C example runs the same entry from plain C): counts of the Python-orchestrated
     chain, a feasible primal solution with glued interfaces, and the non-explicit path of the same call."""
     f = pa.CubeFeti((2, 2, 1), 6, contact=True)
-    G, e = f.coarse()
-    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, kplus_rtol=1e-9, mg_box=dict(dims=[(7, 7, 7)] * f.nsub, ndof=3, min_nodes=400), mg_precision="fp16", bsr3=True,
+    G, e = f.coarse(orthonormalize=False)  # orthonormalised implicitly, the default of pmh_feti_contact_solve
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal="implicit", kplus_rtol=1e-9, mg_box=dict(dims=[(7, 7, 7)] * f.nsub, ndof=3, min_nodes=400), mg_precision="fp16", bsr3=True,
                    explicit=dict(rtol=1e-12))
     ref = q.solve_smalxe(rtol=1e-5)
     for explicit in (True, False):
