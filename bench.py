@@ -580,6 +580,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None, "timing_stride": 1,
             "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
         }
+        if b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
+            roofline["note"] = ("W_c (%.2f GB stored on this rank) is streamed once per group of 8 blocks, %.1f passes per apply: the re-reads are served by the 256 MB Infinity Cache / L2, "
+                                "so `achieved` is an on-chip rate here, not an HBM rate (the HBM bound applies to the 8-blocks-per-GPU case of configs[2])" % (E.dense_bytes / 1e9, b_k / E.dense_bytes))
         kplus_cfg = {"path": "explicit", "storage": storage_used, "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
@@ -705,7 +708,7 @@ def main():
         if rank == 0 and world == 1:
             if not a.no_cpu_baseline and hier is not None and not a.regularize:
                 try:
-                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=orth and not implicit)  # implicit: G0 with the dense (G0 G0')^{-1} = the same projector
+                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=(not a.dense_coarse) and a.orth_form == "explicit")  # implicit form: G0 with the dense (G0 G0')^{-1} = the same projector
                 except Exception as ex:  # noqa: BLE001
                     out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
             if not a.no_c2:

@@ -38,6 +38,7 @@ def test_default_workload_line_small():
     for k in ("iterative", "strict_fp64"):
         assert d[k]["value"] > 0 and ROOF <= set(d[k]["roofline"]) and "k_bsr3<double>" in d[k]["roofline"]["kernel"]
     assert d["config"]["rccl_ranks"] is None
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port", d["cpu_baseline"]
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     c1 = d["configs1"]
