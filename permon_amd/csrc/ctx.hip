@@ -82,10 +82,21 @@ extern "C" int pmh_mem_info(pmh_ctx c, size_t *free_bytes, size_t *total_bytes)
   return PMH_SUCCESS;
 }
 
+// the host waits for the launch stream several times per MPGP step (step decisions on a shell operator); PMH_SYNC_SPIN=1 polls the stream instead of
+// blocking in hipStreamSynchronize (tuning knob)
+static inline hipError_t ctx_wait(pmh_ctx c)
+{
+  static const int spin = getenv("PMH_SYNC_SPIN") ? atoi(getenv("PMH_SYNC_SPIN")) : 0;
+  if (!spin) return hipStreamSynchronize(c->stream);
+  hipError_t e;
+  while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
+  return e;
+}
+
 extern "C" int pmh_sync(pmh_ctx c)
 {
   PMH_ARG(c);
-  PMH_HIP(hipStreamSynchronize(c->stream));
+  PMH_HIP(ctx_wait(c));
   return PMH_SUCCESS;
 }
 
@@ -221,7 +232,7 @@ extern "C" int pmh_comm_barrier(pmh_ctx c)
 
 int pmh_host_scalar(pmh_ctx c, int slot, double *v)
 {
-  PMH_HIP(hipStreamSynchronize(c->stream));
+  PMH_HIP(ctx_wait(c));
   *v = c->h_scal[slot];
   return PMH_SUCCESS;
 }

@@ -35,7 +35,7 @@ def test_block_classes_host():
     assert cls.tolist() == [0, 0, 1, 0]
 
 
-@pytest.mark.parametrize("share,storage", [(True, "sym"), (False, "sym"), (True, "full"), (True, "class"), (True, "class_sym")])
+@pytest.mark.parametrize("share,storage", [(True, "sym"), (False, "sym"), (True, "full"), (True, "class"), (True, "class_sym"), (False, "class_sym")])
 def test_explicit_blocks_vs_pinv(ctx, share, storage):
     """nel = 2: every W_b equals the dense pseudo-inverse of K_b on Gamma_b; F through the explicit path equals B pinv(K) B'."""
     f = pa.CubeFeti((2, 2, 1), 2, contact=True)
