@@ -65,6 +65,8 @@ struct pmh_csr_s {
   int       kind;          // PMH_SPMV_STREAM (row-blocked, LDS staged) or PMH_SPMV_VECTOR (sub-wave per row)
   int       lanes_per_row; // VECTOR kind
   int      *d_rowblocks;   // STREAM kind: row block boundaries [n_rowblocks+1]
+  unsigned short *d_col16; // STREAM kind, short rows: 16-bit column offsets from d_cbase[row block] (nullptr: a row block spans >= 65 536 columns)
+  int      *d_cbase;
   int       st_nnzb, st_mode, st_nt, st_rl; // STREAM kind: tile size, persistence mode, non-temporal streams
   int       n_rowblocks;
   double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue
