@@ -190,6 +190,8 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
             **dict(zip(("traffic", "traffic_source"), pmc_lookup("void k_spmv_stream<3,", "r02_pmc_traffic_c2.json") if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
             "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
             "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+            "note": "algorithmic bytes are SURVEY 8d's CSR figure (12 B per non-zero: fp64 value + int32 column); the kernel streams a device-private copy of the columns as 16-bit offsets "
+                    "per row block (banded matrix), so its HBM traffic (PMC) is BELOW the algorithmic bytes: 2 B per non-zero less",
         },
     }
     A.timing_enable(0)
