@@ -58,6 +58,8 @@ def parse():
                     help="feti: the dense local dual operators per block as their lower block-triangle (sym: SYMV, 4 n^2 bytes per apply) or in full (full: GEMV, 8 n^2), or ONE full matrix per class "
                          "of congruent blocks applied to 8 blocks' vectors per pass (class: 8 n_c^2 for the whole class; class_sym: its lower block-triangle in 16x16 tiles, 4 n_c^2, both products of a tile on the "
                          "fp64 matrix instruction); auto = class_sym when that moves fewer bytes, else sym")
+    ap.add_argument("--no-explicit-symmetry", action="store_true", help="feti: assemble every row of the class-shared explicit operator by its own K^+ solve instead of one solve per orbit of rows under "
+                    "the cube's 48 signed coordinate permutations (checked against K; pmh_fexplicit_set_class_symmetry)")
     ap.add_argument("--no-stripe", action="store_true", help="feti at N > 1: every rank keeps the explicit operators of its OWN blocks instead of an even share of 128-row stripes of all blocks")
     ap.add_argument("--explicit-rtol", type=float, default=1e-12, help="feti: tolerance of the set-up solves of the explicit operators")
     ap.add_argument("--explicit-slots", type=int, default=8, help="feti: a rank with fewer (congruent) blocks than this assembles with a replica solver of this many slots")
@@ -441,6 +443,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             return M
 
         explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
+        if not a.no_explicit_symmetry and not a.regularize:  # used by the class-shared symmetric storage only
+            explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3)
         nshare = world if world > 1 else a.sim_world
         if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
@@ -585,8 +589,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
             roofline["note"] = ("W_c (%.2f GB stored on this rank) is streamed once per group of 8 blocks, %.1f passes per apply: the re-reads are served by the 256 MB Infinity Cache / L2, "
                                 "so `achieved` is an on-chip rate here, not an HBM rate (the HBM bound applies to the 8-blocks-per-GPU case of configs[2])" % (E.dense_bytes / 1e9, b_k / E.dense_bytes))
-        kplus_cfg = {"path": "explicit", "storage": storage_used, "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
-                     "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns" % pc_text
+        kplus_cfg = {"path": "explicit", "storage": storage_used, "setup_symmetries": getattr(q, "explicit_symmetries", 1), "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
+                     "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns%s" % (pc_text, ", one solve per orbit of rows under the %d symmetries of the cube (checked against K, a batch of rows re-solved directly)" % q.explicit_symmetries if getattr(q, "explicit_symmetries", 1) > 1 else "")
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %s%.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
             int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)

@@ -83,7 +83,7 @@ int main(int argc, char **argv)
     if (q < neq) eqv = fmax(eqv, fabs(Bu[q] - c[q]));
     else pen = fmax(pen, Bu[q] - c[q]), lmin = fmin(lmin, lam[q]);
   }
-  printf("n_lambda %d  coarse_dim %d  active contact rows %d  explicit set-up solves %d\n", st.n_lambda, st.coarse_dim, st.n_active, st.explicit_solves);
+  printf("n_lambda %d  coarse_dim %d  active contact rows %d  explicit set-up solves %d (symmetries used: %d)\n", st.n_lambda, st.coarse_dim, st.n_active, st.explicit_solves, st.explicit_symmetries);
   printf("||G lambda - e|| = %.2e   max|B_E u - c_E| / max|u| = %.2e   max(B_I u - c_I) / max|u| = %.2e   min lambda_I = %.2e\n", st.norm_Glambda_minus_e, eqv / umax, pen / umax, lmin);
   fprintf(stderr, "set-up %.2f s (explicit operators %.2f s), solve %.3f s\n", st.setup_seconds, st.explicit_seconds, st.solve_seconds);
   CHECK(pmh_finalize(ctx));

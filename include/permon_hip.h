@@ -332,6 +332,20 @@ int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks]
 int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size);
 int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int size, int *owner_out); /* host: owner rank of every 128-row stripe, block after block */
 int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int size, double *bytes_per_rank); /* host: dense bytes per rank under that rule */
+/* set-up by symmetry (PMH_FX_CLASS_SYM): nsym signed permutations of the class's touched dofs U_c (pmh_fexplicit_class_union: their indices relative to the
+   block start, ascending = the row numbering of W_c) under which K_c, hence K_c^+, is invariant -- posmap[g * n_c + c] = position in U_c of the image of the
+   c-th touched dof, sign[g * n_c + c] = +-1, operation 0 the identity.  W[g p][g c] = sign_g[p] sign_g[c] W[p][c]: ONE K^+ solve per ORBIT of rows (a cube
+   of identical Q1 elasticity elements: the 48 signed coordinate permutations, 48 x fewer set-up solves).  The caller vouches for the invariance; the
+   assembly re-solves a batch of symmetry-filled rows directly and fails if they differ.  Before pmh_fexplicit_assemble. */
+/* host helper: the signed dof permutations of a box of dims[0] x dims[1] x dims[2] nodes (x fastest, ndof dofs per node; ndof = 3: vector components)
+   induced by the signed coordinate permutations that map the box onto itself and leave the block's matrix (CSR rowptr / col / val, n rows; NULL: not
+   checked) invariant -- generators checked on nsample rows, the group is their closure (<= 48 operations, 0 = identity).  perm, sign: [48 * n]. */
+int pmh_box_symmetries(const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int nsample, int *nsym, int *perm, signed char *sign);
+/* the two together for box-shaped blocks: symmetries of the box checked against the CSR of one block of the class (column indices relative to the block),
+   restricted to those that map the class's touched dofs onto themselves, handed to pmh_fexplicit_set_class_symmetry; nsym_used: how many (1 = none) */
+int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int *nsym_used);
+int pmh_fexplicit_class_union(pmh_fexplicit E, int cls, int *n_c, int *urel_out /* [n_c] or NULL */);
+int pmh_fexplicit_set_class_symmetry(pmh_fexplicit E, int cls, int nsym, const int *posmap, const signed char *sign);
 int pmh_fexplicit_class_sym_plan(int n_c, int size, int *megaband_owner /* [ceil(ceil(n_c / 256) / 4)] or NULL */, double *bytes_per_rank /* [size] or NULL */); /* host: PMH_FX_CLASS_SYM's rule */
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
 int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte); /* tuning helper: byte pattern instead of the assembly (not F afterwards) */
@@ -527,11 +541,13 @@ typedef struct {
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
   int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM) */
   int    orthonormalize;            /* QPTOrthonormalizeEq: 1 G <- L^{-1} G formed explicitly, 2 implicitly (G stays sparse, -qp_E_orth_form implicit), 0 none */
+  int    explicit_symmetry;         /* PMH_FX_CLASS_SYM with dims != NULL: set-up by the symmetries of the box (pmh_fexplicit_set_box_symmetry) */
 } pmh_feti_contact_opts;
 typedef struct {
   pmh_smalxe_stats smalxe;
   int    n_lambda, n_eq, coarse_dim, n_active, explicit_solves;
   double setup_seconds, solve_seconds, explicit_seconds, norm_Glambda_minus_e;
+  int    explicit_symmetries;       /* operations used by the set-up by symmetry (0 / 1: none) */
 } pmh_feti_contact_stats;
 int pmh_feti_contact_default_opts(pmh_feti_contact_opts *o);
 int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, int n_lambda, int n_eq, int n_leaves,

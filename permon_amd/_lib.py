@@ -83,12 +83,12 @@ class KspFetiStats(C.Structure):
 
 class FetiContactOpts(C.Structure):
     _fields_ = [("smalxe", SmalxeOpts), ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("mg", C.c_int), ("mg_min_nodes", C.c_int), ("mg_degree", C.c_int), ("mg_precision", C.c_int),
-                ("bsr3", C.c_int), ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("explicit_storage", C.c_int), ("orthonormalize", C.c_int)]
+                ("bsr3", C.c_int), ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("explicit_storage", C.c_int), ("orthonormalize", C.c_int), ("explicit_symmetry", C.c_int)]
 
 
 class FetiContactStats(C.Structure):
     _fields_ = [("smalxe", SmalxeStats), ("n_lambda", C.c_int), ("n_eq", C.c_int), ("coarse_dim", C.c_int), ("n_active", C.c_int), ("explicit_solves", C.c_int),
-                ("setup_seconds", C.c_double), ("solve_seconds", C.c_double), ("explicit_seconds", C.c_double), ("norm_Glambda_minus_e", C.c_double)]
+                ("setup_seconds", C.c_double), ("solve_seconds", C.c_double), ("explicit_seconds", C.c_double), ("norm_Glambda_minus_e", C.c_double), ("explicit_symmetries", C.c_int)]
 
 
 class PcpgStats(C.Structure):
@@ -245,6 +245,10 @@ _PROTOS = {
     "pmh_fexplicit_create_shared": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_create_shared_sym": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_class_sym_plan": [C.c_int, C.c_int, vp, vp],
+    "pmh_box_symmetries": [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp],
+    "pmh_fexplicit_set_box_symmetry": [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp],
+    "pmh_fexplicit_class_union": [vp, C.c_int, vp, vp],
+    "pmh_fexplicit_set_class_symmetry": [vp, C.c_int, C.c_int, vp, vp],
     "pmh_fexplicit_destroy": [vp],
     "pmh_fexplicit_sizes": [vp, c_int_p, vp, C.POINTER(C.c_longlong), c_double_p],
     "pmh_fexplicit_set_stripe": [vp, C.c_int, C.c_int],

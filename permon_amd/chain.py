@@ -105,13 +105,15 @@ class FetiDualQP:
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
-    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None):
+    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None, symmetry=None):
         """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
         right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
         has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit.
         stripe = (rank, size, glob): several GPUs and ALL blocks of the decomposition congruent -- the operator spans every block
         (glob: dict n_x, block_rowstart, leaves_row / _root / _sign of the whole decomposition) and this rank assembles and applies
-        an even share of 128-row stripes of every W_b instead of its own blocks (pmh_fexplicit_set_stripe)."""
+        an even share of 128-row stripes of every W_b instead of its own blocks (pmh_fexplicit_set_stripe).
+        symmetry = dict(dims=(nx, ny, nz), ndof=3) ("class_sym", all blocks one class of box-shaped blocks): the signed coordinate permutations of the
+        box that leave K invariant (feti.box_symmetries, checked against K) serve the set-up: one K^+ solve per orbit of rows (a cube: 48 x fewer)."""
         import scipy.sparse as sp
 
         rs = np.asarray(local["block_rowstart"])
@@ -147,6 +149,11 @@ class FetiDualQP:
         else:
             E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)
             ngl = nb
+        self.explicit_symmetries = 1
+        if symmetry is not None and storage == "class_sym" and one_class:
+            n_i = int(rs[1] - rs[0])
+            Kc = self._Kinv_sp[:n_i, :n_i]  # the class matrix (what the solver inverts)
+            self.explicit_symmetries = E.set_box_symmetry(0, symmetry["dims"], symmetry.get("ndof", 3), Kc)
         if solver_factory is not None and nb < min_slots and one_class:
             solver = solver_factory(int(min_slots))
             E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)

@@ -23,7 +23,7 @@ extern "C" int pmh_feti_contact_default_opts(pmh_feti_contact_opts *o)
   o->kplus_rtol = 1e-9, o->kplus_max_it = 20000;
   o->mg = 1, o->mg_min_nodes = 400, o->mg_degree = 2, o->mg_precision = PMH_MG_FP16;
   o->bsr3 = 1;
-  o->explicit_dual = 1, o->explicit_rtol = 1e-12, o->explicit_storage = PMH_FX_SYM;
+  o->explicit_dual = 1, o->explicit_rtol = 1e-12, o->explicit_storage = PMH_FX_SYM, o->explicit_symmetry = 1;
   o->orthonormalize = 2; // implicit form (the reference's default form): G = R'B' keeps its sparsity
   return PMH_SUCCESS;
 }
@@ -172,6 +172,27 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       if (o->explicit_storage == PMH_FX_CLASS) GO(pmh_fexplicit_create_shared(B, Kb, cls.data(), &E)); // congruent blocks share one matrix per class
       else if (o->explicit_storage == PMH_FX_CLASS_SYM) GO(pmh_fexplicit_create_shared_sym(B, Kb, cls.data(), &E));
       else GO(pmh_fexplicit_create(B, Kb, o->explicit_storage, &E));
+      if (o->explicit_storage == PMH_FX_CLASS_SYM && dims && o->explicit_symmetry) {
+        // box-shaped blocks: one K^+ solve per orbit of rows under the symmetries of the box that leave the class matrix invariant
+        int ncls = 0;
+        for (int b = 0; b < nsub; b++) ncls = std::max(ncls, cls[b] + 1);
+        for (int c = 0; c < ncls; c++) {
+          int b0 = 0;
+          while (b0 < nsub && cls[b0] != c) b0++;
+          const int r0 = block_rowstart[b0], r1 = block_rowstart[b0 + 1];
+          std::vector<int> rp((size_t)(r1 - r0) + 1), cj;
+          std::vector<double> vj;
+          rp[0] = 0;
+          for (int i = r0; i < r1; i++) {
+            for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+              if (col[k] >= r0 && col[k] < r1) cj.push_back(col[k] - r0), vj.push_back(val[k]);
+            rp[i - r0 + 1] = (int)cj.size();
+          }
+          int used = 1;
+          GO(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rp.data(), cj.data(), vj.data(), &used));
+          st->explicit_symmetries = std::max(st->explicit_symmetries, used);
+        }
+      }
       GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));
       GO(pmh_matinv_attach_explicit(Kp, E));
       long long ns;

@@ -593,6 +593,55 @@ extern "C" int pmh_fexplicit_stripe_owner(int nblocks, const int *n_gamma, int s
   return PMH_SUCCESS;
 }
 
+// class-shared storages: the touched dofs of a class (the numbering of W_c's rows) and the set-up by symmetry (fshared.hip)
+extern "C" int pmh_fexplicit_class_union(pmh_fexplicit E, int cls, int *n_c, int *urel_out)
+{
+  PMH_ARG(E);
+  if (!E->sh) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_class_union: needs a class-shared storage");
+  return fxs_class_union(E->sh, cls, n_c, urel_out);
+}
+
+extern "C" int pmh_fexplicit_set_class_symmetry(pmh_fexplicit E, int cls, int nsym, const int *posmap, const signed char *sign)
+{
+  PMH_ARG(E);
+  if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_class_symmetry: call before the assembly");
+  if (!E->sh) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_class_symmetry: needs the PMH_FX_CLASS_SYM storage");
+  return fxs_set_symmetry(E->sh, cls, nsym, posmap, sign);
+}
+
+// box-shaped blocks: the symmetries of the box that leave the class matrix invariant (pmh_box_symmetries: generators checked against the CSR of one
+// block of the class, column indices relative to the block) and map the class's touched dofs onto themselves -> pmh_fexplicit_set_class_symmetry
+extern "C" int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int *nsym_used)
+{
+  PMH_ARG(E && dims && ndof >= 1);
+  if (nsym_used) *nsym_used = 1;
+  if (!E->sh || E->storage != PMH_FX_CLASS_SYM) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_box_symmetry: needs the PMH_FX_CLASS_SYM storage");
+  int nc = 0;
+  PMH_CHK(fxs_class_union(E->sh, cls, &nc, nullptr));
+  if (nc == 0) return PMH_SUCCESS;
+  std::vector<int> urel((size_t)nc);
+  PMH_CHK(fxs_class_union(E->sh, cls, &nc, urel.data()));
+  const long long n = (long long)dims[0] * dims[1] * dims[2] * ndof;
+  if (urel.back() >= n) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_set_box_symmetry: the blocks of class %d have more than %d x %d x %d x %d dofs", cls, dims[0], dims[1], dims[2], ndof);
+  std::vector<int>         perm((size_t)48 * n), pos((size_t)n, -1), pm;
+  std::vector<signed char> sign((size_t)48 * n), sg;
+  int                      nsym = 0;
+  PMH_CHK(pmh_box_symmetries(dims, ndof, rowptr, col, val, 4000, &nsym, perm.data(), sign.data()));
+  for (int i = 0; i < nc; i++) pos[urel[i]] = i;
+  int used = 0;
+  for (int g = 0; g < nsym; g++) { // keep the operations under which the touched set is closed
+    bool closed = true;
+    for (int i = 0; i < nc && closed; i++) closed = pos[perm[(size_t)g * n + urel[i]]] >= 0;
+    if (!closed) continue;
+    for (int i = 0; i < nc; i++) pm.push_back(pos[perm[(size_t)g * n + urel[i]]]), sg.push_back(sign[(size_t)g * n + urel[i]]);
+    used++;
+  }
+  if (nsym_used) *nsym_used = used;
+  if (used <= 1) return PMH_SUCCESS;
+  if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_box_symmetry: call before the assembly");
+  return fxs_set_symmetry(E->sh, cls, used, pm.data(), sg.data());
+}
+
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
 {
   PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);

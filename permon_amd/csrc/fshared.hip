@@ -13,6 +13,7 @@
 // Set-up: one K^+ solve per dof of U_c (what the per-block storage already did for congruent blocks), each giving one full row of W_c.
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <cmath>
 
 #include "feti_internal.h"
@@ -40,6 +41,12 @@ struct fxs_class {
   int             *d_nseg = nullptr;      // items (= segments of the direct sums) per (group, mega band) (0: not owned)
   long long       *d_ptoff = nullptr;
   int             *d_ownfirst = nullptr, nown = 0;
+  // set-up by symmetry (fxs_set_symmetry): nsym signed permutations of U_c under which K_c^+ is invariant, op 0 = identity
+  int                      nsym = 0;
+  std::vector<int>         h_posmap; // [nsym][nc]: position of the image of the c-th touched dof
+  std::vector<signed char> h_sign;   // [nsym][nc]: +-1
+  int                     *d_posmap = nullptr;
+  signed char             *d_sign = nullptr;
 };
 
 struct fx_shared {
@@ -350,6 +357,37 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_extract_sym(int p, const int 
   }
 }
 
+// the same for a row obtained by symmetry: the solve gave row p (u), the operation g maps dof c to position posmap[c] with sign[c]:
+// W[g p][g c] = sign[p] sign[c] W[p][c].  r = posmap[p] is the row written, sp = sign[p]
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_extract_symg(int r, int nc, double sp, const int *__restrict__ urel, const double *__restrict__ u, const int *__restrict__ posmap,
+                                                               const signed char *__restrict__ sign, double *__restrict__ wsb)
+{
+  const int Il = (r % FXM_RS) / 16, rr = r & 15, q = rr >> 2;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) {
+    const int cc = posmap[c];
+    if (cc > r) continue;
+    const double v = sp * (double)sign[c] * u[urel[c]];
+    const int    l = 16 * (rr & 3) + (cc & 15);
+    wsb[((long long)(cc >> 4) * FXM_RT + Il) * 256 + (q >> 1) * 128 + 2 * l + (q & 1)] = cc == r ? 0.5 * v : v;
+  }
+}
+
+// set-up self-check: max |stored row r - the directly solved row| and max |row| (entries c <= r), one value pair per workgroup
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *__restrict__ urel, const double *__restrict__ u, const double *__restrict__ wsb, double *__restrict__ out)
+{
+  __shared__ double red[PMH_BLOCK / 64];
+  const int Il = (r % FXM_RS) / 16, rr = r & 15, q = rr >> 2;
+  double    d = 0.0, m = 0.0;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c <= r; c += gridDim.x * PMH_BLOCK) {
+    const int    l = 16 * (rr & 3) + (c & 15);
+    const double w = wsb[((long long)(c >> 4) * FXM_RT + Il) * 256 + (q >> 1) * 128 + 2 * l + (q & 1)] * (c == r ? 2.0 : 1.0), v = u[urel[c]];
+    d = fmax(d, fabs(w - v)), m = fmax(m, fabs(v));
+  }
+  d = -pmh_block_reduce<PMH_RED_MIN>(-d, red);
+  m = -pmh_block_reduce<PMH_RED_MIN>(-m, red);
+  if (threadIdx.x == 0) out[2 * blockIdx.x] = d, out[2 * blockIdx.x + 1] = m;
+}
+
 static int fxs_build_launch(fx_shared *S)
 {
   if (S->sym) {
@@ -585,6 +623,7 @@ void fxs_destroy(fx_shared *S)
     if (C.d_nseg) pmh_free(ctx, C.d_nseg);
     if (C.d_ptoff) pmh_free(ctx, C.d_ptoff);
     if (C.d_ownfirst) pmh_free(ctx, C.d_ownfirst);
+    if (C.d_posmap) pmh_free(ctx, C.d_posmap), pmh_free(ctx, C.d_sign);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
@@ -643,12 +682,57 @@ int fxs_set_stripe(fx_shared *S, int rank, int size)
 long long fxs_dense_bytes(fx_shared *S) { return S->sym ? (long long)S->owned_bytes : (long long)sizeof(double) * S->wtot; }
 double    fxs_apply_bytes(fx_shared *S) { return S->bytes; }
 
+// the touched dofs of class c, ascending, relative to the block start (the numbering of W_c's rows)
+int fxs_class_union(fx_shared *S, int c, int *n_c, int *urel_out)
+{
+  PMH_ARG(S && c >= 0 && c < S->ncls);
+  if (n_c) *n_c = S->C[c].nc;
+  if (urel_out && S->C[c].nc) memcpy(urel_out, S->C[c].urel.data(), sizeof(int) * (size_t)S->C[c].nc);
+  return PMH_SUCCESS;
+}
+
+// Set-up by symmetry: nsym signed permutations of U_c (posmap[g * n_c + c] = position of the image of the c-th touched dof, sign = +-1; operation 0 the
+// identity) under which K_c, hence K_c^+, is invariant: W[g p][g c] = sign_g[p] sign_g[c] W[p][c], so ONE K^+ solve serves the whole orbit of a row
+// (a cube of Q1 elasticity elements: the 48 signed coordinate permutations -> 48 x fewer solves).  The caller vouches for the invariance (permon_amd
+// checks the generators against K); the assembly re-solves a handful of symmetry-filled rows directly and fails if they differ.
+int fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, const signed char *sign)
+{
+  PMH_ARG(S && c >= 0 && c < S->ncls && nsym >= 1 && posmap && sign);
+  if (!S->sym) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_class_symmetry: needs the PMH_FX_CLASS_SYM storage");
+  fxs_class &C  = S->C[c];
+  const int  nc = C.nc;
+  std::vector<char> seen((size_t)std::max(1, nc));
+  for (int g = 0; g < nsym; g++) {
+    std::fill(seen.begin(), seen.end(), 0);
+    for (int i = 0; i < nc; i++) {
+      const int t = posmap[(size_t)g * nc + i];
+      if (t < 0 || t >= nc || seen[t] || (sign[(size_t)g * nc + i] != 1 && sign[(size_t)g * nc + i] != -1))
+        return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_set_class_symmetry: operation %d is not a signed permutation of the %d touched dofs", g, nc);
+      if (g == 0 && (t != i || sign[i] != 1)) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_set_class_symmetry: operation 0 must be the identity");
+      seen[t] = 1;
+    }
+  }
+  C.nsym = nsym;
+  C.h_posmap.assign(posmap, posmap + (size_t)nsym * nc);
+  C.h_sign.assign(sign, sign + (size_t)nsym * nc);
+  if (C.d_posmap) pmh_free(S->ctx, C.d_posmap), pmh_free(S->ctx, C.d_sign);
+  PMH_CHK(pmh_malloc(S->ctx, sizeof(int) * (size_t)std::max(1, nsym * nc), (void **)&C.d_posmap));
+  PMH_CHK(pmh_malloc(S->ctx, (size_t)std::max(1, nsym * nc), (void **)&C.d_sign));
+  if (nc) {
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_posmap, C.h_posmap.data(), sizeof(int) * (size_t)nsym * nc));
+    PMH_CHK(pmh_memcpy_h2d(S->ctx, C.d_sign, C.h_sign.data(), (size_t)nsym * nc));
+  }
+  return PMH_SUCCESS;
+}
+
 int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves)
 {
   PMH_ARG(S && solver && nslots >= 1 && solver->nblocks == nslots && slot_class);
   pmh_ctx                       ctx = S->ctx;
   const std::vector<int>       &srs = solver->K->rowstart;
   std::vector<std::vector<int>> cslots(S->ncls), todo(S->ncls);
+  std::vector<std::vector<int>> rep_of(S->ncls), op_of(S->ncls), check(S->ncls);
+  std::vector<std::map<int, std::vector<int>>> members(S->ncls); // representative row -> the owned rows of its orbit
   for (int s = 0; s < nslots; s++)
     if (slot_class[s] >= 0 && slot_class[s] < S->ncls) cslots[slot_class[s]].push_back(s);
   int nbatch = 0;
@@ -658,7 +742,28 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
     if (cslots[c].empty()) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: no solver slot for block class %d", c);
     for (int s : cslots[c])
       if (srs[s + 1] - srs[s] != C.nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, C.nloc);
-    if (S->sym) {
+    if (S->sym && C.nsym > 1) {
+      // orbits of the rows under the class's symmetries: rep_of / op_of, one solve per orbit that has a row in this rank's super bands
+      rep_of[c].assign((size_t)C.nc, -1), op_of[c].assign((size_t)C.nc, 0);
+      for (int p = 0; p < C.nc; p++) {
+        if (rep_of[c][p] >= 0) continue;
+        for (int g = 0; g < C.nsym; g++) {
+          const int r = C.h_posmap[(size_t)g * C.nc + p];
+          if (rep_of[c][r] < 0) rep_of[c][r] = p, op_of[c][r] = g;
+        }
+      }
+      std::vector<char> need((size_t)C.nc, 0);
+      for (int r = 0; r < C.nc; r++)
+        if (C.own[r / FXM_RS]) need[rep_of[c][r]] = 1, members[c][rep_of[c][r]].push_back(r);
+      for (int p = 0; p < C.nc; p++)
+        if (need[p]) todo[c].push_back(p);
+      // self-check: up to one batch of symmetry-filled owned rows, spread over the range, solved directly at the end
+      std::vector<int> filled;
+      for (int r = 0; r < C.nc; r++)
+        if (C.own[r / FXM_RS] && op_of[c][r] != 0) filled.push_back(r);
+      const int nchk = (int)std::min(filled.size(), cslots[c].size());
+      for (int i = 0; i < nchk; i++) check[c].push_back(filled[(size_t)((long long)filled.size() * (2 * i + 1) / (2 * nchk))]);
+    } else if (S->sym) {
       for (int p = 0; p < C.nc; p++)
         if (C.own[p / FXM_RS]) todo[c].push_back(p); // the rows of this rank's super bands
     } else
@@ -706,7 +811,15 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (prow[s] < 0) continue;
       (*n_solves)++;
       const fxs_class &C = S->C[slot_class[s]];
-      if (S->sym) {
+      if (S->sym && C.nsym > 1) {
+        const int p = prow[s];
+        for (int r : members[slot_class[s]][p]) {
+          const int g = op_of[slot_class[s]][r], sb = r / FXM_RS;
+          hipLaunchKernelGGL(k_fxs_extract_symg, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, r, C.nc, (double)C.h_sign[(size_t)g * C.nc + p],
+                             (const int *)C.d_urel, (const double *)(sol + srs[s]), (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc),
+                             S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
+        }
+      } else if (S->sym) {
         const int sb = prow[s] / FXM_RS;
         hipLaunchKernelGGL(k_fxs_extract_sym, dim3(std::max(1, std::min(64, (prow[s] + PMH_BLOCK) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, prow[s], (const int *)C.d_urel, (const double *)(sol + srs[s]),
                            S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
@@ -715,6 +828,40 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
                          S->Wbase + C.woff + (long long)prow[s] * C.ld); // row p of W_c = column p (K^+ symmetric)
     }
     if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);
+  }
+  // self-check of the set-up by symmetry: a few symmetry-filled rows against their direct solves
+  bool any_check = false;
+  for (int c = 0; c < S->ncls; c++) any_check = any_check || !check[c].empty();
+  if (!rc && any_check) rc = pmh_sync(ctx); // the pinned index buffer is reused below
+  if (!rc && any_check) {
+    int *hh = h_idx;
+    for (int s = 0; s < nslots; s++) hh[s] = -1, prow[s] = -1;
+    for (int c = 0; c < S->ncls; c++)
+      for (size_t t = 0; t < check[c].size(); t++) {
+        const int s = cslots[c][t];
+        prow[s] = check[c][t], hh[s] = srs[s] + S->C[c].urel[prow[s]];
+      }
+    double *d_out = nullptr, h_out[2 * 64];
+    rc = pmh_malloc(ctx, sizeof(double) * 2 * 64, (void **)&d_out);
+    if (!rc && hipMemcpyAsync(d_idx, hh, sizeof(int) * nslots, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: index upload failed");
+    if (!rc) {
+      hipLaunchKernelGGL(k_fxs_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
+      rc = pmh_matinv_mult(solver, rhs, sol);
+    }
+    for (int s = 0; s < nslots && !rc; s++) {
+      if (prow[s] < 0) continue;
+      (*n_solves)++;
+      const fxs_class &C  = S->C[slot_class[s]];
+      const int        r = prow[s], sb = r / FXM_RS, nb = std::max(1, std::min(64, (r + PMH_BLOCK) / PMH_BLOCK));
+      hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
+                         (const double *)(S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2)), d_out);
+      if ((rc = pmh_memcpy_d2h(ctx, h_out, d_out, sizeof(double) * 2 * nb))) break;
+      double d = 0.0, m = 0.0;
+      for (int i = 0; i < nb; i++) d = std::max(d, h_out[2 * i]), m = std::max(m, h_out[2 * i + 1]);
+      if (!(d <= 1e-8 * m))
+        rc = pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_assemble: row %d of class %d filled by symmetry differs from its direct solve by %.2e (relative to the row's largest entry): the operations handed to pmh_fexplicit_set_class_symmetry are not symmetries of K^+", r, slot_class[s], d / m);
+    }
+    if (d_out) pmh_free(ctx, d_out);
   }
   if (!rc) rc = pmh_sync(ctx);
   pmh_matinv_set_tolerances(solver, old_rtol, old_atol, old_maxit);

@@ -524,3 +524,72 @@ def box_mg_hierarchy(blocks, dims, ndof, min_nodes=400, max_levels=12):
         pinvs.append(pb[3] if len(pb[0]) == nlev else np.linalg.pinv(pb[0][nlev - 1].toarray(), rcond=1e-10, hermitian=True))
     out["coarse_pinv"] = np.concatenate([p.ravel() for p in pinvs]) if pinvs else np.zeros(0)
     return out
+
+
+# ---- symmetries of a box block (set-up of the class-shared explicit operators by symmetry) -----------------------
+def box_symmetries(dims, ndof, K=None, nsample=4000, tol=1e-11, seed=0):
+    """Signed dof permutations of a block of nx x ny x nz nodes (x fastest) x ndof dofs per node induced by the signed coordinate
+    permutations that map the box onto itself (a cube: the 48 elements of the hyperoctahedral group; ndof = 3: the components
+    transform as a vector, ndof = 1: as a scalar).  K (the block's matrix): every GENERATOR (reflections, swaps of equal axes) is
+    checked against K on `nsample` random rows (K[g i, g j] s_i s_j = K[i, j]) and dropped if it fails; the group is the closure of
+    the surviving generators, so every operation returned is a composition of checked ones.  Returns (perm[nsym, n], sign[nsym, n])
+    with operation 0 the identity: dof i goes to perm[g, i] with sign[g, i]."""
+    import itertools
+
+    nx, ny, nz = (int(d) for d in dims)
+    n = nx * ny * nz * ndof
+    nodes = np.arange(nx * ny * nz)
+    ijk = np.stack([nodes % nx, (nodes // nx) % ny, nodes // (nx * ny)], axis=1)
+    dim = (nx, ny, nz)
+
+    def op(axes, flips):  # new coordinate a = (+-) old coordinate axes[a]
+        if any(dim[axes[a]] != dim[a] for a in range(3)):
+            return None
+        new = np.empty_like(ijk)
+        for a in range(3):
+            src = ijk[:, axes[a]]
+            new[:, a] = (dim[a] - 1 - src) if flips[a] < 0 else src
+        node2 = new[:, 0] + nx * (new[:, 1] + ny * new[:, 2])
+        perm = np.empty(n, dtype=np.int64)
+        sign = np.ones(n, dtype=np.int8)
+        if ndof == 3:  # component axes[a] of the old field becomes component a of the new one, with the flip's sign
+            for a in range(3):
+                perm[nodes * 3 + axes[a]] = node2 * 3 + a
+                sign[nodes * 3 + axes[a]] = flips[a]
+        else:
+            for d in range(ndof):
+                perm[nodes * ndof + d] = node2 * ndof + d
+        return perm, sign
+
+    gens = [op((0, 1, 2), f) for f in ((-1, 1, 1), (1, -1, 1), (1, 1, -1))] + [op(a, (1, 1, 1)) for a in ((1, 0, 2), (0, 2, 1), (2, 1, 0))]
+    gens = [g for g in gens if g is not None]
+    if K is not None:
+        K = K.tocsr()
+        rng = np.random.default_rng(seed)
+        rows = rng.choice(n, size=min(nsample, n), replace=False)
+        sub = K[rows].tocoo()
+        ri, cj, v = rows[sub.row], sub.col, sub.data
+        scale = np.abs(v).max() if v.size else 1.0
+        ok = []
+        for perm, sign in gens:
+            w = np.asarray(K[perm[ri], perm[cj]]).ravel() * sign[ri] * sign[cj]
+            if np.abs(w - v).max() <= tol * scale:
+                ok.append((perm, sign))
+        gens = ok
+    ident = (np.arange(n, dtype=np.int64), np.ones(n, dtype=np.int8))
+    import hashlib
+
+    group, frontier = [ident], [ident]
+    key = lambda g: hashlib.blake2b(g[0].tobytes() + g[1].tobytes(), digest_size=16).digest()  # noqa: E731
+    seen = {key(ident)}
+    while frontier:
+        nxt = []
+        for (p1, s1), (p2, s2) in itertools.product(frontier, gens):
+            pc, sc = p2[p1], (s1 * s2[p1]).astype(np.int8)  # apply (p1, s1) first, then the generator
+            k = key((pc, sc))
+            if k not in seen:
+                seen.add(k)
+                group.append((pc, sc))
+                nxt.append((pc, sc))
+        frontier = nxt
+    return np.stack([g[0] for g in group]).astype(np.int32), np.stack([g[1] for g in group]).astype(np.int8)

@@ -268,6 +268,42 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_sizes(self.h, None, None, None, C.byref(gb)))
         self.gemv_bytes = gb.value  # this rank's share
 
+    def class_union(self, cls):
+        """The touched dofs of class `cls` relative to the block start, ascending (the row numbering of W_c); class-shared storages."""
+        n = C.c_int()
+        check(self.ctx.L.pmh_fexplicit_class_union(self.h, int(cls), C.byref(n), None))
+        u = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(self.ctx.L.pmh_fexplicit_class_union(self.h, int(cls), C.byref(n), u.ctypes.data_as(C.c_void_p)))
+        return u[:n.value]
+
+    def set_class_symmetry(self, cls, perm, sign):
+        """Set-up by symmetry ("class_sym"): perm[g, i], sign[g, i] = signed permutations of the block's dofs under which K (hence K^+) is
+        invariant, operation 0 the identity (feti.box_symmetries); operations that do not map the touched dofs onto themselves are dropped.
+        Returns the number of operations used: one K^+ solve per orbit of rows."""
+        u = self.class_union(cls)
+        nloc = perm.shape[1]
+        pos = -np.ones(nloc, dtype=np.int64)
+        pos[u] = np.arange(u.size)
+        pm = pos[perm[:, u]]  # [nsym, n_c]
+        keep = np.all(pm >= 0, axis=1)
+        keep[0] = True
+        pm = np.ascontiguousarray(pm[keep], dtype=np.int32)
+        sg = np.ascontiguousarray(sign[keep][:, u], dtype=np.int8)
+        check(self.ctx.L.pmh_fexplicit_set_class_symmetry(self.h, int(cls), int(pm.shape[0]), pm.ctypes.data_as(C.c_void_p), sg.ctypes.data_as(C.c_void_p)))
+        return int(pm.shape[0])
+
+    def set_box_symmetry(self, cls, dims, ndof, Kblock):
+        """Box-shaped blocks ("class_sym"): the symmetries of the box that leave Kblock (one block of the class, scipy CSR) invariant and map the
+        touched dofs onto themselves serve the set-up (pmh_fexplicit_set_box_symmetry).  Returns the number of operations used."""
+        Kb = Kblock.tocsr()
+        Kb.sort_indices()
+        d = np.ascontiguousarray(dims, dtype=np.int32)
+        ip, ci, va = (np.ascontiguousarray(Kb.indptr, dtype=np.int32), np.ascontiguousarray(Kb.indices, dtype=np.int32), np.ascontiguousarray(Kb.data, dtype=np.float64))
+        n = C.c_int()
+        check(self.ctx.L.pmh_fexplicit_set_box_symmetry(self.h, int(cls), d.ctypes.data_as(C.c_void_p), int(ndof), ip.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                                         va.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return n.value
+
     def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
         """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
         sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None

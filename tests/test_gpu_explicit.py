@@ -114,6 +114,45 @@ def test_explicit_vs_iterative_F(ctx, storage, monkeypatch):
         assert np.max(np.abs(yh[gs[b]:gs[b] + n] - ref)) <= 1e-13 * np.max(np.abs(W)) * np.linalg.norm(xh) * np.sqrt(n)
 
 
+@pytest.mark.parametrize("sub,nel,nsym", [((2, 2, 2), 2, 48), ((2, 2, 2), 4, 48), ((2, 2, 1), 5, 8)])
+def test_explicit_setup_by_symmetry(ctx, sub, nel, nsym):
+    """PMH_FX_CLASS_SYM assembled with the cube's symmetries (feti.box_symmetries, checked against K): one K^+ solve per orbit of rows of W_c
+    (up to 48 x fewer) + one batch of direct solves as the library's self-check; every W_b still equals pinv(K_b) on Gamma_b, F = B pinv(K) B'.
+    A permutation that is NOT a symmetry makes the assembly fail loudly."""
+    f = pa.CubeFeti(sub, nel, contact=True)
+    G, e = f.coarse()
+    nn = nel + 1
+    loc = f.subset(range(f.nsub))
+    q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym"))
+    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    # 2 x 2 x 2 cubes: the union of the touched faces is the whole boundary, closed under all 48 operations; 2 x 2 x 1: the operations that keep
+    # the touched set (no top face) are kept, the others dropped
+    assert q.explicit_symmetries == nsym
+    n0, n1 = q0.E.assemble_stats()[0], q.E.assemble_stats()[0]
+    assert n1 < n0 / (nsym / 8.0) + f.nsub  # orbits of <= nsym rows (rows on symmetry planes have shorter ones) + the self-check batch
+    Fref, Kp = _dense_F(f)
+    for b in range(f.nsub):
+        W, g = q.E.block(b)
+        gl = g - b * f.n_i
+        ref = Kp[np.ix_(gl, gl)]
+        assert np.max(np.abs(W - ref)) <= 1e-10 * np.max(np.abs(ref))
+    lam = np.random.default_rng(6).standard_normal(f.n_lambda)
+    y = ctx.vec(f.n_lambda)
+    q.F.mult(ctx.vec_from(lam), y)
+    assert np.linalg.norm(y.to_numpy() - Fref @ lam) <= 1e-10 * np.linalg.norm(Fref @ lam)
+    # not a symmetry: the identity + a swap of two touched dofs
+    q2 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    cls = np.zeros(f.nsub, dtype=np.int32)
+    E = pa.MatExplicitDual(q2.B, q2.K, storage="class_sym", block_class=cls)
+    u = E.class_union(0)
+    perm = np.tile(np.arange(f.n_i, dtype=np.int32), (2, 1))
+    perm[1, u[0]], perm[1, u[-1]] = u[-1], u[0]
+    E.set_class_symmetry(0, perm, np.ones((2, f.n_i), dtype=np.int8))
+    with pytest.raises(Exception, match="symmetr"):
+        E.assemble(q2.Kplus, slot_class=cls, block_class=cls, rtol=1e-13)
+    E.destroy()
+
+
 def test_explicit_contact_solve_same_counts(ctx):
     """Contact TFETI (SMALXE + MPGP) through the explicit F: same outer / inner counts and solution as the iterative K^+."""
     f = pa.CubeFeti((2, 2, 2), 5, contact=True)
@@ -172,7 +211,8 @@ def test_striped_shares_sum_to_F(ctx, storage):
         # rank r owns blocks [r] only (a 1-block K^+), but applies its stripes of ALL four W_b
         lr = f.subset([r])
         q = FetiDualQP(ctx, lr, G, e, f.c, f.lb, kplus_rtol=1e-13)
-        E = q.assemble_explicit(lr, rtol=1e-13, stripe=(r, 3, glob), storage=storage)
+        sym = dict(dims=(f.nel + 1,) * 3, ndof=3) if storage == "class_sym" else None  # the 4-mega-band case also takes its rows from orbit representatives
+        E = q.assemble_explicit(lr, rtol=1e-13, stripe=(r, 3, glob), storage=storage, symmetry=sym)
         y, y2 = ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
         q.F.mult(lv, y)
         q.F.mult(lv, y2)
@@ -181,7 +221,7 @@ def test_striped_shares_sum_to_F(ctx, storage):
         solves.append(E.assemble_stats()[0])
     ref = y0.to_numpy()
     assert np.linalg.norm(tot - ref) <= 1e-10 * np.linalg.norm(ref)
-    assert max(solves) < q0.E.assemble_stats()[0] and sum(solves) >= q0.E.assemble_stats()[0]
+    assert max(solves) < q0.E.assemble_stats()[0] and (sum(solves) >= q0.E.assemble_stats()[0] or storage == "class_sym")  # by symmetry: every rank solves (nearly) all orbit representatives, far fewer than rows
 
 
 def test_contact_solve_one_call(ctx):

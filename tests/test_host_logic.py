@@ -243,3 +243,43 @@ def test_class_sym_plan_balances_the_tile_bytes():
         assert b.max() / b.mean() < 1.03
         nsb = -(-n_c // 256)
         assert abs(b.sum() - 8.0 * 256 * 256 * nsb * (nsb + 1) / 2) < 1.0  # the lower block-triangle in 256-row super bands
+
+
+def test_box_symmetries_c_vs_numpy():
+    """pmh_box_symmetries (host C++): the group of signed dof permutations of a box block that leave K invariant -- the same operations as the numpy
+    restatement feti.box_symmetries (48 for a cube of Q1 elasticity elements, 8 / 16 for boxes with unequal sides), identity first, and K^+ is
+    invariant under every one of them (what the set-up by symmetry relies on)."""
+    import ctypes as C
+
+    import permon_amd as pa
+    from permon_amd.feti import CubeFeti, box_symmetries
+
+    L = pa.load()
+    f = CubeFeti((2, 1, 1), 3, contact=True)
+    K = f.Ki.tocsr()
+    K.sort_indices()
+    n = K.shape[0]
+
+    def c_group(dims, ndof, K=None, n=None):
+        d = np.array(dims, dtype=np.int32)
+        perm, sign, ns = np.zeros(48 * n, dtype=np.int32), np.zeros(48 * n, dtype=np.int8), C.c_int()
+        args = [None, None, None] if K is None else [np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data)]
+        pa._lib.check(L.pmh_box_symmetries(d.ctypes.data_as(C.c_void_p), ndof, *[a.ctypes.data_as(C.c_void_p) if a is not None else None for a in args], 4000, C.byref(ns),
+                                           perm.ctypes.data_as(C.c_void_p), sign.ctypes.data_as(C.c_void_p)))
+        return perm.reshape(48, n)[:ns.value], sign.reshape(48, n)[:ns.value]
+
+    pc, sc = c_group((4, 4, 4), 3, K, n)
+    pn, sn = box_symmetries((4, 4, 4), 3, K=K)
+    assert pc.shape[0] == 48 and np.array_equal(pc[0], np.arange(n)) and sc[0].min() == 1
+    assert {(pc[g].tobytes(), sc[g].tobytes()) for g in range(48)} == {(pn[g].astype(np.int32).tobytes(), sn[g].tobytes()) for g in range(48)}
+    Kp = np.linalg.pinv(K.toarray(), rcond=1e-10, hermitian=True)
+    for g in range(48):
+        W = np.empty_like(Kp)
+        s = sc[g].astype(float)
+        W[np.ix_(pc[g], pc[g])] = Kp * s[:, None] * s[None, :]
+        assert np.abs(W - Kp).max() <= 1e-12 * np.abs(Kp).max()
+    assert c_group((3, 4, 5), 3, n=180)[0].shape[0] == 8 and c_group((4, 4, 5), 1, n=80)[0].shape[0] == 16
+    # a matrix that is NOT invariant (one stiffened entry): the generators that move it are dropped
+    K2 = K.copy().tolil()
+    K2[0, 0] *= 2.0
+    assert c_group((4, 4, 4), 3, K2.tocsr(), n)[0].shape[0] < 48
