@@ -281,7 +281,7 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     return u, lam[:st.n_lambda].copy(), st
 
 
-def FETIContactSolve(ctx, f, explicit=True, mg_precision="fp16", rtol=1e-5, kplus_rtol=1e-9, explicit_rtol=1e-12, mg_min_nodes=400, dims=None):
+def FETIContactSolve(ctx, f, explicit=True, mg_precision="fp16", rtol=1e-5, kplus_rtol=1e-9, explicit_rtol=1e-12, mg_min_nodes=400, dims=None, explicit_storage=None, explicit_symmetry=True):
     """pmh_feti_contact_solve (contact.hip): the whole contact TFETI solve in ONE library call -- QPTFromOptions / QPTAllInOne
     (qptransform.c:2152-2237) + QPSSolve + the post-solve chain; f: a CubeFeti-like problem (K, f, leaves, c, R, n_eq).
     Returns (u, lambda, stats: _lib.FetiContactStats)."""
@@ -293,6 +293,9 @@ def FETIContactSolve(ctx, f, explicit=True, mg_precision="fp16", rtol=1e-5, kplu
     check(ctx.L.pmh_feti_contact_default_opts(C.byref(o)))
     o.smalxe.rtol, o.kplus_rtol, o.explicit_dual, o.explicit_rtol = rtol, kplus_rtol, int(bool(explicit)), explicit_rtol
     o.mg_precision, o.mg_min_nodes = {"fp64": 0, "fp32": 1, "fp16": 2}[mg_precision], int(mg_min_nodes)
+    if explicit_storage is not None:
+        o.explicit_storage = {"full": 0, "sym": 1, "class": 2, "class_sym": 3}[explicit_storage]
+    o.explicit_symmetry = int(bool(explicit_symmetry))
     if dims is None and hasattr(f, "nel"):
         dims = [(f.nel + 1,) * 3] * f.nsub
     a32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
