@@ -12,6 +12,7 @@
 #include "pmh_internal.h"
 
 #include <algorithm>
+#include <thread>
 
 #define BSR_TB_MAX 2048 // largest tile (blocks)
 
@@ -139,27 +140,55 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
   const int        n = A->nrows, nbr = n / 3;
   const int        tb = (tile == 512 || tile == 1024 || tile == 2048) ? tile : bsr_tile(storage), W = bsr_width(storage);
-  std::vector<int> rp((size_t)n + 1), ci((size_t)A->nnz);
-  std::vector<double> va((size_t)A->nnz);
-  PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), A->d_rowptr, sizeof(int) * rp.size()));
-  if (A->nnz) {
-    PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), A->d_col, sizeof(int) * ci.size()));
-    PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), A->d_val, sizeof(double) * va.size()));
+  std::vector<int>    rp_own, ci_own;
+  std::vector<double> va_own;
+  const int          *rp = A->h_rowptr, *ci = A->h_col;
+  const double       *va = A->h_val;
+  if (!(rp && (A->nnz == 0 || (ci && va)))) { // no host copy lent by the caller: download
+    rp_own.resize((size_t)n + 1), ci_own.resize((size_t)A->nnz), va_own.resize((size_t)A->nnz);
+    PMH_CHK(pmh_memcpy_d2h(ctx, rp_own.data(), A->d_rowptr, sizeof(int) * rp_own.size()));
+    if (A->nnz) {
+      PMH_CHK(pmh_memcpy_d2h(ctx, ci_own.data(), A->d_col, sizeof(int) * ci_own.size()));
+      PMH_CHK(pmh_memcpy_d2h(ctx, va_own.data(), A->d_val, sizeof(double) * va_own.size()));
+    }
+    rp = rp_own.data(), ci = ci_own.data(), va = va_own.data();
   }
   // block structure: union of the block columns of the three rows of each block row (sorted)
+  // (host threads over contiguous ranges of block rows: the fine level of configs[2] has 158 M non-zeros and is converted three times per set-up)
   std::vector<int> browptr((size_t)nbr + 1, 0), bcol;
-  bcol.reserve((size_t)A->nnz / 9 + 16);
-  std::vector<int> tmp;
-  for (int br = 0; br < nbr; br++) {
-    tmp.clear();
-    for (int r = 0; r < 3; r++)
-      for (int k = rp[3 * br + r]; k < rp[3 * br + r + 1]; k++) tmp.push_back(ci[k] / 3);
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    if ((int)tmp.size() > tb) return PMH_SUCCESS;
-    bcol.insert(bcol.end(), tmp.begin(), tmp.end());
-    if (bcol.size() > (size_t)0x7fffff00) return PMH_SUCCESS;
-    browptr[br + 1] = (int)bcol.size();
+  const int        nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), nbr / 4096 + 1}));
+  {
+    std::vector<std::vector<int>> tbc(nt);
+    std::vector<char>             toobig(nt, 0);
+    auto work = [&](int t) {
+      std::vector<int> tmp;
+      tbc[t].reserve((size_t)(A->nnz / 9 / nt) + 16);
+      for (int br = (int)((long long)nbr * t / nt); br < (int)((long long)nbr * (t + 1) / nt); br++) {
+        tmp.clear();
+        for (int r = 0; r < 3; r++)
+          for (int k = rp[3 * br + r]; k < rp[3 * br + r + 1]; k++) tmp.push_back(ci[k] / 3);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        if ((int)tmp.size() > tb) {
+          toobig[t] = 1;
+          return;
+        }
+        tbc[t].insert(tbc[t].end(), tmp.begin(), tmp.end());
+        browptr[br + 1] = (int)tmp.size();
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+    size_t tot = 0;
+    for (int t = 0; t < nt; t++) {
+      if (toobig[t]) return PMH_SUCCESS;
+      tot += tbc[t].size();
+    }
+    if (tot > (size_t)0x7fffff00) return PMH_SUCCESS;
+    bcol.reserve(tot + 16);
+    for (int t = 0; t < nt; t++) bcol.insert(bcol.end(), tbc[t].begin(), tbc[t].end());
+    for (int br = 0; br < nbr; br++) browptr[br + 1] += browptr[br];
   }
   const long long nblocks = (long long)bcol.size();
   if (nblocks * 9 > 2 * A->nnz + 64) return PMH_SUCCESS; // blocks mostly empty: the CSR kernel moves fewer bytes
@@ -183,7 +212,10 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   std::vector<double> bv((size_t)npad * 9, 0.0);
   std::vector<int>    bcp((size_t)npad, 0);
   double              amax = 0.0;
-  for (int t = 0; t < ntiles; t++) {
+  std::vector<double> tamax(nt, 0.0);
+  auto fill = [&](int tt) {
+  double amax = 0.0;
+  for (int t = (int)((long long)ntiles * tt / nt); t < (int)((long long)ntiles * (tt + 1) / nt); t++) {
     const int s0 = browptr[tile_br[t]], nbt = browptr[tile_br[t + 1]] - s0, nbp = (nbt + W - 1) / W * W;
     double   *v  = bv.data() + (size_t)tile_off[t] * 9;
     std::copy(bcol.begin() + s0, bcol.begin() + s0 + nbt, bcp.begin() + tile_off[t]);
@@ -199,6 +231,14 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
           amax = std::max(amax, fabs(va[k]));
         }
     }
+  }
+  tamax[tt] = amax;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(fill, t);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nt; t++) amax = std::max(amax, tamax[t]);
   }
   pmh_bsr3 B = new pmh_bsr3_s();
   B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;

@@ -57,6 +57,15 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
   memset(st, 0, sizeof(*st));
   st->n_lambda = nl, st->n_eq = n_eq;
   auto t_start  = std::chrono::steady_clock::now();
+  auto       t_last = t_start;
+  const bool verbose = getenv("PMH_CONTACT_TIMING") != nullptr;
+  auto       stage  = [&](const char *what) { // PMH_CONTACT_TIMING=1: where the set-up time goes (stderr)
+    if (!verbose) return;
+    hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "pmh_feti_contact_solve: %-44s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   auto block_of = [&](int i) { return (int)(std::upper_bound(block_rowstart, block_rowstart + nsub + 1, i) - block_rowstart) - 1; };
 
   // ---- kernel bases: block-wise Gram-Schmidt (QPTDualize orthonormalises R, qptransform.c:1001)
@@ -151,18 +160,23 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     if ((rc = (call))) goto done; \
   } while (0)
   {
+    stage("kernel bases, dense G, e (host)");
     GO(pmh_csr_create(ctx, N, N, rowptr, col, val, &Kc));
+    pmh_csr_set_host_hint(Kc, rowptr, col, val); // the set-up builders (3x3-block copies) read the caller's arrays instead of downloading them again
     GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kc, &Kb));
     GO(pmh_matinv_create(Kb, o->kplus_rtol, 1e-50, o->kplus_max_it, 1, &Kp));
     GO(pmh_matinv_set_nullspace(Kp, kdim, Rn.data())); // P_R K^- P_R
+    stage("K upload, block structure, inner KSP");
     if (o->bsr3 && ndof == 3 && pmh_matinv_enable_bsr3(Kp)) (void)0; // no 3x3 block structure: the CSR kernel stays
     if (o->mg && dims) {
       GO(pmh_mg_create_box(ctx, Kc, nsub, block_rowstart, dims, ndof, rowptr, col, val, kdim, Rn.data(), std::max(1, o->mg_min_nodes), std::max(1, o->mg_degree), o->mg_precision, &mg));
       GO(pmh_matinv_set_pc_mg(Kp, mg));
+      stage("multigrid hierarchy (pmh_mg_create_box)");
     }
     GO(pmh_gluing_create(ctx, N, nl, n_leaves, leaves_row, leaves_root, leaves_val, &B));
     GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
     GO(pmh_qppf_create(ctx, Gc, o->orthonormalize, &pf));
+    stage("gluing, G, projector");
     std::vector<double> e_raw = e; // pairs with Gd = G0 in the diagnostic below
     if (o->orthonormalize == 2) GO(pmh_qppf_orth_rhs(pf, e_raw.data(), e.data())); // the constraint becomes (T G0) lambda = T e0
     if (o->explicit_dual) { // MatInvExplicitly restricted to the dofs B touches; congruent blocks share their columns
@@ -195,6 +209,7 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       }
       GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));
       GO(pmh_matinv_attach_explicit(Kp, E));
+      stage("explicit operators (classes, symmetries, assembly)");
       long long ns;
       GO(pmh_fexplicit_assemble_stats(E, &ns, &st->explicit_seconds));
       st->explicit_solves = (int)ns;
@@ -223,6 +238,8 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     GO(pmh_qpt_feti_chain_get(ch, nullptr, &A, nullptr, nullptr, &b, &lbn, nullptr));
     GO(pmh_smalxe_create(ctx, A, b, d_x, lbn, nullptr, pf, &o->smalxe, &sx));
     GO(pmh_sync(ctx));
+    stage("dual chain (d, lambda~, bounds), SMALXE set-up");
+    pmh_csr_set_host_hint(Kc, nullptr, nullptr, nullptr);
     auto t_solve     = std::chrono::steady_clock::now();
     st->setup_seconds = std::chrono::duration<double>(t_solve - t_start).count();
     GO(pmh_smalxe_solve(sx));

@@ -10,6 +10,7 @@
 //     injected from the fine level (P R_{l+1} = R_l), by a threaded blocked Cholesky; plain inverse for a non-singular block.
 // Congruent blocks (bit-identical matrices, pmh_csr_block_classes) are processed once.  The result goes to pmh_mg_create.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <functional>
@@ -285,9 +286,18 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   for (int b = 0; b < nblocks; b++)
     if (block_rowstart[b + 1] - block_rowstart[b] != dims[3 * b] * dims[3 * b + 1] * dims[3 * b + 2] * ndof)
       return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_box: block %d has %d rows, its box %d x %d x %d x %d dof", b, block_rowstart[b + 1] - block_rowstart[b], dims[3 * b], dims[3 * b + 1], dims[3 * b + 2], ndof);
+  const bool verbose = getenv("PMH_CONTACT_TIMING") != nullptr;
+  auto       t_last  = std::chrono::steady_clock::now();
+  auto       stage   = [&](const char *what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  pmh_mg_create_box: %-40s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   std::vector<int> cls(nblocks);
   int              ncls = 0;
   PMH_CHK(pmh_csr_block_classes(nblocks, block_rowstart, rowptr, col, val, cls.data(), &ncls));
+  stage("block classes");
   // blocks of one class must also share the box and the kernel dimension (the kernel SPACE follows from the matrix)
   struct Level {
     HCsr                A, P;
@@ -342,6 +352,7 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
     }
     nlev = std::min(nlev, (int)C.L.size());
   }
+  stage("Galerkin operators, lambda_max (host)");
   // dense (pseudo-)inverse of the level every class is cut at
   for (int c = 0; c < ncls; c++) {
     ClassH     &C = H[c];
@@ -381,6 +392,7 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
         for (int j = 0; j < n; j++) M[(size_t)i * n + j] -= Q[(size_t)k * n + i] * Q[(size_t)k * n + j] / sc;
     C.pinv = std::move(M);
   }
+  stage("dense coarse pseudo-inverses");
   // block-diagonal concatenation per level -> device CSRs -> pmh_mg_create
   std::vector<pmh_csr> Ah(nlev), Ph(std::max(1, nlev - 1)), created;
   std::vector<double>  lam(std::max(1, nlev - 1), 1.0);
@@ -408,6 +420,7 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
       for (int c = 0; c < ncls; c++) lam[l] = (c == 0) ? H[c].L[l].lam : std::max(lam[l], H[c].L[l].lam);
     }
   }
+  stage("level matrices -> device CSR");
   std::vector<int>    crs(nblocks + 1, 0);
   std::vector<double> cp;
   for (int b = 0; b < nblocks; b++) {
@@ -416,6 +429,7 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
     cp.insert(cp.end(), C.pinv.begin(), C.pinv.end());
   }
   PMH_CHK(pmh_mg_create(ctx, nlev, Ah.data(), Ph.data(), degree, lam.data(), 0.1, 1.1, nblocks, crs.data(), cp.data(), precision, out));
+  stage("pmh_mg_create (block copies, transfer operators)");
   for (pmh_csr a : created) PMH_CHK(pmh_mg_adopt_csr(*out, a));
   return PMH_SUCCESS;
 }

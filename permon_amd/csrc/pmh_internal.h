@@ -72,6 +72,9 @@ struct pmh_csr_s {
   double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue
   int       n_launch_blocks;
   pmh_csr   transpose;     // built lazily for mult_transpose
+  // borrowed host copy of the arrays (set-up builders only: pmh_csr_set_host_hint; the caller keeps them alive and unchanged until it clears the hint)
+  const int    *h_rowptr, *h_col;
+  const double *h_val;
   // very long rows (G of the coarse problem: a few dozen rows of ~10^4 non-zeros): rows split into chunks, see spmv.hip
   int      *d_lchunks, *d_lrow; // [3*l_nchunks] (row, k0, k1) and [nrows+1] first chunk of each row
   double   *d_lpart;            // [l_nchunks] chunk sums
@@ -92,6 +95,7 @@ struct pmh_spmv_epi {
   const int    *halt;           // optional device flag: when set the launch (and its finalise) is a no-op
 };
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
+inline void pmh_csr_set_host_hint(pmh_csr A, const int *rowptr, const int *col, const double *val) { A->h_rowptr = rowptr, A->h_col = col, A->h_val = val; }
 int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y); // y = M (A x), Mt = M' (m x m, device)
 
 // ---- operators -------------------------------------------------------------------------------------------
