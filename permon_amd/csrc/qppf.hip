@@ -403,6 +403,39 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1(int n, const int *__res
   }
 }
 
+// ... and with the finishing step of G0 v and the dense T'T product folded in (implicit orthonormalisation, m <= 64): every workgroup adds the
+// chunk sums of k_spmv_long_part per row in chunk order and applies the m x m matrix exactly as k_rows_then_dense does (same order => same bits),
+// then takes its rows -- one launch less per projector application
+__global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int m, const int *__restrict__ lrow,
+                                                         const double *__restrict__ part, const double *__restrict__ Mt, int mode, const double *__restrict__ x, double *__restrict__ y,
+                                                         double *__restrict__ z, double rho)
+{
+  __shared__ double t0[64], w[64];
+  if ((int)threadIdx.x < m) {
+    double sum = 0.0;
+    for (int c = lrow[threadIdx.x]; c < lrow[threadIdx.x + 1]; c++) sum += part[c];
+    t0[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m) {
+    double s = 0.0;
+    for (int c = 0; c < m; c++) s += Mt[(size_t)c * m + threadIdx.x] * t0[c];
+    w[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  double sum = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; k++) sum += val[k] * w[col[k]];
+  if (mode == 0) {
+    y[r] = sum;
+    z[r] = -1.0 * sum + x[r];
+  } else {
+    const double t = x[r] + -1.0 * sum;
+    y[r]           = y[r] * rho + t;
+  }
+}
+
 // the fused path applies when G' is the 8-lanes-per-row stream case (a few dozen entries per row: the rigid-body modes of the
 // subdomains a dual row touches), otherwise the callers keep the unfused sequence
 static bool gt_fusable(pmh_qppf pf)
@@ -411,6 +444,26 @@ static bool gt_fusable(pmh_qppf pf)
   if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
   const pmh_csr Gt = pf->G->transpose;
   return Gt->kind == PMH_SPMV_STREAM && (Gt->st_rl == 8 || Gt->st_rl == 1) && Gt->l_nchunks == 0;
+}
+
+// Q v's G' product with its vector epilogue, starting from v: G0 v (chunk sums), then everything else in ONE launch where the folded kernel
+// applies (implicit orthonormalisation, long-row G0, short-row G0', m <= 64); otherwise qppf_left + gt_fused
+static int gt_fused(pmh_qppf pf, const double *w, int mode, const double *x, double *y, double *z, double rho);
+static int qppf_left(pmh_qppf pf, const double *v);
+static int q_fused(pmh_qppf pf, const double *v, int mode, const double *x, double *y, double *z, double rho)
+{
+  const pmh_csr Gt = pf->G->transpose;
+  if (pf->implicit_orth && pf->G->l_nchunks > 0 && pf->m <= 64 && Gt->st_rl == 1 && !getenv("PMH_NO_GT_DENSE_FUSION")) {
+    const int    *lrow;
+    const double *part;
+    PMH_CHK(pmh_csr_mult_partials(pf->G, v, &lrow, &part));
+    hipLaunchKernelGGL(k_gt_fused1d, dim3((Gt->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, pf->ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, pf->m,
+                       lrow, part, (const double *)pf->d_S, mode, x, y, z, rho);
+    PMH_HIP(hipGetLastError());
+    return PMH_SUCCESS;
+  }
+  PMH_CHK(qppf_left(pf, v));
+  return gt_fused(pf, pf->G_left, mode, x, y, z, rho);
 }
 
 static int gt_fused(pmh_qppf pf, const double *w, int mode, const double *x, double *y, double *z, double rho)
@@ -487,11 +540,9 @@ struct PenalizedOp : pmh_op_s {
     ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
     if (pa && pa->pf == pf && pa->symmetric && gt_fusable(pf)) {
       // A = P F P with the same orthonormal projector: y = rho Q x + P F (P x) in 10 launches (see k_gt_fused)
-      PMH_CHK(qppf_left(pf, x));
-      PMH_CHK(gt_fused(pf, pf->G_left, 0, x, y, pa->w1, 0.0)); // y = Q x, w1 = P x
+      PMH_CHK(q_fused(pf, x, 0, x, y, pa->w1, 0.0)); // y = Q x, w1 = P x
       PMH_CHK(pa->A->mult(pa->w1, pa->w2));
-      PMH_CHK(qppf_left(pf, pa->w2));
-      return gt_fused(pf, pf->G_left, 1, pa->w2, y, nullptr, rho); // y = rho y + (w2 - Q w2)
+      return q_fused(pf, pa->w2, 1, pa->w2, y, nullptr, rho); // y = rho y + (w2 - Q w2)
     }
     PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));
     if (pa && pa->pf == pf && pa->symmetric && pf->orthonormal) {

@@ -675,6 +675,19 @@ extern "C" int pmh_csr_mult(pmh_csr A, const double *x, double *y)
   return pmh_csr_spmv_launch(A, x, y, e);
 }
 
+// the chunk sums of A x alone (long-row matrices): the consumer adds them per row in chunk order itself (qppf.hip folds that and the dense
+// T'T product into the G0' kernel of the projector)
+int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part)
+{
+  PMH_ARG(A && x && lrow && part && A->l_nchunks > 0);
+  static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+  if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
+  else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
+  PMH_HIP(hipGetLastError());
+  *lrow = A->d_lrow, *part = A->d_lpart;
+  return PMH_SUCCESS;
+}
+
 // y = M (A x), M m x m dense given transposed on the device (see k_rows_then_dense); tmp: m doubles of device scratch (short-row matrices)
 int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y)
 {
