@@ -224,13 +224,6 @@ __global__ __launch_bounds__(FXM_THREADS, 1) void k_fxs_symm8(const int *__restr
     const int  ld = c_ld[c], nsb = ld / FXM_RS, sb = FXM_MB * m + sbq;
     const long long xbase = c_xoff[c] + (long long)g * ld * FXS_S;
     const double *__restrict__ x = X + xbase;
-    {
-      const int     n  = min(FXM_MB * FXM_RS, ld - m * FXM_MB * FXM_RS) * FXS_S;
-      const double *xm = x + (long long)m * FXM_MB * FXM_RS * FXS_S;
-      double       *xf = &xs[0][0];
-      for (int i = threadIdx.x * 2; i < n; i += 2 * FXM_THREADS) *(dbl2 *)(xf + i) = *(const dbl2 *)(xm + i);
-    }
-    __syncthreads();
     // this wave's column tiles: J = jbeg + par, + 2, ... below jhi (a super band ends at its diagonal block)
     const int jhi = sb < nsb ? min(jend, (sb + 1) * FXM_RT) : jbeg, nst = (jend - jbeg + 1) >> 1, myst = jhi > jbeg + par ? (jhi - jbeg - par + 1) >> 1 : 0;
     const int ntile = myst * FXM_RT;
@@ -249,6 +242,13 @@ __global__ __launch_bounds__(FXM_THREADS, 1) void k_fxs_symm8(const int *__restr
       }
       xraw = *(const dbl2 *)(x + (long long)(jbeg + par) * 16 * FXS_S + lane * 2);
     }
+    { // X of the mega band's rows -> LDS, with the first tiles of the stream already in flight
+      const int     n  = min(FXM_MB * FXM_RS, ld - m * FXM_MB * FXM_RS) * FXS_S;
+      const double *xm = x + (long long)m * FXM_MB * FXM_RS * FXS_S;
+      double       *xf = &xs[0][0];
+      for (int i = threadIdx.x * 2; i < n; i += 2 * FXM_THREADS) *(dbl2 *)(xf + i) = *(const dbl2 *)(xm + i);
+    }
+    __syncthreads();
     const double *xsb = xs[sbq];
     int           t   = 0;
     for (int s = 0; s < nst; s++) {
