@@ -48,6 +48,8 @@ struct pmh_mpgp_s {
   int     nwork;
   // convergence
   pmh_converged_fn cvg;
+  int (*pre_test)(void *); // optional: enqueues what the injected convergence test will read, BEFORE the host waits for the step's scalars (one round trip instead of two)
+  void *pre_test_user;
   void            *cvg_user;
   double           norm_rhs, ttol, norm_rhs_div;
   int              cvg_setup;
@@ -350,6 +352,7 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   for (int i = 0; i < 10; i++) s->work[i] = nullptr;
   s->nwork = 0;
   s->cvg = nullptr, s->cvg_user = nullptr, s->cvg_setup = 0;
+  s->pre_test = nullptr, s->pre_test_user = nullptr;
   s->norm_rhs = s->ttol = s->norm_rhs_div = 0.0;
   s->rnorm = s->gfnorm = s->gcnorm = 0.0;
   s->iteration = 0, s->reason = 0;
@@ -396,6 +399,15 @@ extern "C" int pmh_mpgp_destroy(pmh_mpgp s)
   if (s->h_ctl) hipHostFree(s->h_ctl);
   if (s->h_ring) hipHostFree(s->h_ring);
   delete s;
+  return PMH_SUCCESS;
+}
+
+// internal (SMALXE): f is called before the host waits for the scalars of a step, with the iterate already updated; what it enqueues is complete when the
+// injected convergence test runs
+int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user)
+{
+  PMH_ARG(s);
+  s->pre_test = f, s->pre_test_user = user;
   return PMH_SUCCESS;
 }
 
@@ -837,6 +849,7 @@ static int solve_fused(pmh_mpgp s)
       nmv += ndev;
       if (!s->h_ctl[CTL_HALT]) continue; // whole batch were CG steps
     }
+    if (s->pre_test) PMH_CHK(s->pre_test(s->pre_test_user));
     PMH_CHK(pmh_sync(ctx));
     s->rnorm           = sqrt(ctx->h_scal[S_GP2]);
     const double gcTgc = ctx->h_scal[S_GC2], gfTgf = ctx->h_scal[S_GF2];

@@ -136,6 +136,8 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
+int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user);             // mpgp.hip: see there
+#define PMH_SLOT_NORMBU2 48 // ||B u||^2 prefetched for SMALXE's inner convergence test
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
 
 // ---- 3x3-block SpMV (bsr.hip) -------------------------------------------------------------------------------------

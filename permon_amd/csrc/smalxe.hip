@@ -25,6 +25,7 @@ struct pmh_smalxe_s {
   pmh_op   A_inner;
   pmh_mpgp inner;
   double  *Btmu, *b_inner, *BtBu, *Bu, *xwork;
+  int      normBu_prefetched;
   // QPSConvergedCtx_Inner_SMALXE + outer QPSConvergedDefaultCtx
   double gtol, ttol_outer, norm_rhs_outer, MNormBu;
   double outer_norm_rhs, outer_ttol, outer_norm_rhs_div;
@@ -83,13 +84,28 @@ extern "C" int pmh_smalxe_default_opts(pmh_smalxe_opts *o)
 // QPSSMALXEUpdateNormBu_SMALXE smalxe.c:247-261 (cE is homogenised away before SMALXE, smalxe.c:782-787)
 static int update_normBu_std(pmh_smalxe s, const double *u, double *normBu, double *enorm)
 {
-  if (s->pf->m > 0) {
+  if (s->pf->m > 0 && s->normBu_prefetched && u == s->u) {
+    // prefetch_normBu enqueued B u and its squared norm before the inner solver waited for this step's scalars: same kernels, same value, no second round trip
+    *normBu              = sqrt(s->ctx->h_scal[PMH_SLOT_NORMBU2]);
+    s->normBu_prefetched = 0;
+  } else if (s->pf->m > 0) {
     PMH_CHK(pmh_qppf_apply_G(s->pf, u, s->Bu));
     PMH_CHK(pmh_vec_norm2(s->ctx, s->pf->m, s->Bu, normBu));
   } else {
     *normBu = 0.0;
   }
   *enorm = *normBu / s->o.rtol_E;
+  return PMH_SUCCESS;
+}
+
+// pre-test hook of the inner MPGP (pmh_mpgp_set_pre_test_hook): the standard ||B u|| of the inner convergence test, enqueued behind the step
+static int prefetch_normBu(void *user)
+{
+  pmh_smalxe s = (pmh_smalxe)user;
+  if (s->o.be_implicit || s->pf->m == 0 || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  PMH_CHK(pmh_qppf_apply_G(s->pf, s->u, s->Bu));
+  PMH_CHK(pmh_k_dot_partials(s->ctx, s->pf->m, s->Bu, s->Bu, PMH_SLOT_NORMBU2));
+  s->normBu_prefetched = 1;
   return PMH_SUCCESS;
 }
 
@@ -272,6 +288,7 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   if (inject) io.maxeig = maxeig_in;
   PMH_CHK(pmh_mpgp_create(ctx, s->A_inner, s->b_inner, u, lb, ub, &io, &s->inner));
   PMH_CHK(pmh_mpgp_set_convergence_test(s->inner, inner_converged, s));
+  PMH_CHK(pmh_mpgp_set_pre_test_hook(s->inner, prefetch_normBu, s));
   *out = s;
   return PMH_SUCCESS;
 }
@@ -362,6 +379,7 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->ttol_outer = fmax(s->o.rtol * s->norm_rhs_outer, s->o.atol);
     PMH_CHK(pmh_vec_norm2(ctx, n, s->b_inner, &s->outer_norm_rhs_div));
     PMH_CHK(pmh_mpgp_set_tolerances(s->inner, s->o.inner.rtol, s->o.inner.atol, s->o.divtol, s->inner_max_it));
+    s->normBu_prefetched = 0;
     PMH_CHK(pmh_mpgp_solve(s->inner));
     pmh_mpgp_stats st;
     PMH_CHK(pmh_mpgp_get_stats(s->inner, &st));
