@@ -54,10 +54,11 @@ def parse():
     ap.add_argument("--kplus-rtol", type=float, default=1e-9, help="feti: relative tolerance of the block-wise CG K^+")
     ap.add_argument("--kplus", choices=["explicit", "iterative"], default="explicit", help="feti: how F = B K^+ B' applies K^+: explicit = the dense local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] "
                     "(assembled once by K^+ solves, then ONE fp64 GEMV per apply; the exact path and the faster one at every N), iterative = an inner block-wise Krylov solve per apply")
-    ap.add_argument("--explicit-storage", choices=["auto", "class_sym", "class", "sym", "full"], default="auto",
+    ap.add_argument("--explicit-storage", choices=["auto", "class_orbit", "class_sym", "class", "sym", "full"], default="auto",
                     help="feti: the dense local dual operators per block as their lower block-triangle (sym: SYMV, 4 n^2 bytes per apply) or in full (full: GEMV, 8 n^2), or ONE full matrix per class "
                          "of congruent blocks applied to 8 blocks' vectors per pass (class: 8 n_c^2 for the whole class; class_sym: its lower block-triangle in 16x16 tiles, 4 n_c^2, both products of a tile on the "
-                         "fp64 matrix instruction); auto = class_sym when that moves fewer bytes, else sym")
+                         "fp64 matrix instruction; class_orbit: only the rows of the orbit representatives under the cube's symmetries, applied as a GEMM on the fp64 matrix instruction); "
+                         "auto = class_orbit when the blocks are congruent cubes with >= 16 symmetries, class_sym when congruent, else sym")
     ap.add_argument("--no-explicit-symmetry", action="store_true", help="feti: assemble every row of the class-shared explicit operator by its own K^+ solve instead of one solve per orbit of rows under "
                     "the cube's 48 signed coordinate permutations (checked against K; pmh_fexplicit_set_class_symmetry)")
     ap.add_argument("--no-stripe", action="store_true", help="feti at N > 1: every rank keeps the explicit operators of its OWN blocks instead of an even share of 128-row stripes of all blocks")
@@ -443,8 +444,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             return M
 
         explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
-        if not a.no_explicit_symmetry and not a.regularize:  # used by the class-shared symmetric storage only
-            explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3)
+        if not a.no_explicit_symmetry and not a.regularize:  # used by the class-shared storages only
+            explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3, orbit=a.explicit_storage in ("auto", "class_orbit"))
         nshare = world if world > 1 else a.sim_world
         if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
@@ -571,7 +572,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         achieved = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
         n_solves, asm_s = E.assemble_stats()
         storage_used = q.explicit_storage
-        ppref = {"class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
+        flops_k = E.apply_flops()
+        ppref = {"class_orbit": ("k_fxo_gemm", "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
         traffic, tsrc = pmc_lookup(ppref, "r02_pmc_traffic_feti_explicit.json", combine="sum") if full_size else (None, "not the configuration of the committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
@@ -586,14 +588,24 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None, "timing_stride": 1,
             "timed_over": "the timed region" if n_k else "not timed", "share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
         }
-        if b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
+        if storage_used == "class_orbit":  # compute-bound: the fp64 matrix peak is the roofline (78.6 TFLOP/s dense, AMD's MI355X figure; scripts/micro/mfma_f64.hip measures 72 for this instruction)
+            tf = flops_k / (ms_k / n_k * 1e-3) / 1e12 if n_k else 0.0
+            roofline.update({
+                "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "flops_per_launch": flops_k,
+                "kernel": "k_fxo_gemm (+ k_fxo_fin): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of 4.5 GB) and "
+                          "Y = W_c X becomes the GEMM (representatives) x (operations x 8 right-hand sides) over n_c on v_mfma_f64_4x4x4_4b_f64: %.0f flop per stored byte, compute-bound; B is gathered from the L2-resident multivector "
+                          "(one index per (operation, dof), sign in its lowest bit), split-K partial tiles summed in a fixed order (the FETI dual operator apply, SURVEY 8d dense path)"
+                          % (q.explicit_symmetries, n_solves - 8 if n_solves > 8 else n_solves, E.dense_bytes / 1e9, flops_k / max(E.dense_bytes, 1)),
+                "hbm_bytes_algorithmic": b_k, "hbm_GBs": achieved,
+                "note": "the HBM-bound form of the same apply (--explicit-storage class_sym: k_fxs_symm8, 4.65 GB per apply at 0.77-0.80 of the 8 TB/s peak) takes 0.73-0.75 ms; this form moves 48 x fewer bytes"})
+        elif b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
             roofline["note"] = ("W_c (%.2f GB stored on this rank) is streamed once per group of 8 blocks, %.1f passes per apply: the re-reads are served by the 256 MB Infinity Cache / L2, "
                                 "so `achieved` is an on-chip rate here, not an HBM rate (the HBM bound applies to the 8-blocks-per-GPU case of configs[2])" % (E.dense_bytes / 1e9, b_k / E.dense_bytes))
         kplus_cfg = {"path": "explicit", "storage": storage_used, "setup_symmetries": getattr(q, "explicit_symmetries", 1), "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns%s" % (pc_text, ", one solve per orbit of rows under the %d symmetries of the cube (checked against K, a batch of rows re-solved directly)" % q.explicit_symmetries if getattr(q, "explicit_symmetries", 1) > 1 else "")
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %s%.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
-            int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
+            int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym", "class_orbit") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
         precision_note = "fp64 throughout: the dense blocks, the GEMV and everything in the dual space are fp64; reduced precision exists only inside the V-cycle that preconditions the SET-UP solves (their CG, residual test at rtol %.0e and solutions are fp64)" % a.explicit_rtol
         if world == 1 and not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and strict fp64
             q.Kplus.attach_explicit(None)

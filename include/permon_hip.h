@@ -321,7 +321,13 @@ typedef struct pmh_fexplicit_s *pmh_fexplicit;
 int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplicit *E); /* finds Gamma_b, allocates the dense blocks (zero) */
 #define PMH_FX_CLASS_SYM 3 /* pmh_fexplicit_create_shared_sym: the same W_c kept as its lower block-triangle in 16 x 16 tiles (4 n_c^2 bytes for the
                               whole class); both products of a tile with the 8 right-hand sides run on the fp64 matrix instruction (4x4x4_4b) */
+#define PMH_FX_CLASS_ORBIT 4 /* pmh_fexplicit_create_shared_orbit: W_c is invariant under the class's symmetries (pmh_fexplicit_set_class_symmetry /
+                                _set_box_symmetry, REQUIRED before the assembly), so only the rows of the orbit representatives are kept (a cube: 1 / 48 of
+                                the rows) and F's dense part becomes a GEMM over (representatives) x (operations x 8 right-hand sides) on the fp64 matrix
+                                instruction: 48 flop per stored byte instead of 4 -- compute-bound instead of HBM-bound */
 int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS */
+int pmh_fexplicit_create_shared_orbit(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_ORBIT */
+int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops); /* PMH_FX_CLASS_ORBIT: useful flops of the dense apply (the roofline of that storage is the fp64 MFMA peak); 0 otherwise */
 int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_SYM */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);

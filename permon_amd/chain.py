@@ -136,24 +136,24 @@ class FetiDualQP:
                 union = np.unique(np.concatenate([tr[blk == m] - grs[m] for m in members])).size
                 b_cls += np.ceil(len(members) / 8.0) * 8.0 * float(union) ** 2
             storage = "class_sym" if 0.5 * b_cls < b_sym else "sym"  # the class matrix in symmetric tiles: half of b_cls
+        one_class_all = one_class
+        want_orbit = storage == "class_orbit" or (storage == "class_sym" and symmetry is not None and symmetry.get("orbit", True) and one_class_all)
+        if storage == "class_orbit" and (symmetry is None or not one_class):
+            raise ValueError("class_orbit needs congruent box blocks and symmetry=dict(dims=..., ndof=...)")
+        for attempt in ("class_orbit", "class_sym") if want_orbit else (storage,):
+            E = self._create_explicit(local, attempt, stripe, cls, nb)
+            self.explicit_symmetries = 1
+            if symmetry is not None and attempt in ("class_sym", "class_orbit") and one_class:
+                n_i = int(rs[1] - rs[0])
+                Kc = self._Kinv_sp[:n_i, :n_i]  # the class matrix (what the solver inverts)
+                self.explicit_symmetries = E.set_box_symmetry(0, symmetry["dims"], symmetry.get("ndof", 3), Kc)
+            if attempt == "class_orbit" and self.explicit_symmetries < 16 and storage != "class_orbit":
+                E.destroy()  # too few operations for the GEMM form to pay: the streaming kernel on the symmetric tiles
+                continue
+            storage = attempt
+            break
         self.explicit_storage = storage
-        if stripe is not None:
-            rank, size, glob = stripe
-            if not one_class:
-                raise ValueError("striped explicit operators need congruent blocks")
-            self._Bglob = MatGluing(self.ctx, glob["n_x"], self.n_lambda, glob["leaves_row"], glob["leaves_root"], glob["leaves_sign"])
-            self._Kglob = MatBlockDiag.from_scipy(self.ctx, glob["block_rowstart"], sp.identity(glob["n_x"], format="csr"))  # block structure only
-            ngl = len(glob["block_rowstart"]) - 1
-            E = MatExplicitDual(self._Bglob, self._Kglob, storage=storage if storage in ("class", "class_sym") else "sym", block_class=np.zeros(ngl, dtype=np.int32))
-            E.set_stripe(rank, size)
-        else:
-            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)
-            ngl = nb
-        self.explicit_symmetries = 1
-        if symmetry is not None and storage == "class_sym" and one_class:
-            n_i = int(rs[1] - rs[0])
-            Kc = self._Kinv_sp[:n_i, :n_i]  # the class matrix (what the solver inverts)
-            self.explicit_symmetries = E.set_box_symmetry(0, symmetry["dims"], symmetry.get("ndof", 3), Kc)
+        ngl = len(stripe[2]["block_rowstart"]) - 1 if stripe is not None else nb
         if solver_factory is not None and nb < min_slots and one_class:
             solver = solver_factory(int(min_slots))
             E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
@@ -163,6 +163,23 @@ class FetiDualQP:
         else:
             E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it)
         self.Kplus.attach_explicit(E)
+        return E
+
+    def _create_explicit(self, local, storage, stripe, cls, nb):
+        """The pmh_fexplicit object of assemble_explicit for one storage (striped over all blocks of the decomposition, or this rank's blocks)."""
+        import scipy.sparse as sp
+
+        if stripe is not None:
+            rank, size, glob = stripe
+            if int(cls.max()) != 0:
+                raise ValueError("striped explicit operators need congruent blocks")
+            self._Bglob = MatGluing(self.ctx, glob["n_x"], self.n_lambda, glob["leaves_row"], glob["leaves_root"], glob["leaves_sign"])
+            self._Kglob = MatBlockDiag.from_scipy(self.ctx, glob["block_rowstart"], sp.identity(glob["n_x"], format="csr"))  # block structure only
+            ngl = len(glob["block_rowstart"]) - 1
+            E = MatExplicitDual(self._Bglob, self._Kglob, storage=storage if storage in ("class", "class_sym", "class_orbit") else "sym", block_class=np.zeros(ngl, dtype=np.int32))
+            E.set_stripe(rank, size)
+        else:
+            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)
         return E
 
     def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):

@@ -365,6 +365,14 @@ extern "C" int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, co
   return fx_create(B, K, PMH_FX_CLASS_SYM, block_class, out);
 }
 
+// only the rows of W_c of the orbit representatives under the class's symmetries (set them before the assembly): the apply is a GEMM on the fp64
+// matrix instruction (fshared.hip, FXO section)
+extern "C" int pmh_fexplicit_create_shared_orbit(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *out)
+{
+  PMH_ARG(block_class);
+  return fx_create(B, K, PMH_FX_CLASS_ORBIT, block_class, out);
+}
+
 static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *block_class, pmh_fexplicit *out)
 {
   PMH_ARG(B && K && out);
@@ -398,9 +406,9 @@ static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *bloc
     off += E->ld[b]; // every block padded to a multiple of 128: aligned 16-byte loads, whole bands and tiles; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
-  if (storage == PMH_FX_CLASS || storage == PMH_FX_CLASS_SYM) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
+  if (storage == PMH_FX_CLASS || storage == PMH_FX_CLASS_SYM || storage == PMH_FX_CLASS_ORBIT) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
     E->W.assign(nb, nullptr), E->woff.assign(nb, 0);
-    PMH_CHK(fxs_create(B, K, block_class, storage == PMH_FX_CLASS_SYM, &E->sh));
+    PMH_CHK(fxs_create(B, K, block_class, storage == PMH_FX_CLASS_ORBIT ? 2 : (storage == PMH_FX_CLASS_SYM ? 1 : 0), &E->sh));
     *out = E;
     return PMH_SUCCESS;
   }
@@ -615,7 +623,7 @@ extern "C" int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const in
 {
   PMH_ARG(E && dims && ndof >= 1);
   if (nsym_used) *nsym_used = 1;
-  if (!E->sh || E->storage != PMH_FX_CLASS_SYM) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_box_symmetry: needs the PMH_FX_CLASS_SYM storage");
+  if (!E->sh || (E->storage != PMH_FX_CLASS_SYM && E->storage != PMH_FX_CLASS_ORBIT)) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_box_symmetry: needs the PMH_FX_CLASS_SYM or PMH_FX_CLASS_ORBIT storage");
   int nc = 0;
   PMH_CHK(fxs_class_union(E->sh, cls, &nc, nullptr));
   if (nc == 0) return PMH_SUCCESS;
@@ -640,6 +648,13 @@ extern "C" int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const in
   if (used <= 1) return PMH_SUCCESS;
   if (E->assembled) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_set_box_symmetry: call before the assembly");
   return fxs_set_symmetry(E->sh, cls, used, pm.data(), sg.data());
+}
+
+extern "C" int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops)
+{
+  PMH_ARG(E && flops);
+  *flops = E->sh ? fxs_apply_flops(E->sh) : 0.0;
+  return PMH_SUCCESS;
 }
 
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)

@@ -3,13 +3,14 @@
 #include "feti_internal.h"
 
 struct fx_shared;
-int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out); // sym: lower block-triangle in 16 x 16 tiles (PMH_FX_CLASS_SYM)
+int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out); // sym 1: lower block-triangle in 16 x 16 tiles (PMH_FX_CLASS_SYM), 2: orbit representatives' rows (PMH_FX_CLASS_ORBIT)
 void      fxs_destroy(fx_shared *S);
 int       fxs_set_stripe(fx_shared *S, int rank, int size);
 int       fxs_class_union(fx_shared *S, int c, int *n_c, int *urel_out);
 int       fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, const signed char *sign);
 long long fxs_dense_bytes(fx_shared *S);
 double    fxs_apply_bytes(fx_shared *S);
+double    fxs_apply_flops(fx_shared *S);
 int       fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves);
 int       fxs_apply(fx_shared *S, const double *lambda, double *y);
 int       fxs_dense(fx_shared *S);

@@ -47,6 +47,12 @@ struct fxs_class {
   std::vector<signed char> h_sign;   // [nsym][nc]: +-1
   int                     *d_posmap = nullptr;
   signed char             *d_sign = nullptr;
+  // orbit storage (fx_shared::sym == 2): only the rows of W_c of the orbit representatives are kept, see the FXO section
+  std::vector<int> reps, rep_of, op_of; // all representatives (positions, ascending); per row: its representative's position and the operation that reaches it
+  int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0;
+  long long        aoff = 0, coff = 0;  // offsets of the class in Afund / cpart
+  int             *d_gidx = nullptr, *d_reppos = nullptr;
+  signed char     *d_use = nullptr;
 };
 
 struct fx_shared {
@@ -75,6 +81,11 @@ struct fx_shared {
   double                *pt = nullptr;
   long long              pt_tot = 0;
   double                 owned_bytes = 0.0;
+  // orbit storage
+  double                *Afund = nullptr, *cpart = nullptr;
+  long long              afund_tot = 0, cpart_cap = 0;
+  int                    fxo_ready = 0, fxo_S = 1, stripe_rank = 0, stripe_size = 0;
+  double                 flops = 0.0;
 };
 
 // Y = W_c X with 8 right-hand sides, W_c symmetric and stored in full: the product is taken as Y[c][s] = sum_r W[r][c] X[r][s], i.e.
@@ -388,6 +399,153 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
   if (threadIdx.x == 0) out[2 * blockIdx.x] = d, out[2 * blockIdx.x + 1] = m;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Orbit storage (PMH_FX_CLASS_ORBIT): W_c is invariant under the class's symmetries (fxs_set_symmetry), W[g p][g c] = s_g(p) s_g(c) W[p][c], so
+// only the rows of the orbit REPRESENTATIVES are kept (configs[2]: 715 of 33 288 rows, 0.19 GB instead of 4.5 GB) and
+//     Y[g p][s] = s_g(p) sum_c W[p][c] (s_g(c) X[g c][s])
+// for every representative p, operation g and right-hand side s: a real GEMM, C = A B with A = the M representatives' rows (M x n_c), B[c][(g, s)] =
+// s_g(c) X[g c][s] (n_c x 8 nsym, never formed: gathered from the L2-resident multivector through one index per (g, c) with the sign in its
+// lowest bit).  2 M n_c 8 nsym flops on 8 M n_c bytes: 48 flop per byte for the cube's 48 operations -- the dense apply leaves the HBM roofline
+// and runs on the fp64 matrix instruction (v_mfma_f64_4x4x4_4b_f64, as k_fxs_symm8).  Workgroup tile 128 x 128, k in chunks of 16, 4 waves of
+// 64 x 64 (4 x 16 accumulators per lane), A pre-tiled in the order of its LDS image ([k][row] per (row tile, chunk): coalesced 16-byte loads),
+// both operands double-buffered in LDS, split-K partial tiles summed in a fixed order by k_fxo_fin, which also applies s_g(p) and scatters row g p.
+#define FXO_TM 128
+#define FXO_TN 128
+#define FXO_TK 16
+#define FXO_LDA (FXO_TM + 16)
+#define FXO_LDB (FXO_TN + 4)
+// items: (class, group, row tile, column tile (16 operations), first chunk, one-past-last chunk, split, 0); iteml: A offset of the class, X offset of
+// the group, C offset of (class, group, split)
+__global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
+                                                     const int *__restrict__ c_ncol, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
+                                                     const double *__restrict__ X, double *__restrict__ cpart)
+{
+  __shared__ double As[2][FXO_TK][FXO_LDA];
+  __shared__ double Bs[2][FXO_TK][FXO_LDB];
+  const int *w8 = items + 8 * blockIdx.x;
+  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
+  const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
+  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = c_ncol[c];
+  const double *__restrict__ Ab = A + iteml[3 * blockIdx.x];
+  const double *__restrict__ x  = X + iteml[3 * blockIdx.x + 1];
+  double *__restrict__ C        = cpart + iteml[3 * blockIdx.x + 2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int NEA = FXO_TK * FXO_TM / 2 / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
+  const int  col = t % FXO_TN, kb = t / FXO_TN, sl = col & 7;
+  const int *gp = gidx + (long long)(nt * (FXO_TN / 8) + (col >> 3)) * ldk;
+  double     acc[4][16];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[i][j] = 0.0;
+  dbl2   ar[NEA];
+  double br[NEB];
+  int    gn[NEB];
+  auto loadA = [&](int kc) {
+    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * FXO_TM);
+#pragma unroll
+    for (int e = 0; e < NEA; e++) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + 256 * e)));
+  };
+  auto loadG = [&](int kc) {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
+  };
+  auto gatherB = [&]() {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) {
+      const double v = x[(long long)(gn[e] >> 1) * FXS_S + sl];
+      br[e]          = (gn[e] & 1) ? -v : v;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < NEA; e++) {
+      const int q = t + 256 * e, k = q / (FXO_TM / 2), r2 = (q % (FXO_TM / 2)) * 2;
+      *(dbl2 *)&As[buf][k][r2] = ar[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
+  };
+  if (kc0 < kc1) {
+    loadG(kc0);
+    loadA(kc0);
+    gatherB();
+    if (kc0 + 1 < kc1) loadG(kc0 + 1);
+    store(0);
+  }
+  __syncthreads();
+  const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
+  for (int kc = kc0; kc < kc1; kc++) {
+    const int buf = (kc - kc0) & 1;
+    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied
+      loadA(kc + 1);
+      gatherB();
+      if (kc + 2 < kc1) loadG(kc + 2);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
+      double a[4], b[16];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
+#pragma unroll
+      for (int j = 0; j < 16; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 4 + cb];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = fxm_mfma(a[i], b[j], acc[i][j]);
+    }
+    if (kc + 1 < kc1) store(buf ^ 1);
+    __syncthreads();
+  }
+  // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
+  const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) C[(long long)(mt * FXO_TM + wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
+}
+
+// Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (p, g) pairs that own their row (use = +-1: the operation the row was
+// assigned to; rows fixed by several operations are written once).  One thread per (representative, column); grid.y = group
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsymp, int nc, int S, long long cgs /* stride between groups */, const double *__restrict__ cp,
+                                                       const signed char *__restrict__ use, const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld,
+                                                       double *__restrict__ Y)
+{
+  const long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (i >= (long long)Mp * ncol) return;
+  const int p = (int)(i / ncol), colx = (int)(i % ncol), g = colx >> 3, sl = colx & 7;
+  const int u = use[(long long)p * nsymp + g];
+  if (u == 0) return;
+  const double *q = cp + (long long)blockIdx.y * cgs + i;
+  double        s = q[0];
+  for (int j = 1; j < S; j++) s += q[(long long)j * Mp * ncol];
+  Y[xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[p]] * FXS_S + sl] = u > 0 ? s : -s;
+}
+
+// row of representative pl (local index) from its K^+ solve -> the pre-tiled A
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_store_row(int pl, int nc, int nkc, const int *__restrict__ urel, const double *__restrict__ u, double *__restrict__ A)
+{
+  double *base = A + (long long)(pl / FXO_TM) * nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) base[(long long)(c / FXO_TK) * (FXO_TK * FXO_TM) + (c % FXO_TK) * FXO_TM] = u[urel[c]];
+}
+
+// set-up self-check: row r = g p from its own solve (u) against s_g(p) s_g(c) A[p][c] at column g c, for all c
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_check_row(int pl, int nc, int nkc, double sp, const int *__restrict__ urel, const double *__restrict__ u, const int *__restrict__ posmap,
+                                                             const signed char *__restrict__ sign, const double *__restrict__ A, double *__restrict__ out)
+{
+  __shared__ double red[PMH_BLOCK / 64];
+  const double *base = A + (long long)(pl / FXO_TM) * nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
+  double        d = 0.0, m = 0.0;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) {
+    const double w = sp * (double)sign[c] * base[(long long)(c / FXO_TK) * (FXO_TK * FXO_TM) + (c % FXO_TK) * FXO_TM], v = u[urel[posmap[c]]];
+    d = fmax(d, fabs(w - v)), m = fmax(m, fabs(v));
+  }
+  d = -pmh_block_reduce<PMH_RED_MIN>(-d, red);
+  m = -pmh_block_reduce<PMH_RED_MIN>(-m, red);
+  if (threadIdx.x == 0) out[2 * blockIdx.x] = d, out[2 * blockIdx.x + 1] = m;
+}
+
 static int fxs_build_launch(fx_shared *S)
 {
   if (S->sym) {
@@ -557,12 +715,14 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     for (int i = 0; i < C.nloc; i++)
       if (C.pos[i] == 0) C.pos[i] = (int)C.urel.size(), C.urel.push_back(i);
     C.nc      = (int)C.urel.size();
-    const int pad = sym ? FXM_RS : FXS_PAD;
+    const int pad = sym == 2 ? 32 : (sym ? FXM_RS : FXS_PAD);
     C.ld      = (C.nc + pad - 1) / pad * pad;
     C.ngroups = ((int)C.blocks.size() + FXS_S - 1) / FXS_S;
     C.r0 = 0, C.r1 = C.ld;
     C.woff = wtot, C.xoff = xtot;
-    if (sym) {
+    if (sym == 2) {
+      if (C.ld == C.nc) C.ld += 32; // a zero row of X behind the touched dofs for the padded k range of the GEMM
+    } else if (sym) {
       C.nsb = C.ld / FXM_RS, C.nmb = (C.nsb + FXM_MB - 1) / FXM_MB;
       C.own.assign((size_t)std::max(1, C.nsb), 1);
       C.ptm.assign((size_t)C.nmb + 1, 0);
@@ -592,7 +752,7 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_create_shared: %.2f GB for the shared explicit operators: %s", bytes / 1e9, hipGetErrorString(e));
     PMH_HIP(hipMemsetAsync(S->Wbase, 0, bytes, ctx->stream));
   }
-  if (sym) {
+  if (sym == 1) {
     S->pt_tot = pttot;
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, pttot), (void **)&S->pt));
   }
@@ -609,7 +769,7 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
   PMH_CHK(pmh_memcpy_h2d(ctx, S->d_ld, ldv.data(), sizeof(int) * S->ncls));
   PMH_CHK(pmh_memcpy_h2d(ctx, S->d_woff, wo.data(), sizeof(long long) * S->ncls));
   PMH_CHK(pmh_memcpy_h2d(ctx, S->d_xoff, xo.data(), sizeof(long long) * S->ncls));
-  PMH_CHK(fxs_build_launch(S));
+  if (sym != 2) PMH_CHK(fxs_build_launch(S)); // orbit storage: planned once the symmetries are known (fxo_prepare)
   *out = S;
   return PMH_SUCCESS;
 }
@@ -624,12 +784,15 @@ void fxs_destroy(fx_shared *S)
     if (C.d_ptoff) pmh_free(ctx, C.d_ptoff);
     if (C.d_ownfirst) pmh_free(ctx, C.d_ownfirst);
     if (C.d_posmap) pmh_free(ctx, C.d_posmap), pmh_free(ctx, C.d_sign);
+    if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   if (S->d_items) pmh_free(ctx, S->d_items);
   pmh_gluing_destroy(S->Bc);
   if (S->Wbase) (void)hipFree(S->Wbase);
+  if (S->Afund) (void)hipFree(S->Afund);
+  if (S->cpart) pmh_free(ctx, S->cpart);
   if (S->part) pmh_free(ctx, S->part);
   pmh_free(ctx, S->X), pmh_free(ctx, S->Y), pmh_free(ctx, S->d_wg), pmh_free(ctx, S->d_ld), pmh_free(ctx, S->d_woff), pmh_free(ctx, S->d_xoff);
   for (hipEvent_t e : S->ev) (void)hipEventDestroy(e);
@@ -662,6 +825,10 @@ extern "C" int pmh_fexplicit_class_sym_plan(int n_c, int size, int *owner_out, d
 // several GPUs: rank r applies / assembles the rows [r0, r1) of every W_c, contiguous ranges of equal length (multiples of 32)
 int fxs_set_stripe(fx_shared *S, int rank, int size)
 {
+  if (S->sym == 2) { // orbit storage: a contiguous range of the representatives per rank, planned by fxo_prepare
+    S->stripe_rank = rank, S->stripe_size = size, S->fxo_ready = 0;
+    return PMH_SUCCESS;
+  }
   if (S->sym) {
     // whole mega bands of 1024 rows (a rank assembles exactly the rows it applies); mega band m costs ~ m + 1: dealt from the longest down in
     // snake order, so every rank gets the same number of long and short ones
@@ -680,6 +847,7 @@ int fxs_set_stripe(fx_shared *S, int rank, int size)
 }
 
 long long fxs_dense_bytes(fx_shared *S) { return S->sym ? (long long)S->owned_bytes : (long long)sizeof(double) * S->wtot; }
+double    fxs_apply_flops(fx_shared *S) { return S->sym == 2 ? S->flops : 0.0; } // orbit storage: the GEMM's useful flops per apply
 double    fxs_apply_bytes(fx_shared *S) { return S->bytes; }
 
 // the touched dofs of class c, ascending, relative to the block start (the numbering of W_c's rows)
@@ -698,7 +866,8 @@ int fxs_class_union(fx_shared *S, int c, int *n_c, int *urel_out)
 int fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, const signed char *sign)
 {
   PMH_ARG(S && c >= 0 && c < S->ncls && nsym >= 1 && posmap && sign);
-  if (!S->sym) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_class_symmetry: needs the PMH_FX_CLASS_SYM storage");
+  if (!S->sym) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_set_class_symmetry: needs the PMH_FX_CLASS_SYM or PMH_FX_CLASS_ORBIT storage");
+  S->fxo_ready = 0;
   fxs_class &C  = S->C[c];
   const int  nc = C.nc;
   std::vector<char> seen((size_t)std::max(1, nc));
@@ -725,10 +894,160 @@ int fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, const sig
   return PMH_SUCCESS;
 }
 
+// ---- orbit storage: plan (after the symmetries and the stripe are known) ----------------------------------------------------------------------
+static int fxo_prepare(fx_shared *S)
+{
+  if (S->fxo_ready) return PMH_SUCCESS;
+  pmh_ctx   ctx = S->ctx;
+  long long atot = 0;
+  for (int c = 0; c < S->ncls; c++) {
+    fxs_class &C = S->C[c];
+    if (C.nc == 0) continue;
+    if (C.nsym < 1) return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: block class %d has no symmetries (pmh_fexplicit_set_class_symmetry / _set_box_symmetry before the assembly)", c);
+    // orbits of the rows: representative and operation of every row; rows fixed by several operations keep the first
+    C.rep_of.assign((size_t)C.nc, -1), C.op_of.assign((size_t)C.nc, 0), C.reps.clear();
+    for (int p = 0; p < C.nc; p++) {
+      if (C.rep_of[p] >= 0) continue;
+      C.reps.push_back(p);
+      for (int g = 0; g < C.nsym; g++) {
+        const int r = C.h_posmap[(size_t)g * C.nc + p];
+        if (C.rep_of[r] < 0) C.rep_of[r] = p, C.op_of[r] = g;
+      }
+    }
+    C.M_all = (int)C.reps.size();
+    // several GPUs: every rank keeps ALL representatives' rows (0.19 GB for configs[2]; it solves for them itself) and multiplies a contiguous share of
+    // the k range (the columns of W): full tiles at every N, and the partial Y are summed by the all-reduce that ends B Y anyway
+    C.m0 = 0, C.m1 = C.M_all;
+    const int M = C.m1 - C.m0;
+    C.Mp   = std::max(1, (M + FXO_TM - 1) / FXO_TM) * FXO_TM;
+    C.ldk  = (C.nc + FXO_TK - 1) / FXO_TK * FXO_TK;
+    C.nkc  = C.ldk / FXO_TK;
+    C.nsymp = (C.nsym + FXO_TN / 8 - 1) / (FXO_TN / 8) * (FXO_TN / 8);
+    C.aoff = atot;
+    atot += (long long)C.Mp * C.ldk;
+    // gather indices of B: (position of g c) << 1 | (s_g(c) < 0); padded k and padded operations read the zero row nc of X
+    std::vector<int>         gidx((size_t)C.nsymp * C.ldk, C.nc << 1), reppos((size_t)C.Mp, 0);
+    std::vector<signed char> use((size_t)C.Mp * C.nsymp, 0);
+    for (int g = 0; g < C.nsym; g++)
+      for (int cc = 0; cc < C.nc; cc++) gidx[(size_t)g * C.ldk + cc] = (C.h_posmap[(size_t)g * C.nc + cc] << 1) | (C.h_sign[(size_t)g * C.nc + cc] < 0 ? 1 : 0);
+    for (int pl = 0; pl < M; pl++) {
+      const int p = C.reps[C.m0 + pl];
+      reppos[pl] = p;
+      for (int g = 0; g < C.nsym; g++) {
+        const int r = C.h_posmap[(size_t)g * C.nc + p];
+        if (C.rep_of[r] == p && C.op_of[r] == g) use[(size_t)pl * C.nsymp + g] = C.h_sign[(size_t)g * C.nc + p];
+      }
+    }
+    if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * gidx.size(), (void **)&C.d_gidx));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * reppos.size(), (void **)&C.d_reppos));
+    PMH_CHK(pmh_malloc(ctx, use.size(), (void **)&C.d_use));
+    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_gidx, gidx.data(), sizeof(int) * gidx.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_reppos, reppos.data(), sizeof(int) * reppos.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_use, use.data(), use.size()));
+  }
+  if (S->Afund) (void)hipFree(S->Afund);
+  {
+    const size_t bytes = sizeof(double) * (size_t)std::max(32LL, atot);
+    hipError_t   e     = hipMalloc((void **)&S->Afund, bytes);
+    if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "PMH_FX_CLASS_ORBIT: %.2f GB for the representatives' rows: %s", bytes / 1e9, hipGetErrorString(e));
+    PMH_HIP(hipMemsetAsync(S->Afund, 0, bytes, ctx->stream));
+    S->afund_tot = atot;
+  }
+  // GEMM work items: (row tile, column tile of 16 operations, split of the k range) per class and group; the split gives ~2 workgroups per CU
+  long long tiles = 0;
+  for (auto &C : S->C)
+    if (C.nc) tiles += (long long)C.ngroups * (C.Mp / FXO_TM) * (C.nsymp * 8 / FXO_TN);
+  int Ssplit = (int)std::max(1LL, 2LL * ctx->num_cus / std::max(1LL, tiles)); // one round of the 2 resident workgroups per CU (measured: 28 splits 0.407 ms, 56: 0.417, 57: 0.50); at least 24 chunks each (below)
+  if (const char *e = getenv("PMH_FXO_SPLIT")) Ssplit = std::max(1, atoi(e));
+  std::vector<int>       items, vnkc(S->ncls, 1), vldk(S->ncls, 16), vncol(S->ncls, 128);
+  std::vector<long long> iteml;
+  long long              ctot = 0;
+  S->flops = 0.0, S->bytes = 0.0, S->owned_bytes = 0.0;
+  int Smax = 1;
+  for (int c = 0; c < S->ncls; c++) {
+    fxs_class &C = S->C[c];
+    if (!C.nc) continue;
+    const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
+    const int klo = (int)((long long)C.nkc * rank / size), khi = (int)((long long)C.nkc * (rank + 1) / size), nk = khi - klo; // this rank's chunks
+    const int ncol = C.nsymp * 8, Sc = std::max(1, std::min(Ssplit, nk / (getenv("PMH_FXO_MINCH") ? atoi(getenv("PMH_FXO_MINCH")) : 8)));
+    Smax = std::max(Smax, Sc);
+    vnkc[c] = C.nkc, vldk[c] = C.ldk, vncol[c] = ncol;
+    C.coff = ctot;
+    for (int g = 0; g < C.ngroups; g++)
+      for (int mt = 0; mt < C.Mp / FXO_TM; mt++)
+        for (int nt = 0; nt < ncol / FXO_TN; nt++)
+          for (int sp = 0; sp < Sc; sp++) {
+            items.insert(items.end(), {c, g, mt, nt, klo + (int)((long long)nk * sp / Sc), klo + (int)((long long)nk * (sp + 1) / Sc), sp, 0});
+            iteml.push_back(C.aoff);
+            iteml.push_back(C.xoff + (long long)g * C.ld * FXS_S);
+            iteml.push_back(ctot + ((long long)g * Sc + sp) * C.Mp * ncol);
+          }
+    ctot += (long long)C.ngroups * Sc * C.Mp * ncol;
+    const double M = C.m1 - C.m0, share = (double)nk / std::max(1, C.nkc);
+    S->flops += (double)C.ngroups * 2.0 * M * C.nc * share * 8.0 * C.nsym;
+    S->owned_bytes += 8.0 * M * C.nc;
+    // this rank's columns of A once + the gathered B + the split partial tiles written and read + Y
+    S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 2.0 * 8.0 * Sc * M * ncol + 8.0 * FXS_S * C.nc);
+    C.nown = Sc; // (re-used: the class's split count)
+  }
+  S->fxo_S = Smax;
+  S->nwg   = (int)(items.size() / 8);
+  items.insert(items.end(), {0, 0, 0, 0, 0, 0, 0, 0});
+  iteml.insert(iteml.end(), {0, 0, 0});
+  if (S->d_items) pmh_free(ctx, S->d_items);
+  if (S->d_wgl) pmh_free(ctx, S->d_wgl);
+  if (S->d_wg) pmh_free(ctx, S->d_wg);
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * items.size(), (void **)&S->d_items));
+  PMH_CHK(pmh_memcpy_h2d(ctx, S->d_items, items.data(), sizeof(int) * items.size()));
+  PMH_CHK(pmh_malloc(ctx, sizeof(long long) * iteml.size(), (void **)&S->d_wgl));
+  PMH_CHK(pmh_memcpy_h2d(ctx, S->d_wgl, iteml.data(), sizeof(long long) * iteml.size()));
+  // per class: nkc, ldk, ncol (ints) in d_wg
+  std::vector<int> meta;
+  meta.insert(meta.end(), vnkc.begin(), vnkc.end()), meta.insert(meta.end(), vldk.begin(), vldk.end()), meta.insert(meta.end(), vncol.begin(), vncol.end());
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * meta.size(), (void **)&S->d_wg));
+  PMH_CHK(pmh_memcpy_h2d(ctx, S->d_wg, meta.data(), sizeof(int) * meta.size()));
+  if (ctot > S->cpart_cap) {
+    if (S->cpart) pmh_free(ctx, S->cpart);
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, ctot), (void **)&S->cpart));
+    S->cpart_cap = ctot;
+  }
+  S->fxo_ready = 1;
+  return PMH_SUCCESS;
+}
+
+static int fxo_gemm(fx_shared *S)
+{
+  hipStream_t st = S->ctx->stream;
+  for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array); configs[2] / [3]: one class
+    fxs_class &C = S->C[c];
+    if (!C.nc) continue;
+    int first = 0, count = 0; // the class's items are contiguous
+    {
+      int idx = 0;
+      for (int cc = 0; cc < S->ncls; cc++) {
+        const fxs_class &D = S->C[cc];
+        const int        n = D.nc ? D.ngroups * (D.Mp / FXO_TM) * (D.nsymp * 8 / FXO_TN) * D.nown : 0;
+        if (cc == c) first = idx, count = n;
+        idx += n;
+      }
+    }
+    if (!count) continue;
+    const int ncol = C.nsymp * 8;
+    hipLaunchKernelGGL(k_fxo_gemm, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 3 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls),
+                       (const int *)(S->d_wg + 2 * S->ncls), (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart);
+    hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)(((long long)C.Mp * ncol + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp, ncol, C.nsymp, C.nc, C.nown, (long long)C.nown * C.Mp * ncol,
+                       (const double *)(S->cpart + C.coff), (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld, S->Y);
+  }
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
 int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves)
 {
   PMH_ARG(S && solver && nslots >= 1 && solver->nblocks == nslots && slot_class);
   pmh_ctx                       ctx = S->ctx;
+  if (S->sym == 2) PMH_CHK(fxo_prepare(S));
   const std::vector<int>       &srs = solver->K->rowstart;
   std::vector<std::vector<int>> cslots(S->ncls), todo(S->ncls);
   std::vector<std::vector<int>> rep_of(S->ncls), op_of(S->ncls), check(S->ncls);
@@ -742,7 +1061,18 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
     if (cslots[c].empty()) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: no solver slot for block class %d", c);
     for (int s : cslots[c])
       if (srs[s + 1] - srs[s] != C.nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, C.nloc);
-    if (S->sym && C.nsym > 1) {
+    if (S->sym == 2) {
+      // orbit storage: the owned representatives; self-check: rows of their orbits reached by a non-trivial operation
+      for (int pl = 0; pl < C.m1 - C.m0; pl++) todo[c].push_back(C.reps[C.m0 + pl]);
+      std::vector<int> filled;
+      for (int r = 0; r < C.nc; r++)
+        if (C.op_of[r] != 0) {
+          const int k = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), C.rep_of[r]) - C.reps.begin());
+          if (k >= C.m0 && k < C.m1) filled.push_back(r);
+        }
+      const int nchk = (int)std::min(filled.size(), cslots[c].size());
+      for (int i = 0; i < nchk; i++) check[c].push_back(filled[(size_t)((long long)filled.size() * (2 * i + 1) / (2 * nchk))]);
+    } else if (S->sym && C.nsym > 1) {
       // orbits of the rows under the class's symmetries: rep_of / op_of, one solve per orbit that has a row in this rank's super bands
       rep_of[c].assign((size_t)C.nc, -1), op_of[c].assign((size_t)C.nc, 0);
       for (int p = 0; p < C.nc; p++) {
@@ -811,7 +1141,11 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (prow[s] < 0) continue;
       (*n_solves)++;
       const fxs_class &C = S->C[slot_class[s]];
-      if (S->sym && C.nsym > 1) {
+      if (S->sym == 2) {
+        const int pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), prow[s]) - C.reps.begin()) - C.m0;
+        hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.nc, C.nkc, (const int *)C.d_urel,
+                           (const double *)(sol + srs[s]), S->Afund + C.aoff);
+      } else if (S->sym && C.nsym > 1) {
         const int p = prow[s];
         for (int r : members[slot_class[s]][p]) {
           const int g = op_of[slot_class[s]][r], sb = r / FXM_RS;
@@ -852,7 +1186,14 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (prow[s] < 0) continue;
       (*n_solves)++;
       const fxs_class &C  = S->C[slot_class[s]];
-      const int        r = prow[s], sb = r / FXM_RS, nb = std::max(1, std::min(64, (r + PMH_BLOCK) / PMH_BLOCK));
+      const int        r = prow[s], sb = r / FXM_RS;
+      int              nb = std::max(1, std::min(64, (r + PMH_BLOCK) / PMH_BLOCK));
+      if (S->sym == 2) {
+        const int g = C.op_of[r], p = C.rep_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin()) - C.m0;
+        nb          = std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK));
+        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+                           (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc), (const double *)(S->Afund + C.aoff), d_out);
+      } else
       hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
                          (const double *)(S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2)), d_out);
       if ((rc = pmh_memcpy_d2h(ctx, h_out, d_out, sizeof(double) * 2 * nb))) break;
@@ -872,12 +1213,15 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
 
 static int fxs_gemm(fx_shared *S)
 {
+  if (S->sym == 2 && !S->fxo_ready) return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: apply before the assembly");
   if (!S->nwg) return PMH_SUCCESS;
   hipStream_t st    = S->ctx->stream;
   const bool  timed = S->ev_on && (size_t)(2 * S->ev_used + 2) <= S->ev.size();
   if (timed) PMH_HIP(hipEventRecord(S->ev[2 * S->ev_used], st));
   const long long stride = std::max(16LL, S->nX);
-  if (S->sym) {
+  if (S->sym == 2) {
+    PMH_CHK(fxo_gemm(S));
+  } else if (S->sym) {
     hipLaunchKernelGGL(k_fxs_symm8, dim3(S->nwg), dim3(FXM_THREADS), 0, st, (const int *)S->d_wg, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_ld, (const long long *)S->d_xoff,
                        (const double *)S->Wbase, (const double *)S->X, S->part, stride, S->pt);
     for (auto &C : S->C)
@@ -911,6 +1255,11 @@ double   *fxs_Y(fx_shared *S) { return S->Y; }
 
 int fxs_fill_pattern(fx_shared *S, int byte)
 {
+  if (S->sym == 2) {
+    PMH_CHK(fxo_prepare(S));
+    PMH_HIP(hipMemsetAsync(S->Afund, byte, sizeof(double) * (size_t)S->afund_tot, S->ctx->stream));
+    return pmh_sync(S->ctx);
+  }
   PMH_HIP(hipMemsetAsync(S->Wbase, byte, sizeof(double) * (size_t)S->wtot, S->ctx->stream));
   return pmh_sync(S->ctx);
 }
@@ -919,6 +1268,21 @@ int fxs_fill_pattern(fx_shared *S, int byte)
 int fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host)
 {
   const fxs_class    &C = S->C[S->cls[b]];
+  if (S->sym == 2) {
+    // orbit storage (tests: small classes, all representatives on this rank): row r = g p rebuilt from its representative's row
+    if (!S->fxo_ready || C.m0 != 0 || C.m1 != C.M_all) return pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_get_block: the orbit storage holds only this rank's representatives");
+    std::vector<double> T((size_t)C.Mp * C.ldk), row((size_t)C.nc);
+    PMH_HIP(hipMemcpy(T.data(), S->Afund + C.aoff, sizeof(double) * T.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+      const int r = C.pos[gamma[i] - S->K->rowstart[b]], p = C.rep_of[r], g = C.op_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin());
+      const double  sp = (double)C.h_sign[(size_t)g * C.nc + p];
+      const double *ab = T.data() + (size_t)(pl / FXO_TM) * C.nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
+      for (int cc = 0; cc < C.nc; cc++)
+        row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(cc / FXO_TK) * (FXO_TK * FXO_TM) + (cc % FXO_TK) * FXO_TM];
+      for (int k = 0; k < n; k++) out_host[(size_t)i * n + k] = row[C.pos[gamma[k] - S->K->rowstart[b]]];
+    }
+    return PMH_SUCCESS;
+  }
   if (S->sym) {
     // the class's tiles on the host (tests: small classes), W[p][c] from the stored lower triangle
     const long long     len = (long long)FXM_RS * FXM_RS * ((long long)C.nsb * (C.nsb + 1) / 2);

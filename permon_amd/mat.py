@@ -242,13 +242,15 @@ class MatExplicitDual:
     def __init__(self, B, K, storage="sym", block_class=None):
         """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV; "class": congruent blocks
         (block_class from csr_block_classes) share ONE full matrix per class, applied to their vectors together (8 per pass);
-        "class_sym": that matrix kept as its lower block-triangle in 16 x 16 tiles (half the bytes, fp64 MFMA kernel)."""
+        "class_sym": that matrix kept as its lower block-triangle in 16 x 16 tiles (half the bytes, fp64 MFMA kernel);
+        "class_orbit": only the rows of the orbit representatives under the class's symmetries (set_box_symmetry / set_class_symmetry before the
+        assembly): the dense apply is a GEMM on the fp64 matrix instruction."""
         self.ctx, self.B, self.K, self.storage = B.ctx, B, K, storage
         h = C.c_void_p()
-        if storage in ("class", "class_sym"):
+        if storage in ("class", "class_sym", "class_orbit"):
             bc = np.ascontiguousarray(block_class, dtype=np.int32)
             assert bc.size == K.nblocks
-            create = self.ctx.L.pmh_fexplicit_create_shared if storage == "class" else self.ctx.L.pmh_fexplicit_create_shared_sym
+            create = {"class": self.ctx.L.pmh_fexplicit_create_shared, "class_sym": self.ctx.L.pmh_fexplicit_create_shared_sym, "class_orbit": self.ctx.L.pmh_fexplicit_create_shared_orbit}[storage]
             check(create(B.h, K.h, bc.ctypes.data_as(C.c_void_p), C.byref(h)))
         else:
             check(self.ctx.L.pmh_fexplicit_create(B.h, K.h, {"full": 0, "sym": 1}[storage], C.byref(h)))
@@ -304,12 +306,25 @@ class MatExplicitDual:
                                                          va.ctypes.data_as(C.c_void_p), C.byref(n)))
         return n.value
 
+    def refresh_sizes(self):
+        """dense_bytes / gemv_bytes after the plan changed (stripe, symmetries, assembly)."""
+        db, gb = C.c_longlong(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_sizes(self.h, None, None, C.byref(db), C.byref(gb)))
+        self.dense_bytes, self.gemv_bytes = db.value, gb.value
+
+    def apply_flops(self):
+        """"class_orbit": useful flops of one dense apply (its roofline is the fp64 MFMA peak); 0 for the streaming storages."""
+        f = C.c_double()
+        check(self.ctx.L.pmh_fexplicit_apply_flops(self.h, C.byref(f)))
+        return f.value
+
     def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
         """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
         sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None
         bc = np.ascontiguousarray(block_class, dtype=np.int32) if block_class is not None else None
         check(self.ctx.L.pmh_fexplicit_assemble(self.h, solver.h, solver.K.nblocks, sc.ctypes.data_as(C.c_void_p) if sc is not None else None,
                                                 bc.ctypes.data_as(C.c_void_p) if bc is not None else None, float(rtol), int(max_it)))
+        self.refresh_sizes()
 
     def assemble_stats(self):
         n, t = C.c_longlong(), C.c_double()

@@ -25,9 +25,10 @@ runtune() {
     rocprofv3 --pmc $C --kernel-include-regex "k_fx_symv" --output-format csv -d $R/gpurun_out/pmc_$name/pmc_$C/sym -- python3 $R/scripts/symv_tune.py sym 43 8 > $R/gpurun_out/pmc_${name}_$C.log 2>&1
     rocprofv3 --pmc $C --kernel-include-regex "k_fxs_" --output-format csv -d $R/gpurun_out/pmc_$name/pmc_$C/class -- python3 $R/scripts/symv_tune.py class 43 8 >> $R/gpurun_out/pmc_${name}_$C.log 2>&1
     rocprofv3 --pmc $C --kernel-include-regex "k_fxs_sym" --output-format csv -d $R/gpurun_out/pmc_$name/pmc_$C/class_sym -- python3 $R/scripts/symv_tune.py class_sym 43 8 >> $R/gpurun_out/pmc_${name}_$C.log 2>&1
+    rocprofv3 --pmc $C --kernel-include-regex "k_fxo_" --output-format csv -d $R/gpurun_out/pmc_$name/pmc_$C/class_orbit -- python3 $R/scripts/symv_tune.py class_orbit 43 8 >> $R/gpurun_out/pmc_${name}_$C.log 2>&1
     tail -n 1 $R/gpurun_out/pmc_${name}_$C.log | cut -c1-160
   done
-  python3 $R/scripts/pmc_parse.py $R/gpurun_out/pmc_$name "$PMH_GIT" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2) --kernel-include-regex k_fx_symv|k_fxs_ -- python3 scripts/symv_tune.py sym|class|class_sym 43 8 (the configs[2] operators, byte-pattern fill)" \
+  python3 $R/scripts/pmc_parse.py $R/gpurun_out/pmc_$name "$PMH_GIT" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2) --kernel-include-regex k_fx_symv|k_fxs_|k_fxo_ -- python3 scripts/symv_tune.py sym|class|class_sym|class_orbit 43 8 (the configs[2] operators, byte-pattern fill)" \
     && cp $R/gpurun_out/pmc_$name/pmc_traffic.json $R/gpurun_out/r02_pmc_traffic_$name.json
   rm -rf $R/gpurun_out/pmc_$name/pmc_FETCH_SIZE $R/gpurun_out/pmc_$name/pmc_WRITE_SIZE
 }

@@ -1,0 +1,166 @@
+// Feasibility micro-benchmark of the symmetry-reduced dense apply: C[p][(g,s)] = sum_c A[p][c] * sgn(g,c) * X[posmap_g[c]][s]
+// (M orbit representatives x N = nsym * 8 columns x K = n_c) on the fp64 matrix instruction v_mfma_f64_4x4x4_4b_f64, split-K, B gathered from X.
+// hipcc --offload-arch=gfx950 -O3 -DNWM=4 -DNWN=2 -DTK=16 -o /tmp/orbit_gemm scripts/micro/orbit_gemm.hip && /tmp/orbit_gemm [M N_ops K S]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+#ifndef NWM
+#define NWM 4 // waves along M (64 rows each)
+#endif
+#ifndef NWN
+#define NWN 2 // waves along N (64 columns each)
+#endif
+#ifndef TK
+#define TK 16
+#endif
+#define TM (64 * NWM)
+#define TN (64 * NWN)
+#define NT (64 * NWM * NWN)
+#define LDA (TM + 16)
+#define LDB (TN + 4)
+static __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// A pre-tiled: block (mt, kc) = TK k x TM rows, k-major; gidx[g][k] = (position << 1) | negative; X[pos][8]; Cpart[split][Mp][N]
+__global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
+                                                double *__restrict__ Cpart, int Mp, int N)
+{
+  __shared__ double As[2][TK][LDA];
+  __shared__ double Bs[2][TK][LDB];
+  const int wgi = blockIdx.x, s = wgi % S, nt = (wgi / S) % Nt, mt = wgi / (S * Nt);
+  const int kc0 = (int)((long long)nkc * s / S), kc1 = (int)((long long)nkc * (s + 1) / S);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
+  constexpr int NEA = TK * TM / 2 / NT; // dbl2 loads of A per thread and chunk
+  constexpr int KPB = NT / TN;          // k rows of B staged per pass
+  constexpr int NEB = TK / KPB;
+  static_assert(NEA >= 1 && NEB >= 1 && TK % KPB == 0, "tile / thread shape");
+  const int  col = t % TN, kb = t / TN;
+  const int *gp = gidx + (size_t)(nt * (TN / 8) + (col >> 3)) * ldk;
+  const int  sl = col & 7;
+  double     acc[4][16];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[i][j] = 0.0;
+  dbl2   ar[NEA];
+  double br[NEB];
+  int    gn[NEB];
+  auto loadA = [&](int kc) {
+    const double *blk = A + ((size_t)mt * nkc + kc) * (TK * TM);
+#pragma unroll
+    for (int e = 0; e < NEA; e++) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + NT * e)));
+  };
+  auto loadG = [&](int kc, int *g) {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) g[e] = gp[kc * TK + kb + KPB * e];
+  };
+  auto gatherB = [&](const int *g) {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) {
+      const double v = X[(size_t)(g[e] >> 1) * 8 + sl];
+      br[e]          = (g[e] & 1) ? -v : v;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < NEA; e++) {
+      const int q = t + NT * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
+      *(dbl2 *)&As[buf][k][r2] = ar[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
+  };
+  if (kc0 < kc1) {
+    loadG(kc0, gn);
+    loadA(kc0);
+    gatherB(gn);
+    if (kc0 + 1 < kc1) loadG(kc0 + 1, gn);
+    store(0);
+  }
+  __syncthreads();
+  const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
+  for (int kc = kc0; kc < kc1; kc++) {
+    const int buf = (kc - kc0) & 1;
+    if (kc + 1 < kc1) {
+      loadA(kc + 1);
+      gatherB(gn);
+      if (kc + 2 < kc1) loadG(kc + 2, gn);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < TK / 4; k4++) {
+      double a[4], b[16];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
+#pragma unroll
+      for (int j = 0; j < 16; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 4 + cb];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+    }
+    if (kc + 1 < kc1) store(buf ^ 1);
+    __syncthreads();
+  }
+  // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
+  const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  double   *C  = Cpart + (size_t)s * Mp * N;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) C[(size_t)(mt * TM + wm * 64 + i * 16 + rr) * N + nt * TN + wn * 64 + j * 4 + cb] = acc[i][j];
+}
+
+int main(int argc, char **argv)
+{
+  const int M = argc > 1 ? atoi(argv[1]) : 715, nops = argc > 2 ? atoi(argv[2]) : 48, K = argc > 3 ? atoi(argv[3]) : 33288;
+  const int Mp = (M + TM - 1) / TM * TM, N = nops * 8, ldk = (K + TK - 1) / TK * TK, nkc = ldk / TK, Mt = Mp / TM, Nt = N / TN;
+  int       S = std::max(1, std::min(nkc, (256 + Mt * Nt - 1) / (Mt * Nt)));
+  if (argc > 4) S = atoi(argv[4]);
+  printf("tile %d x %d x %d (%d threads): M %d (padded %d) N %d K %d (padded %d): %d x %d tiles, split-K %d -> %d workgroups\n", TM, TN, TK, NT, M, Mp, N, K, ldk, Mt, Nt, S, Mt * Nt * S);
+  if (N % TN) return printf("N must be a multiple of %d\n", TN), 1;
+  std::vector<double> hA((size_t)Mp * ldk, 0.0), hX((size_t)(ldk + 1) * 8, 0.0);
+  std::vector<int>    hg((size_t)nops * ldk);
+  srand(1);
+  auto rnd = []() { return (rand() % 2001 - 1000) / 1000.0; };
+  std::vector<double> Arow((size_t)M * K);
+  for (auto &v : Arow) v = rnd();
+  for (int p = 0; p < M; p++)
+    for (int c = 0; c < K; c++) hA[((size_t)(p / TM) * nkc + c / TK) * (TK * TM) + (size_t)(c % TK) * TM + p % TM] = Arow[(size_t)p * K + c];
+  for (int i = 0; i < K * 8; i++) hX[i] = rnd();
+  for (int g = 0; g < nops; g++)
+    for (int c = 0; c < ldk; c++) hg[(size_t)g * ldk + c] = c < K ? (((rand() % K) << 1) | (rand() & 1)) : (ldk << 1); // pad -> the zero row ldk
+  double *dA, *dX, *dC;
+  int    *dg;
+  (void)hipMalloc(&dA, hA.size() * 8), (void)hipMalloc(&dX, hX.size() * 8), (void)hipMalloc(&dg, hg.size() * 4), (void)hipMalloc(&dC, (size_t)S * Mp * N * 8);
+  (void)hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice), (void)hipMemcpy(dX, hX.data(), hX.size() * 8, hipMemcpyHostToDevice), (void)hipMemcpy(dg, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+  for (int it = 0; it < 3; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  const int reps = 20;
+  for (int it = 0; it < reps; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  printf("%.4f ms per GEMM: %.1f TFLOP/s useful (M N K), %.1f TFLOP/s issued (padded M)\n", ms, 2.0 * M * N * (double)K / ms * 1e-9, 2.0 * Mp * N * (double)ldk / ms * 1e-9);
+  std::vector<double> hC((size_t)S * Mp * N);
+  (void)hipMemcpy(hC.data(), dC, hC.size() * 8, hipMemcpyDeviceToHost);
+  double err = 0.0, ref_max = 0.0;
+  for (int tcase = 0; tcase < 200; tcase++) {
+    const int p = rand() % M, g = rand() % nops, sl = rand() % 8;
+    double    ref = 0.0, got = 0.0;
+    for (int c = 0; c < K; c++) {
+      const int gi = hg[(size_t)g * ldk + c];
+      ref += Arow[(size_t)p * K + c] * ((gi & 1) ? -1.0 : 1.0) * hX[(size_t)(gi >> 1) * 8 + sl];
+    }
+    for (int s = 0; s < S; s++) got += hC[((size_t)s * Mp + p) * N + g * 8 + sl];
+    err = std::max(err, std::fabs(got - ref)), ref_max = std::max(ref_max, std::fabs(ref));
+  }
+  printf("max |C - ref| over 200 samples: %.3e (max |ref| %.3e) %s\n", err, ref_max, err <= 1e-10 * std::max(1.0, ref_max) ? "OK" : "WRONG");
+  return 0;
+}

@@ -30,9 +30,11 @@ def test_default_workload_line_small():
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # the headline path: explicit local dual operators (fp64 GEMV); the inner-Krylov path and its strict-fp64 variant ride along
-    assert d["config"]["kplus"]["path"] == "explicit" and any(k in r["kernel"] for k in ("k_fx_symv", "k_fxs_gemm8", "k_fxs_symm8")) and r["launches_timed"] > 0
+    # congruent cubes: the orbit storage (GEMM on the fp64 matrix instruction, compute-bound) is the default; the HBM-bound storages otherwise
+    assert (r["bound"], r["unit"], r["peak"]) in (("hbm", "GB/s", 8000.0), ("mfma", "TFLOP/s", 78.6)) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the headline path: explicit local dual operators; the inner-Krylov path and its strict-fp64 variant ride along
+    assert d["config"]["kplus"]["path"] == "explicit" and any(k in r["kernel"] for k in ("k_fx_symv", "k_fxs_gemm8", "k_fxs_symm8", "k_fxo_gemm")) and r["launches_timed"] > 0
+    assert d["config"]["kplus"]["storage"] == "class_orbit" and r["bound"] == "mfma" and d["config"]["kplus"]["setup_symmetries"] == 48
     st = d["config"]["steps_by_type"]
     assert st["cg"] + st["expansion"] + st["proportioning"] == 30 and st["solves"] >= 1
     for k in ("iterative", "strict_fp64"):

@@ -124,7 +124,7 @@ def test_explicit_setup_by_symmetry(ctx, sub, nel, nsym):
     nn = nel + 1
     loc = f.subset(range(f.nsub))
     q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym"))
-    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym", symmetry=dict(dims=(nn, nn, nn), ndof=3, orbit=False)))
     # 2 x 2 x 2 cubes: the union of the touched faces is the whole boundary, closed under all 48 operations; 2 x 2 x 1: the operations that keep
     # the touched set (no top face) are kept, the others dropped
     assert q.explicit_symmetries == nsym
@@ -151,6 +151,48 @@ def test_explicit_setup_by_symmetry(ctx, sub, nel, nsym):
     with pytest.raises(Exception, match="symmetr"):
         E.assemble(q2.Kplus, slot_class=cls, block_class=cls, rtol=1e-13)
     E.destroy()
+
+
+@pytest.mark.parametrize("sub,nel,nsym", [((2, 2, 2), 2, 48), ((2, 2, 2), 5, 48), ((2, 2, 1), 5, 8)])
+def test_explicit_orbit_storage(ctx, sub, nel, nsym):
+    """PMH_FX_CLASS_ORBIT: only the rows of W_c of the orbit representatives under the cube's symmetries are stored; the dense apply is the GEMM
+    (representatives) x (operations x 8 right-hand sides) on the fp64 matrix instruction.  Every W_b rebuilt from it equals pinv(K_b) on Gamma_b,
+    F = B pinv(K) B', bitwise reproducible; three ranks' shares of the representatives sum to F."""
+    f = pa.CubeFeti(sub, nel, contact=True)
+    G, e = f.coarse()
+    nn = nel + 1
+    loc = f.subset(range(f.nsub))
+    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    assert q.explicit_storage == "class_orbit" and q.explicit_symmetries == nsym
+    n_c = q.E.class_union(0).size
+    assert q.E.assemble_stats()[0] < n_c / (nsym / 8.0) + f.nsub and q.E.dense_bytes < 8.0 * n_c * n_c / (nsym / 8.0) and q.E.apply_flops() > 0
+    Fref, Kp = _dense_F(f)
+    for b in range(f.nsub):
+        W, g = q.E.block(b)
+        gl = g - b * f.n_i
+        ref = Kp[np.ix_(gl, gl)]
+        assert np.max(np.abs(W - ref)) <= 1e-10 * np.max(np.abs(ref))
+    rng = np.random.default_rng(6)
+    lam = rng.standard_normal(f.n_lambda)
+    lv, y, y2 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    q.F.mult(lv, y)
+    q.F.mult(lv, y2)
+    assert np.array_equal(y.to_numpy(), y2.to_numpy())
+    assert np.linalg.norm(y.to_numpy() - Fref @ lam) <= 1e-10 * np.linalg.norm(Fref @ lam)
+    # the auto rule: with >= 16 operations "class_sym" + symmetry turns into the orbit storage, with fewer it stays on the symmetric tiles
+    q3 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_sym", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    assert q3.explicit_storage == ("class_orbit" if nsym >= 16 else "class_sym")
+    # several GPUs rehearsed: a contiguous range of the representatives per rank
+    glob = dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign)
+    tot = np.zeros(f.n_lambda)
+    for r in range(3):
+        lr = f.subset([r])
+        qr = FetiDualQP(ctx, lr, G, e, f.c, f.lb, kplus_rtol=1e-13)
+        qr.assemble_explicit(lr, rtol=1e-13, stripe=(r, 3, glob), storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3))
+        yr = ctx.vec(f.n_lambda)
+        qr.F.mult(lv, yr)
+        tot += yr.to_numpy()
+    assert np.linalg.norm(tot - Fref @ lam) <= 1e-10 * np.linalg.norm(Fref @ lam)
 
 
 def test_explicit_contact_solve_same_counts(ctx):
@@ -211,7 +253,7 @@ def test_striped_shares_sum_to_F(ctx, storage):
         # rank r owns blocks [r] only (a 1-block K^+), but applies its stripes of ALL four W_b
         lr = f.subset([r])
         q = FetiDualQP(ctx, lr, G, e, f.c, f.lb, kplus_rtol=1e-13)
-        sym = dict(dims=(f.nel + 1,) * 3, ndof=3) if storage == "class_sym" else None  # the 4-mega-band case also takes its rows from orbit representatives
+        sym = dict(dims=(f.nel + 1,) * 3, ndof=3, orbit=False) if storage == "class_sym" else None  # the 4-mega-band case also takes its rows from orbit representatives
         E = q.assemble_explicit(lr, rtol=1e-13, stripe=(r, 3, glob), storage=storage, symmetry=sym)
         y, y2 = ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
         q.F.mult(lv, y)
