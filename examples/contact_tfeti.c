@@ -5,7 +5,7 @@
  *   int32 header[8] = {magic 0x504D4831, nsub, N, nnz, n_lambda, n_eq, n_leaves, kdim}, int32 ndof, int32 dims[3 nsub],
  *   int32 block_rowstart[nsub+1], rowptr[N+1], col[nnz], leaves_row[n_leaves], leaves_root[n_leaves]; then float64 val[nnz], f[N],
  *   leaves_val[n_leaves], c[n_lambda], R[kdim N].
- * usage: contact_tfeti problem.bin [explicit=1] [mg_precision 0|1|2] [explicit_storage 0|1|2]      prints the -qps_view_convergence block and checks of the solution */
+ * usage: contact_tfeti problem.bin [explicit=1] [mg_precision 0|1|2] [explicit_storage 0|1|2|3|4]      prints the -qps_view_convergence block and checks of the solution */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,7 +61,7 @@ int main(int argc, char **argv)
   CHECK(pmh_feti_contact_default_opts(&o));
   if (argc > 2) o.explicit_dual = atoi(argv[2]);
   if (argc > 3) o.mg_precision = atoi(argv[3]);
-  if (argc > 4) o.explicit_storage = atoi(argv[4]); /* 1 PMH_FX_SYM (default), 0 PMH_FX_FULL, 2 PMH_FX_CLASS, 3 PMH_FX_CLASS_SYM */
+  if (argc > 4) o.explicit_storage = atoi(argv[4]); /* 1 PMH_FX_SYM (default), 0 PMH_FX_FULL, 2 PMH_FX_CLASS, 3 PMH_FX_CLASS_SYM, 4 PMH_FX_CLASS_ORBIT */
   double *u = (double *)malloc(sizeof(double) * N), *lam = (double *)malloc(sizeof(double) * nl);
   CHECK(pmh_feti_contact_solve(ctx, nsub, rs, rp, ci, va, f, nl, neq, nleaf, lrow, lroot, lval, c, kdim, R, dims, *ndof, &o, u, lam, &st));
 

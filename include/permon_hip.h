@@ -545,9 +545,9 @@ typedef struct {
   double kplus_rtol; int kplus_max_it;
   int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
-  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM) */
+  int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM / PMH_FX_CLASS_ORBIT) */
   int    orthonormalize;            /* QPTOrthonormalizeEq: 1 G <- L^{-1} G formed explicitly, 2 implicitly (G stays sparse, -qp_E_orth_form implicit), 0 none */
-  int    explicit_symmetry;         /* PMH_FX_CLASS_SYM with dims != NULL: set-up by the symmetries of the box (pmh_fexplicit_set_box_symmetry) */
+  int    explicit_symmetry;         /* PMH_FX_CLASS_SYM / _ORBIT with dims != NULL: the symmetries of the box (pmh_fexplicit_set_box_symmetry) serve the set-up / the storage */
 } pmh_feti_contact_opts;
 typedef struct {
   pmh_smalxe_stats smalxe;

@@ -311,7 +311,7 @@ def FETIContactSolve(ctx, f, explicit=True, mg_precision="fp16", rtol=1e-5, kplu
     o.smalxe.rtol, o.kplus_rtol, o.explicit_dual, o.explicit_rtol = rtol, kplus_rtol, int(bool(explicit)), explicit_rtol
     o.mg_precision, o.mg_min_nodes = {"fp64": 0, "fp32": 1, "fp16": 2}[mg_precision], int(mg_min_nodes)
     if explicit_storage is not None:
-        o.explicit_storage = {"full": 0, "sym": 1, "class": 2, "class_sym": 3}[explicit_storage]
+        o.explicit_storage = {"full": 0, "sym": 1, "class": 2, "class_sym": 3, "class_orbit": 4}[explicit_storage]
     o.explicit_symmetry = int(bool(explicit_symmetry))
     if dims is None and hasattr(f, "nel"):
         dims = [(f.nel + 1,) * 3] * f.nsub

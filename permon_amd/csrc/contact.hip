@@ -183,18 +183,17 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       std::vector<int> cls(nsub);
       GO(pmh_csr_block_classes(nsub, block_rowstart, rowptr, col, val, cls.data(), nullptr));
       // blocks of one class share K, hence K^+ (the Moore-Penrose inverse does not depend on the basis chosen for the kernel)
-      if (o->explicit_storage == PMH_FX_CLASS) GO(pmh_fexplicit_create_shared(B, Kb, cls.data(), &E)); // congruent blocks share one matrix per class
-      else if (o->explicit_storage == PMH_FX_CLASS_SYM) GO(pmh_fexplicit_create_shared_sym(B, Kb, cls.data(), &E));
-      else GO(pmh_fexplicit_create(B, Kb, o->explicit_storage, &E));
-      if (o->explicit_storage == PMH_FX_CLASS_SYM && dims && o->explicit_symmetry) {
-        // box-shaped blocks: one K^+ solve per orbit of rows under the symmetries of the box that leave the class matrix invariant
-        int ncls = 0;
-        for (int b = 0; b < nsub; b++) ncls = std::max(ncls, cls[b] + 1);
+      int ncls = 0;
+      for (int b = 0; b < nsub; b++) ncls = std::max(ncls, cls[b] + 1);
+      // box-shaped blocks: the symmetries of the box that leave the class matrix invariant -> one K^+ solve per orbit of rows (PMH_FX_CLASS_SYM), or only the
+      // representatives' rows kept and F's dense part applied as a GEMM (PMH_FX_CLASS_ORBIT; falls back to the symmetric tiles when a class has < 16 operations)
+      auto set_symmetries = [&](int *least) -> int {
+        *least = 1 << 30;
         for (int c = 0; c < ncls; c++) {
           int b0 = 0;
           while (b0 < nsub && cls[b0] != c) b0++;
           const int r0 = block_rowstart[b0], r1 = block_rowstart[b0 + 1];
-          std::vector<int> rp((size_t)(r1 - r0) + 1), cj;
+          std::vector<int>    rp((size_t)(r1 - r0) + 1), cj;
           std::vector<double> vj;
           rp[0] = 0;
           for (int i = r0; i < r1; i++) {
@@ -203,8 +202,30 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
             rp[i - r0 + 1] = (int)cj.size();
           }
           int used = 1;
-          GO(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rp.data(), cj.data(), vj.data(), &used));
+          PMH_CHK(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rp.data(), cj.data(), vj.data(), &used));
           st->explicit_symmetries = std::max(st->explicit_symmetries, used);
+          *least = std::min(*least, used);
+        }
+        return PMH_SUCCESS;
+      };
+      int storage = o->explicit_storage;
+      if (storage == PMH_FX_CLASS_ORBIT && !(dims && o->explicit_symmetry)) storage = PMH_FX_CLASS_SYM;
+      if (storage == PMH_FX_CLASS_ORBIT) {
+        int least = 0;
+        GO(pmh_fexplicit_create_shared_orbit(B, Kb, cls.data(), &E));
+        GO(set_symmetries(&least));
+        if (least < 16) { // too few operations for the GEMM form
+          pmh_fexplicit_destroy(E);
+          E = nullptr, storage = PMH_FX_CLASS_SYM, st->explicit_symmetries = 0;
+        }
+      }
+      if (!E) {
+        if (storage == PMH_FX_CLASS) GO(pmh_fexplicit_create_shared(B, Kb, cls.data(), &E)); // congruent blocks share one matrix per class
+        else if (storage == PMH_FX_CLASS_SYM) GO(pmh_fexplicit_create_shared_sym(B, Kb, cls.data(), &E));
+        else GO(pmh_fexplicit_create(B, Kb, storage, &E));
+        if (storage == PMH_FX_CLASS_SYM && dims && o->explicit_symmetry) {
+          int least = 0;
+          GO(set_symmetries(&least));
         }
       }
       GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));

@@ -12,7 +12,8 @@ import permon_amd as pa  # noqa: E402
 nel = int(sys.argv[1]) if len(sys.argv) > 1 else 43
 ctx = pa.Context(0)
 f = pa.CubeFeti((2, 2, 2), nel, contact=True)
-cases = [("explicit class_sym, set-up by symmetry", dict(explicit=True, explicit_storage="class_sym", explicit_symmetry=True)),
+cases = [("explicit class_orbit (representatives' rows, GEMM apply)", dict(explicit=True, explicit_storage="class_orbit", explicit_symmetry=True)),
+         ("explicit class_sym, set-up by symmetry", dict(explicit=True, explicit_storage="class_sym", explicit_symmetry=True)),
          ("inner-Krylov K^+ (fp16 V-cycle PC)", dict(explicit=False))]
 if len(sys.argv) > 2:
     cases.append(("explicit class_sym, one solve per row", dict(explicit=True, explicit_storage="class_sym", explicit_symmetry=False)))

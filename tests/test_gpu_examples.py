@@ -53,7 +53,7 @@ def test_example_output_equals_the_reference_golden_file(goldens, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("explicit,storage", [(1, 1), (1, 2), (1, 3), (0, 1)])
+@pytest.mark.parametrize("explicit,storage", [(1, 1), (1, 2), (1, 3), (1, 4), (0, 1)])
 def test_contact_example_reproduces_the_python_chain(tmp_path, explicit, storage):
     """examples/contact_tfeti.c = pmh_feti_contact_solve from plain C (hierarchy built by pmh_mg_create_box, explicit dual operators,
     SMALXE + MPGP, rigid-body recovery, no Python in the solve) against the Python-orchestrated chain on the same problem: identical
@@ -75,7 +75,7 @@ def test_contact_example_reproduces_the_python_chain(tmp_path, explicit, storage
     G, e = f.coarse(orthonormalize=False)  # orthonormalised implicitly by the library, as pmh_feti_contact_solve does by default
     nn = f.nel + 1
     hier = pa.box_mg_hierarchy([f.Ki] * f.nsub, [(nn, nn, nn)] * f.nsub, 3, min_nodes=400)
-    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal="implicit", kplus_rtol=1e-9, mg_hierarchy=hier, mg_precision="fp16", bsr3=True, explicit=dict(rtol=1e-12, storage={0: "full", 1: "sym", 2: "class", 3: "class_sym"}[storage]) if explicit else None)  # the same storage = the same rounding as the C run
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal="implicit", kplus_rtol=1e-9, mg_hierarchy=hier, mg_precision="fp16", bsr3=True, explicit=dict(rtol=1e-12, storage={0: "full", 1: "sym", 2: "class", 3: "class_sym", 4: "class_orbit"}[storage], **({"symmetry": dict(dims=(9, 9, 9), ndof=3)} if storage == 4 else {})) if explicit else None)  # the same storage = the same rounding as the C run
     st = q.solve_smalxe(rtol=1e-5)
     want = q.qps.ViewConvergence()
     # the C program prints the same block (its first line without the reason's name)
