@@ -16,21 +16,21 @@ for n, f in [(1, "default"), (2, "sim2"), (4, "sim4"), (8, "sim8")]:
     rows.append((n, d["ms_per_step"], c["operator_applies"], c["ms_per_operator_apply"], r["avg_launch_ms"], r["frac"], k["assemble_solves"], k["assemble_seconds"]))
 base, mix, a8 = rows[0][3], rows[0][2] / 216.0, rows[3][3]
 out = ["# bench.py --no-cpu-baseline --no-c2 --sim-world N: rank 0's share of an N-GPU run of configs[2] on ONE MI355X (no collective); explicit local dual operators,",
-       "# class-shared symmetric tile storage (PMH_FX_CLASS_SYM, k_fxs_symm8), whole mega bands of 1024 rows dealt in snake order, G orthonormalised implicitly, set-up by symmetry,",
-       "# one host round trip per step (final round-2 state; N = 1 = profiles/r02_bench_default_1gpu.json).",
+       "# orbit storage (PMH_FX_CLASS_ORBIT: the representatives' rows, k_fxo_gemm on the fp64 matrix instruction), every rank multiplies a contiguous share of the k range, G orthonormalised",
+       "# implicitly, one host round trip per step (final round-2 state; N = 1 = profiles/r02_bench_default_1gpu.json).",
        "# A lone share of F is not F: the rehearsed solver follows ANOTHER trajectory (other CG / expansion mix, other number of outer iterations), so ms/step is not comparable",
        "# across N -- the comparable number is the time per operator application (one F apply + its share of the dual-space work); the projection puts it back on the",
        "# real step mix of the N = 1 run (%.2f applications per step) and adds nothing for the all-reduce of 0.82 MB per application (unmeasured here)." % mix,
-       "# N  ms/step(as run)  applications  ms/application  speed-up per application  dense apply ms (k_fxs_symm8+symfin)  frac of 8 TB/s  projected ms/step on the real mix  set-up solves  s"]
+       "# N  ms/step(as run)  applications  ms/application  speed-up per application  dense apply ms (k_fxo_gemm+fin)  frac of the 78.6 TFLOP/s fp64 matrix peak  projected ms/step on the real mix  set-up solves  s"]
 for n, ms, na, mpa, dl, fr, ns, sec in rows:
     out.append(" %d   %7.3f   %4d   %7.4f   %5.2fx   %7.4f   %5.3f   %7.3f   %6d  %5.1f" % (n, ms, na, mpa, base / mpa, dl, fr, mpa * mix, ns, sec))
 proj = (a8 + 0.035) * mix
 out += ["# => the dense apply scales %.1fx to N = 8 (%.3f -> %.3f ms); ~%.2f ms of REPLICATED dual-space launches per application (projector G0 / G0', gluing, MPGP vector kernels:" % (rows[0][4] / rows[3][4], rows[0][4], rows[3][4], a8 - rows[3][4]),
         "#    profiles/r02_b_per_step_kernels_rehearsal8.txt) do not shrink: %.1fx per application before communication; with ~35 us per all-reduce: (%.3f + 0.035) * %.2f = %.3f ms per step" % (base / a8, a8, mix, proj),
         "#    = ~%d it/s projected at N = 8 (%.1fx the 1-GPU %.0f it/s).  Earlier states of this round, per application at the 1/8 share: 0.454 ms (per-block SYM storage, 5.5x), 0.270 ms (class-shared symmetric" % (round(1000 / proj, -1), rows[0][1] / proj, 1000 / rows[0][1]),
-        "#    tiles, 3.4x), 0.230 (implicit orthonormalisation), 0.211 (8-lane finishing kernel, folded projector kernels); round 1 (inner-Krylov K^+): 4.8x (4.2 ms per step, ~240 it/s).",
-        "#    The ratio fell while every absolute number rose: the 1-GPU application got 10x faster than round 1's, the N = 8 share 20x.",
-        "#    Set-up by symmetry: every rank solves the (at most 715) orbit representatives its rows need: ~1.1 s at every N (column 'set-up solves')."]
+        "#    tiles, 3.4x), 0.230 (implicit orthonormalisation), 0.199 (8-lane finishing kernel, folded projector kernels, one host round trip per step; 4.2x); round 1 (inner-Krylov K^+): 4.8x (4.2 ms per step, ~240 it/s).",
+        "#    The ratio fell while every absolute number rose: the replicated dual-space launches (~0.09 ms per application) do not shrink with N.",
+        "#    Set-up: every rank solves all 715 orbit representatives itself (+ the self-check batch): ~1.1 s at every N (column 'set-up solves')."]
 open("profiles/r02_c_strong_scaling_rehearsal_explicit.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out[7:]))
 shutil.copy("gpurun_out/bench_r02_default.json", "profiles/r02_bench_default_1gpu.json")
@@ -39,7 +39,7 @@ for n in (2, 4, 8):
 shutil.copy("gpurun_out/bench_r02_c3.json", "profiles/r02_c_bench_configs3_shape_1gpu.json")
 shutil.copy("gpurun_out/bench_r02_c3_sim8.json", "profiles/r02_c_bench_configs3_shape_share_of_8.json")
 for tag, name, head in (("ex1", "n1", ["# rocprofv3 --kernel-trace --marker-trace --stats --selected-regions -- python3 bench.py --no-cpu-baseline --no-c2 --no-iterative : the TIMED REGION only (roctxProfilerResume / Pause, PMH_BENCH_ROCTX=1);",
-                                       "# default bench (class-shared explicit operator in symmetric tiles, implicit orthonormalisation of G), N = 1.  scripts/gpu_prof_r02.sh + scripts/per_step.py, final round-2 state"]),
+                                       "# default bench (orbit storage of the class-shared explicit operator, implicit orthonormalisation of G), N = 1.  scripts/gpu_prof_r02.sh + scripts/per_step.py, final round-2 state"]),
                         ("ex8", "rehearsal8", ["# the same for rank 0's share of an 8-GPU run (bench.py --sim-world 8): the replicated dual-space launches are half of the step"])):
     f = max(glob.glob("gpurun_out/prof_%s/*/*kernel_stats.csv" % tag), key=os.path.getmtime)
     txt = subprocess.run([sys.executable, "scripts/per_step.py", f, "gpurun_out/prof_%s.json" % tag], capture_output=True, text=True, check=True).stdout
