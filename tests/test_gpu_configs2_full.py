@@ -102,18 +102,20 @@ def test_full_size_solution_properties(c2):
     assert np.linalg.norm(y1.to_numpy() - y2.to_numpy()) <= 1e-9 * np.linalg.norm(y2.to_numpy())
 
 
-def test_full_size_headline_path(c2):
-    """The bench's headline configuration at full size: ONE symmetric class matrix for the 8 congruent cubes (PMH_FX_CLASS_SYM, k_fxs_symm8), assembled
-    by symmetry (715 orbit representatives + the self-check batch instead of 33 288 rows), G orthonormalised implicitly -- the same solver counts as every
-    other K^+, the same dual solution, and F lambda equal to the per-block operators' to the set-up tolerance."""
+@pytest.mark.parametrize("storage", ["class_orbit", "class_sym"])
+def test_full_size_headline_path(c2, storage):
+    """The bench's headline configurations at full size: ONE symmetric class matrix for the 8 congruent cubes -- "class_orbit": only the rows of the 715 orbit
+    representatives under the cube's 48 symmetries, applied as a GEMM on the fp64 matrix instruction (k_fxo_gemm, the default); "class_sym": the lower
+    block-triangle in tiles (k_fxs_symm8), assembled by symmetry -- G orthonormalised implicitly: the same solver counts as every other K^+, the same dual
+    solution, and F lambda equal to the per-block operators' (33 288 direct solves) to the set-up tolerance."""
     ctx, f, G, e, hier, q = c2
     st_ref, lam_ref = _solve(q)
     G0, e0 = f.coarse(orthonormalize=False)
     qh = FetiDualQP(ctx, f.subset(range(8)), G0, e0, f.c, f.lb, orthonormal="implicit", kplus_rtol=1e-9, mg_hierarchy=hier, mg_degree=2, mg_precision="fp16", bsr3=True,
-                    explicit=dict(rtol=1e-12, storage="class_sym", symmetry=dict(dims=(44, 44, 44), ndof=3)))
-    assert qh.explicit_symmetries == 48
+                    explicit=dict(rtol=1e-12, storage=storage, symmetry=dict(dims=(44, 44, 44), ndof=3, orbit=storage == "class_orbit")))
+    assert qh.explicit_symmetries == 48 and qh.explicit_storage == storage
     n_solves, secs = qh.E.assemble_stats()
-    assert 700 <= n_solves <= 760 and qh.E.dense_bytes < 4.7e9
+    assert 700 <= n_solves <= 760 and qh.E.dense_bytes < (0.2e9 if storage == "class_orbit" else 4.7e9)
     st, lam = _solve(qh)
     assert st.reason == 2 and _counts(st) == COUNTS
     assert np.linalg.norm(lam - lam_ref) <= 1e-6 * np.linalg.norm(lam_ref)
