@@ -99,6 +99,15 @@ __global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, 
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 16; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+#ifdef SGB
+      // interleave: 1 LDS read per 3 MFMAs (20 reads, 64 MFMAs per k4-step)
+#pragma unroll
+      for (int g = 0; g < 20; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); // MFMA
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
     }
     if (kc + 1 < kc1) store(buf ^ 1);
     __syncthreads();
