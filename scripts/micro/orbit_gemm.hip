@@ -16,15 +16,21 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 #ifndef TK
 #define TK 16
 #endif
+#ifndef WTN
+#define WTN 64 // columns of a wave's tile
+#endif
 #define TM (64 * NWM)
-#define TN (64 * NWN)
+#define TN (WTN * NWN)
 #define NT (64 * NWM * NWN)
 #define LDA (TM + 16)
 #define LDB (TN + 4)
 static __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 // A pre-tiled: block (mt, kc) = TK k x TM rows, k-major; gidx[g][k] = (position << 1) | negative; X[pos][8]; Cpart[split][Mp][N]
-__global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
+#ifndef MINB
+#define MINB 1
+#endif
+__global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
                                                 double *__restrict__ Cpart, int Mp, int N)
 {
   __shared__ double As[2][TK][LDA];
@@ -39,11 +45,11 @@ __global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, 
   const int  col = t % TN, kb = t / TN;
   const int *gp = gidx + (size_t)(nt * (TN / 8) + (col >> 3)) * ldk;
   const int  sl = col & 7;
-  double     acc[4][16];
+  double     acc[4][WTN / 4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 16; j++) acc[i][j] = 0.0;
+    for (int j = 0; j < WTN / 4; j++) acc[i][j] = 0.0;
   dbl2   ar[NEA];
   double br[NEB];
   int    gn[NEB];
@@ -90,15 +96,15 @@ __global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, 
     }
 #pragma unroll
     for (int k4 = 0; k4 < TK / 4; k4++) {
-      double a[4], b[16];
+      double a[4], b[WTN / 4];
 #pragma unroll
       for (int i = 0; i < 4; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
 #pragma unroll
-      for (int j = 0; j < 16; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 4 + cb];
+      for (int j = 0; j < WTN / 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WTN + j * 4 + cb];
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < WTN / 4; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
 #ifdef SGB
       // interleave: 1 LDS read per 3 MFMAs (20 reads, 64 MFMAs per k4-step)
 #pragma unroll
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(NT, 1) void k_gemm(int Mt, int Nt, int S, int nkc, 
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 16; j++) C[(size_t)(mt * TM + wm * 64 + i * 16 + rr) * N + nt * TN + wn * 64 + j * 4 + cb] = acc[i][j];
+    for (int j = 0; j < WTN / 4; j++) C[(size_t)(mt * TM + wm * 64 + i * 16 + rr) * N + nt * TN + wn * WTN + j * 4 + cb] = acc[i][j];
 }
 
 int main(int argc, char **argv)
