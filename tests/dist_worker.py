@@ -107,6 +107,15 @@ def main():
     tc = torch.from_numpy(Yc.copy())
     dist.all_reduce(tc)
     assert np.linalg.norm(tc.numpy() - Wc @ Xc) <= 1e-12 * np.linalg.norm(Wc @ Xc)
+    # ---- the orbit storage (PMH_FX_CLASS_ORBIT): every rank keeps all representatives' rows and multiplies a contiguous share of the k range (chunks
+    # of 16 columns, [nkc r / N, nkc (r + 1) / N)); the partial Y need no collective of their own -- the all-reduce that ends B Y sums them
+    Mr, Kc_, Nc = 37, 1000, 24
+    Af, Bf = rngc.standard_normal((Mr, Kc_)), rngc.standard_normal((Kc_, Nc))
+    nkc = -(-Kc_ // 16)
+    k0, k1 = 16 * (nkc * rank // world), min(Kc_, 16 * (nkc * (rank + 1) // world))
+    tp = torch.from_numpy(Af[:, k0:k1] @ Bf[k0:k1])
+    dist.all_reduce(tp)
+    assert np.linalg.norm(tp.numpy() - Af @ Bf) <= 1e-12 * np.linalg.norm(Af @ Bf)
     # 128-byte communicator id broadcast (what bench.py does with the ncclUniqueId)
     idt = torch.arange(128, dtype=torch.uint8) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
     dist.broadcast(idt, 0)
