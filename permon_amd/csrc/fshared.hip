@@ -11,6 +11,13 @@
 // The gluing over the multivector numbering (index = (position in U_c) * 8 + slot of the block) is a pmh_gluing, so
 //   F lambda = Bc' -> X,  Y = W_c X,  Bc Y (+ all-reduce)           stays three launches.
 // Set-up: one K^+ solve per dof of U_c (what the per-block storage already did for congruent blocks), each giving one full row of W_c.
+//
+// Three storages of W_c live in this file (fx_shared::sym):
+//   0  PMH_FX_CLASS        the full matrix, k_fxs_gemm8: 8 n_c^2 bytes per apply, HBM-bound
+//   1  PMH_FX_CLASS_SYM    its lower block-triangle in 16 x 16 tiles, k_fxs_symm8 (both products of a tile on the fp64 matrix instruction): 4 n_c^2 bytes, HBM-bound
+//   2  PMH_FX_CLASS_ORBIT  only the rows of the orbit representatives under the class's symmetries, k_fxo_gemm: a GEMM on the fp64 matrix instruction,
+//                          4 n_c^2 / 24 bytes for the cube's 48 operations, compute-bound (the default for congruent cubes)
+// and the set-up by symmetry (fxs_set_symmetry: one K^+ solve per orbit of rows, self-checked against direct solves) serves 1 and 2.
 #include <algorithm>
 #include <chrono>
 #include <map>
