@@ -188,13 +188,13 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
         "setup_seconds": round(t_setup, 2),
         "roofline": {
-            "bound": "hbm", "kernel": "k_spmv_stream<MPGP epilogue> (Ap = A p fused with p'Ap, g'p, QPCFeas)",
+            "bound": "hbm", "kernel": "k_spmv_ell<MPGP epilogue> (uniformly short rows: slot-major device copy, one thread per row, no LDS staging; k_spmv_stream otherwise): Ap = A p fused with p'Ap, g'p, QPCFeas",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            **dict(zip(("traffic", "traffic_source"), pmc_lookup("void k_spmv_stream<3,", "r02_pmc_traffic_c2.json") if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
+            **dict(zip(("traffic", "traffic_source"), (lambda t: t if t[0] is not None else pmc_lookup("void k_spmv_stream<3,", "r02_pmc_traffic_c2.json"))(pmc_lookup("void k_spmv_ell<3,", "r02_pmc_traffic_c2.json")) if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
             "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
             "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
             "note": "algorithmic bytes are SURVEY 8d's CSR figure (12 B per non-zero: fp64 value + int32 column); the kernel streams a device-private copy of the columns as 16-bit offsets "
-                    "per row block (banded matrix), so its HBM traffic (PMC) is BELOW the algorithmic bytes: 2 B per non-zero less",
+                    "per row block (banded matrix), so its HBM traffic (PMC) is BELOW the algorithmic bytes: 2 B per non-zero less (rows padded to the longest row: +2 % for the 5-point Laplacian)",
         },
     }
     A.timing_enable(0)

@@ -67,6 +67,12 @@ struct pmh_csr_s {
   int      *d_rowblocks;   // STREAM kind: row block boundaries [n_rowblocks+1]
   unsigned short *d_col16; // STREAM kind, short rows: 16-bit column offsets from d_cbase[row block] (nullptr: a row block spans >= 65 536 columns)
   int      *d_cbase;
+  // STREAM kind, uniformly short rows (<= 8 non-zeros, little padding): slot-major copy per block of 256 rows (k_spmv_ell, no LDS staging)
+  double         *d_ell_val;
+  unsigned short *d_ell_c16; // offsets from d_ell_cbase[row block] (blocks span < 65 536 columns) ...
+  int            *d_ell_col; // ... or absolute columns
+  int            *d_ell_cbase;
+  int             ell_w, ell_nrb;
   int       st_nnzb, st_mode, st_nt, st_rl; // STREAM kind: tile size, persistence mode, non-temporal streams
   int       n_rowblocks;
   double   *d_blockpart;   // [4][n_launch_blocks] partials of the fused MPGP epilogue

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PMH_BENCH_NO_TIMING=1
-name=c2; rx="k_spmv_stream|k_step_update|k_dir_update"
+name=c2; rx="k_spmv_stream|k_spmv_ell|k_step_update|k_dir_update"
 mkdir -p $R/gpurun_out/pmc_$name
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-include-regex "$rx" --output-format csv -d $R/gpurun_out/pmc_$name/pmc_$C -- python3 $R/bench.py --workload c2 --no-cpu-baseline --steps 50 --warmup 5 > $R/gpurun_out/pmc_${name}_$C.log 2>&1

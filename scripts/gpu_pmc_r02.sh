@@ -37,4 +37,4 @@ echo "explicit done"
 [ -n "$PMH_PMC_ONLY_EXPLICIT" ] && exit 0
 run feti_iterative "bsr3" --no-cpu-baseline --no-c2 --no-iterative --kplus iterative --steps 20 --warmup 2
 echo "iterative done"
-run c2 "k_spmv_stream|k_step_update|k_dir_update" --workload c2 --no-cpu-baseline --steps 50 --warmup 5
+run c2 "k_spmv_stream|k_spmv_ell|k_step_update|k_dir_update" --workload c2 --no-cpu-baseline --steps 50 --warmup 5
