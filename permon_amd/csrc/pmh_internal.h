@@ -103,7 +103,7 @@ struct pmh_spmv_epi {
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
 inline void pmh_csr_set_host_hint(pmh_csr A, const int *rowptr, const int *col, const double *val) { A->h_rowptr = rowptr, A->h_col = col, A->h_val = val; }
 int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part); // chunk sums of A x (long rows), summed by the consumer
-int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y); // y = M (A x), Mt = M' (m x m, device)
+int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y, int norm_slot = -1); // y = M (A x), Mt = M' (m x m, device); norm_slot >= 0 (m <= 64): ||y||^2 -> d_scal / h_scal[slot]
 
 // ---- operators -------------------------------------------------------------------------------------------
 struct pmh_op_s {
@@ -142,6 +142,7 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
+int pmh_qppf_apply_G_norm2(pmh_qppf pf, const double *v, double *Gv, int slot);          // qppf.hip: G v and ||G v||^2 -> scalar slot, enqueue only
 int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user);             // mpgp.hip: see there
 #define PMH_SLOT_NORMBU2 48 // ||B u||^2 prefetched for SMALXE's inner convergence test
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]

@@ -280,6 +280,15 @@ extern "C" int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv)
   return pmh_csr_mult(pf->G, v, Gv);
 }
 
+// G v and ||G v||^2 (-> scalar slot, device + pinned host) without waiting: one launch pair where the implicit form with m <= 64 allows it
+int pmh_qppf_apply_G_norm2(pmh_qppf pf, const double *v, double *Gv, int slot)
+{
+  if (pf->m == 0) return PMH_SUCCESS;
+  if (pf->implicit_orth && pf->m <= 64) return pmh_csr_mult_then_dense(pf->G, v, pf->d_Tt, pf->tmp_m, Gv, slot);
+  PMH_CHK(pmh_qppf_apply_G(pf, v, Gv));
+  return pmh_k_dot_partials(pf->ctx, pf->m, Gv, Gv, slot);
+}
+
 // G_left = what G' is applied to in Q v = G'(..): G v for orthonormal rows, S G0 v under implicit orthonormalisation
 static int qppf_left(pmh_qppf pf, const double *v)
 {

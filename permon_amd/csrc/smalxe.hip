@@ -103,8 +103,7 @@ static int prefetch_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
   if (s->o.be_implicit || s->pf->m == 0 || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
-  PMH_CHK(pmh_qppf_apply_G(s->pf, s->u, s->Bu));
-  PMH_CHK(pmh_k_dot_partials(s->ctx, s->pf->m, s->Bu, s->Bu, PMH_SLOT_NORMBU2));
+  PMH_CHK(pmh_qppf_apply_G_norm2(s->pf, s->u, s->Bu, PMH_SLOT_NORMBU2));
   s->normBu_prefetched = 1;
   return PMH_SUCCESS;
 }

@@ -365,9 +365,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_fin(int nrows, const in
 // applied by one thread, left to right -- the finishing launch of the long-row product and the dense product in ONE launch of one workgroup
 // (the implicitly orthonormalised G = T G0 of qppf.hip: G0 keeps its sparsity, T or T'T is applied here).  lrow == nullptr: `part` already
 // holds A x (the product of a short-row matrix).
-__global__ __launch_bounds__(PMH_BLOCK) void k_rows_then_dense(int m, const int *__restrict__ lrow, const double *__restrict__ part, const double *__restrict__ Mt, double *__restrict__ y)
+// norm_d / norm_h != nullptr (m <= 64 only): also ||y||^2, summed exactly as k_dot + k_finalize sum a vector of this length (one block: products in
+// wave 0, the fixed shuffle tree, zeros from the other waves) -- the same bits, two launches less (SMALXE's ||B u|| of every inner iteration)
+__global__ __launch_bounds__(PMH_BLOCK) void k_rows_then_dense(int m, const int *__restrict__ lrow, const double *__restrict__ part, const double *__restrict__ Mt, double *__restrict__ y,
+                                                               double *__restrict__ norm_d = nullptr, double *__restrict__ norm_h = nullptr)
 {
   extern __shared__ double t0[];
+  __shared__ double        red[PMH_BLOCK / 64];
   for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
     double sum = 0.0;
     if (lrow)
@@ -376,10 +380,16 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_rows_then_dense(int m, const int 
     t0[r] = sum;
   }
   __syncthreads();
+  double sq = 0.0;
   for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
     double s = 0.0;
     for (int c = 0; c < m; c++) s += Mt[(size_t)c * m + r] * t0[c];
     y[r] = s;
+    sq += s * s;
+  }
+  if (norm_d) { // uniform
+    sq = pmh_block_reduce<PMH_RED_SUM>(sq, red);
+    if (threadIdx.x == 0) *norm_d = sq, *norm_h = sq;
   }
 }
 
@@ -796,19 +806,20 @@ int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const do
 }
 
 // y = M (A x), M m x m dense given transposed on the device (see k_rows_then_dense); tmp: m doubles of device scratch (short-row matrices)
-int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y)
+int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y, int norm_slot)
 {
-  PMH_ARG(A && x && Mt && tmp && y && A->nrows >= 1 && A->nrows <= 4096);
+  PMH_ARG(A && x && Mt && tmp && y && A->nrows >= 1 && A->nrows <= 4096 && (norm_slot < 0 || (A->nrows <= 64 && norm_slot < PMH_NSCAL)));
+  double *nd = norm_slot >= 0 ? A->ctx->d_scal + norm_slot : nullptr, *nh = norm_slot >= 0 ? A->ctx->h_scal + norm_slot : nullptr;
   pmh_ctx      ctx = A->ctx;
   const size_t lds = sizeof(double) * (size_t)A->nrows;
   if (A->l_nchunks) {
     static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
     if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
     else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
-    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, Mt, y);
+    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, Mt, y, nd, nh);
   } else {
     PMH_CHK(pmh_csr_mult(A, x, tmp));
-    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)nullptr, (const double *)tmp, Mt, y);
+    hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)nullptr, (const double *)tmp, Mt, y, nd, nh);
   }
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
