@@ -19,11 +19,22 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 #ifndef WTN
 #define WTN 64 // columns of a wave's tile
 #endif
+#ifdef ORIENT4 // a wave's tile = WR rows (4 per A operand, the same in the 4 blocks of the instruction) x 64 columns (16 per B operand)
+#ifndef WR
+#define WR 60
+#endif
+#define TM (WR * NWM)
+#else
 #define TM (64 * NWM)
+#endif
 #define TN (WTN * NWN)
 #define NT (64 * NWM * NWN)
 #define LDA (TM + 16)
+#ifdef ORIENT4
+#define LDB (TN + 16)
+#else
 #define LDB (TN + 4)
+#endif
 static __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 // A pre-tiled: block (mt, kc) = TK k x TM rows, k-major; gidx[g][k] = (position << 1) | negative; X[pos][8]; Cpart[split][Mp][N]
@@ -38,30 +49,47 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   const int wgi = blockIdx.x, s = wgi % S, nt = (wgi / S) % Nt, mt = wgi / (S * Nt);
   const int kc0 = (int)((long long)nkc * s / S), kc1 = (int)((long long)nkc * (s + 1) / S);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
-  constexpr int NEA = TK * TM / 2 / NT; // dbl2 loads of A per thread and chunk
+  constexpr int NEA = (TK * TM / 2 + NT - 1) / NT; // dbl2 loads of A per thread and chunk
   constexpr int KPB = NT / TN;          // k rows of B staged per pass
   constexpr int NEB = TK / KPB;
   static_assert(NEA >= 1 && NEB >= 1 && TK % KPB == 0, "tile / thread shape");
   const int  col = t % TN, kb = t / TN;
   const int *gp = gidx + (size_t)(nt * (TN / 8) + (col >> 3)) * ldk;
   const int  sl = col & 7;
-  double     acc[4][WTN / 4];
+#ifdef ORIENT4
+  constexpr int NA = WR / 4, NB = WTN / 16;
+#else
+  constexpr int NA = 4, NB = WTN / 4;
+#endif
+  double     acc[NA][NB];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NA; i++)
 #pragma unroll
-    for (int j = 0; j < WTN / 4; j++) acc[i][j] = 0.0;
+    for (int j = 0; j < NB; j++) acc[i][j] = 0.0;
   dbl2   ar[NEA];
   double br[NEB];
   int    gn[NEB];
   auto loadA = [&](int kc) {
     const double *blk = A + ((size_t)mt * nkc + kc) * (TK * TM);
 #pragma unroll
-    for (int e = 0; e < NEA; e++) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + NT * e)));
+    for (int e = 0; e < NEA; e++)
+      if ((TK * TM / 2) % NT == 0 || t + NT * e < TK * TM / 2) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + NT * e)));
   };
   auto loadG = [&](int kc, int *g) {
 #pragma unroll
     for (int e = 0; e < NEB; e++) g[e] = gp[kc * TK + kb + KPB * e];
   };
+#ifdef DEFSIGN
+  unsigned sg = 0; // the signs of the gathered values: applied when they are stored to LDS, so that nothing waits for the gather before the products
+  auto gatherB = [&](const int *g) {
+    sg = 0;
+#pragma unroll
+    for (int e = 0; e < NEB; e++) {
+      br[e] = X[(size_t)(g[e] >> 1) * 8 + sl];
+      sg |= (unsigned)(g[e] & 1) << e;
+    }
+  };
+#else
   auto gatherB = [&](const int *g) {
 #pragma unroll
     for (int e = 0; e < NEB; e++) {
@@ -69,14 +97,19 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
       br[e]          = (g[e] & 1) ? -v : v;
     }
   };
+#endif
   auto store = [&](int buf) {
 #pragma unroll
     for (int e = 0; e < NEA; e++) {
       const int q = t + NT * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
-      *(dbl2 *)&As[buf][k][r2] = ar[e];
+      if ((TK * TM / 2) % NT == 0 || q < TK * TM / 2) *(dbl2 *)&As[buf][k][r2] = ar[e];
     }
 #pragma unroll
+#ifdef DEFSIGN
+    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = (sg >> e & 1) ? -br[e] : br[e];
+#else
     for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
+#endif
   };
   if (kc0 < kc1) {
     loadG(kc0, gn);
@@ -94,17 +127,63 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
       gatherB(gn);
       if (kc + 2 < kc1) loadG(kc + 2, gn);
     }
+#if defined(PIPE) && !defined(ORIENT4)
+    // half steps: the operands of the next half step (a: 4 values every other half step, b: 8 values) are read from LDS before the 32 products of this one are issued
+    {
+      constexpr int NH = NB / 2;
+      double a0[4], a1[4], b0[NH], b1[NH];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a0[i] = As[buf][ka][wm * 64 + i * 16 + ra];
+#pragma unroll
+      for (int j = 0; j < NH; j++) b0[j] = Bs[buf][ka][wn * WTN + j * 4 + cb];
+#pragma unroll
+      for (int k4 = 0; k4 < TK / 4; k4++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NH; j++) b1[j] = Bs[buf][4 * k4 + ka][wn * WTN + (NH + j) * 4 + cb];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < NH; j++) acc[i][j] = mfma4(a0[i], b0[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 1 < TK / 4) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) a1[i] = As[buf][4 * (k4 + 1) + ka][wm * 64 + i * 16 + ra];
+#pragma unroll
+          for (int j = 0; j < NH; j++) b0[j] = Bs[buf][4 * (k4 + 1) + ka][wn * WTN + j * 4 + cb];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < NH; j++) acc[i][NH + j] = mfma4(a0[i], b1[j], acc[i][NH + j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 1 < TK / 4) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) a0[i] = a1[i];
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int k4 = 0; k4 < TK / 4; k4++) {
-      double a[4], b[WTN / 4];
+      double a[NA], b[NB];
+#ifdef ORIENT4
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
+      for (int i = 0; i < NA; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 4 + cb];
 #pragma unroll
-      for (int j = 0; j < WTN / 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WTN + j * 4 + cb];
+      for (int j = 0; j < NB; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WTN + j * 16 + ra];
+#else
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NA; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
 #pragma unroll
-        for (int j = 0; j < WTN / 4; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < NB; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WTN + j * 4 + cb];
+#endif
+#pragma unroll
+      for (int i = 0; i < NA; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
 #ifdef SGB
       // interleave: 1 LDS read per 3 MFMAs (20 reads, 64 MFMAs per k4-step)
 #pragma unroll
@@ -115,16 +194,26 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #endif
     }
+#endif
     if (kc + 1 < kc1) store(buf ^ 1);
     __syncthreads();
   }
   // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
   const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);
   double   *C  = Cpart + (size_t)s * Mp * N;
+#ifdef ORIENT4
+  // same A in the 4 blocks, B block b = columns 4 b .. 4 b + 3: D lane l = row l >> 4 of the 4, column l & 15 of the 16
+  (void)rr;
+#pragma unroll
+  for (int i = 0; i < NA; i++)
+#pragma unroll
+    for (int j = 0; j < NB; j++) C[(size_t)(mt * TM + wm * WR + i * 4 + ka) * N + nt * TN + wn * WTN + j * 16 + ra] = acc[i][j];
+#else
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < WTN / 4; j++) C[(size_t)(mt * TM + wm * 64 + i * 16 + rr) * N + nt * TN + wn * WTN + j * 4 + cb] = acc[i][j];
+#endif
 }
 
 int main(int argc, char **argv)
