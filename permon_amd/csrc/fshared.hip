@@ -15,7 +15,7 @@
 // Three storages of W_c live in this file (fx_shared::sym):
 //   0  PMH_FX_CLASS        the full matrix, k_fxs_gemm8: 8 n_c^2 bytes per apply, HBM-bound
 //   1  PMH_FX_CLASS_SYM    its lower block-triangle in 16 x 16 tiles, k_fxs_symm8 (both products of a tile on the fp64 matrix instruction): 4 n_c^2 bytes, HBM-bound
-//   2  PMH_FX_CLASS_ORBIT  only the rows of the orbit representatives under the class's symmetries, k_fxo_gemm: a GEMM on the fp64 matrix instruction,
+//   2  PMH_FX_CLASS_ORBIT  only the rows of the orbit representatives under the class's symmetries, k_fxo_gemm / k_fxo_gemm4: a GEMM on the fp64 matrix instruction,
 //                          4 n_c^2 / 24 bytes for the cube's 48 operations, compute-bound (the default for congruent cubes)
 // and the set-up by symmetry (fxs_set_symmetry: one K^+ solve per orbit of rows, self-checked against direct solves) serves 1 and 2.
 #include <algorithm>
@@ -56,7 +56,7 @@ struct fxs_class {
   signed char             *d_sign = nullptr;
   // orbit storage (fx_shared::sym == 2): only the rows of W_c of the orbit representatives are kept, see the FXO section
   std::vector<int> reps, rep_of, op_of; // all representatives (positions, ascending); per row: its representative's position and the operation that reaches it
-  int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0;
+  int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0, tm = 128; // tm: row tile of the GEMM (fxo_row_tile)
   long long        aoff = 0, coff = 0;  // offsets of the class in Afund / cpart
   int             *d_gidx = nullptr, *d_reppos = nullptr;
   signed char     *d_use = nullptr;
@@ -513,6 +513,117 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
     for (int j = 0; j < 16; j++) C[(long long)(mt * FXO_TM + wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
 }
 
+// The same GEMM with the instruction's operands the other way round: the SAME 4 rows of A in its 4 blocks, 16 columns of B (4 per block) -- rows come in
+// units of 4 instead of 16, so the row tile can be 8 NA = 96 ... 120 and 715 representatives pad to 720 rows (6 x 120) instead of 768.  At equal tile
+// this orientation is ~2 % slower than k_fxo_gemm (scripts/micro/orbit_gemm.hip), so it is used when it saves more than that in padding (fxo_row_tile).
+// Wave tile 4 NA x 64: NA x 4 accumulators; D lane l = row l >> 4 of the 4, column l & 15 of the 16.
+#define FXO_LDB4 (FXO_TN + 16) // 16 consecutive columns x 4 k per read: rows of B 32 banks apart
+template <int NA>
+__global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
+                                                      const int *__restrict__ c_ncol, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
+                                                      const double *__restrict__ X, double *__restrict__ cpart)
+{
+  constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
+  __shared__ double As[2][FXO_TK][LDA];
+  __shared__ double Bs[2][FXO_TK][FXO_LDB4];
+  const int *w8 = items + 8 * blockIdx.x;
+  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
+  const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
+  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = c_ncol[c];
+  const double *__restrict__ Ab = A + iteml[3 * blockIdx.x];
+  const double *__restrict__ x  = X + iteml[3 * blockIdx.x + 1];
+  double *__restrict__ C        = cpart + iteml[3 * blockIdx.x + 2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // NQ 16-byte pieces of A per chunk
+  const int  col = t % FXO_TN, kb = t / FXO_TN, sl = col & 7;
+  const int *gp = gidx + (long long)(nt * (FXO_TN / 8) + (col >> 3)) * ldk;
+  double     acc[NA][4];
+#pragma unroll
+  for (int i = 0; i < NA; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+  dbl2   ar[NEA];
+  double br[NEB];
+  int    gn[NEB];
+  auto loadA = [&](int kc) {
+    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM);
+#pragma unroll
+    for (int e = 0; e < NEA; e++)
+      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + 256 * e)));
+  };
+  auto loadG = [&](int kc) {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
+  };
+  auto gatherB = [&]() {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) {
+      const double v = x[(long long)(gn[e] >> 1) * FXS_S + sl];
+      br[e]          = (gn[e] & 1) ? -v : v;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < NEA; e++) {
+      const int q = t + 256 * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
+      if (NQ % 256 == 0 || q < NQ) *(dbl2 *)&As[buf][k][r2] = ar[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
+  };
+  if (kc0 < kc1) {
+    loadG(kc0);
+    loadA(kc0);
+    gatherB();
+    if (kc0 + 1 < kc1) loadG(kc0 + 1);
+    store(0);
+  }
+  __syncthreads();
+  const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
+  for (int kc = kc0; kc < kc1; kc++) {
+    const int buf = (kc - kc0) & 1;
+    if (kc + 1 < kc1) {
+      loadA(kc + 1);
+      gatherB();
+      if (kc + 2 < kc1) loadG(kc + 2);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
+      double a[NA], b[4];
+#pragma unroll
+      for (int i = 0; i < NA; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 4 + cb];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 16 + ra];
+#pragma unroll
+      for (int i = 0; i < NA; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = fxm_mfma(a[i], b[j], acc[i][j]);
+    }
+    if (kc + 1 < kc1) store(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < NA; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) C[(long long)(mt * TM + wm * WR + i * 4 + ka) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j];
+}
+
+// row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
+static int fxo_row_tile(int M)
+{
+  if (const char *e = getenv("PMH_FXO_TM")) {
+    const int v = atoi(e);
+    if (v == 128 || v == 120 || v == 112 || v == 104 || v == 96) return v;
+  }
+  int    best = 128;
+  double cost = (double)((M + 127) / 128 * 128);
+  for (int tm : {120, 112, 104, 96}) {
+    const double cst = 1.025 * (double)((M + tm - 1) / tm * tm);
+    if (cst < cost) cost = cst, best = tm;
+  }
+  return best;
+}
+
 // Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (p, g) pairs that own their row (use = +-1: the operation the row was
 // assigned to; rows fixed by several operations are written once).  One thread per (representative, column); grid.y = group
 __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsymp, int nc, int S, long long cgs /* stride between groups */, const double *__restrict__ cp,
@@ -531,21 +642,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsy
 }
 
 // row of representative pl (local index) from its K^+ solve -> the pre-tiled A
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_store_row(int pl, int nc, int nkc, const int *__restrict__ urel, const double *__restrict__ u, double *__restrict__ A)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_store_row(int pl, int tm, int nc, int nkc, const int *__restrict__ urel, const double *__restrict__ u, double *__restrict__ A)
 {
-  double *base = A + (long long)(pl / FXO_TM) * nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
-  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) base[(long long)(c / FXO_TK) * (FXO_TK * FXO_TM) + (c % FXO_TK) * FXO_TM] = u[urel[c]];
+  double *base = A + (long long)(pl / tm) * nkc * (FXO_TK * tm) + pl % tm;
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) base[(long long)(c / FXO_TK) * (FXO_TK * tm) + (c % FXO_TK) * tm] = u[urel[c]];
 }
 
 // set-up self-check: row r = g p from its own solve (u) against s_g(p) s_g(c) A[p][c] at column g c, for all c
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_check_row(int pl, int nc, int nkc, double sp, const int *__restrict__ urel, const double *__restrict__ u, const int *__restrict__ posmap,
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_check_row(int pl, int tm, int nc, int nkc, double sp, const int *__restrict__ urel, const double *__restrict__ u, const int *__restrict__ posmap,
                                                              const signed char *__restrict__ sign, const double *__restrict__ A, double *__restrict__ out)
 {
   __shared__ double red[PMH_BLOCK / 64];
-  const double *base = A + (long long)(pl / FXO_TM) * nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
+  const double *base = A + (long long)(pl / tm) * nkc * (FXO_TK * tm) + pl % tm;
   double        d = 0.0, m = 0.0;
   for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) {
-    const double w = sp * (double)sign[c] * base[(long long)(c / FXO_TK) * (FXO_TK * FXO_TM) + (c % FXO_TK) * FXO_TM], v = u[urel[posmap[c]]];
+    const double w = sp * (double)sign[c] * base[(long long)(c / FXO_TK) * (FXO_TK * tm) + (c % FXO_TK) * tm], v = u[urel[posmap[c]]];
     d = fmax(d, fabs(w - v)), m = fmax(m, fabs(v));
   }
   d = -pmh_block_reduce<PMH_RED_MIN>(-d, red);
@@ -926,7 +1037,8 @@ static int fxo_prepare(fx_shared *S)
     // the k range (the columns of W): full tiles at every N, and the partial Y are summed by the all-reduce that ends B Y anyway
     C.m0 = 0, C.m1 = C.M_all;
     const int M = C.m1 - C.m0;
-    C.Mp   = std::max(1, (M + FXO_TM - 1) / FXO_TM) * FXO_TM;
+    C.tm   = fxo_row_tile(M);
+    C.Mp   = std::max(1, (M + C.tm - 1) / C.tm) * C.tm;
     C.ldk  = (C.nc + FXO_TK - 1) / FXO_TK * FXO_TK;
     C.nkc  = C.ldk / FXO_TK;
     C.nsymp = (C.nsym + FXO_TN / 8 - 1) / (FXO_TN / 8) * (FXO_TN / 8);
@@ -964,7 +1076,7 @@ static int fxo_prepare(fx_shared *S)
   // GEMM work items: (row tile, column tile of 16 operations, split of the k range) per class and group; the split gives ~2 workgroups per CU
   long long tiles = 0;
   for (auto &C : S->C)
-    if (C.nc) tiles += (long long)C.ngroups * (C.Mp / FXO_TM) * (C.nsymp * 8 / FXO_TN);
+    if (C.nc) tiles += (long long)C.ngroups * (C.Mp / C.tm) * (C.nsymp * 8 / FXO_TN);
   int Ssplit = (int)std::max(1LL, 2LL * ctx->num_cus / std::max(1LL, tiles)); // one round of the 2 resident workgroups per CU (measured: 28 splits 0.407 ms, 56: 0.417, 57: 0.50); at least 24 chunks each (below)
   if (const char *e = getenv("PMH_FXO_SPLIT")) Ssplit = std::max(1, atoi(e));
   std::vector<int>       items, vnkc(S->ncls, 1), vldk(S->ncls, 16), vncol(S->ncls, 128);
@@ -982,7 +1094,7 @@ static int fxo_prepare(fx_shared *S)
     vnkc[c] = C.nkc, vldk[c] = C.ldk, vncol[c] = ncol;
     C.coff = ctot;
     for (int g = 0; g < C.ngroups; g++)
-      for (int mt = 0; mt < C.Mp / FXO_TM; mt++)
+      for (int mt = 0; mt < C.Mp / C.tm; mt++)
         for (int nt = 0; nt < ncol / FXO_TN; nt++)
           for (int sp = 0; sp < Sc; sp++) {
             items.insert(items.end(), {c, g, mt, nt, klo + (int)((long long)nk * sp / Sc), klo + (int)((long long)nk * (sp + 1) / Sc), sp, 0});
@@ -1034,15 +1146,25 @@ static int fxo_gemm(fx_shared *S)
       int idx = 0;
       for (int cc = 0; cc < S->ncls; cc++) {
         const fxs_class &D = S->C[cc];
-        const int        n = D.nc ? D.ngroups * (D.Mp / FXO_TM) * (D.nsymp * 8 / FXO_TN) * D.nown : 0;
+        const int        n = D.nc ? D.ngroups * (D.Mp / D.tm) * (D.nsymp * 8 / FXO_TN) * D.nown : 0;
         if (cc == c) first = idx, count = n;
         idx += n;
       }
     }
     if (!count) continue;
     const int ncol = C.nsymp * 8;
-    hipLaunchKernelGGL(k_fxo_gemm, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 3 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls),
-                       (const int *)(S->d_wg + 2 * S->ncls), (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart);
+#define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
+  hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 3 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
+                     (const int *)(S->d_wg + 2 * S->ncls), (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
+    switch (C.tm) {
+    case 128: FXO_LAUNCH(k_fxo_gemm); break;
+    case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;
+    case 112: FXO_LAUNCH(k_fxo_gemm4<14>); break;
+    case 104: FXO_LAUNCH(k_fxo_gemm4<13>); break;
+    case 96: FXO_LAUNCH(k_fxo_gemm4<12>); break;
+    default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
+    }
+#undef FXO_LAUNCH
     hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)(((long long)C.Mp * ncol + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp, ncol, C.nsymp, C.nc, C.nown, (long long)C.nown * C.Mp * ncol,
                        (const double *)(S->cpart + C.coff), (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld, S->Y);
   }
@@ -1150,7 +1272,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       const fxs_class &C = S->C[slot_class[s]];
       if (S->sym == 2) {
         const int pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), prow[s]) - C.reps.begin()) - C.m0;
-        hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.nc, C.nkc, (const int *)C.d_urel,
+        hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.tm, C.nc, C.nkc, (const int *)C.d_urel,
                            (const double *)(sol + srs[s]), S->Afund + C.aoff);
       } else if (S->sym && C.nsym > 1) {
         const int p = prow[s];
@@ -1198,7 +1320,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int g = C.op_of[r], p = C.rep_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin()) - C.m0;
         nb          = std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK));
-        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
                            (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc), (const double *)(S->Afund + C.aoff), d_out);
       } else
       hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
@@ -1283,9 +1405,9 @@ int fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host
     for (int i = 0; i < n; i++) {
       const int r = C.pos[gamma[i] - S->K->rowstart[b]], p = C.rep_of[r], g = C.op_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin());
       const double  sp = (double)C.h_sign[(size_t)g * C.nc + p];
-      const double *ab = T.data() + (size_t)(pl / FXO_TM) * C.nkc * (FXO_TK * FXO_TM) + pl % FXO_TM;
+      const double *ab = T.data() + (size_t)(pl / C.tm) * C.nkc * (FXO_TK * C.tm) + pl % C.tm;
       for (int cc = 0; cc < C.nc; cc++)
-        row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(cc / FXO_TK) * (FXO_TK * FXO_TM) + (cc % FXO_TK) * FXO_TM];
+        row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(cc / FXO_TK) * (FXO_TK * C.tm) + (cc % FXO_TK) * C.tm];
       for (int k = 0; k < n; k++) out_host[(size_t)i * n + k] = row[C.pos[gamma[k] - S->K->rowstart[b]]];
     }
     return PMH_SUCCESS;

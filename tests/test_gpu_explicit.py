@@ -195,6 +195,32 @@ def test_explicit_orbit_storage(ctx, sub, nel, nsym):
     assert np.linalg.norm(tot - Fref @ lam) <= 1e-10 * np.linalg.norm(Fref @ lam)
 
 
+@pytest.mark.parametrize("tm", [128, 120, 112, 104, 96])
+def test_explicit_orbit_row_tiles(ctx, tm, monkeypatch):
+    """Every row tile of the orbit GEMM (k_fxo_gemm: 16 rows per instruction operand, tile 128; k_fxo_gemm4<NA>: 4 rows per operand, tiles 8 NA = 96 ... 120,
+    chosen by the padding of the representatives' rows): forced through PMH_FXO_TM, two row tiles per class (nel = 20: n_c = 7206, ~165 representatives), F = B pinv(K) B'
+    through each and the blocks rebuilt from the pre-tiled rows."""
+    monkeypatch.setenv("PMH_FXO_TM", str(tm))
+    nel = 20
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True)
+    G, e = f.coarse()
+    nn = nel + 1
+    loc = f.subset(range(f.nsub))
+    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    assert q.explicit_storage == "class_orbit" and q.explicit_symmetries == 48
+    rng = np.random.default_rng(16)
+    lam = rng.standard_normal(f.n_lambda)
+    lv, y = ctx.vec_from(lam), ctx.vec(f.n_lambda)
+    q.F.mult(lv, y)
+    # reference: the iterative K^+ at rtol 1e-13 (a dense pseudo-inverse of 27 783-dof blocks is out of reach)
+    q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    y0 = ctx.vec(f.n_lambda)
+    q0.F.mult(lv, y0)
+    assert np.linalg.norm(y.to_numpy() - y0.to_numpy()) <= 1e-9 * np.linalg.norm(y0.to_numpy())
+    W, g = q.E.block(3)
+    assert np.max(np.abs(W - W.T)) <= 1e-9 * np.max(np.abs(W))
+
+
 def test_explicit_contact_solve_same_counts(ctx):
     """Contact TFETI (SMALXE + MPGP) through the explicit F: same outer / inner counts and solution as the iterative K^+."""
     f = pa.CubeFeti((2, 2, 2), 5, contact=True)
