@@ -35,7 +35,7 @@ open("profiles/r02_c_strong_scaling_rehearsal_explicit.txt", "w").write("\n".joi
 print("\n".join(out[7:]))
 shutil.copy("gpurun_out/bench_r02_default.json", "profiles/r02_bench_default_1gpu.json")
 for n in (2, 4, 8):
-    shutil.copy("gpurun_out/bench_r02_sim%d.json" % n, "profiles/r02_a_bench_rehearsal%d_class_sym.json" % n)
+    shutil.copy("gpurun_out/bench_r02_sim%d.json" % n, "profiles/r02_c_bench_rehearsal%d.json" % n)
 shutil.copy("gpurun_out/bench_r02_c3.json", "profiles/r02_c_bench_configs3_shape_1gpu.json")
 shutil.copy("gpurun_out/bench_r02_c3_sim8.json", "profiles/r02_c_bench_configs3_shape_share_of_8.json")
 for tag, name, head in (("ex1", "n1", ["# rocprofv3 --kernel-trace --marker-trace --stats --selected-regions -- python3 bench.py --no-cpu-baseline --no-c2 --no-iterative : the TIMED REGION only (roctxProfilerResume / Pause, PMH_BENCH_ROCTX=1);",
