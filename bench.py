@@ -592,10 +592,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             tf = flops_k / (ms_k / n_k * 1e-3) / 1e12 if n_k else 0.0
             roofline.update({
                 "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "flops_per_launch": flops_k,
-                "kernel": "k_fxo_gemm / k_fxo_gemm4<NA> (row tile 128, or 8 NA = 96..120 where that pads the representatives' rows less: 715 -> 720 with NA = 15) (+ k_fxo_fin): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of 4.5 GB) and "
+                "kernel": "k_fxo_gemm / k_fxo_gemm4<NA> (row tile 128, or 8 NA = 96..120 where that pads the representatives' rows less: 715 -> 720 with NA = 15) (+ k_fxo_fin): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of %.2f GB of symmetric tiles) and "
                           "Y = W_c X becomes the GEMM (representatives) x (operations x 8 right-hand sides) over n_c on v_mfma_f64_4x4x4_4b_f64: %.0f flop per stored byte, compute-bound; B is gathered from the L2-resident multivector "
                           "(one index per (operation, dof), sign in its lowest bit), split-K partial tiles summed in a fixed order (the FETI dual operator apply, SURVEY 8d dense path)"
-                          % (q.explicit_symmetries, n_solves - len(E.n_gamma) if n_solves > len(E.n_gamma) else n_solves, E.dense_bytes / 1e9, flops_k / max(E.dense_bytes, 1)),
+                          % (q.explicit_symmetries, n_solves - len(E.n_gamma) if n_solves > len(E.n_gamma) else n_solves, E.dense_bytes / 1e9, 4.0 * float(E.class_union(0).size) ** 2 / 1e9, flops_k / max(E.dense_bytes, 1)),
                 "hbm_bytes_algorithmic": b_k, "hbm_GBs": achieved,
                 "note": "the HBM-bound form of the same apply (--explicit-storage class_sym: k_fxs_symm8, 4.65 GB per apply at 0.77-0.80 of the 8 TB/s peak) takes 0.73-0.75 ms; this form moves 48 x fewer bytes"})
         elif b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
