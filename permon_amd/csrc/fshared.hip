@@ -172,7 +172,15 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_fin(long long n, int nseg, lo
   const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x);
   if (i >= n) return;
   dbl2 s = *(const dbl2 *)(part + i);
-  for (int j = 1; j < nseg; j++) s += *(const dbl2 *)(part + (long long)j * part_stride + i);
+  int  j = 1;
+  for (; j + 8 <= nseg; j += 8) { // segment order kept, 8 loads in flight (a plain loop waits for every load before its add)
+    dbl2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = *(const dbl2 *)(part + (long long)(j + k) * part_stride + i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[k];
+  }
+  for (; j < nseg; j++) s += *(const dbl2 *)(part + (long long)j * part_stride + i);
   *(dbl2 *)(Y + i) = s;
 }
 
@@ -635,10 +643,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsy
   const int p = (int)(i / ncol), colx = (int)(i % ncol), g = colx >> 3, sl = colx & 7;
   const int u = use[(long long)p * nsymp + g];
   if (u == 0) return;
-  const double *q = cp + (long long)blockIdx.y * cgs + i;
-  double        s = q[0];
-  for (int j = 1; j < S; j++) s += q[(long long)j * Mp * ncol];
-  Y[xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[p]] * FXS_S + sl] = u > 0 ? s : -s;
+  const long long dst    = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[p]] * FXS_S + sl;
+  const long long stride = (long long)Mp * ncol;
+  const double   *q      = cp + (long long)blockIdx.y * cgs + i;
+  double          s      = q[0];
+  int             j      = 1;
+  // the splits are added in split order, but their loads travel together (a plain loop compiles to load - wait - add per split: 27 memory latencies)
+  for (; j + 8 <= S; j += 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = q[(long long)(j + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[k];
+  }
+  for (; j < S; j++) s += q[(long long)j * stride];
+  Y[dst] = u > 0 ? s : -s;
 }
 
 // row of representative pl (local index) from its K^+ solve -> the pre-tiled A

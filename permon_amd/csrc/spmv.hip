@@ -336,6 +336,21 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_spmv_long_part(const int *__restr
   const int k0 = chunks[3 * blockIdx.x + 1], k1 = chunks[3 * blockIdx.x + 2];
   double    s[4] = {0.0, 0.0, 0.0, 0.0};
   int       k    = k0 + (int)threadIdx.x;
+  if (k1 - k0 == 16 * PMH_BLOCK) { // a full chunk of 4096 (PMH_LONG_CHUNK): all 16 entries of the thread in flight at once, added in the order of the loop below
+    double v[16];
+    int    c[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      v[e] = NT ? __builtin_nontemporal_load(&val[k + e * PMH_BLOCK]) : val[k + e * PMH_BLOCK];
+      c[e] = NT ? __builtin_nontemporal_load(&col[k + e * PMH_BLOCK]) : col[k + e * PMH_BLOCK];
+    }
+    double xv[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) xv[e] = x[c[e]];
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e & 3] += v[e] * xv[e];
+    k = k1;
+  }
   for (; k + 3 * PMH_BLOCK < k1; k += 4 * PMH_BLOCK) {
 #pragma unroll
     for (int j = 0; j < 4; j++) s[j] += (NT ? __builtin_nontemporal_load(&val[k + j * PMH_BLOCK]) : val[k + j * PMH_BLOCK]) * x[NT ? __builtin_nontemporal_load(&col[k + j * PMH_BLOCK]) : col[k + j * PMH_BLOCK]];
@@ -372,18 +387,34 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_rows_then_dense(int m, const int 
 {
   extern __shared__ double t0[];
   __shared__ double        red[PMH_BLOCK / 64];
+  // the sums keep their order, their loads travel in batches (a plain loop compiles to load - wait - add per entry: this kernel is made of latencies)
   for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
     double sum = 0.0;
-    if (lrow)
-      for (int c = lrow[r]; c < lrow[r + 1]; c++) sum += part[c];
-    else sum = part[r];
+    if (lrow) {
+      const int c0 = lrow[r], c1 = lrow[r + 1];
+      for (int c = c0; c < c1; c += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (c + j < c1) ? part[c + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (c + j < c1) sum += v[j];
+      }
+    } else sum = part[r];
     t0[r] = sum;
   }
   __syncthreads();
   double sq = 0.0;
   for (int r = threadIdx.x; r < m; r += PMH_BLOCK) {
     double s = 0.0;
-    for (int c = 0; c < m; c++) s += Mt[(size_t)c * m + r] * t0[c];
+    for (int c = 0; c < m; c += 16) {
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = (c + j < m) ? Mt[(size_t)(c + j) * m + r] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (c + j < m) s += v[j] * t0[c + j];
+    }
     y[r] = s;
     sq += s * s;
   }
