@@ -366,13 +366,24 @@ def pmc_lookup(prefix, fname, combine="mean", contains=None):
     except (OSError, ValueError) as ex:
         return None, "no PMC pass: %r" % (ex,)
     prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
-    hits = [v for k, v in pmc.items() if k != "_meta" and k.startswith(prefixes) and (contains is None or any(c in k for c in contains))]
-    if not hits:
-        return None, "kernel %r not in profiles/%s" % (prefixes, fname)
-    n = sum(v["launches"] for v in hits)
+    keep = lambda k: k != "_meta" and (contains is None or any(c in k for c in contains))
     meta = pmc.get("_meta", {})
-    # "mean": launch-weighted mean over the instantiations of one kernel; "sum": the kernels of one operation launched once each
-    total = sum(v["hbm_bytes_per_launch"] for v in hits) if combine == "sum" else sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+    if combine == "sum":
+        # the kernels of ONE operation, launched once each: every element of `prefix` (a name prefix, or a tuple of alternative prefixes for the
+        # instantiations of one kernel) must be in the file -- a partial sum would be a wrong figure, not a missing one
+        total = 0.0
+        for e in prefixes:
+            alts = (e,) if isinstance(e, str) else tuple(e)
+            hits = [v for k, v in pmc.items() if keep(k) and k.startswith(alts)]
+            if not hits:
+                return None, "kernel %r not in profiles/%s" % (alts, fname)
+            total += sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits)
+    else:
+        flat = tuple(a for e in prefixes for a in ((e,) if isinstance(e, str) else tuple(e)))
+        hits = [v for k, v in pmc.items() if keep(k) and k.startswith(flat)]
+        if not hits:
+            return None, "kernel %r not in profiles/%s" % (flat, fname)
+        total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits)  # launch-weighted mean over the instantiations of one kernel
     return (total,
             "profiles/%s @ %s (%s)" % (fname, meta.get("git", "git state not recorded"), meta.get("command", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled")))
 
@@ -573,7 +584,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         n_solves, asm_s = E.assemble_stats()
         storage_used = q.explicit_storage
         flops_k = E.apply_flops()
-        ppref = {"class_orbit": ("k_fxo_gemm", "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
+        ppref = {"class_orbit": (("k_fxo_gemm", "void k_fxo_gemm4<"), "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
         traffic, tsrc = pmc_lookup(ppref, "r02_pmc_traffic_feti_explicit.json", combine="sum") if full_size else (None, "not the configuration of the committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
