@@ -180,10 +180,16 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
 #pragma unroll
       for (int j = 0; j < NB; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WTN + j * 4 + cb];
 #endif
+#ifdef SETPRIO
+      __builtin_amdgcn_s_setprio(SETPRIO);
+#endif
 #pragma unroll
       for (int i = 0; i < NA; i++)
 #pragma unroll
         for (int j = 0; j < NB; j++) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+#ifdef SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef SGB
       // interleave: 1 LDS read per 3 MFMAs (20 reads, 64 MFMAs per k4-step)
 #pragma unroll
