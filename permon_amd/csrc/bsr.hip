@@ -12,6 +12,9 @@
 #include "pmh_internal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <memory>
 #include <thread>
 
 #define BSR_TB_MAX 2048 // largest tile (blocks)
@@ -140,6 +143,15 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
   const int        n = A->nrows, nbr = n / 3;
   const int        tb = (tile == 512 || tile == 1024 || tile == 2048) ? tile : bsr_tile(storage), W = bsr_width(storage);
+  const bool       verbose = getenv("PMH_CONTACT_TIMING") != nullptr && A->nnz > 10000000;
+  auto             tnow    = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double           tlast   = tnow();
+  auto             stage   = [&](const char *what) {
+    if (!verbose) return;
+    const double t = tnow();
+    fprintf(stderr, "      pmh_bsr3_from_csr: %-40s %.3f s\n", what, t - tlast);
+    tlast = t;
+  };
   std::vector<int>    rp_own, ci_own;
   std::vector<double> va_own;
   const int          *rp = A->h_rowptr, *ci = A->h_col;
@@ -153,6 +165,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
     }
     rp = rp_own.data(), ci = ci_own.data(), va = va_own.data();
   }
+  stage("host copy of the CSR arrays");
   // block structure: union of the block columns of the three rows of each block row (sorted)
   // (host threads over contiguous ranges of block rows: the fine level of configs[2] has 158 M non-zeros and is converted three times per set-up)
   std::vector<int> browptr((size_t)nbr + 1, 0), bcol;
@@ -192,6 +205,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   }
   const long long nblocks = (long long)bcol.size();
   if (nblocks * 9 > 2 * A->nnz + 64) return PMH_SUCCESS; // blocks mostly empty: the CSR kernel moves fewer bytes
+  stage("block structure");
   // tiles of whole block rows
   std::vector<int> tile_br(1, 0);
   for (int br = 0, start = 0; br < nbr; br++) {
@@ -209,16 +223,24 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   }
   const long long npad = tile_off[ntiles];
   // values, tile-wise structure of arrays; padding blocks are zero and point at block column 0
-  std::vector<double> bv((size_t)npad * 9, 0.0);
-  std::vector<int>    bcp((size_t)npad, 0);
+  // (1.3 GB for the fine level of configs[2]: left uninitialised here, every thread zeroes the planes of its own tiles -- a zero-filled std::vector
+  // was 0.22 s of page faults on one thread)
+  std::unique_ptr<double[]> bv_own(new double[(size_t)npad * 9 + 1]);
+  std::unique_ptr<int[]>    bcp_own(new int[(size_t)npad + 1]);
+  double *const             bv  = bv_own.get();
+  int *const                bcp = bcp_own.get();
+  const size_t              nbv = (size_t)npad * 9;
   double              amax = 0.0;
   std::vector<double> tamax(nt, 0.0);
+  stage("tile table, zeroed value planes");
   auto fill = [&](int tt) {
   double amax = 0.0;
   for (int t = (int)((long long)ntiles * tt / nt); t < (int)((long long)ntiles * (tt + 1) / nt); t++) {
     const int s0 = browptr[tile_br[t]], nbt = browptr[tile_br[t + 1]] - s0, nbp = (nbt + W - 1) / W * W;
-    double   *v  = bv.data() + (size_t)tile_off[t] * 9;
-    std::copy(bcol.begin() + s0, bcol.begin() + s0 + nbt, bcp.begin() + tile_off[t]);
+    double   *v  = bv + (size_t)tile_off[t] * 9;
+    std::fill(v, v + (size_t)nbp * 9, 0.0);
+    std::copy(bcol.begin() + s0, bcol.begin() + s0 + nbt, bcp + tile_off[t]);
+    std::fill(bcp + tile_off[t] + nbt, bcp + tile_off[t] + nbp, 0);
     for (int br = tile_br[t]; br < tile_br[t + 1]; br++) {
       const int *bc = bcol.data() + browptr[br];
       const int  nb = browptr[br + 1] - browptr[br];
@@ -240,6 +262,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
     for (auto &x : th) x.join();
     for (int t = 0; t < nt; t++) amax = std::max(amax, tamax[t]);
   }
+  stage("values into the tile planes");
   pmh_bsr3 B = new pmh_bsr3_s();
   B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
   B->scale   = 1.0;
@@ -256,25 +279,36 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_br, tmeta.data(), sizeof(int) * tmeta.size())); // int4 per tile
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_tile_off, tile_off.data(), sizeof(long long) * tile_off.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, B->d_browptr, browptr.data(), sizeof(int) * browptr.size()));
-  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_bcol, bcp.data(), sizeof(int) * (size_t)npad));
+  PMH_CHK(pmh_memcpy_h2d(ctx, B->d_bcol, bcp, sizeof(int) * (size_t)npad));
+  auto threaded = [&](auto &&body) { // body(first, one-past-last) over [0, nbv) on the conversion threads
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(body, nbv * (size_t)t / nt, nbv * (size_t)(t + 1) / nt);
+    for (auto &x : th) x.join();
+  };
   if (storage == PMH_BSR_F32) {
-    std::vector<float> bf(bv.size());
-    for (size_t i = 0; i < bv.size(); i++) bf[i] = (float)bv[i];
-    PMH_CHK(pmh_malloc(ctx, sizeof(float) * (bf.size() + 2), &B->d_val));
-    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bf.data(), sizeof(float) * bf.size()));
+    std::unique_ptr<float[]> bf(new float[nbv + 1]);
+    threaded([&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) bf[i] = (float)bv[i];
+    });
+    PMH_CHK(pmh_malloc(ctx, sizeof(float) * (nbv + 2), &B->d_val));
+    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bf.get(), sizeof(float) * nbv));
   } else if (storage == PMH_BSR_F16) {
     // power-of-two scale that brings the largest entry to [1, 2): entries below 2^-24 of it flush to zero
     int ex = 0;
     if (amax > 0.0) frexp(amax, &ex);
     B->scale = ldexp(1.0, ex - 1);
-    std::vector<_Float16> bh(bv.size());
-    for (size_t i = 0; i < bv.size(); i++) bh[i] = (_Float16)(float)(bv[i] / B->scale);
-    PMH_CHK(pmh_malloc(ctx, sizeof(_Float16) * (bh.size() + 4), &B->d_val));
-    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bh.data(), sizeof(_Float16) * bh.size()));
+    const double               sc = B->scale;
+    std::unique_ptr<_Float16[]> bh(new _Float16[nbv + 1]);
+    threaded([&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) bh[i] = (_Float16)(float)(bv[i] / sc);
+    });
+    PMH_CHK(pmh_malloc(ctx, sizeof(_Float16) * (nbv + 4), &B->d_val));
+    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bh.get(), sizeof(_Float16) * nbv));
   } else {
-    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (bv.size() + 2), &B->d_val));
-    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bv.data(), sizeof(double) * bv.size()));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (nbv + 2), &B->d_val));
+    PMH_CHK(pmh_memcpy_h2d(ctx, B->d_val, bv, sizeof(double) * nbv));
   }
+  stage("value conversion + upload");
   *out = B;
   return PMH_SUCCESS;
 }

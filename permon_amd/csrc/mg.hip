@@ -10,6 +10,9 @@
 // Every kernel is HBM bound, so the cycle is built to move few bytes: level operators with 3x3 block structure run on the
 // block kernel of bsr.hip (one column index per block), and with precision = PMH_MG_FP32 the whole cycle (operators and
 // vectors) is single precision -- it only preconditions the fp64 CG, whose residual and solution stay fp64.
+#include <chrono>
+#include <cstdio>
+
 #include "pmh_internal.h"
 
 struct mg_level {
@@ -571,6 +574,16 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   if (const char *e = getenv("PMH_MG_FUSED")) mg->fused = mg->fused && atoi(e); // testing knob: 0 = separate smoothing kernels
   mg->L.resize(nlevels);
   const bool no_bsr = getenv("PMH_MG_NO_BSR") != nullptr; // testing knob: keep the CSR kernels (fp64 only)
+  const bool verbose = getenv("PMH_CONTACT_TIMING") != nullptr;
+  auto       tnow    = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double     tlast   = tnow();
+  auto       stage   = [&](const char *what, int l) {
+    if (!verbose) return;
+    (void)pmh_sync(ctx);
+    const double t = tnow();
+    fprintf(stderr, "    pmh_mg_create: level %d %-44s %.3f s\n", l, what, t - tlast);
+    tlast = t;
+  };
   for (int l = 0; l < nlevels; l++) {
     mg_level &Lv = mg->L[l];
     Lv.A = A[l], Lv.P = (l + 1 < nlevels) ? P[l] : nullptr, Lv.n = A[l]->nrows, Lv.Ab = nullptr;
@@ -590,12 +603,14 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       // instantiation of their own, so that profiler averages of the fine-level operator are not mixed with the coarse launches
       static const int coarse_tile = getenv("PMH_MG_COARSE_TILE") ? atoi(getenv("PMH_MG_COARSE_TILE")) : 512;
       if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab, l == 0 ? 0 : coarse_tile));
+      stage("3x3-block operator (pmh_bsr3_from_csr)", l);
       if (fl && !Lv.Ab) {
         pmh_mg_destroy(mg);
         return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32/FP16 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
       }
       if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches only
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
+      stage("transpose of the prolongation", l);
       Lv.pv = P[l]->d_val, Lv.rv = P[l]->transpose->d_val;
       if (fl && P[l]->nnz > 0) {
         const int nz = (int)P[l]->nnz;
@@ -616,7 +631,9 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
         PMH_HIP(hipGetLastError());
       }
+      stage("value conversion, diagonal, work vectors", l);
       if (!getenv("PMH_MG_NO_NODAL_P")) PMH_CHK(mg_build_nodal_transfer(mg, l, fl));
+      stage("node-wise transfer operators", l);
       // KSPChebyshev recurrence on the window [lo, hi] x lambda_max
       const double a = lo_frac * lambda_max[l], b = hi_frac * lambda_max[l];
       Lv.theta = 0.5 * (a + b), Lv.delta = 0.5 * (b - a);
