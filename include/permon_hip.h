@@ -353,6 +353,7 @@ int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const int *dims, in
 int pmh_fexplicit_class_union(pmh_fexplicit E, int cls, int *n_c, int *urel_out /* [n_c] or NULL */);
 int pmh_fexplicit_set_class_symmetry(pmh_fexplicit E, int cls, int nsym, const int *posmap, const signed char *sign);
 int pmh_fexplicit_class_sym_plan(int n_c, int size, int *megaband_owner /* [ceil(ceil(n_c / 256) / 4)] or NULL */, double *bytes_per_rank /* [size] or NULL */); /* host: PMH_FX_CLASS_SYM's rule */
+int pmh_fexplicit_orbit_row_tile(int n_representatives, int *row_tile /* 128, 120, 112, 104 or 96 */, int *padded_rows); /* host: PMH_FX_CLASS_ORBIT's rule for the row tile of its GEMM */
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
 int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte); /* tuning helper: byte pattern instead of the assembly (not F afterwards) */
 int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds);

@@ -936,6 +936,16 @@ void fxs_destroy(fx_shared *S)
   delete S;
 }
 
+// host helper (no device): the row tile fxo_prepare picks for a class with M orbit representatives and the padded row count of its GEMM
+extern "C" int pmh_fexplicit_orbit_row_tile(int M, int *tm, int *Mp)
+{
+  PMH_ARG(M >= 1);
+  const int t = fxo_row_tile(M);
+  if (tm) *tm = t;
+  if (Mp) *Mp = (M + t - 1) / t * t;
+  return PMH_SUCCESS;
+}
+
 // the dealing rule of the symmetric tile storage: mega band m of nmb (1024 rows; cost ~ m + 1) -> rank: from the longest down in snake order
 static inline int fxm_owner(int m, int nmb, int size)
 {

@@ -245,6 +245,33 @@ def test_class_sym_plan_balances_the_tile_bytes():
         assert abs(b.sum() - 8.0 * 256 * 256 * nsb * (nsb + 1) / 2) < 1.0  # the lower block-triangle in 256-row super bands
 
 
+def test_orbit_row_tile_rule(monkeypatch):
+    """PMH_FX_CLASS_ORBIT (host helper, no GPU): the row tile of the orbit GEMM is 128 (16 rows per instruction operand) unless a tile of 8 NA = 96 ... 120
+    rows (4 rows per operand, ~2 % slower at equal size) pads the representatives' rows by more than 2.5 % less: configs[2]'s 715 -> 6 x 120 = 720."""
+    import ctypes as C
+
+    import permon_amd as pa
+
+    L = pa.load()
+    monkeypatch.delenv("PMH_FXO_TM", raising=False)
+
+    def rule(M):
+        tm, Mp = C.c_int(), C.c_int()
+        pa._lib.check(L.pmh_fexplicit_orbit_row_tile(M, C.byref(tm), C.byref(Mp)))
+        return tm.value, Mp.value
+
+    assert rule(715) == (120, 720)
+    assert rule(128) == (128, 128) and rule(1024) == (128, 1024) and rule(256) == (128, 256)
+    assert rule(96) == (96, 96) and rule(1) == (96, 96)
+    assert rule(176) == (96, 192)  # the configs[3] shape
+    for M in range(1, 2000, 7):
+        tm, Mp = rule(M)
+        assert tm in (128, 120, 112, 104, 96) and Mp % tm == 0 and M <= Mp < M + tm
+        assert Mp <= -(-M // 128) * 128  # never more padding than the 128-row tile
+    monkeypatch.setenv("PMH_FXO_TM", "112")
+    assert rule(715) == (112, 784)
+
+
 def test_box_symmetries_c_vs_numpy():
     """pmh_box_symmetries (host C++): the group of signed dof permutations of a box block that leave K invariant -- the same operations as the numpy
     restatement feti.box_symmetries (48 for a cube of Q1 elasticity elements, 8 / 16 for boxes with unequal sides), identity first, and K^+ is
