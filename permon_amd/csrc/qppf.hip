@@ -401,8 +401,20 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1(int n, const int *__res
 {
   const int r = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (r >= n) return;
-  double sum = 0.0;
-  for (int k = rowptr[r]; k < rowptr[r + 1]; k++) sum += val[k] * w[col[k]];
+  const int k0 = rowptr[r], k1 = rowptr[r + 1];
+  double    sum = 0.0;
+  for (int k = k0; k < k1; k += 16) { // left to right as the plain loop, the loads of 16 entries in flight together
+    double v[16];
+    int    c[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool in = k + j < k1;
+      v[j] = in ? val[k + j] : 0.0, c[j] = in ? col[k + j] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (k + j < k1) sum += v[j] * w[c[j]];
+  }
   if (mode == 0) {
     y[r] = sum;
     z[r] = -1.0 * sum + x[r];
@@ -410,6 +422,31 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1(int n, const int *__res
     const double t = x[r] + -1.0 * sum;
     y[r]           = y[r] * rho + t;
   }
+}
+
+// G not orthonormalised (the dense (G G')^{-1} of QPPFSetUp, qppf.c:213-278): the penalty term rho G'G x and the projector's G'(GG')^{-1}G x are two
+// G' products with different coarse vectors -- one pass over G' for both: y = G' t0 (t0 = G x), z = x - G' w (w = (GG')^{-1} t0), each sum left to right
+__global__ __launch_bounds__(PMH_BLOCK) void k_gt_dual1(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ t0,
+                                                       const double *__restrict__ w, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ z)
+{
+  const int r = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const int k0 = rowptr[r], k1 = rowptr[r + 1];
+  double    s0 = 0.0, s1 = 0.0;
+  for (int k = k0; k < k1; k += 16) {
+    double v[16];
+    int    c[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const bool in = k + j < k1;
+      v[j] = in ? val[k + j] : 0.0, c[j] = in ? col[k + j] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (k + j < k1) s0 += v[j] * t0[c[j]], s1 += v[j] * w[c[j]];
+  }
+  y[r] = s0;
+  z[r] = -1.0 * s1 + x[r];
 }
 
 // ... and with the finishing step of G0 v and the dense T'T product folded in (implicit orthonormalisation, m <= 64): every workgroup adds the
@@ -484,6 +521,15 @@ static bool gt_fusable(pmh_qppf pf)
   if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
   const pmh_csr Gt = pf->G->transpose;
   return Gt->kind == PMH_SPMV_STREAM && (Gt->st_rl == 8 || Gt->st_rl == 1) && Gt->l_nchunks == 0;
+}
+
+// the same for G with its dense (G G')^{-1}: one-lane-per-row G' only (k_gt_dual1 / k_gt_fused1)
+static bool gt_fusable_dense_inverse(pmh_qppf pf)
+{
+  if (pf->orthonormal || !pf->d_inv || pf->m == 0 || getenv("PMH_NO_GT_FUSION")) return false;
+  if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
+  const pmh_csr Gt = pf->G->transpose;
+  return Gt->kind == PMH_SPMV_STREAM && Gt->st_rl == 1 && Gt->l_nchunks == 0;
 }
 
 // Q v's G' product with its vector epilogue, starting from v: G0 v (chunk sums), then everything else in ONE launch where the folded kernel
@@ -583,6 +629,24 @@ struct PenalizedOp : pmh_op_s {
       PMH_CHK(q_fused(pf, x, 0, x, y, pa->w1, 0.0)); // y = Q x, w1 = P x
       PMH_CHK(pa->A->mult(pa->w1, pa->w2));
       return q_fused(pf, pa->w2, 1, pa->w2, y, nullptr, rho); // y = rho y + (w2 - Q w2)
+    }
+    if (pa && pa->pf == pf && pa->symmetric && gt_fusable_dense_inverse(pf)) {
+      // y = rho G'G x + P F P x, P = I - G'(GG')^{-1}G: G x once for both terms, one pass over G' for G'(G x) and x - G'(GG')^{-1}(G x), the second
+      // projector with the penalty update in its epilogue -- 12 launches instead of 19, the same bits as the sequence below
+      const pmh_csr Gt = pf->G->transpose;
+      const dim3    grid((Gt->nrows + PMH_BLOCK - 1) / PMH_BLOCK);
+      PMH_CHK(pmh_csr_mult(pf->G, x, pf->G_left));
+      PMH_CHK(pmh_qppf_apply_CP(pf, pf->G_left, pf->Gt_right));
+      hipLaunchKernelGGL(k_gt_dual1, grid, dim3(PMH_BLOCK), 0, ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, (const double *)pf->G_left,
+                         (const double *)pf->Gt_right, x, y, pa->w1);
+      PMH_HIP(hipGetLastError());
+      PMH_CHK(pa->A->mult(pa->w1, pa->w2));
+      PMH_CHK(pmh_csr_mult(pf->G, pa->w2, pf->G_left));
+      PMH_CHK(pmh_qppf_apply_CP(pf, pf->G_left, pf->Gt_right));
+      hipLaunchKernelGGL(k_gt_fused1, grid, dim3(PMH_BLOCK), 0, ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, (const double *)pf->Gt_right, 1,
+                         (const double *)pa->w2, y, (double *)nullptr, rho);
+      PMH_HIP(hipGetLastError());
+      return PMH_SUCCESS;
     }
     PMH_CHK(pmh_qppf_apply_GtG(pf, x, y));
     if (pa && pa->pf == pf && pa->symmetric && pf->orthonormal) {

@@ -89,7 +89,8 @@ def test_qppf_implicit_orthonormalisation(ctx, size, monkeypatch):
     Dm = sp.diags(1.0 + rng.random(n)).tocsr()
     D = pa.Op.from_csr(pa.CsrMat(ctx, n, n, Dm.indptr, Dm.indices, Dm.data))
     out = []
-    for pf in (pi, pe):
+    pd = pa.QPPF.from_scipy(ctx, G0)  # G as it is, dense (G G')^{-1}: the fused form is k_gt_dual1 + k_gt_fused1 (its penalty term is rho G'G, not rho Q)
+    for pf in (pi, pe, pd):
         Ap = pa.MatCreatePenalized(pa.MatCreateProjected(D, pf, symmetric=True), pf, 2.5)
         y1, y2 = ctx.vec(n), ctx.vec(n)
         pa._lib.check(ctx.L.pmh_op_mult(Ap.h, vd.p, y1.p))
@@ -99,6 +100,10 @@ def test_qppf_implicit_orthonormalisation(ctx, size, monkeypatch):
         assert np.array_equal(y1.to_numpy(), y2.to_numpy())
         out.append(y1.to_numpy())
     assert np.linalg.norm(out[0] - out[1]) <= 1e-11 * np.linalg.norm(out[1])
+    G0d = G0.toarray()
+    proj = lambda z: z - G0d.T @ np.linalg.solve(G0d @ G0d.T, G0d @ z)
+    ref = 2.5 * (G0d.T @ (G0d @ v)) + proj(Dm @ proj(v))
+    assert np.linalg.norm(out[2] - ref) <= 1e-10 * np.linalg.norm(ref)
     if size[3] > 4:
         return
     # the whole dual chain and the contact solve: same counts, same solution
