@@ -633,12 +633,12 @@ static int fxo_row_tile(int M)
 }
 
 // Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (p, g) pairs that own their row (use = +-1: the operation the row was
-// assigned to; rows fixed by several operations are written once).  One thread per (representative, column); grid.y = group
+// assigned to; rows fixed by several operations are written once).  One thread per (representative, pair of columns); grid.y = group
 __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsymp, int nc, int S, long long cgs /* stride between groups */, const double *__restrict__ cp,
                                                        const signed char *__restrict__ use, const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld,
                                                        double *__restrict__ Y)
 {
-  const long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x;
+  const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x); // two neighbouring right-hand sides per thread: 16-byte loads
   if (i >= (long long)Mp * ncol) return;
   const int p = (int)(i / ncol), colx = (int)(i % ncol), g = colx >> 3, sl = colx & 7;
   const int u = use[(long long)p * nsymp + g];
@@ -646,18 +646,18 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsy
   const long long dst    = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[p]] * FXS_S + sl;
   const long long stride = (long long)Mp * ncol;
   const double   *q      = cp + (long long)blockIdx.y * cgs + i;
-  double          s      = q[0];
+  dbl2            s      = *(const dbl2 *)q;
   int             j      = 1;
   // the splits are added in split order, but their loads travel together (a plain loop compiles to load - wait - add per split: 27 memory latencies)
   for (; j + 8 <= S; j += 8) {
-    double v[8];
+    dbl2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = q[(long long)(j + k) * stride];
+    for (int k = 0; k < 8; k++) v[k] = *(const dbl2 *)(q + (long long)(j + k) * stride);
 #pragma unroll
     for (int k = 0; k < 8; k++) s += v[k];
   }
-  for (; j < S; j++) s += q[(long long)j * stride];
-  Y[dst] = u > 0 ? s : -s;
+  for (; j < S; j++) s += *(const dbl2 *)(q + (long long)j * stride);
+  *(dbl2 *)(Y + dst) = u > 0 ? s : -s;
 }
 
 // row of representative pl (local index) from its K^+ solve -> the pre-tiled A
@@ -1194,7 +1194,7 @@ static int fxo_gemm(fx_shared *S)
     default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
     }
 #undef FXO_LAUNCH
-    hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)(((long long)C.Mp * ncol + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp, ncol, C.nsymp, C.nc, C.nown, (long long)C.nown * C.Mp * ncol,
+    hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)(((long long)C.Mp * ncol / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp, ncol, C.nsymp, C.nc, C.nown, (long long)C.nown * C.Mp * ncol,
                        (const double *)(S->cpart + C.coff), (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld, S->Y);
   }
   PMH_HIP(hipGetLastError());
