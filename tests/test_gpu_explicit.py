@@ -227,6 +227,28 @@ def test_explicit_orbit_row_tiles(ctx, tm, monkeypatch):
         assert np.array_equal(y.to_numpy(), y1.to_numpy())
 
 
+@pytest.mark.parametrize("nel", [3, 7, 11, 13])
+def test_explicit_orbit_sizes_against_iterative_kplus(ctx, nel):
+    """Odd sizes (row / k / column remainders of the orbit GEMM's tiles; scripts/orbit_size_sweep.py runs more of them): F through the orbit storage equals F
+    through the inner-Krylov K^+ to 1e-9, the contact solve takes the same SMALXE / MPGP counts and ends at the same lambda."""
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True)
+    G, e = f.coarse()
+    loc = f.subset(range(f.nsub))
+    nn = nel + 1
+    qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-12)
+    qo = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-12, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    assert qo.explicit_storage == "class_orbit" and qo.explicit_symmetries == 48
+    lam = np.random.default_rng(nel).standard_normal(f.n_lambda)
+    lv, y0, y1 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    qi.F.mult(lv, y0)
+    qo.F.mult(lv, y1)
+    assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-9 * np.linalg.norm(y0.to_numpy())
+    si, so = qi.solve_smalxe(rtol=1e-6), qo.solve_smalxe(rtol=1e-6)
+    assert (si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp, si.reason) == (so.iteration, so.inner_iter_accu, so.inner.ncg, so.inner.nexp, so.reason)
+    li, lo = qi.dual_solution(), qo.dual_solution()
+    assert np.linalg.norm(li - lo) <= 1e-7 * np.linalg.norm(li)
+
+
 def test_explicit_contact_solve_same_counts(ctx):
     """Contact TFETI (SMALXE + MPGP) through the explicit F: same outer / inner counts and solution as the iterative K^+."""
     f = pa.CubeFeti((2, 2, 2), 5, contact=True)
