@@ -615,6 +615,13 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kplus_cfg = {"path": "explicit", "storage": storage_used, "setup_symmetries": getattr(q, "explicit_symmetries", 1), "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns%s" % (pc_text, ", one solve per orbit of rows under the %d symmetries of the cube (checked against K, a batch of rows re-solved directly)" % q.explicit_symmetries if getattr(q, "explicit_symmetries", 1) > 1 else "")
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
+        if storage_used == "class_orbit" and world == 1 and not a.sim_world:  # the GEMM's shape: representatives (rows), their padding to the row tile, operations x 8 right-hand sides (columns), n_c (k)
+            import ctypes as _C
+
+            n_rep = int(n_solves - len(E.n_gamma)) if n_solves > len(E.n_gamma) else int(n_solves)
+            tm_, mp_ = _C.c_int(), _C.c_int()
+            pa._lib.check(ctx.L.pmh_fexplicit_orbit_row_tile(max(1, n_rep), _C.byref(tm_), _C.byref(mp_)))
+            kplus_cfg["orbit_gemm"] = {"representatives": n_rep, "row_tile": tm_.value, "padded_rows": mp_.value, "columns": 8 * int(q.explicit_symmetries), "k": int(E.class_union(0).size)}
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %s%.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
             int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym", "class_orbit") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
         precision_note = "fp64 throughout: the dense blocks, the GEMV and everything in the dual space are fp64; reduced precision exists only inside the V-cycle that preconditions the SET-UP solves (their CG, residual test at rtol %.0e and solutions are fp64)" % a.explicit_rtol
