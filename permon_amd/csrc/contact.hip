@@ -182,6 +182,7 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     if (o->explicit_dual) { // MatInvExplicitly restricted to the dofs B touches; congruent blocks share their columns
       std::vector<int> cls(nsub);
       GO(pmh_csr_block_classes(nsub, block_rowstart, rowptr, col, val, cls.data(), nullptr));
+      stage("  explicit operators: block classes");
       // blocks of one class share K, hence K^+ (the Moore-Penrose inverse does not depend on the basis chosen for the kernel)
       int ncls = 0;
       for (int b = 0; b < nsub; b++) ncls = std::max(ncls, cls[b] + 1);
@@ -228,9 +229,10 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
           GO(set_symmetries(&least));
         }
       }
+      stage("  explicit operators: class union, gluing of the classes, symmetries");
       GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));
       GO(pmh_matinv_attach_explicit(Kp, E));
-      stage("explicit operators (classes, symmetries, assembly)");
+      stage("  explicit operators: assembly (K^+ solves, self-check)");
       long long ns;
       GO(pmh_fexplicit_assemble_stats(E, &ns, &st->explicit_seconds));
       st->explicit_solves = (int)ns;
