@@ -59,6 +59,13 @@ struct fxs_class {
   int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0, tm = 128; // tm: row tile of the GEMM (fxo_row_tile)
   long long        aoff = 0, coff = 0;  // offsets of the class in Afund / cpart
   int             *d_gidx = nullptr, *d_reppos = nullptr;
+  // output pruning of the orbit GEMM: block (group, slot) touches only part of U_c, so row g p of Y is needed for the slots that touch it only.  Per (group, row tile)
+  // the columns (operation << 3 | slot) some row of the tile needs, padded to 128 with -1; the representatives are ordered by their need pattern (rows of A)
+  std::vector<char> tmask;              // [ngroups][nc][8]
+  std::vector<int>  reprow;             // representative index (in reps) -> row of A / cpart
+  int              *d_coltab = nullptr, *d_fintab = nullptr; // fintab per (group, row tile): coltab offset, padded columns, first element of the tile in the group's numbering
+  long long        *d_finbase = nullptr;                     // per (group, row tile): offset of split 0 in cpart
+  int               item_first = 0, item_count = 0, fin_elems = 0;
   signed char     *d_use = nullptr;
 };
 
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // items: (class, group, row tile, column tile (16 operations), first chunk, one-past-last chunk, split, 0); iteml: A offset of the class, X offset of
 // the group, C offset of (class, group, split)
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
-                                                     const int *__restrict__ c_ncol, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
+                                                     const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
                                                      const double *__restrict__ X, double *__restrict__ cpart)
 {
   __shared__ double As[2][FXO_TK][FXO_LDA];
@@ -441,14 +448,16 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
-  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = c_ncol[c];
-  const double *__restrict__ Ab = A + iteml[3 * blockIdx.x];
-  const double *__restrict__ x  = X + iteml[3 * blockIdx.x + 1];
-  double *__restrict__ C        = cpart + iteml[3 * blockIdx.x + 2];
+  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
+  const double *__restrict__ Ab = A + iteml[4 * blockIdx.x];
+  const double *__restrict__ x  = X + iteml[4 * blockIdx.x + 1];
+  double *__restrict__ C        = cpart + iteml[4 * blockIdx.x + 2]; // the (group, row tile, split) block: tile rows x ncol
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   constexpr int NEA = FXO_TK * FXO_TM / 2 / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
-  const int  col = t % FXO_TN, kb = t / FXO_TN, sl = col & 7;
-  const int *gp = gidx + (long long)(nt * (FXO_TN / 8) + (col >> 3)) * ldk;
+  const int  col = t % FXO_TN, kb = t / FXO_TN;
+  const int  ct  = coltab[iteml[4 * blockIdx.x + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
+  const int  sl  = ct < 0 ? 0 : (ct & 7);
+  const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
   double     acc[4][16];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 16; j++) C[(long long)(mt * FXO_TM + wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
+    for (int j = 0; j < 16; j++) C[(long long)(wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
 }
 
 // The same GEMM with the instruction's operands the other way round: the SAME 4 rows of A in its 4 blocks, 16 columns of B (4 per block) -- rows come in
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
 #define FXO_LDB4 (FXO_TN + 16) // 16 consecutive columns x 4 k per read: rows of B 32 banks apart
 template <int NA>
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
-                                                      const int *__restrict__ c_ncol, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
+                                                      const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
                                                       const double *__restrict__ X, double *__restrict__ cpart)
 {
   constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
@@ -537,14 +546,16 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ it
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
-  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = c_ncol[c];
-  const double *__restrict__ Ab = A + iteml[3 * blockIdx.x];
-  const double *__restrict__ x  = X + iteml[3 * blockIdx.x + 1];
-  double *__restrict__ C        = cpart + iteml[3 * blockIdx.x + 2];
+  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
+  const double *__restrict__ Ab = A + iteml[4 * blockIdx.x];
+  const double *__restrict__ x  = X + iteml[4 * blockIdx.x + 1];
+  double *__restrict__ C        = cpart + iteml[4 * blockIdx.x + 2]; // the (group, row tile, split) block: tile rows x ncol
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // NQ 16-byte pieces of A per chunk
-  const int  col = t % FXO_TN, kb = t / FXO_TN, sl = col & 7;
-  const int *gp = gidx + (long long)(nt * (FXO_TN / 8) + (col >> 3)) * ldk;
+  const int  col = t % FXO_TN, kb = t / FXO_TN;
+  const int  ct  = coltab[iteml[4 * blockIdx.x + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
+  const int  sl  = ct < 0 ? 0 : (ct & 7);
+  const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
   double     acc[NA][4];
 #pragma unroll
   for (int i = 0; i < NA; i++)
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ it
 #pragma unroll
   for (int i = 0; i < NA; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) C[(long long)(mt * TM + wm * WR + i * 4 + ka) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j];
+    for (int j = 0; j < 4; j++) C[(long long)(wm * WR + i * 4 + ka) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j];
 }
 
 // row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
@@ -632,32 +643,39 @@ static int fxo_row_tile(int M)
   return best;
 }
 
-// Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (p, g) pairs that own their row (use = +-1: the operation the row was
-// assigned to; rows fixed by several operations are written once).  One thread per (representative, pair of columns); grid.y = group
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int Mp, int ncol, int nsymp, int nc, int S, long long cgs /* stride between groups */, const double *__restrict__ cp,
-                                                       const signed char *__restrict__ use, const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld,
-                                                       double *__restrict__ Y)
+// Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (row, operation) pairs that own their row (use = +-1: the operation the row was
+// assigned to; rows fixed by several operations are written once), over the columns the (group, row tile) pairs list.  One thread per (row, listed column);
+// grid.y = group.  fintab per (group, row tile): offset of its column list, its padded column count, its first element in the group's numbering
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, int S, const int *__restrict__ fintab, const long long *__restrict__ finbase, const int *__restrict__ coltab,
+                                                       const double *__restrict__ cp, const signed char *__restrict__ use, const int *__restrict__ reppos, const int *__restrict__ posmap,
+                                                       long long xbase0, int ld, double *__restrict__ Y)
 {
-  const long long i = 2 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x); // two neighbouring right-hand sides per thread: 16-byte loads
-  if (i >= (long long)Mp * ncol) return;
-  const int p = (int)(i / ncol), colx = (int)(i % ncol), g = colx >> 3, sl = colx & 7;
-  const int u = use[(long long)p * nsymp + g];
+  const int  i  = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  const int *ft = fintab + 3 * (ntile + 1) * blockIdx.y;
+  if (i >= ft[3 * ntile + 2]) return; // the group's element count
+  int mt = 0;
+  while (mt + 1 < ntile && i >= ft[3 * (mt + 1) + 2]) mt++;
+  const int ncol = ft[3 * mt + 1], local = i - ft[3 * mt + 2], r = local / ncol, j = local % ncol;
+  const int ct = coltab[ft[3 * mt] + j];
+  if (ct < 0) return;
+  const int g = ct >> 3, sl = ct & 7, row = mt * tm + r;
+  const int u = use[(long long)row * nsymp + g];
   if (u == 0) return;
-  const long long dst    = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[p]] * FXS_S + sl;
-  const long long stride = (long long)Mp * ncol;
-  const double   *q      = cp + (long long)blockIdx.y * cgs + i;
-  dbl2            s      = *(const dbl2 *)q;
-  int             j      = 1;
-  // the splits are added in split order, but their loads travel together (a plain loop compiles to load - wait - add per split: 27 memory latencies)
-  for (; j + 8 <= S; j += 8) {
-    dbl2 v[8];
+  const long long dst    = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[row]] * FXS_S + sl;
+  const long long stride = (long long)tm * ncol;
+  const double   *q      = cp + finbase[(long long)ntile * blockIdx.y + mt] + (long long)r * ncol + j;
+  double          s      = q[0];
+  int             k      = 1;
+  // the splits are added in split order, but their loads travel together (a plain loop compiles to load - wait - add per split)
+  for (; k + 8 <= S; k += 8) {
+    double v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = *(const dbl2 *)(q + (long long)(j + k) * stride);
+    for (int e = 0; e < 8; e++) v[e] = q[(long long)(k + e) * stride];
 #pragma unroll
-    for (int k = 0; k < 8; k++) s += v[k];
+    for (int e = 0; e < 8; e++) s += v[e];
   }
-  for (; j < S; j++) s += *(const dbl2 *)(q + (long long)j * stride);
-  *(dbl2 *)(Y + dst) = u > 0 ? s : -s;
+  for (; k < S; k++) s += q[(long long)k * stride];
+  Y[dst] = u > 0 ? s : -s;
 }
 
 // row of representative pl (local index) from its K^+ solve -> the pre-tiled A
@@ -882,6 +900,14 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     const fxs_class &C = S->C[S->cls[b]];
     rows[i]            = (int)(C.xoff + (long long)group[b] * C.ld * FXS_S + (long long)C.pos[B->h_row[i] - K->rowstart[b]] * FXS_S + slot[b]);
   }
+  if (sym == 2) {
+    for (auto &C : S->C) C.tmask.assign((size_t)std::max(1, C.ngroups) * std::max(1, C.nc) * FXS_S, 0);
+    for (int i = 0; i < B->n_leaves; i++) {
+      const int  b = lb[i];
+      fxs_class &C = S->C[S->cls[b]];
+      C.tmask[((size_t)group[b] * C.nc + C.pos[B->h_row[i] - K->rowstart[b]]) * FXS_S + slot[b]] = 1;
+    }
+  }
   PMH_CHK(pmh_gluing_create(ctx, (int)std::max(1LL, xtot), B->n_lambda, B->n_leaves, rows.data(), B->h_root.data(), B->h_sign.data(), &S->Bc));
   {
     const size_t bytes = sizeof(double) * (size_t)std::max(32LL, wtot);
@@ -922,6 +948,7 @@ void fxs_destroy(fx_shared *S)
     if (C.d_ownfirst) pmh_free(ctx, C.d_ownfirst);
     if (C.d_posmap) pmh_free(ctx, C.d_posmap), pmh_free(ctx, C.d_sign);
     if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
+    if (C.d_coltab) pmh_free(ctx, C.d_coltab), pmh_free(ctx, C.d_fintab), pmh_free(ctx, C.d_finbase);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
@@ -1047,9 +1074,12 @@ static int fxo_prepare(fx_shared *S)
   if (S->fxo_ready) return PMH_SUCCESS;
   pmh_ctx   ctx = S->ctx;
   long long atot = 0;
+  std::vector<std::vector<int>> h_fintab, h_coltab, h_rowrep; // per class with touched dofs, in class order
+  std::vector<int>              tab_of(S->ncls, -1);
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
     if (C.nc == 0) continue;
+    tab_of[c] = (int)h_fintab.size();
     if (C.nsym < 1) return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: block class %d has no symmetries (pmh_fexplicit_set_class_symmetry / _set_box_symmetry before the assembly)", c);
     // orbits of the rows: representative and operation of every row; rows fixed by several operations keep the first
     C.rep_of.assign((size_t)C.nc, -1), C.op_of.assign((size_t)C.nc, 0), C.reps.clear();
@@ -1074,18 +1104,92 @@ static int fxo_prepare(fx_shared *S)
     C.aoff = atot;
     atot += (long long)C.Mp * C.ldk;
     // gather indices of B: (position of g c) << 1 | (s_g(c) < 0); padded k and padded operations read the zero row nc of X
-    std::vector<int>         gidx((size_t)C.nsymp * C.ldk, C.nc << 1), reppos((size_t)C.Mp, 0);
-    std::vector<signed char> use((size_t)C.Mp * C.nsymp, 0);
+    // (one more row of gather indices, all on the zero row of X: what the padding columns of the lists below read)
+    std::vector<int>         gidx((size_t)(C.nsymp + 1) * C.ldk, C.nc << 1), reppos((size_t)C.Mp, 0);
+    std::vector<signed char> use((size_t)C.Mp * C.nsymp, 0), use_h((size_t)M * C.nsym, 0);
     for (int g = 0; g < C.nsym; g++)
       for (int cc = 0; cc < C.nc; cc++) gidx[(size_t)g * C.ldk + cc] = (C.h_posmap[(size_t)g * C.nc + cc] << 1) | (C.h_sign[(size_t)g * C.nc + cc] < 0 ? 1 : 0);
     for (int pl = 0; pl < M; pl++) {
       const int p = C.reps[C.m0 + pl];
-      reppos[pl] = p;
       for (int g = 0; g < C.nsym; g++) {
         const int r = C.h_posmap[(size_t)g * C.nc + p];
-        if (C.rep_of[r] == p && C.op_of[r] == g) use[(size_t)pl * C.nsymp + g] = C.h_sign[(size_t)g * C.nc + p];
+        if (C.rep_of[r] == p && C.op_of[r] == g) use_h[(size_t)pl * C.nsym + g] = C.h_sign[(size_t)g * C.nc + p];
       }
     }
+    // need pattern of a representative: bit ((group * nsym + g) * 8 + slot) = row g p is owned by (p, g) and block (group, slot) touches it.  The rows of A follow
+    // the patterns (the widest first), so that a row tile holds few patterns and its column list stays short: a face-interior representative of a 2 x 2 x 2
+    // decomposition needs 224 or 256 of the 384 columns
+    const bool   prune = !getenv("PMH_FXO_NO_PRUNE") && !C.tmask.empty();
+    const size_t nbits = (size_t)C.ngroups * C.nsym * FXS_S, nw = (nbits + 63) / 64;
+    std::vector<unsigned long long> pat((size_t)M * nw, 0ULL);
+    std::vector<int>                cnt((size_t)M, 0), rowrep((size_t)M);
+    for (int pl = 0; pl < M; pl++) {
+      const int p = C.reps[C.m0 + pl];
+      for (int gr = 0; gr < C.ngroups; gr++)
+        for (int g = 0; g < C.nsym; g++) {
+          if (!use_h[(size_t)pl * C.nsym + g]) continue;
+          const int r = C.h_posmap[(size_t)g * C.nc + p];
+          for (int sl = 0; sl < FXS_S; sl++)
+            if (!prune || C.tmask[((size_t)gr * C.nc + r) * FXS_S + sl]) {
+              const size_t b = ((size_t)gr * C.nsym + g) * FXS_S + sl;
+              pat[(size_t)pl * nw + b / 64] |= 1ULL << (b % 64), cnt[pl]++;
+            }
+        }
+      rowrep[pl] = pl;
+    }
+    if (prune) {
+      // rows with the same pattern together; the RARE patterns first (representatives on the cube's edges and corners need other columns than the face-interior
+      // ones: they share the first row tile, whose list is the full one anyway), then the common ones, the wider first
+      auto less_pat = [&](int a, int b) {
+        return std::lexicographical_compare(pat.begin() + (size_t)a * nw, pat.begin() + (size_t)(a + 1) * nw, pat.begin() + (size_t)b * nw, pat.begin() + (size_t)(b + 1) * nw);
+      };
+      std::stable_sort(rowrep.begin(), rowrep.end(), less_pat);
+      std::vector<int> gsize((size_t)M, 0); // size of the pattern group a representative belongs to
+      for (int i = 0; i < M;) {
+        int j = i + 1;
+        while (j < M && !less_pat(rowrep[i], rowrep[j]) && !less_pat(rowrep[j], rowrep[i])) j++;
+        for (int k = i; k < j; k++) gsize[rowrep[k]] = j - i;
+        i = j;
+      }
+      std::stable_sort(rowrep.begin(), rowrep.end(), [&](int a, int b) {
+        if (gsize[a] != gsize[b]) return gsize[a] < gsize[b];
+        if (cnt[a] != cnt[b]) return cnt[a] > cnt[b];
+        return less_pat(a, b);
+      });
+    }
+    C.reprow.assign((size_t)M, 0);
+    for (int row = 0; row < M; row++) {
+      const int pl = rowrep[row];
+      C.reprow[pl] = row, reppos[row] = C.reps[C.m0 + pl];
+      for (int g = 0; g < C.nsym; g++) use[(size_t)row * C.nsymp + g] = use_h[(size_t)pl * C.nsym + g];
+    }
+    // column lists per (group, row tile)
+    const int        ntile = C.Mp / C.tm;
+    std::vector<int> coltab, fintab((size_t)C.ngroups * (ntile + 1) * 3, 0);
+    for (int gr = 0; gr < C.ngroups; gr++) {
+      int elems = 0;
+      for (int mt = 0; mt < ntile; mt++) {
+        const int coff = (int)coltab.size();
+        for (int code = 0; code < C.nsym * FXS_S; code++) {
+          const size_t b   = ((size_t)gr * C.nsym + (code >> 3)) * FXS_S + (code & 7);
+          bool         any = false;
+          for (int row = mt * C.tm; row < std::min(M, (mt + 1) * C.tm) && !any; row++) any = (pat[(size_t)rowrep[row] * nw + b / 64] >> (b % 64)) & 1ULL;
+          if (any) coltab.push_back(code);
+        }
+        while ((coltab.size() - coff) % FXO_TN) coltab.push_back(-1);
+        int *ft = fintab.data() + ((size_t)gr * (ntile + 1) + mt) * 3;
+        ft[0] = coff, ft[1] = (int)coltab.size() - coff, ft[2] = elems;
+        elems += C.tm * ft[1];
+      }
+      fintab[((size_t)gr * (ntile + 1) + ntile) * 3 + 2] = elems;
+      C.fin_elems = std::max(gr ? C.fin_elems : 0, elems);
+    }
+    if (C.d_coltab) pmh_free(ctx, C.d_coltab), pmh_free(ctx, C.d_fintab), C.d_coltab = nullptr;
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max<size_t>(1, coltab.size()), (void **)&C.d_coltab));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * fintab.size(), (void **)&C.d_fintab));
+    if (!coltab.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_coltab, coltab.data(), sizeof(int) * coltab.size()));
+    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_fintab, fintab.data(), sizeof(int) * fintab.size()));
+    h_fintab.push_back(fintab), h_coltab.push_back(coltab), h_rowrep.push_back(rowrep);
     if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * gidx.size(), (void **)&C.d_gidx));
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * reppos.size(), (void **)&C.d_reppos));
@@ -1104,8 +1208,13 @@ static int fxo_prepare(fx_shared *S)
   }
   // GEMM work items: (row tile, column tile of 16 operations, split of the k range) per class and group; the split gives ~2 workgroups per CU
   long long tiles = 0;
-  for (auto &C : S->C)
-    if (C.nc) tiles += (long long)C.ngroups * (C.Mp / C.tm) * (C.nsymp * 8 / FXO_TN);
+  for (int c = 0; c < S->ncls; c++) {
+    const fxs_class &C = S->C[c];
+    if (!C.nc) continue;
+    const int ntile = C.Mp / C.tm;
+    for (int gr = 0; gr < C.ngroups; gr++)
+      for (int mt = 0; mt < ntile; mt++) tiles += h_fintab[tab_of[c]][((size_t)gr * (ntile + 1) + mt) * 3 + 1] / FXO_TN;
+  }
   int Ssplit = (int)std::max(1LL, 2LL * ctx->num_cus / std::max(1LL, tiles)); // one round of the 2 resident workgroups per CU (measured: 28 splits 0.407 ms, 56: 0.417, 57: 0.50); at least 24 chunks each (below)
   if (const char *e = getenv("PMH_FXO_SPLIT")) Ssplit = std::max(1, atoi(e));
   std::vector<int>       items, vnkc(S->ncls, 1), vldk(S->ncls, 16), vncol(S->ncls, 128);
@@ -1122,27 +1231,50 @@ static int fxo_prepare(fx_shared *S)
     Smax = std::max(Smax, Sc);
     vnkc[c] = C.nkc, vldk[c] = C.ldk, vncol[c] = ncol;
     C.coff = ctot;
+    const int               ntile = C.Mp / C.tm, Mrows = C.m1 - C.m0;
+    const std::vector<int> &ftab = h_fintab[tab_of[c]], &ctab = h_coltab[tab_of[c]];
+    std::vector<long long>  finbase((size_t)C.ngroups * ntile, 0);
+    double                  prod = 0.0, ctiles = 0.0; // (valid rows) x (listed columns) and rows x padded columns over the class's (group, row tile) pairs
+    C.item_first = (int)(items.size() / 8);
     for (int g = 0; g < C.ngroups; g++)
-      for (int mt = 0; mt < C.Mp / C.tm; mt++)
-        for (int nt = 0; nt < ncol / FXO_TN; nt++)
+      for (int mt = 0; mt < ntile; mt++) {
+        const int *ft = ftab.data() + ((size_t)g * (ntile + 1) + mt) * 3;
+        const int  nct = ft[1]; // padded columns of this (group, row tile)
+        finbase[(size_t)g * ntile + mt] = ctot;
+        int listed = 0;
+        for (int j = 0; j < nct; j++) listed += ctab[(size_t)ft[0] + j] >= 0;
+        prod += (double)std::max(0, std::min(Mrows, (mt + 1) * C.tm) - mt * C.tm) * listed, ctiles += (double)C.tm * nct;
+        for (int nt = 0; nt < nct / FXO_TN; nt++)
           for (int sp = 0; sp < Sc; sp++) {
-            items.insert(items.end(), {c, g, mt, nt, klo + (int)((long long)nk * sp / Sc), klo + (int)((long long)nk * (sp + 1) / Sc), sp, 0});
+            items.insert(items.end(), {c, g, mt, nt, klo + (int)((long long)nk * sp / Sc), klo + (int)((long long)nk * (sp + 1) / Sc), sp, nct});
             iteml.push_back(C.aoff);
             iteml.push_back(C.xoff + (long long)g * C.ld * FXS_S);
-            iteml.push_back(ctot + ((long long)g * Sc + sp) * C.Mp * ncol);
+            iteml.push_back(ctot + (long long)sp * C.tm * nct);
+            iteml.push_back((long long)ft[0] + (long long)nt * FXO_TN);
           }
-    ctot += (long long)C.ngroups * Sc * C.Mp * ncol;
-    const double M = C.m1 - C.m0, share = (double)nk / std::max(1, C.nkc);
-    S->flops += (double)C.ngroups * 2.0 * M * C.nc * share * 8.0 * C.nsym;
+        ctot += (long long)Sc * C.tm * nct;
+      }
+    C.item_count = (int)(items.size() / 8) - C.item_first;
+    if (getenv("PMH_FXO_VERBOSE")) {
+      fprintf(stderr, "PMH_FX_CLASS_ORBIT class %d: %d representatives in %d row tiles of %d, %d splits, padded columns per (group, row tile):", c, Mrows, ntile, C.tm, Sc);
+      for (int g = 0; g < C.ngroups; g++)
+        for (int mt = 0; mt < ntile; mt++) fprintf(stderr, " %d", ftab[((size_t)g * (ntile + 1) + mt) * 3 + 1]);
+      fprintf(stderr, " (of %d); listed x rows / all = %.3f\n", C.nsym * 8, prod / std::max(1.0, (double)C.ngroups * Mrows * C.nsym * 8));
+    }
+    if (C.d_finbase) pmh_free(ctx, C.d_finbase), C.d_finbase = nullptr;
+    PMH_CHK(pmh_malloc(ctx, sizeof(long long) * std::max<size_t>(1, finbase.size()), (void **)&C.d_finbase));
+    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_finbase, finbase.data(), sizeof(long long) * finbase.size()));
+    const double M = Mrows, share = (double)nk / std::max(1, C.nkc);
+    S->flops += 2.0 * C.nc * share * prod; // the products of the listed columns with the tiles' rows (padding rows and columns not counted)
     S->owned_bytes += 8.0 * M * C.nc;
     // this rank's columns of A once + the gathered B + the split partial tiles written and read + Y
-    S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 2.0 * 8.0 * Sc * M * ncol + 8.0 * FXS_S * C.nc);
+    S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 8.0 * FXS_S * C.nc) + 2.0 * 8.0 * Sc * ctiles;
     C.nown = Sc; // (re-used: the class's split count)
   }
   S->fxo_S = Smax;
   S->nwg   = (int)(items.size() / 8);
   items.insert(items.end(), {0, 0, 0, 0, 0, 0, 0, 0});
-  iteml.insert(iteml.end(), {0, 0, 0});
+  iteml.insert(iteml.end(), {0, 0, 0, 0});
   if (S->d_items) pmh_free(ctx, S->d_items);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   if (S->d_wg) pmh_free(ctx, S->d_wg);
@@ -1167,24 +1299,14 @@ static int fxo_prepare(fx_shared *S)
 static int fxo_gemm(fx_shared *S)
 {
   hipStream_t st = S->ctx->stream;
-  for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array); configs[2] / [3]: one class
+  for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array and column lists); configs[2] / [3]: one class
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
-    int first = 0, count = 0; // the class's items are contiguous
-    {
-      int idx = 0;
-      for (int cc = 0; cc < S->ncls; cc++) {
-        const fxs_class &D = S->C[cc];
-        const int        n = D.nc ? D.ngroups * (D.Mp / D.tm) * (D.nsymp * 8 / FXO_TN) * D.nown : 0;
-        if (cc == c) first = idx, count = n;
-        idx += n;
-      }
-    }
+    const int first = C.item_first, count = C.item_count; // the class's items are contiguous
     if (!count) continue;
-    const int ncol = C.nsymp * 8;
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
-  hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 3 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
-                     (const int *)(S->d_wg + 2 * S->ncls), (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
+  hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
+                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
     case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;
@@ -1194,8 +1316,10 @@ static int fxo_gemm(fx_shared *S)
     default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
     }
 #undef FXO_LAUNCH
-    hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)(((long long)C.Mp * ncol / 2 + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp, ncol, C.nsymp, C.nc, C.nown, (long long)C.nown * C.Mp * ncol,
-                       (const double *)(S->cpart + C.coff), (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld, S->Y);
+    if (C.fin_elems > 0)
+      hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, C.nown, (const int *)C.d_fintab,
+                         (const long long *)C.d_finbase, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
+                         S->Y);
   }
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
@@ -1301,7 +1425,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       const fxs_class &C = S->C[slot_class[s]];
       if (S->sym == 2) {
         const int pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), prow[s]) - C.reps.begin()) - C.m0;
-        hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.tm, C.nc, C.nkc, (const int *)C.d_urel,
+        hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (const int *)C.d_urel,
                            (const double *)(sol + srs[s]), S->Afund + C.aoff);
       } else if (S->sym && C.nsym > 1) {
         const int p = prow[s];
@@ -1349,7 +1473,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int g = C.op_of[r], p = C.rep_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin()) - C.m0;
         nb          = std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK));
-        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, pl, C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
                            (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc), (const double *)(S->Afund + C.aoff), d_out);
       } else
       hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
@@ -1434,7 +1558,8 @@ int fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host
     for (int i = 0; i < n; i++) {
       const int r = C.pos[gamma[i] - S->K->rowstart[b]], p = C.rep_of[r], g = C.op_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin());
       const double  sp = (double)C.h_sign[(size_t)g * C.nc + p];
-      const double *ab = T.data() + (size_t)(pl / C.tm) * C.nkc * (FXO_TK * C.tm) + pl % C.tm;
+      const int     pr = C.reprow[pl]; // the representative's row of A
+      const double *ab = T.data() + (size_t)(pr / C.tm) * C.nkc * (FXO_TK * C.tm) + pr % C.tm;
       for (int cc = 0; cc < C.nc; cc++)
         row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(cc / FXO_TK) * (FXO_TK * C.tm) + (cc % FXO_TK) * C.tm];
       for (int k = 0; k < n; k++) out_host[(size_t)i * n + k] = row[C.pos[gamma[k] - S->K->rowstart[b]]];
