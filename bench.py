@@ -601,11 +601,17 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         }
         if storage_used == "class_orbit":  # compute-bound: the fp64 matrix peak is the roofline (78.6 TFLOP/s dense, AMD's MI355X figure; scripts/micro/mfma_f64.hip measures 72 for this instruction)
             tf = flops_k / (ms_k / n_k * 1e-3) / 1e12 if n_k else 0.0
+            fl_issued, fl_dense = E.apply_flops_detail()
             roofline.update({
                 "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "flops_per_launch": flops_k,
+                "flops_issued_per_launch": fl_issued, "frac_issued": (fl_issued / (ms_k / n_k * 1e-3) / 1e12 / 78.6) if n_k else None, "flops_unpruned_product": fl_dense,
+                "flops_note": "flops_per_launch = 2 n_c x (rows of each row tile) x (the columns (operation, block) whose rows of Y the tile's representatives need: a block only reads the rows of "
+                              "Y on the dofs it touches, 52-77 %% of the union); flops_issued adds the padding of rows and columns to the 120 x 128 tiles (what the matrix cores execute); "
+                              "flops_unpruned_product = every (representative, operation, block), the count of the line before the pruning (%.2f of it is left)" % (flops_k / max(fl_dense, 1.0)),
                 "kernel": "k_fxo_gemm / k_fxo_gemm4<NA> (row tile 128, or 8 NA = 96..120 where that pads the representatives' rows less: 715 -> 720 with NA = 15) (+ k_fxo_fin): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of %.2f GB of symmetric tiles) and "
                           "Y = W_c X becomes the GEMM (representatives) x (operations x 8 right-hand sides) over n_c on v_mfma_f64_4x4x4_4b_f64: %.0f flop per stored byte, compute-bound; B is gathered from the L2-resident multivector "
-                          "(one index per (operation, dof), sign in its lowest bit), split-K partial tiles summed in a fixed order (the FETI dual operator apply, SURVEY 8d dense path)"
+                          "(one index per (operation, dof), sign in its lowest bit), split-K partial tiles summed in a fixed order; the representatives are ordered by which (operation, block) columns their rows are needed for and "
+                          "every row tile multiplies its own column list only (the FETI dual operator apply, SURVEY 8d dense path)"
                           % (q.explicit_symmetries, n_solves - len(E.n_gamma) if n_solves > len(E.n_gamma) else n_solves, E.dense_bytes / 1e9, 4.0 * float(E.class_union(0).size) ** 2 / 1e9, flops_k / max(E.dense_bytes, 1)),
                 "hbm_bytes_algorithmic": b_k, "hbm_GBs": achieved,
                 "note": "the HBM-bound form of the same apply (--explicit-storage class_sym: k_fxs_symm8, 4.65 GB per apply at 0.77-0.80 of the 8 TB/s peak) takes 0.73-0.75 ms; this form moves 48 x fewer bytes"})

@@ -327,7 +327,8 @@ int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplic
                                 instruction: 48 flop per stored byte instead of 4 -- compute-bound instead of HBM-bound */
 int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS */
 int pmh_fexplicit_create_shared_orbit(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_ORBIT */
-int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops); /* PMH_FX_CLASS_ORBIT: useful flops of the dense apply (the roofline of that storage is the fp64 MFMA peak); 0 otherwise */
+int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops); /* PMH_FX_CLASS_ORBIT: useful flops of the dense apply = (rows of the row tiles) x (the columns their blocks need) x 2 n_c (the roofline of that storage is the fp64 MFMA peak); 0 otherwise */
+int pmh_fexplicit_apply_flops_detail(pmh_fexplicit E, double *issued /* padded tiles, what the matrix cores execute */, double *dense /* every (representative, operation, block): the count without the pruning by the blocks' touched dofs */);
 int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_SYM */
 int pmh_fexplicit_destroy(pmh_fexplicit E);
 int pmh_fexplicit_sizes(pmh_fexplicit E, int *nblocks, int *n_gamma /* [nblocks] or NULL */, long long *dense_bytes, double *gemv_algorithmic_bytes);

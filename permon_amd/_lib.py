@@ -246,6 +246,7 @@ _PROTOS = {
     "pmh_fexplicit_create_shared_sym": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_create_shared_orbit": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_apply_flops": [vp, c_double_p],
+    "pmh_fexplicit_apply_flops_detail": [vp, c_double_p, c_double_p],
     "pmh_fexplicit_class_sym_plan": [C.c_int, C.c_int, vp, vp],
     "pmh_fexplicit_orbit_row_tile": [C.c_int, vp, vp],
     "pmh_box_symmetries": [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp],

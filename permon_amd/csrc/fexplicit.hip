@@ -658,6 +658,14 @@ extern "C" int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops)
   return PMH_SUCCESS;
 }
 
+extern "C" int pmh_fexplicit_apply_flops_detail(pmh_fexplicit E, double *issued, double *dense)
+{
+  PMH_ARG(E && issued && dense);
+  *issued = *dense = 0.0;
+  if (E->sh) fxs_apply_flops_detail(E->sh, issued, dense);
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_fexplicit_set_stripe(pmh_fexplicit E, int rank, int size)
 {
   PMH_ARG(E && size >= 1 && rank >= 0 && rank < size);

@@ -11,6 +11,7 @@ int       fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, con
 long long fxs_dense_bytes(fx_shared *S);
 double    fxs_apply_bytes(fx_shared *S);
 double    fxs_apply_flops(fx_shared *S);
+void      fxs_apply_flops_detail(fx_shared *S, double *issued, double *dense);
 int       fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves);
 int       fxs_apply(fx_shared *S, const double *lambda, double *y);
 int       fxs_dense(fx_shared *S);

@@ -99,7 +99,7 @@ struct fx_shared {
   double                *Afund = nullptr, *cpart = nullptr;
   long long              afund_tot = 0, cpart_cap = 0;
   int                    fxo_ready = 0, fxo_S = 1, stripe_rank = 0, stripe_size = 0;
-  double                 flops = 0.0;
+  double                 flops = 0.0, flops_issued = 0.0, flops_dense = 0.0; // listed columns x valid rows; padded tiles; every (representative, operation, block)
 };
 
 // Y = W_c X with 8 right-hand sides, W_c symmetric and stored in full: the product is taken as Y[c][s] = sum_r W[r][c] X[r][s], i.e.
@@ -1022,6 +1022,7 @@ int fxs_set_stripe(fx_shared *S, int rank, int size)
 
 long long fxs_dense_bytes(fx_shared *S) { return S->sym ? (long long)S->owned_bytes : (long long)sizeof(double) * S->wtot; }
 double    fxs_apply_flops(fx_shared *S) { return S->sym == 2 ? S->flops : 0.0; } // orbit storage: the GEMM's useful flops per apply
+void      fxs_apply_flops_detail(fx_shared *S, double *issued, double *dense) { *issued = S->sym == 2 ? S->flops_issued : 0.0, *dense = S->sym == 2 ? S->flops_dense : 0.0; }
 double    fxs_apply_bytes(fx_shared *S) { return S->bytes; }
 
 // the touched dofs of class c, ascending, relative to the block start (the numbering of W_c's rows)
@@ -1220,7 +1221,7 @@ static int fxo_prepare(fx_shared *S)
   std::vector<int>       items, vnkc(S->ncls, 1), vldk(S->ncls, 16), vncol(S->ncls, 128);
   std::vector<long long> iteml;
   long long              ctot = 0;
-  S->flops = 0.0, S->bytes = 0.0, S->owned_bytes = 0.0;
+  S->flops = 0.0, S->flops_issued = 0.0, S->flops_dense = 0.0, S->bytes = 0.0, S->owned_bytes = 0.0;
   int Smax = 1;
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
@@ -1266,6 +1267,7 @@ static int fxo_prepare(fx_shared *S)
     PMH_CHK(pmh_memcpy_h2d(ctx, C.d_finbase, finbase.data(), sizeof(long long) * finbase.size()));
     const double M = Mrows, share = (double)nk / std::max(1, C.nkc);
     S->flops += 2.0 * C.nc * share * prod; // the products of the listed columns with the tiles' rows (padding rows and columns not counted)
+    S->flops_issued += 2.0 * C.ldk * share * ctiles, S->flops_dense += (double)C.ngroups * 2.0 * M * C.nc * share * 8.0 * C.nsym;
     S->owned_bytes += 8.0 * M * C.nc;
     // this rank's columns of A once + the gathered B + the split partial tiles written and read + Y
     S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 8.0 * FXS_S * C.nc) + 2.0 * 8.0 * Sc * ctiles;

@@ -318,6 +318,12 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_apply_flops(self.h, C.byref(f)))
         return f.value
 
+    def apply_flops_detail(self):
+        """"class_orbit": (flops the matrix cores execute: padded tiles, flops of the unpruned product over every (representative, operation, block))."""
+        a, b = C.c_double(), C.c_double()
+        check(self.ctx.L.pmh_fexplicit_apply_flops_detail(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
         """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
         sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None
