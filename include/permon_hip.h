@@ -214,10 +214,6 @@ int pmh_qppf_apply_G(pmh_qppf pf, const double *v, double *Gv);     /* MatMult(c
 
 /* ---- composed operators of the QP transform chain ------------------------------------------------------ */
 int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op *op);   /* MatCreatePenalized matpenalized.c:212-243; mult :12-22 */
-/* the other three op slots MatCreatePenalized registers (matpenalized.c:232-235): MatMultTranspose_Penalized :26-36,
-   MatMultAdd_Penalized :40-57 (y = x2 + A_rho x; x2 may be y), MatMultTransposeAdd_Penalized :61-78 */
-int pmh_op_penalized_mult_add(pmh_op op, const double *x, const double *x2, double *y);
-int pmh_op_penalized_mult_transpose_add(pmh_op op, const double *x, const double *x2, double *y);
 /* the other three op slots MatCreatePenalized registers (matpenalized.c:232-235): MatMultTranspose_Penalized :26-36 (through
    pmh_op_mult_transpose), MatMultAdd_Penalized :40-57 (y = x2 + A_rho x; x2 may be y), MatMultTransposeAdd_Penalized :61-78 */
 int pmh_op_penalized_mult_add(pmh_op op, const double *x, const double *x2, double *y);

@@ -432,6 +432,14 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // and runs on the fp64 matrix instruction (v_mfma_f64_4x4x4_4b_f64, as k_fxs_symm8).  Workgroup tile 128 x 128, k in chunks of 16, 4 waves of
 // 64 x 64 (4 x 16 accumulators per lane), A pre-tiled in the order of its LDS image ([k][row] per (row tile, chunk): coalesced 16-byte loads),
 // both operands double-buffered in LDS, split-K partial tiles summed in a fixed order by k_fxo_fin, which also applies s_g(p) and scatters row g p.
+// Two workgroups share a CU (one round of 2 x 256 CUs) and run the same loop: started together, the two waves of a SIMD reach their LDS-read waits, their
+// operand stores and the barrier of every chunk at the same time and the matrix pipe idles through each of them (PMC: 65 % busy).  The second half of the
+// grid -- the workgroups that take the CUs' second slots -- starts `stagger` x ~1000 cycles late, so that one wave multiplies while its partner waits.
+#define FXO_STAGGER(st)                                                                     \
+  do {                                                                                      \
+    if ((st) > 0 && 2 * blockIdx.x >= gridDim.x)                                            \
+      for (int i_ = 0; i_ < (st); i_++) __builtin_amdgcn_s_sleep(16);                        \
+  } while (0)
 #define FXO_TM 128
 #define FXO_TN 128
 #define FXO_TK 16
@@ -441,10 +449,11 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // the group, C offset of (class, group, split)
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                      const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                     const double *__restrict__ X, double *__restrict__ cpart)
+                                                     const double *__restrict__ X, double *__restrict__ cpart, int stagger)
 {
   __shared__ double As[2][FXO_TK][FXO_LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB];
+  FXO_STAGGER(stagger);
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
@@ -538,11 +547,12 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
 template <int NA>
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                       const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                      const double *__restrict__ X, double *__restrict__ cpart)
+                                                      const double *__restrict__ X, double *__restrict__ cpart, int stagger)
 {
   constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB4];
+  FXO_STAGGER(stagger);
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
@@ -1301,6 +1311,7 @@ static int fxo_prepare(fx_shared *S)
 static int fxo_gemm(fx_shared *S)
 {
   hipStream_t st = S->ctx->stream;
+  static const int stagger = getenv("PMH_FXO_STAGGER") ? atoi(getenv("PMH_FXO_STAGGER")) : 0;
   for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array and column lists); configs[2] / [3]: one class
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
@@ -1308,7 +1319,7 @@ static int fxo_gemm(fx_shared *S)
     if (!count) continue;
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
-                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
+                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart, stagger)
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
     case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;

@@ -69,15 +69,23 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   dbl2   ar[NEA];
   double br[NEB];
   int    gn[NEB];
+#if defined(NOALOAD) || defined(NOGATHER)
+  for (int e = 0; e < NEA; e++) ar[e] = dbl2{1.0 + t, 2.0};
+  for (int e = 0; e < NEB; e++) br[e] = 0.5 + t, gn[e] = 0;
+#endif
   auto loadA = [&](int kc) {
+#ifndef NOALOAD // knock-out: no HBM stream of A (timing only)
     const double *blk = A + ((size_t)mt * nkc + kc) * (TK * TM);
 #pragma unroll
     for (int e = 0; e < NEA; e++)
       if ((TK * TM / 2) % NT == 0 || t + NT * e < TK * TM / 2) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + NT * e)));
+#endif
   };
   auto loadG = [&](int kc, int *g) {
+#ifndef NOGATHER
 #pragma unroll
     for (int e = 0; e < NEB; e++) g[e] = gp[kc * TK + kb + KPB * e];
+#endif
   };
 #ifdef DEFSIGN
   unsigned sg = 0; // the signs of the gathered values: applied when they are stored to LDS, so that nothing waits for the gather before the products
@@ -91,11 +99,13 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   };
 #else
   auto gatherB = [&](const int *g) {
+#ifndef NOGATHER // knock-out: no index loads, no gathers (timing only)
 #pragma unroll
     for (int e = 0; e < NEB; e++) {
       const double v = X[(size_t)(g[e] >> 1) * 8 + sl];
       br[e]          = (g[e] & 1) ? -v : v;
     }
+#endif
   };
 #endif
   auto store = [&](int buf) {
@@ -123,9 +133,15 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   for (int kc = kc0; kc < kc1; kc++) {
     const int buf = (kc - kc0) & 1;
     if (kc + 1 < kc1) {
+#ifdef GFIRST // the gathers (and the next index loads) go out BEFORE the HBM loads of A: vmcnt retires in order, so a wait for a gather no longer waits for A
+      gatherB(gn);
+      if (kc + 2 < kc1) loadG(kc + 2, gn);
+      loadA(kc + 1);
+#else
       loadA(kc + 1);
       gatherB(gn);
       if (kc + 2 < kc1) loadG(kc + 2, gn);
+#endif
     }
 #if defined(PIPE) && !defined(ORIENT4)
     // half steps: the operands of the next half step (a: 4 values every other half step, b: 8 values) are read from LDS before the 32 products of this one are issued
@@ -201,8 +217,12 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
 #endif
     }
 #endif
+#ifndef NOSTORE
     if (kc + 1 < kc1) store(buf ^ 1);
+#endif
+#ifndef NOBAR
     __syncthreads();
+#endif
   }
   // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
   const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);

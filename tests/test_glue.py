@@ -1,0 +1,143 @@
+"""The PETSc glue TU (permon_amd/csrc/petsc_glue/permonhip_petsc.c) cannot be compiled here (no PETSc on the image), so it is checked
+textually against the two files it must agree with:
+  * include/permon_hip.h -- every pmh_* call of the glue names a function of the header and passes as many arguments as its prototype has;
+  * INTEGRATION.md -- every glue function the integration guide names is defined in the glue, and every entry point / registration the
+    glue exports is named in the guide.
+It also pins what the round-2 verdict found missing: the glue binds the path bench.py measures (explicit dual operators, SMALXE, the
+operator towers) and fills all of QPSCreate_MPGP's op-table slots and composed methods (src/qps/impls/mpgp/mpgp.c:849-869)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLUE = os.path.join(ROOT, "permon_amd", "csrc", "petsc_glue", "permonhip_petsc.c")
+HEADER = os.path.join(ROOT, "include", "permon_hip.h")
+GUIDE = os.path.join(ROOT, "INTEGRATION.md")
+
+
+def strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", lambda m: " " * len(m.group(0)) if "\n" not in m.group(0) else re.sub(r"[^\n]", " ", m.group(0)), src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def split_args(s):
+    """Top-level comma split of an argument list (parentheses, brackets and braces nest)."""
+    args, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    last = "".join(cur).strip()
+    if last or args:
+        args.append(last)
+    return args
+
+
+def balanced(src, open_pos):
+    """src[open_pos] == '(' -> the text between it and its matching ')'."""
+    depth = 0
+    for i in range(open_pos, len(src)):
+        if src[i] == "(":
+            depth += 1
+        elif src[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return src[open_pos + 1:i]
+    raise AssertionError("unbalanced parentheses")
+
+
+def header_prototypes():
+    src = strip_comments(open(HEADER).read())
+    protos = {}
+    for m in re.finditer(r"\b(?:int|void\s*\*|const\s+char\s*\*)\s*(pmh_\w+)\s*\(", src):
+        name = m.group(1)
+        if src[:m.start()].rstrip().endswith("typedef"):
+            continue
+        args = split_args(balanced(src, m.end() - 1))
+        n = 0 if args in ([], ["void"]) else len(args)
+        protos.setdefault(name, set()).add(n)
+    return protos
+
+
+def glue_calls():
+    src = strip_comments(open(GLUE).read())
+    calls = []
+    for m in re.finditer(r"\b(pmh_\w+)\s*\(", src):
+        name = m.group(1)
+        args = split_args(balanced(src, m.end() - 1))
+        n = 0 if args == [] else len(args)
+        line = src.count("\n", 0, m.start()) + 1
+        calls.append((name, n, line))
+    return calls
+
+
+def glue_functions():
+    src = strip_comments(open(GLUE).read())
+    return set(re.findall(r"^(?:PERMON_EXTERN|static)\s+(?:PetscErrorCode|int)\s+(\w+)\s*\(", src, flags=re.M))
+
+
+def test_header_has_no_conflicting_prototypes():
+    for name, ns in header_prototypes().items():
+        assert len(ns) == 1, "%s is declared with different argument counts %s" % (name, sorted(ns))
+
+
+def test_every_pmh_call_of_the_glue_matches_the_header():
+    protos = header_prototypes()
+    types = {"pmh_ctx", "pmh_csr", "pmh_op", "pmh_mpgp", "pmh_qppf", "pmh_gluing", "pmh_extension", "pmh_blockdiag", "pmh_matinv", "pmh_fexplicit", "pmh_smalxe", "pmh_mg", "pmh_feti_chain",
+             "pmh_shell_mult_fn", "pmh_converged_fn"}
+    calls = [c for c in glue_calls() if c[0] not in types and not c[0].endswith(("_opts", "_stats", "_rc_"))]
+    assert len(calls) > 80, "the glue should call into the library in many places (%d found)" % len(calls)
+    for name, n, line in calls:
+        assert name in protos, "permonhip_petsc.c:%d calls %s, which include/permon_hip.h does not declare" % (line, name)
+        assert n in protos[name], "permonhip_petsc.c:%d calls %s with %d arguments, the header declares %s" % (line, name, n, sorted(protos[name]))
+
+
+def test_every_glue_function_named_in_integration_md_exists():
+    guide = open(GUIDE).read()
+    funcs = glue_functions()
+    named = set(re.findall(r"`((?:QPS|QPC|QPPF|QPT|Mat|PC|KSP|PermonHip)\w*HIP\w*)(?:\([^`]*\))?`", guide))
+    named = {n for n in named if not n.endswith("_C")}
+    assert len(named) >= 40, sorted(named)
+    missing = sorted(n for n in named if n not in funcs)
+    assert not missing, "INTEGRATION.md names glue functions that permonhip_petsc.c does not define: %s" % missing
+    # and the other way round: what the glue exports is documented
+    src = strip_comments(open(GLUE).read())
+    exported = set(re.findall(r"^PERMON_EXTERN\s+PetscErrorCode\s+(\w+)\s*\(", src, flags=re.M)) - {"QPCCreate_Box", "QPSCreate_SMALXE"}  # the reference's own constructors, re-declared
+    undocumented = sorted(e for e in exported if e not in guide)
+    assert not undocumented, "exported by the glue but absent from INTEGRATION.md: %s" % undocumented
+
+
+def test_glue_binds_the_measured_path():
+    calls = {c[0] for c in glue_calls()}
+    for need in ("pmh_fexplicit_create_shared_orbit", "pmh_fexplicit_set_box_symmetry", "pmh_fexplicit_assemble", "pmh_matinv_attach_explicit", "pmh_csr_block_classes",  # explicit K^+
+                 "pmh_op_create_feti_dual", "pmh_op_create_projected", "pmh_op_create_penalized", "pmh_op_create_shell", "pmh_op_create_csr",  # operator towers
+                 "pmh_qppf_create", "pmh_qppf_apply_Q", "pmh_qppf_apply_P", "pmh_qppf_apply_GtG", "pmh_qppf_apply_CP", "pmh_qppf_apply_halfQ", "pmh_qppf_apply_halfQ_transpose",
+                 "pmh_smalxe_create", "pmh_smalxe_solve", "pmh_smalxe_get_stats", "pmh_smalxe_get_inner", "pmh_pcpg_solve", "pmh_ksp_cg_solve", "pmh_kspfeti_solve",
+                 "pmh_mg_create", "pmh_matinv_set_pc_mg", "pmh_matinv_enable_bsr3", "pmh_comm_unique_id", "pmh_comm_init"):
+        assert need in calls, "the glue never calls %s" % need
+    src = strip_comments(open(GLUE).read())
+    for name in ("mpgphip", "smalxehip", "pcpghip", "ksphip"):
+        assert re.search(r'QPSRegister\("%s"' % name, src), "QPS type %s is not registered" % name
+
+
+def test_mpgphip_fills_the_reference_op_table_and_composed_methods():
+    """QPSCreate_MPGP sets 8 op slots (mpgp.c:849-856) and composes 12 methods (mpgp.c:858-869)."""
+    src = strip_comments(open(GLUE).read())
+    body = src[src.index("QPSCreate_MPGPHIP(QPS qps)"):]
+    body = body[:body.index("PetscFunctionReturn")]
+    for slot in ("setup", "solve", "resetstatistics", "destroy", "isqpcompatible", "setfromoptions", "monitor", "viewconvergence"):
+        assert re.search(r"qps->ops->%s\s*=" % slot, body), "QPSCreate_MPGPHIP leaves _QPSOps.%s empty" % slot
+    composed = ["QPSMPGPGetCurrentStepType", "QPSMPGPGetAlpha", "QPSMPGPSetAlpha", "QPSMPGPGetGamma", "QPSMPGPSetGamma", "QPSMPGPGetOperatorMaxEigenvalue", "QPSMPGPSetOperatorMaxEigenvalue",
+                "QPSMPGPSetOperatorMaxEigenvalueTolerance", "QPSMPGPGetOperatorMaxEigenvalueTolerance", "QPSMPGPGetOperatorMaxEigenvalueIterations", "QPSMPGPSetOperatorMaxEigenvalueIterations",
+                "QPSMPGPUpdateMaxEigenvalue"]
+    for c in composed:
+        assert '"%s_MPGP_C", %s_MPGPHIP' % (c, c) in body, "composed method %s_MPGP_C is not bound" % c
+    # the options the reference's QPSSetFromOptions_MPGP reads (mpgp.c:723-745)
+    for key in ("-qps_mpgp_alpha_direct", "-qps_mpgp_alpha", "-qps_mpgp_gamma", "-qps_mpgp_maxeig", "-qps_mpgp_maxeig_tol", "-qps_mpgp_maxeig_iter", "-qps_mpgp_btol", "-qps_mpgp_bound_chop_tol",
+                "-qps_mpgp_expansion_type", "-qps_mpgp_expansion_length_type", "-qps_mpgp_alpha_reset", "-qps_mpgp_fallback", "-qps_mpgp_fallback2"):
+        assert '"%s"' % key in src, "option %s is not read by QPSSetFromOptions_MPGPHIP" % key
