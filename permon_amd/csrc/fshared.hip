@@ -432,14 +432,6 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // and runs on the fp64 matrix instruction (v_mfma_f64_4x4x4_4b_f64, as k_fxs_symm8).  Workgroup tile 128 x 128, k in chunks of 16, 4 waves of
 // 64 x 64 (4 x 16 accumulators per lane), A pre-tiled in the order of its LDS image ([k][row] per (row tile, chunk): coalesced 16-byte loads),
 // both operands double-buffered in LDS, split-K partial tiles summed in a fixed order by k_fxo_fin, which also applies s_g(p) and scatters row g p.
-// Two workgroups share a CU (one round of 2 x 256 CUs) and run the same loop: started together, the two waves of a SIMD reach their LDS-read waits, their
-// operand stores and the barrier of every chunk at the same time and the matrix pipe idles through each of them (PMC: 65 % busy).  The second half of the
-// grid -- the workgroups that take the CUs' second slots -- starts `stagger` x ~1000 cycles late, so that one wave multiplies while its partner waits.
-#define FXO_STAGGER(st)                                                                     \
-  do {                                                                                      \
-    if ((st) > 0 && 2 * blockIdx.x >= gridDim.x)                                            \
-      for (int i_ = 0; i_ < (st); i_++) __builtin_amdgcn_s_sleep(16);                        \
-  } while (0)
 #define FXO_TM 128
 #define FXO_TN 128
 #define FXO_TK 16
@@ -449,11 +441,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // the group, C offset of (class, group, split)
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                      const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                     const double *__restrict__ X, double *__restrict__ cpart, int stagger)
+                                                     const double *__restrict__ X, double *__restrict__ cpart)
 {
   __shared__ double As[2][FXO_TK][FXO_LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB];
-  FXO_STAGGER(stagger);
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
@@ -478,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
   auto loadA = [&](int kc) {
     const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * FXO_TM);
 #pragma unroll
-    for (int e = 0; e < NEA; e++) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + 256 * e)));
+    for (int e = 0; e < NEA; e++) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e)); // default cache policy: the workgroups of the other column tiles read the same chunk from the XCD's L2 (work-item order below)
   };
   auto loadG = [&](int kc) {
 #pragma unroll
@@ -547,12 +538,11 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
 template <int NA>
 __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                       const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                      const double *__restrict__ X, double *__restrict__ cpart, int stagger)
+                                                      const double *__restrict__ X, double *__restrict__ cpart)
 {
   constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB4];
-  FXO_STAGGER(stagger);
   const int *w8 = items + 8 * blockIdx.x;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
@@ -578,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ it
     const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM);
 #pragma unroll
     for (int e = 0; e < NEA; e++)
-      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + 256 * e)));
+      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e)); // default cache policy, see k_fxo_gemm
   };
   auto loadG = [&](int kc) {
 #pragma unroll
@@ -1247,6 +1237,8 @@ static int fxo_prepare(fx_shared *S)
     std::vector<long long>  finbase((size_t)C.ngroups * ntile, 0);
     double                  prod = 0.0, ctiles = 0.0; // (valid rows) x (listed columns) and rows x padded columns over the class's (group, row tile) pairs
     C.item_first = (int)(items.size() / 8);
+    struct aset { int g, mt, sp, ntl, nct, coff; long long cbase; }; // one (group, row tile, split): its column tiles read the same chunks of A
+    std::vector<aset> sets;
     for (int g = 0; g < C.ngroups; g++)
       for (int mt = 0; mt < ntile; mt++) {
         const int *ft = ftab.data() + ((size_t)g * (ntile + 1) + mt) * 3;
@@ -1255,16 +1247,37 @@ static int fxo_prepare(fx_shared *S)
         int listed = 0;
         for (int j = 0; j < nct; j++) listed += ctab[(size_t)ft[0] + j] >= 0;
         prod += (double)std::max(0, std::min(Mrows, (mt + 1) * C.tm) - mt * C.tm) * listed, ctiles += (double)C.tm * nct;
-        for (int nt = 0; nt < nct / FXO_TN; nt++)
-          for (int sp = 0; sp < Sc; sp++) {
-            items.insert(items.end(), {c, g, mt, nt, klo + (int)((long long)nk * sp / Sc), klo + (int)((long long)nk * (sp + 1) / Sc), sp, nct});
-            iteml.push_back(C.aoff);
-            iteml.push_back(C.xoff + (long long)g * C.ld * FXS_S);
-            iteml.push_back(ctot + (long long)sp * C.tm * nct);
-            iteml.push_back((long long)ft[0] + (long long)nt * FXO_TN);
-          }
+        for (int sp = 0; sp < Sc; sp++) sets.push_back({g, mt, sp, nct / FXO_TN, nct, ft[0], ctot});
         ctot += (long long)Sc * C.tm * nct;
       }
+    {
+      // The column tiles of one (row tile, split) read the SAME chunks of A at the same pace.  Workgroups b and b + 8 run on one XCD (one L2: MI355X_MICROARCH.md, workgroup
+      // dispatch; scripts/micro/census.hip), so the items go out 8 sets at a time, column tile after column tile: the nt-th tile of a set sits 8 nt items after its first one and
+      // finds the chunk in the XCD's L2 instead of fetching it again from beyond (with default-policy loads of A: scripts/micro/orbit_gemm.hip -DAPLAIN, OG_MAP=2: -8 % per GEMM).
+      // The partial sums stay indexed by (tile, split): the order of the items changes nothing in the result.  PMH_FXO_NO_XCDMAP=1: column tile after column tile, all splits each.
+      static const bool xcdmap = !getenv("PMH_FXO_NO_XCDMAP");
+      auto emit = [&](const aset &a, int nt) {
+        items.insert(items.end(), {c, a.g, a.mt, nt, klo + (int)((long long)nk * a.sp / Sc), klo + (int)((long long)nk * (a.sp + 1) / Sc), a.sp, a.nct});
+        iteml.push_back(C.aoff);
+        iteml.push_back(C.xoff + (long long)a.g * C.ld * FXS_S);
+        iteml.push_back(a.cbase + (long long)a.sp * C.tm * a.nct);
+        iteml.push_back((long long)a.coff + (long long)nt * FXO_TN);
+      };
+      if (xcdmap) {
+        for (size_t s0 = 0; s0 < sets.size(); s0 += 8) {
+          const size_t s1 = std::min(sets.size(), s0 + 8);
+          int          ntmax = 0;
+          for (size_t i = s0; i < s1; i++) ntmax = std::max(ntmax, sets[i].ntl);
+          for (int nt = 0; nt < ntmax; nt++)
+            for (size_t i = s0; i < s1; i++)
+              if (nt < sets[i].ntl) emit(sets[i], nt);
+        }
+      } else {
+        for (size_t i = 0; i < sets.size(); i += (size_t)Sc) // the sets of one (group, row tile) are contiguous
+          for (int nt = 0; nt < sets[i].ntl; nt++)
+            for (int sp = 0; sp < Sc; sp++) emit(sets[i + sp], nt);
+      }
+    }
     C.item_count = (int)(items.size() / 8) - C.item_first;
     if (getenv("PMH_FXO_VERBOSE")) {
       fprintf(stderr, "PMH_FX_CLASS_ORBIT class %d: %d representatives in %d row tiles of %d, %d splits, padded columns per (group, row tile):", c, Mrows, ntile, C.tm, Sc);
@@ -1311,7 +1324,6 @@ static int fxo_prepare(fx_shared *S)
 static int fxo_gemm(fx_shared *S)
 {
   hipStream_t st = S->ctx->stream;
-  static const int stagger = getenv("PMH_FXO_STAGGER") ? atoi(getenv("PMH_FXO_STAGGER")) : 0;
   for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array and column lists); configs[2] / [3]: one class
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
@@ -1319,7 +1331,7 @@ static int fxo_gemm(fx_shared *S)
     if (!count) continue;
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
-                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart, stagger)
+                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
     case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;

@@ -42,11 +42,11 @@ static __device__ __forceinline__ double mfma4(double a, double b, double c) { r
 #define MINB 1
 #endif
 __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
-                                                double *__restrict__ Cpart, int Mp, int N)
+                                                double *__restrict__ Cpart, int Mp, int N, const int *__restrict__ wmap)
 {
   __shared__ double As[2][TK][LDA];
   __shared__ double Bs[2][TK][LDB];
-  const int wgi = blockIdx.x, s = wgi % S, nt = (wgi / S) % Nt, mt = wgi / (S * Nt);
+  const int wgi = wmap ? __builtin_amdgcn_readfirstlane(wmap[blockIdx.x]) : blockIdx.x, s = wgi % S, nt = (wgi / S) % Nt, mt = wgi / (S * Nt);
   const int kc0 = (int)((long long)nkc * s / S), kc1 = (int)((long long)nkc * (s + 1) / S);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
   constexpr int NEA = (TK * TM / 2 + NT - 1) / NT; // dbl2 loads of A per thread and chunk
@@ -78,7 +78,11 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
     const double *blk = A + ((size_t)mt * nkc + kc) * (TK * TM);
 #pragma unroll
     for (int e = 0; e < NEA; e++)
+#ifdef APLAIN // default cache policy: the workgroup that shares the CU (or the XCD) and reads the same chunk of A a moment later finds it in L1 / L2
+      if ((TK * TM / 2) % NT == 0 || t + NT * e < TK * TM / 2) ar[e] = *(const dbl2 *)(blk + 2 * (t + NT * e));
+#else
       if ((TK * TM / 2) % NT == 0 || t + NT * e < TK * TM / 2) ar[e] = __builtin_nontemporal_load((const dbl2 *)(blk + 2 * (t + NT * e)));
+#endif
 #endif
   };
   auto loadG = [&](int kc, int *g) {
@@ -267,11 +271,40 @@ int main(int argc, char **argv)
   (void)hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice), (void)hipMemcpy(dX, hX.data(), hX.size() * 8, hipMemcpyHostToDevice), (void)hipMemcpy(dg, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
-  for (int it = 0; it < 3; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N);
+  int *dmap = nullptr;
+  const int mapmode = getenv("OG_MAP") ? atoi(getenv("OG_MAP")) : 0;
+  if (mapmode) {
+    // blocks b and b + 256 share a CU (scripts/micro/census.hip), blocks b and b + 8 an XCD.  mode 1: the column tiles 0 and 1 of one (row tile, split) on ONE CU (blocks b, b + 256),
+    // the third column tile wherever there is room; mode 2: the column tiles of one (row tile, split) 8 blocks apart (one XCD)
+    const int nwg = Mt * Nt * S;
+    std::vector<int> map(nwg, -1), rest;
+    if (mapmode == 1) {
+      int p = 0;
+      for (int mt = 0; mt < Mt; mt++)
+        for (int sp = 0; sp < S; sp++) {
+          if (p < 256 && p + 256 < nwg && Nt >= 2) map[p] = (mt * Nt + 0) * S + sp, map[p + 256] = (mt * Nt + 1) * S + sp, p++;
+          else rest.push_back((mt * Nt + 0) * S + sp), rest.push_back((mt * Nt + 1) * S + sp);
+          for (int nt = 2; nt < Nt; nt++) rest.push_back((mt * Nt + nt) * S + sp);
+        }
+      size_t r = 0;
+      for (int b = 0; b < nwg; b++) if (map[b] < 0) map[b] = rest[r++];
+    } else {
+      int b = 0;
+      for (int mt = 0; mt < Mt; mt++)
+        for (int s0 = 0; s0 < S; s0 += 8) {
+          const int w = std::min(8, S - s0);
+          for (int nt = 0; nt < Nt; nt++)
+            for (int j = 0; j < w; j++) map[b++] = (mt * Nt + nt) * S + s0 + j;
+        }
+    }
+    (void)hipMalloc(&dmap, nwg * 4), (void)hipMemcpy(dmap, map.data(), nwg * 4, hipMemcpyHostToDevice);
+    printf("work-item map mode %d\n", mapmode);
+  }
+  for (int it = 0; it < 3; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N, dmap);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
   const int reps = 20;
-  for (int it = 0; it < reps; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N);
+  for (int it = 0; it < reps; it++) k_gemm<<<Mt * Nt * S, NT>>>(Mt, Nt, S, nkc, dA, dg, ldk, dX, dC, Mp, N, dmap);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
