@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed reg
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -74,10 +75,19 @@ def parse():
                     "P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp); identical on the projected dual problem, the V-cycle hierarchy is then built per block on K_reg")
     ap.add_argument("--no-bsr3", action="store_true", help="feti: keep K x of the inner CG on the CSR kernel instead of the 3x3-block kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-c2", action="store_true", help="feti at N=1: skip the secondary configs[1] measurement")
+    ap.add_argument("--no-c2", action="store_true", help="feti at N=1: the headline alone -- skip every secondary block (configs[1], configs[3], configs[4], general, contact_solve)")
     ap.add_argument("--sim-world", type=int, default=0, help="feti, testing: this single process takes the share rank 0 would have in a run on SIM_WORLD GPUs (8/SIM_WORLD blocks, no collective): per-GPU launch-latency rehearsal of the strong-scaling run")
     ap.add_argument("--cpu-its", type=int, default=24, help="c2: MPGP iterations of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-its-feti", type=int, default=5, help="feti: MPGP iterations of the bounded CPU-baseline sample (median of their times; cut at ~45 s)")
+    ap.add_argument("--young", default="", help="feti: Young's moduli of the subdomains, comma separated, or 'distinct' (1, 1.25, 1.5 ...): a heterogeneous body whose blocks K_s = E_s K_1 all differ -- "
+                    "the non-congruent case: no class sharing, no symmetry set-up, per-block symmetric storage (k_fx_symv, HBM-bound)")
+    ap.add_argument("--general-nel", type=int, default=21, help="feti at N=1: elements per edge of the secondary 'general' block (8 subdomains of 8 different materials: every column of every W_b by its own K^+ solve, "
+                    "so the set-up grows with n_Gamma: 21 -> ~20 s, 43 -> ~5 min); 0 = skip")
+    ap.add_argument("--c2-steps", type=int, default=2500, help="feti at N=1: MPGP iterations of the secondary configs[1] block (from x0 = 0 the first ~hundreds of iterations are pure CG; the expansion steps start once the iterate reaches the obstacle)")
+    ap.add_argument("--no-configs3", action="store_true", help="feti at N=1: skip the secondary configs[3] block (4x4x4 subdomains of 21^3 elements, dense 384 x 384 coarse problem)")
+    ap.add_argument("--no-svm", action="store_true", help="feti at N=1: skip the secondary configs[4] block (5 M x 64 SVM dual)")
+    ap.add_argument("--no-contact-solve", action="store_true", help="feti at N=1: skip the one-call contact solve (pmh_feti_contact_solve: set-up + solve = time to solution)")
+    ap.add_argument("--cpu-direct-nel", type=int, default=21, help="feti: subdomain size at which the CPU baseline factors K_reg with scipy's SuperLU (the reference's direct K^+); the 43^3 block itself would take ~20 min and ~10 GB")
     return ap.parse_args()
 
 
@@ -146,7 +156,9 @@ def cpu_baseline_c2(p, its):
     }
 
 
-def run_c2(ctx, a, steps, warmup, cpu=True):
+def run_c2(ctx, a, steps, warmup, cpu=True, whole_solves=False):
+    """whole_solves: time WHOLE MPGP solves from x0 (expansion and proportioning steps included, the real stopping rule; restarted until at least `steps`
+    iterations are done) instead of exactly `steps` iterations from x0 with the verdict of the test ignored (the first few hundred are pure CG steps)."""
     import permon_amd as pa
     from permon_amd import problems as P
 
@@ -168,13 +180,32 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
     qps.RunFixed(warmup)
     x.set_numpy(p["x0"])
     pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
-    A.timing_enable(2 * steps + 64)
-    ctx.sync()
-    t1 = time.perf_counter()
-    st = qps.RunFixed(steps)
-    ctx.sync()
-    dt = time.perf_counter() - t1
-    assert st.iteration == steps, (st.iteration, steps)
+    nsolves, reasons = 0, []
+    if whole_solves:
+        # QPS defaults (qps.c:73-76): rtol 1e-5, max_it 10 000 = SURVEY 8d's configs[1] set-up
+        A.timing_enable(2 * 10001 * max(1, -(-steps // 10001)) + 64)
+        ctx.sync()
+        t1 = time.perf_counter()
+        done = 0
+        while done < steps:
+            x.set_numpy(p["x0"])
+            st = qps.Solve()
+            done += int(st.iteration)
+            nsolves += 1
+            reasons.append(int(st.reason))
+            if st.iteration == 0:
+                break
+        ctx.sync()
+        dt = time.perf_counter() - t1
+        steps = done
+    else:
+        A.timing_enable(2 * steps + 64)
+        ctx.sync()
+        t1 = time.perf_counter()
+        st = qps.RunFixed(steps)
+        ctx.sync()
+        dt = time.perf_counter() - t1
+        assert st.iteration == steps, (st.iteration, steps)
     n_p1, ms_p1 = A.timing_get(3)  # fused MPGP phase-P1 SpMV launches (the dominant kernel)
     has_ub = p["ub"] is not None
     b_spmv = 12.0 * nnz + 20.0 * n
@@ -186,6 +217,9 @@ def run_c2(ctx, a, steps, warmup, cpu=True):
         "value": steps / dt, "unit": "QPS iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
         "workload": "configs[1]: 5-pt Laplacian %dx%d (n=%d, nnz=%d) MPGP box QP (%s), fp64, CSR int32" % (a.grid, a.grid, n, nnz, a.variant),
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
+        "timed": ("%d whole solve(s) from x0 (rtol 1e-5, max_it 10 000; reasons %s): the real step mix" % (nsolves, reasons)) if whole_solves else "exactly %d iterations from x0, verdict of the convergence test ignored" % steps,
+        "algorithmic_bytes_per_step_type": {"cg": b_spmv + 112.0 * n + ve, "expansion": 2 * b_spmv + 112.0 * n + ve, "proportioning": b_spmv + 104.0 * n + ve,
+                                            "note": "SURVEY 8d: B_cg = B_spmv + 112 n, B_exp = 2 B_spmv + 112 n, B_prop = B_spmv + 104 n (+16 n with an upper bound); whole_iteration_GBs = sum over the timed steps / wall time"},
         "setup_seconds": round(t_setup, 2),
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv_ell<MPGP epilogue> (uniformly short rows: slot-major device copy, one thread per row, no LDS staging; k_spmv_stream otherwise): Ap = A p fused with p'Ap, g'p, QPCFeas",
@@ -356,6 +390,57 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     }
 
 
+def cpu_baseline_direct(ctx, nel_full, nel_factor, applies_per_step, nblocks=8):
+    """The reference's own K^+ on the host: MATINV factors K_reg = MatRegularize(K, R) once per block (PCCHOLESKY / MUMPS, src/mat/impls/inv/matinv.c:481-580)
+    and every F = B K^+ B' application is one forward / backward substitution per block (MatMult_Inv -> KSPSolve with KSPPREONLY, matinv.c:734-743), one block
+    per MPI rank.  PETSc and MUMPS are absent, so the sparse direct solver of the image stands in: scipy.sparse.linalg.splu (SuperLU, minimum-degree ordering on
+    A' + A, symmetric mode, no pivoting) on K_reg from the library's own MatRegularize.  The 43^3 block (255 552 dof, ~1.3e9 factor entries, ~10 GB) would take
+    ~20 min to factor, so two smaller congruent cubes are factored, the solve time per block is measured and extrapolated to the full block with the measured
+    exponent of the growth in n (said in `sample`).  The 8 blocks are independent: 8 ranks on 8 cores are assumed to solve them in parallel without
+    interference; B / B' and the dual-space vector work are not counted."""
+    import scipy.sparse.linalg as spla
+
+    import permon_amd as pa
+
+    sizes = sorted({max(7, (nel_factor * 5) // 7), nel_factor})
+    rows = []
+    for nel in sizes:
+        g = pa.CubeFeti((1, 1, 1), nel, contact=False)
+        Kreg, piv, rho = pa.MatRegularize(ctx, g.Ki, g.R)
+        t0 = time.perf_counter()
+        lu = spla.splu(Kreg.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        t_fac = time.perf_counter() - t0
+        rhs = np.random.default_rng(3).standard_normal(Kreg.shape[0])
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            x = lu.solve(rhs)
+            ts.append(time.perf_counter() - t0)
+        res = float(np.linalg.norm(Kreg @ x - rhs) / np.linalg.norm(rhs))
+        rows.append(dict(nel=nel, n=int(Kreg.shape[0]), factor_s=t_fac, solve_s=float(np.median(ts)), factor_nnz=int(lu.L.nnz + lu.U.nnz), residual=res))
+        del lu
+    n_full = 3 * (nel_full + 1) ** 3
+    a, b = rows[0], rows[-1]
+    expo = math.log(b["solve_s"] / a["solve_s"]) / math.log(b["n"] / a["n"]) if len(rows) > 1 and a["solve_s"] > 0 else 4.0 / 3.0
+    expo_f = math.log(b["factor_s"] / a["factor_s"]) / math.log(b["n"] / a["n"]) if len(rows) > 1 and a["factor_s"] > 0 else 2.0
+    t_solve_full = b["solve_s"] * (n_full / b["n"]) ** expo if nel_full != b["nel"] else b["solve_s"]
+    t_fac_full = b["factor_s"] * (n_full / b["n"]) ** expo_f if nel_full != b["nel"] else b["factor_s"]
+    return {
+        "value": 1.0 / (applies_per_step * t_solve_full), "unit": "QPS iterations/s", "cores": nblocks, "kind": "port",
+        "solve_seconds_per_block_measured": {("%d^3" % r["nel"]): round(r["solve_s"], 4) for r in rows}, "factor_seconds_measured": {("%d^3" % r["nel"]): round(r["factor_s"], 2) for r in rows},
+        "solve_seconds_per_block_full_size": t_solve_full, "factor_seconds_full_size_extrapolated": t_fac_full, "growth_exponent_solve": expo, "growth_exponent_factor": expo_f,
+        "extrapolated": nel_full != b["nel"],
+        "sample": "the reference's direct K^+ (matinv.c:481-580, :734-743): sparse factorisation of K_reg = MatRegularize(K, R) per subdomain, one forward/backward substitution per block and F application; "
+                  "scipy.sparse.linalg.splu (SuperLU, MMD on A'+A, symmetric mode) stands in for PETSc Cholesky / MUMPS.  Factored on this host: %s; residuals %s.  "
+                  "%s  x %.2f F applications per QPS iteration (the GPU run's own mix), %d subdomain blocks on %d cores in parallel (one block per rank, as the reference runs), B / B' and dual-space vector work not counted"
+                  % ("; ".join("%d^3 elements (n = %d): factor %.1f s, %.3g factor entries, solve %.4f s" % (r["nel"], r["n"], r["factor_s"], r["factor_nnz"], r["solve_s"]) for r in rows),
+                     ", ".join("%.1e" % r["residual"] for r in rows),
+                     ("The %d^3 block (n = %d) is EXTRAPOLATED from these with the measured growth of the solve time, n^%.2f: %.2f s per block and application (factorisation n^%.2f: ~%.0f s, not run)."
+                      % (nel_full, n_full, expo, t_solve_full, expo_f, t_fac_full)) if nel_full != b["nel"] else "Measured at the full block size.",
+                     applies_per_step, nblocks, nblocks),
+    }
+
+
 def pmc_lookup(prefix, fname, combine="mean", contains=None):
     """(HBM bytes per launch, provenance) of a kernel from a committed rocprofv3 PMC pass (profiles/<fname>, written by
     scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
@@ -398,7 +483,11 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     sub = tuple(int(v) for v in a.sub.split(","))
     nsub = sub[0] * sub[1] * sub[2]
     orth = not a.dense_coarse
-    f = pa.CubeFeti(sub, a.nel, contact=True)
+    young = None
+    if getattr(a, "young", ""):
+        young = [1.0 + 0.25 * i for i in range(nsub)] if a.young == "distinct" else [float(v) for v in a.young.split(",")]
+    f = pa.CubeFeti(sub, a.nel, contact=True, young=young)
+    congruent = f.congruent
     implicit = orth and a.orth_form == "implicit"
     G, e = f.coarse(orthonormalize=orth and not implicit)  # implicit: G0 = R'B', e0; the library orthonormalises (pmh_qppf_create orthonormal = 2)
     if nsub % world:
@@ -412,7 +501,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     t_gen = time.time() - t0
     t0 = time.time()
     nn = a.nel + 1
-    blocks = [f.Ki] * per
+    blocks = [f.block_K(rank * per + i) for i in range(per)]
     if a.regularize:  # MatRegularize per block (the kernel bases, hence the fixing DOFs, differ from block to block)
         from permon_amd.chain import regularize_blocks
 
@@ -454,11 +543,11 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             replica["M"], replica["K"] = M, Kb
             return M
 
-        explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if a.regularize else a.explicit_slots, solver_factory=None if a.regularize else solver_factory)
-        if not a.no_explicit_symmetry and not a.regularize:  # used by the class-shared storages only
+        explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if (a.regularize or not congruent) else a.explicit_slots, solver_factory=None if (a.regularize or not congruent) else solver_factory)
+        if not a.no_explicit_symmetry and not a.regularize and congruent:  # used by the class-shared storages only
             explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3, orbit=a.explicit_storage in ("auto", "class_orbit"))
         nshare = world if world > 1 else a.sim_world
-        if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe:
+        if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe and congruent:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
             explicit["stripe"] = (rank, nshare, dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign))
     q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal="implicit" if implicit else orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if use_c_builder else None,
@@ -522,7 +611,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         return dt, cnt
 
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
-    full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world)
+    full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world and congruent)
     kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
     pc_text = ("multigrid-preconditioned CG (Galerkin V-cycle in %s built by %s, dense coarse solve at <= %d nodes per block, Chebyshev(%d)/Jacobi smoothing)"
                % (a.mg_precision, "pmh_mg_create_box" if use_c_builder else "permon_amd.feti.box_mg_hierarchy", mg_box(per)["min_nodes"], a.mg_degree)) if has_mg else "Jacobi-CG"
@@ -651,12 +740,26 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if world == 1 and not a.sim_world and has_mg and a.mg_precision != "fp64" and not a.no_iterative:
             switch_mg("fp64")
             extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
+    # one whole solve from lambda = 0 to the outer tolerance (the REAL stopping rule): what a user waits for after the set-up
+    q.lam.set(0.0)
+    qps_full = q.make_smalxe()  # a fresh solver object (QPS_SMALXE.state = 1 as after QPSCreate; the throughput passes above leave it at 3)
+    ctx.sync()
+    t1 = time.perf_counter()
+    st_full = qps_full.Solve()
+    ctx.sync()
+    t_solve = time.perf_counter() - t1
+    full_solve = {"solve_seconds": t_solve, "outer_iterations": int(st_full.iteration), "inner_iterations": int(st_full.inner_iter_accu), "reason": int(st_full.reason),
+                  "setup_seconds": round(t_setup, 2), "time_to_solution_seconds": round(t_setup + t_solve, 3),
+                  "note": "set-up = everything between the generated problem and the first solver iteration as bench.py orchestrates it (uploads, 3x3-block copies, multigrid hierarchy, explicit operators by K^+ solves, "
+                          "coarse problem, dual chain, SMALXE set-up with its power method); solve = pmh_smalxe_solve to rtol 1e-5"}
     comm_rank, comm_size = ctx.comm_rank()
     res = {
-        "value": steps / dt, "ms_per_step": dt / steps * 1e3,
+        "value": steps / dt, "ms_per_step": dt / steps * 1e3, "full_solve": full_solve,
         "workload": "%s: 3-D elasticity TFETI, %dx%dx%d cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
                     "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP (the real solver loop, restarted when it converges), F = B K^+ B' through %s%s"
-                    % ("configs[2]" if (sub == (2, 2, 2) and orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like", sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
+                    % (("configs[2]-like, HETEROGENEOUS (Young's moduli %s: no two subdomain matrices are equal -- the general, non-congruent case)" % ", ".join("%g" % v for v in f.young)) if not congruent else
+                       "configs[2]" if (sub == (2, 2, 2) and orth and a.nel == 43) else "configs[3]" if (nsub == 64 and a.nel == 21 and not orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like",
+                       sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
                        kplus_text, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
         "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s) (K_i, K^+, the set-up solves); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
                        + ("; the dense local dual operators are applied in 128-row stripes dealt evenly over the GPUs (the cubes are congruent: every rank assembles its stripes of every W_b with its own K^+)" if (explicit and "stripe" in explicit) else "")
@@ -744,18 +847,83 @@ def main():
                        "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
             "roofline": r["roofline"],
         }
+        # what lets two windows of the same solver be compared (the driver's 20 + 5 steps are the START of a solve: many short outer iterations, ~3.1 F
+        # applications per step; the default 216 steps are two whole solves, 1.9 per step): F applications per step and the time of one of them, all included
+        sbt = r["steps_by_type"]
+        out["applies_per_step"] = (sbt["operator_applies"] / steps) if sbt.get("operator_applies") else None
+        out["ms_per_operator_apply"] = sbt.get("ms_per_operator_apply")
+        out["time_to_solution_s"] = r["full_solve"]["time_to_solution_seconds"]
+        out["full_solve"] = r["full_solve"]
         for k in ("iterative", "strict_fp64"):
             if k in r:
                 out[k] = r[k]
-        if rank == 0 and world == 1:
-            if not a.no_cpu_baseline and hier is not None and not a.regularize:
+        if rank == 0 and world == 1 and not a.sim_world:
+            applies_per_step = out["applies_per_step"] or 1.9
+            if not a.no_cpu_baseline and not a.regularize:
+                # the reference's own K^+ (a sparse direct solve per block); the host restatement of the GPU's iterative K^+ rides along as cpu_baseline_iterative
                 try:
-                    out["cpu_baseline"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=(not a.dense_coarse) and a.orth_form == "explicit")  # implicit form: G0 with the dense (G0 G0')^{-1} = the same projector
+                    out["cpu_baseline"] = cpu_baseline_direct(ctx, a.nel, min(a.cpu_direct_nel, a.nel), applies_per_step, nblocks=len(f.block_rowstart) - 1)
                 except Exception as ex:  # noqa: BLE001
                     out["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+                if hier is not None:
+                    try:
+                        out["cpu_baseline_iterative"] = cpu_baseline_feti(f, G, hier, b_dual, lb_dual, a.cpu_its_feti, a.kplus_rtol, orth=(not a.dense_coarse) and a.orth_form == "explicit")  # implicit form: G0 with the dense (G0 G0')^{-1} = the same projector
+                    except Exception as ex:  # noqa: BLE001
+                        out["cpu_baseline_iterative"] = {"value": None, "unit": "QPS iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+            del f, G, hier
+            import copy
+
+            if a.no_c2:  # --no-c2 = the headline alone: no secondary block at all
+                a.general_nel, a.no_configs3, a.no_svm, a.no_contact_solve = 0, True, True, True
+
+            def secondary(name, fn):
+                """A secondary block must never cost the headline: failures are recorded, not raised."""
+                t0 = time.time()
+                try:
+                    blk = fn()
+                except Exception as ex:  # noqa: BLE001
+                    blk = {"value": None, "failed": repr(ex)}
+                blk["block_seconds"] = round(time.time() - t0, 1)
+                out[name] = blk
+
+            def feti_block(**over):
+                a2 = copy.copy(a)
+                for k_, v_ in over.items():
+                    setattr(a2, k_, v_)
+                r2 = run_feti(ctx, a2, over.get("_steps", 108), 8, 0, 1, None)[0]
+                sb = r2["steps_by_type"]
+                return {"value": r2["value"], "unit": "QPS iterations/s", "ms_per_step": r2["ms_per_step"], "steps": over.get("_steps", 108), "warmup": 8, "workload": r2["workload"],
+                        "applies_per_step": sb["operator_applies"] / over.get("_steps", 108) if sb.get("operator_applies") else None, "ms_per_operator_apply": sb.get("ms_per_operator_apply"),
+                        "steps_by_type": sb, "kplus": r2["kplus"], "coarse_problem": r2["coarse_problem"], "full_solve": r2["full_solve"], "setup_seconds": r2["setup_seconds"], "roofline": r2["roofline"]}
+
+            if a.general_nel and not a.young:
+                # the general (non-congruent) path of the explicit operators: 8 subdomains of 8 different materials -> no class sharing, no set-up by symmetry,
+                # per-block symmetric storage applied by k_fx_symv (HBM-bound); every column of every W_b by its own K^+ solve
+                secondary("general", lambda: feti_block(young="distinct", nel=a.general_nel, sub="2,2,2", dense_coarse=False, no_iterative=True, explicit_storage="auto"))
+            if not a.no_configs3:
+                # BASELINE configs[3]: 4 x 4 x 4 subdomains (64, 8 per GPU at N = 8) of 21^3 elements, G NOT orthonormalised: the projector applies the dense 384 x 384 (G G')^{-1},
+                # G G' assembled on the fp64 matrix cores (coarse_problem.GGt_TFLOPs)
+                secondary("configs3", lambda: feti_block(sub="4,4,4", nel=21, dense_coarse=True, no_iterative=True, young="", explicit_storage="auto"))
+            if not a.no_svm:
+                def svm_block():
+                    rs = run_svm(ctx, a, 60, 6, 0, 1, None)
+                    return {"value": rs["value"], "unit": "QPS iterations/s", "ms_per_step": rs["ms_per_step"], "steps": 60, "warmup": 6, "workload": rs["workload"], "steps_by_type": rs["steps_by_type"],
+                            "setup_seconds": rs["setup_seconds"], "roofline": rs["roofline"]}
+                secondary("configs4", svm_block)
+            if not a.no_contact_solve and a.kplus == "explicit" and not a.young and not a.regularize and not a.dense_coarse:
+                def contact_block():
+                    fc = pa.CubeFeti(tuple(int(v) for v in a.sub.split(",")), a.nel, contact=True)
+                    t0 = time.perf_counter()
+                    _, _, stc = pa.FETIContactSolve(ctx, fc, explicit=True, explicit_storage="class_orbit", explicit_symmetry=True)
+                    wall = time.perf_counter() - t0
+                    sx = stc.smalxe
+                    return {"what": "pmh_feti_contact_solve: the whole contact solve in ONE library call (multigrid hierarchy, explicit operators, SMALXE + MPGP, rigid-body recovery), host CSR in, u out",
+                            "wall_seconds_incl_upload": round(wall, 3), "setup_seconds": round(stc.setup_seconds, 3), "explicit_assembly_seconds": round(stc.explicit_seconds, 3), "explicit_solves": int(stc.explicit_solves),
+                            "solve_seconds": round(stc.solve_seconds, 4), "time_to_solution_seconds": round(stc.setup_seconds + stc.solve_seconds, 3), "outer": int(sx.iteration), "inner": int(sx.inner_iter_accu),
+                            "hessian_mults": int(sx.inner.nmv), "active_contact_rows": int(stc.n_active)}
+                secondary("contact_solve", contact_block)
             if not a.no_c2:
-                del f, G
-                out["configs1"] = run_c2(ctx, a, 300, 30, cpu=not a.no_cpu_baseline)
+                secondary("configs1", lambda: run_c2(ctx, a, a.c2_steps, 30, cpu=not a.no_cpu_baseline, whole_solves=True))
     if rank == 0:
         try:
             out["roofline"]["measured_ceiling"] = measured_ceiling(ctx)

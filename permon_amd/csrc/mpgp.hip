@@ -50,6 +50,10 @@ struct pmh_mpgp_s {
   pmh_converged_fn cvg;
   int (*pre_test)(void *); // optional: enqueues what the injected convergence test will read, BEFORE the host waits for the step's scalars (one round trip instead of two)
   void *pre_test_user;
+  int (*pre_p1)(void *);   // optional: called right before the speculative Ap = A p of the NEXT iteration is enqueued (the iterate is final then): SMALXE lets its ||B u|| ride on that product
+  void *pre_p1_user;
+  int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
+  int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
   void            *cvg_user;
   double           norm_rhs, ttol, norm_rhs_div;
   int              cvg_setup;
@@ -353,6 +357,8 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->nwork = 0;
   s->cvg = nullptr, s->cvg_user = nullptr, s->cvg_setup = 0;
   s->pre_test = nullptr, s->pre_test_user = nullptr;
+  s->pre_p1 = nullptr, s->pre_p1_user = nullptr;
+  s->epi_ok = -1, s->fin4_pending = 0;
   s->norm_rhs = s->ttol = s->norm_rhs_div = 0.0;
   s->rnorm = s->gfnorm = s->gcnorm = 0.0;
   s->iteration = 0, s->reason = 0;
@@ -408,6 +414,13 @@ int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user)
 {
   PMH_ARG(s);
   s->pre_test = f, s->pre_test_user = user;
+  return PMH_SUCCESS;
+}
+
+int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user)
+{
+  PMH_ARG(s);
+  s->pre_p1 = f, s->pre_p1_user = user;
   return PMH_SUCCESS;
 }
 
@@ -752,10 +765,33 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr)
     return pmh_csr_spmv_launch(s->csr, p, Ap, e);
   }
   if (halt) return pmh_set_error(PMH_ERR_STATE, "speculative chain needs a CSR operator");
-  PMH_CHK(s->A->mult(p, Ap));
   const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
+  const int nb     = s->n > 0 ? pmh_vec_grid(s->n) : 0;
+  if (s->epi_ok) { // the three reductions inside the operator's last kernel (rows 4..6 of the partials: rows 0..3 may still hold a gradient split that waits for its finalising launch)
+    pmh_vec_epi e;
+    memset(&e, 0, sizeof(e));
+    e.kind = PMH_VEPI_P1, e.g = g, e.xx = s->x, e.lb = s->lb, e.ub = s->ub, e.partials = s->ctx->d_partials, e.ld = s->ctx->partials_cap, e.prow = 4;
+    const int rc = s->A->mult_epi(p, Ap, e);
+    if (rc != PMH_EPI_UNSUPPORTED) {
+      PMH_CHK(rc);
+      s->epi_ok = 1;
+      if (s->fin4_pending) { // (Ap'gf, |gP|^2, |gc|^2, |gf|^2) of the gradient split and (p'Ap, g'p, afeas) in ONE finalising launch: every quantity reduced as on its own
+        const int ops7[7] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
+        const int slots7[7] = {S_APGF, S_GP2, S_GC2, S_GF2, S_PAP, S_GP, S_FEAS};
+        s->fin4_pending = 0;
+        return pmh_finalize_partials_slots(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, nb, 7, ops7, slots7);
+      }
+      return pmh_finalize_partials(s->ctx, s->ctx->d_partials + (size_t)4 * s->ctx->partials_cap, s->ctx->partials_cap, nb, 3, ops, S_PAP);
+    }
+    s->epi_ok = 0;
+  }
+  if (s->fin4_pending) { // (cannot happen with one operator: it answers mult_epi the same way every time) the split's partials sit in the rows k_p1_dots is about to overwrite
+    PMH_CHK(finalize_vec4(s));
+    s->fin4_pending = 0;
+  }
+  PMH_CHK(s->A->mult(p, Ap));
   LAUNCH(k_p1_dots, (const double *)p, (const double *)Ap, (const double *)g, (const double *)s->x, s->lb, s->ub, s->ctx->d_partials, s->ctx->partials_cap);
-  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, s->n > 0 ? pmh_vec_grid(s->n) : 0, 3, ops, S_PAP);
+  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, nb, 3, ops, S_PAP);
 }
 
 // g = A x - b (mpgp.c:500-502, :578-580)
@@ -773,6 +809,33 @@ static int f_gradient(pmh_mpgp s)
   return pmh_vec_axpy(s->ctx, s->n, g, -1.0, s->b);
 }
 
+// g = A x - b, the gradient split with p = gf and the partials of its norms (mpgp.c:500-507, :578-580 + :612-615): inside the operator's last kernel where it offers that
+// (the finalising launch then waits for the next P1: fin4_pending), else as three launches + the finalising one
+static int f_gradient_split(pmh_mpgp s, bool defer_finalize)
+{
+  pmh_ctx ctx = s->ctx;
+  double *gf = s->work[1], *g = s->work[3], *p = s->work[4];
+  if (s->epi_ok && !s->csr) {
+    pmh_vec_epi e;
+    memset(&e, 0, sizeof(e));
+    e.kind = PMH_VEPI_GRAD_SPLIT, e.b = s->b, e.lb = s->lb, e.ub = s->ub, e.astol = s->o.astol, e.gf = gf, e.p = p, e.partials = ctx->d_partials, e.ld = ctx->partials_cap, e.prow = 0;
+    const int rc = s->A->mult_epi(s->x, g, e);
+    if (rc != PMH_EPI_UNSUPPORTED) {
+      PMH_CHK(rc);
+      s->epi_ok = 1;
+      if (defer_finalize && !ctx->dist_scalars) {
+        s->fin4_pending = 1;
+        return PMH_SUCCESS;
+      }
+      return finalize_vec4(s);
+    }
+    s->epi_ok = 0;
+  }
+  PMH_CHK(f_gradient(s));
+  LAUNCH(k_split_setp, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap);
+  return finalize_vec4(s);
+}
+
 static int solve_fused(pmh_mpgp s)
 {
   pmh_ctx ctx = s->ctx;
@@ -787,10 +850,10 @@ static int solve_fused(pmh_mpgp s)
   bool         spec = false; // P1 for the current p already enqueued
 
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
-  PMH_CHK(f_gradient(s));                                   // :500-502
+  s->fin4_pending = 0;
+  if (s->epi_ok < 0) s->epi_ok = (s->csr || s->o.distributed || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it
+  PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
   nmv++;
-  LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap); // :504-507
-  PMH_CHK(finalize_vec4(s));
   s->step      = ' ';
   s->iteration = 0;
   pmh_spec_args nosa;
@@ -819,12 +882,17 @@ static int solve_fused(pmh_mpgp s)
     sa.max_it = s->o.max_it, sa.fixed_iters = s->fixed_iters;
     sa.ttol = s->ttol, sa.divtol_rhs = s->o.divtol * s->norm_rhs_div, sa.gamma2 = gamma2;
   }
+  // length of the next speculative batch: a batch that ran to its end doubles it, one that halted early cuts it to what it ran (an expansion-heavy stretch
+  // would otherwise enqueue 16 x 4 no-op launches behind every expansion step: ~0.1 ms each time); 0 = the host takes the next step.  The iterates do not
+  // depend on it: the device chain takes exactly the steps the host would.
+  int spec_len = SPEC_BATCH;
   while (1) {
-    if (can_spec && spec) {
+    if (can_spec && spec && spec_len > 0) {
       // a batch of CG steps decided on the device: no host round trip between them
+      const int nbatch = spec_len;
       s->h_ctl[CTL_HALT] = 0, s->h_ctl[CTL_ITER] = s->iteration, s->h_ctl[CTL_NCG] = 0, s->h_ctl[CTL_BASE] = s->iteration;
       PMH_HIP(hipMemcpyAsync(s->d_ctl, s->h_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyHostToDevice, ctx->stream));
-      for (int j = 0; j < SPEC_BATCH; j++) {
+      for (int j = 0; j < nbatch; j++) {
         LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
         PMH_CHK(finalize_vec4(s, s->d_ctl + CTL_HALT, s->d_ctl + CTL_ITER));
         LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p);
@@ -847,6 +915,7 @@ static int solve_fused(pmh_mpgp s)
       s->iteration += ndev;
       ncg += ndev;
       nmv += ndev;
+      spec_len = (ndev >= nbatch) ? std::min(SPEC_BATCH, 2 * nbatch) : ndev; // 0 after a batch that took no step: the host path decides when speculation resumes
       if (!s->h_ctl[CTL_HALT]) continue; // whole batch were CG steps
     }
     if (s->pre_test) PMH_CHK(s->pre_test(s->pre_test_user));
@@ -869,6 +938,7 @@ static int solve_fused(pmh_mpgp s)
       if (acg <= afeas) { // CG step (mpgp.c:547-560)
         ncg++;
         s->step = 'c';
+        spec_len = std::max(spec_len, 1); // a CG step taken by the host: the next ones may well be CG steps too
         LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
         PMH_CHK(finalize_vec4(s));
         LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p);
@@ -876,10 +946,8 @@ static int solve_fused(pmh_mpgp s)
         nexp++;
         s->step = 'e';
         LAUNCH(k_expansion_std, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol);
-        PMH_CHK(f_gradient(s));
+        PMH_CHK(f_gradient_split(s, true)); // the speculative P1 below finalises both groups of partial sums
         nmv++;
-        LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap);
-        PMH_CHK(finalize_vec4(s));
       }
     } else { // proportioning (mpgp.c:617-639)
       nprop++;
@@ -892,6 +960,7 @@ static int solve_fused(pmh_mpgp s)
       PMH_CHK(finalize_vec4(s));
     }
     // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p
+    if (s->pre_p1) PMH_CHK(s->pre_p1(s->pre_p1_user));
     PMH_CHK(f_apply_p1(s));
     spec = true;
     s->iteration++;

@@ -84,6 +84,7 @@ struct pmh_csr_s {
   // very long rows (G of the coarse problem: a few dozen rows of ~10^4 non-zeros): rows split into chunks, see spmv.hip
   int      *d_lchunks, *d_lrow; // [3*l_nchunks] (row, k0, k1) and [nrows+1] first chunk of each row
   double   *d_lpart;            // [l_nchunks] chunk sums
+  double   *d_lpart2;           // second vector of pmh_csr_mult_partials2 (lazily allocated)
   int       l_nchunks;
   // optional per-launch timing (HIP event pairs recorded on the launch stream)
   std::vector<hipEvent_t> *ev;
@@ -103,14 +104,31 @@ struct pmh_spmv_epi {
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
 inline void pmh_csr_set_host_hint(pmh_csr A, const int *rowptr, const int *col, const double *val) { A->h_rowptr = rowptr, A->h_col = col, A->h_val = val; }
 int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part); // chunk sums of A x (long rows), summed by the consumer
+int pmh_csr_mult_partials2(pmh_csr A, const double *x, const double *x2, const int **lrow, const double **part, const double **part2); // the same for two vectors in ONE pass over A (each sum as the single form takes it)
 int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y, int norm_slot = -1); // y = M (A x), Mt = M' (m x m, device); norm_slot >= 0 (m <= 64): ||y||^2 -> d_scal / h_scal[slot]
 
 // ---- operators -------------------------------------------------------------------------------------------
+// Vector epilogues an operator may fold into the LAST kernel of its product y = A x (one entry per thread, the grid of the streaming Vec kernels:
+// the same per-workgroup partial sums as the separate kernels, hence the same bits).  mult_epi returns PMH_EPI_UNSUPPORTED where an operator (or its
+// current configuration) has no such kernel: the caller then runs the separate launches.
+#define PMH_EPI_UNSUPPORTED (-77)
+enum { PMH_VEPI_P1 = 1, PMH_VEPI_GRAD_SPLIT = 2 };
+struct pmh_vec_epi {
+  int           kind;
+  // PMH_VEPI_P1 (x = p, y = Ap): p'Ap, g'p, QPCFeas(xx, p) -> partials rows prow .. prow + 2 (k_p1_dots)
+  // PMH_VEPI_GRAD_SPLIT (x = the iterate, y = g): g = A x - b, then gf, p = gf and the partials of Ap'gf (0), |gP|^2, |gc|^2, |gf|^2 -> rows prow .. prow + 3 (k_axpy + k_split_setp)
+  const double *g, *xx, *lb, *ub, *b;
+  double        astol;
+  double       *gf, *p;
+  double       *partials;
+  int           ld, prow;
+};
 struct pmh_op_s {
   pmh_ctx ctx;
   int     n;
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
+  virtual int     mult_epi(const double *, double *, const pmh_vec_epi &) { return PMH_EPI_UNSUPPORTED; }
   // MatMultTranspose slot; operators that are symmetric by construction forward to mult
   virtual int     mult_transpose(const double *, double *) { return pmh_set_error(PMH_ERR_SUP, "this operator has no MatMultTranspose slot"); }
   virtual pmh_csr as_csr() { return nullptr; }
@@ -138,12 +156,18 @@ struct pmh_qppf_s {
 enum { PMH_RED_SUM = 0, PMH_RED_MIN = 1 };
 // finalise K block-partial arrays (stride = ld) into d_scal[base+k] and h_scal[base+k]
 int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base, const int *halt = nullptr, int *post_inc = nullptr);
+int pmh_finalize_partials_slots(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, const int *slots); // the same with one scalar slot per quantity: two groups of reductions in ONE launch
 int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (function of n only)
 
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_qppf_apply_G_norm2(pmh_qppf pf, const double *v, double *Gv, int slot);          // qppf.hip: G v and ||G v||^2 -> scalar slot, enqueue only
 int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user);             // mpgp.hip: see there
+int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user);               // mpgp.hip: called right before the speculative Ap = A p of the next iteration is enqueued
+// SMALXE's ||B u|| riding on the next product of the penalised operator (qppf.hip): G0 u shares the pass over G0 with G0 x, T (G0 u) and its squared norm are
+// finished by workgroup 0 of the projector's kernel -- two launches less per inner iteration, the same bits as pmh_qppf_apply_G_norm2
+int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int slot);
+int pmh_op_penalized_take_aux_done(pmh_op op); // 1 if the armed request was served by the last product (and clears it), 0 otherwise (and disarms)
 #define PMH_SLOT_NORMBU2 48 // ||B u||^2 prefetched for SMALXE's inner convergence test
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
 

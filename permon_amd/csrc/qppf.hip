@@ -452,9 +452,31 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_dual1(int n, const int *__rest
 // ... and with the finishing step of G0 v and the dense T'T product folded in (implicit orthonormalisation, m <= 64): every workgroup adds the
 // chunk sums of k_spmv_long_part per row in chunk order and applies the m x m matrix exactly as k_rows_then_dense does (same order => same bits),
 // then takes its rows -- one launch less per projector application
+// aux (workgroup 0 only; SMALXE's ||B u|| riding along): the chunk sums of G0 u (part2, from k_spmv_long_part2) are added per row, T is applied and ||T G0 u||^2 is summed exactly
+// as k_rows_then_dense does it -- the same bits as the two launches of pmh_qppf_apply_G_norm2.
+// epi: the MPGP vector phase that follows the product, folded in (mode 1 only; one row per thread = the grid of the streaming Vec kernels, so the block partials equal
+// those of k_p1_dots / k_axpy + k_split_setp).
+struct gt_aux {
+  const double *part2, *Mt2; // chunk sums of G0 u, T' (row-major)
+  double       *y2, *norm_d, *norm_h;
+};
+// the box predicates of qpcbox.c per element, as in mpgp.hip (QPCGrads_Box qpcbox.c:41-55: the lower bound wins ties)
+static __device__ __forceinline__ void gt_box_split(double xi, double gi, const double *lb, const double *ub, long long i, double astol, double &gf, double &gc)
+{
+  gf = gi;
+  gc = 0.0;
+  if (lb && fabs(xi - lb[i]) <= astol) {
+    gf = 0.0;
+    gc = (gi < 0.0) ? gi : 0.0;
+  } else if (ub && fabs(xi - ub[i]) <= astol) {
+    gf = 0.0;
+    gc = (gi > 0.0) ? gi : 0.0;
+  }
+}
+template <int EPI>
 __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int m, const int *__restrict__ lrow,
                                                          const double *__restrict__ part, const double *__restrict__ Mt, int mode, const double *__restrict__ x, double *__restrict__ y,
-                                                         double *__restrict__ z, double rho)
+                                                         double *__restrict__ z, double rho, gt_aux aux, pmh_vec_epi epi, const double *__restrict__ pin)
 {
   // A 5-8 us kernel is made of memory latencies, not of bytes: every loop below keeps the order of its sum (the same bits as the plain loops) but sends its
   // loads out together -- the plain forms compile to load - wait - add per entry, i.e. ~6 + 12 + 12 latencies in a row (measured 7.7 us against ~4 for a launch).
@@ -490,26 +512,111 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__re
     w[t] = s;
   }
   __syncthreads();
-  if (r >= n) return;
-  double sum = 0.0;
-  for (int k = k0; k < k1; k += 16) { // G0' has 6 or 12 entries per row: one trip
-    double v[16];
-    int    c[16];
+  if (aux.part2 && blockIdx.x == 0) { // uniform per workgroup.  k_rows_then_dense(m, lrow, part2, Mt2, y2, norm): same sums, same order
+    __shared__ double t2[64], red2[PMH_BLOCK / 64];
+    if (t < m) {
+      const int c0 = lrow[t], c1 = lrow[t + 1];
+      double    sum = 0.0;
+      for (int c = c0; c < c1; c += 8) {
+        double v[8];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const bool in = k + j < k1;
-      v[j] = in ? val[k + j] : 0.0, c[j] = in ? col[k + j] : 0;
+        for (int j = 0; j < 8; j++) v[j] = (c + j < c1) ? aux.part2[c + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (c + j < c1) sum += v[j];
+      }
+      t2[t] = sum;
+    }
+    __syncthreads();
+    double sq = 0.0;
+    if (t < m) {
+      double s = 0.0;
+      for (int c = 0; c < m; c += 16) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = (c + j < m) ? aux.Mt2[(size_t)(c + j) * m + t] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          if (c + j < m) s += v[j] * t2[c + j];
+      }
+      aux.y2[t] = s;
+      sq += s * s;
+    }
+    sq = pmh_block_reduce<PMH_RED_SUM>(sq, red2);
+    if (t == 0) *aux.norm_d = sq, *aux.norm_h = sq;
+  }
+  double sum = 0.0;
+  if (r < n) {
+    for (int k = k0; k < k1; k += 16) { // G0' has 6 or 12 entries per row: one trip
+      double v[16];
+      int    c[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const bool in = k + j < k1;
+        v[j] = in ? val[k + j] : 0.0, c[j] = in ? col[k + j] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (k + j < k1) sum += v[j] * w[c[j]];
+    }
+  }
+  double out = 0.0;
+  if (r < n) {
+    if (mode == 0) {
+      y[r] = sum;
+      z[r] = -1.0 * sum + x[r];
+    } else {
+      const double tt = x[r] + -1.0 * sum;
+      out             = y[r] * rho + tt;
+      if (EPI != PMH_VEPI_GRAD_SPLIT) y[r] = out;
+    }
+  }
+  if (EPI == PMH_VEPI_P1) { // k_p1_dots (mpgp.hip) on this workgroup's rows: p'Ap, g'p, QPCFeas -- `out` is Ap[r], pin the operator's input p
+    __shared__ double redp[PMH_BLOCK / 64];
+    double            s0 = 0.0, s1 = 0.0, mn = INFINITY;
+    if (r < n) {
+      const double pi = pin[r];
+      s0 += pi * out;
+      s1 += epi.g[r] * pi;
+      if (pi > 0. && epi.lb) {
+        const double l = epi.lb[r];
+        if (l > -INFINITY) mn = fmin(mn, (epi.xx[r] - l) / pi);
+      }
+      if (pi < 0. && epi.ub) {
+        const double u = epi.ub[r];
+        if (u < INFINITY) mn = fmin(mn, (epi.xx[r] - u) / pi);
+      }
+    }
+    s0 = pmh_block_reduce<PMH_RED_SUM>(s0, redp);
+    s1 = pmh_block_reduce<PMH_RED_SUM>(s1, redp);
+    mn = pmh_block_reduce<PMH_RED_MIN>(mn, redp);
+    if (t == 0) {
+      epi.partials[(size_t)epi.prow * epi.ld + blockIdx.x]       = s0;
+      epi.partials[(size_t)(epi.prow + 1) * epi.ld + blockIdx.x] = s1;
+      epi.partials[(size_t)(epi.prow + 2) * epi.ld + blockIdx.x] = mn;
+    }
+  }
+  if (EPI == PMH_VEPI_GRAD_SPLIT) { // k_axpy(g, -1, b) + k_split_setp (mpgp.hip): g = A x - b, gf, p = gf, the partials of (0, |gP|^2, |gc|^2, |gf|^2) -- pin is the iterate
+    __shared__ double redg[PMH_BLOCK / 64];
+    double            acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r < n) {
+      double gi = out;
+      gi += -1.0 * epi.b[r];
+      y[r] = gi;
+      double f, c;
+      gt_box_split(pin[r], gi, epi.lb, epi.ub, r, epi.astol, f, c);
+      epi.gf[r]        = f;
+      epi.p[r]         = f;
+      const double gPi = f + c;
+      acc[1] += gPi * gPi;
+      acc[2] += c * c;
+      acc[3] += f * f;
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-      if (k + j < k1) sum += v[j] * w[c[j]];
-  }
-  if (mode == 0) {
-    y[r] = sum;
-    z[r] = -1.0 * sum + x[r];
-  } else {
-    const double tt = x[r] + -1.0 * sum;
-    y[r]            = y[r] * rho + tt;
+    for (int k = 0; k < 4; k++) {
+      const double rr = pmh_block_reduce<PMH_RED_SUM>(acc[k], redg);
+      if (t == 0) epi.partials[(size_t)(epi.prow + k) * epi.ld + blockIdx.x] = rr;
+    }
   }
 }
 
@@ -536,18 +643,41 @@ static bool gt_fusable_dense_inverse(pmh_qppf pf)
 // applies (implicit orthonormalisation, long-row G0, short-row G0', m <= 64); otherwise qppf_left + gt_fused
 static int gt_fused(pmh_qppf pf, const double *w, int mode, const double *x, double *y, double *z, double rho);
 static int qppf_left(pmh_qppf pf, const double *v);
-static int q_fused(pmh_qppf pf, const double *v, int mode, const double *x, double *y, double *z, double rho)
+// the one-launch form (k_gt_fused1d) applies: implicit orthonormalisation, long-row G0, one-lane-per-row G0', m <= 64
+static bool q_fused_dense(pmh_qppf pf)
+{
+  static const bool off = getenv("PMH_NO_GT_DENSE_FUSION") != nullptr;
+  return pf->implicit_orth && pf->G->l_nchunks > 0 && pf->m <= 64 && pf->G->transpose && pf->G->transpose->st_rl == 1 && !off;
+}
+// aux_u != nullptr (one-launch form only): G0 aux_u shares the pass over G0, T G0 aux_u -> aux_Gu and its squared norm -> scalar slot aux_slot by workgroup 0.
+// epi (mode 1, one-launch form only): the vector phase folded into the kernel, pin = the operator's input vector.
+static int q_fused(pmh_qppf pf, const double *v, int mode, const double *x, double *y, double *z, double rho, const double *aux_u = nullptr, double *aux_Gu = nullptr, int aux_slot = -1,
+                   const pmh_vec_epi *epi = nullptr, const double *pin = nullptr)
 {
   const pmh_csr Gt = pf->G->transpose;
-  if (pf->implicit_orth && pf->G->l_nchunks > 0 && pf->m <= 64 && Gt->st_rl == 1 && !getenv("PMH_NO_GT_DENSE_FUSION")) {
+  if (q_fused_dense(pf)) {
     const int    *lrow;
-    const double *part;
-    PMH_CHK(pmh_csr_mult_partials(pf->G, v, &lrow, &part));
-    hipLaunchKernelGGL(k_gt_fused1d, dim3((Gt->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, pf->ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, pf->m,
-                       lrow, part, (const double *)pf->d_S, mode, x, y, z, rho);
+    const double *part, *part2 = nullptr;
+    if (aux_u) PMH_CHK(pmh_csr_mult_partials2(pf->G, v, aux_u, &lrow, &part, &part2));
+    else PMH_CHK(pmh_csr_mult_partials(pf->G, v, &lrow, &part));
+    gt_aux aux;
+    memset(&aux, 0, sizeof(aux));
+    if (aux_u) aux.part2 = part2, aux.Mt2 = pf->d_Tt, aux.y2 = aux_Gu, aux.norm_d = pf->ctx->d_scal + aux_slot, aux.norm_h = pf->ctx->h_scal + aux_slot;
+    pmh_vec_epi e;
+    memset(&e, 0, sizeof(e));
+    if (epi) e = *epi;
+    const dim3 grid((Gt->nrows + PMH_BLOCK - 1) / PMH_BLOCK);
+#define GT1D(EPI)                                                                                                                                                                                            \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gt_fused1d<EPI>), grid, dim3(PMH_BLOCK), 0, pf->ctx->stream, Gt->nrows, (const int *)Gt->d_rowptr, (const int *)Gt->d_col, (const double *)Gt->d_val, pf->m, lrow, part, \
+                     (const double *)pf->d_S, mode, x, y, z, rho, aux, e, pin)
+    if (e.kind == PMH_VEPI_P1) GT1D(PMH_VEPI_P1);
+    else if (e.kind == PMH_VEPI_GRAD_SPLIT) GT1D(PMH_VEPI_GRAD_SPLIT);
+    else GT1D(0);
+#undef GT1D
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
+  if (aux_u || epi) return pmh_set_error(PMH_ERR_STATE, "q_fused: the folded forms need the one-launch projector kernel");
   PMH_CHK(qppf_left(pf, v));
   return gt_fused(pf, pf->G_left, mode, x, y, z, rho);
 }
@@ -615,6 +745,32 @@ struct PenalizedOp : pmh_op_s {
   pmh_qppf pf;
   double   rho;
   double  *t, *xwork = nullptr;
+  // ||G u|| request riding on the next product (pmh_op_penalized_arm_aux_normG)
+  const double *aux_u = nullptr;
+  double       *aux_Gu = nullptr;
+  int           aux_slot = -1, aux_done = 0;
+  // the fully fused product y = rho Q x + P F (P x) [+ vector epilogue] of the one-launch projector form
+  bool fused_dense()
+  {
+    ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
+    return pa && pa->pf == pf && pa->symmetric && gt_fusable(pf) && q_fused_dense(pf);
+  }
+  int mult_fused_dense(const double *x, double *y, const pmh_vec_epi *epi)
+  {
+    ProjectedOp *pa = static_cast<ProjectedOp *>(A);
+    const double *au = aux_u;
+    aux_u            = nullptr;
+    PMH_CHK(q_fused(pf, x, 0, x, y, pa->w1, 0.0, au, aux_Gu, aux_slot)); // y = Q x, w1 = P x (+ T G0 u and its squared norm)
+    if (au) aux_done = 1;
+    PMH_CHK(pa->A->mult(pa->w1, pa->w2));
+    return q_fused(pf, pa->w2, 1, pa->w2, y, nullptr, rho, nullptr, nullptr, -1, epi, x); // y = rho y + (w2 - Q w2) (+ the vector phase)
+  }
+  int mult_epi(const double *x, double *y, const pmh_vec_epi &e) override
+  {
+    static const bool off = getenv("PMH_NO_VEC_EPI") != nullptr; // A/B: the separate vector kernels
+    if (off || !fused_dense() || n > PMH_MAX_VEC_BLOCKS * PMH_BLOCK || pmh_vec_grid(n) != (n + PMH_BLOCK - 1) / PMH_BLOCK) return PMH_EPI_UNSUPPORTED;
+    return mult_fused_dense(x, y, &e);
+  }
   ~PenalizedOp() override
   {
     pmh_free(ctx, t);
@@ -624,6 +780,8 @@ struct PenalizedOp : pmh_op_s {
   int mult(const double *x, double *y) override
   {
     ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
+    if (fused_dense()) return mult_fused_dense(x, y, nullptr);
+    aux_u = nullptr; // a ||G u|| request can only ride on the one-launch form
     if (pa && pa->pf == pf && pa->symmetric && gt_fusable(pf)) {
       // A = P F P with the same orthonormal projector: y = rho Q x + P F (P x) in 10 launches (see k_gt_fused)
       PMH_CHK(q_fused(pf, x, 0, x, y, pa->w1, 0.0)); // y = Q x, w1 = P x
@@ -710,6 +868,26 @@ extern "C" int pmh_op_penalized_mult_transpose_add(pmh_op op, const double *x, c
   PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
   PMH_ARG(o && x && x2 && y);
   return o->mult_add(x, x2, y, true);
+}
+
+int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int slot)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && u && Gu && slot >= 0 && slot < PMH_NSCAL);
+  static const bool off = getenv("PMH_NO_AUX_NORMG") != nullptr; // A/B: ||G u|| by its own two launches
+  o->aux_done = 0;
+  if (off || !o->fused_dense()) return PMH_SUCCESS; // not armed: the caller's own launches follow
+  o->aux_u = u, o->aux_Gu = Gu, o->aux_slot = slot;
+  return PMH_SUCCESS;
+}
+
+int pmh_op_penalized_take_aux_done(pmh_op op)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  if (!o) return 0;
+  const int d = o->aux_done;
+  o->aux_done = 0, o->aux_u = nullptr;
+  return d;
 }
 
 extern "C" int pmh_op_penalized_set_penalty(pmh_op op, double rho)

@@ -103,9 +103,23 @@ static int prefetch_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
   if (s->o.be_implicit || s->pf->m == 0 || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  if (pmh_op_penalized_take_aux_done(s->A_inner)) { // it rode on the speculative A_rho p of this iteration (arm_normBu below): already in the scalar slot, same bits
+    s->normBu_prefetched = 1;
+    return PMH_SUCCESS;
+  }
   PMH_CHK(pmh_qppf_apply_G_norm2(s->pf, s->u, s->Bu, PMH_SLOT_NORMBU2));
   s->normBu_prefetched = 1;
   return PMH_SUCCESS;
+}
+
+// pre-P1 hook (pmh_mpgp_set_pre_p1_hook): the iterate u is final when the inner MPGP enqueues the next A_rho p; G0 u then shares the pass over G0 with the projector's
+// G0 p and T G0 u / its squared norm are finished inside the projector's kernel (the one-launch projector form with m <= 64 only -- the condition under which
+// pmh_qppf_apply_G_norm2 takes the same two kernels on its own)
+static int arm_normBu(void *user)
+{
+  pmh_smalxe s = (pmh_smalxe)user;
+  if (s->o.be_implicit || s->pf->m == 0 || !(s->pf->implicit_orth && s->pf->m <= 64) || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  return pmh_op_penalized_arm_aux_normG(s->A_inner, s->u, s->Bu, PMH_SLOT_NORMBU2);
 }
 
 // QPSSMALXEUpdateNormBu_SMALXEON smalxe.c:265-285: only the penalised term B'B is available; ||Bu|| = sqrt(u'B'Bu).
@@ -288,6 +302,7 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   PMH_CHK(pmh_mpgp_create(ctx, s->A_inner, s->b_inner, u, lb, ub, &io, &s->inner));
   PMH_CHK(pmh_mpgp_set_convergence_test(s->inner, inner_converged, s));
   PMH_CHK(pmh_mpgp_set_pre_test_hook(s->inner, prefetch_normBu, s));
+  PMH_CHK(pmh_mpgp_set_pre_p1_hook(s->inner, arm_normBu, s));
   *out = s;
   return PMH_SUCCESS;
 }

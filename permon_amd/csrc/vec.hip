@@ -20,10 +20,11 @@ int pmh_vec_grid(int n)
 // ---- finalise block partials -----------------------------------------------------------------------------
 struct pmh_ops8 {
   int op[PMH_MAX_RED];
+  int slot[PMH_MAX_RED]; // destination scalar slot of every quantity
 };
 
 #define PMH_FIN_THREADS 1024
-__global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, int base, const int *__restrict__ halt, int *__restrict__ post_inc)
+__global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__restrict__ partials, int ld, int nblocks, int K, pmh_ops8 ops, double *__restrict__ d_scal, double *__restrict__ h_scal, const int *__restrict__ halt, int *__restrict__ post_inc)
 {
   __shared__ double lds[PMH_MAX_RED][PMH_FIN_THREADS / 64];
   if (halt && *halt) return; // speculative chain stopped: keep the scalars of the last valid state
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__re
     const int k = threadIdx.x;
     double    r = lds[k][0];
     for (int w = 1; w < PMH_FIN_THREADS / 64; w++) r = (ops.op[k] == PMH_RED_SUM) ? (r + lds[k][w]) : fmin(r, lds[k][w]);
-    d_scal[base + k] = r;
-    h_scal[base + k] = r;
+    d_scal[ops.slot[k]] = r;
+    h_scal[ops.slot[k]] = r;
   }
   if (post_inc && threadIdx.x == 0) { // device-side iteration / CG-step counters of the speculative chain
     post_inc[0]++;
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(PMH_FIN_THREADS) void k_finalize(const double *__re
 int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base, const int *halt, int *post_inc)
 {
   pmh_ops8 o;
-  for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, scal_base, halt, post_inc);
+  for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0, o.slot[k] = scal_base + k;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, halt, post_inc);
   PMH_HIP(hipGetLastError());
   if (ctx->dist_scalars && ctx->comm && (ctx->size > 1 || ctx->force_comm)) {
     // row-distributed vectors: complete the reductions across ranks (VecDot / VecNorm / QPCFeas MPI_Allreduce)
@@ -76,6 +77,19 @@ int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nbloc
     PMH_NCCL(ncclGroupEnd());
     PMH_HIP(hipMemcpyAsync(ctx->h_scal + scal_base, ctx->d_scal + scal_base, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
   }
+  return PMH_SUCCESS;
+}
+
+// K <= PMH_MAX_RED quantities (rows of `partials`) into arbitrary scalar slots: every quantity is reduced exactly as pmh_finalize_partials reduces it (the
+// reduction of a row does not depend on the others), so finalising two groups in one launch changes no bit.  Not for row-distributed vectors.
+int pmh_finalize_partials_slots(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, const int *slots)
+{
+  PMH_ARG(K >= 1 && K <= PMH_MAX_RED);
+  if (ctx->dist_scalars && ctx->comm && (ctx->size > 1 || ctx->force_comm)) return pmh_set_error(PMH_ERR_STATE, "pmh_finalize_partials_slots: not with row-distributed vectors");
+  pmh_ops8 o;
+  for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0, o.slot[k] = (k < K) ? slots[k] : 0;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, (const int *)nullptr, (int *)nullptr);
+  PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
 

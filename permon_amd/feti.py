@@ -128,7 +128,10 @@ class CubeFeti:
     Dual rows are ordered [Dirichlet | gluing | contact]; the first n_eq are equalities.
     """
 
-    def __init__(self, sub=(2, 2, 2), nel=3, physics="elasticity", gluing="full", scale=True, contact=True, gap0=0.0, gap_slope=0.05, load=-1.0):
+    def __init__(self, sub=(2, 2, 2), nel=3, physics="elasticity", gluing="full", scale=True, contact=True, gap0=0.0, gap_slope=0.05, load=-1.0, young=None):
+        """young: None (one material: every subdomain has the SAME stiffness matrix, the congruent case) or one Young's modulus per subdomain --
+        a heterogeneous body whose subdomain matrices K_s = E_s K_1 all differ (no two blocks are bit-identical: pmh_csr_block_classes finds nsub
+        classes), the general, non-congruent case of the explicit dual operators."""
         self.sub, self.nel, self.physics = tuple(sub), int(nel), physics
         self.ndof = 3 if physics == "elasticity" else 1
         self.kdim = 6 if physics == "elasticity" else 1
@@ -158,6 +161,9 @@ class CubeFeti:
         Ki.sort_indices()
         self.Ki = Ki
         self._K = None
+        self.young = None if young is None else np.asarray(young, dtype=np.float64)
+        if self.young is not None and self.young.size != self.nsub:
+            raise ValueError("young: one modulus per subdomain")
 
         # body force: constant `load` in the last component (z for elasticity), consistent Q1 load vector
         fe = np.zeros(nloc)
@@ -251,9 +257,21 @@ class CubeFeti:
     def K(self):
         """blockdiag(K_i) of all subdomains (built on demand: 158 M non-zeros at configs[2] size)."""
         if self._K is None:
-            self._K = sp.block_diag([self.Ki] * self.nsub, format="csr")
+            self._K = sp.block_diag([self.block_K(s) for s in range(self.nsub)], format="csr")
             self._K.sort_indices()
         return self._K
+
+    def block_K(self, s):
+        """Stiffness matrix of subdomain s (E_s K_1 for a heterogeneous body; the one shared matrix object otherwise)."""
+        if self.young is None:
+            return self.Ki
+        Ks = self.Ki.copy()
+        Ks.data = Ks.data * float(self.young[s])
+        return Ks
+
+    @property
+    def congruent(self):
+        return self.young is None or bool(np.all(self.young == self.young[0]))
 
     # ---- coarse space -----------------------------------------------------------------------------------
     def kernel_matrix(self):
@@ -291,7 +309,7 @@ class CubeFeti:
         sel = keep[self.leaves_row]
         return dict(
             nblocks=len(blocks), block_rowstart=np.arange(len(blocks) + 1, dtype=np.int32) * nloc,
-            K=sp.block_diag([self.Ki] * len(blocks), format="csr"), f=self.f[keep], R=self.R[:, keep],
+            K=sp.block_diag([self.block_K(s) for s in blocks], format="csr"), f=self.f[keep], R=self.R[:, keep],
             leaves_row=newidx[self.leaves_row[sel]].astype(np.int32), leaves_root=self.leaves_root[sel], leaves_sign=self.leaves_sign[sel],
             n_x=len(blocks) * nloc, n_lambda=self.n_lambda)
 

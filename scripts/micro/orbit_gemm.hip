@@ -38,10 +38,15 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 // A pre-tiled: block (mt, kc) = TK k x TM rows, k-major; gidx[g][k] = (position << 1) | negative; X[pos][8]; Cpart[split][Mp][N]
+#ifdef NVGPR
+#define NVGPR_ATTR __attribute__((amdgpu_num_vgpr(NVGPR)))
+#else
+#define NVGPR_ATTR
+#endif
 #ifndef MINB
 #define MINB 1
 #endif
-__global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
+__global__ __launch_bounds__(NT, MINB) NVGPR_ATTR void k_gemm(int Mt, int Nt, int S, int nkc, const double *__restrict__ A, const int *__restrict__ gidx, int ldk, const double *__restrict__ X,
                                                 double *__restrict__ Cpart, int Mp, int N, const int *__restrict__ wmap)
 {
   __shared__ double As[2][TK][LDA];
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   for (int e = 0; e < NEA; e++) ar[e] = dbl2{1.0 + t, 2.0};
   for (int e = 0; e < NEB; e++) br[e] = 0.5 + t, gn[e] = 0;
 #endif
-  auto loadA = [&](int kc) {
+  auto loadA = [&](int kc, dbl2 (&ar)[NEA]) {
 #ifndef NOALOAD // knock-out: no HBM stream of A (timing only)
     const double *blk = A + ((size_t)mt * nkc + kc) * (TK * TM);
 #pragma unroll
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
 #endif
   };
 #endif
-  auto store = [&](int buf) {
+  auto store = [&](int buf, dbl2 (&ar)[NEA]) {
 #pragma unroll
     for (int e = 0; e < NEA; e++) {
       const int q = t + NT * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
@@ -127,26 +132,36 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
   };
   if (kc0 < kc1) {
     loadG(kc0, gn);
-    loadA(kc0);
+    loadA(kc0, ar);
     gatherB(gn);
     if (kc0 + 1 < kc1) loadG(kc0 + 1, gn);
-    store(0);
+    store(0, ar);
+#ifdef APF2 // A travels TWO chunks ahead: chunk kc0 + 1 is requested here and stored at the end of the first step
+    if (kc0 + 1 < kc1) loadA(kc0 + 1, ar);
+#endif
   }
   __syncthreads();
   const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
-  for (int kc = kc0; kc < kc1; kc++) {
-    const int buf = (kc - kc0) & 1;
+  auto body = [&](int kc, int buf, dbl2 (&arst)[NEA], dbl2 (&arld)[NEA]) { // arst: the registers stored at the end of this step (chunk kc + 1), arld: where this step's loads of A go
+#ifdef APF2
+    if (kc + 2 < kc1) loadA(kc + 2, arld);
+    if (kc + 1 < kc1) {
+      gatherB(gn);
+      if (kc + 2 < kc1) loadG(kc + 2, gn);
+    }
+#else
     if (kc + 1 < kc1) {
 #ifdef GFIRST // the gathers (and the next index loads) go out BEFORE the HBM loads of A: vmcnt retires in order, so a wait for a gather no longer waits for A
       gatherB(gn);
       if (kc + 2 < kc1) loadG(kc + 2, gn);
-      loadA(kc + 1);
+      loadA(kc + 1, arld);
 #else
-      loadA(kc + 1);
+      loadA(kc + 1, arld);
       gatherB(gn);
       if (kc + 2 < kc1) loadG(kc + 2, gn);
 #endif
     }
+#endif
 #if defined(PIPE) && !defined(ORIENT4)
     // half steps: the operands of the next half step (a: 4 values every other half step, b: 8 values) are read from LDS before the 32 products of this one are issued
     {
@@ -222,12 +237,21 @@ __global__ __launch_bounds__(NT, MINB) void k_gemm(int Mt, int Nt, int S, int nk
     }
 #endif
 #ifndef NOSTORE
-    if (kc + 1 < kc1) store(buf ^ 1);
+    if (kc + 1 < kc1) store(buf ^ 1, arst);
 #endif
 #ifndef NOBAR
     __syncthreads();
 #endif
+  };
+#ifdef APF2
+  dbl2 ar2[NEA];
+  for (int kc = kc0; kc < kc1; kc += 2) {
+    body(kc, 0, ar, ar2);
+    if (kc + 1 < kc1) body(kc + 1, 1, ar2, ar);
   }
+#else
+  for (int kc = kc0; kc < kc1; kc++) body(kc, (kc - kc0) & 1, ar, ar);
+#endif
   // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
   const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);
   double   *C  = Cpart + (size_t)s * Mp * N;

@@ -23,7 +23,7 @@ def _run(*args):
 
 
 def test_default_workload_line_small():
-    d = _run("--nel", "7", "--steps", "30", "--warmup", "3", "--grid", "300", "--cpu-its", "3", "--cpu-its-feti", "3")
+    d = _run("--nel", "7", "--steps", "30", "--warmup", "3", "--grid", "300", "--cpu-its", "3", "--cpu-its-feti", "3", "--general-nel", "5", "--cpu-direct-nel", "7", "--c2-steps", "100", "--svm-n", "200000")
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "QPS iterations/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "strong"
@@ -41,10 +41,24 @@ def test_default_workload_line_small():
         assert d[k]["value"] > 0 and ROOF <= set(d[k]["roofline"]) and "k_bsr3<double>" in d[k]["roofline"]["kernel"]
     assert d["config"]["rccl_ranks"] is None
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port", d["cpu_baseline"]
-    cb = d["cpu_baseline"]
-    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    for cb in (d["cpu_baseline"], d["cpu_baseline_iterative"]):  # the reference's direct K^+ (sparse factorisation per block) and the host restatement of the iterative K^+
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1, cb
+    assert "splu" in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["growth_exponent_solve"] > 0
+    # what makes windows of different length comparable, at the top level
+    assert d["applies_per_step"] > 1.0 and d["ms_per_operator_apply"] > 0 and d["time_to_solution_s"] > 0
+    assert d["full_solve"]["reason"] > 0 and d["full_solve"]["inner_iterations"] > 0
     c1 = d["configs1"]
-    assert ROOF <= set(c1["roofline"]) and c1["value"] > 0 and c1["cpu_baseline"]["value"] > 0
+    assert ROOF <= set(c1["roofline"]) and c1["value"] > 0 and c1["cpu_baseline"]["value"] > 0, c1
+    assert "whole solve" in c1["timed"] and c1["steps_by_type"]["cg"] + c1["steps_by_type"]["expansion"] + c1["steps_by_type"]["proportioning"] == c1["steps"]
+    # the secondary blocks of the driver-run line: general (non-congruent) decomposition, configs[3], configs[4], the one-call contact solve
+    g = d["general"]
+    assert g["value"] > 0 and g["kplus"]["storage"] == "sym" and g["roofline"]["bound"] == "hbm" and "k_fx_symv" in g["roofline"]["kernel"] and "HETEROGENEOUS" in g["workload"], g
+    c3 = d["configs3"]
+    assert c3["value"] > 0 and c3["coarse_problem"]["m"] == 384 and c3["coarse_problem"]["GGt_mfma_ms"] > 0 and c3["workload"].startswith("configs[3]"), c3
+    c4 = d["configs4"]
+    assert c4["value"] > 0 and c4["workload"].startswith("configs[4]") and ROOF - {"traffic_source"} <= set(c4["roofline"]), c4
+    cs = d["contact_solve"]
+    assert cs["time_to_solution_seconds"] > 0 and cs["outer"] >= 1 and cs["explicit_solves"] > 0, cs
 
 
 def test_rehearsal_and_other_workloads_small():
