@@ -740,6 +740,26 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if world == 1 and not a.sim_world and has_mg and a.mg_precision != "fp64" and not a.no_iterative:
             switch_mg("fp64")
             extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
+    # the north star's "FETI dual SpMV": the fp64 K x of the CG inside K^+ (k_bsr3<double>), timed on three K^+ applications with the bench's own event pairs
+    kx = None
+    if world == 1 and not a.sim_world and not a.no_bsr3 and want_timing:
+        os.environ["PMH_TIMING_STRIDE"] = "1"
+        rhsv, uv = ctx.vec_from(np.random.default_rng(5).standard_normal(local["n_x"])), ctx.vec(local["n_x"])
+        q.Kplus.timing_enable(512)
+        for _ in range(3):
+            q.Kplus.mult(rhsv, uv)
+        n_x, ms_x, b_x = q.Kplus.timing_get()
+        q.Kplus.timing_enable(0)
+        rhsv.free(), uv.free()
+        if n_x:
+            gbs = b_x / (ms_x / n_x * 1e-3) / 1e9
+            kx = {"bound": "hbm", "kernel": "k_bsr3<double>: y = K x of the block-wise CG inside K^+ (3x3 blocks, 8.44 B per non-zero; the set-up solves of the explicit operators and the inner-Krylov path run on it)",
+                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_x, "launches_timed": n_x, "avg_launch_ms": ms_x / n_x,
+                  "matrix_copies_on_device": 1 if congruent else per,
+                  "note": ("the %d congruent blocks share ONE device copy of K_i (pmh_bsr3_from_csr compares them entry by entry): the replicas of a tile run back to back on one XCD and read the tile from its L2, so the "
+                           "algorithmic bytes of the block-diagonal product (SURVEY 8d: every K_i once) are NOT all streamed from HBM -- a rate above the 8 TB/s peak means exactly that; the HBM-streaming form of the same "
+                           "kernel is the `general` block's (one copy per block: 0.65-0.70 of the peak)" % per) if congruent and per > 1 else
+                          "one device copy per block (the blocks differ): every byte of the block-diagonal product is streamed from HBM once"}
     # one whole solve from lambda = 0 to the outer tolerance (the REAL stopping rule): what a user waits for after the set-up
     q.lam.set(0.0)
     qps_full = q.make_smalxe()  # a fresh solver object (QPS_SMALXE.state = 1 as after QPSCreate; the throughput passes above leave it at 3)
@@ -770,7 +790,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
                                       "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": "implicit: T G0 with T = chol(G0 G0')^{-1} applied in the finishing launch of G0 v, G0 kept sparse (%d non-zeros)" % G.nnz if implicit else True},
-        "roofline": roofline,
+        "roofline": roofline, "feti_dual_spmv": kx,
     }
     res.update(extra)
     return res, f, G, hier, q.b.to_numpy(), q.lb_new.to_numpy()  # (the CPU baseline leg re-uses the generated problem)
@@ -854,6 +874,7 @@ def main():
         out["ms_per_operator_apply"] = sbt.get("ms_per_operator_apply")
         out["time_to_solution_s"] = r["full_solve"]["time_to_solution_seconds"]
         out["full_solve"] = r["full_solve"]
+        out["feti_dual_spmv"] = r["feti_dual_spmv"]
         for k in ("iterative", "strict_fp64"):
             if k in r:
                 out[k] = r[k]
@@ -894,7 +915,7 @@ def main():
                 sb = r2["steps_by_type"]
                 return {"value": r2["value"], "unit": "QPS iterations/s", "ms_per_step": r2["ms_per_step"], "steps": over.get("_steps", 108), "warmup": 8, "workload": r2["workload"],
                         "applies_per_step": sb["operator_applies"] / over.get("_steps", 108) if sb.get("operator_applies") else None, "ms_per_operator_apply": sb.get("ms_per_operator_apply"),
-                        "steps_by_type": sb, "kplus": r2["kplus"], "coarse_problem": r2["coarse_problem"], "full_solve": r2["full_solve"], "setup_seconds": r2["setup_seconds"], "roofline": r2["roofline"]}
+                        "steps_by_type": sb, "kplus": r2["kplus"], "coarse_problem": r2["coarse_problem"], "full_solve": r2["full_solve"], "setup_seconds": r2["setup_seconds"], "roofline": r2["roofline"], "feti_dual_spmv": r2["feti_dual_spmv"]}
 
             if a.general_nel and not a.young:
                 # the general (non-congruent) path of the explicit operators: 8 subdomains of 8 different materials -> no class sharing, no set-up by symmetry,

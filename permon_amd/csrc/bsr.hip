@@ -37,17 +37,30 @@ template <typename V> struct lane_of<V, 1> {
 //   POST1 (x gathered):       r = dinv (b - A x); d = c0 r; y = x + d             first step of the post-smoother
 //   POST2 (x = d gathered):   y += c1 d + c2 (r - dinv A d); optional fp64 copy   second step of the post-smoother
 // TM: storage type of the matrix entries, T: arithmetic / vector type, W: adjacent blocks per thread-load.
+// nrep > 1 (congruent diagonal blocks, e.g. the 8 cubes of a structured decomposition): the tiles describe ONE diagonal block and are applied to nrep vector segments of
+// rep_stride entries each.  The replicas of a tile are consecutive workgroups of ONE XCD (every 8th workgroup index), so the tile's matrix bytes leave HBM once and the other
+// nrep - 1 readers find them in that XCD's L2: an eighth of the device copy, an eighth of the host conversion, and a product that no longer streams 8 copies of K.
 template <typename TM, typename T, int EPI, int W, int BSR_TB>
 __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int4 *__restrict__ tile_meta, const long long *__restrict__ tile_off, int ntiles, const int *__restrict__ browptr, const int *__restrict__ bcol, const TM *__restrict__ val, T scale,
-                                                     const T *__restrict__ x, T *__restrict__ y, pmh_bsr3_epi<T> e, const int *__restrict__ halt)
+                                                     const T *__restrict__ x, T *__restrict__ y, pmh_bsr3_epi<T> e, const int *__restrict__ halt, int nrep, long long rep_stride)
 {
   typedef typename vecw<TM, W>::type VM;
   typedef typename ivecw<W>::type    VI;
   __shared__ T prod[3][BSR_TB];
   const int    tid   = threadIdx.x;
-  const int    chunk = gridDim.x >> 3; // XCD-aware: XCD x works on a contiguous slab of tiles (x stays in its L2)
-  const int    t     = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const int    chunk = (gridDim.x >> 3) / nrep; // XCD-aware: XCD x works on a contiguous slab of tiles (x stays in its L2), every tile for its nrep replicas in a row
+  const int    v_    = blockIdx.x >> 3;
+  const int    t     = (blockIdx.x & 7) * chunk + v_ / nrep;
   if (t >= ntiles) return;
+  if (nrep > 1) {
+    const long long o = (long long)(v_ % nrep) * rep_stride;
+    x += o, y += o;
+    if (e.y1) e.y1 += o;
+    if (e.dinv) e.dinv += o;
+    if (e.r) e.r += o;
+    if (e.d) e.d += o;
+    if (e.z64) e.z64 += o;
+  }
   // the halt flag, the tile descriptor {first block row, end block row, first block, block count} and the tile's offset are
   // fetched together: one memory round trip instead of three dependent ones (the coarse-level launches are latency bound)
   const int       hlt = halt ? *halt : 0;
@@ -135,13 +148,16 @@ static int bsr_width(int storage)
 
 // Build from a resident CSR (downloaded once); *out = NULL without error when the matrix has no 3x3 block structure that
 // fits the tile (n not a multiple of 3, or a block row with more blocks than a tile holds).
-int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
+int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile, int nrep_hint)
 {
   PMH_ARG(A && out && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
   *out        = nullptr;
   pmh_ctx ctx = A->ctx;
   if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
-  const int        n = A->nrows, nbr = n / 3;
+  static const bool no_share = getenv("PMH_BSR_NO_SHARE") != nullptr; // A/B: one device copy per diagonal block (the HBM-streaming form)
+  int nrep = (nrep_hint > 1 && !no_share && A->nrows % nrep_hint == 0 && (A->nrows / nrep_hint) % 3 == 0 && A->nnz % nrep_hint == 0) ? nrep_hint : 1;
+  const int        n_all = A->nrows;
+  int              n = n_all / nrep, nbr = n / 3;
   const int        tb = (tile == 512 || tile == 1024 || tile == 2048) ? tile : bsr_tile(storage), W = bsr_width(storage);
   const bool       verbose = getenv("PMH_CONTACT_TIMING") != nullptr && A->nnz > 10000000;
   auto             tnow    = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -157,7 +173,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   const int          *rp = A->h_rowptr, *ci = A->h_col;
   const double       *va = A->h_val;
   if (!(rp && (A->nnz == 0 || (ci && va)))) { // no host copy lent by the caller: download
-    rp_own.resize((size_t)n + 1), ci_own.resize((size_t)A->nnz), va_own.resize((size_t)A->nnz);
+    rp_own.resize((size_t)n_all + 1), ci_own.resize((size_t)A->nnz), va_own.resize((size_t)A->nnz);
     PMH_CHK(pmh_memcpy_d2h(ctx, rp_own.data(), A->d_rowptr, sizeof(int) * rp_own.size()));
     if (A->nnz) {
       PMH_CHK(pmh_memcpy_d2h(ctx, ci_own.data(), A->d_col, sizeof(int) * ci_own.size()));
@@ -166,6 +182,40 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
     rp = rp_own.data(), ci = ci_own.data(), va = va_own.data();
   }
   stage("host copy of the CSR arrays");
+  if (nrep > 1) {
+    // the caller says the matrix is block diagonal with nrep congruent blocks: believed only after every entry of the other blocks has been compared with block 0
+    // (threads over the replicas' rows; a mismatch anywhere falls back to the unshared form)
+    const long long nnzb = A->nnz / nrep;
+    bool            same = rp[n] == nnzb;
+    for (int r = 1; r < nrep && same; r++) same = (long long)rp[(size_t)r * n] == (long long)r * nnzb;
+    if (same) {
+      const int         ntc = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+      std::vector<char> bad(ntc, 0);
+      auto              cmp = [&](int tt) {
+        for (int r = 1; r < nrep && !bad[tt]; r++) {
+          const int       *rpr = rp + (size_t)r * n;
+          const long long  ko  = (long long)r * nnzb;
+          const int        i0 = (int)((long long)n * tt / ntc), i1 = (int)((long long)n * (tt + 1) / ntc);
+          for (int i = i0; i < i1 && !bad[tt]; i++) {
+            if ((long long)rpr[i + 1] - ko != rp[i + 1]) bad[tt] = 1;
+            else
+              for (int k = rp[i]; k < rp[i + 1]; k++)
+                if (ci[k + ko] - r * n != ci[k] || memcmp(&va[k + ko], &va[k], sizeof(double)) || ci[k] >= n) {
+                  bad[tt] = 1;
+                  break;
+                }
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      for (int tt = 0; tt < ntc; tt++) th.emplace_back(cmp, tt);
+      for (auto &x : th) x.join();
+      for (char b : bad) same = same && !b;
+    }
+    if (!same) nrep = 1, n = n_all, nbr = n / 3;
+    stage(nrep > 1 ? "congruent diagonal blocks confirmed (one device copy serves all)" : "diagonal blocks differ: one device copy each");
+  }
+  const long long nnz_used = nrep > 1 ? A->nnz / nrep : A->nnz;
   // block structure: union of the block columns of the three rows of each block row (sorted)
   // (host threads over contiguous ranges of block rows: the fine level of configs[2] has 158 M non-zeros and is converted three times per set-up)
   std::vector<int> browptr((size_t)nbr + 1, 0), bcol;
@@ -175,7 +225,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
     std::vector<char>             toobig(nt, 0);
     auto work = [&](int t) {
       std::vector<int> tmp;
-      tbc[t].reserve((size_t)(A->nnz / 9 / nt) + 16);
+      tbc[t].reserve((size_t)(nnz_used / 9 / nt) + 16);
       for (int br = (int)((long long)nbr * t / nt); br < (int)((long long)nbr * (t + 1) / nt); br++) {
         tmp.clear();
         for (int r = 0; r < 3; r++)
@@ -204,7 +254,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
     for (int br = 0; br < nbr; br++) browptr[br + 1] += browptr[br];
   }
   const long long nblocks = (long long)bcol.size();
-  if (nblocks * 9 > 2 * A->nnz + 64) return PMH_SUCCESS; // blocks mostly empty: the CSR kernel moves fewer bytes
+  if (nblocks * 9 > 2 * nnz_used + 64) return PMH_SUCCESS; // blocks mostly empty: the CSR kernel moves fewer bytes
   stage("block structure");
   // tiles of whole block rows
   std::vector<int> tile_br(1, 0);
@@ -264,7 +314,8 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile)
   }
   stage("values into the tile planes");
   pmh_bsr3 B = new pmh_bsr3_s();
-  B->ctx = ctx, B->n = n, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
+  B->ctx = ctx, B->n = n_all, B->nbr = nbr, B->ntiles = ntiles, B->nblocks = nblocks, B->npad = npad, B->storage = storage, B->W = W, B->tb = tb;
+  B->nrep = nrep, B->rep_rows = n; // nbr, ntiles, nblocks, npad describe ONE replica
   B->scale   = 1.0;
   B->ev_used = 0, B->ev_on = 0, B->ev_seen = 0, B->ev_stride = 1;
   std::vector<int> tmeta((size_t)4 * ntiles);
@@ -331,20 +382,22 @@ double pmh_bsr3_bytes(pmh_bsr3 B)
 {
   const double wm = (B->storage == PMH_BSR_F64) ? 8.0 : (B->storage == PMH_BSR_F32 ? 4.0 : 2.0);
   const double wv = (B->storage == PMH_BSR_F64) ? 8.0 : 4.0;
-  return (double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1) + 2.0 * wv * B->n;
+  // with congruent blocks sharing one device copy (nrep > 1) the figure stays the one of the block-diagonal product -- nrep times the matrix bytes, what SURVEY 8d counts per K_i --
+  // so that a rate above the HBM peak says what it means: the copies are served by the XCDs' L2, not streamed
+  return (double)B->nrep * ((double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1)) + 2.0 * wv * B->n;
 }
 
 template <typename TM, typename T, int W, int TB>
 static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)
 {
-  const dim3       grid((unsigned)(((B->ntiles + 7) / 8) * 8)), blk(PMH_BLOCK);
+  const dim3       grid((unsigned)(((B->ntiles + 7) / 8) * 8 * B->nrep)), blk(PMH_BLOCK);
   hipStream_t      st = B->ctx->stream;
   const int4      *tb = (const int4 *)B->d_tile_br;
   const int       *bp = B->d_browptr, *bc = B->d_bcol;
   const long long *to = B->d_tile_off;
   const TM        *v  = (const TM *)B->d_val;
   const T          sc = (T)B->scale;
-#define BSR_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<TM, T, EPI, W, TB>), grid, blk, 0, st, tb, to, B->ntiles, bp, bc, v, sc, x, y, e, halt)
+#define BSR_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bsr3<TM, T, EPI, W, TB>), grid, blk, 0, st, tb, to, B->ntiles, bp, bc, v, sc, x, y, e, halt, B->nrep, (long long)B->rep_rows)
   switch (epi) {
   case PMH_EPI_NONE: BSR_LAUNCH(PMH_EPI_NONE); break;
   case PMH_EPI_ADD: BSR_LAUNCH(PMH_EPI_ADD); break;

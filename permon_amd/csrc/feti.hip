@@ -692,7 +692,11 @@ extern "C" int pmh_matinv_enable_bsr3(pmh_matinv M)
 {
   PMH_ARG(M);
   if (M->Kb) return PMH_SUCCESS;
-  PMH_CHK(pmh_bsr3_from_csr(M->K->K, 0, &M->Kb));
+  // blocks of equal size may be congruent (pmh_bsr3_from_csr compares them entry by entry): one device copy of the block then serves all of them
+  int nrep = M->nblocks;
+  for (int b = 0; b < M->nblocks && nrep > 1; b++)
+    if (M->K->rowstart[b + 1] - M->K->rowstart[b] != M->K->rowstart[1] - M->K->rowstart[0]) nrep = 1;
+  PMH_CHK(pmh_bsr3_from_csr(M->K->K, 0, &M->Kb, 0, nrep));
   if (!M->Kb) return pmh_set_error(PMH_ERR_SUP, "pmh_matinv_enable_bsr3: K (n = %d) has no usable 3x3 block structure", M->n);
   return PMH_SUCCESS;
 }

@@ -602,7 +602,9 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       // coarser levels use 512-block tiles: twice the workgroups on operators that are too small to fill the chip, and a kernel
       // instantiation of their own, so that profiler averages of the fine-level operator are not mixed with the coarse launches
       static const int coarse_tile = getenv("PMH_MG_COARSE_TILE") ? atoi(getenv("PMH_MG_COARSE_TILE")) : 512;
-      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab, l == 0 ? 0 : coarse_tile));
+      // congruent blocks (every cube of a structured decomposition): nb_coarse is the number of diagonal blocks on every level; pmh_bsr3_from_csr keeps ONE device copy of the
+      // block when all of them turn out to be bit-identical (it compares them), applied to the nb_coarse vector segments
+      if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab, l == 0 ? 0 : coarse_tile, (nb_coarse > 1 && Lv.n % nb_coarse == 0) ? nb_coarse : 1));
       stage("3x3-block operator (pmh_bsr3_from_csr)", l);
       if (fl && !Lv.Ab) {
         pmh_mg_destroy(mg);

@@ -175,6 +175,7 @@ int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                          
 struct pmh_bsr3_s {
   pmh_ctx   ctx;
   int       n, nbr, ntiles, storage, W, tb; // storage: PMH_BSR_F64 / F32 / F16 (matrix entries); W: blocks per load
+  int       nrep, rep_rows;                 // nrep > 1: the tiles hold ONE of nrep congruent diagonal blocks of rep_rows rows each (n = nrep * rep_rows)
   long long nblocks, npad;
   double    scale; // F16: the stored entries are A / scale
   int      *d_tile_br, *d_browptr, *d_bcol;
@@ -195,7 +196,7 @@ template <typename T> struct pmh_bsr3_epi {
   double  *z64;  // POST2: optional fp64 copy of the result
   T        c0, c1, c2;
 };
-int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0); // *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default
+int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0, int nrep_hint = 1); // *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default; nrep_hint > 1: A is said to be block diagonal with that many congruent blocks (checked entry by entry: one device copy then serves all)
 int    pmh_bsr3_destroy(pmh_bsr3 B);
 double pmh_bsr3_bytes(pmh_bsr3 B);
 int    pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt);
