@@ -194,16 +194,16 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
           int b0 = 0;
           while (b0 < nsub && cls[b0] != c) b0++;
           const int r0 = block_rowstart[b0], r1 = block_rowstart[b0 + 1];
-          std::vector<int>    rp((size_t)(r1 - r0) + 1), cj;
-          std::vector<double> vj;
-          rp[0] = 0;
-          for (int i = r0; i < r1; i++) {
-            for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
-              if (col[k] >= r0 && col[k] < r1) cj.push_back(col[k] - r0), vj.push_back(val[k]);
-            rp[i - r0 + 1] = (int)cj.size();
+          int       used = 1;
+          if (r0 == 0) { // K is block diagonal: the first block's rows ARE its CSR (no copy of 20 M entries)
+            PMH_CHK(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rowptr, col, val, &used));
+          } else {
+            const int           k0 = rowptr[r0], nz = rowptr[r1] - k0;
+            std::vector<int>    rp((size_t)(r1 - r0) + 1), cj((size_t)nz);
+            for (int i = r0; i <= r1; i++) rp[i - r0] = rowptr[i] - k0;
+            for (int k = 0; k < nz; k++) cj[k] = col[k0 + k] - r0;
+            PMH_CHK(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rp.data(), cj.data(), val + k0, &used));
           }
-          int used = 1;
-          PMH_CHK(pmh_fexplicit_set_box_symmetry(E, c, dims + 3 * b0, ndof, rp.data(), cj.data(), vj.data(), &used));
           st->explicit_symmetries = std::max(st->explicit_symmetries, used);
           *least = std::min(*least, used);
         }

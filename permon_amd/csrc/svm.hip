@@ -85,8 +85,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x(int n, int d, const double 
 }
 
 // ---- d == 64 fast path: 16-byte loads, two rows per wave-instruction (lanes 0-31 row r, lanes 32-63 row r+1), 4-fold unroll ----
-#define SVM_UNR 4
 typedef double dbl2 __attribute__((ext_vector_type(2))); // native 16-byte vector: accepted by the non-temporal builtins
+template <int SVM_UNR>
 __global__ __launch_bounds__(PMH_BLOCK) void k_svm_xt64(int n, const double *__restrict__ X, const double *__restrict__ y, const double *__restrict__ a, double *__restrict__ part)
 {
   __shared__ double lds[PMH_BLOCK / 64][64];
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_xt64(int n, const double *__r
   }
 }
 
+template <int SVM_UNR>
 __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64(int n, const double *__restrict__ X, const double *__restrict__ y, const double *__restrict__ w, double *__restrict__ Ha)
 {
   const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l2 = lane & 31;
@@ -151,11 +152,23 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64(int n, const double *__re
 int SvmDualOp::mult(const double *a, double *Ha)
 {
   if (d == 64 && n > 0) {
-    hipLaunchKernelGGL(k_svm_xt64, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, a, part);
-    hipLaunchKernelGGL(k_svm_colsum, dim3((d + 3) / 4), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
-    PMH_HIP(hipGetLastError());
-    PMH_CHK(pmh_comm_allreduce_sum(ctx, w, (size_t)d));
-    hipLaunchKernelGGL(k_svm_x64, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, (const double *)w, Ha);
+    // rows in flight per wave-instruction group: 2 x UNR rows of 512 B (16-byte loads, UNR of them outstanding per lane).  UNR decides which wave visits which rows,
+    // i.e. the summation order of pass 1 (last-digit differences between UNR values; fixed for a given UNR).  Measured 4 / 8 / 12 / 16 on configs[4]: 464 / 452-488 / 433 / 487
+    // iterations per second -- inside the run-to-run spread of the box (the two passes already stream X at the box's copy rate): 4 stays
+    static const int unr = getenv("PMH_SVM_UNR") ? atoi(getenv("PMH_SVM_UNR")) : 4;
+#define SVM_GO(U)                                                                                                                          \
+  do {                                                                                                                                     \
+    hipLaunchKernelGGL(k_svm_xt64<U>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, a, part);                                   \
+    hipLaunchKernelGGL(k_svm_colsum, dim3((d + 3) / 4), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);            \
+    PMH_HIP(hipGetLastError());                                                                                                            \
+    PMH_CHK(pmh_comm_allreduce_sum(ctx, w, (size_t)d));                                                                                    \
+    hipLaunchKernelGGL(k_svm_x64<U>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, (const double *)w, Ha);                      \
+  } while (0)
+    if (unr >= 16) SVM_GO(16);
+    else if (unr >= 12) SVM_GO(12);
+    else if (unr >= 8) SVM_GO(8);
+    else SVM_GO(4);
+#undef SVM_GO
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
