@@ -65,8 +65,14 @@ struct fxs_class {
   std::vector<int>  reprow;             // representative index (in reps) -> row of A / cpart
   int              *d_coltab = nullptr, *d_fintab = nullptr; // fintab per (group, row tile): coltab offset, padded columns, first element of the tile in the group's numbering
   long long        *d_finbase = nullptr;                     // per (group, row tile): offset of split 0 in cpart
-  int               item_first = 0, item_count = 0, fin_elems = 0;
+  int               item_first = 0, item_count = 0, fin_elems = 0, wgf_first = 0, wg_count = 0; // the class's items; its workgroups (slice of fx_shared::d_wgfirst)
   signed char     *d_use = nullptr;
+  // k segments of the orbit GEMM: the positions (= the k index of the product) are grouped by WHICH columns have a structural non-zero of B there (block (group, slot)
+  // does not touch g c => B[c][(g, slot)] = 0), the rows of B are permuted segment after segment (each padded to whole chunks) and a (row tile, segment) multiplies
+  // only the columns that are non-zero on the segment (fxo_prepare).  kinv: position -> row of B / column of the pre-tiled A
+  std::vector<int> kinv;
+  int             *d_kinv = nullptr, *d_unittab = nullptr, *d_lut = nullptr; // unittab per (group, row tile, segment) unit: offset of its look-up table, padded columns, splits, 0
+  int              nseg = 1;
 };
 
 struct fx_shared {
@@ -91,7 +97,7 @@ struct fx_shared {
   // symmetric tile storage (PMH_FX_CLASS_SYM): the lower block-triangle of W_c in 16 x 16 tiles, k_fxs_symm8 (fp64 MFMA) + k_fxs_symfin
   int                    sym = 0, segj = 0;
   long long             *d_wgl = nullptr; // per item: offset of its class's tiles, offset of its transposed partial sums
-  int                   *d_items = nullptr;
+  int                   *d_items = nullptr, *d_wgfirst = nullptr;
   double                *pt = nullptr;
   long long              pt_tot = 0;
   double                 owned_bytes = 0.0;
@@ -439,23 +445,26 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 #define FXO_LDB (FXO_TN + 4)
 // items: (class, group, row tile, column tile (16 operations), first chunk, one-past-last chunk, split, 0); iteml: A offset of the class, X offset of
 // the group, C offset of (class, group, split)
-__global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
+__global__ __launch_bounds__(256, 2) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                      const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                     const double *__restrict__ X, double *__restrict__ cpart)
+                                                     const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
 {
   __shared__ double As[2][FXO_TK][FXO_LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB];
-  const int *w8 = items + 8 * blockIdx.x;
+  // the workgroup's items one after the other (a piece of the k range may end one unit and begin the next: fxo_prepare)
+  for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
+  __builtin_amdgcn_sched_barrier(0);
+  const int *w8 = items + 8 * it;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
   const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
-  const double *__restrict__ Ab = A + iteml[4 * blockIdx.x];
-  const double *__restrict__ x  = X + iteml[4 * blockIdx.x + 1];
-  double *__restrict__ C        = cpart + iteml[4 * blockIdx.x + 2]; // the (group, row tile, split) block: tile rows x ncol
+  const double *__restrict__ Ab = A + iteml[4 * it];
+  const double *__restrict__ x  = X + iteml[4 * it + 1];
+  double *__restrict__ C        = cpart + iteml[4 * it + 2]; // the (group, row tile, split) block: tile rows x ncol
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   constexpr int NEA = FXO_TK * FXO_TM / 2 / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
   const int  col = t % FXO_TN, kb = t / FXO_TN;
-  const int  ct  = coltab[iteml[4 * blockIdx.x + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
+  const int  ct  = coltab[iteml[4 * it + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
   const int  sl  = ct < 0 ? 0 : (ct & 7);
   const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
   double     acc[4][16];
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 16; j++) C[(long long)(wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
+  }
 }
 
 // The same GEMM with the instruction's operands the other way round: the SAME 4 rows of A in its 4 blocks, 16 columns of B (4 per block) -- rows come in
@@ -536,24 +546,27 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm(const int *__restrict__ ite
 // Wave tile 4 NA x 64: NA x 4 accumulators; D lane l = row l >> 4 of the 4, column l & 15 of the 16.
 #define FXO_LDB4 (FXO_TN + 16) // 16 consecutive columns x 4 k per read: rows of B 32 banks apart
 template <int NA>
-__global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
+__global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                       const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                      const double *__restrict__ X, double *__restrict__ cpart)
+                                                      const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
 {
   constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB4];
-  const int *w8 = items + 8 * blockIdx.x;
+  // the workgroup's items one after the other (a piece of the k range may end one unit and begin the next: fxo_prepare)
+  for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
+  __builtin_amdgcn_sched_barrier(0);
+  const int *w8 = items + 8 * it;
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
   const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
-  const double *__restrict__ Ab = A + iteml[4 * blockIdx.x];
-  const double *__restrict__ x  = X + iteml[4 * blockIdx.x + 1];
-  double *__restrict__ C        = cpart + iteml[4 * blockIdx.x + 2]; // the (group, row tile, split) block: tile rows x ncol
+  const double *__restrict__ Ab = A + iteml[4 * it];
+  const double *__restrict__ x  = X + iteml[4 * it + 1];
+  double *__restrict__ C        = cpart + iteml[4 * it + 2]; // the (group, row tile, split) block: tile rows x ncol
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // NQ 16-byte pieces of A per chunk
   const int  col = t % FXO_TN, kb = t / FXO_TN;
-  const int  ct  = coltab[iteml[4 * blockIdx.x + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
+  const int  ct  = coltab[iteml[4 * it + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
   const int  sl  = ct < 0 ? 0 : (ct & 7);
   const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
   double     acc[NA][4];
@@ -625,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void k_fxo_gemm4(const int *__restrict__ it
   for (int i = 0; i < NA; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) C[(long long)(wm * WR + i * 4 + ka) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j];
+  }
 }
 
 // row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
@@ -643,57 +657,80 @@ static int fxo_row_tile(int M)
   return best;
 }
 
-// Y[g p][slot] = s_g(p) * (sum over the splits, in split order) for the (row, operation) pairs that own their row (use = +-1: the operation the row was
-// assigned to; rows fixed by several operations are written once), over the columns the (group, row tile) pairs list.  One thread per (row, listed column);
-// grid.y = group.  fintab per (group, row tile): offset of its column list, its padded column count, its first element in the group's numbering
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, int S, const int *__restrict__ fintab, const long long *__restrict__ finbase, const int *__restrict__ coltab,
-                                                       const double *__restrict__ cp, const signed char *__restrict__ use, const int *__restrict__ reppos, const int *__restrict__ posmap,
-                                                       long long xbase0, int ld, double *__restrict__ Y)
+// Y[g p][slot] = s_g(p) * (sum over the row tile's units (k segments) in unit order, over a unit's splits in split order) for the (row, operation) pairs that own
+// their row (use = +-1: the operation the row was assigned to; rows fixed by several operations are written once), over the columns the (group, row tile) pairs list.
+// One thread per (row, listed column); grid.y = group.  fintab per (group, row tile): offset of its column list, its padded column count, its first element in the
+// group's numbering, its first unit; unittab per unit: offset of its look-up table (column of the tile's list -> column of the unit's list, -1: B is zero there on the
+// whole segment, nothing was multiplied), its padded column count, its splits; unitbase: split 0 of the unit in cpart
+#define FXO_FU 4
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, const int *__restrict__ fintab, const int *__restrict__ unittab, const long long *__restrict__ unitbase,
+                                                       const int *__restrict__ lut, const int *__restrict__ coltab, const double *__restrict__ cp, const signed char *__restrict__ use,
+                                                       const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld, double *__restrict__ Y)
 {
   const int  i  = blockIdx.x * PMH_BLOCK + threadIdx.x;
-  const int *ft = fintab + 3 * (ntile + 1) * blockIdx.y;
-  if (i >= ft[3 * ntile + 2]) return; // the group's element count
+  const int *ft = fintab + 4 * (ntile + 1) * blockIdx.y;
+  if (i >= ft[4 * ntile + 2]) return; // the group's element count
   int mt = 0;
-  while (mt + 1 < ntile && i >= ft[3 * (mt + 1) + 2]) mt++;
-  const int ncol = ft[3 * mt + 1], local = i - ft[3 * mt + 2], r = local / ncol, j = local % ncol;
-  const int ct = coltab[ft[3 * mt] + j];
+  while (mt + 1 < ntile && i >= ft[4 * (mt + 1) + 2]) mt++;
+  const int ncol = ft[4 * mt + 1], local = i - ft[4 * mt + 2], r = local / ncol, j = local % ncol;
+  const int ct = coltab[ft[4 * mt] + j];
   if (ct < 0) return;
   const int g = ct >> 3, sl = ct & 7, row = mt * tm + r;
   const int u = use[(long long)row * nsymp + g];
   if (u == 0) return;
-  const long long dst    = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[row]] * FXS_S + sl;
-  const long long stride = (long long)tm * ncol;
-  const double   *q      = cp + finbase[(long long)ntile * blockIdx.y + mt] + (long long)r * ncol + j;
-  double          s      = q[0];
-  int             k      = 1;
-  // the splits are added in split order, but their loads travel together (a plain loop compiles to load - wait - add per split)
-  for (; k + 8 <= S; k += 8) {
-    double v[8];
+  const long long dst = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[row]] * FXS_S + sl;
+  double          s   = 0.0;
+  // FXO_FU units at a time: their look-ups, then the first 8 splits of each travel together (a plain loop compiles to load - wait - add per unit and split);
+  // the sums are still taken unit after unit, split after split (+ 0.0 for a split that does not exist changes nothing)
+  const int u1 = ft[4 * (mt + 1) + 3];
+  for (int un = ft[4 * mt + 3]; un < u1; un += FXO_FU) {
+    int           Su[FXO_FU];
+    long long     st[FXO_FU];
+    const double *q[FXO_FU];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = q[(long long)(k + e) * stride];
+    for (int e = 0; e < FXO_FU; e++) {
+      const bool in  = un + e < u1;
+      const int *ut  = unittab + 4 * (in ? un + e : un);
+      const int  pos = lut[ut[0] + j], nct = ut[1];
+      Su[e] = in && pos >= 0 ? ut[2] : 0;
+      st[e] = (long long)tm * nct;
+      q[e]  = cp + unitbase[in ? un + e : un] + (long long)r * nct + (pos >= 0 ? pos : 0);
+    }
+    double v[FXO_FU][8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) s += v[e];
+    for (int e = 0; e < FXO_FU; e++)
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[e][k] = k < Su[e] ? q[e][(long long)k * st[e]] : 0.0;
+#pragma unroll
+    for (int e = 0; e < FXO_FU; e++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += v[e][k];
+      for (int k = 8; k < Su[e]; k++) s += q[e][(long long)k * st[e]];
+    }
   }
-  for (; k < S; k++) s += q[(long long)k * stride];
   Y[dst] = u > 0 ? s : -s;
 }
 
-// row of representative pl (local index) from its K^+ solve -> the pre-tiled A
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_store_row(int pl, int tm, int nc, int nkc, const int *__restrict__ urel, const double *__restrict__ u, double *__restrict__ A)
+// row of representative pl (local index) from its K^+ solve -> the pre-tiled A (column kinv[c] for position c)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_store_row(int pl, int tm, int nc, int nkc, const int *__restrict__ urel, const int *__restrict__ kinv, const double *__restrict__ u, double *__restrict__ A)
 {
   double *base = A + (long long)(pl / tm) * nkc * (FXO_TK * tm) + pl % tm;
-  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) base[(long long)(c / FXO_TK) * (FXO_TK * tm) + (c % FXO_TK) * tm] = u[urel[c]];
+  for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) {
+    const int k = kinv[c];
+    base[(long long)(k / FXO_TK) * (FXO_TK * tm) + (k % FXO_TK) * tm] = u[urel[c]];
+  }
 }
 
 // set-up self-check: row r = g p from its own solve (u) against s_g(p) s_g(c) A[p][c] at column g c, for all c
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_check_row(int pl, int tm, int nc, int nkc, double sp, const int *__restrict__ urel, const double *__restrict__ u, const int *__restrict__ posmap,
-                                                             const signed char *__restrict__ sign, const double *__restrict__ A, double *__restrict__ out)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_check_row(int pl, int tm, int nc, int nkc, double sp, const int *__restrict__ urel, const int *__restrict__ kinv, const double *__restrict__ u,
+                                                             const int *__restrict__ posmap, const signed char *__restrict__ sign, const double *__restrict__ A, double *__restrict__ out)
 {
   __shared__ double red[PMH_BLOCK / 64];
   const double *base = A + (long long)(pl / tm) * nkc * (FXO_TK * tm) + pl % tm;
   double        d = 0.0, m = 0.0;
   for (int c = blockIdx.x * PMH_BLOCK + threadIdx.x; c < nc; c += gridDim.x * PMH_BLOCK) {
-    const double w = sp * (double)sign[c] * base[(long long)(c / FXO_TK) * (FXO_TK * tm) + (c % FXO_TK) * tm], v = u[urel[posmap[c]]];
+    const int    k = kinv[c];
+    const double w = sp * (double)sign[c] * base[(long long)(k / FXO_TK) * (FXO_TK * tm) + (k % FXO_TK) * tm], v = u[urel[posmap[c]]];
     d = fmax(d, fabs(w - v)), m = fmax(m, fabs(v));
   }
   d = -pmh_block_reduce<PMH_RED_MIN>(-d, red);
@@ -949,10 +986,12 @@ void fxs_destroy(fx_shared *S)
     if (C.d_posmap) pmh_free(ctx, C.d_posmap), pmh_free(ctx, C.d_sign);
     if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
     if (C.d_coltab) pmh_free(ctx, C.d_coltab), pmh_free(ctx, C.d_fintab), pmh_free(ctx, C.d_finbase);
+    if (C.d_kinv) pmh_free(ctx, C.d_kinv), pmh_free(ctx, C.d_unittab), pmh_free(ctx, C.d_lut);
   }
   if (S->pt) pmh_free(ctx, S->pt);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   if (S->d_items) pmh_free(ctx, S->d_items);
+  if (S->d_wgfirst) pmh_free(ctx, S->d_wgfirst);
   pmh_gluing_destroy(S->Bc);
   if (S->Wbase) (void)hipFree(S->Wbase);
   if (S->Afund) (void)hipFree(S->Afund);
@@ -1070,17 +1109,26 @@ int fxs_set_symmetry(fx_shared *S, int c, int nsym, const int *posmap, const sig
 }
 
 // ---- orbit storage: plan (after the symmetries and the stripe are known) ----------------------------------------------------------------------
+struct fxo_unit { // a (group, row tile, k segment): its columns (a sub-list of the tile's), its chunks on this rank, its splits and partial tiles
+  int       g = 0, mt = 0, seg = 0, coff = 0, nct = 0, listed = 0, lutoff = 0, kc0 = 0, kc1 = 0, S = 0;
+  long long cbase = 0;
+};
+struct fxo_plan {
+  std::vector<fxo_unit> units;
+  std::vector<int>      coltab, fintab, lut, segc0;
+};
+
 static int fxo_prepare(fx_shared *S)
 {
   if (S->fxo_ready) return PMH_SUCCESS;
   pmh_ctx   ctx = S->ctx;
   long long atot = 0;
-  std::vector<std::vector<int>> h_fintab, h_coltab, h_rowrep; // per class with touched dofs, in class order
-  std::vector<int>              tab_of(S->ncls, -1);
+  std::vector<fxo_plan> plan; // per class with touched dofs, in class order
+  std::vector<int>      tab_of(S->ncls, -1);
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
     if (C.nc == 0) continue;
-    tab_of[c] = (int)h_fintab.size();
+    tab_of[c] = (int)plan.size();
     if (C.nsym < 1) return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: block class %d has no symmetries (pmh_fexplicit_set_class_symmetry / _set_box_symmetry before the assembly)", c);
     // orbits of the rows: representative and operation of every row; rows fixed by several operations keep the first
     C.rep_of.assign((size_t)C.nc, -1), C.op_of.assign((size_t)C.nc, 0), C.reps.clear();
@@ -1099,17 +1147,9 @@ static int fxo_prepare(fx_shared *S)
     const int M = C.m1 - C.m0;
     C.tm   = fxo_row_tile(M);
     C.Mp   = std::max(1, (M + C.tm - 1) / C.tm) * C.tm;
-    C.ldk  = (C.nc + FXO_TK - 1) / FXO_TK * FXO_TK;
-    C.nkc  = C.ldk / FXO_TK;
     C.nsymp = (C.nsym + FXO_TN / 8 - 1) / (FXO_TN / 8) * (FXO_TN / 8);
-    C.aoff = atot;
-    atot += (long long)C.Mp * C.ldk;
-    // gather indices of B: (position of g c) << 1 | (s_g(c) < 0); padded k and padded operations read the zero row nc of X
-    // (one more row of gather indices, all on the zero row of X: what the padding columns of the lists below read)
-    std::vector<int>         gidx((size_t)(C.nsymp + 1) * C.ldk, C.nc << 1), reppos((size_t)C.Mp, 0);
+    std::vector<int>         reppos((size_t)C.Mp, 0);
     std::vector<signed char> use((size_t)C.Mp * C.nsymp, 0), use_h((size_t)M * C.nsym, 0);
-    for (int g = 0; g < C.nsym; g++)
-      for (int cc = 0; cc < C.nc; cc++) gidx[(size_t)g * C.ldk + cc] = (C.h_posmap[(size_t)g * C.nc + cc] << 1) | (C.h_sign[(size_t)g * C.nc + cc] < 0 ? 1 : 0);
     for (int pl = 0; pl < M; pl++) {
       const int p = C.reps[C.m0 + pl];
       for (int g = 0; g < C.nsym; g++) {
@@ -1164,33 +1204,150 @@ static int fxo_prepare(fx_shared *S)
       C.reprow[pl] = row, reppos[row] = C.reps[C.m0 + pl];
       for (int g = 0; g < C.nsym; g++) use[(size_t)row * C.nsymp + g] = use_h[(size_t)pl * C.nsym + g];
     }
-    // column lists per (group, row tile)
-    const int        ntile = C.Mp / C.tm;
-    std::vector<int> coltab, fintab((size_t)C.ngroups * (ntile + 1) * 3, 0);
+    // column lists per (group, row tile): the columns some row of the tile needs (what k_fxo_fin walks)
+    const int        ntile = C.Mp / C.tm, ncode = C.nsym * FXS_S, cw = (ncode + 63) / 64;
+    std::vector<int> coltab, fintab((size_t)C.ngroups * (ntile + 1) * 4, 0);
+    std::vector<unsigned long long> need((size_t)C.ngroups * ntile * cw, 0ULL); // the same lists as bit sets over the codes
     for (int gr = 0; gr < C.ngroups; gr++) {
       int elems = 0;
       for (int mt = 0; mt < ntile; mt++) {
         const int coff = (int)coltab.size();
-        for (int code = 0; code < C.nsym * FXS_S; code++) {
+        for (int code = 0; code < ncode; code++) {
           const size_t b   = ((size_t)gr * C.nsym + (code >> 3)) * FXS_S + (code & 7);
           bool         any = false;
           for (int row = mt * C.tm; row < std::min(M, (mt + 1) * C.tm) && !any; row++) any = (pat[(size_t)rowrep[row] * nw + b / 64] >> (b % 64)) & 1ULL;
-          if (any) coltab.push_back(code);
+          if (any) coltab.push_back(code), need[((size_t)gr * ntile + mt) * cw + code / 64] |= 1ULL << (code % 64);
         }
         while ((coltab.size() - coff) % FXO_TN) coltab.push_back(-1);
-        int *ft = fintab.data() + ((size_t)gr * (ntile + 1) + mt) * 3;
+        int *ft = fintab.data() + ((size_t)gr * (ntile + 1) + mt) * 4;
         ft[0] = coff, ft[1] = (int)coltab.size() - coff, ft[2] = elems;
         elems += C.tm * ft[1];
       }
-      fintab[((size_t)gr * (ntile + 1) + ntile) * 3 + 2] = elems;
+      fintab[((size_t)gr * (ntile + 1) + ntile) * 4 + 2] = elems;
       C.fin_elems = std::max(gr ? C.fin_elems : 0, elems);
     }
+    // k segments: B[c][(g, slot)] = s_g(c) X[g c][slot] is structurally zero where block (group, slot) does not touch g c.  The signature of a position is the set of
+    // columns that are NOT zero there; positions of one signature form a segment (the interior of a face of the cube with one dof component, ...), small ones are pooled,
+    // and two segments are joined whenever that does not add column tiles (fewer, longer units split more evenly).  The k index of the product runs segment after segment,
+    // each padded to whole chunks, and a (row tile, segment) unit multiplies only the columns of the tile's list that are non-zero on the segment: for a 2 x 2 x 2
+    // decomposition a face segment keeps 128 ... 256 of the 384 columns.  PMH_FXO_NO_KSEG=1: one segment (every listed column over the whole k range).
+    const size_t sw = (size_t)C.ngroups * cw;
+    std::vector<std::vector<unsigned long long>> ssig;
+    std::vector<std::vector<int>>                spos;
+    if (prune && !getenv("PMH_FXO_NO_KSEG")) {
+      std::map<std::vector<unsigned long long>, int> ids;
+      std::vector<unsigned long long>                sg(sw);
+      for (int cc = 0; cc < C.nc; cc++) {
+        std::fill(sg.begin(), sg.end(), 0ULL);
+        for (int gr = 0; gr < C.ngroups; gr++)
+          for (int g = 0; g < C.nsym; g++) {
+            const char *tm8 = &C.tmask[((size_t)gr * C.nc + C.h_posmap[(size_t)g * C.nc + cc]) * FXS_S];
+            for (int sl = 0; sl < FXS_S; sl++)
+              if (tm8[sl]) sg[(size_t)gr * cw + (g * FXS_S + sl) / 64] |= 1ULL << ((g * FXS_S + sl) % 64);
+          }
+        auto it = ids.find(sg);
+        if (it == ids.end()) it = ids.emplace(sg, (int)ssig.size()).first, ssig.push_back(sg), spos.emplace_back();
+        spos[it->second].push_back(cc);
+      }
+      const int minseg = getenv("PMH_FXO_SEGMIN") ? std::max(1, atoi(getenv("PMH_FXO_SEGMIN"))) : std::max(2 * FXO_TK, C.nc / 64);
+      auto join = [&](size_t a, size_t b) { // b into a
+        for (size_t w = 0; w < sw; w++) ssig[a][w] |= ssig[b][w];
+        spos[a].insert(spos[a].end(), spos[b].begin(), spos[b].end());
+        ssig.erase(ssig.begin() + b), spos.erase(spos.begin() + b);
+      };
+      long long pool = -1; // the small segments together
+      for (size_t i = 0; i < spos.size();) {
+        if ((int)spos[i].size() >= minseg) { i++; continue; }
+        if (pool < 0) pool = (long long)i++;
+        else join((size_t)pool, i);
+      }
+      auto cost = [&](const std::vector<unsigned long long> &sig, size_t npos) { // chunks x column tiles over the (group, row tile) pairs
+        long long tiles = 0;
+        for (int gr = 0; gr < C.ngroups; gr++)
+          for (int mt = 0; mt < ntile; mt++) {
+            int n = 0;
+            for (int w = 0; w < cw; w++) n += __builtin_popcountll(need[((size_t)gr * ntile + mt) * cw + w] & sig[(size_t)gr * cw + w]);
+            tiles += (n + FXO_TN - 1) / FXO_TN;
+          }
+        return (long long)((npos + FXO_TK - 1) / FXO_TK) * tiles;
+      };
+      for (;;) { // greedy: the pair whose union saves most (>= 0: equal cost still gives fewer, longer units)
+        long long best = -1;
+        size_t    ba = 0, bb = 0;
+        std::vector<unsigned long long> un(sw);
+        for (size_t a2 = 0; a2 < spos.size(); a2++)
+          for (size_t b2 = a2 + 1; b2 < spos.size(); b2++) {
+            for (size_t w = 0; w < sw; w++) un[w] = ssig[a2][w] | ssig[b2][w];
+            const long long save = cost(ssig[a2], spos[a2].size()) + cost(ssig[b2], spos[b2].size()) - cost(un, spos[a2].size() + spos[b2].size());
+            if (save > best) best = save, ba = a2, bb = b2;
+          }
+        if (best < 0) break;
+        join(ba, bb);
+      }
+      for (auto &v : spos) std::sort(v.begin(), v.end());
+      std::vector<size_t> order(spos.size());
+      for (size_t i = 0; i < order.size(); i++) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return spos[x].size() != spos[y].size() ? spos[x].size() > spos[y].size() : spos[x][0] < spos[y][0]; }); // the long segments first
+      std::vector<std::vector<unsigned long long>> s2;
+      std::vector<std::vector<int>>                p2;
+      for (size_t i : order) s2.push_back(ssig[i]), p2.push_back(spos[i]);
+      ssig.swap(s2), spos.swap(p2);
+    } else {
+      ssig.emplace_back(sw, ~0ULL), spos.emplace_back((size_t)C.nc);
+      for (int cc = 0; cc < C.nc; cc++) spos[0][cc] = cc;
+    }
+    C.nseg = (int)spos.size();
+    std::vector<int> segc0((size_t)C.nseg + 1, 0); // first chunk of every segment
+    C.kinv.assign((size_t)C.nc, 0);
+    for (int sg = 0; sg < C.nseg; sg++) {
+      for (size_t i = 0; i < spos[sg].size(); i++) C.kinv[spos[sg][i]] = segc0[sg] * FXO_TK + (int)i;
+      segc0[sg + 1] = segc0[sg] + ((int)spos[sg].size() + FXO_TK - 1) / FXO_TK;
+    }
+    C.nkc  = std::max(1, segc0[C.nseg]);
+    C.ldk  = C.nkc * FXO_TK;
+    C.aoff = atot;
+    atot += (long long)C.Mp * C.ldk;
+    // gather indices of B: (position of g c) << 1 | (s_g(c) < 0) at row kinv[c]; padded k and padded operations read the zero row nc of X
+    // (one more row of gather indices, all on the zero row of X: what the padding columns of the lists below read)
+    std::vector<int> gidx((size_t)(C.nsymp + 1) * C.ldk, C.nc << 1);
+    for (int g = 0; g < C.nsym; g++)
+      for (int cc = 0; cc < C.nc; cc++) gidx[(size_t)g * C.ldk + C.kinv[cc]] = (C.h_posmap[(size_t)g * C.nc + cc] << 1) | (C.h_sign[(size_t)g * C.nc + cc] < 0 ? 1 : 0);
+    // the units: (group, row tile, segment) with the columns of the tile's list that are non-zero on the segment; look-up table from the tile's list
+    fxo_plan P;
+    P.segc0 = segc0;
+    for (int gr = 0; gr < C.ngroups; gr++)
+      for (int mt = 0; mt <= ntile; mt++) {
+        fintab[((size_t)gr * (ntile + 1) + mt) * 4 + 3] = (int)P.units.size();
+        if (mt == ntile) break;
+        const int *ft = fintab.data() + ((size_t)gr * (ntile + 1) + mt) * 4;
+        for (int sg = 0; sg < C.nseg; sg++) {
+          fxo_unit U;
+          U.g = gr, U.mt = mt, U.seg = sg, U.coff = (int)coltab.size(), U.lutoff = (int)P.lut.size();
+          int n = 0;
+          for (int j = 0; j < ft[1]; j++) {
+            const int  code = coltab[(size_t)ft[0] + j];
+            const bool in   = code >= 0 && ((ssig[sg][(size_t)gr * cw + code / 64] >> (code % 64)) & 1ULL);
+            P.lut.push_back(in ? n : -1);
+            if (in) coltab.push_back(code), n++;
+          }
+          U.listed = n;
+          while ((coltab.size() - U.coff) % FXO_TN) coltab.push_back(-1);
+          U.nct = (int)coltab.size() - U.coff;
+          P.units.push_back(U);
+        }
+      }
+    P.coltab = coltab, P.fintab = fintab;
+    plan.push_back(P);
     if (C.d_coltab) pmh_free(ctx, C.d_coltab), pmh_free(ctx, C.d_fintab), C.d_coltab = nullptr;
+    if (C.d_kinv) pmh_free(ctx, C.d_kinv), pmh_free(ctx, C.d_lut), C.d_kinv = nullptr;
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max<size_t>(1, coltab.size()), (void **)&C.d_coltab));
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * fintab.size(), (void **)&C.d_fintab));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max<size_t>(1, C.kinv.size()), (void **)&C.d_kinv));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max<size_t>(1, P.lut.size()), (void **)&C.d_lut));
     if (!coltab.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_coltab, coltab.data(), sizeof(int) * coltab.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, C.d_fintab, fintab.data(), sizeof(int) * fintab.size()));
-    h_fintab.push_back(fintab), h_coltab.push_back(coltab), h_rowrep.push_back(rowrep);
+    if (!C.kinv.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_kinv, C.kinv.data(), sizeof(int) * C.kinv.size()));
+    if (!P.lut.empty()) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_lut, P.lut.data(), sizeof(int) * P.lut.size()));
     if (C.d_gidx) pmh_free(ctx, C.d_gidx), pmh_free(ctx, C.d_reppos), pmh_free(ctx, C.d_use);
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * gidx.size(), (void **)&C.d_gidx));
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * reppos.size(), (void **)&C.d_reppos));
@@ -1207,102 +1364,227 @@ static int fxo_prepare(fx_shared *S)
     PMH_HIP(hipMemsetAsync(S->Afund, 0, bytes, ctx->stream));
     S->afund_tot = atot;
   }
-  // GEMM work items: (row tile, column tile of 16 operations, split of the k range) per class and group; the split gives ~2 workgroups per CU
-  long long tiles = 0;
+  // GEMM work items: (unit, column tile, split of the unit's chunks).  Every unit is split so that no workgroup has more than T chunks, T the smallest for which
+  // the class's workgroups still fit ONE round of the 2 resident per CU (measured: 507 workgroups 0.275 ms, 513: 0.34); the k range of a rank (several GPUs) cuts the segments it crosses
+  const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
+  const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
+  const int slots = getenv("PMH_FXO_SLOTS") ? std::max(1, atoi(getenv("PMH_FXO_SLOTS"))) : 2 * ctx->num_cus;
   for (int c = 0; c < S->ncls; c++) {
+    if (tab_of[c] < 0) continue;
+    fxo_plan &P = plan[tab_of[c]];
     const fxs_class &C = S->C[c];
-    if (!C.nc) continue;
-    const int ntile = C.Mp / C.tm;
-    for (int gr = 0; gr < C.ngroups; gr++)
-      for (int mt = 0; mt < ntile; mt++) tiles += h_fintab[tab_of[c]][((size_t)gr * (ntile + 1) + mt) * 3 + 1] / FXO_TN;
+    const int klo = (int)((long long)C.nkc * rank / size), khi = (int)((long long)C.nkc * (rank + 1) / size); // this rank's chunks
+    for (fxo_unit &U : P.units) {
+      U.kc0 = std::max(klo, P.segc0[U.seg]), U.kc1 = std::min(khi, P.segc0[U.seg + 1]);
+      if (U.kc1 <= U.kc0 || !U.listed) U.kc0 = U.kc1 = 0;
+    }
   }
-  int Ssplit = (int)std::max(1LL, 2LL * ctx->num_cus / std::max(1LL, tiles)); // one round of the 2 resident workgroups per CU (measured: 28 splits 0.407 ms, 56: 0.417, 57: 0.50); at least 24 chunks each (below)
-  if (const char *e = getenv("PMH_FXO_SPLIT")) Ssplit = std::max(1, atoi(e));
+  const int fixedS = getenv("PMH_FXO_SPLIT") ? std::max(1, atoi(getenv("PMH_FXO_SPLIT"))) : 0;
   std::vector<int>       items, vnkc(S->ncls, 1), vldk(S->ncls, 16), vncol(S->ncls, 128);
   std::vector<long long> iteml;
+  std::vector<int>       wgfirst; // per class: first item of every workgroup (relative to the class's first item) + the end
   long long              ctot = 0;
   S->flops = 0.0, S->flops_issued = 0.0, S->flops_dense = 0.0, S->bytes = 0.0, S->owned_bytes = 0.0;
   int Smax = 1;
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
-    const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
-    const int klo = (int)((long long)C.nkc * rank / size), khi = (int)((long long)C.nkc * (rank + 1) / size), nk = khi - klo; // this rank's chunks
-    const int ncol = C.nsymp * 8, Sc = std::max(1, std::min(Ssplit, nk / (getenv("PMH_FXO_MINCH") ? atoi(getenv("PMH_FXO_MINCH")) : 8)));
-    Smax = std::max(Smax, Sc);
-    vnkc[c] = C.nkc, vldk[c] = C.ldk, vncol[c] = ncol;
+    fxo_plan &P = plan[tab_of[c]];
+    const int klo = (int)((long long)C.nkc * rank / size), khi = (int)((long long)C.nkc * (rank + 1) / size), nk = khi - klo;
+    vnkc[c] = C.nkc, vldk[c] = C.ldk, vncol[c] = C.nsymp * 8;
     C.coff = ctot;
     const int               ntile = C.Mp / C.tm, Mrows = C.m1 - C.m0;
-    const std::vector<int> &ftab = h_fintab[tab_of[c]], &ctab = h_coltab[tab_of[c]];
-    std::vector<long long>  finbase((size_t)C.ngroups * ntile, 0);
-    double                  prod = 0.0, ctiles = 0.0; // (valid rows) x (listed columns) and rows x padded columns over the class's (group, row tile) pairs
-    C.item_first = (int)(items.size() / 8);
-    struct aset { int g, mt, sp, ntl, nct, coff; long long cbase; }; // one (group, row tile, split): its column tiles read the same chunks of A
-    std::vector<aset> sets;
+    const std::vector<int> &ftab = P.fintab, &ctab = P.coltab;
+    std::vector<long long>  unitbase(P.units.size(), 0);
+    std::vector<int>        unittab(P.units.size() * 4, 0);
+    double                  prod = 0.0, uprod = 0.0, ctiles = 0.0, ptiles = 0.0; // (valid rows) x (listed columns) of the tiles; x chunks of the units; padded tile x chunks; partial tiles
     for (int g = 0; g < C.ngroups; g++)
       for (int mt = 0; mt < ntile; mt++) {
-        const int *ft = ftab.data() + ((size_t)g * (ntile + 1) + mt) * 3;
-        const int  nct = ft[1]; // padded columns of this (group, row tile)
-        finbase[(size_t)g * ntile + mt] = ctot;
-        int listed = 0;
-        for (int j = 0; j < nct; j++) listed += ctab[(size_t)ft[0] + j] >= 0;
-        prod += (double)std::max(0, std::min(Mrows, (mt + 1) * C.tm) - mt * C.tm) * listed, ctiles += (double)C.tm * nct;
-        for (int sp = 0; sp < Sc; sp++) sets.push_back({g, mt, sp, nct / FXO_TN, nct, ft[0], ctot});
-        ctot += (long long)Sc * C.tm * nct;
+        const int *ft = ftab.data() + ((size_t)g * (ntile + 1) + mt) * 4;
+        int        listed = 0;
+        for (int j = 0; j < ft[1]; j++) listed += ctab[(size_t)ft[0] + j] >= 0;
+        prod += (double)std::max(0, std::min(Mrows, (mt + 1) * C.tm) - mt * C.tm) * listed;
       }
+    C.item_first = (int)(items.size() / 8);
+    // Pieces: the units with the same number of column tiles form one sequence of chunks (unit after unit), cut into equal pieces of at most T chunks -- T the smallest for
+    // which the class's workgroups (one per piece and column tile) still fit ONE round of the 2 resident per CU (measured: 507 workgroups 0.275 ms, 513: 0.34).  A piece may end
+    // one unit and begin the next (two items for its workgroups, two partial tiles): the kernel is bound by the latency of a workgroup's own chunk loop, so what counts is
+    // the LONGEST workgroup, and unit-aligned splits (PMH_FXO_NO_STREAMK=1, or PMH_FXO_SPLIT) leave it at 48 chunks where the mean is 41.  Cuts closer than `snap`
+    // chunks to a unit's end move there.
+    struct part { int u, k0, k1, sp; };
+    struct piece { int ntl; std::vector<part> parts; };
+    std::vector<piece> pieces;
+    int                Tbest = 1, wmax = 0;
+    const bool         aligned = fixedS || getenv("PMH_FXO_NO_STREAMK");
+    for (fxo_unit &U : P.units) U.S = 0;
+    int ntlmax = 0;
+    for (const fxo_unit &U : P.units) ntlmax = std::max(ntlmax, U.nct / FXO_TN);
+    if (aligned) {
+      auto wgs = [&](int T) {
+        long long n = 0;
+        for (const fxo_unit &U : P.units) {
+          const int nku = U.kc1 - U.kc0;
+          if (nku > 0) n += (long long)(U.nct / FXO_TN) * std::max(1, std::min((nku + T - 1) / T, std::max(1, nku / minch)));
+        }
+        return n;
+      };
+      int lo = 1, hi = 1;
+      for (const fxo_unit &U : P.units) hi = std::max(hi, U.kc1 - U.kc0);
+      while (lo < hi) { // wgs does not grow with T
+        const int mid = (lo + hi) / 2;
+        if (wgs(mid) <= slots) hi = mid;
+        else lo = mid + 1;
+      }
+      Tbest = lo;
+      for (size_t ui = 0; ui < P.units.size(); ui++) {
+        fxo_unit &U  = P.units[ui];
+        const int nku = U.kc1 - U.kc0;
+        U.S          = nku > 0 ? std::max(1, std::min(fixedS ? fixedS : (nku + Tbest - 1) / Tbest, std::max(1, nku / minch))) : 0;
+        for (int sp = 0; sp < U.S; sp++) pieces.push_back({U.nct / FXO_TN, {{(int)ui, U.kc0 + (int)((long long)nku * sp / U.S), U.kc0 + (int)((long long)nku * (sp + 1) / U.S), sp}}});
+      }
+    } else {
+      std::vector<std::vector<int>> seq((size_t)ntlmax + 1); // units by column tile count, in unit order (group, row tile, segment)
+      std::vector<long long>        N((size_t)ntlmax + 1, 0);
+      for (size_t ui = 0; ui < P.units.size(); ui++)
+        if (P.units[ui].kc1 > P.units[ui].kc0) seq[P.units[ui].nct / FXO_TN].push_back((int)ui), N[P.units[ui].nct / FXO_TN] += P.units[ui].kc1 - P.units[ui].kc0;
+      auto wgs = [&](long long T) {
+        long long n = 0;
+        for (int k = 1; k <= ntlmax; k++) n += (long long)k * ((N[k] + T - 1) / T);
+        return n;
+      };
+      long long lo = 1, hi = 1;
+      for (int k = 1; k <= ntlmax; k++) hi = std::max(hi, N[k]);
+      while (lo < hi) {
+        const long long mid = (lo + hi) / 2;
+        if (wgs(mid) <= slots) hi = mid;
+        else lo = mid + 1;
+      }
+      Tbest = (int)lo;
+      const int snap = std::max(0, std::min(minch / 4, Tbest / 8));
+      for (int k = ntlmax; k >= 1; k--) {
+        if (!N[k]) continue;
+        const long long W = (N[k] + Tbest - 1) / Tbest;
+        std::vector<long long> ends; // prefix sums: the units' ends in the sequence
+        long long              acc = 0;
+        for (int ui : seq[k]) acc += P.units[ui].kc1 - P.units[ui].kc0, ends.push_back(acc);
+        std::vector<long long> cut((size_t)W + 1, 0);
+        for (long long i = 1; i < W; i++) {
+          long long cpos = N[k] * i / W;
+          auto      itb  = std::lower_bound(ends.begin(), ends.end(), cpos);
+          if (itb != ends.end() && *itb - cpos <= snap) cpos = *itb;
+          else if (itb != ends.begin() && cpos - *(itb - 1) <= snap) cpos = *(itb - 1);
+          cut[i] = std::max(cut[i - 1], cpos);
+        }
+        cut[W] = N[k];
+        size_t    iu = 0;
+        long long ubeg = 0; // start of unit seq[k][iu] in the sequence
+        for (long long i = 0; i < W; i++) {
+          if (cut[i + 1] <= cut[i]) continue;
+          piece pc{k, {}};
+          long long pos = cut[i];
+          while (pos < cut[i + 1]) {
+            while (ends[iu] <= pos) ubeg = ends[iu], iu++;
+            fxo_unit       &U   = P.units[seq[k][iu]];
+            const long long upto = std::min(cut[i + 1], ends[iu]);
+            pc.parts.push_back({seq[k][iu], U.kc0 + (int)(pos - ubeg), U.kc0 + (int)(upto - ubeg), U.S++});
+            pos = upto;
+          }
+          pieces.push_back(pc);
+        }
+      }
+    }
+    for (size_t ui = 0; ui < P.units.size(); ui++) {
+      fxo_unit &U  = P.units[ui];
+      const int nku = U.kc1 - U.kc0;
+      U.cbase      = ctot;
+      unitbase[ui] = ctot;
+      unittab[4 * ui] = U.lutoff, unittab[4 * ui + 1] = U.nct, unittab[4 * ui + 2] = U.S;
+      Smax = std::max(Smax, U.S);
+      ctot += (long long)U.S * C.tm * U.nct;
+      const double rows = (double)std::max(0, std::min(Mrows, (U.mt + 1) * C.tm) - U.mt * C.tm);
+      uprod += rows * U.listed * nku * FXO_TK, ctiles += (double)C.tm * U.nct * nku * FXO_TK, ptiles += (double)U.S * C.tm * U.nct;
+    }
+    int nitem2 = 0; // workgroups with more than one item
     {
-      // The column tiles of one (row tile, split) read the SAME chunks of A at the same pace.  Workgroups b and b + 8 run on one XCD (one L2: MI355X_MICROARCH.md, workgroup
-      // dispatch; scripts/micro/census.hip), so the items go out 8 sets at a time, column tile after column tile: the nt-th tile of a set sits 8 nt items after its first one and
-      // finds the chunk in the XCD's L2 instead of fetching it again from beyond (with default-policy loads of A: scripts/micro/orbit_gemm.hip -DAPLAIN, OG_MAP=2: -8 % per GEMM).
-      // The partial sums stay indexed by (tile, split): the order of the items changes nothing in the result.  PMH_FXO_NO_XCDMAP=1: column tile after column tile, all splits each.
+      // The column tiles of one piece read the SAME chunks of A at the same pace.  Workgroups b and b + 8 run on one XCD (one L2: MI355X_MICROARCH.md, workgroup
+      // dispatch; scripts/micro/census.hip), so the workgroups go out 8 pieces at a time, column tile after column tile: the nt-th tile of a piece sits 8 nt workgroups after its
+      // first one and finds the chunk in the XCD's L2 instead of fetching it again from beyond (with default-policy loads of A: scripts/micro/orbit_gemm.hip -DAPLAIN, OG_MAP=2:
+      // -8 % per GEMM).  The pieces are grouped by their number of column tiles, so that the groups of 8 are uniform.  The partial sums stay indexed by (unit, split): the order of
+      // the workgroups changes nothing in the result.  PMH_FXO_NO_XCDMAP=1: piece after piece, all column tiles each.
       static const bool xcdmap = !getenv("PMH_FXO_NO_XCDMAP");
-      auto emit = [&](const aset &a, int nt) {
-        items.insert(items.end(), {c, a.g, a.mt, nt, klo + (int)((long long)nk * a.sp / Sc), klo + (int)((long long)nk * (a.sp + 1) / Sc), a.sp, a.nct});
-        iteml.push_back(C.aoff);
-        iteml.push_back(C.xoff + (long long)a.g * C.ld * FXS_S);
-        iteml.push_back(a.cbase + (long long)a.sp * C.tm * a.nct);
-        iteml.push_back((long long)a.coff + (long long)nt * FXO_TN);
+      C.wgf_first = (int)wgfirst.size();
+      auto emit = [&](const piece &pc, int nt) {
+        wgfirst.push_back((int)(items.size() / 8) - C.item_first);
+        int len = 0;
+        for (const part &a : pc.parts) {
+          const fxo_unit &U = P.units[a.u];
+          items.insert(items.end(), {c, U.g, U.mt, nt, a.k0, a.k1, a.sp, U.nct});
+          iteml.push_back(C.aoff);
+          iteml.push_back(C.xoff + (long long)U.g * C.ld * FXS_S);
+          iteml.push_back(U.cbase + (long long)a.sp * C.tm * U.nct);
+          iteml.push_back((long long)U.coff + (long long)nt * FXO_TN);
+          len += a.k1 - a.k0;
+        }
+        wmax = std::max(wmax, len), nitem2 += pc.parts.size() > 1;
       };
       if (xcdmap) {
-        for (size_t s0 = 0; s0 < sets.size(); s0 += 8) {
-          const size_t s1 = std::min(sets.size(), s0 + 8);
+        std::stable_sort(pieces.begin(), pieces.end(), [](const piece &x, const piece &y) { return x.ntl > y.ntl; });
+        for (size_t s0 = 0; s0 < pieces.size(); s0 += 8) {
+          const size_t s1 = std::min(pieces.size(), s0 + 8);
           int          ntmax = 0;
-          for (size_t i = s0; i < s1; i++) ntmax = std::max(ntmax, sets[i].ntl);
+          for (size_t i = s0; i < s1; i++) ntmax = std::max(ntmax, pieces[i].ntl);
           for (int nt = 0; nt < ntmax; nt++)
             for (size_t i = s0; i < s1; i++)
-              if (nt < sets[i].ntl) emit(sets[i], nt);
+              if (nt < pieces[i].ntl) emit(pieces[i], nt);
         }
       } else {
-        for (size_t i = 0; i < sets.size(); i += (size_t)Sc) // the sets of one (group, row tile) are contiguous
-          for (int nt = 0; nt < sets[i].ntl; nt++)
-            for (int sp = 0; sp < Sc; sp++) emit(sets[i + sp], nt);
+        for (const piece &pc : pieces)
+          for (int nt = 0; nt < pc.ntl; nt++) emit(pc, nt);
       }
+      C.wg_count = (int)wgfirst.size() - C.wgf_first;
+      wgfirst.push_back((int)(items.size() / 8) - C.item_first);
     }
     C.item_count = (int)(items.size() / 8) - C.item_first;
     if (getenv("PMH_FXO_VERBOSE")) {
-      fprintf(stderr, "PMH_FX_CLASS_ORBIT class %d: %d representatives in %d row tiles of %d, %d splits, padded columns per (group, row tile):", c, Mrows, ntile, C.tm, Sc);
+      fprintf(stderr, "PMH_FX_CLASS_ORBIT class %d: %d representatives in %d row tiles of %d, %d k segments (chunks:", c, Mrows, ntile, C.tm, C.nseg);
+      for (int sg = 0; sg < C.nseg; sg++) fprintf(stderr, " %d", P.segc0[sg + 1] - P.segc0[sg]);
+      fprintf(stderr, "), %d workgroups (%d with two or more items) of at most %d chunks (limit %d of %d slots); padded columns per (group, row tile): unit by unit /", C.wg_count, nitem2, wmax, Tbest, slots);
       for (int g = 0; g < C.ngroups; g++)
-        for (int mt = 0; mt < ntile; mt++) fprintf(stderr, " %d", ftab[((size_t)g * (ntile + 1) + mt) * 3 + 1]);
-      fprintf(stderr, " (of %d); listed x rows / all = %.3f\n", C.nsym * 8, prod / std::max(1.0, (double)C.ngroups * Mrows * C.nsym * 8));
+        for (int mt = 0; mt < ntile; mt++) {
+          for (const fxo_unit &U : P.units)
+            if (U.g == g && U.mt == mt) fprintf(stderr, " %d", U.kc1 > U.kc0 ? U.nct : 0);
+          fprintf(stderr, " of %d /", ftab[((size_t)g * (ntile + 1) + mt) * 4 + 1]);
+        }
+      fprintf(stderr, " (all: %d); listed x rows / all = %.3f, non-zero k of those = %.3f\n", C.nsym * 8, prod / std::max(1.0, (double)C.ngroups * Mrows * C.nsym * 8),
+              uprod / std::max(1.0, prod * nk * FXO_TK));
     }
-    if (C.d_finbase) pmh_free(ctx, C.d_finbase), C.d_finbase = nullptr;
-    PMH_CHK(pmh_malloc(ctx, sizeof(long long) * std::max<size_t>(1, finbase.size()), (void **)&C.d_finbase));
-    PMH_CHK(pmh_memcpy_h2d(ctx, C.d_finbase, finbase.data(), sizeof(long long) * finbase.size()));
+    if (C.d_finbase) pmh_free(ctx, C.d_finbase), pmh_free(ctx, C.d_unittab), C.d_finbase = nullptr;
+    PMH_CHK(pmh_malloc(ctx, sizeof(long long) * std::max<size_t>(1, unitbase.size()), (void **)&C.d_finbase));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * std::max<size_t>(4, unittab.size()), (void **)&C.d_unittab));
+    if (!unitbase.empty()) {
+      PMH_CHK(pmh_memcpy_h2d(ctx, C.d_finbase, unitbase.data(), sizeof(long long) * unitbase.size()));
+      PMH_CHK(pmh_memcpy_h2d(ctx, C.d_unittab, unittab.data(), sizeof(int) * unittab.size()));
+    }
     const double M = Mrows, share = (double)nk / std::max(1, C.nkc);
-    S->flops += 2.0 * C.nc * share * prod; // the products of the listed columns with the tiles' rows (padding rows and columns not counted)
-    S->flops_issued += 2.0 * C.ldk * share * ctiles, S->flops_dense += (double)C.ngroups * 2.0 * M * C.nc * share * 8.0 * C.nsym;
+    S->flops += 2.0 * C.nc * share * prod; // the products of the listed columns with the tiles' rows over the rank's k range (padding rows and columns not counted; structural zeros of B counted)
+    S->flops_issued += 2.0 * ctiles, S->flops_dense += (double)C.ngroups * 2.0 * M * C.nc * share * 8.0 * C.nsym;
     S->owned_bytes += 8.0 * M * C.nc;
     // this rank's columns of A once + the gathered B + the split partial tiles written and read + Y
-    S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 8.0 * FXS_S * C.nc) + 2.0 * 8.0 * Sc * ctiles;
-    C.nown = Sc; // (re-used: the class's split count)
+    S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 8.0 * FXS_S * C.nc) + 2.0 * 8.0 * ptiles;
+    C.nown = Smax; // (re-used: the class's largest split count)
   }
   S->fxo_S = Smax;
-  S->nwg   = (int)(items.size() / 8);
+  S->nwg = 0;
+  for (const fxs_class &C : S->C) S->nwg += C.wg_count;
   items.insert(items.end(), {0, 0, 0, 0, 0, 0, 0, 0});
   iteml.insert(iteml.end(), {0, 0, 0, 0});
   if (S->d_items) pmh_free(ctx, S->d_items);
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   if (S->d_wg) pmh_free(ctx, S->d_wg);
+  if (S->d_wgfirst) pmh_free(ctx, S->d_wgfirst);
+  wgfirst.push_back(0);
+  PMH_CHK(pmh_malloc(ctx, sizeof(int) * wgfirst.size(), (void **)&S->d_wgfirst));
+  PMH_CHK(pmh_memcpy_h2d(ctx, S->d_wgfirst, wgfirst.data(), sizeof(int) * wgfirst.size()));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * items.size(), (void **)&S->d_items));
   PMH_CHK(pmh_memcpy_h2d(ctx, S->d_items, items.data(), sizeof(int) * items.size()));
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * iteml.size(), (void **)&S->d_wgl));
@@ -1327,11 +1609,11 @@ static int fxo_gemm(fx_shared *S)
   for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array and column lists); configs[2] / [3]: one class
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
-    const int first = C.item_first, count = C.item_count; // the class's items are contiguous
+    const int first = C.item_first, count = C.wg_count; // the class's items are contiguous
     if (!count) continue;
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
-                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart)
+                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first))
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
     case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;
@@ -1342,8 +1624,8 @@ static int fxo_gemm(fx_shared *S)
     }
 #undef FXO_LAUNCH
     if (C.fin_elems > 0)
-      hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, C.nown, (const int *)C.d_fintab,
-                         (const long long *)C.d_finbase, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
+      hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, (const int *)C.d_fintab,
+                         (const int *)C.d_unittab, (const long long *)C.d_finbase, (const int *)C.d_lut, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
                          S->Y);
   }
   PMH_HIP(hipGetLastError());
@@ -1451,7 +1733,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), prow[s]) - C.reps.begin()) - C.m0;
         hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (const int *)C.d_urel,
-                           (const double *)(sol + srs[s]), S->Afund + C.aoff);
+                           (const int *)C.d_kinv, (const double *)(sol + srs[s]), S->Afund + C.aoff);
       } else if (S->sym && C.nsym > 1) {
         const int p = prow[s];
         for (int r : members[slot_class[s]][p]) {
@@ -1498,7 +1780,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int g = C.op_of[r], p = C.rep_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin()) - C.m0;
         nb          = std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK));
-        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const int *)C.d_kinv, (const double *)(sol + srs[s]),
                            (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc), (const double *)(S->Afund + C.aoff), d_out);
       } else
       hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
@@ -1585,8 +1867,10 @@ int fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host
       const double  sp = (double)C.h_sign[(size_t)g * C.nc + p];
       const int     pr = C.reprow[pl]; // the representative's row of A
       const double *ab = T.data() + (size_t)(pr / C.tm) * C.nkc * (FXO_TK * C.tm) + pr % C.tm;
-      for (int cc = 0; cc < C.nc; cc++)
-        row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(cc / FXO_TK) * (FXO_TK * C.tm) + (cc % FXO_TK) * C.tm];
+      for (int cc = 0; cc < C.nc; cc++) {
+        const int k = C.kinv[cc];
+        row[C.h_posmap[(size_t)g * C.nc + cc]] = sp * (double)C.h_sign[(size_t)g * C.nc + cc] * ab[(size_t)(k / FXO_TK) * (FXO_TK * C.tm) + (k % FXO_TK) * C.tm];
+      }
       for (int k = 0; k < n; k++) out_host[(size_t)i * n + k] = row[C.pos[gamma[k] - S->K->rowstart[b]]];
     }
     return PMH_SUCCESS;
