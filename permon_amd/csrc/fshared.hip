@@ -1452,14 +1452,20 @@ static int fxo_prepare(fx_shared *S)
         for (int k = 1; k <= ntlmax; k++) n += (long long)k * ((N[k] + T - 1) / T);
         return n;
       };
-      long long lo = 1, hi = 1;
-      for (int k = 1; k <= ntlmax; k++) hi = std::max(hi, N[k]);
-      while (lo < hi) {
-        const long long mid = (lo + hi) / 2;
-        if (wgs(mid) <= slots) hi = mid;
-        else lo = mid + 1;
-      }
-      Tbest = (int)lo;
+      auto search = [&](int nslots) {
+        long long lo = 1, hi = 1;
+        for (int k = 1; k <= ntlmax; k++) hi = std::max(hi, N[k]);
+        while (lo < hi) {
+          const long long mid = (lo + hi) / 2;
+          if (wgs(mid) <= nslots) hi = mid;
+          else lo = mid + 1;
+        }
+        return (int)lo;
+      };
+      Tbest = search(slots);
+      // short pieces (a rank's 1/8 share of configs[2]: 5 chunks): the launch is prologue / epilogue / partial tiles rather than products, and one workgroup per CU with
+      // pieces twice as long is faster (measured at the 1/8 share: 0.066 -> 0.062 ms per dense apply; 384 slots 0.070, 192: 0.075)
+      if (!getenv("PMH_FXO_SLOTS") && Tbest < 12) Tbest = search(ctx->num_cus);
       const int snap = std::max(0, std::min(minch / 4, Tbest / 8));
       for (int k = ntlmax; k >= 1; k--) {
         if (!N[k]) continue;
@@ -1493,16 +1499,25 @@ static int fxo_prepare(fx_shared *S)
         }
       }
     }
+    // k_fxo_fin walks the units that have partial tiles on this rank only (a rank's share of the k range crosses one to three segments)
+    std::vector<int> before(P.units.size() + 1, 0);
+    unitbase.clear(), unittab.clear();
     for (size_t ui = 0; ui < P.units.size(); ui++) {
       fxo_unit &U  = P.units[ui];
       const int nku = U.kc1 - U.kc0;
+      before[ui]   = (int)unitbase.size();
       U.cbase      = ctot;
-      unitbase[ui] = ctot;
-      unittab[4 * ui] = U.lutoff, unittab[4 * ui + 1] = U.nct, unittab[4 * ui + 2] = U.S;
+      if (U.S > 0) unitbase.push_back(ctot), unittab.insert(unittab.end(), {U.lutoff, U.nct, U.S, 0});
       Smax = std::max(Smax, U.S);
       ctot += (long long)U.S * C.tm * U.nct;
       const double rows = (double)std::max(0, std::min(Mrows, (U.mt + 1) * C.tm) - U.mt * C.tm);
       uprod += rows * U.listed * nku * FXO_TK, ctiles += (double)C.tm * U.nct * nku * FXO_TK, ptiles += (double)U.S * C.tm * U.nct;
+    }
+    before[P.units.size()] = (int)unitbase.size();
+    {
+      std::vector<int> ft2 = P.fintab;
+      for (size_t i = 3; i < ft2.size(); i += 4) ft2[i] = before[(size_t)ft2[i]];
+      PMH_CHK(pmh_memcpy_h2d(ctx, C.d_fintab, ft2.data(), sizeof(int) * ft2.size()));
     }
     int nitem2 = 0; // workgroups with more than one item
     {
