@@ -224,7 +224,7 @@ def run_c2(ctx, a, steps, warmup, cpu=True, whole_solves=False):
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv_ell<MPGP epilogue> (uniformly short rows: slot-major device copy, one thread per row, no LDS staging; k_spmv_stream otherwise): Ap = A p fused with p'Ap, g'p, QPCFeas",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            **dict(zip(("traffic", "traffic_source"), (lambda t: t if t[0] is not None else pmc_lookup("void k_spmv_stream<3,", "r02_pmc_traffic_c2.json"))(pmc_lookup("void k_spmv_ell<3,", "r02_pmc_traffic_c2.json")) if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
+            **dict(zip(("traffic", "traffic_source"), (lambda t: t if t[0] is not None else pmc_lookup("void k_spmv_stream<3,", "r03_pmc_traffic_c2.json"))(pmc_lookup("void k_spmv_ell<3,", "r03_pmc_traffic_c2.json")) if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
             "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
             "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
             "note": "algorithmic bytes are SURVEY 8d's CSR figure (12 B per non-zero: fp64 value + int32 column); the kernel streams a device-private copy of the columns as 16-bit offsets "
@@ -313,7 +313,8 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
         "steps_by_type": {"cg": st.ncg, "expansion": st.nexp, "proportioning": st.nprop, "hessian_mults": st.nmv},
         "setup_seconds": round(t_setup, 1),
         "roofline": {"bound": "hbm", "kernel": "k_svm_xt + k_svm_x (two GEMV passes over X)", "achieved": st.nmv * b_H / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": st.nmv * b_H / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_H,
+                     "frac": st.nmv * b_H / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_H,
+                     **dict(zip(("traffic", "traffic_source"), pmc_lookup(("void k_svm_xt64<", "void k_svm_x64<"), "r03_pmc_traffic_configs4.json", combine="sum") if (N == 5000000 and world == 1) else (None, "not the configuration of the committed PMC pass"))),
                      "note": "achieved = Hessian-apply bytes (2*8*N*d + 40*N per apply, local rows) x applies / WHOLE step time (vector phases included)"},
     }
 
@@ -634,7 +635,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kname = ("k_bsr3<double>: the fp64 K x of the block CG inside K^+ = the FETI dual SpMV (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
                  else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
-        traffic, tsrc = pmc_lookup(kpat, "r02_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        traffic, tsrc = pmc_lookup(kpat, "r03_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
         roof = {"bound": "hbm", "kernel": kname, "achieved": cg_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_GBs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": b_cg, "launches_timed": n_cg, "avg_launch_ms": ms_cg / n_cg if n_cg else None, "timing_stride": stride,
                 "share_of_step_time": (ms_cg * 1e-3) * stride / dt if n_cg else None}
@@ -643,7 +644,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             pk = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
             ppat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[precision]
             # the fine-level instantiations only (tile size 1024; the second level runs the 512 ones)
-            ptraffic, ptsrc = pmc_lookup(ppat, "r02_pmc_traffic_feti_iterative.json", contains=("Li1024E", ", 1024>")) if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
+            ptraffic, ptsrc = pmc_lookup(ppat, "r03_pmc_traffic_feti_iterative.json", contains=("Li1024E", ", 1024>")) if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
             roof["preconditioner"] = {"kernel": "k_bsr3<%s>: fine-level K x of the V-cycle (%s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[precision],
                                       "achieved": pk, "frac": pk / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
                                       "share_of_step_time": (ms_k * 1e-3) * stride / dt if n_k else None, "traffic": ptraffic, "traffic_source": ptsrc}
@@ -674,7 +675,13 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         storage_used = q.explicit_storage
         flops_k = E.apply_flops()
         ppref = {"class_orbit": (("k_fxo_gemm", "void k_fxo_gemm4<"), "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
-        traffic, tsrc = pmc_lookup(ppref, "r02_pmc_traffic_feti_explicit.json", combine="sum") if full_size else (None, "not the configuration of the committed PMC pass")
+        # the committed PMC passes (scripts/gpu_final_r03_b.sh / _c.sh): the headline, the configs[3] block, the general (non-congruent) block
+        pmc_file = None
+        if world == 1 and not a.sim_world:
+            pmc_file = ("r03_pmc_traffic_feti_explicit.json" if full_size else
+                        "r03_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
+                        "r03_pmc_traffic_general.json" if (a.nel == 21 and a.sub == "2,2,2" and not congruent) else None)
+        traffic, tsrc = pmc_lookup(ppref, pmc_file, combine="sum") if pmc_file else (None, "not the configuration of a committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
                                        "(every stored byte read once) and applied to the blocks' vectors together: 8 right-hand sides per pass, both products of a tile (W_IJ X_J and W_IJ' X_I) on the fp64 matrix "
