@@ -385,6 +385,10 @@ int pmh_qpt_feti_chain_destroy(pmh_feti_chain ch);
 /* H = diag(y) X X' diag(y), X: n_local x d row-major in HBM (d <= 256), applied as two GEMV passes; with a
    communicator the samples are sharded by rows and w = X'(y o a) is all-reduced (d doubles) between the passes */
 int pmh_op_create_svm_dual(pmh_ctx ctx, int n_local, int d, const double *X_dev, const double *y_dev, pmh_op *op);
+/* how many times the operator has streamed X since it was created (2 per plain application; inside pmh_mpgp_solve on one GPU with d = 64 the second pass of an
+   application also does the first pass of the next one wherever the MPGP step allows it -- svm.hip, "paired passes" -- so a run of expansion steps costs 2 passes
+   per step instead of 4): what a bandwidth figure for this operator has to be computed from */
+int pmh_op_svm_dual_passes(pmh_op op, long long *passes);
 
 /* ---- QPS SMALXE (src/qps/impls/smalxe/smalxe.c) -------------------------------------------------------- */
 typedef struct {

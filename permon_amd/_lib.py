@@ -214,6 +214,7 @@ _PROTOS = {
     "pmh_qpt_feti_chain_post_solve": [vp, vp, vp, vp, vp],
     "pmh_qpt_feti_chain_destroy": [vp],
     "pmh_op_create_svm_dual": [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
+    "pmh_op_svm_dual_passes": [vp, C.POINTER(C.c_longlong)],
     "pmh_smalxe_default_opts": [C.POINTER(SmalxeOpts)],
     "pmh_smalxe_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(SmalxeOpts), C.POINTER(vp)],
     "pmh_smalxe_destroy": [vp],

@@ -749,7 +749,7 @@ static int solve_unfused(pmh_mpgp s)
 // fused driver (std expansion, fixed step length, no fallback)
 // --------------------------------------------------------------------------------------------------------------------
 // P1: Ap = A p and the three reductions into d_scal/h_scal[S_PAP..S_FEAS]
-static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr)
+static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = false)
 {
   double *g = s->work[3], *p = s->work[4], *Ap = s->work[5];
   if (s->csr) {
@@ -771,6 +771,7 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr)
     pmh_vec_epi e;
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_P1, e.g = g, e.xx = s->x, e.lb = s->lb, e.ub = s->ub, e.partials = s->ctx->d_partials, e.ld = s->ctx->partials_cap, e.prow = 4;
+    e.p_fresh = p_fresh, e.spec_alpha = s->alpha, e.astol = s->o.astol; // (operators that pair their passes: svm.hip)
     const int rc = s->A->mult_epi(p, Ap, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
@@ -811,7 +812,7 @@ static int f_gradient(pmh_mpgp s)
 
 // g = A x - b, the gradient split with p = gf and the partials of its norms (mpgp.c:500-507, :578-580 + :612-615): inside the operator's last kernel where it offers that
 // (the finalising launch then waits for the next P1: fin4_pending), else as three launches + the finalising one
-static int f_gradient_split(pmh_mpgp s, bool defer_finalize)
+static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = false)
 {
   pmh_ctx ctx = s->ctx;
   double *gf = s->work[1], *g = s->work[3], *p = s->work[4];
@@ -819,6 +820,7 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize)
     pmh_vec_epi e;
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_GRAD_SPLIT, e.b = s->b, e.lb = s->lb, e.ub = s->ub, e.astol = s->o.astol, e.gf = gf, e.p = p, e.partials = ctx->d_partials, e.ld = ctx->partials_cap, e.prow = 0;
+    e.x_from_spec = x_from_spec, e.x_out = s->x;
     const int rc = s->A->mult_epi(s->x, g, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
@@ -831,6 +833,7 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize)
     }
     s->epi_ok = 0;
   }
+  if (x_from_spec) return pmh_set_error(PMH_ERR_STATE, "pmh_mpgp: the operator prepared an expansion step and then refused the gradient");
   PMH_CHK(f_gradient(s));
   LAUNCH(k_split_setp, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap);
   return finalize_vec4(s);
@@ -848,11 +851,13 @@ static int solve_fused(pmh_mpgp s)
   const double gamma2 = s->o.gamma * s->o.gamma, astol = s->o.astol;
   int          nmv = 0, ncg = 0, nprop = 0, nexp = 0;
   bool         spec = false; // P1 for the current p already enqueued
+  bool         p_fresh = false; // p is the gf of the last gradient split, untouched (told to operators that pair their passes)
 
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
   if (s->epi_ok < 0) s->epi_ok = (s->csr || s->o.distributed || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it
   PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
+  p_fresh = true;
   nmv++;
   s->step      = ' ';
   s->iteration = 0;
@@ -929,7 +934,7 @@ static int solve_fused(pmh_mpgp s)
 
     if (gcTgc <= gamma2 * gfTgf) { // proportional (mpgp.c:535)
       if (!spec) {
-        PMH_CHK(f_apply_p1(s));
+        PMH_CHK(f_apply_p1(s, nullptr, p_fresh));
         PMH_CHK(pmh_sync(ctx));
       }
       spec = false;
@@ -942,17 +947,21 @@ static int solve_fused(pmh_mpgp s)
         LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
         PMH_CHK(finalize_vec4(s));
         LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p);
+        p_fresh = false;
       } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
         nexp++;
         s->step = 'e';
-        LAUNCH(k_expansion_std, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol);
-        PMH_CHK(f_gradient_split(s, true)); // the speculative P1 below finalises both groups of partial sums
+        const bool prepared = s->epi_ok == 1 && s->A->spec_expansion_ready(); // the operator's P1 pass already formed k_expansion_std's iterate (svm.hip): it hands it over with the gradient
+        if (!prepared) LAUNCH(k_expansion_std, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol);
+        PMH_CHK(f_gradient_split(s, true, prepared)); // the speculative P1 below finalises both groups of partial sums
+        p_fresh = true;
         nmv++;
       }
     } else { // proportioning (mpgp.c:617-639)
       nprop++;
       s->step = 'p';
       spec    = false; // a speculative P1 (if any) used the wrong direction; it is simply not counted
+      p_fresh = false;
       LAUNCH(k_prop_dir, (const double *)x, (const double *)g, s->lb, s->ub, astol, p);
       PMH_CHK(f_apply_p1(s));
       nmv++;
@@ -961,7 +970,7 @@ static int solve_fused(pmh_mpgp s)
     }
     // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p
     if (s->pre_p1) PMH_CHK(s->pre_p1(s->pre_p1_user));
-    PMH_CHK(f_apply_p1(s));
+    PMH_CHK(f_apply_p1(s, nullptr, p_fresh));
     spec = true;
     s->iteration++;
   }

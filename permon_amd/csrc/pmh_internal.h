@@ -122,6 +122,13 @@ struct pmh_vec_epi {
   double       *gf, *p;
   double       *partials;
   int           ld, prow;
+  // pairing of passes for operators that stream a big matrix twice per application (the dense-row SVM Hessian, svm.hip); ignored by the others.
+  // P1: p_fresh = p is still the gf the last PMH_VEPI_GRAD_SPLIT of this operator wrote (nothing touched it since); spec_alpha > 0: the driver will, if the step turns
+  // out to be an expansion (std direction, fixed length alpha), ask for the gradient at exactly k_expansion_std(x, g, p, Ap, afeas, alpha): the operator may prepare it.
+  // GRAD_SPLIT: x_from_spec = the iterate is that prepared expansion (the driver did NOT run k_expansion_std; the operator also writes it to x)
+  int           p_fresh, x_from_spec;
+  double        spec_alpha;
+  double       *x_out;
 };
 struct pmh_op_s {
   pmh_ctx ctx;
@@ -129,6 +136,7 @@ struct pmh_op_s {
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
   virtual int     mult_epi(const double *, double *, const pmh_vec_epi &) { return PMH_EPI_UNSUPPORTED; }
+  virtual int     spec_expansion_ready() { return 0; } // the last PMH_VEPI_P1 prepared the expansion step (pmh_vec_epi::spec_alpha)
   // MatMultTranspose slot; operators that are symmetric by construction forward to mult
   virtual int     mult_transpose(const double *, double *) { return pmh_set_error(PMH_ERR_SUP, "this operator has no MatMultTranspose slot"); }
   virtual pmh_csr as_csr() { return nullptr; }

@@ -521,4 +521,13 @@ def MatCreateSVMDual(ctx, X, y):
     yd = Vec.from_numpy(ctx, y)
     h = C.c_void_p()
     check(ctx.L.pmh_op_create_svm_dual(ctx.h, n, d, Xd.p, yd.p, C.byref(h)))
-    return Op(ctx, h, n, keep=[Xd, yd])
+    op = Op(ctx, h, n, keep=[Xd, yd])
+
+    def passes():
+        """How many times the operator has streamed X so far (pmh_op_svm_dual_passes)."""
+        k = C.c_longlong(0)
+        check(ctx.L.pmh_op_svm_dual_passes(op.h, C.byref(k)))
+        return int(k.value)
+
+    op.passes = passes
+    return op

@@ -60,10 +60,42 @@ def test_svm_mpgp_vs_oracle(oracle):
     ctx.close()
 
 
-def test_distributed_scalar_mode_single_rank_communicator():
+def test_svm_paired_passes_equal_separate_passes(monkeypatch):
+    """svm.hip "paired passes": inside MPGP the second pass over X of one Hessian application also does the first pass of the next one (X'(y o p) while the
+    gradient is formed, X'(y o x+) for the prepared expansion step while Ap is formed).  Against the separate passes (PMH_SVM_NO_PAIRING=1): the same solve --
+    reason, step types within the rounding of the partial sums' order, the same w and objective -- from fewer passes over X."""
+    ctx = pa.Context(0)
+    p = P.svm_dual(6000, 64)
+    X, y = p["X"], p["y"]
+    Hp, st_p, x_p = _solve(ctx, p)
+    monkeypatch.setenv("PMH_SVM_NO_PAIRING", "1")
+    Hs, st_s, x_s = _solve(ctx, p)
+    monkeypatch.delenv("PMH_SVM_NO_PAIRING")
+    assert st_p.reason == st_s.reason == 2
+    assert abs(st_p.iteration - st_s.iteration) <= max(3, st_s.iteration // 6) and st_p.nexp > 0
+    w_p, w_s = X.T @ (y * x_p), X.T @ (y * x_s)
+    assert np.linalg.norm(w_p - w_s) <= 1e-3 * np.linalg.norm(w_s)
+    f = lambda a: 0.5 * np.dot(X.T @ (y * a), X.T @ (y * a)) - a.sum()
+    assert abs(f(x_p) - f(x_s)) <= 1e-6 * abs(f(x_s))
+    astol = 10 * np.finfo(float).eps
+    assert x_p.min() >= -astol and x_p.max() <= 1.0 + astol
+    # separate passes: two per Hessian application; paired: the P1 after every gradient split saves one, an expansion step that follows such a P1 another one
+    # (per counted application; the count also holds the power iterations of the set-up and the P1 passes a proportioning step discards)
+    per_s, per_p = Hs.passes() / st_s.nmv, Hp.passes() / st_p.nmv
+    assert 2.0 <= per_s <= 2.2
+    assert per_p <= per_s - 0.9 * (st_p.nexp - 1) / st_p.nmv, (per_p, per_s, st_p.nexp, st_p.nmv)
+    # a fixed run of steps is reproducible bit for bit (no atomics, fixed orders)
+    _, st_q, x_q = _solve(ctx, p)
+    assert st_q.iteration == st_p.iteration and np.array_equal(x_q, x_p)
+    ctx.close()
+
+
+def test_distributed_scalar_mode_single_rank_communicator(monkeypatch):
     """Row-distributed vectors: every reduction goes through the grouped RCCL all-reduce.  On a 1-rank communicator
-    (PMH_COMM_FORCE keeps the collectives on) the result must equal the local mode bit for bit."""
+    (PMH_COMM_FORCE keeps the collectives on) the result must equal the local mode bit for bit (the local mode on the separate passes the
+    distributed mode takes: the paired passes of svm.hip sum other elements per workgroup)."""
     os.environ["PMH_COMM_FORCE"] = "1"
+    monkeypatch.setenv("PMH_SVM_NO_PAIRING", "1")
     try:
         ctx = pa.Context(0)
         ctx.comm_init(0, 1, ctx.comm_unique_id())
