@@ -321,10 +321,12 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
     x.set(0.0)
     pa._lib.check(ctx.L.pmh_mpgp_reset_statistics(qps.h))
     barrier()
+    passes0 = H.passes()
     t1 = time.perf_counter()
     st = qps.RunFixed(steps)
     barrier()
     dt = time.perf_counter() - t1
+    passes = H.passes() - passes0  # how many times X was streamed in the timed region (pmh_op_svm_dual_passes)
     if dist is not None:
         import torch
 
