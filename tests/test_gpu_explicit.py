@@ -230,6 +230,42 @@ def test_explicit_orbit_row_tiles(ctx, tm, monkeypatch):
         assert np.array_equal(y1.to_numpy(), y2.to_numpy())
 
 
+def test_explicit_orbit_plan_variants(ctx, monkeypatch):
+    """The plan of the orbit GEMM (fxo_prepare): k segments of equal non-zero columns of the gathered operand, units = (row tile, segment) with their own column lists,
+    equal pieces that may end one unit and begin the next (workgroups with several items).  Every variant of the plan -- one segment, unit-aligned splits, every
+    signature its own segment, few long pieces, many short ones -- is the same product: F lambda agrees to rounding with the default plan and with the inner-Krylov K^+."""
+    nel = 12
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True)
+    G, e = f.coarse()
+    nn = nel + 1
+    loc = f.subset(range(f.nsub))
+    lam = np.random.default_rng(21).standard_normal(f.n_lambda)
+    lv = ctx.vec_from(lam)
+
+    def F_lambda(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert q.explicit_storage == "class_orbit"
+        y, y2 = ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+        q.F.mult(lv, y)
+        q.F.mult(lv, y2)
+        assert np.array_equal(y.to_numpy(), y2.to_numpy())  # fixed orders: the same bits from a second apply
+        return y.to_numpy()
+
+    y0 = F_lambda({})
+    q0 = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    yi = ctx.vec(f.n_lambda)
+    q0.F.mult(lv, yi)
+    assert np.linalg.norm(y0 - yi.to_numpy()) <= 1e-9 * np.linalg.norm(y0)
+    for env in ({"PMH_FXO_NO_KSEG": "1"}, {"PMH_FXO_NO_STREAMK": "1"}, {"PMH_FXO_NO_KSEG": "1", "PMH_FXO_NO_STREAMK": "1"}, {"PMH_FXO_SEGMIN": "1"}, {"PMH_FXO_SEGMIN": "1", "PMH_FXO_SLOTS": "4096"},
+                {"PMH_FXO_SLOTS": "48"}, {"PMH_FXO_SLOTS": "4096", "PMH_FXO_MINCH": "1"}, {"PMH_FXO_SPLIT": "3"}, {"PMH_FXO_NO_PRUNE": "1"}):
+        y = F_lambda(env)
+        assert np.linalg.norm(y - y0) <= 1e-13 * np.linalg.norm(y0), env
+
+
 @pytest.mark.parametrize("nel", [3, 7, 11, 13])
 def test_explicit_orbit_sizes_against_iterative_kplus(ctx, nel):
     """Odd sizes (row / k / column remainders of the orbit GEMM's tiles; scripts/orbit_size_sweep.py runs more of them): F through the orbit storage equals F
