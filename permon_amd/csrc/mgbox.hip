@@ -355,10 +355,22 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
       int              dc[3];
       std::vector<int> c2f;
       Level           &F = C.L.back();
+      stage("  (class) level copy / injected kernel");
       F.P                = prolongation(d, ndof, dc, c2f);
+      stage("  (class) prolongation");
       F.lam              = lambda_max_dinv_a(F.A, 20);
+      stage("  (class) lambda_max, 20 products");
       Level Cn;
-      Cn.A = symmetrize(spgemm(transpose(F.P), spgemm(F.A, F.P)));
+      {
+        const HCsr AP = spgemm(F.A, F.P);
+        stage("  (class) A P");
+        const HCsr Pt = transpose(F.P);
+        stage("  (class) P'");
+        const HCsr G2 = spgemm(Pt, AP);
+        stage("  (class) P' (A P)");
+        Cn.A = symmetrize(G2);
+        stage("  (class) symmetrise");
+      }
       const int nc = Cn.A.nr, nf = F.A.nr;
       Cn.R.resize((size_t)C.kd * nc);
       for (int k = 0; k < C.kd; k++)
