@@ -60,12 +60,13 @@ def test_svm_mpgp_vs_oracle(oracle):
     ctx.close()
 
 
-def test_svm_paired_passes_equal_separate_passes(monkeypatch):
+@pytest.mark.parametrize("N", [6000, 4003, 777])
+def test_svm_paired_passes_equal_separate_passes(monkeypatch, N):
     """svm.hip "paired passes": inside MPGP the second pass over X of one Hessian application also does the first pass of the next one (X'(y o p) while the
     gradient is formed, X'(y o x+) for the prepared expansion step while Ap is formed).  Against the separate passes (PMH_SVM_NO_PAIRING=1): the same solve --
     reason, step types within the rounding of the partial sums' order, the same w and objective -- from fewer passes over X."""
     ctx = pa.Context(0)
-    p = P.svm_dual(6000, 64)
+    p = P.svm_dual(N, 64)  # (4003, 777: rows past the last full group of 8 a wave has in flight)
     X, y = p["X"], p["y"]
     Hp, st_p, x_p = _solve(ctx, p)
     monkeypatch.setenv("PMH_SVM_NO_PAIRING", "1")
