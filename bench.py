@@ -795,6 +795,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             kx = {"bound": "hbm", "kernel": "k_bsr3<double>: y = K x of the block-wise CG inside K^+ (3x3 blocks, 8.44 B per non-zero; the set-up solves of the explicit operators and the inner-Krylov path run on it)",
                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_x, "launches_timed": n_x, "avg_launch_ms": ms_x / n_x,
                   "matrix_copies_on_device": 1 if congruent else per,
+                  # what HBM has to deliver when the copies are shared: the matrix once + the vectors (the rest of the algorithmic figure is served by the XCDs' L2)
+                  **({"hbm_streamed_bytes": (b_x - 16.0 * local["n_x"]) / per + 16.0 * local["n_x"], "frac_streamed": ((b_x - 16.0 * local["n_x"]) / per + 16.0 * local["n_x"]) / (ms_x / n_x * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                     if congruent and per > 1 else {}),
                   "note": ("the %d congruent blocks share ONE device copy of K_i (pmh_bsr3_from_csr compares them entry by entry): the replicas of a tile run back to back on one XCD and read the tile from its L2, so the "
                            "algorithmic bytes of the block-diagonal product (SURVEY 8d: every K_i once) are NOT all streamed from HBM -- a rate above the 8 TB/s peak means exactly that; the HBM-streaming form of the same "
                            "kernel is the `general` block's (one copy per block: 0.65-0.70 of the peak)" % per) if congruent and per > 1 else
@@ -807,6 +810,34 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     st_full = qps_full.Solve()
     ctx.sync()
     t_solve = time.perf_counter() - t1
+    # the same solve and the same throughput window with the EXTENSION pmh_smalxe_set_reuse_products (off in everything above: the headline keeps the reference's
+    # operation sequence): A_rho u carried from the inner solve's last gradient, two operator applications less per outer iteration
+    reuse = None
+    if a.kplus == "explicit" and world == 1 and not a.sim_world:
+        lam_ref = q.lam.to_numpy().copy()
+        q.lam.set(0.0)
+        qps_r = q.make_smalxe()
+        qps_r.SMALXESetReuseProducts(True)
+        ctx.sync()
+        t1 = time.perf_counter()
+        st_r = qps_r.Solve()
+        ctx.sync()
+        t_r = time.perf_counter() - t1
+        lam_r = q.lam.to_numpy().copy()
+        if warmup:
+            qps_r.RunFixedSolve(warmup)
+        ctx.sync()
+        t1 = time.perf_counter()
+        cnt_r = qps_r.RunFixedSolve(steps)
+        ctx.sync()
+        dt_r = time.perf_counter() - t1
+        reuse = {"what": "EXTENSION, not the reference's operation sequence (off in the headline): pmh_smalxe_set_reuse_products carries A_rho u from the last gradient of an inner solve into the Lagrangian "
+                         "(QPComputeObjective's own product, smalxe.c:982) and into the next inner solve's first gradient (mpgp.c:500): g' = g + rho B'B u",
+                 "value": steps / dt_r, "unit": "QPS iterations/s", "ms_per_step": dt_r / steps * 1e3, "steps": steps, "warmup": warmup, "steps_by_type": cnt_r,
+                 "full_solve": {"solve_seconds": t_r, "outer_iterations": int(st_r.iteration), "inner_iterations": int(st_r.inner_iter_accu), "hessian_mults": int(st_r.inner.nmv), "reason": int(st_r.reason)},
+                 "reference_sequence": {"solve_seconds": t_solve, "outer_iterations": int(st_full.iteration), "inner_iterations": int(st_full.inner_iter_accu), "hessian_mults": int(st_full.inner.nmv)},
+                 "rel_diff_lambda": float(np.linalg.norm(lam_r - lam_ref) / max(np.linalg.norm(lam_ref), 1e-300))}
+        q.lam.set_numpy(lam_ref)  # (the checksum below is of the reference-sequence solve)
     full_solve = {"solve_seconds": t_solve, "outer_iterations": int(st_full.iteration), "inner_iterations": int(st_full.inner_iter_accu), "reason": int(st_full.reason),
                   "setup_seconds": round(t_setup, 2), "time_to_solution_seconds": round(t_setup + t_solve, 3),
                   "note": "set-up = everything between the generated problem and the first solver iteration as bench.py orchestrates it (uploads, 3x3-block copies, multigrid hierarchy, explicit operators by K^+ solves, "
@@ -829,7 +860,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
                                       "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": "implicit: T G0 with T = chol(G0 G0')^{-1} applied in the finishing launch of G0 v, G0 kept sparse (%d non-zeros)" % G.nnz if implicit else True},
-        "roofline": roofline, "feti_dual_spmv": kx,
+        "roofline": roofline, "feti_dual_spmv": kx, "reuse_products": reuse,
     }
     res.update(extra)
     return res, f, G, hier, q.b.to_numpy(), q.lb_new.to_numpy()  # (the CPU baseline leg re-uses the generated problem)
@@ -914,6 +945,8 @@ def main():
         out["time_to_solution_s"] = r["full_solve"]["time_to_solution_seconds"]
         out["full_solve"] = r["full_solve"]
         out["feti_dual_spmv"] = r["feti_dual_spmv"]
+        if r.get("reuse_products"):
+            out["reuse_products"] = r["reuse_products"]
         for k in ("iterative", "strict_fp64"):
             if k in r:
                 out[k] = r[k]

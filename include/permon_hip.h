@@ -424,6 +424,11 @@ int pmh_smalxe_default_opts(pmh_smalxe_opts *o);
 int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double *u, const double *lb, const double *ub, pmh_qppf pf, const pmh_smalxe_opts *o, pmh_smalxe *s);
 int pmh_smalxe_destroy(pmh_smalxe s);
 int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve_SMALXE smalxe.c:893-997 */
+/* Extension, off by default: carry A_rho u from the last gradient of an inner solve into the Lagrangian (smalxe.c:982 forms it by QPComputeObjective's own MatMult)
+   and into the first gradient of the next inner solve (mpgp.c:500 starts every solve with MatMult) -- g' = g + rho_new B'B u, B'B u being at hand for the multiplier
+   update: two operator applications less per outer iteration, the same iterates up to the rounding of g's recurrence over the CG steps of the inner solve.  The
+   number of Hessian multiplications reported then differs from the reference's for the same solve. */
+int pmh_smalxe_set_reuse_products(pmh_smalxe s, int on);
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
 /* throughput mode for bench.py: the real solver loop for exactly `inner_iters` inner MPGP iterations in total (a solve that
    converges earlier restarts from u = 0; counts accumulate over the restarts) */

@@ -219,6 +219,7 @@ _PROTOS = {
     "pmh_smalxe_create": [vp, vp, vp, vp, vp, vp, vp, C.POINTER(SmalxeOpts), C.POINTER(vp)],
     "pmh_smalxe_destroy": [vp],
     "pmh_smalxe_solve": [vp],
+    "pmh_smalxe_set_reuse_products": [vp, C.c_int],
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_smalxe_run_fixed": [vp, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],

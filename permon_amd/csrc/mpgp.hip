@@ -52,6 +52,7 @@ struct pmh_mpgp_s {
   void *pre_test_user;
   int (*pre_p1)(void *);   // optional: called right before the speculative Ap = A p of the NEXT iteration is enqueued (the iterate is final then): SMALXE lets its ||B u|| ride on that product
   void *pre_p1_user;
+  int   g_valid;           // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
   int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
   int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
   void            *cvg_user;
@@ -358,7 +359,7 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->cvg = nullptr, s->cvg_user = nullptr, s->cvg_setup = 0;
   s->pre_test = nullptr, s->pre_test_user = nullptr;
   s->pre_p1 = nullptr, s->pre_p1_user = nullptr;
-  s->epi_ok = -1, s->fin4_pending = 0;
+  s->epi_ok = -1, s->fin4_pending = 0, s->g_valid = 0;
   s->norm_rhs = s->ttol = s->norm_rhs_div = 0.0;
   s->rnorm = s->gfnorm = s->gcnorm = 0.0;
   s->iteration = 0, s->reason = 0;
@@ -624,6 +625,7 @@ static int u_objective_from_gradient(pmh_mpgp s, const double *x, const double *
 
 static int solve_unfused(pmh_mpgp s)
 {
+  s->g_valid  = 0; // (this driver always forms its own gradient)
   pmh_ctx ctx = s->ctx;
   int     n   = s->n;
   int     nw  = 7;
@@ -856,9 +858,15 @@ static int solve_fused(pmh_mpgp s)
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
   if (s->epi_ok < 0) s->epi_ok = (s->csr || s->o.distributed || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it
-  PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
+  if (s->g_valid) { // the caller carried g = A x - b over from the previous solve (pmh_smalxe_set_reuse_products): the split, p = gf and the norms only
+    s->g_valid = 0;
+    LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap);
+    PMH_CHK(finalize_vec4(s));
+  } else {
+    PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
+    nmv++;
+  }
   p_fresh = true;
-  nmv++;
   s->step      = ' ';
   s->iteration = 0;
   pmh_spec_args nosa;
@@ -1027,6 +1035,15 @@ extern "C" int pmh_mpgp_get_trace(pmh_mpgp s, int cap, char *step, double *gp, d
 
 // work[0..6] = gP, gf, gc, g, p, Ap, gr (mpgp.c:6-17).  The fused driver does not keep gP, gc, gr:
 // they are recomputed here from the final x, g (MPGPGrads) so that callers see the reference's work vectors.
+// internal (smalxe.hip): the next pmh_mpgp_solve may take work[3] as the gradient at its starting point (fused driver only; others ignore it)
+int pmh_mpgp_set_gradient_valid(pmh_mpgp s, int valid, double **g)
+{
+  PMH_ARG(s);
+  s->g_valid = (valid && use_fused(s) && s->work[3]) ? 1 : 0;
+  if (g) *g = s->work[3];
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_mpgp_get_work(pmh_mpgp s, int idx, const double **dptr)
 {
   PMH_ARG(s && dptr && idx >= 0 && idx < 10);

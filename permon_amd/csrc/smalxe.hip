@@ -40,6 +40,8 @@ struct pmh_smalxe_s {
   int    lag_II, lag_J, lag_neval, lag_niter;
   // throughput mode (pmh_smalxe_run_fixed): budget of inner iterations left, -1 = off
   long long fixed_left;
+  // pmh_smalxe_set_reuse_products: A_rho u is carried from the inner solve's last gradient into the Lagrangian and into the next inner solve's first gradient
+  int reuse;
 };
 
 // QPSCreate_SMALXE defaults smalxe.c:1159-1207
@@ -262,6 +264,7 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   s->state  = 1;
   s->normBu = s->normBu_old = s->enorm = NAN;
   s->fixed_left = -1;
+  s->reuse      = 0;
   const int n = s->n;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->BtBu));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->Btmu));
@@ -304,6 +307,16 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   PMH_CHK(pmh_mpgp_set_pre_test_hook(s->inner, prefetch_normBu, s));
   PMH_CHK(pmh_mpgp_set_pre_p1_hook(s->inner, arm_normBu, s));
   *out = s;
+  return PMH_SUCCESS;
+}
+
+// Extension (off by default; the reference forms both quantities by a product of their own, smalxe.c:982 QPComputeObjective and mpgp.c:500 at the start of
+// every inner solve): carry A_rho u from the last gradient of the inner solve -- two operator applications less per outer iteration, the same numbers up to the rounding
+// of g's recurrence over the inner CG steps.  The count of Hessian multiplications then differs from the reference's.
+extern "C" int pmh_smalxe_set_reuse_products(pmh_smalxe s, int on)
+{
+  PMH_ARG(s);
+  s->reuse = on ? 1 : 0;
   return PMH_SUCCESS;
 }
 
@@ -394,6 +407,14 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     PMH_CHK(pmh_vec_norm2(ctx, n, s->b_inner, &s->outer_norm_rhs_div));
     PMH_CHK(pmh_mpgp_set_tolerances(s->inner, s->o.inner.rtol, s->o.inner.atol, s->o.divtol, s->inner_max_it));
     s->normBu_prefetched = 0;
+    if (s->reuse && i > 0) {
+      // the inner solver still holds g = A_rho u - b_inner of the solve that just ended.  Since then b_inner lost rho_old B'B u (the multiplier update above) and A_rho
+      // gained (rho_new - rho_old) B'B (smalxe_update): the gradient the next solve starts from is g + rho_new B'B u, with B'B u = BtBu already at hand -- no product with F
+      double  rho_now, *g = nullptr;
+      PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho_now));
+      PMH_CHK(pmh_mpgp_set_gradient_valid(s->inner, 1, &g));
+      if (g) PMH_CHK(pmh_vec_axpy(ctx, n, g, rho_now, s->BtBu));
+    }
     PMH_CHK(pmh_mpgp_solve(s->inner));
     pmh_mpgp_stats st;
     PMH_CHK(pmh_mpgp_get_stats(s->inner, &st));
@@ -409,6 +430,14 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     }
     PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
     PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
+    if (s->reuse) { // f = -u'(b_inner - 1/2 A_rho u) with A_rho u = g + b_inner: -1/2 u'(b_inner - g)
+      double *g = nullptr, dot;
+      PMH_CHK(pmh_mpgp_set_gradient_valid(s->inner, 0, &g));
+      PMH_ARG(g);
+      PMH_CHK(pmh_vec_waxpy(ctx, n, s->xwork, -1.0, g, s->b_inner));
+      PMH_CHK(pmh_vec_dot(ctx, n, s->u, s->xwork, &dot));
+      Lag = -0.5 * dot;
+    } else
     PMH_CHK(objective(s, &Lag));
     PMH_CHK(smalxe_update(s, Lag_old, Lag, rho));
     Lag_old       = Lag;

@@ -178,6 +178,14 @@ class QPS:
         """x, b, lb, ub are row-distributed over the communicator's ranks (PETSc MPI Vec layout)."""
         self._mo().distributed = int(flag)
 
+    def SMALXESetReuseProducts(self, flag=True):
+        """Extension (pmh_smalxe_set_reuse_products, off by default): A_rho u carried from the inner solve's last gradient -- two operator applications less
+        per outer iteration than the reference's sequence.  Call after SetUp."""
+        if self.type != "smalxe":
+            raise ValueError("SMALXESetReuseProducts is for QPS of type smalxe")
+        self.SetUp()
+        check(self.L.pmh_smalxe_set_reuse_products(self.h, int(bool(flag))))
+
     def MonitorSet(self, flag=True):  # QPSMonitorSet(qps, QPSMonitorDefault, ...)
         self._mo().monitor = int(flag)
 

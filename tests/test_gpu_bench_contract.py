@@ -47,6 +47,10 @@ def test_default_workload_line_small():
     # what makes windows of different length comparable, at the top level
     assert d["applies_per_step"] > 1.0 and d["ms_per_operator_apply"] > 0 and d["time_to_solution_s"] > 0
     assert d["full_solve"]["reason"] > 0 and d["full_solve"]["inner_iterations"] > 0
+    # the opt-in extension (A_rho u carried between the inner solve and the outer update) beside the reference's operation sequence: same iterations, fewer products
+    rp = d["reuse_products"]
+    assert rp["value"] > 0 and rp["rel_diff_lambda"] <= 1e-9 and rp["full_solve"]["inner_iterations"] == rp["reference_sequence"]["inner_iterations"], rp
+    assert rp["full_solve"]["hessian_mults"] < rp["reference_sequence"]["hessian_mults"] and "EXTENSION" in rp["what"], rp
     c1 = d["configs1"]
     assert ROOF <= set(c1["roofline"]) and c1["value"] > 0 and c1["cpu_baseline"]["value"] > 0, c1
     assert "whole solve" in c1["timed"] and c1["steps_by_type"]["cg"] + c1["steps_by_type"]["expansion"] + c1["steps_by_type"]["proportioning"] == c1["steps"]

@@ -139,3 +139,26 @@ def test_fused_projector_epilogues_are_bit_identical(ctx, problem, monkeypatch):
     q.F.mult(ctx.vec_from(P(x)), Fx)
     ref = 3.25 * (Gd.T @ (Gd @ x)) + P(Fx.to_numpy())
     assert np.linalg.norm(y1.to_numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("nel", [3, 9])
+def test_smalxe_reuse_products_extension(ctx, nel):
+    """pmh_smalxe_set_reuse_products (an EXTENSION, off by default): A_rho u is carried from the last gradient of an inner solve into the Lagrangian and into the first
+    gradient of the next inner solve (g' = g + rho B'B u) instead of two products of their own (smalxe.c:982, mpgp.c:500).  The same outer / inner iterations and step
+    types, the same solution to rounding, two Hessian multiplications less per outer iteration after the first."""
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    q = FetiDualQP(ctx, f.subset(range(f.nsub)), G, e, f.c, f.lb, orthonormal=True, kplus_rtol=1e-13, explicit=dict(rtol=1e-13))
+    res = []
+    for reuse in (False, True):
+        q.lam.set(0.0)
+        qps = q.make_smalxe(rtol=1e-6)
+        if reuse:
+            qps.SMALXESetReuseProducts(True)
+        st = qps.Solve()
+        res.append((st, q.dual_solution()))
+    (s0, l0), (s1, l1) = res
+    assert s0.reason == s1.reason == 2
+    assert (s0.iteration, s0.inner_iter_accu, s0.inner.ncg, s0.inner.nexp, s0.inner.nprop) == (s1.iteration, s1.inner_iter_accu, s1.inner.ncg, s1.inner.nexp, s1.inner.nprop)
+    assert np.linalg.norm(l1 - l0) <= 1e-9 * np.linalg.norm(l0)
+    assert s1.inner.nmv == s0.inner.nmv - (s0.iteration - 1)  # (the Lagrangian's product is not a counted Hessian multiplication of the inner solver: one counted product less per outer iteration)
