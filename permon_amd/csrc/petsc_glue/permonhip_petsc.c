@@ -1695,6 +1695,13 @@ static PetscErrorCode QPSSetUp_SMALXEHIP(QPS qps)
   if (ub) PetscCall(VecHIPGetArrayRead(ub, &ub_d));
   /* eta, maxeig (power method on A), M1, rho, the penalised operator and the inner MPGP with the injected test: smalxe.c:806-875 */
   PMHCall(pmh_smalxe_create(ctx, hip->A, b_d, u_d, lb_d, ub_d, pf, &hip->opts, &hip->solver));
+  {
+    /* -qps_smalxehip_reuse_products: an extension of this back end, off by default (the reference forms A_rho u by a MatMult of its own in QPComputeObjective,
+       smalxe.c:982, and at the start of every inner solve, mpgp.c:500; the library can carry it from the inner solve's last gradient) */
+    PetscBool reuse = PETSC_FALSE;
+    PetscCall(PetscOptionsGetBool(((PetscObject)qps)->options, ((PetscObject)qps)->prefix, "-qps_smalxehip_reuse_products", &reuse, NULL));
+    PMHCall(pmh_smalxe_set_reuse_products(hip->solver, reuse ? 1 : 0));
+  }
   if (ub) PetscCall(VecHIPRestoreArrayRead(ub, &ub_d));
   if (lb) PetscCall(VecHIPRestoreArrayRead(lb, &lb_d));
   PetscCall(VecHIPRestoreArray(u, &u_d));
