@@ -52,6 +52,7 @@ struct pmh_mpgp_s {
   void *pre_test_user;
   int (*pre_p1)(void *);   // optional: called right before the speculative Ap = A p of the NEXT iteration is enqueued (the iterate is final then): SMALXE lets its ||B u|| ride on that product
   void *pre_p1_user;
+  double cvg_margin;       // set by the convergence test: rnorm / (the threshold it has to fall below), 0 = unknown -- how close the NEXT test is to ending the solve
   int   g_valid;           // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
   int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
   int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
@@ -359,7 +360,7 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->cvg = nullptr, s->cvg_user = nullptr, s->cvg_setup = 0;
   s->pre_test = nullptr, s->pre_test_user = nullptr;
   s->pre_p1 = nullptr, s->pre_p1_user = nullptr;
-  s->epi_ok = -1, s->fin4_pending = 0, s->g_valid = 0;
+  s->epi_ok = -1, s->fin4_pending = 0, s->g_valid = 0, s->cvg_margin = 0.0;
   s->norm_rhs = s->ttol = s->norm_rhs_div = 0.0;
   s->rnorm = s->gfnorm = s->gcnorm = 0.0;
   s->iteration = 0, s->reason = 0;
@@ -497,6 +498,7 @@ static int converged_default(pmh_mpgp s)
   if (std::isnan(s->rnorm) || std::isinf(s->rnorm)) s->reason = PMH_DIVERGED_NANORINF;
   else if (s->rnorm <= s->ttol) s->reason = (s->rnorm < s->o.atol) ? PMH_CONVERGED_ATOL : PMH_CONVERGED_RTOL;
   else if (s->rnorm >= s->o.divtol * s->norm_rhs_div) s->reason = PMH_DIVERGED_DTOL;
+  s->cvg_margin = (s->iteration >= s->o.max_it) ? 1e-300 : s->rnorm / fmax(s->ttol, 1e-300);
   return PMH_SUCCESS;
 }
 
@@ -853,6 +855,7 @@ static int solve_fused(pmh_mpgp s)
   const double gamma2 = s->o.gamma * s->o.gamma, astol = s->o.astol;
   int          nmv = 0, ncg = 0, nprop = 0, nexp = 0;
   bool         spec = false; // P1 for the current p already enqueued
+  double       prev_margin = 0.0; // cvg_margin of the previous test (see the speculation at the end of the loop)
   bool         p_fresh = false; // p is the gf of the last gradient split, untouched (told to operators that pair their passes)
 
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
@@ -976,10 +979,32 @@ static int solve_fused(pmh_mpgp s)
       LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
       PMH_CHK(finalize_vec4(s));
     }
-    // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p
-    if (s->pre_p1) PMH_CHK(s->pre_p1(s->pre_p1_user));
-    PMH_CHK(f_apply_p1(s, nullptr, p_fresh));
-    spec = true;
+    // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p -- enqueued before the host has seen this step's norms, so
+    // that the round trip costs nothing.  If the NEXT test ends the solve that product is wasted (0.35 ms for configs[2] against the ~30 us of an exposed round trip):
+    // the test reports how far the norm is above its threshold (cvg_margin), and with the last step's reduction the driver skips the speculation when the next norm
+    // is likely to pass (SMALXE's early outer iterations end their inner solves after 2-3 steps: 8 of 63 products in the driver's 20-step window were such orphans).
+    // Nothing numerical depends on it: the product is then enqueued after the test, by the `!spec` branch above.
+    bool orphan_risk = false;
+    {
+      static const bool always = getenv("PMH_MPGP_ALWAYS_SPEC") != nullptr;
+      const double      m      = s->cvg_margin;
+      if (!always && m > 0.0) {
+        const double red = (prev_margin > 0.0 && m < prev_margin) ? m / prev_margin : 1.0;
+        orphan_risk      = (m < 3.0) || (m * red < 2.0);
+      }
+      prev_margin = m;
+    }
+    if (orphan_risk) {
+      spec = false;
+      if (s->fin4_pending) { // the gradient split left its partial sums for the product's finalising launch: the host reads the norms next
+        PMH_CHK(finalize_vec4(s));
+        s->fin4_pending = 0;
+      }
+    } else {
+      if (s->pre_p1) PMH_CHK(s->pre_p1(s->pre_p1_user));
+      PMH_CHK(f_apply_p1(s, nullptr, p_fresh));
+      spec = true;
+    }
     s->iteration++;
   }
   s->ncg += ncg, s->nexp += nexp, s->nmv += nmv, s->nprop += nprop;
@@ -1035,6 +1060,14 @@ extern "C" int pmh_mpgp_get_trace(pmh_mpgp s, int cap, char *step, double *gp, d
 
 // work[0..6] = gP, gf, gc, g, p, Ap, gr (mpgp.c:6-17).  The fused driver does not keep gP, gc, gr:
 // they are recomputed here from the final x, g (MPGPGrads) so that callers see the reference's work vectors.
+// internal (an injected convergence test says how close it is to ending the solve, see solve_fused's speculation)
+int pmh_mpgp_set_convergence_margin(pmh_mpgp s, double margin)
+{
+  PMH_ARG(s);
+  s->cvg_margin = margin;
+  return PMH_SUCCESS;
+}
+
 // internal (smalxe.hip): the next pmh_mpgp_solve may take work[3] as the gradient at its starting point (fused driver only; others ignore it)
 int pmh_mpgp_set_gradient_valid(pmh_mpgp s, int valid, double **g)
 {

@@ -171,6 +171,7 @@ int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (fu
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_qppf_apply_G_norm2(pmh_qppf pf, const double *v, double *Gv, int slot);          // qppf.hip: G v and ||G v||^2 -> scalar slot, enqueue only
 int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user);             // mpgp.hip: see there
+int pmh_mpgp_set_convergence_margin(pmh_mpgp s, double margin); // from an injected convergence test: rnorm / its threshold (the fused driver's speculation reads it)
 int pmh_mpgp_set_gradient_valid(pmh_mpgp s, int valid, double **g); // the next solve starts from a gradient the caller has put into the solver's g (returned): smalxe.hip
 int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user);               // mpgp.hip: called right before the speculative Ap = A p of the next iteration is enqueued
 // SMALXE's ||B u|| riding on the next product of the penalised operator (qppf.hip): G0 u shares the pass over G0 with G0 x, T (G0 u) and its squared norm are

@@ -219,6 +219,15 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
   s->rnorm      = fmax(s->enorm, gnorm);
   s->MNormBu    = s->M1 * s->normBu;
   s->inner_atol = fmin(s->MNormBu, s->eta);
+  {
+    // how far the inner solve is from its end (the inner MPGP does not enqueue the next A_rho p ahead of a test that is likely to end the solve): the larger of the two
+    // thresholds the norm has to fall below; the iteration budget of the throughput mode and the iteration limit end it for certain
+    const bool   gtol_on = !(s->state == 3 && (i < s->o.inner_iter_min || s->o.inner_no_gtol_stop));
+    const double thr     = fmax(s->inner_atol, gtol_on ? s->gtol : 0.0);
+    double       margin  = gnorm / fmax(thr, 1e-300);
+    if ((s->fixed_left >= 0 && (long long)(i + 1) >= s->fixed_left) || i + 1 > s->inner_max_it - s->inner_iter_accu) margin = 1e-300;
+    (void)pmh_mpgp_set_convergence_margin(s->inner, margin);
+  }
 
   if (i > s->inner_max_it - s->inner_iter_accu) {
     *reason   = PMH_DIVERGED_ITS;
