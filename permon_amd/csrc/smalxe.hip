@@ -42,6 +42,7 @@ struct pmh_smalxe_s {
   long long fixed_left;
   // pmh_smalxe_set_reuse_products: A_rho u is carried from the inner solve's last gradient into the Lagrangian and into the next inner solve's first gradient
   int reuse;
+  int normBu_final_valid; // normBu / enorm are those of the current u (set by the inner convergence test)
 };
 
 // QPSCreate_SMALXE defaults smalxe.c:1159-1207
@@ -212,6 +213,7 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
   s->inner_it_now = i;
   s->BtBu_valid   = 0; // the inner solver has moved u
   if (update_normBu(s, s->u, &s->normBu, &s->enorm)) return 1;
+  s->normBu_final_valid = 1; // (normBu / enorm are those of the current u; the next step of the inner solver is followed by another test)
   if (s->fixed_left >= 0 && (long long)i >= s->fixed_left) { // throughput mode: the iteration budget ends this inner solve
     *reason = PMH_CONVERGED_ITS;
     return 0;
@@ -410,12 +412,13 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     if (s->reason) break;
     PMH_CHK(pmh_vec_waxpy(ctx, n, s->b_inner, -1.0, s->Btmu, s->b)); // b_inner = b - Btmu
     // QPSConvergedSetUp_Inner_SMALXE smalxe.c:537-557
-    PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs_outer));
+    if (i == 0) PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs_outer)); // (b does not change over the outer iterations: the same value, one host round trip per outer iteration less)
     s->gtol       = s->o.rtol * s->norm_rhs_outer;
     s->ttol_outer = fmax(s->o.rtol * s->norm_rhs_outer, s->o.atol);
     PMH_CHK(pmh_vec_norm2(ctx, n, s->b_inner, &s->outer_norm_rhs_div));
     PMH_CHK(pmh_mpgp_set_tolerances(s->inner, s->o.inner.rtol, s->o.inner.atol, s->o.divtol, s->inner_max_it));
     s->normBu_prefetched = 0;
+    s->normBu_final_valid = 0;
     if (s->reuse && i > 0) {
       // the inner solver still holds g = A_rho u - b_inner of the solve that just ended.  Since then b_inner lost rho_old B'B u (the multiplier update above) and A_rho
       // gained (rho_new - rho_old) B'B (smalxe_update): the gradient the next solve starts from is g + rho_new B'B u, with B'B u = BtBu already at hand -- no product with F
@@ -437,7 +440,10 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
       s->fixed_left -= st.iteration;
       if (s->fixed_left <= 0) break;
     }
-    PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
+    // QPSSMALXEUpdateNormBu after the inner solve (smalxe.c:977): the inner solver's last convergence test evaluated ||B u|| for this very u (inner_converged calls the same
+    // function on s->u and nothing has moved u since) -- the value is at hand, a second evaluation would cost two launches and a host round trip for the same bits.  Not
+    // with the lagged update (its in-solve value may be the approximate one) or a caller-supplied B'B-only path
+    if (!(s->normBu_final_valid && !s->o.be_implicit && !s->o.lag_enabled)) PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
     PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
     if (s->reuse) { // f = -u'(b_inner - 1/2 A_rho u) with A_rho u = g + b_inner: -1/2 u'(b_inner - g)
       double *g = nullptr, dot;
