@@ -1586,7 +1586,6 @@ static int fxo_prepare(fx_shared *S)
     S->owned_bytes += 8.0 * M * C.nc;
     // this rank's columns of A once + the gathered B + the split partial tiles written and read + Y
     S->bytes += (double)C.ngroups * (8.0 * M * C.nc * share + 8.0 * FXS_S * C.nc * share + 8.0 * FXS_S * C.nc) + 2.0 * 8.0 * ptiles;
-    C.nown = Smax; // (re-used: the class's largest split count)
   }
   S->fxo_S = Smax;
   S->nwg = 0;
