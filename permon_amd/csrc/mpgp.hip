@@ -19,6 +19,7 @@
 
 #include "pmh_internal.h"
 #include "reduce.h"
+#include "box_inline.h"
 
 #define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < (n); i += (long long)gridDim.x * PMH_BLOCK)
 
@@ -78,34 +79,7 @@ struct pmh_mpgp_s {
 // --------------------------------------------------------------------------------------------------------------------
 // device helpers: the box predicates of qpcbox.c restated per element
 // --------------------------------------------------------------------------------------------------------------------
-// QPCGrads_Box qpcbox.c:41-55 (lower bound wins ties, `else if`)
-__device__ __forceinline__ void box_split(double xi, double gi, const double *lb, const double *ub, long long i, double astol, double &gf, double &gc)
-{
-  gf = gi;
-  gc = 0.0;
-  if (lb && fabs(xi - lb[i]) <= astol) {
-    gf = 0.0;
-    gc = (gi < 0.0) ? gi : 0.0;
-  } else if (ub && fabs(xi - ub[i]) <= astol) {
-    gf = 0.0;
-    gc = (gi > 0.0) ? gi : 0.0;
-  }
-}
-
-// QPCGradReduced_Box qpcbox.c:86-92
-__device__ __forceinline__ double box_reduced(double xi, double gf, const double *lb, const double *ub, long long i, double alpha)
-{
-  double r = gf;
-  if (lb && gf > 0.0) {
-    double t = (xi - lb[i]) / alpha;
-    r        = (gf < t) ? gf : t;
-  } else if (ub && gf < 0.0) {
-    double t = (xi - ub[i]) / alpha;
-    r        = (gf < t) ? t : gf;
-  }
-  return r;
-}
-
+// (the box predicates pmh_box_split / pmh_box_reduced: box_inline.h)
 template <int K>
 __device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld)
 {
@@ -125,7 +99,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_split_setp(long long n, const dou
   GRID_STRIDE(i, n)
   {
     double f, c;
-    box_split(x[i], g[i], lb, ub, i, astol, f, c);
+    pmh_box_split(x[i], g[i], lb, ub, i, astol, f, c);
     gf[i]      = f;
     p[i]       = f;
     double gPi = f + c; // VecWAXPY(gP,1,gf,gc)
@@ -185,7 +159,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const do
     double xi  = x[i] + ma * p[i];
     double gi  = g[i] + ma * api;
     double f, c;
-    box_split(xi, gi, lb, ub, i, astol, f, c);
+    pmh_box_split(xi, gi, lb, ub, i, astol, f, c);
     x[i]  = xi;
     g[i]  = gi;
     gf[i] = f;
@@ -214,7 +188,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_prop_dir(long long n, const doubl
   GRID_STRIDE(i, n)
   {
     double f, c;
-    box_split(x[i], g[i], lb, ub, i, astol, f, c);
+    pmh_box_split(x[i], g[i], lb, ub, i, astol, f, c);
     p[i] = c;
   }
 }
@@ -229,8 +203,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_expansion_std(long long n, double
     double xi = x[i] + maf * p[i];
     double gi = g[i] + maf * Ap[i];
     double f, c;
-    box_split(xi, gi, lb, ub, i, astol, f, c);
-    double r = box_reduced(xi, f, lb, ub, i, alpha);
+    pmh_box_split(xi, gi, lb, ub, i, astol, f, c);
+    double r = pmh_box_reduced(xi, f, lb, ub, i, alpha);
     x[i]     = xi + mal * r;
   }
 }

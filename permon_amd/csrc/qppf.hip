@@ -11,6 +11,7 @@
 
 #include "pmh_internal.h"
 #include "reduce.h"
+#include "box_inline.h"
 
 
 // y = M x, M dense m x m row-major; one 64-lane wavefront per row
@@ -460,19 +461,6 @@ struct gt_aux {
   const double *part2, *Mt2; // chunk sums of G0 u, T' (row-major)
   double       *y2, *norm_d, *norm_h;
 };
-// the box predicates of qpcbox.c per element, as in mpgp.hip (QPCGrads_Box qpcbox.c:41-55: the lower bound wins ties)
-static __device__ __forceinline__ void gt_box_split(double xi, double gi, const double *lb, const double *ub, long long i, double astol, double &gf, double &gc)
-{
-  gf = gi;
-  gc = 0.0;
-  if (lb && fabs(xi - lb[i]) <= astol) {
-    gf = 0.0;
-    gc = (gi < 0.0) ? gi : 0.0;
-  } else if (ub && fabs(xi - ub[i]) <= astol) {
-    gf = 0.0;
-    gc = (gi > 0.0) ? gi : 0.0;
-  }
-}
 template <int EPI>
 __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int m, const int *__restrict__ lrow,
                                                          const double *__restrict__ part, const double *__restrict__ Mt, int mode, const double *__restrict__ x, double *__restrict__ y,
@@ -604,7 +592,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__re
       gi += -1.0 * epi.b[r];
       y[r] = gi;
       double f, c;
-      gt_box_split(pin[r], gi, epi.lb, epi.ub, r, epi.astol, f, c);
+      pmh_box_split(pin[r], gi, epi.lb, epi.ub, r, epi.astol, f, c);
       epi.gf[r]        = f;
       epi.p[r]         = f;
       const double gPi = f + c;

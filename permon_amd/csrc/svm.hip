@@ -7,6 +7,7 @@
 // Samples shard over GPUs by rows; the only exchange is the all-reduce of w (d doubles) between the passes.
 #include "pmh_internal.h"
 #include "reduce.h"
+#include "box_inline.h"
 
 #define SVM_KMAX 4 // d <= 64 * SVM_KMAX
 // a launch that streams X once (counted: pmh_op_svm_dual_passes)
@@ -176,38 +177,6 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64(int n, const double *__re
 // A run of expansion steps costs two passes over X per step instead of four; a CG or proportioning step discards the prepared sums and pays the usual passes.
 // The driver says what is fresh (pmh_vec_epi::p_fresh / spec_alpha / x_from_spec); the partial sums of the MPGP reductions go to the same rows of the context's
 // partials as the separate Vec kernels write, one entry per workgroup of pmh_vec_grid(n) (the elements a workgroup sums are other ones: same values to rounding).
-// the box predicates of qpcbox.c per element on VALUES (an absent bound is -inf / +inf: every comparison then falls as with the null pointer of box_split /
-// box_reduced in mpgp.hip), so that the bounds are loaded once, with the row's other scalars, before the row's dot product is known
-static __device__ __forceinline__ void svm_box_split(double xi, double gi, double l, double u, double astol, double &gf, double &gc)
-{ // QPCGrads_Box qpcbox.c:41-55 (the lower bound wins ties)
-  gf = gi;
-  gc = 0.0;
-  if (fabs(xi - l) <= astol) {
-    gf = 0.0;
-    gc = (gi < 0.0) ? gi : 0.0;
-  } else if (fabs(xi - u) <= astol) {
-    gf = 0.0;
-    gc = (gi > 0.0) ? gi : 0.0;
-  }
-}
-static __device__ __forceinline__ double svm_box_reduced(double xi, double gf, double l, double u, bool has_l, bool has_u, double alpha)
-{ // QPCGradReduced_Box qpcbox.c:86-92
-  double r = gf;
-  if (has_l && gf > 0.0) {
-    double t = (xi - l) / alpha;
-    r        = (gf < t) ? gf : t;
-  } else if (has_u && gf < 0.0) {
-    double t = (xi - u) / alpha;
-    r        = (gf < t) ? t : gf;
-  }
-  return r;
-}
-static __device__ __forceinline__ double svm_feas(double m, double xi, double pi, double l, double u)
-{ // QPCFeas_Box, as k_p1_dots
-  if (pi > 0. && l > -INFINITY) m = fmin(m, (xi - l) / pi);
-  if (pi < 0. && u < INFINITY) m = fmin(m, (xi - u) / pi);
-  return m;
-}
 // the two column sums a lane holds (columns 2 l2, 2 l2 + 1 of the rows its half of the wave visited) -> part[workgroup][64], as k_svm_xt64
 static __device__ __forceinline__ void svm_fold_cols(double a0, double a1, double (*lds)[64], double *__restrict__ part)
 {
@@ -281,12 +250,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64_grad(int n, const double 
     if (act) {
       const double gi = yi * sm - bi;
       double       f, c;
-      svm_box_split(xi, gi, li, ui, a.astol, f, c);
+      pmh_box_split_v(xi, gi, li, ui, a.astol, f, c);
       a.g[i] = gi, a.gf[i] = f, a.p[i] = f;
       if (a.x_out) a.x_out[i] = xi;
       const double gPi = f + c;
       acc1 += gPi * gPi, acc2 += c * c, acc3 += f * f;
-      m = svm_feas(m, xi, f, li, ui);
+      m = pmh_box_feas_v(m, xi, f, li, ui);
       t = yi * f;
     }
 #pragma unroll
@@ -352,12 +321,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64_p1(int n, const double *_
       const double api = yi * sm;
       a.Ap[i] = api;
       s0 += pi * api, s1 += gi * pi;
-      m = svm_feas(m, xi, pi, li, ui);
+      m = pmh_box_feas_v(m, xi, pi, li, ui);
       if (SPEC) { // k_expansion_std (mpgp.hip) on this entry
         const double xs = xi + maf * pi, gs = gi + maf * api;
         double       f, c;
-        svm_box_split(xs, gs, li, ui, a.astol, f, c);
-        const double r = svm_box_reduced(xs, f, li, ui, a.lb != nullptr, a.ub != nullptr, a.alpha), xn = xs + mal * r;
+        pmh_box_split_v(xs, gs, li, ui, a.astol, f, c);
+        const double r = pmh_box_reduced_v(xs, f, li, ui, a.lb != nullptr, a.ub != nullptr, a.alpha), xn = xs + mal * r;
         a.x_spec[i] = xn;
         t = yi * xn;
       }
