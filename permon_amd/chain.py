@@ -138,8 +138,10 @@ class FetiDualQP:
             storage = "class_sym" if 0.5 * b_cls < b_sym else "sym"  # the class matrix in symmetric tiles: half of b_cls
         one_class_all = one_class
         want_orbit = storage == "class_orbit" or (storage == "class_sym" and symmetry is not None and symmetry.get("orbit", True) and one_class_all)
-        if storage == "class_orbit" and (symmetry is None or not one_class):
-            raise ValueError("class_orbit needs congruent box blocks and symmetry=dict(dims=..., ndof=...)")
+        if storage == "class_orbit" and symmetry is None:
+            raise ValueError("class_orbit needs box-shaped blocks and symmetry=dict(dims=..., ndof=...)")
+        if storage == "class_orbit" and not one_class and stripe is not None:
+            raise ValueError("striped class_orbit operators need congruent blocks")
         for attempt in ("class_orbit", "class_sym") if want_orbit else (storage,):
             E = self._create_explicit(local, attempt, stripe, cls, nb)
             self.explicit_symmetries = 1
@@ -147,6 +149,14 @@ class FetiDualQP:
                 n_i = int(rs[1] - rs[0])
                 Kc = self._Kinv_sp[:n_i, :n_i]  # the class matrix (what the solver inverts)
                 self.explicit_symmetries = E.set_box_symmetry(0, symmetry["dims"], symmetry.get("ndof", 3), Kc)
+            elif symmetry is not None and attempt == "class_orbit":
+                # several classes of box-shaped blocks on the same box (e.g. one material per subdomain): every class has its own matrix, hence its own check of the operations
+                nsym = []
+                for c in np.unique(cls):
+                    b0 = int(np.nonzero(cls == c)[0][0])
+                    Kc = self._Kinv_sp[rs[b0]:rs[b0 + 1], rs[b0]:rs[b0 + 1]]
+                    nsym.append(E.set_box_symmetry(int(c), symmetry["dims"], symmetry.get("ndof", 3), Kc))
+                self.explicit_symmetries = int(min(nsym))
             if attempt == "class_orbit" and self.explicit_symmetries < 16 and storage != "class_orbit":
                 E.destroy()  # too few operations for the GEMM form to pay: the streaming kernel on the symmetric tiles
                 continue

@@ -415,3 +415,27 @@ def test_explicit_edge_cases(ctx):
                 with pytest.raises(pa.PermonHipError):
                     E.set_stripe(0, 2)
             E.destroy()
+
+
+def test_explicit_orbit_several_classes(ctx):
+    """PMH_FX_CLASS_ORBIT with SEVERAL block classes (one material per subdomain: 8 classes of one block each): every class keeps the operations under which ITS touched
+    set is closed (a single block's three interface faces + a Dirichlet or contact face: 2 ... 8 of the cube's 48), has its own representatives, row tile, k segments and
+    launch (fxo_prepare / fxo_gemm per class, the workgroup tables sliced per class).  F against the inner-Krylov K^+, the same SMALXE counts."""
+    nel = 9
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True, young=[1.0 + 0.25 * i for i in range(8)])
+    G, e = f.coarse(orthonormalize=True)
+    loc = f.subset(range(8))
+    nn = nel + 1
+    qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    qo = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    assert qo.explicit_storage == "class_orbit" and 2 <= qo.explicit_symmetries <= 48
+    n_solves, _ = qo.E.assemble_stats()
+    assert n_solves < int(qo.E.n_gamma.sum())  # fewer set-up solves than touched dofs: the orbits
+    lam = np.random.default_rng(3).standard_normal(f.n_lambda)
+    lv, y0, y1 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    qi.F.mult(lv, y0)
+    qo.F.mult(lv, y1)
+    assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-10 * np.linalg.norm(y0.to_numpy())
+    si, so = qi.solve_smalxe(rtol=1e-6), qo.solve_smalxe(rtol=1e-6)
+    assert si.reason == so.reason == 2
+    assert (si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (so.iteration, so.inner_iter_accu, so.inner.ncg, so.inner.nexp)
