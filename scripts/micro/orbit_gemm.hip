@@ -204,7 +204,12 @@ __global__ __launch_bounds__(NT, MINB) NVGPR_ATTR void k_gemm(int Mt, int Nt, in
 #pragma unroll
     for (int k4 = 0; k4 < TK / 4; k4++) {
       double a[NA], b[NB];
-#ifdef ORIENT4
+#if defined(NOLDSREAD) // knock-out (timing only): the operands of every k step are the same registers -- no LDS reads, no waits for them
+#pragma unroll
+      for (int i = 0; i < NA; i++) a[i] = acc[i][0] * 1e-300 + 1.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) b[j] = acc[0][j] * 1e-300 + 0.5;
+#elif defined(ORIENT4)
 #pragma unroll
       for (int i = 0; i < NA; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 4 + cb];
 #pragma unroll
