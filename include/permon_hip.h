@@ -256,6 +256,14 @@ int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y);
 int pmh_blockdiag_mult_transpose(pmh_blockdiag K, const double *x, double *y);                        /* matblockdiag.c:205-216 */
 int pmh_blockdiag_mult_add(pmh_blockdiag K, const double *x, const double *y1, double *y);            /* :220-233, y1 may be y */
 int pmh_blockdiag_mult_transpose_add(pmh_blockdiag K, const double *x, const double *y1, double *y);  /* :237-250 */
+/* MatMult_BlockDiag on a 3x3-block device copy (the role MATSEQBAIJ bs = 3 plays for 3-dof elasticity blocks: 8.44 instead of 12 bytes per non-zero).
+ * share != 0: congruent blocks (checked entry by entry) share ONE device copy -- the product then reads most of K from the XCDs' L2; share == 0: one copy per block,
+ * every byte streamed from HBM.  PMH_ERR_SUP if K has no 3x3 block structure.  The transpose / add forms stay on the CSR kernel. */
+int pmh_blockdiag_enable_bsr3(pmh_blockdiag K, int share);
+/* HIP-event pairs around the launches of pmh_blockdiag_mult.  csr_bytes = 12 nnz + 20 n (SURVEY 8d's figure of the product); hbm_bytes = what the kernel in use has to
+ * move from HBM per launch (its stored format; a shared copy once); device_copies = matrix copies on the device (1 when shared, else nblocks). */
+int pmh_blockdiag_timing_enable(pmh_blockdiag K, int max_launches);
+int pmh_blockdiag_timing_get(pmh_blockdiag K, int *launches, double *total_ms, double *csr_bytes, double *hbm_bytes, int *device_copies);
 
 /* MATINV apply (src/mat/impls/inv/matinv.c:734-743) on the iterative path the reference takes for a
    non-factorisable inner matrix (KSPCG + PCNONE/PCJACOBI per block, matinv.c:535-540): block-wise
@@ -481,6 +489,7 @@ int pmh_matinv_set_pc_mg(pmh_matinv Kplus, pmh_mg mg); /* NULL: back to Jacobi /
 /* MATINV's own K x product on the 3x3-block kernel (PETSc MATSEQBAIJ role: 8.44 instead of 12 bytes per non-zero);
  * returns PMH_ERR_SUP if K has no 3x3 block structure.  Timing as pmh_csr_timing_*. */
 int pmh_matinv_enable_bsr3(pmh_matinv Kplus);
+int pmh_matinv_bsr3_replicas(pmh_matinv Kplus, int *nrep); /* congruent blocks sharing the one device copy of the 3x3-block operator (1: a copy per block / no such copy) */
 int pmh_matinv_timing_enable(pmh_matinv Kplus, int max_launches);
 int pmh_matinv_timing_get(pmh_matinv Kplus, int *launches, double *total_ms, double *bytes_per_launch);
 

@@ -198,6 +198,9 @@ _PROTOS = {
     "pmh_blockdiag_mult_transpose": [vp, vp, vp],
     "pmh_blockdiag_mult_add": [vp, vp, vp, vp],
     "pmh_blockdiag_mult_transpose_add": [vp, vp, vp, vp],
+    "pmh_blockdiag_enable_bsr3": [vp, C.c_int],
+    "pmh_blockdiag_timing_enable": [vp, C.c_int],
+    "pmh_blockdiag_timing_get": [vp, c_int_p, c_double_p, c_double_p, c_double_p, c_int_p],
     "pmh_matinv_create": [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_matinv_destroy": [vp],
     "pmh_matinv_set_nullspace": [vp, C.c_int, vp],
@@ -229,6 +232,7 @@ _PROTOS = {
     "pmh_mg_timing_enable": [vp, C.c_int],
     "pmh_mg_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_matinv_enable_bsr3": [vp],
+    "pmh_matinv_bsr3_replicas": [vp, c_int_p],
     "pmh_matinv_timing_enable": [vp, C.c_int],
     "pmh_matinv_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_mg_apply": [vp, vp, vp],

@@ -377,15 +377,23 @@ int pmh_bsr3_destroy(pmh_bsr3 B)
   return PMH_SUCCESS;
 }
 
-// algorithmic bytes of one launch: values + one index per block, block-row pointers, x read once, y written once
+// bytes one launch moves from HBM: values + one index per block, block-row pointers, x read once, y written once.  With congruent blocks sharing one device copy
+// (nrep > 1) the matrix is streamed ONCE (the other nrep - 1 readers of a tile find it in their XCD's L2); the vectors of all replicas are streamed.
 double pmh_bsr3_bytes(pmh_bsr3 B)
 {
   const double wm = (B->storage == PMH_BSR_F64) ? 8.0 : (B->storage == PMH_BSR_F32 ? 4.0 : 2.0);
   const double wv = (B->storage == PMH_BSR_F64) ? 8.0 : 4.0;
-  // with congruent blocks sharing one device copy (nrep > 1) the figure stays the one of the block-diagonal product -- nrep times the matrix bytes, what SURVEY 8d counts per K_i --
-  // so that a rate above the HBM peak says what it means: the copies are served by the XCDs' L2, not streamed
-  return (double)B->nrep * ((double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1)) + 2.0 * wv * B->n;
+  return ((double)B->nblocks * (9.0 * wm + 4.0) + 4.0 * (B->nbr + 1)) + 2.0 * wv * B->n;
 }
+
+// the figure of the block-diagonal product as SURVEY 8d counts it (every K_i once): nrep times the matrix bytes.  Not an HBM figure when nrep > 1.
+double pmh_bsr3_bytes_blockdiag(pmh_bsr3 B)
+{
+  const double wv = (B->storage == PMH_BSR_F64) ? 8.0 : 4.0;
+  return (double)B->nrep * (pmh_bsr3_bytes(B) - 2.0 * wv * B->n) + 2.0 * wv * B->n;
+}
+
+int pmh_bsr3_replicas(pmh_bsr3 B) { return B->nrep; }
 
 template <typename TM, typename T, int W, int TB>
 static int bsr3_launch_w(pmh_bsr3 B, const T *x, T *y, int epi, const pmh_bsr3_epi<T> &e, const int *halt)

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <map>
+#include <thread>
 
 #include "pmh_internal.h"
 
@@ -67,6 +68,23 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
     t_last = now;
   };
   auto block_of = [&](int i) { return (int)(std::upper_bound(block_rowstart, block_rowstart + nsub + 1, i) - block_rowstart) - 1; };
+  // K must be block diagonal over block_rowstart (MATBLOCKDIAG: one sequential block per subdomain, matblockdiag.c:787-801): the per-class CSR views below index the
+  // block's own columns only.  One pass over the column indices (threads over blocks), an off-block entry is an argument error.
+  {
+    std::vector<int> bad(nsub, -1);
+    std::vector<std::thread> th;
+    for (int s = 0; s < nsub; s++)
+      th.emplace_back([&, s]() {
+        const int lo = block_rowstart[s], hi = block_rowstart[s + 1];
+        if (hi < lo) { bad[s] = lo; return; }
+        for (int i = lo; i < hi && bad[s] < 0; i++)
+          for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+            if (col[k] < lo || col[k] >= hi) { bad[s] = i; break; }
+      });
+    for (auto &t : th) t.join();
+    for (int s = 0; s < nsub; s++)
+      if (bad[s] >= 0) return pmh_set_error(PMH_ERR_ARG, "pmh_feti_contact_solve: K is not block diagonal over block_rowstart (row %d of block %d has a column outside [%d, %d))", bad[s], s, block_rowstart[s], block_rowstart[s + 1]);
+  }
 
   // ---- kernel bases: block-wise Gram-Schmidt (QPTDualize orthonormalises R, qptransform.c:1001)
   std::vector<double> Rn((size_t)kdim * N, 0.0);

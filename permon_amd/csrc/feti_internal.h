@@ -23,6 +23,7 @@ struct pmh_blockdiag_s {
   std::vector<int> rowstart;
   int             *d_rowstart;
   pmh_csr          K;
+  pmh_bsr3         Kb = nullptr; // optional 3x3-block device copy for MatMult_BlockDiag itself (pmh_blockdiag_enable_bsr3)
 };
 
 // ---- MATINV: block-wise CG -------------------------------------------------------------------------------------------

@@ -842,8 +842,10 @@ static int solve_fused(pmh_mpgp s)
   } else {
     PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
     nmv++;
+    p_fresh = true;
   }
-  p_fresh = true;
+  // (the carried-gradient branch did not run the operator's own gradient split: whatever pairing state an operator keeps from the previous solve must not be matched
+  // with this p -- p_fresh stays false there, the first product of the solve is then a lone application)
   s->step      = ' ';
   s->iteration = 0;
   pmh_spec_args nosa;

@@ -208,7 +208,9 @@ template <typename T> struct pmh_bsr3_epi {
 };
 int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0, int nrep_hint = 1); // *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default; nrep_hint > 1: A is said to be block diagonal with that many congruent blocks (checked entry by entry: one device copy then serves all)
 int    pmh_bsr3_destroy(pmh_bsr3 B);
-double pmh_bsr3_bytes(pmh_bsr3 B);
+double pmh_bsr3_bytes(pmh_bsr3 B);           // HBM bytes of one launch (a shared device copy is streamed once)
+double pmh_bsr3_bytes_blockdiag(pmh_bsr3 B); // SURVEY 8d's figure of the block-diagonal product (every replica's matrix counted)
+int    pmh_bsr3_replicas(pmh_bsr3 B);
 int    pmh_bsr3_spmv_f64(pmh_bsr3 B, const double *x, double *y, int epi, const double *y1, const int *halt);
 int    pmh_bsr3_spmv_f32(pmh_bsr3 B, const float *x, float *y, int epi, const float *y1, const int *halt);
 int    pmh_bsr3_spmv_epi_f64(pmh_bsr3 B, const double *x, double *y, int epi, const pmh_bsr3_epi<double> &e, const int *halt);

@@ -100,6 +100,19 @@ class MatBlockDiag:
     def mult_transpose_add(self, x, y1, y):  # MatMultTransposeAdd_BlockDiag
         check(self.ctx.L.pmh_blockdiag_mult_transpose_add(self.h, x.p, y1.p, y.p))
 
+    def enable_bsr3(self, share=True):
+        """MatMult_BlockDiag on the 3x3-block kernel; share: congruent blocks share one device copy (else one copy per block, all of it streamed from HBM)."""
+        check(self.ctx.L.pmh_blockdiag_enable_bsr3(self.h, 1 if share else 0))
+
+    def timing_enable(self, max_launches):
+        check(self.ctx.L.pmh_blockdiag_timing_enable(self.h, int(max_launches)))
+
+    def timing_get(self):
+        """(launches, total ms, CSR bytes 12 nnz + 20 n, HBM bytes of the kernel in use, device copies of the matrix)"""
+        n, ms, cb, hb, cp = C.c_int(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self.ctx.L.pmh_blockdiag_timing_get(self.h, C.byref(n), C.byref(ms), C.byref(cb), C.byref(hb), C.byref(cp)))
+        return n.value, ms.value, cb.value, hb.value, cp.value
+
     def destroy(self):
         if self.h:
             self.ctx.L.pmh_blockdiag_destroy(self.h)
@@ -192,8 +205,14 @@ class MatInv:
     def timing_enable(self, max_launches):
         check(self.ctx.L.pmh_matinv_timing_enable(self.h, int(max_launches)))
 
+    def bsr3_replicas(self):
+        """Congruent blocks served by the ONE device copy of the 3x3-block operator (1: a copy per block, or no 3x3-block copy)."""
+        n = C.c_int()
+        check(self.ctx.L.pmh_matinv_bsr3_replicas(self.h, C.byref(n)))
+        return n.value
+
     def timing_get(self):
-        """(launches, total ms, algorithmic bytes per launch) of the CG's K x products since timing_enable."""
+        """(launches, total ms, HBM bytes per launch: the stored matrix once -- shared copies are streamed once -- + x + y) of the CG's K x products since timing_enable."""
         n, ms, b = C.c_int(), C.c_double(), C.c_double()
         check(self.ctx.L.pmh_matinv_timing_get(self.h, C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
