@@ -1120,6 +1120,11 @@ def main():
     if a.dry_launch:
         print(json.dumps({"dry_launch": True, "pid": os.getpid(), "ppid": os.getppid(), **{k.lower(): os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}, "argv": sys.argv[1:]}))
         return
+    # stdout carries ONE line, the last thing this process prints: whatever a library writes to file descriptor 1 meanwhile (RCCL prints a version banner when a
+    # communicator is created) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     host_threads()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1301,11 +1306,14 @@ def main():
                 fh.write("\n")
         except OSError as ex:
             sys.stderr.write("bench.py: could not write %s: %r\n" % (a.details, ex))
-        sys.stdout.flush()
-        print(compact_line(out, a.details), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(compact_line(out, a.details), flush=True)
 
 
 if __name__ == "__main__":
