@@ -73,6 +73,13 @@ int pmh_comm_rank(pmh_ctx ctx, int *rank, int *size);
 int pmh_comm_allreduce_sum(pmh_ctx ctx, double *dbuf, size_t count);    /* in place, device buffer */
 int pmh_comm_allreduce_min(pmh_ctx ctx, double *dbuf, size_t count);
 int pmh_comm_barrier(pmh_ctx ctx);
+/* Host-staged transport instead of RCCL: every collective of the data path (B u in pmh_gluing_mult_transpose, the SVM w, the grouped MPGP scalars, the barrier) copies its
+ * device buffer to pinned host memory and calls fn -- an IN-PLACE all-reduce over the ranks (op: PMH_COMM_SUM / PMH_COMM_MIN; PMH_COMM_BARRIER with count 0), returning 0 on
+ * success -- then copies the result back, in stream order.  What the PETSc glue passes when the ranks cannot form an RCCL communicator: MPI_Allreduce(MPI_IN_PLACE, buf, count,
+ * MPI_DOUBLE, MPI_SUM / MPI_MIN, comm) (replaces the reference's MPI reductions: gluing.c:144-147, qpc.c:521, VecDot / VecNorm).  fn == NULL removes it.  Not together with pmh_comm_init. */
+enum { PMH_COMM_SUM = 0, PMH_COMM_MIN = 1, PMH_COMM_BARRIER = 2 };
+typedef int (*pmh_comm_host_fn)(void *user, int op, double *host_buf, size_t count);
+int pmh_comm_set_host_transport(pmh_ctx ctx, int rank, int size, pmh_comm_host_fn fn, void *user);
 
 /* ---- Mat: CSR (PETSc SeqAIJ role) ---------------------------------------------------------------- */
 /* replaces MatMult(A,..) at mpgp.c:500,537,578,606,624, mpgp.c:250, permonmatutils.c:487,

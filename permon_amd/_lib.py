@@ -118,6 +118,7 @@ _PROTOS = {
     "pmh_comm_allreduce_sum": [vp, vp, C.c_size_t],
     "pmh_comm_allreduce_min": [vp, vp, C.c_size_t],
     "pmh_comm_barrier": [vp],
+    "pmh_comm_set_host_transport": [vp, C.c_int, C.c_int, vp, vp],
     "pmh_csr_create": [vp, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)],
     "pmh_csr_destroy": [vp],
     "pmh_csr_sizes": [vp, c_int_p, c_int_p, C.POINTER(C.c_longlong)],

@@ -63,6 +63,33 @@ class Context:
         check(self.L.pmh_comm_init(self.h, int(rank), int(size), buf))
         self.rank, self.size = int(rank), int(size)
 
+    def comm_set_host_transport(self, rank, size, allreduce):
+        """pmh_comm_set_host_transport: every collective of the data path goes through `allreduce(op, array)` -- an IN-PLACE all-reduce over the ranks of a float64 numpy
+        view of the pinned staging buffer (op 0 sum, 1 min, 2 barrier with an empty array) -- instead of RCCL.  allreduce = None removes it."""
+        if allreduce is None:
+            check(self.L.pmh_comm_set_host_transport(self.h, 0, 1, None, None))
+            self._host_cb = None
+            self.rank, self.size = 0, 1
+            return
+        import numpy as np
+
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t)
+
+        def cb(_user, op, buf, count):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(count,)) if count else np.empty(0)
+                allreduce(int(op), arr)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the library's error channel
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._host_cb = proto(cb)  # kept alive with the context
+        check(self.L.pmh_comm_set_host_transport(self.h, int(rank), int(size), C.cast(self._host_cb, C.c_void_p), None))
+        self.rank, self.size = int(rank), int(size)
+
     def comm_rank(self):
         """(rank, size) of the RCCL communicator (pmh_comm_rank); (0, 1) without one."""
         r, n = C.c_int(), C.c_int()

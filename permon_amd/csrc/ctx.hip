@@ -52,6 +52,7 @@ extern "C" int pmh_finalize(pmh_ctx c)
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   hipFree(c->d_partials);
   hipFree(c->d_scal);
   hipFree(c->d_commbuf);
@@ -204,10 +205,38 @@ extern "C" int pmh_comm_rank(pmh_ctx c, int *rank, int *size)
   return PMH_SUCCESS;
 }
 
+// Host-staged transport of the collectives: device -> pinned host -> fn (an in-place all-reduce over the ranks, e.g. MPI_Allreduce(MPI_IN_PLACE, ...) on the communicator of the
+// PETSc objects the glue was handed) -> device, in stream order.  For deployments whose ranks cannot form an RCCL communicator (several ranks per GPU, a fabric RCCL does not
+// drive) and for the 2-process tests on a one-GPU box; RCCL over xGMI (pmh_comm_init) stays the transport of the benchmarked path.
+extern "C" int pmh_comm_set_host_transport(pmh_ctx c, int rank, int size, pmh_comm_host_fn fn, void *user)
+{
+  PMH_ARG(c && size >= 1 && rank >= 0 && rank < size);
+  if (fn && c->comm) return pmh_set_error(PMH_ERR_STATE, "pmh_comm_set_host_transport: the context already has an RCCL communicator");
+  c->hook = fn, c->hook_user = user;
+  c->rank = fn ? rank : 0, c->size = fn ? size : 1;
+  return PMH_SUCCESS;
+}
+
+static int host_reduce(pmh_ctx c, int op, double *dbuf, size_t count)
+{
+  if (count > c->stage_cap) {
+    if (c->h_stage) PMH_HIP(hipHostFree(c->h_stage));
+    c->h_stage = nullptr, c->stage_cap = 0;
+    PMH_HIP(hipHostMalloc((void **)&c->h_stage, sizeof(double) * std::max<size_t>(count, 1024), hipHostMallocDefault));
+    c->stage_cap = std::max<size_t>(count, 1024);
+  }
+  if (count) PMH_HIP(hipMemcpyAsync(c->h_stage, dbuf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  if (const int rc = c->hook(c->hook_user, op, c->h_stage, count)) return pmh_set_error(PMH_ERR_COMM, "host transport: the all-reduce callback returned %d", rc);
+  if (count) PMH_HIP(hipMemcpyAsync(dbuf, c->h_stage, sizeof(double) * count, hipMemcpyHostToDevice, c->stream)); // (the next staging copy is ordered behind it on the stream)
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_comm_allreduce_sum(pmh_ctx c, double *dbuf, size_t count)
 {
   PMH_ARG(c);
-  if ((c->size == 1 && !c->force_comm) || !count || !c->comm) return PMH_SUCCESS;
+  if (!pmh_comm_on(c) || !count) return PMH_SUCCESS;
+  if (c->hook) return host_reduce(c, PMH_COMM_SUM, dbuf, count);
   PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, c->comm, c->stream));
   return PMH_SUCCESS;
 }
@@ -215,16 +244,38 @@ extern "C" int pmh_comm_allreduce_sum(pmh_ctx c, double *dbuf, size_t count)
 extern "C" int pmh_comm_allreduce_min(pmh_ctx c, double *dbuf, size_t count)
 {
   PMH_ARG(c);
-  if ((c->size == 1 && !c->force_comm) || !count || !c->comm) return PMH_SUCCESS;
+  if (!pmh_comm_on(c) || !count) return PMH_SUCCESS;
+  if (c->hook) return host_reduce(c, PMH_COMM_MIN, dbuf, count);
   PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclMin, c->comm, c->stream));
+  return PMH_SUCCESS;
+}
+
+// K device scalars with their own operations (the MPGP reductions of a phase: sums and QPCFeas's MIN) in one grouped exchange
+int pmh_comm_allreduce_scalars(pmh_ctx c, double *dscal, int K, const int *ops)
+{
+  if (!pmh_comm_on(c) || K <= 0) return PMH_SUCCESS;
+  if (c->hook) {
+    // runs of equal operations go out together (same values as one exchange per scalar: an all-reduce acts element-wise)
+    for (int k0 = 0; k0 < K;) {
+      int k1 = k0 + 1;
+      while (k1 < K && (ops[k1] == PMH_RED_MIN) == (ops[k0] == PMH_RED_MIN)) k1++;
+      PMH_CHK(host_reduce(c, ops[k0] == PMH_RED_MIN ? PMH_COMM_MIN : PMH_COMM_SUM, dscal + k0, (size_t)(k1 - k0)));
+      k0 = k1;
+    }
+    return PMH_SUCCESS;
+  }
+  PMH_NCCL(ncclGroupStart());
+  for (int k = 0; k < K; k++) PMH_NCCL(ncclAllReduce(dscal + k, dscal + k, 1, ncclDouble, ops[k] == PMH_RED_MIN ? ncclMin : ncclSum, c->comm, c->stream));
+  PMH_NCCL(ncclGroupEnd());
   return PMH_SUCCESS;
 }
 
 extern "C" int pmh_comm_barrier(pmh_ctx c)
 {
   PMH_ARG(c);
-  if (c->comm && (c->size > 1 || c->force_comm)) {
-    PMH_NCCL(ncclAllReduce(c->d_commbuf, c->d_commbuf, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  if (pmh_comm_on(c)) {
+    if (c->hook) PMH_CHK(host_reduce(c, PMH_COMM_BARRIER, c->d_commbuf, 0));
+    else PMH_NCCL(ncclAllReduce(c->d_commbuf, c->d_commbuf, 1, ncclDouble, ncclSum, c->comm, c->stream));
   }
   PMH_HIP(hipStreamSynchronize(c->stream));
   return PMH_SUCCESS;

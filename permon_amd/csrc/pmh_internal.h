@@ -52,7 +52,15 @@ struct pmh_ctx_s {
   int        rank, size, force_comm;
   double    *d_commbuf; // small staging buffer for scalar allreduces
   int        dist_scalars; // set while a solver with row-distributed vectors runs: finalised scalars are all-reduced
+  // host-staged transport of the collectives (pmh_comm_set_host_transport: e.g. MPI_Allreduce on the glue's communicator) instead of RCCL
+  pmh_comm_host_fn hook      = nullptr;
+  void            *hook_user = nullptr;
+  double          *h_stage   = nullptr; // pinned
+  size_t           stage_cap = 0;
 };
+// the data-path collectives are live: a transport exists (RCCL communicator or host transport) and there is more than one rank (or PMH_COMM_FORCE=1)
+static inline bool pmh_comm_on(pmh_ctx c) { return (c->comm || c->hook) && (c->size > 1 || c->force_comm); }
+int pmh_comm_allreduce_scalars(pmh_ctx c, double *dscal, int K, const int *ops /* PMH_RED_SUM / PMH_RED_MIN per scalar */); // K device scalars, one grouped exchange
 
 // ---- CSR -----------------------------------------------------------------------------------------------
 enum { PMH_SPMV_STREAM = 0, PMH_SPMV_VECTOR = 1 };

@@ -67,14 +67,11 @@ int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nbloc
   for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0, o.slot[k] = scal_base + k;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, halt, post_inc);
   PMH_HIP(hipGetLastError());
-  if (ctx->dist_scalars && ctx->comm && (ctx->size > 1 || ctx->force_comm)) {
+  if (ctx->dist_scalars && pmh_comm_on(ctx)) {
     // row-distributed vectors: complete the reductions across ranks (VecDot / VecNorm / QPCFeas MPI_Allreduce)
-    // as ONE grouped RCCL launch over the K device scalars, then refresh the pinned host mirror
+    // as ONE grouped exchange over the K device scalars, then refresh the pinned host mirror
     if (halt) return pmh_set_error(PMH_ERR_STATE, "the speculative device-side chain is not available with row-distributed vectors");
-    PMH_NCCL(ncclGroupStart());
-    for (int k = 0; k < K; k++)
-      PMH_NCCL(ncclAllReduce(ctx->d_scal + scal_base + k, ctx->d_scal + scal_base + k, 1, ncclDouble, ops[k] == PMH_RED_MIN ? ncclMin : ncclSum, ctx->comm, ctx->stream));
-    PMH_NCCL(ncclGroupEnd());
+    PMH_CHK(pmh_comm_allreduce_scalars(ctx, ctx->d_scal + scal_base, K, ops));
     PMH_HIP(hipMemcpyAsync(ctx->h_scal + scal_base, ctx->d_scal + scal_base, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
   }
   return PMH_SUCCESS;
@@ -85,7 +82,7 @@ int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nbloc
 int pmh_finalize_partials_slots(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, const int *slots)
 {
   PMH_ARG(K >= 1 && K <= PMH_MAX_RED);
-  if (ctx->dist_scalars && ctx->comm && (ctx->size > 1 || ctx->force_comm)) return pmh_set_error(PMH_ERR_STATE, "pmh_finalize_partials_slots: not with row-distributed vectors");
+  if (ctx->dist_scalars && pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_STATE, "pmh_finalize_partials_slots: not with row-distributed vectors");
   pmh_ops8 o;
   for (int k = 0; k < PMH_MAX_RED; k++) o.op[k] = (k < K) ? ops[k] : 0, o.slot[k] = (k < K) ? slots[k] : 0;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PMH_FIN_THREADS), 0, ctx->stream, partials, ld, nblocks, K, o, ctx->d_scal, ctx->h_scal, (const int *)nullptr, (int *)nullptr);
