@@ -395,6 +395,17 @@ int pmh_qpt_feti_chain_get(pmh_feti_chain ch, pmh_op *F, pmh_op *A, double **d, 
    lambda = lambda_child + lambda~; u0 = K^+(f - B' lambda); r = F lambda - d (u0, r optional) */
 int pmh_qpt_feti_chain_post_solve(pmh_feti_chain ch, const double *lambda_child, double *lambda, double *u0, double *r);
 int pmh_qpt_feti_chain_destroy(pmh_feti_chain ch);
+/* the numbers of -qp_chain_view_kkt (QPViewKKT qp.c:245-369 on every QP of the chain, qpchain.c:247-268) for the QPs this chain object stands for; linear chain (no dual box).
+ * K: the block-diagonal stiffness of the primal QP; x_child: the solved vector of the last QP; lambda = x_child + lambda~; u: the recovered primal solution */
+typedef struct {
+  int    has_coarse;                             /* the projected and the homogenised QP exist (floating subdomains) */
+  double proj_r, proj_normb;                     /* ||P F x - P b_bar||, ||P b_bar|| */
+  double hom_r, hom_be, hom_normb;               /* ||F x - b_bar + (B'lambda)|| (0 by construction of the missing multiplier), ||G x||, ||b_bar|| */
+  double dual_r, dual_be, dual_normb;            /* ||F lambda - d + (B'lambda)||, ||G lambda - e||, ||d|| */
+  double prim_r, prim_be, prim_normb;            /* ||K u - f + B' lambda||, ||B u||, ||f|| */
+  double prim_r_zeroed_operator;                 /* ||B' lambda - f||: the same line once QPTPostSolve_QPTMatISToBlockDiag has left K zeroed (-qpt_matis_to_diag_norm with Dirichlet by B) */
+} pmh_feti_chain_kkt;
+int pmh_qpt_feti_chain_kkt(pmh_feti_chain chain, pmh_blockdiag K, const double *x_child, const double *lambda, const double *u, pmh_feti_chain_kkt *out);
 
 /* ---- dense-row SVM dual Hessian (BASELINE configs[4]) ---------------------------------------------------- */
 /* H = diag(y) X X' diag(y), X: n_local x d row-major in HBM (d <= 256), applied as two GEMV passes; with a
@@ -532,6 +543,13 @@ typedef struct {
   double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */
   double rtol, atol, divtol; int max_it; /* -qps_rtol ... of the dual solve (qps.c:73-76) */
   int    explicit_dual; double explicit_rtol; /* 1: F applies through the explicit local dual operators (pmh_fexplicit_*), assembled at explicit_rtol (default 0 / 1e-13) */
+  /* the reference's post-solve report, QPChainPostSolve (src/qp/interface/qpchain.c:198-275): */
+  int    view_convergence;   /* -qps_view_convergence: "  last QPSSolve CONVERGED due to ..., KSPReason=.., required .. iterations" (qps.c:1188-1230) */
+  int    view_kkt;           /* -qp_chain_view_kkt: the `r = ...` lines of QPViewKKT (qp.c:245-369) for EVERY QP of the chain, last to first: projected dual, homogenised dual, dual
+                                (twice: QPTScale always adds a child sharing all vectors, qptransform.c:1459), decomposed primal (twice), assembled original */
+  int    matis_to_diag_norm; /* -qpt_matis_to_diag_norm: the "Dirichlet in Hess: .., r = ||Ax-b|| = .." line of QPTPostSolve_QPTMatISToBlockDiag (qptransform.c:1954-1979), and its
+                                side effect on the two QPs printed after it when the Dirichlet dofs are enforced by B (see pmh_kspfeti_solve in kspfeti.hip) */
+  char  *view_buf; int view_cap; /* the text (full PETSc viewer lines, '\n'-separated, NUL-terminated, truncated to view_cap) goes here; NULL: to stdout */
 } pmh_kspfeti_opts;
 typedef struct {
   int    iteration, reason;

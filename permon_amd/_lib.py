@@ -74,7 +74,8 @@ class QpsOpts(C.Structure):
 class KspFetiOpts(C.Structure):
     _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
                 ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int),
-                ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double)]
+                ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("view_convergence", C.c_int), ("view_kkt", C.c_int), ("matis_to_diag_norm", C.c_int),
+                ("view_buf", C.c_char_p), ("view_cap", C.c_int)]
 
 
 class KspFetiStats(C.Structure):
@@ -217,6 +218,7 @@ _PROTOS = {
     "pmh_qpt_feti_chain_get": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "pmh_qpt_feti_chain_post_solve": [vp, vp, vp, vp, vp],
     "pmh_qpt_feti_chain_destroy": [vp],
+    "pmh_qpt_feti_chain_kkt": [vp, vp, vp, vp, vp, vp],
     "pmh_op_create_svm_dual": [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
     "pmh_op_svm_dual_passes": [vp, C.POINTER(C.c_longlong)],
     "pmh_smalxe_default_opts": [C.POINTER(SmalxeOpts)],

@@ -304,7 +304,10 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     cap = int(dl.size + 8 * N)
     lam = np.zeros(cap)
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+    view = C.create_string_buffer(8192)  # -qps_view_convergence / -qp_chain_view_kkt / -qpt_matis_to_diag_norm text, if asked for in `options`
+    o.view_buf, o.view_cap = C.cast(view, C.c_char_p), len(view)
     check(ctx.L.pmh_kspfeti_solve(ctx.h, rs.size - 1, p(rs), p(ip), p(ci), p(va), p(fv), p(lg), dl.size, p(dl), Rm.shape[0], p(Rm), C.byref(o), p(u), p(lam), cap, C.byref(st)))
+    st.view_text = view.value.decode()
     return u, lam[:st.n_lambda].copy(), st
 
 

@@ -922,6 +922,80 @@ extern "C" int pmh_qpt_feti_chain_post_solve(pmh_feti_chain ch, const double *la
   return PMH_SUCCESS;
 }
 
+// The numbers behind -qp_chain_view_kkt for the QPs this chain stands for (QPViewKKT, src/qp/interface/qp.c:245-369, called by QPChainPostSolve qpchain.c:247-268 on every QP
+// from the last one up, each AFTER the post-solve of the QP below it and QPComputeMissingEqMultiplier :777-826 on itself).  Linear chain (no dual box):
+//   projected QP     A = P F, b = P b_bar                      : ||A x - b||, ||b||                                        (only with a coarse problem)
+//   homogenised QP   A = F, b = b_bar, BE = G, cE = 0          : Bt_lambda := -(F x - b_bar) (the missing multiplier: BE == B :806-808) => r = 0 exactly; ||G x||; ||b_bar||
+//   dual QP (x2)     A = F, b = d, BE = G, cE = e              : the Bt_lambda vector is SHARED with the homogenised QP (QP_DUPLICATE_COPY_POINTERS, qp.c:197): r = ||F lambda - d + Bt_lambda||,
+//                                                                 rounding level; ||G lambda - e||; ||d||
+//   primal QP (x2)   A = K, b = f, BE = B, cE = 0              : ||K u - f + B' lambda||, ||B u||, ||f||;  also ||B' lambda - f|| (what the line shows once K has been zeroed)
+// x_child: the solved vector of the last QP; lambda = x_child + lambda~; u: the recovered primal solution (with its rigid-body part).
+extern "C" int pmh_qpt_feti_chain_kkt(pmh_feti_chain ch, pmh_blockdiag K, const double *x_child, const double *lambda, const double *u, pmh_feti_chain_kkt *out)
+{
+  PMH_ARG(ch && K && x_child && lambda && u && out && K->n == ch->n_x);
+  pmh_ctx   ctx = ch->ctx;
+  const int nl = ch->n_lambda, nx = ch->n_x;
+  memset(out, 0, sizeof(*out));
+  double *t = ch->t_l, *w = nullptr, *btl = nullptr, *tx = ch->t_x, *tx2 = nullptr, *gm = nullptr;
+  const size_t bl = sizeof(double) * (size_t)(nl ? nl : 1), bx = sizeof(double) * (size_t)(nx ? nx : 1);
+  PMH_CHK(pmh_malloc(ctx, bl, (void **)&w));
+  PMH_CHK(pmh_malloc(ctx, bl, (void **)&btl));
+  PMH_CHK(pmh_malloc(ctx, bx, (void **)&tx2));
+  int rc = PMH_SUCCESS;
+#define GO(call) \
+  do { \
+    if ((rc = (call))) goto done; \
+  } while (0)
+  out->has_coarse = ch->pf ? 1 : 0;
+  if (ch->pf) {
+    const int m = ch->pf->m;
+    GO(pmh_malloc(ctx, sizeof(double) * (size_t)(m ? m : 1), (void **)&gm));
+    // projected QP
+    GO(ch->A->mult(x_child, t));
+    GO(pmh_vec_axpy(ctx, nl, t, -1.0, ch->b));
+    GO(pmh_vec_norm2(ctx, nl, t, &out->proj_r));
+    GO(pmh_vec_norm2(ctx, nl, ch->b, &out->proj_normb));
+    // homogenised QP: Bt_lambda = -(F x - b_bar); r = (F x - b_bar) + Bt_lambda
+    GO(ch->F->mult(x_child, t));
+    GO(pmh_vec_axpy(ctx, nl, t, -1.0, ch->b_bar));
+    GO(pmh_vec_copy(ctx, nl, t, btl));
+    GO(pmh_vec_scale(ctx, nl, btl, -1.0));
+    GO(pmh_vec_axpy(ctx, nl, t, 1.0, btl));
+    GO(pmh_vec_norm2(ctx, nl, t, &out->hom_r));
+    GO(pmh_vec_norm2(ctx, nl, ch->b_bar, &out->hom_normb));
+    GO(pmh_qppf_apply_G(ch->pf, x_child, gm));
+    GO(pmh_vec_norm2(ctx, m, gm, &out->hom_be));
+    // dual QP: r = F lambda - d + Bt_lambda; ||G lambda - e|| with e recovered as G lambda~ (lambda~ = G'(GG')^{-1} e)
+    GO(ch->F->mult(lambda, t));
+    GO(pmh_vec_axpy(ctx, nl, t, -1.0, ch->d));
+    GO(pmh_vec_axpy(ctx, nl, t, 1.0, btl));
+    GO(pmh_vec_norm2(ctx, nl, t, &out->dual_r));
+    GO(pmh_vec_norm2(ctx, nl, ch->d, &out->dual_normb));
+    GO(pmh_vec_waxpy(ctx, nl, w, -1.0, ch->lam_tilde, lambda)); // G (lambda - lambda~) = G lambda - e
+    GO(pmh_qppf_apply_G(ch->pf, w, gm));
+    GO(pmh_vec_norm2(ctx, m, gm, &out->dual_be));
+  } else {
+    GO(ch->F->mult(lambda, t));
+    GO(pmh_vec_axpy(ctx, nl, t, -1.0, ch->d));
+    GO(pmh_vec_norm2(ctx, nl, t, &out->dual_r));
+    GO(pmh_vec_norm2(ctx, nl, ch->d, &out->dual_normb));
+  }
+  // primal QP
+  GO(pmh_gluing_mult(ch->B, lambda, tx)); // B' lambda
+  GO(pmh_vec_waxpy(ctx, nx, tx2, -1.0, ch->f, tx)); // B' lambda - f
+  GO(pmh_vec_norm2(ctx, nx, tx2, &out->prim_r_zeroed_operator));
+  GO(pmh_blockdiag_mult(K, u, tx));
+  GO(pmh_vec_axpy(ctx, nx, tx2, 1.0, tx));
+  GO(pmh_vec_norm2(ctx, nx, tx2, &out->prim_r));
+  GO(pmh_vec_norm2(ctx, nx, ch->f, &out->prim_normb));
+  GO(pmh_gluing_mult_transpose(ch->B, u, t));
+  GO(pmh_vec_norm2(ctx, nl, t, &out->prim_be));
+done:
+#undef GO
+  pmh_free(ctx, w), pmh_free(ctx, btl), pmh_free(ctx, tx2), pmh_free(ctx, gm);
+  return rc;
+}
+
 extern "C" int pmh_qpt_feti_chain_destroy(pmh_feti_chain ch)
 {
   if (!ch) return PMH_SUCCESS;

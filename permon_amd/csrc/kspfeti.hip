@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <string>
 
 #include "pmh_internal.h"
 
@@ -23,6 +24,97 @@ struct LumpedOp : pmh_op_s { // PCApply_Dual lumped (pcdual.c:63-78) as an opera
   int           mult(const double *x, double *y) override { return pmh_pc_dual_lumped_apply(B, K, x, y); }
 };
 } // namespace
+
+// QPChainPostSolve's report (src/qp/interface/qpchain.c:198-275) for the chain KSPFETI builds (feti.c:71-94, QPTAllInOne qptransform.c:2152-2207):
+//   #0 the assembled MATIS QP -> #1 QPTMatISToBlockDiag -> #2 QPTScale -> #3 QPTDualize -> #4 QPTScale [-> #5 QPTHomogenizeEq -> #6 QPTEnforceEqByProjector with floating subdomains].
+// QPTScale adds a child even when nothing is scaled (:1459, QP_DUPLICATE_COPY_POINTERS: operator, right-hand side, solution and multipliers are the parent's own objects), so
+// #4 / #3 and #2 / #1 print the same lines.  Every QP is viewed after the post-solve of the QP below it.  -qpt_matis_to_diag_norm adds the line of
+// QPTPostSolve_QPTMatISToBlockDiag (:1954-1979) between #2 and #1; with the Dirichlet dofs enforced by B that routine zeroes rows / columns of the local matrices IN PLACE (:1933 --
+// the MATIS of #0 shares them) and restores them with MatCopy (:1967), which for MATBLOCKDIAG is PETSc's MatCopy_Basic: MatZeroEntries + a row loop the type has no MatGetRow
+// for -- what #1 and #0 print afterwards is consistent with an operator left at ZERO (feti/output/ex1_1.out: ||B' lambda - f|| = 2.31e-02 and ||b|| / ||b|| = 1.00e+00;
+// with -dir_in_hess, ex1_2.out, nothing is touched).  Reproduced as observed, said here so that nobody mistakes those two lines for residuals of the solve.
+static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_stats &ks, pmh_feti_chain ch, pmh_blockdiag Kb, int N, int nsub, const int *l2g, int n_dir, const int *dir_local,
+                        const double *f, const double *u_host, const double *d_x, const double *d_lam, double *d_u, std::string &text)
+{
+  (void)nsub;
+  char line[256];
+  if (o->view_convergence) { // QPSViewConvergence qps.c:1188-1230 (KSPConvergedReasons: 2 RTOL, 3 ATOL, -3 ITS, -4 DTOL)
+    const char *why = ks.reason == 2 ? "CONVERGED_RTOL" : ks.reason == 3 ? "CONVERGED_ATOL" : ks.reason == 1 ? "CONVERGED_RTOL_NORMAL" : ks.reason == 5 ? "CONVERGED_HAPPY_BREAKDOWN"
+                      : ks.reason == -3 ? "DIVERGED_ITS" : ks.reason == -4 ? "DIVERGED_DTOL" : ks.reason == -9 ? "DIVERGED_NANORINF" : "DIVERGED_BREAKDOWN";
+    snprintf(line, sizeof(line), "  last QPSSolve %s due to %s, KSPReason=%d, required %d iterations\n", ks.reason > 0 ? "CONVERGED" : "DIVERGED", why, ks.reason, ks.iteration);
+    text += line;
+  }
+  if (!o->view_kkt && !o->matis_to_diag_norm) return PMH_SUCCESS;
+  PMH_CHK(pmh_memcpy_h2d(ctx, d_u, u_host, sizeof(double) * (size_t)N)); // u with its rigid-body part
+  pmh_feti_chain_kkt k;
+  PMH_CHK(pmh_qpt_feti_chain_kkt(ch, Kb, d_x, d_lam, d_u, &k));
+  auto kkt = [&](const char *name, double r, double nb) { // qp.c:296
+    snprintf(line, sizeof(line), "r = ||%s|| = %.2e    rO/||b|| = %.2e\n", name, r, r / nb);
+    text += line;
+  };
+  auto be = [&](bool with_c, double r, double nb) { // qp.c:310-312
+    snprintf(line, sizeof(line), with_c ? "r = ||BE*x-cE||          = %.2e    r/||b|| = %.2e\n" : "r = ||BE*x||             = %.2e    r/||b|| = %.2e\n", r, r / nb);
+    text += line;
+  };
+  if (o->view_kkt) {
+    if (k.has_coarse) {
+      kkt("A*x - b", k.proj_r, k.proj_normb);                 // #6
+      kkt("A*x - b + (B'*lambda)", k.hom_r, k.hom_normb);     // #5
+      be(false, k.hom_be, k.hom_normb);
+    }
+    for (int rep = 0; rep < 2; rep++) {                       // #4, #3
+      kkt(k.has_coarse ? "A*x - b + (B'*lambda)" : "A*x - b", k.dual_r, k.dual_normb);
+      if (k.has_coarse) be(true, k.dual_be, k.dual_normb);
+    }
+    kkt("A*x - b + B'*lambda", k.prim_r, k.prim_normb);       // #2
+    be(false, k.prim_be, k.prim_normb);
+  }
+  // ---- the assembled problem: x0 = INSERT_VALUES assembly of u (:1948-1952), A0 = sum of the local matrices, b0 = the assembled right-hand side
+  int ng = 0;
+  for (int i = 0; i < N; i++) ng = std::max(ng, l2g[i] + 1);
+  std::vector<double> x0((size_t)ng, 0.0), b0((size_t)ng, 0.0), xl((size_t)N), yl((size_t)N), r0((size_t)ng, 0.0);
+  for (int i = 0; i < N; i++) x0[l2g[i]] = u_host[i], b0[l2g[i]] += f[i];
+  auto assembled_residual = [&](bool zero_dirichlet, double *rn, double *bn) -> int {
+    // r = A x0 - b: A applied through the local matrices (MatMult_IS: scatter, local products, add); zero_dirichlet: the Dirichlet rows / columns zeroed with a unit diagonal
+    // and b_dir = 0 (MatZeroRowsColumnsIS(child->A, isDir, 1.0, dir = 0, b) :1926-1933)
+    std::vector<char> isd((size_t)N, 0);
+    if (zero_dirichlet)
+      for (int q = 0; q < n_dir; q++) isd[dir_local[q]] = 1;
+    for (int i = 0; i < N; i++) xl[i] = isd[i] ? 0.0 : x0[l2g[i]];
+    PMH_CHK(pmh_memcpy_h2d(ctx, d_u, xl.data(), sizeof(double) * (size_t)N));
+    double *d_y = nullptr;
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(N, 1), (void **)&d_y));
+    int rc = pmh_blockdiag_mult(Kb, d_u, d_y);
+    if (!rc) rc = pmh_memcpy_d2h(ctx, yl.data(), d_y, sizeof(double) * (size_t)N);
+    pmh_free(ctx, d_y);
+    PMH_CHK(rc);
+    std::fill(r0.begin(), r0.end(), 0.0);
+    std::vector<double> bb((size_t)ng, 0.0);
+    for (int i = 0; i < N; i++) {
+      if (isd[i]) r0[l2g[i]] += x0[l2g[i]]; // unit diagonal
+      else r0[l2g[i]] += yl[i], bb[l2g[i]] += f[i];
+    }
+    double sr = 0.0, sb = 0.0;
+    for (int g = 0; g < ng; g++) sr += (r0[g] - bb[g]) * (r0[g] - bb[g]), sb += bb[g] * bb[g];
+    *rn = std::sqrt(sr), *bn = std::sqrt(sb);
+    return PMH_SUCCESS;
+  };
+  const bool zeroed = o->matis_to_diag_norm && n_dir > 0; // see the comment above this function
+  if (o->matis_to_diag_norm) {
+    double rn = 0.0, bn = 0.0;
+    PMH_CHK(assembled_residual(n_dir > 0, &rn, &bn));
+    snprintf(line, sizeof(line), "Dirichlet in Hess: %d, r = ||Ax-b|| = %e, r/||b|| = %e\n", n_dir > 0 ? 0 : 1, rn, rn / bn);
+    text += line;
+  }
+  if (o->view_kkt) {
+    kkt("A*x - b + B'*lambda", zeroed ? k.prim_r_zeroed_operator : k.prim_r, k.prim_normb); // #1
+    be(false, k.prim_be, k.prim_normb);
+    double rn = 0.0, bn = 0.0;
+    PMH_CHK(assembled_residual(false, &rn, &bn));
+    kkt("A*x - b", zeroed ? bn : rn, bn);                                                  // #0
+  }
+  return PMH_SUCCESS;
+}
 
 extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
 {
@@ -235,6 +327,12 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
           const double a = -alpha[grow0[s] + k];
           for (int i = block_rowstart[s]; i < block_rowstart[s + 1]; i++) u_host[i] -= Rn[(size_t)k * N + i] * a;
         }
+    }
+    if (o->view_convergence || o->view_kkt || o->matis_to_diag_norm) {
+      std::string text;
+      GO(kspfeti_view(ctx, o, ks, ch, Kb, N, nsub, l2g, n_dir, dir_local, f, u_host, d_x, d_lam, d_u0, text));
+      if (o->view_buf && o->view_cap > 0) snprintf(o->view_buf, (size_t)o->view_cap, "%s", text.c_str());
+      else fputs(text.c_str(), stdout), fflush(stdout);
     }
   }
 done:

@@ -366,6 +366,9 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     else if (k == "dual_mat_inv_ksp_rtol") rc = get_real(t, &o->kplus_rtol) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_max_it") rc = get_int(t, &o->kplus_max_it) ? -1 : 1;
     else if (k == "feti") rc = get_bool(t, &b) ? -1 : 1; // the combination this driver always performs
+    else if (k == "qp_chain_view_kkt") rc = get_bool(t, &o->view_kkt) ? -1 : 1;
+    else if (k == "qps_view_convergence") rc = get_bool(t, &o->view_convergence) ? -1 : 1;
+    else if (k == "qpt_matis_to_diag_norm") rc = get_bool(t, &o->matis_to_diag_norm) ? -1 : 1;
     else rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
     if (rc < 0) return PMH_ERR_ARG;
     if (!rc) left += (left.empty() ? "-" : " -") + k;

@@ -88,7 +88,7 @@ def test_feti_driver_options():
 
     rc, o, left = parse("-pde_type Poisson -cells 7,8,9 -dim 3 -feti_gluing_type orth -qps_view_convergence -qp_chain_view_kkt")
     assert rc == 0 and o.gluing_type == 2 and (o.scale, o.regularize, o.lumped_pc, o.rtol) == (1, 1, 0, 1e-5)
-    assert left == ["-pde_type", "-cells", "-dim", "-qps_view_convergence", "-qp_chain_view_kkt"]
+    assert left == ["-pde_type", "-cells", "-dim"] and (o.view_convergence, o.view_kkt, o.matis_to_diag_norm) == (1, 1, 0)  # the two view keys configure the post-solve report
     rc, o, left = parse("-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type lumped")
     assert rc == 0 and o.lumped_pc == 1 and o.rtol == 1e-6 and o.gluing_type == 1
     rc, o, left = parse("-feti_gluing_type NONRED -SCALE_ON 0 -feti_gluing_exclude_dirichlet -regularize false -dual_mat_inv_ksp_rtol 1e-10 -qps_max_it 50")
