@@ -4,8 +4,9 @@
  * (the MATIS input), the ASSEMBLED right-hand side, the local-to-global map, the Dirichlet ends.  Where the reference calls
  * KSPSetType(ksp, KSPFETI) / KSPFETISetDirichlet / KSPSolve, this calls pmh_qpt_matis_split_rhs, pmh_kspfeti_solve and
  * pmh_qpt_matis_assemble_solution.
- *   ./feti_ex1 -ns 4 -ne 7 [-dir_in_hess] [-feti_gluing_type full] ...      prints "PERMON FETI CONVERGED_RTOL in 1 iteration"
- * (the last line of src/tutorials/feti/output/ex1_1.out / ex1_2.out, 4 ranks, -ne 7).
+ *   ./feti_ex1 -ns 4 -ne 7 -qp_chain_view_kkt -qpt_matis_to_diag_norm [-dir_in_hess] [-feti_gluing_type full] ...
+ * prints what the reference's test harness keeps of the tutorial's output (src/tutorials/feti/output/ex1_1.out / ex1_2.out, 4 ranks, -ne 7): the `r = ...` lines of
+ * every QP of the chain (written by pmh_kspfeti_solve, as QPChainPostSolve writes them inside KSPSolve) and "PERMON FETI CONVERGED_RTOL in 1 iteration".
  */
 #include <math.h>
 #include <stdio.h>
