@@ -115,5 +115,5 @@ def test_configs4_full_size_hessian_properties_and_pairing():
     os.environ.pop("PMH_SVM_NO_PAIRING", None)
     assert c_sep == c_pair, (c_sep, c_pair)
     assert np.linalg.norm(x_pair - x_sep) <= 1e-10 * np.linalg.norm(x_sep)
-    assert p_sep == 2 * c_sep[3] and p_pair < 0.75 * p_sep  # two passes over X per application when separate; the pairing removes a good part of them
+    assert 2 * c_sep[3] <= p_sep <= 2 * (c_sep[3] + 2) and p_pair < 0.75 * p_sep  # two passes over X per application when separate (the speculated product after the last step included); the pairing removes a good part of them
     ctx.close()
