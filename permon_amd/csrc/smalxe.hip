@@ -528,6 +528,7 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&Ap));
   double alpha, alpha1, beta, beta1 = 0, beta2, norm_rhs, ttol;
   int    rc = PMH_SUCCESS;
+  const bool monitor = getenv("PMH_KSP_MONITOR") != nullptr;
 #define PC_CHK(call) \
   if ((rc = (call))) break;
   st->iteration = 0;
@@ -544,6 +545,7 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
         PC_CHK(pmh_vec_copy(ctx, n, r, w));
       }
       PC_CHK(pmh_vec_norm2(ctx, n, w, &st->rnorm));
+      if (monitor) fprintf(stderr, "%3d KSP Residual norm %.12e (threshold %.12e)\n", st->iteration, st->rnorm, ttol); // -ksp_monitor's line (PMH_KSP_MONITOR=1)
       st->reason = PMH_CONVERGED_ITERATING; // QPSConvergedDefault
       if (st->iteration > max_it) st->reason = PMH_DIVERGED_ITS;
       else if (std::isnan(st->rnorm) || std::isinf(st->rnorm)) st->reason = PMH_DIVERGED_NANORINF;
