@@ -209,3 +209,67 @@ def test_gpu_ex71_elasticity_iteration_goldens(ctx, goldens, lumped):
     res = prob.K @ u - prob.f + prob.B.T @ lam
     assert np.linalg.norm(res) <= 1e-4 * np.linalg.norm(prob.f)
     assert np.linalg.norm(prob.B @ u) <= 1e-3 * np.linalg.norm(u)
+
+
+def test_nonred_final_residual_is_not_pinned_by_the_gluing():
+    """VERDICT r3 next #7(iii).  feti/output/ex71_1_feti_gluing_type-nonred.out ends at ||F lambda - d|| = 1.73e-04 after 16 iterations; this library stops after the same 16
+    iterations at 2.36e-04 (GPU) / 1.80e-04 (a host CG on the same B with a sparse direct K^{-1}).  Why that number cannot be pinned:
+      (a) the B of pmh_feti_gluing_from_l2g IS the reading of qpfeti.c:643-648 / :786-806 (m - 1 links per multi-node, every link between the LOWEST rank's copy and one other
+          copy in rank order, +-1/sqrt(m), the sort of the link ids at :708 a no-op because they are issued in global dof order) -- compared row for row below;
+      (b) CG's residual history on that B is reproducible to 4 digits up to iteration 15 and rounding-determined from iteration 16 on: a 1e-14 relative perturbation of f moves the
+          16th residual by several percent and the 17th by a factor of 2-3 (the Krylov space of the separated part of the spectrum is exhausted after 15 steps; what is left is
+          at the level the rounding of K^{-1} feeds in).  The golden's 1.73e-04 lies inside the spread of those perturbed runs.
+    full / orth stop at iteration 9, well before that regime, and are reproduced to the printed digits (test_*_ex71_poisson_iteration_goldens)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    prob = DmdaFeti((7, 8, 9), 6, "poisson", "nonred")
+    N, nd = prob.N, prob.ndof
+    l2g = np.concatenate([(np.asarray(g)[:, None] * nd + np.arange(nd)[None, :]).ravel() for g in prob.gids])
+    copies = {}
+    for i, g in enumerate(l2g):  # local dofs are numbered subdomain after subdomain: the copies of a global dof come out in rank order
+        copies.setdefault(int(g), []).append(i)
+    want = set()
+    for c in copies.values():
+        m = len(c)
+        for k in range(1, m):
+            want.add((c[0], c[k], round(1.0 / np.sqrt(m), 12)))
+    B = prob.B.tocsr()
+    got = set()
+    for r in range(B.shape[0]):
+        idx, val = B.indices[B.indptr[r]:B.indptr[r + 1]], B.data[B.indptr[r]:B.indptr[r + 1]]
+        assert idx.size == 2 and val[0] == -val[1]
+        o = np.argsort(idx)
+        assert val[o[0]] > 0  # +1 on the lower rank, -1 on the highest rank of the link (qpfeti.c:789-793)
+        got.add((int(idx[o[0]]), int(idx[o[1]]), round(abs(float(val[0])), 12)))
+    assert got == want and len(want) == 240
+
+    lu = spla.splu(prob.K.tocsc())
+
+    def history(pert, nit=18):
+        f = prob.f * (1.0 + pert * np.random.default_rng(1).standard_normal(N))
+        F = lambda v: B @ lu.solve(B.T @ v)  # noqa: E731
+        d = B @ lu.solve(f)
+        x, r = np.zeros(B.shape[0]), d.copy()
+        p, rr, h = r.copy(), float(r @ r), []
+        for _ in range(nit):
+            Ap = F(p)
+            a = rr / float(p @ Ap)
+            x += a * p
+            r -= a * Ap
+            rn = float(r @ r)
+            p = r + (rn / rr) * p
+            rr = rn
+            h.append(np.sqrt(rr))
+        return np.array(h), float(np.linalg.norm(d))
+
+    runs = [history(p) for p in (0.0, 1e-14, 1e-13, 1e-12, 1e-11)]
+    h0, nd0 = runs[0]
+    assert abs(nd0 - 29.2) < 0.15
+    assert h0[14] > 1e-5 * nd0 >= h0[15]  # 16 iterations at rtol 1e-5, as the golden says
+    for h, _ in runs[1:]:
+        assert np.allclose(h[:15], h0[:15], rtol=2e-3)  # reproducible up to iteration 15
+    r16 = np.array([h[15] for h, _ in runs])
+    r17 = np.array([h[16] for h, _ in runs])
+    assert r16.max() / r16.min() > 1.02 and r17.max() / r17.min() > 1.5  # rounding-determined from iteration 16 on
+    assert 0.9 * r16.min() <= 1.73e-4 <= 1.1 * r16.max()  # the golden's value is one sample of that spread

@@ -66,7 +66,14 @@ def test_ex71_elasticity_floating_slabs(ctx, goldens, regularize, lumped, explic
                                  options="-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type %s" % ("lumped" if lumped else "none"))  # feti/ex71.c:442
     gold = goldens["feti_ex71_2_lumped" if lumped else "feti_ex71_2_none"]["solves"][0]["iterations"]
     print("ex71_2 %s regularize=%s explicit=%s: %d iterations (golden %d)" % ("lumped" if lumped else "none", regularize, explicit, st.iteration, gold))
-    assert st.reason == 2 and abs(st.iteration - gold) <= (2 if regularize else 5) and st.coarse_dim == 36
+    assert st.reason == 2 and st.coarse_dim == 36
+    if not lumped:
+        assert st.iteration == gold == 66  # -dual_pc_dual_type none: the golden count on every K^+ (profiles/r04_ex71_2_residual_history.txt)
+    else:
+        # lumped: golden 26, here 27 (K_reg^{-1}) / 29 (Moore-Penrose).  The residual stalls at iterations 25-26 at 1.2-1.3 x the threshold (2.39e-04 ... 2.70e-04 against 2.04e-04, not
+        # monotone) and differs by 10 % between this library's own K^+ variants there; the reference's MUMPS-backed run passed the threshold at 26 with 2.00e-04 (0.98 x).  Same operator
+        # (pcdual.c:63-78: B K B' with the UNregularised K, projected as qptransform.c:119-127), a stall resolved by rounding: profiles/r04_ex71_2_residual_history.txt
+        assert abs(st.iteration - gold) <= (1 if regularize else 5)
     Rg, A, b = _assembled(prob, l2g)
     x = spla.spsolve(A, b)
     assert np.linalg.norm(u - Rg @ x) <= 1e-3 * np.linalg.norm(x)
