@@ -83,6 +83,11 @@ struct fx_shared {
   std::vector<int>       cls; // class of every block
   std::vector<fxs_class> C;
   pmh_gluing             Bc = nullptr;
+  // orbit storage: the multivector the GEMM gathers from holds every entry TWICE, [position][+x | -x][slot] -- the gather index (position << 1 | negative) addresses the signed
+  // value directly, no sign is applied to a loaded value inside the GEMM (a use of the loaded value in front of the products made every wave wait for all of a chunk's global
+  // loads before its first MFMA).  Bc2: the gluing that fills it (every leaf of Bc twice, the second with the opposite sign); Bc stays for B Y on the way back
+  pmh_gluing             Bc2 = nullptr;
+  double                *X2  = nullptr;
   double                *Wbase = nullptr, *X = nullptr, *Y = nullptr;
   long long              nX = 0, wtot = 0;
   int                   *d_wg = nullptr; // launch table: (class, group, first column, segment, first row, one-past-last row) per workgroup
@@ -484,11 +489,11 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm(const int *__restrict__ ite
 #pragma unroll
     for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
   };
-  auto gatherB = [&]() {
+  auto gatherB = [&]() { // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
+                         // put the wait for all of the chunk's global loads in front of the products)
 #pragma unroll
     for (int e = 0; e < NEB; e++) {
-      const double v = x[(long long)(gn[e] >> 1) * FXS_S + sl];
-      br[e]          = (gn[e] & 1) ? -v : v;
+      br[e] = x[(long long)gn[e] * FXS_S + sl];
     }
   };
   auto store = [&](int buf) {
@@ -511,10 +516,12 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm(const int *__restrict__ ite
   const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
   for (int kc = kc0; kc < kc1; kc++) {
     const int buf = (kc - kc0) & 1;
-    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied
-      loadA(kc + 1);
+    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
+                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order, and the compiler
+                        // counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
       gatherB();
       if (kc + 2 < kc1) loadG(kc + 2);
+      loadA(kc + 1);
     }
 #pragma unroll
     for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
@@ -587,11 +594,11 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ it
 #pragma unroll
     for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
   };
-  auto gatherB = [&]() {
+  auto gatherB = [&]() { // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
+                         // put the wait for all of the chunk's global loads in front of the products)
 #pragma unroll
     for (int e = 0; e < NEB; e++) {
-      const double v = x[(long long)(gn[e] >> 1) * FXS_S + sl];
-      br[e]          = (gn[e] & 1) ? -v : v;
+      br[e] = x[(long long)gn[e] * FXS_S + sl];
     }
   };
   auto store = [&](int buf) {
@@ -614,10 +621,12 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ it
   const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
   for (int kc = kc0; kc < kc1; kc++) {
     const int buf = (kc - kc0) & 1;
-    if (kc + 1 < kc1) {
-      loadA(kc + 1);
+    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
+                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order, and the compiler
+                        // counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
       gatherB();
       if (kc + 2 < kc1) loadG(kc + 2);
+      loadA(kc + 1);
     }
 #pragma unroll
     for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
@@ -641,9 +650,122 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ it
   }
 }
 
+// The same GEMM on the other fp64 shape of the matrix pipe, v_mfma_f64_16x16x4_f64: one instruction = a 16 x 16 tile over 4 k (2048 flop, 16 passes) where the 4x4x4_4b form
+// needs four (4 x 512 flop, 4 passes each).  Same flop rate, but a quarter of the instructions and half of the operand registers read per flop: A[m = l & 15][k = l >> 4],
+// B[k = l >> 4][n = l & 15], D column l & 15, rows (l >> 4) + 4 r in the 4 registers (scripts/micro/mfma_f64.hip).  Wave tile 16 NI x 64 (NI x 4 instruction tiles, 4 NI x 4
+// accumulator doubles per lane), workgroup tile 32 NI x 128 (2 x 2 waves); the LDS images are the ones of k_fxo_gemm (A) and k_fxo_gemm4 (B): per k step of 4 a lane reads
+// NI + 4 operands for 4 NI instructions of 64 cycles (k_fxo_gemm4<15>: 19 operands for 60 instructions of 16 cycles).
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+template <int NI>
+__global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
+                                                       const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
+                                                       const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
+{
+  constexpr int TM = 32 * NI, WR = 16 * NI, LDA = TM + 16;
+  __shared__ double As[2][FXO_TK][LDA];
+  __shared__ double Bs[2][FXO_TK][FXO_LDB4];
+  for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
+  __builtin_amdgcn_sched_barrier(0);
+  const int *w8 = items + 8 * it;
+  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
+  const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
+  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]);
+  const double *__restrict__ Ab = A + iteml[4 * it];
+  const double *__restrict__ x  = X + iteml[4 * it + 1];
+  double *__restrict__ C        = cpart + iteml[4 * it + 2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
+  const int  col = t % FXO_TN, kb = t / FXO_TN;
+  const int  ct  = coltab[iteml[4 * it + 3] + col];
+  const int  sl  = ct < 0 ? 0 : (ct & 7);
+  const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
+  dbl4       acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+  dbl2   ar[NEA];
+  double br[NEB];
+  int    gn[NEB];
+  auto loadA = [&](int kc) {
+    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM);
+#pragma unroll
+    for (int e = 0; e < NEA; e++)
+      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e));
+  };
+  auto loadG = [&](int kc) {
+#pragma unroll
+    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
+  };
+  auto gatherB = [&]() { // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
+                         // put the wait for all of the chunk's global loads in front of the products)
+#pragma unroll
+    for (int e = 0; e < NEB; e++) {
+      br[e] = x[(long long)gn[e] * FXS_S + sl];
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < NEA; e++) {
+      const int q = t + 256 * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
+      if (NQ % 256 == 0 || q < NQ) *(dbl2 *)&As[buf][k][r2] = ar[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
+  };
+  if (kc0 < kc1) {
+    loadG(kc0);
+    loadA(kc0);
+    gatherB();
+    if (kc0 + 1 < kc1) loadG(kc0 + 1);
+    store(0);
+  }
+  __syncthreads();
+  const int ka = lane >> 4, ra = lane & 15;
+  for (int kc = kc0; kc < kc1; kc++) {
+    const int buf = (kc - kc0) & 1;
+    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
+                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order, and the compiler
+                        // counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
+      gatherB();
+      if (kc + 2 < kc1) loadG(kc + 2);
+      loadA(kc + 1);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
+      double a[NI], b[4];
+#pragma unroll
+      for (int i = 0; i < NI; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 16 + ra];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 16 + ra];
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < kc1) store(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j][r];
+  }
+}
+
 // row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
+static bool fxo_mfma16() { static const bool on = getenv("PMH_FXO_MFMA16") != nullptr; return on; }
 static int fxo_row_tile(int M)
 {
+  if (fxo_mfma16()) { // 16-row instruction tiles: 128 or 96 rows per workgroup, whichever pads less
+    if (const char *e = getenv("PMH_FXO_TM")) {
+      const int v = atoi(e);
+      if (v == 128 || v == 96) return v;
+    }
+    return ((M + 95) / 96 * 96 < (M + 127) / 128 * 128) ? 96 : 128;
+  }
   if (const char *e = getenv("PMH_FXO_TM")) {
     const int v = atoi(e);
     if (v == 128 || v == 120 || v == 112 || v == 104 || v == 96) return v;
@@ -946,6 +1068,20 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     }
   }
   PMH_CHK(pmh_gluing_create(ctx, (int)std::max(1LL, xtot), B->n_lambda, B->n_leaves, rows.data(), B->h_root.data(), B->h_sign.data(), &S->Bc));
+  if (sym == 2) {
+    if (2 * xtot >= (1LL << 31)) return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_create_shared_orbit: the signed multivector numbering exceeds 32-bit indices");
+    std::vector<int>    rows2((size_t)std::max(1, 2 * B->n_leaves)), root2((size_t)std::max(1, 2 * B->n_leaves));
+    std::vector<double> sign2((size_t)std::max(1, 2 * B->n_leaves));
+    for (int i = 0; i < B->n_leaves; i++) {
+      const int slot_i = rows[i] % FXS_S, base = rows[i] - slot_i; // entry (position, slot) -> (position, +, slot) and (position, -, slot)
+      rows2[2 * i] = 2 * base + slot_i, rows2[2 * i + 1] = 2 * base + FXS_S + slot_i;
+      root2[2 * i] = root2[2 * i + 1] = B->h_root[i];
+      sign2[2 * i] = B->h_sign[i], sign2[2 * i + 1] = -B->h_sign[i];
+    }
+    PMH_CHK(pmh_gluing_create(ctx, (int)std::max(1LL, 2 * xtot), B->n_lambda, 2 * B->n_leaves, rows2.data(), root2.data(), sign2.data(), &S->Bc2));
+    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(32LL, 2 * xtot), (void **)&S->X2));
+    PMH_CHK(pmh_memset(ctx, S->X2, 0, sizeof(double) * (size_t)std::max(32LL, 2 * xtot)));
+  }
   {
     const size_t bytes = sizeof(double) * (size_t)std::max(32LL, wtot);
     hipError_t   e     = hipMalloc((void **)&S->Wbase, bytes);
@@ -993,6 +1129,8 @@ void fxs_destroy(fx_shared *S)
   if (S->d_items) pmh_free(ctx, S->d_items);
   if (S->d_wgfirst) pmh_free(ctx, S->d_wgfirst);
   pmh_gluing_destroy(S->Bc);
+  pmh_gluing_destroy(S->Bc2);
+  pmh_free(ctx, S->X2);
   if (S->Wbase) (void)hipFree(S->Wbase);
   if (S->Afund) (void)hipFree(S->Afund);
   if (S->cpart) pmh_free(ctx, S->cpart);
@@ -1535,7 +1673,7 @@ static int fxo_prepare(fx_shared *S)
           const fxo_unit &U = P.units[a.u];
           items.insert(items.end(), {c, U.g, U.mt, nt, a.k0, a.k1, a.sp, U.nct});
           iteml.push_back(C.aoff);
-          iteml.push_back(C.xoff + (long long)U.g * C.ld * FXS_S);
+          iteml.push_back(2 * (C.xoff + (long long)U.g * C.ld * FXS_S)); // in the signed multivector X2
           iteml.push_back(U.cbase + (long long)a.sp * C.tm * U.nct);
           iteml.push_back((long long)U.coff + (long long)nt * FXO_TN);
           len += a.k1 - a.k0;
@@ -1627,7 +1765,12 @@ static int fxo_gemm(fx_shared *S)
     if (!count) continue;
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
-                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first))
+                     (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first))
+    if (fxo_mfma16()) {
+      if (C.tm == 128) FXO_LAUNCH(k_fxo_gemm16<4>);
+      else if (C.tm == 96) FXO_LAUNCH(k_fxo_gemm16<3>);
+      else return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
+    } else
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
     case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;
@@ -1843,15 +1986,33 @@ static int fxs_gemm(fx_shared *S)
   return PMH_SUCCESS;
 }
 
+// X (position, slot) -> X2 (position, +-, slot): only for the dense kernel alone on a multivector handed in (pmh_fexplicit_dense_mult); the operator fills X2 by its own gluing
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_signed_copy(long long n, const double *__restrict__ X, double *__restrict__ X2)
+{
+  for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * PMH_BLOCK) {
+    const long long p = i / FXS_S, sl = i % FXS_S;
+    const double    v = X[i];
+    X2[2 * p * FXS_S + sl] = v, X2[(2 * p + 1) * FXS_S + sl] = -v;
+  }
+}
+
 int fxs_apply(fx_shared *S, const double *lambda, double *y)
 {
-  PMH_CHK(pmh_gluing_mult(S->Bc, lambda, S->X));
+  if (S->sym == 2) PMH_CHK(pmh_gluing_mult(S->Bc2, lambda, S->X2));
+  else PMH_CHK(pmh_gluing_mult(S->Bc, lambda, S->X));
   PMH_CHK(fxs_gemm(S));
   return pmh_gluing_mult_transpose(S->Bc, S->Y, y); // ends with the all-reduce on several GPUs
 }
 
 // the dense kernel alone (tests, tuning): Y = blockdiag(W_c) X on the multivectors as they stand
-int fxs_dense(fx_shared *S) { return fxs_gemm(S); }
+int fxs_dense(fx_shared *S)
+{
+  if (S->sym == 2 && S->nX > 0) {
+    hipLaunchKernelGGL(k_fxo_signed_copy, dim3((unsigned)std::min<long long>(4096, (S->nX + PMH_BLOCK - 1) / PMH_BLOCK)), dim3(PMH_BLOCK), 0, S->ctx->stream, S->nX, (const double *)S->X, S->X2);
+    PMH_HIP(hipGetLastError());
+  }
+  return fxs_gemm(S);
+}
 long long fxs_multivector_length(fx_shared *S) { return S->nX; }
 double   *fxs_X(fx_shared *S) { return S->X; }
 double   *fxs_Y(fx_shared *S) { return S->Y; }
