@@ -656,12 +656,28 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ it
 // accumulator doubles per lane), workgroup tile 32 NI x 128 (2 x 2 waves); the LDS images are the ones of k_fxo_gemm (A) and k_fxo_gemm4 (B): per k step of 4 a lane reads
 // NI + 4 operands for 4 NI instructions of 64 cycles (k_fxo_gemm4<15>: 19 operands for 60 instructions of 16 cycles).
 typedef double dbl4 __attribute__((ext_vector_type(4)));
-template <int NI>
+#ifdef FXO_TRACE // diagnostic build (make EXTRA=-DFXO_TRACE): cycle stamps of the phases of every chunk of a few workgroups' wave 0 (s_memrealtime, 100 MHz) and s_memtime (shader clock)
+__device__ unsigned long long *fxo_trace_buf;
+#define FXO_STAMP(slot)                                                                                              \
+  do {                                                                                                               \
+    if (trace_on) {                                                                                                  \
+      const unsigned long long ts_ = __builtin_readcyclecounter();                                                   \
+      if (lane == 0) fxo_trace_buf[((size_t)trace_wg * 64 + (size_t)trace_chunk) * 8 + (slot)] = ts_;                \
+    }                                                                                                                \
+  } while (0)
+#else
+#define FXO_STAMP(slot) \
+  do {                  \
+  } while (0)
+#endif
+// NWM waves down x (4 / NWM) across: NWM = 2: wave tile 16 NI x 64 (workgroup 32 NI x 128: 128 or 96 rows); NWM = 1: wave tile 16 NI x 32, the workgroup's rows are ANY multiple of 16
+// up to 144 (715 representatives pad to 720 = 5 x 144, as with the 4-row units of k_fxo_gemm4<15>; NI + 2 operand reads for 2 NI instructions per k step of 4)
+template <int NI, int NWM>
 __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                        const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
                                                        const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
 {
-  constexpr int TM = 32 * NI, WR = 16 * NI, LDA = TM + 16;
+  constexpr int NWN = 4 / NWM, NJ = FXO_TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
   __shared__ double Bs[2][FXO_TK][FXO_LDB4];
   for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
@@ -673,42 +689,53 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   const double *__restrict__ Ab = A + iteml[4 * it];
   const double *__restrict__ x  = X + iteml[4 * it + 1];
   double *__restrict__ C        = cpart + iteml[4 * it + 2];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
+  constexpr int NQ = FXO_TK * TM / 2, NEA = NQ / 256, RA = NQ % 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // a chunk of A: NEA passes of 16 bytes per lane + (RA = 128) one of 8
+  static_assert(RA == 0 || RA == 128, "row tile");
   const int  col = t % FXO_TN, kb = t / FXO_TN;
   const int  ct  = coltab[iteml[4 * it + 3] + col];
   const int  sl  = ct < 0 ? 0 : (ct & 7);
   const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
-  dbl4       acc[NI][4];
+  dbl4       acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; j++) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
   dbl2   ar[NEA];
+  double ar1 = 0.0;
   double br[NEB];
   int    gn[NEB];
-  auto loadA = [&](int kc) {
-    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM);
+  // Addresses as UNIFORM 64-bit bases (scalar registers) + 32-bit per-lane offsets: one 32-bit vector operation per gather and none per load of A or of an index
+  // (per-lane 64-bit pointers cost a sign extension, a 64-bit shift and a 64-bit add each -- vector-ALU cycles the fp64 products need)
+  const char *__restrict__ xb   = (const char *)x;
+  const char *__restrict__ gb   = (const char *)gidx;
+  const unsigned           slo  = 8u * (unsigned)sl;
+  const unsigned           goff = 4u * ((unsigned)(ct < 0 ? zrow : (ct >> 3)) * (unsigned)ldk + (unsigned)kb); // this lane's row of the index array (+ its k within a pass)
+  const unsigned           aoff = 16u * (unsigned)t;
+  auto loadA = [&](int kc) { // no lane is masked: a masked tail would move its load behind the products, next to the store that waits for it
+    const char *blk = (const char *)(Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM));
 #pragma unroll
-    for (int e = 0; e < NEA; e++)
-      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e));
+    for (int e = 0; e < NEA; e++) ar[e] = *(const dbl2 *)(blk + (aoff + 4096u * e));
+    if (RA) ar1 = *(const double *)(blk + (4096u * NEA + 8u * (unsigned)t));
   };
   auto loadG = [&](int kc) {
+    const char *gk = gb + 4 * (long long)kc * FXO_TK;
 #pragma unroll
-    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
+    for (int e = 0; e < NEB; e++) gn[e] = *(const int *)(gk + (goff + 4u * KPB * e));
   };
-  auto gatherB = [&]() { // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
-                         // put the wait for all of the chunk's global loads in front of the products)
+  auto gatherB = [&]() { // signed multivector: the index (position << 1 | negative) addresses the value with its sign; 64 bytes per (position, sign)
 #pragma unroll
-    for (int e = 0; e < NEB; e++) {
-      br[e] = x[(long long)gn[e] * FXS_S + sl];
-    }
+    for (int e = 0; e < NEB; e++) br[e] = *(const double *)(xb + ((unsigned)gn[e] * 64u + slo));
   };
   auto store = [&](int buf) {
 #pragma unroll
     for (int e = 0; e < NEA; e++) {
       const int q = t + 256 * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
-      if (NQ % 256 == 0 || q < NQ) *(dbl2 *)&As[buf][k][r2] = ar[e];
+      *(dbl2 *)&As[buf][k][r2] = ar[e];
+    }
+    if (RA) {
+      const int d = 512 * NEA + t;
+      As[buf][d / TM][d % TM] = ar1;
     }
 #pragma unroll
     for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
@@ -722,36 +749,52 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   }
   __syncthreads();
   const int ka = lane >> 4, ra = lane & 15;
+#ifdef FXO_TRACE
+  const bool trace_on = wave == 0 && (blockIdx.x % 37) == 0 && blockIdx.x / 37 < 8 && it == __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]);
+  const int  trace_wg = blockIdx.x / 37;
+#endif
   for (int kc = kc0; kc < kc1; kc++) {
     const int buf = (kc - kc0) & 1;
-    if (kc + 1 < kc1) { // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
-                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order, and the compiler
-                        // counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
-      gatherB();
-      if (kc + 2 < kc1) loadG(kc + 2);
-      loadA(kc + 1);
-    }
+#ifdef FXO_TRACE
+    const int trace_chunk = (kc - kc0) < 63 ? (kc - kc0) : 63;
+#endif
+    FXO_STAMP(0);
+    // The next chunk's operands travel while this chunk is multiplied -- WITHOUT a branch: the last iterations ask for the last chunk again (kn, kg clamped) and store it to the
+    // buffer nobody reads, so loads, products and stores are one basic block and the scheduler may place the address arithmetic and the loads among the products.  The gathers need
+    // the indices asked for one chunk ago (the only loads outstanding here), so they go first.
+    const int kn = kc + 1 < kc1 ? kc + 1 : kc1 - 1, kg = kc + 2 < kc1 ? kc + 2 : kc1 - 1;
+    gatherB();
+    loadG(kg);
+    loadA(kn);
+    FXO_STAMP(1);
 #pragma unroll
     for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
-      double a[NI], b[4];
+      double a[NI], b[NJ];
 #pragma unroll
       for (int i = 0; i < NI; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 16 + ra];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 16 + ra];
+      for (int j = 0; j < NJ; j++) b[j] = Bs[buf][4 * k4 + ka][wn * WC + j * 16 + ra];
 #pragma unroll
       for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kc + 1 < kc1) store(buf ^ 1);
+    FXO_STAMP(2);
+#ifdef FXO_TRACE
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0) only (gfx9 encoding: lgkmcnt / expcnt left at their maxima)
+    FXO_STAMP(3);
+#endif
+    store(buf ^ 1);
+    FXO_STAMP(4);
     __syncthreads();
+    FXO_STAMP(5);
   }
 #pragma unroll
   for (int i = 0; i < NI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j][r];
+      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * FXO_TN + wn * WC + j * 16 + ra] = acc[i][j][r];
   }
 }
 
@@ -759,12 +802,15 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 static bool fxo_mfma16() { static const bool on = getenv("PMH_FXO_MFMA16") != nullptr; return on; }
 static int fxo_row_tile(int M)
 {
-  if (fxo_mfma16()) { // 16-row instruction tiles: 128 or 96 rows per workgroup, whichever pads less
+  if (fxo_mfma16()) { // 16-row instruction tiles: the workgroup tile that pads least among 144, 128, 112, 96, 80 (ties: the larger tile)
     if (const char *e = getenv("PMH_FXO_TM")) {
       const int v = atoi(e);
-      if (v == 128 || v == 96) return v;
+      if (v == 144 || v == 128 || v == 112 || v == 96 || v == 80) return v;
     }
-    return ((M + 95) / 96 * 96 < (M + 127) / 128 * 128) ? 96 : 128;
+    int best = 144, pad = (M + 143) / 144 * 144;
+    for (int tm : {128, 112, 96, 80})
+      if ((M + tm - 1) / tm * tm < pad) pad = (M + tm - 1) / tm * tm, best = tm;
+    return best;
   }
   if (const char *e = getenv("PMH_FXO_TM")) {
     const int v = atoi(e);
@@ -1496,7 +1542,7 @@ static int fxo_prepare(fx_shared *S)
   }
   if (S->Afund) (void)hipFree(S->Afund);
   {
-    const size_t bytes = sizeof(double) * (size_t)std::max(32LL, atot);
+    const size_t bytes = sizeof(double) * (size_t)std::max(32LL, atot) + 8192; // (k_fxo_gemm16 loads whole 4 KB pieces: up to one piece past the last chunk, never used)
     hipError_t   e     = hipMalloc((void **)&S->Afund, bytes);
     if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "PMH_FX_CLASS_ORBIT: %.2f GB for the representatives' rows: %s", bytes / 1e9, hipGetErrorString(e));
     PMH_HIP(hipMemsetAsync(S->Afund, 0, bytes, ctx->stream));
@@ -1766,10 +1812,24 @@ static int fxo_gemm(fx_shared *S)
 #define FXO_LAUNCH(KERNEL)                                                                                                                                                                              \
   hipLaunchKernelGGL(KERNEL, dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, (const int *)(S->d_wg + S->ncls), \
                      (const int *)C.d_coltab, C.nsymp, (const double *)S->Afund, (const int *)C.d_gidx, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first))
+#ifdef FXO_TRACE
+    static unsigned long long *d_trace = nullptr;
+    static int                 traced  = 0;
+    if (!d_trace) {
+      PMH_HIP(hipMalloc((void **)&d_trace, sizeof(unsigned long long) * 8 * 64 * 8));
+      PMH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fxo_trace_buf), &d_trace, sizeof(d_trace)));
+    }
+    PMH_HIP(hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 64 * 8, st));
+#endif
     if (fxo_mfma16()) {
-      if (C.tm == 128) FXO_LAUNCH(k_fxo_gemm16<4>);
-      else if (C.tm == 96) FXO_LAUNCH(k_fxo_gemm16<3>);
-      else return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
+      switch (C.tm) {
+      case 144: FXO_LAUNCH((k_fxo_gemm16<9, 1>)); break;
+      case 128: FXO_LAUNCH((k_fxo_gemm16<4, 2>)); break;
+      case 112: FXO_LAUNCH((k_fxo_gemm16<7, 1>)); break;
+      case 96: FXO_LAUNCH((k_fxo_gemm16<3, 2>)); break;
+      case 80: FXO_LAUNCH((k_fxo_gemm16<5, 1>)); break;
+      default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
+      }
     } else
     switch (C.tm) {
     case 128: FXO_LAUNCH(k_fxo_gemm); break;
@@ -1780,6 +1840,21 @@ static int fxo_gemm(fx_shared *S)
     default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
     }
 #undef FXO_LAUNCH
+#ifdef FXO_TRACE
+    if (++traced == 300) { // one launch in the steady state of the bench
+      std::vector<unsigned long long> h(8 * 64 * 8);
+      PMH_HIP(hipStreamSynchronize(st));
+      PMH_HIP(hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+      for (int w = 0; w < 8; w++) {
+        fprintf(stderr, "FXO_TRACE workgroup %d (cycles of the shader clock; per chunk: loads issued | products | wait vmcnt | LDS store | barrier | total)\n", w * 37);
+        for (int ch = 0; ch < 63; ch++) {
+          const unsigned long long *q = &h[((size_t)w * 64 + ch) * 8];
+          if (!q[5]) break;
+          fprintf(stderr, "  chunk %2d: %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", ch, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+        }
+      }
+    }
+#endif
     if (C.fin_elems > 0)
       hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, (const int *)C.d_fintab,
                          (const int *)C.d_unittab, (const long long *)C.d_finbase, (const int *)C.d_lut, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
