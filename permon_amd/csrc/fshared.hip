@@ -656,6 +656,12 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ it
 // accumulator doubles per lane), workgroup tile 32 NI x 128 (2 x 2 waves); the LDS images are the ones of k_fxo_gemm (A) and k_fxo_gemm4 (B): per k step of 4 a lane reads
 // NI + 4 operands for 4 NI instructions of 64 cycles (k_fxo_gemm4<15>: 19 operands for 60 instructions of 16 cycles).
 typedef double dbl4 __attribute__((ext_vector_type(4)));
+#ifndef FXO_IL_MFMA
+#define FXO_IL_MFMA 2
+#endif
+#ifndef FXO_IL_VALU
+#define FXO_IL_VALU 4
+#endif
 #ifdef FXO_TRACE // diagnostic build (make EXTRA=-DFXO_TRACE): cycle stamps of the phases of every chunk of a few workgroups' wave 0 (s_memrealtime, 100 MHz) and s_memtime (shader clock)
 __device__ unsigned long long *fxo_trace_buf;
 #define FXO_STAMP(slot)                                                                                              \
@@ -766,7 +772,9 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
     gatherB();
     loadG(kg);
     loadA(kn);
+#ifdef FXO_TRACE_FULL
     FXO_STAMP(1);
+#endif
 #pragma unroll
     for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
       double a[NI], b[NJ];
@@ -779,13 +787,25 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+#ifndef FXO_NO_INTERLEAVE
+    // the loads and their address arithmetic one by one BETWEEN the products (a product occupies the pipe for 64 cycles; what the wave issues meanwhile is free, what it issues
+    // in a block of its own in front of the products is not): 3 products, 1 global load, 2 vector-ALU operations, ...
+#pragma unroll
+    for (int i = 0; i < NEB * 2 + NEA + (RA ? 1 : 0); i++) { // all loads within the first 2/3 of the products: the last one has a third of the chunk's products to arrive in
+      __builtin_amdgcn_sched_group_barrier(0x008, FXO_IL_MFMA, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, FXO_IL_VALU, 0);
+    }
+#endif
     FXO_STAMP(2);
-#ifdef FXO_TRACE
+#ifdef FXO_TRACE_FULL
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0) only (gfx9 encoding: lgkmcnt / expcnt left at their maxima)
     FXO_STAMP(3);
 #endif
     store(buf ^ 1);
+#ifdef FXO_TRACE_FULL
     FXO_STAMP(4);
+#endif
     __syncthreads();
     FXO_STAMP(5);
   }
@@ -799,7 +819,8 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 }
 
 // row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
-static bool fxo_mfma16() { static const bool on = getenv("PMH_FXO_MFMA16") != nullptr; return on; }
+// the orbit GEMM runs on v_mfma_f64_16x16x4_f64 (k_fxo_gemm16); PMH_FXO_MFMA4=1: the 4x4x4_4b kernels of rounds 2-3 (k_fxo_gemm / k_fxo_gemm4<NA>) for the A/B
+static bool fxo_mfma16() { return getenv("PMH_FXO_MFMA4") == nullptr; }
 static int fxo_row_tile(int M)
 {
   if (fxo_mfma16()) { // 16-row instruction tiles: the workgroup tile that pads least among 144, 128, 112, 96, 80 (ties: the larger tile)
@@ -1850,7 +1871,11 @@ static int fxo_gemm(fx_shared *S)
         for (int ch = 0; ch < 63; ch++) {
           const unsigned long long *q = &h[((size_t)w * 64 + ch) * 8];
           if (!q[5]) break;
+#ifdef FXO_TRACE_FULL
           fprintf(stderr, "  chunk %2d: %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", ch, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+#else
+          fprintf(stderr, "  chunk %2d: %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", ch, 0ULL, q[2] - q[0], 0ULL, 0ULL, q[5] - q[2], q[5] - q[0]); // loads + products | store + barrier
+#endif
         }
       }
     }

@@ -4,17 +4,17 @@
 set -o pipefail
 mkdir -p gpurun_out
 if [ -z "$NOTESTS" ]; then
-  PMH_FXO_MFMA16=1 python -m pytest tests/test_gpu_explicit.py -x -q > gpurun_out/ab16_tests.log 2>&1 || { tail -30 gpurun_out/ab16_tests.log; exit 1; }
+  python -m pytest tests/test_gpu_explicit.py -x -q > gpurun_out/ab16_tests.log 2>&1 || { tail -30 gpurun_out/ab16_tests.log; exit 1; }
   tail -2 gpurun_out/ab16_tests.log
 fi
 B="python bench.py --steps 216 --warmup 8 --no-c2 --no-iterative --no-cpu-baseline --no-dual-spmv"
 for v in ${VARIANTS:-base m16 m16_128}; do
   case $v in
-    base) env="" ;;
-    m16) env="PMH_FXO_MFMA16=1" ;;
-    s256) env="PMH_FXO_SLOTS=256" ;;
-    m16s256) env="PMH_FXO_MFMA16=1 PMH_FXO_SLOTS=256" ;;
-    m16_*) env="PMH_FXO_MFMA16=1 PMH_FXO_TM=${v#m16_}" ;;
+    base) env="PMH_FXO_MFMA4=1" ;;
+    m16) env="" ;;
+    s256) env="PMH_FXO_MFMA4=1 PMH_FXO_SLOTS=256" ;;
+    m16s256) env="PMH_FXO_SLOTS=256" ;;
+    m16_*) env="PMH_FXO_TM=${v#m16_}" ;;
   esac
   env $env $B --details gpurun_out/ab16_$v.json > gpurun_out/ab16_$v.line 2> gpurun_out/ab16_$v.err || { tail -5 gpurun_out/ab16_$v.err; exit 1; }
   python - <<P

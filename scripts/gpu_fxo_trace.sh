@@ -3,7 +3,7 @@
 set -o pipefail
 rm -f permon_amd/csrc/fshared.o
 make -C permon_amd/csrc -j8 -s all EXTRA=-DFXO_TRACE > gpurun_out/trace_build.log 2>&1 || { tail -5 gpurun_out/trace_build.log; exit 1; }
-env PMH_FXO_MFMA16=1 ${TRACE_ENV} python bench.py --steps 216 --warmup 8 --no-c2 --no-iterative --no-cpu-baseline --no-dual-spmv --details gpurun_out/trace_details.json > gpurun_out/trace.line 2> gpurun_out/trace.err
+env ${TRACE_ENV} python bench.py --steps 216 --warmup 8 --no-c2 --no-iterative --no-cpu-baseline --no-dual-spmv --details gpurun_out/trace_details.json > gpurun_out/trace.line 2> gpurun_out/trace.err
 grep -A48 "FXO_TRACE workgroup" gpurun_out/trace.err | head -120 > gpurun_out/fxo_trace.txt
 python - <<P
 import re,collections

@@ -73,6 +73,7 @@ def test_kernel_name_only():
     import bench
 
     assert bench.kernel_name_only("k_fxo_gemm / k_fxo_gemm4<NA> (row tile 128, or 8 NA): W_c is") == "k_fxo_gemm / k_fxo_gemm4<NA>"
+    assert bench.kernel_name_only("k_fxo_gemm16<NI, NWM> (+ k_fxo_fin) (v_mfma_f64_16x16x4_f64; ...") == "k_fxo_gemm16<NI, NWM>"
     assert bench.kernel_name_only("k_bsr3<double>: the fp64 K x") == "k_bsr3<double>"
     assert bench.kernel_name_only("k_svm_x64_p1 + k_svm_x64_grad (paired passes") == "k_svm_x64_p1 + k_svm_x64_grad"
     assert bench.kernel_name_only("k_spmv_stream") == "k_spmv_stream"

@@ -246,24 +246,37 @@ def test_class_sym_plan_balances_the_tile_bytes():
 
 
 def test_orbit_row_tile_rule(monkeypatch):
-    """PMH_FX_CLASS_ORBIT (host helper, no GPU): the row tile of the orbit GEMM is 128 (16 rows per instruction operand) unless a tile of 8 NA = 96 ... 120
-    rows (4 rows per operand, ~2 % slower at equal size) pads the representatives' rows by more than 2.5 % less: configs[2]'s 715 -> 6 x 120 = 720."""
+    """PMH_FX_CLASS_ORBIT (host helper, no GPU): the row tile of the orbit GEMM.  Default kernel (k_fxo_gemm16, v_mfma_f64_16x16x4: 16 rows per instruction tile): the tile among
+    144, 128, 112, 96, 80 that pads the representatives' rows least (ties: the larger): configs[2]'s 715 -> 5 x 144 = 720.  PMH_FXO_MFMA4=1 (the 4x4x4_4b kernels of rounds 2-3):
+    128 unless a tile of 8 NA = 96 ... 120 rows pads by more than 2.5 % less: 715 -> 6 x 120."""
     import ctypes as C
 
     import permon_amd as pa
 
     L = pa.load()
     monkeypatch.delenv("PMH_FXO_TM", raising=False)
+    monkeypatch.delenv("PMH_FXO_MFMA4", raising=False)
 
     def rule(M):
         tm, Mp = C.c_int(), C.c_int()
         pa._lib.check(L.pmh_fexplicit_orbit_row_tile(M, C.byref(tm), C.byref(Mp)))
         return tm.value, Mp.value
 
+    assert rule(715) == (144, 720) and rule(144) == (144, 144) and rule(128) == (128, 128) and rule(1024) == (128, 1024)
+    assert rule(176) == (96, 192) or rule(176) == (80, 240) or rule(176)[1] == 192  # the configs[3] shape: 176 -> 192 (2 x 96)
+    assert rule(176) == (96, 192)
+    for M in range(1, 2000, 7):
+        tm, Mp = rule(M)
+        assert tm in (144, 128, 112, 96, 80) and Mp % tm == 0 and M <= Mp < M + tm
+        assert Mp <= min(-(-M // t) * t for t in (144, 128, 112, 96, 80))
+    monkeypatch.setenv("PMH_FXO_TM", "112")
+    assert rule(715) == (112, 784)
+    monkeypatch.delenv("PMH_FXO_TM")
+    monkeypatch.setenv("PMH_FXO_MFMA4", "1")
     assert rule(715) == (120, 720)
     assert rule(128) == (128, 128) and rule(1024) == (128, 1024) and rule(256) == (128, 256)
     assert rule(96) == (96, 96) and rule(1) == (96, 96)
-    assert rule(176) == (96, 192)  # the configs[3] shape
+    assert rule(176) == (96, 192)
     for M in range(1, 2000, 7):
         tm, Mp = rule(M)
         assert tm in (128, 120, 112, 104, 96) and Mp % tm == 0 and M <= Mp < M + tm
