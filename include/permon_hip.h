@@ -374,7 +374,7 @@ int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double *y);       
 int pmh_fexplicit_compressed_size(pmh_fexplicit E, int *ntot, int *gstart /* [nblocks+1] or NULL */);
 int pmh_fexplicit_dense_mult(pmh_fexplicit E, const double *xhat, double *yhat);        /* the dense kernel alone, compressed vectors */
 int pmh_fexplicit_timing_enable(pmh_fexplicit E, int max_launches, int stride);         /* HIP-event pairs around the GEMV launches */
-int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms, double *first_kernel_ms /* SYM: k_fx_symv alone; or NULL */);
+int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *total_ms, double *first_kernel_ms /* SYM: k_fx_symv alone; CLASS_ORBIT: the GEMM kernel alone (total - first = the finishing kernel); or NULL */);
 /* F = B K^+ B' built on this MATINV (pmh_op_create_feti_dual, the FETI chain) applies through E from now on (E built from the
    same B; NULL detaches).  K^+ f for a general f (d = B K^+ f - c, primal recovery) stays on the inner KSP. */
 int pmh_matinv_attach_explicit(pmh_matinv Kplus, pmh_fexplicit E);

@@ -1043,9 +1043,7 @@ extern "C" int pmh_fexplicit_timing_get(pmh_fexplicit E, int *launches, double *
 {
   PMH_ARG(E && launches && total_ms);
   if (E->sh) {
-    PMH_CHK(fxs_timing_get(E->sh, launches, total_ms));
-    if (first_kernel_ms) *first_kernel_ms = *total_ms;
-    return PMH_SUCCESS;
+    return fxs_timing_get(E->sh, launches, total_ms, first_kernel_ms); // orbit storage: first = the GEMM kernel alone
   }
   PMH_CHK(pmh_sync(E->ctx));
   double tot = 0.0, first = 0.0;

@@ -21,4 +21,4 @@ double   *fxs_Y(fx_shared *S);
 int       fxs_fill_pattern(fx_shared *S, int byte);
 int       fxs_get_block(fx_shared *S, int b, int n, const int *gamma, double *out_host);
 int       fxs_timing_enable(fx_shared *S, int max_launches);
-int       fxs_timing_get(fx_shared *S, int *launches, double *total_ms);
+int       fxs_timing_get(fx_shared *S, int *launches, double *total_ms, double *first_kernel_ms);

@@ -72,6 +72,7 @@ def test_default_workload_line_small():
     assert st["cg"] + st["expansion"] + st["proportioning"] == 30 and st["solves"] >= 1
     # what the matrix cores execute / launch time: the round-2/3 count (skipped k segments still in it) rides along under its own name
     assert r["flops_per_launch"] > 0 and r["frac_legacy_r02"] > 0 and abs(r["frac"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12 / 78.6) < 1e-9
+    assert 0 < r["avg_launch_ms"] < r["dense_apply_ms"] and r["finishing_kernel_ms"] > 0 and r["frac_dense_apply"] < r["frac"]  # avg_launch_ms = the GEMM kernel alone
     for k in ("iterative", "strict_fp64"):
         assert d[k]["value"] > 0 and ROOF <= set(d[k]["roofline"]) and "k_bsr3<double>" in d[k]["roofline"]["kernel"]
         assert 0 < d[k]["roofline"]["frac"] <= 1.0 and d[k]["roofline"]["blocks_per_device_copy"] == 8 and d[k]["roofline"]["blockdiag_figure_GBs"] > d[k]["roofline"]["achieved"]
