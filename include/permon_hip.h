@@ -193,9 +193,7 @@ int pmh_mpgp_set_operator_max_eigenvalue(pmh_mpgp s, double maxeig);   /* "QPSMP
 int pmh_mpgp_update_max_eigenvalue(pmh_mpgp s, double maxeig_update);  /* "QPSMPGPUpdateMaxEigenvalue_MPGP_C"      mpgp.c:119-143 */
 int pmh_mpgp_get_current_step_type(pmh_mpgp s, char *step);            /* "QPSMPGPGetCurrentStepType_MPGP_C"       mpgp.c:38-45  */
 int pmh_mpgp_reset_statistics(pmh_mpgp s);                             /* QPSResetStatistics_MPGP mpgp.c:654-664 */
-/* throughput mode for bench.py: run exactly `iters` iterations of the loop with the convergence test
-   evaluated but its verdict ignored (the work per iteration is unchanged) */
-int pmh_mpgp_run_fixed(pmh_mpgp s, int iters);
+int pmh_mpgp_get_tolerances(pmh_mpgp s, double *rtol, double *atol, double *divtol, int *max_it); /* QPSGetTolerances; any pointer may be NULL */
 
 /* ---- QPPF projector factory (src/qppf/interface/qppf.c) ----------------------------------------------- */
 typedef struct pmh_qppf_s *pmh_qppf;
@@ -456,9 +454,10 @@ int pmh_smalxe_solve(pmh_smalxe s);                                  /* QPSSolve
    number of Hessian multiplications reported then differs from the reference's for the same solve. */
 int pmh_smalxe_set_reuse_products(pmh_smalxe s, int on);
 int pmh_smalxe_get_stats(pmh_smalxe s, pmh_smalxe_stats *st);
-/* throughput mode for bench.py: the real solver loop for exactly `inner_iters` inner MPGP iterations in total (a solve that
-   converges earlier restarts from u = 0; counts accumulate over the restarts) */
-int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv);
+int pmh_smalxe_reset(pmh_smalxe s);                                  /* QPSReset: the state machine of the inner convergence test back to 1 (a solve from a fresh initial guess) */
+int pmh_smalxe_set_inner_max_it(pmh_smalxe s, int max_it);           /* the inner QPS's iteration limit, summed over the outer iterations (smalxe.c:626-631: DIVERGED_ITS / outer BREAKDOWN beyond it) */
+int pmh_smalxe_get_inner_max_it(pmh_smalxe s, int *max_it);
+int pmh_smalxe_get_solution(pmh_smalxe s, pmh_ctx *ctx, double **u, int *n); /* QPGetSolutionVector: the caller's device vector (+ context, length); any pointer may be NULL */
 int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
 /* ---- options front end (QPSSetFromOptions qps.c:860-900, _MPGP mpgp.c:712-745, _SMALXE smalxe.c:696-766) ----------
@@ -600,6 +599,13 @@ int pmh_feti_contact_default_opts(pmh_feti_contact_opts *o);
 int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, int n_lambda, int n_eq, int n_leaves,
                            const int *leaves_row, const int *leaves_root, const double *leaves_val, const double *c, int kdim, const double *R, const int *dims /* or NULL */, int ndof,
                            const pmh_feti_contact_opts *o, double *u_host, double *lambda_host /* or NULL */, pmh_feti_contact_stats *st);
+
+/* ---- bench-only shims (csrc/bench_shims.hip: written over the public hooks above, nothing inside the solvers) --------------------------------
+ * pmh_mpgp_run_fixed: exactly `iters` MPGP iterations (rtol = atol = 0, max_it = iters - 1 around pmh_mpgp_solve; the test is evaluated every iteration);
+ * pmh_smalxe_run_fixed: the real SMALXE loop for exactly `inner_iters` inner iterations in total (inner iteration limit = what is left of the budget; a solve
+ * that converges earlier restarts from u = 0 after pmh_smalxe_reset; counts accumulate over the restarts). */
+int pmh_mpgp_run_fixed(pmh_mpgp s, int iters);
+int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,7 @@ _PROTOS = {
     "pmh_mpgp_get_current_step_type": [vp, C.c_char_p],
     "pmh_mpgp_reset_statistics": [vp],
     "pmh_mpgp_run_fixed": [vp, C.c_int],
+    "pmh_mpgp_get_tolerances": [vp, c_double_p, c_double_p, c_double_p, c_int_p],
     "pmh_qppf_create": [vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_qppf_destroy": [vp],
     "pmh_qppf_orth_rhs": [vp, vp, vp],
@@ -229,6 +230,10 @@ _PROTOS = {
     "pmh_smalxe_get_stats": [vp, C.POINTER(SmalxeStats)],
     "pmh_smalxe_get_inner": [vp, C.POINTER(vp)],
     "pmh_smalxe_run_fixed": [vp, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
+    "pmh_smalxe_reset": [vp],
+    "pmh_smalxe_set_inner_max_it": [vp, C.c_int],
+    "pmh_smalxe_get_inner_max_it": [vp, c_int_p],
+    "pmh_smalxe_get_solution": [vp, C.POINTER(vp), C.POINTER(vp), c_int_p],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
     "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_mg_create_box": [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],

@@ -70,7 +70,6 @@ struct pmh_mpgp_s {
   std::vector<char>   t_step;
   std::vector<double> t_gp, t_gf, t_gc, t_alpha;
   // throughput mode
-  int fixed_iters;
   // speculative device-side CG chain
   int    *d_ctl, *h_ctl;
   double *d_ring, *h_ring;
@@ -117,7 +116,7 @@ struct pmh_spec_args { // constants of one solve, passed by value
   int    *ctl;   // device: [halt, iteration, ncg, base]
   double *ring;  // device: per device-side iteration (|gP|^2, |gf|^2, |gc|^2) for the monitor trace
   int     ring_cap;
-  int     max_it, fixed_iters;
+  int     max_it;
   double  ttol, divtol_rhs, gamma2;
 };
 
@@ -137,8 +136,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const do
     const int    it  = sa.ctl[CTL_ITER];
     const double gP2 = scal[S_GP2], gc2 = scal[S_GC2], gf2 = scal[S_GF2], rnorm = sqrt(gP2);
     bool         go;
-    if (sa.fixed_iters >= 0) go = it < sa.fixed_iters;
-    else go = (it <= sa.max_it) && (rnorm > sa.ttol) && (rnorm < sa.divtol_rhs); // NaN fails every comparison -> halt
+    go = (it <= sa.max_it) && (rnorm > sa.ttol) && (rnorm < sa.divtol_rhs); // NaN fails every comparison -> halt
     go = go && (gc2 <= sa.gamma2 * gf2) && (acg <= scal[S_FEAS]) && (it - sa.ctl[CTL_BASE] < sa.ring_cap);
     if (!go) {
       if (blockIdx.x == 0 && threadIdx.x == 0) sa.ctl[CTL_HALT] = 1; // every workgroup reaches the same verdict
@@ -340,7 +338,6 @@ extern "C" int pmh_mpgp_create(pmh_ctx ctx, pmh_op A, const double *b, double *x
   s->iteration = 0, s->reason = 0;
   s->nmv = s->ncg = s->nexp = s->nprop = s->nfinc = s->nfall = 0;
   s->step           = ' ';
-  s->fixed_iters    = -1;
   s->fallback_state = s->o.fallback;
   s->d_ctl = s->h_ctl = nullptr;
   s->d_ring = s->h_ring = nullptr;
@@ -494,7 +491,6 @@ static int test_convergence(pmh_mpgp s)
   } else {
     PMH_CHK(converged_default(s));
   }
-  if (s->fixed_iters >= 0) s->reason = (s->iteration >= s->fixed_iters) ? PMH_CONVERGED_ITS : PMH_CONVERGED_ITERATING; // throughput mode
   return PMH_SUCCESS;
 }
 
@@ -871,7 +867,7 @@ static int solve_fused(pmh_mpgp s)
       s->cvg_setup    = 1;
     }
     sa.ctl = s->d_ctl, sa.ring = s->d_ring, sa.ring_cap = SPEC_BATCH;
-    sa.max_it = s->o.max_it, sa.fixed_iters = s->fixed_iters;
+    sa.max_it = s->o.max_it;
     sa.ttol = s->ttol, sa.divtol_rhs = s->o.divtol * s->norm_rhs_div, sa.gamma2 = gamma2;
   }
   // length of the next speculative batch: a batch that ran to its end doubles it, one that halted early cuts it to what it ran (an expansion-heavy stretch
@@ -997,13 +993,14 @@ extern "C" int pmh_mpgp_solve(pmh_mpgp s)
   return rc;
 }
 
-extern "C" int pmh_mpgp_run_fixed(pmh_mpgp s, int iters)
+extern "C" int pmh_mpgp_get_tolerances(pmh_mpgp s, double *rtol, double *atol, double *divtol, int *max_it) // QPSGetTolerances
 {
-  PMH_ARG(s && iters >= 0);
-  s->fixed_iters = iters;
-  int rc         = pmh_mpgp_solve(s);
-  s->fixed_iters = -1;
-  return rc;
+  PMH_ARG(s);
+  if (rtol) *rtol = s->o.rtol;
+  if (atol) *atol = s->o.atol;
+  if (divtol) *divtol = s->o.divtol;
+  if (max_it) *max_it = s->o.max_it;
+  return PMH_SUCCESS;
 }
 
 extern "C" int pmh_mpgp_get_stats(pmh_mpgp s, pmh_mpgp_stats *st)

@@ -38,8 +38,6 @@ struct pmh_smalxe_s {
   int    BtBu_valid, inner_it_now;
   double lag_normBu0;
   int    lag_II, lag_J, lag_neval, lag_niter;
-  // throughput mode (pmh_smalxe_run_fixed): budget of inner iterations left, -1 = off
-  long long fixed_left;
   // pmh_smalxe_set_reuse_products: A_rho u is carried from the inner solve's last gradient into the Lagrangian and into the next inner solve's first gradient
   int reuse;
   int normBu_final_valid; // normBu / enorm are those of the current u (set by the inner convergence test)
@@ -214,10 +212,6 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
   s->BtBu_valid   = 0; // the inner solver has moved u
   if (update_normBu(s, s->u, &s->normBu, &s->enorm)) return 1;
   s->normBu_final_valid = 1; // (normBu / enorm are those of the current u; the next step of the inner solver is followed by another test)
-  if (s->fixed_left >= 0 && (long long)i >= s->fixed_left) { // throughput mode: the iteration budget ends this inner solve
-    *reason = PMH_CONVERGED_ITS;
-    return 0;
-  }
   s->rnorm      = fmax(s->enorm, gnorm);
   s->MNormBu    = s->M1 * s->normBu;
   s->inner_atol = fmin(s->MNormBu, s->eta);
@@ -227,7 +221,7 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
     const bool   gtol_on = !(s->state == 3 && (i < s->o.inner_iter_min || s->o.inner_no_gtol_stop));
     const double thr     = fmax(s->inner_atol, gtol_on ? s->gtol : 0.0);
     double       margin  = gnorm / fmax(thr, 1e-300);
-    if ((s->fixed_left >= 0 && (long long)(i + 1) >= s->fixed_left) || i + 1 > s->inner_max_it - s->inner_iter_accu) margin = 1e-300;
+    if (i + 1 > s->inner_max_it - s->inner_iter_accu) margin = 1e-300;
     (void)pmh_mpgp_set_convergence_margin(s->inner, margin);
   }
 
@@ -274,7 +268,6 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   s->ctx = ctx, s->A = A, s->b = b, s->u = u, s->lb = lb, s->ub = ub, s->pf = pf, s->o = *o, s->n = A->n;
   s->state  = 1;
   s->normBu = s->normBu_old = s->enorm = NAN;
-  s->fixed_left = -1;
   s->reuse      = 0;
   const int n = s->n;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)n, (void **)&s->BtBu));
@@ -436,10 +429,6 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->inner_it_now = st.iteration;
     s->BtBu_valid   = 0;
     s->iteration = i + 1;
-    if (s->fixed_left >= 0) {
-      s->fixed_left -= st.iteration;
-      if (s->fixed_left <= 0) break;
-    }
     // QPSSMALXEUpdateNormBu after the inner solve (smalxe.c:977): the inner solver's last convergence test evaluated ||B u|| for this very u (inner_converged calls the same
     // function on s->u and nothing has moved u since) -- the value is at hand, a second evaluation would cost two launches and a host round trip for the same bits.  Not
     // with the lagged update (its in-solve value may be the approximate one) or a caller-supplied B'B-only path
@@ -462,34 +451,37 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
   return PMH_SUCCESS;
 }
 
-// Throughput mode of bench.py: the REAL solver loop (outer updates of lambda, M1, rho and the inner stopping rule included) for
-// exactly `inner_iters` inner MPGP iterations in total; a solve that converges earlier is restarted from u = 0 (the statistics
-// of the restarts accumulate in *cg / *exp / *prop / *mv), the last one is cut when the budget is spent.
-extern "C" int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv)
+// QPSReset for a solver object that is to solve again from a fresh initial guess: the state machine of QPSConverged_Inner_SMALXE back to 1 (as after QPSCreate, smalxe.c:1149)
+extern "C" int pmh_smalxe_reset(pmh_smalxe s)
 {
-  PMH_ARG(s && inner_iters >= 0);
-  long long left = inner_iters;
-  int       ns = 0, no = 0, cg = 0, ex = 0, pr = 0, mv = 0;
-  while (left > 0) {
-    PMH_CHK(pmh_memset(s->ctx, s->u, 0, sizeof(double) * (size_t)s->n));
-    s->state      = 1;
-    s->fixed_left = left;
-    int rc        = pmh_smalxe_solve(s);
-    s->fixed_left = -1;
-    if (rc) return rc;
-    pmh_mpgp_stats st;
-    PMH_CHK(pmh_mpgp_get_stats(s->inner, &st));
-    cg += st.ncg, ex += st.nexp, pr += st.nprop, mv += st.nmv;
-    ns++, no += s->iteration;
-    if (s->inner_iter_accu <= 0) return pmh_set_error(PMH_ERR_STATE, "pmh_smalxe_run_fixed: the solve made no inner iteration");
-    left -= s->inner_iter_accu;
-  }
-  if (solves) *solves = ns;
-  if (outer_iters) *outer_iters = no;
-  if (ncg) *ncg = cg;
-  if (nexp) *nexp = ex;
-  if (nprop) *nprop = pr;
-  if (nmv) *nmv = mv;
+  PMH_ARG(s);
+  s->state = 1;
+  return PMH_SUCCESS;
+}
+
+// the limit of the inner solver's iterations summed over the outer iterations (the inner QPS's max_it: QPSConverged_Inner_SMALXE smalxe.c:626-631 ends the solve with
+// DIVERGED_ITS / outer DIVERGED_BREAKDOWN once inner iteration i > max_it - accumulated)
+extern "C" int pmh_smalxe_set_inner_max_it(pmh_smalxe s, int max_it)
+{
+  PMH_ARG(s && max_it >= 0);
+  s->inner_max_it = max_it;
+  return PMH_SUCCESS;
+}
+
+// QPGetSolutionVector of the QP this solver works on (the caller's device vector handed to pmh_smalxe_create), with its context and length
+extern "C" int pmh_smalxe_get_solution(pmh_smalxe s, pmh_ctx *ctx, double **u, int *n)
+{
+  PMH_ARG(s);
+  if (ctx) *ctx = s->ctx;
+  if (u) *u = s->u;
+  if (n) *n = s->n;
+  return PMH_SUCCESS;
+}
+
+extern "C" int pmh_smalxe_get_inner_max_it(pmh_smalxe s, int *max_it)
+{
+  PMH_ARG(s && max_it);
+  *max_it = s->inner_max_it;
   return PMH_SUCCESS;
 }
 
