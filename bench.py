@@ -559,10 +559,7 @@ def dual_spmv_hbm(ctx, f, reps=20):
     nl, ms, csr_b, hbm_b, cp = timed()
     y_csr = y.to_numpy().copy()
     out["csr"] = {"kernel": "k_spmv_stream (row-blocked CSR: coalesced tile loads, LDS partial sums, wavefront shuffle reduction)", "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": csr_b,
-                  "bytes_note": "SURVEY 8d: 12 nnz + 20 n (fp64 value + int32 column per non-zero).  The kernel streams a device-private copy of the columns as 16-bit offsets per row block "
-                                "(a row block of a banded K_i spans < 65 536 columns): `streamed_bytes_per_launch` = 10 nnz + 20 n is what HBM has to deliver, `streamed_GBs` / `frac_streamed` the rate on that",
-                  "achieved": csr_b / (ms / nl) / 1e6, "frac": csr_b / (ms / nl) / 1e6 / HBM_PEAK_GBS, "device_copies": cp,
-                  "streamed_bytes_per_launch": hbm_b, "streamed_GBs": hbm_b / (ms / nl) / 1e6, "frac_streamed": hbm_b / (ms / nl) / 1e6 / HBM_PEAK_GBS}
+                  "bytes_note": "SURVEY 8d: 12 nnz + 20 n", "achieved": csr_b / (ms / nl) / 1e6, "frac": csr_b / (ms / nl) / 1e6 / HBM_PEAK_GBS, "device_copies": cp}
     try:
         K.enable_bsr3(share=False)
         nl, ms, csr_b, hbm_b, cp = timed()

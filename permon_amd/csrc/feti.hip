@@ -277,7 +277,7 @@ extern "C" int pmh_blockdiag_timing_get(pmh_blockdiag K, int *launches, double *
     if (device_copies) *device_copies = pmh_bsr3_replicas(K->Kb) > 1 ? 1 : K->nblocks;
     return pmh_bsr3_timing_get(K->Kb, launches, total_ms);
   }
-  if (hbm_bytes) *hbm_bytes = csr - (K->K->d_col16 ? 2.0 * (double)K->K->nnz : 0.0); // the stream kernel reads a device-private copy of the columns as 16-bit offsets per row block where it can: 10 B per non-zero
+  if (hbm_bytes) *hbm_bytes = csr;
   if (device_copies) *device_copies = K->nblocks;
   return pmh_csr_timing_get(K->K, PMH_EPI_NONE, launches, total_ms);
 }

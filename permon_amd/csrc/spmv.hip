@@ -526,7 +526,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
     A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb - 1, rb); // -1: room for the aligned-down start of the 16-byte load variant
     PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowblocks, rb.data(), sizeof(int) * rb.size()));
-    if ((A->st_rl == 1 || A->st_rl == 8) && !(A->st_nt & 2) && A->st_nnzb <= 2048 && !getenv("PMH_SPMV_NO_COL16")) { // (medium rows too: the K_i of MatMult_BlockDiag -- a row block of 2048 entries spans ~25 rows of a banded block)
+    if (A->st_rl == 1 && !(A->st_nt & 2) && A->st_nnzb <= 2048 && !getenv("PMH_SPMV_NO_COL16")) {
       // 16-bit column offsets per row block where every block spans < 65 536 columns (device-private copy next to the int32 indices)
       std::vector<int>            cb((size_t)A->n_rowblocks, 0);
       std::vector<unsigned short> c16((size_t)nnz + 8, 0);
@@ -708,9 +708,9 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   if (A->kind == PMH_SPMV_STREAM) {
 #define ST_LAUNCH(NNZB, MODE, NT) \
   do { \
-    if constexpr ((((NT)&2) == 0) && NNZB <= 2048) { \
+    if constexpr (RLV == 1 && (((NT)&2) == 0) && NNZB <= 2048) { \
       if (A->d_col16) { \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, false, RLV, true>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl, \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_stream<EPI, NNZB, MODE, ((NT)&1) != 0, false, 1, true>), dim3(nl), dim3(PMH_BLOCK), 0, ctx->stream, A->d_rowblocks, A->n_rowblocks, (A->n_rowblocks + 7) / 8, A->d_rowptr, A->d_col, A->d_val, x, y, a, A->d_blockpart, nl, \
                            (const unsigned short *)A->d_col16, (const int *)A->d_cbase); \
         break; \
       } \
