@@ -509,7 +509,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   PMH_CHK(pmh_memcpy_h2d(ctx, A->d_val, val, sizeof(double) * (size_t)nnz));
 
   const double avg = nrows ? (double)nnz / nrows : 0.0;
-  int medium_stream = 1, m_nnzb = 2048, m_mode = 0, m_nt = 1; // measured best on 81 nnz/row K_i: 5.0 TB/s (profiles/)
+  int medium_stream = 1, m_nnzb = 2048, m_mode = 0, m_nt = 3; // measured best on 81 nnz/row K_i (round 4 sweep at 43^3 x 8 distinct blocks: nt 3 = non-temporal 16-byte value / 8-byte column loads 0.391 ms, nt 1 0.406; 1024 / 4096 entries per row block 0.41 / 0.43)
   if (const char *t = getenv("PMH_SPMV_MTUNE")) sscanf(t, "%d,%d,%d,%d", &medium_stream, &m_nnzb, &m_mode, &m_nt); // medium-row tuning knob
   const bool medium = avg > 24.0 && avg <= 256.0 && medium_stream;
   if (avg <= 24.0 || avg > 1024.0 || medium) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
