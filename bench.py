@@ -229,7 +229,7 @@ def run_c2(ctx, a, steps, warmup, cpu=True, whole_solves=False):
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv_ell<MPGP epilogue> (uniformly short rows: slot-major device copy, one thread per row, no LDS staging; k_spmv_stream otherwise): Ap = A p fused with p'Ap, g'p, QPCFeas",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            **dict(zip(("traffic", "traffic_source"), (lambda t: t if t[0] is not None else pmc_lookup("void k_spmv_stream<3,", "r03_pmc_traffic_c2.json"))(pmc_lookup("void k_spmv_ell<3,", "r03_pmc_traffic_c2.json")) if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
+            **dict(zip(("traffic", "traffic_source"), (lambda t: t if t[0] is not None else pmc_lookup("void k_spmv_stream<3,", "r04_pmc_traffic_c2.json"))(pmc_lookup("void k_spmv_ell<3,", "r04_pmc_traffic_c2.json")) if (a.grid == 3162 and a.variant == "obstacle") else (None, "not the configuration of the committed PMC pass"))),
             "algorithmic_bytes_per_launch": b_p1, "launches_timed": n_p1, "avg_launch_ms": ms_p1 / n_p1 if n_p1 else None,
             "whole_iteration_GBs": alg / dt / 1e9, "whole_iteration_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
             "note": "algorithmic bytes are SURVEY 8d's CSR figure (12 B per non-zero: fp64 value + int32 column); the kernel streams a device-private copy of the columns as 16-bit offsets "
@@ -261,13 +261,13 @@ def svm_roofline(N, n, d, world, st, dt, passes):
     if N == 5000000 and world == 1:
         # HBM bytes per Hessian application from the committed PMC pass: all k_svm* launches, divided by the applications (= the launches of the second-pass kernels)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_configs4.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_configs4.json")))
             # a Hessian application of the steady state (a run of expansion steps) is ONE launch of either paired kernel + the 64-column sum before it
             pk = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k != "_meta" and ("k_svm_x64_grad" in k or "k_svm_x64_p1<1>" in k)]
             cs = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k != "_meta" and "k_svm_colsum_feas" in k]
             meta = pmc.get("_meta", {})
             if len(pk) == 2:
-                traffic, tsrc = sum(pk) / 2 + (cs[0] if cs else 0.0), "profiles/r03_pmc_traffic_configs4.json @ %s (%s): mean of k_svm_x64_grad and k_svm_x64_p1<1> (one launch = one application in a run of expansion steps) + k_svm_colsum_feas" % (meta.get("git", "?"), meta.get("command", "?"))
+                traffic, tsrc = sum(pk) / 2 + (cs[0] if cs else 0.0), "profiles/r04_pmc_traffic_configs4.json @ %s (%s): mean of k_svm_x64_grad and k_svm_x64_p1<1> (one launch = one application in a run of expansion steps) + k_svm_colsum_feas" % (meta.get("git", "?"), meta.get("command", "?"))
         except (OSError, ValueError) as ex:
             tsrc = "no PMC pass: %r" % (ex,)
     b_pair = 8.0 * n * d + 68.0 * n  # one pass over X + half of the 17 vectors the two fused passes of an expansion step read or write
@@ -573,8 +573,14 @@ def dual_spmv_hbm(ctx, f, reps=20):
     K.destroy()
     A.destroy()
     # headline of the block: the CSR kernel on the CSR bytes (what the metric names)
+    full = nsub == 8 and f.nel == 43
+    t_csr, src_csr = pmc_lookup("void k_spmv_stream<0, 2048", "r04_pmc_traffic_dual_spmv.json") if full else (None, "not the configuration of the committed PMC pass")
+    t_bsr, src_bsr = pmc_lookup("void k_bsr3<double", "r04_pmc_traffic_dual_spmv.json") if full else (None, "not the configuration of the committed PMC pass")
+    out["csr"]["traffic"], out["csr"]["traffic_source"] = t_csr, src_csr
+    if "failed" not in out["bsr3"]:
+        out["bsr3"]["traffic"], out["bsr3"]["traffic_source"] = t_bsr, src_bsr
     out.update({"kernel": "k_spmv_stream", "achieved": out["csr"]["achieved"], "frac": out["csr"]["frac"], "algorithmic_bytes_per_launch": out["csr"]["algorithmic_bytes_per_launch"],
-                "avg_launch_ms": out["csr"]["avg_launch_ms"], "traffic": None})
+                "avg_launch_ms": out["csr"]["avg_launch_ms"], "traffic": t_csr, "traffic_source": src_csr})
     return out
 
 
@@ -739,7 +745,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kname = ("k_bsr3<double>: the fp64 K x of the block CG inside K^+ = the FETI dual SpMV (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
                  else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
-        traffic, tsrc = pmc_lookup(kpat, "r03_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
+        traffic, tsrc = pmc_lookup(kpat, "r04_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
         nrep = q.Kplus.bsr3_replicas() if not a.no_bsr3 else 1
         roof = {"bound": "hbm", "kernel": kname, "achieved": cg_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_GBs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": b_cg, "launches_timed": n_cg, "avg_launch_ms": ms_cg / n_cg if n_cg else None, "timing_stride": stride,
@@ -754,7 +760,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             pk = b_k / (ms_k / n_k * 1e-3) / 1e9 if n_k else 0.0
             ppat = {"fp16": ("void k_bsr3<_Float16", "_Z6k_bsr3IDF16_"), "fp32": "void k_bsr3<float", "fp64": "void k_bsr3<double"}[precision]
             # the fine-level instantiations only (tile size 1024; the second level runs the 512 ones)
-            ptraffic, ptsrc = pmc_lookup(ppat, "r03_pmc_traffic_feti_iterative.json", contains=("Li1024E", ", 1024>")) if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
+            ptraffic, ptsrc = pmc_lookup(ppat, "r04_pmc_traffic_feti_iterative.json", contains=("Li1024E", ", 1024>")) if (full_size and precision != "fp64") else (None, "fp64 cycle: same kernel as the CG product" if precision == "fp64" else "not the configuration of the committed PMC pass")
             roof["preconditioner"] = {"kernel": "k_bsr3<%s>: fine-level K x of the V-cycle (%s B per non-zero)" % {"fp16": ("_Float16 entries, float vectors", "2.44"), "fp32": ("float", "4.44"), "fp64": ("double", "8.44")}[precision],
                                       "achieved": pk, "frac": pk / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_k, "launches_timed": n_k, "avg_launch_ms": ms_k / n_k if n_k else None,
                                       "share_of_step_time": (ms_k * 1e-3) * stride / dt if n_k else None, "traffic": ptraffic, "traffic_source": ptsrc}
@@ -787,12 +793,12 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         storage_used = q.explicit_storage
         flops_k = E.apply_flops()
         ppref = {"class_orbit": (("k_fxo_gemm", "void k_fxo_gemm4<", "void k_fxo_gemm16<"), "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
-        # the committed PMC passes (scripts/gpu_final_r03_b.sh / _c.sh): the headline, the configs[3] block, the general (non-congruent) block
+        # the committed PMC passes (scripts/gpu_final_r04.sh): the headline, the configs[3] block, the general (non-congruent) block
         pmc_file = None
         if world == 1 and not a.sim_world:
-            pmc_file = ("r03_pmc_traffic_feti_explicit.json" if full_size else
-                        "r03_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
-                        "r03_pmc_traffic_general.json" if (a.nel == 21 and a.sub == "2,2,2" and not congruent) else None)
+            pmc_file = ("r04_pmc_traffic_feti_explicit.json" if full_size else
+                        "r04_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
+                        "r04_pmc_traffic_general.json" if (a.nel == 21 and a.sub == "2,2,2" and not congruent) else None)
         traffic, tsrc = pmc_lookup(ppref, pmc_file, combine="sum") if pmc_file else (None, "not the configuration of a committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
