@@ -830,7 +830,8 @@ static int solve_fused(pmh_mpgp s)
 
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
-  if (s->epi_ok < 0) s->epi_ok = (s->csr || s->o.distributed || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it
+  if (s->epi_ok < 0) s->epi_ok = (s->csr || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
+                                                                                  // partials are finalised at once and completed across the ranks, pmh_finalize_partials)
   if (s->g_valid) { // the caller carried g = A x - b over from the previous solve (pmh_smalxe_set_reuse_products): the split, p = gf and the norms only
     s->g_valid = 0;
     LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap);

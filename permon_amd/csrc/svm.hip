@@ -369,7 +369,9 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_colsum_feas(int nblocks, cons
 int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
 {
   const bool off = getenv("PMH_SVM_NO_PAIRING") != nullptr; // (read per call: tests switch it between two solves of one process)
-  if (off || d != 64 || n <= 0 || ctx->size > 1 || ctx->force_comm) return PMH_EPI_UNSUPPORTED; // (several GPUs: w and afeas would need their all-reduces between the passes -- not built)
+  if (off || d != 64 || n <= 0) return PMH_EPI_UNSUPPORTED;
+  // several GPUs (samples sharded by rows): the 64 column sums w and, where the next pass uses it, the feasible step length afeas are completed across the ranks between the
+  // passes -- the same exchange step as the lone application's, one (+ one 8-byte MIN) per pass
   if (!part_next) {
     grid_epi = pmh_vec_grid(n); // one partial sum per workgroup, where pmh_finalize_partials expects them
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)grid_epi * 64, (void **)&part_next));
@@ -387,6 +389,8 @@ int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
       SVM_PASS(k_svm_xt64<4>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, in, part);
       hipLaunchKernelGGL(k_svm_colsum, dim3(16), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
     }
+    PMH_HIP(hipGetLastError());
+    PMH_CHK(pmh_comm_allreduce_sum(ctx, w, 64));
     svm_grad_args a;
     a.b = e.b, a.x_in = spec ? (const double *)x_spec : in, a.lb = e.lb, a.ub = e.ub, a.x_out = spec ? e.x_out : nullptr, a.g = out, a.gf = e.gf, a.p = e.p;
     a.partials = e.partials, a.feas_part = feas_part, a.part_next = part_next, a.astol = e.astol, a.ld = e.ld, a.prow = e.prow;
@@ -403,6 +407,9 @@ int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
       SVM_PASS(k_svm_xt64<4>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, in, part);
       hipLaunchKernelGGL(k_svm_colsum, dim3(16), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
     }
+    PMH_HIP(hipGetLastError());
+    PMH_CHK(pmh_comm_allreduce_sum(ctx, w, 64));
+    if (paired) PMH_CHK(pmh_comm_allreduce_min(ctx, d_afeas, 1)); // the P1 pass forms the expansion iterate with it (k_svm_x64_p1<1>)
     svm_p1_args a;
     a.p = in, a.g = e.g, a.x = e.xx, a.lb = e.lb, a.ub = e.ub, a.afeas = d_afeas, a.Ap = out, a.partials = e.partials, a.x_spec = x_spec, a.part_next = part_next;
     a.alpha = e.spec_alpha, a.astol = e.astol, a.ld = e.ld, a.prow = e.prow;

@@ -60,8 +60,13 @@ def case_svm(ctx, rank, world):
         w = X.T @ (y * a)
         return 0.5 * float(w @ w) - float(a.sum())
 
-    # the single-rank references: the whole sample set on this process, no transport (separate passes over X: what the sharded run takes)
-    os.environ["PMH_SVM_NO_PAIRING"] = "1"
+    # the single-rank references: the whole sample set on this process, no transport.  PAIRING (argv[2]): the paired passes over X inside MPGP (the default; on two ranks w and
+    # the feasible step length are completed across the ranks between the passes) or the separate passes (PMH_SVM_NO_PAIRING=1)
+    if len(sys.argv) > 2 and sys.argv[2] == "separate":
+        os.environ["PMH_SVM_NO_PAIRING"] = "1"
+    else:
+        os.environ.pop("PMH_SVM_NO_PAIRING", None)
+    p_before = 0
     ref60, x60 = solve(X, y, False, 60)
     ref, x_ref = solve(X, y, False, 10000)
     assert ref.reason > 0, ref.reason

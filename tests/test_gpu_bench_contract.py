@@ -141,8 +141,8 @@ def test_forced_distributed_path_on_one_rank():
                  ("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"),
                  ("--nel", "9", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--sim-world", "2"),  # striped operators + replica solver + the all-reduce
                  ("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2")):
-        # (the SVM operator pairs its passes over X on one GPU without a communicator only: the local run takes the separate passes the forced-communicator run takes)
-        loc = run(dict(os.environ, PMH_SVM_NO_PAIRING="1"), *args)
+        # (round 4: the SVM operator pairs its passes over X with a communicator too -- w and the feasible step length are completed across the ranks between the passes)
+        loc = run(dict(os.environ), *args)
         dst = run(env, *args)
         assert loc["config"]["rccl_ranks"] is None and dst["config"]["rccl_ranks"] == 1
         assert loc["config"]["checksum"] == dst["config"]["checksum"], (loc["config"]["checksum"], dst["config"]["checksum"])

@@ -19,13 +19,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("case", ["svm", "feti_iterative", "feti_explicit"])
+@pytest.mark.parametrize("case", ["svm", "svm separate", "feti_iterative", "feti_explicit"])
 def test_world2_library_distributed_arithmetic(case):
     port = str(_free_port())
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_transport_worker.py"), case], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_transport_worker.py")] + case.split(), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         try:
