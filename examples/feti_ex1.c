@@ -4,7 +4,7 @@
  * (the MATIS input), the ASSEMBLED right-hand side, the local-to-global map, the Dirichlet ends.  Where the reference calls
  * KSPSetType(ksp, KSPFETI) / KSPFETISetDirichlet / KSPSolve, this calls pmh_qpt_matis_split_rhs, pmh_kspfeti_solve and
  * pmh_qpt_matis_assemble_solution.
- *   ./feti_ex1 -ns 4 -ne 7 -qp_chain_view_kkt -qpt_matis_to_diag_norm [-dir_in_hess] [-feti_gluing_type full] ...
+ *   ./feti_ex1 -ns 4 -ne 7 -qp_chain_view_kkt -qpt_matis_to_diag_norm [-dir_in_hess] [-feti_gluing_type full] [-project 0 -qps_smalxe_rho 1e1 -dual_qp_E_orth_type gs|implicit] ...
  * prints what the reference's test harness keeps of the tutorial's output (src/tutorials/feti/output/ex1_1.out / ex1_2.out, 4 ranks, -ne 7): the `r = ...` lines of
  * every QP of the chain (written by pmh_kspfeti_solve, as QPChainPostSolve writes them inside KSPSolve) and "PERMON FETI CONVERGED_RTOL in 1 iteration".
  */
@@ -83,6 +83,9 @@ int main(int argc, char **argv)
   char              left[512];
   CHK(pmh_init(0, &ctx));
   CHK(pmh_kspfeti_default_opts(&o));
+  /* The tutorial hands the reference no kernel of K: QPTDualize computes one and, having done so, switches to the left generalised inverse K^- P_R without regularisation
+     (qptransform.c:997-1008).  This library cannot compute kernels (it has no direct solver), so R is given above -- and the reference's choice of K^+ is made here. */
+  o.kplus_left = 1, o.regularize = 0;
   CHK(pmh_kspfeti_set_from_options(opts, &o, left, (int)sizeof(left)));
   CHK(pmh_kspfeti_solve(ctx, ns, rs, rowptr, col, val, f, l2g, n_dir, dir, 1, R, &o, u, NULL, 0, &st));
   CHK(pmh_qpt_matis_assemble_solution(N, l2g, u, ng, x));

@@ -281,6 +281,10 @@ int pmh_matinv_destroy(pmh_matinv Kplus);
    R_host: kdim (<= 8) columns of length n, column-major; rows of block b hold that block's orthonormal kernel basis */
 int pmh_matinv_set_nullspace(pmh_matinv Kplus, int kdim, const double *R_host);
 int pmh_matinv_mult(pmh_matinv Kplus, const double *f, double *u);
+/* -qpt_dualize_Kplus_left (QPTDualize qptransform.c:997-1062): K^+ := K^- P_R, what the reference takes when it had to compute the kernel itself.  K^- = the solve of a
+   factorisation with null-pivot detection: the fixing dofs (ascending local indices; identity rows / columns in the K given to pmh_matinv_create) carry 0 and their
+   equations are dropped.  Needs pmh_matinv_set_nullspace; the result is not projected.  nfix = 0: back to P_R K^- P_R. */
+int pmh_matinv_set_left_inverse(pmh_matinv Kplus, int nfix, const int *fix_dofs_host);
 int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *total_spmv);
 
 /* MatRegularize (src/mat/interface/permonmatregularize.c:198-287), the set-up step of the reference's default FETI path
@@ -458,6 +462,7 @@ int pmh_smalxe_reset(pmh_smalxe s);                                  /* QPSReset
 int pmh_smalxe_set_inner_max_it(pmh_smalxe s, int max_it);           /* the inner QPS's iteration limit, summed over the outer iterations (smalxe.c:626-631: DIVERGED_ITS / outer BREAKDOWN beyond it) */
 int pmh_smalxe_get_inner_max_it(pmh_smalxe s, int *max_it);
 int pmh_smalxe_get_solution(pmh_smalxe s, pmh_ctx *ctx, double **u, int *n); /* QPGetSolutionVector: the caller's device vector (+ context, length); any pointer may be NULL */
+int pmh_smalxe_get_penalized(pmh_smalxe s, pmh_op *A_rho, double **b_inner, double **Bt_mu); /* the penalised child QP (A + rho B'B, b - B'mu) and B'mu (borrowed; any may be NULL) */
 int pmh_smalxe_get_inner(pmh_smalxe s, pmh_mpgp *inner);             /* QPSSMALXEGetInnerQPS smalxe.c:492-507 (borrowed) */
 
 /* ---- options front end (QPSSetFromOptions qps.c:860-900, _MPGP mpgp.c:712-745, _SMALXE smalxe.c:696-766) ----------
@@ -537,6 +542,11 @@ typedef struct {
   int    scale;              /* -SCALE_ON (default 1) */
   int    exclude_dirichlet;  /* -feti_gluing_exclude_dirichlet (default 0) */
   int    regularize;         /* -regularize (default 1, qptransform.c:2215); 0: -qpt_dualize_Kplus_mp */
+  int    kplus_left;         /* -qpt_dualize_Kplus_left: K^+ = K^- P_R with the fixing dofs of MatRegularize as null pivots (pmh_matinv_set_left_inverse).  The reference switches to it,
+                                and to -regularize 0, by itself whenever the QP came without a kernel and it computed one (qptransform.c:997-1008) -- the case of feti/ex1.c */
+  int    project;            /* -project (default 1, set by -feti: QPTEnforceEqByProjector).  0: the equality constraint G lambda = e stays in the dual QP, which is homogenised and
+                                handed to QPS SMALXE (QPSSetDefaultType qps.c:437-441; QPTEnforceEqByPenalty inside SMALXE) -- `smalxe` below configures it */
+  int    E_orth_type;        /* -dual_qp_E_orth_type (QPTOrthonormalizeEqFromOptions qptransform.c:643-660; MatOrthTypes): 0 none, 1 gs (explicit T G, T e), 4 implicit */
   int    lumped_pc;          /* -dual_pc_dual_type lumped (default none) */
   double regularize_rho;     /* > 0: the rho of MatRegularize for every block; 0 (default): the reference's power-method estimate */
   double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */
@@ -549,11 +559,13 @@ typedef struct {
   int    matis_to_diag_norm; /* -qpt_matis_to_diag_norm: the "Dirichlet in Hess: .., r = ||Ax-b|| = .." line of QPTPostSolve_QPTMatISToBlockDiag (qptransform.c:1954-1979), and its
                                 side effect on the two QPs printed after it when the Dirichlet dofs are enforced by B (see pmh_kspfeti_solve in kspfeti.hip) */
   char  *view_buf; int view_cap; /* the text (full PETSc viewer lines, '\n'-separated, NUL-terminated, truncated to view_cap) goes here; NULL: to stdout */
+  pmh_smalxe_opts smalxe;    /* -qps_smalxe_* / -qps_smalxe_qps_* of the SMALXE solve taken with project == 0 (its outer tolerances are rtol / atol / divtol / max_it above) */
 } pmh_kspfeti_opts;
 typedef struct {
-  int    iteration, reason;
-  double rnorm;              /* ||P (F lambda - d)|| at exit */
+  int    iteration, reason;  /* CG iterations on P F; with project == 0 SMALXE's outer iterations */
+  double rnorm;              /* ||P (F lambda - d)|| at exit; with project == 0 SMALXE's max(||G x||, ||g||) */
   int    n_lambda, n_dirichlet_rows, coarse_dim;
+  pmh_smalxe_stats smalxe;   /* filled with project == 0 */
 } pmh_kspfeti_stats;
 /* vector part of QPTMatISToBlockDiag (qptransform.c:2095-2113: assembled rhs -> copies, interface values divided by their
    multiplicity) and of its post-solve (:1945-1949: INSERT_VALUES assembly of the solution, no averaging); host routines */

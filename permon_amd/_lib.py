@@ -72,14 +72,16 @@ class QpsOpts(C.Structure):
 
 
 class KspFetiOpts(C.Structure):
-    _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
+    _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("kplus_left", C.c_int), ("project", C.c_int),
+                ("E_orth_type", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
                 ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int),
                 ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("view_convergence", C.c_int), ("view_kkt", C.c_int), ("matis_to_diag_norm", C.c_int),
-                ("view_buf", C.c_char_p), ("view_cap", C.c_int)]
+                ("view_buf", C.c_char_p), ("view_cap", C.c_int), ("smalxe", SmalxeOpts)]
 
 
 class KspFetiStats(C.Structure):
-    _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("n_lambda", C.c_int), ("n_dirichlet_rows", C.c_int), ("coarse_dim", C.c_int)]
+    _fields_ = [("iteration", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("n_lambda", C.c_int), ("n_dirichlet_rows", C.c_int), ("coarse_dim", C.c_int),
+                ("smalxe", SmalxeStats)]
 
 
 class FetiContactOpts(C.Structure):
@@ -207,6 +209,7 @@ _PROTOS = {
     "pmh_matinv_create": [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_matinv_destroy": [vp],
     "pmh_matinv_set_nullspace": [vp, C.c_int, vp],
+    "pmh_matinv_set_left_inverse": [vp, C.c_int, vp],
     "pmh_matinv_mult": [vp, vp, vp],
     "pmh_matinv_last_iterations": [vp, c_int_p, C.POINTER(C.c_longlong)],
     "pmh_mat_regularize_pivots": [C.c_int, C.c_int, vp, vp],
@@ -234,6 +237,7 @@ _PROTOS = {
     "pmh_smalxe_set_inner_max_it": [vp, C.c_int],
     "pmh_smalxe_get_inner_max_it": [vp, c_int_p],
     "pmh_smalxe_get_solution": [vp, C.POINTER(vp), C.POINTER(vp), c_int_p],
+    "pmh_smalxe_get_penalized": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "pmh_pcpg_solve": [vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(PcpgStats)],
     "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_mg_create_box": [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],

@@ -597,6 +597,27 @@ extern "C" int pmh_matinv_set_nullspace(pmh_matinv M, int kdim, const double *R_
   return PMH_SUCCESS;
 }
 
+__global__ void k_zero_entries(int n, const int *__restrict__ idx, double *__restrict__ v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[idx[i]] = 0.0;
+}
+
+// K^+ := K^- P_R, the left generalised inverse QPTDualize takes when PERMON had to compute the kernel itself (qptransform.c:997-1008: "computed null space matrix => using
+// -qpt_dualize_Kplus_left and -regularize 0"; :1040-1062: MatCreateProd of P_R and K^-).  K^- is what a factorisation with null-pivot detection returns: the null-pivot
+// ("fixing") dofs carry a zero and their equations are dropped.  Here: the matrix handed to pmh_matinv_create has those dofs' rows / columns replaced by the identity (SPD),
+// this call names them (ascending local indices over all blocks) so that their right-hand side entries are zeroed, and the result is NOT projected.  nfix == 0 turns it off.
+extern "C" int pmh_matinv_set_left_inverse(pmh_matinv M, int nfix, const int *fix_dofs_host)
+{
+  PMH_ARG(M && nfix >= 0 && (nfix == 0 || fix_dofs_host));
+  for (int i = 0; i < nfix; i++) PMH_ARG(fix_dofs_host[i] >= 0 && fix_dofs_host[i] < M->n);
+  if (M->d_fix) pmh_free(M->ctx, M->d_fix), M->d_fix = nullptr;
+  M->left = nfix > 0, M->nfix = nfix;
+  if (!nfix) return PMH_SUCCESS;
+  PMH_CHK(pmh_malloc(M->ctx, sizeof(int) * (size_t)nfix, (void **)&M->d_fix));
+  return pmh_memcpy_h2d(M->ctx, M->d_fix, fix_dofs_host, sizeof(int) * (size_t)nfix);
+}
+
 // v_out = (I - R R') v, block-wise
 static int matinv_project(pmh_matinv M, const double *v, double *out)
 {
@@ -617,6 +638,7 @@ extern "C" int pmh_matinv_destroy(pmh_matinv M)
   if (M->d_coef) pmh_free(ctx, M->d_coef);
   if (M->d_fproj) pmh_free(ctx, M->d_fproj);
   if (M->d_kpart) pmh_free(ctx, M->d_kpart);
+  if (M->d_fix) pmh_free(ctx, M->d_fix);
   pmh_bsr3_destroy(M->Kb);
   pmh_free(ctx, M->dinv);
   pmh_free(ctx, M->r);
@@ -646,6 +668,10 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   if (M->kdim) { // f <- P_R f
     PMH_CHK(matinv_project(M, f, M->d_fproj));
     f = M->d_fproj;
+  }
+  if (M->left) { // the equations of the fixing dofs are dropped (their unknowns stay 0 through the identity rows of K)
+    if (!M->kdim) return pmh_set_error(PMH_ERR_STATE, "pmh_matinv_mult: the left generalised inverse needs the kernel (pmh_matinv_set_nullspace)");
+    hipLaunchKernelGGL(k_zero_entries, dim3((M->nfix + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, M->nfix, (const int *)M->d_fix, M->d_fproj);
   }
   PMH_HIP(hipMemsetAsync(M->d_nactive, 0, sizeof(int), st));
   const int extpc = M->mg ? 1 : 0;
@@ -696,7 +722,7 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
     }
   }
   M->last_max_its = M->h_nactive[1]; // largest per-block iteration count
-  if (M->kdim) { // u <- P_R u (in place through the scratch vector)
+  if (M->kdim && !M->left) { // u <- P_R u (in place through the scratch vector)
     PMH_CHK(matinv_project(M, u, M->d_fproj));
     PMH_CHK(pmh_memcpy_d2d(ctx, u, M->d_fproj, sizeof(double) * (size_t)M->n));
   }

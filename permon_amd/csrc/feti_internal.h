@@ -44,6 +44,10 @@ struct pmh_matinv_s {
   // P_R = I - R R', R = block-wise orthonormal kernel basis stored as kdim columns of length n
   int     kdim;
   double *d_R, *d_coef, *d_fproj, *d_kpart;
+  // left generalised inverse (QPTDualize's -qpt_dualize_Kplus_left, qptransform.c:1006-1062: K^+ := K^- P_R): no projection of the result, and the right-hand side entries of
+  // the fixing dofs (the null pivots of the reference's factorisation; identity rows / columns of the K handed in) are zeroed
+  int  left = 0, nfix = 0;
+  int *d_fix = nullptr;
   pmh_mg  mg; // optional V-cycle preconditioner (pmh_matinv_set_pc_mg); NULL: Jacobi / none
   pmh_bsr3 Kb; // optional 3x3-block copy of K for the CG's own product (pmh_matinv_enable_bsr3)
   pmh_fexplicit_s *E; // optional explicit K^+ on the dofs B touches (pmh_matinv_attach_explicit): F applies through it

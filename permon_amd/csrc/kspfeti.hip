@@ -7,7 +7,10 @@
 //        the gluing rows of QPFetiGetBgtSF (pmh_feti_gluing_from_l2g);
 //   K^+: MATINV on K_reg = MatRegularize(K, R) (-regularize 1, the default) or P_R K^- P_R (-regularize 0 -qpt_dualize_Kplus_mp);
 //   G  = R'B' (explicit, qptransform.c:838), e = R'f;  chain: pmh_qpt_feti_chain_create (dualize, homogenize, project);
+//        or, with -qpt_dualize_Kplus_left (what the reference switches to when it computed the kernel itself, qptransform.c:997-1008), K^- P_R;
 //   QPS: the dual QP has no box, so QPSSetDefaultType picks QPSKSP = CG on P F (qps.c:448) with PC none or P (B K B') (PCDUAL lumped);
+//        with -project 0 the equality constraint stays, the QP is homogenised and QPSSetDefaultType picks SMALXE (qps.c:437-441), optionally on orthonormalised G
+//        (-dual_qp_E_orth_type gs | implicit);
 //   post-solve: lambda = lambda_child + lambda~, u = K^+(f - B' lambda) - R alpha with G' alpha = d - F lambda (qptransform.c:783-833).
 // Host orchestration in C++; every operator application runs on the device.
 #include <algorithm>
@@ -33,8 +36,13 @@ struct LumpedOp : pmh_op_s { // PCApply_Dual lumped (pcdual.c:63-78) as an opera
 // the MATIS of #0 shares them) and restores them with MatCopy (:1967), which for MATBLOCKDIAG is PETSc's MatCopy_Basic: MatZeroEntries + a row loop the type has no MatGetRow
 // for -- what #1 and #0 print afterwards is consistent with an operator left at ZERO (feti/output/ex1_1.out: ||B' lambda - f|| = 2.31e-02 and ||b|| / ||b|| = 1.00e+00;
 // with -dir_in_hess, ex1_2.out, nothing is touched).  Reproduced as observed, said here so that nobody mistakes those two lines for residuals of the solve.
+static int kspfeti_view_smalxe(pmh_ctx ctx, const pmh_kspfeti_opts *o, pmh_smalxe S, pmh_feti_chain ch, const pmh_feti_chain_kkt &k, pmh_qppf pf0, const double *e0, int nl, int m,
+                               const double *d_x, const double *d_lam, std::string &text);
+
+// S != NULL: the dual QP was solved unprojected by SMALXE (-project 0); pf0 / e0: the projector of the plain G = R'B' and e = R'f
 static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_stats &ks, pmh_feti_chain ch, pmh_blockdiag Kb, int N, int nsub, const int *l2g, int n_dir, const int *dir_local,
-                        const double *f, const double *u_host, const double *d_x, const double *d_lam, double *d_u, std::string &text)
+                        const double *f, const double *u_host, const double *d_x, const double *d_lam, double *d_u, pmh_smalxe S, pmh_qppf pf0, const double *e0, int nl, int m,
+                        std::string &text)
 {
   (void)nsub;
   char line[256];
@@ -56,7 +64,11 @@ static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_s
     snprintf(line, sizeof(line), with_c ? "r = ||BE*x-cE||          = %.2e    r/||b|| = %.2e\n" : "r = ||BE*x||             = %.2e    r/||b|| = %.2e\n", r, r / nb);
     text += line;
   };
-  if (o->view_kkt) {
+  if (o->view_kkt && S) {
+    PMH_CHK(kspfeti_view_smalxe(ctx, o, S, ch, k, pf0, e0, nl, m, d_x, d_lam, text));
+    kkt("A*x - b + B'*lambda", k.prim_r, k.prim_normb);
+    be(false, k.prim_be, k.prim_normb);
+  } else if (o->view_kkt) {
     if (k.has_coarse) {
       kkt("A*x - b", k.proj_r, k.proj_normb);                 // #6
       kkt("A*x - b + (B'*lambda)", k.hom_r, k.hom_normb);     // #5
@@ -116,6 +128,111 @@ static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_s
   return PMH_SUCCESS;
 }
 
+
+// MatOrthRows with MAT_ORTH_GS, explicit form (permonmatorth.c:208-236 MatOrthColumns_GS_Default on the columns of G'): classical Gram-Schmidt -- all the dots against the
+// finished rows at once -- repeated while the norm has dropped to half or less; T collects the same row operations (TG0 = G, Te0 = e).  Host, dense m x n rows.
+static int orth_rows_gs(int m, int n, std::vector<double> &G, std::vector<double> &T)
+{
+  T.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++) T[(size_t)i * m + i] = 1.0;
+  std::vector<double> dots((size_t)std::max(m, 1));
+  auto nrm2 = [&](const double *v) {
+    double t = 0.0;
+    for (int k = 0; k < n; k++) t += v[k] * v[k];
+    return std::sqrt(t);
+  };
+  for (int i = 0; i < m; i++) {
+    double *q = &G[(size_t)i * n], norm = nrm2(q), norm_last;
+    do {
+      norm_last = norm;
+      for (int j = 0; j < i; j++) {
+        const double *qj = &G[(size_t)j * n];
+        double        t  = 0.0;
+        for (int k = 0; k < n; k++) t += q[k] * qj[k];
+        dots[j] = -t;
+      }
+      for (int j = 0; j < i; j++) {
+        const double *qj = &G[(size_t)j * n];
+        for (int k = 0; k < n; k++) q[k] += dots[j] * qj[k];
+        for (int k = 0; k < m; k++) T[(size_t)i * m + k] += dots[j] * T[(size_t)j * m + k];
+      }
+      norm = nrm2(q);
+      if (!(norm >= 1e2 * 2.220446049250313e-16)) return pmh_set_error(PMH_ERR_ARG, "pmh_kspfeti_solve: the rows 0 - %d of G are linearly dependent", i);
+    } while (norm <= 0.5 * norm_last);
+    for (int k = 0; k < n; k++) q[k] /= norm;
+    for (int k = 0; k < m; k++) T[(size_t)i * m + k] /= norm;
+  }
+  return PMH_SUCCESS;
+}
+
+// The -qp_chain_view_kkt lines of the QPs that differ when the dual QP is NOT projected (-project 0), last QP first (QPTAllInOne qptransform.c:2178-2207):
+//   QPTEnforceEqByPenalty (SMALXE's inner QP: A + rho G'G, b - B'mu), QPTHomogenizeEq (multiplier term B'mu, which QPSSolve_SMALXE leaves in Bt_lambda), [QPTOrthonormalizeEq: the
+//   same multiplier term -- QPTHomogenizeEqPostSolve copies it up -- against d; ||BE x - cE|| only when BE can be multiplied with, i.e. not for the implicit type, qp.c:303-318],
+//   then QPTScale / QPTDualize's child twice with G0, e0 and the multiplier term QPViewKKT computes itself for a QP that was handed none (QPTPostSolve_QPTOrthonormalizeEq skips
+//   both multipliers): r = 0 by construction.  Without orthonormalisation the last two print the homogenised QP's multiplier term as in the projected chain.
+static int kspfeti_view_smalxe(pmh_ctx ctx, const pmh_kspfeti_opts *o, pmh_smalxe S, pmh_feti_chain ch, const pmh_feti_chain_kkt &k, pmh_qppf pf0, const double *e0, int nl, int m,
+                               const double *d_x, const double *d_lam, std::string &text)
+{
+  char    line[256];
+  pmh_op  F = nullptr, Arho = nullptr;
+  double *d = nullptr, *bbar = nullptr, *b_in = nullptr, *btmu = nullptr, *t = nullptr, *gm = nullptr;
+  PMH_CHK(pmh_qpt_feti_chain_get(ch, &F, nullptr, &d, &bbar, nullptr, nullptr, nullptr));
+  PMH_CHK(pmh_smalxe_get_penalized(S, &Arho, &b_in, &btmu));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(nl, 1), (void **)&t));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(m, 1), (void **)&gm));
+  int    rc = PMH_SUCCESS;
+  double r7 = 0, nb7 = 0, r6 = 0, r5 = 0, be4 = 0;
+#define GO(call) \
+  do { \
+    if ((rc = (call))) goto done; \
+  } while (0)
+  GO(pmh_op_mult(Arho, d_x, t));
+  GO(pmh_vec_axpy(ctx, nl, t, -1.0, b_in));
+  GO(pmh_vec_norm2(ctx, nl, t, &r7));
+  GO(pmh_vec_norm2(ctx, nl, b_in, &nb7));
+  GO(pmh_op_mult(F, d_x, t));
+  GO(pmh_vec_axpy(ctx, nl, t, -1.0, bbar));
+  GO(pmh_vec_axpy(ctx, nl, t, 1.0, btmu));
+  GO(pmh_vec_norm2(ctx, nl, t, &r6));
+  GO(pmh_op_mult(F, d_lam, t));
+  GO(pmh_vec_axpy(ctx, nl, t, -1.0, d));
+  GO(pmh_vec_axpy(ctx, nl, t, 1.0, btmu));
+  GO(pmh_vec_norm2(ctx, nl, t, &r5));
+  {
+    std::vector<double> g((size_t)std::max(m, 1));
+    GO(pmh_qppf_apply_G(pf0, d_lam, gm));
+    GO(pmh_memcpy_d2h(ctx, g.data(), gm, sizeof(double) * (size_t)m));
+    for (int i = 0; i < m; i++) be4 += (g[i] - e0[i]) * (g[i] - e0[i]);
+    be4 = std::sqrt(be4);
+  }
+  {
+    auto kkt = [&](const char *name, double r, double nb) {
+      snprintf(line, sizeof(line), "r = ||%s|| = %.2e    rO/||b|| = %.2e\n", name, r, r / nb);
+      text += line;
+    };
+    auto be = [&](bool with_c, double r, double nb) {
+      snprintf(line, sizeof(line), with_c ? "r = ||BE*x-cE||          = %.2e    r/||b|| = %.2e\n" : "r = ||BE*x||             = %.2e    r/||b|| = %.2e\n", r, r / nb);
+      text += line;
+    };
+    kkt("A*x - b", r7, nb7);                                  // penalised
+    kkt("A*x - b + (B'*lambda)", r6, k.hom_normb);            // homogenised
+    be(false, k.hom_be, k.hom_normb);
+    if (o->E_orth_type) {                                     // orthonormalised
+      kkt("A*x - b + (B'*lambda)", r5, k.dual_normb);
+      if (o->E_orth_type == 4) text += "r = ||BE*x-cE||         not available\n";
+      else be(true, k.dual_be, k.dual_normb);
+    }
+    for (int rep = 0; rep < 2; rep++) {                       // QPTScale's child, QPTDualize's child
+      kkt("A*x - b + (B'*lambda)", o->E_orth_type ? 0.0 : r5, k.dual_normb);
+      be(true, be4, k.dual_normb);
+    }
+  }
+done:
+#undef GO
+  pmh_free(ctx, t), pmh_free(ctx, gm);
+  return rc;
+}
+
 extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
 {
   PMH_ARG(o);
@@ -123,6 +240,8 @@ extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
   o->gluing_type = 1;   // FETI_GLUING_FULL, qpfeti.c:322
   o->scale       = 1;   // -SCALE_ON, qpfeti.c:757
   o->regularize  = 1;   // QPTFromOptions qptransform.c:2215
+  o->project     = 1;   // -feti (qptransform.c:2224)
+  PMH_CHK(pmh_smalxe_default_opts(&o->smalxe));
   o->kplus_rtol = 1e-12, o->kplus_max_it = 20000; // a stand-in for "direct": the reference factorises K_reg
   o->rtol = 1e-5, o->atol = 1e-50, o->divtol = 1e4, o->max_it = 10000; // QPSCreate qps.c:73-76
   o->explicit_dual = 0, o->explicit_rtol = 1e-13;
@@ -196,7 +315,9 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
   pmh_blockdiag  Kb = nullptr, Kregb = nullptr;
   pmh_matinv     Kp = nullptr;
   pmh_gluing     B  = nullptr;
-  pmh_qppf       pf = nullptr;
+  pmh_qppf       pf = nullptr, pfo = nullptr; // of G = R'B'; of the orthonormalised G (-dual_qp_E_orth_type)
+  pmh_csr        Goc = nullptr;
+  pmh_smalxe     S  = nullptr;
   pmh_feti_chain ch = nullptr;
   pmh_fexplicit  E  = nullptr;
   LumpedOp      *lump = nullptr;
@@ -211,7 +332,41 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     GO(pmh_csr_create(ctx, N, N, rowptr, col, val, &Kc));
     GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kc, &Kb));
     const bool any_kernel = std::any_of(bdim.begin(), bdim.end(), [](int d) { return d > 0; });
-    if (o->regularize && any_kernel) {
+    if (o->kplus_left && any_kernel) {
+      // K^+ = K^- P_R (qptransform.c:1040-1062).  The reference's K^- is the MUMPS solve with null-pivot detection (MatInvComputeNullSpace's factorisation): the null pivots carry 0.
+      // Which dofs those are is MUMPS's choice; here they are the fixing dofs MatRegularize would take (permonmatregularize.c:57-124), one set per floating block, eliminated from
+      // K by identity rows / columns -- for feti/ex1.c that is an end dof of every subdomain, and the reference's outputs are reproduced with it (tests/test_gpu_feti_kkt_text.py).
+      if (o->explicit_dual) {
+        rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: K^- P_R is not symmetric, the explicit local dual operators store symmetric blocks");
+        goto done;
+      }
+      std::vector<int>  fix;
+      std::vector<char> isfix((size_t)N, 0);
+      for (int s = 0; s < nsub; s++) {
+        const int lo = block_rowstart[s], hi = block_rowstart[s + 1], p = hi - lo, d = bdim[s];
+        if (!d) continue;
+        std::vector<double> Rb((size_t)d * p);
+        std::vector<int>    piv((size_t)d);
+        for (int k = 0; k < d; k++) std::copy(&Rn[(size_t)k * N + lo], &Rn[(size_t)k * N + hi], &Rb[(size_t)k * p]);
+        GO(pmh_mat_regularize_pivots(p, d, Rb.data(), piv.data()));
+        for (int k = 0; k < d; k++) fix.push_back(lo + piv[k]), isfix[lo + piv[k]] = 1;
+      }
+      std::vector<int>    rp((size_t)N + 1, 0), ci;
+      std::vector<double> va;
+      ci.reserve((size_t)rowptr[N]), va.reserve((size_t)rowptr[N]);
+      for (int i = 0; i < N; i++) {
+        if (isfix[i]) ci.push_back(i), va.push_back(1.0);
+        else
+          for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
+            if (!isfix[col[k]]) ci.push_back(col[k]), va.push_back(val[k]);
+        rp[i + 1] = (int)ci.size();
+      }
+      GO(pmh_csr_create(ctx, N, N, rp.data(), ci.data(), va.data(), &Kregc)); // (the handles of the regularised K serve the fixed one)
+      GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kregc, &Kregb));
+      GO(pmh_matinv_create(Kregb, o->kplus_rtol, 1e-50, o->kplus_max_it, 1, &Kp));
+      GO(pmh_matinv_set_nullspace(Kp, kdim, Rn.data()));
+      GO(pmh_matinv_set_left_inverse(Kp, (int)fix.size(), fix.data()));
+    } else if (o->regularize && any_kernel) {
       // MatRegularize block by block (permonmatregularize.c:241-266 works on the rank's diagonal block)
       std::vector<int>    rp((size_t)N + 1, 0), ci;
       std::vector<double> va;
@@ -263,7 +418,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     for (int s = 0; s < nsub; s++) grow0[s + 1] = grow0[s] + bdim[s];
     const int m = grow0[nsub];
     st->coarse_dim = m;
-    std::vector<double> e((size_t)std::max(m, 1), 0.0);
+    std::vector<double> e((size_t)std::max(m, 1), 0.0), eo((size_t)std::max(m, 1), 0.0); // e = R'f; T e
     if (m) {
       std::vector<std::map<int, double>> rows((size_t)m);
       for (size_t q = 0; q < lrow.size(); q++) {
@@ -287,7 +442,35 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         }
       GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
       GO(pmh_qppf_create(ctx, Gc, 0, &pf));
+      if (o->E_orth_type == 1) { // QPTOrthonormalizeEq, MAT_ORTH_GS: the child QP gets the explicit T G and T e (qptransform.c:593-606)
+        if ((double)m * nl > 5e7) {
+          rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -dual_qp_E_orth_type gs forms the dense %d x %d G on the host; use implicit", m, nl);
+          goto done;
+        }
+        std::vector<double> Gd((size_t)m * nl, 0.0), T;
+        for (int r = 0; r < m; r++)
+          for (auto &kv : rows[r]) Gd[(size_t)r * nl + kv.first] = kv.second;
+        GO(orth_rows_gs(m, nl, Gd, T));
+        std::vector<int>    orp((size_t)m + 1, 0), oci;
+        std::vector<double> ova;
+        for (int r = 0; r < m; r++) {
+          for (int c = 0; c < nl; c++)
+            if (Gd[(size_t)r * nl + c] != 0.0) oci.push_back(c), ova.push_back(Gd[(size_t)r * nl + c]);
+          orp[r + 1] = (int)oci.size();
+        }
+        for (int r = 0; r < m; r++) {
+          double t = 0.0;
+          for (int c = 0; c < m; c++) t += T[(size_t)r * m + c] * e[c];
+          eo[r] = t;
+        }
+        GO(pmh_csr_create(ctx, m, nl, orp.data(), oci.data(), ova.data(), &Goc));
+        GO(pmh_qppf_create(ctx, Goc, 0, &pfo)); // QPSetEq re-creates the QPPF from T G (qptransform.c:609): GG' is formed and inverted like any other
+      } else if (o->E_orth_type == 4) { // MAT_ORTH_IMPLICIT: G stays, the projector carries T (:612-619)
+        GO(pmh_qppf_create(ctx, Gc, 2, &pfo));
+        GO(pmh_qppf_orth_rhs(pfo, e.data(), eo.data()));
+      }
     }
+    pmh_qppf pfs = pfo ? pfo : pf; // the equality constraint of the QP that gets solved
 
     // ---- chain, solve, post-solve
     const size_t bl = sizeof(double) * (size_t)std::max(nl, 1), bx = sizeof(double) * (size_t)std::max(N, 1);
@@ -302,18 +485,40 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     GO(pmh_memcpy_h2d(ctx, d_f, f, sizeof(double) * (size_t)N));
     GO(pmh_memset(ctx, d_c, 0, bl)); // c = B x0 with x0 = 0 (qpfeti.c:268-270)
     GO(pmh_memset(ctx, d_x, 0, bl));
-    if (m) GO(pmh_memcpy_h2d(ctx, d_e, e.data(), sizeof(double) * (size_t)m));
-    GO(pmh_qpt_feti_chain_create(B, Kp, d_f, d_c, pf, m ? d_e : nullptr, nullptr, &ch));
+    if (m) GO(pmh_memcpy_h2d(ctx, d_e, (pfo ? eo : e).data(), sizeof(double) * (size_t)m));
+    GO(pmh_qpt_feti_chain_create(B, Kp, d_f, d_c, pfs, m ? d_e : nullptr, nullptr, &ch));
     pmh_op  A;
     double *b;
     GO(pmh_qpt_feti_chain_get(ch, nullptr, &A, nullptr, nullptr, &b, nullptr, nullptr));
     if (o->lumped_pc) { // PCDUAL lumped, projected as qptransform.c:301-309 does for an equality-only QP
       lump      = new LumpedOp();
       lump->ctx = ctx, lump->n = nl, lump->B = B, lump->K = Kb;
-      if (pf) GO(pmh_op_create_projected(lump, pf, 0, &pc));
+      if (pfs) GO(pmh_op_create_projected(lump, pfs, 0, &pc));
     }
     pmh_pcpg_stats ks;
-    GO(pmh_ksp_cg_solve(ctx, A, b, d_x, o->lumped_pc ? (pc ? pc : (pmh_op)lump) : nullptr, o->rtol, o->atol, o->divtol, o->max_it, &ks));
+    memset(&ks, 0, sizeof(ks));
+    if (m && !o->project) {
+      // -project 0: QPTAllInOne skips QPTEnforceEqByProjector (qptransform.c:2185), QPSSetDefaultType sees the equality constraint and picks SMALXE (qps.c:437-441), whose set-up
+      // homogenises (smalxe.c:800-806: the chain's lambda~ / b_bar) and penalises.  The inner QP has no box: the reference's default inner solver is then QPSKSP = CG
+      // (qps.c:448) under SMALXE's stopping rule; this library's inner solver is MPGP with no bounds, whose steps are all CG steps -- the same iteration.
+      if (o->lumped_pc) {
+        rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -dual_pc_dual_type lumped with -project 0 is not built");
+        goto done;
+      }
+      pmh_op  F    = nullptr;
+      double *bbar = nullptr;
+      GO(pmh_qpt_feti_chain_get(ch, &F, nullptr, nullptr, &bbar, nullptr, nullptr, nullptr));
+      pmh_smalxe_opts sx = o->smalxe;
+      sx.rtol = o->rtol, sx.atol = o->atol, sx.divtol = o->divtol;
+      if (o->max_it != 10000) sx.max_it = o->max_it; // -qps_max_it given: QPSCreate_SMALXE's own default (100, smalxe.c:1203) otherwise
+      if (o->E_orth_type == 4) sx.be_implicit = 1;   // the implicit BE has no product of its own: ||BE u|| through B'B (smalxe.c:878-886)
+      GO(pmh_smalxe_create(ctx, F, bbar, d_x, nullptr, nullptr, pfs, &sx, &S));
+      GO(pmh_smalxe_solve(S));
+      GO(pmh_smalxe_get_stats(S, &st->smalxe));
+      ks.iteration = st->smalxe.iteration, ks.reason = st->smalxe.reason, ks.rnorm = st->smalxe.rnorm;
+    } else {
+      GO(pmh_ksp_cg_solve(ctx, A, b, d_x, o->lumped_pc ? (pc ? pc : (pmh_op)lump) : nullptr, o->rtol, o->atol, o->divtol, o->max_it, &ks));
+    }
     st->iteration = ks.iteration, st->reason = ks.reason, st->rnorm = ks.rnorm;
     GO(pmh_qpt_feti_chain_post_solve(ch, d_x, d_lam, d_u0, d_r));
     GO(pmh_memcpy_d2h(ctx, u_host, d_u0, sizeof(double) * (size_t)N));
@@ -330,7 +535,11 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     }
     if (o->view_convergence || o->view_kkt || o->matis_to_diag_norm) {
       std::string text;
-      GO(kspfeti_view(ctx, o, ks, ch, Kb, N, nsub, l2g, n_dir, dir_local, f, u_host, d_x, d_lam, d_u0, text));
+      if (pfo && o->view_kkt && !S) {
+        rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -qp_chain_view_kkt for the projected chain with an orthonormalised G is not built");
+        goto done;
+      }
+      GO(kspfeti_view(ctx, o, ks, ch, Kb, N, nsub, l2g, n_dir, dir_local, f, u_host, d_x, d_lam, d_u0, S, pf, e.data(), nl, m, text));
       if (o->view_buf && o->view_cap > 0) snprintf(o->view_buf, (size_t)o->view_cap, "%s", text.c_str());
       else fputs(text.c_str(), stdout), fflush(stdout);
     }
@@ -340,14 +549,15 @@ done:
   pmh_free(ctx, d_f), pmh_free(ctx, d_c), pmh_free(ctx, d_e), pmh_free(ctx, d_x), pmh_free(ctx, d_lam), pmh_free(ctx, d_u0), pmh_free(ctx, d_r), pmh_free(ctx, d_alpha);
   if (pc) pmh_op_destroy(pc);
   if (lump) delete lump;
+  pmh_smalxe_destroy(S);
   pmh_qpt_feti_chain_destroy(ch);
   if (Kp && E) pmh_matinv_attach_explicit(Kp, nullptr);
   pmh_fexplicit_destroy(E);
-  pmh_qppf_destroy(pf);
+  pmh_qppf_destroy(pfo), pmh_qppf_destroy(pf);
   pmh_gluing_destroy(B);
   pmh_matinv_destroy(Kp);
   pmh_blockdiag_destroy(Kregb), pmh_blockdiag_destroy(Kb);
-  pmh_csr_destroy(Gc), pmh_csr_destroy(Kregc), pmh_csr_destroy(Kc);
+  pmh_csr_destroy(Goc), pmh_csr_destroy(Gc), pmh_csr_destroy(Kregc), pmh_csr_destroy(Kc);
   return rc;
 }
 

@@ -351,7 +351,9 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
   PMH_CHK(tokenize(options, toks));
   static const char *const gtypes[] = {"nonred", "full", "orth"};    // FetiGluingTypes
   static const char *const pctypes[] = {"none", "lumped"};           // PCDualTypes (pcdual.c)
+  static const char *const orthtypes[] = {"none", "gs", "gslingen", "cholesky", "implicit", "inexact"}; // MatOrthTypes (permonmatorth.c:6)
   std::string left;
+  int         inner_alpha_bits = 0;
   for (const Token &t : toks) {
     const std::string &k = t.key;
     int                rc = 1, b = 0;
@@ -369,10 +371,26 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     else if (k == "qp_chain_view_kkt") rc = get_bool(t, &o->view_kkt) ? -1 : 1;
     else if (k == "qps_view_convergence") rc = get_bool(t, &o->view_convergence) ? -1 : 1;
     else if (k == "qpt_matis_to_diag_norm") rc = get_bool(t, &o->matis_to_diag_norm) ? -1 : 1;
-    else rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
+    else if (k == "qpt_dualize_Kplus_left") { // QPTDualize qptransform.c:1018; implies -regularize 0 as the reference's own switch does (:1003-1005)
+      rc = get_bool(t, &o->kplus_left) ? -1 : 1;
+      if (rc == 1 && o->kplus_left) o->regularize = 0;
+    } else if (k == "project") rc = get_bool(t, &o->project) ? -1 : 1;                     // QPTFromOptions qptransform.c:2228
+    else if (k == "dual_qp_E_orth_type") {                                                  // QPTOrthonormalizeEqFromOptions on the dual QP (prefix dual_)
+      rc = get_enum(t, orthtypes, 6, &o->E_orth_type) ? -1 : 1;
+      if (rc == 1 && o->E_orth_type != 0 && o->E_orth_type != 1 && o->E_orth_type != 4) return pmh_set_error(PMH_ERR_SUP, "options: -dual_qp_E_orth_type %s is not built (none, gs, implicit)", t.val.c_str());
+    } else {
+      rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
+      if (!rc) rc = smalxe_key(t, k, &o->smalxe);                                           // -qps_smalxe_*: the solver of -project 0
+      if (!rc && k.compare(0, 7, "smalxe_") == 0) {                                         // its inner solver (smalxe.c:500-502)
+        const std::string ki = k.substr(7);
+        rc = tol_key(t, ki, &o->smalxe.inner.rtol, &o->smalxe.inner.atol, &o->smalxe.inner.divtol, &o->smalxe.inner.max_it, nullptr);
+        if (!rc) rc = mpgp_key(t, ki, &o->smalxe.inner, &inner_alpha_bits);
+      }
+    }
     if (rc < 0) return PMH_ERR_ARG;
     if (!rc) left += (left.empty() ? "-" : " -") + k;
   }
+  if (inner_alpha_bits == 1) o->smalxe.inner.alpha_direct = 0;
   if (unknown && unknown_cap > 0) snprintf(unknown, (size_t)unknown_cap, "%s", left.c_str());
   return PMH_SUCCESS;
 }

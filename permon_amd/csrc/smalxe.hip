@@ -478,6 +478,17 @@ extern "C" int pmh_smalxe_get_solution(pmh_smalxe s, pmh_ctx *ctx, double **u, i
   return PMH_SUCCESS;
 }
 
+// the QP SMALXE hands to its inner solver -- the child QPTEnforceEqByPenalty adds (smalxe.c:822-838): Hessian A + rho B'B with the current rho, right-hand side
+// b - B'mu of the last outer iteration -- and B'mu itself, which QPSSolve_SMALXE leaves as the parent's Bt_lambda (what -qp_chain_view_kkt reports them from)
+extern "C" int pmh_smalxe_get_penalized(pmh_smalxe s, pmh_op *A_rho, double **b_inner, double **Bt_mu)
+{
+  PMH_ARG(s);
+  if (A_rho) *A_rho = s->A_inner;
+  if (b_inner) *b_inner = s->b_inner;
+  if (Bt_mu) *Bt_mu = s->Btmu;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_smalxe_get_inner_max_it(pmh_smalxe s, int *max_it)
 {
   PMH_ARG(s && max_it);

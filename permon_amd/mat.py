@@ -168,6 +168,11 @@ class MatInv:
         assert R.ndim == 2 and R.shape[1] == self.K.n
         check(self.ctx.L.pmh_matinv_set_nullspace(self.h, R.shape[0], R.ctypes.data_as(C.c_void_p)))
 
+    def set_left_inverse(self, fix_dofs):
+        """-qpt_dualize_Kplus_left (QPTDualize qptransform.c:997-1062): K^+ := K^- P_R; fix_dofs = the null-pivot dofs (identity rows / columns in K), [] = off."""
+        fx = np.ascontiguousarray(fix_dofs, dtype=np.int32)
+        check(self.ctx.L.pmh_matinv_set_left_inverse(self.h, int(fx.size), fx.ctypes.data_as(C.c_void_p) if fx.size else None))
+
     def set_pc_mg(self, hier, degree=2, lo=0.1, hi=1.1, precision="fp64"):
         """PCMG-like V-cycle as the PC of the inner CG (-mat_inv_pc_type mg): hier is box_mg_hierarchy()'s dict whose
         level 0 is this matrix (the resident CSR of the MATBLOCKDIAG is reused, not uploaded twice).

@@ -143,6 +143,40 @@ def test_matinv_block_cg_is_pseudoinverse(ctx, physics):
     assert np.linalg.norm(y.to_numpy() - f.K @ u.to_numpy()) <= 1e-12 * np.linalg.norm(rhs)
 
 
+def test_matinv_left_generalised_inverse(ctx):
+    """-qpt_dualize_Kplus_left (qptransform.c:997-1062): K^+ = K^- P_R with K^- the solve that leaves the null-pivot dofs at zero.  Against dense numpy: K^- = the inverse of
+    K without the fixing dofs, zero-padded; K K^+ g = P_R g away from the fixing dofs; the result is NOT orthogonal to the kernel (the Moore-Penrose form's is)."""
+    import scipy.sparse as sp
+
+    f = pa.CubeFeti((2, 1, 1), 2, physics="poisson")  # two floating blocks, kernel = constants
+    Kd, N, rs = f.K.toarray(), f.N, np.asarray(f.block_rowstart)
+    fix = [int(rs[0]), int(rs[1])]  # the first dof of every block
+    Kfix = Kd.copy()
+    Kfix[fix, :] = 0.0
+    Kfix[:, fix] = 0.0
+    Kfix[fix, fix] = 1.0
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, sp.csr_matrix(Kfix))
+    Kplus = pa.MatInv(K, rtol=1e-13, nullspace=f.R)
+    Kplus.set_left_inverse(fix)
+    g = np.random.default_rng(11).standard_normal(N)
+    u = ctx.vec(N)
+    Kplus.mult(ctx.vec_from(g), u)
+    u = u.to_numpy()
+    R = np.asarray(f.R)
+    Pg = g - R.T @ (R @ g)
+    keep = np.setdiff1d(np.arange(N), fix)
+    ref = np.zeros(N)
+    ref[keep] = np.linalg.solve(Kd[np.ix_(keep, keep)], Pg[keep])
+    assert np.linalg.norm(u - ref) <= 1e-9 * np.linalg.norm(ref) and np.all(u[fix] == 0.0)
+    assert np.linalg.norm((Kd @ u - Pg)[keep]) <= 1e-9 * np.linalg.norm(Pg)  # the kept equations hold; the dropped ones follow from R'P_R g = 0
+    assert np.linalg.norm(Kd @ u - Pg) <= 1e-8 * np.linalg.norm(Pg)
+    assert np.linalg.norm(R @ u) > 1e-3 * np.linalg.norm(u)  # a kernel component stays: this is K^- P_R, not P_R K^- P_R
+    Kplus.set_left_inverse([])
+    v = ctx.vec(N)
+    Kplus.mult(ctx.vec_from(g), v)
+    assert np.linalg.norm(R @ v.to_numpy()) <= 1e-10 * np.linalg.norm(v.to_numpy())
+
+
 def test_feti_dual_operator_and_lumped_pc(ctx):
     f = pa.CubeFeti((2, 2, 1), 2)
     Kp, Bd, Fd = _dense_ops(f)

@@ -62,6 +62,26 @@ def test_feti_ex1_example_prints_the_golden_file(goldens, args, case):
         assert "2.31e-02" in got[10] and "5.04e+00" in got[10] and got[12].endswith("1.00e+00")
 
 
+@pytest.mark.parametrize("orth", ["gs", "implicit"])
+def test_feti_ex1_unprojected_smalxe_prints_the_golden_file(goldens, orth):
+    """ex1.c's TEST block smalxe_orth (-project 0 -qps_smalxe_rho 1e1 -dual_qp_E_orth_type {implicit gs}): the dual QP keeps its equality constraint, G is orthonormalised, the QP
+    is homogenised and solved by SMALXE -- 16 KKT lines (penalised, homogenised, orthonormalised, dual x 2, primal, Dirichlet, decomposed, assembled) and "in 16 iteration" (outer
+    iterations).  K^+ is the left generalised inverse the reference switches to for this tutorial (qptransform.c:997-1008); with K_reg^{-1} the same solve takes 11 outer iterations
+    and other residuals, which is how the choice of K^+ was identified."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    args = f"-ns 4 -ne 7 -qp_chain_view_kkt -qpt_matis_to_diag_norm -project 0 -qps_smalxe_rho 1e1 -dual_qp_E_orth_type {orth}"
+    out = subprocess.run([os.path.join(ROOT, "examples", "feti_ex1")] + args.split(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    exp = goldens[f"feti_ex1_smalxe_orth_{orth}"]["text"]
+    assert len([ln for ln in exp if ln.strip()]) == 16 and exp[-1].strip() == "PERMON FETI CONVERGED_RTOL in 16 iteration"
+    got = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert got[-1] == "PERMON FETI CONVERGED_RTOL in 16 iteration", out.stdout
+    if orth == "implicit":
+        assert got[4] == "r = ||BE*x-cE||         not available"
+    # lines 5 and 7 (the two QPs above the orthonormalisation): r = 0.00e+00 exactly, the multiplier term is computed from the residual itself (compare_text: rounding class)
+    compare_text(got, exp)
+
+
 def _l2g(prob):
     nd = prob.ndof
     return np.concatenate([(np.asarray(g)[:, None] * nd + np.arange(nd)[None, :]).ravel() for g in prob.gids]).astype(np.int32)
