@@ -84,8 +84,7 @@ int main(int argc, char **argv)
   CHK(pmh_init(0, &ctx));
   CHK(pmh_kspfeti_default_opts(&o));
   /* The tutorial hands the reference no kernel of K: QPTDualize computes one and, having done so, switches to the left generalised inverse K^- P_R without regularisation
-     (qptransform.c:997-1008).  This library cannot compute kernels (it has no direct solver), so R is given above -- and the reference's choice of K^+ is made here. */
-  o.kplus_left = 1, o.regularize = 0;
+     (qptransform.c:997-1008).  This library cannot compute kernels (it has no direct solver), so R is given above; K^- P_R is pmh_kspfeti_default_opts' K^+ (kplus_left = 1). */
   CHK(pmh_kspfeti_set_from_options(opts, &o, left, (int)sizeof(left)));
   CHK(pmh_kspfeti_solve(ctx, ns, rs, rowptr, col, val, f, l2g, n_dir, dir, 1, R, &o, u, NULL, 0, &st));
   CHK(pmh_qpt_matis_assemble_solution(N, l2g, u, ng, x));

@@ -542,8 +542,9 @@ typedef struct {
   int    scale;              /* -SCALE_ON (default 1) */
   int    exclude_dirichlet;  /* -feti_gluing_exclude_dirichlet (default 0) */
   int    regularize;         /* -regularize (default 1, qptransform.c:2215); 0: -qpt_dualize_Kplus_mp */
-  int    kplus_left;         /* -qpt_dualize_Kplus_left: K^+ = K^- P_R with the fixing dofs of MatRegularize as null pivots (pmh_matinv_set_left_inverse).  The reference switches to it,
-                                and to -regularize 0, by itself whenever the QP came without a kernel and it computed one (qptransform.c:997-1008) -- the case of feti/ex1.c */
+  int    kplus_left;         /* -qpt_dualize_Kplus_left (DEFAULT 1): K^+ = K^- P_R with the fixing dofs of MatRegularize as null pivots (pmh_matinv_set_left_inverse).  The reference switches to it,
+                                and to -regularize 0, by itself whenever the QP came without a kernel and it computed one (qptransform.c:997-1008) -- always the case under KSPFETI, which
+                                never sets one (feti.c:71-94; feti/ex1.c, ex71.c).  0: `regularize` decides (K_reg^{-1} or the Moore-Penrose form).  Ignored with explicit_dual (K^- P_R is not symmetric) */
   int    project;            /* -project (default 1, set by -feti: QPTEnforceEqByProjector).  0: the equality constraint G lambda = e stays in the dual QP, which is homogenised and
                                 handed to QPS SMALXE (QPSSetDefaultType qps.c:437-441; QPTEnforceEqByPenalty inside SMALXE) -- `smalxe` below configures it */
   int    E_orth_type;        /* -dual_qp_E_orth_type (QPTOrthonormalizeEqFromOptions qptransform.c:643-660; MatOrthTypes): 0 none, 1 gs (explicit T G, T e), 4 implicit */

@@ -272,11 +272,13 @@ class FetiDualQP:
         return out
 
 
-def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, gluing="full", scale=True, exclude_dirichlet=False, regularize=True, lumped=False,
+def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, gluing="full", scale=True, exclude_dirichlet=False, regularize=None, lumped=False,
                  rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000, options=None, regularize_rho=0.0, explicit=False):
     """KSPFETI (src/ksp/impls/feti/feti.c:71-156) for a decomposed linear problem, one call into pmh_kspfeti_solve (C++):
     K block-diagonal scipy CSR, f split among copies, l2g global dof of every local dof, dirichlet_local = local dofs enforced
     by B (TFETI) or None, R = (kdim, N) kernel vectors (zero over non-floating blocks) or None.
+    regularize: None = the library's default K^+, which is KSPFETI's (the left generalised inverse K^- P_R; K_reg^{-1} with explicit=True); True = K_reg^{-1} (MatRegularize);
+    False = the Moore-Penrose form P_R K^- P_R.
     Returns (u, lambda, stats) with stats = (iteration, reason, rnorm, n_lambda, n_dirichlet_rows, coarse_dim)."""
     from . import _lib
 
@@ -293,7 +295,9 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     o = _lib.KspFetiOpts()
     check(ctx.L.pmh_kspfeti_default_opts(C.byref(o)))
     o.gluing_type, o.scale, o.exclude_dirichlet = {"nonred": 0, "full": 1, "orth": 2}[gluing], int(bool(scale)), int(bool(exclude_dirichlet))
-    o.regularize, o.lumped_pc, o.regularize_rho = int(bool(regularize)), int(bool(lumped)), float(regularize_rho)
+    if regularize is not None:
+        o.kplus_left, o.regularize = 0, int(bool(regularize))
+    o.lumped_pc, o.regularize_rho = int(bool(lumped)), float(regularize_rho)
     o.kplus_rtol, o.kplus_max_it, o.rtol, o.atol, o.divtol, o.max_it = kplus_rtol, kplus_max_it, rtol, atol, divtol, max_it
     o.explicit_dual = int(bool(explicit))  # F through the explicit local dual operators (pmh_fexplicit_*)
     if options:  # the reference's command line on top of the keyword arguments (pmh_kspfeti_set_from_options)

@@ -240,6 +240,7 @@ extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
   o->gluing_type = 1;   // FETI_GLUING_FULL, qpfeti.c:322
   o->scale       = 1;   // -SCALE_ON, qpfeti.c:757
   o->regularize  = 1;   // QPTFromOptions qptransform.c:2215
+  o->kplus_left  = 1;   // KSPFETI never hands QPTDualize a kernel (feti.c:71-94), so the reference computes one and switches to K^- P_R, -regularize 0 (qptransform.c:997-1008)
   o->project     = 1;   // -feti (qptransform.c:2224)
   PMH_CHK(pmh_smalxe_default_opts(&o->smalxe));
   o->kplus_rtol = 1e-12, o->kplus_max_it = 20000; // a stand-in for "direct": the reference factorises K_reg
@@ -332,14 +333,10 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     GO(pmh_csr_create(ctx, N, N, rowptr, col, val, &Kc));
     GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kc, &Kb));
     const bool any_kernel = std::any_of(bdim.begin(), bdim.end(), [](int d) { return d > 0; });
-    if (o->kplus_left && any_kernel) {
+    if (o->kplus_left && !o->explicit_dual && any_kernel) { // (the explicit local dual operators store symmetric blocks: they stay on K_reg^{-1} / the Moore-Penrose form)
       // K^+ = K^- P_R (qptransform.c:1040-1062).  The reference's K^- is the MUMPS solve with null-pivot detection (MatInvComputeNullSpace's factorisation): the null pivots carry 0.
       // Which dofs those are is MUMPS's choice; here they are the fixing dofs MatRegularize would take (permonmatregularize.c:57-124), one set per floating block, eliminated from
       // K by identity rows / columns -- for feti/ex1.c that is an end dof of every subdomain, and the reference's outputs are reproduced with it (tests/test_gpu_feti_kkt_text.py).
-      if (o->explicit_dual) {
-        rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: K^- P_R is not symmetric, the explicit local dual operators store symmetric blocks");
-        goto done;
-      }
       std::vector<int>  fix;
       std::vector<char> isfix((size_t)N, 0);
       for (int s = 0; s < nsub; s++) {

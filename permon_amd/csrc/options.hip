@@ -360,10 +360,10 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     if (k == "feti_gluing_type") rc = get_enum(t, gtypes, 3, &o->gluing_type) ? -1 : 1;
     else if (k == "feti_gluing_exclude_dirichlet") rc = get_bool(t, &o->exclude_dirichlet) ? -1 : 1;
     else if (k == "SCALE_ON") rc = get_bool(t, &o->scale) ? -1 : 1;
-    else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1;
+    else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1; // (without effect while kplus_left is on, as in the reference once it has computed the kernel)
     else if (k == "qpt_dualize_Kplus_mp") {
       rc = get_bool(t, &b) ? -1 : 1;
-      if (rc == 1 && b) o->regularize = 0; // the Moore-Penrose wrapping is this library's -regularize 0 path
+      if (rc == 1 && b) o->regularize = 0, o->kplus_left = 0; // the Moore-Penrose wrapping is this library's -regularize 0 path; it wins over the left inverse (qptransform.c:1018-1019)
     } else if (k == "dual_pc_dual_type") rc = get_enum(t, pctypes, 2, &o->lumped_pc) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_rtol") rc = get_real(t, &o->kplus_rtol) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_max_it") rc = get_int(t, &o->kplus_max_it) ? -1 : 1;

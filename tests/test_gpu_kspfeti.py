@@ -63,7 +63,7 @@ def test_ex71_elasticity_floating_slabs(ctx, goldens, kplus, lumped, explicit):
     explicit: the same through the explicit local dual operators (K_reg^{-1} on Gamma assembled at rtol 1e-13)."""
     prob = DmdaFeti((8, 6, 4), 7, "elasticity")
     l2g = _dmda_l2g(prob)
-    extra = {"reg": "", "mp": " -qpt_dualize_Kplus_mp", "left": " -qpt_dualize_Kplus_left"}[kplus]
+    extra = {"reg": " -qpt_dualize_Kplus_left 0", "mp": " -qpt_dualize_Kplus_mp", "left": ""}[kplus]  # left: the default (KSPFETI never supplies a kernel)
     u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, kplus_rtol=1e-14 if kplus == "reg" else 1e-13, explicit=explicit,
                                  options="-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type %s%s" % ("lumped" if lumped else "none", extra))  # feti/ex71.c:442
     gold = goldens["feti_ex71_2_lumped" if lumped else "feti_ex71_2_none"]["solves"][0]["iterations"]
@@ -186,7 +186,8 @@ def test_driver_and_chain_release_their_device_memory(ctx):
     l2g = _dmda_l2g(prob)
 
     def once():
-        pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6)
+        pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6)  # the default: K^- P_R
+        pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, regularize=True)
         pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, regularize=False, lumped=True)
 
     once()

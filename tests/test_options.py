@@ -94,11 +94,13 @@ def test_feti_driver_options():
     rc, o, left = parse("-feti_gluing_type NONRED -SCALE_ON 0 -feti_gluing_exclude_dirichlet -regularize false -dual_mat_inv_ksp_rtol 1e-10 -qps_max_it 50")
     assert rc == 0 and (o.gluing_type, o.scale, o.exclude_dirichlet, o.regularize, o.kplus_rtol, o.max_it) == (0, 0, 1, 0, 1e-10, 50) and not left
     rc, o, left = parse("-qpt_dualize_Kplus_mp")
-    assert rc == 0 and o.regularize == 0
+    assert rc == 0 and o.regularize == 0 and o.kplus_left == 0  # the Moore-Penrose form wins over the left inverse (qptransform.c:1018-1019)
     # feti/ex1.c's TEST block smalxe_orth: the unprojected dual QP, SMALXE's rho, the orthonormalisation of G (qptransform.c:2228, smalxe.c:716, qptransform.c:653)
     rc, o, left = parse("-project 0 -qps_smalxe_rho 1e1 -dual_qp_E_orth_type implicit -qpt_dualize_Kplus_left -smalxe_qps_max_it 77")
     assert rc == 0 and not left and (o.project, o.E_orth_type, o.kplus_left, o.regularize) == (0, 4, 1, 0) and o.smalxe.rho_user == 10.0 and o.smalxe.inner.max_it == 77
     rc, o, left = parse("-dual_qp_E_orth_type gs")
-    assert rc == 0 and (o.project, o.E_orth_type, o.kplus_left) == (1, 1, 0) and o.smalxe.rho_user == 1.1  # defaults: projected, smalxe.c:1190
+    assert rc == 0 and (o.project, o.E_orth_type, o.kplus_left) == (1, 1, 1) and o.smalxe.rho_user == 1.1  # defaults: projected, KSPFETI's left inverse, smalxe.c:1190
+    rc, o, left = parse("-qpt_dualize_Kplus_left 0")
+    assert rc == 0 and (o.kplus_left, o.regularize) == (0, 1)  # MatRegularize
     assert parse("-dual_qp_E_orth_type cholesky")[0] != 0  # a MatOrthType this library does not build: said, not ignored
     assert parse("-feti_gluing_type sideways")[0] != 0 and parse("-qps_rtol 2")[0] != 0
