@@ -60,6 +60,41 @@ def test_svm_mpgp_vs_oracle(oracle):
     ctx.close()
 
 
+def test_svm_mpgp_first_iterations_equal_the_oracle(oracle):
+    """The whole solve above can only be compared by what it converges to (1 700 iterations on a rank-deficient Hessian amplify the rounding of the dense sums).  The TRAJECTORY is
+    compared here: the first 60 iterations take the same steps (CG / expansion / proportioning, Hessian multiplications) and reach the same iterate and the same three gradient norms
+    as the oracle's MPGP on a numpy Hessian, on both pass forms."""
+    ctx = pa.Context(0)
+    p = P.svm_dual(4000, 64)
+    X, y = p["X"], p["y"]
+    op = oracle.Op(p["n"], fn=lambda a: y * (X @ (X.T @ (y * a))))
+    ref = oracle.mpgp(op, p["b"], p["x0"], oracle.Box(p["n"], lb=p["lb"], ub=p["ub"]), rtol=1e-30, max_it=60)
+    for pairing in (True, False):
+        if not pairing:
+            os.environ["PMH_SVM_NO_PAIRING"] = "1"
+        try:
+            H = pa.MatCreateSVMDual(ctx, X, y)
+            qp = pa.QP(ctx)
+            qp.SetOperator(H)
+            qp.SetRhs(ctx.vec_from(p["b"]))
+            x = ctx.vec_from(p["x0"])
+            qp.SetInitialVector(x)
+            qp.SetBox(None, ctx.vec_from(p["lb"]), ctx.vec_from(p["ub"]))
+            qps = pa.QPS(ctx)
+            qps.SetQP(qp)
+            qps.SetType("mpgp")
+            qps.SetTolerances(rtol=1e-30, max_it=60)
+            st = qps.Solve()
+        finally:
+            os.environ.pop("PMH_SVM_NO_PAIRING", None)
+        assert (st.iteration, st.reason) == (ref["iteration"], ref["reason"]) and st.reason == -3  # DIVERGED_ITS: it > max_it (qps.c:694)
+        assert (st.ncg, st.nexp, st.nprop, st.nmv) == (ref["ncg"], ref["nexp"], ref["nprop"], ref["nmv"])
+        assert np.linalg.norm(x.to_numpy() - ref["x"]) <= 1e-10 * np.linalg.norm(ref["x"])
+        for k in ("rnorm", "gfnorm", "gcnorm"):
+            assert abs(getattr(st, k) - ref[k]) <= 1e-9 * max(ref["rnorm"], 1e-300), (k, getattr(st, k), ref[k])
+    ctx.close()
+
+
 @pytest.mark.parametrize("N", [6000, 4003, 777])
 def test_svm_paired_passes_equal_separate_passes(monkeypatch, N):
     """svm.hip "paired passes": inside MPGP the second pass over X of one Hessian application also does the first pass of the next one (X'(y o p) while the
