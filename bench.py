@@ -117,6 +117,19 @@ def host_threads():
     return cores
 
 
+def cpu_model():
+    """The host CPU's model name (core count AND model stated next to every CPU baseline)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def measured_ceiling(ctx, n=1 << 26, reps=10):
     """On-box HBM ceiling (SURVEY 8d asks for it next to the 8 TB/s spec): device copy (read n, write n) and the
     VecWAXPY triad (read 2n, write n) on 512 MiB vectors, HIP-event timed on the launch stream."""
@@ -153,8 +166,11 @@ def cpu_baseline_c2(p, its):
     lam, _ = O.max_eigenvalue(op, omp=True)  # maxeig supplied => no power method inside the timed call
     t, done = O.time_mpgp(op, p["b"], p["x0"], box, reps=1, omp=True, maxeig=lam, max_it=its - 1)
     t_spmv = O.time_spmv(A, p["b"], reps=3, omp=True)
+    op1 = O.Op(p["n"], csr=A, omp=False)  # "all host cores and also 1 core" -- the plain (non-OpenMP) build of the oracle on a shorter sample
+    t1, done1 = O.time_mpgp(op1, p["b"], p["x0"], box, reps=1, omp=False, maxeig=lam, max_it=max(2, its // 6) - 1)
     return {
-        "value": done / t, "unit": "QPS iterations/s", "cores": cores, "kind": "port",
+        "value": done / t, "unit": "QPS iterations/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+        "one_core": {"value": done1 / t1, "unit": "QPS iterations/s", "cores": 1, "sample": "%d iterations of the same workload on one thread" % done1},
         "sample": "%d MPGP iterations of the same %d-row workload, oracle/permon_oracle.c with OpenMP on %d threads "
                   "(os.cpu_count()=%d, cgroup quota honoured; reference op order, one pass per PETSc call); SpMV alone %.1f GB/s"
                   % (done, p["n"], cores, os.cpu_count() or 0, (12.0 * A.val.size + 20.0 * p["n"]) / t_spmv / 1e9),
@@ -419,7 +435,7 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     applies_per_it = len(per_apply) / max(1, ref["iteration"])
     med = float(np.median(per_apply)) * applies_per_it
     return {
-        "value": 1.0 / med, "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": False,
+        "value": 1.0 / med, "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": False, "cpu_model": cpu_model(),
         "sample_short": "%d MPGP iterations of the same dual QP, MEASURED on the host: oracle MPGP (reference op order) with the iterative K^+ (block CG + V-cycle) restated on the CPU, OpenMP CSR products on %d threads" % (ref["iteration"], cores),
         "sample": "%d MPGP iterations (oracle/permon_oracle.c, the reference's op order; %.2f Hessian applications each, median application %.2f s => %.1f s per iteration) of the same TFETI dual QP on the host: "
                   "F = B K^+ B' with the GPU's own ITERATIVE K^+ restated on the CPU (oracle/mg_host.py: block-wise CG preconditioned by the same %d-level V-cycle, "
@@ -472,7 +488,7 @@ def cpu_baseline_direct(ctx, nel_full, nel_factor, applies_per_step, nblocks=8):
     t_solve_full = b["solve_s"] * (n_full / b["n"]) ** expo if nel_full != b["nel"] else b["solve_s"]
     t_fac_full = b["factor_s"] * (n_full / b["n"]) ** expo_f if nel_full != b["nel"] else b["factor_s"]
     return {
-        "value": 1.0 / (applies_per_step * t_solve_full), "unit": "QPS iterations/s", "cores": nblocks, "kind": "port",
+        "value": 1.0 / (applies_per_step * t_solve_full), "unit": "QPS iterations/s", "cores": nblocks, "kind": "port", "cpu_model": cpu_model(),
         "solve_seconds_per_block_measured": {("%d^3" % r["nel"]): round(r["solve_s"], 4) for r in rows}, "factor_seconds_measured": {("%d^3" % r["nel"]): round(r["factor_s"], 2) for r in rows},
         "solve_seconds_per_block_full_size": t_solve_full, "factor_seconds_full_size_extrapolated": t_fac_full, "growth_exponent_solve": expo, "growth_exponent_factor": expo_f,
         "extrapolated": nel_full != b["nel"], "sizes_measured": [r["nel"] for r in rows],
@@ -1036,7 +1052,7 @@ def compact_line(out, details_path):
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "extrapolated": bool(cb.get("extrapolated", False)),
-                             "sample": cb.get("sample_short") or str(cb.get("sample", ""))[:200]}
+                             "cpu_model": str(cb.get("cpu_model") or cpu_model())[:64], "sample": cb.get("sample_short") or str(cb.get("sample", ""))[:200]}
     dm = out.get("cpu_baseline_direct_model")
     if isinstance(dm, dict):
         c["cpu_baseline_direct_model"] = {"value": _num(dm.get("value")), "cores": dm.get("cores"), "extrapolated": bool(dm.get("extrapolated")), "sizes_measured": dm.get("sizes_measured")}
@@ -1274,7 +1290,7 @@ def main():
                     # the reference's direct K^+ for THIS block size was measured by cpu_baseline_direct (SuperLU forward/backward solve of one 21^3 block): no extrapolation here
                     cores = host_threads()
                     t_apply = math.ceil(64 / cores) * row["solve_s"]
-                    out["configs3"]["cpu_baseline"] = {"value": 1.0 / (out["configs3"]["applies_per_step"] * t_apply), "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": False,
+                    out["configs3"]["cpu_baseline"] = {"value": 1.0 / (out["configs3"]["applies_per_step"] * t_apply), "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": False, "cpu_model": cpu_model(),
                                                        "sample": "measured: SuperLU (scipy splu, stand-in for the reference's PCCHOLESKY / MUMPS K^+, matinv.c:734-743) forward/backward solve of one 21^3 block = %.4f s; 64 blocks over %d cores "
                                                                  "(%d rounds per F application, perfect parallelism assumed) x %.2f F applications per iteration; B / B' and dual-space work not counted" % (row["solve_s"], cores, math.ceil(64 / cores), out["configs3"]["applies_per_step"])}
             if not a.no_svm:
