@@ -340,6 +340,9 @@ int pmh_fexplicit_create(pmh_gluing B, pmh_blockdiag K, int storage, pmh_fexplic
                                 instruction: 48 flop per stored byte instead of 4 -- compute-bound instead of HBM-bound */
 int pmh_fexplicit_create_shared(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS */
 int pmh_fexplicit_create_shared_orbit(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_ORBIT */
+/* the same with the touched set of class c extended by the block-relative dofs extra_rel[extra_ptr[c] .. extra_ptr[c + 1]) -- e.g. its closure under the block's symmetries
+   (pmh_box_symmetry_closure), which lets a class of ONE box-shaped block (non-congruent decompositions: one material per subdomain) keep all the box's operations */
+int pmh_fexplicit_create_shared_orbit_union(pmh_gluing B, pmh_blockdiag K, const int *block_class, const int *extra_ptr, const int *extra_rel, pmh_fexplicit *E);
 int pmh_fexplicit_apply_flops(pmh_fexplicit E, double *flops); /* PMH_FX_CLASS_ORBIT: useful flops of the dense apply = (rows of the row tiles) x (the columns their blocks need) x 2 n_c (the roofline of that storage is the fp64 MFMA peak); 0 otherwise */
 int pmh_fexplicit_apply_flops_detail(pmh_fexplicit E, double *issued /* padded tiles, what the matrix cores execute */, double *dense /* every (representative, operation, block): the count without the pruning by the blocks' touched dofs */);
 int pmh_fexplicit_create_shared_sym(pmh_gluing B, pmh_blockdiag K, const int *block_class, pmh_fexplicit *E); /* storage PMH_FX_CLASS_SYM */
@@ -361,6 +364,8 @@ int pmh_fexplicit_stripe_bytes(int nblocks, const int *n_gamma, int size, double
    induced by the signed coordinate permutations that map the box onto itself and leave the block's matrix (CSR rowptr / col / val, n rows; NULL: not
    checked) invariant -- generators checked on nsample rows, the group is their closure (<= 48 operations, 0 = identity).  perm, sign: [48 * n]. */
 int pmh_box_symmetries(const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int nsample, int *nsym, int *perm, signed char *sign);
+/* sorted union of the images of the dofs in_rel under those operations (out_rel: capacity nx ny nz ndof, may be NULL to get the count); host */
+int pmh_box_symmetry_closure(const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int n_in, const int *in_rel, int *n_out, int *out_rel, int *nsym);
 /* the two together for box-shaped blocks: symmetries of the box checked against the CSR of one block of the class (column indices relative to the block),
    restricted to those that map the class's touched dofs onto themselves, handed to pmh_fexplicit_set_class_symmetry; nsym_used: how many (1 = none) */
 int pmh_fexplicit_set_box_symmetry(pmh_fexplicit E, int cls, const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int *nsym_used);

@@ -263,11 +263,13 @@ _PROTOS = {
     "pmh_fexplicit_create_shared": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_create_shared_sym": [vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_create_shared_orbit": [vp, vp, vp, C.POINTER(vp)],
+    "pmh_fexplicit_create_shared_orbit_union": [vp, vp, vp, vp, vp, C.POINTER(vp)],
     "pmh_fexplicit_apply_flops": [vp, c_double_p],
     "pmh_fexplicit_apply_flops_detail": [vp, c_double_p, c_double_p],
     "pmh_fexplicit_class_sym_plan": [C.c_int, C.c_int, vp, vp],
     "pmh_fexplicit_orbit_row_tile": [C.c_int, vp, vp],
     "pmh_box_symmetries": [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp],
+    "pmh_box_symmetry_closure": [vp, C.c_int, vp, vp, vp, C.c_int, vp, c_int_p, vp, c_int_p],
     "pmh_fexplicit_set_box_symmetry": [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp],
     "pmh_fexplicit_class_union": [vp, C.c_int, vp, vp],
     "pmh_fexplicit_set_class_symmetry": [vp, C.c_int, C.c_int, vp, vp],

@@ -113,7 +113,9 @@ class FetiDualQP:
         (glob: dict n_x, block_rowstart, leaves_row / _root / _sign of the whole decomposition) and this rank assembles and applies
         an even share of 128-row stripes of every W_b instead of its own blocks (pmh_fexplicit_set_stripe).
         symmetry = dict(dims=(nx, ny, nz), ndof=3) ("class_sym", all blocks one class of box-shaped blocks): the signed coordinate permutations of the
-        box that leave K invariant (feti.box_symmetries, checked against K) serve the set-up: one K^+ solve per orbit of rows (a cube: 48 x fewer)."""
+        box that leave K invariant (feti.box_symmetries, checked against K) serve the set-up: one K^+ solve per orbit of rows (a cube: 48 x fewer).
+        symmetry["close"] ("class_orbit", several classes): every class's touched set is extended to its closure under the box's operations (mat.box_symmetry_closure: the whole
+        boundary of a cube), so that a class of ONE block -- a decomposition into boxes of different materials -- keeps all of them instead of the 2 ... 8 its own faces allow."""
         import scipy.sparse as sp
 
         rs = np.asarray(local["block_rowstart"])
@@ -143,7 +145,20 @@ class FetiDualQP:
         if storage == "class_orbit" and not one_class and stripe is not None:
             raise ValueError("striped class_orbit operators need congruent blocks")
         for attempt in ("class_orbit", "class_sym") if want_orbit else (storage,):
-            E = self._create_explicit(local, attempt, stripe, cls, nb)
+            extra = None
+            if attempt == "class_orbit" and symmetry is not None and symmetry.get("close") and stripe is None:
+                from .mat import box_symmetry_closure
+
+                tr = np.unique(np.asarray(local["leaves_row"]))
+                blk = np.searchsorted(rs, tr, side="right") - 1
+                extra = []
+                for c in range(int(cls.max()) + 1):
+                    members = np.nonzero(cls == c)[0]
+                    touched = np.unique(np.concatenate([tr[blk == m] - rs[m] for m in members]))
+                    b0 = int(members[0])
+                    closure, _ = box_symmetry_closure(symmetry["dims"], symmetry.get("ndof", 3), self._Kinv_sp[rs[b0]:rs[b0 + 1], rs[b0]:rs[b0 + 1]], touched)
+                    extra.append(np.setdiff1d(closure, touched))
+            E = self._create_explicit(local, attempt, stripe, cls, nb, class_extra=extra)
             self.explicit_symmetries = 1
             if symmetry is not None and attempt in ("class_sym", "class_orbit") and one_class:
                 n_i = int(rs[1] - rs[0])
@@ -175,7 +190,7 @@ class FetiDualQP:
         self.Kplus.attach_explicit(E)
         return E
 
-    def _create_explicit(self, local, storage, stripe, cls, nb):
+    def _create_explicit(self, local, storage, stripe, cls, nb, class_extra=None):
         """The pmh_fexplicit object of assemble_explicit for one storage (striped over all blocks of the decomposition, or this rank's blocks)."""
         import scipy.sparse as sp
 
@@ -189,7 +204,7 @@ class FetiDualQP:
             E = MatExplicitDual(self._Bglob, self._Kglob, storage=storage if storage in ("class", "class_sym", "class_orbit") else "sym", block_class=np.zeros(ngl, dtype=np.int32))
             E.set_stripe(rank, size)
         else:
-            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls)
+            E = MatExplicitDual(self.B, self.Kreg if hasattr(self, "Kreg") else self.K, storage=storage, block_class=cls, class_extra=class_extra)
         return E
 
     def make_smalxe(self, rtol=1e-5, max_it=100, inner=None, **smalxe):

@@ -112,3 +112,32 @@ extern "C" int pmh_box_symmetries(const int *dims, int ndof, const int *rowptr, 
   for (size_t g = 0; g < group.size(); g++) materialise(group[g], dims, ndof, perm + g * (size_t)n, sign + g * (size_t)n);
   return PMH_SUCCESS;
 }
+
+// The closure of a set of a block's dofs (in_rel: n_in block-relative indices) under the box's symmetries that leave the block's matrix invariant (pmh_box_symmetries):
+// out_rel receives the sorted union of all images (capacity n = nx ny nz ndof), *n_out its size, *nsym the number of operations.  For a cube and a set that contains a whole face
+// it is the whole boundary.  Host routine (set-up).
+extern "C" int pmh_box_symmetry_closure(const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int n_in, const int *in_rel, int *n_out, int *out_rel, int *nsym_out)
+{
+  PMH_ARG(dims && ndof >= 1 && n_in >= 0 && (n_in == 0 || in_rel) && n_out);
+  const long long nn = (long long)dims[0] * dims[1] * dims[2] * ndof;
+  PMH_ARG(nn >= 1 && nn < (1LL << 31));
+  const int                n = (int)nn;
+  std::vector<int>         perm((size_t)48 * n);
+  std::vector<signed char> sign((size_t)48 * n);
+  int                      nsym = 0;
+  PMH_CHK(pmh_box_symmetries(dims, ndof, rowptr, col, val, 4000, &nsym, perm.data(), sign.data()));
+  std::vector<char> in((size_t)n, 0);
+  for (int i = 0; i < n_in; i++) {
+    PMH_ARG(in_rel[i] >= 0 && in_rel[i] < n);
+    for (int g = 0; g < nsym; g++) in[perm[(size_t)g * n + in_rel[i]]] = 1; // a group: the images under every element ARE the closure
+  }
+  int cnt = 0;
+  for (int i = 0; i < n; i++)
+    if (in[i]) {
+      if (out_rel) out_rel[cnt] = i;
+      cnt++;
+    }
+  *n_out = cnt;
+  if (nsym_out) *nsym_out = nsym;
+  return PMH_SUCCESS;
+}

@@ -3,7 +3,7 @@
 #include "feti_internal.h"
 
 struct fx_shared;
-int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out); // sym 1: lower block-triangle in 16 x 16 tiles (PMH_FX_CLASS_SYM), 2: orbit representatives' rows (PMH_FX_CLASS_ORBIT)
+int       fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out, const int *extra_ptr = nullptr, const int *extra_rel = nullptr); // sym 1: lower block-triangle in 16 x 16 tiles (PMH_FX_CLASS_SYM), 2: orbit representatives' rows (PMH_FX_CLASS_ORBIT)
 void      fxs_destroy(fx_shared *S);
 int       fxs_set_stripe(fx_shared *S, int rank, int size);
 int       fxs_class_union(fx_shared *S, int c, int *n_c, int *urel_out);

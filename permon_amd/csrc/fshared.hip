@@ -105,6 +105,9 @@ struct fx_shared {
   int                    sym = 0, segj = 0;
   long long             *d_wgl = nullptr; // per item: offset of its class's tiles, offset of its transposed partial sums
   int                   *d_items = nullptr, *d_wgfirst = nullptr;
+  // several classes on the same row tile: ONE launch over all their work items (fxo_gemm): workgroup -> items with global item numbers, per-class pointer tables
+  int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0;
+  const int            **d_coltab_of = nullptr, **d_gidx_of = nullptr;
   double                *pt = nullptr;
   long long              pt_tot = 0;
   double                 owned_bytes = 0.0;
@@ -680,10 +683,12 @@ __device__ unsigned long long *fxo_trace_buf;
 #endif
 // NWM waves down x (4 / NWM) across: NWM = 2: wave tile 16 NI x 64 (workgroup 32 NI x 128: 128 or 96 rows); NWM = 1: wave tile 16 NI x 32, the workgroup's rows are ANY multiple of 16
 // up to 144 (715 representatives pad to 720 = 5 x 144, as with the 4-row units of k_fxo_gemm4<15>; NI + 2 operand reads for 2 NI instructions per k step of 4)
-template <int NI, int NWM>
+// MULTI: one launch over the items of several classes (every class its own column lists, gather indices and symmetry count: the *_of tables, indexed by the item's class)
+template <int NI, int NWM, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                        const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                       const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
+                                                       const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst, const int *const *__restrict__ coltab_of = nullptr,
+                                                       const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr)
 {
   constexpr int NWN = 4 / NWM, NJ = FXO_TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
@@ -694,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
   const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]);
+  if constexpr (MULTI) coltab = coltab_of[c], zrow = zrow_of[c], gidx = gidx_of[c];
   const double *__restrict__ Ab = A + iteml[4 * it];
   const double *__restrict__ x  = X + iteml[4 * it + 1];
   double *__restrict__ C        = cpart + iteml[4 * it + 2];
@@ -1062,7 +1068,9 @@ static int fxs_build_launch(fx_shared *S)
   return pmh_memset(S->ctx, S->part, 0, sizeof(double) * (size_t)need); // column chunks beyond a class's ld / empty segments stay zero
 }
 
-int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out)
+// extra_ptr / extra_rel (optional): block-relative dofs ADDED to the touched set of class c (extra_rel[extra_ptr[c] .. extra_ptr[c + 1])): the closure of the touched set under the
+// block's symmetry group (pmh_box_symmetry_closure), so that a class whose own touched set is not invariant keeps all its symmetries
+int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, fx_shared **out, const int *extra_ptr, const int *extra_rel)
 {
   PMH_ARG(B && K && block_class && out && B->n_x == K->n);
   pmh_ctx    ctx = B->ctx;
@@ -1092,6 +1100,12 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     lb[i] = block_of(B->h_row[i]);
     S->C[S->cls[lb[i]]].pos[B->h_row[i] - K->rowstart[lb[i]]] = 0;
   }
+  if (extra_ptr && extra_rel)
+    for (int c = 0; c < S->ncls; c++)
+      for (int e = extra_ptr[c]; e < extra_ptr[c + 1]; e++) {
+        if (extra_rel[e] < 0 || extra_rel[e] >= S->C[c].nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_create_shared: extra dof %d of class %d is outside its blocks (%d rows)", extra_rel[e], c, S->C[c].nloc);
+        S->C[c].pos[extra_rel[e]] = 0;
+      }
   long long wtot = 0, xtot = 0, pttot = 0;
   for (int c = 0; c < S->ncls; c++) {
     fxs_class &C = S->C[c];
@@ -1197,6 +1211,8 @@ void fxs_destroy(fx_shared *S)
   if (S->d_wgl) pmh_free(ctx, S->d_wgl);
   if (S->d_items) pmh_free(ctx, S->d_items);
   if (S->d_wgfirst) pmh_free(ctx, S->d_wgfirst);
+  if (S->d_wgfirst_all) pmh_free(ctx, S->d_wgfirst_all);
+  if (S->d_zrow_of) pmh_free(ctx, S->d_zrow_of), pmh_free(ctx, (void *)S->d_coltab_of), pmh_free(ctx, (void *)S->d_gidx_of);
   pmh_gluing_destroy(S->Bc);
   for (auto e : S->ev_mid) (void)hipEventDestroy(e);
   pmh_gluing_destroy(S->Bc2);
@@ -1576,7 +1592,18 @@ static int fxo_prepare(fx_shared *S)
   // the class's workgroups still fit ONE round of the 2 resident per CU (measured: 507 workgroups 0.275 ms, 513: 0.34); the k range of a rank (several GPUs) cuts the segments it crosses
   const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
   const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
-  const int slots = getenv("PMH_FXO_SLOTS") ? std::max(1, atoi(getenv("PMH_FXO_SLOTS"))) : 2 * ctx->num_cus;
+  // several classes on one row tile share ONE launch (fxo_gemm): the resident workgroups are divided among them
+  int nplanned = 0, tm_first = 0;
+  bool one_tile = fxo_mfma16() && !getenv("PMH_FXO_NO_MERGE");
+  for (int c = 0; c < S->ncls; c++)
+    if (tab_of[c] >= 0) {
+      if (!nplanned) tm_first = S->C[c].tm;
+      else if (S->C[c].tm != tm_first) one_tile = false;
+      nplanned++;
+    }
+  const bool merged = one_tile && nplanned > 1;
+  const int slots_all = getenv("PMH_FXO_SLOTS") ? std::max(1, atoi(getenv("PMH_FXO_SLOTS"))) : 2 * ctx->num_cus;
+  const int slots = merged ? std::max(16, slots_all / nplanned) : slots_all;
   for (int c = 0; c < S->ncls; c++) {
     if (tab_of[c] < 0) continue;
     fxo_plan &P = plan[tab_of[c]];
@@ -1821,6 +1848,33 @@ static int fxo_prepare(fx_shared *S)
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(16LL, ctot), (void **)&S->cpart));
     S->cpart_cap = ctot;
   }
+  // merged launch: workgroup -> items in the global item numbering, and the classes' own tables by class index
+  if (S->d_wgfirst_all) pmh_free(ctx, S->d_wgfirst_all), S->d_wgfirst_all = nullptr;
+  if (S->d_zrow_of) pmh_free(ctx, S->d_zrow_of), pmh_free(ctx, (void *)S->d_coltab_of), pmh_free(ctx, (void *)S->d_gidx_of), S->d_zrow_of = nullptr;
+  S->nwg_all = 0, S->merged_tm = 0;
+  if (merged) {
+    std::vector<int>         wall, zr((size_t)S->ncls, 0);
+    std::vector<const int *> ct((size_t)S->ncls, nullptr), gi((size_t)S->ncls, nullptr);
+    for (int c = 0; c < S->ncls; c++) {
+      const fxs_class &C = S->C[c];
+      zr[c] = C.nsymp, ct[c] = C.d_coltab, gi[c] = C.d_gidx;
+      for (int w = 0; w < C.wg_count; w++) wall.push_back(wgfirst[C.wgf_first + w] + C.item_first); // (a class's items are contiguous and the classes follow one another:
+      S->nwg_all += C.wg_count;                                                                       //  a workgroup ends where the next one, of whichever class, begins)
+    }
+    int last_end = 0;
+    for (int c = 0; c < S->ncls; c++)
+      if (S->C[c].wg_count) last_end = wgfirst[S->C[c].wgf_first + S->C[c].wg_count] + S->C[c].item_first;
+    wall.push_back(last_end);
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * wall.size(), (void **)&S->d_wgfirst_all));
+    PMH_CHK(pmh_memcpy_h2d(ctx, S->d_wgfirst_all, wall.data(), sizeof(int) * wall.size()));
+    PMH_CHK(pmh_malloc(ctx, sizeof(int) * zr.size(), (void **)&S->d_zrow_of));
+    PMH_CHK(pmh_memcpy_h2d(ctx, S->d_zrow_of, zr.data(), sizeof(int) * zr.size()));
+    PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * ct.size(), (void **)&S->d_coltab_of));
+    PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_coltab_of, ct.data(), sizeof(const int *) * ct.size()));
+    PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * gi.size(), (void **)&S->d_gidx_of));
+    PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_gidx_of, gi.data(), sizeof(const int *) * gi.size()));
+    S->merged_tm = tm_first;
+  }
   S->fxo_ready = 1;
   return PMH_SUCCESS;
 }
@@ -1828,6 +1882,23 @@ static int fxo_prepare(fx_shared *S)
 static int fxo_gemm(fx_shared *S)
 {
   hipStream_t st = S->ctx->stream;
+  const bool  merged = S->merged_tm > 0 && S->nwg_all > 0; // several classes on one row tile: one GEMM launch over all their items, then the classes' finishing launches
+  if (merged) {
+#define FXO_LAUNCH_ALL(NI, NWM)                                                                                                                                                                      \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true>), dim3(S->nwg_all), dim3(256), 0, st, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_wg,                 \
+                     (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)S->d_wgfirst_all, \
+                     (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of)
+    switch (S->merged_tm) {
+    case 144: FXO_LAUNCH_ALL(9, 1); break;
+    case 128: FXO_LAUNCH_ALL(4, 2); break;
+    case 112: FXO_LAUNCH_ALL(7, 1); break;
+    case 96: FXO_LAUNCH_ALL(3, 2); break;
+    case 80: FXO_LAUNCH_ALL(5, 1); break;
+    default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", S->merged_tm);
+    }
+#undef FXO_LAUNCH_ALL
+    if (S->ev_mid_pending >= 0) PMH_HIP(hipEventRecord(S->ev_mid[S->ev_mid_pending], st));
+  }
   for (int c = 0; c < S->ncls; c++) { // one launch per class (its own gather-index array and column lists); configs[2] / [3]: one class
     fxs_class &C = S->C[c];
     if (!C.nc) continue;
@@ -1845,7 +1916,9 @@ static int fxo_gemm(fx_shared *S)
     }
     PMH_HIP(hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 8 * 64 * 8, st));
 #endif
-    if (fxo_mfma16()) {
+    if (merged) {
+      // (the class's products were part of the launch above)
+    } else if (fxo_mfma16()) {
       switch (C.tm) {
       case 144: FXO_LAUNCH((k_fxo_gemm16<9, 1>)); break;
       case 128: FXO_LAUNCH((k_fxo_gemm16<4, 2>)); break;
@@ -1864,7 +1937,7 @@ static int fxo_gemm(fx_shared *S)
     default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
     }
 #undef FXO_LAUNCH
-    if (S->ev_mid_pending >= 0 && c == S->ncls - 1) PMH_HIP(hipEventRecord(S->ev_mid[S->ev_mid_pending], st)); // (one class: configs[2] / [3]; several classes: after the last class's GEMM)
+    if (!merged && S->ev_mid_pending >= 0 && c == S->ncls - 1) PMH_HIP(hipEventRecord(S->ev_mid[S->ev_mid_pending], st)); // (one class: configs[2] / [3]; several classes: after the last class's GEMM)
 #ifdef FXO_TRACE
     if (++traced == 300) { // one launch in the steady state of the bench
       std::vector<unsigned long long> h(8 * 64 * 8);

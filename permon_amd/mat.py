@@ -259,19 +259,44 @@ def csr_block_classes(block_rowstart, K):
     return cls
 
 
+def box_symmetry_closure(dims, ndof, K, rel):
+    """pmh_box_symmetry_closure: the sorted union of the images of the block-relative dofs `rel` under the symmetries of a box of dims nodes x ndof that leave the block's matrix K
+    (scipy CSR) invariant; returns (closure, number of operations)."""
+    from . import _lib
+
+    K = K.tocsr()
+    K.sort_indices()
+    ip, ci, va = (np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64))
+    dm = np.ascontiguousarray(dims, dtype=np.int32)
+    rel = np.ascontiguousarray(rel, dtype=np.int32)
+    out = np.zeros(int(np.prod(dm)) * int(ndof), dtype=np.int32)
+    n_out, nsym = C.c_int(), C.c_int()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    check(_lib.load().pmh_box_symmetry_closure(p(dm), int(ndof), p(ip), p(ci), p(va), int(rel.size), p(rel) if rel.size else None, C.byref(n_out), p(out), C.byref(nsym)))
+    return out[:n_out.value].copy(), nsym.value
+
+
 class MatExplicitDual:
     """Explicit local dual operators (pmh_fexplicit): W_b = (K_b^+)[Gamma_b, Gamma_b] dense per block, F = Bhat W Bhat'.
     The exact-K^+ path (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:670-730, restricted to the dofs B touches)."""
 
-    def __init__(self, B, K, storage="sym", block_class=None):
+    def __init__(self, B, K, storage="sym", block_class=None, class_extra=None):
         """storage "sym": lower block-triangle + SYMV (half the bytes per apply); "full": row-major + GEMV; "class": congruent blocks
         (block_class from csr_block_classes) share ONE full matrix per class, applied to their vectors together (8 per pass);
         "class_sym": that matrix kept as its lower block-triangle in 16 x 16 tiles (half the bytes, fp64 MFMA kernel);
         "class_orbit": only the rows of the orbit representatives under the class's symmetries (set_box_symmetry / set_class_symmetry before the
-        assembly): the dense apply is a GEMM on the fp64 matrix instruction."""
+        assembly): the dense apply is a GEMM on the fp64 matrix instruction.  class_extra ("class_orbit"): one array of block-relative dofs per class, added to the class's
+        touched set (pmh_fexplicit_create_shared_orbit_union) -- e.g. box_symmetry_closure(), so that a class of one box keeps all the box's operations."""
         self.ctx, self.B, self.K, self.storage = B.ctx, B, K, storage
         h = C.c_void_p()
-        if storage in ("class", "class_sym", "class_orbit"):
+        if storage == "class_orbit" and class_extra is not None:
+            bc = np.ascontiguousarray(block_class, dtype=np.int32)
+            assert bc.size == K.nblocks and len(class_extra) == int(bc.max()) + 1
+            ptr = np.zeros(len(class_extra) + 1, dtype=np.int32)
+            ptr[1:] = np.cumsum([len(e) for e in class_extra])
+            rel = np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.int32) for e in class_extra]) if ptr[-1] else np.zeros(1), dtype=np.int32)
+            check(self.ctx.L.pmh_fexplicit_create_shared_orbit_union(B.h, K.h, bc.ctypes.data_as(C.c_void_p), ptr.ctypes.data_as(C.c_void_p), rel.ctypes.data_as(C.c_void_p), C.byref(h)))
+        elif storage in ("class", "class_sym", "class_orbit"):
             bc = np.ascontiguousarray(block_class, dtype=np.int32)
             assert bc.size == K.nblocks
             create = {"class": self.ctx.L.pmh_fexplicit_create_shared, "class_sym": self.ctx.L.pmh_fexplicit_create_shared_sym, "class_orbit": self.ctx.L.pmh_fexplicit_create_shared_orbit}[storage]

@@ -443,3 +443,52 @@ def test_explicit_orbit_several_classes(ctx):
     si, so = qi.solve_smalxe(rtol=1e-6), qo.solve_smalxe(rtol=1e-6)
     assert si.reason == so.reason == 2
     assert (si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (so.iteration, so.inner_iter_accu, so.inner.ncg, so.inner.nexp)
+
+
+def test_explicit_orbit_closed_class_sets(ctx):
+    """The same decomposition with the class sets CLOSED under the cube's group (symmetry["close"]: pmh_box_symmetry_closure + pmh_fexplicit_create_shared_orbit_union): every class of one
+    block works on the whole boundary of its cube, keeps all 48 operations and needs one K^+ solve per orbit of boundary dofs -- far fewer set-up solves than with the class's own
+    faces --, F is the same operator (against the inner-Krylov K^+ and against the un-closed orbit storage), the SMALXE solve takes the same steps."""
+    nel = 9
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True, young=[1.0 + 0.25 * i for i in range(8)])
+    G, e = f.coarse(orthonormalize=True)
+    loc = f.subset(range(8))
+    nn = nel + 1
+    qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    qo = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
+    qc = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3, close=True)))
+    assert qc.explicit_storage == "class_orbit" and qc.explicit_symmetries == 48
+    n_open, _ = qo.E.assemble_stats()
+    n_closed, _ = qc.E.assemble_stats()
+    nb_dofs = 3 * (nn ** 3 - (nn - 2) ** 3)  # boundary dofs of a cube: 48 | orbits of them
+    assert n_closed < n_open / 3 and n_closed <= 8 * (nb_dofs // 48 + 3 * nn)  # (orbits of points on symmetry planes are shorter than 48)
+    lam = np.random.default_rng(3).standard_normal(f.n_lambda)
+    lv, y0, y1, y2 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    qi.F.mult(lv, y0)
+    qo.F.mult(lv, y1)
+    qc.F.mult(lv, y2)
+    n0 = np.linalg.norm(y0.to_numpy())
+    assert np.linalg.norm(y2.to_numpy() - y0.to_numpy()) <= 1e-10 * n0 and np.linalg.norm(y2.to_numpy() - y1.to_numpy()) <= 1e-10 * n0
+    si, sc = qi.solve_smalxe(rtol=1e-6), qc.solve_smalxe(rtol=1e-6)
+    assert si.reason == sc.reason == 2
+    assert (si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (sc.iteration, sc.inner_iter_accu, sc.inner.ncg, sc.inner.nexp)
+
+
+def test_box_symmetry_closure_host():
+    """pmh_box_symmetry_closure: a face of a cube closes to the whole boundary under the 48 operations; under a matrix that breaks the symmetry only the identity is left."""
+    from permon_amd.mat import box_symmetry_closure
+
+    f = pa.CubeFeti((1, 1, 1), 4, contact=False)
+    nn = 5
+    K = f.K.tocsr()
+    nodes = np.arange(nn ** 3)
+    ijk = np.stack([nodes % nn, (nodes // nn) % nn, nodes // (nn * nn)], axis=1)
+    face = np.nonzero(ijk[:, 0] == 0)[0]
+    rel = (face[:, None] * 3 + np.arange(3)[None, :]).ravel()
+    closure, nsym = box_symmetry_closure((nn, nn, nn), 3, K, rel)
+    boundary = np.nonzero(((ijk == 0) | (ijk == nn - 1)).any(axis=1))[0]
+    assert nsym == 48 and np.array_equal(closure, np.sort((boundary[:, None] * 3 + np.arange(3)[None, :]).ravel()))
+    K2 = K.tolil()
+    K2[7, 7] += 1.0  # no operation but the identity leaves this matrix invariant ... unless dof 7 is a fixed point of some of them
+    closure2, nsym2 = box_symmetry_closure((nn, nn, nn), 3, K2.tocsr(), rel)
+    assert nsym2 < 48 and set(rel) <= set(closure2) and closure2.size < closure.size
