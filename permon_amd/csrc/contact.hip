@@ -233,9 +233,38 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
         int least = 0;
         GO(pmh_fexplicit_create_shared_orbit(B, Kb, cls.data(), &E));
         GO(set_symmetries(&least));
-        if (least < 16) { // too few operations for the GEMM form
+        if (least < 16) {
+          // a class whose own touched set (a block's interface faces + a Dirichlet or contact face) is not invariant under the box's group keeps few operations -- the case of
+          // non-congruent decompositions, one class per block.  On the CLOSURE of the touched set under the group (the whole boundary of a cube) every operation survives
           pmh_fexplicit_destroy(E);
-          E = nullptr, storage = PMH_FX_CLASS_SYM, st->explicit_symmetries = 0;
+          E = nullptr, st->explicit_symmetries = 0;
+          std::vector<int> eptr((size_t)ncls + 1, 0), erel;
+          std::vector<std::vector<int>> touched((size_t)ncls);
+          for (int i = 0; i < n_leaves; i++) {
+            const int b = block_of(leaves_row[i]);
+            touched[cls[b]].push_back(leaves_row[i] - block_rowstart[b]);
+          }
+          for (int c = 0; c < ncls; c++) {
+            std::sort(touched[c].begin(), touched[c].end());
+            touched[c].erase(std::unique(touched[c].begin(), touched[c].end()), touched[c].end());
+            int b0 = 0;
+            while (b0 < nsub && cls[b0] != c) b0++;
+            const int r0 = block_rowstart[b0], r1 = block_rowstart[b0 + 1], k0 = rowptr[r0], nz = rowptr[r1] - k0;
+            std::vector<int> rp((size_t)(r1 - r0) + 1), cj((size_t)nz), out((size_t)(r1 - r0));
+            for (int i = r0; i <= r1; i++) rp[i - r0] = rowptr[i] - k0;
+            for (int k = 0; k < nz; k++) cj[k] = col[k0 + k] - r0;
+            int n_out = 0;
+            GO(pmh_box_symmetry_closure(dims + 3 * b0, ndof, rp.data(), cj.data(), val + k0, (int)touched[c].size(), touched[c].data(), &n_out, out.data(), nullptr));
+            erel.insert(erel.end(), out.begin(), out.begin() + n_out);
+            eptr[c + 1] = (int)erel.size();
+          }
+          if (erel.empty()) erel.push_back(0);
+          GO(pmh_fexplicit_create_shared_orbit_union(B, Kb, cls.data(), eptr.data(), erel.data(), &E));
+          GO(set_symmetries(&least));
+          if (least < 16) { // still too few operations for the GEMM form (boxes with three different sides): the symmetric tiles
+            pmh_fexplicit_destroy(E);
+            E = nullptr, storage = PMH_FX_CLASS_SYM, st->explicit_symmetries = 0;
+          }
         }
       }
       if (!E) {

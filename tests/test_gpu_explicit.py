@@ -382,6 +382,22 @@ def test_contact_solve_one_call(ctx):
         assert np.linalg.norm(f.K @ u - (f.f - f.B.T @ lam)) <= 1e-4 * np.linalg.norm(f.f)  # equilibrium
 
 
+def test_contact_solve_one_call_non_congruent_cubes(ctx):
+    """pmh_feti_contact_solve on cubes of DIFFERENT materials (one class per block) with the orbit storage asked for: the driver closes every class's touched set under the cube's
+    group (pmh_box_symmetry_closure + pmh_fexplicit_create_shared_orbit_union), all 48 operations survive, the set-up needs one K^+ solve per orbit of boundary dofs -- and the solve
+    is the one the inner-Krylov K^+ gives."""
+    f = pa.CubeFeti((2, 2, 1), 6, contact=True, young=[1.0, 1.5, 2.0, 3.0])
+    assert not f.congruent
+    u0, lam0, st0 = pa.FETIContactSolve(ctx, f, explicit=False)
+    u1, lam1, st1 = pa.FETIContactSolve(ctx, f, explicit=True, explicit_storage="class_orbit", explicit_symmetry=True)
+    assert st1.explicit_symmetries == 48
+    nn = 7
+    assert 0 < st1.explicit_solves <= f.nsub * (3 * (nn ** 3 - (nn - 2) ** 3) // 48 + 3 * nn) < f.nsub * 3 * nn * nn  # orbits of the boundary, not the touched dofs one by one
+    s0, s1 = st0.smalxe, st1.smalxe
+    assert (s0.reason, s0.iteration, s0.inner_iter_accu, s0.inner.ncg, s0.inner.nexp) == (s1.reason, s1.iteration, s1.inner_iter_accu, s1.inner.ncg, s1.inner.nexp)
+    assert np.linalg.norm(lam1 - lam0) <= 1e-6 * np.linalg.norm(lam0) and np.linalg.norm(u1 - u0) <= 1e-5 * np.linalg.norm(u0)
+
+
 def test_explicit_edge_cases(ctx):
     """A block that B does not touch at all (n_Gamma = 0), a block with a single touched dof, non-congruent blocks, n_Gamma around the
     32 / 128 padding boundaries -- F through the explicit operators against the iterative F; striping refuses the full storage."""

@@ -28,12 +28,14 @@ def general():
     qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-12, mg_box=box, mg_precision="fp16", bsr3=True)
     qe = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-12, mg_box=box, mg_precision="fp16", bsr3=True,
                     explicit=dict(rtol=1e-12, storage="auto", symmetry=dict(dims=(nn, nn, nn), ndof=3)))  # the symmetry hint must be ignored: 8 classes
-    yield ctx, f, loc, qi, qe
+    qc = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-12, mg_box=box, mg_precision="fp16", bsr3=True,
+                            explicit=dict(rtol=1e-12, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3, close=True)))  # every class on the closure of its touched set
+    yield ctx, f, loc, qi, qe, qc
     ctx.close()
 
 
 def test_general_decomposition_takes_the_per_block_path(general):
-    ctx, f, loc, qi, qe = general
+    ctx, f, loc, qi, qe, _qc = general
     cls = pa.csr_block_classes(loc["block_rowstart"], loc["K"])
     assert sorted(cls.tolist()) == list(range(8))  # no two blocks are equal
     assert qe.explicit_storage == "sym" and qe.explicit_symmetries == 1
@@ -43,8 +45,29 @@ def test_general_decomposition_takes_the_per_block_path(general):
     assert len(set(qe.E.n_gamma.tolist())) == 4
 
 
+def test_general_closed_orbit_path(general):
+    """The same 8-material decomposition through the orbit storage with the class sets closed under the cube's group (round 4): 48 operations per class, 24 x fewer set-up solves
+    than one per touched dof, F equal to the inner-Krylov F and to the per-block operators, the same SMALXE counts."""
+    ctx, f, loc, qi, qe, qc = general
+    assert qc.explicit_storage == "class_orbit" and qc.explicit_symmetries == 48
+    n_closed, _ = qc.E.assemble_stats()
+    n_open, _ = qe.E.assemble_stats()
+    assert n_closed * 20 < n_open
+    lam = np.random.default_rng(12).standard_normal(f.n_lambda)
+    lv, y0, y1, y2 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+    qi.F.mult(lv, y0)
+    qe.F.mult(lv, y1)
+    qc.F.mult(lv, y2)
+    n0 = np.linalg.norm(y0.to_numpy())
+    assert np.linalg.norm(y2.to_numpy() - y0.to_numpy()) <= 1e-9 * n0 and np.linalg.norm(y2.to_numpy() - y1.to_numpy()) <= 1e-9 * n0
+    qi.lam.set(0.0)
+    qc.lam.set(0.0)
+    si, sc = qi.solve_smalxe(rtol=1e-5), qc.solve_smalxe(rtol=1e-5)
+    assert (si.reason, si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (sc.reason, sc.iteration, sc.inner_iter_accu, sc.inner.ncg, sc.inner.nexp)
+
+
 def test_general_F_equals_inner_krylov_F(general):
-    ctx, f, loc, qi, qe = general
+    ctx, f, loc, qi, qe, _qc = general
     rng = np.random.default_rng(11)
     for _ in range(2):
         lam = rng.standard_normal(f.n_lambda)
@@ -59,7 +82,7 @@ def test_general_blocks_equal_direct_solves_and_scale_with_the_material(general)
     """Columns of W_b = (K_b^+)[Gamma_b, Gamma_b] against K^+ e_j by the iterative solver; and W_b = W_1-like / E_b: blocks 0 and 2 touch the same dofs
     (same position in the decomposition up to the y mirror), so E_0 W_0 and E_2 W_2 agree on their common shape only through the solver -- what IS exact is
     the scaling K_s = E_s K_1 => W_s(E) = W_s(1) / E, checked on the diagonal entries of two blocks with equal n_Gamma."""
-    ctx, f, loc, qi, qe = general
+    ctx, f, loc, qi, qe, _qc = general
     E = qe.E
     rs = np.asarray(loc["block_rowstart"])
     rng = np.random.default_rng(5)
@@ -78,7 +101,7 @@ def test_general_blocks_equal_direct_solves_and_scale_with_the_material(general)
 
 
 def test_general_contact_solve_same_counts_as_inner_krylov(general):
-    ctx, f, loc, qi, qe = general
+    ctx, f, loc, qi, qe, _qc = general
     res = []
     for q in (qi, qe):
         q.lam.set(0.0)
