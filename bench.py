@@ -82,8 +82,9 @@ def parse():
     ap.add_argument("--cpu-its-feti", type=int, default=5, help="feti: MPGP iterations of the bounded CPU-baseline sample (median of their times; cut at ~45 s)")
     ap.add_argument("--young", default="", help="feti: Young's moduli of the subdomains, comma separated, or 'distinct' (1, 1.25, 1.5 ...): a heterogeneous body whose blocks K_s = E_s K_1 all differ -- "
                     "the non-congruent case: no class sharing, no symmetry set-up, per-block symmetric storage (k_fx_symv, HBM-bound)")
-    ap.add_argument("--general-nel", type=int, default=21, help="feti at N=1: elements per edge of the secondary 'general' block (8 subdomains of 8 different materials: every column of every W_b by its own K^+ solve, "
-                    "so the set-up grows with n_Gamma: 21 -> ~20 s, 43 -> ~5 min); 0 = skip")
+    ap.add_argument("--general-nel", type=int, default=43, help="feti at N=1: elements per edge of the secondary 'general' block (8 subdomains of 8 different materials: no two blocks congruent; one class per block, "
+                    "each on the closure of its touched set under the cube's 48 symmetries -> one K^+ solve per orbit: 43 -> ~15 s of set-up; with --no-explicit-symmetry every column of every W_b by its own "
+                    "K^+ solve: 21 -> ~20 s, 43 -> minutes); 0 = skip")
     ap.add_argument("--c2-steps", type=int, default=2500, help="feti at N=1: MPGP iterations of the secondary configs[1] block (from x0 = 0 the first ~hundreds of iterations are pure CG; the expansion steps start once the iterate reaches the obstacle)")
     ap.add_argument("--no-configs3", action="store_true", help="feti at N=1: skip the secondary configs[3] block (4x4x4 subdomains of 21^3 elements, dense 384 x 384 coarse problem)")
     ap.add_argument("--no-svm", action="store_true", help="feti at N=1: skip the secondary configs[4] block (5 M x 64 SVM dual)")
@@ -818,9 +819,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         # the committed PMC passes (scripts/gpu_final_r04.sh): the headline, the configs[3] block, the general (non-congruent) block
         pmc_file = None
         if world == 1 and not a.sim_world:
-            pmc_file = ("r04_pmc_traffic_feti_explicit.json" if full_size else
+            pmc_file = ("r04_pmc_traffic_feti_explicit.json" if (full_size and congruent) else
                         "r04_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
-                        "r04_pmc_traffic_general.json" if (a.nel == 21 and a.sub == "2,2,2" and not congruent) else None)
+                        "r04_pmc_traffic_general.json" if (a.nel == 43 and a.sub == "2,2,2" and not congruent) else None)
         traffic, tsrc = pmc_lookup(ppref, pmc_file, combine="sum") if pmc_file else (None, "not the configuration of a committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "

@@ -42,6 +42,6 @@ if [[ $PART == *c* ]]; then
   run configs4 bench.py "k_svm" --workload svm --steps 20 --warmup 2
   run c2 bench.py "k_spmv_stream|k_spmv_ell|k_step_update|k_dir_update" --workload c2 --no-cpu-baseline --steps 50 --warmup 5
   run feti_iterative bench.py "bsr3" --no-cpu-baseline --no-c2 --no-iterative --kplus iterative --steps 20 --warmup 2
-  run general bench.py "k_fx_symv" --no-cpu-baseline --no-c2 --no-iterative --young distinct --nel 21 --steps 40 --warmup 4
+  run general bench.py "k_fxo_" --no-cpu-baseline --no-c2 --no-iterative --young distinct --nel 43 --steps 40 --warmup 4
   echo "pmc done"
 fi

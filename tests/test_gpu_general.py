@@ -3,8 +3,8 @@
 pmh_csr_block_classes finds 8 classes, `auto` falls to per-block symmetric storage (PMH_FX_SYM, k_fx_symv: the HBM-bound kernel), every column of every W_b
 comes from its own K^+ solve (no class sharing, no set-up by symmetry).  Checked against the inner-Krylov K^+ the reference would run (MATINV's KSP): F to 1e-9,
 sampled columns of the W_b against direct solves, identical SMALXE / MPGP counts and the same dual solution for the contact problem.
-(The full 43^3 size of this case needs 24 384 K^+ applications for the set-up, ~5 min: bench.py --young distinct --nel 43 runs it on request; the driver-run bench line
-carries the 21^3 case as its `general` block.)"""
+(On this per-block path the full 43^3 size needs 24 384 K^+ applications for the set-up, ~5 min.  Since round 4 symmetric boxes of different materials take the orbit storage with
+every class on the CLOSURE of its touched set under the cube's group -- test_general_closed_orbit_path below; the driver-run bench line carries the 43^3 case on it as `general`.)"""
 import numpy as np
 import pytest
 
