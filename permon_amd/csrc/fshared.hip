@@ -66,6 +66,7 @@ struct fxs_class {
   int              *d_coltab = nullptr, *d_fintab = nullptr; // fintab per (group, row tile): coltab offset, padded columns, first element of the tile in the group's numbering
   long long        *d_finbase = nullptr;                     // per (group, row tile): offset of split 0 in cpart
   int               item_first = 0, item_count = 0, fin_elems = 0, wgf_first = 0, wg_count = 0; // the class's items; its workgroups (slice of fx_shared::d_wgfirst)
+  int               S = 8; // orbit storage: slots of a multivector record = the smallest power of two >= the class's blocks (<= 8): a class of ONE block gathers 8-byte records, not a 64-byte line with seven zeros
   signed char     *d_use = nullptr;
   // k segments of the orbit GEMM: the positions (= the k index of the product) are grouped by WHICH columns have a structural non-zero of B there (block (group, slot)
   // does not touch g c => B[c][(g, slot)] = 0), the rows of B are permuted segment after segment (each padded to whole chunks) and a (row tile, segment) multiplies
@@ -688,7 +689,7 @@ template <int NI, int NWM, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                        const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
                                                        const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst, const int *const *__restrict__ coltab_of = nullptr,
-                                                       const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr)
+                                                       const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr, const int *__restrict__ xshift_of = nullptr)
 {
   constexpr int NWN = 4 / NWM, NJ = FXO_TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
   const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
   const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]);
-  if constexpr (MULTI) coltab = coltab_of[c], zrow = zrow_of[c], gidx = gidx_of[c];
+  unsigned xsh = 6; // log2 of the bytes of a (position, sign) record of the signed multivector: 8 slots x 8 bytes
+  if constexpr (MULTI) coltab = coltab_of[c], zrow = zrow_of[c], gidx = gidx_of[c], xsh = (unsigned)xshift_of[c];
   const double *__restrict__ Ab = A + iteml[4 * it];
   const double *__restrict__ x  = X + iteml[4 * it + 1];
   double *__restrict__ C        = cpart + iteml[4 * it + 2];
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   };
   auto gatherB = [&]() { // signed multivector: the index (position << 1 | negative) addresses the value with its sign; 64 bytes per (position, sign)
 #pragma unroll
-    for (int e = 0; e < NEB; e++) br[e] = *(const double *)(xb + ((unsigned)gn[e] * 64u + slo));
+    for (int e = 0; e < NEB; e++) br[e] = *(const double *)(xb + (MULTI ? (((unsigned)gn[e] << xsh) + slo) : ((unsigned)gn[e] * 64u + slo)));
   };
   auto store = [&](int buf) {
 #pragma unroll
@@ -862,7 +864,7 @@ static int fxo_row_tile(int M)
 #define FXO_FU 4
 __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, const int *__restrict__ fintab, const int *__restrict__ unittab, const long long *__restrict__ unitbase,
                                                        const int *__restrict__ lut, const int *__restrict__ coltab, const double *__restrict__ cp, const signed char *__restrict__ use,
-                                                       const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld, double *__restrict__ Y)
+                                                       const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld, double *__restrict__ Y, int nslot)
 {
   const int  i  = blockIdx.x * PMH_BLOCK + threadIdx.x;
   const int *ft = fintab + 4 * (ntile + 1) * blockIdx.y;
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int ns
   const int g = ct >> 3, sl = ct & 7, row = mt * tm + r;
   const int u = use[(long long)row * nsymp + g];
   if (u == 0) return;
-  const long long dst = xbase0 + (long long)blockIdx.y * ld * FXS_S + (long long)posmap[(long long)g * nc + reppos[row]] * FXS_S + sl;
+  const long long dst = xbase0 + (long long)blockIdx.y * ld * nslot + (long long)posmap[(long long)g * nc + reppos[row]] * nslot + sl;
   double          s   = 0.0;
   // FXO_FU units at a time: their look-ups, then the first 8 splits of each travel together (a plain loop compiles to load - wait - add per unit and split);
   // the sums are still taken unit after unit, split after split (+ 0.0 for a split that does not exist changes nothing)
@@ -1092,6 +1094,11 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     slot[b] = (int)C.blocks.size() % FXS_S, group[b] = (int)C.blocks.size() / FXS_S;
     C.blocks.push_back(b);
   }
+  if (sym == 2 && fxo_mfma16() && !getenv("PMH_FXO_SLOTS8"))
+    for (auto &C : S->C) {
+      C.S = 1;
+      while (C.S < FXS_S && C.S < (int)C.blocks.size()) C.S *= 2;
+    }
   // union of the touched dofs per class
   for (int c = 0; c < S->ncls; c++) S->C[c].pos.assign((size_t)std::max(1, S->C[c].nloc), -1);
   auto block_of = [&](int i) { return (int)(std::upper_bound(K->rowstart.begin(), K->rowstart.end(), i) - K->rowstart.begin()) - 1; };
@@ -1129,7 +1136,7 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
       wtot += (long long)FXM_RS * FXM_RS * ((long long)C.nsb * (C.nsb + 1) / 2); // super band sb: (sb + 1) * 16 column tiles x 16 row tiles x 256 doubles
     } else
       wtot += (long long)C.ld * C.ld;
-    xtot += (long long)C.ngroups * C.ld * FXS_S;
+    xtot += (long long)C.ngroups * C.ld * C.S;
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)std::max(1, C.nc), (void **)&C.d_urel));
     if (C.nc) PMH_CHK(pmh_memcpy_h2d(ctx, C.d_urel, C.urel.data(), sizeof(int) * (size_t)C.nc));
   }
@@ -1140,7 +1147,7 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
   for (int i = 0; i < B->n_leaves; i++) {
     const int        b = lb[i];
     const fxs_class &C = S->C[S->cls[b]];
-    rows[i]            = (int)(C.xoff + (long long)group[b] * C.ld * FXS_S + (long long)C.pos[B->h_row[i] - K->rowstart[b]] * FXS_S + slot[b]);
+    rows[i]            = (int)(C.xoff + (long long)group[b] * C.ld * C.S + (long long)C.pos[B->h_row[i] - K->rowstart[b]] * C.S + slot[b]);
   }
   if (sym == 2) {
     for (auto &C : S->C) C.tmask.assign((size_t)std::max(1, C.ngroups) * std::max(1, C.nc) * FXS_S, 0);
@@ -1156,8 +1163,8 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     std::vector<int>    rows2((size_t)std::max(1, 2 * B->n_leaves)), root2((size_t)std::max(1, 2 * B->n_leaves));
     std::vector<double> sign2((size_t)std::max(1, 2 * B->n_leaves));
     for (int i = 0; i < B->n_leaves; i++) {
-      const int slot_i = rows[i] % FXS_S, base = rows[i] - slot_i; // entry (position, slot) -> (position, +, slot) and (position, -, slot)
-      rows2[2 * i] = 2 * base + slot_i, rows2[2 * i + 1] = 2 * base + FXS_S + slot_i;
+      const int slot_i = slot[lb[i]], base = rows[i] - slot_i, Sc = S->C[S->cls[lb[i]]].S; // entry (position, slot) -> (position, +, slot) and (position, -, slot)
+      rows2[2 * i] = 2 * base + slot_i, rows2[2 * i + 1] = 2 * base + Sc + slot_i;
       root2[2 * i] = root2[2 * i + 1] = B->h_root[i];
       sign2[2 * i] = B->h_sign[i], sign2[2 * i + 1] = -B->h_sign[i];
     }
@@ -1601,7 +1608,10 @@ static int fxo_prepare(fx_shared *S)
       else if (S->C[c].tm != tm_first) one_tile = false;
       nplanned++;
     }
-  const bool merged = one_tile && nplanned > 1;
+  bool small_records = false; // a class with fewer than 8 slots per record: only the table-driven kernel knows the record size
+  for (int c = 0; c < S->ncls; c++)
+    if (tab_of[c] >= 0 && S->C[c].S != FXS_S) small_records = true;
+  const bool merged = one_tile && (nplanned > 1 || small_records), tables = merged || small_records; // (classes on different row tiles: one table-driven launch per class)
   const int slots_all = getenv("PMH_FXO_SLOTS") ? std::max(1, atoi(getenv("PMH_FXO_SLOTS"))) : 2 * ctx->num_cus;
   const int slots = merged ? std::max(16, slots_all / nplanned) : slots_all;
   for (int c = 0; c < S->ncls; c++) {
@@ -1770,7 +1780,7 @@ static int fxo_prepare(fx_shared *S)
           const fxo_unit &U = P.units[a.u];
           items.insert(items.end(), {c, U.g, U.mt, nt, a.k0, a.k1, a.sp, U.nct});
           iteml.push_back(C.aoff);
-          iteml.push_back(2 * (C.xoff + (long long)U.g * C.ld * FXS_S)); // in the signed multivector X2
+          iteml.push_back(2 * (C.xoff + (long long)U.g * C.ld * C.S)); // in the signed multivector X2
           iteml.push_back(U.cbase + (long long)a.sp * C.tm * U.nct);
           iteml.push_back((long long)U.coff + (long long)nt * FXO_TN);
           len += a.k1 - a.k0;
@@ -1852,12 +1862,13 @@ static int fxo_prepare(fx_shared *S)
   if (S->d_wgfirst_all) pmh_free(ctx, S->d_wgfirst_all), S->d_wgfirst_all = nullptr;
   if (S->d_zrow_of) pmh_free(ctx, S->d_zrow_of), pmh_free(ctx, (void *)S->d_coltab_of), pmh_free(ctx, (void *)S->d_gidx_of), S->d_zrow_of = nullptr;
   S->nwg_all = 0, S->merged_tm = 0;
-  if (merged) {
-    std::vector<int>         wall, zr((size_t)S->ncls, 0);
+  if (tables) {
+    std::vector<int>         wall, zr((size_t)S->ncls, 0), xs((size_t)S->ncls, 6);
     std::vector<const int *> ct((size_t)S->ncls, nullptr), gi((size_t)S->ncls, nullptr);
     for (int c = 0; c < S->ncls; c++) {
       const fxs_class &C = S->C[c];
       zr[c] = C.nsymp, ct[c] = C.d_coltab, gi[c] = C.d_gidx;
+      for (xs[c] = 3; (1 << (xs[c] - 3)) < C.S; xs[c]++) {}
       for (int w = 0; w < C.wg_count; w++) wall.push_back(wgfirst[C.wgf_first + w] + C.item_first); // (a class's items are contiguous and the classes follow one another:
       S->nwg_all += C.wg_count;                                                                       //  a workgroup ends where the next one, of whichever class, begins)
     }
@@ -1867,13 +1878,14 @@ static int fxo_prepare(fx_shared *S)
     wall.push_back(last_end);
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * wall.size(), (void **)&S->d_wgfirst_all));
     PMH_CHK(pmh_memcpy_h2d(ctx, S->d_wgfirst_all, wall.data(), sizeof(int) * wall.size()));
+    zr.insert(zr.end(), xs.begin(), xs.end()); // [zrow of the classes | record shifts of the classes]
     PMH_CHK(pmh_malloc(ctx, sizeof(int) * zr.size(), (void **)&S->d_zrow_of));
     PMH_CHK(pmh_memcpy_h2d(ctx, S->d_zrow_of, zr.data(), sizeof(int) * zr.size()));
     PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * ct.size(), (void **)&S->d_coltab_of));
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_coltab_of, ct.data(), sizeof(const int *) * ct.size()));
     PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * gi.size(), (void **)&S->d_gidx_of));
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_gidx_of, gi.data(), sizeof(const int *) * gi.size()));
-    S->merged_tm = tm_first;
+    S->merged_tm = merged ? tm_first : 0;
   }
   S->fxo_ready = 1;
   return PMH_SUCCESS;
@@ -1887,7 +1899,7 @@ static int fxo_gemm(fx_shared *S)
 #define FXO_LAUNCH_ALL(NI, NWM)                                                                                                                                                                      \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true>), dim3(S->nwg_all), dim3(256), 0, st, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_wg,                 \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)S->d_wgfirst_all, \
-                     (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of)
+                     (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
     switch (S->merged_tm) {
     case 144: FXO_LAUNCH_ALL(9, 1); break;
     case 128: FXO_LAUNCH_ALL(4, 2); break;
@@ -1918,6 +1930,20 @@ static int fxo_gemm(fx_shared *S)
 #endif
     if (merged) {
       // (the class's products were part of the launch above)
+    } else if (fxo_mfma16() && C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
+#define FXO_LAUNCH_T(NI, NWM)                                                                                                                                                                             \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
+                     (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first),     \
+                     (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
+      switch (C.tm) {
+      case 144: FXO_LAUNCH_T(9, 1); break;
+      case 128: FXO_LAUNCH_T(4, 2); break;
+      case 112: FXO_LAUNCH_T(7, 1); break;
+      case 96: FXO_LAUNCH_T(3, 2); break;
+      case 80: FXO_LAUNCH_T(5, 1); break;
+      default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
+      }
+#undef FXO_LAUNCH_T
     } else if (fxo_mfma16()) {
       switch (C.tm) {
       case 144: FXO_LAUNCH((k_fxo_gemm16<9, 1>)); break;
@@ -1960,7 +1986,7 @@ static int fxo_gemm(fx_shared *S)
     if (C.fin_elems > 0)
       hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, (const int *)C.d_fintab,
                          (const int *)C.d_unittab, (const long long *)C.d_finbase, (const int *)C.d_lut, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
-                         S->Y);
+                         S->Y, C.S);
   }
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
@@ -2166,12 +2192,12 @@ static int fxs_gemm(fx_shared *S)
 }
 
 // X (position, slot) -> X2 (position, +-, slot): only for the dense kernel alone on a multivector handed in (pmh_fexplicit_dense_mult); the operator fills X2 by its own gluing
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_signed_copy(long long n, const double *__restrict__ X, double *__restrict__ X2)
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_signed_copy(long long n, int nslot, const double *__restrict__ X, double *__restrict__ X2)
 {
   for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * PMH_BLOCK) {
-    const long long p = i / FXS_S, sl = i % FXS_S;
+    const long long p = i / nslot, sl = i % nslot;
     const double    v = X[i];
-    X2[2 * p * FXS_S + sl] = v, X2[(2 * p + 1) * FXS_S + sl] = -v;
+    X2[2 * p * nslot + sl] = v, X2[(2 * p + 1) * nslot + sl] = -v;
   }
 }
 
@@ -2187,7 +2213,11 @@ int fxs_apply(fx_shared *S, const double *lambda, double *y)
 int fxs_dense(fx_shared *S)
 {
   if (S->sym == 2 && S->nX > 0) {
-    hipLaunchKernelGGL(k_fxo_signed_copy, dim3((unsigned)std::min<long long>(4096, (S->nX + PMH_BLOCK - 1) / PMH_BLOCK)), dim3(PMH_BLOCK), 0, S->ctx->stream, S->nX, (const double *)S->X, S->X2);
+    for (const fxs_class &C : S->C) { // class by class: the records of a class have C.S slots
+      const long long n = (long long)C.ngroups * C.ld * C.S;
+      if (!n) continue;
+      hipLaunchKernelGGL(k_fxo_signed_copy, dim3((unsigned)std::min<long long>(4096, (n + PMH_BLOCK - 1) / PMH_BLOCK)), dim3(PMH_BLOCK), 0, S->ctx->stream, n, C.S, (const double *)(S->X + C.xoff), S->X2 + 2 * C.xoff);
+    }
     PMH_HIP(hipGetLastError());
   }
   return fxs_gemm(S);
