@@ -66,6 +66,7 @@ struct fxs_class {
   int              *d_coltab = nullptr, *d_fintab = nullptr; // fintab per (group, row tile): coltab offset, padded columns, first element of the tile in the group's numbering
   long long        *d_finbase = nullptr;                     // per (group, row tile): offset of split 0 in cpart
   int               item_first = 0, item_count = 0, fin_elems = 0, wgf_first = 0, wg_count = 0; // the class's items; its workgroups (slice of fx_shared::d_wgfirst)
+  int               tn = 128; // column tile of the class's GEMM: 64 when no (group, row tile) lists more than 64 columns (a class of ONE block lists at most its 48 operations)
   int               S = 8; // orbit storage: slots of a multivector record = the smallest power of two >= the class's blocks (<= 8): a class of ONE block gathers 8-byte records, not a 64-byte line with seven zeros
   signed char     *d_use = nullptr;
   // k segments of the orbit GEMM: the positions (= the k index of the product) are grouped by WHICH columns have a structural non-zero of B there (block (group, slot)
@@ -107,7 +108,7 @@ struct fx_shared {
   long long             *d_wgl = nullptr; // per item: offset of its class's tiles, offset of its transposed partial sums
   int                   *d_items = nullptr, *d_wgfirst = nullptr;
   // several classes on the same row tile: ONE launch over all their work items (fxo_gemm): workgroup -> items with global item numbers, per-class pointer tables
-  int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0;
+  int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0, merged_tn = 128;
   const int            **d_coltab_of = nullptr, **d_gidx_of = nullptr;
   double                *pt = nullptr;
   long long              pt_tot = 0;
@@ -685,15 +686,16 @@ __device__ unsigned long long *fxo_trace_buf;
 // NWM waves down x (4 / NWM) across: NWM = 2: wave tile 16 NI x 64 (workgroup 32 NI x 128: 128 or 96 rows); NWM = 1: wave tile 16 NI x 32, the workgroup's rows are ANY multiple of 16
 // up to 144 (715 representatives pad to 720 = 5 x 144, as with the 4-row units of k_fxo_gemm4<15>; NI + 2 operand reads for 2 NI instructions per k step of 4)
 // MULTI: one launch over the items of several classes (every class its own column lists, gather indices and symmetry count: the *_of tables, indexed by the item's class)
-template <int NI, int NWM, bool MULTI = false>
+// TN: the workgroup's column tile (128; 64 for classes that list at most 64 columns per row tile: half the products of zeros)
+template <int NI, int NWM, bool MULTI = false, int TN = FXO_TN>
 __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
                                                        const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
                                                        const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst, const int *const *__restrict__ coltab_of = nullptr,
                                                        const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr, const int *__restrict__ xshift_of = nullptr)
 {
-  constexpr int NWN = 4 / NWM, NJ = FXO_TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
+  constexpr int NWN = 4 / NWM, NJ = TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
   __shared__ double As[2][FXO_TK][LDA];
-  __shared__ double Bs[2][FXO_TK][FXO_LDB4];
+  __shared__ double Bs[2][FXO_TK][TN + 16];
   for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
   __builtin_amdgcn_sched_barrier(0);
   const int *w8 = items + 8 * it;
@@ -706,9 +708,9 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   const double *__restrict__ x  = X + iteml[4 * it + 1];
   double *__restrict__ C        = cpart + iteml[4 * it + 2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
-  constexpr int NQ = FXO_TK * TM / 2, NEA = NQ / 256, RA = NQ % 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // a chunk of A: NEA passes of 16 bytes per lane + (RA = 128) one of 8
+  constexpr int NQ = FXO_TK * TM / 2, NEA = NQ / 256, RA = NQ % 256, KPB = 256 / TN, NEB = FXO_TK / KPB; // a chunk of A: NEA passes of 16 bytes per lane + (RA = 128) one of 8
   static_assert(RA == 0 || RA == 128, "row tile");
-  const int  col = t % FXO_TN, kb = t / FXO_TN;
+  const int  col = t % TN, kb = t / TN;
   const int  ct  = coltab[iteml[4 * it + 3] + col];
   const int  sl  = ct < 0 ? 0 : (ct & 7);
   const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * FXO_TN + wn * WC + j * 16 + ra] = acc[i][j][r];
+      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * TN + wn * WC + j * 16 + ra] = acc[i][j][r];
   }
 }
 
@@ -1439,6 +1441,23 @@ static int fxo_prepare(fx_shared *S)
     const int        ntile = C.Mp / C.tm, ncode = C.nsym * FXS_S, cw = (ncode + 63) / 64;
     std::vector<int> coltab, fintab((size_t)C.ngroups * (ntile + 1) * 4, 0);
     std::vector<unsigned long long> need((size_t)C.ngroups * ntile * cw, 0ULL); // the same lists as bit sets over the codes
+    { // the class's column tile: 64 when no (group, row tile) lists more than 64 columns -- a class of ONE block lists at most its 48 operations, and a 128-wide tile would
+      // multiply 80 columns of zeros (PMH_FXO_TN=128 keeps the wide tile for the A/B)
+      int most = 0;
+      for (int gr = 0; gr < C.ngroups; gr++)
+        for (int mt = 0; mt < ntile; mt++) {
+          int n = 0;
+          for (int code = 0; code < ncode; code++) {
+            const size_t b   = ((size_t)gr * C.nsym + (code >> 3)) * FXS_S + (code & 7);
+            bool         any = false;
+            for (int row = mt * C.tm; row < std::min(M, (mt + 1) * C.tm) && !any; row++) any = (pat[(size_t)rowrep[row] * nw + b / 64] >> (b % 64)) & 1ULL;
+            n += any;
+          }
+          most = std::max(most, n);
+        }
+      const char *e = getenv("PMH_FXO_TN");
+      C.tn = (fxo_mfma16() && C.S != FXS_S && most <= 64 && !(e && atoi(e) == 128)) ? 64 : 128; // (only classes on the table-driven kernel: the single-class kernel of 8-block classes is left as it is)
+    }
     for (int gr = 0; gr < C.ngroups; gr++) {
       int elems = 0;
       for (int mt = 0; mt < ntile; mt++) {
@@ -1449,7 +1468,7 @@ static int fxo_prepare(fx_shared *S)
           for (int row = mt * C.tm; row < std::min(M, (mt + 1) * C.tm) && !any; row++) any = (pat[(size_t)rowrep[row] * nw + b / 64] >> (b % 64)) & 1ULL;
           if (any) coltab.push_back(code), need[((size_t)gr * ntile + mt) * cw + code / 64] |= 1ULL << (code % 64);
         }
-        while ((coltab.size() - coff) % FXO_TN) coltab.push_back(-1);
+        while ((coltab.size() - coff) % C.tn) coltab.push_back(-1);
         int *ft = fintab.data() + ((size_t)gr * (ntile + 1) + mt) * 4;
         ft[0] = coff, ft[1] = (int)coltab.size() - coff, ft[2] = elems;
         elems += C.tm * ft[1];
@@ -1498,7 +1517,7 @@ static int fxo_prepare(fx_shared *S)
           for (int mt = 0; mt < ntile; mt++) {
             int n = 0;
             for (int w = 0; w < cw; w++) n += __builtin_popcountll(need[((size_t)gr * ntile + mt) * cw + w] & sig[(size_t)gr * cw + w]);
-            tiles += (n + FXO_TN - 1) / FXO_TN;
+            tiles += (n + C.tn - 1) / C.tn;
           }
         return (long long)((npos + FXO_TK - 1) / FXO_TK) * tiles;
       };
@@ -1562,7 +1581,7 @@ static int fxo_prepare(fx_shared *S)
             if (in) coltab.push_back(code), n++;
           }
           U.listed = n;
-          while ((coltab.size() - U.coff) % FXO_TN) coltab.push_back(-1);
+          while ((coltab.size() - U.coff) % C.tn) coltab.push_back(-1);
           U.nct = (int)coltab.size() - U.coff;
           P.units.push_back(U);
         }
@@ -1600,12 +1619,12 @@ static int fxo_prepare(fx_shared *S)
   const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
   const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
   // several classes on one row tile share ONE launch (fxo_gemm): the resident workgroups are divided among them
-  int nplanned = 0, tm_first = 0;
+  int nplanned = 0, tm_first = 0, tn_first = 128;
   bool one_tile = fxo_mfma16() && !getenv("PMH_FXO_NO_MERGE");
   for (int c = 0; c < S->ncls; c++)
     if (tab_of[c] >= 0) {
-      if (!nplanned) tm_first = S->C[c].tm;
-      else if (S->C[c].tm != tm_first) one_tile = false;
+      if (!nplanned) tm_first = S->C[c].tm, tn_first = S->C[c].tn;
+      else if (S->C[c].tm != tm_first || S->C[c].tn != tn_first) one_tile = false;
       nplanned++;
     }
   bool small_records = false; // a class with fewer than 8 slots per record: only the table-driven kernel knows the record size
@@ -1663,13 +1682,13 @@ static int fxo_prepare(fx_shared *S)
     const bool         aligned = fixedS || getenv("PMH_FXO_NO_STREAMK");
     for (fxo_unit &U : P.units) U.S = 0;
     int ntlmax = 0;
-    for (const fxo_unit &U : P.units) ntlmax = std::max(ntlmax, U.nct / FXO_TN);
+    for (const fxo_unit &U : P.units) ntlmax = std::max(ntlmax, U.nct / C.tn);
     if (aligned) {
       auto wgs = [&](int T) {
         long long n = 0;
         for (const fxo_unit &U : P.units) {
           const int nku = U.kc1 - U.kc0;
-          if (nku > 0) n += (long long)(U.nct / FXO_TN) * std::max(1, std::min((nku + T - 1) / T, std::max(1, nku / minch)));
+          if (nku > 0) n += (long long)(U.nct / C.tn) * std::max(1, std::min((nku + T - 1) / T, std::max(1, nku / minch)));
         }
         return n;
       };
@@ -1685,13 +1704,13 @@ static int fxo_prepare(fx_shared *S)
         fxo_unit &U  = P.units[ui];
         const int nku = U.kc1 - U.kc0;
         U.S          = nku > 0 ? std::max(1, std::min(fixedS ? fixedS : (nku + Tbest - 1) / Tbest, std::max(1, nku / minch))) : 0;
-        for (int sp = 0; sp < U.S; sp++) pieces.push_back({U.nct / FXO_TN, {{(int)ui, U.kc0 + (int)((long long)nku * sp / U.S), U.kc0 + (int)((long long)nku * (sp + 1) / U.S), sp}}});
+        for (int sp = 0; sp < U.S; sp++) pieces.push_back({U.nct / C.tn, {{(int)ui, U.kc0 + (int)((long long)nku * sp / U.S), U.kc0 + (int)((long long)nku * (sp + 1) / U.S), sp}}});
       }
     } else {
       std::vector<std::vector<int>> seq((size_t)ntlmax + 1); // units by column tile count, in unit order (group, row tile, segment)
       std::vector<long long>        N((size_t)ntlmax + 1, 0);
       for (size_t ui = 0; ui < P.units.size(); ui++)
-        if (P.units[ui].kc1 > P.units[ui].kc0) seq[P.units[ui].nct / FXO_TN].push_back((int)ui), N[P.units[ui].nct / FXO_TN] += P.units[ui].kc1 - P.units[ui].kc0;
+        if (P.units[ui].kc1 > P.units[ui].kc0) seq[P.units[ui].nct / C.tn].push_back((int)ui), N[P.units[ui].nct / C.tn] += P.units[ui].kc1 - P.units[ui].kc0;
       auto wgs = [&](long long T) {
         long long n = 0;
         for (int k = 1; k <= ntlmax; k++) n += (long long)k * ((N[k] + T - 1) / T);
@@ -1782,7 +1801,7 @@ static int fxo_prepare(fx_shared *S)
           iteml.push_back(C.aoff);
           iteml.push_back(2 * (C.xoff + (long long)U.g * C.ld * C.S)); // in the signed multivector X2
           iteml.push_back(U.cbase + (long long)a.sp * C.tm * U.nct);
-          iteml.push_back((long long)U.coff + (long long)nt * FXO_TN);
+          iteml.push_back((long long)U.coff + (long long)nt * C.tn);
           len += a.k1 - a.k0;
         }
         wmax = std::max(wmax, len), nitem2 += pc.parts.size() > 1;
@@ -1885,7 +1904,7 @@ static int fxo_prepare(fx_shared *S)
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_coltab_of, ct.data(), sizeof(const int *) * ct.size()));
     PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * gi.size(), (void **)&S->d_gidx_of));
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_gidx_of, gi.data(), sizeof(const int *) * gi.size()));
-    S->merged_tm = merged ? tm_first : 0;
+    S->merged_tm = merged ? tm_first : 0, S->merged_tn = tn_first;
   }
   S->fxo_ready = 1;
   return PMH_SUCCESS;
@@ -1896,16 +1915,21 @@ static int fxo_gemm(fx_shared *S)
   hipStream_t st = S->ctx->stream;
   const bool  merged = S->merged_tm > 0 && S->nwg_all > 0; // several classes on one row tile: one GEMM launch over all their items, then the classes' finishing launches
   if (merged) {
-#define FXO_LAUNCH_ALL(NI, NWM)                                                                                                                                                                      \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true>), dim3(S->nwg_all), dim3(256), 0, st, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_wg,                 \
+#define FXO_LAUNCH_ALL(NI, NWM, TNW)                                                                                                                                                                      \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(S->nwg_all), dim3(256), 0, st, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_wg,                 \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)S->d_wgfirst_all, \
                      (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
-    switch (S->merged_tm) {
-    case 144: FXO_LAUNCH_ALL(9, 1); break;
-    case 128: FXO_LAUNCH_ALL(4, 2); break;
-    case 112: FXO_LAUNCH_ALL(7, 1); break;
-    case 96: FXO_LAUNCH_ALL(3, 2); break;
-    case 80: FXO_LAUNCH_ALL(5, 1); break;
+    switch (S->merged_tm + (S->merged_tn == 64 ? 1 : 0)) {
+    case 144: FXO_LAUNCH_ALL(9, 1, 128); break;
+    case 145: FXO_LAUNCH_ALL(9, 1, 64); break;
+    case 128: FXO_LAUNCH_ALL(4, 2, 128); break;
+    case 129: FXO_LAUNCH_ALL(4, 2, 64); break;
+    case 112: FXO_LAUNCH_ALL(7, 1, 128); break;
+    case 113: FXO_LAUNCH_ALL(7, 1, 64); break;
+    case 96: FXO_LAUNCH_ALL(3, 2, 128); break;
+    case 97: FXO_LAUNCH_ALL(3, 2, 64); break;
+    case 80: FXO_LAUNCH_ALL(5, 1, 128); break;
+    case 81: FXO_LAUNCH_ALL(5, 1, 64); break;
     default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", S->merged_tm);
     }
 #undef FXO_LAUNCH_ALL
@@ -1931,16 +1955,21 @@ static int fxo_gemm(fx_shared *S)
     if (merged) {
       // (the class's products were part of the launch above)
     } else if (fxo_mfma16() && C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
-#define FXO_LAUNCH_T(NI, NWM)                                                                                                                                                                             \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
+#define FXO_LAUNCH_T(NI, NWM, TNW)                                                                                                                                                                             \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first),     \
                      (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
-      switch (C.tm) {
-      case 144: FXO_LAUNCH_T(9, 1); break;
-      case 128: FXO_LAUNCH_T(4, 2); break;
-      case 112: FXO_LAUNCH_T(7, 1); break;
-      case 96: FXO_LAUNCH_T(3, 2); break;
-      case 80: FXO_LAUNCH_T(5, 1); break;
+      switch (C.tm + (C.tn == 64 ? 1 : 0)) {
+      case 144: FXO_LAUNCH_T(9, 1, 128); break;
+      case 145: FXO_LAUNCH_T(9, 1, 64); break;
+      case 128: FXO_LAUNCH_T(4, 2, 128); break;
+      case 129: FXO_LAUNCH_T(4, 2, 64); break;
+      case 112: FXO_LAUNCH_T(7, 1, 128); break;
+      case 113: FXO_LAUNCH_T(7, 1, 64); break;
+      case 96: FXO_LAUNCH_T(3, 2, 128); break;
+      case 97: FXO_LAUNCH_T(3, 2, 64); break;
+      case 80: FXO_LAUNCH_T(5, 1, 128); break;
+      case 81: FXO_LAUNCH_T(5, 1, 64); break;
       default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
       }
 #undef FXO_LAUNCH_T
