@@ -103,7 +103,9 @@ def test_default_workload_line_small():
     assert "whole solve" in c1["timed"] and c1["steps_by_type"]["cg"] + c1["steps_by_type"]["expansion"] + c1["steps_by_type"]["proportioning"] == c1["steps"]
     # the secondary blocks of the driver-run line: general (non-congruent) decomposition, configs[3], configs[4], the one-call contact solve
     g = d["general"]
-    assert g["value"] > 0 and g["kplus"]["storage"] == "sym" and g["roofline"]["bound"] == "hbm" and "k_fx_symv" in g["roofline"]["kernel"] and "HETEROGENEOUS" in g["workload"], g
+    # (round 4: one class per block, every class on the closure of its touched set under the cube's group -> orbit storage with all 48 operations, the GEMM as the dense apply)
+    assert g["value"] > 0 and g["kplus"]["storage"] == "class_orbit" and g["kplus"]["setup_symmetries"] == 48 and g["roofline"]["bound"] == "mfma" and "k_fxo_gemm" in g["roofline"]["kernel"], g
+    assert "HETEROGENEOUS" in g["workload"] and 0 < g["roofline"]["frac"] <= 1.0, g
     c3 = d["configs3"]
     assert c3["value"] > 0 and c3["coarse_problem"]["m"] == 384 and c3["coarse_problem"]["GGt_mfma_ms"] > 0 and c3["workload"].startswith("configs[3]"), c3
     c4 = d["configs4"]
