@@ -189,6 +189,10 @@ def test_driver_and_chain_release_their_device_memory(ctx):
         pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6)  # the default: K^- P_R
         pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, regularize=True)
         pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, regularize=False, lumped=True)
+        for orth in ("gs", "implicit"):  # the unprojected chain: SMALXE, the orthonormalised projector, its explicit T G / implicit T
+            _, _, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, rtol=1e-6, options="-project 0 -dual_qp_E_orth_type %s -qp_chain_view_kkt" % orth)
+            assert st.reason > 0 and st.smalxe.iteration == st.iteration
+            assert ("not available" in st.view_text) == (orth == "implicit")  # ||BE x - cE|| of the implicitly orthonormalised QP (qp.c:303-318)
 
     once()
     free0, total = ctx.mem_info()
