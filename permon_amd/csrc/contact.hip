@@ -89,7 +89,8 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
   // ---- kernel bases: block-wise Gram-Schmidt (QPTDualize orthonormalises R, qptransform.c:1001)
   std::vector<double> Rn((size_t)kdim * N, 0.0);
   std::vector<int>    bdim(nsub, 0);
-  for (int s = 0; s < nsub; s++) {
+  std::vector<int> gs_bad(nsub, 0);
+  auto gram_schmidt = [&](int s) { // one host thread per block (8 x 6 vectors of 255 552 entries: 0.06 s on one thread)
     const int lo = block_rowstart[s], hi = block_rowstart[s + 1];
     int       d  = 0;
     for (int k = 0; k < kdim; k++) {
@@ -106,12 +107,22 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
         }
       double nrm = 0.0;
       for (double x : v) nrm += x * x;
-      if (nrm <= 1e-24 * nrm0) return pmh_set_error(PMH_ERR_ARG, "pmh_feti_contact_solve: the kernel vectors of block %d are linearly dependent", s);
+      if (nrm <= 1e-24 * nrm0) {
+        gs_bad[s] = 1;
+        return;
+      }
       nrm = std::sqrt(nrm);
       for (int i = 0; i < hi - lo; i++) Rn[(size_t)d * N + lo + i] = v[i] / nrm;
       d++;
     }
     bdim[s] = d;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int s = 0; s < nsub; s++) th.emplace_back(gram_schmidt, s);
+    for (auto &t : th) t.join();
+    for (int s = 0; s < nsub; s++)
+      if (gs_bad[s]) return pmh_set_error(PMH_ERR_ARG, "pmh_feti_contact_solve: the kernel vectors of block %d are linearly dependent", s);
   }
   std::vector<int> grow0(nsub + 1, 0);
   for (int s = 0; s < nsub; s++) grow0[s + 1] = grow0[s] + bdim[s];

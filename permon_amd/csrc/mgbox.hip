@@ -10,6 +10,7 @@
 //     injected from the fine level (P R_{l+1} = R_l), by a threaded blocked Cholesky; plain inverse for a non-singular block.
 // Congruent blocks (bit-identical matrices, pmh_csr_block_classes) are processed once.  The result goes to pmh_mg_create.
 #include <algorithm>
+#include <deque>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -316,7 +317,7 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   stage("block classes");
   // blocks of one class must also share the box and the kernel dimension (the kernel SPACE follows from the matrix)
   struct Level {
-    HCsr                A, P;
+    HCsr                A, P, Pt;
     double              lam = 0.0;
     std::vector<double> R; // kdim_b x n_l kernel vectors of this level (injected)
   };
@@ -364,9 +365,9 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
       {
         const HCsr AP = spgemm(F.A, F.P);
         stage("  (class) A P");
-        const HCsr Pt = transpose(F.P);
+        F.Pt = transpose(F.P);
         stage("  (class) P'");
-        const HCsr G2 = spgemm(Pt, AP);
+        const HCsr G2 = spgemm(F.Pt, AP);
         stage("  (class) P' (A P)");
         Cn.A = symmetrize(G2);
         stage("  (class) symmetrise");
@@ -425,24 +426,31 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   std::vector<pmh_csr> Ah(nlev), Ph(std::max(1, nlev - 1)), created;
   std::vector<double>  lam(std::max(1, nlev - 1), 1.0);
   Ah[0] = A_fine;
-  auto cat = [&](int l, bool isP, pmh_csr *dst) -> int {
+  struct HostCat { // the concatenated host arrays stay alive until pmh_mg_create has built its block copies from them (host hint: no download of what was just uploaded)
+    std::vector<int>    rp, ci;
+    std::vector<double> va;
+  };
+  std::deque<HostCat> kept;
+  auto cat = [&](int l, int which, pmh_csr *dst) -> int { // which: 0 the level's operator, 1 its prolongation, 2 the transpose of the prolongation
     // sized once, every block filled by its own thread (the entry-by-entry push_back of one thread was 0.2 s of the set-up for configs[2])
     size_t nr_tot = 0, nz_tot = 0;
     std::vector<size_t> r0(nblocks), k0(nblocks);
     std::vector<int>    c0(nblocks);
     int                 roff = 0, coff = 0;
     for (int b = 0; b < nblocks; b++) {
-      const HCsr &M = isP ? H[cls[b]].L[l].P : H[cls[b]].L[l].A;
+      const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
       r0[b] = nr_tot, k0[b] = nz_tot, c0[b] = coff;
       nr_tot += (size_t)M.nr, nz_tot += (size_t)M.rp[M.nr], roff += M.nr, coff += M.nc;
     }
     if (nz_tot > (size_t)0x7fffff00) return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create_box: level %d has %zu non-zeros (int32 row pointers)", l, nz_tot);
-    std::vector<int>    rp(nr_tot + 1), ci(nz_tot);
-    std::vector<double> va(nz_tot);
+    kept.emplace_back();
+    std::vector<int>    &rp = kept.back().rp, &ci = kept.back().ci;
+    std::vector<double> &va = kept.back().va;
+    rp.resize(nr_tot + 1), ci.resize(nz_tot), va.resize(nz_tot);
     rp[0] = 0;
     {
       auto fillb = [&](int b) {
-        const HCsr &M = isP ? H[cls[b]].L[l].P : H[cls[b]].L[l].A;
+        const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
         for (int i = 0; i < M.nr; i++) rp[r0[b] + i + 1] = (int)(k0[b] + (size_t)M.rp[i + 1]);
         const size_t nz = (size_t)M.rp[M.nr];
         for (size_t k = 0; k < nz; k++) ci[k0[b] + k] = M.ci[k] + c0[b];
@@ -453,13 +461,17 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
       for (auto &x : th) x.join();
     }
     PMH_CHK(pmh_csr_create(ctx, roff, coff, rp.data(), ci.data(), va.data(), dst));
-    created.push_back(*dst);
+    pmh_csr_set_host_hint(*dst, rp.data(), ci.data(), va.data());
+    if (which != 2) created.push_back(*dst);
     return PMH_SUCCESS;
   };
   for (int l = 0; l < nlev; l++) {
-    if (l > 0) PMH_CHK(cat(l, false, &Ah[l]));
+    if (l > 0) PMH_CHK(cat(l, 0, &Ah[l]));
     if (l + 1 < nlev) {
-      PMH_CHK(cat(l, true, &Ph[l]));
+      PMH_CHK(cat(l, 1, &Ph[l]));
+      pmh_csr Pt = nullptr; // the classes' own transposes, concatenated: pmh_mg_create would otherwise download P and transpose the 16 M entries on one host thread
+      PMH_CHK(cat(l, 2, &Pt));
+      PMH_CHK(pmh_csr_adopt_transpose(Ph[l], Pt));
       for (int c = 0; c < ncls; c++) lam[l] = (c == 0) ? H[c].L[l].lam : std::max(lam[l], H[c].L[l].lam);
     }
   }
@@ -473,6 +485,10 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   }
   PMH_CHK(pmh_mg_create(ctx, nlev, Ah.data(), Ph.data(), degree, lam.data(), 0.1, 1.1, nblocks, crs.data(), cp.data(), precision, out));
   stage("pmh_mg_create (block copies, transfer operators)");
-  for (pmh_csr a : created) PMH_CHK(pmh_mg_adopt_csr(*out, a));
+  for (pmh_csr a : created) {
+    pmh_csr_set_host_hint(a, nullptr, nullptr, nullptr); // (the host arrays go away with this function)
+    if (a->transpose) pmh_csr_set_host_hint(a->transpose, nullptr, nullptr, nullptr);
+    PMH_CHK(pmh_mg_adopt_csr(*out, a));
+  }
   return PMH_SUCCESS;
 }

@@ -110,6 +110,7 @@ struct pmh_spmv_epi {
   const int    *halt;           // optional device flag: when set the launch (and its finalise) is a no-op
 };
 int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_epi &epi);
+int pmh_csr_adopt_transpose(pmh_csr A, pmh_csr At); // A' built by the caller; A owns it afterwards
 inline void pmh_csr_set_host_hint(pmh_csr A, const int *rowptr, const int *col, const double *val) { A->h_rowptr = rowptr, A->h_col = col, A->h_val = val; }
 int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part); // chunk sums of A x (long rows), summed by the consumer
 int pmh_csr_mult_partials2(pmh_csr A, const double *x, const double *x2, const int **lrow, const double **part, const double **part2); // the same for two vectors in ONE pass over A (each sum as the single form takes it)

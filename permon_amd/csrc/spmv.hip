@@ -945,6 +945,16 @@ static int build_transpose(pmh_csr A)
   return pmh_csr_create(ctx, A->ncols, A->nrows, trp.data(), tci.data(), tva.data(), &A->transpose);
 }
 
+// A' handed over by the caller (who built it anyway): A owns it from here on.  At must be the CSR transpose of A with ascending column indices inside every row
+// (what build_transpose produces), so that products with it sum in the same order
+int pmh_csr_adopt_transpose(pmh_csr A, pmh_csr At)
+{
+  PMH_ARG(A && At && At->nrows == A->ncols && At->ncols == A->nrows && At->nnz == A->nnz);
+  if (A->transpose) pmh_csr_destroy(A->transpose);
+  A->transpose = At;
+  return PMH_SUCCESS;
+}
+
 int pmh_csr_ensure_transpose(pmh_csr A)
 {
   PMH_ARG(A);
