@@ -15,6 +15,7 @@
 #include <climits>
 #include <cmath>
 #include <functional>
+#include <future>
 #include <thread>
 
 #include "pmh_internal.h"
@@ -359,8 +360,8 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
       stage("  (class) level copy / injected kernel");
       F.P                = prolongation(d, ndof, dc, c2f);
       stage("  (class) prolongation");
-      F.lam              = lambda_max_dinv_a(F.A, 20);
-      stage("  (class) lambda_max, 20 products");
+      // lambda_max(D^-1 A) needs only F.A: it runs beside the Galerkin product below (its result does not depend on how many threads it gets)
+      auto lam_job = std::async(std::launch::async, [&F]() { return lambda_max_dinv_a(F.A, 20); });
       Level Cn;
       {
         const HCsr AP = spgemm(F.A, F.P);
@@ -372,6 +373,8 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
         Cn.A = symmetrize(G2);
         stage("  (class) symmetrise");
       }
+      F.lam = lam_job.get();
+      stage("  (class) lambda_max, 20 products (beside the Galerkin product)");
       const int nc = Cn.A.nr, nf = F.A.nr;
       Cn.R.resize((size_t)C.kd * nc);
       for (int k = 0; k < C.kd; k++)
