@@ -1519,7 +1519,7 @@ PERMON_EXTERN PetscErrorCode MatInvSetUp_HIP(Mat imat)
    Bhat blockdiag(W_b) Bhat' -- two CSR launches and ONE dense kernel instead of an inner Krylov solve.
    storage: PMH_FX_SYM (any decomposition), or -- after pmh_csr_block_classes found congruent blocks -- PMH_FX_CLASS_SYM / PMH_FX_CLASS_ORBIT
    (dims != NULL: the blocks are boxes of dims[0] x dims[1] x dims[2] nodes with ndof dofs per node; the symmetries of the box that leave K
-   invariant serve the set-up and, for the orbit storage, the apply: k_fxo_gemm4 on the fp64 matrix cores).  PETSC_DECIDE picks by that rule.
+   invariant serve the set-up and, for the orbit storage, the apply: k_fxo_gemm16 on the fp64 matrix cores).  PETSC_DECIDE picks by that rule.
    Call after MatGluingAttachHIP(Bt), MatBlockDiagAttachHIP(K) and MatInvAttachHIP(imat) [+ MatInvSetUp_HIP]. */
 PERMON_EXTERN PetscErrorCode MatInvAttachExplicitHIP(Mat imat, Mat Bt, PetscInt storage, const PetscInt dims[3], PetscInt ndof, PetscReal rtol)
 {
@@ -1558,7 +1558,22 @@ PERMON_EXTERN PetscErrorCode MatInvAttachExplicitHIP(Mat imat, Mat Bt, PetscInt 
   if (dims && (storage == PMH_FX_CLASS_ORBIT || storage == PMH_FX_CLASS_SYM)) {
     idims[0] = (int)dims[0], idims[1] = (int)dims[1], idims[2] = (int)dims[2];
     PMHCall(pmh_fexplicit_set_box_symmetry(E, 0, idims, (int)ndof, (const int *)ia, (const int *)ja, va, &nsym));
-    if (storage == PMH_FX_CLASS_ORBIT && nsym < 16) { /* too few operations for the GEMM form to pay: the streaming kernel on the symmetric tiles */
+    if (storage == PMH_FX_CLASS_ORBIT && nsym < 16) {
+      /* ONE block per rank (matblockdiag.c:787-788) means one class of one block: its own touched set -- three interface faces, a Dirichlet or contact face -- is invariant under
+         2 ... 8 of the box's operations only.  On the closure of that set under the group (the whole boundary of a cube) every operation survives: one K^+ solve per orbit, the GEMM apply */
+      int  nc = 0, nclo = 0, eptr[2] = {0, 0};
+      int *urel, *clo;
+      PMHCall(pmh_fexplicit_class_union(E, 0, &nc, NULL));
+      PetscCall(PetscMalloc2(nc + 1, &urel, n + 1, &clo));
+      PMHCall(pmh_fexplicit_class_union(E, 0, &nc, urel));
+      PMHCall(pmh_box_symmetry_closure(idims, (int)ndof, (const int *)ia, (const int *)ja, va, nc, urel, &nclo, clo, NULL));
+      PMHCall(pmh_fexplicit_destroy(E));
+      eptr[1] = nclo;
+      PMHCall(pmh_fexplicit_create_shared_orbit_union(B, K, cls, eptr, clo, &E));
+      PetscCall(PetscFree2(urel, clo));
+      PMHCall(pmh_fexplicit_set_box_symmetry(E, 0, idims, (int)ndof, (const int *)ia, (const int *)ja, va, &nsym));
+    }
+    if (storage == PMH_FX_CLASS_ORBIT && nsym < 16) { /* still too few operations for the GEMM form to pay (a box with three different sides): the streaming kernel on the symmetric tiles */
       PMHCall(pmh_fexplicit_destroy(E));
       PMHCall(pmh_fexplicit_create_shared_sym(B, K, cls, &E));
       PMHCall(pmh_fexplicit_set_box_symmetry(E, 0, idims, (int)ndof, (const int *)ia, (const int *)ja, va, &nsym));

@@ -490,6 +490,30 @@ def test_explicit_orbit_closed_class_sets(ctx):
     assert (si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (sc.iteration, sc.inner_iter_accu, sc.inner.ncg, sc.inner.nexp)
 
 
+@pytest.mark.parametrize("block", [0, 5])
+def test_explicit_orbit_one_block_per_rank(ctx, block):
+    """The reference's own layout -- ONE block per rank (matblockdiag.c:787-788; what the PETSc glue's MatInvAttachExplicitHIP sees): one class of one block.  With the class set closed
+    under the cube's group the rank keeps all 48 operations, its multivector records have one slot (8 bytes) and the table-driven GEMM runs on a 64-wide column tile; the rank's
+    share of F (its block's B_b W_b B_b') equals the one the inner-Krylov K^+ gives."""
+    nel = 8
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True)
+    G, e = f.coarse(orthonormalize=True)
+    loc = f.subset([block])
+    nn = nel + 1
+    qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    qc = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3, close=True)))
+    assert qc.explicit_storage == "class_orbit" and qc.explicit_symmetries == 48
+    n_solves, _ = qc.E.assemble_stats()
+    assert n_solves < int(qc.E.n_gamma.sum()) / 10
+    rng = np.random.default_rng(8)
+    for _ in range(2):
+        lam = rng.standard_normal(f.n_lambda)
+        lv, y0, y1 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+        qi.F.mult(lv, y0)
+        qc.F.mult(lv, y1)
+        assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-10 * np.linalg.norm(y0.to_numpy())
+
+
 def test_box_symmetry_closure_host():
     """pmh_box_symmetry_closure: a face of a cube closes to the whole boundary under the 48 operations; under a matrix that breaks the symmetry only the identity is left."""
     from permon_amd.mat import box_symmetry_closure
