@@ -131,6 +131,29 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
+HOST_TRANSPORT = os.environ.get("PMH_BENCH_TRANSPORT") == "host"  # test mode: the ranks share ONE GPU, the collectives ride on the library's host transport over gloo
+
+
+def dist_max(dist, value):
+    """MAX of a host scalar over the ranks (the contract's max-over-ranks time)."""
+    import torch
+
+    tt = torch.tensor([value], dtype=torch.float64, device="cpu" if HOST_TRANSPORT else "cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def global_norm(dist, local_norm):
+    """2-norm of a row-distributed vector from the ranks' local norms (the SVM workload shards the samples)."""
+    if dist is None:
+        return local_norm
+    import torch
+
+    tt = torch.tensor([local_norm * local_norm], dtype=torch.float64, device="cpu" if HOST_TRANSPORT else "cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+    return float(tt.item()) ** 0.5
+
+
 def measured_ceiling(ctx, n=1 << 26, reps=10):
     """On-box HBM ceiling (SURVEY 8d asks for it next to the 8 TB/s spec): device copy (read n, write n) and the
     VecWAXPY triad (read 2n, write n) on 512 MiB vectors, HIP-event timed on the launch stream."""
@@ -358,12 +381,10 @@ def run_svm(ctx, a, steps, warmup, rank, world, dist):
     if dist is not None:
         import torch
 
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = dist_max(dist, dt)
     comm_rank, comm_size = ctx.comm_rank()
     return {
-        "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None, "checksum": {"norm_x_after_last_step": repr(float(x.norm()))},
+        "rccl_ranks": comm_size if (world > 1 or os.environ.get("PMH_BENCH_FORCE_DIST")) else None, "checksum": {"norm_x_after_last_step": repr(global_norm(dist if world > 1 else None, float(x.norm())))},
         "value": steps / dt, "ms_per_step": dt / steps * 1e3,
         "workload": "configs[4]: PermonSVM-style hinge-loss dual, N=%d samples x d=%d dense fp64 (%.2f GB), H = diag(y) X X' diag(y) matrix-free, MPGP box 0<=a<=1" % (N, d, N * d * 8 / 1e9),
         "parallelism": "samples sharded by rows over %d GPU(s); w all-reduce (d doubles) per Hessian apply; scalar all-reduces for the MPGP reductions" % world,
@@ -739,9 +760,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if dist is not None:
             import torch
 
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = dist_max(dist, dt)
         return dt, cnt
 
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
@@ -1048,6 +1067,8 @@ def compact_line(out, details_path):
     c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     c["value"], c["ms_per_step"] = _num(c["value"], 7), _num(c["ms_per_step"], 7)
     c["config"] = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:300], "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism", ""))[:160], "rccl_ranks": cfg.get("rccl_ranks")}
+    if cfg.get("transport"):
+        c["config"]["transport"] = cfg["transport"]
     if cfg.get("checksum"):
         c["config"]["checksum"] = cfg["checksum"]
     if cfg.get("steps_by_type"):
@@ -1173,13 +1194,30 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if HOST_TRANSPORT:
+            # PMH_BENCH_TRANSPORT=host (tests): every rank on device 0, gloo between the processes, the library's collectives through pmh_comm_set_host_transport -- what runs is
+            # bench.py's own N > 1 orchestration (shares of the operator, barriers, max over ranks) and the library's distributed arithmetic; RCCL cannot put two ranks on one device
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import permon_amd as pa
 
     ctx = pa.Context(local_rank)
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and HOST_TRANSPORT:
+        import torch
+
+        def host_transport(op, arr):
+            if op == 2 or arr.size == 0:
+                dist.barrier()
+                return
+            dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)  # a view of the library's pinned staging buffer: reduced in place
+
+        ctx.comm_set_host_transport(rank, world, host_transport)
+    elif world > 1 or force_dist:
         import torch
 
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -1194,9 +1232,7 @@ def main():
         if dist is not None:
             import torch
 
-            tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            r["ms_per_step"] = float(tt.item())
+            r["ms_per_step"] = dist_max(dist, r["ms_per_step"])
             r["value"] = 1e3 / r["ms_per_step"]
         out = {
             "metric": "QPS iterations/sec + CSR SpMV GB/s (% HBM roofline)", "value": world * r["value"], "unit": "QPS iterations/s",
@@ -1335,6 +1371,8 @@ def main():
                 out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / out["roofline"]["measured_ceiling"]["copy_GBs"]
         except Exception as ex:  # noqa: BLE001
             out["roofline"]["measured_ceiling"] = "failed: %r" % (ex,)
+        if HOST_TRANSPORT and dist is not None:
+            out["config"]["transport"] = "host (gloo) -- TEST MODE: the %d ranks share one GPU (PMH_BENCH_TRANSPORT=host); not a multi-GPU measurement" % world
         try:
             with open(a.details, "w") as fh:
                 json.dump(out, fh, indent=1)

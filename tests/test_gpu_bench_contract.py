@@ -150,3 +150,24 @@ def test_forced_distributed_path_on_one_rank():
         assert loc["config"]["checksum"] == dst["config"]["checksum"], (loc["config"]["checksum"], dst["config"]["checksum"])
         for k in ("cg", "expansion", "proportioning", "hessian_mults"):
             assert loc["config"]["steps_by_type"][k] == dst["config"]["steps_by_type"][k]
+
+
+def test_two_ranks_on_one_gpu_host_transport():
+    """`python bench.py --gpus 2` END TO END on the one-GPU box: the self-launcher starts two ranks, PMH_BENCH_TRANSPORT=host puts both on device 0 with gloo between them and the
+    library's collectives on its host transport (RCCL cannot put two ranks on one device).  What this runs that nothing else does: bench.py's own N > 1 orchestration -- the ranks'
+    shares of the operator (k-range split of the orbit GEMM; subdomain blocks for the inner-Krylov K^+; samples for the SVM), barriers, max over ranks, rank 0's line -- on top of the
+    library's distributed arithmetic.  The two-rank run must take the steps the one-rank run takes and land on the same iterate (to the rounding of the split sums)."""
+    env = dict(os.environ, PMH_BENCH_TRANSPORT="host")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for args, key in ((("--nel", "7", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),
+                      (("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"), "norm_lambda_child_after_last_step"),
+                      (("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2"), "norm_x_after_last_step")):
+        one = _run(*args)[1]
+        two = _run("--gpus", "2", *args, env=env)[1]
+        assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and "host" in two["config"]["transport"]
+        a, b = float(one["config"]["checksum"][key]), float(two["config"]["checksum"][key])
+        assert abs(a - b) <= 1e-9 * abs(a), (args, a, b)  # (the FETI paths reproduce the one-rank iterate bit for bit: replicated dual arithmetic, the split sums added in a fixed order)
+        for k in ("cg", "expansion", "proportioning", "hessian_mults"):
+            assert one["config"]["steps_by_type"][k] == two["config"]["steps_by_type"][k], (k, one["config"]["steps_by_type"], two["config"]["steps_by_type"])
+        assert two["value"] > 0 and two["scaling"] == one["scaling"]
