@@ -171,3 +171,20 @@ def test_two_ranks_on_one_gpu_host_transport():
         for k in ("cg", "expansion", "proportioning", "hessian_mults"):
             assert one["config"]["steps_by_type"][k] == two["config"]["steps_by_type"][k], (k, one["config"]["steps_by_type"], two["config"]["steps_by_type"])
         assert two["value"] > 0 and two["scaling"] == one["scaling"]
+
+
+def test_four_ranks_on_one_gpu_host_transport():
+    """The same with FOUR ranks (the driver's N = 4; N = 8 exceeds the six processes a box lets share its GPU): the k range of the orbit GEMM in four shares, configs[3]'s shape
+    (64 subdomains, dense coarse problem) with 16 blocks per rank.  The split sums are added in rank order by the all-reduce: the iterate agrees with the one-rank run to rounding."""
+    env = dict(os.environ, PMH_BENCH_TRANSPORT="host")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for args in (("--nel", "9", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"),
+                 ("--sub", "4,4,4", "--nel", "5", "--dense-coarse", "--steps", "30", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative")):
+        one = _run(*args)[1]
+        four = _run("--gpus", "4", *args, env=env)[1]
+        assert four["n_gpus"] == 4 and four["config"]["rccl_ranks"] == 4 and "host" in four["config"]["transport"]
+        a, b = float(one["config"]["checksum"]["norm_lambda_child_after_last_step"]), float(four["config"]["checksum"]["norm_lambda_child_after_last_step"])
+        assert abs(a - b) <= 1e-12 * abs(a), (args, a, b)
+        for k in ("cg", "expansion", "proportioning", "hessian_mults", "outer"):
+            assert one["config"]["steps_by_type"][k] == four["config"]["steps_by_type"][k]
