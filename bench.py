@@ -692,11 +692,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             replica["M"], replica["K"] = M, Kb
             return M
 
-        nshare_pre = world if world > 1 else a.sim_world
         explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if (a.regularize or not congruent) else a.explicit_slots, solver_factory=None if (a.regularize or not congruent) else solver_factory)
         if not a.no_explicit_symmetry and not a.regularize and congruent:  # used by the class-shared storages only
             explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3, orbit=a.explicit_storage in ("auto", "class_orbit"))
-        elif not a.no_explicit_symmetry and not a.regularize and not congruent and a.explicit_storage in ("auto", "class_orbit") and nshare_pre <= 1:
+        elif not a.no_explicit_symmetry and not a.regularize and not congruent and a.explicit_storage in ("auto", "class_orbit"):  # (several GPUs: every rank its own blocks' classes -- owner computes)
             # cubes of different materials: one class per block, each on the CLOSURE of its touched set under the cube's group (the whole boundary): all 48 operations survive, one K^+
             # solve per orbit instead of one per touched dof, and the apply is the orbit GEMM (one per class) instead of the HBM-bound stream over every full W_b
             explicit["storage"] = "class_orbit"

@@ -161,6 +161,7 @@ def test_two_ranks_on_one_gpu_host_transport():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     for args, key in ((("--nel", "7", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),
+                      (("--nel", "7", "--young", "distinct", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),  # 8 materials: every rank the closed orbit classes of its own 4 blocks
                       (("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"), "norm_lambda_child_after_last_step"),
                       (("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2"), "norm_x_after_last_step")):
         one = _run(*args)[1]
