@@ -552,7 +552,7 @@ typedef struct {
                                 never sets one (feti.c:71-94; feti/ex1.c, ex71.c).  0: `regularize` decides (K_reg^{-1} or the Moore-Penrose form).  Ignored with explicit_dual (K^- P_R is not symmetric) */
   int    project;            /* -project (default 1, set by -feti: QPTEnforceEqByProjector).  0: the equality constraint G lambda = e stays in the dual QP, which is homogenised and
                                 handed to QPS SMALXE (QPSSetDefaultType qps.c:437-441; QPTEnforceEqByPenalty inside SMALXE) -- `smalxe` below configures it */
-  int    E_orth_type;        /* -dual_qp_E_orth_type (QPTOrthonormalizeEqFromOptions qptransform.c:643-660; MatOrthTypes): 0 none, 1 gs (explicit T G, T e), 4 implicit */
+  int    E_orth_type;        /* -dual_qp_E_orth_type (QPTOrthonormalizeEqFromOptions qptransform.c:643-660; MatOrthTypes): 0 none, 1 gs / 2 gslingen (explicit T G, T e), 3 cholesky / 4 implicit (G stays sparse, the projector carries T = L^{-1}) */
   int    lumped_pc;          /* -dual_pc_dual_type lumped (default none) */
   double regularize_rho;     /* > 0: the rho of MatRegularize for every block; 0 (default): the reference's power-method estimate */
   double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */

@@ -165,6 +165,46 @@ static int orth_rows_gs(int m, int n, std::vector<double> &G, std::vector<double
   return PMH_SUCCESS;
 }
 
+// MAT_ORTH_GS_LINGEN (permonmatorth.c:248-288 MatOrthColumns_GS_Lingen): the same projections, but the norm of the projected row is NOT recomputed -- it follows from
+// Pythagoras, delta = delta_last sqrt|1 - ||p||^2 / delta_last^2| with p the dots just subtracted --, the row is re-projected while delta <= delta_last / 2, and it is scaled by 1 / delta
+static int orth_rows_gs_lingen(int m, int n, std::vector<double> &G, std::vector<double> &T)
+{
+  T.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++) T[(size_t)i * m + i] = 1.0;
+  std::vector<double> p((size_t)m + 1);
+  for (int k = 0; k < m; k++) {
+    double *q = &G[(size_t)k * n];
+    auto    dots = [&](int upto) {
+      for (int j = 0; j < upto; j++) {
+        const double *qj = &G[(size_t)j * n];
+        double        t  = 0.0;
+        for (int c = 0; c < n; c++) t += q[c] * qj[c];
+        p[j] = t;
+      }
+    };
+    dots(k + 1); // p[k] = q_k . q_k
+    double delta_last = std::sqrt(p[k]), delta;
+    for (;;) {
+      for (int j = 0; j < k; j++) {
+        const double *qj = &G[(size_t)j * n];
+        for (int c = 0; c < n; c++) q[c] -= p[j] * qj[c];
+        for (int c = 0; c < m; c++) T[(size_t)k * m + c] -= p[j] * T[(size_t)j * m + c];
+      }
+      double pp = 0.0;
+      for (int j = 0; j < k; j++) pp += p[j] * p[j];
+      const double beta = 1.0 - pp / (delta_last * delta_last);
+      delta             = delta_last * std::sqrt(std::fabs(beta));
+      if (!(delta >= 1e2 * 2.220446049250313e-16)) return pmh_set_error(PMH_ERR_ARG, "pmh_kspfeti_solve: the rows 0 - %d of G are linearly dependent", k);
+      if (delta > 0.5 * delta_last) break;
+      dots(k);
+      delta_last = delta;
+    }
+    for (int c = 0; c < n; c++) q[c] /= delta;
+    for (int c = 0; c < m; c++) T[(size_t)k * m + c] /= delta;
+  }
+  return PMH_SUCCESS;
+}
+
 // The -qp_chain_view_kkt lines of the QPs that differ when the dual QP is NOT projected (-project 0), last QP first (QPTAllInOne qptransform.c:2178-2207):
 //   QPTEnforceEqByPenalty (SMALXE's inner QP: A + rho G'G, b - B'mu), QPTHomogenizeEq (multiplier term B'mu, which QPSSolve_SMALXE leaves in Bt_lambda), [QPTOrthonormalizeEq: the
 //   same multiplier term -- QPTHomogenizeEqPostSolve copies it up -- against d; ||BE x - cE|| only when BE can be multiplied with, i.e. not for the implicit type, qp.c:303-318],
@@ -439,7 +479,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         }
       GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
       GO(pmh_qppf_create(ctx, Gc, 0, &pf));
-      if (o->E_orth_type == 1) { // QPTOrthonormalizeEq, MAT_ORTH_GS: the child QP gets the explicit T G and T e (qptransform.c:593-606)
+      if (o->E_orth_type == 1 || o->E_orth_type == 2) { // QPTOrthonormalizeEq, MAT_ORTH_GS / MAT_ORTH_GS_LINGEN: the child QP gets the explicit T G and T e (qptransform.c:593-606)
         if ((double)m * nl > 5e7) {
           rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -dual_qp_E_orth_type gs forms the dense %d x %d G on the host; use implicit", m, nl);
           goto done;
@@ -447,7 +487,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         std::vector<double> Gd((size_t)m * nl, 0.0), T;
         for (int r = 0; r < m; r++)
           for (auto &kv : rows[r]) Gd[(size_t)r * nl + kv.first] = kv.second;
-        GO(orth_rows_gs(m, nl, Gd, T));
+        GO(o->E_orth_type == 1 ? orth_rows_gs(m, nl, Gd, T) : orth_rows_gs_lingen(m, nl, Gd, T));
         std::vector<int>    orp((size_t)m + 1, 0), oci;
         std::vector<double> ova;
         for (int r = 0; r < m; r++) {
@@ -462,7 +502,9 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         }
         GO(pmh_csr_create(ctx, m, nl, orp.data(), oci.data(), ova.data(), &Goc));
         GO(pmh_qppf_create(ctx, Goc, 0, &pfo)); // QPSetEq re-creates the QPPF from T G (qptransform.c:609): GG' is formed and inverted like any other
-      } else if (o->E_orth_type == 4) { // MAT_ORTH_IMPLICIT: G stays, the projector carries T (:612-619)
+      } else if (o->E_orth_type == 4 || o->E_orth_type == 3) {
+        // MAT_ORTH_IMPLICIT: G stays, the projector carries T (:612-619).  MAT_ORTH_CHOLESKY in its (default) implicit form: BE = L^{-1} G as a product of the forward solve and G
+        // (permonmatorth.c:121-128) -- the same object here; unlike the dummy BE of the implicit TYPE it can be multiplied with, so its ||BE x - cE|| line is printed
         GO(pmh_qppf_create(ctx, Gc, 2, &pfo));
         GO(pmh_qppf_orth_rhs(pfo, e.data(), eo.data()));
       }

@@ -377,7 +377,7 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     } else if (k == "project") rc = get_bool(t, &o->project) ? -1 : 1;                     // QPTFromOptions qptransform.c:2228
     else if (k == "dual_qp_E_orth_type") {                                                  // QPTOrthonormalizeEqFromOptions on the dual QP (prefix dual_)
       rc = get_enum(t, orthtypes, 6, &o->E_orth_type) ? -1 : 1;
-      if (rc == 1 && o->E_orth_type != 0 && o->E_orth_type != 1 && o->E_orth_type != 4) return pmh_set_error(PMH_ERR_SUP, "options: -dual_qp_E_orth_type %s is not built (none, gs, implicit)", t.val.c_str());
+      if (rc == 1 && o->E_orth_type == 5) return pmh_set_error(PMH_ERR_SUP, "options: -dual_qp_E_orth_type %s is not built (none, gs, gslingen, cholesky, implicit)", t.val.c_str());
     } else {
       rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
       if (!rc) rc = smalxe_key(t, k, &o->smalxe);                                           // -qps_smalxe_*: the solver of -project 0

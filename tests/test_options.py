@@ -102,5 +102,6 @@ def test_feti_driver_options():
     assert rc == 0 and (o.project, o.E_orth_type, o.kplus_left) == (1, 1, 1) and o.smalxe.rho_user == 1.1  # defaults: projected, KSPFETI's left inverse, smalxe.c:1190
     rc, o, left = parse("-qpt_dualize_Kplus_left 0")
     assert rc == 0 and (o.kplus_left, o.regularize) == (0, 1)  # MatRegularize
-    assert parse("-dual_qp_E_orth_type cholesky")[0] != 0  # a MatOrthType this library does not build: said, not ignored
+    assert parse("-dual_qp_E_orth_type cholesky")[1].E_orth_type == 3 and parse("-dual_qp_E_orth_type gslingen")[1].E_orth_type == 2
+    assert parse("-dual_qp_E_orth_type inexact")[0] != 0  # the one MatOrthType this library does not build: said, not ignored
     assert parse("-feti_gluing_type sideways")[0] != 0 and parse("-qps_rtol 2")[0] != 0
