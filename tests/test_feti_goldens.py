@@ -144,7 +144,9 @@ def test_oracle_ex71_elasticity_iteration_goldens(oracle, goldens, lumped):
     pc = (lambda w: pf.P(B.mult_transpose(Ks @ B.mult(w)))) if lumped else None  # P (B K B')
     res = oracle.pcpg(A, b, np.zeros(prob.n_lambda), None, rtol=1e-6, pc=pc)
     assert res["reason"] == 2
-    assert abs(res["iteration"] - _golden_its(goldens, ELAST[lumped])) <= 5
+    # golden 66 / 26; the oracle's Moore-Penrose K^+ gives 64 / 27 -- what the product gives on the Moore-Penrose AND on the left generalised inverse (tests/test_gpu_kspfeti.py) --
+    # since its block CG, like the product's, no longer iterates on the rounding residue of a load that lies in the kernel (67 / 29 before)
+    assert res["iteration"] == (27 if lumped else 64) and abs(res["iteration"] - _golden_its(goldens, ELAST[lumped])) <= 2
     # golden KKT line 1 of ex71_2_*: rO/||b|| with ||b|| = ||P b_bar|| = 2.00e-04/9.79e-07 = 1.41e-04/6.90e-07 = 204.3
     assert abs(np.linalg.norm(b) - 204.3) < 0.5
 
