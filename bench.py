@@ -610,6 +610,29 @@ def dual_spmv_hbm(ctx, f, reps=20):
     x.free(), y.free()
     K.destroy()
     A.destroy()
+    # SURVEY 8d names B and B' beside K_i ("each measured with its own B_spmv"): MatMult_Gluing / MatMultTranspose_Gluing (gluing.c:47-159) of the run's own gluing -- 1-2 entries per
+    # dual row, a few MB in all: LATENCY-bound launches, reported as what they are (the K_i product above carries the roofline target)
+    try:
+        B = pa.MatGluing(ctx, f.N, f.n_lambda, f.leaves_row, f.leaves_root, f.leaves_sign)
+        lam, xx = ctx.vec_from(np.random.default_rng(12).standard_normal(f.n_lambda)), ctx.vec(f.N)
+        nleaf = int(np.size(f.leaves_row))
+        res = {}
+        for name, fn, rows in (("Bt_lambda (MatMult_Gluing)", lambda: B.mult(lam, xx), f.N), ("B_u (MatMultTranspose_Gluing)", lambda: B.mult_transpose(xx, lam), f.n_lambda)):
+            for _ in range(5):
+                fn()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(50):
+                fn()
+            ms_b = ctx.timer_stop() / 50
+            b_spmv = 12.0 * nleaf + 20.0 * rows
+            res[name] = {"avg_ms": ms_b, "algorithmic_bytes_per_launch": b_spmv, "achieved_GBs": b_spmv / ms_b / 1e6, "frac": b_spmv / ms_b / 1e6 / HBM_PEAK_GBS}
+        out["gluing"] = dict(res, note="n_lambda = %d, %d leaves.  B' lambda writes the whole primal vector (%.1f MB by SURVEY's 12 nnz + 20 rows: a bandwidth-bound launch); B u gathers 1-2 entries per dual row "
+                                       "(%.1f MB: launch latency, not bandwidth).  The K_i product moves 45 x / 470 x these bytes and carries the roofline target" % (f.n_lambda, nleaf, (12.0 * nleaf + 20.0 * f.N) / 1e6, (12.0 * nleaf + 20.0 * f.n_lambda) / 1e6))
+        lam.free(), xx.free()
+        B.destroy()
+    except Exception as ex:  # noqa: BLE001
+        out["gluing"] = {"failed": repr(ex)}
     # headline of the block: the CSR kernel on the CSR bytes (what the metric names)
     full = nsub == 8 and f.nel == 43
     t_csr, src_csr = pmc_lookup("void k_spmv_stream<0, 2048", "r04_pmc_traffic_dual_spmv.json") if full else (None, "not the configuration of the committed PMC pass")
