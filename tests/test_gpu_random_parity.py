@@ -80,3 +80,49 @@ def test_random_box_qp_parity(ctx, oracle, seed):
         assert np.all(xs >= lb - astol) and np.all(xs <= ub + astol), tag
         for k in ("rnorm", "gfnorm", "gcnorm"):
             assert abs(getattr(st, k) - ref[k]) <= 1e-9 * max(ref["rnorm"], ref["norm_rhs"] * 1e-8) + 4e-16 * max(ref["norm_rhs"], 1.0), (tag, k)  # (+ the rounding level of a residual that is exactly zero)
+
+
+def _eq_problem(seed):
+    rng = np.random.default_rng(5000 + seed)
+    n = int((20, 64, 257, 1000)[seed % 4])
+    m = int((1, 3, 8)[seed % 3])
+    band = sp.diags([-1.0, 2.0 + rng.uniform(0.2, 1.0), -1.0], [-1, 0, 1], shape=(n, n)).tocsr()  # SPD, condition number O(10)
+    G0 = sp.random(m, n, density=min(1.0, 12.0 / n), random_state=int(seed), data_rvs=rng.standard_normal).toarray() + 0.0
+    G0[np.arange(m), rng.choice(n, size=m, replace=False)] += 1.0  # full row rank
+    Q, _ = np.linalg.qr(G0.T)  # orthonormal rows
+    orth = seed % 2 == 0
+    G = sp.csr_matrix(Q.T if orth else G0)
+    G.sort_indices()
+    b = rng.standard_normal(n)
+    lb = rng.uniform(-0.5, 0.0, size=n)
+    lb[rng.random(n) < 0.3] = -np.inf
+    return band, G, orth, b, lb
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_equality_constrained_qp_smalxe_parity(ctx, oracle, seed):
+    """min 1/2 x'Ax - b'x  s.t.  G x = 0, x >= lb on random data through SMALXE (inner MPGP): outer iterations, M1 / rho updates and the state machine as the oracle's, the inner
+    iteration total within 2 % (the G products sum in other orders), the solution to 1e-6 -- orthonormal and general G (dense (GG')^{-1} in between)."""
+    A, G, orth, b, lb = _eq_problem(seed)
+    n = A.shape[0]
+    pfo = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=orth)
+    ref = oracle.smalxe(oracle.Op(n, csr=oracle.Csr.from_scipy(A)), b, np.zeros(n), oracle.Box(n, lb=lb), pfo, rtol=1e-7)
+    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+    qp = pa.QP(ctx)
+    qp.SetOperator(pa.Op.from_csr(Ad))
+    qp.SetRhs(ctx.vec_from(b))
+    x = ctx.vec(n)
+    qp.SetInitialVector(x)
+    qp.SetBox(None, ctx.vec_from(lb), None)
+    qp.SetEq(pa.QPPF.from_scipy(ctx, G, orthonormal=orth))
+    qps = pa.QPS(ctx)
+    qps.SetQP(qp)
+    qps.SetType("smalxe")
+    qps.SetTolerances(rtol=1e-7)
+    st = qps.Solve()
+    tag = (seed, n, G.shape[0], orth)
+    assert (st.reason, st.iteration, st.M1_updates, st.rho_updates, st.state) == (ref["reason"], ref["iteration"], ref["M1_updates"], ref["rho_updates"], ref["state"]), tag
+    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(2, ref["inner_iter_accu"] // 50), tag
+    xs = x.to_numpy()
+    assert np.linalg.norm(xs - ref["u"]) <= 1e-6 * max(np.linalg.norm(ref["u"]), 1e-300), tag
+    assert np.linalg.norm(G @ xs) <= 1e-6 * max(np.linalg.norm(b), 1.0) and np.all(xs >= lb - 1e-14), tag
