@@ -512,23 +512,3 @@ def test_explicit_orbit_one_block_per_rank(ctx, block):
         qi.F.mult(lv, y0)
         qc.F.mult(lv, y1)
         assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-10 * np.linalg.norm(y0.to_numpy())
-
-
-def test_box_symmetry_closure_host():
-    """pmh_box_symmetry_closure: a face of a cube closes to the whole boundary under the 48 operations; under a matrix that breaks the symmetry only the identity is left."""
-    from permon_amd.mat import box_symmetry_closure
-
-    f = pa.CubeFeti((1, 1, 1), 4, contact=False)
-    nn = 5
-    K = f.K.tocsr()
-    nodes = np.arange(nn ** 3)
-    ijk = np.stack([nodes % nn, (nodes // nn) % nn, nodes // (nn * nn)], axis=1)
-    face = np.nonzero(ijk[:, 0] == 0)[0]
-    rel = (face[:, None] * 3 + np.arange(3)[None, :]).ravel()
-    closure, nsym = box_symmetry_closure((nn, nn, nn), 3, K, rel)
-    boundary = np.nonzero(((ijk == 0) | (ijk == nn - 1)).any(axis=1))[0]
-    assert nsym == 48 and np.array_equal(closure, np.sort((boundary[:, None] * 3 + np.arange(3)[None, :]).ravel()))
-    K2 = K.tolil()
-    K2[7, 7] += 1.0  # no operation but the identity leaves this matrix invariant ... unless dof 7 is a fixed point of some of them
-    closure2, nsym2 = box_symmetry_closure((nn, nn, nn), 3, K2.tocsr(), rel)
-    assert nsym2 < 48 and set(rel) <= set(closure2) and closure2.size < closure.size
