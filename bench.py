@@ -1123,6 +1123,9 @@ def compact_line(out, details_path):
     for k in ("iterative", "strict_fp64", "general", "configs1", "configs3", "configs4", "reuse_products"):
         if k in out:
             c[k] = block(out[k])
+    if isinstance(c.get("general"), dict) and isinstance(out["general"], dict) and isinstance(out["general"].get("kplus"), dict):  # the non-congruent block's set-up: K^+ solves and their time
+        kp = out["general"]["kplus"]
+        c["general"].update({k: kp.get(k) for k in ("storage", "assemble_seconds", "assemble_solves") if kp.get(k) is not None})
     if isinstance(out.get("contact_solve"), dict):
         c["contact_solve"] = {k: out["contact_solve"].get(k) for k in ("setup_seconds", "solve_seconds", "time_to_solution_seconds", "failed") if out["contact_solve"].get(k) is not None}
     c["details"] = os.path.relpath(details_path, ROOT) if details_path.startswith(ROOT) else details_path
