@@ -179,6 +179,38 @@ def test_feti_ex1_tutorial_one_iteration(ctx, goldens, dir_in_hess):
     assert np.linalg.norm(xg - x) <= 1e-10 * np.linalg.norm(x)
 
 
+@pytest.mark.parametrize("orth", ["none", "gs", "gslingen", "cholesky", "implicit"])
+def test_unprojected_smalxe_chain_solves_the_same_problem(ctx, orth):
+    """-project 0 (SMALXE on the dual QP with its equality constraint kept, qptransform.c:2185 / qps.c:437-441) against the projected CG chain on a 3-D TFETI problem with a
+    24-dimensional coarse space: the same primal solution, for every way of orthonormalising G the driver offers (none: the dense (GG')^{-1} sits in the projector and the penalty
+    term is rho G'G)."""
+    f = CubeFeti((2, 2, 1), 3, contact=False, gluing="full")
+    nn, ne = f.nel + 1, f.nel
+    sx, sy, sz = f.sub
+    GX, GY = sx * ne + 1, sy * ne + 1
+    l2g, dirl = [], []
+    for s in range(f.nsub):
+        ix, iy, iz = s % sx, (s // sx) % sy, s // (sx * sy)
+        for k in range(nn):
+            for j in range(nn):
+                for i in range(nn):
+                    gnode = ((iz * ne + k) * GY + (iy * ne + j)) * GX + (ix * ne + i)
+                    for c in range(3):
+                        if ix * ne + i == 0:
+                            dirl.append(len(l2g))
+                        l2g.append(gnode * 3 + c)
+    l2g = np.asarray(l2g, dtype=np.int32)
+    ng = int(l2g.max()) + 1
+    Rg = sp.csr_matrix((np.ones(f.N), (np.arange(f.N), l2g)), shape=(f.N, ng))
+    mult = np.asarray(Rg.sum(axis=0)).ravel()
+    fsplit = Rg @ ((Rg.T @ f.f) / mult)
+    u0, _, st0 = pa.KSPFETISolve(ctx, f.block_rowstart, f.K, fsplit, l2g, dirichlet_local=dirl, R=f.R, rtol=1e-9, kplus_rtol=1e-13)
+    u1, _, st1 = pa.KSPFETISolve(ctx, f.block_rowstart, f.K, fsplit, l2g, dirichlet_local=dirl, R=f.R, rtol=1e-9, kplus_rtol=1e-13,
+                                 options="-project 0 -dual_qp_E_orth_type %s -qps_smalxe_rho 1e1" % orth)
+    assert st0.reason > 0 and st1.reason > 0 and st1.smalxe.iteration == st1.iteration >= 1
+    assert np.linalg.norm(u1 - u0) <= 1e-6 * np.linalg.norm(u0), (orth, np.linalg.norm(u1 - u0) / np.linalg.norm(u0))
+
+
 def test_driver_and_chain_release_their_device_memory(ctx):
     """Every object pmh_kspfeti_solve creates (CSR copies, K_reg, MATINV work vectors, gluing, projector, chain) is released:
     repeated solves do not grow the HBM footprint (hipMemGetInfo through pmh_mem_info)."""
