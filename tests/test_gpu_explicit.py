@@ -512,3 +512,28 @@ def test_explicit_orbit_one_block_per_rank(ctx, block):
         qi.F.mult(lv, y0)
         qc.F.mult(lv, y1)
         assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-10 * np.linalg.norm(y0.to_numpy())
+
+
+def test_explicit_orbit_mixed_class_sizes(ctx):
+    """Classes of 3, 2, 2 and 1 congruent blocks in one decomposition (materials 1, 1, 1, 2, 2, 3, 3, 4): multivector records of 4, 2, 2 and 1 slots, column tiles of 128 and 64,
+    hence table-driven GEMM launches per class (no single merged launch) -- F against the inner-Krylov K^+ and the same SMALXE steps."""
+    nel = 8
+    f = pa.CubeFeti((2, 2, 2), nel, contact=True, young=[1.0, 1.0, 1.0, 2.0, 2.0, 3.0, 3.0, 4.0])
+    G, e = f.coarse(orthonormalize=True)
+    loc = f.subset(range(8))
+    cls = pa.csr_block_classes(loc["block_rowstart"], loc["K"])
+    assert sorted(np.bincount(cls).tolist()) == [1, 2, 2, 3]
+    nn = nel + 1
+    qi = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13)
+    qc = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3, close=True)))
+    assert qc.explicit_storage == "class_orbit" and qc.explicit_symmetries == 48
+    rng = np.random.default_rng(4)
+    for _ in range(2):
+        lam = rng.standard_normal(f.n_lambda)
+        lv, y0, y1 = ctx.vec_from(lam), ctx.vec(f.n_lambda), ctx.vec(f.n_lambda)
+        qi.F.mult(lv, y0)
+        qc.F.mult(lv, y1)
+        assert np.linalg.norm(y1.to_numpy() - y0.to_numpy()) <= 1e-10 * np.linalg.norm(y0.to_numpy())
+    si, sc = qi.solve_smalxe(rtol=1e-6), qc.solve_smalxe(rtol=1e-6)
+    assert (si.reason, si.iteration, si.inner_iter_accu, si.inner.ncg, si.inner.nexp) == (sc.reason, sc.iteration, sc.inner_iter_accu, sc.inner.ncg, sc.inner.nexp)
+
