@@ -110,6 +110,8 @@ struct fx_shared {
   // several classes on the same row tile: ONE launch over all their work items (fxo_gemm): workgroup -> items with global item numbers, per-class pointer tables
   int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0, merged_tn = 128;
   const int            **d_coltab_of = nullptr, **d_gidx_of = nullptr;
+  void                  *d_fin_args = nullptr; // fxo_fin_args per class: the classes' finishing launches as one (k_fxo_fin_all)
+  int                    fin_nbx = 0, fin_ngroups = 0;
   double                *pt = nullptr;
   long long              pt_tot = 0;
   double                 owned_bytes = 0.0;
@@ -864,12 +866,12 @@ static int fxo_row_tile(int M)
 // group's numbering, its first unit; unittab per unit: offset of its look-up table (column of the tile's list -> column of the unit's list, -1: B is zero there on the
 // whole segment, nothing was multiplied), its padded column count, its splits; unitbase: split 0 of the unit in cpart
 #define FXO_FU 4
-__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, const int *__restrict__ fintab, const int *__restrict__ unittab, const long long *__restrict__ unitbase,
+__device__ __forceinline__ void fxo_fin_body(int bx, int by, int ntile, int tm, int nsymp, int nc, const int *__restrict__ fintab, const int *__restrict__ unittab, const long long *__restrict__ unitbase,
                                                        const int *__restrict__ lut, const int *__restrict__ coltab, const double *__restrict__ cp, const signed char *__restrict__ use,
                                                        const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld, double *__restrict__ Y, int nslot)
 {
-  const int  i  = blockIdx.x * PMH_BLOCK + threadIdx.x;
-  const int *ft = fintab + 4 * (ntile + 1) * blockIdx.y;
+  const int  i  = bx * PMH_BLOCK + (int)threadIdx.x;
+  const int *ft = fintab + 4 * (ntile + 1) * by;
   if (i >= ft[4 * ntile + 2]) return; // the group's element count
   int mt = 0;
   while (mt + 1 < ntile && i >= ft[4 * (mt + 1) + 2]) mt++;
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int ns
   const int g = ct >> 3, sl = ct & 7, row = mt * tm + r;
   const int u = use[(long long)row * nsymp + g];
   if (u == 0) return;
-  const long long dst = xbase0 + (long long)blockIdx.y * ld * nslot + (long long)posmap[(long long)g * nc + reppos[row]] * nslot + sl;
+  const long long dst = xbase0 + (long long)by * ld * nslot + (long long)posmap[(long long)g * nc + reppos[row]] * nslot + sl;
   double          s   = 0.0;
   // FXO_FU units at a time: their look-ups, then the first 8 splits of each travel together (a plain loop compiles to load - wait - add per unit and split);
   // the sums are still taken unit after unit, split after split (+ 0.0 for a split that does not exist changes nothing)
@@ -910,6 +912,28 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int ns
     }
   }
   Y[dst] = u > 0 ? s : -s;
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin(int ntile, int tm, int nsymp, int nc, const int *__restrict__ fintab, const int *__restrict__ unittab, const long long *__restrict__ unitbase,
+                                                       const int *__restrict__ lut, const int *__restrict__ coltab, const double *__restrict__ cp, const signed char *__restrict__ use,
+                                                       const int *__restrict__ reppos, const int *__restrict__ posmap, long long xbase0, int ld, double *__restrict__ Y, int nslot)
+{
+  fxo_fin_body(blockIdx.x, blockIdx.y, ntile, tm, nsymp, nc, fintab, unittab, unitbase, lut, coltab, cp, use, reppos, posmap, xbase0, ld, Y, nslot);
+}
+
+// several classes in ONE launch (blockIdx.z = class; grid.x / grid.y = the largest class's): every class's parameters from a device table
+struct fxo_fin_args {
+  int              ntile, tm, nsymp, nc, ld, nslot, nbx, ngroups;
+  const int       *fintab, *unittab, *lut, *coltab, *reppos, *posmap;
+  const long long *unitbase;
+  const signed char *use;
+  long long        xbase0;
+};
+__global__ __launch_bounds__(PMH_BLOCK) void k_fxo_fin_all(const fxo_fin_args *__restrict__ args, const double *__restrict__ cp, double *__restrict__ Y)
+{
+  const fxo_fin_args a = args[blockIdx.z];
+  if ((int)blockIdx.x >= a.nbx || (int)blockIdx.y >= a.ngroups) return;
+  fxo_fin_body(blockIdx.x, blockIdx.y, a.ntile, a.tm, a.nsymp, a.nc, a.fintab, a.unittab, a.unitbase, a.lut, a.coltab, cp, a.use, a.reppos, a.posmap, a.xbase0, a.ld, Y, a.nslot);
 }
 
 // row of representative pl (local index) from its K^+ solve -> the pre-tiled A (column kinv[c] for position c)
@@ -1221,6 +1245,7 @@ void fxs_destroy(fx_shared *S)
   if (S->d_items) pmh_free(ctx, S->d_items);
   if (S->d_wgfirst) pmh_free(ctx, S->d_wgfirst);
   if (S->d_wgfirst_all) pmh_free(ctx, S->d_wgfirst_all);
+  if (S->d_fin_args) pmh_free(ctx, S->d_fin_args);
   if (S->d_zrow_of) pmh_free(ctx, S->d_zrow_of), pmh_free(ctx, (void *)S->d_coltab_of), pmh_free(ctx, (void *)S->d_gidx_of);
   pmh_gluing_destroy(S->Bc);
   for (auto e : S->ev_mid) (void)hipEventDestroy(e);
@@ -1906,6 +1931,22 @@ static int fxo_prepare(fx_shared *S)
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_gidx_of, gi.data(), sizeof(const int *) * gi.size()));
     S->merged_tm = merged ? tm_first : 0, S->merged_tn = tn_first;
   }
+  if (S->d_fin_args) pmh_free(ctx, S->d_fin_args), S->d_fin_args = nullptr;
+  S->fin_nbx = S->fin_ngroups = 0;
+  if (S->ncls > 1 && !getenv("PMH_FXO_NO_MERGE")) { // the classes' finishing kernels in one launch
+    std::vector<fxo_fin_args> fa((size_t)S->ncls);
+    for (int c = 0; c < S->ncls; c++) {
+      const fxs_class &C = S->C[c];
+      fxo_fin_args     &a = fa[c];
+      memset(&a, 0, sizeof(a));
+      if (!C.nc || C.fin_elems <= 0) continue; // nbx = 0: the class's workgroups return at once
+      a.ntile = C.Mp / C.tm, a.tm = C.tm, a.nsymp = C.nsymp, a.nc = C.nc, a.ld = C.ld, a.nslot = C.S, a.nbx = (C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK, a.ngroups = C.ngroups;
+      a.fintab = C.d_fintab, a.unittab = C.d_unittab, a.lut = C.d_lut, a.coltab = C.d_coltab, a.reppos = C.d_reppos, a.posmap = C.d_posmap, a.unitbase = C.d_finbase, a.use = C.d_use, a.xbase0 = C.xoff;
+      S->fin_nbx = std::max(S->fin_nbx, a.nbx), S->fin_ngroups = std::max(S->fin_ngroups, a.ngroups);
+    }
+    PMH_CHK(pmh_malloc(ctx, sizeof(fxo_fin_args) * fa.size(), &S->d_fin_args));
+    PMH_CHK(pmh_memcpy_h2d(ctx, S->d_fin_args, fa.data(), sizeof(fxo_fin_args) * fa.size()));
+  }
   S->fxo_ready = 1;
   return PMH_SUCCESS;
 }
@@ -2012,11 +2053,13 @@ static int fxo_gemm(fx_shared *S)
       }
     }
 #endif
-    if (C.fin_elems > 0)
+    if (C.fin_elems > 0 && !S->d_fin_args)
       hipLaunchKernelGGL(k_fxo_fin, dim3((unsigned)((C.fin_elems + PMH_BLOCK - 1) / PMH_BLOCK), C.ngroups), dim3(PMH_BLOCK), 0, st, C.Mp / C.tm, C.tm, C.nsymp, C.nc, (const int *)C.d_fintab,
                          (const int *)C.d_unittab, (const long long *)C.d_finbase, (const int *)C.d_lut, (const int *)C.d_coltab, (const double *)S->cpart, (const signed char *)C.d_use, (const int *)C.d_reppos, (const int *)C.d_posmap, C.xoff, C.ld,
                          S->Y, C.S);
   }
+  if (S->d_fin_args && S->fin_nbx > 0) // after ALL classes' products
+    hipLaunchKernelGGL(k_fxo_fin_all, dim3((unsigned)S->fin_nbx, (unsigned)S->fin_ngroups, (unsigned)S->ncls), dim3(PMH_BLOCK), 0, st, (const fxo_fin_args *)S->d_fin_args, (const double *)S->cpart, S->Y);
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
