@@ -48,6 +48,12 @@ const char *pmh_last_error(void);
 typedef struct pmh_ctx_s *pmh_ctx;
 
 int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; fails loudly without a GPU */
+/* Process-wide run-time switches (the role of PETSc's options database for the library's own A/B switches; the environment variable PMH_<NAME> gives the initial value).
+ * "chain" (PMH_NO_CHAIN unset = 1): the penalised, projected FETI operator as the five-launch dual-space chain (dualchain.hip); 0 = the round-4 launch sequence.
+ * Takes effect for operators created afterwards.  "chain_applies" / "chain_launches": counters of the chain's applications and of its own kernel launches (the middle
+ * stage's -- GEMM + finishing launch, or the inner Krylov solve -- not included); set to reset.  Unknown name: PMH_ERR_ARG. */
+int pmh_set_knob(const char *name, int value);
+int pmh_get_knob(const char *name, int *value);
 int pmh_finalize(pmh_ctx ctx);
 int pmh_mem_info(pmh_ctx ctx, size_t *free_bytes, size_t *total_bytes); /* HBM of the context's device */
 int pmh_device_name(pmh_ctx ctx, char *buf, size_t len);

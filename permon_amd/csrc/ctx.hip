@@ -14,6 +14,39 @@ int pmh_set_error(int code, const char *fmt, ...)
 
 extern "C" const char *pmh_last_error(void) { return g_err; }
 
+// ---- run-time switches ---------------------------------------------------------------------------------------------------------
+pmh_knobs_s &pmh_knobs()
+{
+  static pmh_knobs_s k = [] {
+    pmh_knobs_s v;
+    v.chain = getenv("PMH_NO_CHAIN") ? 0 : 1;
+    return v;
+  }();
+  return k;
+}
+static int *knob_by_name(const char *name)
+{
+  if (!name) return nullptr;
+  if (!strcmp(name, "chain")) return &pmh_knobs().chain;
+  if (!strcmp(name, "chain_applies")) return &pmh_knobs().chain_applies;
+  if (!strcmp(name, "chain_launches")) return &pmh_knobs().chain_launches;
+  return nullptr;
+}
+extern "C" int pmh_set_knob(const char *name, int value)
+{
+  int *k = knob_by_name(name);
+  if (!k) return pmh_set_error(PMH_ERR_ARG, "pmh_set_knob: unknown switch '%s'", name ? name : "(null)");
+  *k = value;
+  return PMH_SUCCESS;
+}
+extern "C" int pmh_get_knob(const char *name, int *value)
+{
+  int *k = knob_by_name(name);
+  if (!k || !value) return pmh_set_error(PMH_ERR_ARG, "pmh_get_knob: unknown switch '%s'", name ? name : "(null)");
+  *value = *k;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_init(int device, pmh_ctx *out)
 {
   PMH_ARG(out);

@@ -838,6 +838,19 @@ struct FetiDualOp : pmh_op_s {
     return pmh_gluing_mult_transpose(B, t2, y);
   }
   int mult_transpose(const double *x, double *y) override { return mult(x, y); } // F = B K^+ B' is symmetric
+  // the three stages of the product for the fused dual-space chain (dualchain.hip): B' as the gather, K^+ (explicit local dual operators or the inner Krylov solve) in the
+  // middle, B as the scatter -- the all-reduce that ends B u on several GPUs is the chain's
+  int stages(pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out) override
+  {
+    if (Kplus->E && pmh_fexplicit_matches(Kplus->E, B)) return pmh_fexplicit_stages(Kplus->E, gather, mid_in, scatter, mid_out);
+    *gather = B->Bt, *mid_in = t1, *scatter = B->B, *mid_out = t2;
+    return PMH_SUCCESS;
+  }
+  int mid_apply() override
+  {
+    if (Kplus->E && pmh_fexplicit_matches(Kplus->E, B)) return pmh_fexplicit_mid(Kplus->E);
+    return pmh_matinv_mult(Kplus, t1, t2);
+  }
 };
 
 extern "C" int pmh_op_create_feti_dual(pmh_gluing B, pmh_matinv Kplus, pmh_op *F)

@@ -57,3 +57,5 @@ struct pmh_matinv_s {
 // explicit local dual operators (fexplicit.hip)
 bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B);
 int  pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y);
+int  pmh_fexplicit_stages(pmh_fexplicit_s *E, pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out); // the sparse stages around the dense one (FetiDualOp::stages)
+int  pmh_fexplicit_mid(pmh_fexplicit_s *E);                                                                                // the dense stage alone: mid_in -> mid_out

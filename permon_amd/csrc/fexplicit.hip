@@ -983,6 +983,14 @@ int pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y)
   return pmh_gluing_mult_transpose(E->Bhat, E->yh, y); // ends with the all-reduce on several GPUs
 }
 
+int pmh_fexplicit_stages(pmh_fexplicit_s *E, pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out)
+{
+  if (E->sh) return fxs_stages(E->sh, gather, mid_in, scatter, mid_out);
+  *gather = E->Bhat->Bt, *mid_in = E->xh, *scatter = E->Bhat->B, *mid_out = E->yh;
+  return PMH_SUCCESS;
+}
+int pmh_fexplicit_mid(pmh_fexplicit_s *E) { return E->sh ? fxs_mid(E->sh) : fx_gemv(E); }
+
 extern "C" int pmh_fexplicit_mult(pmh_fexplicit E, const double *lambda, double *y)
 {
   PMH_ARG(E && lambda && y);

@@ -15,6 +15,8 @@ void      fxs_apply_flops_detail(fx_shared *S, double *issued, double *dense);
 int       fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves);
 int       fxs_apply(fx_shared *S, const double *lambda, double *y);
 int       fxs_dense(fx_shared *S);
+int       fxs_stages(fx_shared *S, pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out);
+int       fxs_mid(fx_shared *S);
 long long fxs_multivector_length(fx_shared *S);
 double   *fxs_X(fx_shared *S);
 double   *fxs_Y(fx_shared *S);

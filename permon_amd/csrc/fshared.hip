@@ -2281,6 +2281,15 @@ int fxs_apply(fx_shared *S, const double *lambda, double *y)
   return pmh_gluing_mult_transpose(S->Bc, S->Y, y); // ends with the all-reduce on several GPUs
 }
 
+int fxs_stages(fx_shared *S, pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out)
+{
+  if (S->sym == 2) *gather = S->Bc2->Bt, *mid_in = S->X2;
+  else *gather = S->Bc->Bt, *mid_in = S->X;
+  *scatter = S->Bc->B, *mid_out = S->Y;
+  return PMH_SUCCESS;
+}
+int fxs_mid(fx_shared *S) { return fxs_gemm(S); }
+
 // the dense kernel alone (tests, tuning): Y = blockdiag(W_c) X on the multivectors as they stand
 int fxs_dense(fx_shared *S)
 {

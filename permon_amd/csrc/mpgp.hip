@@ -20,8 +20,14 @@
 #include "pmh_internal.h"
 #include "reduce.h"
 #include "box_inline.h"
+#include "emit_inline.h"
 
 #define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < (n); i += (long long)gridDim.x * PMH_BLOCK)
+// the entries of a vector kernel: grid-strided over workgroups of 256 threads, or -- EMIT variants, which end with pmh_emit_tail -- thread t of the 1024-thread
+// workgroup b owns entry 1024 b + t
+#define VEC_ENTRIES(i, n) \
+  for (long long i = EMIT ? ((long long)blockIdx.x * PMH_EMIT_TILE + threadIdx.x) : ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x); i < (n); i += EMIT ? (long long)(n) : (long long)gridDim.x * PMH_BLOCK)
+#define VEC_BOUNDS __launch_bounds__(EMIT ? PMH_EMIT_TILE : PMH_BLOCK)
 
 // scalar slots
 #define S_PAP 8
@@ -56,6 +62,7 @@ struct pmh_mpgp_s {
   double cvg_margin;       // set by the convergence test: rnorm / (the threshold it has to fall below), 0 = unknown -- how close the NEXT test is to ending the solve
   int   g_valid;           // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
   int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
+  bool  cx[2] = {false, false}; // fused dual-space chain (pmh_op_s::emit_begin): the operator holds G0 x (0) / G0 p (1) of the CURRENT x / p, emitted by the kernel that wrote them
   int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
   void            *cvg_user;
   double           norm_rhs, ttol, norm_rhs_div;
@@ -79,9 +86,16 @@ struct pmh_mpgp_s {
 // device helpers: the box predicates of qpcbox.c restated per element
 // --------------------------------------------------------------------------------------------------------------------
 // (the box predicates pmh_box_split / pmh_box_reduced: box_inline.h)
-template <int K>
+template <int K, bool AGENT = false>
 __device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld)
 {
+  if (AGENT) { // read by the ticket workgroup of the same kernel (emit_inline.h)
+    int op[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) op[k] = PMH_RED_SUM;
+    pmh_block_partials_agent<K>(v, op, partials, ld);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < K; k++) {
     double r = pmh_block_reduce<PMH_RED_SUM>(v[k], lds);
@@ -91,22 +105,25 @@ __device__ __forceinline__ void write_partials(double (&v)[K], double *lds, doub
 
 // gradient split + norms (+ p = gf): after the initial gradient and after an expansion step
 // (MPGPGrads mpgp.c:198-223 + VecCopy(gf,p) :507/:615 + the three reductions of :514-521)
-__global__ __launch_bounds__(PMH_BLOCK) void k_split_setp(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ p, double *__restrict__ partials, int ld)
+template <bool EMIT>
+__global__ VEC_BOUNDS void k_split_setp(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ p, double *__restrict__ partials, int ld, pmh_emit_args ea, pmh_fin_desc fin)
 {
   __shared__ double lds[PMH_BLOCK / 64];
-  double            acc[4] = {0.0, 0.0, 0.0, 0.0};
-  GRID_STRIDE(i, n)
+  double            acc[4] = {0.0, 0.0, 0.0, 0.0}, pv = 0.0, zv = 0.0;
+  VEC_ENTRIES(i, n)
   {
     double f, c;
     pmh_box_split(x[i], g[i], lb, ub, i, astol, f, c);
     gf[i]      = f;
     p[i]       = f;
+    pv     = f;
     double gPi = f + c; // VecWAXPY(gP,1,gf,gc)
     acc[1] += gPi * gPi;
     acc[2] += c * c;
     acc[3] += f * f;
   }
-  write_partials<4>(acc, lds, partials, ld);
+  write_partials<4, EMIT>(acc, lds, partials, ld);
+  if (EMIT) pmh_emit_tail(ea, fin, zv, pv); // G0 p for the p = gf just written, the four sums reduced by the last workgroup
 }
 
 // device control words of the speculative CG chain
@@ -126,8 +143,8 @@ struct pmh_spec_args { // constants of one solve, passed by value
 // at the top of this iteration -- QPSConvergedDefault (qps.c:688-712), proportionality (mpgp.c:535) and
 // acg <= afeas (mpgp.c:547).  If this is a plain CG step it is taken without any host round trip; otherwise
 // the chain halts with the state untouched and the host driver takes this iteration.
-template <bool SETP, bool SPEC>
-__global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const double *__restrict__ scal, pmh_spec_args sa, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld)
+template <bool SETP, bool SPEC, bool EMIT = false>
+__global__ VEC_BOUNDS void k_step_update(long long n, const double *__restrict__ scal, pmh_spec_args sa, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld, pmh_emit_args ea, pmh_fin_desc fin)
 {
   __shared__ double lds[PMH_BLOCK / 64];
   double            acg = scal[S_GP] / scal[S_PAP];
@@ -150,8 +167,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const do
     }
   }
   const double ma     = -acg;
-  double       acc[4] = {0.0, 0.0, 0.0, 0.0};
-  GRID_STRIDE(i, n)
+  double       acc[4] = {0.0, 0.0, 0.0, 0.0}, xv = 0.0, pv = 0.0;
+  VEC_ENTRIES(i, n)
   {
     double api = Ap[i];
     double xi  = x[i] + ma * p[i];
@@ -162,49 +179,60 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_step_update(long long n, const do
     g[i]  = gi;
     gf[i] = f;
     if (SETP) p[i] = f;
+    xv = xi, pv = f;
     double gPi = f + c;
     acc[0] += api * f;
     acc[1] += gPi * gPi;
     acc[2] += c * c;
     acc[3] += f * f;
   }
-  write_partials<4>(acc, lds, partials, ld);
+  write_partials<4, EMIT>(acc, lds, partials, ld);
+  if (EMIT) pmh_emit_tail(ea, fin, xv, pv); // G0 x (and G0 p where p = gf was set), the four sums reduced by the last workgroup
 }
 
 // P3: p = gf - bcg p, bcg = (Ap'gf)/(p'Ap) (mpgp.c:558-560: VecAYPX(p,-bcg,gf))
-__global__ __launch_bounds__(PMH_BLOCK) void k_dir_update(long long n, const double *__restrict__ scal, const int *__restrict__ halt, const double *__restrict__ gf, double *__restrict__ p)
+template <bool EMIT>
+__global__ VEC_BOUNDS void k_dir_update(long long n, const double *__restrict__ scal, const int *__restrict__ halt, const double *__restrict__ gf, double *__restrict__ p, pmh_emit_args ea, pmh_fin_desc fin)
 {
   if (halt && *halt) return;
   double       bcg = scal[S_APGF] / scal[S_PAP];
   const double mb  = -bcg;
-  GRID_STRIDE(i, n) p[i] = gf[i] + mb * p[i];
+  double       pv = 0.0, zv = 0.0;
+  VEC_ENTRIES(i, n) p[i] = pv = gf[i] + mb * p[i];
+  if (EMIT) pmh_emit_tail(ea, fin, zv, pv);
 }
 
 // proportioning direction p = gc (mpgp.c:623), gc recomputed from x, g
-__global__ __launch_bounds__(PMH_BLOCK) void k_prop_dir(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ p)
+template <bool EMIT>
+__global__ VEC_BOUNDS void k_prop_dir(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ p, pmh_emit_args ea, pmh_fin_desc fin)
 {
-  GRID_STRIDE(i, n)
+  double pv = 0.0, zv = 0.0;
+  VEC_ENTRIES(i, n)
   {
     double f, c;
     pmh_box_split(x[i], g[i], lb, ub, i, astol, f, c);
-    p[i] = c;
+    p[i] = pv = c;
   }
+  if (EMIT) pmh_emit_tail(ea, fin, zv, pv);
 }
 
 // expansion (std direction, fixed length; MPGPExpansion_Std mpgp.c:299-323):
 // x -= afeas p; g -= afeas Ap; split; gr; x -= alpha gr.  g is not stored: it is recomputed as A x - b next.
-__global__ __launch_bounds__(PMH_BLOCK) void k_expansion_std(long long n, double afeas, double alpha, double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol)
+template <bool EMIT>
+__global__ VEC_BOUNDS void k_expansion_std(long long n, double afeas, double alpha, double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, pmh_emit_args ea, pmh_fin_desc fin)
 {
   const double maf = -afeas, mal = -alpha;
-  GRID_STRIDE(i, n)
+  double       xv = 0.0, zv = 0.0;
+  VEC_ENTRIES(i, n)
   {
     double xi = x[i] + maf * p[i];
     double gi = g[i] + maf * Ap[i];
     double f, c;
     pmh_box_split(xi, gi, lb, ub, i, astol, f, c);
     double r = pmh_box_reduced(xi, f, lb, ub, i, alpha);
-    x[i]     = xi + mal * r;
+    x[i] = xv = xi + mal * r;
   }
+  if (EMIT) pmh_emit_tail(ea, fin, xv, zv);
 }
 
 // p'Ap, g'p, QPCFeas for operators without a fused SpMV epilogue (shell operators: F, P F P, A + rho Q ...)
@@ -269,6 +297,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_obj_from_grad(long long n, const 
 #define LAUNCH(kern, ...) \
   do { \
     if (s->n > 0) hipLaunchKernelGGL(kern, dim3(pmh_vec_grid(s->n)), dim3(PMH_BLOCK), 0, s->ctx->stream, (long long)s->n, __VA_ARGS__); \
+    PMH_HIP(hipGetLastError()); \
+  } while (0)
+
+// the EMIT variants: workgroups of PMH_EMIT_TILE threads, one entry each
+#define LAUNCH_EMIT(kern, ...) \
+  do { \
+    if (s->n > 0) hipLaunchKernelGGL(kern, dim3((s->n + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE), dim3(PMH_EMIT_TILE), 0, s->ctx->stream, (long long)s->n, __VA_ARGS__); \
     PMH_HIP(hipGetLastError()); \
   } while (0)
 
@@ -494,6 +529,37 @@ static int test_convergence(pmh_mpgp s)
   return PMH_SUCCESS;
 }
 
+// ---- fused dual-space chain: emission by the vector kernels (pmh_op_s::emit_begin, emit_inline.h) ----------------------------
+static pmh_emit_args g_noea;
+static pmh_fin_desc  g_nofin;
+// the kernel about to be launched writes x (wx) and / or p (wp), one entry per thread: true = *ea is filled and the EMIT variant must be launched
+static bool emit_try(pmh_mpgp s, bool wx, bool wp, pmh_emit_args *ea)
+{
+  if (wx) s->cx[0] = false;
+  if (wp) s->cx[1] = false;
+  if (s->csr || s->epi_ok != 1 || s->o.distributed) {
+    s->A->emit_invalidate();
+    return false;
+  }
+  if (s->A->emit_begin(wx ? s->x : nullptr, wp ? s->work[4] : nullptr, ea) != PMH_SUCCESS) {
+    s->A->emit_invalidate();
+    return false;
+  }
+  if (wx) s->cx[0] = true;
+  if (wp) s->cx[1] = true;
+  return true;
+}
+// the four sums of a gradient split (rows 0..3 of the block partials -> S_APGF .. S_GF2) reduced inside the emitting kernel
+static pmh_fin_desc fin_vec4(pmh_mpgp s)
+{
+  pmh_fin_desc f;
+  memset(&f, 0, sizeof(f));
+  f.partials = s->ctx->d_partials, f.ld = s->ctx->partials_cap, f.nblocks = (s->n + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE, f.K = 4; // (the EMIT variants' grid)
+  for (int k = 0; k < 4; k++) f.op[k] = PMH_RED_SUM, f.slot[k] = S_APGF + k;
+  f.d_scal = s->ctx->d_scal, f.h_scal = s->ctx->h_scal;
+  return f;
+}
+
 static int finalize_vec4(pmh_mpgp s, const int *halt = nullptr, int *post = nullptr)
 {
   const int ops[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
@@ -598,6 +664,8 @@ static int u_objective_from_gradient(pmh_mpgp s, const double *x, const double *
 static int solve_unfused(pmh_mpgp s)
 {
   s->g_valid  = 0; // (this driver always forms its own gradient)
+  s->cx[0] = s->cx[1] = false;
+  s->A->emit_invalidate();
   pmh_ctx ctx = s->ctx;
   int     n   = s->n;
   int     nw  = 7;
@@ -746,10 +814,17 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = fals
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_P1, e.g = g, e.xx = s->x, e.lb = s->lb, e.ub = s->ub, e.partials = s->ctx->d_partials, e.ld = s->ctx->partials_cap, e.prow = 4;
     e.p_fresh = p_fresh, e.spec_alpha = s->alpha, e.astol = s->o.astol; // (operators that pair their passes: svm.hip)
+    int fin_done = 0;
+    e.in_slot = s->cx[1] ? 2 : 0, e.scal_base = S_PAP, e.finalized = s->ctx->dist_scalars ? nullptr : &fin_done; // (the fused dual-space chain: G0 p emitted by the kernel that wrote p; the three sums reduced in its last kernel)
     const int rc = s->A->mult_epi(p, Ap, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
       s->epi_ok = 1;
+      if (fin_done) {
+        if (s->fin4_pending) PMH_CHK(finalize_vec4(s)); // (an operator that reduces its own sums does so for the gradient split too: not reached)
+        s->fin4_pending = 0;
+        return PMH_SUCCESS;
+      }
       if (s->fin4_pending) { // (Ap'gf, |gP|^2, |gc|^2, |gf|^2) of the gradient split and (p'Ap, g'p, afeas) in ONE finalising launch: every quantity reduced as on its own
         const int ops7[7] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
         const int slots7[7] = {S_APGF, S_GP2, S_GC2, S_GF2, S_PAP, S_GP, S_FEAS};
@@ -795,10 +870,14 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = 
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_GRAD_SPLIT, e.b = s->b, e.lb = s->lb, e.ub = s->ub, e.astol = s->o.astol, e.gf = gf, e.p = p, e.partials = ctx->d_partials, e.ld = ctx->partials_cap, e.prow = 0;
     e.x_from_spec = x_from_spec, e.x_out = s->x;
+    int fin_done = 0, p_emitted = 0;
+    e.in_slot = s->cx[0] ? 1 : 0, e.scal_base = S_APGF, e.finalized = ctx->dist_scalars ? nullptr : &fin_done, e.emitted_p = &p_emitted;
     const int rc = s->A->mult_epi(s->x, g, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
       s->epi_ok = 1;
+      s->cx[1]  = p_emitted != 0; // p = gf was written by the operator's last kernel
+      if (fin_done) return PMH_SUCCESS;
       if (defer_finalize && !ctx->dist_scalars) {
         s->fin4_pending = 1;
         return PMH_SUCCESS;
@@ -809,7 +888,8 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = 
   }
   if (x_from_spec) return pmh_set_error(PMH_ERR_STATE, "pmh_mpgp: the operator prepared an expansion step and then refused the gradient");
   PMH_CHK(f_gradient(s));
-  LAUNCH(k_split_setp, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap);
+  s->cx[1] = false;
+  LAUNCH(k_split_setp<false>, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
   return finalize_vec4(s);
 }
 
@@ -828,14 +908,21 @@ static int solve_fused(pmh_mpgp s)
   double       prev_margin = 0.0; // cvg_margin of the previous test (see the speculation at the end of the loop)
   bool         p_fresh = false; // p is the gf of the last gradient split, untouched (told to operators that pair their passes)
 
+  s->cx[0] = s->cx[1] = false; // x and p come from outside
+  s->A->emit_invalidate();
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
   if (s->epi_ok < 0) s->epi_ok = (s->csr || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
                                                                                   // partials are finalised at once and completed across the ranks, pmh_finalize_partials)
   if (s->g_valid) { // the caller carried g = A x - b over from the previous solve (pmh_smalxe_set_reuse_products): the split, p = gf and the norms only
     s->g_valid = 0;
-    LAUNCH(k_split_setp, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap);
-    PMH_CHK(finalize_vec4(s));
+    pmh_emit_args ea;
+    if (emit_try(s, false, true, &ea)) {
+      LAUNCH_EMIT(k_split_setp<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+    } else {
+      LAUNCH(k_split_setp<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+      PMH_CHK(finalize_vec4(s));
+    }
   } else {
     PMH_CHK(f_gradient_split(s, false)); // :500-507 (the host reads the norms before any P1: finalised at once)
     nmv++;
@@ -850,6 +937,8 @@ static int solve_fused(pmh_mpgp s)
   auto k_cg_spec = k_step_update<false, true>;
   auto k_cg_host = k_step_update<false, false>;
   auto k_prop_host = k_step_update<true, false>;
+  auto k_cg_emit = k_step_update<false, false, true>;
+  auto k_prop_emit = k_step_update<true, false, true>;
   // the device-side CG chain needs the default convergence test (its constants go to the kernels) and a CSR operator
   const int SPEC_BATCH = 16;
   bool      can_spec   = s->csr && !s->cvg && !s->o.distributed && !getenv("PMH_MPGP_NO_SPEC");
@@ -882,9 +971,9 @@ static int solve_fused(pmh_mpgp s)
       s->h_ctl[CTL_HALT] = 0, s->h_ctl[CTL_ITER] = s->iteration, s->h_ctl[CTL_NCG] = 0, s->h_ctl[CTL_BASE] = s->iteration;
       PMH_HIP(hipMemcpyAsync(s->d_ctl, s->h_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyHostToDevice, ctx->stream));
       for (int j = 0; j < nbatch; j++) {
-        LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
+        LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
         PMH_CHK(finalize_vec4(s, s->d_ctl + CTL_HALT, s->d_ctl + CTL_ITER));
-        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p);
+        LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p, g_noea, g_nofin);
         PMH_CHK(f_apply_p1(s, s->d_ctl + CTL_HALT));
       }
       PMH_HIP(hipMemcpyAsync(s->h_ctl, s->d_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyDeviceToHost, ctx->stream));
@@ -928,15 +1017,28 @@ static int solve_fused(pmh_mpgp s)
         ncg++;
         s->step = 'c';
         spec_len = std::max(spec_len, 1); // a CG step taken by the host: the next ones may well be CG steps too
-        LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
-        PMH_CHK(finalize_vec4(s));
-        LAUNCH(k_dir_update, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p);
+        pmh_emit_args ea;
+        if (emit_try(s, true, false, &ea)) { // x -= acg p with G0 x emitted, the four sums reduced by the kernel's last workgroup
+          LAUNCH_EMIT(k_cg_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+        } else {
+          LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+          PMH_CHK(finalize_vec4(s));
+        }
+        if (emit_try(s, false, true, &ea)) LAUNCH_EMIT(k_dir_update<true>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, ea, g_nofin);
+        else LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, g_noea, g_nofin);
         p_fresh = false;
       } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
         nexp++;
         s->step = 'e';
         const bool prepared = s->epi_ok == 1 && s->A->spec_expansion_ready(); // the operator's P1 pass already formed k_expansion_std's iterate (svm.hip): it hands it over with the gradient
-        if (!prepared) LAUNCH(k_expansion_std, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol);
+        if (!prepared) {
+          pmh_emit_args ea;
+          if (emit_try(s, true, false, &ea)) LAUNCH_EMIT(k_expansion_std<true>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, ea, g_nofin);
+          else LAUNCH(k_expansion_std<false>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, g_noea, g_nofin);
+        } else {
+          s->cx[0] = false;
+          s->A->emit_invalidate();
+        }
         PMH_CHK(f_gradient_split(s, true, prepared)); // the speculative P1 below finalises both groups of partial sums
         p_fresh = true;
         nmv++;
@@ -946,11 +1048,17 @@ static int solve_fused(pmh_mpgp s)
       s->step = 'p';
       spec    = false; // a speculative P1 (if any) used the wrong direction; it is simply not counted
       p_fresh = false;
-      LAUNCH(k_prop_dir, (const double *)x, (const double *)g, s->lb, s->ub, astol, p);
+      pmh_emit_args ea;
+      if (emit_try(s, false, true, &ea)) LAUNCH_EMIT(k_prop_dir<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, ea, g_nofin);
+      else LAUNCH(k_prop_dir<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, g_noea, g_nofin);
       PMH_CHK(f_apply_p1(s));
       nmv++;
-      LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap);
-      PMH_CHK(finalize_vec4(s));
+      if (emit_try(s, true, true, &ea)) {
+        LAUNCH_EMIT(k_prop_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+      } else {
+        LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+        PMH_CHK(finalize_vec4(s));
+      }
     }
     // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p -- enqueued before the host has seen this step's norms, so
     // that the round trip costs nothing.  If the NEXT test ends the solve that product is wasted (0.35 ms for configs[2] against the ~30 us of an exposed round trip):

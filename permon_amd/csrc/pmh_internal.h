@@ -18,6 +18,14 @@
 
 int pmh_set_error(int code, const char *fmt, ...);
 
+// process-wide run-time switches (pmh_set_knob; initial values from the environment, read ONCE)
+struct pmh_knobs_s {
+  int chain; // the five-launch dual-space chain (dualchain.hip)
+  // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and the launches they took, the middle stage's included
+  int chain_applies = 0, chain_launches = 0;
+};
+pmh_knobs_s &pmh_knobs();
+
 #define PMH_HIP(call) \
   do { \
     hipError_t e_ = (call); \
@@ -138,17 +146,60 @@ struct pmh_vec_epi {
   int           p_fresh, x_from_spec;
   double        spec_alpha;
   double       *x_out;
+  // fused dual-space chain (dualchain.hip): in_slot = 1 + the emission target that holds G0 x for this input (pmh_op_s::emit_begin: 1 = iterate, 2 = direction; 0 = none: the
+  // operator forms it itself).  scal_base >= 0: the operator may reduce the block partials into d_scal / h_scal[scal_base + k] inside its last kernel (P1: 3 scalars,
+  // GRAD_SPLIT: 4) and then sets *finalized = 1; emit_p (GRAD_SPLIT): its last kernel also emits G0 p for the p = gf it writes and sets *emitted_p = 1
+  int           in_slot, scal_base;
+  int          *finalized, *emitted_p;
 };
+// ---- coarse-space emission of the fused dual-space chain (dualchain.hip, emit_inline.h) ----------------------------------
+// G0 of the projector cut into (row, block of 256 columns) segments; the kernel that writes a dual vector sums its own segments (see emit_inline.h)
+struct pmh_emit_tab {
+  const int    *seg;     // [nwg][64][3] per tile of 1024 dual entries its segments (k0, k1, position of the segment's sum in the row-major array of partial sums), k1 = k0: none
+  const int    *gcol;    // G0 as CSR (device)
+  const double *gval;
+  const int    *lrow;    // [m + 1] a row's partial sums are part[lrow[r] .. lrow[r + 1])
+  int           m, nwg;
+};
+struct pmh_emit_out { // one emitted vector v
+  double       *part;     // [nseg] segment sums (nullptr: target off)
+  double       *coarse;   // [m] a = G0 v (may be nullptr)
+  const double *S;        // m x m symmetric: c = S a -> coarse_c (nullptr: not wanted)
+  double       *coarse_c;
+  const double *Tt;       // T' row-major: y2 = T a and ||T a||^2 -> *norm_d, *norm_h (nullptr: not wanted)
+  double       *y2, *norm_d, *norm_h;
+};
+struct pmh_emit_args {
+  pmh_emit_tab tab;
+  pmh_emit_out o[2]; // target 0: the iterate, target 1: the direction (mpgp.hip); dualchain.hip's own kernels use target 0
+  unsigned    *ticket;
+};
+struct pmh_fin_desc { // block partials -> scalar slots inside the kernel that produced them (K = 0: none)
+  const double *partials;
+  int           ld, nblocks, K;
+  int           op[PMH_MAX_RED], slot[PMH_MAX_RED];
+  double       *d_scal, *h_scal;
+};
+
 struct pmh_op_s {
   pmh_ctx ctx;
   int     n;
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
   virtual int     mult_epi(const double *, double *, const pmh_vec_epi &) { return PMH_EPI_UNSUPPORTED; }
+  // Coarse emission (fused dual-space chain): the caller is about to launch a kernel that writes the iterate x (x != nullptr) and / or the direction p (p != nullptr), one entry
+  // per thread on the grid of the streaming Vec kernels; on PMH_SUCCESS *ea is filled and the kernel MUST end with pmh_emit_tail(*ea, ...) -- the operator then takes
+  // G0 x / G0 p as given when it is applied with pmh_vec_epi::in_slot 0 / 1.  PMH_EPI_UNSUPPORTED: no such chain, launch the plain kernel.
+  virtual int     emit_begin(const double * /*x*/, const double * /*p*/, pmh_emit_args *) { return PMH_EPI_UNSUPPORTED; }
+  virtual void    emit_invalidate() {} // x or p are about to change without emission
   virtual int     spec_expansion_ready() { return 0; } // the last PMH_VEPI_P1 prepared the expansion step (pmh_vec_epi::spec_alpha)
   // MatMultTranspose slot; operators that are symmetric by construction forward to mult
   virtual int     mult_transpose(const double *, double *) { return pmh_set_error(PMH_ERR_SUP, "this operator has no MatMultTranspose slot"); }
   virtual pmh_csr as_csr() { return nullptr; }
+  // Operators of the form (scatter) o (middle) o (gather) -- F = B K^+ B' with either K^+ (feti.hip): gather = B' as CSR (rows = entries of mid_in), scatter = B as CSR
+  // (rows = dual entries, columns = entries of mid_out); mid_apply runs the middle stage mid_in -> mid_out.  The fused dual-space chain folds the projector into the two sparse stages.
+  virtual int     stages(pmh_csr * /*gather*/, double ** /*mid_in*/, pmh_csr * /*scatter*/, const double ** /*mid_out*/) { return PMH_EPI_UNSUPPORTED; }
+  virtual int     mid_apply() { return pmh_set_error(PMH_ERR_SUP, "this operator has no middle stage"); }
 };
 
 // ---- projector factory -------------------------------------------------------------------------------------
@@ -186,7 +237,10 @@ int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user);         
 // SMALXE's ||B u|| riding on the next product of the penalised operator (qppf.hip): G0 u shares the pass over G0 with G0 x, T (G0 u) and its squared norm are
 // finished by workgroup 0 of the projector's kernel -- two launches less per inner iteration, the same bits as pmh_qppf_apply_G_norm2
 int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int slot);
-int pmh_op_penalized_take_aux_done(pmh_op op); // 1 if the armed request was served by the last product (and clears it), 0 otherwise (and disarms)
+int pmh_op_penalized_take_aux_done(pmh_op op);
+int pmh_op_penalized_set_normG_target(pmh_op op, double *Gu, int slot); // the five-launch chain (dualchain.hip): ||T G0 u||^2 of every emitted iterate -> Gu, scalar slot
+int pmh_op_penalized_normG_ready(pmh_op op, const double *u);           // 1: slot and Gu hold the values of this u
+int pmh_op_penalized_chain_launches(pmh_op op);                        // launches of the chain's last application (-1: no chain) // 1 if the armed request was served by the last product (and clears it), 0 otherwise (and disarms)
 #define PMH_SLOT_NORMBU2 48 // ||B u||^2 prefetched for SMALXE's inner convergence test
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
 

@@ -12,6 +12,7 @@
 #include "pmh_internal.h"
 #include "reduce.h"
 #include "box_inline.h"
+#include "dualchain.h"
 
 
 // y = M x, M dense m x m row-major; one 64-lane wavefront per row
@@ -737,6 +738,29 @@ struct PenalizedOp : pmh_op_s {
   const double *aux_u = nullptr;
   double       *aux_Gu = nullptr;
   int           aux_slot = -1, aux_done = 0;
+  // the five-launch chain (dualchain.hip) where F offers its stages: created at the first product
+  pmh_dualchain dc = nullptr;
+  int           dc_state = -1; // -1 not asked yet, 0 does not apply, 1 live
+  int           chain_allowed = 1; // pmh_set_knob("chain") as it stood when the operator was created
+  pmh_dualchain chain()
+  {
+    if (dc_state < 0) {
+      dc_state        = 0;
+      ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
+      if (chain_allowed && pa && pa->pf == pf && pa->symmetric && pmh_dc_create(pf, pa->A, &dc) == PMH_SUCCESS && dc) {
+        dc_state = 1;
+        if (norm_Gu) (void)pmh_dc_set_norm_target(dc, norm_Gu, norm_slot);
+      }
+    }
+    return dc_state == 1 ? dc : nullptr;
+  }
+  double *norm_Gu = nullptr;
+  int     norm_slot = -1;
+  int  emit_begin(const double *x, const double *p, pmh_emit_args *ea) override { return chain() ? pmh_dc_emit_begin(dc, x, p, ea) : PMH_EPI_UNSUPPORTED; }
+  void emit_invalidate() override
+  {
+    if (dc) pmh_dc_invalidate(dc);
+  }
   // the fully fused product y = rho Q x + P F (P x) [+ vector epilogue] of the one-launch projector form
   bool fused_dense()
   {
@@ -755,12 +779,14 @@ struct PenalizedOp : pmh_op_s {
   }
   int mult_epi(const double *x, double *y, const pmh_vec_epi &e) override
   {
+    if (chain()) return pmh_dc_apply(dc, x, y, rho, &e);
     static const bool off = getenv("PMH_NO_VEC_EPI") != nullptr; // A/B: the separate vector kernels
     if (off || !fused_dense() || n > PMH_MAX_VEC_BLOCKS * PMH_BLOCK || pmh_vec_grid(n) != (n + PMH_BLOCK - 1) / PMH_BLOCK) return PMH_EPI_UNSUPPORTED;
     return mult_fused_dense(x, y, &e);
   }
   ~PenalizedOp() override
   {
+    pmh_dc_destroy(dc);
     pmh_free(ctx, t);
     if (xwork) pmh_free(ctx, xwork);
   }
@@ -768,6 +794,7 @@ struct PenalizedOp : pmh_op_s {
   int mult(const double *x, double *y) override
   {
     ProjectedOp *pa = dynamic_cast<ProjectedOp *>(A);
+    if (chain()) return pmh_dc_apply(dc, x, y, rho, nullptr);
     if (fused_dense()) return mult_fused_dense(x, y, nullptr);
     aux_u = nullptr; // a ||G u|| request can only ride on the one-launch form
     if (pa && pa->pf == pf && pa->symmetric && gt_fusable(pf)) {
@@ -839,6 +866,7 @@ extern "C" int pmh_op_create_penalized(pmh_op A, pmh_qppf pf, double rho, pmh_op
   o->A           = A;
   o->pf          = pf;
   o->rho         = rho;
+  o->chain_allowed = pmh_knobs().chain;
   PMH_CHK(pmh_malloc(o->ctx, sizeof(double) * (size_t)o->n, (void **)&o->t));
   *op = o;
   return PMH_SUCCESS;
@@ -864,9 +892,30 @@ int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int s
   PMH_ARG(o && u && Gu && slot >= 0 && slot < PMH_NSCAL);
   static const bool off = getenv("PMH_NO_AUX_NORMG") != nullptr; // A/B: ||G u|| by its own two launches
   o->aux_done = 0;
-  if (off || !o->fused_dense()) return PMH_SUCCESS; // not armed: the caller's own launches follow
+  if (off || o->dc || !o->fused_dense()) return PMH_SUCCESS; // not armed: the caller's own launches follow
   o->aux_u = u, o->aux_Gu = Gu, o->aux_slot = slot;
   return PMH_SUCCESS;
+}
+
+// SMALXE's ||B u|| from the chain: every emission of the iterate leaves T G0 u in Gu and its squared norm in the scalar slot (pmh_dc_set_norm_target);
+// ready = the last such emission was for this very u and nothing has invalidated it since
+int pmh_op_penalized_set_normG_target(pmh_op op, double *Gu, int slot)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  PMH_ARG(o && Gu && slot >= 0 && slot < PMH_NSCAL);
+  o->norm_Gu = Gu, o->norm_slot = slot;
+  if (o->dc) PMH_CHK(pmh_dc_set_norm_target(o->dc, Gu, slot));
+  return PMH_SUCCESS;
+}
+int pmh_op_penalized_normG_ready(pmh_op op, const double *u)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  return (o && o->dc && pmh_dc_norm_ready(o->dc, u)) ? 1 : 0;
+}
+int pmh_op_penalized_chain_launches(pmh_op op)
+{
+  PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
+  return (o && o->dc) ? pmh_dc_last_launches(o->dc) : -1;
 }
 
 int pmh_op_penalized_take_aux_done(pmh_op op)

@@ -104,6 +104,10 @@ static int prefetch_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
   if (s->o.be_implicit || s->pf->m == 0 || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  if (pmh_op_penalized_normG_ready(s->A_inner, s->u)) { // the kernel that wrote u emitted G0 u; its last workgroup left T G0 u and the squared norm in place (dualchain.hip)
+    s->normBu_prefetched = 1;
+    return PMH_SUCCESS;
+  }
   if (pmh_op_penalized_take_aux_done(s->A_inner)) { // it rode on the speculative A_rho p of this iteration (arm_normBu below): already in the scalar slot, same bits
     s->normBu_prefetched = 1;
     return PMH_SUCCESS;
@@ -310,6 +314,7 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
   PMH_CHK(pmh_mpgp_set_convergence_test(s->inner, inner_converged, s));
   PMH_CHK(pmh_mpgp_set_pre_test_hook(s->inner, prefetch_normBu, s));
   PMH_CHK(pmh_mpgp_set_pre_p1_hook(s->inner, arm_normBu, s));
+  if (!s->o.be_implicit && pf->m > 0 && pf->implicit_orth && pf->m <= 64) PMH_CHK(pmh_op_penalized_set_normG_target(s->A_inner, s->Bu, PMH_SLOT_NORMBU2));
   *out = s;
   return PMH_SUCCESS;
 }
