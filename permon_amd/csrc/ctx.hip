@@ -74,6 +74,8 @@ extern "C" int pmh_init(int device, pmh_ctx *out)
   PMH_HIP(hipMemset(c->d_scal, 0, sizeof(double) * PMH_NSCAL));
   PMH_HIP(hipHostMalloc((void **)&c->h_scal, sizeof(double) * PMH_NSCAL, hipHostMallocMapped));
   memset(c->h_scal, 0, sizeof(double) * PMH_NSCAL);
+  PMH_HIP(hipHostMalloc((void **)&c->h_partials, sizeof(double) * PMH_MAX_RED * c->partials_cap, hipHostMallocMapped));
+  memset(c->h_partials, 0, sizeof(double) * PMH_MAX_RED * c->partials_cap);
   PMH_HIP(hipMalloc((void **)&c->d_commbuf, sizeof(double) * PMH_NSCAL));
   *out = c;
   return PMH_SUCCESS;
@@ -90,6 +92,7 @@ extern "C" int pmh_finalize(pmh_ctx c)
   hipFree(c->d_scal);
   hipFree(c->d_commbuf);
   hipHostFree(c->h_scal);
+  hipHostFree(c->h_partials);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);

@@ -5,17 +5,18 @@
 // (MatMult_Penalized src/qp/utils/matpenalized.c:12-22 over MatCreateProd(P, F, P) src/qp/interface/qptransform.c:273-284 with QPPFApplyQ / QPPFApplyP
 // src/qppf/interface/qppf.c:454-503,563-575 and MatMult(Transpose)_Gluing src/mat/impls/gluing/gluing.c:47-159) in FIVE launches, two of them the middle stage's:
 //
-//     [producer of x: its own entries of G0 x, segment by segment; the last workgroup: a = G0 x, c = S a]          (emit_inline.h; k_dc_emit where nobody emitted)
-//     k_dc_gather    mid_in = Bg' (x - G0' c)         the projection is recomputed per gathered entry: P x is never stored
+//     [the kernel that wrote x left the segment sums of G0 x behind (emit_inline.h; k_dc_emit where nobody did)]
+//     k_dc_gather    a = G0 x from the segment sums, c = S a;  mid_in = Bg' (x - G0' c): the projection is recomputed per gathered entry, P x is never stored
 //     middle stage   mid_out = W mid_in               (orbit GEMM + its finishing launch, or the inner Krylov solve)
-//     k_dc_scatter   w = Bs mid_out, the segments of G0 w; the last workgroup: d = G0 w, stored behind w ([w; d] is ONE all-reduce on several GPUs)
-//     k_dc_final     e = S d;  y = rho G0' c + (w - G0' e);  the MPGP vector phase (mpgp.c:537-544 / :578-615), its block partials reduced by the last workgroup,
-//                    which also emits G0 p for the p = gf it wrote
+//     k_dc_scatter   w = Bs mid_out and the segment sums of G0 w, stored behind w ([w; sums] is ONE all-reduce on several GPUs)
+//     k_dc_final     d = G0 w from the sums, e = S d;  y = rho G0' c + (w - G0' e);  the MPGP vector phase (mpgp.c:537-544 / :578-615) with its block partials
+//                    left for the host's next wait, and the segment sums of G0 p for the p = gf it wrote
 //
 // Round 4 took 9 launches + a finalising one for the same product (k_spmv_long_part, k_gt_fused1d<0>, k_spmv_ell, GEMM, fin, k_spmv_stream, k_spmv_long_part,
 // k_gt_fused1d<EPI>, k_finalize): at 5-9 us each they were a quarter of the one-GPU step and what bounded the share of one of eight GPUs.
-// Determinism: every sum has a fixed order (lane tree -> wave order -> segment order); the one atomic is a ticket that decides WHICH workgroup adds last, nothing else.
+// Determinism: every sum has a fixed order (lane-strided in segment order -> wave tree -> waves in order); no atomics anywhere.
 #include <algorithm>
+#include <cmath>
 
 #include "dualchain.h"
 #include "emit_inline.h"
@@ -43,28 +44,52 @@ struct pmh_dualchain_s {
   int     *d_sc2 = nullptr;
   double  *d_sv2 = nullptr;
   unsigned char *d_scnt = nullptr;
-  double  *part[4]   = {nullptr, nullptr, nullptr, nullptr}; // segment sums: iterate, direction, scratch, w
-  double  *coarse    = nullptr;                               // [3][2][64]: a and c = S a per slot
-  double  *w         = nullptr;                               // [n + m]: Bs mid_out, then d = G0 w
-  unsigned *ticket   = nullptr;                               // [4]
+  double  *part[3] = {nullptr, nullptr, nullptr}; // segment sums: iterate, direction, scratch
+  double  *c_cur   = nullptr;                     // [64] c = S G0 x of the application under way (written by k_dc_gather, read by k_dc_final)
+  double  *w       = nullptr;                     // [n + nseg]: Bs mid_out, then the segment sums of G0 w
+  // SMALXE's ||B u||: T G0 u and its squared norm ride on the gather kernel of the application that follows an emission of the iterate
   double  *normGu    = nullptr;
   int      norm_slot = -1;
-  const double *norm_ptr = nullptr; // the vector whose T G0 u / squared norm the last emission of the iterate left in normGu / the slot
+  const double *x_emitted = nullptr; // the iterate whose segment sums target 0 holds
+  bool     norm_done = false;        // ... and whether its norm has been formed (enqueued)
+  const double *norm_ptr = nullptr;  // the vector whose T G0 u / squared norm are in normGu / the slot (as far as the stream has got)
   int      launches = 0;
-  double  *a_of(int s) { return coarse + (size_t)s * 128; }
-  double  *c_of(int s) { return coarse + (size_t)s * 128 + 64; }
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------------
 // All of them are made of memory latencies, not of bytes (the dual space has ~10^5 entries): what counts is the number of DEPENDENT load levels and that every wave is
 // resident at once.  G0' is therefore kept as a fixed-width slot copy (W = 8 or 16 entries per row, one byte per column: m <= 64) addressed by the row number alone, the
-// gather visits only the rows of Bg' that have entries (the others are zero once and for all), and the kernels with a ticket run four entries per thread.
+// gather visits only the rows of Bg' that have entries (the others are zero once and for all) through one record per row, the scatter matrix keeps its first two
+// entries per row at fixed places.
 
 // G0 x for a vector nobody emitted (the first product of a solve, plain MatMult callers)
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_emit(int n, const double *__restrict__ x, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_emit(int n, const double *__restrict__ x, pmh_emit_args ea)
 {
+  pmh_emit_regs R;
+  pmh_emit_prefetch(ea, R);
   const int r = blockIdx.x * PMH_EMIT_TILE + threadIdx.x;
-  pmh_emit_tail(ea, fin, r < n ? x[r] : 0.0, 0.0);
+  pmh_emit_tail(ea, R, r < n ? x[r] : 0.0, 0.0);
+}
+
+// T G0 u and ||T G0 u||^2 from the segment sums of the iterate, on their own (one workgroup): where no application follows the emission before the host waits
+template <int NU>
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_norm(pmh_emit_tab tab, const double *__restrict__ part, const double *__restrict__ Tt, double *__restrict__ y2, double *__restrict__ norm_d,
+                                                         double *__restrict__ norm_h)
+{
+  __shared__ double pt[PMH_EMIT_NW][64];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = tab.m;
+  double            s1, s2;
+  pmh_coarse_share<4, NU>(tab, part, Tt, nullptr, nullptr, s1, s2);
+  pt[wave][lane] = s1;
+  __syncthreads();
+  if (wave == 0) {
+    double y = 0.0;
+#pragma unroll
+    for (int w = 0; w < PMH_EMIT_NW; w++) y += pt[w][lane];
+    if (lane < m) y2[lane] = y;
+    const double sq = pmh_wave_all<PMH_RED_SUM>(lane < m ? y * y : 0.0);
+    if (lane == 0) *norm_d = sq, *norm_h = sq;
+  }
 }
 
 // (G0' c)_j over the slot copy: left to right as the CSR row (padded slots hold 0 x c[0])
@@ -77,65 +102,95 @@ static __device__ __forceinline__ void dc_gt_load(const double *__restrict__ ev,
     const dbl2 d = *(const dbl2 *)(ev + (size_t)j * W + e);
     v[e] = d.x, v[e + 1] = d.y;
   }
-  if (W == 8) {
-    const unsigned long long cc = *(const unsigned long long *)(ec + (size_t)j * 8);
 #pragma unroll
-    for (int e = 0; e < 8; e++) c[e] = (unsigned char)(cc >> (8 * e));
-  } else {
+  for (int h = 0; h < W / 8; h++) {
+    const unsigned long long cc = *(const unsigned long long *)(ec + (size_t)j * W + 8 * h);
 #pragma unroll
-    for (int h = 0; h < W / 8; h++) {
-      const unsigned long long cc = *(const unsigned long long *)(ec + (size_t)j * W + 8 * h);
-#pragma unroll
-      for (int e = 0; e < 8; e++) c[8 * h + e] = (unsigned char)(cc >> (8 * e));
-    }
+    for (int e = 0; e < 8; e++) c[8 * h + e] = (unsigned char)(cc >> (8 * e));
   }
 }
 
+// a = G0 x from the segment sums, c = S a (every workgroup for itself, overlapping its record loads; workgroup 0 leaves c for k_dc_final, the last workgroup forms
+// SMALXE's T G0 u and ||T G0 u||^2 where an emission of the iterate is waiting for it).  Then
 // mid_in[r] = sum_k Bg'[r][k] (x - G0' c)[col k] for the rows of Bg' that have entries, each sum left to right as the plain loops take it: row r as MatMult_SeqAIJ sums
 // it, (P x)_j = -1 (G0' c)_j + x_j as QPPFApplyP's VecAYPX forms it (qppf.c:563-575).  One record per listed row: the row, its first three entries (more: the rest from
 // the CSR) and -- where another row holds the same entries with the opposite signs (the +x / -x copies of the orbit GEMM's multivector) -- that partner row, which gets
 // the negated sum (exactly what its own left-to-right sum would be).
-template <int W>
-__global__ __launch_bounds__(PMH_BLOCK) void k_dc_gather(int nlist, const int *__restrict__ reci, const double *__restrict__ recd, const int *__restrict__ bcol, const double *__restrict__ bval,
-                                                        const double *__restrict__ ev, const unsigned char *__restrict__ ec, int m, const double *__restrict__ cin,
-                                                        const double *__restrict__ x, double *__restrict__ mid)
+struct dc_norm_args {
+  const double *part, *Tt; // the iterate's segment sums, T' (nullptr: nothing to do)
+  double       *y2, *norm_d, *norm_h;
+};
+template <int W, int NU>
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_gather(int nlist, const int *__restrict__ reci, const double *__restrict__ recd, const int *__restrict__ bcol, const double *__restrict__ bval,
+                                                        const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab, const double *__restrict__ part,
+                                                        const double *__restrict__ S, double *__restrict__ c_out, dc_norm_args na, const double *__restrict__ x, double *__restrict__ mid)
 {
   typedef int    int4v __attribute__((ext_vector_type(4)));
   typedef double dbl2 __attribute__((ext_vector_type(2)));
-  __shared__ double cs[64];
-  const int         t = threadIdx.x, i = blockIdx.x * PMH_BLOCK + t;
+  __shared__ double cs[64], ps[PMH_EMIT_NW][64], pt[PMH_EMIT_NW][64];
+  const int         t = threadIdx.x, lane = t & 63, wave = t >> 6, i = blockIdx.x * PMH_EMIT_TILE + t, m = tab.m;
   int4v             ra = {0, -1, 0, 0}, rb = {0, 0, 0, 0};
   dbl2              da = {0.0, 0.0}, db = {0.0, 0.0};
   if (i < nlist) {
     ra = *(const int4v *)(reci + (size_t)8 * i), rb = *(const int4v *)(reci + (size_t)8 * i + 4);
     da = *(const dbl2 *)(recd + (size_t)4 * i), db = *(const dbl2 *)(recd + (size_t)4 * i + 2);
   }
-  if (t < m) cs[t] = cin[t];
-  __syncthreads();
-  if (i >= nlist) return;
-  const int    r = ra.x, r2 = ra.y, k0 = ra.z, k1 = ra.w, cnt = k1 - k0;
+  const int    r = ra.x, r2 = ra.y, k0 = ra.z, k1 = ra.w, cnt = (i < nlist) ? k1 - k0 : 0;
   const int    j[3]  = {rb.x, rb.y, rb.z};
   const double bv[3] = {da.x, da.y, db.x};
-  double        v[3][W], xv[3];
-  unsigned char c[3][W];
+  double        xv[3], v0[W];
+  unsigned char c0[W];
 #pragma unroll
-  for (int u = 0; u < 3; u++) {
-    if (u < cnt) {
-      dc_gt_load<W>(ev, ec, j[u], v[u], c[u]);
-      xv[u] = x[j[u]];
-    } else {
+  for (int u = 0; u < 3; u++) xv[u] = (u < cnt) ? x[j[u]] : 0.0;
 #pragma unroll
-      for (int e = 0; e < W; e++) v[u][e] = 0.0, c[u][e] = 0;
-      xv[u] = 0.0;
+  for (int e = 0; e < W; e++) v0[e] = 0.0, c0[e] = 0;
+  if (cnt > 0) dc_gt_load<W>(ev, ec, j[0], v0, c0); // most rows have ONE entry: its row of G0' travels with the coarse sums
+  if (na.part && blockIdx.x == gridDim.x - 1) {     // uniform: the extra workgroup forms SMALXE's T G0 u and ||T G0 u||^2 (it has no rows of its own: i >= nlist)
+    double s1, s2;
+    pmh_coarse_share<4, NU>(tab, na.part, na.Tt, nullptr, nullptr, s1, s2);
+    pt[wave][lane] = s1;
+    __syncthreads();
+    if (wave == 0) {
+      double y = 0.0;
+#pragma unroll
+      for (int w = 0; w < PMH_EMIT_NW; w++) y += pt[w][lane];
+      if (lane < m) na.y2[lane] = y;
+      const double sq = pmh_wave_all<PMH_RED_SUM>(lane < m ? y * y : 0.0);
+      if (lane == 0) *na.norm_d = sq, *na.norm_h = sq;
     }
+    return;
   }
-  double sum = 0.0;
+  {
+    double s1, s2;
+    pmh_coarse_share<4, NU>(tab, part, S, nullptr, nullptr, s1, s2);
+    ps[wave][lane] = s1;
+    __syncthreads();
+    if (wave == 0) {
+      double cc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 3; u++)
+      for (int w = 0; w < PMH_EMIT_NW; w++) cc += ps[w][lane];
+      cs[lane] = cc;
+      if (blockIdx.x == 0 && lane < m) c_out[lane] = cc;
+    }
+    __syncthreads();
+  }
+  if (i >= nlist) return;
+  double sum = 0.0;
+  {
+    double q = 0.0;
+#pragma unroll
+    for (int e = 0; e < W; e++) q += v0[e] * cs[c0[e]];
+    sum += bv[0] * (-1.0 * q + xv[0]);
+  }
+#pragma unroll
+  for (int u = 1; u < 3; u++)
     if (u < cnt) {
+      double        vv[W];
+      unsigned char cc[W];
+      dc_gt_load<W>(ev, ec, j[u], vv, cc);
       double q = 0.0;
 #pragma unroll
-      for (int e = 0; e < W; e++) q += v[u][e] * cs[c[u][e]];
+      for (int e = 0; e < W; e++) q += vv[e] * cs[cc[e]];
       sum += bv[u] * (-1.0 * q + xv[u]);
     }
   for (int k = k0 + 3; k < k1; k++) { // rows with more than three entries (corner dofs of a redundant gluing)
@@ -152,11 +207,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_dc_gather(int nlist, const int *_
   if (r2 >= 0) mid[r2] = -sum;
 }
 
-// w = Bs mid_out (row j left to right: MatMultTranspose_Gluing's accumulation order, gluing.c:142-150), the segments of G0 w, d = G0 w behind w
+// w = Bs mid_out (row j left to right: MatMultTranspose_Gluing's accumulation order, gluing.c:142-150) and the segment sums of G0 w, stored behind w
 __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsigned char *__restrict__ scnt, const int *__restrict__ sc2, const double *__restrict__ sv2, const int *__restrict__ srp,
-                                                            const int *__restrict__ scol, const double *__restrict__ sval, const double *__restrict__ Y, double *__restrict__ w, pmh_emit_args ea,
-                                                            pmh_fin_desc fin)
+                                                            const int *__restrict__ scol, const double *__restrict__ sval, const double *__restrict__ Y, double *__restrict__ w, pmh_emit_args ea)
 {
+  pmh_emit_regs R;
+  pmh_emit_prefetch(ea, R);
   const int r   = blockIdx.x * PMH_EMIT_TILE + threadIdx.x;
   double    sum = 0.0;
   if (r < n) {
@@ -174,24 +230,24 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsig
     }
     w[r] = sum;
   }
-  pmh_emit_tail(ea, fin, sum, 0.0);
+  pmh_emit_tail(ea, R, sum, 0.0);
 }
 
-// e = S d; out = rho (G0' c)_j + (w_j - (G0' e)_j) -- VecAYPX, VecScale, VecAXPY of matpenalized.c:12-22 per entry -- and the MPGP vector phase
-template <int EPI, int W>
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double *__restrict__ ev, const unsigned char *__restrict__ ec, int m, const double *__restrict__ S,
+// d = G0 w from the segment sums behind w, e = S d; out = rho (G0' c)_j + (w_j - (G0' e)_j) -- VecAYPX, VecScale, VecAXPY of matpenalized.c:12-22 per entry -- and the
+// MPGP vector phase: its block partials go to the device rows and to the pinned host copy, the segment sums of G0 p to the direction's target
+template <int EPI, int W, int NU>
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab, const double *__restrict__ S,
                                                           const double *__restrict__ cin, const double *__restrict__ w, double rho, double *__restrict__ y, pmh_vec_epi epi,
-                                                          const double *__restrict__ pin, pmh_emit_args ea, pmh_fin_desc fin)
+                                                          const double *__restrict__ pin, pmh_emit_args ea)
 {
-  __shared__ double t0[64], cs[64], es[64], Ms[64 * 64];
-  const int         t = threadIdx.x, mm = m * m, r = blockIdx.x * PMH_EMIT_TILE + t;
-  double            mreg[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) mreg[e] = (t + PMH_EMIT_TILE * e < mm) ? S[t + PMH_EMIT_TILE * e] : 0.0;
-  // the row's own operands travel with the small matrix
+  __shared__ double cs[64], es[64], ps[PMH_EMIT_NW][64];
+  const int         t = threadIdx.x, lane = t & 63, wave = t >> 6, m = tab.m, r = blockIdx.x * PMH_EMIT_TILE + t;
+  // the row's own operands travel with the coarse sums
   double        v[W];
   unsigned char c[W];
   double        wr = 0.0, pi = 0.0, gq = 0.0, xq = 0.0, lq = -INFINITY, uq = INFINITY, bq = 0.0;
+  pmh_emit_regs R;
+  if (EPI == PMH_VEPI_GRAD_SPLIT) pmh_emit_prefetch(ea, R);
 #pragma unroll
   for (int e = 0; e < W; e++) v[e] = 0.0, c[e] = 0;
   if (r < n) {
@@ -205,17 +261,20 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double 
     }
     if (EPI == PMH_VEPI_GRAD_SPLIT) bq = epi.b[r];
   }
-  if (t < m) t0[t] = w[n + t], cs[t] = cin[t];
+  if (t < m) cs[t] = cin[t];
+  {
+    double s1, s2;
+    pmh_coarse_share<4, NU>(tab, w + n, S, nullptr, nullptr, s1, s2);
+    ps[wave][lane] = s1;
+    __syncthreads();
+    if (wave == 0) {
+      double ee = 0.0;
 #pragma unroll
-  for (int e = 0; e < 4; e++)
-    if (t + PMH_EMIT_TILE * e < mm) Ms[t + PMH_EMIT_TILE * e] = mreg[e];
-  __syncthreads();
-  if (t < m) {
-    double s = 0.0;
-    for (int cc = 0; cc < m; cc++) s += Ms[cc * m + t] * t0[cc];
-    es[t] = s;
+      for (int q = 0; q < PMH_EMIT_NW; q++) ee += ps[q][lane];
+      es[lane] = ee;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   double pv = 0.0, s0 = 0.0, s1 = 0.0, mn = INFINITY, acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (r < n) {
     double sumc = 0.0, sume = 0.0;
@@ -247,13 +306,13 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double 
   if (EPI == PMH_VEPI_P1) {
     const double q[3]  = {s0, s1, mn};
     const int    op[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
-    pmh_block_partials_agent<3>(q, op, epi.partials + (size_t)epi.prow * epi.ld, epi.ld);
+    pmh_block_partials<3>(q, op, epi.partials + (size_t)epi.prow * epi.ld, epi.h_partials ? epi.h_partials + (size_t)epi.prow * epi.ld : nullptr, epi.ld);
   }
   if (EPI == PMH_VEPI_GRAD_SPLIT) {
     const int op[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
-    pmh_block_partials_agent<4>(acc, op, epi.partials + (size_t)epi.prow * epi.ld, epi.ld);
+    pmh_block_partials<4>(acc, op, epi.partials + (size_t)epi.prow * epi.ld, epi.h_partials ? epi.h_partials + (size_t)epi.prow * epi.ld : nullptr, epi.ld);
+    pmh_emit_tail(ea, R, 0.0, pv);
   }
-  if (EPI != 0) pmh_emit_tail(ea, fin, 0.0, pv);
 }
 
 // ---- set-up ------------------------------------------------------------------------------------------------------------------------
@@ -330,16 +389,14 @@ int pmh_dc_create(pmh_qppf pf, pmh_op F, pmh_dualchain *out)
   PMH_CHK(pmh_malloc(ctx, ec.size(), (void **)&dc->d_ec));
   PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_ev, ev.data(), sizeof(double) * ev.size()));
   PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_ec, ec.data(), ec.size()));
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(nseg + 1), (void **)&dc->part[s]));
     PMH_CHK(pmh_memset(ctx, dc->part[s], 0, sizeof(double) * (size_t)(nseg + 1)));
   }
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 3 * 128, (void **)&dc->coarse));
-  PMH_CHK(pmh_memset(ctx, dc->coarse, 0, sizeof(double) * 3 * 128));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * ((size_t)n + 64), (void **)&dc->w));
-  PMH_CHK(pmh_memset(ctx, dc->w, 0, sizeof(double) * ((size_t)n + 64)));
-  PMH_CHK(pmh_malloc(ctx, sizeof(unsigned) * 4, (void **)&dc->ticket));
-  PMH_CHK(pmh_memset(ctx, dc->ticket, 0, sizeof(unsigned) * 4));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 64, (void **)&dc->c_cur));
+  PMH_CHK(pmh_memset(ctx, dc->c_cur, 0, sizeof(double) * 64));
+  PMH_CHK(pmh_malloc(ctx, sizeof(double) * ((size_t)n + nseg + 1), (void **)&dc->w));
+  PMH_CHK(pmh_memset(ctx, dc->w, 0, sizeof(double) * ((size_t)n + nseg + 1)));
   *out = dc;
   return PMH_SUCCESS;
 }
@@ -451,131 +508,142 @@ void pmh_dc_destroy(pmh_dualchain dc)
   pmh_free(dc->ctx, dc->d_seg), pmh_free(dc->ctx, dc->d_lrow), pmh_free(dc->ctx, dc->d_ev), pmh_free(dc->ctx, dc->d_ec);
   if (dc->d_reci) pmh_free(dc->ctx, dc->d_reci), pmh_free(dc->ctx, dc->d_recd);
   if (dc->d_sc2) pmh_free(dc->ctx, dc->d_sc2), pmh_free(dc->ctx, dc->d_sv2), pmh_free(dc->ctx, dc->d_scnt);
-  for (int s = 0; s < 4; s++) pmh_free(dc->ctx, dc->part[s]);
-  pmh_free(dc->ctx, dc->coarse), pmh_free(dc->ctx, dc->w), pmh_free(dc->ctx, dc->ticket);
+  for (int s = 0; s < 3; s++) pmh_free(dc->ctx, dc->part[s]);
+  pmh_free(dc->ctx, dc->c_cur), pmh_free(dc->ctx, dc->w);
   delete dc;
 }
 
-static void dc_tab(pmh_dualchain dc, pmh_emit_args *ea)
+static pmh_emit_tab dc_tab(pmh_dualchain dc)
 {
-  memset(ea, 0, sizeof(*ea));
-  ea->tab.seg = dc->d_seg, ea->tab.gcol = dc->pf->G->d_col, ea->tab.gval = dc->pf->G->d_val, ea->tab.lrow = dc->d_lrow;
-  ea->tab.m = dc->m, ea->tab.nwg = dc->nwg;
-}
-// emission target of slot s (0 iterate, 1 direction, 2 scratch) into o
-static void dc_target(pmh_dualchain dc, int s, pmh_emit_out *o)
-{
-  memset(o, 0, sizeof(*o));
-  o->part = dc->part[s], o->coarse = dc->a_of(s), o->S = dc->pf->d_S, o->coarse_c = dc->c_of(s);
-  if (s == 0 && dc->normGu) o->Tt = dc->pf->d_Tt, o->y2 = dc->normGu, o->norm_d = dc->ctx->d_scal + dc->norm_slot, o->norm_h = dc->ctx->h_scal + dc->norm_slot;
+  pmh_emit_tab t;
+  t.seg = dc->d_seg, t.gcol = dc->pf->G->d_col, t.gval = dc->pf->G->d_val, t.lrow = dc->d_lrow, t.m = dc->m, t.nwg = dc->nwg;
+  return t;
 }
 
 int pmh_dc_emit_begin(pmh_dualchain dc, const double *x, const double *p, pmh_emit_args *ea)
 {
-  dc_tab(dc, ea);
-  ea->ticket = dc->ticket + 0;
+  memset(ea, 0, sizeof(*ea));
+  ea->tab = dc_tab(dc);
   if (x) {
-    dc_target(dc, 0, &ea->o[0]);
-    dc->norm_ptr = dc->normGu ? x : nullptr;
+    ea->o[0].part = dc->part[0];
+    dc->x_emitted = x, dc->norm_done = false, dc->norm_ptr = nullptr;
   }
-  if (p) dc_target(dc, 1, &ea->o[1]);
+  if (p) ea->o[1].part = dc->part[1];
   return PMH_SUCCESS;
 }
 
-void pmh_dc_invalidate(pmh_dualchain dc) { dc->norm_ptr = nullptr; }
+void pmh_dc_invalidate(pmh_dualchain dc) { dc->x_emitted = nullptr, dc->norm_ptr = nullptr, dc->norm_done = false; }
 
 int pmh_dc_set_norm_target(pmh_dualchain dc, double *Gu, int slot)
 {
   PMH_ARG(dc && Gu && slot >= 0 && slot < PMH_NSCAL);
-  dc->normGu = Gu, dc->norm_slot = slot, dc->norm_ptr = nullptr;
+  dc->normGu = Gu, dc->norm_slot = slot, dc->norm_ptr = nullptr, dc->norm_done = false;
   return PMH_SUCCESS;
 }
 
-bool pmh_dc_norm_ready(pmh_dualchain dc, const double *u) { return dc && dc->normGu && dc->norm_ptr == u; }
-int  pmh_dc_last_launches(pmh_dualchain dc) { return dc ? dc->launches : 0; }
+// T G0 u and its squared norm are (as far as the stream has got) in place for this u; where the iterate's segment sums are there but no application has followed, one
+// small launch forms them
+bool pmh_dc_norm_ready(pmh_dualchain dc, const double *u)
+{
+  if (!dc || !dc->normGu) return false;
+  if (dc->norm_ptr == u) return true;
+  if (dc->x_emitted == u && !dc->norm_done) {
+    if (dc->nwg <= 128)
+      hipLaunchKernelGGL(k_dc_norm<2>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt, dc->normGu, dc->ctx->d_scal + dc->norm_slot,
+                         dc->ctx->h_scal + dc->norm_slot);
+    else
+      hipLaunchKernelGGL(k_dc_norm<8>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt, dc->normGu, dc->ctx->d_scal + dc->norm_slot,
+                         dc->ctx->h_scal + dc->norm_slot);
+    if (hipGetLastError() != hipSuccess) return false;
+    dc->norm_done = true, dc->norm_ptr = u;
+    return true;
+  }
+  return false;
+}
+int pmh_dc_last_launches(pmh_dualchain dc) { return dc ? dc->launches : 0; }
 
 // ---- one application ---------------------------------------------------------------------------------------------------------------
 int pmh_dc_apply(pmh_dualchain dc, const double *x, double *y, double rho, const pmh_vec_epi *epi)
 {
-  pmh_ctx      ctx = dc->ctx;
-  hipStream_t  st  = ctx->stream;
-  const int    n = dc->n, m = dc->m;
-  const dim3   vgrid((unsigned)dc->nwg), blk(PMH_BLOCK), eblk(PMH_EMIT_TILE);
-  pmh_fin_desc nofin;
-  memset(&nofin, 0, sizeof(nofin));
-  const int kind = epi ? epi->kind : 0;
-  dc->launches   = 0;
-  // 1. c = S G0 x: emitted by the kernel that wrote x, or formed here
+  pmh_ctx     ctx = dc->ctx;
+  hipStream_t st  = ctx->stream;
+  const int   n = dc->n, m = dc->m;
+  const dim3  vgrid((unsigned)dc->nwg), blk(PMH_BLOCK), eblk(PMH_EMIT_TILE);
+  const int   kind = epi ? epi->kind : 0;
+  dc->launches     = 0;
+  const pmh_emit_tab tab = dc_tab(dc);
+  // 1. the segment sums of G0 x: left behind by the kernel that wrote x, or formed here
   int slot = (epi && epi->in_slot > 0) ? epi->in_slot - 1 : -1;
   if (slot < 0) {
     slot = (kind == PMH_VEPI_GRAD_SPLIT) ? 0 : (kind == PMH_VEPI_P1 ? 1 : 2);
     pmh_emit_args ea;
-    dc_tab(dc, &ea);
-    ea.ticket = dc->ticket + 1;
-    dc_target(dc, slot, &ea.o[0]);
-    if (slot == 0) dc->norm_ptr = dc->normGu ? x : nullptr;
-    hipLaunchKernelGGL(k_dc_emit, vgrid, eblk, 0, st, n, x, ea, nofin);
+    memset(&ea, 0, sizeof(ea));
+    ea.tab = tab, ea.o[0].part = dc->part[slot];
+    if (slot == 0) dc->x_emitted = x, dc->norm_done = false, dc->norm_ptr = nullptr;
+    hipLaunchKernelGGL(k_dc_emit, vgrid, eblk, 0, st, n, x, ea);
     dc->launches++;
   }
-  const double *cin = dc->c_of(slot);
   // 2. gather with the projection folded in
   // (the stages are asked for at every application: explicit local dual operators may be attached to K^+ after the first product)
   PMH_CHK(dc->F->stages(&dc->gather, &dc->mid_in, &dc->scatter, &dc->mid_out));
   const pmh_csr Bg = dc->gather, Bs = dc->scatter;
   if (Bg->ncols != n || Bs->nrows != n) return pmh_set_error(PMH_ERR_STATE, "pmh_dc_apply: the operator's stages changed their dual dimension");
   PMH_CHK(dc_prepare_stages(dc));
-  if (dc->nlist > 0) {
-    const dim3 ggrid((unsigned)((dc->nlist + PMH_BLOCK - 1) / PMH_BLOCK));
-#define DC_GATHER(WW)                                                                                                                                                                       \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dc_gather<WW>), ggrid, blk, 0, st, dc->nlist, (const int *)dc->d_reci, (const double *)dc->d_recd, (const int *)Bg->d_col, (const double *)Bg->d_val, \
-                     (const double *)dc->d_ev, (const unsigned char *)dc->d_ec, m, cin, x, dc->mid_in)
-    if (dc->W == 8) DC_GATHER(8);
-    else DC_GATHER(16);
+  {
+    dc_norm_args na;
+    memset(&na, 0, sizeof(na));
+    if (dc->normGu && dc->x_emitted && !dc->norm_done) { // SMALXE's ||B u|| for the iterate whose segment sums are waiting
+      na.part = dc->part[0], na.Tt = dc->pf->d_Tt, na.y2 = dc->normGu, na.norm_d = ctx->d_scal + dc->norm_slot, na.norm_h = ctx->h_scal + dc->norm_slot;
+      dc->norm_done = true, dc->norm_ptr = dc->x_emitted;
+    }
+    const dim3 ggrid((unsigned)(std::max(1, (dc->nlist + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE) + (na.part ? 1 : 0))); // + the workgroup that forms ||B u||
+#define DC_GATHER(WW, NU)                                                                                                                                                                       \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dc_gather<WW, NU>), ggrid, eblk, 0, st, dc->nlist, (const int *)dc->d_reci, (const double *)dc->d_recd, (const int *)Bg->d_col, (const double *)Bg->d_val, \
+                     (const double *)dc->d_ev, (const unsigned char *)dc->d_ec, tab, (const double *)dc->part[slot], (const double *)dc->pf->d_S, dc->c_cur, na, x, dc->mid_in)
+    if (dc->W == 8 && dc->nwg <= 128) DC_GATHER(8, 2);
+    else if (dc->W == 8) DC_GATHER(8, 8);
+    else if (dc->nwg <= 128) DC_GATHER(16, 2);
+    else DC_GATHER(16, 8);
 #undef DC_GATHER
     dc->launches++;
   }
   PMH_HIP(hipGetLastError());
   // 3. the middle stage
   PMH_CHK(dc->F->mid_apply());
-  // 4. scatter + G0 w
+  // 4. scatter + the segment sums of G0 w
   {
     pmh_emit_args ea;
-    dc_tab(dc, &ea);
-    ea.ticket = dc->ticket + 2;
-    memset(&ea.o[0], 0, sizeof(ea.o[0]));
-    ea.o[0].part = dc->part[3], ea.o[0].coarse = dc->w + n;
-    hipLaunchKernelGGL(k_dc_scatter, vgrid, eblk, 0, st, n, (const unsigned char *)dc->d_scnt, (const int *)dc->d_sc2, (const double *)dc->d_sv2, (const int *)Bs->d_rowptr, (const int *)Bs->d_col, (const double *)Bs->d_val, dc->mid_out, dc->w, ea, nofin);
+    memset(&ea, 0, sizeof(ea));
+    ea.tab = tab, ea.o[0].part = dc->w + n;
+    hipLaunchKernelGGL(k_dc_scatter, vgrid, eblk, 0, st, n, (const unsigned char *)dc->d_scnt, (const int *)dc->d_sc2, (const double *)dc->d_sv2, (const int *)Bs->d_rowptr, (const int *)Bs->d_col,
+                       (const double *)Bs->d_val, dc->mid_out, dc->w, ea);
     dc->launches++;
   }
   PMH_HIP(hipGetLastError());
-  PMH_CHK(pmh_comm_allreduce_sum(ctx, dc->w, (size_t)n + (size_t)m)); // the ranks' shares of B u and of G0 (B u) in one exchange (PetscSFReduce, gluing.c:144-147)
+  PMH_CHK(pmh_comm_allreduce_sum(ctx, dc->w, (size_t)n + (size_t)dc->nseg)); // the ranks' shares of B u and of the sums of G0 (B u) in one exchange (PetscSFReduce, gluing.c:144-147)
   // 5. the second projection, the penalty term and the vector phase
   {
     pmh_emit_args ea;
-    dc_tab(dc, &ea);
-    ea.ticket = dc->ticket + 3;
-    pmh_fin_desc fin = nofin;
-    pmh_vec_epi  e;
+    memset(&ea, 0, sizeof(ea));
+    ea.tab = tab;
+    pmh_vec_epi e;
     memset(&e, 0, sizeof(e));
     if (epi) e = *epi;
-    if (epi && epi->finalized) {
-      fin.partials = epi->partials + (size_t)epi->prow * epi->ld, fin.ld = epi->ld, fin.nblocks = dc->nwg, fin.d_scal = ctx->d_scal, fin.h_scal = ctx->h_scal;
-      fin.K = (kind == PMH_VEPI_P1) ? 3 : 4;
-      for (int k = 0; k < fin.K; k++) fin.op[k] = PMH_RED_SUM, fin.slot[k] = epi->scal_base + k;
-      if (kind == PMH_VEPI_P1) fin.op[2] = PMH_RED_MIN;
-      *epi->finalized = 1;
-    }
+    e.h_partials = nullptr;
+    if (epi && epi->hosted) e.h_partials = ctx->h_partials, *epi->hosted = dc->nwg;
     if (kind == PMH_VEPI_GRAD_SPLIT && epi->emitted_p) {
-      dc_target(dc, 1, &ea.o[1]);
+      ea.o[1].part    = dc->part[1];
       *epi->emitted_p = 1;
     }
-#define DC_FINAL(EPI, WW)                                                                                                                                                       \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dc_final<EPI, WW>), vgrid, eblk, 0, st, n, (const double *)dc->d_ev, (const unsigned char *)dc->d_ec, m, (const double *)dc->pf->d_S, cin, \
-                     (const double *)dc->w, rho, y, e, x, ea, fin)
-#define DC_FINAL_W(EPI)                                                                                                                                                         \
-  do {                                                                                                                                                                          \
-    if (dc->W == 8) DC_FINAL(EPI, 8);                                                                                                                                           \
-    else DC_FINAL(EPI, 16);                                                                                                                                                     \
+#define DC_FINAL(EPI, WW, NU)                                                                                                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dc_final<EPI, WW, NU>), vgrid, eblk, 0, st, n, (const double *)dc->d_ev, (const unsigned char *)dc->d_ec, tab, (const double *)dc->pf->d_S, \
+                     (const double *)dc->c_cur, (const double *)dc->w, rho, y, e, x, ea)
+#define DC_FINAL_W(EPI)                                                                                                                                                              \
+  do {                                                                                                                                                                               \
+    if (dc->W == 8 && dc->nwg <= 128) DC_FINAL(EPI, 8, 2);                                                                                                                           \
+    else if (dc->W == 8) DC_FINAL(EPI, 8, 8);                                                                                                                                        \
+    else if (dc->nwg <= 128) DC_FINAL(EPI, 16, 2);                                                                                                                                   \
+    else DC_FINAL(EPI, 16, 8);                                                                                                                                                       \
   } while (0)
     if (kind == PMH_VEPI_P1) DC_FINAL_W(PMH_VEPI_P1);
     else if (kind == PMH_VEPI_GRAD_SPLIT) DC_FINAL_W(PMH_VEPI_GRAD_SPLIT);

@@ -62,6 +62,7 @@ struct pmh_mpgp_s {
   double cvg_margin;       // set by the convergence test: rnorm / (the threshold it has to fall below), 0 = unknown -- how close the NEXT test is to ending the solve
   int   g_valid;           // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
   int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
+  int   hsum4 = 0, hsum3 = 0;   // > 0: rows 0..3 (gradient split) / 4..6 (P1) of the pinned block partials wait for the host's sum over that many blocks (host_sums)
   bool  cx[2] = {false, false}; // fused dual-space chain (pmh_op_s::emit_begin): the operator holds G0 x (0) / G0 p (1) of the CURRENT x / p, emitted by the kernel that wrote them
   int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
   void            *cvg_user;
@@ -86,14 +87,14 @@ struct pmh_mpgp_s {
 // device helpers: the box predicates of qpcbox.c restated per element
 // --------------------------------------------------------------------------------------------------------------------
 // (the box predicates pmh_box_split / pmh_box_reduced: box_inline.h)
-template <int K, bool AGENT = false>
-__device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld)
+template <int K, bool EMIT = false>
+__device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld, double *__restrict__ h_partials = nullptr)
 {
-  if (AGENT) { // read by the ticket workgroup of the same kernel (emit_inline.h)
+  if (EMIT) { // 1024-thread workgroups; the rows also go to the pinned host copy: the host adds the block sums after its next wait (host_sums), no finalising launch
     int op[K];
 #pragma unroll
     for (int k = 0; k < K; k++) op[k] = PMH_RED_SUM;
-    pmh_block_partials_agent<K>(v, op, partials, ld);
+    pmh_block_partials<K>(v, op, partials, h_partials, ld);
     return;
   }
 #pragma unroll
@@ -106,10 +107,12 @@ __device__ __forceinline__ void write_partials(double (&v)[K], double *lds, doub
 // gradient split + norms (+ p = gf): after the initial gradient and after an expansion step
 // (MPGPGrads mpgp.c:198-223 + VecCopy(gf,p) :507/:615 + the three reductions of :514-521)
 template <bool EMIT>
-__global__ VEC_BOUNDS void k_split_setp(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ p, double *__restrict__ partials, int ld, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ VEC_BOUNDS void k_split_setp(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ p, double *__restrict__ partials, int ld, pmh_emit_args ea, double *__restrict__ h_partials)
 {
   __shared__ double lds[PMH_BLOCK / 64];
   double            acc[4] = {0.0, 0.0, 0.0, 0.0}, pv = 0.0, zv = 0.0;
+  pmh_emit_regs     R;
+  if (EMIT) pmh_emit_prefetch(ea, R);
   VEC_ENTRIES(i, n)
   {
     double f, c;
@@ -122,8 +125,8 @@ __global__ VEC_BOUNDS void k_split_setp(long long n, const double *__restrict__ 
     acc[2] += c * c;
     acc[3] += f * f;
   }
-  write_partials<4, EMIT>(acc, lds, partials, ld);
-  if (EMIT) pmh_emit_tail(ea, fin, zv, pv); // G0 p for the p = gf just written, the four sums reduced by the last workgroup
+  write_partials<4, EMIT>(acc, lds, partials, ld, h_partials);
+  if (EMIT) pmh_emit_tail(ea, R, zv, pv); // the segment sums of G0 p for the p = gf just written
 }
 
 // device control words of the speculative CG chain
@@ -144,10 +147,18 @@ struct pmh_spec_args { // constants of one solve, passed by value
 // acg <= afeas (mpgp.c:547).  If this is a plain CG step it is taken without any host round trip; otherwise
 // the chain halts with the state untouched and the host driver takes this iteration.
 template <bool SETP, bool SPEC, bool EMIT = false>
-__global__ VEC_BOUNDS void k_step_update(long long n, const double *__restrict__ scal, pmh_spec_args sa, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ VEC_BOUNDS void k_step_update(long long n, const double *__restrict__ scal, pmh_spec_args sa, double *__restrict__ x, double *__restrict__ g, double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ gf, double *__restrict__ partials, int ld, pmh_emit_args ea, double *__restrict__ h_partials, double acg_host, int nb_p1)
 {
   __shared__ double lds[PMH_BLOCK / 64];
-  double            acg = scal[S_GP] / scal[S_PAP];
+  double            acg;
+  pmh_emit_regs     R;
+  if (EMIT) pmh_emit_prefetch(ea, R);
+  if (EMIT) { // no finalising launch ran: acg from the host (it has read p'Ap, g'p) or -- proportioning, taken without a host wait -- from the P1 block partials (rows 4, 5)
+    acg = acg_host;
+    if (nb_p1 > 0) acg = pmh_sum_block_partials(partials + (size_t)5 * ld, nb_p1) / pmh_sum_block_partials(partials + (size_t)4 * ld, nb_p1);
+  } else {
+    acg = scal[S_GP] / scal[S_PAP];
+  }
   if (SPEC) {
     if (sa.ctl[CTL_HALT]) return;
     const int    it  = sa.ctl[CTL_ITER];
@@ -186,43 +197,50 @@ __global__ VEC_BOUNDS void k_step_update(long long n, const double *__restrict__
     acc[2] += c * c;
     acc[3] += f * f;
   }
-  write_partials<4, EMIT>(acc, lds, partials, ld);
-  if (EMIT) pmh_emit_tail(ea, fin, xv, pv); // G0 x (and G0 p where p = gf was set), the four sums reduced by the last workgroup
+  write_partials<4, EMIT>(acc, lds, partials, ld, h_partials);
+  if (EMIT) pmh_emit_tail(ea, R, xv, pv); // the segment sums of G0 x (and of G0 p where p = gf was set)
 }
 
 // P3: p = gf - bcg p, bcg = (Ap'gf)/(p'Ap) (mpgp.c:558-560: VecAYPX(p,-bcg,gf))
 template <bool EMIT>
-__global__ VEC_BOUNDS void k_dir_update(long long n, const double *__restrict__ scal, const int *__restrict__ halt, const double *__restrict__ gf, double *__restrict__ p, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ VEC_BOUNDS void k_dir_update(long long n, const double *__restrict__ scal, const int *__restrict__ halt, const double *__restrict__ gf, double *__restrict__ p, pmh_emit_args ea, const double *__restrict__ partials, int nb, double pAp_host)
 {
   if (halt && *halt) return;
-  double       bcg = scal[S_APGF] / scal[S_PAP];
+  pmh_emit_regs R;
+  if (EMIT) pmh_emit_prefetch(ea, R);
+  // EMIT: Ap'gf from the block partials k_step_update just left (row 0: no finalising launch ran), p'Ap from the host
+  double       bcg = EMIT ? pmh_sum_block_partials(partials, nb) / pAp_host : scal[S_APGF] / scal[S_PAP];
   const double mb  = -bcg;
   double       pv = 0.0, zv = 0.0;
   VEC_ENTRIES(i, n) p[i] = pv = gf[i] + mb * p[i];
-  if (EMIT) pmh_emit_tail(ea, fin, zv, pv);
+  if (EMIT) pmh_emit_tail(ea, R, zv, pv);
 }
 
 // proportioning direction p = gc (mpgp.c:623), gc recomputed from x, g
 template <bool EMIT>
-__global__ VEC_BOUNDS void k_prop_dir(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ p, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ VEC_BOUNDS void k_prop_dir(long long n, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ lb, const double *__restrict__ ub, double astol, double *__restrict__ p, pmh_emit_args ea)
 {
-  double pv = 0.0, zv = 0.0;
+  double        pv = 0.0, zv = 0.0;
+  pmh_emit_regs R;
+  if (EMIT) pmh_emit_prefetch(ea, R);
   VEC_ENTRIES(i, n)
   {
     double f, c;
     pmh_box_split(x[i], g[i], lb, ub, i, astol, f, c);
     p[i] = pv = c;
   }
-  if (EMIT) pmh_emit_tail(ea, fin, zv, pv);
+  if (EMIT) pmh_emit_tail(ea, R, zv, pv);
 }
 
 // expansion (std direction, fixed length; MPGPExpansion_Std mpgp.c:299-323):
 // x -= afeas p; g -= afeas Ap; split; gr; x -= alpha gr.  g is not stored: it is recomputed as A x - b next.
 template <bool EMIT>
-__global__ VEC_BOUNDS void k_expansion_std(long long n, double afeas, double alpha, double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, pmh_emit_args ea, pmh_fin_desc fin)
+__global__ VEC_BOUNDS void k_expansion_std(long long n, double afeas, double alpha, double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ lb, const double *__restrict__ ub, double astol, pmh_emit_args ea)
 {
   const double maf = -afeas, mal = -alpha;
   double       xv = 0.0, zv = 0.0;
+  pmh_emit_regs R;
+  if (EMIT) pmh_emit_prefetch(ea, R);
   VEC_ENTRIES(i, n)
   {
     double xi = x[i] + maf * p[i];
@@ -232,7 +250,7 @@ __global__ VEC_BOUNDS void k_expansion_std(long long n, double afeas, double alp
     double r = pmh_box_reduced(xi, f, lb, ub, i, alpha);
     x[i] = xv = xi + mal * r;
   }
-  if (EMIT) pmh_emit_tail(ea, fin, xv, zv);
+  if (EMIT) pmh_emit_tail(ea, R, xv, zv);
 }
 
 // p'Ap, g'p, QPCFeas for operators without a fused SpMV epilogue (shell operators: F, P F P, A + rho Q ...)
@@ -531,35 +549,70 @@ static int test_convergence(pmh_mpgp s)
 
 // ---- fused dual-space chain: emission by the vector kernels (pmh_op_s::emit_begin, emit_inline.h) ----------------------------
 static pmh_emit_args g_noea;
-static pmh_fin_desc  g_nofin;
 // the kernel about to be launched writes x (wx) and / or p (wp), one entry per thread: true = *ea is filled and the EMIT variant must be launched
 static bool emit_try(pmh_mpgp s, bool wx, bool wp, pmh_emit_args *ea)
 {
   if (wx) s->cx[0] = false;
   if (wp) s->cx[1] = false;
   if (s->csr || s->epi_ok != 1 || s->o.distributed) {
-    s->A->emit_invalidate();
+    if (wx) s->A->emit_invalidate();
     return false;
   }
   if (s->A->emit_begin(wx ? s->x : nullptr, wp ? s->work[4] : nullptr, ea) != PMH_SUCCESS) {
-    s->A->emit_invalidate();
+    if (wx) s->A->emit_invalidate();
     return false;
   }
   if (wx) s->cx[0] = true;
   if (wp) s->cx[1] = true;
   return true;
 }
-// the four sums of a gradient split (rows 0..3 of the block partials -> S_APGF .. S_GF2) reduced inside the emitting kernel
-static pmh_fin_desc fin_vec4(pmh_mpgp s)
+static int emit_blocks(pmh_mpgp s) { return (s->n + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE; } // grid of the EMIT variants
+
+// The last step of a reduction whose block partials a kernel left in the pinned host copy, taken by the host after its wait: lane l of a wave of 64 adds its entries
+// l, l + 64, ... in that order, then the butterflies of pmh_wave_all (emit_inline.h) -- the order in which a device consumer adds the same row (pmh_sum_block_partials),
+// so both see the same number.
+static double host_sum_row(const double *row, int nb, int op)
 {
-  pmh_fin_desc f;
-  memset(&f, 0, sizeof(f));
-  f.partials = s->ctx->d_partials, f.ld = s->ctx->partials_cap, f.nblocks = (s->n + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE, f.K = 4; // (the EMIT variants' grid)
-  for (int k = 0; k < 4; k++) f.op[k] = PMH_RED_SUM, f.slot[k] = S_APGF + k;
-  f.d_scal = s->ctx->d_scal, f.h_scal = s->ctx->h_scal;
-  return f;
+  double v[64];
+  for (int l = 0; l < 64; l++) {
+    double acc = (op == PMH_RED_SUM) ? 0.0 : INFINITY;
+    for (int u = 0; u < 8; u++) {
+      const double p = (l + 64 * u < nb) ? row[l + 64 * u] : ((op == PMH_RED_SUM) ? 0.0 : INFINITY);
+      acc            = (op == PMH_RED_SUM) ? acc + p : fmin(acc, p);
+    }
+    v[l] = acc;
+  }
+  auto comb = [&](double a, double b) { return (op == PMH_RED_SUM) ? a + b : fmin(a, b); };
+  double t[64];
+  for (int l = 0; l < 64; l++) t[l] = comb(v[l], v[l ^ 1]);
+  for (int l = 0; l < 64; l++) v[l] = comb(t[l], t[l ^ 2]);
+  for (int l = 0; l < 64; l++) t[l] = comb(v[l], v[(l & ~7) | (7 - (l & 7))]);
+  for (int l = 0; l < 64; l++) v[l] = comb(t[l], t[(l & ~15) | (15 - (l & 15))]);
+  return comb(comb(v[0], v[16]), comb(v[32], v[48]));
+}
+// after a wait on the stream: the sums the EMIT kernels / the operator's last kernel left to the host (the role of k_finalize) -> h_scal
+static void host_sums(pmh_mpgp s)
+{
+  pmh_ctx   ctx = s->ctx;
+  const int ld  = ctx->partials_cap;
+  if (s->hsum4) {
+    for (int k = 0; k < 4; k++) ctx->h_scal[S_APGF + k] = host_sum_row(ctx->h_partials + (size_t)k * ld, s->hsum4, PMH_RED_SUM);
+    s->hsum4 = 0;
+  }
+  if (s->hsum3) {
+    ctx->h_scal[S_PAP]  = host_sum_row(ctx->h_partials + (size_t)4 * ld, s->hsum3, PMH_RED_SUM);
+    ctx->h_scal[S_GP]   = host_sum_row(ctx->h_partials + (size_t)5 * ld, s->hsum3, PMH_RED_SUM);
+    ctx->h_scal[S_FEAS] = host_sum_row(ctx->h_partials + (size_t)6 * ld, s->hsum3, PMH_RED_MIN);
+    s->hsum3            = 0;
+  }
 }
 
+static int finalize_vec4_from(pmh_mpgp s, int nblocks) // rows 0..3 written by an EMIT variant (its own grid) after all: finalise on the device
+{
+  const int ops[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
+  s->hsum4         = 0;
+  return pmh_finalize_partials(s->ctx, s->ctx->d_partials, s->ctx->partials_cap, nblocks, 4, ops, S_APGF);
+}
 static int finalize_vec4(pmh_mpgp s, const int *halt = nullptr, int *post = nullptr)
 {
   const int ops[4] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM};
@@ -814,15 +867,16 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = fals
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_P1, e.g = g, e.xx = s->x, e.lb = s->lb, e.ub = s->ub, e.partials = s->ctx->d_partials, e.ld = s->ctx->partials_cap, e.prow = 4;
     e.p_fresh = p_fresh, e.spec_alpha = s->alpha, e.astol = s->o.astol; // (operators that pair their passes: svm.hip)
-    int fin_done = 0;
-    e.in_slot = s->cx[1] ? 2 : 0, e.scal_base = S_PAP, e.finalized = s->ctx->dist_scalars ? nullptr : &fin_done; // (the fused dual-space chain: G0 p emitted by the kernel that wrote p; the three sums reduced in its last kernel)
+    int hosted = 0;
+    e.in_slot = s->cx[1] ? 2 : 0, e.hosted = s->ctx->dist_scalars ? nullptr : &hosted; // (the fused dual-space chain: G0 p left behind by the kernel that wrote p; the three sums' block partials go to the pinned host copy)
     const int rc = s->A->mult_epi(p, Ap, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
       s->epi_ok = 1;
-      if (fin_done) {
-        if (s->fin4_pending) PMH_CHK(finalize_vec4(s)); // (an operator that reduces its own sums does so for the gradient split too: not reached)
+      if (hosted) {
+        if (s->fin4_pending) PMH_CHK(finalize_vec4(s)); // (an operator that leaves its sums to the host does so for the gradient split too: not reached)
         s->fin4_pending = 0;
+        s->hsum3        = hosted;
         return PMH_SUCCESS;
       }
       if (s->fin4_pending) { // (Ap'gf, |gP|^2, |gc|^2, |gf|^2) of the gradient split and (p'Ap, g'p, afeas) in ONE finalising launch: every quantity reduced as on its own
@@ -870,14 +924,17 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = 
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_GRAD_SPLIT, e.b = s->b, e.lb = s->lb, e.ub = s->ub, e.astol = s->o.astol, e.gf = gf, e.p = p, e.partials = ctx->d_partials, e.ld = ctx->partials_cap, e.prow = 0;
     e.x_from_spec = x_from_spec, e.x_out = s->x;
-    int fin_done = 0, p_emitted = 0;
-    e.in_slot = s->cx[0] ? 1 : 0, e.scal_base = S_APGF, e.finalized = ctx->dist_scalars ? nullptr : &fin_done, e.emitted_p = &p_emitted;
+    int hosted = 0, p_emitted = 0;
+    e.in_slot = s->cx[0] ? 1 : 0, e.hosted = ctx->dist_scalars ? nullptr : &hosted, e.emitted_p = &p_emitted;
     const int rc = s->A->mult_epi(s->x, g, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
       s->epi_ok = 1;
       s->cx[1]  = p_emitted != 0; // p = gf was written by the operator's last kernel
-      if (fin_done) return PMH_SUCCESS;
+      if (hosted) {
+        s->hsum4 = hosted;
+        return PMH_SUCCESS;
+      }
       if (defer_finalize && !ctx->dist_scalars) {
         s->fin4_pending = 1;
         return PMH_SUCCESS;
@@ -889,7 +946,7 @@ static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = 
   if (x_from_spec) return pmh_set_error(PMH_ERR_STATE, "pmh_mpgp: the operator prepared an expansion step and then refused the gradient");
   PMH_CHK(f_gradient(s));
   s->cx[1] = false;
-  LAUNCH(k_split_setp<false>, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+  LAUNCH(k_split_setp<false>, (const double *)s->x, (const double *)g, s->lb, s->ub, s->o.astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, (double *)nullptr);
   return finalize_vec4(s);
 }
 
@@ -909,6 +966,7 @@ static int solve_fused(pmh_mpgp s)
   bool         p_fresh = false; // p is the gf of the last gradient split, untouched (told to operators that pair their passes)
 
   s->cx[0] = s->cx[1] = false; // x and p come from outside
+  s->hsum4 = s->hsum3 = 0;
   s->A->emit_invalidate();
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
@@ -918,9 +976,10 @@ static int solve_fused(pmh_mpgp s)
     s->g_valid = 0;
     pmh_emit_args ea;
     if (emit_try(s, false, true, &ea)) {
-      LAUNCH_EMIT(k_split_setp<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+      LAUNCH_EMIT(k_split_setp<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, ea, ctx->h_partials);
+      s->hsum4 = emit_blocks(s);
     } else {
-      LAUNCH(k_split_setp<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+      LAUNCH(k_split_setp<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, gf, p, ctx->d_partials, ctx->partials_cap, g_noea, (double *)nullptr);
       PMH_CHK(finalize_vec4(s));
     }
   } else {
@@ -971,9 +1030,9 @@ static int solve_fused(pmh_mpgp s)
       s->h_ctl[CTL_HALT] = 0, s->h_ctl[CTL_ITER] = s->iteration, s->h_ctl[CTL_NCG] = 0, s->h_ctl[CTL_BASE] = s->iteration;
       PMH_HIP(hipMemcpyAsync(s->d_ctl, s->h_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyHostToDevice, ctx->stream));
       for (int j = 0; j < nbatch; j++) {
-        LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+        LAUNCH(k_cg_spec, (const double *)ctx->d_scal, sa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, (double *)nullptr, 0.0, 0);
         PMH_CHK(finalize_vec4(s, s->d_ctl + CTL_HALT, s->d_ctl + CTL_ITER));
-        LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p, g_noea, g_nofin);
+        LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)(s->d_ctl + CTL_HALT), (const double *)gf, p, g_noea, (const double *)nullptr, 0, 0.0);
         PMH_CHK(f_apply_p1(s, s->d_ctl + CTL_HALT));
       }
       PMH_HIP(hipMemcpyAsync(s->h_ctl, s->d_ctl, sizeof(int) * CTL_NWORDS, hipMemcpyDeviceToHost, ctx->stream));
@@ -998,6 +1057,7 @@ static int solve_fused(pmh_mpgp s)
     }
     if (s->pre_test) PMH_CHK(s->pre_test(s->pre_test_user));
     PMH_CHK(pmh_sync(ctx));
+    host_sums(s);
     s->rnorm           = sqrt(ctx->h_scal[S_GP2]);
     const double gcTgc = ctx->h_scal[S_GC2], gfTgf = ctx->h_scal[S_GF2];
     s->gfnorm = sqrt(gfTgf);
@@ -1009,6 +1069,7 @@ static int solve_fused(pmh_mpgp s)
       if (!spec) {
         PMH_CHK(f_apply_p1(s, nullptr, p_fresh));
         PMH_CHK(pmh_sync(ctx));
+        host_sums(s);
       }
       spec = false;
       nmv++;
@@ -1018,14 +1079,21 @@ static int solve_fused(pmh_mpgp s)
         s->step = 'c';
         spec_len = std::max(spec_len, 1); // a CG step taken by the host: the next ones may well be CG steps too
         pmh_emit_args ea;
-        if (emit_try(s, true, false, &ea)) { // x -= acg p with G0 x emitted, the four sums reduced by the kernel's last workgroup
-          LAUNCH_EMIT(k_cg_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+        bool emitted_step = false;
+        if (emit_try(s, true, false, &ea)) { // x -= acg p with the segment sums of G0 x left behind; acg as the host has it; the four sums' block partials go to the pinned host copy
+          LAUNCH_EMIT(k_cg_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, ctx->h_partials, acg, 0);
+          s->hsum4 = emit_blocks(s), emitted_step = true;
         } else {
-          LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+          LAUNCH(k_cg_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, (double *)nullptr, 0.0, 0);
           PMH_CHK(finalize_vec4(s));
         }
-        if (emit_try(s, false, true, &ea)) LAUNCH_EMIT(k_dir_update<true>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, ea, g_nofin);
-        else LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, g_noea, g_nofin);
+        if (emitted_step && emit_try(s, false, true, &ea)) {
+          LAUNCH_EMIT(k_dir_update<true>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, ea, (const double *)ctx->d_partials, emit_blocks(s), pAp);
+        } else {
+          if (emitted_step) PMH_CHK(finalize_vec4_from(s, emit_blocks(s))); // (not reached: an operator that took the step's emission takes the direction's)
+          s->cx[1] = false;
+          LAUNCH(k_dir_update<false>, (const double *)ctx->d_scal, (const int *)nullptr, (const double *)gf, p, g_noea, (const double *)nullptr, 0, 0.0);
+        }
         p_fresh = false;
       } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
         nexp++;
@@ -1033,8 +1101,8 @@ static int solve_fused(pmh_mpgp s)
         const bool prepared = s->epi_ok == 1 && s->A->spec_expansion_ready(); // the operator's P1 pass already formed k_expansion_std's iterate (svm.hip): it hands it over with the gradient
         if (!prepared) {
           pmh_emit_args ea;
-          if (emit_try(s, true, false, &ea)) LAUNCH_EMIT(k_expansion_std<true>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, ea, g_nofin);
-          else LAUNCH(k_expansion_std<false>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, g_noea, g_nofin);
+          if (emit_try(s, true, false, &ea)) LAUNCH_EMIT(k_expansion_std<true>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, ea);
+          else LAUNCH(k_expansion_std<false>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, g_noea);
         } else {
           s->cx[0] = false;
           s->A->emit_invalidate();
@@ -1049,14 +1117,21 @@ static int solve_fused(pmh_mpgp s)
       spec    = false; // a speculative P1 (if any) used the wrong direction; it is simply not counted
       p_fresh = false;
       pmh_emit_args ea;
-      if (emit_try(s, false, true, &ea)) LAUNCH_EMIT(k_prop_dir<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, ea, g_nofin);
-      else LAUNCH(k_prop_dir<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, g_noea, g_nofin);
+      if (emit_try(s, false, true, &ea)) LAUNCH_EMIT(k_prop_dir<true>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, ea);
+      else LAUNCH(k_prop_dir<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, g_noea);
       PMH_CHK(f_apply_p1(s));
       nmv++;
-      if (emit_try(s, true, true, &ea)) {
-        LAUNCH_EMIT(k_prop_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, fin_vec4(s));
+      if (s->hsum3 && emit_try(s, true, true, &ea)) { // the product left its sums to the host: the step forms acg from the P1 block partials itself (no host wait in between)
+        LAUNCH_EMIT(k_prop_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, ctx->h_partials, 0.0, s->hsum3);
+        s->hsum4 = emit_blocks(s);
       } else {
-        LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, g_nofin);
+        if (s->hsum3) { // (not reached: the operator that left the sums to the host takes the emission) the step reads acg from d_scal: finalise the P1 rows on the device
+          const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
+          PMH_CHK(pmh_finalize_partials(ctx, ctx->d_partials + (size_t)4 * ctx->partials_cap, ctx->partials_cap, s->hsum3, 3, ops, S_PAP));
+          s->hsum3 = 0;
+        }
+        s->cx[0] = s->cx[1] = false;
+        LAUNCH(k_prop_host, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, g_noea, (double *)nullptr, 0.0, 0);
         PMH_CHK(finalize_vec4(s));
       }
     }

@@ -55,6 +55,7 @@ struct pmh_ctx_s {
   int         partials_cap;
   double     *d_scal; // finalised reductions (device copy), consumed by follow-up kernels
   double     *h_scal; // pinned host mirror written by the finalise kernel
+  double     *h_partials; // pinned host copy of d_partials for kernels that leave the last reduction step to the host (emit_inline.h pmh_block_partials)
   // multi-GPU
   ncclComm_t comm;
   int        rank, size, force_comm;
@@ -147,10 +148,12 @@ struct pmh_vec_epi {
   double        spec_alpha;
   double       *x_out;
   // fused dual-space chain (dualchain.hip): in_slot = 1 + the emission target that holds G0 x for this input (pmh_op_s::emit_begin: 1 = iterate, 2 = direction; 0 = none: the
-  // operator forms it itself).  scal_base >= 0: the operator may reduce the block partials into d_scal / h_scal[scal_base + k] inside its last kernel (P1: 3 scalars,
-  // GRAD_SPLIT: 4) and then sets *finalized = 1; emit_p (GRAD_SPLIT): its last kernel also emits G0 p for the p = gf it writes and sets *emitted_p = 1
-  int           in_slot, scal_base;
-  int          *finalized, *emitted_p;
+  // operator forms it itself).  hosted != nullptr: the operator may ALSO store its block partials in the pinned host copy h_partials (same rows / ld) and then sets
+  // *hosted = the number of blocks it wrote: the caller adds them up on the host after its next wait, no finalising launch.  emitted_p (GRAD_SPLIT): the last kernel
+  // also emits G0 p for the p = gf it writes and sets *emitted_p = 1
+  int           in_slot;
+  double       *h_partials;
+  int          *hosted, *emitted_p;
 };
 // ---- coarse-space emission of the fused dual-space chain (dualchain.hip, emit_inline.h) ----------------------------------
 // G0 of the projector cut into (row, block of 256 columns) segments; the kernel that writes a dual vector sums its own segments (see emit_inline.h)
@@ -162,23 +165,11 @@ struct pmh_emit_tab {
   int           m, nwg;
 };
 struct pmh_emit_out { // one emitted vector v
-  double       *part;     // [nseg] segment sums (nullptr: target off)
-  double       *coarse;   // [m] a = G0 v (may be nullptr)
-  const double *S;        // m x m symmetric: c = S a -> coarse_c (nullptr: not wanted)
-  double       *coarse_c;
-  const double *Tt;       // T' row-major: y2 = T a and ||T a||^2 -> *norm_d, *norm_h (nullptr: not wanted)
-  double       *y2, *norm_d, *norm_h;
+  double *part; // [nseg] segment sums of G0 v (nullptr: target off)
 };
 struct pmh_emit_args {
   pmh_emit_tab tab;
   pmh_emit_out o[2]; // target 0: the iterate, target 1: the direction (mpgp.hip); dualchain.hip's own kernels use target 0
-  unsigned    *ticket;
-};
-struct pmh_fin_desc { // block partials -> scalar slots inside the kernel that produced them (K = 0: none)
-  const double *partials;
-  int           ld, nblocks, K;
-  int           op[PMH_MAX_RED], slot[PMH_MAX_RED];
-  double       *d_scal, *h_scal;
 };
 
 struct pmh_op_s {
