@@ -113,8 +113,15 @@ def host_threads():
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    # several ranks on one node share its cores: every rank takes cores // (ranks on the node) for its numpy / OpenMP work AND for the library's host-side builders
+    # (pmh_set_knob "host_threads" reads PMH_HOST_THREADS once): 8 ranks x 16 threads on a 16-CPU cgroup was the first-run risk of the N = 8 bench
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    cores = max(1, cores // local_world)
     _HOST_THREADS = cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ["PMH_HOST_THREADS"] = str(cores)
+    for k in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = str(cores)
     return cores
 
 
@@ -694,7 +701,9 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     use_c_builder = a.kplus_pc == "mg" and a.mg_builder == "c" and not a.regularize
 
     def mg_box(nblk):
-        auto_nodes = 2000 if nblk <= (4 if a.mg_precision == "fp16" else 1) else 400
+        # (explicit K^+: the rank's own inner-Krylov solver only serves a handful of set-up products -- d = B K^+ f, the replica's columns come from the replica solver --
+        # so it does not pay for the 5000-dof dense coarse pseudo-inverse that makes the cycle of a 1-4 block rank faster: 6 s of host set-up at the 1/8 share)
+        auto_nodes = 2000 if (nblk <= (4 if a.mg_precision == "fp16" else 1) and a.kplus != "explicit") else 400
         return dict(dims=[(nn, nn, nn)] * nblk, ndof=3, min_nodes=a.mg_min_nodes or min(auto_nodes, nn ** 3 // 8))
     explicit = None
     replica = {}
@@ -702,14 +711,17 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         def solver_factory(nslots):
             """A K^+ over `nslots` replicas of this rank's (congruent) block: the set-up solves of the explicit operators fill the GPU
             although the rank owns fewer blocks (1 at N = 8)."""
-            Kb = pa.MatBlockDiag.from_scipy(ctx, np.arange(nslots + 1, dtype=np.int32) * f.n_i, sp.block_diag([f.Ki] * nslots, format="csr"))
+            from permon_amd.feti import csr_block_diag
+
+            Krep = csr_block_diag([f.Ki] * nslots)
+            Kb = pa.MatBlockDiag.from_scipy(ctx, np.arange(nslots + 1, dtype=np.int32) * f.n_i, Krep)
             Rb = np.tile(local["R"][:, :f.n_i], (1, nslots))
             M = pa.MatInv(Kb, rtol=a.explicit_rtol, max_it=20000, jacobi=True, nullspace=Rb)
             if not a.no_bsr3:
                 M.enable_bsr3()
             if use_c_builder:
                 mb = mg_box(nslots)
-                M.set_pc_mg_box(sp.block_diag([f.Ki] * nslots, format="csr"), mb["dims"], 3, R=Rb, min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=a.mg_precision)
+                M.set_pc_mg_box(Krep, mb["dims"], 3, R=Rb, min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=a.mg_precision)
             elif a.kplus_pc == "mg":
                 M.set_pc_mg(make_hier([f.Ki] * nslots, nslots), degree=a.mg_degree, precision=a.mg_precision)
             replica["M"], replica["K"] = M, Kb
@@ -767,11 +779,17 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         lib = ctypes.CDLL("/opt/rocm/lib/librocprofiler-sdk-roctx.so")
         (lib.roctxProfilerResume if resume else lib.roctxProfilerPause)(ctypes.c_uint64(0))
 
+    collective = {}
+
     def timed_pass(nsteps, nwarm):
         """W untimed + exactly K timed inner MPGP iterations of the real SMALXE solver loop (restarting from lambda = 0 whenever the
         solve converges: configs[2] takes 108 iterations), bracketed by barriers; max over ranks."""
         if nwarm:
             qps.RunFixedSolve(nwarm)
+        if dist is not None and want_timing:
+            import ctypes as _C
+
+            pa._lib.check(ctx.L.pmh_comm_timing_enable(ctx.h, 4 * nsteps + 64))  # event pairs around the all-reduce that ends every B u
         barrier()
         roctx(True)
         t1 = time.perf_counter()
@@ -783,6 +801,16 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             import torch
 
             dt = dist_max(dist, dt)
+            if want_timing:
+                import ctypes as _C
+
+                nc, msc, byc = _C.c_int(), _C.c_double(), _C.c_double()
+                pa._lib.check(ctx.L.pmh_comm_timing_get(ctx.h, _C.byref(nc), _C.byref(msc), _C.byref(byc)))
+                pa._lib.check(ctx.L.pmh_comm_timing_enable(ctx.h, 0))
+                if nc.value:
+                    collective.update({"allreduces_timed": nc.value, "ms_per_allreduce": msc.value / nc.value, "bytes_per_allreduce": byc.value / nc.value,
+                                       "ms_per_allreduce_max_over_ranks": dist_max(dist, msc.value / nc.value), "share_of_step_time": msc.value * 1e-3 / dt,
+                                       "transport": "host (gloo, TEST MODE)" if HOST_TRANSPORT else "RCCL"})
         return dt, cnt
 
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
@@ -1027,6 +1055,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "steps_by_type": cnt, "precision_note": precision_note, "kplus": kplus_cfg,
         "checksum": {"norm_lambda_child_after_last_step": repr(float(q.lam.norm()))},  # bitwise comparable between runs (deterministic reductions)
         "generate_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1),
+        "setup_seconds_max_over_ranks": round(dist_max(dist, t_setup), 1) if dist is not None else None, "generate_seconds_max_over_ranks": round(dist_max(dist, t_gen), 1) if dist is not None else None,
+        "host_threads_per_rank": host_threads(), "collective": collective or None,
         "coarse_problem": (lambda s: {"m": q.pf.m, "GGt_mfma_ms": round(s[0], 3), "GGt_TFLOPs": round(s[1] / (s[0] * 1e-3) / 1e12, 2) if s[0] > 0 else None,
                                       "host_cholesky_inverse_ms": round(s[2], 2)})(q.pf.setup_stats()) if (q.pf is not None and not orth) else {"m": q.pf.m if q.pf is not None else 0, "orthonormal_G": "implicit: T G0 with T = chol(G0 G0')^{-1} applied in the finishing launch of G0 v, G0 kept sparse (%d non-zeros)" % G.nnz if implicit else True},
         "roofline": roofline, "feti_dual_spmv": dual, "kplus_cg_product": kx, "reuse_products": reuse,
@@ -1091,6 +1121,11 @@ def compact_line(out, details_path):
     c["config"] = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:300], "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism", ""))[:160], "rccl_ranks": cfg.get("rccl_ranks")}
     if cfg.get("transport"):
         c["config"]["transport"] = cfg["transport"]
+    if cfg.get("collective"):  # N > 1: the all-reduce that ends every B u, HIP-event timed on the launch stream (pmh_comm_timing_*)
+        c["config"]["collective"] = {k: _num(v) if isinstance(v, float) else v for k, v in cfg["collective"].items()}
+    for k in ("host_threads_per_rank", "setup_seconds_max_over_ranks", "generate_seconds_max_over_ranks"):
+        if cfg.get(k) is not None:
+            c["config"][k] = cfg[k]
     if cfg.get("checksum"):
         c["config"]["checksum"] = cfg["checksum"]
     if cfg.get("steps_by_type"):
@@ -1154,14 +1189,35 @@ def launch_ranks(a):
         port = sk.getsockname()[1]
     tmp = tempfile.mkdtemp(prefix="pmh_bench_")
     procs, outs = [], []
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    share = max(1, cores // n)  # the node's CPUs dealt over the ranks: numpy / OpenMP threads and the library's host-side builders (host_threads() in the child arrives at the same number)
+    deadline = time.time() + float(os.environ.get("PMH_BENCH_DEADLINE_S", "1500"))  # watchdog: a hung rank must not hang the launcher (children are ended by PID, exit code 124)
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS=str(share), PMH_HOST_THREADS=str(share), OPENBLAS_NUM_THREADS=str(share), MKL_NUM_THREADS=str(share))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
         fo = open(os.path.join(tmp, "rank%d.out" % r), "w+")
         outs.append(fo)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=fo, stderr=None))
     rc, alive = 0, set(range(n))
     while alive:
+        if time.time() > deadline and rc == 0:
+            rc = 124
+            sys.stderr.write("bench.py: the ranks did not finish within PMH_BENCH_DEADLINE_S; ending them\n")
+            for o in alive:
+                procs[o].terminate()
+            t_kill = time.time() + 10
+            while any(procs[o].poll() is None for o in alive) and time.time() < t_kill:
+                time.sleep(0.1)
+            for o in alive:
+                if procs[o].poll() is None:
+                    procs[o].kill()
         for r in sorted(alive):
             c = procs[r].poll()
             if c is None:
@@ -1199,7 +1255,10 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything initialises the GPU (or imports torch)
         return launch_ranks(a)
     if a.dry_launch:
-        print(json.dumps({"dry_launch": True, "pid": os.getpid(), "ppid": os.getppid(), **{k.lower(): os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}, "argv": sys.argv[1:]}))
+        if os.environ.get("PMH_BENCH_TEST_HANG"):  # (tests/test_bench_host.py: a rank that never finishes, for the launcher's watchdog)
+            time.sleep(3600)
+        print(json.dumps({"dry_launch": True, "pid": os.getpid(), "ppid": os.getppid(), **{k.lower(): os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}, "argv": sys.argv[1:],
+                          "host_threads": host_threads(), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "pmh_host_threads": os.environ.get("PMH_HOST_THREADS")}))
         return
     # stdout carries ONE line, the last thing this process prints: whatever a library writes to file descriptor 1 meanwhile (RCCL prints a version banner when a
     # communicator is created) goes to stderr
@@ -1207,6 +1266,17 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     host_threads()
+    if os.environ.get("PMH_BENCH_RANK_DEADLINE_S"):  # per-rank watchdog (a launcher that does not watch, e.g. torch.distributed.run): leave with a message instead of hanging in a collective
+        import threading
+
+        def _late():
+            sys.stderr.write("bench.py: rank %s gave up after PMH_BENCH_RANK_DEADLINE_S\n" % os.environ.get("RANK", "0"))
+            sys.stderr.flush()
+            os._exit(124)
+
+        _wd = threading.Timer(float(os.environ["PMH_BENCH_RANK_DEADLINE_S"]), _late)
+        _wd.daemon = True
+        _wd.start()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1287,7 +1357,9 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": r["workload"], "workload_short": r["workload_short"], "parallelism": r["parallelism"], "parallelism_short": r["parallelism_short"], "rccl_ranks": r["rccl_ranks"], "steps_by_type": r["steps_by_type"], "kplus": r["kplus"], "coarse_problem": r["coarse_problem"], "checksum": r["checksum"],
-                       "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"]},
+                       "precision_note": r["precision_note"], "generate_seconds": r["generate_seconds"], "setup_seconds": r["setup_seconds"],
+                       "setup_seconds_max_over_ranks": r["setup_seconds_max_over_ranks"], "generate_seconds_max_over_ranks": r["generate_seconds_max_over_ranks"], "host_threads_per_rank": r["host_threads_per_rank"],
+                       "collective": r["collective"]},
             "roofline": r["roofline"],
         }
         # what lets two windows of the same solver be compared (the driver's 20 + 5 steps are the START of a solve: many short outer iterations, ~3.1 F

@@ -51,7 +51,9 @@ int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; f
 /* Process-wide run-time switches (the role of PETSc's options database for the library's own A/B switches; the environment variable PMH_<NAME> gives the initial value).
  * "chain" (PMH_NO_CHAIN unset = 1): the penalised, projected FETI operator as the five-launch dual-space chain (dualchain.hip); 0 = the round-4 launch sequence.
  * Takes effect for operators created afterwards.  "chain_applies" / "chain_launches": counters of the chain's applications and of its own kernel launches (the middle
- * stage's -- GEMM + finishing launch, or the inner Krylov solve -- not included); set to reset.  Unknown name: PMH_ERR_ARG. */
+ * stage's -- GEMM + finishing launch, or the inner Krylov solve -- not included); set to reset.  "host_threads": threads of the host-side set-up builders (3x3-block
+ * copies, multigrid hierarchy, class detection); initial value PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the CPUs the process may run on) -- with several ranks
+ * per node every rank must get its share.  Unknown name: PMH_ERR_ARG. */
 int pmh_set_knob(const char *name, int value);
 int pmh_get_knob(const char *name, int *value);
 int pmh_finalize(pmh_ctx ctx);
@@ -79,6 +81,10 @@ int pmh_comm_rank(pmh_ctx ctx, int *rank, int *size);
 int pmh_comm_allreduce_sum(pmh_ctx ctx, double *dbuf, size_t count);    /* in place, device buffer */
 int pmh_comm_allreduce_min(pmh_ctx ctx, double *dbuf, size_t count);
 int pmh_comm_barrier(pmh_ctx ctx);
+/* HIP-event pairs (on the launch stream) around the next max_events vector all-reduces of the data path -- the sum of the ranks' B u that ends MatMultTranspose_Gluing
+ * (PetscSFReduce, gluing.c:144-147); 0 switches the timing off.  _get: how many were timed, their total milliseconds and bytes; resets the counters. */
+int pmh_comm_timing_enable(pmh_ctx ctx, int max_events);
+int pmh_comm_timing_get(pmh_ctx ctx, int *count, double *total_ms, double *bytes);
 /* Host-staged transport instead of RCCL: every collective of the data path (B u in pmh_gluing_mult_transpose, the SVM w, the grouped MPGP scalars, the barrier) copies its
  * device buffer to pinned host memory and calls fn -- an IN-PLACE all-reduce over the ranks (op: PMH_COMM_SUM / PMH_COMM_MIN; PMH_COMM_BARRIER with count 0), returning 0 on
  * success -- then copies the result back, in stream order.  What the PETSc glue passes when the ranks cannot form an RCCL communicator: MPI_Allreduce(MPI_IN_PLACE, buf, count,

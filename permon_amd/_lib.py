@@ -104,6 +104,8 @@ CONVERGED_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, C.c_double, c_int_p)
 _PROTOS = {
     "pmh_init": [C.c_int, C.POINTER(vp)],
     "pmh_finalize": [vp],
+    "pmh_comm_timing_enable": [vp, C.c_int],
+    "pmh_comm_timing_get": [vp, c_int_p, c_double_p, c_double_p],
     "pmh_set_knob": [C.c_char_p, C.c_int],
     "pmh_get_knob": [C.c_char_p, c_int_p],
     "pmh_device_name": [vp, C.c_char_p, C.c_size_t],

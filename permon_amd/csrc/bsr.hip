@@ -189,7 +189,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile, int nrep_
     bool            same = rp[n] == nnzb;
     for (int r = 1; r < nrep && same; r++) same = (long long)rp[(size_t)r * n] == (long long)r * nnzb;
     if (same) {
-      const int         ntc = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+      const int         ntc = std::max(1, pmh_host_threads());
       std::vector<char> bad(ntc, 0);
       auto              cmp = [&](int tt) {
         for (int r = 1; r < nrep && !bad[tt]; r++) {
@@ -219,7 +219,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile, int nrep_
   // block structure: union of the block columns of the three rows of each block row (sorted)
   // (host threads over contiguous ranges of block rows: the fine level of configs[2] has 158 M non-zeros and is converted three times per set-up)
   std::vector<int> browptr((size_t)nbr + 1, 0), bcol;
-  const int        nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), nbr / 4096 + 1}));
+  const int        nt = std::max(1, std::min({pmh_host_threads(), nbr / 4096 + 1}));
   {
     std::vector<std::vector<int>> tbc(nt);
     std::vector<char>             toobig(nt, 0);

@@ -1,4 +1,9 @@
 // Context, device memory, HIP-event timers and the RCCL communicator of libpermonhip.
+#include <sched.h>
+
+#include <algorithm>
+#include <thread>
+
 #include "pmh_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -20,6 +25,17 @@ pmh_knobs_s &pmh_knobs()
   static pmh_knobs_s k = [] {
     pmh_knobs_s v;
     v.chain = getenv("PMH_NO_CHAIN") ? 0 : 1;
+    int         nt = 0;
+    const char *e  = getenv("PMH_HOST_THREADS");
+    if (!e) e = getenv("OMP_NUM_THREADS");
+    if (e) nt = atoi(e);
+    if (nt <= 0) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      nt = (sched_getaffinity(0, sizeof(set), &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+      nt = std::min(16, nt);
+    }
+    v.host_threads = std::max(1, std::min(64, nt));
     return v;
   }();
   return k;
@@ -30,6 +46,7 @@ static int *knob_by_name(const char *name)
   if (!strcmp(name, "chain")) return &pmh_knobs().chain;
   if (!strcmp(name, "chain_applies")) return &pmh_knobs().chain_applies;
   if (!strcmp(name, "chain_launches")) return &pmh_knobs().chain_launches;
+  if (!strcmp(name, "host_threads")) return &pmh_knobs().host_threads;
   return nullptr;
 }
 extern "C" int pmh_set_knob(const char *name, int value)
@@ -87,6 +104,8 @@ extern "C" int pmh_finalize(pmh_ctx c)
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  for (int i = 0; i < c->comm_ev_cap; i++) hipEventDestroy(c->comm_ev[i]);
+  delete[] c->comm_ev;
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   hipFree(c->d_partials);
   hipFree(c->d_scal);
@@ -248,8 +267,10 @@ extern "C" int pmh_comm_set_host_transport(pmh_ctx c, int rank, int size, pmh_co
 {
   PMH_ARG(c && size >= 1 && rank >= 0 && rank < size);
   if (fn && c->comm) return pmh_set_error(PMH_ERR_STATE, "pmh_comm_set_host_transport: the context already has an RCCL communicator");
+  const bool had_hook = c->hook != nullptr;
   c->hook = fn, c->hook_user = user;
-  c->rank = fn ? rank : 0, c->size = fn ? size : 1;
+  if (fn) c->rank = rank, c->size = size;
+  else if (had_hook && !c->comm) c->rank = 0, c->size = 1; // removing the hook of a context that had nothing else: one rank again (an RCCL communicator keeps its rank / size)
   return PMH_SUCCESS;
 }
 
@@ -272,8 +293,46 @@ extern "C" int pmh_comm_allreduce_sum(pmh_ctx c, double *dbuf, size_t count)
 {
   PMH_ARG(c);
   if (!pmh_comm_on(c) || !count) return PMH_SUCCESS;
-  if (c->hook) return host_reduce(c, PMH_COMM_SUM, dbuf, count);
-  PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, c->comm, c->stream));
+  // optional timing of the data-path exchanges (vectors, not scalars): HIP event pairs on the launch stream (pmh_comm_timing_enable)
+  const bool timed = c->comm_ev_cap > 0 && count >= 1024 && 2 * (c->comm_ev_used + 1) <= c->comm_ev_cap;
+  if (timed) PMH_HIP(hipEventRecord(c->comm_ev[2 * c->comm_ev_used], c->stream));
+  if (c->hook) PMH_CHK(host_reduce(c, PMH_COMM_SUM, dbuf, count));
+  else PMH_NCCL(ncclAllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, c->comm, c->stream));
+  if (timed) {
+    PMH_HIP(hipEventRecord(c->comm_ev[2 * c->comm_ev_used + 1], c->stream));
+    c->comm_ev_used++;
+    c->comm_ev_bytes += 8.0 * (double)count;
+  }
+  return PMH_SUCCESS;
+}
+
+// event pairs around the next max_events vector all-reduces (0: off, frees the events); pmh_comm_timing_get: how many were timed, their total milliseconds and bytes
+extern "C" int pmh_comm_timing_enable(pmh_ctx c, int max_events)
+{
+  PMH_ARG(c && max_events >= 0);
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->comm_ev_cap; i++) hipEventDestroy(c->comm_ev[i]);
+  delete[] c->comm_ev;
+  c->comm_ev = nullptr, c->comm_ev_cap = 0, c->comm_ev_used = 0, c->comm_ev_bytes = 0.0;
+  if (max_events > 0) {
+    c->comm_ev = new hipEvent_t[2 * (size_t)max_events];
+    for (int i = 0; i < 2 * max_events; i++) PMH_HIP(hipEventCreate(&c->comm_ev[i]));
+    c->comm_ev_cap = 2 * max_events;
+  }
+  return PMH_SUCCESS;
+}
+extern "C" int pmh_comm_timing_get(pmh_ctx c, int *count, double *total_ms, double *bytes)
+{
+  PMH_ARG(c && count && total_ms);
+  PMH_HIP(hipStreamSynchronize(c->stream));
+  *count = c->comm_ev_used, *total_ms = 0.0;
+  for (int i = 0; i < c->comm_ev_used; i++) {
+    float ms = 0.f;
+    PMH_HIP(hipEventElapsedTime(&ms, c->comm_ev[2 * i], c->comm_ev[2 * i + 1]));
+    *total_ms += ms;
+  }
+  if (bytes) *bytes = c->comm_ev_bytes;
+  c->comm_ev_used = 0, c->comm_ev_bytes = 0.0;
   return PMH_SUCCESS;
 }
 

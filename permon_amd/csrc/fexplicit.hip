@@ -711,7 +711,7 @@ extern "C" int pmh_csr_block_classes(int nblocks, const int *rowstart, const int
       bool same = true;
       for (int i = 0; i <= n && same; i++) same = (rowptr[r0 + i] - k0) == (rowptr[q0 + i] - j0);
       if (same) { // columns and values: 12 bytes per entry of two blocks -- 0.13 s on one thread for the 8 cubes of configs[2], and the set-up asks twice
-        const int         nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), nnz / (1 << 20) + 1}));
+        const int         nt = std::max(1, std::min({pmh_host_threads(), nnz / (1 << 20) + 1}));
         std::vector<char> eq((size_t)nt, 1);
         auto              cmp = [&](int t) {
           const int a0 = (int)((long long)nnz * t / nt), a1 = (int)((long long)nnz * (t + 1) / nt);

@@ -50,7 +50,7 @@ HCsr spgemm(const HCsr &A, const HCsr &B)
   HCsr C;
   C.nr = A.nr, C.nc = B.nc;
   C.rp.assign((size_t)A.nr + 1, 0);
-  const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  const int nt = std::max(1, pmh_host_threads());
   std::vector<std::vector<int>>    tci(nt);
   std::vector<std::vector<double>> tva(nt);
   std::vector<int>                 lo(nt + 1);
@@ -216,7 +216,7 @@ double lambda_max_dinv_a(const HCsr &A, int its)
 
 void parallel_for(int n, const std::function<void(int, int)> &f)
 {
-  const int nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), n}));
+  const int nt = std::max(1, std::min({pmh_host_threads(), n}));
   if (nt == 1) return f(0, n);
   std::vector<std::thread> th;
   for (int t = 0; t < nt; t++) th.emplace_back(f, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));

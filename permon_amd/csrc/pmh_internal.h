@@ -23,8 +23,11 @@ struct pmh_knobs_s {
   int chain; // the five-launch dual-space chain (dualchain.hip)
   // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and the launches they took, the middle stage's included
   int chain_applies = 0, chain_launches = 0;
+  int host_threads = 1; // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the
+                        // CPUs this process may run on) -- several ranks per node must share the node's cores (bench.py hands every rank its share)
 };
 pmh_knobs_s &pmh_knobs();
+inline int   pmh_host_threads() { return pmh_knobs().host_threads > 1 ? pmh_knobs().host_threads : 1; }
 
 #define PMH_HIP(call) \
   do { \
@@ -66,6 +69,10 @@ struct pmh_ctx_s {
   void            *hook_user = nullptr;
   double          *h_stage   = nullptr; // pinned
   size_t           stage_cap = 0;
+  // optional timing of the vector all-reduces (pmh_comm_timing_enable)
+  hipEvent_t *comm_ev      = nullptr;
+  int         comm_ev_cap = 0, comm_ev_used = 0;
+  double      comm_ev_bytes = 0.0;
 };
 // the data-path collectives are live: a transport exists (RCCL communicator or host transport) and there is more than one rank (or PMH_COMM_FORCE=1)
 static inline bool pmh_comm_on(pmh_ctx c) { return (c->comm || c->hook) && (c->size > 1 || c->force_comm); }

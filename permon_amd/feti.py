@@ -257,7 +257,7 @@ class CubeFeti:
     def K(self):
         """blockdiag(K_i) of all subdomains (built on demand: 158 M non-zeros at configs[2] size)."""
         if self._K is None:
-            self._K = sp.block_diag([self.block_K(s) for s in range(self.nsub)], format="csr")
+            self._K = csr_block_diag([self.block_K(s) for s in range(self.nsub)])
             self._K.sort_indices()
         return self._K
 
@@ -309,9 +309,26 @@ class CubeFeti:
         sel = keep[self.leaves_row]
         return dict(
             nblocks=len(blocks), block_rowstart=np.arange(len(blocks) + 1, dtype=np.int32) * nloc,
-            K=sp.block_diag([self.block_K(s) for s in blocks], format="csr"), f=self.f[keep], R=self.R[:, keep],
+            K=csr_block_diag([self.block_K(s) for s in blocks]), f=self.f[keep], R=self.R[:, keep],
             leaves_row=newidx[self.leaves_row[sel]].astype(np.int32), leaves_root=self.leaves_root[sel], leaves_sign=self.leaves_sign[sel],
             n_x=len(blocks) * nloc, n_lambda=self.n_lambda)
+
+
+def csr_block_diag(blocks):
+    """blockdiag(blocks) of CSR matrices by concatenating their arrays (scipy.sparse.block_diag goes through COO: ~5 s for the 8 x 20 M non-zeros of configs[2], this is ~0.3 s).
+    Rows keep their order and sorted indices."""
+    blocks = [b.tocsr() for b in blocks]
+    nnz = np.cumsum([0] + [b.nnz for b in blocks])
+    rows = np.cumsum([0] + [b.shape[0] for b in blocks])
+    cols = np.cumsum([0] + [b.shape[1] for b in blocks])
+    wide = nnz[-1] > np.iinfo(np.int32).max or cols[-1] > np.iinfo(np.int32).max
+    it = np.int64 if wide else np.int32
+    indptr = np.concatenate([np.asarray(b.indptr[:-1], dtype=it) + it(nnz[i]) for i, b in enumerate(blocks)] + [np.asarray([nnz[-1]], dtype=it)])
+    indices = np.concatenate([np.asarray(b.indices, dtype=it) + it(cols[i]) for i, b in enumerate(blocks)]) if len(blocks) else np.zeros(0, dtype=it)
+    data = np.concatenate([b.data for b in blocks]) if len(blocks) else np.zeros(0)
+    out = sp.csr_matrix((data, indices, indptr), shape=(int(rows[-1]), int(cols[-1])))
+    out.has_sorted_indices = all(b.has_sorted_indices for b in blocks)
+    return out
 
 
 def _dmda_partition3(M, N, P, size):

@@ -26,6 +26,45 @@ def test_gpus_n_launches_n_ranks_itself():
         assert k["argv"] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--dry-launch"]
 
 
+def test_ranks_share_the_host_threads():
+    """Eight ranks on one node must not start eight full thread pools: the launcher hands every child cores // N threads (OMP_NUM_THREADS = PMH_HOST_THREADS: numpy / OpenMP and
+    the library's host-side builders), and a rank launched by torch.distributed.run arrives at the same share from LOCAL_WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS", "PMH_HOST_THREADS")}
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_children"] == 8
+    share = max(1, cores // 8)
+    for k in d["children"]:
+        assert k["host_threads"] == share and k["omp_num_threads"] == str(share) and k["pmh_host_threads"] == str(share), k
+    assert 8 * share <= max(cores, 8)
+    # the driver's launch: torch.distributed.run exports LOCAL_WORLD_SIZE (and OMP_NUM_THREADS=1 unless set); the rank derives its share itself
+    env2 = dict(env, RANK="3", LOCAL_RANK="3", WORLD_SIZE="4", LOCAL_WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"], capture_output=True, text=True, timeout=60, env=env2)
+    assert out.returncode == 0, out.stderr[-2000:]
+    k = json.loads(out.stdout.strip().splitlines()[-1])
+    assert k["host_threads"] == max(1, cores // 4) and k["pmh_host_threads"] == str(max(1, cores // 4))
+
+
+def test_launcher_watchdog_ends_hung_ranks():
+    """A rank that never finishes must not hang the launcher: PMH_BENCH_DEADLINE_S ends the children by PID and the launcher exits non-zero."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PMH_BENCH_DEADLINE_S="2", PMH_BENCH_TEST_HANG="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode != 0 and time.time() - t0 < 30
+    assert "did not finish" in out.stderr
+
+
 def test_launched_by_torchrun_env_is_not_relaunched():
     """With WORLD_SIZE in the environment (the driver's torch.distributed.run launch) bench.py is a rank, not a launcher."""
     env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
