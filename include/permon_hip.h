@@ -297,6 +297,10 @@ int pmh_matinv_mult(pmh_matinv Kplus, const double *f, double *u);
    factorisation with null-pivot detection: the fixing dofs (ascending local indices; identity rows / columns in the K given to pmh_matinv_create) carry 0 and their
    equations are dropped.  Needs pmh_matinv_set_nullspace; the result is not projected.  nfix = 0: back to P_R K^- P_R. */
 int pmh_matinv_set_left_inverse(pmh_matinv Kplus, int nfix, const int *fix_dofs_host);
+/* DEVIATION from the reference, which factorises (matinv.c:481-580) and has no such case: a block whose load lies in the kernel of K_b altogether leaves the block CG only the
+ * rounding residue of P_R f_b, which is not in the range of the singular K_b.  ||P_R f_b|| <= c eps ||f_b|| (default c = 64): the block's image is taken as zero (what the
+ * Moore-Penrose inverse gives for a load in the kernel); c = 0 switches the rule off.  No other block's threshold is touched. */
+int pmh_matinv_set_kernel_load_tolerance(pmh_matinv Kplus, double c);
 int pmh_matinv_last_iterations(pmh_matinv Kplus, int *max_block_its, long long *total_spmv);
 
 /* MatRegularize (src/mat/interface/permonmatregularize.c:198-287), the set-up step of the reference's default FETI path

@@ -98,9 +98,9 @@ class KplusMG:
         p = z.copy()
         rz = self._bdot(r, z)
         tol = self.rtol * np.sqrt(self._bdot(r, r))
-        if self.R is not None:  # the product's floor (k_cg_init): a load in the kernel leaves only the rounding residue of its projection, which is not in the range of the singular K
-            tol = np.maximum(tol, 16.0 * np.finfo(float).eps * np.sqrt(self._bdot(f0, f0)))
         active = np.sqrt(self._bdot(r, r)) > tol
+        if self.R is not None:  # the product's rule (k_cg_init): a load in the kernel leaves only the rounding residue of its projection, which is not in the range of the singular K: u_b = 0
+            active &= np.sqrt(self._bdot(r, r)) > 64.0 * np.finfo(float).eps * np.sqrt(self._bdot(f0, f0))
         it = 0
         while it < self.max_it and active.any():
             Ap = self._Kx(p)

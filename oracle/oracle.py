@@ -399,7 +399,7 @@ class Gluing:
 class MatInv:
     """MATINV apply on the reference's iterative path: per-block Jacobi-CG, Moore-Penrose wrapped (orc_matinv_mult)."""
 
-    def __init__(self, K, rowstart, R=None, rtol=1e-10, atol=1e-50, max_it=20000, omp=False):
+    def __init__(self, K, rowstart, R=None, rtol=1e-10, atol=1e-50, max_it=20000, omp=False, kernel_tol=0.0):
         self.L = lib(omp)
         self.L.orc_matinv_new.restype = C.c_void_p
         self.L.orc_matinv_spmv_count.restype = C.c_longlong
@@ -407,6 +407,8 @@ class MatInv:
         self.R = _f64(R) if R is not None else None
         kdim = self.R.shape[0] if self.R is not None else 0
         self.h = self.L.orc_matinv_new(C.byref(K.c), len(self.rowstart) - 1, _p(self.rowstart), kdim, _p(self.R), C.c_double(rtol), C.c_double(atol), C.c_int(max_it))
+        if kernel_tol:  # the product's rule for loads that lie in the kernel (off by default: the reference has none)
+            self.L.orc_matinv_set_kernel_tol(C.c_void_p(self.h), C.c_double(kernel_tol))
 
     def mult(self, f):
         u = np.empty(self.K.nrows)

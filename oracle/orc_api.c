@@ -186,6 +186,7 @@ orc_matinv *orc_matinv_new(const orc_csr *K, int nblocks, const int *rowstart, i
   M->K = K, M->nblocks = nblocks, M->rowstart = rowstart, M->kdim = kdim, M->R = R, M->rtol = rtol, M->atol = atol, M->max_it = max_it;
   return M;
 }
+void      orc_matinv_set_kernel_tol(orc_matinv *M, double c) { M->kernel_tol = c; }
 long long orc_matinv_spmv_count(orc_matinv *M) { return M->spmv_count; }
 int       orc_matinv_last_its(orc_matinv *M) { return M->last_max_its; }
 void      orc_matinv_delete(orc_matinv *M) { free(M); }

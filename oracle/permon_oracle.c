@@ -1142,10 +1142,11 @@ void orc_matinv_mult(orc_matinv *M, const double *f, double *u)
     double rr = v_dot(m, r + lo, r + lo);
     rz[b]     = v_dot(m, r + lo, z + lo);
     tol[b]    = fmax(M->rtol * sqrt(rr), M->atol);
-    /* a load that lies in the kernel of K leaves only the rounding residue of its projection, which is NOT in the range of the singular K: CG on it diverges along the kernel
-       (feti/ex71.c's interior slabs under a uniform body force).  The threshold is floored at the rounding level of the projection, as in the product (k_cg_init) */
-    if (M->kdim) tol[b] = fmax(tol[b], 16.0 * 2.220446049250313e-16 * sqrt(v_dot(m, f + lo, f + lo)));
     active[b] = sqrt(rr) > tol[b];
+    /* OPTION (off by default; not in the reference, whose K^+ is a factorisation): a load that lies in the kernel of K leaves only the rounding residue of its projection,
+       which is NOT in the range of the singular K -- CG on it diverges along the kernel (feti/ex71.c's interior slabs under a uniform body force).  With kernel_tol = c such a
+       block gets u_b = 0, as in the product (k_cg_init) */
+    if (M->kdim && M->kernel_tol > 0.0 && sqrt(rr) <= M->kernel_tol * 2.220446049250313e-16 * sqrt(v_dot(m, f + lo, f + lo))) active[b] = 0;
     nactive += active[b];
   }
   for (it = 0; it < M->max_it && nactive; it++) {

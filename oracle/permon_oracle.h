@@ -261,6 +261,8 @@ typedef struct {
   int            max_it;
   long long      spmv_count;
   int            last_max_its;
+  double         kernel_tol; /* 0 (default): the plain KSPCG of the reference's iterative MATINV.  c > 0: a block with ||P_R f_b|| <= c eps ||f_b|| is given u_b = 0 -- the
+                                product's rule for loads in the kernel (pmh_matinv_set_kernel_load_tolerance); tests switch it on explicitly and check it against a dense pinv */
 } orc_matinv;
 void orc_matinv_mult(orc_matinv *M, const double *f, double *u);
 

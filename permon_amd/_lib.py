@@ -214,6 +214,7 @@ _PROTOS = {
     "pmh_matinv_destroy": [vp],
     "pmh_matinv_set_nullspace": [vp, C.c_int, vp],
     "pmh_matinv_set_left_inverse": [vp, C.c_int, vp],
+    "pmh_matinv_set_kernel_load_tolerance": [vp, C.c_double],
     "pmh_matinv_mult": [vp, vp, vp],
     "pmh_matinv_last_iterations": [vp, c_int_p, C.POINTER(C.c_longlong)],
     "pmh_mat_regularize_pivots": [C.c_int, C.c_int, vp, vp],

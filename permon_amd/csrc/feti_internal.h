@@ -44,7 +44,8 @@ struct pmh_matinv_s {
   // P_R = I - R R', R = block-wise orthonormal kernel basis stored as kdim columns of length n
   int     kdim;
   double *d_R, *d_coef, *d_fproj, *d_kpart;
-  double *d_fnorm2 = nullptr; // ||f_b||^2 of the last right-hand side before its projection (k_cg_init's floor)
+  double *d_fnorm2 = nullptr; // ||f_b||^2 of the last right-hand side before its projection (k_cg_init: loads in the kernel)
+  double  kernel_tol = 64.0;  // ||P_R f_b|| <= kernel_tol eps ||f_b||: the block's load lies in the kernel, u_b = 0 (pmh_matinv_set_kernel_load_tolerance)
   // left generalised inverse (QPTDualize's -qpt_dualize_Kplus_left, qptransform.c:1006-1062: K^+ := K^- P_R): no projection of the result, and the right-hand side entries of
   // the fixing dofs (the null pivots of the reference's factorisation; identity rows / columns of the K handed in) are zeroed
   int  left = 0, nfix = 0;

@@ -29,6 +29,9 @@
 #include <permon/private/qpimpl.h>
 #include "permon_hip.h"
 
+/* defined in libpermon but in none of its headers (src/mat/impls/timer/mattimer.c:5): PermonHipOpFromMat recognises a MATTIMER shell by its mult slot */
+PERMON_EXTERN PetscErrorCode MatMult_Timer(Mat W, Vec x, Vec y);
+
 #define PMHCall(call) \
   do { \
     int pmh_rc_ = (call); \
@@ -858,18 +861,26 @@ static PetscErrorCode MatMult_InvHIP(Mat imat, Vec right, Vec left)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-PERMON_EXTERN PetscErrorCode MatInvAttachHIP(Mat imat, PetscBool moore_penrose)
+/* form: 0 = the MATINV as it is (K_reg^{-1}, or a non-singular K); 1 = P_R K^- P_R (QPTDualize -qpt_dualize_Kplus_mp, qptransform.c:1020-1062: MatCreateProd(P_R, Kplus, P_R));
+ * 2 = K^- P_R, the LEFT generalised inverse QPTDualize takes when PERMON had to compute the kernel itself (qptransform.c:997-1008, :1040-1062: MatCreateProd(P_R, Kplus) with
+ * -regularize 0).  For 1 and 2 the library carries the wrapping (pmh_matinv_set_nullspace / pmh_matinv_set_left_inverse), so that F = B K^+ B' is ONE library operator.
+ * The reference's K^- of form 2 is its factorisation with null pivots; here the fixing dofs MatRegularize would take (permonmatregularize.c:57-124) stand in for them: the
+ * local block gets identity rows / columns there (a second device copy of K, as pmh_kspfeti_solve builds it) */
+typedef enum { PERMONHIP_KPLUS_PLAIN = 0, PERMONHIP_KPLUS_MP = 1, PERMONHIP_KPLUS_LEFT = 2 } PermonHipKplusForm;
+
+PERMON_EXTERN PetscErrorCode MatInvAttachHIPForm(Mat imat, PermonHipKplusForm form)
 {
   Mat_Inv      *inv = (Mat_Inv *)imat->data;
+  pmh_ctx       ctx;
   pmh_blockdiag Kb;
   pmh_matinv    Kp;
   PetscReal     rtol, abstol;
-  PetscInt      maxits, n, kdim, k;
+  PetscInt      maxits, n = 0, kdim = 0, k;
   PetscFunctionBegin;
+  PetscCall(PermonHipGetCtx(&ctx));
   PetscCall(PermonHipQuery((PetscObject)inv->A, "pmh_blockdiag", (void **)&Kb));
   PetscCall(KSPGetTolerances(inv->ksp, &rtol, &abstol, NULL, &maxits));
-  PMHCall(pmh_matinv_create(Kb, rtol, abstol, (int)maxits, 1, &Kp));
-  if (moore_penrose && inv->R) { /* P_R K^- P_R (QPTDualize -qpt_dualize_Kplus_mp, qptransform.c:1020-1062): R's local rows, column-major */
+  if (form != PERMONHIP_KPLUS_PLAIN && inv->R) {
     const PetscScalar *r;
     Mat                Rloc;
     PetscCall(MatGetLocalSize(inv->R, &n, NULL));
@@ -878,12 +889,84 @@ PERMON_EXTERN PetscErrorCode MatInvAttachHIP(Mat imat, PetscBool moore_penrose)
     PetscCall(MatDenseGetArrayRead(Rloc, &r));
     PetscCall(MatDenseGetLDA(Rloc, &k));
     PetscCheck(k == n, PETSC_COMM_SELF, PETSC_ERR_SUP, "R must be stored with lda = local rows");
-    PMHCall(pmh_matinv_set_nullspace(Kp, (int)kdim, r)); /* kdim columns of length n = the layout pmh_matinv_set_nullspace takes */
+    if (form == PERMONHIP_KPLUS_LEFT && kdim > 0) {
+      /* the block with identity rows / columns on the fixing dofs: a second CSR + block-diagonal handle, owned by the MATINV */
+      Mat_BlockDiag     *bd = (Mat_BlockDiag *)inv->A->data;
+      const PetscInt    *ia, *ja;
+      const PetscScalar *va;
+      PetscInt           m, nz = 0, i, kk;
+      PetscBool          done;
+      int               *piv, *rp, *ci, rowstart[2];
+      char              *isfix;
+      double            *vv;
+      pmh_csr            Kfix;
+      pmh_blockdiag      Kfixb;
+      PetscCall(PetscMalloc1(kdim, &piv));
+      PMHCall(pmh_mat_regularize_pivots((int)n, (int)kdim, r, piv)); /* R: kdim columns of length n, column-major = the layout it takes */
+      PetscCall(MatGetRowIJ(bd->localBlock, 0, PETSC_FALSE, PETSC_FALSE, &m, &ia, &ja, &done));
+      PetscCheck(done && m == n, PETSC_COMM_SELF, PETSC_ERR_SUP, "the local block must be MATSEQAIJ of the kernel's row count");
+      PetscCall(MatSeqAIJGetArrayRead(bd->localBlock, &va));
+      PetscCall(PetscCalloc1(n, &isfix));
+      for (kk = 0; kk < kdim; kk++) isfix[piv[kk]] = 1;
+      PetscCall(PetscMalloc3(n + 1, &rp, ia[n] + n, &ci, ia[n] + n, &vv));
+      rp[0] = 0;
+      for (i = 0; i < n; i++) {
+        if (isfix[i]) ci[nz] = (int)i, vv[nz] = 1.0, nz++;
+        else
+          for (kk = ia[i]; kk < ia[i + 1]; kk++)
+            if (!isfix[ja[kk]]) ci[nz] = (int)ja[kk], vv[nz] = va[kk], nz++;
+        rp[i + 1] = (int)nz;
+      }
+      PMHCall(pmh_csr_create(ctx, (int)n, (int)n, rp, ci, vv, &Kfix));
+      rowstart[0] = 0, rowstart[1] = (int)n;
+      PMHCall(pmh_blockdiag_create(ctx, 1, rowstart, Kfix, &Kfixb));
+      PetscCall(PermonHipCompose((PetscObject)imat, "pmh_csr_fixed", Kfix, PermonHipCsrDestroy));
+      PetscCall(PermonHipCompose((PetscObject)imat, "pmh_blockdiag_fixed", Kfixb, PermonHipBlockDiagDestroy));
+      PMHCall(pmh_matinv_create(Kfixb, rtol, abstol, (int)maxits, 1, &Kp));
+      PMHCall(pmh_matinv_set_nullspace(Kp, (int)kdim, r));
+      PMHCall(pmh_matinv_set_left_inverse(Kp, (int)kdim, piv));
+      PetscCall(PetscFree3(rp, ci, vv));
+      PetscCall(PetscFree(isfix));
+      PetscCall(PetscFree(piv));
+      PetscCall(MatSeqAIJRestoreArrayRead(bd->localBlock, &va));
+      PetscCall(MatRestoreRowIJ(bd->localBlock, 0, PETSC_FALSE, PETSC_FALSE, &m, &ia, &ja, &done));
+    } else {
+      PMHCall(pmh_matinv_create(Kb, rtol, abstol, (int)maxits, 1, &Kp));
+      PMHCall(pmh_matinv_set_nullspace(Kp, (int)kdim, r)); /* kdim columns of length n = the layout pmh_matinv_set_nullspace takes */
+    }
     PetscCall(MatDenseRestoreArrayRead(Rloc, &r));
+  } else {
+    PMHCall(pmh_matinv_create(Kb, rtol, abstol, (int)maxits, 1, &Kp));
   }
   PetscCall(PermonHipCompose((PetscObject)imat, "pmh_matinv", Kp, PermonHipMatInvDestroy));
-  imat->ops->mult = MatMult_InvHIP;
+  imat->ops->mult = MatMult_InvHIP; /* (with form 1 / 2 this slot already applies the wrapped inverse: use it on its own, not under the reference's MatProd wrapper) */
   PetscCall(MatSetVecType(imat, VECHIP));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PERMON_EXTERN PetscErrorCode MatInvAttachHIP(Mat imat, PetscBool moore_penrose)
+{
+  PetscFunctionBegin;
+  PetscCall(MatInvAttachHIPForm(imat, moore_penrose ? PERMONHIP_KPLUS_MP : PERMONHIP_KPLUS_PLAIN));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* QPTDualize's "Kplus" as composed on F (qptransform.c:1116-1120) is the MATINV itself, or -- after the generalised-inverse wrapping (:1020-1062) -- the product
+ * MatCreateProd(P_R, Kplus[, P_R]) that keeps the MATINV composed under "Kplus" (:1047).  Returns the MATINV and which form the wrapper stands for. */
+static PetscErrorCode PermonHipUnwrapKplus(Mat Kplus, Mat *imat, PermonHipKplusForm *form)
+{
+  Mat       inner = NULL;
+  PetscBool iscomposite;
+  PetscInt  nmat = 0;
+  PetscFunctionBegin;
+  *imat = Kplus, *form = PERMONHIP_KPLUS_PLAIN;
+  PetscCall(PetscObjectTypeCompare((PetscObject)Kplus, MATCOMPOSITE, &iscomposite));
+  if (!iscomposite) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(PetscObjectQuery((PetscObject)Kplus, "Kplus", (PetscObject *)&inner));
+  PetscCheck(inner, PetscObjectComm((PetscObject)Kplus), PETSC_ERR_ARG_WRONGSTATE, "a composite K^+ that does not carry the MATINV it wraps");
+  PetscCall(MatCompositeGetNumberMat(Kplus, &nmat));
+  PetscCheck(nmat == 2 || nmat == 3, PetscObjectComm((PetscObject)Kplus), PETSC_ERR_SUP, "K^+ wrapper of %" PetscInt_FMT " factors", nmat);
+  *imat = inner, *form = (nmat == 3) ? PERMONHIP_KPLUS_MP : PERMONHIP_KPLUS_LEFT;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -1214,10 +1297,13 @@ static PetscErrorCode PermonHipOpFromMat(Mat A, pmh_op *op, PetscInt *nowned, pm
   PetscCall(PetscObjectQuery((PetscObject)A, "Bt", (PetscObject *)&Bt));
   PetscCall(PetscObjectQuery((PetscObject)A, "Kplus", (PetscObject *)&Kplus));
   if (Bt && Kplus) {
-    pmh_gluing B;
-    pmh_matinv Kp;
-    PetscCall(PermonHipQuery((PetscObject)Bt, "pmh_gluing", (void **)&B));     /* MatGluingAttachHIP(Bt) */
-    PetscCall(PermonHipQuery((PetscObject)Kplus, "pmh_matinv", (void **)&Kp)); /* MatInvAttachHIP(Kplus) [+ MatInvAttachExplicitHIP] */
+    pmh_gluing         B;
+    pmh_matinv         Kp;
+    Mat                imat;
+    PermonHipKplusForm form;
+    PetscCall(PermonHipUnwrapKplus(Kplus, &imat, &form)); /* the MATINV under QPTDualize's MatCreateProd(P_R, Kplus[, P_R]): its library handle carries the wrapping */
+    PetscCall(PermonHipQuery((PetscObject)Bt, "pmh_gluing", (void **)&B));    /* MatGluingAttachHIP(Bt) */
+    PetscCall(PermonHipQuery((PetscObject)imat, "pmh_matinv", (void **)&Kp)); /* MatInvAttachHIPForm(imat, form) [+ MatInvAttachExplicitHIP] */
     PMHCall(pmh_op_create_feti_dual(B, Kp, op));                               /* applies through the explicit dual operators when they are attached to Kp */
     PetscCall(PermonHipOpOwn(*op, nowned, owned));
     PetscFunctionReturn(PETSC_SUCCESS);
@@ -1606,9 +1692,18 @@ PERMON_EXTERN PetscErrorCode QPTDualizeAttachHIP(QP child, PetscBool moore_penro
   PetscCheck(isgluing, PetscObjectComm((PetscObject)child), PETSC_ERR_SUP, "the fused dual operator needs -feti_gluing_mattype gluing (MATEXTENSION keeps its slot-wise device mults: MatExtensionAttachHIP)");
   PetscCall(MatGluingAttachHIP(Bt));
   PetscCall(MatBlockDiagAttachHIP(K));
-  PetscCall(MatInvAttachHIP(Kplus, moore_penrose));
-  PetscCall(MatInvSetUp_HIP(Kplus));
-  if (explicit_dual) PetscCall(MatInvAttachExplicitHIP(Kplus, Bt, PETSC_DECIDE, dims, ndof, 1e-12));
+  {
+    /* which generalised inverse QPTDualize built (qptransform.c:997-1062) is read off the object it left behind; `moore_penrose` only matters for an unwrapped MATINV
+       whose kernel the caller wants projected out (-qpt_dualize_Kplus_mp given to the library instead of to QPTDualize) */
+    Mat                imat;
+    PermonHipKplusForm form;
+    PetscCall(PermonHipUnwrapKplus(Kplus, &imat, &form));
+    if (form == PERMONHIP_KPLUS_PLAIN && moore_penrose) form = PERMONHIP_KPLUS_MP;
+    PetscCheck(!(explicit_dual && form == PERMONHIP_KPLUS_LEFT), PetscObjectComm((PetscObject)child), PETSC_ERR_SUP, "the explicit local dual operators store symmetric blocks: K_reg^{-1} or -qpt_dualize_Kplus_mp, not the left generalised inverse");
+    PetscCall(MatInvAttachHIPForm(imat, form));
+    PetscCall(MatInvSetUp_HIP(imat));
+    if (explicit_dual) PetscCall(MatInvAttachExplicitHIP(imat, Bt, PETSC_DECIDE, dims, ndof, 1e-12));
+  }
   PetscCall(QPGetQPPF(child, &pf));
   if (pf) PetscCall(QPPFAttachHIP(pf));
   PetscFunctionReturn(PETSC_SUCCESS);

@@ -1,0 +1,2 @@
+/* test stub: see petsc_stub.h */
+#include "petsc_stub.h"
