@@ -53,7 +53,8 @@ int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; f
  * Takes effect for operators created afterwards.  "chain_applies" / "chain_launches": counters of the chain's applications and of its own kernel launches (the middle
  * stage's -- GEMM + finishing launch, or the inner Krylov solve -- not included); set to reset.  "host_threads": threads of the host-side set-up builders (3x3-block
  * copies, multigrid hierarchy, class detection); initial value PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the CPUs the process may run on) -- with several ranks
- * per node every rank must get its share.  Unknown name: PMH_ERR_ARG. */
+ * per node every rank must get its share.  "svm_pairing" (PMH_SVM_NO_PAIRING unset = 1): the SVM dual's paired passes over X inside MPGP; 0 = every Hessian application as its
+ * own two passes (may change between two solves; every rank of a job must set it alike).  Unknown name: PMH_ERR_ARG. */
 int pmh_set_knob(const char *name, int value);
 int pmh_get_knob(const char *name, int *value);
 int pmh_finalize(pmh_ctx ctx);
@@ -573,6 +574,7 @@ typedef struct {
   double regularize_rho;     /* > 0: the rho of MatRegularize for every block; 0 (default): the reference's power-method estimate */
   double kplus_rtol; int kplus_max_it; /* inner KSP of MATINV */
   double rtol, atol, divtol; int max_it; /* -qps_rtol ... of the dual solve (qps.c:73-76) */
+  int    max_it_set;         /* 1: max_it was given (-qps_max_it, or by the caller): with project == 0 it replaces QPSCreate_SMALXE's own default of 100 (smalxe.c:1203) whatever its value */
   int    explicit_dual; double explicit_rtol; /* 1: F applies through the explicit local dual operators (pmh_fexplicit_*), assembled at explicit_rtol (default 0 / 1e-13) */
   /* the reference's post-solve report, QPChainPostSolve (src/qp/interface/qpchain.c:198-275): */
   int    view_convergence;   /* -qps_view_convergence: "  last QPSSolve CONVERGED due to ..., KSPReason=.., required .. iterations" (qps.c:1188-1230) */

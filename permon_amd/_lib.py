@@ -74,7 +74,7 @@ class QpsOpts(C.Structure):
 class KspFetiOpts(C.Structure):
     _fields_ = [("gluing_type", C.c_int), ("scale", C.c_int), ("exclude_dirichlet", C.c_int), ("regularize", C.c_int), ("kplus_left", C.c_int), ("project", C.c_int),
                 ("E_orth_type", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
-                ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int),
+                ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int), ("max_it_set", C.c_int),
                 ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("view_convergence", C.c_int), ("view_kkt", C.c_int), ("matis_to_diag_norm", C.c_int),
                 ("view_buf", C.c_char_p), ("view_cap", C.c_int), ("smalxe", SmalxeOpts)]
 

@@ -25,6 +25,7 @@ pmh_knobs_s &pmh_knobs()
   static pmh_knobs_s k = [] {
     pmh_knobs_s v;
     v.chain = getenv("PMH_NO_CHAIN") ? 0 : 1;
+    v.svm_pairing = getenv("PMH_SVM_NO_PAIRING") ? 0 : 1;
     int         nt = 0;
     const char *e  = getenv("PMH_HOST_THREADS");
     if (!e) e = getenv("OMP_NUM_THREADS");
@@ -47,6 +48,7 @@ static int *knob_by_name(const char *name)
   if (!strcmp(name, "chain_applies")) return &pmh_knobs().chain_applies;
   if (!strcmp(name, "chain_launches")) return &pmh_knobs().chain_launches;
   if (!strcmp(name, "host_threads")) return &pmh_knobs().host_threads;
+  if (!strcmp(name, "svm_pairing")) return &pmh_knobs().svm_pairing;
   return nullptr;
 }
 extern "C" int pmh_set_knob(const char *name, int value)

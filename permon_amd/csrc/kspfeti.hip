@@ -219,7 +219,10 @@ static int kspfeti_view_smalxe(pmh_ctx ctx, const pmh_kspfeti_opts *o, pmh_smalx
   PMH_CHK(pmh_qpt_feti_chain_get(ch, &F, nullptr, &d, &bbar, nullptr, nullptr, nullptr));
   PMH_CHK(pmh_smalxe_get_penalized(S, &Arho, &b_in, &btmu));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(nl, 1), (void **)&t));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)std::max(m, 1), (void **)&gm));
+  if (const int rc_gm = pmh_malloc(ctx, sizeof(double) * (size_t)std::max(m, 1), (void **)&gm)) {
+    pmh_free(ctx, t);
+    return rc_gm;
+  }
   int    rc = PMH_SUCCESS;
   double r7 = 0, nb7 = 0, r6 = 0, r5 = 0, be4 = 0;
 #define GO(call) \
@@ -549,7 +552,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
       GO(pmh_qpt_feti_chain_get(ch, &F, nullptr, nullptr, &bbar, nullptr, nullptr, nullptr));
       pmh_smalxe_opts sx = o->smalxe;
       sx.rtol = o->rtol, sx.atol = o->atol, sx.divtol = o->divtol;
-      if (o->max_it != 10000) sx.max_it = o->max_it; // -qps_max_it given: QPSCreate_SMALXE's own default (100, smalxe.c:1203) otherwise
+      if (o->max_it_set || o->max_it != 10000) sx.max_it = o->max_it; // -qps_max_it given (max_it_set: also an explicit 10000): QPSCreate_SMALXE's own default (100, smalxe.c:1203) otherwise
       if (o->E_orth_type == 4) sx.be_implicit = 1;   // the implicit BE has no product of its own: ||BE u|| through B'B (smalxe.c:878-886)
       GO(pmh_smalxe_create(ctx, F, bbar, d_x, nullptr, nullptr, pfs, &sx, &S));
       GO(pmh_smalxe_solve(S));

@@ -354,6 +354,7 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
   static const char *const orthtypes[] = {"none", "gs", "gslingen", "cholesky", "implicit", "inexact"}; // MatOrthTypes (permonmatorth.c:6)
   std::string left;
   int         inner_alpha_bits = 0;
+  int         mp_given = 0, left_given = -1; // resolved AFTER the loop: -qpt_dualize_Kplus_mp wins over -qpt_dualize_Kplus_left in whatever order they come (qptransform.c:1018-1019 reads _left only if !true_mp)
   for (const Token &t : toks) {
     const std::string &k = t.key;
     int                rc = 1, b = 0;
@@ -363,7 +364,7 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1; // (without effect while kplus_left is on, as in the reference once it has computed the kernel)
     else if (k == "qpt_dualize_Kplus_mp") {
       rc = get_bool(t, &b) ? -1 : 1;
-      if (rc == 1 && b) o->regularize = 0, o->kplus_left = 0; // the Moore-Penrose wrapping is this library's -regularize 0 path; it wins over the left inverse (qptransform.c:1018-1019)
+      if (rc == 1) mp_given = b; // the Moore-Penrose wrapping is this library's -regularize 0 path
     } else if (k == "dual_pc_dual_type") rc = get_enum(t, pctypes, 2, &o->lumped_pc) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_rtol") rc = get_real(t, &o->kplus_rtol) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_max_it") rc = get_int(t, &o->kplus_max_it) ? -1 : 1;
@@ -372,14 +373,14 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     else if (k == "qps_view_convergence") rc = get_bool(t, &o->view_convergence) ? -1 : 1;
     else if (k == "qpt_matis_to_diag_norm") rc = get_bool(t, &o->matis_to_diag_norm) ? -1 : 1;
     else if (k == "qpt_dualize_Kplus_left") { // QPTDualize qptransform.c:1018; implies -regularize 0 as the reference's own switch does (:1003-1005)
-      rc = get_bool(t, &o->kplus_left) ? -1 : 1;
-      if (rc == 1 && o->kplus_left) o->regularize = 0;
+      rc = get_bool(t, &b) ? -1 : 1;
+      if (rc == 1) left_given = b;
     } else if (k == "project") rc = get_bool(t, &o->project) ? -1 : 1;                     // QPTFromOptions qptransform.c:2228
     else if (k == "dual_qp_E_orth_type") {                                                  // QPTOrthonormalizeEqFromOptions on the dual QP (prefix dual_)
       rc = get_enum(t, orthtypes, 6, &o->E_orth_type) ? -1 : 1;
       if (rc == 1 && o->E_orth_type == 5) return pmh_set_error(PMH_ERR_SUP, "options: -dual_qp_E_orth_type %s is not built (none, gs, gslingen, cholesky, implicit)", t.val.c_str());
     } else {
-      rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, nullptr);
+      rc = tol_key(t, k, &o->rtol, &o->atol, &o->divtol, &o->max_it, &o->max_it_set);
       if (!rc) rc = smalxe_key(t, k, &o->smalxe);                                           // -qps_smalxe_*: the solver of -project 0
       if (!rc && k.compare(0, 7, "smalxe_") == 0) {                                         // its inner solver (smalxe.c:500-502)
         const std::string ki = k.substr(7);
@@ -391,6 +392,11 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     if (!rc) left += (left.empty() ? "-" : " -") + k;
   }
   if (inner_alpha_bits == 1) o->smalxe.inner.alpha_direct = 0;
+  if (left_given >= 0) {
+    o->kplus_left = left_given;
+    if (left_given) o->regularize = 0; // implies -regularize 0 as the reference's own switch does (qptransform.c:1003-1005)
+  }
+  if (mp_given) o->regularize = 0, o->kplus_left = 0;
   if (unknown && unknown_cap > 0) snprintf(unknown, (size_t)unknown_cap, "%s", left.c_str());
   return PMH_SUCCESS;
 }

@@ -23,6 +23,7 @@ struct pmh_knobs_s {
   int chain; // the five-launch dual-space chain (dualchain.hip)
   // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and the launches they took, the middle stage's included
   int chain_applies = 0, chain_launches = 0;
+  int svm_pairing = 1;  // the SVM dual's paired passes over X inside MPGP (svm.hip); 0 (PMH_SVM_NO_PAIRING): every Hessian application as its own two passes
   int host_threads = 1; // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the
                         // CPUs this process may run on) -- several ranks per node must share the node's cores (bench.py hands every rank its share)
 };

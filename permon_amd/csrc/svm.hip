@@ -368,8 +368,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_colsum_feas(int nblocks, cons
 
 int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
 {
-  const bool off = getenv("PMH_SVM_NO_PAIRING") != nullptr; // (read per call: tests switch it between two solves of one process)
-  if (off || d != 64 || n <= 0) return PMH_EPI_UNSUPPORTED;
+  // (the switch may change between two solves of one process: pmh_set_knob("svm_pairing"), initial value from PMH_SVM_NO_PAIRING -- no getenv on the per-product path.  It is
+  // process-wide state that every rank of a job must set alike: ranks that disagree would issue different sequences of collectives)
+  if (n <= 0 && pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_ARG, "SVM dual operator: this rank holds no samples; with a communicator every rank needs at least one row (an empty shard would skip the collectives the other ranks issue)");
+  if (!pmh_knobs().svm_pairing || d != 64 || n <= 0) return PMH_EPI_UNSUPPORTED;
   // several GPUs (samples sharded by rows): the 64 column sums w and, where the next pass uses it, the feasible step length afeas are completed across the ranks between the
   // passes -- the same exchange step as the lone application's, one (+ one 8-byte MIN) per pass
   if (!part_next) {
@@ -426,6 +428,7 @@ int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
 int SvmDualOp::mult(const double *a, double *Ha)
 {
   next_is = NEXT_NONE; // (whatever was prepared belonged to the MPGP driver's vectors)
+  if (n == 0 && pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_ARG, "SVM dual operator: this rank holds no samples; with a communicator every rank needs at least one row");
   if (d == 64 && n > 0) {
     // rows in flight per wave-instruction group: 2 x UNR rows of 512 B (16-byte loads, UNR of them outstanding per lane).  UNR decides which wave visits which rows,
     // i.e. the summation order of pass 1 (last-digit differences between UNR values; fixed for a given UNR).  Measured 4 / 8 / 12 / 16 on configs[4]: 464 / 452-488 / 433 / 487
@@ -447,7 +450,10 @@ int SvmDualOp::mult(const double *a, double *Ha)
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
-  if (n == 0) return PMH_SUCCESS;
+  if (n == 0) {
+    if (pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_ARG, "SVM dual operator: this rank holds no samples; with a communicator every rank needs at least one row");
+    return PMH_SUCCESS;
+  }
   SVM_PASS(k_svm_xt, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, d, X, y, a, part);
   hipLaunchKernelGGL(k_svm_colsum, dim3((d + 3) / 4), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
   PMH_HIP(hipGetLastError());

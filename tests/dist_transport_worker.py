@@ -62,10 +62,9 @@ def case_svm(ctx, rank, world):
 
     # the single-rank references: the whole sample set on this process, no transport.  PAIRING (argv[2]): the paired passes over X inside MPGP (the default; on two ranks w and
     # the feasible step length are completed across the ranks between the passes) or the separate passes (PMH_SVM_NO_PAIRING=1)
-    if len(sys.argv) > 2 and sys.argv[2] == "separate":
-        os.environ["PMH_SVM_NO_PAIRING"] = "1"
-    else:
-        os.environ.pop("PMH_SVM_NO_PAIRING", None)
+    from permon_amd._lib import check as _check
+
+    _check(ctx.L.pmh_set_knob(b"svm_pairing", 0 if (len(sys.argv) > 2 and sys.argv[2] == "separate") else 1))
     p_before = 0
     ref60, x60 = solve(X, y, False, 60)
     ref, x_ref = solve(X, y, False, 10000)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import permon_amd as pa
+from permon_amd._lib import check
 from permon_amd.chain import FetiDualQP
 
 pytestmark = pytest.mark.gpu
@@ -93,10 +94,7 @@ def test_configs4_full_size_hessian_properties_and_pairing():
     del X
     # MPGP on the box 0 <= a <= 1: the paired passes over X (one pass per application in a run of expansion steps) against the separate passes: same steps, same iterate
     def run(no_pairing):
-        if no_pairing:
-            os.environ["PMH_SVM_NO_PAIRING"] = "1"
-        else:
-            os.environ.pop("PMH_SVM_NO_PAIRING", None)
+        check(ctx.L.pmh_set_knob(b"svm_pairing", 0 if no_pairing else 1))  # (the same operator H serves both runs: the switch is read per product)
         qp = pa.QP(ctx)
         qp.SetOperator(H)
         qp.SetRhs(ctx.vec_from(np.ones(N)))
@@ -112,7 +110,7 @@ def test_configs4_full_size_hessian_properties_and_pairing():
         return (st.ncg, st.nexp, st.nprop, st.nmv), x.to_numpy().copy(), H.passes() - p0
     c_sep, x_sep, p_sep = run(True)
     c_pair, x_pair, p_pair = run(False)
-    os.environ.pop("PMH_SVM_NO_PAIRING", None)
+    check(ctx.L.pmh_set_knob(b"svm_pairing", 1))
     assert c_sep == c_pair, (c_sep, c_pair)
     assert np.linalg.norm(x_pair - x_sep) <= 1e-10 * np.linalg.norm(x_sep)
     assert 2 * c_sep[3] <= p_sep <= 2 * (c_sep[3] + 2) and p_pair < 0.75 * p_sep  # two passes over X per application when separate (the speculated product after the last step included); the pairing removes a good part of them

@@ -6,6 +6,7 @@ import pytest
 
 import permon_amd as pa
 from permon_amd import problems as P
+from permon_amd._lib import check
 
 pytestmark = pytest.mark.gpu
 
@@ -70,8 +71,7 @@ def test_svm_mpgp_first_iterations_equal_the_oracle(oracle):
     op = oracle.Op(p["n"], fn=lambda a: y * (X @ (X.T @ (y * a))))
     ref = oracle.mpgp(op, p["b"], p["x0"], oracle.Box(p["n"], lb=p["lb"], ub=p["ub"]), rtol=1e-30, max_it=60)
     for pairing in (True, False):
-        if not pairing:
-            os.environ["PMH_SVM_NO_PAIRING"] = "1"
+        check(ctx.L.pmh_set_knob(b"svm_pairing", 1 if pairing else 0))
         try:
             H = pa.MatCreateSVMDual(ctx, X, y)
             qp = pa.QP(ctx)
@@ -86,7 +86,7 @@ def test_svm_mpgp_first_iterations_equal_the_oracle(oracle):
             qps.SetTolerances(rtol=1e-30, max_it=60)
             st = qps.Solve()
         finally:
-            os.environ.pop("PMH_SVM_NO_PAIRING", None)
+            check(ctx.L.pmh_set_knob(b"svm_pairing", 1))
         assert (st.iteration, st.reason) == (ref["iteration"], ref["reason"]) and st.reason == -3  # DIVERGED_ITS: it > max_it (qps.c:694)
         assert (st.ncg, st.nexp, st.nprop, st.nmv) == (ref["ncg"], ref["nexp"], ref["nprop"], ref["nmv"])
         assert np.linalg.norm(x.to_numpy() - ref["x"]) <= 1e-10 * np.linalg.norm(ref["x"])
@@ -104,9 +104,11 @@ def test_svm_paired_passes_equal_separate_passes(monkeypatch, N):
     p = P.svm_dual(N, 64)  # (4003, 777: rows past the last full group of 8 a wave has in flight)
     X, y = p["X"], p["y"]
     Hp, st_p, x_p = _solve(ctx, p)
-    monkeypatch.setenv("PMH_SVM_NO_PAIRING", "1")
-    Hs, st_s, x_s = _solve(ctx, p)
-    monkeypatch.delenv("PMH_SVM_NO_PAIRING")
+    check(ctx.L.pmh_set_knob(b"svm_pairing", 0))
+    try:
+        Hs, st_s, x_s = _solve(ctx, p)
+    finally:
+        check(ctx.L.pmh_set_knob(b"svm_pairing", 1))
     assert st_p.reason == st_s.reason == 2
     assert abs(st_p.iteration - st_s.iteration) <= max(3, st_s.iteration // 6) and st_p.nexp > 0
     w_p, w_s = X.T @ (y * x_p), X.T @ (y * x_s)
@@ -131,9 +133,9 @@ def test_distributed_scalar_mode_single_rank_communicator(monkeypatch):
     (PMH_COMM_FORCE keeps the collectives on) the result must equal the local mode bit for bit (the local mode on the separate passes the
     distributed mode takes: the paired passes of svm.hip sum other elements per workgroup)."""
     os.environ["PMH_COMM_FORCE"] = "1"
-    monkeypatch.setenv("PMH_SVM_NO_PAIRING", "1")
     try:
         ctx = pa.Context(0)
+        check(ctx.L.pmh_set_knob(b"svm_pairing", 0))
         ctx.comm_init(0, 1, ctx.comm_unique_id())
         p = P.svm_dual(2000, 64)
         _, st_d, x_d = _solve(ctx, p, distributed=True)
@@ -155,6 +157,10 @@ def test_distributed_scalar_mode_single_rank_communicator(monkeypatch):
             qps.MPGPSetDistributed(dist)
             st = qps.Solve()
             assert (st.iteration, st.nmv, st.ncg, st.nexp, st.nprop) == (181, 200, 156, 18, 7)
+        check(ctx.L.pmh_set_knob(b"svm_pairing", 1))
         ctx.close()
     finally:
         del os.environ["PMH_COMM_FORCE"]
+        from permon_amd import _lib
+
+        _lib.load().pmh_set_knob(b"svm_pairing", 1)

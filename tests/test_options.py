@@ -105,3 +105,9 @@ def test_feti_driver_options():
     assert parse("-dual_qp_E_orth_type cholesky")[1].E_orth_type == 3 and parse("-dual_qp_E_orth_type gslingen")[1].E_orth_type == 2
     assert parse("-dual_qp_E_orth_type inexact")[0] != 0  # the one MatOrthType this library does not build: said, not ignored
     assert parse("-feti_gluing_type sideways")[0] != 0 and parse("-qps_rtol 2")[0] != 0
+    # -qpt_dualize_Kplus_mp wins over -qpt_dualize_Kplus_left in EITHER order (qptransform.c:1018-1019 reads _left only if !true_mp)
+    for opts in ("-qpt_dualize_Kplus_mp -qpt_dualize_Kplus_left 1", "-qpt_dualize_Kplus_left 1 -qpt_dualize_Kplus_mp"):
+        rc, o, left = parse(opts)
+        assert rc == 0 and (o.kplus_left, o.regularize) == (0, 0), opts
+    # an explicit -qps_max_it 10000 is "given" (it must reach SMALXE with -project 0 instead of falling to its default of 100): tracked, not compared with the default value
+    assert parse("-project 0 -qps_max_it 10000")[1].max_it_set == 1 and parse("-project 0")[1].max_it_set == 0
