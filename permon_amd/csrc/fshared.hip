@@ -119,6 +119,7 @@ struct fx_shared {
   double                *Afund = nullptr, *cpart = nullptr;
   long long              afund_tot = 0, cpart_cap = 0;
   int                    fxo_ready = 0, fxo_S = 1, stripe_rank = 0, stripe_size = 0;
+  bool                   mfma16 = true; // the orbit GEMM on v_mfma_f64_16x16x4 (PMH_FXO_MFMA4 read ONCE, when the operator is created: nothing on the apply path asks the environment)
   double                 flops = 0.0, flops_issued = 0.0, flops_dense = 0.0; // listed columns x valid rows; padded tiles; every (representative, operation, block)
 };
 
@@ -696,6 +697,9 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
                                                        const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr, const int *__restrict__ xshift_of = nullptr)
 {
   constexpr int NWN = 4 / NWM, NJ = TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
+  // (Round 5, measured and not adopted: a THREE-stage operand pipeline -- the registers that hold chunk kc + 1 stored to LDS at the START of chunk kc, under the products, then
+  // asked to fetch chunk kc + 2; the barrier directly behind the last product.  Same bits; 0.651 instead of 0.656-0.67 of the fp64 peak on the 144 x 128 tile (256 VGPRs, an
+  // 8-byte spill), 0.506 instead of 0.51 on the 64-wide tile: the tail of a chunk -- wait, 13 LDS writes, barrier -- is not what the pipe waits for.)
   __shared__ double As[2][FXO_TK][LDA];
   __shared__ double Bs[2][FXO_TK][TN + 16];
   for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
@@ -1120,7 +1124,8 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     slot[b] = (int)C.blocks.size() % FXS_S, group[b] = (int)C.blocks.size() / FXS_S;
     C.blocks.push_back(b);
   }
-  if (sym == 2 && fxo_mfma16() && !getenv("PMH_FXO_SLOTS8"))
+  S->mfma16 = fxo_mfma16();
+  if (sym == 2 && S->mfma16 && !getenv("PMH_FXO_SLOTS8"))
     for (auto &C : S->C) {
       C.S = 1;
       while (C.S < FXS_S && C.S < (int)C.blocks.size()) C.S *= 2;
@@ -1481,7 +1486,7 @@ static int fxo_prepare(fx_shared *S)
           most = std::max(most, n);
         }
       const char *e = getenv("PMH_FXO_TN");
-      C.tn = (fxo_mfma16() && C.S != FXS_S && most <= 64 && !(e && atoi(e) == 128)) ? 64 : 128; // (only classes on the table-driven kernel: the single-class kernel of 8-block classes is left as it is)
+      C.tn = (S->mfma16 && C.S != FXS_S && most <= 64 && !(e && atoi(e) == 128)) ? 64 : 128; // (only classes on the table-driven kernel: the single-class kernel of 8-block classes is left as it is)
     }
     for (int gr = 0; gr < C.ngroups; gr++) {
       int elems = 0;
@@ -1645,7 +1650,7 @@ static int fxo_prepare(fx_shared *S)
   const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
   // several classes on one row tile share ONE launch (fxo_gemm): the resident workgroups are divided among them
   int nplanned = 0, tm_first = 0, tn_first = 128;
-  bool one_tile = fxo_mfma16() && !getenv("PMH_FXO_NO_MERGE");
+  bool one_tile = S->mfma16 && !getenv("PMH_FXO_NO_MERGE");
   for (int c = 0; c < S->ncls; c++)
     if (tab_of[c] >= 0) {
       if (!nplanned) tm_first = S->C[c].tm, tn_first = S->C[c].tn;
@@ -1995,7 +2000,7 @@ static int fxo_gemm(fx_shared *S)
 #endif
     if (merged) {
       // (the class's products were part of the launch above)
-    } else if (fxo_mfma16() && C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
+    } else if (S->mfma16 && C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
 #define FXO_LAUNCH_T(NI, NWM, TNW)                                                                                                                                                                             \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first),     \
@@ -2014,7 +2019,7 @@ static int fxo_gemm(fx_shared *S)
       default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
       }
 #undef FXO_LAUNCH_T
-    } else if (fxo_mfma16()) {
+    } else if (S->mfma16) {
       switch (C.tm) {
       case 144: FXO_LAUNCH((k_fxo_gemm16<9, 1>)); break;
       case 128: FXO_LAUNCH((k_fxo_gemm16<4, 2>)); break;
