@@ -78,12 +78,13 @@ def test_default_workload_line_small():
         assert 0 < d[k]["roofline"]["frac"] <= 1.0 and d[k]["roofline"]["blocks_per_device_copy"] == 8 and d[k]["roofline"]["blockdiag_figure_GBs"] > d[k]["roofline"]["achieved"]
         assert c[k]["value"] > 0 and c[k]["roofline_frac"] <= 1.0
     assert d["config"]["rccl_ranks"] is None
-    # cpu_baseline.value is MEASURED (the host restatement of the iterative K^+ under the oracle's MPGP); the reference's direct K^+ is a model from three measured sizes
+    # cpu_baseline = the REFERENCE's algorithm on the host: the sparse direct K^+ (splu per block, solve phase timed; at this test's block size it is factored in the run itself,
+    # at the headline's 43^3 the committed one-time measurement is carried over); cpu_baseline_iterative = the host port of the GPU's inner-Krylov K^+, measured in the run
     cb = d["cpu_baseline"]
-    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["extrapolated"] is False, cb
-    assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["extrapolated"] is False and c["cpu_baseline"]["kind"] == "port"
-    dm = d["cpu_baseline_direct_model"]
-    assert "splu" in dm["sample"] and dm["growth_exponent_solve"] > 0 and dm["value"] > 0 and len(dm["sizes_measured"]) >= 2, dm
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "splu" in cb["sample"], cb
+    assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
+    ci = d["cpu_baseline_iterative"]
+    assert ci["value"] > 0 and ci["kind"] == "port" and "V-cycle" in ci["kplus"] and c["cpu_baseline_iterative"]["value"] > 0, ci
     # the FETI dual SpMV on HBM: distinct K_i, one device copy each, both kernels, fractions of the peak <= 1 and the two kernels agree
     fd = d["feti_dual_spmv"]
     assert fd["csr"]["device_copies"] == 8 and fd["bsr3"]["device_copies"] == 8 and 0 < fd["frac"] <= 1.0 and 0 < fd["bsr3"]["frac"] <= 1.0, fd
