@@ -54,7 +54,8 @@ int pmh_init(int device, pmh_ctx *ctx);     /* PermonInitialize's device part; f
  * stage's -- GEMM + finishing launch, or the inner Krylov solve -- not included); set to reset.  "host_threads": threads of the host-side set-up builders (3x3-block
  * copies, multigrid hierarchy, class detection); initial value PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the CPUs the process may run on) -- with several ranks
  * per node every rank must get its share.  "svm_pairing" (PMH_SVM_NO_PAIRING unset = 1): the SVM dual's paired passes over X inside MPGP; 0 = every Hessian application as its
- * own two passes (may change between two solves; every rank of a job must set it alike).  Unknown name: PMH_ERR_ARG. */
+ * own two passes (may change between two solves; every rank of a job must set it alike).  "gt_fusion" (PMH_NO_GT_FUSION), "smalxe_prefetch" (PMH_SMALXE_NO_PREFETCH),
+ * "mg_d0_fusion" (PMH_MG_NO_D0_FUSION): A/B switches of fusions on per-product paths, 1 = fused (the default).  Unknown name: PMH_ERR_ARG. */
 int pmh_set_knob(const char *name, int value);
 int pmh_get_knob(const char *name, int *value);
 int pmh_finalize(pmh_ctx ctx);

@@ -26,6 +26,11 @@ pmh_knobs_s &pmh_knobs()
     pmh_knobs_s v;
     v.chain = getenv("PMH_NO_CHAIN") ? 0 : 1;
     v.svm_pairing = getenv("PMH_SVM_NO_PAIRING") ? 0 : 1;
+    v.gt_fusion = getenv("PMH_NO_GT_FUSION") ? 0 : 1;
+    v.smalxe_prefetch = getenv("PMH_SMALXE_NO_PREFETCH") ? 0 : 1;
+    v.mg_d0_fusion = getenv("PMH_MG_NO_D0_FUSION") ? 0 : 1;
+    v.vec_epi = getenv("PMH_NO_VEC_EPI") ? 0 : 1;
+    v.mpgp_spec = getenv("PMH_MPGP_NO_SPEC") ? 0 : 1;
     int         nt = 0;
     const char *e  = getenv("PMH_HOST_THREADS");
     if (!e) e = getenv("OMP_NUM_THREADS");
@@ -49,6 +54,10 @@ static int *knob_by_name(const char *name)
   if (!strcmp(name, "chain_launches")) return &pmh_knobs().chain_launches;
   if (!strcmp(name, "host_threads")) return &pmh_knobs().host_threads;
   if (!strcmp(name, "svm_pairing")) return &pmh_knobs().svm_pairing;
+  if (!strcmp(name, "gt_fusion")) return &pmh_knobs().gt_fusion;
+  if (!strcmp(name, "smalxe_prefetch")) return &pmh_knobs().smalxe_prefetch;
+  if (!strcmp(name, "mg_d0_fusion")) return &pmh_knobs().mg_d0_fusion;
+  if (!strcmp(name, "mpgp_spec")) return &pmh_knobs().mpgp_spec;
   return nullptr;
 }
 extern "C" int pmh_set_knob(const char *name, int value)

@@ -717,7 +717,7 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   epi.halt = M->d_done; // once every block has converged the remaining enqueued launches return at once
   const float *mg_dinv = nullptr;
   float        mg_itheta = 0.f, *mg_d0 = nullptr, *mg_b32 = nullptr;
-  const bool   d0_fused = extpc && !getenv("PMH_MG_NO_D0_FUSION") && pmh_mg_fine_d0_slots(M->mg, &mg_dinv, &mg_itheta, &mg_d0, &mg_b32);
+  const bool   d0_fused = extpc && pmh_knobs().mg_d0_fusion && pmh_mg_fine_d0_slots(M->mg, &mg_dinv, &mg_itheta, &mg_d0, &mg_b32);
   // The host enqueues iterations without waiting and looks at the device state only where it expects the solve to end: the
   // iteration count of the previous application (successive right-hand sides of the dual iteration need the same number, give
   // or take one).  Launches enqueued past convergence are no-ops (done flag).  One synchronisation per application in the

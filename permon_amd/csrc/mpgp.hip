@@ -970,7 +970,7 @@ static int solve_fused(pmh_mpgp s)
   s->A->emit_invalidate();
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
-  if (s->epi_ok < 0) s->epi_ok = (s->csr || getenv("PMH_NO_VEC_EPI")) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
+  if (s->epi_ok < 0) s->epi_ok = (s->csr || !pmh_knobs().vec_epi) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
                                                                                   // partials are finalised at once and completed across the ranks, pmh_finalize_partials)
   if (s->g_valid) { // the caller carried g = A x - b over from the previous solve (pmh_smalxe_set_reuse_products): the split, p = gf and the norms only
     s->g_valid = 0;
@@ -1000,7 +1000,7 @@ static int solve_fused(pmh_mpgp s)
   auto k_prop_emit = k_step_update<true, false, true>;
   // the device-side CG chain needs the default convergence test (its constants go to the kernels) and a CSR operator
   const int SPEC_BATCH = 16;
-  bool      can_spec   = s->csr && !s->cvg && !s->o.distributed && !getenv("PMH_MPGP_NO_SPEC");
+  bool      can_spec   = s->csr && !s->cvg && !s->o.distributed && pmh_knobs().mpgp_spec;
   pmh_spec_args sa     = nosa;
   if (can_spec) {
     if (!s->d_ctl) {

@@ -23,6 +23,12 @@ struct pmh_knobs_s {
   int chain; // the five-launch dual-space chain (dualchain.hip)
   // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and the launches they took, the middle stage's included
   int chain_applies = 0, chain_launches = 0;
+  // A/B switches that sit on per-product / per-iteration paths: the environment is read ONCE (ctx.hip pmh_knobs), never inside a solver loop
+  int gt_fusion = 1;       // PMH_NO_GT_FUSION: the projector's v - G'(...) epilogue folded into the G' kernel (qppf.hip)
+  int smalxe_prefetch = 1; // PMH_SMALXE_NO_PREFETCH: ||B u|| enqueued before the inner solver's host wait (smalxe.hip)
+  int vec_epi = 1;         // PMH_NO_VEC_EPI: MPGP's vector phase in the operator's last kernel (mpgp.hip; qppf.hip reads the variable itself, once)
+  int mpgp_spec = 1;       // PMH_MPGP_NO_SPEC: batches of device-side CG steps for CSR operators (mpgp.hip)
+  int mg_d0_fusion = 1;    // PMH_MG_NO_D0_FUSION: the first smoothing step written by the producer of the right-hand side (feti.hip)
   int svm_pairing = 1;  // the SVM dual's paired passes over X inside MPGP (svm.hip); 0 (PMH_SVM_NO_PAIRING): every Hessian application as its own two passes
   int host_threads = 1; // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the
                         // CPUs this process may run on) -- several ranks per node must share the node's cores (bench.py hands every rank its share)

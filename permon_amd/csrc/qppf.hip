@@ -613,7 +613,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__re
 // subdomains a dual row touches), otherwise the callers keep the unfused sequence
 static bool gt_fusable(pmh_qppf pf)
 {
-  if (!pf->orthonormal || pf->d_inv || pf->m == 0 || getenv("PMH_NO_GT_FUSION")) return false;
+  if (!pf->orthonormal || pf->d_inv || pf->m == 0 || !pmh_knobs().gt_fusion) return false;
   if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
   const pmh_csr Gt = pf->G->transpose;
   return Gt->kind == PMH_SPMV_STREAM && (Gt->st_rl == 8 || Gt->st_rl == 1) && Gt->l_nchunks == 0;
@@ -622,7 +622,7 @@ static bool gt_fusable(pmh_qppf pf)
 // the same for G with its dense (G G')^{-1}: one-lane-per-row G' only (k_gt_dual1 / k_gt_fused1)
 static bool gt_fusable_dense_inverse(pmh_qppf pf)
 {
-  if (pf->orthonormal || !pf->d_inv || pf->m == 0 || getenv("PMH_NO_GT_FUSION")) return false;
+  if (pf->orthonormal || !pf->d_inv || pf->m == 0 || !pmh_knobs().gt_fusion) return false;
   if (!pf->G->transpose && pmh_csr_ensure_transpose(pf->G)) return false;
   const pmh_csr Gt = pf->G->transpose;
   return Gt->kind == PMH_SPMV_STREAM && Gt->st_rl == 1 && Gt->l_nchunks == 0;

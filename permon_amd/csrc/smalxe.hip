@@ -103,7 +103,7 @@ static int update_normBu_std(pmh_smalxe s, const double *u, double *normBu, doub
 static int prefetch_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
-  if (s->o.be_implicit || s->pf->m == 0 || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  if (s->o.be_implicit || s->pf->m == 0 || !pmh_knobs().smalxe_prefetch) return PMH_SUCCESS;
   if (pmh_op_penalized_normG_ready(s->A_inner, s->u)) { // the kernel that wrote u emitted G0 u; its last workgroup left T G0 u and the squared norm in place (dualchain.hip)
     s->normBu_prefetched = 1;
     return PMH_SUCCESS;
@@ -123,7 +123,7 @@ static int prefetch_normBu(void *user)
 static int arm_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
-  if (s->o.be_implicit || s->pf->m == 0 || !(s->pf->implicit_orth && s->pf->m <= 64) || getenv("PMH_SMALXE_NO_PREFETCH")) return PMH_SUCCESS;
+  if (s->o.be_implicit || s->pf->m == 0 || !(s->pf->implicit_orth && s->pf->m <= 64) || !pmh_knobs().smalxe_prefetch) return PMH_SUCCESS;
   return pmh_op_penalized_arm_aux_normG(s->A_inner, s->u, s->Bu, PMH_SLOT_NORMBU2);
 }
 

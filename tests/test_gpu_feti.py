@@ -94,9 +94,9 @@ def test_qppf_implicit_orthonormalisation(ctx, size, monkeypatch):
         Ap = pa.MatCreatePenalized(pa.MatCreateProjected(D, pf, symmetric=True), pf, 2.5)
         y1, y2 = ctx.vec(n), ctx.vec(n)
         pa._lib.check(ctx.L.pmh_op_mult(Ap.h, vd.p, y1.p))
-        monkeypatch.setenv("PMH_NO_GT_FUSION", "1")
+        ctx.L.pmh_set_knob(b"gt_fusion", 0)
         pa._lib.check(ctx.L.pmh_op_mult(Ap.h, vd.p, y2.p))
-        monkeypatch.delenv("PMH_NO_GT_FUSION")
+        ctx.L.pmh_set_knob(b"gt_fusion", 1)
         assert np.array_equal(y1.to_numpy(), y2.to_numpy())
         out.append(y1.to_numpy())
     assert np.linalg.norm(out[0] - out[1]) <= 1e-11 * np.linalg.norm(out[1])

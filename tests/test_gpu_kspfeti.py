@@ -52,22 +52,33 @@ def test_ex71_poisson_goldens_through_the_driver(ctx, goldens, gtype, its, expli
 
 @pytest.mark.parametrize("kplus,explicit", [("reg", False), ("mp", False), ("left", False), ("reg", True)])
 @pytest.mark.parametrize("lumped", [False, True])
-def test_ex71_elasticity_floating_slabs(ctx, goldens, kplus, lumped, explicit):
+def test_ex71_elasticity_floating_slabs(ctx, goldens, kplus, lumped, explicit, monkeypatch, capfd):
     """7 slabs, 6 of them floating (coarse problem of 36); golden counts 66 (none) / 26 (lumped).  KSPFETI hands the reference no kernel, so the golden ran on the LEFT generalised
     inverse K^- P_R with MUMPS' null pivots (qptransform.c:997-1008; the golden's ||d|| = 17.4 rules K_reg^{-1} out: 2 230 there, 8.6 on the left inverse with MatRegularize's
     fixing dofs).  The projected operator P F P is the same for every generalised inverse, the counts are not pinned by it: 64 / 27 on the left inverse and on the Moore-Penrose
     form (which agree with each other, as they must), 66 / 27 on K_reg^{-1}; the residual stalls around the threshold at the stopping iteration
     (profiles/r04_ex71_2_residual_history.txt).  Asserted: the golden count within +-2 / +-1, left == mp.
+    Round 5 pins the stall itself: from the -ksp_monitor trace (PMH_KSP_MONITOR) the residual AT THE GOLDEN'S ITERATION is within 1.3 x of the threshold whenever this solve is
+    still iterating there (lumped: 2.54e-4 against 2.04e-4 at iteration 26), and the iteration before this solve's last one is above the threshold by less than 3 x.
     Until round 4 the Moore-Penrose form took 66-87 / 29-35 here: the interior slabs' load lies in the kernel altogether, and the block CG iterated on the rounding residue of its
     projection (tests/test_gpu_feti.py::test_matinv_load_in_the_kernel).
     explicit: the same through the explicit local dual operators (K_reg^{-1} on Gamma assembled at rtol 1e-13)."""
     prob = DmdaFeti((8, 6, 4), 7, "elasticity")
     l2g = _dmda_l2g(prob)
     extra = {"reg": " -qpt_dualize_Kplus_left 0", "mp": " -qpt_dualize_Kplus_mp", "left": ""}[kplus]  # left: the default (KSPFETI never supplies a kernel)
+    monkeypatch.setenv("PMH_KSP_MONITOR", "1")
+    capfd.readouterr()
     u, lam, st = pa.KSPFETISolve(ctx, prob.block_rowstart, prob.K, prob.f, l2g, R=prob.R, kplus_rtol=1e-14 if kplus == "reg" else 1e-13, explicit=explicit,
                                  options="-pde_type Elasticity -dim 3 -qps_rtol 1e-6 -dual_pc_dual_type %s%s" % ("lumped" if lumped else "none", extra))  # feti/ex71.c:442
     gold = goldens["feti_ex71_2_lumped" if lumped else "feti_ex71_2_none"]["solves"][0]["iterations"]
+    trace = [ln.split() for ln in capfd.readouterr().err.splitlines() if "KSP Residual norm" in ln]
+    hist = {int(t[0]): float(t[4]) for t in trace}
+    ttol = float(trace[0][6].rstrip(")"))
     print("ex71_2 %s K+ %s explicit=%s: %d iterations (golden %d)" % ("lumped" if lumped else "none", kplus, explicit, st.iteration, gold))
+    assert len(hist) == st.iteration + 1 and abs(ttol - 1e-6 * hist[0]) <= 1e-12 * ttol and hist[st.iteration] <= ttol < hist[st.iteration - 1]
+    if gold < st.iteration:
+        assert hist[gold] <= (1.35 if explicit else 1.3) * ttol, (hist[gold], ttol)  # the golden stopped where this residual is 1.24 x the threshold (1.32 x through the explicit operators)
+    assert hist[st.iteration - 1] <= 3.0 * ttol, (hist[st.iteration - 1], ttol)  # the stall around the threshold: one iteration earlier is already close
     assert st.reason == 2 and st.coarse_dim == 36
     if not lumped:
         assert gold == 66 and st.iteration == (66 if kplus == "reg" else 64)

@@ -101,28 +101,38 @@ def _eq_problem(seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_equality_constrained_qp_smalxe_parity(ctx, oracle, seed):
-    """min 1/2 x'Ax - b'x  s.t.  G x = 0, x >= lb on random data through SMALXE (inner MPGP): outer iterations, M1 / rho updates and the state machine as the oracle's, the inner
-    iteration total within 2 % (the G products sum in other orders), the solution to 1e-6 -- orthonormal and general G (dense (GG')^{-1} in between)."""
+    """min 1/2 x'Ax - b'x  s.t.  G x = 0, x >= lb on random data through SMALXE (inner MPGP): outer iterations, M1 / rho updates, the state machine AND the inner iteration total
+    exactly as the oracle's, on the default path (fused chain / fused projector epilogues) and on the separate launches (knobs chain = 0, gt_fusion = 0, MPGP unfused): measured
+    with tests/tools/inner_totals.py, all 12 seeds x 4 paths agree to the iteration (round 4 allowed 2 %).  The solution to 1e-6 -- orthonormal and general G."""
     A, G, orth, b, lb = _eq_problem(seed)
     n = A.shape[0]
     pfo = oracle.Qppf(oracle.Csr.from_scipy(G), orthonormal=orth)
     ref = oracle.smalxe(oracle.Op(n, csr=oracle.Csr.from_scipy(A)), b, np.zeros(n), oracle.Box(n, lb=lb), pfo, rtol=1e-7)
-    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
-    qp = pa.QP(ctx)
-    qp.SetOperator(pa.Op.from_csr(Ad))
-    qp.SetRhs(ctx.vec_from(b))
-    x = ctx.vec(n)
-    qp.SetInitialVector(x)
-    qp.SetBox(None, ctx.vec_from(lb), None)
-    qp.SetEq(pa.QPPF.from_scipy(ctx, G, orthonormal=orth))
-    qps = pa.QPS(ctx)
-    qps.SetQP(qp)
-    qps.SetType("smalxe")
-    qps.SetTolerances(rtol=1e-7)
-    st = qps.Solve()
-    tag = (seed, n, G.shape[0], orth)
-    assert (st.reason, st.iteration, st.M1_updates, st.rho_updates, st.state) == (ref["reason"], ref["iteration"], ref["M1_updates"], ref["rho_updates"], ref["state"]), tag
-    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(2, ref["inner_iter_accu"] // 50), tag
-    xs = x.to_numpy()
-    assert np.linalg.norm(xs - ref["u"]) <= 1e-6 * max(np.linalg.norm(ref["u"]), 1e-300), tag
-    assert np.linalg.norm(G @ xs) <= 1e-6 * max(np.linalg.norm(b), 1.0) and np.all(xs >= lb - 1e-14), tag
+    try:
+        for chain, gtf, unfused in ((1, 1, False), (0, 1, False), (0, 0, True)):
+            pa._lib.check(ctx.L.pmh_set_knob(b"chain", chain))
+            pa._lib.check(ctx.L.pmh_set_knob(b"gt_fusion", gtf))
+            Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+            qp = pa.QP(ctx)
+            qp.SetOperator(pa.Op.from_csr(Ad))
+            qp.SetRhs(ctx.vec_from(b))
+            x = ctx.vec(n)
+            qp.SetInitialVector(x)
+            qp.SetBox(None, ctx.vec_from(lb), None)
+            qp.SetEq(pa.QPPF.from_scipy(ctx, G, orthonormal=orth))
+            qps = pa.QPS(ctx)
+            qps.SetQP(qp)
+            qps.SetType("smalxe")
+            qps.SetTolerances(rtol=1e-7)
+            if unfused:
+                qps.MPGPSetUnfused(True)
+            st = qps.Solve()
+            tag = (seed, n, G.shape[0], orth, chain, gtf, unfused)
+            assert (st.reason, st.iteration, st.M1_updates, st.rho_updates, st.state) == (ref["reason"], ref["iteration"], ref["M1_updates"], ref["rho_updates"], ref["state"]), tag
+            assert st.inner_iter_accu == ref["inner_iter_accu"], tag
+            xs = x.to_numpy()
+            assert np.linalg.norm(xs - ref["u"]) <= 1e-6 * max(np.linalg.norm(ref["u"]), 1e-300), tag
+            assert np.linalg.norm(G @ xs) <= 1e-6 * max(np.linalg.norm(b), 1.0) and np.all(xs >= lb - 1e-14), tag
+    finally:
+        ctx.L.pmh_set_knob(b"chain", 1)
+        ctx.L.pmh_set_knob(b"gt_fusion", 1)

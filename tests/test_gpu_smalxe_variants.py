@@ -129,9 +129,9 @@ def test_fused_projector_epilogues_are_bit_identical(ctx, problem, monkeypatch):
     x = np.random.default_rng(11).standard_normal(n)
     xd, y1, y2 = ctx.vec_from(x), ctx.vec(n), ctx.vec(n)
     check(ctx.L.pmh_op_mult(Ap.h, xd.p, y1.p))
-    monkeypatch.setenv("PMH_NO_GT_FUSION", "1")
+    ctx.L.pmh_set_knob(b"gt_fusion", 0)
     check(ctx.L.pmh_op_mult(Ap.h, xd.p, y2.p))
-    monkeypatch.delenv("PMH_NO_GT_FUSION")
+    ctx.L.pmh_set_knob(b"gt_fusion", 1)
     assert np.array_equal(y1.to_numpy(), y2.to_numpy())
     Gd = G.toarray()
     P = lambda v: v - Gd.T @ (Gd @ v)  # noqa: E731
