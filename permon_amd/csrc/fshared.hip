@@ -56,7 +56,7 @@ struct fxs_class {
   signed char             *d_sign = nullptr;
   // orbit storage (fx_shared::sym == 2): only the rows of W_c of the orbit representatives are kept, see the FXO section
   std::vector<int> reps, rep_of, op_of; // all representatives (positions, ascending); per row: its representative's position and the operation that reaches it
-  int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0, tm = 128; // tm: row tile of the GEMM (fxo_row_tile)
+  int              M_all = 0, m0 = 0, m1 = 0, Mp = 0, ldk = 0, nkc = 0, nsymp = 0, tm = 128, tnw = 0; // tm: row tile of the GEMM (fxo_row_tile); tnw = 48: the 48-column kernel (one-block classes)
   long long        aoff = 0, coff = 0;  // offsets of the class in Afund / cpart
   int             *d_gidx = nullptr, *d_reppos = nullptr;
   // output pruning of the orbit GEMM: block (group, slot) touches only part of U_c, so row g p of Y is needed for the slots that touch it only.  Per (group, row tile)
@@ -108,7 +108,7 @@ struct fx_shared {
   long long             *d_wgl = nullptr; // per item: offset of its class's tiles, offset of its transposed partial sums
   int                   *d_items = nullptr, *d_wgfirst = nullptr;
   // several classes on the same row tile: ONE launch over all their work items (fxo_gemm): workgroup -> items with global item numbers, per-class pointer tables
-  int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0, merged_tn = 128;
+  int                   *d_wgfirst_all = nullptr, *d_zrow_of = nullptr, nwg_all = 0, merged_tm = 0, merged_tn = 128, merged_tnw = 0;
   const int            **d_coltab_of = nullptr, **d_gidx_of = nullptr;
   void                  *d_fin_args = nullptr; // fxo_fin_args per class: the classes' finishing launches as one (k_fxo_fin_all)
   int                    fin_nbx = 0, fin_ngroups = 0;
@@ -696,12 +696,16 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
                                                        const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst, const int *const *__restrict__ coltab_of = nullptr,
                                                        const int *__restrict__ zrow_of = nullptr, const int *const *__restrict__ gidx_of = nullptr, const int *__restrict__ xshift_of = nullptr)
 {
+  // TN = 48 (classes of ONE block: at most the 48 operations of the cube as columns): the column LIST and the partial tiles keep their stride of 64 (TNL), the gathers fill 64 columns
+  // of the LDS image (16 of them from the zero row) and only 48 are multiplied -- 4 waves down the rows (NWM = 4), 3 column blocks each
+  constexpr int TNL = TN == 48 ? 64 : TN;
   constexpr int NWN = 4 / NWM, NJ = TN / (16 * NWN), WC = 16 * NJ, TM = 16 * NI * NWM, WR = 16 * NI, LDA = TM + 16;
+  static_assert(TN == 128 || TN == 64 || (TN == 48 && NWM == 4), "column tile");
   // (Round 5, measured and not adopted: a THREE-stage operand pipeline -- the registers that hold chunk kc + 1 stored to LDS at the START of chunk kc, under the products, then
   // asked to fetch chunk kc + 2; the barrier directly behind the last product.  Same bits; 0.651 instead of 0.656-0.67 of the fp64 peak on the 144 x 128 tile (256 VGPRs, an
   // 8-byte spill), 0.506 instead of 0.51 on the 64-wide tile: the tail of a chunk -- wait, 13 LDS writes, barrier -- is not what the pipe waits for.)
   __shared__ double As[2][FXO_TK][LDA];
-  __shared__ double Bs[2][FXO_TK][TN + 16];
+  __shared__ double Bs[2][FXO_TK][TNL + 16];
   for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
   __builtin_amdgcn_sched_barrier(0);
   const int *w8 = items + 8 * it;
@@ -714,9 +718,9 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
   const double *__restrict__ x  = X + iteml[4 * it + 1];
   double *__restrict__ C        = cpart + iteml[4 * it + 2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / NWN, wn = wave % NWN;
-  constexpr int NQ = FXO_TK * TM / 2, NEA = NQ / 256, RA = NQ % 256, KPB = 256 / TN, NEB = FXO_TK / KPB; // a chunk of A: NEA passes of 16 bytes per lane + (RA = 128) one of 8
+  constexpr int NQ = FXO_TK * TM / 2, NEA = NQ / 256, RA = NQ % 256, KPB = 256 / TNL, NEB = FXO_TK / KPB; // a chunk of A: NEA passes of 16 bytes per lane + (RA = 128) one of 8
   static_assert(RA == 0 || RA == 128, "row tile");
-  const int  col = t % TN, kb = t / TN;
+  const int  col = t % TNL, kb = t / TNL;
   const int  ct  = coltab[iteml[4 * it + 3] + col];
   const int  sl  = ct < 0 ? 0 : (ct & 7);
   const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * TN + wn * WC + j * 16 + ra] = acc[i][j][r];
+      for (int r = 0; r < 4; r++) C[(long long)(wm * WR + i * 16 + ka + 4 * r) * ncol + nt * TNL + wn * WC + j * 16 + ra] = acc[i][j][r];
   }
 }
 
@@ -1409,6 +1413,13 @@ static int fxo_prepare(fx_shared *S)
     C.m0 = 0, C.m1 = C.M_all;
     const int M = C.m1 - C.m0;
     C.tm   = fxo_row_tile(M);
+    C.tnw  = 0;
+    if (S->mfma16 && C.S == 1 && C.nsym * C.S <= 48 && !getenv("PMH_FXO_NO_TN48")) {
+      // a class of ONE block lists at most 48 columns: the 64-wide tile multiplies a quarter of zeros.  48 columns x (4 waves x NI x 16 rows): 192 rows unless fewer pad less
+      C.tnw = 48, C.tm = 192;
+      for (int tm : {128, 64})
+        if ((M + tm - 1) / tm * tm < (M + C.tm - 1) / C.tm * C.tm) C.tm = tm;
+    }
     C.Mp   = std::max(1, (M + C.tm - 1) / C.tm) * C.tm;
     C.nsymp = (C.nsym + FXO_TN / 8 - 1) / (FXO_TN / 8) * (FXO_TN / 8);
     std::vector<int>         reppos((size_t)C.Mp, 0);
@@ -1649,12 +1660,12 @@ static int fxo_prepare(fx_shared *S)
   const int rank = S->stripe_size > 1 ? S->stripe_rank : 0, size = std::max(1, S->stripe_size);
   const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
   // several classes on one row tile share ONE launch (fxo_gemm): the resident workgroups are divided among them
-  int nplanned = 0, tm_first = 0, tn_first = 128;
+  int nplanned = 0, tm_first = 0, tn_first = 128, tnw_first = 0;
   bool one_tile = S->mfma16 && !getenv("PMH_FXO_NO_MERGE");
   for (int c = 0; c < S->ncls; c++)
     if (tab_of[c] >= 0) {
-      if (!nplanned) tm_first = S->C[c].tm, tn_first = S->C[c].tn;
-      else if (S->C[c].tm != tm_first || S->C[c].tn != tn_first) one_tile = false;
+      if (!nplanned) tm_first = S->C[c].tm, tn_first = S->C[c].tn, tnw_first = S->C[c].tnw;
+      else if (S->C[c].tm != tm_first || S->C[c].tn != tn_first || S->C[c].tnw != tnw_first) one_tile = false;
       nplanned++;
     }
   bool small_records = false; // a class with fewer than 8 slots per record: only the table-driven kernel knows the record size
@@ -1934,7 +1945,7 @@ static int fxo_prepare(fx_shared *S)
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_coltab_of, ct.data(), sizeof(const int *) * ct.size()));
     PMH_CHK(pmh_malloc(ctx, sizeof(const int *) * gi.size(), (void **)&S->d_gidx_of));
     PMH_CHK(pmh_memcpy_h2d(ctx, (void *)S->d_gidx_of, gi.data(), sizeof(const int *) * gi.size()));
-    S->merged_tm = merged ? tm_first : 0, S->merged_tn = tn_first;
+    S->merged_tm = merged ? tm_first : 0, S->merged_tn = tn_first, S->merged_tnw = tnw_first;
   }
   if (S->d_fin_args) pmh_free(ctx, S->d_fin_args), S->d_fin_args = nullptr;
   S->fin_nbx = S->fin_ngroups = 0;
@@ -1965,7 +1976,10 @@ static int fxo_gemm(fx_shared *S)
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(S->nwg_all), dim3(256), 0, st, (const int *)S->d_items, (const long long *)S->d_wgl, (const int *)S->d_wg,                 \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)S->d_wgfirst_all, \
                      (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
-    switch (S->merged_tm + (S->merged_tn == 64 ? 1 : 0)) {
+    switch (S->merged_tm + (S->merged_tn == 64 ? 1 : 0) + (S->merged_tnw == 48 ? 1 : 0)) {
+    case 194: FXO_LAUNCH_ALL(3, 4, 48); break;
+    case 130: FXO_LAUNCH_ALL(2, 4, 48); break;
+    case 66: FXO_LAUNCH_ALL(1, 4, 48); break;
     case 144: FXO_LAUNCH_ALL(9, 1, 128); break;
     case 145: FXO_LAUNCH_ALL(9, 1, 64); break;
     case 128: FXO_LAUNCH_ALL(4, 2, 128); break;
@@ -2005,7 +2019,10 @@ static int fxo_gemm(fx_shared *S)
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first),     \
                      (const int *const *)S->d_coltab_of, (const int *)S->d_zrow_of, (const int *const *)S->d_gidx_of, (const int *)(S->d_zrow_of + S->ncls))
-      switch (C.tm + (C.tn == 64 ? 1 : 0)) {
+      switch (C.tm + (C.tn == 64 ? 1 : 0) + (C.tnw == 48 ? 1 : 0)) {
+      case 194: FXO_LAUNCH_T(3, 4, 48); break;
+      case 130: FXO_LAUNCH_T(2, 4, 48); break;
+      case 66: FXO_LAUNCH_T(1, 4, 48); break;
       case 144: FXO_LAUNCH_T(9, 1, 128); break;
       case 145: FXO_LAUNCH_T(9, 1, 64); break;
       case 128: FXO_LAUNCH_T(4, 2, 128); break;
