@@ -271,9 +271,10 @@ extern "C" int pmh_comm_rank(pmh_ctx c, int *rank, int *size)
   return PMH_SUCCESS;
 }
 
-// Host-staged transport of the collectives: device -> pinned host -> fn (an in-place all-reduce over the ranks, e.g. MPI_Allreduce(MPI_IN_PLACE, ...) on the communicator of the
-// PETSc objects the glue was handed) -> device, in stream order.  For deployments whose ranks cannot form an RCCL communicator (several ranks per GPU, a fabric RCCL does not
-// drive) and for the 2-process tests on a one-GPU box; RCCL over xGMI (pmh_comm_init) stays the transport of the benchmarked path.
+// Host-staged transport of the collectives: device -> pinned host -> fn (an in-place all-reduce over the ranks, e.g. MPI_Allreduce(MPI_IN_PLACE, ...) on the
+// communicator of the PETSc objects the glue was handed) -> device, in stream order.  For deployments whose ranks cannot form an RCCL communicator (several
+// ranks per GPU, a fabric RCCL does not drive) and for the 2-process tests on a one-GPU box; RCCL over xGMI (pmh_comm_init) stays the transport of the
+// benchmarked path.
 extern "C" int pmh_comm_set_host_transport(pmh_ctx c, int rank, int size, pmh_comm_host_fn fn, void *user)
 {
   PMH_ARG(c && size >= 1 && rank >= 0 && rank < size);
@@ -281,7 +282,8 @@ extern "C" int pmh_comm_set_host_transport(pmh_ctx c, int rank, int size, pmh_co
   const bool had_hook = c->hook != nullptr;
   c->hook = fn, c->hook_user = user;
   if (fn) c->rank = rank, c->size = size;
-  else if (had_hook && !c->comm) c->rank = 0, c->size = 1; // removing the hook of a context that had nothing else: one rank again (an RCCL communicator keeps its rank / size)
+  // removing the hook of a context that had nothing else: one rank again (an RCCL communicator keeps its rank / size)
+  else if (had_hook && !c->comm) c->rank = 0, c->size = 1;
   return PMH_SUCCESS;
 }
 
@@ -296,7 +298,8 @@ static int host_reduce(pmh_ctx c, int op, double *dbuf, size_t count)
   if (count) PMH_HIP(hipMemcpyAsync(c->h_stage, dbuf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
   PMH_HIP(hipStreamSynchronize(c->stream));
   if (const int rc = c->hook(c->hook_user, op, c->h_stage, count)) return pmh_set_error(PMH_ERR_COMM, "host transport: the all-reduce callback returned %d", rc);
-  if (count) PMH_HIP(hipMemcpyAsync(dbuf, c->h_stage, sizeof(double) * count, hipMemcpyHostToDevice, c->stream)); // (the next staging copy is ordered behind it on the stream)
+  // (the next staging copy is ordered behind it on the stream)
+  if (count) PMH_HIP(hipMemcpyAsync(dbuf, c->h_stage, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
   return PMH_SUCCESS;
 }
 
@@ -317,7 +320,8 @@ extern "C" int pmh_comm_allreduce_sum(pmh_ctx c, double *dbuf, size_t count)
   return PMH_SUCCESS;
 }
 
-// event pairs around the next max_events vector all-reduces (0: off, frees the events); pmh_comm_timing_get: how many were timed, their total milliseconds and bytes
+// event pairs around the next max_events vector all-reduces (0: off, frees the events); pmh_comm_timing_get: how many were timed, their total milliseconds and
+// bytes
 extern "C" int pmh_comm_timing_enable(pmh_ctx c, int max_events)
 {
   PMH_ARG(c && max_events >= 0);

@@ -3,7 +3,8 @@
 //     y = rho Q x + P F P x,   Q = G0' S G0,  P = I - Q,  F = Bs (middle) Bg'        (S = T'T = (G0 G0')^{-1}: implicit orthonormalisation)
 //
 // (MatMult_Penalized src/qp/utils/matpenalized.c:12-22 over MatCreateProd(P, F, P) src/qp/interface/qptransform.c:273-284 with QPPFApplyQ / QPPFApplyP
-// src/qppf/interface/qppf.c:454-503,563-575 and MatMult(Transpose)_Gluing src/mat/impls/gluing/gluing.c:47-159) in FIVE launches, two of them the middle stage's:
+// src/qppf/interface/qppf.c:454-503,563-575 and MatMult(Transpose)_Gluing src/mat/impls/gluing/gluing.c:47-159) in FIVE launches, two of them the middle
+// stage's:
 //
 //     [the kernel that wrote x left the segment sums of G0 x behind (emit_inline.h; k_dc_emit where nobody did)]
 //     k_dc_gather    a = G0 x from the segment sums, c = S a;  mid_in = Bg' (x - G0' c): the projection is recomputed per gathered entry, P x is never stored
@@ -57,10 +58,10 @@ struct pmh_dualchain_s {
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------------
-// All of them are made of memory latencies, not of bytes (the dual space has ~10^5 entries): what counts is the number of DEPENDENT load levels and that every wave is
-// resident at once.  G0' is therefore kept as a fixed-width slot copy (W = 8 or 16 entries per row, one byte per column: m <= 64) addressed by the row number alone, the
-// gather visits only the rows of Bg' that have entries (the others are zero once and for all) through one record per row, the scatter matrix keeps its first two
-// entries per row at fixed places.
+// All of them are made of memory latencies, not of bytes (the dual space has ~10^5 entries): what counts is the number of DEPENDENT load levels and that every
+// wave is resident at once.  G0' is therefore kept as a fixed-width slot copy (W = 8 or 16 entries per row, one byte per column: m <= 64) addressed by the row
+// number alone, the gather visits only the rows of Bg' that have entries (the others are zero once and for all) through one record per row, the scatter matrix
+// keeps its first two entries per row at fixed places.
 
 // G0 x for a vector nobody emitted (the first product of a solve, plain MatMult callers)
 __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_emit(int n, const double *__restrict__ x, pmh_emit_args ea)
@@ -110,12 +111,12 @@ static __device__ __forceinline__ void dc_gt_load(const double *__restrict__ ev,
   }
 }
 
-// a = G0 x from the segment sums, c = S a (every workgroup for itself, overlapping its record loads; workgroup 0 leaves c for k_dc_final, the last workgroup forms
-// SMALXE's T G0 u and ||T G0 u||^2 where an emission of the iterate is waiting for it).  Then
-// mid_in[r] = sum_k Bg'[r][k] (x - G0' c)[col k] for the rows of Bg' that have entries, each sum left to right as the plain loops take it: row r as MatMult_SeqAIJ sums
-// it, (P x)_j = -1 (G0' c)_j + x_j as QPPFApplyP's VecAYPX forms it (qppf.c:563-575).  One record per listed row: the row, its first three entries (more: the rest from
-// the CSR) and -- where another row holds the same entries with the opposite signs (the +x / -x copies of the orbit GEMM's multivector) -- that partner row, which gets
-// the negated sum (exactly what its own left-to-right sum would be).
+// a = G0 x from the segment sums, c = S a (every workgroup for itself, overlapping its record loads; workgroup 0 leaves c for k_dc_final, the last workgroup
+// forms SMALXE's T G0 u and ||T G0 u||^2 where an emission of the iterate is waiting for it).  Then mid_in[r] = sum_k Bg'[r][k] (x - G0' c)[col k] for the rows
+// of Bg' that have entries, each sum left to right as the plain loops take it: row r as MatMult_SeqAIJ sums it, (P x)_j = -1 (G0' c)_j + x_j as QPPFApplyP's
+// VecAYPX forms it (qppf.c:563-575).  One record per listed row: the row, its first three entries (more: the rest from the CSR) and -- where another row holds
+// the same entries with the opposite signs (the +x / -x copies of the orbit GEMM's multivector) -- that partner row, which gets the negated sum (exactly what
+// its own left-to-right sum would be).
 struct dc_norm_args {
   const double *part, *Tt; // the iterate's segment sums, T' (nullptr: nothing to do)
   double       *y2, *norm_d, *norm_h;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_gather(int nlist, const in
 #pragma unroll
   for (int e = 0; e < W; e++) v0[e] = 0.0, c0[e] = 0;
   if (cnt > 0) dc_gt_load<W>(ev, ec, j[0], v0, c0); // most rows have ONE entry: its row of G0' travels with the coarse sums
-  if (na.part && blockIdx.x == gridDim.x - 1) {     // uniform: the extra workgroup forms SMALXE's T G0 u and ||T G0 u||^2 (it has no rows of its own: i >= nlist)
+  // uniform: the extra workgroup forms SMALXE's T G0 u and ||T G0 u||^2 (it has no rows of its own: i >= nlist)
+  if (na.part && blockIdx.x == gridDim.x - 1) {
     double s1, s2;
     pmh_coarse_share<4, NU>(tab, na.part, na.Tt, nullptr, nullptr, s1, s2);
     pt[wave][lane] = s1;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsig
   pmh_emit_tail(ea, R, sum, 0.0);
 }
 
-// d = G0 w from the segment sums behind w, e = S d; out = rho (G0' c)_j + (w_j - (G0' e)_j) -- VecAYPX, VecScale, VecAXPY of matpenalized.c:12-22 per entry -- and the
-// MPGP vector phase: its block partials go to the device rows and to the pinned host copy, the segment sums of G0 p to the direction's target
+// d = G0 w from the segment sums behind w, e = S d; out = rho (G0' c)_j + (w_j - (G0' e)_j) -- VecAYPX, VecScale, VecAXPY of matpenalized.c:12-22 per entry --
+// and the MPGP vector phase: its block partials go to the device rows and to the pinned host copy, the segment sums of G0 p to the direction's target
 template <int EPI, int W, int NU>
 __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab, const double *__restrict__ S,
                                                           const double *__restrict__ cin, const double *__restrict__ w, double rho, double *__restrict__ y, pmh_vec_epi epi,
@@ -401,8 +403,8 @@ int pmh_dc_create(pmh_qppf pf, pmh_op F, pmh_dualchain *out)
   return PMH_SUCCESS;
 }
 
-// the records of the gather matrix's rows that have entries (the rest of mid_in is zeroed here, once: nothing but an SpMV with the same matrix ever writes there -- zeros
-// again) and the fixed-place copy of the scatter matrix
+// the records of the gather matrix's rows that have entries (the rest of mid_in is zeroed here, once: nothing but an SpMV with the same matrix ever writes
+// there -- zeros again) and the fixed-place copy of the scatter matrix
 static int dc_prepare_stages(pmh_dualchain dc)
 {
   pmh_ctx ctx = dc->ctx;
@@ -541,8 +543,8 @@ int pmh_dc_set_norm_target(pmh_dualchain dc, double *Gu, int slot)
   return PMH_SUCCESS;
 }
 
-// T G0 u and its squared norm are (as far as the stream has got) in place for this u; where the iterate's segment sums are there but no application has followed, one
-// small launch forms them
+// T G0 u and its squared norm are (as far as the stream has got) in place for this u; where the iterate's segment sums are there but no application has
+// followed, one small launch forms them
 bool pmh_dc_norm_ready(pmh_dualchain dc, const double *u)
 {
   if (!dc || !dc->normGu) return false;
@@ -620,7 +622,8 @@ int pmh_dc_apply(pmh_dualchain dc, const double *x, double *y, double rho, const
     dc->launches++;
   }
   PMH_HIP(hipGetLastError());
-  PMH_CHK(pmh_comm_allreduce_sum(ctx, dc->w, (size_t)n + (size_t)dc->nseg)); // the ranks' shares of B u and of the sums of G0 (B u) in one exchange (PetscSFReduce, gluing.c:144-147)
+  // the ranks' shares of B u and of the sums of G0 (B u) in one exchange (PetscSFReduce, gluing.c:144-147)
+  PMH_CHK(pmh_comm_allreduce_sum(ctx, dc->w, (size_t)n + (size_t)dc->nseg));
   // 5. the second projection, the penalty term and the vector phase
   {
     pmh_emit_args ea;

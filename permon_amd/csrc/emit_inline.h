@@ -1,14 +1,16 @@
 // Coarse-space emission (device side), shared by the fused dual-space chain (dualchain.hip) and the MPGP vector kernels (mpgp.hip).
 //
-// The projector Q = G0' S G0 (src/qppf/interface/qppf.c:454-503) needs a = G0 v for every vector v an operator application starts from.  G0 (m = 6 x #subdomains rows,
-// each ~10^4 entries long) is cut into (row, tile of 1024 columns) SEGMENTS.  The kernel that WRITES v -- workgroups of 1024 threads, thread t of workgroup b owns entry
-// 1024 b + t -- keeps its fresh values in LDS and sums its own segments (one of the 16 waves per segment, fixed tree): G0 v needs no launch of its own.  The kernel that
-// READS a = G0 v (the next one in the stream) adds the segment sums per row in segment order itself, every workgroup for itself: ~2500 numbers out of L2.
+// The projector Q = G0' S G0 (src/qppf/interface/qppf.c:454-503) needs a = G0 v for every vector v an operator application starts from.  G0 (m = 6 x
+// #subdomains rows, each ~10^4 entries long) is cut into (row, tile of 1024 columns) SEGMENTS.  The kernel that WRITES v -- workgroups of 1024 threads, thread
+// t of workgroup b owns entry 1024 b + t -- keeps its fresh values in LDS and sums its own segments (one of the 16 waves per segment, fixed tree): G0 v needs
+// no launch of its own.  The kernel that READS a = G0 v (the next one in the stream) adds the segment sums per row in segment order itself, every workgroup for
+// itself: ~2500 numbers out of L2.
 //
-// Built, measured and dropped on the way here (profiles/r05_ticket_micro.txt, docs/LAB_NOTEBOOK.md): a "last workgroup done" ticket that finishes a = G0 v and the scalar
-// reductions inside the producing kernel.  The textbook ticket (__threadfence + acq_rel atomic) costs 31 us per 400 workgroups -- the release fence writes back the L2 in every
-// workgroup; with agent-scope stores / loads of the partial sums only and a relaxed counter it is 1.4 us per 100 workgroups, but the chain store -> counter -> load across
-// XCDs still adds ~10 us of fabric round trips to a 3 us kernel.  The consumer-side sum costs one L2 round trip that overlaps with the consumer's own loads.
+// Built, measured and dropped on the way here (profiles/r05_ticket_micro.txt, docs/LAB_NOTEBOOK.md): a "last workgroup done" ticket that finishes a = G0 v and
+// the scalar reductions inside the producing kernel.  The textbook ticket (__threadfence + acq_rel atomic) costs 31 us per 400 workgroups -- the release fence
+// writes back the L2 in every workgroup; with agent-scope stores / loads of the partial sums only and a relaxed counter it is 1.4 us per 100 workgroups, but
+// the chain store -> counter -> load across XCDs still adds ~10 us of fabric round trips to a 3 us kernel.  The consumer-side sum costs one L2 round trip that
+// overlaps with the consumer's own loads.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,8 +28,9 @@ static __device__ __forceinline__ double pmh_dpp_mov(double v)
   return __hiloint2double(hi, lo);
 }
 
-// the sum of the 64 lanes' values in EVERY lane: butterflies inside a row of 16 lanes on the DPP cross-bar (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror:
-// both partners of an exchange add the same two numbers), then the four row sums through scalar registers, (r0 + r1) + (r2 + r3).  MIN: the same exchanges with fmin.
+// the sum of the 64 lanes' values in EVERY lane: butterflies inside a row of 16 lanes on the DPP cross-bar (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror: both partners of an exchange add the same two numbers), then the four row sums through scalar registers, (r0 + r1) + (r2 + r3).  MIN: the same
+// exchanges with fmin.
 template <int OP = PMH_RED_SUM>
 static __device__ __forceinline__ double pmh_wave_all(double v)
 {
@@ -45,8 +48,8 @@ static __device__ __forceinline__ double pmh_wave_all(double v)
 #undef PMH_COMB
 }
 
-// a workgroup's partial sums of K quantities: wave tree, the waves in order; row k goes to partials[k ld + blockIdx.x] on the device AND in the pinned host copy (the host
-// adds the block sums itself after its next wait: no finalising launch; device consumers add them in their preamble, pmh_sum_block_partials)
+// a workgroup's partial sums of K quantities: wave tree, the waves in order; row k goes to partials[k ld + blockIdx.x] on the device AND in the pinned host
+// copy (the host adds the block sums itself after its next wait: no finalising launch; device consumers add them in their preamble, pmh_sum_block_partials)
 template <int K>
 static __device__ __forceinline__ void pmh_block_partials(const double (&v)[K], const int (&op)[K], double *__restrict__ partials, double *__restrict__ h_partials, int ld)
 {
@@ -67,7 +70,8 @@ static __device__ __forceinline__ void pmh_block_partials(const double (&v)[K], 
   }
 }
 
-// the sum of one row of block partials (nblocks <= 512) in every lane of the calling wave: lane l adds its entries l, l + 64, ... in that order, then the wave tree
+// the sum of one row of block partials (nblocks <= 512) in every lane of the calling wave: lane l adds its entries l, l + 64, ... in that order, then the wave
+// tree
 static __device__ __forceinline__ double pmh_sum_block_partials(const double *__restrict__ row, int nblocks)
 {
   const int lane = threadIdx.x & 63;
@@ -80,11 +84,12 @@ static __device__ __forceinline__ double pmh_sum_block_partials(const double *__
   return pmh_wave_all<PMH_RED_SUM>(acc);
 }
 
-// Emission by a kernel of PMH_EMIT_TILE-thread workgroups whose thread t of workgroup b writes entry 1024 b + t of up to two vectors (v0 -> target 0, v1 -> target 1; a
-// target with part == nullptr is off; entries past the end of the vector: 0): the segment sums of G0 v, in two halves.  pmh_emit_prefetch at the START of the kernel requests
-// what does not depend on the values -- the tile's segment descriptors (fixed places in the table: 64 per tile, absent ones empty; a wave takes the segments wave,
-// wave + 16, ...) and the first 256 entries of each of the wave's four segments -- so that these latencies run under the kernel's own work; pmh_emit_tail at the END puts the
-// fresh values into LDS and sums.  Every thread of every workgroup must call both (barrier inside the tail).
+// Emission by a kernel of PMH_EMIT_TILE-thread workgroups whose thread t of workgroup b writes entry 1024 b + t of up to two vectors (v0 -> target 0, v1 ->
+// target 1; a target with part == nullptr is off; entries past the end of the vector: 0): the segment sums of G0 v, in two halves.  pmh_emit_prefetch at the
+// START of the kernel requests what does not depend on the values -- the tile's segment descriptors (fixed places in the table: 64 per tile, absent ones empty;
+// a wave takes the segments wave, wave + 16, ...) and the first 256 entries of each of the wave's four segments -- so that these latencies run under the
+// kernel's own work; pmh_emit_tail at the END puts the fresh values into LDS and sums.  Every thread of every workgroup must call both (barrier inside the
+// tail).
 struct pmh_emit_regs {
   int    k0[4], k1[4], pp[4], gc[4][4];
   double gv[4][4];
@@ -138,11 +143,11 @@ static __device__ __forceinline__ void pmh_emit_tail(const pmh_emit_args &ea, co
   }
 }
 
-// Consumer side: a = G0 v from the segment sums and the share of the calling wave in M a for up to two m x m matrices given by rows (lane = column).  Wave w of nw owns the
-// rows r = w + nw q of G0 (q < RPW: 4 for 16 waves, 16 for 4 waves; m <= 64); a row has at most one segment sum per tile (<= 512), added lane-strided in segment
-// order, then the wave tree.  Returns, per lane (= column), s1 = sum_q M1[r_q][lane] a[r_q] and s2 likewise for M2 (0 where the pointer is null); a[r] also goes to
-// a_out[r] (LDS or global; may be null).  The caller adds the waves' shares in wave order.  NU: 64 NU >= the number of tiles (2 serves up to 131 072 dual entries
-// with a quarter of the registers of 8).
+// Consumer side: a = G0 v from the segment sums and the share of the calling wave in M a for up to two m x m matrices given by rows (lane = column).  Wave w of
+// nw owns the rows r = w + nw q of G0 (q < RPW: 4 for 16 waves, 16 for 4 waves; m <= 64); a row has at most one segment sum per tile (<= 512), added
+// lane-strided in segment order, then the wave tree.  Returns, per lane (= column), s1 = sum_q M1[r_q][lane] a[r_q] and s2 likewise for M2 (0 where the pointer
+// is null); a[r] also goes to a_out[r] (LDS or global; may be null).  The caller adds the waves' shares in wave order.  NU: 64 NU >= the number of tiles (2
+// serves up to 131 072 dual entries with a quarter of the registers of 8).
 template <int RPW, int NU = 8>
 static __device__ __forceinline__ void pmh_coarse_share(const pmh_emit_tab &tab, const double *__restrict__ part, const double *__restrict__ M1, const double *__restrict__ M2, double *a_out,
                                                        double &s1, double &s2)

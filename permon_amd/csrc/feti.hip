@@ -244,8 +244,8 @@ extern "C" int pmh_blockdiag_mult(pmh_blockdiag K, const double *x, double *y)
 }
 
 // MatMult_BlockDiag on a 3x3-block device copy (the role MATSEQBAIJ bs = 3 plays for the reference's elasticity blocks): 8.44 instead of 12 bytes per non-zero.
-// share != 0: blocks of equal size are compared entry by entry and, when congruent, ONE device copy serves all of them (the product then reads most of K from L2, not HBM);
-// share == 0: one device copy per block, every byte streamed from HBM.
+// share != 0: blocks of equal size are compared entry by entry and, when congruent, ONE device copy serves all of them (the product then reads most of K from
+// L2, not HBM); share == 0: one device copy per block, every byte streamed from HBM.
 extern "C" int pmh_blockdiag_enable_bsr3(pmh_blockdiag K, int share)
 {
   PMH_ARG(K);
@@ -265,7 +265,8 @@ extern "C" int pmh_blockdiag_timing_enable(pmh_blockdiag K, int max_launches)
   return K->Kb ? pmh_bsr3_timing_enable(K->Kb, max_launches) : pmh_csr_timing_enable(K->K, max_launches);
 }
 
-// csr_bytes: SURVEY 8d's figure 12 nnz + 20 n of the product; hbm_bytes: what the kernel in use has to move from HBM per launch (the stored format's bytes, a shared copy once)
+// csr_bytes: SURVEY 8d's figure 12 nnz + 20 n of the product; hbm_bytes: what the kernel in use has to move from HBM per launch (the stored format's bytes, a
+// shared copy once)
 extern "C" int pmh_blockdiag_timing_get(pmh_blockdiag K, int *launches, double *total_ms, double *csr_bytes, double *hbm_bytes, int *device_copies)
 {
   PMH_ARG(K && launches && total_ms);
@@ -381,12 +382,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_cg_start_pz(const int *__restrict
   if (threadIdx.x == 0) part[blockIdx.x] = s0;
 }
 
-// one workgroup per block: rz, tolerance (KSPConvergedDefault: ||r|| <= max(rtol ||b||, atol), zero initial guess), active set
-// fnorm2 (optional): ||f_b||^2 of the right-hand side BEFORE its projection onto the range of K.  A block whose load lies in the kernel altogether (ex71's interior slabs under a
-// uniform body force: ||P_R f|| = 1e-15 ||f||) has a right-hand side that is pure rounding residue of the projection, NOT in the range of the singular K: CG on it diverges along
-// the kernel and pollutes the range (measured: 1e-4 absolute).  DEVIATION from the reference (whose K^+ is a factorisation and has no such case), stated in DESIGN.md:
-// ||P_R f_b|| <= kernel_tol eps ||f_b|| -> the block's load is taken as zero (u_b = 0, the Moore-Penrose image of a load in the kernel).  Every other block keeps the plain
-// KSPConvergedDefault threshold (round 4 floored EVERY block's threshold at 16 eps ||f_b||: that also loosened the set-up solves of the explicit operators at rtol 1e-13).
+// one workgroup per block: rz, tolerance (KSPConvergedDefault: ||r|| <= max(rtol ||b||, atol), zero initial guess), active set fnorm2 (optional): ||f_b||^2 of
+// the right-hand side BEFORE its projection onto the range of K.  A block whose load lies in the kernel altogether (ex71's interior slabs under a uniform body
+// force: ||P_R f|| = 1e-15 ||f||) has a right-hand side that is pure rounding residue of the projection, NOT in the range of the singular K: CG on it diverges
+// along the kernel and pollutes the range (measured: 1e-4 absolute).  DEVIATION from the reference (whose K^+ is a factorisation and has no such case), stated
+// in DESIGN.md: ||P_R f_b|| <= kernel_tol eps ||f_b|| -> the block's load is taken as zero (u_b = 0, the Moore-Penrose image of a load in the kernel).  Every
+// other block keeps the plain KSPConvergedDefault threshold (round 4 floored EVERY block's threshold at 16 eps ||f_b||: that also loosened the set-up solves of
+// the explicit operators at rtol 1e-13).
 __global__ __launch_bounds__(PMH_BLOCK) void k_cg_init(int nb, int wgs, int ld, const double *__restrict__ part, double *__restrict__ bs, int *__restrict__ bi, int *__restrict__ nactive, int *__restrict__ done, double rtol, double atol,
                                                        const double *__restrict__ fnorm2, double kernel_tol)
 {
@@ -620,10 +622,11 @@ __global__ void k_zero_entries(int n, const int *__restrict__ idx, double *__res
   if (i < n) v[idx[i]] = 0.0;
 }
 
-// K^+ := K^- P_R, the left generalised inverse QPTDualize takes when PERMON had to compute the kernel itself (qptransform.c:997-1008: "computed null space matrix => using
-// -qpt_dualize_Kplus_left and -regularize 0"; :1040-1062: MatCreateProd of P_R and K^-).  K^- is what a factorisation with null-pivot detection returns: the null-pivot
-// ("fixing") dofs carry a zero and their equations are dropped.  Here: the matrix handed to pmh_matinv_create has those dofs' rows / columns replaced by the identity (SPD),
-// this call names them (ascending local indices over all blocks) so that their right-hand side entries are zeroed, and the result is NOT projected.  nfix == 0 turns it off.
+// K^+ := K^- P_R, the left generalised inverse QPTDualize takes when PERMON had to compute the kernel itself (qptransform.c:997-1008: "computed null space
+// matrix => using -qpt_dualize_Kplus_left and -regularize 0"; :1040-1062: MatCreateProd of P_R and K^-).  K^- is what a factorisation with null-pivot detection
+// returns: the null-pivot ("fixing") dofs carry a zero and their equations are dropped.  Here: the matrix handed to pmh_matinv_create has those dofs' rows /
+// columns replaced by the identity (SPD), this call names them (ascending local indices over all blocks) so that their right-hand side entries are zeroed, and
+// the result is NOT projected.  nfix == 0 turns it off.
 extern "C" int pmh_matinv_set_left_inverse(pmh_matinv M, int nfix, const int *fix_dofs_host)
 {
   PMH_ARG(M && nfix >= 0 && (nfix == 0 || fix_dofs_host));
@@ -848,8 +851,8 @@ struct FetiDualOp : pmh_op_s {
     return pmh_gluing_mult_transpose(B, t2, y);
   }
   int mult_transpose(const double *x, double *y) override { return mult(x, y); } // F = B K^+ B' is symmetric
-  // the three stages of the product for the fused dual-space chain (dualchain.hip): B' as the gather, K^+ (explicit local dual operators or the inner Krylov solve) in the
-  // middle, B as the scatter -- the all-reduce that ends B u on several GPUs is the chain's
+  // the three stages of the product for the fused dual-space chain (dualchain.hip): B' as the gather, K^+ (explicit local dual operators or the inner Krylov
+  // solve) in the middle, B as the scatter -- the all-reduce that ends B u on several GPUs is the chain's
   int stages(pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out) override
   {
     if (Kplus->E && pmh_fexplicit_matches(Kplus->E, B)) return pmh_fexplicit_stages(Kplus->E, gather, mid_in, scatter, mid_out);
@@ -988,13 +991,16 @@ extern "C" int pmh_qpt_feti_chain_post_solve(pmh_feti_chain ch, const double *la
   return PMH_SUCCESS;
 }
 
-// The numbers behind -qp_chain_view_kkt for the QPs this chain stands for (QPViewKKT, src/qp/interface/qp.c:245-369, called by QPChainPostSolve qpchain.c:247-268 on every QP
-// from the last one up, each AFTER the post-solve of the QP below it and QPComputeMissingEqMultiplier :777-826 on itself).  Linear chain (no dual box):
+// The numbers behind -qp_chain_view_kkt for the QPs this chain stands for (QPViewKKT, src/qp/interface/qp.c:245-369, called by QPChainPostSolve
+// qpchain.c:247-268 on every QP from the last one up, each AFTER the post-solve of the QP below it and QPComputeMissingEqMultiplier :777-826 on itself). 
+// Linear chain (no dual box):
 //   projected QP     A = P F, b = P b_bar                      : ||A x - b||, ||b||                                        (only with a coarse problem)
-//   homogenised QP   A = F, b = b_bar, BE = G, cE = 0          : Bt_lambda := -(F x - b_bar) (the missing multiplier: BE == B :806-808) => r = 0 exactly; ||G x||; ||b_bar||
-//   dual QP (x2)     A = F, b = d, BE = G, cE = e              : the Bt_lambda vector is SHARED with the homogenised QP (QP_DUPLICATE_COPY_POINTERS, qp.c:197): r = ||F lambda - d + Bt_lambda||,
+//   homogenised QP A = F, b = b_bar, BE = G, cE = 0 : Bt_lambda := -(F x - b_bar) (the missing multiplier: BE == B :806-808) => r = 0 exactly; ||G x||;
+//     ||b_bar||
+//   dual QP (x2) A = F, b = d, BE = G, cE = e : the Bt_lambda vector is SHARED with the homogenised QP (QP_DUPLICATE_COPY_POINTERS, qp.c:197): r = ||F lambda -
+//     d + Bt_lambda||,
 //                                                                 rounding level; ||G lambda - e||; ||d||
-//   primal QP (x2)   A = K, b = f, BE = B, cE = 0              : ||K u - f + B' lambda||, ||B u||, ||f||;  also ||B' lambda - f|| (what the line shows once K has been zeroed)
+//   primal QP (x2) A = K, b = f, BE = B, cE = 0 : ||K u - f + B' lambda||, ||B u||, ||f||; also ||B' lambda - f|| (what the line shows once K has been zeroed)
 // x_child: the solved vector of the last QP; lambda = x_child + lambda~; u: the recovered primal solution (with its rigid-body part).
 extern "C" int pmh_qpt_feti_chain_kkt(pmh_feti_chain ch, pmh_blockdiag K, const double *x_child, const double *lambda, const double *u, pmh_feti_chain_kkt *out)
 {

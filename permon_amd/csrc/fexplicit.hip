@@ -329,7 +329,8 @@ static int fx_build_launch(pmh_fexplicit E)
   for (int b = 0; b < nb; b++) {
     const int nsb = E->ld[b] / FX_TC;
     for (int sb = 0; sb < nsb; sb++)
-      if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 2.0 * 8.0 * FX_TC * (sb + 1) + 2.0 * 8.0 * 128.0 * ((sb + seg) / seg); // its tiles, its partial row and its direct sums written + read back
+      // its tiles, its partial row and its direct sums written + read back
+      if (E->owned[b][sb]) E->sym_bytes += 8.0 * 4.0 * FX_TILE * (sb + 1) + 2.0 * 8.0 * FX_TC * (sb + 1) + 2.0 * 8.0 * 128.0 * ((sb + seg) / seg);
     E->sym_bytes += 16.0 * E->ld[b]; // x read, y written
   }
   return PMH_SUCCESS;
@@ -374,10 +375,11 @@ extern "C" int pmh_fexplicit_create_shared_orbit(pmh_gluing B, pmh_blockdiag K, 
   return fx_create(B, K, PMH_FX_CLASS_ORBIT, block_class, out);
 }
 
-// ... with the class sets extended (extra_ptr: nclasses + 1 offsets, extra_rel: block-relative dofs): decompositions whose blocks are symmetric boxes but not congruent (one
-// material per subdomain) have one class per block, whose own touched set -- three interface faces, a Dirichlet or contact face -- is mapped onto itself by 2 ... 8 of the box's 48
-// operations only; on the closure of that set under the whole group (pmh_box_symmetry_closure: the whole boundary of a cube) every operation survives, the set-up needs one K^+
-// solve per orbit (715 instead of 17 000 ... 24 000 for a 44^3-node cube) and the apply is the GEMM of the orbit storage instead of the HBM-bound stream over a full W_b
+// ... with the class sets extended (extra_ptr: nclasses + 1 offsets, extra_rel: block-relative dofs): decompositions whose blocks are symmetric boxes but not
+// congruent (one material per subdomain) have one class per block, whose own touched set -- three interface faces, a Dirichlet or contact face -- is mapped
+// onto itself by 2 ... 8 of the box's 48 operations only; on the closure of that set under the whole group (pmh_box_symmetry_closure: the whole boundary of a
+// cube) every operation survives, the set-up needs one K^+ solve per orbit (715 instead of 17 000 ... 24 000 for a 44^3-node cube) and the apply is the GEMM of
+// the orbit storage instead of the HBM-bound stream over a full W_b
 extern "C" int pmh_fexplicit_create_shared_orbit_union(pmh_gluing B, pmh_blockdiag K, const int *block_class, const int *extra_ptr, const int *extra_rel, pmh_fexplicit *out)
 {
   PMH_ARG(block_class && extra_ptr && (extra_rel || true));
@@ -417,7 +419,8 @@ static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *bloc
     off += E->ld[b]; // every block padded to a multiple of 128: aligned 16-byte loads, whole bands and tiles; the pad entries are empty rows of Bhat'
   }
   E->gstart[nb] = off, E->goff[nb] = E->gamma.size(), E->ntot = off;
-  if (storage == PMH_FX_CLASS || storage == PMH_FX_CLASS_SYM || storage == PMH_FX_CLASS_ORBIT) { // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
+  // the dense side lives in the class-shared object; the Gamma_b lists above serve sizes / get_block
+  if (storage == PMH_FX_CLASS || storage == PMH_FX_CLASS_SYM || storage == PMH_FX_CLASS_ORBIT) {
     E->W.assign(nb, nullptr), E->woff.assign(nb, 0);
     PMH_CHK(fxs_create(B, K, block_class, storage == PMH_FX_CLASS_ORBIT ? 2 : (storage == PMH_FX_CLASS_SYM ? 1 : 0), &E->sh, extra_ptr, extra_rel));
     *out = E;

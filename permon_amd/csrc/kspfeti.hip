@@ -9,7 +9,8 @@
 //   G  = R'B' (explicit, qptransform.c:838), e = R'f;  chain: pmh_qpt_feti_chain_create (dualize, homogenize, project);
 //        or, with -qpt_dualize_Kplus_left (what the reference switches to when it computed the kernel itself, qptransform.c:997-1008), K^- P_R;
 //   QPS: the dual QP has no box, so QPSSetDefaultType picks QPSKSP = CG on P F (qps.c:448) with PC none or P (B K B') (PCDUAL lumped);
-//        with -project 0 the equality constraint stays, the QP is homogenised and QPSSetDefaultType picks SMALXE (qps.c:437-441), optionally on orthonormalised G
+//        with -project 0 the equality constraint stays, the QP is homogenised and QPSSetDefaultType picks SMALXE (qps.c:437-441), optionally on orthonormalised
+//          G
 //        (-dual_qp_E_orth_type gs | implicit);
 //   post-solve: lambda = lambda_child + lambda~, u = K^+(f - B' lambda) - R alpha with G' alpha = d - F lambda (qptransform.c:783-833).
 // Host orchestration in C++; every operator application runs on the device.
@@ -29,13 +30,15 @@ struct LumpedOp : pmh_op_s { // PCApply_Dual lumped (pcdual.c:63-78) as an opera
 } // namespace
 
 // QPChainPostSolve's report (src/qp/interface/qpchain.c:198-275) for the chain KSPFETI builds (feti.c:71-94, QPTAllInOne qptransform.c:2152-2207):
-//   #0 the assembled MATIS QP -> #1 QPTMatISToBlockDiag -> #2 QPTScale -> #3 QPTDualize -> #4 QPTScale [-> #5 QPTHomogenizeEq -> #6 QPTEnforceEqByProjector with floating subdomains].
-// QPTScale adds a child even when nothing is scaled (:1459, QP_DUPLICATE_COPY_POINTERS: operator, right-hand side, solution and multipliers are the parent's own objects), so
-// #4 / #3 and #2 / #1 print the same lines.  Every QP is viewed after the post-solve of the QP below it.  -qpt_matis_to_diag_norm adds the line of
-// QPTPostSolve_QPTMatISToBlockDiag (:1954-1979) between #2 and #1; with the Dirichlet dofs enforced by B that routine zeroes rows / columns of the local matrices IN PLACE (:1933 --
-// the MATIS of #0 shares them) and restores them with MatCopy (:1967), which for MATBLOCKDIAG is PETSc's MatCopy_Basic: MatZeroEntries + a row loop the type has no MatGetRow
-// for -- what #1 and #0 print afterwards is consistent with an operator left at ZERO (feti/output/ex1_1.out: ||B' lambda - f|| = 2.31e-02 and ||b|| / ||b|| = 1.00e+00;
-// with -dir_in_hess, ex1_2.out, nothing is touched).  Reproduced as observed, said here so that nobody mistakes those two lines for residuals of the solve.
+//   #0 the assembled MATIS QP -> #1 QPTMatISToBlockDiag -> #2 QPTScale -> #3 QPTDualize -> #4 QPTScale [-> #5 QPTHomogenizeEq -> #6 QPTEnforceEqByProjector
+//     with floating subdomains].
+// QPTScale adds a child even when nothing is scaled (:1459, QP_DUPLICATE_COPY_POINTERS: operator, right-hand side, solution and multipliers are the parent's
+// own objects), so #4 / #3 and #2 / #1 print the same lines.  Every QP is viewed after the post-solve of the QP below it.  -qpt_matis_to_diag_norm adds the
+// line of QPTPostSolve_QPTMatISToBlockDiag (:1954-1979) between #2 and #1; with the Dirichlet dofs enforced by B that routine zeroes rows / columns of the
+// local matrices IN PLACE (:1933 -- the MATIS of #0 shares them) and restores them with MatCopy (:1967), which for MATBLOCKDIAG is PETSc's MatCopy_Basic:
+// MatZeroEntries + a row loop the type has no MatGetRow for -- what #1 and #0 print afterwards is consistent with an operator left at ZERO
+// (feti/output/ex1_1.out: ||B' lambda - f|| = 2.31e-02 and ||b|| / ||b|| = 1.00e+00; with -dir_in_hess, ex1_2.out, nothing is touched).  Reproduced as
+// observed, said here so that nobody mistakes those two lines for residuals of the solve.
 static int kspfeti_view_smalxe(pmh_ctx ctx, const pmh_kspfeti_opts *o, pmh_smalxe S, pmh_feti_chain ch, const pmh_feti_chain_kkt &k, pmh_qppf pf0, const double *e0, int nl, int m,
                                const double *d_x, const double *d_lam, std::string &text);
 
@@ -87,8 +90,8 @@ static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_s
   std::vector<double> x0((size_t)ng, 0.0), b0((size_t)ng, 0.0), xl((size_t)N), yl((size_t)N), r0((size_t)ng, 0.0);
   for (int i = 0; i < N; i++) x0[l2g[i]] = u_host[i], b0[l2g[i]] += f[i];
   auto assembled_residual = [&](bool zero_dirichlet, double *rn, double *bn) -> int {
-    // r = A x0 - b: A applied through the local matrices (MatMult_IS: scatter, local products, add); zero_dirichlet: the Dirichlet rows / columns zeroed with a unit diagonal
-    // and b_dir = 0 (MatZeroRowsColumnsIS(child->A, isDir, 1.0, dir = 0, b) :1926-1933)
+    // r = A x0 - b: A applied through the local matrices (MatMult_IS: scatter, local products, add); zero_dirichlet: the Dirichlet rows / columns zeroed with a
+    // unit diagonal and b_dir = 0 (MatZeroRowsColumnsIS(child->A, isDir, 1.0, dir = 0, b) :1926-1933)
     std::vector<char> isd((size_t)N, 0);
     if (zero_dirichlet)
       for (int q = 0; q < n_dir; q++) isd[dir_local[q]] = 1;
@@ -129,8 +132,9 @@ static int kspfeti_view(pmh_ctx ctx, const pmh_kspfeti_opts *o, const pmh_pcpg_s
 }
 
 
-// MatOrthRows with MAT_ORTH_GS, explicit form (permonmatorth.c:208-236 MatOrthColumns_GS_Default on the columns of G'): classical Gram-Schmidt -- all the dots against the
-// finished rows at once -- repeated while the norm has dropped to half or less; T collects the same row operations (TG0 = G, Te0 = e).  Host, dense m x n rows.
+// MatOrthRows with MAT_ORTH_GS, explicit form (permonmatorth.c:208-236 MatOrthColumns_GS_Default on the columns of G'): classical Gram-Schmidt -- all the dots
+// against the finished rows at once -- repeated while the norm has dropped to half or less; T collects the same row operations (TG0 = G, Te0 = e).  Host, dense
+// m x n rows.
 static int orth_rows_gs(int m, int n, std::vector<double> &G, std::vector<double> &T)
 {
   T.assign((size_t)m * m, 0.0);
@@ -165,8 +169,9 @@ static int orth_rows_gs(int m, int n, std::vector<double> &G, std::vector<double
   return PMH_SUCCESS;
 }
 
-// MAT_ORTH_GS_LINGEN (permonmatorth.c:248-288 MatOrthColumns_GS_Lingen): the same projections, but the norm of the projected row is NOT recomputed -- it follows from
-// Pythagoras, delta = delta_last sqrt|1 - ||p||^2 / delta_last^2| with p the dots just subtracted --, the row is re-projected while delta <= delta_last / 2, and it is scaled by 1 / delta
+// MAT_ORTH_GS_LINGEN (permonmatorth.c:248-288 MatOrthColumns_GS_Lingen): the same projections, but the norm of the projected row is NOT recomputed -- it
+// follows from Pythagoras, delta = delta_last sqrt|1 - ||p||^2 / delta_last^2| with p the dots just subtracted --, the row is re-projected while delta <=
+// delta_last / 2, and it is scaled by 1 / delta
 static int orth_rows_gs_lingen(int m, int n, std::vector<double> &G, std::vector<double> &T)
 {
   T.assign((size_t)m * m, 0.0);
@@ -206,9 +211,12 @@ static int orth_rows_gs_lingen(int m, int n, std::vector<double> &G, std::vector
 }
 
 // The -qp_chain_view_kkt lines of the QPs that differ when the dual QP is NOT projected (-project 0), last QP first (QPTAllInOne qptransform.c:2178-2207):
-//   QPTEnforceEqByPenalty (SMALXE's inner QP: A + rho G'G, b - B'mu), QPTHomogenizeEq (multiplier term B'mu, which QPSSolve_SMALXE leaves in Bt_lambda), [QPTOrthonormalizeEq: the
-//   same multiplier term -- QPTHomogenizeEqPostSolve copies it up -- against d; ||BE x - cE|| only when BE can be multiplied with, i.e. not for the implicit type, qp.c:303-318],
-//   then QPTScale / QPTDualize's child twice with G0, e0 and the multiplier term QPViewKKT computes itself for a QP that was handed none (QPTPostSolve_QPTOrthonormalizeEq skips
+//   QPTEnforceEqByPenalty (SMALXE's inner QP: A + rho G'G, b - B'mu), QPTHomogenizeEq (multiplier term B'mu, which QPSSolve_SMALXE leaves in Bt_lambda),
+//     [QPTOrthonormalizeEq: the
+//   same multiplier term -- QPTHomogenizeEqPostSolve copies it up -- against d; ||BE x - cE|| only when BE can be multiplied with, i.e. not for the implicit
+//     type, qp.c:303-318],
+//   then QPTScale / QPTDualize's child twice with G0, e0 and the multiplier term QPViewKKT computes itself for a QP that was handed none
+//     (QPTPostSolve_QPTOrthonormalizeEq skips
 //   both multipliers): r = 0 by construction.  Without orthonormalisation the last two print the homogenised QP's multiplier term as in the projected chain.
 static int kspfeti_view_smalxe(pmh_ctx ctx, const pmh_kspfeti_opts *o, pmh_smalxe S, pmh_feti_chain ch, const pmh_feti_chain_kkt &k, pmh_qppf pf0, const double *e0, int nl, int m,
                                const double *d_x, const double *d_lam, std::string &text)
@@ -283,7 +291,8 @@ extern "C" int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o)
   o->gluing_type = 1;   // FETI_GLUING_FULL, qpfeti.c:322
   o->scale       = 1;   // -SCALE_ON, qpfeti.c:757
   o->regularize  = 1;   // QPTFromOptions qptransform.c:2215
-  o->kplus_left  = 1;   // KSPFETI never hands QPTDualize a kernel (feti.c:71-94), so the reference computes one and switches to K^- P_R, -regularize 0 (qptransform.c:997-1008)
+  // KSPFETI never hands QPTDualize a kernel (feti.c:71-94), so the reference computes one and switches to K^- P_R, -regularize 0 (qptransform.c:997-1008)
+  o->kplus_left  = 1;
   o->project     = 1;   // -feti (qptransform.c:2224)
   PMH_CHK(pmh_smalxe_default_opts(&o->smalxe));
   o->kplus_rtol = 1e-12, o->kplus_max_it = 20000; // a stand-in for "direct": the reference factorises K_reg
@@ -376,10 +385,12 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     GO(pmh_csr_create(ctx, N, N, rowptr, col, val, &Kc));
     GO(pmh_blockdiag_create(ctx, nsub, block_rowstart, Kc, &Kb));
     const bool any_kernel = std::any_of(bdim.begin(), bdim.end(), [](int d) { return d > 0; });
-    if (o->kplus_left && !o->explicit_dual && any_kernel) { // (the explicit local dual operators store symmetric blocks: they stay on K_reg^{-1} / the Moore-Penrose form)
-      // K^+ = K^- P_R (qptransform.c:1040-1062).  The reference's K^- is the MUMPS solve with null-pivot detection (MatInvComputeNullSpace's factorisation): the null pivots carry 0.
-      // Which dofs those are is MUMPS's choice; here they are the fixing dofs MatRegularize would take (permonmatregularize.c:57-124), one set per floating block, eliminated from
-      // K by identity rows / columns -- for feti/ex1.c that is an end dof of every subdomain, and the reference's outputs are reproduced with it (tests/test_gpu_feti_kkt_text.py).
+    // (the explicit local dual operators store symmetric blocks: they stay on K_reg^{-1} / the Moore-Penrose form)
+    if (o->kplus_left && !o->explicit_dual && any_kernel) {
+      // K^+ = K^- P_R (qptransform.c:1040-1062).  The reference's K^- is the MUMPS solve with null-pivot detection (MatInvComputeNullSpace's factorisation):
+      // the null pivots carry 0. Which dofs those are is MUMPS's choice; here they are the fixing dofs MatRegularize would take (permonmatregularize.c:57-124),
+      // one set per floating block, eliminated from K by identity rows / columns -- for feti/ex1.c that is an end dof of every subdomain, and the reference's
+      // outputs are reproduced with it (tests/test_gpu_feti_kkt_text.py).
       std::vector<int>  fix;
       std::vector<char> isfix((size_t)N, 0);
       for (int s = 0; s < nsub; s++) {
@@ -482,7 +493,8 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         }
       GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));
       GO(pmh_qppf_create(ctx, Gc, 0, &pf));
-      if (o->E_orth_type == 1 || o->E_orth_type == 2) { // QPTOrthonormalizeEq, MAT_ORTH_GS / MAT_ORTH_GS_LINGEN: the child QP gets the explicit T G and T e (qptransform.c:593-606)
+      // QPTOrthonormalizeEq, MAT_ORTH_GS / MAT_ORTH_GS_LINGEN: the child QP gets the explicit T G and T e (qptransform.c:593-606)
+      if (o->E_orth_type == 1 || o->E_orth_type == 2) {
         if ((double)m * nl > 5e7) {
           rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -dual_qp_E_orth_type gs forms the dense %d x %d G on the host; use implicit", m, nl);
           goto done;
@@ -506,8 +518,9 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
         GO(pmh_csr_create(ctx, m, nl, orp.data(), oci.data(), ova.data(), &Goc));
         GO(pmh_qppf_create(ctx, Goc, 0, &pfo)); // QPSetEq re-creates the QPPF from T G (qptransform.c:609): GG' is formed and inverted like any other
       } else if (o->E_orth_type == 4 || o->E_orth_type == 3) {
-        // MAT_ORTH_IMPLICIT: G stays, the projector carries T (:612-619).  MAT_ORTH_CHOLESKY in its (default) implicit form: BE = L^{-1} G as a product of the forward solve and G
-        // (permonmatorth.c:121-128) -- the same object here; unlike the dummy BE of the implicit TYPE it can be multiplied with, so its ||BE x - cE|| line is printed
+        // MAT_ORTH_IMPLICIT: G stays, the projector carries T (:612-619).  MAT_ORTH_CHOLESKY in its (default) implicit form: BE = L^{-1} G as a product of the
+        // forward solve and G (permonmatorth.c:121-128) -- the same object here; unlike the dummy BE of the implicit TYPE it can be multiplied with, so its
+        // ||BE x - cE|| line is printed
         GO(pmh_qppf_create(ctx, Gc, 2, &pfo));
         GO(pmh_qppf_orth_rhs(pfo, e.data(), eo.data()));
       }
@@ -540,9 +553,10 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     pmh_pcpg_stats ks;
     memset(&ks, 0, sizeof(ks));
     if (m && !o->project) {
-      // -project 0: QPTAllInOne skips QPTEnforceEqByProjector (qptransform.c:2185), QPSSetDefaultType sees the equality constraint and picks SMALXE (qps.c:437-441), whose set-up
-      // homogenises (smalxe.c:800-806: the chain's lambda~ / b_bar) and penalises.  The inner QP has no box: the reference's default inner solver is then QPSKSP = CG
-      // (qps.c:448) under SMALXE's stopping rule; this library's inner solver is MPGP with no bounds, whose steps are all CG steps -- the same iteration.
+      // -project 0: QPTAllInOne skips QPTEnforceEqByProjector (qptransform.c:2185), QPSSetDefaultType sees the equality constraint and picks SMALXE
+      // (qps.c:437-441), whose set-up homogenises (smalxe.c:800-806: the chain's lambda~ / b_bar) and penalises.  The inner QP has no box: the reference's
+      // default inner solver is then QPSKSP = CG (qps.c:448) under SMALXE's stopping rule; this library's inner solver is MPGP with no bounds, whose steps are
+      // all CG steps -- the same iteration.
       if (o->lumped_pc) {
         rc = pmh_set_error(PMH_ERR_SUP, "pmh_kspfeti_solve: -dual_pc_dual_type lumped with -project 0 is not built");
         goto done;
@@ -552,7 +566,8 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
       GO(pmh_qpt_feti_chain_get(ch, &F, nullptr, nullptr, &bbar, nullptr, nullptr, nullptr));
       pmh_smalxe_opts sx = o->smalxe;
       sx.rtol = o->rtol, sx.atol = o->atol, sx.divtol = o->divtol;
-      if (o->max_it_set || o->max_it != 10000) sx.max_it = o->max_it; // -qps_max_it given (max_it_set: also an explicit 10000): QPSCreate_SMALXE's own default (100, smalxe.c:1203) otherwise
+      // -qps_max_it given (max_it_set: also an explicit 10000): QPSCreate_SMALXE's own default (100, smalxe.c:1203) otherwise
+      if (o->max_it_set || o->max_it != 10000) sx.max_it = o->max_it;
       if (o->E_orth_type == 4) sx.be_implicit = 1;   // the implicit BE has no product of its own: ||BE u|| through B'B (smalxe.c:878-886)
       GO(pmh_smalxe_create(ctx, F, bbar, d_x, nullptr, nullptr, pfs, &sx, &S));
       GO(pmh_smalxe_solve(S));

@@ -55,15 +55,22 @@ struct pmh_mpgp_s {
   int     nwork;
   // convergence
   pmh_converged_fn cvg;
-  int (*pre_test)(void *); // optional: enqueues what the injected convergence test will read, BEFORE the host waits for the step's scalars (one round trip instead of two)
+  // optional: enqueues what the injected convergence test will read, BEFORE the host waits for the step's scalars (one round trip instead of two)
+  int (*pre_test)(void *);
   void *pre_test_user;
-  int (*pre_p1)(void *);   // optional: called right before the speculative Ap = A p of the NEXT iteration is enqueued (the iterate is final then): SMALXE lets its ||B u|| ride on that product
+  // optional: called right before the speculative Ap = A p of the NEXT iteration is enqueued (the iterate is final then): SMALXE lets its ||B u|| ride on that
+  // product
+  int (*pre_p1)(void *);
   void *pre_p1_user;
-  double cvg_margin;       // set by the convergence test: rnorm / (the threshold it has to fall below), 0 = unknown -- how close the NEXT test is to ending the solve
-  int   g_valid;           // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
+  // set by the convergence test: rnorm / (the threshold it has to fall below), 0 = unknown -- how close the NEXT test is to ending the solve
+  double cvg_margin;
+  // work[3] already holds A x - b for the x and b the next solve starts from (pmh_mpgp_set_gradient_valid): the fused driver skips its first product
+  int   g_valid;
   int   epi_ok;            // 1: the operator folds the vector phases into its last kernel (pmh_op_s::mult_epi), 0: it does not, -1: not asked yet
-  int   hsum4 = 0, hsum3 = 0;   // > 0: rows 0..3 (gradient split) / 4..6 (P1) of the pinned block partials wait for the host's sum over that many blocks (host_sums)
-  bool  cx[2] = {false, false}; // fused dual-space chain (pmh_op_s::emit_begin): the operator holds G0 x (0) / G0 p (1) of the CURRENT x / p, emitted by the kernel that wrote them
+  // > 0: rows 0..3 (gradient split) / 4..6 (P1) of the pinned block partials wait for the host's sum over that many blocks (host_sums)
+  int   hsum4 = 0, hsum3 = 0;
+  // fused dual-space chain (pmh_op_s::emit_begin): the operator holds G0 x (0) / G0 p (1) of the CURRENT x / p, emitted by the kernel that wrote them
+  bool  cx[2] = {false, false};
   int   fin4_pending;      // the partials of the gradient split (rows 0..3) wait for the finalising launch of the next P1 (rows 4..6): one launch for both
   void            *cvg_user;
   double           norm_rhs, ttol, norm_rhs_div;
@@ -90,7 +97,8 @@ struct pmh_mpgp_s {
 template <int K, bool EMIT = false>
 __device__ __forceinline__ void write_partials(double (&v)[K], double *lds, double *__restrict__ partials, int ld, double *__restrict__ h_partials = nullptr)
 {
-  if (EMIT) { // 1024-thread workgroups; the rows also go to the pinned host copy: the host adds the block sums after its next wait (host_sums), no finalising launch
+  // 1024-thread workgroups; the rows also go to the pinned host copy: the host adds the block sums after its next wait (host_sums), no finalising launch
+  if (EMIT) {
     int op[K];
 #pragma unroll
     for (int k = 0; k < K; k++) op[k] = PMH_RED_SUM;
@@ -153,7 +161,9 @@ __global__ VEC_BOUNDS void k_step_update(long long n, const double *__restrict__
   double            acg;
   pmh_emit_regs     R;
   if (EMIT) pmh_emit_prefetch(ea, R);
-  if (EMIT) { // no finalising launch ran: acg from the host (it has read p'Ap, g'p) or -- proportioning, taken without a host wait -- from the P1 block partials (rows 4, 5)
+  // no finalising launch ran: acg from the host (it has read p'Ap, g'p) or -- proportioning, taken without a host wait -- from the P1 block partials (rows 4,
+  // 5)
+  if (EMIT) {
     acg = acg_host;
     if (nb_p1 > 0) acg = pmh_sum_block_partials(partials + (size_t)5 * ld, nb_p1) / pmh_sum_block_partials(partials + (size_t)4 * ld, nb_p1);
   } else {
@@ -568,9 +578,9 @@ static bool emit_try(pmh_mpgp s, bool wx, bool wp, pmh_emit_args *ea)
 }
 static int emit_blocks(pmh_mpgp s) { return (s->n + PMH_EMIT_TILE - 1) / PMH_EMIT_TILE; } // grid of the EMIT variants
 
-// The last step of a reduction whose block partials a kernel left in the pinned host copy, taken by the host after its wait: lane l of a wave of 64 adds its entries
-// l, l + 64, ... in that order, then the butterflies of pmh_wave_all (emit_inline.h) -- the order in which a device consumer adds the same row (pmh_sum_block_partials),
-// so both see the same number.
+// The last step of a reduction whose block partials a kernel left in the pinned host copy, taken by the host after its wait: lane l of a wave of 64 adds its
+// entries l, l + 64, ... in that order, then the butterflies of pmh_wave_all (emit_inline.h) -- the order in which a device consumer adds the same row
+// (pmh_sum_block_partials), so both see the same number.
 static double host_sum_row(const double *row, int nb, int op)
 {
   double v[64];
@@ -862,13 +872,16 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = fals
   if (halt) return pmh_set_error(PMH_ERR_STATE, "speculative chain needs a CSR operator");
   const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
   const int nb     = s->n > 0 ? pmh_vec_grid(s->n) : 0;
-  if (s->epi_ok) { // the three reductions inside the operator's last kernel (rows 4..6 of the partials: rows 0..3 may still hold a gradient split that waits for its finalising launch)
+  // the three reductions inside the operator's last kernel (rows 4..6 of the partials: rows 0..3 may still hold a gradient split that waits for its finalising
+  // launch)
+  if (s->epi_ok) {
     pmh_vec_epi e;
     memset(&e, 0, sizeof(e));
     e.kind = PMH_VEPI_P1, e.g = g, e.xx = s->x, e.lb = s->lb, e.ub = s->ub, e.partials = s->ctx->d_partials, e.ld = s->ctx->partials_cap, e.prow = 4;
     e.p_fresh = p_fresh, e.spec_alpha = s->alpha, e.astol = s->o.astol; // (operators that pair their passes: svm.hip)
     int hosted = 0;
-    e.in_slot = s->cx[1] ? 2 : 0, e.hosted = s->ctx->dist_scalars ? nullptr : &hosted; // (the fused dual-space chain: G0 p left behind by the kernel that wrote p; the three sums' block partials go to the pinned host copy)
+    // (the fused dual-space chain: G0 p left behind by the kernel that wrote p; the three sums' block partials go to the pinned host copy)
+    e.in_slot = s->cx[1] ? 2 : 0, e.hosted = s->ctx->dist_scalars ? nullptr : &hosted;
     const int rc = s->A->mult_epi(p, Ap, e);
     if (rc != PMH_EPI_UNSUPPORTED) {
       PMH_CHK(rc);
@@ -879,7 +892,8 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = fals
         s->hsum3        = hosted;
         return PMH_SUCCESS;
       }
-      if (s->fin4_pending) { // (Ap'gf, |gP|^2, |gc|^2, |gf|^2) of the gradient split and (p'Ap, g'p, afeas) in ONE finalising launch: every quantity reduced as on its own
+      // (Ap'gf, |gP|^2, |gc|^2, |gf|^2) of the gradient split and (p'Ap, g'p, afeas) in ONE finalising launch: every quantity reduced as on its own
+      if (s->fin4_pending) {
         const int ops7[7] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
         const int slots7[7] = {S_APGF, S_GP2, S_GC2, S_GF2, S_PAP, S_GP, S_FEAS};
         s->fin4_pending = 0;
@@ -889,7 +903,8 @@ static int f_apply_p1(pmh_mpgp s, const int *halt = nullptr, bool p_fresh = fals
     }
     s->epi_ok = 0;
   }
-  if (s->fin4_pending) { // (cannot happen with one operator: it answers mult_epi the same way every time) the split's partials sit in the rows k_p1_dots is about to overwrite
+  // (cannot happen with one operator: it answers mult_epi the same way every time) the split's partials sit in the rows k_p1_dots is about to overwrite
+  if (s->fin4_pending) {
     PMH_CHK(finalize_vec4(s));
     s->fin4_pending = 0;
   }
@@ -913,8 +928,8 @@ static int f_gradient(pmh_mpgp s)
   return pmh_vec_axpy(s->ctx, s->n, g, -1.0, s->b);
 }
 
-// g = A x - b, the gradient split with p = gf and the partials of its norms (mpgp.c:500-507, :578-580 + :612-615): inside the operator's last kernel where it offers that
-// (the finalising launch then waits for the next P1: fin4_pending), else as three launches + the finalising one
+// g = A x - b, the gradient split with p = gf and the partials of its norms (mpgp.c:500-507, :578-580 + :612-615): inside the operator's last kernel where it
+// offers that (the finalising launch then waits for the next P1: fin4_pending), else as three launches + the finalising one
 static int f_gradient_split(pmh_mpgp s, bool defer_finalize, bool x_from_spec = false)
 {
   pmh_ctx ctx = s->ctx;
@@ -970,8 +985,10 @@ static int solve_fused(pmh_mpgp s)
   s->A->emit_invalidate();
   PMH_CHK(pmh_qpc_box_project(ctx, n, x, s->lb, s->ub, x)); // mpgp.c:497
   s->fin4_pending = 0;
-  if (s->epi_ok < 0) s->epi_ok = (s->csr || !pmh_knobs().vec_epi) ? 0 : 1; // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
-                                                                                  // partials are finalised at once and completed across the ranks, pmh_finalize_partials)
+  // asked once: a refusal (PMH_EPI_UNSUPPORTED) clears it.  (Row-distributed vectors: the operator's
+  if (s->epi_ok < 0) s->epi_ok = (s->csr || !pmh_knobs().vec_epi) ? 0 : 1;
+                                                                                  // partials are finalised at once and completed across the ranks,
+                                                                                  // pmh_finalize_partials)
   if (s->g_valid) { // the caller carried g = A x - b over from the previous solve (pmh_smalxe_set_reuse_products): the split, p = gf and the norms only
     s->g_valid = 0;
     pmh_emit_args ea;
@@ -987,8 +1004,8 @@ static int solve_fused(pmh_mpgp s)
     nmv++;
     p_fresh = true;
   }
-  // (the carried-gradient branch did not run the operator's own gradient split: whatever pairing state an operator keeps from the previous solve must not be matched
-  // with this p -- p_fresh stays false there, the first product of the solve is then a lone application)
+  // (the carried-gradient branch did not run the operator's own gradient split: whatever pairing state an operator keeps from the previous solve must not be
+  // matched with this p -- p_fresh stays false there, the first product of the solve is then a lone application)
   s->step      = ' ';
   s->iteration = 0;
   pmh_spec_args nosa;
@@ -1052,7 +1069,8 @@ static int solve_fused(pmh_mpgp s)
       s->iteration += ndev;
       ncg += ndev;
       nmv += ndev;
-      spec_len = (ndev >= nbatch) ? std::min(SPEC_BATCH, 2 * nbatch) : ndev; // 0 after a batch that took no step: the host path decides when speculation resumes
+      // 0 after a batch that took no step: the host path decides when speculation resumes
+      spec_len = (ndev >= nbatch) ? std::min(SPEC_BATCH, 2 * nbatch) : ndev;
       if (!s->h_ctl[CTL_HALT]) continue; // whole batch were CG steps
     }
     if (s->pre_test) PMH_CHK(s->pre_test(s->pre_test_user));
@@ -1080,7 +1098,8 @@ static int solve_fused(pmh_mpgp s)
         spec_len = std::max(spec_len, 1); // a CG step taken by the host: the next ones may well be CG steps too
         pmh_emit_args ea;
         bool emitted_step = false;
-        if (emit_try(s, true, false, &ea)) { // x -= acg p with the segment sums of G0 x left behind; acg as the host has it; the four sums' block partials go to the pinned host copy
+        // x -= acg p with the segment sums of G0 x left behind; acg as the host has it; the four sums' block partials go to the pinned host copy
+        if (emit_try(s, true, false, &ea)) {
           LAUNCH_EMIT(k_cg_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, ctx->h_partials, acg, 0);
           s->hsum4 = emit_blocks(s), emitted_step = true;
         } else {
@@ -1098,7 +1117,8 @@ static int solve_fused(pmh_mpgp s)
       } else { // expansion (mpgp.c:561-616), std direction + fixed length => no re-projection (:388)
         nexp++;
         s->step = 'e';
-        const bool prepared = s->epi_ok == 1 && s->A->spec_expansion_ready(); // the operator's P1 pass already formed k_expansion_std's iterate (svm.hip): it hands it over with the gradient
+        // the operator's P1 pass already formed k_expansion_std's iterate (svm.hip): it hands it over with the gradient
+        const bool prepared = s->epi_ok == 1 && s->A->spec_expansion_ready();
         if (!prepared) {
           pmh_emit_args ea;
           if (emit_try(s, true, false, &ea)) LAUNCH_EMIT(k_expansion_std<true>, afeas, s->alpha, x, (const double *)g, (const double *)p, (const double *)Ap, s->lb, s->ub, astol, ea);
@@ -1121,11 +1141,13 @@ static int solve_fused(pmh_mpgp s)
       else LAUNCH(k_prop_dir<false>, (const double *)x, (const double *)g, s->lb, s->ub, astol, p, g_noea);
       PMH_CHK(f_apply_p1(s));
       nmv++;
-      if (s->hsum3 && emit_try(s, true, true, &ea)) { // the product left its sums to the host: the step forms acg from the P1 block partials itself (no host wait in between)
+      // the product left its sums to the host: the step forms acg from the P1 block partials itself (no host wait in between)
+      if (s->hsum3 && emit_try(s, true, true, &ea)) {
         LAUNCH_EMIT(k_prop_emit, (const double *)ctx->d_scal, nosa, x, g, p, (const double *)Ap, s->lb, s->ub, astol, gf, ctx->d_partials, ctx->partials_cap, ea, ctx->h_partials, 0.0, s->hsum3);
         s->hsum4 = emit_blocks(s);
       } else {
-        if (s->hsum3) { // (not reached: the operator that left the sums to the host takes the emission) the step reads acg from d_scal: finalise the P1 rows on the device
+        // (not reached: the operator that left the sums to the host takes the emission) the step reads acg from d_scal: finalise the P1 rows on the device
+        if (s->hsum3) {
           const int ops[3] = {PMH_RED_SUM, PMH_RED_SUM, PMH_RED_MIN};
           PMH_CHK(pmh_finalize_partials(ctx, ctx->d_partials + (size_t)4 * ctx->partials_cap, ctx->partials_cap, s->hsum3, 3, ops, S_PAP));
           s->hsum3 = 0;
@@ -1135,11 +1157,11 @@ static int solve_fused(pmh_mpgp s)
         PMH_CHK(finalize_vec4(s));
       }
     }
-    // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p -- enqueued before the host has seen this step's norms, so
-    // that the round trip costs nothing.  If the NEXT test ends the solve that product is wasted (0.35 ms for configs[2] against the ~30 us of an exposed round trip):
-    // the test reports how far the norm is above its threshold (cvg_margin), and with the last step's reduction the driver skips the speculation when the next norm
-    // is likely to pass (SMALXE's early outer iterations end their inner solves after 2-3 steps: 8 of 63 products in the driver's 20-step window were such orphans).
-    // Nothing numerical depends on it: the product is then enqueued after the test, by the `!spec` branch above.
+    // speculation: whatever the next step type, unless it is a proportioning step it starts with Ap = A p -- enqueued before the host has seen this step's
+    // norms, so that the round trip costs nothing.  If the NEXT test ends the solve that product is wasted (0.35 ms for configs[2] against the ~30 us of an
+    // exposed round trip): the test reports how far the norm is above its threshold (cvg_margin), and with the last step's reduction the driver skips the
+    // speculation when the next norm is likely to pass (SMALXE's early outer iterations end their inner solves after 2-3 steps: 8 of 63 products in the
+    // driver's 20-step window were such orphans). Nothing numerical depends on it: the product is then enqueued after the test, by the `!spec` branch above.
     bool orphan_risk = false;
     {
       static const bool always = getenv("PMH_MPGP_ALWAYS_SPEC") != nullptr;

@@ -354,14 +354,17 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
   static const char *const orthtypes[] = {"none", "gs", "gslingen", "cholesky", "implicit", "inexact"}; // MatOrthTypes (permonmatorth.c:6)
   std::string left;
   int         inner_alpha_bits = 0;
-  int         mp_given = 0, left_given = -1; // resolved AFTER the loop: -qpt_dualize_Kplus_mp wins over -qpt_dualize_Kplus_left in whatever order they come (qptransform.c:1018-1019 reads _left only if !true_mp)
+  // resolved AFTER the loop: -qpt_dualize_Kplus_mp wins over -qpt_dualize_Kplus_left in whatever order they come (qptransform.c:1018-1019 reads _left only if
+  // !true_mp)
+  int         mp_given = 0, left_given = -1;
   for (const Token &t : toks) {
     const std::string &k = t.key;
     int                rc = 1, b = 0;
     if (k == "feti_gluing_type") rc = get_enum(t, gtypes, 3, &o->gluing_type) ? -1 : 1;
     else if (k == "feti_gluing_exclude_dirichlet") rc = get_bool(t, &o->exclude_dirichlet) ? -1 : 1;
     else if (k == "SCALE_ON") rc = get_bool(t, &o->scale) ? -1 : 1;
-    else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1; // (without effect while kplus_left is on, as in the reference once it has computed the kernel)
+    // (without effect while kplus_left is on, as in the reference once it has computed the kernel)
+    else if (k == "regularize") rc = get_bool(t, &o->regularize) ? -1 : 1;
     else if (k == "qpt_dualize_Kplus_mp") {
       rc = get_bool(t, &b) ? -1 : 1;
       if (rc == 1) mp_given = b; // the Moore-Penrose wrapping is this library's -regularize 0 path

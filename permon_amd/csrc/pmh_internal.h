@@ -30,7 +30,8 @@ struct pmh_knobs_s {
   int mpgp_spec = 1;       // PMH_MPGP_NO_SPEC: batches of device-side CG steps for CSR operators (mpgp.hip)
   int mg_d0_fusion = 1;    // PMH_MG_NO_D0_FUSION: the first smoothing step written by the producer of the right-hand side (feti.hip)
   int svm_pairing = 1;  // the SVM dual's paired passes over X inside MPGP (svm.hip); 0 (PMH_SVM_NO_PAIRING): every Hessian application as its own two passes
-  int host_threads = 1; // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the
+  // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the
+  int host_threads = 1;
                         // CPUs this process may run on) -- several ranks per node must share the node's cores (bench.py hands every rank its share)
 };
 pmh_knobs_s &pmh_knobs();
@@ -136,8 +137,10 @@ int pmh_csr_spmv_launch(pmh_csr A, const double *x, double *y, const pmh_spmv_ep
 int pmh_csr_adopt_transpose(pmh_csr A, pmh_csr At); // A' built by the caller; A owns it afterwards
 inline void pmh_csr_set_host_hint(pmh_csr A, const int *rowptr, const int *col, const double *val) { A->h_rowptr = rowptr, A->h_col = col, A->h_val = val; }
 int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part); // chunk sums of A x (long rows), summed by the consumer
-int pmh_csr_mult_partials2(pmh_csr A, const double *x, const double *x2, const int **lrow, const double **part, const double **part2); // the same for two vectors in ONE pass over A (each sum as the single form takes it)
-int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y, int norm_slot = -1); // y = M (A x), Mt = M' (m x m, device); norm_slot >= 0 (m <= 64): ||y||^2 -> d_scal / h_scal[slot]
+// the same for two vectors in ONE pass over A (each sum as the single form takes it)
+int pmh_csr_mult_partials2(pmh_csr A, const double *x, const double *x2, const int **lrow, const double **part, const double **part2);
+// y = M (A x), Mt = M' (m x m, device); norm_slot >= 0 (m <= 64): ||y||^2 -> d_scal / h_scal[slot]
+int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double *tmp, double *y, int norm_slot = -1);
 
 // ---- operators -------------------------------------------------------------------------------------------
 // Vector epilogues an operator may fold into the LAST kernel of its product y = A x (one entry per thread, the grid of the streaming Vec kernels:
@@ -147,24 +150,24 @@ int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double
 enum { PMH_VEPI_P1 = 1, PMH_VEPI_GRAD_SPLIT = 2 };
 struct pmh_vec_epi {
   int           kind;
-  // PMH_VEPI_P1 (x = p, y = Ap): p'Ap, g'p, QPCFeas(xx, p) -> partials rows prow .. prow + 2 (k_p1_dots)
-  // PMH_VEPI_GRAD_SPLIT (x = the iterate, y = g): g = A x - b, then gf, p = gf and the partials of Ap'gf (0), |gP|^2, |gc|^2, |gf|^2 -> rows prow .. prow + 3 (k_axpy + k_split_setp)
+  // PMH_VEPI_P1 (x = p, y = Ap): p'Ap, g'p, QPCFeas(xx, p) -> partials rows prow .. prow + 2 (k_p1_dots) PMH_VEPI_GRAD_SPLIT (x = the iterate, y = g): g = A x
+  // - b, then gf, p = gf and the partials of Ap'gf (0), |gP|^2, |gc|^2, |gf|^2 -> rows prow .. prow + 3 (k_axpy + k_split_setp)
   const double *g, *xx, *lb, *ub, *b;
   double        astol;
   double       *gf, *p;
   double       *partials;
   int           ld, prow;
-  // pairing of passes for operators that stream a big matrix twice per application (the dense-row SVM Hessian, svm.hip); ignored by the others.
-  // P1: p_fresh = p is still the gf the last PMH_VEPI_GRAD_SPLIT of this operator wrote (nothing touched it since); spec_alpha > 0: the driver will, if the step turns
-  // out to be an expansion (std direction, fixed length alpha), ask for the gradient at exactly k_expansion_std(x, g, p, Ap, afeas, alpha): the operator may prepare it.
-  // GRAD_SPLIT: x_from_spec = the iterate is that prepared expansion (the driver did NOT run k_expansion_std; the operator also writes it to x)
+  // pairing of passes for operators that stream a big matrix twice per application (the dense-row SVM Hessian, svm.hip); ignored by the others. P1: p_fresh = p
+  // is still the gf the last PMH_VEPI_GRAD_SPLIT of this operator wrote (nothing touched it since); spec_alpha > 0: the driver will, if the step turns out to
+  // be an expansion (std direction, fixed length alpha), ask for the gradient at exactly k_expansion_std(x, g, p, Ap, afeas, alpha): the operator may prepare
+  // it. GRAD_SPLIT: x_from_spec = the iterate is that prepared expansion (the driver did NOT run k_expansion_std; the operator also writes it to x)
   int           p_fresh, x_from_spec;
   double        spec_alpha;
   double       *x_out;
-  // fused dual-space chain (dualchain.hip): in_slot = 1 + the emission target that holds G0 x for this input (pmh_op_s::emit_begin: 1 = iterate, 2 = direction; 0 = none: the
-  // operator forms it itself).  hosted != nullptr: the operator may ALSO store its block partials in the pinned host copy h_partials (same rows / ld) and then sets
-  // *hosted = the number of blocks it wrote: the caller adds them up on the host after its next wait, no finalising launch.  emitted_p (GRAD_SPLIT): the last kernel
-  // also emits G0 p for the p = gf it writes and sets *emitted_p = 1
+  // fused dual-space chain (dualchain.hip): in_slot = 1 + the emission target that holds G0 x for this input (pmh_op_s::emit_begin: 1 = iterate, 2 = direction;
+  // 0 = none: the operator forms it itself).  hosted != nullptr: the operator may ALSO store its block partials in the pinned host copy h_partials (same rows /
+  // ld) and then sets *hosted = the number of blocks it wrote: the caller adds them up on the host after its next wait, no finalising launch.  emitted_p
+  // (GRAD_SPLIT): the last kernel also emits G0 p for the p = gf it writes and sets *emitted_p = 1
   int           in_slot;
   double       *h_partials;
   int          *hosted, *emitted_p;
@@ -172,7 +175,8 @@ struct pmh_vec_epi {
 // ---- coarse-space emission of the fused dual-space chain (dualchain.hip, emit_inline.h) ----------------------------------
 // G0 of the projector cut into (row, block of 256 columns) segments; the kernel that writes a dual vector sums its own segments (see emit_inline.h)
 struct pmh_emit_tab {
-  const int    *seg;     // [nwg][64][3] per tile of 1024 dual entries its segments (k0, k1, position of the segment's sum in the row-major array of partial sums), k1 = k0: none
+  // [nwg][64][3] per tile of 1024 dual entries its segments (k0, k1, position of the segment's sum in the row-major array of partial sums), k1 = k0: none
+  const int    *seg;
   const int    *gcol;    // G0 as CSR (device)
   const double *gval;
   const int    *lrow;    // [m + 1] a row's partial sums are part[lrow[r] .. lrow[r + 1])
@@ -192,17 +196,19 @@ struct pmh_op_s {
   virtual ~pmh_op_s() {}
   virtual int     mult(const double *x, double *y) = 0;
   virtual int     mult_epi(const double *, double *, const pmh_vec_epi &) { return PMH_EPI_UNSUPPORTED; }
-  // Coarse emission (fused dual-space chain): the caller is about to launch a kernel that writes the iterate x (x != nullptr) and / or the direction p (p != nullptr), one entry
-  // per thread on the grid of the streaming Vec kernels; on PMH_SUCCESS *ea is filled and the kernel MUST end with pmh_emit_tail(*ea, ...) -- the operator then takes
-  // G0 x / G0 p as given when it is applied with pmh_vec_epi::in_slot 0 / 1.  PMH_EPI_UNSUPPORTED: no such chain, launch the plain kernel.
+  // Coarse emission (fused dual-space chain): the caller is about to launch a kernel that writes the iterate x (x != nullptr) and / or the direction p (p !=
+  // nullptr), one entry per thread on the grid of the streaming Vec kernels; on PMH_SUCCESS *ea is filled and the kernel MUST end with pmh_emit_tail(*ea, ...)
+  // -- the operator then takes G0 x / G0 p as given when it is applied with pmh_vec_epi::in_slot 0 / 1.  PMH_EPI_UNSUPPORTED: no such chain, launch the plain
+  // kernel.
   virtual int     emit_begin(const double * /*x*/, const double * /*p*/, pmh_emit_args *) { return PMH_EPI_UNSUPPORTED; }
   virtual void    emit_invalidate() {} // x or p are about to change without emission
   virtual int     spec_expansion_ready() { return 0; } // the last PMH_VEPI_P1 prepared the expansion step (pmh_vec_epi::spec_alpha)
   // MatMultTranspose slot; operators that are symmetric by construction forward to mult
   virtual int     mult_transpose(const double *, double *) { return pmh_set_error(PMH_ERR_SUP, "this operator has no MatMultTranspose slot"); }
   virtual pmh_csr as_csr() { return nullptr; }
-  // Operators of the form (scatter) o (middle) o (gather) -- F = B K^+ B' with either K^+ (feti.hip): gather = B' as CSR (rows = entries of mid_in), scatter = B as CSR
-  // (rows = dual entries, columns = entries of mid_out); mid_apply runs the middle stage mid_in -> mid_out.  The fused dual-space chain folds the projector into the two sparse stages.
+  // Operators of the form (scatter) o (middle) o (gather) -- F = B K^+ B' with either K^+ (feti.hip): gather = B' as CSR (rows = entries of mid_in), scatter =
+  // B as CSR (rows = dual entries, columns = entries of mid_out); mid_apply runs the middle stage mid_in -> mid_out.  The fused dual-space chain folds the
+  // projector into the two sparse stages.
   virtual int     stages(pmh_csr * /*gather*/, double ** /*mid_in*/, pmh_csr * /*scatter*/, const double ** /*mid_out*/) { return PMH_EPI_UNSUPPORTED; }
   virtual int     mid_apply() { return pmh_set_error(PMH_ERR_SUP, "this operator has no middle stage"); }
 };
@@ -229,23 +235,29 @@ struct pmh_qppf_s {
 enum { PMH_RED_SUM = 0, PMH_RED_MIN = 1 };
 // finalise K block-partial arrays (stride = ld) into d_scal[base+k] and h_scal[base+k]
 int pmh_finalize_partials(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, int scal_base, const int *halt = nullptr, int *post_inc = nullptr);
-int pmh_finalize_partials_slots(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, const int *slots); // the same with one scalar slot per quantity: two groups of reductions in ONE launch
+// the same with one scalar slot per quantity: two groups of reductions in ONE launch
+int pmh_finalize_partials_slots(pmh_ctx ctx, const double *partials, int ld, int nblocks, int K, const int *ops, const int *slots);
 int pmh_vec_grid(int n); // deterministic grid size of the streaming kernels (function of n only)
 
 // vec kernels needed across translation units (device pointers, enqueue only)
 int pmh_k_dot_partials(pmh_ctx ctx, int n, const double *x, const double *y, int slot); // -> d_scal/h_scal[slot]
 int pmh_qppf_apply_G_norm2(pmh_qppf pf, const double *v, double *Gv, int slot);          // qppf.hip: G v and ||G v||^2 -> scalar slot, enqueue only
 int pmh_mpgp_set_pre_test_hook(pmh_mpgp s, int (*f)(void *), void *user);             // mpgp.hip: see there
-int pmh_mpgp_set_convergence_margin(pmh_mpgp s, double margin); // from an injected convergence test: rnorm / its threshold (the fused driver's speculation reads it)
-int pmh_mpgp_set_gradient_valid(pmh_mpgp s, int valid, double **g); // the next solve starts from a gradient the caller has put into the solver's g (returned): smalxe.hip
-int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user);               // mpgp.hip: called right before the speculative Ap = A p of the next iteration is enqueued
+// from an injected convergence test: rnorm / its threshold (the fused driver's speculation reads it)
+int pmh_mpgp_set_convergence_margin(pmh_mpgp s, double margin);
+// the next solve starts from a gradient the caller has put into the solver's g (returned): smalxe.hip
+int pmh_mpgp_set_gradient_valid(pmh_mpgp s, int valid, double **g);
+// mpgp.hip: called right before the speculative Ap = A p of the next iteration is enqueued
+int pmh_mpgp_set_pre_p1_hook(pmh_mpgp s, int (*f)(void *), void *user);
 // SMALXE's ||B u|| riding on the next product of the penalised operator (qppf.hip): G0 u shares the pass over G0 with G0 x, T (G0 u) and its squared norm are
 // finished by workgroup 0 of the projector's kernel -- two launches less per inner iteration, the same bits as pmh_qppf_apply_G_norm2
 int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int slot);
 int pmh_op_penalized_take_aux_done(pmh_op op);
-int pmh_op_penalized_set_normG_target(pmh_op op, double *Gu, int slot); // the five-launch chain (dualchain.hip): ||T G0 u||^2 of every emitted iterate -> Gu, scalar slot
+// the five-launch chain (dualchain.hip): ||T G0 u||^2 of every emitted iterate -> Gu, scalar slot
+int pmh_op_penalized_set_normG_target(pmh_op op, double *Gu, int slot);
 int pmh_op_penalized_normG_ready(pmh_op op, const double *u);           // 1: slot and Gu hold the values of this u
-int pmh_op_penalized_chain_launches(pmh_op op);                        // launches of the chain's last application (-1: no chain) // 1 if the armed request was served by the last product (and clears it), 0 otherwise (and disarms)
+// launches of the chain's last application (-1: no chain) // 1 if the armed request was served by the last product (and clears it), 0 otherwise (and disarms)
+int pmh_op_penalized_chain_launches(pmh_op op);
 #define PMH_SLOT_NORMBU2 48 // ||B u||^2 prefetched for SMALXE's inner convergence test
 int pmh_host_scalar(pmh_ctx ctx, int slot, double *v);                                  // sync + read h_scal[slot]
 
@@ -274,7 +286,9 @@ template <typename T> struct pmh_bsr3_epi {
   double  *z64;  // POST2: optional fp64 copy of the result
   T        c0, c1, c2;
 };
-int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0, int nrep_hint = 1); // *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default; nrep_hint > 1: A is said to be block diagonal with that many congruent blocks (checked entry by entry: one device copy then serves all)
+// *out = NULL (no error) if A has no usable 3x3 block structure; tile 0 = default; nrep_hint > 1: A is said to be block diagonal with that many congruent
+// blocks (checked entry by entry: one device copy then serves all)
+int    pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile = 0, int nrep_hint = 1);
 int    pmh_bsr3_destroy(pmh_bsr3 B);
 double pmh_bsr3_bytes(pmh_bsr3 B);           // HBM bytes of one launch (a shared device copy is streamed once)
 double pmh_bsr3_bytes_blockdiag(pmh_bsr3 B); // SURVEY 8d's figure of the block-diagonal product (every replica's matrix counted)

@@ -451,13 +451,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_dual1(int n, const int *__rest
   z[r] = -1.0 * s1 + x[r];
 }
 
-// ... and with the finishing step of G0 v and the dense T'T product folded in (implicit orthonormalisation, m <= 64): every workgroup adds the
-// chunk sums of k_spmv_long_part per row in chunk order and applies the m x m matrix exactly as k_rows_then_dense does (same order => same bits),
-// then takes its rows -- one launch less per projector application
-// aux (workgroup 0 only; SMALXE's ||B u|| riding along): the chunk sums of G0 u (part2, from k_spmv_long_part2) are added per row, T is applied and ||T G0 u||^2 is summed exactly
-// as k_rows_then_dense does it -- the same bits as the two launches of pmh_qppf_apply_G_norm2.
-// epi: the MPGP vector phase that follows the product, folded in (mode 1 only; one row per thread = the grid of the streaming Vec kernels, so the block partials equal
-// those of k_p1_dots / k_axpy + k_split_setp).
+// ... and with the finishing step of G0 v and the dense T'T product folded in (implicit orthonormalisation, m <= 64): every workgroup adds the chunk sums of
+// k_spmv_long_part per row in chunk order and applies the m x m matrix exactly as k_rows_then_dense does (same order => same bits), then takes its rows -- one
+// launch less per projector application aux (workgroup 0 only; SMALXE's ||B u|| riding along): the chunk sums of G0 u (part2, from k_spmv_long_part2) are added
+// per row, T is applied and ||T G0 u||^2 is summed exactly as k_rows_then_dense does it -- the same bits as the two launches of pmh_qppf_apply_G_norm2. epi:
+// the MPGP vector phase that follows the product, folded in (mode 1 only; one row per thread = the grid of the streaming Vec kernels, so the block partials
+// equal those of k_p1_dots / k_axpy + k_split_setp).
 struct gt_aux {
   const double *part2, *Mt2; // chunk sums of G0 u, T' (row-major)
   double       *y2, *norm_d, *norm_h;
@@ -468,7 +467,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__re
                                                          double *__restrict__ z, double rho, gt_aux aux, pmh_vec_epi epi, const double *__restrict__ pin)
 {
   // A 5-8 us kernel is made of memory latencies, not of bytes: every loop below keeps the order of its sum (the same bits as the plain loops) but sends its
-  // loads out together -- the plain forms compile to load - wait - add per entry, i.e. ~6 + 12 + 12 latencies in a row (measured 7.7 us against ~4 for a launch).
+  // loads out together -- the plain forms compile to load - wait - add per entry, i.e. ~6 + 12 + 12 latencies in a row (measured 7.7 us against ~4 for a
+  // launch).
   __shared__ double t0[64], w[64], Ms[64 * 64];
   const int t = threadIdx.x, mm = m * m;
   // the small matrix goes to LDS while the chunk sums are added (m <= 64: at most 16 entries per thread)
@@ -585,7 +585,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_gt_fused1d(int n, const int *__re
       epi.partials[(size_t)(epi.prow + 2) * epi.ld + blockIdx.x] = mn;
     }
   }
-  if (EPI == PMH_VEPI_GRAD_SPLIT) { // k_axpy(g, -1, b) + k_split_setp (mpgp.hip): g = A x - b, gf, p = gf, the partials of (0, |gP|^2, |gc|^2, |gf|^2) -- pin is the iterate
+  // k_axpy(g, -1, b) + k_split_setp (mpgp.hip): g = A x - b, gf, p = gf, the partials of (0, |gP|^2, |gc|^2, |gf|^2) -- pin is the iterate
+  if (EPI == PMH_VEPI_GRAD_SPLIT) {
     __shared__ double redg[PMH_BLOCK / 64];
     double            acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (r < n) {

@@ -104,11 +104,13 @@ static int prefetch_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
   if (s->o.be_implicit || s->pf->m == 0 || !pmh_knobs().smalxe_prefetch) return PMH_SUCCESS;
-  if (pmh_op_penalized_normG_ready(s->A_inner, s->u)) { // the kernel that wrote u emitted G0 u; its last workgroup left T G0 u and the squared norm in place (dualchain.hip)
+  // the kernel that wrote u emitted G0 u; its last workgroup left T G0 u and the squared norm in place (dualchain.hip)
+  if (pmh_op_penalized_normG_ready(s->A_inner, s->u)) {
     s->normBu_prefetched = 1;
     return PMH_SUCCESS;
   }
-  if (pmh_op_penalized_take_aux_done(s->A_inner)) { // it rode on the speculative A_rho p of this iteration (arm_normBu below): already in the scalar slot, same bits
+  // it rode on the speculative A_rho p of this iteration (arm_normBu below): already in the scalar slot, same bits
+  if (pmh_op_penalized_take_aux_done(s->A_inner)) {
     s->normBu_prefetched = 1;
     return PMH_SUCCESS;
   }
@@ -117,9 +119,9 @@ static int prefetch_normBu(void *user)
   return PMH_SUCCESS;
 }
 
-// pre-P1 hook (pmh_mpgp_set_pre_p1_hook): the iterate u is final when the inner MPGP enqueues the next A_rho p; G0 u then shares the pass over G0 with the projector's
-// G0 p and T G0 u / its squared norm are finished inside the projector's kernel (the one-launch projector form with m <= 64 only -- the condition under which
-// pmh_qppf_apply_G_norm2 takes the same two kernels on its own)
+// pre-P1 hook (pmh_mpgp_set_pre_p1_hook): the iterate u is final when the inner MPGP enqueues the next A_rho p; G0 u then shares the pass over G0 with the
+// projector's G0 p and T G0 u / its squared norm are finished inside the projector's kernel (the one-launch projector form with m <= 64 only -- the condition
+// under which pmh_qppf_apply_G_norm2 takes the same two kernels on its own)
 static int arm_normBu(void *user)
 {
   pmh_smalxe s = (pmh_smalxe)user;
@@ -220,8 +222,8 @@ static int inner_converged(void *user, int i, double gnorm, int *reason)
   s->MNormBu    = s->M1 * s->normBu;
   s->inner_atol = fmin(s->MNormBu, s->eta);
   {
-    // how far the inner solve is from its end (the inner MPGP does not enqueue the next A_rho p ahead of a test that is likely to end the solve): the larger of the two
-    // thresholds the norm has to fall below; the iteration budget of the throughput mode and the iteration limit end it for certain
+    // how far the inner solve is from its end (the inner MPGP does not enqueue the next A_rho p ahead of a test that is likely to end the solve): the larger of
+    // the two thresholds the norm has to fall below; the iteration budget of the throughput mode and the iteration limit end it for certain
     const bool   gtol_on = !(s->state == 3 && (i < s->o.inner_iter_min || s->o.inner_no_gtol_stop));
     const double thr     = fmax(s->inner_atol, gtol_on ? s->gtol : 0.0);
     double       margin  = gnorm / fmax(thr, 1e-300);
@@ -320,8 +322,8 @@ extern "C" int pmh_smalxe_create(pmh_ctx ctx, pmh_op A, const double *b, double 
 }
 
 // Extension (off by default; the reference forms both quantities by a product of their own, smalxe.c:982 QPComputeObjective and mpgp.c:500 at the start of
-// every inner solve): carry A_rho u from the last gradient of the inner solve -- two operator applications less per outer iteration, the same numbers up to the rounding
-// of g's recurrence over the inner CG steps.  The count of Hessian multiplications then differs from the reference's.
+// every inner solve): carry A_rho u from the last gradient of the inner solve -- two operator applications less per outer iteration, the same numbers up to the
+// rounding of g's recurrence over the inner CG steps.  The count of Hessian multiplications then differs from the reference's.
 extern "C" int pmh_smalxe_set_reuse_products(pmh_smalxe s, int on)
 {
   PMH_ARG(s);
@@ -410,7 +412,8 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     if (s->reason) break;
     PMH_CHK(pmh_vec_waxpy(ctx, n, s->b_inner, -1.0, s->Btmu, s->b)); // b_inner = b - Btmu
     // QPSConvergedSetUp_Inner_SMALXE smalxe.c:537-557
-    if (i == 0) PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs_outer)); // (b does not change over the outer iterations: the same value, one host round trip per outer iteration less)
+    // (b does not change over the outer iterations: the same value, one host round trip per outer iteration less)
+    if (i == 0) PMH_CHK(pmh_vec_norm2(ctx, n, s->b, &s->norm_rhs_outer));
     s->gtol       = s->o.rtol * s->norm_rhs_outer;
     s->ttol_outer = fmax(s->o.rtol * s->norm_rhs_outer, s->o.atol);
     PMH_CHK(pmh_vec_norm2(ctx, n, s->b_inner, &s->outer_norm_rhs_div));
@@ -418,8 +421,9 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->normBu_prefetched = 0;
     s->normBu_final_valid = 0;
     if (s->reuse && i > 0) {
-      // the inner solver still holds g = A_rho u - b_inner of the solve that just ended.  Since then b_inner lost rho_old B'B u (the multiplier update above) and A_rho
-      // gained (rho_new - rho_old) B'B (smalxe_update): the gradient the next solve starts from is g + rho_new B'B u, with B'B u = BtBu already at hand -- no product with F
+      // the inner solver still holds g = A_rho u - b_inner of the solve that just ended.  Since then b_inner lost rho_old B'B u (the multiplier update above)
+      // and A_rho gained (rho_new - rho_old) B'B (smalxe_update): the gradient the next solve starts from is g + rho_new B'B u, with B'B u = BtBu already at
+      // hand -- no product with F
       double  rho_now, *g = nullptr;
       PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho_now));
       PMH_CHK(pmh_mpgp_set_gradient_valid(s->inner, 1, &g));
@@ -434,9 +438,9 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
     s->inner_it_now = st.iteration;
     s->BtBu_valid   = 0;
     s->iteration = i + 1;
-    // QPSSMALXEUpdateNormBu after the inner solve (smalxe.c:977): the inner solver's last convergence test evaluated ||B u|| for this very u (inner_converged calls the same
-    // function on s->u and nothing has moved u since) -- the value is at hand, a second evaluation would cost two launches and a host round trip for the same bits.  Not
-    // with the lagged update (its in-solve value may be the approximate one) or a caller-supplied B'B-only path
+    // QPSSMALXEUpdateNormBu after the inner solve (smalxe.c:977): the inner solver's last convergence test evaluated ||B u|| for this very u (inner_converged
+    // calls the same function on s->u and nothing has moved u since) -- the value is at hand, a second evaluation would cost two launches and a host round trip
+    // for the same bits.  Not with the lagged update (its in-solve value may be the approximate one) or a caller-supplied B'B-only path
     if (!(s->normBu_final_valid && !s->o.be_implicit && !s->o.lag_enabled)) PMH_CHK(update_normBu(s, s->u, &s->normBu, &s->enorm));
     PMH_CHK(pmh_op_penalized_get_penalty(s->A_inner, &rho));
     if (s->reuse) { // f = -u'(b_inner - 1/2 A_rho u) with A_rho u = g + b_inner: -1/2 u'(b_inner - g)
@@ -456,7 +460,8 @@ extern "C" int pmh_smalxe_solve(pmh_smalxe s)
   return PMH_SUCCESS;
 }
 
-// QPSReset for a solver object that is to solve again from a fresh initial guess: the state machine of QPSConverged_Inner_SMALXE back to 1 (as after QPSCreate, smalxe.c:1149)
+// QPSReset for a solver object that is to solve again from a fresh initial guess: the state machine of QPSConverged_Inner_SMALXE back to 1 (as after QPSCreate,
+// smalxe.c:1149)
 extern "C" int pmh_smalxe_reset(pmh_smalxe s)
 {
   PMH_ARG(s);
@@ -464,8 +469,8 @@ extern "C" int pmh_smalxe_reset(pmh_smalxe s)
   return PMH_SUCCESS;
 }
 
-// the limit of the inner solver's iterations summed over the outer iterations (the inner QPS's max_it: QPSConverged_Inner_SMALXE smalxe.c:626-631 ends the solve with
-// DIVERGED_ITS / outer DIVERGED_BREAKDOWN once inner iteration i > max_it - accumulated)
+// the limit of the inner solver's iterations summed over the outer iterations (the inner QPS's max_it: QPSConverged_Inner_SMALXE smalxe.c:626-631 ends the
+// solve with DIVERGED_ITS / outer DIVERGED_BREAKDOWN once inner iteration i > max_it - accumulated)
 extern "C" int pmh_smalxe_set_inner_max_it(pmh_smalxe s, int max_it)
 {
   PMH_ARG(s && max_it >= 0);
@@ -553,7 +558,8 @@ extern "C" int pmh_pcpg_solve(pmh_ctx ctx, pmh_op A, const double *b, double *x,
         PC_CHK(pmh_vec_copy(ctx, n, r, w));
       }
       PC_CHK(pmh_vec_norm2(ctx, n, w, &st->rnorm));
-      if (monitor) fprintf(stderr, "%3d KSP Residual norm %.12e (threshold %.12e)\n", st->iteration, st->rnorm, ttol); // -ksp_monitor's line (PMH_KSP_MONITOR=1)
+      // -ksp_monitor's line (PMH_KSP_MONITOR=1)
+      if (monitor) fprintf(stderr, "%3d KSP Residual norm %.12e (threshold %.12e)\n", st->iteration, st->rnorm, ttol);
       st->reason = PMH_CONVERGED_ITERATING; // QPSConvergedDefault
       if (st->iteration > max_it) st->reason = PMH_DIVERGED_ITS;
       else if (std::isnan(st->rnorm) || std::isinf(st->rnorm)) st->reason = PMH_DIVERGED_NANORINF;

@@ -27,7 +27,8 @@ struct SvmDualOp : pmh_op_s {
   int           mult_epi(const double *in, double *out, const pmh_vec_epi &e) override;
   int           spec_expansion_ready() override { return next_is == NEXT_XSPEC; }
   enum { NEXT_NONE = 0, NEXT_P, NEXT_XSPEC };
-  int           next_is = NEXT_NONE; // what part_next holds the partial sums of X'(y o v) for: the p of the last gradient split / the prepared expansion iterate
+  // what part_next holds the partial sums of X'(y o v) for: the p of the last gradient split / the prepared expansion iterate
+  int           next_is = NEXT_NONE;
   const double *next_p = nullptr;
   double       *part_next = nullptr, *feas_part = nullptr, *d_afeas = nullptr, *x_spec = nullptr;
   int           grid_epi = 0;
@@ -168,16 +169,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64(int n, const double *__re
 
 // ---- paired passes -------------------------------------------------------------------------------------------------------------------------
 // One application of H streams X twice (w = X'(y o a), then y o (X w)); an MPGP expansion step applies H twice (Ap = H p, then g = H x+ - b): four passes over
-// X, 2.56 GB each for configs[4], and the kernels already run at the box's streaming rate.  But the row that pass 2 of one application has in registers is the row
-// pass 1 of the NEXT application needs, and what that next application multiplies is an elementwise function of this pass's result:
-//   * the gradient pass  g_i = y_i (x_i . w) - b_i  knows gf_i, hence p_i = gf_i, hence (y_i p_i) x_i: it accumulates X'(y o p) for the P1 that follows, and the
+// X, 2.56 GB each for configs[4], and the kernels already run at the box's streaming rate.  But the row that pass 2 of one application has in registers is the
+// row pass 1 of the NEXT application needs, and what that next application multiplies is an elementwise function of this pass's result:
+//   * the gradient pass g_i = y_i (x_i . w) - b_i knows gf_i, hence p_i = gf_i, hence (y_i p_i) x_i: it accumulates X'(y o p) for the P1 that follows, and the
 //     feasible step length QPCFeas(x, p) (which needs no Ap);
 //   * the P1 pass  (Ap)_i = y_i (x_i . w)  knows, with that afeas and the fixed alpha, the iterate an expansion step would produce,
-//     x+_i = k_expansion_std(x_i, g_i, p_i, (Ap)_i): it stores it and accumulates X'(y o x+) for the gradient that follows IF the host then chooses the expansion.
+//     x+_i = k_expansion_std(x_i, g_i, p_i, (Ap)_i): it stores it and accumulates X'(y o x+) for the gradient that follows IF the host then chooses the
+//       expansion.
 // A run of expansion steps costs two passes over X per step instead of four; a CG or proportioning step discards the prepared sums and pays the usual passes.
 // The driver says what is fresh (pmh_vec_epi::p_fresh / spec_alpha / x_from_spec); the partial sums of the MPGP reductions go to the same rows of the context's
-// partials as the separate Vec kernels write, one entry per workgroup of pmh_vec_grid(n) (the elements a workgroup sums are other ones: same values to rounding).
-// the two column sums a lane holds (columns 2 l2, 2 l2 + 1 of the rows its half of the wave visited) -> part[workgroup][64], as k_svm_xt64
+// partials as the separate Vec kernels write, one entry per workgroup of pmh_vec_grid(n) (the elements a workgroup sums are other ones: same values to
+// rounding). the two column sums a lane holds (columns 2 l2, 2 l2 + 1 of the rows its half of the wave visited) -> part[workgroup][64], as k_svm_xt64
 static __device__ __forceinline__ void svm_fold_cols(double a0, double a1, double (*lds)[64], double *__restrict__ part)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l2 = lane & 31;
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_x64_grad(int n, const double 
       const long long i = r0 + 2 * u + half;
       v[u] = (i < n) ? __builtin_nontemporal_load((const dbl2 *)(X + (size_t)i * 64) + l2) : dbl2{0.0, 0.0};
     }
-    // the rows' dot products land in the first lane of each half-wave; lane j < 2 SVM_EU takes row r0 + j (u = j >> 1, half = j & 1): ONE coalesced load per vector
-    // for the 2 SVM_EU rows (a load per row costs the address unit a whole instruction each: measured 2 x the time of the plain pass), asked for before the dot
-    // products so that they travel with the rows of X, the elementwise work once
+    // the rows' dot products land in the first lane of each half-wave; lane j < 2 SVM_EU takes row r0 + j (u = j >> 1, half = j & 1): ONE coalesced load per
+    // vector for the 2 SVM_EU rows (a load per row costs the address unit a whole instruction each: measured 2 x the time of the plain pass), asked for before
+    // the dot products so that they travel with the rows of X, the elementwise work once
     const long long i   = r0 + lane;
     const bool      act = lane < 2 * SVM_EU && i < n;
     double          yi = 0.0, xi = 0.0, bi = 0.0, li = -INFINITY, ui = INFINITY;
@@ -368,12 +370,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_svm_colsum_feas(int nblocks, cons
 
 int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
 {
-  // (the switch may change between two solves of one process: pmh_set_knob("svm_pairing"), initial value from PMH_SVM_NO_PAIRING -- no getenv on the per-product path.  It is
-  // process-wide state that every rank of a job must set alike: ranks that disagree would issue different sequences of collectives)
+  // (the switch may change between two solves of one process: pmh_set_knob("svm_pairing"), initial value from PMH_SVM_NO_PAIRING -- no getenv on the
+  // per-product path.  It is process-wide state that every rank of a job must set alike: ranks that disagree would issue different sequences of collectives)
   if (n <= 0 && pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_ARG, "SVM dual operator: this rank holds no samples; with a communicator every rank needs at least one row (an empty shard would skip the collectives the other ranks issue)");
   if (!pmh_knobs().svm_pairing || d != 64 || n <= 0) return PMH_EPI_UNSUPPORTED;
-  // several GPUs (samples sharded by rows): the 64 column sums w and, where the next pass uses it, the feasible step length afeas are completed across the ranks between the
-  // passes -- the same exchange step as the lone application's, one (+ one 8-byte MIN) per pass
+  // several GPUs (samples sharded by rows): the 64 column sums w and, where the next pass uses it, the feasible step length afeas are completed across the
+  // ranks between the passes -- the same exchange step as the lone application's, one (+ one 8-byte MIN) per pass
   if (!part_next) {
     grid_epi = pmh_vec_grid(n); // one partial sum per workgroup, where pmh_finalize_partials expects them
     PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)grid_epi * 64, (void **)&part_next));
@@ -386,7 +388,8 @@ int SvmDualOp::mult_epi(const double *in, double *out, const pmh_vec_epi &e)
   if (e.kind == PMH_VEPI_GRAD_SPLIT) {
     const bool spec = e.x_from_spec && have == NEXT_XSPEC;
     if (e.x_from_spec && !spec) return pmh_set_error(PMH_ERR_STATE, "SVM dual operator: the driver asks for the prepared expansion step, none is prepared");
-    if (spec) hipLaunchKernelGGL(k_svm_colsum_feas, dim3(17), dim3(PMH_BLOCK), 0, ctx->stream, grid_epi, (const double *)part_next, w, (const double *)feas_part, d_afeas); // (the min it also takes is not used here)
+    // (the min it also takes is not used here)
+    if (spec) hipLaunchKernelGGL(k_svm_colsum_feas, dim3(17), dim3(PMH_BLOCK), 0, ctx->stream, grid_epi, (const double *)part_next, w, (const double *)feas_part, d_afeas);
     else {
       SVM_PASS(k_svm_xt64<4>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, in, part);
       hipLaunchKernelGGL(k_svm_colsum, dim3(16), dim3(PMH_BLOCK), 0, ctx->stream, nblocks, d, (const double *)part, w);
@@ -430,9 +433,9 @@ int SvmDualOp::mult(const double *a, double *Ha)
   next_is = NEXT_NONE; // (whatever was prepared belonged to the MPGP driver's vectors)
   if (n == 0 && pmh_comm_on(ctx)) return pmh_set_error(PMH_ERR_ARG, "SVM dual operator: this rank holds no samples; with a communicator every rank needs at least one row");
   if (d == 64 && n > 0) {
-    // rows in flight per wave-instruction group: 2 x UNR rows of 512 B (16-byte loads, UNR of them outstanding per lane).  UNR decides which wave visits which rows,
-    // i.e. the summation order of pass 1 (last-digit differences between UNR values; fixed for a given UNR).  Measured 4 / 8 / 12 / 16 on configs[4]: 464 / 452-488 / 433 / 487
-    // iterations per second -- inside the run-to-run spread of the box (the two passes already stream X at the box's copy rate): 4 stays
+    // rows in flight per wave-instruction group: 2 x UNR rows of 512 B (16-byte loads, UNR of them outstanding per lane).  UNR decides which wave visits which
+    // rows, i.e. the summation order of pass 1 (last-digit differences between UNR values; fixed for a given UNR).  Measured 4 / 8 / 12 / 16 on configs[4]: 464
+    // / 452-488 / 433 / 487 iterations per second -- inside the run-to-run spread of the box (the two passes already stream X at the box's copy rate): 4 stays
     static const int unr = getenv("PMH_SVM_UNR") ? atoi(getenv("PMH_SVM_UNR")) : 4;
 #define SVM_GO(U)                                                                                                                          \
   do {                                                                                                                                     \
