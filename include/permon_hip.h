@@ -644,6 +644,17 @@ int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, con
 int pmh_mpgp_run_fixed(pmh_mpgp s, int iters);
 int pmh_smalxe_run_fixed(pmh_smalxe s, int inner_iters, int *solves, int *outer_iters, int *ncg, int *nexp, int *nprop, int *nmv);
 
+/* ---- multi-right-hand-side K^+ (csrc/mv.hip, mg_mv.hip, matinv_mv.hip): PMH_MV_R = 8 columns per block solved together on interleaved multivectors
+ * V[(dof) * 8 + column] -- the column-blocked set-up of the explicit inverse (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:640-730: MatMatSolve on blocks of
+ * right-hand sides) for blocks with NO symmetry and NO congruence: every 3 x 3 block of K_b is loaded once for the 8 columns.
+ * pmh_mv_test_spmv: the operator product alone (measurement / test entry): Y = A X for a resident CSR of 3 x 3 blocks and 8 columns, entries kept in `storage`
+ * (0 fp64, 1 fp32, 2 fp16 with fp32 vectors); x, y: device, 8 n doubles; the average launch time of `repeats` products through HIP events. */
+int pmh_mv_test_spmv(pmh_csr A, int storage, const double *x, double *y, int repeats, float *ms_per_launch);
+/* U = K^+ F for 8 columns per block at once: F, U device arrays of 8 n doubles, entry (dof i, column r) at i * 8 + r; K, the V-cycle (pmh_matinv_set_pc_mg), the kernel
+ * basis (pmh_matinv_set_nullspace: K^+ = P_R K^- P_R) and the tolerances are the solver's own; every (block, column) pair converges by its own test.  PMH_ERR_SUP where
+ * the multi-right-hand-side kernels do not apply (K without regular 3 x 3 blocks, a V-cycle other than the fused fp32 one, the left generalised inverse). */
+int pmh_matinv_mult_multi(pmh_matinv M, const double *F, double *U, int *max_iterations /* or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,6 +250,8 @@ _PROTOS = {
     "pmh_mg_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_matinv_enable_bsr3": [vp],
     "pmh_matinv_bsr3_replicas": [vp, c_int_p],
+    "pmh_mv_test_spmv": [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float)],
+    "pmh_matinv_mult_multi": [vp, vp, vp, c_int_p],
     "pmh_matinv_timing_enable": [vp, C.c_int],
     "pmh_matinv_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pmh_mg_apply": [vp, vp, vp],
@@ -334,4 +336,6 @@ def load(strict=True):
 
 def check(rc):
     if rc != 0:
-        raise PermonHipError("libpermonhip error %d: %s" % (rc, load().pmh_last_error().decode(errors="replace")))
+        ex = PermonHipError("libpermonhip error %d: %s" % (rc, load().pmh_last_error().decode(errors="replace")))
+        ex.code = int(rc)
+        raise ex

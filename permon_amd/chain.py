@@ -105,7 +105,7 @@ class FetiDualQP:
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
-    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None, symmetry=None):
+    def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None, symmetry=None, multi_rhs="auto"):
         """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
         right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
         has fewer blocks than min_slots and all of them are congruent.  Attaches the result to K^+: every F built on it is explicit.
@@ -114,6 +114,9 @@ class FetiDualQP:
         an even share of 128-row stripes of every W_b instead of its own blocks (pmh_fexplicit_set_stripe).
         symmetry = dict(dims=(nx, ny, nz), ndof=3) ("class_sym", all blocks one class of box-shaped blocks): the signed coordinate permutations of the
         box that leave K invariant (feti.box_symmetries, checked against K) serve the set-up: one K^+ solve per orbit of rows (a cube: 48 x fewer).
+        multi_rhs: True / False / "auto" -- the set-up solves 8 columns per block at a time on the multi-right-hand-side K^+ (matinv_mv.hip: every 3 x 3 block of K_b loaded once
+        for 8 columns, every launch of the V-cycle serving 8 columns; blocks need no symmetry and no congruence for it); "auto": where that solver applies (fused fp32 V-cycle on
+        3 x 3 blocks, no left inverse), else one column per block.
         symmetry["close"] ("class_orbit", several classes): every class's touched set is extended to its closure under the box's operations (mat.box_symmetry_closure: the whole
         boundary of a cube), so that a class of ONE block -- a decomposition into boxes of different materials -- keeps all of them instead of the 2 ... 8 its own faces allow."""
         import scipy.sparse as sp
@@ -179,14 +182,30 @@ class FetiDualQP:
             break
         self.explicit_storage = storage
         ngl = len(stripe[2]["block_rowstart"]) - 1 if stripe is not None else nb
-        if solver_factory is not None and nb < min_slots and one_class:
-            solver = solver_factory(int(min_slots))
-            E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
-            self._replica_solver = solver
-        elif stripe is not None:
-            E.assemble(self.Kplus, slot_class=np.zeros(nb, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
+        def run(mv):
+            if solver_factory is not None and nb < min_slots and one_class and not mv:
+                solver = solver_factory(int(min_slots))
+                E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
+                self._replica_solver = solver
+            elif stripe is not None:
+                E.assemble(self.Kplus, slot_class=np.zeros(nb, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it, multi_rhs=mv)
+            else:
+                E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it, multi_rhs=mv)
+
+        self.explicit_multi_rhs = False
+        if multi_rhs == "auto":
+            from ._lib import PermonHipError
+
+            try:
+                run(True)
+                self.explicit_multi_rhs = True
+            except PermonHipError as ex:
+                if getattr(ex, "code", 0) != 4:  # PMH_ERR_SUP: the multi-right-hand-side solver does not apply here
+                    raise
+                run(False)
         else:
-            E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it)
+            run(bool(multi_rhs))
+            self.explicit_multi_rhs = bool(multi_rhs)
         self.Kplus.attach_explicit(E)
         return E
 

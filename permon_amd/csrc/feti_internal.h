@@ -1,5 +1,6 @@
 // Handle structs of the FETI Mats shared by feti.hip and fexplicit.hip (internal; public ABI: include/permon_hip.h)
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "pmh_internal.h"
@@ -60,3 +61,41 @@ bool pmh_fexplicit_matches(pmh_fexplicit_s *E, pmh_gluing B);
 int  pmh_fexplicit_apply(pmh_fexplicit_s *E, const double *lambda, double *y);
 int  pmh_fexplicit_stages(pmh_fexplicit_s *E, pmh_csr *gather, double **mid_in, pmh_csr *scatter, const double **mid_out); // the sparse stages around the dense one (FetiDualOp::stages)
 int  pmh_fexplicit_mid(pmh_fexplicit_s *E);                                                                                // the dense stage alone: mid_in -> mid_out
+
+// ---- what the set-up loops of the explicit operators (fexplicit.hip, fshared.hip) need from a K^+ solver: one COLUMN per slot ----------------------------------
+// nslots == solver->nblocks: slot s = block s of the one-column solver (pmh_matinv_mult).  nslots == PMH_MV_R * solver->nblocks: the multi-right-hand-side solver
+// (matinv_mv.hip), slot s = column s % R of block s / R; its interleaved result is laid out column by column before the rows are extracted.
+#include "mv_internal.h"
+struct pmh_asm_solver {
+  pmh_matinv    M = nullptr;
+  pmh_matinv_mv V = nullptr;
+  double       *umv = nullptr; // mv: the interleaved result (the caller's `sol` receives the columns one after the other)
+  int open(pmh_matinv solver, int nslots)
+  {
+    M = solver;
+    if (nslots == solver->nblocks) return PMH_SUCCESS;
+    if (nslots != solver->nblocks * PMH_MV_R) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: %d slots for a solver of %d blocks (one per block, or %d per block)", nslots, solver->nblocks, PMH_MV_R);
+    int rc = pmh_matinv_mv_create(solver, &V);
+    if (rc == PMH_EPI_UNSUPPORTED)
+      return pmh_set_error(PMH_ERR_SUP, "pmh_fexplicit_assemble: the multi-right-hand-side K^+ does not apply to this solver: %s", pmh_mv_why());
+    if (rc) return rc;
+    return pmh_malloc(M->ctx, sizeof(double) * len(), (void **)&umv);
+  }
+  void close()
+  {
+    if (V) pmh_matinv_mv_destroy(V), V = nullptr;
+    if (umv) pmh_free(M->ctx, umv), umv = nullptr;
+  }
+  int    R() const { return V ? PMH_MV_R : 1; }
+  size_t len() const { return (size_t)std::max(1, M->n) * R(); }
+  int    rows(int s) const { return M->K->rowstart[s / R() + 1] - M->K->rowstart[s / R()]; }
+  int    rhs_index(int s, int rel) const { return V ? (M->K->rowstart[s / PMH_MV_R] + rel) * PMH_MV_R + s % PMH_MV_R : M->K->rowstart[s] + rel; }
+  const double *sol_of(const double *sol, int s) const { return V ? sol + (size_t)(s % PMH_MV_R) * M->n + M->K->rowstart[s / PMH_MV_R] : sol + M->K->rowstart[s]; }
+  int solve(const double *rhs, double *sol)
+  {
+    if (!V) return pmh_matinv_mult(M, rhs, sol);
+    PMH_CHK(pmh_matinv_mv_mult(V, rhs, umv));
+    return pmh_matinv_mv_to_columns(V, umv, sol);
+  }
+  bool hit_the_limit() const { return (V ? pmh_matinv_mv_last_iterations(V) : M->last_max_its) >= M->max_it; }
+};

@@ -753,8 +753,8 @@ static inline bool fx_owns_row(pmh_fexplicit E, int b, int p) { return E->stripe
 // class have identical K_b, so K_b^+ e_j serves all of them).  NULL, NULL: slot s <-> block s (the solver is the operator's own K^+).
 extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it)
 {
-  PMH_ARG(E && solver && nslots >= 1 && solver->nblocks == nslots);
-  PMH_ARG((slot_class && block_class) || (!slot_class && !block_class && nslots == E->nb));
+  PMH_ARG(E && solver && nslots >= 1 && (solver->nblocks == nslots || solver->nblocks * PMH_MV_R == nslots));
+  PMH_ARG((slot_class && block_class) || (!slot_class && !block_class && (nslots == E->nb || nslots == E->nb * PMH_MV_R)));
   if (E->sh) { // class-shared storage: one full row of W_c per solve (the classes are those given at creation)
     PMH_ARG(slot_class);
     auto t0s = std::chrono::steady_clock::now();
@@ -767,11 +767,16 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   const int nb  = E->nb;
   auto      t0  = std::chrono::steady_clock::now();
   std::vector<int> sc(nslots), bc(nb);
-  for (int s = 0; s < nslots; s++) sc[s] = slot_class ? slot_class[s] : s;
+  for (int s = 0; s < nslots; s++) sc[s] = slot_class ? slot_class[s] : s / (nslots / nb); // (no classes given: slot s is block s, or column s % R of block s / R)
   for (int b = 0; b < nb; b++) bc[b] = block_class ? block_class[b] : b;
   int ncls = 0;
   for (int b = 0; b < nb; b++) ncls = std::max(ncls, bc[b] + 1);
-  const std::vector<int> &srs = solver->K->rowstart;
+  pmh_asm_solver A;
+  PMH_CHK(A.open(solver, nslots));
+  struct closer {
+    pmh_asm_solver &a;
+    ~closer() { a.close(); }
+  } closer_{A};
   // per class: its slots, its blocks, the union of the blocks' relative Gamma indices
   std::vector<std::vector<int>> cslots(ncls), cblocks(ncls), cunion(ncls);
   for (int s = 0; s < nslots; s++)
@@ -787,7 +792,7 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
     for (int b : cblocks[c])
       if (E->K->rowstart[b + 1] - E->K->rowstart[b] != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: blocks of class %d differ in size", c);
     for (int s : cslots[c])
-      if (srs[s + 1] - srs[s] != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, nloc);
+      if (A.rows(s) != nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, A.rows(s), c, nloc);
     std::vector<char> in((size_t)std::max(1, nloc), 0);
     for (int b : cblocks[c])
       for (size_t k = E->goff[b]; k < E->goff[b + 1]; k++)
@@ -806,7 +811,7 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
     if (!cblocks[c].empty()) nbatch = std::max(nbatch, (int)((cunion[c].size() + cslots[c].size() - 1) / cslots[c].size()));
   double *rhs, *sol;
   int    *d_idx, *h_idx;
-  const size_t nsol = (size_t)std::max(1, solver->n);
+  const size_t nsol = A.len();
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&rhs));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&sol));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * nslots, (void **)&d_idx));
@@ -828,7 +833,7 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
         if (j < cunion[c].size()) {
           const int s = cslots[c][t];
           col[s]      = cunion[c][j];
-          hh[s]       = srs[s] + col[s];
+          hh[s]       = A.rhs_index(s, col[s]);
         }
       }
     }
@@ -837,8 +842,8 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
       break;
     }
     hipLaunchKernelGGL(k_fx_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
-    if ((rc = pmh_matinv_mult(solver, rhs, sol))) break;
-    if (solver->last_max_its >= solver->max_it) { // a column that is not converged would silently make F inexact
+    if ((rc = A.solve(rhs, sol))) break;
+    if (A.hit_the_limit()) { // a column that is not converged would silently make F inexact
       rc = pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_assemble: a set-up solve of batch %d did not reach rtol %.1e within %d iterations of the inner KSP", k, rtol, solver->max_it);
       break;
     }
@@ -854,9 +859,9 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
         const int       n    = (E->storage == PMH_FX_SYM) ? std::min(E->ngam[b], FX_RB * (kb + 1)) : E->ngam[b];
         const dim3      grid(std::max(1, std::min(64, (n + PMH_BLOCK - 1) / PMH_BLOCK)));
         if (E->storage == PMH_FX_SYM)
-          hipLaunchKernelGGL(k_fx_extract_tiled, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), (const double *)(sol + srs[s]), E->W[b] + fx_band_off(kb), p - FX_RB * kb);
+          hipLaunchKernelGGL(k_fx_extract_tiled, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), A.sol_of(sol, s), E->W[b] + fx_band_off(kb), p - FX_RB * kb);
         else
-          hipLaunchKernelGGL(k_fx_extract, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), (const double *)(sol + srs[s]), E->W[b] + (long long)p * E->ld[b]);
+          hipLaunchKernelGGL(k_fx_extract, grid, dim3(PMH_BLOCK), 0, ctx->stream, n, (const int *)(E->d_gamma_rel + E->goff[b]), A.sol_of(sol, s), E->W[b] + (long long)p * E->ld[b]);
       }
     }
     if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);

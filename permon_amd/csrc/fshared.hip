@@ -547,10 +547,15 @@ static int fxo_gemm(fx_shared *S)
 
 int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_class, double rtol, int max_it, long long *n_solves)
 {
-  PMH_ARG(S && solver && nslots >= 1 && solver->nblocks == nslots && slot_class);
+  PMH_ARG(S && solver && nslots >= 1 && (solver->nblocks == nslots || solver->nblocks * PMH_MV_R == nslots) && slot_class);
   pmh_ctx                       ctx = S->ctx;
   if (S->sym == 2) PMH_CHK(fxo_prepare(S));
-  const std::vector<int>       &srs = solver->K->rowstart;
+  pmh_asm_solver                A;
+  PMH_CHK(A.open(solver, nslots));
+  struct closer {
+    pmh_asm_solver &a;
+    ~closer() { a.close(); }
+  } closer_{A};
   std::vector<std::vector<int>> cslots(S->ncls), todo(S->ncls);
   std::vector<std::vector<int>> rep_of(S->ncls), op_of(S->ncls), check(S->ncls);
   std::vector<std::map<int, std::vector<int>>> members(S->ncls); // representative row -> the owned rows of its orbit
@@ -562,7 +567,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
     if (C.nc == 0) continue;
     if (cslots[c].empty()) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: no solver slot for block class %d", c);
     for (int s : cslots[c])
-      if (srs[s + 1] - srs[s] != C.nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, srs[s + 1] - srs[s], c, C.nloc);
+      if (A.rows(s) != C.nloc) return pmh_set_error(PMH_ERR_ARG, "pmh_fexplicit_assemble: slot %d has %d rows, class %d blocks have %d", s, A.rows(s), c, C.nloc);
     if (S->sym == 2) {
       // orbit storage: the owned representatives; self-check: rows of their orbits reached by a non-trivial operation
       for (int pl = 0; pl < C.m1 - C.m0; pl++) todo[c].push_back(C.reps[C.m0 + pl]);
@@ -604,7 +609,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
   }
   double      *rhs, *sol;
   int         *d_idx, *h_idx;
-  const size_t nsol = (size_t)std::max(1, solver->n);
+  const size_t nsol = A.len();
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&rhs));
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * nsol, (void **)&sol));
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * nslots, (void **)&d_idx));
@@ -625,7 +630,7 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
         if (j < todo[c].size()) {
           const int s = cslots[c][t];
           prow[s]     = todo[c][j];
-          hh[s]       = srs[s] + S->C[c].urel[prow[s]];
+          hh[s]       = A.rhs_index(s, S->C[c].urel[prow[s]]);
         }
       }
     if (hipMemcpyAsync(d_idx, hh, sizeof(int) * nslots, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
@@ -633,8 +638,8 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       break;
     }
     hipLaunchKernelGGL(k_fxs_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
-    if ((rc = pmh_matinv_mult(solver, rhs, sol))) break;
-    if (solver->last_max_its >= solver->max_it) {
+    if ((rc = A.solve(rhs, sol))) break;
+    if (A.hit_the_limit()) {
       rc = pmh_set_error(PMH_ERR_STATE, "pmh_fexplicit_assemble: a set-up solve of batch %d did not reach rtol %.1e within %d iterations of the inner KSP", k, rtol, solver->max_it);
       break;
     }
@@ -646,21 +651,21 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), prow[s]) - C.reps.begin()) - C.m0;
         hipLaunchKernelGGL(k_fxo_store_row, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (const int *)C.d_urel,
-                           (const int *)C.d_kinv, (const double *)(sol + srs[s]), S->Afund + C.aoff);
+                           (const int *)C.d_kinv, A.sol_of(sol, s), S->Afund + C.aoff);
       } else if (S->sym && C.nsym > 1) {
         const int p = prow[s];
         for (int r : members[slot_class[s]][p]) {
           const int g = op_of[slot_class[s]][r], sb = r / FXM_RS;
           hipLaunchKernelGGL(k_fxs_extract_symg, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, r, C.nc, (double)C.h_sign[(size_t)g * C.nc + p],
-                             (const int *)C.d_urel, (const double *)(sol + srs[s]), (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc),
+                             (const int *)C.d_urel, A.sol_of(sol, s), (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc),
                              S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
         }
       } else if (S->sym) {
         const int sb = prow[s] / FXM_RS;
-        hipLaunchKernelGGL(k_fxs_extract_sym, dim3(std::max(1, std::min(64, (prow[s] + PMH_BLOCK) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, prow[s], (const int *)C.d_urel, (const double *)(sol + srs[s]),
+        hipLaunchKernelGGL(k_fxs_extract_sym, dim3(std::max(1, std::min(64, (prow[s] + PMH_BLOCK) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, prow[s], (const int *)C.d_urel, A.sol_of(sol, s),
                            S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2));
       } else
-      hipLaunchKernelGGL(k_fxs_extract, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.nc, (const int *)C.d_urel, (const double *)(sol + srs[s]),
+      hipLaunchKernelGGL(k_fxs_extract, dim3(std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK))), dim3(PMH_BLOCK), 0, ctx->stream, C.nc, (const int *)C.d_urel, A.sol_of(sol, s),
                          S->Wbase + C.woff + (long long)prow[s] * C.ld); // row p of W_c = column p (K^+ symmetric)
     }
     if (hipGetLastError() != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: launch failed in batch %d", k);
@@ -675,14 +680,14 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
     for (int c = 0; c < S->ncls; c++)
       for (size_t t = 0; t < check[c].size(); t++) {
         const int s = cslots[c][t];
-        prow[s] = check[c][t], hh[s] = srs[s] + S->C[c].urel[prow[s]];
+        prow[s] = check[c][t], hh[s] = A.rhs_index(s, S->C[c].urel[prow[s]]);
       }
     double *d_out = nullptr, h_out[2 * 64];
     rc = pmh_malloc(ctx, sizeof(double) * 2 * 64, (void **)&d_out);
     if (!rc && hipMemcpyAsync(d_idx, hh, sizeof(int) * nslots, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_fexplicit_assemble: index upload failed");
     if (!rc) {
       hipLaunchKernelGGL(k_fxs_set_entries, dim3((nslots + 63) / 64), dim3(64), 0, ctx->stream, nslots, (const int *)d_idx, 1.0, rhs);
-      rc = pmh_matinv_mult(solver, rhs, sol);
+      rc = A.solve(rhs, sol);
     }
     for (int s = 0; s < nslots && !rc; s++) {
       if (prow[s] < 0) continue;
@@ -693,10 +698,10 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
       if (S->sym == 2) {
         const int g = C.op_of[r], p = C.rep_of[r], pl = (int)(std::lower_bound(C.reps.begin(), C.reps.end(), p) - C.reps.begin()) - C.m0;
         nb          = std::max(1, std::min(64, (C.nc + PMH_BLOCK - 1) / PMH_BLOCK));
-        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const int *)C.d_kinv, (const double *)(sol + srs[s]),
+        hipLaunchKernelGGL(k_fxo_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, C.reprow[pl], C.tm, C.nc, C.nkc, (double)C.h_sign[(size_t)g * C.nc + p], (const int *)C.d_urel, (const int *)C.d_kinv, A.sol_of(sol, s),
                            (const int *)(C.d_posmap + (size_t)g * C.nc), (const signed char *)(C.d_sign + (size_t)g * C.nc), (const double *)(S->Afund + C.aoff), d_out);
       } else
-      hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, (const double *)(sol + srs[s]),
+      hipLaunchKernelGGL(k_fxs_check_row, dim3(nb), dim3(PMH_BLOCK), 0, ctx->stream, r, (const int *)C.d_urel, A.sol_of(sol, s),
                          (const double *)(S->Wbase + C.woff + (long long)FXM_RS * FXM_RS * ((long long)sb * (sb + 1) / 2)), d_out);
       if ((rc = pmh_memcpy_d2h(ctx, h_out, d_out, sizeof(double) * 2 * nb))) break;
       double d = 0.0, m = 0.0;

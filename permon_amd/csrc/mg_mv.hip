@@ -1,0 +1,227 @@
+// Multi-right-hand-side K^+, part 2: the V-cycle of mg.hip on interleaved multivectors of R = PMH_MV_R columns (see mv_internal.h).
+//
+// The hierarchy is the one pmh_mg holds (level operators as CSR, node-wise transfer operators, Jacobi scaling, Chebyshev constants, dense coarse pseudo-inverses):
+// nothing is set up twice but the ELL copies of the level operators (built on the device, mv.hip) and the work multivectors.  The cycle is the fused form of
+// mg.hip (mg_level_fused): degree-2 Chebyshev/Jacobi smoothing finished inside the operator kernel, fp32 vectors, level operators in the precision pmh_mg keeps
+// them in (fp16 on the finest levels by default).  Per smoothed level: d0 | PRE | SUB | restrict (+ the coarse d0) | ... | prolong-subtract | POST1 | POST2.
+// A hierarchy of another shape (fp64 cycle, other degree, P not node-wise, a level without 3 x 3 blocks) is refused (PMH_EPI_UNSUPPORTED, no error recorded): the
+// caller keeps the one-column solver.
+#include "mg_internal.h"
+#include "mv_internal.h"
+
+#define MV_R PMH_MV_R
+typedef float mvg_flt4 __attribute__((ext_vector_type(4)));
+
+struct mg_mv_level {
+  pmh_mv_ell E = nullptr;
+  float     *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xa = nullptr;
+};
+struct pmh_mg_mv_s {
+  pmh_mg                   mg;
+  std::vector<mg_mv_level> L;
+};
+
+// d0 = D^-1 b / theta (and the fp32 copy of an fp64 b): one thread per 4 consecutive entries of a row's R columns
+template <typename TB>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_d0(long long nR, const int *__restrict__ halt, const float *__restrict__ dinv, const TB *__restrict__ b, float itheta, float *__restrict__ d, float *__restrict__ bcopy)
+{
+  if (halt && *halt) return;
+  for (long long i = 4 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x); i < nR; i += 4LL * gridDim.x * PMH_BLOCK) {
+    const float di = dinv[i / MV_R] * itheta;
+    float       v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (float)b[i + k];
+    if (bcopy) *(mvg_flt4 *)(bcopy + i) = mvg_flt4{v[0], v[1], v[2], v[3]};
+    *(mvg_flt4 *)(d + i) = mvg_flt4{di * v[0], di * v[1], di * v[2], di * v[3]};
+  }
+}
+
+// b_c = P' t, node-wise P' (<= 27 entries per coarse node), every entry serving the 3 R values of its fine node: lane (coarse node, column r); optionally the coarse
+// level's first smoothing direction d_c = D_c^-1 b_c / theta_c
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict(int ncn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val, const float *__restrict__ t,
+                                                           float *__restrict__ bc, const float *__restrict__ dinv_c, float itheta_c, float *__restrict__ d_c)
+{
+  if (halt && *halt) return;
+  const int r = threadIdx.x % MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < ncn; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+      const float  w = val[k];
+      const float *p = t + (size_t)3 * col[k] * MV_R + r;
+      s0 += w * p[0], s1 += w * p[MV_R], s2 += w * p[2 * MV_R];
+    }
+    float *o = bc + (size_t)3 * i * MV_R + r;
+    o[0] = s0, o[MV_R] = s1, o[2 * MV_R] = s2;
+    if (dinv_c) {
+      float *dd = d_c + (size_t)3 * i * MV_R + r;
+      dd[0] = dinv_c[3 * i] * s0 * itheta_c, dd[MV_R] = dinv_c[3 * i + 1] * s1 * itheta_c, dd[2 * MV_R] = dinv_c[3 * i + 2] * s2 * itheta_c;
+    }
+  }
+}
+
+// x -= P x_c, node-wise P (<= 8 entries per fine node): lane (fine node, column r)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub(int nn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val, const float *__restrict__ xc, float *__restrict__ x)
+{
+  if (halt && *halt) return;
+  const int r = threadIdx.x % MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < nn; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+      const float  w = val[k];
+      const float *p = xc + (size_t)3 * col[k] * MV_R + r;
+      s0 += w * p[0], s1 += w * p[MV_R], s2 += w * p[2 * MV_R];
+    }
+    float *xi = x + (size_t)3 * i * MV_R + r;
+    xi[0] -= s0, xi[MV_R] -= s1, xi[2 * MV_R] -= s2;
+  }
+}
+
+// coarsest level: X_b = pinv_b B_b for the R columns: one wavefront per row of the dense block, lanes stride the row, R sums per lane
+template <typename TP>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const TP *__restrict__ pinv, float scale, const float *__restrict__ b,
+                                                         float *__restrict__ x)
+{
+  if (halt && *halt) return;
+  const int lane = threadIdx.x & 63;
+  const int row  = blockIdx.x * (PMH_BLOCK / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  int lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rs[mid] <= row) lo = mid;
+    else hi = mid;
+  }
+  const int    r0 = rs[lo], m = rs[lo + 1] - r0;
+  const TP    *a  = pinv + ofs[lo] + (size_t)(row - r0) * m;
+  const float *bb = b + (size_t)r0 * MV_R;
+  float        s[MV_R];
+#pragma unroll
+  for (int r = 0; r < MV_R; r++) s[r] = 0.f;
+  for (int j = lane; j < m; j += 64) {
+    const float    w  = (float)a[j];
+    const mvg_flt4 v0 = *(const mvg_flt4 *)(bb + (size_t)j * MV_R), v1 = *(const mvg_flt4 *)(bb + (size_t)j * MV_R + 4);
+    s[0] += w * v0.x, s[1] += w * v0.y, s[2] += w * v0.z, s[3] += w * v0.w;
+    s[4] += w * v1.x, s[5] += w * v1.y, s[6] += w * v1.z, s[7] += w * v1.w;
+  }
+#pragma unroll
+  for (int r = 0; r < MV_R; r++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[r] += __shfl_down(s[r], o, 64);
+  if (lane == 0) {
+    float *xo = x + (size_t)row * MV_R;
+#pragma unroll
+    for (int r = 0; r < MV_R; r++) xo[r] = (sizeof(TP) == 2) ? s[r] * scale : s[r];
+  }
+}
+
+static inline dim3 mvg_grid(long long work_items)
+{
+  long long g = (work_items + PMH_BLOCK - 1) / PMH_BLOCK;
+  return dim3((unsigned)(g < 1 ? 1 : (g > PMH_MAX_VEC_BLOCKS ? PMH_MAX_VEC_BLOCKS : g)));
+}
+
+int pmh_mg_mv_destroy(pmh_mg_mv M)
+{
+  if (!M) return PMH_SUCCESS;
+  pmh_ctx ctx = M->mg->ctx;
+  for (auto &l : M->L) {
+    pmh_mv_ell_destroy(l.E);
+    pmh_free(ctx, l.x), pmh_free(ctx, l.b), pmh_free(ctx, l.r), pmh_free(ctx, l.d), pmh_free(ctx, l.t), pmh_free(ctx, l.xa);
+  }
+  delete M;
+  return PMH_SUCCESS;
+}
+
+int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out)
+{
+  PMH_ARG(mg && out);
+  *out = nullptr;
+  if (!(mg->is_float && mg->fused && mg->nlevels > 1 && mg->degree == 2)) {
+    pmh_mv_set_why(!mg->is_float ? "the V-cycle runs in fp64" : (mg->degree != 2 ? "the smoother is not of degree 2" : (mg->nlevels < 2 ? "the hierarchy has one level" : "the V-cycle is not the fused form (PMH_MG_FUSED=0 or a level without 3 x 3 blocks)")));
+    return PMH_EPI_UNSUPPORTED;
+  }
+  for (int l = 0; l + 1 < mg->nlevels; l++)
+    if (!mg->L[l].Ab || !mg->L[l].pn_rowptr || !mg->L[l].rn_rowptr || mg->L[l].n % 3) {
+      pmh_mv_set_why(!mg->L[l].Ab ? "a level operator has no 3 x 3 block copy" : "a prolongation is not node-wise (P = P_node (x) I_3)");
+      return PMH_EPI_UNSUPPORTED;
+    }
+  pmh_ctx   ctx = mg->ctx;
+  pmh_mg_mv M   = new pmh_mg_mv_s();
+  M->mg = mg;
+  M->L.resize(mg->nlevels);
+  int rc = PMH_SUCCESS;
+  for (int l = 0; l < mg->nlevels && !rc; l++) {
+    mg_level    &Lv = mg->L[l];
+    mg_mv_level &Ml = M->L[l];
+    const size_t nR = (size_t)Lv.n * MV_R;
+    if (l + 1 < mg->nlevels) {
+      rc = pmh_mv_ell_create(Lv.A, Lv.Ab->storage == PMH_BSR_F64 ? PMH_BSR_F32 : Lv.Ab->storage, &Ml.E);
+      if (!rc && !Ml.E) {
+        pmh_mg_mv_destroy(M);
+        pmh_mv_set_why("a level operator has rows with unsorted columns or more than 32 blocks of 3 x 3 in a block row");
+        return PMH_EPI_UNSUPPORTED;
+      }
+      for (float **v : {&Ml.r, &Ml.d, &Ml.t, &Ml.xa})
+        if (!rc) rc = pmh_malloc(ctx, sizeof(float) * nR, (void **)v);
+    }
+    for (float **v : {&Ml.x, &Ml.b})
+      if (!rc) rc = pmh_malloc(ctx, sizeof(float) * nR, (void **)v);
+  }
+  if (rc) {
+    pmh_mg_mv_destroy(M);
+    return rc;
+  }
+  *out = M;
+  return PMH_SUCCESS;
+}
+
+static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0_ready, const int *halt)
+{
+  pmh_mg       mg = M->mg;
+  mg_level    &Lv = mg->L[l];
+  mg_mv_level &Ml = M->L[l];
+  hipStream_t  st = mg->ctx->stream;
+  const dim3   blk(PMH_BLOCK);
+  if (l == mg->nlevels - 1) {
+    if (mg->cp_half)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
+                         (const float *)Ml.b, Ml.x);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<float>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const float *)mg->d_cpinv, 1.f, (const float *)Ml.b, Ml.x);
+    PMH_HIP(hipGetLastError());
+    return PMH_SUCCESS;
+  }
+  mg_level    &Lc = mg->L[l + 1];
+  mg_mv_level &Mc = M->L[l + 1];
+  const long long nR     = (long long)Lv.n * MV_R;
+  const float    *dinv   = (const float *)Lv.dinv;
+  const float     itheta = (float)(1.0 / Lv.theta), c1 = (float)Lv.c1[1], c2 = (float)Lv.c2[1];
+  if (!d0_ready) {
+    if (b64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_d0<double>), mvg_grid(nR / 4), blk, 0, st, nR, halt, dinv, b64, itheta, Ml.d, Ml.b);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_d0<float>), mvg_grid(nR / 4), blk, 0, st, nR, halt, dinv, (const float *)Ml.b, itheta, Ml.d, (float *)nullptr);
+  }
+  pmh_mv_epi<float> e;
+  memset(&e, 0, sizeof(e));
+  e.y1 = Ml.b, e.dinv = dinv, e.r = Ml.r, e.d = Ml.d;
+  e.c0 = 1.f + c1, e.c1 = c1, e.c2 = c2;
+  PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.d, Ml.xa, PMH_BSR_EPI_PRE, &e, halt));
+  PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.t, PMH_EPI_SUB, &e, halt));
+  const bool cf  = l + 2 < mg->nlevels; // the coarse level is a smoothed one: its d0 rides on the restriction
+  const int  ncn = Lc.n / 3;
+  hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col, (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
+                     cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
+  PMH_CHK(mvg_cycle(M, l + 1, nullptr, nullptr, cf, halt));
+  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(Lv.n / 3) * MV_R), blk, 0, st, Lv.n / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
+  PMH_HIP(hipGetLastError());
+  e.c0 = itheta;
+  PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.x, PMH_BSR_EPI_POST1, &e, halt));
+  e.z64 = z64;
+  return pmh_mv_spmv_f32(Ml.E, Ml.d, Ml.x, PMH_BSR_EPI_POST2, &e, halt);
+}
+
+// Z = V(B) for R columns: b, z are fp64 multivectors of n_0 R entries
+int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt)
+{
+  PMH_ARG(M && b && z);
+  return mvg_cycle(M, 0, b, z, false, halt);
+}

@@ -1,0 +1,383 @@
+// Multi-right-hand-side K^+, part 1: the operator.  ELL copy of a matrix of 3 x 3 blocks (built on the device from the resident CSR) and y = A x on interleaved
+// multivectors of R = PMH_MV_R columns with the smoothing epilogues of k_bsr3 (bsr.hip).  See mv_internal.h for what this path is for.
+//
+// FOUR lanes per block row (a first form with one thread per block row left the chip at 1.2 waves per SIMD: 92 us per fp64 product of a 43^3 block where its bytes
+// need 35): lane l of the quad takes the slots s = 4 g + l, per slot ONE block column index, the 9 entries of the block (the slot planes are interleaved by 4, so a
+// wave reads 512 contiguous bytes per entry plane) and the 3 R operand values of that block column -- ONE contiguous piece (192 bytes in fp64, 96 in fp32) loaded as
+// 16-byte vectors.  3 R accumulators per lane, summed across the quad by two butterfly steps (a fixed order); lanes 0 .. 2 of the quad then finish one row each.
+#include "mv_internal.h"
+
+static thread_local const char *g_mv_why = "";
+const char *pmh_mv_why() { return g_mv_why; }
+void        pmh_mv_set_why(const char *why) { g_mv_why = why; }
+
+typedef _Float16 mv_half4 __attribute__((ext_vector_type(4)));
+typedef double   mv_dbl2 __attribute__((ext_vector_type(2)));
+typedef float    mv_flt4 __attribute__((ext_vector_type(4)));
+
+// ---- ELL builder ------------------------------------------------------------------------------------------------------------------------------------------------
+// The blocks of block row br = the sorted union of the block columns (column / 3) its three rows list; an entry a row does not store is a zero of the block.  A three-way
+// merge over the (sorted) rows: walk(br, ...) calls f(slot, block column, the 9 entries) slot after slot and returns the slot count, or -1 for a row whose columns
+// are not ascending.
+template <typename F>
+static __device__ __forceinline__ int mv_walk(int br, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, F f)
+{
+  int k[3], e[3], s = 0;
+#pragma unroll
+  for (int q = 0; q < 3; q++) k[q] = rowptr[3 * br + q], e[q] = rowptr[3 * br + q + 1];
+  while (k[0] < e[0] || k[1] < e[1] || k[2] < e[2]) {
+    int cb = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      if (k[q] < e[q]) cb = min(cb, col[k[q]] / 3);
+    double a[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) a[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int last = -1;
+      while (k[q] < e[q] && col[k[q]] / 3 == cb) {
+        const int c = col[k[q]] - 3 * cb;
+        if (c <= last) return -1;
+        last = c;
+        const double v = val ? val[k[q]] : 0.0;
+        if (c == 0) a[3 * q] = v;
+        else if (c == 1) a[3 * q + 1] = v;
+        else a[3 * q + 2] = v;
+        k[q]++;
+      }
+      if (k[q] < e[q] && col[k[q]] / 3 < cb) return -1;
+    }
+    f(s, cb, a);
+    s++;
+  }
+  return s;
+}
+
+// info[0] = the largest slot count of a block row, info[1] = rows that are not sorted
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_count(int nbr, const int *__restrict__ rowptr, const int *__restrict__ col, int *__restrict__ info)
+{
+  const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (br >= nbr) return;
+  const int n = mv_walk(br, rowptr, col, (const double *)nullptr, [](int, int, const double *) {});
+  if (n < 0) atomicAdd(&info[1], 1);
+  else atomicMax(&info[0], n);
+}
+
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_absmax(long long nnz, const double *__restrict__ val, unsigned long long *__restrict__ out)
+{
+  double m = 0.0;
+  for (long long k = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; k < nnz; k += (long long)gridDim.x * PMH_BLOCK) m = fmax(m, fabs(val[k]));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m)); // non-negative doubles order as their bit patterns
+}
+
+template <typename TM>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval)
+{
+  const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (br >= nbr) return;
+  auto put = [&](int s, int cb, const double *a) {
+    ecol[((size_t)(s >> 2) * nbr + br) * 4 + (s & 3)] = cb;
+#pragma unroll
+    for (int i = 0; i < 9; i++) eval[(((size_t)(s >> 2) * 9 + i) * nbr + br) * 4 + (s & 3)] = (TM)(a[i] * inv_scale);
+  };
+  const int    n = mv_walk(br, rowptr, col, val, put);
+  const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = n; s < W; s++) put(s, br, z); // padding: the row's own block column, zero entries
+}
+// fp16: one vector of 4 halves per block row q (the 4th is zero)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval)
+{
+  const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
+  if (br >= nbr) return;
+  auto put = [&](int s, int cb, const double *a) {
+    ecol[((size_t)(s >> 2) * nbr + br) * 4 + (s & 3)] = cb;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      mv_half4 h;
+      h.x = (_Float16)(float)(a[3 * q] * inv_scale), h.y = (_Float16)(float)(a[3 * q + 1] * inv_scale), h.z = (_Float16)(float)(a[3 * q + 2] * inv_scale), h.w = (_Float16)0.f;
+      eval[(((size_t)(s >> 2) * 3 + q) * nbr + br) * 4 + (s & 3)] = h;
+    }
+  };
+  const int    n = mv_walk(br, rowptr, col, val, put);
+  const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = n; s < W; s++) put(s, br, z);
+}
+
+int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out)
+{
+  PMH_ARG(A && out && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
+  *out        = nullptr;
+  pmh_ctx ctx = A->ctx;
+  if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
+  const int   nbr = A->nrows / 3;
+  hipStream_t st  = ctx->stream;
+  int        *d_info;
+  PMH_CHK(pmh_malloc(ctx, sizeof(unsigned long long) * 2, (void **)&d_info));
+  PMH_HIP(hipMemsetAsync(d_info, 0, sizeof(unsigned long long) * 2, st));
+  hipLaunchKernelGGL(k_mv_ell_count, dim3((nbr + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, nbr, (const int *)A->d_rowptr, (const int *)A->d_col, d_info);
+  int info[2];
+  PMH_CHK(pmh_memcpy_d2h(ctx, info, d_info, sizeof(info)));
+  if (info[1] || info[0] < 1 || info[0] > 32) {
+    pmh_free(ctx, d_info);
+    return PMH_SUCCESS;
+  }
+  pmh_mv_ell E = new pmh_mv_ell_s();
+  E->ctx = ctx, E->nbr = nbr, E->W = (info[0] + 3) / 4 * 4, E->storage = storage, E->scale = 1.0, E->col = nullptr, E->val = nullptr;
+  double inv_scale = 1.0;
+  if (storage == PMH_BSR_F16) { // power-of-two scale that brings the largest entry to [1, 2) (as pmh_bsr3_from_csr)
+    PMH_HIP(hipMemsetAsync(d_info, 0, sizeof(unsigned long long) * 2, st));
+    hipLaunchKernelGGL(k_mv_absmax, dim3(1024), dim3(PMH_BLOCK), 0, st, A->nnz, (const double *)A->d_val, (unsigned long long *)d_info);
+    double amax = 0.0;
+    PMH_CHK(pmh_memcpy_d2h(ctx, &amax, d_info, sizeof(double)));
+    int ex = 0;
+    if (amax > 0.0) frexp(amax, &ex);
+    E->scale  = ldexp(1.0, ex - 1);
+    inv_scale = 1.0 / E->scale;
+  }
+  pmh_free(ctx, d_info);
+  const size_t nslot = (size_t)E->W * nbr;
+  const dim3   g((nbr + PMH_BLOCK - 1) / PMH_BLOCK), blk(PMH_BLOCK);
+  int          rc = pmh_malloc(ctx, sizeof(int) * nslot, (void **)&E->col);
+  if (!rc) rc = pmh_malloc(ctx, (storage == PMH_BSR_F64 ? sizeof(double) * 9 : (storage == PMH_BSR_F32 ? sizeof(float) * 9 : sizeof(mv_half4) * 3)) * nslot, &E->val);
+  if (rc) {
+    pmh_mv_ell_destroy(E);
+    return rc;
+  }
+  if (storage == PMH_BSR_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<double>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (double *)E->val);
+  else if (storage == PMH_BSR_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<float>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (float *)E->val);
+  else hipLaunchKernelGGL(k_mv_ell_fill_h, g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (mv_half4 *)E->val);
+  PMH_HIP(hipGetLastError());
+  *out = E;
+  return PMH_SUCCESS;
+}
+
+int pmh_mv_ell_destroy(pmh_mv_ell E)
+{
+  if (!E) return PMH_SUCCESS;
+  pmh_free(E->ctx, E->col);
+  pmh_free(E->ctx, E->val);
+  delete E;
+  return PMH_SUCCESS;
+}
+
+// ---- the product ------------------------------------------------------------------------------------------------------------------------------------------------
+template <typename T, int N> struct mv_vec;
+template <int N> struct mv_vec<double, N> { // N doubles = N / 2 loads of 16 bytes
+  static __device__ __forceinline__ void load(const double *p, double (&v)[N])
+  {
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+      const mv_dbl2 t = ((const mv_dbl2 *)p)[k];
+      v[2 * k] = t.x, v[2 * k + 1] = t.y;
+    }
+  }
+  static __device__ __forceinline__ void store(double *p, const double (&v)[N])
+  {
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) ((mv_dbl2 *)p)[k] = mv_dbl2{v[2 * k], v[2 * k + 1]};
+  }
+};
+template <int N> struct mv_vec<float, N> {
+  static __device__ __forceinline__ void load(const float *p, float (&v)[N])
+  {
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) {
+      const mv_flt4 t = ((const mv_flt4 *)p)[k];
+      v[4 * k] = t.x, v[4 * k + 1] = t.y, v[4 * k + 2] = t.z, v[4 * k + 3] = t.w;
+    }
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&v)[N])
+  {
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) ((mv_flt4 *)p)[k] = mv_flt4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  }
+};
+
+template <typename TM, typename T> struct mv_blk { // the 9 entries of slot 4 g + l, block row br
+  static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9])
+  {
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = (T)__builtin_nontemporal_load((const TM *)val + ((g * 9 + e) * nbr + br) * 4 + l);
+  }
+};
+template <typename T> struct mv_blk<_Float16, T> {
+  static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9])
+  {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const mv_half4 h = __builtin_nontemporal_load((const mv_half4 *)val + ((g * 3 + q) * nbr + br) * 4 + l);
+      a[3 * q] = (T)h.x, a[3 * q + 1] = (T)h.y, a[3 * q + 2] = (T)h.z;
+    }
+  }
+};
+
+template <typename TM, typename T, int R, int EPI>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale, const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt)
+{
+  const int hlt = halt ? *halt : 0;
+  const int tg  = blockIdx.x * PMH_BLOCK + threadIdx.x, br = tg >> 2, l = tg & 3;
+  if (br >= nbr) return; // whole quads
+  int cn = col[(size_t)br * 4 + l];
+  if (hlt) return;
+  T acc[3][R];
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[q][r] = (T)0;
+  for (int g = 0; g < W4; g++) {
+    const int c = cn;
+    if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l]; // the next slot's index travels during this slot's products
+    T a[9], xv[3 * R];
+    mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
+    mv_vec<T, 3 * R>::load(x + (size_t)3 * c * R, xv);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
+  }
+  // the quad's four partial sums: (l0 + l1) + (l2 + l3) on every lane
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      T v = acc[q][r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      acc[q][r] = v;
+    }
+  if (l == 3) return;
+  // lane l finishes row 3 br + l: R contiguous values
+  const size_t o = ((size_t)3 * br + l) * R;
+  T            out[R], t1[R], t2[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const T v = (l == 0) ? acc[0][r] : (l == 1 ? acc[1][r] : acc[2][r]);
+    out[r]    = (sizeof(TM) == 2) ? v * scale : v; // fp16 storage keeps A / scale
+  }
+  if (EPI == PMH_EPI_ADD || EPI == PMH_EPI_SUB) {
+    mv_vec<T, R>::load(e.y1 + o, t1);
+#pragma unroll
+    for (int k = 0; k < R; k++) out[k] = (EPI == PMH_EPI_ADD) ? t1[k] + out[k] : out[k] - t1[k];
+  }
+  if (EPI == PMH_BSR_EPI_PRE) { // y = c0 d0 + c2 dinv (b - A d0)
+    mv_vec<T, R>::load(e.y1 + o, t1);
+    mv_vec<T, R>::load(x + o, t2);
+    const T di = e.dinv[3 * br + l];
+#pragma unroll
+    for (int k = 0; k < R; k++) out[k] = e.c0 * t2[k] + e.c2 * di * (t1[k] - out[k]);
+  }
+  if (EPI == PMH_BSR_EPI_POST1) { // r = dinv (b - A x); d = c0 r; y = x + d
+    mv_vec<T, R>::load(e.y1 + o, t1);
+    mv_vec<T, R>::load(x + o, t2);
+    const T di = e.dinv[3 * br + l];
+    T       rr[R], dd[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      rr[k]  = di * (t1[k] - out[k]);
+      dd[k]  = e.c0 * rr[k];
+      out[k] = t2[k] + dd[k];
+    }
+    mv_vec<T, R>::store(e.r + o, rr);
+    mv_vec<T, R>::store(e.d + o, dd);
+  }
+  if (EPI == PMH_BSR_EPI_POST2) { // y += c1 d + c2 (r - dinv A d)
+    mv_vec<T, R>::load(y + o, t1);
+    mv_vec<T, R>::load(x + o, t2);
+    const T di = e.dinv[3 * br + l];
+    T       rr[R];
+    mv_vec<T, R>::load(e.r + o, rr);
+#pragma unroll
+    for (int k = 0; k < R; k++) out[k] = t1[k] + e.c1 * t2[k] + e.c2 * (rr[k] - di * out[k]);
+    if (e.z64) {
+#pragma unroll
+      for (int k = 0; k < R; k++) e.z64[o + k] = (double)out[k];
+    }
+  }
+  mv_vec<T, R>::store(y + o, out);
+}
+
+template <typename TM, typename T>
+static int mv_launch(pmh_mv_ell E, const T *x, T *y, int epi, const pmh_mv_epi<T> *ep, const int *halt)
+{
+  const dim3    g((unsigned)(((long long)E->nbr * 4 + PMH_BLOCK - 1) / PMH_BLOCK)), blk(PMH_BLOCK);
+  hipStream_t   st = E->ctx->stream;
+  pmh_mv_epi<T> e;
+  if (ep) e = *ep;
+  else memset(&e, 0, sizeof(e));
+  const T sc = (T)E->scale;
+#define MV_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt)
+  switch (epi) {
+  case PMH_EPI_NONE: MV_LAUNCH(PMH_EPI_NONE); break;
+  case PMH_EPI_ADD: MV_LAUNCH(PMH_EPI_ADD); break;
+  case PMH_EPI_SUB: MV_LAUNCH(PMH_EPI_SUB); break;
+  case PMH_BSR_EPI_PRE: MV_LAUNCH(PMH_BSR_EPI_PRE); break;
+  case PMH_BSR_EPI_POST1: MV_LAUNCH(PMH_BSR_EPI_POST1); break;
+  case PMH_BSR_EPI_POST2: MV_LAUNCH(PMH_BSR_EPI_POST2); break;
+  default: return pmh_set_error(PMH_ERR_ARG, "mv: unsupported epilogue %d", epi);
+  }
+#undef MV_LAUNCH
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+int pmh_mv_spmv_f64(pmh_mv_ell E, const double *x, double *y, int epi, const pmh_mv_epi<double> *e, const int *halt)
+{
+  PMH_ARG(E && x && y);
+  if (E->storage != PMH_BSR_F64) return pmh_set_error(PMH_ERR_ARG, "pmh_mv_spmv_f64: the fp64 product needs fp64 entries");
+  return mv_launch<double, double>(E, x, y, epi, e, halt);
+}
+
+int pmh_mv_spmv_f32(pmh_mv_ell E, const float *x, float *y, int epi, const pmh_mv_epi<float> *e, const int *halt)
+{
+  PMH_ARG(E && x && y);
+  if (E->storage == PMH_BSR_F16) return mv_launch<_Float16, float>(E, x, y, epi, e, halt);
+  if (E->storage == PMH_BSR_F32) return mv_launch<float, float>(E, x, y, epi, e, halt);
+  return pmh_set_error(PMH_ERR_ARG, "pmh_mv_spmv_f32: the fp32 product needs fp32 or fp16 entries");
+}
+
+// ---- test / measurement entry (tests/test_gpu_mv.py, scripts): the product alone on a pmh_csr ---------------------------------------------------------------------
+extern "C" int pmh_mv_test_spmv(pmh_csr A, int storage, const double *x /* 3 nbr R, device */, double *y, int repeats, float *ms_per_launch)
+{
+  PMH_ARG(A && x && y && repeats >= 1);
+  pmh_mv_ell E = nullptr;
+  PMH_CHK(pmh_mv_ell_create(A, storage, &E));
+  if (!E) return pmh_set_error(PMH_ERR_SUP, "pmh_mv_test_spmv: no regular 3 x 3 block structure");
+  pmh_ctx     ctx = A->ctx;
+  const size_t n  = (size_t)A->nrows * PMH_MV_R;
+  int          rc = PMH_SUCCESS;
+  hipEvent_t   e0, e1;
+  PMH_HIP(hipEventCreate(&e0));
+  PMH_HIP(hipEventCreate(&e1));
+  if (storage == PMH_BSR_F64) {
+    rc = pmh_mv_spmv_f64(E, x, y, PMH_EPI_NONE, nullptr, nullptr);
+    PMH_HIP(hipEventRecord(e0, ctx->stream));
+    for (int k = 0; k < repeats && !rc; k++) rc = pmh_mv_spmv_f64(E, x, y, PMH_EPI_NONE, nullptr, nullptr);
+    PMH_HIP(hipEventRecord(e1, ctx->stream));
+  } else { // fp32 vectors: converted on the host side of this test entry
+    std::vector<double> hx(n);
+    std::vector<float>  fx(n), fy(n);
+    float              *dx, *dy;
+    PMH_CHK(pmh_memcpy_d2h(ctx, hx.data(), x, sizeof(double) * n));
+    for (size_t i = 0; i < n; i++) fx[i] = (float)hx[i];
+    PMH_CHK(pmh_malloc(ctx, sizeof(float) * n, (void **)&dx));
+    PMH_CHK(pmh_malloc(ctx, sizeof(float) * n, (void **)&dy));
+    PMH_CHK(pmh_memcpy_h2d(ctx, dx, fx.data(), sizeof(float) * n));
+    rc = pmh_mv_spmv_f32(E, dx, dy, PMH_EPI_NONE, nullptr, nullptr);
+    PMH_HIP(hipEventRecord(e0, ctx->stream));
+    for (int k = 0; k < repeats && !rc; k++) rc = pmh_mv_spmv_f32(E, dx, dy, PMH_EPI_NONE, nullptr, nullptr);
+    PMH_HIP(hipEventRecord(e1, ctx->stream));
+    if (!rc) rc = pmh_memcpy_d2h(ctx, fy.data(), dy, sizeof(float) * n);
+    for (size_t i = 0; i < n; i++) hx[i] = (double)fy[i];
+    if (!rc) rc = pmh_memcpy_h2d(ctx, y, hx.data(), sizeof(double) * n);
+    pmh_free(ctx, dx), pmh_free(ctx, dy);
+  }
+  PMH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PMH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_per_launch) *ms_per_launch = ms / repeats;
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  pmh_mv_ell_destroy(E);
+  return rc;
+}

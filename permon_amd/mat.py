@@ -225,6 +225,12 @@ class MatInv:
     def mult(self, f, u):  # MatMult_Inv
         check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
 
+    def mult_multi(self, F, U):
+        """U = K^+ F for 8 columns per block at once (pmh_matinv_mult_multi): F, U vectors of 8 n entries, entry (dof i, column r) at 8 i + r.  Returns the largest iteration count."""
+        its = C.c_int()
+        check(self.ctx.L.pmh_matinv_mult_multi(self.h, F.p, U.p, C.byref(its)))
+        return its.value
+
     def set_tolerances(self, rtol, atol=1e-50, max_it=10000):  # KSPSetTolerances of the inner KSP
         check(self.ctx.L.pmh_matinv_set_tolerances(self.h, float(rtol), float(atol), int(max_it)))
 
@@ -373,11 +379,15 @@ class MatExplicitDual:
         check(self.ctx.L.pmh_fexplicit_apply_flops_detail(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0):
-        """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides."""
+    def assemble(self, solver, slot_class=None, block_class=None, rtol=1e-12, max_it=0, multi_rhs=False):
+        """One K^+ application of `solver` (a MatInv with solver.K.nblocks slots) per batch of unit right-hand sides.  multi_rhs: 8 columns per block and application on the
+        multi-right-hand-side solver (matinv_mv.hip: slot s = column s % 8 of block s // 8; slot_class still names the class of every BLOCK of the solver)."""
+        nslots = solver.K.nblocks * (8 if multi_rhs else 1)
+        if multi_rhs and slot_class is not None:
+            slot_class = np.repeat(np.asarray(slot_class, dtype=np.int32), 8)
         sc = np.ascontiguousarray(slot_class, dtype=np.int32) if slot_class is not None else None
         bc = np.ascontiguousarray(block_class, dtype=np.int32) if block_class is not None else None
-        check(self.ctx.L.pmh_fexplicit_assemble(self.h, solver.h, solver.K.nblocks, sc.ctypes.data_as(C.c_void_p) if sc is not None else None,
+        check(self.ctx.L.pmh_fexplicit_assemble(self.h, solver.h, nslots, sc.ctypes.data_as(C.c_void_p) if sc is not None else None,
                                                 bc.ctypes.data_as(C.c_void_p) if bc is not None else None, float(rtol), int(max_it)))
         self.refresh_sizes()
 

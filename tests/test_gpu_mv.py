@@ -1,0 +1,111 @@
+"""Multi-right-hand-side K^+ (csrc/mv.hip ...): the operator product on interleaved multivectors against scipy, column by column."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import permon_amd as pa
+from permon_amd._lib import check
+
+pytestmark = pytest.mark.gpu
+R = 8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def _block_matrix(rng, nn, extra):
+    """a matrix of full 3 x 3 blocks on nn nodes: chain neighbours + `extra` random block pairs, ragged rows (1 ... many blocks)"""
+    pairs = {(i, i) for i in range(nn)} | {(i, i + 1) for i in range(nn - 1)} | {(i + 1, i) for i in range(nn - 1)}
+    for _ in range(extra):
+        a, b = int(rng.integers(0, nn)), int(rng.integers(0, nn))
+        pairs.add((a, b))
+    rows, cols, vals = [], [], []
+    for (a, b) in pairs:
+        blk = rng.standard_normal((3, 3))
+        keep = rng.random((3, 3)) < 0.8  # incomplete blocks: an entry a row does not store is a zero of the block
+        keep[rng.integers(0, 3), rng.integers(0, 3)] = True
+        for q in range(3):
+            for c in range(3):
+                if keep[q, c]:
+                    rows.append(3 * a + q), cols.append(3 * b + c), vals.append(blk[q, c])
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(3 * nn, 3 * nn))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("nn,extra", [(1, 0), (7, 5), (300, 900), (5000, 20000)])
+@pytest.mark.parametrize("storage", [0, 1, 2])
+def test_mv_product_against_scipy(ctx, nn, extra, storage):
+    rng = np.random.default_rng(nn + storage)
+    A = _block_matrix(rng, nn, extra)
+    n = A.shape[0]
+    X = rng.standard_normal((n, R))
+    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+    xd, yd = ctx.vec_from(X.reshape(-1)), ctx.vec(n * R)
+    ms = C.c_float(0)
+    check(ctx.L.pmh_mv_test_spmv(Ad.h, storage, xd.p, yd.p, 1, C.byref(ms)))
+    Y = yd.to_numpy().reshape(n, R)
+    ref = A @ X
+    tol = {0: 1e-14, 1: 2e-6, 2: 3e-3}[storage]
+    scale = np.abs(A).dot(np.abs(X)).max()
+    assert np.abs(Y - ref).max() <= tol * scale, (nn, storage, np.abs(Y - ref).max() / scale)
+
+
+def test_mv_wide_rows_are_refused(ctx):
+    A = sp.csr_matrix(np.ones((3 * 40, 3 * 40)))  # 40 blocks in a block row: more than the 32 slots
+    Ad = pa.CsrMat(ctx, 120, 120, A.indptr, A.indices, A.data)
+    xd, yd = ctx.vec(120 * R), ctx.vec(120 * R)
+    assert ctx.L.pmh_mv_test_spmv(Ad.h, 0, xd.p, yd.p, 1, None) != 0
+
+
+@pytest.mark.parametrize("case", ["floating", "regularized", "odd_box", "jacobi"])
+def test_multi_rhs_kplus_against_the_one_column_solver(ctx, case):
+    """U = K^+ F for 8 columns per block (matinv_mv.hip: interleaved multivectors, the V-cycle of mg_mv.hip) against pmh_matinv_mult column by column and against the dense
+    pseudo-inverse: floating blocks (K^+ = P_R K^- P_R), regularised blocks (no kernel), a box with a short last coarse interval, and Jacobi-CG without a hierarchy; two
+    DIFFERENT blocks (the second one twice as stiff) so that nothing leans on congruence.  Columns of very different size, one of them zero, one in the kernel."""
+    from permon_amd.feti import CubeFeti
+    import scipy.sparse as sp
+
+    nel = 9 if case == "odd_box" else 6
+    f = CubeFeti((2, 1, 1), nel, "elasticity", contact=False)
+    nn, n_i, N = f.nel + 1, f.n_i, f.N
+    Ksp = sp.block_diag([f.K[:n_i, :n_i], 2.0 * f.K[n_i:, n_i:]]).tocsr()
+    R = f.R
+    if case == "regularized":
+        Ksp = (Ksp + sp.diags(np.full(N, 1e-2 * abs(Ksp.diagonal()).max()))).tocsr()
+        R = None
+    Ksp.sort_indices()
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Ksp)
+    M = pa.MatInv(K, rtol=1e-11, nullspace=R)
+    if case != "jacobi":
+        M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=R, min_nodes=27, degree=2, precision="fp32")
+    rng = np.random.default_rng(5)
+    F = rng.standard_normal((N, 8)) * (10.0 ** rng.integers(-3, 4, size=8))
+    F[:, 3] = 0.0
+    if R is not None:
+        F[:n_i, 5] = R[0, :n_i]  # block 0, column 5: a load in the kernel -> u = 0 there
+    Fd, Ud = ctx.vec_from(F.reshape(-1)), ctx.vec(N * 8)
+    its = M.mult_multi(Fd, Ud)
+    U = Ud.to_numpy().reshape(N, 8)
+    u1 = ctx.vec(N)
+    worst = 0
+    for r in range(8):
+        M.mult(ctx.vec_from(F[:, r].copy()), u1)
+        ref = u1.to_numpy()
+        worst = max(worst, M.last_iterations()[0])
+        assert np.linalg.norm(U[:, r] - ref) <= 1e-8 * max(np.linalg.norm(ref), 1e-300) + (0 if np.linalg.norm(ref) else 1e-300), (case, r)
+    assert abs(its - worst) <= 2, (its, worst)
+    assert np.all(U[:, 3] == 0.0)
+    if R is not None:
+        assert np.linalg.norm(U[:n_i, 5]) <= 1e-10
+        for b in range(2):
+            Kd = Ksp[b * n_i:(b + 1) * n_i, b * n_i:(b + 1) * n_i].toarray()
+            ref = np.linalg.pinv(Kd, rcond=1e-10, hermitian=True) @ F[b * n_i:(b + 1) * n_i]
+            for r in (0, 1, 2, 4, 6, 7):
+                assert np.linalg.norm(U[b * n_i:(b + 1) * n_i, r] - ref[:, r]) <= 1e-8 * np.linalg.norm(ref[:, r]), (case, b, r)
