@@ -961,7 +961,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         elif b_k > 1.5 * E.dense_bytes:  # more than 8 blocks per class: one pass over W_c per group of 8
             roofline["note"] = ("W_c (%.2f GB stored on this rank) is streamed once per group of 8 blocks, %.1f passes per apply: the re-reads are served by the 256 MB Infinity Cache / L2, "
                                 "so `achieved` is an on-chip rate here, not an HBM rate (the HBM bound applies to the 8-blocks-per-GPU case of configs[2])" % (E.dense_bytes / 1e9, b_k / E.dense_bytes))
-        kplus_cfg = {"path": "explicit", "storage": storage_used, "setup_symmetries": getattr(q, "explicit_symmetries", 1), "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves),
+        kplus_cfg = {"path": "explicit", "storage": storage_used, "setup_symmetries": getattr(q, "explicit_symmetries", 1), "n_gamma": [int(v) for v in E.n_gamma], "dense_GB": round(E.dense_bytes / 1e9, 2), "assemble_seconds": round(asm_s, 1), "assemble_solves": int(n_solves), "assemble_multi_rhs": bool(getattr(q, "explicit_multi_rhs", False)),
                      "assemble_rtol": a.explicit_rtol, "assemble_solver": "this rank's K^+ (%s), one unit right-hand side per block and application, congruent blocks share their columns%s" % (pc_text, ", one solve per orbit of rows under the %d symmetries of the cube (checked against K, a batch of rows re-solved directly)" % q.explicit_symmetries if getattr(q, "explicit_symmetries", 1) > 1 else "")
                      if not replica else "a %d-slot replica K^+ of the rank's congruent block(s) (%s)" % (a.explicit_slots, pc_text)}
         if storage_used == "class_orbit" and world == 1 and not a.sim_world:  # the GEMM's shape: representatives (rows), their padding to the row tile, operations x 8 right-hand sides (columns), n_c (k)
@@ -1202,7 +1202,7 @@ def compact_line(out, details_path):
             c[k] = block(out[k])
     if isinstance(c.get("general"), dict) and isinstance(out["general"], dict) and isinstance(out["general"].get("kplus"), dict):  # the non-congruent block's set-up: K^+ solves and their time
         kp = out["general"]["kplus"]
-        c["general"].update({k: kp.get(k) for k in ("storage", "assemble_seconds", "assemble_solves") if kp.get(k) is not None})
+        c["general"].update({k: kp.get(k) for k in ("storage", "assemble_seconds", "assemble_solves", "assemble_multi_rhs") if kp.get(k) is not None})
     if isinstance(out.get("contact_solve"), dict):
         c["contact_solve"] = {k: out["contact_solve"].get(k) for k in ("setup_seconds", "solve_seconds", "time_to_solution_seconds", "failed") if out["contact_solve"].get(k) is not None}
     c["details"] = os.path.relpath(details_path, ROOT) if details_path.startswith(ROOT) else details_path

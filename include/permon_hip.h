@@ -392,6 +392,10 @@ int pmh_fexplicit_set_class_symmetry(pmh_fexplicit E, int cls, int nsym, const i
 int pmh_fexplicit_class_sym_plan(int n_c, int size, int *megaband_owner /* [ceil(ceil(n_c / 256) / 4)] or NULL */, double *bytes_per_rank /* [size] or NULL */); /* host: PMH_FX_CLASS_SYM's rule */
 int pmh_fexplicit_orbit_row_tile(int n_representatives, int *row_tile /* 128, 120, 112, 104 or 96 */, int *padded_rows); /* host: PMH_FX_CLASS_ORBIT's rule for the row tile of its GEMM */
 int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int nslots, const int *slot_class, const int *block_class, double rtol, int max_it);
+/* nslots == 8 x (blocks of the solver): the multi-right-hand-side K^+ (csrc/matinv_mv.hip) solves 8 columns per block and application, slot s = column s % 8 of block s / 8
+   (slot_class per slot; PMH_ERR_SUP where that solver does not apply).  pmh_fexplicit_assemble_auto tries exactly that and falls back to one column per block;
+   slot_class there names the class of every BLOCK of the solver.  Column-blocked set-up of the reference: MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:640-730. */
+int pmh_fexplicit_assemble_auto(pmh_fexplicit E, pmh_matinv solver, const int *slot_class, const int *block_class, double rtol, int max_it, int *used_multi_rhs /* or NULL */);
 int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte); /* tuning helper: byte pattern instead of the assembly (not F afterwards) */
 int pmh_fexplicit_assemble_stats(pmh_fexplicit E, long long *n_solves, double *seconds);
 int pmh_fexplicit_get_block(pmh_fexplicit E, int b, double *W_host /* n_Gamma_b^2 row-major or NULL */, int *gamma_host /* or NULL */);

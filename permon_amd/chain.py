@@ -105,6 +105,11 @@ class FetiDualQP:
         self.tprim = ctx.vec(local["n_x"])
         self.lam = ctx.vec(nl)  # child solution (lambda - lambda~), zero initial guess (qptransform.c:1164-1165)
 
+    def _knob(self, name):
+        v = C.c_int(1)
+        check(self.ctx.L.pmh_get_knob(name.encode(), C.byref(v)))
+        return v.value
+
     def assemble_explicit(self, local, rtol=1e-12, max_it=0, min_slots=0, solver_factory=None, share_congruent=True, storage="sym", stripe=None, symmetry=None, multi_rhs="auto"):
         """MatInvExplicitly restricted to Gamma (pmh_fexplicit_assemble): the columns come from this rank's own K^+ (one unit
         right-hand side per block and application; congruent blocks share their columns), or from a replica solver when the rank
@@ -193,7 +198,11 @@ class FetiDualQP:
                 E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it, multi_rhs=mv)
 
         self.explicit_multi_rhs = False
-        if multi_rhs == "auto":
+        if multi_rhs == "auto" and solver_factory is not None and nb < min_slots and one_class:
+            run(False)  # the caller's replica solver supplies the slots
+        elif multi_rhs == "auto" and not self._knob("multi_rhs"):
+            run(False)  # PMH_NO_MULTI_RHS / pmh_set_knob("multi_rhs", 0): the A/B switch
+        elif multi_rhs == "auto":
             from ._lib import PermonHipError
 
             try:

@@ -288,7 +288,7 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
         }
       }
       stage("  explicit operators: class union, gluing of the classes, symmetries");
-      GO(pmh_fexplicit_assemble(E, Kp, nsub, cls.data(), cls.data(), o->explicit_rtol, 0));
+      GO(pmh_fexplicit_assemble_auto(E, Kp, cls.data(), cls.data(), o->explicit_rtol, 0, nullptr)); // 8 columns per block and application where the multi-right-hand-side K^+ applies
       GO(pmh_matinv_attach_explicit(Kp, E));
       stage("  explicit operators: assembly (K^+ solves, self-check)");
       long long ns;

@@ -876,6 +876,28 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   return PMH_SUCCESS;
 }
 
+// The set-up with 8 columns per block and application where the multi-right-hand-side K^+ applies to `solver` (matinv_mv.hip), one column per block otherwise
+// (PMH_ERR_SUP of the first attempt is not an error here).  slot_class: class of every BLOCK of the solver (or NULL with block_class NULL: block s of the operator).
+extern "C" int pmh_fexplicit_assemble_auto(pmh_fexplicit E, pmh_matinv solver, const int *slot_class, const int *block_class, double rtol, int max_it, int *used_multi_rhs)
+{
+  PMH_ARG(E && solver);
+  if (used_multi_rhs) *used_multi_rhs = 0;
+  if (pmh_knobs().multi_rhs) {
+    const int        nb = solver->nblocks;
+    std::vector<int> sc;
+    if (slot_class) {
+      sc.resize((size_t)nb * PMH_MV_R);
+      for (int s = 0; s < nb * PMH_MV_R; s++) sc[s] = slot_class[s / PMH_MV_R];
+    }
+    const int rc = pmh_fexplicit_assemble(E, solver, nb * PMH_MV_R, slot_class ? sc.data() : nullptr, block_class, rtol, max_it);
+    if (rc != PMH_ERR_SUP) {
+      if (!rc && used_multi_rhs) *used_multi_rhs = 1;
+      return rc;
+    }
+  }
+  return pmh_fexplicit_assemble(E, solver, solver->nblocks, slot_class, block_class, rtol, max_it);
+}
+
 // kernel-tuning helper (scripts/symv_tune.py): fills the dense storage with a byte pattern instead of assembling it, so that the
 // apply kernels can be timed at full size without the set-up solves.  The operator is NOT F afterwards.
 extern "C" int pmh_fexplicit_fill_pattern(pmh_fexplicit E, int byte)

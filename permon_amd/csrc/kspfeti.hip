@@ -460,7 +460,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     GO(pmh_gluing_create(ctx, N, nl, (int)lrow.size(), lrow.data(), lroot.data(), lval.data(), &B));
     if (o->explicit_dual) { // the exact K^+ path: W_b = (K_b^+)[Gamma_b, Gamma_b] by one K^+ solve per column, then F = Bhat W Bhat'
       GO(pmh_fexplicit_create(B, Kregb ? Kregb : Kb, PMH_FX_SYM, &E));
-      GO(pmh_fexplicit_assemble(E, Kp, nsub, nullptr, nullptr, o->explicit_rtol, 0));
+      GO(pmh_fexplicit_assemble_auto(E, Kp, nullptr, nullptr, o->explicit_rtol, 0, nullptr));
       GO(pmh_matinv_attach_explicit(Kp, E));
     }
 

@@ -128,7 +128,7 @@ class CubeFeti:
     Dual rows are ordered [Dirichlet | gluing | contact]; the first n_eq are equalities.
     """
 
-    def __init__(self, sub=(2, 2, 2), nel=3, physics="elasticity", gluing="full", scale=True, contact=True, gap0=0.0, gap_slope=0.05, load=-1.0, young=None):
+    def __init__(self, sub=(2, 2, 2), nel=3, physics="elasticity", gluing="full", scale=True, contact=True, gap0=0.0, gap_slope=0.05, load=-1.0, young=None, graded=None):
         """young: None (one material: every subdomain has the SAME stiffness matrix, the congruent case) or one Young's modulus per subdomain --
         a heterogeneous body whose subdomain matrices K_s = E_s K_1 all differ (no two blocks are bit-identical: pmh_csr_block_classes finds nsub
         classes), the general, non-congruent case of the explicit dual operators."""
@@ -164,6 +164,12 @@ class CubeFeti:
         self.young = None if young is None else np.asarray(young, dtype=np.float64)
         if self.young is not None and self.young.size != self.nsub:
             raise ValueError("young: one modulus per subdomain")
+        # graded: {subdomain: E(x, y, z)} -- a modulus that varies from element to element inside the subdomain (x, y, z: the element centre in the unit cube of the subdomain):
+        # such a block is congruent to no other one AND invariant under none of the cube's symmetries (the set-up of its explicit operator has nothing to lean on)
+        self.graded = dict(graded) if graded else {}
+        if self.graded and self.young is None:
+            self.young = np.ones(self.nsub)
+        self._conn = (rows, cols, Ke, (ix.ravel() + 0.5) * h, (iy.ravel() + 0.5) * h, (iz.ravel() + 0.5) * h) if self.graded else None
 
         # body force: constant `load` in the last component (z for elasticity), consistent Q1 load vector
         fe = np.zeros(nloc)
@@ -265,13 +271,20 @@ class CubeFeti:
         """Stiffness matrix of subdomain s (E_s K_1 for a heterogeneous body; the one shared matrix object otherwise)."""
         if self.young is None:
             return self.Ki
+        if s in self.graded:
+            rows, cols, Ke, cx, cy, cz = self._conn
+            Ee = float(self.young[s]) * np.asarray(self.graded[s](cx, cy, cz), dtype=np.float64)
+            Ks = sp.coo_matrix(((Ee[:, None] * Ke.ravel()[None, :]).ravel(), (rows, cols)), shape=self.Ki.shape).tocsr()
+            Ks.sum_duplicates()
+            Ks.sort_indices()
+            return Ks
         Ks = self.Ki.copy()
         Ks.data = Ks.data * float(self.young[s])
         return Ks
 
     @property
     def congruent(self):
-        return self.young is None or bool(np.all(self.young == self.young[0]))
+        return self.young is None or (not self.graded and bool(np.all(self.young == self.young[0])))
 
     # ---- coarse space -----------------------------------------------------------------------------------
     def kernel_matrix(self):

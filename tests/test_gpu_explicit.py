@@ -129,7 +129,7 @@ def test_explicit_setup_by_symmetry(ctx, sub, nel, nsym):
     # the touched set (no top face) are kept, the others dropped
     assert q.explicit_symmetries == nsym
     n0, n1 = q0.E.assemble_stats()[0], q.E.assemble_stats()[0]
-    assert n1 < n0 / (nsym / 8.0) + f.nsub  # orbits of <= nsym rows (rows on symmetry planes have shorter ones) + the self-check batch
+    assert n1 < n0 / (nsym / 8.0) + 8 * f.nsub  # orbits of <= nsym rows (rows on symmetry planes have shorter ones) + the self-check batch (one row per slot: 8 columns per block on the multi-right-hand-side K^+)
     Fref, Kp = _dense_F(f)
     for b in range(f.nsub):
         W, g = q.E.block(b)
@@ -165,7 +165,7 @@ def test_explicit_orbit_storage(ctx, sub, nel, nsym):
     q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, storage="class_orbit", symmetry=dict(dims=(nn, nn, nn), ndof=3)))
     assert q.explicit_storage == "class_orbit" and q.explicit_symmetries == nsym
     n_c = q.E.class_union(0).size
-    assert q.E.assemble_stats()[0] < n_c / (nsym / 8.0) + f.nsub and q.E.dense_bytes < 8.0 * n_c * n_c / (nsym / 8.0) and q.E.apply_flops() > 0
+    assert q.E.assemble_stats()[0] < n_c / (nsym / 8.0) + 8 * f.nsub and q.E.dense_bytes < 8.0 * n_c * n_c / (nsym / 8.0) and q.E.apply_flops() > 0
     Fref, Kp = _dense_F(f)
     for b in range(f.nsub):
         W, g = q.E.block(b)

@@ -114,3 +114,40 @@ def test_general_contact_solve_same_counts_as_inner_krylov(general):
     # feasibility and complementarity of the contact multipliers (dual box: lambda_I >= 0)
     lamI = le[f.n_eq:]
     assert lamI.min() >= -1e-12 and (lamI > 0).sum() > 0
+
+
+def test_block_without_any_symmetry_against_pinv():
+    """A decomposition NOTHING leans on: two subdomains, the second one of a GRADED material (the modulus varies from element to element: E = 2 (1 + 3 x + y^2 + 0.5 x z)),
+    so that no two blocks are congruent and no coordinate permutation of the cube leaves K_2 invariant.  The explicit operators are assembled column by column through the
+    multi-right-hand-side K^+ (8 columns per block and application, matinv_mv.hip; the reference's column-blocked MatInvExplicitly_Inv, matinv.c:640-730) and every W_b is
+    compared with numpy.linalg.pinv(K_b) on Gamma_b; the same assembly one column at a time gives the same operators."""
+    import scipy.sparse as sp
+
+    ctx = pa.Context(0)
+    nel = 6
+    f = pa.CubeFeti((2, 1, 1), nel, contact=True, young=[1.0, 2.0], graded={1: lambda x, y, z: 1.0 + 3.0 * x + y * y + 0.5 * x * z})
+    assert not f.congruent
+    nn = nel + 1
+    K1 = f.block_K(1)
+    from permon_amd.feti import box_symmetries
+
+    ops = box_symmetries((nn, nn, nn), 3, K1)
+    assert len(ops[0]) == 1  # only the identity survives the check against the graded matrix
+    G, e = f.coarse(orthonormalize=True)
+    loc = f.subset(range(2))
+    box = dict(dims=[(nn, nn, nn)] * 2, ndof=3, min_nodes=27)
+    W = {}
+    for mv in (True, False):
+        q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, mg_box=box, mg_precision="fp32", bsr3=True, explicit=dict(rtol=1e-13, storage="sym", multi_rhs=mv))
+        assert q.explicit_storage == "sym" and q.explicit_multi_rhs == mv
+        assert q.E.assemble_stats()[0] == int(q.E.n_gamma.sum())
+        W[mv] = [q.E.block(b) for b in range(2)]
+    for b in range(2):
+        Kb = f.block_K(b).toarray()
+        Kp = np.linalg.pinv(Kb, rcond=1e-10, hermitian=True)
+        Wb, g = W[True][b]
+        g = g - int(f.block_rowstart[b])  # Gamma_b is given in the rank's primal numbering
+        ref = Kp[np.ix_(g, g)]
+        assert np.max(np.abs(Wb - ref)) <= 1e-9 * np.max(np.abs(ref)), b
+        assert np.max(np.abs(Wb - W[False][b][0])) <= 1e-10 * np.max(np.abs(ref)), b
+    ctx.close()
