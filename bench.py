@@ -308,13 +308,14 @@ def svm_roofline(N, n, d, world, st, dt, passes):
     if N == 5000000 and world == 1:
         # HBM bytes per Hessian application from the committed PMC pass: all k_svm* launches, divided by the applications (= the launches of the second-pass kernels)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_configs4.json")))
+            c4file = next(f_ for f_ in ("r05_pmc_traffic_configs4.json", "r04_pmc_traffic_configs4.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", c4file)))
             # a Hessian application of the steady state (a run of expansion steps) is ONE launch of either paired kernel + the 64-column sum before it
             pk = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k != "_meta" and ("k_svm_x64_grad" in k or "k_svm_x64_p1<1>" in k)]
             cs = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k != "_meta" and "k_svm_colsum_feas" in k]
             meta = pmc.get("_meta", {})
             if len(pk) == 2:
-                traffic, tsrc = sum(pk) / 2 + (cs[0] if cs else 0.0), "profiles/r04_pmc_traffic_configs4.json @ %s (%s): mean of k_svm_x64_grad and k_svm_x64_p1<1> (one launch = one application in a run of expansion steps) + k_svm_colsum_feas" % (meta.get("git", "?"), meta.get("command", "?"))
+                traffic, tsrc = sum(pk) / 2 + (cs[0] if cs else 0.0), "profiles/" + c4file + " @ %s (%s): mean of k_svm_x64_grad and k_svm_x64_p1<1> (one launch = one application in a run of expansion steps) + k_svm_colsum_feas" % (meta.get("git", "?"), meta.get("command", "?"))
         except (OSError, ValueError) as ex:
             tsrc = "no PMC pass: %r" % (ex,)
     b_pair = 8.0 * n * d + 68.0 * n  # one pass over X + half of the 17 vectors the two fused passes of an expansion step read or write
@@ -567,6 +568,10 @@ def pmc_lookup(prefix, fname, combine="mean", contains=None):
     """(HBM bytes per launch, provenance) of a kernel from a committed rocprofv3 PMC pass (profiles/<fname>, written by
     scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
     carries no traffic figure rather than a stale one."""
+    # the newest committed pass of that name wins (profiles/r05_* over r04_*: the callers name the round-4 file the figure first came from)
+    for newer in ("r05_" + fname[4:],) if fname.startswith("r04_") else ():
+        if os.path.exists(os.path.join(ROOT, "profiles", newer)):
+            fname = newer
     path = os.path.join(ROOT, "profiles", fname)
     try:
         pmc = json.load(open(path))

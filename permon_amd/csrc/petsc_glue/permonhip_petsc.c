@@ -1667,7 +1667,7 @@ PERMON_EXTERN PetscErrorCode MatInvAttachExplicitHIP(Mat imat, Mat Bt, PetscInt 
   }
   PetscCall(MatSeqAIJRestoreArrayRead(bd->localBlock, &va));
   PetscCall(MatRestoreRowIJ(bd->localBlock, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
-  PMHCall(pmh_fexplicit_assemble(E, Kp, 1, cls, cls, rtol > 0 ? rtol : 1e-12, 0)); /* MatInvExplicitly's loop of KSPSolves (matinv.c:640-665), one unit right-hand side per block and pass */
+  PMHCall(pmh_fexplicit_assemble_auto(E, Kp, cls, cls, rtol > 0 ? rtol : 1e-12, 0, NULL)); /* MatInvExplicitly's loop of KSPSolves (matinv.c:640-665): 8 unit right-hand sides per block and pass on the multi-right-hand-side K^+ where it applies, else one */
   PMHCall(pmh_matinv_attach_explicit(Kp, E));
   PetscCall(PermonHipCompose((PetscObject)imat, "pmh_fexplicit", E, PermonHipFexplicitDestroy));
   PetscFunctionReturn(PETSC_SUCCESS);
