@@ -114,7 +114,7 @@ def test_every_glue_function_named_in_integration_md_exists():
 
 def test_glue_binds_the_measured_path():
     calls = {c[0] for c in glue_calls()}
-    for need in ("pmh_fexplicit_create_shared_orbit", "pmh_fexplicit_set_box_symmetry", "pmh_fexplicit_assemble", "pmh_matinv_attach_explicit", "pmh_csr_block_classes",  # explicit K^+
+    for need in ("pmh_fexplicit_create_shared_orbit", "pmh_fexplicit_set_box_symmetry", "pmh_fexplicit_assemble_auto", "pmh_matinv_attach_explicit", "pmh_csr_block_classes",  # explicit K^+
                  "pmh_op_create_feti_dual", "pmh_op_create_projected", "pmh_op_create_penalized", "pmh_op_create_shell", "pmh_op_create_csr",  # operator towers
                  "pmh_qppf_create", "pmh_qppf_apply_Q", "pmh_qppf_apply_P", "pmh_qppf_apply_GtG", "pmh_qppf_apply_CP", "pmh_qppf_apply_halfQ", "pmh_qppf_apply_halfQ_transpose",
                  "pmh_smalxe_create", "pmh_smalxe_solve", "pmh_smalxe_get_stats", "pmh_smalxe_get_inner", "pmh_pcpg_solve", "pmh_ksp_cg_solve", "pmh_kspfeti_solve",
