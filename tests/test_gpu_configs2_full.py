@@ -115,7 +115,7 @@ def test_full_size_headline_path(c2, storage):
                     explicit=dict(rtol=1e-12, storage=storage, symmetry=dict(dims=(44, 44, 44), ndof=3, orbit=storage == "class_orbit")))
     assert qh.explicit_symmetries == 48 and qh.explicit_storage == storage
     n_solves, secs = qh.E.assemble_stats()
-    assert 700 <= n_solves <= 760 and qh.E.dense_bytes < (0.2e9 if storage == "class_orbit" else 4.7e9)
+    assert 700 <= n_solves <= 715 + 64 and qh.E.dense_bytes < (0.2e9 if storage == "class_orbit" else 4.7e9)
     st, lam = _solve(qh)
     assert st.reason == 2 and _counts(st) == COUNTS
     assert np.linalg.norm(lam - lam_ref) <= 1e-6 * np.linalg.norm(lam_ref)
