@@ -28,6 +28,7 @@ pmh_knobs_s &pmh_knobs()
     v.svm_pairing = getenv("PMH_SVM_NO_PAIRING") ? 0 : 1;
     v.gt_fusion = getenv("PMH_NO_GT_FUSION") ? 0 : 1;
     v.multi_rhs = getenv("PMH_NO_MULTI_RHS") ? 0 : 1;
+    v.kplus_mv = getenv("PMH_NO_KPLUS_MV") ? 0 : 1;
     v.smalxe_prefetch = getenv("PMH_SMALXE_NO_PREFETCH") ? 0 : 1;
     v.mg_d0_fusion = getenv("PMH_MG_NO_D0_FUSION") ? 0 : 1;
     v.vec_epi = getenv("PMH_NO_VEC_EPI") ? 0 : 1;
@@ -57,6 +58,7 @@ static int *knob_by_name(const char *name)
   if (!strcmp(name, "svm_pairing")) return &pmh_knobs().svm_pairing;
   if (!strcmp(name, "gt_fusion")) return &pmh_knobs().gt_fusion;
   if (!strcmp(name, "multi_rhs")) return &pmh_knobs().multi_rhs;
+  if (!strcmp(name, "kplus_mv")) return &pmh_knobs().kplus_mv;
   if (!strcmp(name, "smalxe_prefetch")) return &pmh_knobs().smalxe_prefetch;
   if (!strcmp(name, "mg_d0_fusion")) return &pmh_knobs().mg_d0_fusion;
   if (!strcmp(name, "mpgp_spec")) return &pmh_knobs().mpgp_spec;

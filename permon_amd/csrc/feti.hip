@@ -17,6 +17,7 @@
 
 #include "pmh_internal.h"
 #include "feti_internal.h"
+#include "mv_internal.h"
 #include "reduce.h"
 
 // ---- MATGLUING -----------------------------------------------------------------------------------------------------
@@ -558,6 +559,22 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_seg_project(const int *__restrict
   }
 }
 
+// 8 congruent blocks as the 8 columns of one block (matinv_mv.hip): dropped whenever the solver changes, tried again at the next application
+static void matinv_mvc_reset(pmh_matinv M)
+{
+  if (M->mvc) pmh_matinv_mv_destroy(M->mvc), M->mvc = nullptr;
+  M->mvc_state = 0;
+}
+static int matinv_mvc_init(pmh_matinv M)
+{
+  if (M->mvc_state != 0) return PMH_SUCCESS;
+  M->mvc_state = -1;
+  if (!pmh_knobs().kplus_mv || M->nblocks != PMH_MV_R || !M->Kb || !M->mg || M->left) return PMH_SUCCESS;
+  const int rc = pmh_matinv_mv_create_congruent(M, &M->mvc);
+  if (rc == PMH_SUCCESS) M->mvc_state = 1;
+  return rc == PMH_EPI_UNSUPPORTED ? PMH_SUCCESS : rc;
+}
+
 extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int max_it, int jacobi, pmh_matinv *out)
 {
   PMH_ARG(K && out && max_it > 0);
@@ -606,6 +623,7 @@ extern "C" int pmh_matinv_set_nullspace(pmh_matinv M, int kdim, const double *R_
   pmh_ctx ctx = M->ctx;
   if (M->d_R) pmh_free(ctx, M->d_R), M->d_R = nullptr;
   M->kdim = kdim;
+  matinv_mvc_reset(M);
   if (!kdim) return PMH_SUCCESS;
   PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)kdim * M->n, (void **)&M->d_R));
   PMH_CHK(pmh_memcpy_h2d(ctx, M->d_R, R_host, sizeof(double) * (size_t)kdim * M->n));
@@ -633,6 +651,7 @@ extern "C" int pmh_matinv_set_left_inverse(pmh_matinv M, int nfix, const int *fi
   for (int i = 0; i < nfix; i++) PMH_ARG(fix_dofs_host[i] >= 0 && fix_dofs_host[i] < M->n);
   if (M->d_fix) pmh_free(M->ctx, M->d_fix), M->d_fix = nullptr;
   M->left = nfix > 0, M->nfix = nfix;
+  matinv_mvc_reset(M);
   if (!nfix) return PMH_SUCCESS;
   PMH_CHK(pmh_malloc(M->ctx, sizeof(int) * (size_t)nfix, (void **)&M->d_fix));
   return pmh_memcpy_h2d(M->ctx, M->d_fix, fix_dofs_host, sizeof(int) * (size_t)nfix);
@@ -663,6 +682,7 @@ extern "C" int pmh_matinv_destroy(pmh_matinv M)
 {
   if (!M) return PMH_SUCCESS;
   pmh_ctx ctx = M->ctx;
+  matinv_mvc_reset(M);
   if (M->d_R) pmh_free(ctx, M->d_R);
   if (M->d_coef) pmh_free(ctx, M->d_coef);
   if (M->d_fproj) pmh_free(ctx, M->d_fproj);
@@ -695,6 +715,14 @@ extern "C" int pmh_matinv_mult(pmh_matinv M, const double *f, double *u)
   const int *rs  = M->K->d_rowstart;
   hipStream_t st = ctx->stream;
   if (M->n == 0) return PMH_SUCCESS;
+  PMH_CHK(matinv_mvc_init(M));
+  if (M->mvc_state == 1) { // 8 congruent blocks: the 8 columns of one block on the multi-right-hand-side kernels (same tolerances, same per-block convergence test)
+    const long long p0 = pmh_matinv_mv_products(M->mvc);
+    PMH_CHK(pmh_matinv_mv_mult_blocks(M->mvc, f, u));
+    M->last_max_its = pmh_matinv_mv_last_iterations(M->mvc);
+    M->total_spmv += pmh_matinv_mv_products(M->mvc) - p0;
+    return PMH_SUCCESS;
+  }
   if (M->kdim) { // f <- P_R f
     PMH_CHK(matinv_project(M, f, M->d_fproj, M->d_fnorm2));
     f = M->d_fproj;
@@ -764,6 +792,7 @@ extern "C" int pmh_matinv_set_pc_mg(pmh_matinv M, pmh_mg mg)
 {
   PMH_ARG(M);
   M->mg = mg; // NULL restores Jacobi / none
+  matinv_mvc_reset(M);
   return PMH_SUCCESS;
 }
 
@@ -795,6 +824,7 @@ extern "C" int pmh_matinv_enable_bsr3(pmh_matinv M)
     if (M->K->rowstart[b + 1] - M->K->rowstart[b] != M->K->rowstart[1] - M->K->rowstart[0]) nrep = 1;
   PMH_CHK(pmh_bsr3_from_csr(M->K->K, 0, &M->Kb, 0, nrep));
   if (!M->Kb) return pmh_set_error(PMH_ERR_SUP, "pmh_matinv_enable_bsr3: K (n = %d) has no usable 3x3 block structure", M->n);
+  matinv_mvc_reset(M);
   return PMH_SUCCESS;
 }
 
@@ -809,6 +839,8 @@ extern "C" int pmh_matinv_bsr3_replicas(pmh_matinv M, int *nrep)
 extern "C" int pmh_matinv_timing_enable(pmh_matinv M, int max_launches)
 {
   PMH_ARG(M);
+  PMH_CHK(matinv_mvc_init(M));
+  if (M->mvc_state == 1) return pmh_matinv_mv_timing(M->mvc, std::max(1, max_launches), nullptr, nullptr, nullptr);
   if (M->Kb) return pmh_bsr3_timing_enable(M->Kb, max_launches);
   return pmh_csr_timing_enable(M->K->K, max_launches);
 }
@@ -816,6 +848,7 @@ extern "C" int pmh_matinv_timing_enable(pmh_matinv M, int max_launches)
 extern "C" int pmh_matinv_timing_get(pmh_matinv M, int *launches, double *total_ms, double *bytes_per_launch)
 {
   PMH_ARG(M && launches && total_ms);
+  if (M->mvc_state == 1) return pmh_matinv_mv_timing(M->mvc, 0, launches, total_ms, bytes_per_launch);
   if (M->Kb) {
     if (bytes_per_launch) *bytes_per_launch = pmh_bsr3_bytes(M->Kb);
     return pmh_bsr3_timing_get(M->Kb, launches, total_ms);

@@ -54,6 +54,10 @@ struct pmh_matinv_s {
   pmh_mg  mg; // optional V-cycle preconditioner (pmh_matinv_set_pc_mg); NULL: Jacobi / none
   pmh_bsr3 Kb; // optional 3x3-block copy of K for the CG's own product (pmh_matinv_enable_bsr3)
   pmh_fexplicit_s *E; // optional explicit K^+ on the dofs B touches (pmh_matinv_attach_explicit): F applies through it
+  // 8 congruent blocks with a fused fp32 V-cycle: pmh_matinv_mult runs them as the 8 columns of ONE block on the multi-right-hand-side kernels (matinv_mv.hip; knob "kplus_mv").
+  // mvc_state: 0 not tried yet, 1 in use, -1 does not apply; reset by whatever changes the solver (V-cycle, kernel, left inverse, block copy)
+  struct pmh_matinv_mv_s *mvc = nullptr;
+  int                     mvc_state = 0;
 };
 
 // explicit local dual operators (fexplicit.hip)

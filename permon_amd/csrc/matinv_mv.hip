@@ -16,6 +16,10 @@ struct pmh_matinv_mv_s {
   pmh_mg_mv  mgmv = nullptr;
   pmh_mv_ell K64  = nullptr;
   int        nb = 0, n = 0, ncol = 0, wgs = 0;
+  int        nrep = 1, ldR = 0;               // nrep = 8: the solver's 8 congruent blocks are the 8 columns of its FIRST block (n = rows of one block); ldR: row stride of M->d_R
+  double    *fin = nullptr, *uout = nullptr;  // congruent mode: the interleaved right-hand side / result around pmh_matinv_mv_mult
+  std::vector<hipEvent_t> ev;                 // optional timing of the fp64 products (pairs)
+  int        ev_on = 0, ev_used = 0;
   double    *r = nullptr, *z = nullptr, *p = nullptr, *Ap = nullptr, *fproj = nullptr;
   double    *partA = nullptr, *partB = nullptr, *partC = nullptr; // [ncol][wgs]: p'Ap | r'z | r'r
   double    *cs = nullptr;                                        // [2 parities][ncol][rz, tol]
@@ -259,13 +263,26 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_columns(int n, const double *
   if (i0 + oi < n) c[(size_t)orr * n + i0 + oi] = tile[oi][orr];
 }
 
+// C[r][i] -> V[i][r]
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_from_columns(int n, const double *__restrict__ c, double *__restrict__ v)
+{
+  __shared__ double tile[MVC_ROWS][MV_R + 1];
+  const int         i0 = blockIdx.x * MVC_ROWS;
+  const int         ii = threadIdx.x % MVC_ROWS, ir = threadIdx.x / MVC_ROWS;
+  if (i0 + ii < n) tile[ii][ir] = c[(size_t)ir * n + i0 + ii];
+  __syncthreads();
+  const int ti = threadIdx.x / MV_R, tr = threadIdx.x % MV_R;
+  if (i0 + ti < n) v[(size_t)(i0 + ti) * MV_R + tr] = tile[ti][tr];
+}
+
 int pmh_matinv_mv_destroy(pmh_matinv_mv V)
 {
   if (!V) return PMH_SUCCESS;
   pmh_ctx ctx = V->ctx;
   pmh_mg_mv_destroy(V->mgmv);
   pmh_mv_ell_destroy(V->K64);
-  for (double *p : {V->r, V->z, V->p, V->Ap, V->fproj, V->partA, V->partB, V->partC, V->cs, V->d_coef, V->d_kpart, V->d_fnorm2}) pmh_free(ctx, p);
+  for (double *p : {V->r, V->z, V->p, V->Ap, V->fproj, V->partA, V->partB, V->partC, V->cs, V->d_coef, V->d_kpart, V->d_fnorm2, V->fin, V->uout}) pmh_free(ctx, p);
+  for (hipEvent_t e : V->ev) (void)hipEventDestroy(e);
   pmh_free(ctx, V->ci), pmh_free(ctx, V->d_nactive), pmh_free(ctx, V->d_done);
   if (V->h_state) (void)hipHostFree(V->h_state);
   delete V;
@@ -274,7 +291,21 @@ int pmh_matinv_mv_destroy(pmh_matinv_mv V)
 
 // *out = NULL with PMH_EPI_UNSUPPORTED (no error recorded) where this solver does not apply: K without regular 3 x 3 blocks, a V-cycle of another shape than
 // mg_mv.hip runs, the left generalised inverse
-int pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out)
+static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out);
+int        pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out) { return mvc_create(M, 1, out); }
+
+int pmh_matinv_mv_create_congruent(pmh_matinv M, pmh_matinv_mv *out)
+{
+  PMH_ARG(M && out);
+  *out = nullptr;
+  if (M->nblocks != MV_R || !M->Kb || M->Kb->nrep != MV_R || !M->mg) {
+    pmh_mv_set_why("not 8 congruent blocks with a V-cycle (pmh_matinv_enable_bsr3 verifies the congruence)");
+    return PMH_EPI_UNSUPPORTED;
+  }
+  return mvc_create(M, MV_R, out);
+}
+
+static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out)
 {
   PMH_ARG(M && out);
   *out = nullptr;
@@ -284,16 +315,19 @@ int pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out)
   }
   pmh_ctx       ctx = M->ctx;
   pmh_matinv_mv V   = new pmh_matinv_mv_s();
-  V->M = M, V->ctx = ctx, V->nb = M->nblocks, V->n = M->n, V->ncol = M->nblocks * MV_R;
+  V->M = M, V->ctx = ctx, V->nrep = nrep, V->nb = M->nblocks / nrep, V->n = M->n / nrep, V->ncol = V->nb * MV_R, V->ldR = M->n;
   int maxrows = 1;
   for (int b = 0; b < V->nb; b++) maxrows = std::max(maxrows, M->K->rowstart[b + 1] - M->K->rowstart[b]);
   V->wgs = std::max(1, std::min({PMH_BLOCK, (maxrows + 4 * MVC_ROWS - 1) / (4 * MVC_ROWS), std::max(1, 4 * ctx->num_cus / std::max(1, V->nb))}));
-  int rc = pmh_mv_ell_create(M->K->K, PMH_BSR_F64, &V->K64);
+  int rc = pmh_mv_ell_create_prefix(M->K->K, nrep, PMH_BSR_F64, &V->K64);
   if (!rc && !V->K64) pmh_mv_set_why("K has rows with unsorted columns or more than 32 blocks of 3 x 3 in a block row"), rc = PMH_EPI_UNSUPPORTED;
-  if (!rc && M->mg) rc = pmh_mg_mv_create(M->mg, &V->mgmv);
+  if (!rc && M->mg) rc = pmh_mg_mv_create(M->mg, &V->mgmv, nrep);
   const size_t nR = (size_t)V->n * MV_R, np = (size_t)V->ncol * V->wgs;
   for (double **v : {&V->r, &V->z, &V->p, &V->Ap, &V->fproj})
     if (!rc) rc = pmh_malloc(ctx, sizeof(double) * nR, (void **)v);
+  if (nrep > 1)
+    for (double **v : {&V->fin, &V->uout})
+      if (!rc) rc = pmh_malloc(ctx, sizeof(double) * nR, (void **)v);
   for (double **v : {&V->partA, &V->partB, &V->partC})
     if (!rc) rc = pmh_malloc(ctx, sizeof(double) * np, (void **)v);
   if (!rc) rc = pmh_malloc(ctx, sizeof(double) * 4 * V->ncol, (void **)&V->cs);
@@ -321,9 +355,9 @@ static int mvc_project(pmh_matinv_mv V, const double *v, double *out, double *vn
   const int    grid = V->nb * V->wgs;
   const size_t ld   = (size_t)V->ncol * V->wgs;
   hipStream_t  st   = V->ctx->stream;
-  hipLaunchKernelGGL(k_mvc_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->n, M->kdim, ld, (const double *)M->d_R, v, V->d_kpart);
+  hipLaunchKernelGGL(k_mvc_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, ld, (const double *)M->d_R, v, V->d_kpart);
   hipLaunchKernelGGL(k_mvc_coef, dim3(V->nb), dim3(PMH_BLOCK), 0, st, V->wgs, M->kdim, ld, (const double *)V->d_kpart, V->d_coef, vnorm2);
-  hipLaunchKernelGGL(k_mvc_project, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->n, M->kdim, (const double *)M->d_R, (const double *)V->d_coef, v, out);
+  hipLaunchKernelGGL(k_mvc_project, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, (const double *)M->d_R, (const double *)V->d_coef, v, out);
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
@@ -355,7 +389,15 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
   int it = 0, next_check = (V->last_max_its > 0) ? V->last_max_its : (extpc ? 1 : 4);
   while (it < M->max_it) {
     const int q = it & 1;
+    const bool timed = V->ev_on && V->ev_used + 2 <= (int)V->ev.size();
+    if (timed) {
+      PMH_HIP(hipEventRecord(V->ev[V->ev_used], st));
+    }
     PMH_CHK(pmh_mv_spmv_f64(V->K64, V->p, V->Ap, PMH_EPI_NONE, nullptr, V->d_done));
+    if (timed) {
+      PMH_HIP(hipEventRecord(V->ev[V->ev_used + 1], st));
+      V->ev_used += 2;
+    }
     V->products++;
     hipLaunchKernelGGL(k_mvc_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->p, (const double *)V->Ap, V->partA);
     hipLaunchKernelGGL(k_mvc_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, extpc, (const int *)V->d_done, (const double *)V->cs, (const int *)V->ci, (const double *)V->partA, (const double *)M->dinv, (const double *)V->p,
@@ -379,6 +421,46 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
     PMH_CHK(mvc_project(V, u, V->fproj, nullptr));
     PMH_CHK(pmh_memcpy_d2d(ctx, u, V->fproj, sizeof(double) * (size_t)V->n * MV_R));
   }
+  return PMH_SUCCESS;
+}
+
+// congruent mode: u = K^+ f in the solver's own layout (block after block = column after column of the first block)
+int pmh_matinv_mv_mult_blocks(pmh_matinv_mv V, const double *f, double *u)
+{
+  PMH_ARG(V && V->nrep == MV_R && f && u);
+  const dim3 g((V->n + MVC_ROWS - 1) / MVC_ROWS), blk(PMH_BLOCK);
+  hipLaunchKernelGGL(k_mvc_from_columns, g, blk, 0, V->ctx->stream, V->n, f, V->fin);
+  PMH_CHK(pmh_matinv_mv_mult(V, V->fin, V->uout));
+  hipLaunchKernelGGL(k_mvc_columns, g, blk, 0, V->ctx->stream, V->n, (const double *)V->uout, u);
+  PMH_HIP(hipGetLastError());
+  return PMH_SUCCESS;
+}
+
+long long pmh_matinv_mv_products(pmh_matinv_mv V) { return V ? V->products : 0; }
+
+// event pairs around the fp64 products: enable > 0: (re)start with room for that many launches; enable == 0: read (launches, total ms, bytes one launch moves: the ELL copy once + x + y)
+int pmh_matinv_mv_timing(pmh_matinv_mv V, int enable, int *launches, double *total_ms, double *bytes_per_launch)
+{
+  PMH_ARG(V);
+  if (enable > 0) {
+    while ((int)V->ev.size() < 2 * enable) {
+      hipEvent_t e;
+      PMH_HIP(hipEventCreate(&e));
+      V->ev.push_back(e);
+    }
+    V->ev_on = 1, V->ev_used = 0;
+    return PMH_SUCCESS;
+  }
+  PMH_CHK(pmh_sync(V->ctx));
+  double tot = 0.0;
+  for (int i = 0; i + 1 < V->ev_used; i += 2) {
+    float ms = 0.f;
+    PMH_HIP(hipEventElapsedTime(&ms, V->ev[i], V->ev[i + 1]));
+    tot += ms;
+  }
+  if (launches) *launches = V->ev_used / 2;
+  if (total_ms) *total_ms = tot;
+  if (bytes_per_launch) *bytes_per_launch = (double)V->K64->W * V->K64->nbr * (9.0 * 8.0 + 4.0) + 2.0 * 8.0 * (double)V->n * MV_R;
   return PMH_SUCCESS;
 }
 

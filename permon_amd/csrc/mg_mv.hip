@@ -18,8 +18,17 @@ struct mg_mv_level {
 };
 struct pmh_mg_mv_s {
   pmh_mg                   mg;
+  int                      nrep = 1; // > 1: every level is block diagonal with nrep congruent blocks and this object works on the FIRST one (a prefix of every array of pmh_mg)
   std::vector<mg_mv_level> L;
 };
+
+// max |pinv_b - pinv_0| over the coarse blocks b > 0 (fp16 or fp32 entries, equal sizes): the coarse inverses of congruent blocks must be equal too
+template <typename TP> __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_pinv_diff(int nb, long long m2, const TP *__restrict__ pinv, int *__restrict__ differs)
+{
+  for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < m2; i += (long long)gridDim.x * PMH_BLOCK)
+    for (int b = 1; b < nb; b++)
+      if ((float)pinv[(long long)b * m2 + i] != (float)pinv[i]) *differs = 1;
+}
 
 // d0 = D^-1 b / theta (and the fp32 copy of an fp64 b): one thread per 4 consecutive entries of a row's R columns
 template <typename TB>
@@ -132,10 +141,34 @@ int pmh_mg_mv_destroy(pmh_mg_mv M)
   return PMH_SUCCESS;
 }
 
-int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out)
+int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
 {
-  PMH_ARG(mg && out);
+  PMH_ARG(mg && out && nrep >= 1);
   *out = nullptr;
+  if (nrep > 1) { // congruence of every level as pmh_bsr3_from_csr verified it, equal coarse inverses
+    for (int l = 0; l + 1 < mg->nlevels; l++)
+      if (!mg->L[l].Ab || mg->L[l].Ab->nrep != nrep) {
+        pmh_mv_set_why("the blocks are not congruent on every level of the hierarchy");
+        return PMH_EPI_UNSUPPORTED;
+      }
+    const int nc = mg->L[mg->nlevels - 1].n;
+    if (mg->nb_coarse != nrep || nc % nrep) {
+      pmh_mv_set_why("the coarse level does not have one block per congruent block");
+      return PMH_EPI_UNSUPPORTED;
+    }
+    int *d_diff, h_diff = 0;
+    PMH_CHK(pmh_malloc(mg->ctx, sizeof(int), (void **)&d_diff));
+    PMH_HIP(hipMemsetAsync(d_diff, 0, sizeof(int), mg->ctx->stream));
+    const long long m2 = (long long)(nc / nrep) * (nc / nrep);
+    if (mg->cp_half) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<_Float16>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2, (const _Float16 *)mg->d_cpinv, d_diff);
+    else if (mg->is_float) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<float>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2, (const float *)mg->d_cpinv, d_diff);
+    PMH_CHK(pmh_memcpy_d2h(mg->ctx, &h_diff, d_diff, sizeof(int)));
+    pmh_free(mg->ctx, d_diff);
+    if (h_diff) {
+      pmh_mv_set_why("the coarse pseudo-inverses of the congruent blocks differ");
+      return PMH_EPI_UNSUPPORTED;
+    }
+  }
   if (!(mg->is_float && mg->fused && mg->nlevels > 1 && mg->degree == 2)) {
     pmh_mv_set_why(!mg->is_float ? "the V-cycle runs in fp64" : (mg->degree != 2 ? "the smoother is not of degree 2" : (mg->nlevels < 2 ? "the hierarchy has one level" : "the V-cycle is not the fused form (PMH_MG_FUSED=0 or a level without 3 x 3 blocks)")));
     return PMH_EPI_UNSUPPORTED;
@@ -147,15 +180,15 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out)
     }
   pmh_ctx   ctx = mg->ctx;
   pmh_mg_mv M   = new pmh_mg_mv_s();
-  M->mg = mg;
+  M->mg = mg, M->nrep = nrep;
   M->L.resize(mg->nlevels);
   int rc = PMH_SUCCESS;
   for (int l = 0; l < mg->nlevels && !rc; l++) {
     mg_level    &Lv = mg->L[l];
     mg_mv_level &Ml = M->L[l];
-    const size_t nR = (size_t)Lv.n * MV_R;
+    const size_t nR = (size_t)(Lv.n / nrep) * MV_R;
     if (l + 1 < mg->nlevels) {
-      rc = pmh_mv_ell_create(Lv.A, Lv.Ab->storage == PMH_BSR_F64 ? PMH_BSR_F32 : Lv.Ab->storage, &Ml.E);
+      rc = pmh_mv_ell_create_prefix(Lv.A, nrep, Lv.Ab->storage == PMH_BSR_F64 ? PMH_BSR_F32 : Lv.Ab->storage, &Ml.E);
       if (!rc && !Ml.E) {
         pmh_mg_mv_destroy(M);
         pmh_mv_set_why("a level operator has rows with unsorted columns or more than 32 blocks of 3 x 3 in a block row");
@@ -182,18 +215,20 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   mg_mv_level &Ml = M->L[l];
   hipStream_t  st = mg->ctx->stream;
   const dim3   blk(PMH_BLOCK);
+  const int    nrep = M->nrep, n_l = Lv.n / nrep; // (congruent blocks: the first block's share of every level)
   if (l == mg->nlevels - 1) {
+    const int nbc = mg->nb_coarse / nrep;
     if (mg->cp_half)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
                          (const float *)Ml.b, Ml.x);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<float>), dim3((Lv.n + 3) / 4), blk, 0, st, mg->nb_coarse, Lv.n, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const float *)mg->d_cpinv, 1.f, (const float *)Ml.b, Ml.x);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<float>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const float *)mg->d_cpinv, 1.f, (const float *)Ml.b, Ml.x);
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
   mg_level    &Lc = mg->L[l + 1];
   mg_mv_level &Mc = M->L[l + 1];
-  const long long nR     = (long long)Lv.n * MV_R;
+  const long long nR     = (long long)n_l * MV_R;
   const float    *dinv   = (const float *)Lv.dinv;
   const float     itheta = (float)(1.0 / Lv.theta), c1 = (float)Lv.c1[1], c2 = (float)Lv.c2[1];
   if (!d0_ready) {
@@ -207,11 +242,11 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.d, Ml.xa, PMH_BSR_EPI_PRE, &e, halt));
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.t, PMH_EPI_SUB, &e, halt));
   const bool cf  = l + 2 < mg->nlevels; // the coarse level is a smoothed one: its d0 rides on the restriction
-  const int  ncn = Lc.n / 3;
+  const int  ncn = Lc.n / 3 / nrep;
   hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col, (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
                      cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   PMH_CHK(mvg_cycle(M, l + 1, nullptr, nullptr, cf, halt));
-  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(Lv.n / 3) * MV_R), blk, 0, st, Lv.n / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
+  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.x, PMH_BSR_EPI_POST1, &e, halt));

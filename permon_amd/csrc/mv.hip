@@ -105,13 +105,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, con
   for (int s = n; s < W; s++) put(s, br, z);
 }
 
-int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out)
+int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out) { return pmh_mv_ell_create_prefix(A, 1, storage, out); }
+
+// nrep > 1: A is block diagonal with nrep congruent blocks (the caller has verified it): the ELL copy of its FIRST block (rows / columns [0, n / nrep), nnz / nrep entries)
+int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
 {
-  PMH_ARG(A && out && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
+  PMH_ARG(A && out && nrep >= 1 && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
   *out        = nullptr;
   pmh_ctx ctx = A->ctx;
-  if (A->nrows != A->ncols || A->nrows % 3 || A->nrows == 0) return PMH_SUCCESS;
-  const int   nbr = A->nrows / 3;
+  if (A->nrows != A->ncols || A->nrows % (3 * nrep) || A->nrows == 0 || A->nnz % nrep) return PMH_SUCCESS;
+  const int       nbr  = A->nrows / 3 / nrep;
+  const long long nnzb = A->nnz / nrep;
   hipStream_t st  = ctx->stream;
   int        *d_info;
   PMH_CHK(pmh_malloc(ctx, sizeof(unsigned long long) * 2, (void **)&d_info));
@@ -128,7 +132,7 @@ int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out)
   double inv_scale = 1.0;
   if (storage == PMH_BSR_F16) { // power-of-two scale that brings the largest entry to [1, 2) (as pmh_bsr3_from_csr)
     PMH_HIP(hipMemsetAsync(d_info, 0, sizeof(unsigned long long) * 2, st));
-    hipLaunchKernelGGL(k_mv_absmax, dim3(1024), dim3(PMH_BLOCK), 0, st, A->nnz, (const double *)A->d_val, (unsigned long long *)d_info);
+    hipLaunchKernelGGL(k_mv_absmax, dim3(1024), dim3(PMH_BLOCK), 0, st, nnzb, (const double *)A->d_val, (unsigned long long *)d_info);
     double amax = 0.0;
     PMH_CHK(pmh_memcpy_d2h(ctx, &amax, d_info, sizeof(double)));
     int ex = 0;

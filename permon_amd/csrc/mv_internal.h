@@ -34,6 +34,7 @@ template <typename T> struct pmh_mv_epi {
 
 // *out = NULL without error when A has no regular 3 x 3 block structure (unsorted rows, or more than 32 blocks in a block row)
 int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out);
+int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out); // the first of nrep congruent diagonal blocks of A
 int pmh_mv_ell_destroy(pmh_mv_ell E);
 // y = A x on multivectors of R = PMH_MV_R columns (x, y: 3 nbr R entries) with the epilogues of k_bsr3 (PMH_EPI_NONE / ADD / SUB, PMH_BSR_EPI_PRE / POST1 / POST2)
 int pmh_mv_spmv_f64(pmh_mv_ell E, const double *x, double *y, int epi, const pmh_mv_epi<double> *e, const int *halt);
@@ -42,7 +43,7 @@ int pmh_mv_spmv_f32(pmh_mv_ell E, const float *x, float *y, int epi, const pmh_m
 // the V-cycle of pmh_mg on multivectors (mg_mv.hip).  create: PMH_EPI_UNSUPPORTED (no error recorded) for a hierarchy of another shape than the fused fp32 cycle
 struct pmh_mg_mv_s;
 typedef pmh_mg_mv_s *pmh_mg_mv;
-int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out);
+int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep = 1); // nrep > 1: the hierarchy of the FIRST of nrep congruent blocks (every level is block diagonal with nrep equal blocks)
 int pmh_mg_mv_destroy(pmh_mg_mv M);
 int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt);
 
@@ -50,6 +51,12 @@ int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt);
 struct pmh_matinv_mv_s;
 typedef pmh_matinv_mv_s *pmh_matinv_mv;
 int pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out); // PMH_EPI_UNSUPPORTED (no error recorded) where it does not apply
+// The solver's 8 CONGRUENT blocks as the 8 columns of ONE block: u = K^+ f of pmh_matinv_mult itself through the multi-right-hand-side kernels (f, u in the solver's own
+// block-after-block layout).  PMH_EPI_UNSUPPORTED unless the solver has exactly PMH_MV_R blocks whose congruence pmh_bsr3_from_csr has verified on every level.
+int pmh_matinv_mv_create_congruent(pmh_matinv M, pmh_matinv_mv *out);
+int pmh_matinv_mv_mult_blocks(pmh_matinv_mv V, const double *f, double *u);
+long long pmh_matinv_mv_products(pmh_matinv_mv V);
+int pmh_matinv_mv_timing(pmh_matinv_mv V, int enable, int *launches, double *total_ms, double *bytes_per_launch);
 int pmh_matinv_mv_destroy(pmh_matinv_mv V);
 int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u);               // f, u: n R doubles, interleaved
 int pmh_matinv_mv_to_columns(pmh_matinv_mv V, const double *u, double *cols);       // cols[r * n + i] = u[i * R + r]

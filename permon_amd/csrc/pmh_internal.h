@@ -29,6 +29,7 @@ struct pmh_knobs_s {
   int vec_epi = 1;         // PMH_NO_VEC_EPI: MPGP's vector phase in the operator's last kernel (mpgp.hip; qppf.hip reads the variable itself, once)
   int mpgp_spec = 1;       // PMH_MPGP_NO_SPEC: batches of device-side CG steps for CSR operators (mpgp.hip)
   int mg_d0_fusion = 1;    // PMH_MG_NO_D0_FUSION: the first smoothing step written by the producer of the right-hand side (feti.hip)
+  int kplus_mv = 1;        // PMH_NO_KPLUS_MV: pmh_matinv_mult on 8 congruent blocks runs them as the 8 columns of one block on the multi-right-hand-side kernels (feti.hip)
   int multi_rhs = 1;       // PMH_NO_MULTI_RHS: the set-up of the explicit operators solves 8 columns per block at a time where matinv_mv.hip applies (pmh_fexplicit_assemble_auto)
   int svm_pairing = 1;  // the SVM dual's paired passes over X inside MPGP (svm.hip); 0 (PMH_SVM_NO_PAIRING): every Hessian application as its own two passes
   // threads of the host-side set-up builders (bsr.hip, mgbox.hip, fexplicit.hip, contact.hip): PMH_HOST_THREADS, else OMP_NUM_THREADS, else min(16, the

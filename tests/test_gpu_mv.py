@@ -109,3 +109,40 @@ def test_multi_rhs_kplus_against_the_one_column_solver(ctx, case):
             ref = np.linalg.pinv(Kd, rcond=1e-10, hermitian=True) @ F[b * n_i:(b + 1) * n_i]
             for r in (0, 1, 2, 4, 6, 7):
                 assert np.linalg.norm(U[b * n_i:(b + 1) * n_i, r] - ref[:, r]) <= 1e-8 * np.linalg.norm(ref[:, r]), (case, b, r)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_eight_congruent_blocks_run_as_eight_columns(ctx, prec):
+    """pmh_matinv_mult on 8 CONGRUENT floating blocks (the cubes of a 2 x 2 x 2 decomposition) with the box V-cycle: the 8 blocks are the 8 columns of ONE block on the
+    multi-right-hand-side kernels (knob kplus_mv, the default) -- against the one-column block CG on 8 replicas (knob 0): the same K^+ to 1e-8 per block, iteration counts
+    within 2; and against the dense pseudo-inverse.  The first call after a change of the solver (here: tolerances stay, the knob flips) re-decides the path."""
+    from permon_amd.feti import CubeFeti
+
+    f = CubeFeti((2, 2, 2), 6, "elasticity", contact=False)
+    nn, n_i, N = f.nel + 1, f.n_i, f.N
+    Ksp = f.K
+    rhs = np.random.default_rng(3).standard_normal(N) * np.repeat(10.0 ** np.arange(-3, 5), n_i)
+    out = []
+    try:
+        for knob in (1, 0):
+            check(ctx.L.pmh_set_knob(b"kplus_mv", knob))
+            K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Ksp)
+            M = pa.MatInv(K, rtol=1e-11, nullspace=f.R)
+            M.enable_bsr3()
+            M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=f.R, min_nodes=27, degree=2, precision=prec)
+            u = ctx.vec(N)
+            M.mult(ctx.vec_from(rhs), u)
+            M.mult(ctx.vec_from(rhs), u)  # twice: the second application starts from the first one's iteration estimate
+            out.append((u.to_numpy(), M.last_iterations()[0]))
+    finally:
+        ctx.L.pmh_set_knob(b"kplus_mv", 1)
+    (ua, ia), (ub, ib) = out
+    for b in range(8):
+        sl = slice(b * n_i, (b + 1) * n_i)
+        assert np.linalg.norm(ua[sl] - ub[sl]) <= 1e-8 * np.linalg.norm(ub[sl]), b
+    assert abs(ia - ib) <= 2 and ia < 30
+    Kp = np.linalg.pinv(Ksp[:n_i, :n_i].toarray(), rcond=1e-10, hermitian=True)
+    for b in (0, 7):
+        sl = slice(b * n_i, (b + 1) * n_i)
+        ref = Kp @ rhs[sl]
+        assert np.linalg.norm(ua[sl] - ref) <= 1e-8 * np.linalg.norm(ref), b
