@@ -18,6 +18,7 @@ struct mg_mv_level {
 };
 struct pmh_mg_mv_s {
   pmh_mg                   mg;
+  pmh_ctx                  ctx; // (kept: the caller may destroy the pmh_mg before this object)
   int                      nrep = 1; // > 1: every level is block diagonal with nrep congruent blocks and this object works on the FIRST one (a prefix of every array of pmh_mg)
   std::vector<mg_mv_level> L;
 };
@@ -132,7 +133,7 @@ static inline dim3 mvg_grid(long long work_items)
 int pmh_mg_mv_destroy(pmh_mg_mv M)
 {
   if (!M) return PMH_SUCCESS;
-  pmh_ctx ctx = M->mg->ctx;
+  pmh_ctx ctx = M->ctx;
   for (auto &l : M->L) {
     pmh_mv_ell_destroy(l.E);
     pmh_free(ctx, l.x), pmh_free(ctx, l.b), pmh_free(ctx, l.r), pmh_free(ctx, l.d), pmh_free(ctx, l.t), pmh_free(ctx, l.xa);
@@ -180,7 +181,7 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
     }
   pmh_ctx   ctx = mg->ctx;
   pmh_mg_mv M   = new pmh_mg_mv_s();
-  M->mg = mg, M->nrep = nrep;
+  M->mg = mg, M->ctx = ctx, M->nrep = nrep;
   M->L.resize(mg->nlevels);
   int rc = PMH_SUCCESS;
   for (int l = 0; l < mg->nlevels && !rc; l++) {
