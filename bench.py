@@ -873,12 +873,19 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kname = ("k_bsr3<double>: the fp64 K x of the block CG inside K^+ = the FETI dual SpMV (3x3 blocks, 8.44 B per non-zero)" if not a.no_bsr3
                  else "k_spmv_stream<plain, 2048-nnz tile, 8 lanes/row> on blockdiag(K_i): the FETI dual SpMV inside K^+")
         kpat = "void k_bsr3<double" if not a.no_bsr3 else "void k_spmv_stream<0, 2048,"
+        mv_active = q.Kplus.multi_rhs_active()
+        if mv_active:  # 8 congruent blocks = the 8 columns of one block: the product streams ONE ELL copy of K_1 from HBM and serves 8 vectors
+            kname = "k_mv_spmv<double, 8 columns>: the fp64 K x of the block CG inside K^+ on interleaved multivectors (ELL 3x3 blocks, 8 congruent blocks as the 8 columns of one)"
+            kpat = "void k_mv_spmv<double"
         traffic, tsrc = pmc_lookup(kpat, "r04_pmc_traffic_feti_iterative.json") if full_size else (None, "not the configuration of the committed PMC pass")
         nrep = q.Kplus.bsr3_replicas() if not a.no_bsr3 else 1
         roof = {"bound": "hbm", "kernel": kname, "achieved": cg_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_GBs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": b_cg, "launches_timed": n_cg, "avg_launch_ms": ms_cg / n_cg if n_cg else None, "timing_stride": stride,
                 "share_of_step_time": (ms_cg * 1e-3) * stride / dt if n_cg else None, "blocks_per_device_copy": nrep}
-        if nrep > 1:  # congruent blocks share ONE device copy: achieved / frac are on what HBM delivers; the block-diagonal figure (every K_i counted) is an L2-served rate
+        if mv_active:
+            roof["blocks_per_device_copy"] = 8
+            roof["note"] = "8 congruent blocks run as the 8 columns of ONE block (matinv_mv.hip): bytes = the ELL copy of K_1 once + the 8 x and 8 y (HBM)"
+        elif nrep > 1:  # congruent blocks share ONE device copy: achieved / frac are on what HBM delivers; the block-diagonal figure (every K_i counted) is an L2-served rate
             roof["bound"] = "l2"  # (the kernel is NOT at `frac` of HBM: most of what it reads comes from the XCDs' L2; the HBM-streaming form is the feti_dual_spmv block / PMH_BSR_NO_SHARE=1)
             b_bd = nrep * (b_cg - 16.0 * local["n_x"]) + 16.0 * local["n_x"]
             roof["blockdiag_figure_bytes"] = b_bd
@@ -1012,7 +1019,14 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         n_x, ms_x, b_x = q.Kplus.timing_get()
         q.Kplus.timing_enable(0)
         rhsv.free(), uv.free()
-        if n_x:
+        if n_x and q.Kplus.multi_rhs_active():
+            gbs = b_x / (ms_x / n_x * 1e-3) / 1e9
+            kx = {"bound": "hbm", "kernel": "k_mv_spmv<double, 8 columns>", "what": "Y = K_1 X of the block-wise CG inside K^+ as pmh_matinv_mult runs it on 8 congruent blocks: the 8 blocks' vectors are the 8 columns of "
+                                                                                    "ONE block (matinv_mv.hip), the ELL copy of K_1 (3x3 blocks) streamed once per launch",
+                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_x, "launches_timed": n_x, "avg_launch_ms": ms_x / n_x,
+                  "matrix_copies_on_device": 1, "blocks_per_copy": 8,
+                  "note": "the one-column kernel k_bsr3<double> (8 replicas of one device copy served from L2; the set-up solves of non-congruent blocks and every N > 1 run use it) is timed with PMH_NO_KPLUS_MV=1"}
+        elif n_x:
             nrep = q.Kplus.bsr3_replicas()
             gbs = b_x / (ms_x / n_x * 1e-3) / 1e9
             b_bd = nrep * (b_x - 16.0 * local["n_x"]) + 16.0 * local["n_x"]

@@ -658,6 +658,9 @@ int pmh_mv_test_spmv(pmh_csr A, int storage, const double *x, double *y, int rep
  * basis (pmh_matinv_set_nullspace: K^+ = P_R K^- P_R) and the tolerances are the solver's own; every (block, column) pair converges by its own test.  PMH_ERR_SUP where
  * the multi-right-hand-side kernels do not apply (K without regular 3 x 3 blocks, a V-cycle other than the fused fp32 one, the left generalised inverse). */
 int pmh_matinv_mult_multi(pmh_matinv M, const double *F, double *U, int *max_iterations /* or NULL */);
+/* pmh_matinv_mult (MatMult_Inv, matinv.c:734-743) itself takes these kernels when the solver has exactly 8 congruent blocks (verified entry by entry by pmh_matinv_enable_bsr3)
+   and the fused fp32 V-cycle: the 8 blocks' vectors are the 8 columns of ONE block.  *active: whether the next application will (knob "kplus_mv" / PMH_NO_KPLUS_MV for the A/B). */
+int pmh_matinv_multi_rhs_active(pmh_matinv M, int *active);
 
 #ifdef __cplusplus
 }

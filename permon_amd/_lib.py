@@ -252,6 +252,7 @@ _PROTOS = {
     "pmh_matinv_bsr3_replicas": [vp, c_int_p],
     "pmh_mv_test_spmv": [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float)],
     "pmh_matinv_mult_multi": [vp, vp, vp, c_int_p],
+    "pmh_matinv_multi_rhs_active": [vp, c_int_p],
     "pmh_fexplicit_assemble_auto": [vp, vp, vp, vp, C.c_double, C.c_int, c_int_p],
     "pmh_matinv_timing_enable": [vp, C.c_int],
     "pmh_matinv_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],

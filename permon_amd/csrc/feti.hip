@@ -857,6 +857,15 @@ extern "C" int pmh_matinv_timing_get(pmh_matinv M, int *launches, double *total_
   return pmh_csr_timing_get(M->K->K, PMH_EPI_NONE, launches, total_ms);
 }
 
+// 1: pmh_matinv_mult runs the solver's 8 congruent blocks as the 8 columns of one block on the multi-right-hand-side kernels (decided at the first application after a change)
+extern "C" int pmh_matinv_multi_rhs_active(pmh_matinv M, int *active)
+{
+  PMH_ARG(M && active);
+  PMH_CHK(matinv_mvc_init(M));
+  *active = M->mvc_state == 1;
+  return PMH_SUCCESS;
+}
+
 extern "C" int pmh_matinv_last_iterations(pmh_matinv M, int *max_block_its, long long *total_spmv)
 {
   PMH_ARG(M);

@@ -225,6 +225,12 @@ class MatInv:
     def mult(self, f, u):  # MatMult_Inv
         check(self.ctx.L.pmh_matinv_mult(self.h, f.p, u.p))
 
+    def multi_rhs_active(self):
+        """True when mult() runs the solver's 8 congruent blocks as the 8 columns of one block (pmh_matinv_multi_rhs_active)."""
+        v = C.c_int()
+        check(self.ctx.L.pmh_matinv_multi_rhs_active(self.h, C.byref(v)))
+        return bool(v.value)
+
     def mult_multi(self, F, U):
         """U = K^+ F for 8 columns per block at once (pmh_matinv_mult_multi): F, U vectors of 8 n entries, entry (dof i, column r) at 8 i + r.  Returns the largest iteration count."""
         its = C.c_int()
