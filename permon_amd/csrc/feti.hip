@@ -572,6 +572,7 @@ static int matinv_mvc_init(pmh_matinv M)
   if (!pmh_knobs().kplus_mv || M->nblocks != PMH_MV_R || !M->Kb || !M->mg || M->left) return PMH_SUCCESS;
   const int rc = pmh_matinv_mv_create_congruent(M, &M->mvc);
   if (rc == PMH_SUCCESS) M->mvc_state = 1;
+  else if (rc == PMH_EPI_UNSUPPORTED && getenv("PMH_MV_VERBOSE")) fprintf(stderr, "pmh_matinv: 8 congruent blocks, but not on the multi-right-hand-side kernels: %s\n", pmh_mv_why());
   return rc == PMH_EPI_UNSUPPORTED ? PMH_SUCCESS : rc;
 }
 
