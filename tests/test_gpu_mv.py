@@ -146,3 +146,29 @@ def test_eight_congruent_blocks_run_as_eight_columns(ctx, prec):
         sl = slice(b * n_i, (b + 1) * n_i)
         ref = Kp @ rhs[sl]
         assert np.linalg.norm(ua[sl] - ref) <= 1e-8 * np.linalg.norm(ref), b
+
+
+def test_multi_rhs_kplus_on_blocks_of_different_sizes(ctx):
+    """ex71's elasticity slabs (DmdaFeti): 7 blocks of two different sizes, one of them non-singular (Dirichlet in the matrix), thin in x, a hierarchy built by the Python
+    builder and handed in (pmh_mg_create with node-wise P) -- the 8-column solver against the one-column solver on every column, and the explicit operators assembled
+    8 columns at a time against the same assembly one column at a time."""
+    from permon_amd.feti import DmdaFeti, box_mg_hierarchy
+
+    prob = DmdaFeti((8, 6, 4), 7, "elasticity")
+    dims = [(2, 7, 5), (3, 7, 5)] + [(2, 7, 5)] * 5
+    H = box_mg_hierarchy(prob.blocks, dims, 3, min_nodes=27)
+    K = pa.MatBlockDiag.from_scipy(ctx, prob.block_rowstart, prob.K)
+    M = pa.MatInv(K, rtol=1e-12, nullspace=prob.R)
+    M.enable_bsr3()
+    M.set_pc_mg(H, degree=2, precision="fp32")
+    N = prob.N
+    F = np.random.default_rng(21).standard_normal((N, 8))
+    Ud = ctx.vec(N * 8)
+    its = M.mult_multi(ctx.vec_from(F.reshape(-1)), Ud)
+    U = Ud.to_numpy().reshape(N, 8)
+    u1 = ctx.vec(N)
+    for r in range(8):
+        M.mult(ctx.vec_from(F[:, r].copy()), u1)
+        ref = u1.to_numpy()
+        assert np.linalg.norm(U[:, r] - ref) <= 1e-8 * np.linalg.norm(ref), r
+    assert its < 40
