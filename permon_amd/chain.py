@@ -187,7 +187,7 @@ class FetiDualQP:
             break
         self.explicit_storage = storage
         ngl = len(stripe[2]["block_rowstart"]) - 1 if stripe is not None else nb
-        def run(mv):
+        def run(mv):  # (8 columns per block need no replica solver: a rank with one block gets its 8 slots from the multi-right-hand-side K^+)
             if solver_factory is not None and nb < min_slots and one_class and not mv:
                 solver = solver_factory(int(min_slots))
                 E.assemble(solver, slot_class=np.zeros(solver.K.nblocks, dtype=np.int32), block_class=np.zeros(ngl, dtype=np.int32), rtol=rtol, max_it=max_it)
@@ -198,9 +198,7 @@ class FetiDualQP:
                 E.assemble(self.Kplus, slot_class=cls, block_class=cls, rtol=rtol, max_it=max_it, multi_rhs=mv)
 
         self.explicit_multi_rhs = False
-        if multi_rhs == "auto" and solver_factory is not None and nb < min_slots and one_class:
-            run(False)  # the caller's replica solver supplies the slots
-        elif multi_rhs == "auto" and not self._knob("multi_rhs"):
+        if multi_rhs == "auto" and not self._knob("multi_rhs"):
             run(False)  # PMH_NO_MULTI_RHS / pmh_set_knob("multi_rhs", 0): the A/B switch
         elif multi_rhs == "auto":
             from ._lib import PermonHipError

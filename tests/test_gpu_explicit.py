@@ -320,7 +320,7 @@ def test_explicit_replica_solver(ctx):
         made["K"] = Kb
         return pa.MatInv(Kb, rtol=1e-13, max_it=20000, nullspace=np.tile(loc["R"], (1, nslots)))
 
-    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, min_slots=4, solver_factory=factory))
+    q = FetiDualQP(ctx, loc, G, e, f.c, f.lb, kplus_rtol=1e-13, explicit=dict(rtol=1e-13, min_slots=4, solver_factory=factory, multi_rhs=False))  # (with multi_rhs the block's own solver has 8 slots)
     assert made["K"].nblocks == 4
     Kp = np.linalg.pinv(f.Ki.toarray(), rcond=1e-10, hermitian=True)
     W, g = q.E.block(0)
