@@ -188,7 +188,9 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile, int nrep_
     const long long nnzb = A->nnz / nrep;
     bool            same = rp[n] == nnzb;
     for (int r = 1; r < nrep && same; r++) same = (long long)rp[(size_t)r * n] == (long long)r * nnzb;
-    if (same) {
+    if (same && A->congruent_nrep == nrep) {
+      // compared before (another storage of the same matrix)
+    } else if (same) {
       const int         ntc = std::max(1, pmh_host_threads());
       std::vector<char> bad(ntc, 0);
       auto              cmp = [&](int tt) {
@@ -213,6 +215,7 @@ int pmh_bsr3_from_csr(pmh_csr A, int storage, pmh_bsr3 *out, int tile, int nrep_
       for (char b : bad) same = same && !b;
     }
     if (!same) nrep = 1, n = n_all, nbr = n / 3;
+    else A->congruent_nrep = nrep;
     stage(nrep > 1 ? "congruent diagonal blocks confirmed (one device copy serves all)" : "diagonal blocks differ: one device copy each");
   }
   const long long nnz_used = nrep > 1 ? A->nnz / nrep : A->nnz;

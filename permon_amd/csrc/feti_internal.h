@@ -88,7 +88,7 @@ struct pmh_asm_solver {
   void close()
   {
     if (V) pmh_matinv_mv_destroy(V), V = nullptr;
-    if (umv) pmh_free(M->ctx, umv), umv = nullptr;
+    if (umv && M) pmh_free(M->ctx, umv), umv = nullptr;
   }
   int    R() const { return V ? PMH_MV_R : 1; }
   size_t len() const { return (size_t)std::max(1, M->n) * R(); }

@@ -772,11 +772,11 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   int ncls = 0;
   for (int b = 0; b < nb; b++) ncls = std::max(ncls, bc[b] + 1);
   pmh_asm_solver A;
-  PMH_CHK(A.open(solver, nslots));
   struct closer {
     pmh_asm_solver &a;
     ~closer() { a.close(); }
   } closer_{A};
+  PMH_CHK(A.open(solver, nslots));
   // per class: its slots, its blocks, the union of the blocks' relative Gamma indices
   std::vector<std::vector<int>> cslots(ncls), cblocks(ncls), cunion(ncls);
   for (int s = 0; s < nslots; s++)

@@ -551,11 +551,11 @@ int fxs_assemble(fx_shared *S, pmh_matinv solver, int nslots, const int *slot_cl
   pmh_ctx                       ctx = S->ctx;
   if (S->sym == 2) PMH_CHK(fxo_prepare(S));
   pmh_asm_solver                A;
-  PMH_CHK(A.open(solver, nslots));
   struct closer {
     pmh_asm_solver &a;
     ~closer() { a.close(); }
   } closer_{A};
+  PMH_CHK(A.open(solver, nslots));
   std::vector<std::vector<int>> cslots(S->ncls), todo(S->ncls);
   std::vector<std::vector<int>> rep_of(S->ncls), op_of(S->ncls), check(S->ncls);
   std::vector<std::map<int, std::vector<int>>> members(S->ncls); // representative row -> the owned rows of its orbit

@@ -11,6 +11,8 @@
 // block kernel of bsr.hip (one column index per block), and with precision = PMH_MG_FP32 the whole cycle (operators and
 // vectors) is single precision -- it only preconditions the fp64 CG, whose residual and solution stay fp64.
 #include <chrono>
+#include <thread>
+#include <algorithm>
 #include <cstdio>
 
 #include "pmh_internal.h"
@@ -447,26 +449,44 @@ static int mg_build_nodal_transfer(pmh_mg mg, int l, int fl)
   pmh_ctx   ctx = mg->ctx;
   if (P->nrows % 3 || P->ncols % 3 || P->nrows == 0 || P->nnz % 3) return PMH_SUCCESS;
   const int           n = P->nrows, nn = n / 3, ncn = P->ncols / 3;
-  std::vector<int>    rp((size_t)n + 1), ci((size_t)P->nnz);
-  std::vector<double> va((size_t)P->nnz);
-  PMH_CHK(pmh_memcpy_d2h(ctx, rp.data(), P->d_rowptr, sizeof(int) * rp.size()));
-  PMH_CHK(pmh_memcpy_d2h(ctx, ci.data(), P->d_col, sizeof(int) * ci.size()));
-  PMH_CHK(pmh_memcpy_d2h(ctx, va.data(), P->d_val, sizeof(double) * va.size()));
-  std::vector<int>    nrp((size_t)nn + 1, 0), nci;
-  std::vector<double> nva;
-  nci.reserve((size_t)P->nnz / 3), nva.reserve((size_t)P->nnz / 3);
-  for (int i = 0; i < nn; i++) {
-    const int k0 = rp[3 * i], m = rp[3 * i + 1] - k0;
-    if (rp[3 * i + 2] - rp[3 * i + 1] != m || rp[3 * i + 3] - rp[3 * i + 2] != m) return PMH_SUCCESS;
-    for (int q = 0; q < m; q++) {
-      const int    j = ci[k0 + q];
-      const double w = va[k0 + q];
-      if (j % 3 != 0) return PMH_SUCCESS;
-      for (int c = 1; c < 3; c++)
-        if (ci[rp[3 * i + c] + q] != j + c || va[rp[3 * i + c] + q] != w) return PMH_SUCCESS;
-      nci.push_back(j / 3), nva.push_back(w);
-    }
-    nrp[i + 1] = (int)nci.size();
+  std::vector<int>    rp_own, ci_own;
+  std::vector<double> va_own;
+  const int          *rp = P->h_rowptr, *ci = P->h_col; // the builder's host copy where it lent one (pmh_mg_create_box): no download of what was just uploaded
+  const double       *va = P->h_val;
+  if (!(rp && ci && va)) {
+    rp_own.resize((size_t)n + 1), ci_own.resize((size_t)P->nnz), va_own.resize((size_t)P->nnz);
+    PMH_CHK(pmh_memcpy_d2h(ctx, rp_own.data(), P->d_rowptr, sizeof(int) * rp_own.size()));
+    PMH_CHK(pmh_memcpy_d2h(ctx, ci_own.data(), P->d_col, sizeof(int) * ci_own.size()));
+    PMH_CHK(pmh_memcpy_d2h(ctx, va_own.data(), P->d_val, sizeof(double) * va_own.size()));
+    rp = rp_own.data(), ci = ci_own.data(), va = va_own.data();
+  }
+  // node rows: counts, prefix, then the entries -- host threads over ranges of nodes (one thread took 0.05 s for the fine level of configs[2])
+  std::vector<int> nrp((size_t)nn + 1, 0);
+  for (int i = 0; i < nn; i++) nrp[i + 1] = nrp[i] + (rp[3 * i + 1] - rp[3 * i]);
+  std::vector<int>    nci((size_t)nrp[nn]);
+  std::vector<double> nva((size_t)nrp[nn]);
+  {
+    const int         nt = std::max(1, std::min(pmh_host_threads(), nn / 4096 + 1));
+    std::vector<char> bad(nt, 0);
+    auto work = [&](int t) {
+      for (int i = (int)((long long)nn * t / nt); i < (int)((long long)nn * (t + 1) / nt); i++) {
+        const int k0 = rp[3 * i], m = rp[3 * i + 1] - k0;
+        if (rp[3 * i + 2] - rp[3 * i + 1] != m || rp[3 * i + 3] - rp[3 * i + 2] != m) { bad[t] = 1; return; }
+        for (int q = 0; q < m; q++) {
+          const int    j = ci[k0 + q];
+          const double w = va[k0 + q];
+          if (j % 3 != 0) { bad[t] = 1; return; }
+          for (int c = 1; c < 3; c++)
+            if (ci[rp[3 * i + c] + q] != j + c || va[rp[3 * i + c] + q] != w) { bad[t] = 1; return; }
+          nci[(size_t)nrp[i] + q] = j / 3, nva[(size_t)nrp[i] + q] = w;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+    for (char b : bad)
+      if (b) return PMH_SUCCESS;
   }
   // node-level transpose (counting sort: columns of every row of P' ascending, the order of the scalar P')
   std::vector<int>    trp((size_t)ncn + 1, 0), tci(nci.size());

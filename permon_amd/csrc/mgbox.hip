@@ -342,8 +342,20 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
     L0.A.nr = L0.A.nc = n;
     L0.A.rp.resize((size_t)n + 1);
     for (int i = 0; i <= n; i++) L0.A.rp[i] = rowptr[r0 + i] - k0;
-    L0.A.ci.resize((size_t)L0.A.rp[n]), L0.A.va.assign(val + k0, val + k0 + L0.A.rp[n]);
-    for (int k = 0; k < L0.A.rp[n]; k++) L0.A.ci[k] = col[k0 + k] - r0;
+    {
+      // the class representative's block as a matrix of its own (column indices relative to the block): host threads over its entries (19 M for configs[2]: 45 ms on one thread)
+      const size_t nz = (size_t)L0.A.rp[n];
+      L0.A.ci.resize(nz), L0.A.va.resize(nz);
+      const int                nt = std::max(1, std::min(pmh_host_threads(), (int)(nz / 1000000) + 1));
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t]() {
+          const size_t a0 = nz * t / nt, a1 = nz * (t + 1) / nt;
+          std::copy(val + k0 + a0, val + k0 + a1, L0.A.va.begin() + a0);
+          for (size_t k = a0; k < a1; k++) L0.A.ci[k] = col[k0 + k] - r0;
+        });
+      for (auto &x : th) x.join();
+    }
     C.kd = 0;
     for (int k = 0; k < kdim; k++) { // the block's non-zero kernel vectors
       const double *r = R_host + (size_t)k * N + r0;
