@@ -74,7 +74,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_emit(int n, const double *
 
 // T G0 u and ||T G0 u||^2 from the segment sums of the iterate, on their own (one workgroup): where no application follows the emission before the host waits
 template <int NU>
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_norm(pmh_emit_tab tab, const double *__restrict__ part, const double *__restrict__ Tt, double *__restrict__ y2, double *__restrict__ norm_d,
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_norm(pmh_emit_tab tab, const double *__restrict__ part, const double *__restrict__ Tt,
+                        double *__restrict__ y2, double *__restrict__ norm_d,
                                                          double *__restrict__ norm_h)
 {
   __shared__ double pt[PMH_EMIT_NW][64];
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_norm(pmh_emit_tab tab, con
 
 // (G0' c)_j over the slot copy: left to right as the CSR row (padded slots hold 0 x c[0])
 template <int W>
-static __device__ __forceinline__ void dc_gt_load(const double *__restrict__ ev, const unsigned char *__restrict__ ec, int j, double (&v)[W], unsigned char (&c)[W])
+static __device__ __forceinline__ void dc_gt_load(const double *__restrict__ ev, const unsigned char *__restrict__ ec, int j, double (&v)[W],
+                        unsigned char (&c)[W])
 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -122,7 +124,8 @@ struct dc_norm_args {
   double       *y2, *norm_d, *norm_h;
 };
 template <int W, int NU>
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_gather(int nlist, const int *__restrict__ reci, const double *__restrict__ recd, const int *__restrict__ bcol, const double *__restrict__ bval,
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_gather(int nlist, const int *__restrict__ reci, const double *__restrict__ recd,
+                        const int *__restrict__ bcol, const double *__restrict__ bval,
                                                         const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab, const double *__restrict__ part,
                                                         const double *__restrict__ S, double *__restrict__ c_out, dc_norm_args na, const double *__restrict__ x, double *__restrict__ mid)
 {
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_gather(int nlist, const in
 }
 
 // w = Bs mid_out (row j left to right: MatMultTranspose_Gluing's accumulation order, gluing.c:142-150) and the segment sums of G0 w, stored behind w
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsigned char *__restrict__ scnt, const int *__restrict__ sc2, const double *__restrict__ sv2, const int *__restrict__ srp,
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsigned char *__restrict__ scnt, const int *__restrict__ sc2,
+                        const double *__restrict__ sv2, const int *__restrict__ srp,
                                                             const int *__restrict__ scol, const double *__restrict__ sval, const double *__restrict__ Y, double *__restrict__ w, pmh_emit_args ea)
 {
   pmh_emit_regs R;
@@ -238,7 +242,8 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_scatter(int n, const unsig
 // d = G0 w from the segment sums behind w, e = S d; out = rho (G0' c)_j + (w_j - (G0' e)_j) -- VecAYPX, VecScale, VecAXPY of matpenalized.c:12-22 per entry --
 // and the MPGP vector phase: its block partials go to the device rows and to the pinned host copy, the segment sums of G0 p to the direction's target
 template <int EPI, int W, int NU>
-__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab, const double *__restrict__ S,
+__global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double *__restrict__ ev, const unsigned char *__restrict__ ec, pmh_emit_tab tab,
+                        const double *__restrict__ S,
                                                           const double *__restrict__ cin, const double *__restrict__ w, double rho, double *__restrict__ y, pmh_vec_epi epi,
                                                           const double *__restrict__ pin, pmh_emit_args ea)
 {
@@ -551,10 +556,12 @@ bool pmh_dc_norm_ready(pmh_dualchain dc, const double *u)
   if (dc->norm_ptr == u) return true;
   if (dc->x_emitted == u && !dc->norm_done) {
     if (dc->nwg <= 128)
-      hipLaunchKernelGGL(k_dc_norm<2>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt, dc->normGu, dc->ctx->d_scal + dc->norm_slot,
+      hipLaunchKernelGGL(k_dc_norm<2>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt,
+                         dc->normGu, dc->ctx->d_scal + dc->norm_slot,
                          dc->ctx->h_scal + dc->norm_slot);
     else
-      hipLaunchKernelGGL(k_dc_norm<8>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt, dc->normGu, dc->ctx->d_scal + dc->norm_slot,
+      hipLaunchKernelGGL(k_dc_norm<8>, dim3(1), dim3(PMH_EMIT_TILE), 0, dc->ctx->stream, dc_tab(dc), (const double *)dc->part[0], (const double *)dc->pf->d_Tt,
+                         dc->normGu, dc->ctx->d_scal + dc->norm_slot,
                          dc->ctx->h_scal + dc->norm_slot);
     if (hipGetLastError() != hipSuccess) return false;
     dc->norm_done = true, dc->norm_ptr = u;
@@ -617,7 +624,8 @@ int pmh_dc_apply(pmh_dualchain dc, const double *x, double *y, double rho, const
     pmh_emit_args ea;
     memset(&ea, 0, sizeof(ea));
     ea.tab = tab, ea.o[0].part = dc->w + n;
-    hipLaunchKernelGGL(k_dc_scatter, vgrid, eblk, 0, st, n, (const unsigned char *)dc->d_scnt, (const int *)dc->d_sc2, (const double *)dc->d_sv2, (const int *)Bs->d_rowptr, (const int *)Bs->d_col,
+    hipLaunchKernelGGL(k_dc_scatter, vgrid, eblk, 0, st, n, (const unsigned char *)dc->d_scnt, (const int *)dc->d_sc2, (const double *)dc->d_sv2,
+                       (const int *)Bs->d_rowptr, (const int *)Bs->d_col,
                        (const double *)Bs->d_val, dc->mid_out, dc->w, ea);
     dc->launches++;
   }

@@ -51,7 +51,8 @@ static __device__ __forceinline__ double pmh_wave_all(double v)
 // a workgroup's partial sums of K quantities: wave tree, the waves in order; row k goes to partials[k ld + blockIdx.x] on the device AND in the pinned host
 // copy (the host adds the block sums itself after its next wait: no finalising launch; device consumers add them in their preamble, pmh_sum_block_partials)
 template <int K>
-static __device__ __forceinline__ void pmh_block_partials(const double (&v)[K], const int (&op)[K], double *__restrict__ partials, double *__restrict__ h_partials, int ld)
+static __device__ __forceinline__ void pmh_block_partials(const double (&v)[K], const int (&op)[K], double *__restrict__ partials,
+                        double *__restrict__ h_partials, int ld)
 {
   __shared__ double bp[K][PMH_EMIT_NW];
   const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -149,7 +150,8 @@ static __device__ __forceinline__ void pmh_emit_tail(const pmh_emit_args &ea, co
 // is null); a[r] also goes to a_out[r] (LDS or global; may be null).  The caller adds the waves' shares in wave order.  NU: 64 NU >= the number of tiles (2
 // serves up to 131 072 dual entries with a quarter of the registers of 8).
 template <int RPW, int NU = 8>
-static __device__ __forceinline__ void pmh_coarse_share(const pmh_emit_tab &tab, const double *__restrict__ part, const double *__restrict__ M1, const double *__restrict__ M2, double *a_out,
+static __device__ __forceinline__ void pmh_coarse_share(const pmh_emit_tab &tab, const double *__restrict__ part, const double *__restrict__ M1,
+                        const double *__restrict__ M2, double *a_out,
                                                        double &s1, double &s2)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, m = tab.m;

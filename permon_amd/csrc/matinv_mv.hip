@@ -2,7 +2,8 @@
 // V[(dof) * R + column] -- every (block, column) pair is its own CG with its own scalars and its own convergence test (KSPConvergedDefault on the true residual
 // recurrence, as the one-column solver), the operator product, the V-cycle and every vector kernel serve all of them at once.  See mv_internal.h.
 //   U = K^+ F:   F <- P_R F (Moore-Penrose form) | CG on K U = F, preconditioned by the V-cycle (mg_mv.hip) or by Jacobi | U <- P_R U
-// Workgroup (block b, part w) of the vector kernels covers rows lo_b + 32 w + (t / 8), ... of block b and, per row, the 8 columns: thread t works on column t % 8.
+// Workgroup (block b, part w) of the vector kernels covers rows lo_b + 32 w + (t / 8), ... of block b and, per row, the 8 columns: thread t works on column t %
+// 8.
 #include "feti_internal.h"
 #include "mv_internal.h"
 
@@ -16,7 +17,8 @@ struct pmh_matinv_mv_s {
   pmh_mg_mv  mgmv = nullptr;
   pmh_mv_ell K64  = nullptr;
   int        nb = 0, n = 0, ncol = 0, wgs = 0;
-  int        nrep = 1, ldR = 0;               // nrep = 8: the solver's 8 congruent blocks are the 8 columns of its FIRST block (n = rows of one block); ldR: row stride of M->d_R
+  // nrep = 8: the solver's 8 congruent blocks are the 8 columns of its FIRST block (n = rows of one block); ldR: row stride of M->d_R
+  int        nrep = 1, ldR = 0;
   double    *fin = nullptr, *uout = nullptr;  // congruent mode: the interleaved right-hand side / result around pmh_matinv_mv_mult
   std::vector<hipEvent_t> ev;                 // optional timing of the fp64 products (pairs)
   int        ev_on = 0, ev_used = 0;
@@ -59,7 +61,8 @@ static __device__ __forceinline__ double mvc_total(const double *__restrict__ pa
 #define CSQ(cs, q, c, k) (cs)[(((size_t)(q)*ncol + (c)) * 2) + (k)]
 #define CIQ(ci, q, c, k) (ci)[(((size_t)(q)*ncol + (c)) * 2) + (k)]
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start(const int *__restrict__ rs, int wgs, int extpc, const double *__restrict__ f, const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z,
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start(const int *__restrict__ rs, int wgs, int extpc, const double *__restrict__ f,
+                        const double *__restrict__ dinv, double *__restrict__ u, double *__restrict__ r, double *__restrict__ z,
                                                         double *__restrict__ p, double *__restrict__ partB, double *__restrict__ partC)
 {
   __shared__ double lds[32];
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start(const int *__restrict__
   }
 }
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start_pz(const int *__restrict__ rs, int wgs, const double *__restrict__ r, const double *__restrict__ z, double *__restrict__ p, double *__restrict__ partB)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start_pz(const int *__restrict__ rs, int wgs, const double *__restrict__ r, const double *__restrict__ z,
+                        double *__restrict__ p, double *__restrict__ partB)
 {
   __shared__ double lds[32];
   double            s0 = 0.0;
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start_pz(const int *__restric
 }
 
 // one workgroup per block: rz, the threshold max(rtol ||f||, atol) and the active flag of its 8 columns (k_cg_init of feti.hip, column by column)
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_init(int ncol, int wgs, const double *__restrict__ partB, const double *__restrict__ partC, double *__restrict__ cs, int *__restrict__ ci, int *__restrict__ nactive, double rtol, double atol,
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_init(int ncol, int wgs, const double *__restrict__ partB, const double *__restrict__ partC,
+                        double *__restrict__ cs, int *__restrict__ ci, int *__restrict__ nactive, double rtol, double atol,
                                                        const double *__restrict__ fnorm2, double kernel_tol)
 {
   __shared__ double lds[32];
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_init(int ncol, int wgs, const
 }
 __global__ void k_mvc_init_done(const int *nactive, int *done) { *done = (*nactive == 0) ? 1 : 0; }
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_dot(const int *__restrict__ rs, int wgs, const int *__restrict__ done, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_dot(const int *__restrict__ rs, int wgs, const int *__restrict__ done, const double *__restrict__ x,
+                        const double *__restrict__ y, double *__restrict__ part)
 {
   __shared__ double lds[32];
   if (*done) return;
@@ -127,8 +133,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_dot(const int *__restrict__ r
   if (threadIdx.x < MV_R) part[((size_t)b * MV_R + threadIdx.x) * wgs + w_] = s;
 }
 
-// alpha_c = rz_c / (p'Ap)_c for the active columns (0 for the frozen ones: nothing moves there); u += alpha p; r -= alpha Ap; z = D^-1 r (Jacobi); partials r'z, r'r
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_ur(const int *__restrict__ rs, int ncol, int wgs, int q, int extpc, const int *__restrict__ done, const double *__restrict__ cs, const int *__restrict__ ci,
+// alpha_c = rz_c / (p'Ap)_c for the active columns (0 for the frozen ones: nothing moves there); u += alpha p; r -= alpha Ap; z = D^-1 r (Jacobi); partials
+// r'z, r'r
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_ur(const int *__restrict__ rs, int ncol, int wgs, int q, int extpc, const int *__restrict__ done,
+                        const double *__restrict__ cs, const int *__restrict__ ci,
                                                             const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u,
                                                             double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, double *__restrict__ partC)
 {
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_ur(const int *__restri
 }
 
 // beta_c = rz_new / rz; convergence of column c; p = z + beta p; the block's first workgroup publishes the next state
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_p(const int *__restrict__ rs, int ncol, int wgs, int q, int it, int max_it, double *__restrict__ cs, int *__restrict__ ci, int *__restrict__ nactive, int *__restrict__ done,
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_p(const int *__restrict__ rs, int ncol, int wgs, int q, int it, int max_it, double *__restrict__ cs,
+                        int *__restrict__ ci, int *__restrict__ nactive, int *__restrict__ done,
                                                            const double *__restrict__ partB, const double *__restrict__ partC, const double *__restrict__ z, double *__restrict__ p)
 {
   __shared__ double lds[32];
@@ -199,9 +208,10 @@ __global__ void k_mvc_publish(int ncol, const int *__restrict__ ci, const int *n
   h[0] = *nactive;
 }
 
-// ---- P_R = I - R R' column by column (k_seg_rt_dot / k_seg_coef / k_seg_project of feti.hip) ---------------------------------------------------------------------
+// ---- P_R = I - R R' column by column (k_seg_rt_dot / k_seg_coef / k_seg_project of feti.hip) ----------------------------------------------------------------
 #define MVC_MAX_KDIM 8
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_rt_dot(const int *__restrict__ rs, int wgs, int n, int kdim, size_t ld, const double *__restrict__ R, const double *__restrict__ v, double *__restrict__ part)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_rt_dot(const int *__restrict__ rs, int wgs, int n, int kdim, size_t ld, const double *__restrict__ R,
+                        const double *__restrict__ v, double *__restrict__ part)
 {
   __shared__ double lds[32];
   double            acc[MVC_MAX_KDIM], vv = 0.0;
@@ -225,7 +235,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_rt_dot(const int *__restrict_
       if (threadIdx.x < MV_R) part[(size_t)k * ld + o] = s;
     }
 }
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_coef(int wgs, int kdim, size_t ld, const double *__restrict__ part, double *__restrict__ coef, double *__restrict__ vnorm2)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_coef(int wgs, int kdim, size_t ld, const double *__restrict__ part, double *__restrict__ coef,
+                        double *__restrict__ vnorm2)
 {
   __shared__ double lds[32];
   const int         b = blockIdx.x, c = b * MV_R + (int)threadIdx.x % MV_R;
@@ -238,7 +249,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_coef(int wgs, int kdim, size_
     if (threadIdx.x < MV_R) coef[(size_t)c * MVC_MAX_KDIM + k] = v;
   }
 }
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_project(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R, const double *__restrict__ coef, const double *__restrict__ v, double *__restrict__ out)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_project(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R,
+                        const double *__restrict__ coef, const double *__restrict__ v, double *__restrict__ out)
 {
   MV_ROW_LOOP(i, b, rs, wgs)
   {
@@ -281,7 +293,8 @@ int pmh_matinv_mv_destroy(pmh_matinv_mv V)
   pmh_ctx ctx = V->ctx;
   pmh_mg_mv_destroy(V->mgmv);
   pmh_mv_ell_destroy(V->K64);
-  for (double *p : {V->r, V->z, V->p, V->Ap, V->fproj, V->partA, V->partB, V->partC, V->cs, V->d_coef, V->d_kpart, V->d_fnorm2, V->fin, V->uout}) pmh_free(ctx, p);
+  for (double *p : {V->r, V->z, V->p, V->Ap, V->fproj, V->partA, V->partB, V->partC, V->cs, V->d_coef, V->d_kpart, V->d_fnorm2, V->fin, V->uout}) pmh_free(ctx,
+                          p);
   for (hipEvent_t e : V->ev) (void)hipEventDestroy(e);
   pmh_free(ctx, V->ci), pmh_free(ctx, V->d_nactive), pmh_free(ctx, V->d_done);
   if (V->h_state) (void)hipHostFree(V->h_state);
@@ -337,7 +350,8 @@ static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out)
   if (!rc) rc = pmh_malloc(ctx, sizeof(double) * (size_t)V->ncol * MVC_MAX_KDIM, (void **)&V->d_coef);
   if (!rc) rc = pmh_malloc(ctx, sizeof(double) * (MVC_MAX_KDIM + 1) * np, (void **)&V->d_kpart);
   if (!rc) rc = pmh_malloc(ctx, sizeof(double) * V->ncol, (void **)&V->d_fnorm2);
-  if (!rc && hipHostMalloc((void **)&V->h_state, sizeof(int) * 2, hipHostMallocDefault) != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP, "pmh_matinv_mv_create: pinned allocation failed");
+  if (!rc && hipHostMalloc((void **)&V->h_state, sizeof(int) * 2, hipHostMallocDefault) != hipSuccess) rc = pmh_set_error(PMH_ERR_HIP,
+                          "pmh_matinv_mv_create: pinned allocation failed");
   if (rc) {
     pmh_matinv_mv_destroy(V);
     return rc;
@@ -355,9 +369,11 @@ static int mvc_project(pmh_matinv_mv V, const double *v, double *out, double *vn
   const int    grid = V->nb * V->wgs;
   const size_t ld   = (size_t)V->ncol * V->wgs;
   hipStream_t  st   = V->ctx->stream;
-  hipLaunchKernelGGL(k_mvc_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, ld, (const double *)M->d_R, v, V->d_kpart);
+  hipLaunchKernelGGL(k_mvc_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, ld, (const double *)M->d_R, v,
+                     V->d_kpart);
   hipLaunchKernelGGL(k_mvc_coef, dim3(V->nb), dim3(PMH_BLOCK), 0, st, V->wgs, M->kdim, ld, (const double *)V->d_kpart, V->d_coef, vnorm2);
-  hipLaunchKernelGGL(k_mvc_project, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, (const double *)M->d_R, (const double *)V->d_coef, v, out);
+  hipLaunchKernelGGL(k_mvc_project, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, (const double *)M->d_R,
+                     (const double *)V->d_coef, v, out);
   PMH_HIP(hipGetLastError());
   return PMH_SUCCESS;
 }
@@ -383,7 +399,8 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
     PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, V->z, V->d_done));
     hipLaunchKernelGGL(k_mvc_start_pz, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const double *)V->r, (const double *)V->z, V->p, V->partB);
   }
-  hipLaunchKernelGGL(k_mvc_init, dim3(nb), dim3(PMH_BLOCK), 0, st, ncol, wgs, (const double *)V->partB, (const double *)V->partC, V->cs, V->ci, V->d_nactive, M->rtol, M->atol, (const double *)(M->kdim ? V->d_fnorm2 : nullptr), M->kernel_tol);
+  hipLaunchKernelGGL(k_mvc_init, dim3(nb), dim3(PMH_BLOCK), 0, st, ncol, wgs, (const double *)V->partB, (const double *)V->partC, V->cs, V->ci, V->d_nactive,
+                     M->rtol, M->atol, (const double *)(M->kdim ? V->d_fnorm2 : nullptr), M->kernel_tol);
   hipLaunchKernelGGL(k_mvc_init_done, dim3(1), dim3(1), 0, st, (const int *)V->d_nactive, V->d_done);
   PMH_HIP(hipGetLastError());
   int it = 0, next_check = (V->last_max_its > 0) ? V->last_max_its : (extpc ? 1 : 4);
@@ -400,13 +417,15 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
     }
     V->products++;
     hipLaunchKernelGGL(k_mvc_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->p, (const double *)V->Ap, V->partA);
-    hipLaunchKernelGGL(k_mvc_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, extpc, (const int *)V->d_done, (const double *)V->cs, (const int *)V->ci, (const double *)V->partA, (const double *)M->dinv, (const double *)V->p,
+    hipLaunchKernelGGL(k_mvc_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, extpc, (const int *)V->d_done, (const double *)V->cs,
+                       (const int *)V->ci, (const double *)V->partA, (const double *)M->dinv, (const double *)V->p,
                        (const double *)V->Ap, u, V->r, V->z, V->partB, V->partC);
     if (extpc) {
       PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, V->z, V->d_done));
       hipLaunchKernelGGL(k_mvc_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->r, (const double *)V->z, V->partB);
     }
-    hipLaunchKernelGGL(k_mvc_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, it, M->max_it, V->cs, V->ci, V->d_nactive, V->d_done, (const double *)V->partB, (const double *)V->partC, (const double *)V->z, V->p);
+    hipLaunchKernelGGL(k_mvc_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, it, M->max_it, V->cs, V->ci, V->d_nactive, V->d_done,
+                       (const double *)V->partB, (const double *)V->partC, (const double *)V->z, V->p);
     PMH_HIP(hipGetLastError());
     it++;
     if (it >= next_check || it >= M->max_it) {
@@ -438,7 +457,8 @@ int pmh_matinv_mv_mult_blocks(pmh_matinv_mv V, const double *f, double *u)
 
 long long pmh_matinv_mv_products(pmh_matinv_mv V) { return V ? V->products : 0; }
 
-// event pairs around the fp64 products: enable > 0: (re)start with room for that many launches; enable == 0: read (launches, total ms, bytes one launch moves: the ELL copy once + x + y)
+// event pairs around the fp64 products: enable > 0: (re)start with room for that many launches; enable == 0: read (launches, total ms, bytes one launch moves:
+// the ELL copy once + x + y)
 int pmh_matinv_mv_timing(pmh_matinv_mv V, int enable, int *launches, double *total_ms, double *bytes_per_launch)
 {
   PMH_ARG(V);
@@ -473,13 +493,14 @@ int pmh_matinv_mv_to_columns(pmh_matinv_mv V, const double *u, double *cols)
   return PMH_SUCCESS;
 }
 
-// ---- test / direct use: U = K^+ F for 8 columns per block, host-side convenience around the calls above (F, U: device, n x 8 interleaved) ------------------------
+// ---- test / direct use: U = K^+ F for 8 columns per block, host-side convenience around the calls above (F, U: device, n x 8 interleaved) -------------------
 extern "C" int pmh_matinv_mult_multi(pmh_matinv M, const double *F, double *U, int *max_iterations)
 {
   PMH_ARG(M && F && U);
   pmh_matinv_mv V  = nullptr;
   int           rc = pmh_matinv_mv_create(M, &V);
-  if (rc == PMH_EPI_UNSUPPORTED) return pmh_set_error(PMH_ERR_SUP, "pmh_matinv_mult_multi: the multi-right-hand-side solver does not apply to this K^+: %s", pmh_mv_why());
+  if (rc == PMH_EPI_UNSUPPORTED) return pmh_set_error(PMH_ERR_SUP, "pmh_matinv_mult_multi: the multi-right-hand-side solver does not apply to this K^+: %s",
+                          pmh_mv_why());
   if (rc) return rc;
   rc = pmh_matinv_mv_mult(V, F, U);
   if (!rc) rc = pmh_sync(M->ctx);

@@ -1,11 +1,11 @@
 // Multi-right-hand-side K^+, part 2: the V-cycle of mg.hip on interleaved multivectors of R = PMH_MV_R columns (see mv_internal.h).
 //
-// The hierarchy is the one pmh_mg holds (level operators as CSR, node-wise transfer operators, Jacobi scaling, Chebyshev constants, dense coarse pseudo-inverses):
-// nothing is set up twice but the ELL copies of the level operators (built on the device, mv.hip) and the work multivectors.  The cycle is the fused form of
-// mg.hip (mg_level_fused): degree-2 Chebyshev/Jacobi smoothing finished inside the operator kernel, fp32 vectors, level operators in the precision pmh_mg keeps
-// them in (fp16 on the finest levels by default).  Per smoothed level: d0 | PRE | SUB | restrict (+ the coarse d0) | ... | prolong-subtract | POST1 | POST2.
-// A hierarchy of another shape (fp64 cycle, other degree, P not node-wise, a level without 3 x 3 blocks) is refused (PMH_EPI_UNSUPPORTED, no error recorded): the
-// caller keeps the one-column solver.
+// The hierarchy is the one pmh_mg holds (level operators as CSR, node-wise transfer operators, Jacobi scaling, Chebyshev constants, dense coarse
+// pseudo-inverses): nothing is set up twice but the ELL copies of the level operators (built on the device, mv.hip) and the work multivectors.  The cycle is
+// the fused form of mg.hip (mg_level_fused): degree-2 Chebyshev/Jacobi smoothing finished inside the operator kernel, fp32 vectors, level operators in the
+// precision pmh_mg keeps them in (fp16 on the finest levels by default).  Per smoothed level: d0 | PRE | SUB | restrict (+ the coarse d0) | ... |
+// prolong-subtract | POST1 | POST2. A hierarchy of another shape (fp64 cycle, other degree, P not node-wise, a level without 3 x 3 blocks) is refused
+// (PMH_EPI_UNSUPPORTED, no error recorded): the caller keeps the one-column solver.
 #include "mg_internal.h"
 #include "mv_internal.h"
 
@@ -19,12 +19,14 @@ struct mg_mv_level {
 struct pmh_mg_mv_s {
   pmh_mg                   mg;
   pmh_ctx                  ctx; // (kept: the caller may destroy the pmh_mg before this object)
-  int                      nrep = 1; // > 1: every level is block diagonal with nrep congruent blocks and this object works on the FIRST one (a prefix of every array of pmh_mg)
+  // > 1: every level is block diagonal with nrep congruent blocks and this object works on the FIRST one (a prefix of every array of pmh_mg)
+  int                      nrep = 1;
   std::vector<mg_mv_level> L;
 };
 
 // max |pinv_b - pinv_0| over the coarse blocks b > 0 (fp16 or fp32 entries, equal sizes): the coarse inverses of congruent blocks must be equal too
-template <typename TP> __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_pinv_diff(int nb, long long m2, const TP *__restrict__ pinv, int *__restrict__ differs)
+template <typename TP> __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_pinv_diff(int nb, long long m2, const TP *__restrict__ pinv,
+                        int *__restrict__ differs)
 {
   for (long long i = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; i < m2; i += (long long)gridDim.x * PMH_BLOCK)
     for (int b = 1; b < nb; b++)
@@ -33,7 +35,8 @@ template <typename TP> __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_pinv_d
 
 // d0 = D^-1 b / theta (and the fp32 copy of an fp64 b): one thread per 4 consecutive entries of a row's R columns
 template <typename TB>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_d0(long long nR, const int *__restrict__ halt, const float *__restrict__ dinv, const TB *__restrict__ b, float itheta, float *__restrict__ d, float *__restrict__ bcopy)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_d0(long long nR, const int *__restrict__ halt, const float *__restrict__ dinv, const TB *__restrict__ b,
+                        float itheta, float *__restrict__ d, float *__restrict__ bcopy)
 {
   if (halt && *halt) return;
   for (long long i = 4 * ((long long)blockIdx.x * PMH_BLOCK + threadIdx.x); i < nR; i += 4LL * gridDim.x * PMH_BLOCK) {
@@ -46,9 +49,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_d0(long long nR, const int *_
   }
 }
 
-// b_c = P' t, node-wise P' (<= 27 entries per coarse node), every entry serving the 3 R values of its fine node: lane (coarse node, column r); optionally the coarse
-// level's first smoothing direction d_c = D_c^-1 b_c / theta_c
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict(int ncn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val, const float *__restrict__ t,
+// b_c = P' t, node-wise P' (<= 27 entries per coarse node), every entry serving the 3 R values of its fine node: lane (coarse node, column r); optionally the
+// coarse level's first smoothing direction d_c = D_c^-1 b_c / theta_c
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict(int ncn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col,
+                        const float *__restrict__ val, const float *__restrict__ t,
                                                            float *__restrict__ bc, const float *__restrict__ dinv_c, float itheta_c, float *__restrict__ d_c)
 {
   if (halt && *halt) return;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict(int ncn, const int *
 }
 
 // x -= P x_c, node-wise P (<= 8 entries per fine node): lane (fine node, column r)
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub(int nn, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val, const float *__restrict__ xc, float *__restrict__ x)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub(int nn, const int *__restrict__ halt, const int *__restrict__ rowptr,
+                        const int *__restrict__ col, const float *__restrict__ val, const float *__restrict__ xc, float *__restrict__ x)
 {
   if (halt && *halt) return;
   const int r = threadIdx.x % MV_R;
@@ -88,7 +93,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub(int nn, const int
 
 // coarsest level: X_b = pinv_b B_b for the R columns: one wavefront per row of the dense block, lanes stride the row, R sums per lane
 template <typename TP>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs, const TP *__restrict__ pinv, float scale, const float *__restrict__ b,
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const int *__restrict__ halt, const int *__restrict__ rs,
+                        const long long *__restrict__ ofs, const TP *__restrict__ pinv, float scale, const float *__restrict__ b,
                                                          float *__restrict__ x)
 {
   if (halt && *halt) return;
@@ -161,8 +167,10 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
     PMH_CHK(pmh_malloc(mg->ctx, sizeof(int), (void **)&d_diff));
     PMH_HIP(hipMemsetAsync(d_diff, 0, sizeof(int), mg->ctx->stream));
     const long long m2 = (long long)(nc / nrep) * (nc / nrep);
-    if (mg->cp_half) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<_Float16>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2, (const _Float16 *)mg->d_cpinv, d_diff);
-    else if (mg->is_float) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<float>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2, (const float *)mg->d_cpinv, d_diff);
+    if (mg->cp_half) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<_Float16>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2,
+                            (const _Float16 *)mg->d_cpinv, d_diff);
+    else if (mg->is_float) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_pinv_diff<float>), dim3(256), dim3(PMH_BLOCK), 0, mg->ctx->stream, nrep, m2,
+                            (const float *)mg->d_cpinv, d_diff);
     PMH_CHK(pmh_memcpy_d2h(mg->ctx, &h_diff, d_diff, sizeof(int)));
     pmh_free(mg->ctx, d_diff);
     if (h_diff) {
@@ -220,10 +228,12 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   if (l == mg->nlevels - 1) {
     const int nbc = mg->nb_coarse / nrep;
     if (mg->cp_half)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs,
+                         (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
                          (const float *)Ml.b, Ml.x);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<float>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const float *)mg->d_cpinv, 1.f, (const float *)Ml.b, Ml.x);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<float>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs,
+                         (const long long *)mg->d_cofs, (const float *)mg->d_cpinv, 1.f, (const float *)Ml.b, Ml.x);
     PMH_HIP(hipGetLastError());
     return PMH_SUCCESS;
   }
@@ -234,7 +244,8 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   const float     itheta = (float)(1.0 / Lv.theta), c1 = (float)Lv.c1[1], c2 = (float)Lv.c2[1];
   if (!d0_ready) {
     if (b64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_d0<double>), mvg_grid(nR / 4), blk, 0, st, nR, halt, dinv, b64, itheta, Ml.d, Ml.b);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_d0<float>), mvg_grid(nR / 4), blk, 0, st, nR, halt, dinv, (const float *)Ml.b, itheta, Ml.d, (float *)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_d0<float>), mvg_grid(nR / 4), blk, 0, st, nR, halt, dinv, (const float *)Ml.b, itheta, Ml.d,
+                            (float *)nullptr);
   }
   pmh_mv_epi<float> e;
   memset(&e, 0, sizeof(e));
@@ -244,10 +255,12 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.t, PMH_EPI_SUB, &e, halt));
   const bool cf  = l + 2 < mg->nlevels; // the coarse level is a smoothed one: its d0 rides on the restriction
   const int  ncn = Lc.n / 3 / nrep;
-  hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col, (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
+  hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
+                     (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
                      cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   PMH_CHK(mvg_cycle(M, l + 1, nullptr, nullptr, cf, halt));
-  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
+  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col,
+                     (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.x, PMH_BSR_EPI_POST1, &e, halt));

@@ -1,10 +1,11 @@
 // Multi-right-hand-side K^+, part 1: the operator.  ELL copy of a matrix of 3 x 3 blocks (built on the device from the resident CSR) and y = A x on interleaved
 // multivectors of R = PMH_MV_R columns with the smoothing epilogues of k_bsr3 (bsr.hip).  See mv_internal.h for what this path is for.
 //
-// FOUR lanes per block row (a first form with one thread per block row left the chip at 1.2 waves per SIMD: 92 us per fp64 product of a 43^3 block where its bytes
-// need 35): lane l of the quad takes the slots s = 4 g + l, per slot ONE block column index, the 9 entries of the block (the slot planes are interleaved by 4, so a
-// wave reads 512 contiguous bytes per entry plane) and the 3 R operand values of that block column -- ONE contiguous piece (192 bytes in fp64, 96 in fp32) loaded as
-// 16-byte vectors.  3 R accumulators per lane, summed across the quad by two butterfly steps (a fixed order); lanes 0 .. 2 of the quad then finish one row each.
+// FOUR lanes per block row (a first form with one thread per block row left the chip at 1.2 waves per SIMD: 92 us per fp64 product of a 43^3 block where its
+// bytes need 35): lane l of the quad takes the slots s = 4 g + l, per slot ONE block column index, the 9 entries of the block (the slot planes are interleaved
+// by 4, so a wave reads 512 contiguous bytes per entry plane) and the 3 R operand values of that block column -- ONE contiguous piece (192 bytes in fp64, 96 in
+// fp32) loaded as 16-byte vectors.  3 R accumulators per lane, summed across the quad by two butterfly steps (a fixed order); lanes 0 .. 2 of the quad then
+// finish one row each.
 #include "mv_internal.h"
 
 static thread_local const char *g_mv_why = "";
@@ -15,10 +16,10 @@ typedef _Float16 mv_half4 __attribute__((ext_vector_type(4)));
 typedef double   mv_dbl2 __attribute__((ext_vector_type(2)));
 typedef float    mv_flt4 __attribute__((ext_vector_type(4)));
 
-// ---- ELL builder ------------------------------------------------------------------------------------------------------------------------------------------------
-// The blocks of block row br = the sorted union of the block columns (column / 3) its three rows list; an entry a row does not store is a zero of the block.  A three-way
-// merge over the (sorted) rows: walk(br, ...) calls f(slot, block column, the 9 entries) slot after slot and returns the slot count, or -1 for a row whose columns
-// are not ascending.
+// ---- ELL builder --------------------------------------------------------------------------------------------------------------------------------------------
+// The blocks of block row br = the sorted union of the block columns (column / 3) its three rows list; an entry a row does not store is a zero of the block.  A
+// three-way merge over the (sorted) rows: walk(br, ...) calls f(slot, block column, the 9 entries) slot after slot and returns the slot count, or -1 for a row
+// whose columns are not ascending.
 template <typename F>
 static __device__ __forceinline__ int mv_walk(int br, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, F f)
 {
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_absmax(long long nnz, const do
 }
 
 template <typename TM>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
+                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval)
 {
   const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (br >= nbr) return;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const
   for (int s = n; s < W; s++) put(s, br, z); // padding: the row's own block column, zero entries
 }
 // fp16: one vector of 4 halves per block row q (the 4th is zero)
-__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
+                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval)
 {
   const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (br >= nbr) return;
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, con
 
 int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out) { return pmh_mv_ell_create_prefix(A, 1, storage, out); }
 
-// nrep > 1: A is block diagonal with nrep congruent blocks (the caller has verified it): the ELL copy of its FIRST block (rows / columns [0, n / nrep), nnz / nrep entries)
+// nrep > 1: A is block diagonal with nrep congruent blocks (the caller has verified it): the ELL copy of its FIRST block (rows / columns [0, n / nrep), nnz /
+// nrep entries)
 int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
 {
   PMH_ARG(A && out && nrep >= 1 && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
@@ -120,7 +124,8 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
   int        *d_info;
   PMH_CHK(pmh_malloc(ctx, sizeof(unsigned long long) * 2, (void **)&d_info));
   PMH_HIP(hipMemsetAsync(d_info, 0, sizeof(unsigned long long) * 2, st));
-  hipLaunchKernelGGL(k_mv_ell_count, dim3((nbr + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, nbr, (const int *)A->d_rowptr, (const int *)A->d_col, d_info);
+  hipLaunchKernelGGL(k_mv_ell_count, dim3((nbr + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, st, nbr, (const int *)A->d_rowptr, (const int *)A->d_col,
+                     d_info);
   int info[2];
   PMH_CHK(pmh_memcpy_d2h(ctx, info, d_info, sizeof(info)));
   if (info[1] || info[0] < 1 || info[0] > 32) {
@@ -144,14 +149,18 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
   const size_t nslot = (size_t)E->W * nbr;
   const dim3   g((nbr + PMH_BLOCK - 1) / PMH_BLOCK), blk(PMH_BLOCK);
   int          rc = pmh_malloc(ctx, sizeof(int) * nslot, (void **)&E->col);
-  if (!rc) rc = pmh_malloc(ctx, (storage == PMH_BSR_F64 ? sizeof(double) * 9 : (storage == PMH_BSR_F32 ? sizeof(float) * 9 : sizeof(mv_half4) * 3)) * nslot, &E->val);
+  if (!rc) rc = pmh_malloc(ctx, (storage == PMH_BSR_F64 ? sizeof(double) * 9 : (storage == PMH_BSR_F32 ? sizeof(float) * 9 : sizeof(mv_half4) * 3)) * nslot,
+                          &E->val);
   if (rc) {
     pmh_mv_ell_destroy(E);
     return rc;
   }
-  if (storage == PMH_BSR_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<double>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (double *)E->val);
-  else if (storage == PMH_BSR_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<float>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (float *)E->val);
-  else hipLaunchKernelGGL(k_mv_ell_fill_h, g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (mv_half4 *)E->val);
+  if (storage == PMH_BSR_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<double>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
+                          (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (double *)E->val);
+  else if (storage == PMH_BSR_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<float>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
+                          (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (float *)E->val);
+  else hipLaunchKernelGGL(k_mv_ell_fill_h, g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale,
+                          E->col, (mv_half4 *)E->val);
   PMH_HIP(hipGetLastError());
   *out = E;
   return PMH_SUCCESS;
@@ -166,7 +175,7 @@ int pmh_mv_ell_destroy(pmh_mv_ell E)
   return PMH_SUCCESS;
 }
 
-// ---- the product ------------------------------------------------------------------------------------------------------------------------------------------------
+// ---- the product --------------------------------------------------------------------------------------------------------------------------------------------
 template <typename T, int N> struct mv_vec;
 template <int N> struct mv_vec<double, N> { // N doubles = N / 2 loads of 16 bytes
   static __device__ __forceinline__ void load(const double *p, double (&v)[N])
@@ -218,7 +227,8 @@ template <typename T> struct mv_blk<_Float16, T> {
 };
 
 template <typename TM, typename T, int R, int EPI>
-__global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale, const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale,
+                        const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt)
 {
   const int hlt = halt ? *halt : 0;
   const int tg  = blockIdx.x * PMH_BLOCK + threadIdx.x, br = tg >> 2, l = tg & 3;
@@ -341,7 +351,7 @@ int pmh_mv_spmv_f32(pmh_mv_ell E, const float *x, float *y, int epi, const pmh_m
   return pmh_set_error(PMH_ERR_ARG, "pmh_mv_spmv_f32: the fp32 product needs fp32 or fp16 entries");
 }
 
-// ---- test / measurement entry (tests/test_gpu_mv.py, scripts): the product alone on a pmh_csr ---------------------------------------------------------------------
+// ---- test / measurement entry (tests/test_gpu_mv.py, scripts): the product alone on a pmh_csr ---------------------------------------------------------------
 extern "C" int pmh_mv_test_spmv(pmh_csr A, int storage, const double *x /* 3 nbr R, device */, double *y, int repeats, float *ms_per_launch)
 {
   PMH_ARG(A && x && y && repeats >= 1);

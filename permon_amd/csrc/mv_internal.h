@@ -1,21 +1,21 @@
 // Multi-right-hand-side K^+ (mv.hip, mg_mv.hip, matinv_mv.hip; internal): R = PMH_MV_R columns per block solved TOGETHER on interleaved multivectors.
 //
-// The set-up of the explicit local dual operators needs (K^+)[Gamma_b, Gamma_b] column by column -- what the reference gets from its factorisation with a block of
-// right-hand sides (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:640-730: MatMatSolve on column blocks).  The one-column-per-block solver streams K_b once per
-// column; here a multivector V[(dof i) * R + r] keeps the R columns of a dof side by side, so that
+// The set-up of the explicit local dual operators needs (K^+)[Gamma_b, Gamma_b] column by column -- what the reference gets from its factorisation with a block
+// of right-hand sides (MatInvExplicitly_Inv, src/mat/impls/inv/matinv.c:640-730: MatMatSolve on column blocks).  The one-column-per-block solver streams K_b
+// once per column; here a multivector V[(dof i) * R + r] keeps the R columns of a dof side by side, so that
 //   * a 3 x 3 block of K_b is loaded ONCE and applied to R columns (8 x fewer matrix bytes per column; fp64: 154 MB per product of a 43^3 block),
 //   * the gathered operand of a block column is ONE contiguous piece of 3 R values (192 bytes in fp64) instead of R separate 24-byte gathers,
 //   * every launch of the V-cycle and of the CG serves R columns (the coarse levels are launch-latency bound).
-// Blocks are concatenated as in MATBLOCKDIAG (global dof index), every block with its own matrix: no congruence, no symmetry, no box structure is assumed by the
-// kernels (the hierarchy is whatever pmh_mg holds: its P must be node-wise, P = P_node (x) I_3).
+// Blocks are concatenated as in MATBLOCKDIAG (global dof index), every block with its own matrix: no congruence, no symmetry, no box structure is assumed by
+// the kernels (the hierarchy is whatever pmh_mg holds: its P must be node-wise, P = P_node (x) I_3).
 #pragma once
 #include "pmh_internal.h"
 
 #define PMH_MV_R 8
 
-// ELL copy of a matrix of 3 x 3 blocks, W slots per block row (a multiple of 4; padding: the row's own block column with zero values), slot planes interleaved by 4
-// for the four lanes of a block row: col[((s / 4) * nbr + br) * 4 + s % 4]; val fp64 / fp32 at [(((s / 4) * 9 + e) * nbr + br) * 4 + s % 4] (e = 3 q + c), fp16 at
-// [(((s / 4) * 3 + q) * nbr + br) * 4 + s % 4] as vectors of 4 halves (row q of the block, entries / scale, the 4th zero)
+// ELL copy of a matrix of 3 x 3 blocks, W slots per block row (a multiple of 4; padding: the row's own block column with zero values), slot planes interleaved
+// by 4 for the four lanes of a block row: col[((s / 4) * nbr + br) * 4 + s % 4]; val fp64 / fp32 at [(((s / 4) * 9 + e) * nbr + br) * 4 + s % 4] (e = 3 q + c),
+// fp16 at [(((s / 4) * 3 + q) * nbr + br) * 4 + s % 4] as vectors of 4 halves (row q of the block, entries / scale, the 4th zero)
 struct pmh_mv_ell_s {
   pmh_ctx ctx;
   int     nbr, W, storage; // PMH_BSR_F64 / F32 / F16
@@ -36,14 +36,17 @@ template <typename T> struct pmh_mv_epi {
 int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out);
 int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out); // the first of nrep congruent diagonal blocks of A
 int pmh_mv_ell_destroy(pmh_mv_ell E);
-// y = A x on multivectors of R = PMH_MV_R columns (x, y: 3 nbr R entries) with the epilogues of k_bsr3 (PMH_EPI_NONE / ADD / SUB, PMH_BSR_EPI_PRE / POST1 / POST2)
+// y = A x on multivectors of R = PMH_MV_R columns (x, y: 3 nbr R entries) with the epilogues of k_bsr3 (PMH_EPI_NONE / ADD / SUB, PMH_BSR_EPI_PRE / POST1 /
+// POST2)
 int pmh_mv_spmv_f64(pmh_mv_ell E, const double *x, double *y, int epi, const pmh_mv_epi<double> *e, const int *halt);
 int pmh_mv_spmv_f32(pmh_mv_ell E, const float *x, float *y, int epi, const pmh_mv_epi<float> *e, const int *halt);
 
-// the V-cycle of pmh_mg on multivectors (mg_mv.hip).  create: PMH_EPI_UNSUPPORTED (no error recorded) for a hierarchy of another shape than the fused fp32 cycle
+// the V-cycle of pmh_mg on multivectors (mg_mv.hip).  create: PMH_EPI_UNSUPPORTED (no error recorded) for a hierarchy of another shape than the fused fp32
+// cycle
 struct pmh_mg_mv_s;
 typedef pmh_mg_mv_s *pmh_mg_mv;
-int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep = 1); // nrep > 1: the hierarchy of the FIRST of nrep congruent blocks (every level is block diagonal with nrep equal blocks)
+// nrep > 1: the hierarchy of the FIRST of nrep congruent blocks (every level is block diagonal with nrep equal blocks)
+int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep = 1);
 int pmh_mg_mv_destroy(pmh_mg_mv M);
 int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt);
 
@@ -51,8 +54,9 @@ int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt);
 struct pmh_matinv_mv_s;
 typedef pmh_matinv_mv_s *pmh_matinv_mv;
 int pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out); // PMH_EPI_UNSUPPORTED (no error recorded) where it does not apply
-// The solver's 8 CONGRUENT blocks as the 8 columns of ONE block: u = K^+ f of pmh_matinv_mult itself through the multi-right-hand-side kernels (f, u in the solver's own
-// block-after-block layout).  PMH_EPI_UNSUPPORTED unless the solver has exactly PMH_MV_R blocks whose congruence pmh_bsr3_from_csr has verified on every level.
+// The solver's 8 CONGRUENT blocks as the 8 columns of ONE block: u = K^+ f of pmh_matinv_mult itself through the multi-right-hand-side kernels (f, u in the
+// solver's own block-after-block layout).  PMH_EPI_UNSUPPORTED unless the solver has exactly PMH_MV_R blocks whose congruence pmh_bsr3_from_csr has verified on
+// every level.
 int pmh_matinv_mv_create_congruent(pmh_matinv M, pmh_matinv_mv *out);
 int pmh_matinv_mv_mult_blocks(pmh_matinv_mv V, const double *f, double *u);
 long long pmh_matinv_mv_products(pmh_matinv_mv V);

@@ -2,7 +2,7 @@
   * a line that is only a `//` comment is split at spaces into several `//` lines of the same indent;
   * a code line with a trailing `//` comment that makes it too long gets the comment moved to `//` lines of its own ABOVE it.
 Lines of macros (ending in a backslash, or following one), preprocessor lines and lines whose `//` sits inside a string literal are left alone.
-usage: python scripts/wrap_comments.py [--width 160] file..."""
+usage: python scripts/wrap_comments.py [--width 160] [--code] file...     (--code: over-long code lines are broken at commas inside parentheses as well)"""
 import re
 import sys
 
@@ -111,10 +111,73 @@ def process(path):
     print("%s: %d comments re-flowed, %d lines still > %d (code)" % (path, changed, left, WIDTH))
 
 
+def wrap_code_line(line):
+    """break an over-long CODE line at a `, ` that lies inside parentheses and outside string / char literals; the rest goes to continuation lines aligned one past the
+    innermost open parenthesis that is still open at the break (capped).  Lines of macros and preprocessor lines are left alone by the caller."""
+    out = []
+    while len(line) > WIDTH:
+        depth, q, opens, best, i, n = 0, None, [], -1, 0, len(line)
+        best_open = None
+        while i < min(n, WIDTH):
+            c = line[i]
+            if q:
+                if c == "\\":
+                    i += 2
+                    continue
+                if c == q:
+                    q = None
+            elif c in "\"'":
+                q = c
+            elif c == "/" and i + 1 < n and line[i + 1] == "/":
+                break
+            elif c in "([{":
+                depth += 1
+                opens.append(i)
+            elif c in ")]}":
+                depth -= 1
+                if opens:
+                    opens.pop()
+            elif c == "," and depth >= 1 and i + 1 < n and line[i + 1] == " " and i < WIDTH - 1:
+                best, best_open = i, (opens[-1] if opens else None)
+            i += 1
+        if best < 0:
+            break
+        indent = len(line) - len(line.lstrip())
+        col = min((best_open + 1) if best_open is not None else indent + 4, indent + 24)
+        col = max(col, indent + 2)
+        out.append(line[:best + 1])
+        line = " " * col + line[best + 2:]
+    out.append(line)
+    return out
+
+
+def process_code(path):
+    src = open(path).read().split("\n")
+    out, changed, in_macro = [], 0, False
+    for line in src:
+        cont = line.rstrip().endswith("\\")
+        if len(line) <= WIDTH or in_macro or cont or line.lstrip().startswith("#") or line.lstrip().startswith("//") or "\t" in line:
+            out.append(line)
+            in_macro = cont
+            continue
+        in_macro = cont
+        pieces = wrap_code_line(line)
+        changed += len(pieces) > 1
+        out.extend(pieces)
+    if changed:
+        open(path, "w").write("\n".join(out))
+    print("%s: %d code lines wrapped, %d still > %d" % (path, changed, sum(1 for l in out if len(l) > WIDTH), WIDTH))
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     if args and args[0] == "--width":
         WIDTH = int(args[1])
         args = args[2:]
+    code = bool(args) and args[0] == "--code"
+    if code:
+        args = args[1:]
     for p in args:
         process(p)
+        if code:
+            process_code(p)
