@@ -172,3 +172,35 @@ def test_multi_rhs_kplus_on_blocks_of_different_sizes(ctx):
         ref = u1.to_numpy()
         assert np.linalg.norm(U[:, r] - ref) <= 1e-8 * np.linalg.norm(ref), r
     assert its < 40
+
+
+def test_multi_rhs_refusals_are_loud(ctx):
+    """Where the 8-column solver does not apply the library says so (PMH_ERR_SUP with the reason) instead of computing something else: the left generalised inverse, a
+    fp64 V-cycle; and a slot count that is neither one nor eight per block is an argument error of the assembly."""
+    from permon_amd.feti import CubeFeti
+    from permon_amd._lib import PermonHipError
+
+    f = CubeFeti((2, 1, 1), 4, "elasticity", contact=True)
+    nn, N = f.nel + 1, f.N
+    K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, f.K)
+    Fd, Ud = ctx.vec(N * 8), ctx.vec(N * 8)
+    M = pa.MatInv(K, rtol=1e-10, nullspace=f.R)
+    M.set_pc_mg_box(f.K, [(nn, nn, nn)] * f.nsub, 3, R=f.R, min_nodes=27, degree=2, precision="fp64")
+    with pytest.raises(PermonHipError) as ei:
+        M.mult_multi(Fd, Ud)
+    assert ei.value.code == 4 and "fp64" in str(ei.value)
+    M2 = pa.MatInv(K, rtol=1e-10, nullspace=f.R)
+    check(ctx.L.pmh_matinv_set_left_inverse(M2.h, 1, np.zeros(1, dtype=np.int32).ctypes.data_as(C.c_void_p)))
+    with pytest.raises(PermonHipError) as ei:
+        M2.mult_multi(Fd, Ud)
+    assert ei.value.code == 4 and "left" in str(ei.value)
+    # the assembly: 3 slots for a solver of 2 blocks
+    G, e = f.coarse()
+    from permon_amd.chain import FetiDualQP
+
+    q = FetiDualQP(ctx, f.subset(range(2)), G, e, f.c, f.lb, kplus_rtol=1e-10)
+    E = q._create_explicit(f.subset(range(2)), "sym", None, np.arange(2, dtype=np.int32), 2)
+    sc = np.zeros(3, dtype=np.int32)
+    rc = ctx.L.pmh_fexplicit_assemble(E.h, q.Kplus.h, 3, sc.ctypes.data_as(C.c_void_p), np.arange(2, dtype=np.int32).ctypes.data_as(C.c_void_p), 1e-10, 0)
+    assert rc == 2  # PMH_ERR_ARG
+    E.destroy()
