@@ -311,17 +311,30 @@ extern "C" int pmh_blockdiag_mult_transpose_add(pmh_blockdiag K, const double *x
   const int lo_ = (rs)[b], hi_ = (rs)[b + 1]; \
   for (int i = lo_ + w_ * PMH_BLOCK + (int)threadIdx.x; i < hi_; i += (wgs)*PMH_BLOCK)
 
+// position of the LAST entry (row i, column i) of a CSR row, -1 if there is none: 8 lanes walk the row together (one thread per row read 81 entries one after the
+// other: 2 ms for the 2 M rows of configs[2])
+static __device__ __forceinline__ int pmh_diag_pos8(const int *__restrict__ rowptr, const int *__restrict__ col, int i, int lane8)
+{
+  int best = -1;
+  for (int k = rowptr[i] + lane8; k < rowptr[i + 1]; k += 8)
+    if (col[k] == i) best = k;
+  best = max(best, __shfl_xor(best, 4, 8));
+  best = max(best, __shfl_xor(best, 2, 8));
+  best = max(best, __shfl_xor(best, 1, 8));
+  return best;
+}
 __global__ __launch_bounds__(PMH_BLOCK) void k_extract_dinv(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int jacobi, double *__restrict__ dinv)
 {
-  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    double d = 1.0;
+  const int lane8 = threadIdx.x & 7;
+  for (int i0 = (blockIdx.x * PMH_BLOCK + threadIdx.x) >> 3; i0 < ((n + 7) & ~7); i0 += (gridDim.x * PMH_BLOCK) >> 3) { // uniform trip count within every group of 8 lanes
+    const int i = min(i0, n - 1);
+    double    d = 1.0;
     if (jacobi) {
-      d = 0.0;
-      for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
-        if (col[k] == i) d = val[k];
-      d = (d != 0.0) ? 1.0 / d : 1.0;
+      const int k = pmh_diag_pos8(rowptr, col, i, lane8);
+      d           = (k >= 0) ? val[k] : 0.0;
+      d           = (d != 0.0) ? 1.0 / d : 1.0;
     }
-    dinv[i] = d;
+    if (lane8 == 0 && i0 < n) dinv[i] = d;
   }
 }
 
@@ -608,7 +621,7 @@ extern "C" int pmh_matinv_create(pmh_blockdiag K, double rtol, double atol, int 
   PMH_CHK(pmh_malloc(ctx, sizeof(int), (void **)&M->d_done));
   PMH_HIP(hipHostMalloc((void **)&M->h_nactive, 2 * sizeof(int), hipHostMallocMapped));
   if (M->n > 0) {
-    hipLaunchKernelGGL(k_extract_dinv, dim3(pmh_vec_grid(M->n)), dim3(PMH_BLOCK), 0, ctx->stream, M->n, K->K->d_rowptr, K->K->d_col, K->K->d_val, jacobi, M->dinv);
+    hipLaunchKernelGGL(k_extract_dinv, dim3(pmh_vec_grid((int)std::min<long long>(8LL * M->n, 0x7fffff00LL))), dim3(PMH_BLOCK), 0, ctx->stream, M->n, K->K->d_rowptr, K->K->d_col, K->K->d_val, jacobi, M->dinv);
     PMH_HIP(hipGetLastError());
   }
   *out = M;

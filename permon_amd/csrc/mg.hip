@@ -18,14 +18,27 @@
 #include "pmh_internal.h"
 #include "mg_internal.h"
 
+// position of the LAST entry (row i, column i) of a CSR row, -1 if there is none: 8 lanes walk the row together (one thread per row read 81 entries one after the
+// other: 2 ms for the 2 M rows of configs[2])
+static __device__ __forceinline__ int mg_diag_pos8(const int *__restrict__ rowptr, const int *__restrict__ col, int i, int lane8)
+{
+  int best = -1;
+  for (int k = rowptr[i] + lane8; k < rowptr[i + 1]; k += 8)
+    if (col[k] == i) best = k;
+  best = max(best, __shfl_xor(best, 4, 8));
+  best = max(best, __shfl_xor(best, 2, 8));
+  best = max(best, __shfl_xor(best, 1, 8));
+  return best;
+}
 template <typename TV>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mg_dinv(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, TV *__restrict__ dinv)
 {
-  for (int i = blockIdx.x * PMH_BLOCK + threadIdx.x; i < n; i += gridDim.x * PMH_BLOCK) {
-    double d = 0.0;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; k++)
-      if (col[k] == i) d = val[k];
-    dinv[i] = (TV)((d != 0.0) ? 1.0 / d : 1.0);
+  const int lane8 = threadIdx.x & 7;
+  for (int i0 = (blockIdx.x * PMH_BLOCK + threadIdx.x) >> 3; i0 < ((n + 7) & ~7); i0 += (gridDim.x * PMH_BLOCK) >> 3) { // uniform trip count within every group of 8 lanes
+    const int    i = min(i0, n - 1);
+    const int    k = mg_diag_pos8(rowptr, col, i, lane8);
+    const double d = (k >= 0) ? val[k] : 0.0;
+    if (lane8 == 0 && i0 < n) dinv[i] = (TV)((d != 0.0) ? 1.0 / d : 1.0);
   }
 }
 
@@ -608,8 +621,8 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.t));
       PMH_CHK(pmh_malloc(ctx, nbytes, &Lv.xa));
       if (Lv.n > 0) {
-        if (fl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<float>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (float *)Lv.dinv);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
+        if (fl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<float>), mg_grid((int)std::min<long long>(8LL * Lv.n, 0x7fffff00LL)), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (float *)Lv.dinv);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_dinv<double>), mg_grid((int)std::min<long long>(8LL * Lv.n, 0x7fffff00LL)), dim3(PMH_BLOCK), 0, ctx->stream, Lv.n, (const int *)A[l]->d_rowptr, (const int *)A[l]->d_col, (const double *)A[l]->d_val, (double *)Lv.dinv);
         PMH_HIP(hipGetLastError());
       }
       stage("value conversion, diagonal, work vectors", l);
