@@ -529,6 +529,19 @@ int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const pmh_csr *P, 
  * Coarsening stops at <= min_nodes nodes per block; congruent blocks are processed once.  rowptr / col / val: host copy of A_fine. */
 int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_rowstart, const int *dims, int ndof, const int *rowptr, const int *col, const double *val, int kdim,
                       const double *R_host, int min_nodes, int degree, int precision, pmh_mg *mg);
+/* The same PC with an ALGEBRAIC hierarchy built HERE (host C++, runs once) for blocks of ANY shape -- subdomains that are not boxes, what a mesh partitioner hands
+ * the reference, whose MATINV factorises any block (src/mat/impls/inv/matinv.c:481-580) and whose iterative path takes -mat_inv_pc_type gamg: smoothed aggregation
+ * (Vanek, Mandel, Brezina 1996).  Per level: node graph (ndof dofs per node on the fine level, one node per aggregate below), couplings kept where the Frobenius norm
+ * of their block exceeds theta * 0.5^level * sqrt(|A_ii| |A_jj|), greedy aggregates, a tentative prolongation that reproduces the block's near-kernel exactly, one
+ * damped-Jacobi smoothing step of it, Galerkin operators; coarsening stops when every block has <= max_coarse dofs (every block is coarsened equally often);
+ * congruent blocks are processed once.  Near-kernel of a block: its kernel vectors where R_host (kdim x n) is non-zero over it (a floating block: the rigid-body
+ * modes; such a block stays consistently singular down the hierarchy and its coarsest operator gets a pseudo-inverse), else the rows of nns_host (nns x n; NULL or
+ * zero over the block: the ndof translations).  A near-kernel of 3 or 6 vectors keeps 3 x 3 blocks on every level (PMH_MG_FP32 / PMH_MG_FP16 and the
+ * multi-right-hand-side solver apply).  rowptr / col / val: host copy of A_fine. */
+int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_rowstart, int ndof, const int *rowptr, const int *col, const double *val, int kdim, const double *R_host,
+                     int nns, const double *nns_host, int max_coarse, double theta, int degree, int precision, pmh_mg *mg);
+/* host routine (tests, diagnostics): the aggregates pmh_mg_create_sa forms on ONE level of one block -- A: n x n host CSR with bs dofs per node; agg_out[n / bs] */
+int pmh_sa_aggregate(int n, int bs, const int *rowptr, const int *col, const double *val, double theta, int *agg_out, int *n_agg);
 int pmh_mg_apply(pmh_mg mg, const double *b_dev, double *x_dev); /* x = V(b), zero initial guess (PCApply) */
 int pmh_mg_stats(pmh_mg mg, long long *fine_spmv);
 int pmh_mg_timing_enable(pmh_mg mg, int max_launches); /* HIP-event pairs around the fine-level operator launches */
@@ -624,7 +637,8 @@ int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const in
 typedef struct {
   pmh_smalxe_opts smalxe;           /* outer tolerances + SMALXE / inner MPGP parameters (pmh_smalxe_default_opts) */
   double kplus_rtol; int kplus_max_it;
-  int    mg, mg_min_nodes, mg_degree, mg_precision; /* box-multigrid PC of the inner KSP when dims != NULL (pmh_mg_create_box) */
+  int    mg, mg_min_nodes, mg_degree, mg_precision; /* multigrid PC of the inner KSP: the box hierarchy when dims != NULL (pmh_mg_create_box), else the algebraic one
+                                                       (pmh_mg_create_sa on the kernel vectors; max_coarse = 3 mg_min_nodes): blocks of any shape */
   int    bsr3;                      /* K x of the inner CG on the 3x3-block kernel when ndof == 3 */
   int    explicit_dual; double explicit_rtol; int explicit_storage; /* pmh_fexplicit_* (PMH_FX_SYM / PMH_FX_FULL / PMH_FX_CLASS / PMH_FX_CLASS_SYM / PMH_FX_CLASS_ORBIT) */
   int    orthonormalize;            /* QPTOrthonormalizeEq: 1 G <- L^{-1} G formed explicitly, 2 implicitly (G stays sparse, -qp_E_orth_form implicit), 0 none */

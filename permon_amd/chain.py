@@ -46,7 +46,7 @@ class FetiDualQP:
     """Dual QP of a TFETI problem on this rank's subdomain blocks (lambda replicated on every rank)."""
 
     def __init__(self, ctx, local, G, e, c, lb, orthonormal=True, kplus_rtol=1e-10, kplus_max_it=20000, jacobi=True, mg_hierarchy=None, mg_degree=2, mg_precision="fp64", bsr3=False,
-                 regularize=False, explicit=None, mg_box=None):
+                 regularize=False, explicit=None, mg_box=None, mg_sa=None):
         """local: dict from CubeFeti.subset(); G, e: coarse matrix / rhs (global, replicated); c: constraint rhs;
         lb: dual lower bound (-inf on equality rows, 0 on inequality rows).
         regularize: the reference's default (-regularize 1, QPTDualize -> MatInvSetRegularizationType(MAT_REG_EXPLICIT),
@@ -75,6 +75,9 @@ class FetiDualQP:
         elif mg_box is not None:  # the same PC, hierarchy built inside the library (pmh_mg_create_box): dict(dims=[(nx, ny, nz)], ndof, min_nodes)
             self.Kplus.set_pc_mg_box(self._Kinv_sp, mg_box["dims"], mg_box["ndof"], R=None if regularize else local["R"], min_nodes=mg_box.get("min_nodes", 400),
                                      degree=mg_degree, precision=mg_precision)
+        elif mg_sa is not None:  # the same PC on blocks of ANY shape, algebraic hierarchy built inside the library (pmh_mg_create_sa): dict(ndof, max_coarse, theta, nns)
+            self.Kplus.set_pc_mg_sa(self._Kinv_sp, mg_sa.get("ndof", 3), R=None if regularize else local["R"], nns=mg_sa.get("nns"), max_coarse=mg_sa.get("max_coarse", 1500),
+                                    theta=mg_sa.get("theta", 0.08), degree=mg_degree, precision=mg_precision)
         self.B = MatGluing(ctx, local["n_x"], nl, local["leaves_row"], local["leaves_root"], local["leaves_sign"])
         self.E = None
         if explicit is not None:

@@ -201,6 +201,11 @@ extern "C" int pmh_feti_contact_solve(pmh_ctx ctx, int nsub, const int *block_ro
       GO(pmh_mg_create_box(ctx, Kc, nsub, block_rowstart, dims, ndof, rowptr, col, val, kdim, Rn.data(), std::max(1, o->mg_min_nodes), std::max(1, o->mg_degree), o->mg_precision, &mg));
       GO(pmh_matinv_set_pc_mg(Kp, mg));
       stage("multigrid hierarchy (pmh_mg_create_box)");
+    } else if (o->mg && ndof >= 1 && N % ndof == 0) { // blocks of any shape: the algebraic hierarchy (smoothed aggregation on the kernel vectors, mgsa.hip)
+      const int prec = (ndof == 3 && kdim % 3 == 0) ? o->mg_precision : PMH_MG_FP64; // (the single-precision cycles need 3 x 3 blocks on every level)
+      GO(pmh_mg_create_sa(ctx, Kc, nsub, block_rowstart, ndof, rowptr, col, val, kdim, Rn.data(), 0, nullptr, 3 * std::max(1, o->mg_min_nodes), 0.08, std::max(1, o->mg_degree), prec, &mg));
+      GO(pmh_matinv_set_pc_mg(Kp, mg));
+      stage("multigrid hierarchy (pmh_mg_create_sa)");
     }
     GO(pmh_gluing_create(ctx, N, nl, n_leaves, leaves_row, leaves_root, leaves_val, &B));
     GO(pmh_csr_create(ctx, m, nl, grp.data(), gci.data(), gva.data(), &Gc));

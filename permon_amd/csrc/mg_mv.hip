@@ -4,8 +4,9 @@
 // pseudo-inverses): nothing is set up twice but the ELL copies of the level operators (built on the device, mv.hip) and the work multivectors.  The cycle is
 // the fused form of mg.hip (mg_level_fused): degree-2 Chebyshev/Jacobi smoothing finished inside the operator kernel, fp32 vectors, level operators in the
 // precision pmh_mg keeps them in (fp16 on the finest levels by default).  Per smoothed level: d0 | PRE | SUB | restrict (+ the coarse d0) | ... |
-// prolong-subtract | POST1 | POST2. A hierarchy of another shape (fp64 cycle, other degree, P not node-wise, a level without 3 x 3 blocks) is refused
-// (PMH_EPI_UNSUPPORTED, no error recorded): the caller keeps the one-column solver.
+// prolong-subtract | POST1 | POST2.  The transfers are node-wise where P = P_node (x) I_3 (the box hierarchies) and scalar CSR otherwise (smoothed aggregation).  A
+// hierarchy of another shape (fp64 cycle, other degree, a level without 3 x 3 blocks) is refused (PMH_EPI_UNSUPPORTED, no error recorded): the caller keeps the
+// one-column solver.
 #include "mg_internal.h"
 #include "mv_internal.h"
 
@@ -88,6 +89,33 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub(int nn, const int
     }
     float *xi = x + (size_t)3 * i * MV_R + r;
     xi[0] -= s0, xi[MV_R] -= s1, xi[2 * MV_R] -= s2;
+  }
+}
+
+// The same two transfers for a prolongation that is NOT node-wise (smoothed aggregation, mgsa.hip: a fine dof interpolates from the m dofs of several aggregates): the scalar
+// CSR of P' / P (values in the cycle's precision), lane (row, column r); the operand of an entry is the R-vector of ONE dof (32 contiguous bytes per 8 lanes).
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict_s(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col,
+                        const float *__restrict__ val, const float *__restrict__ t, float *__restrict__ bc, const float *__restrict__ dinv_c, float itheta_c,
+                        float *__restrict__ d_c)
+{
+  if (halt && *halt) return;
+  const int r = threadIdx.x % MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < nc; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+    float s = 0.f;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += val[k] * t[(size_t)col[k] * MV_R + r];
+    bc[(size_t)i * MV_R + r] = s;
+    if (dinv_c) d_c[(size_t)i * MV_R + r] = dinv_c[i] * s * itheta_c;
+  }
+}
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub_s(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col,
+                        const float *__restrict__ val, const float *__restrict__ xc, float *__restrict__ x)
+{
+  if (halt && *halt) return;
+  const int r = threadIdx.x % MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < n; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+    float s = 0.f;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += val[k] * xc[(size_t)col[k] * MV_R + r];
+    x[(size_t)i * MV_R + r] -= s;
   }
 }
 
@@ -182,11 +210,13 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
     pmh_mv_set_why(!mg->is_float ? "the V-cycle runs in fp64" : (mg->degree != 2 ? "the smoother is not of degree 2" : (mg->nlevels < 2 ? "the hierarchy has one level" : "the V-cycle is not the fused form (PMH_MG_FUSED=0 or a level without 3 x 3 blocks)")));
     return PMH_EPI_UNSUPPORTED;
   }
-  for (int l = 0; l + 1 < mg->nlevels; l++)
-    if (!mg->L[l].Ab || !mg->L[l].pn_rowptr || !mg->L[l].rn_rowptr || mg->L[l].n % 3) {
-      pmh_mv_set_why(!mg->L[l].Ab ? "a level operator has no 3 x 3 block copy" : "a prolongation is not node-wise (P = P_node (x) I_3)");
+  for (int l = 0; l + 1 < mg->nlevels; l++) {
+    const bool nodal = mg->L[l].pn_rowptr && mg->L[l].rn_rowptr;
+    if (!mg->L[l].Ab || mg->L[l].n % 3 || (!nodal && (nrep > 1 || !mg->L[l].pv_owned))) { // (a scalar P of congruent blocks: its prefix is not addressed separately here)
+      pmh_mv_set_why(!mg->L[l].Ab ? "a level operator has no 3 x 3 block copy" : "a prolongation that is not node-wise (P = P_node (x) I_3) on congruent blocks");
       return PMH_EPI_UNSUPPORTED;
     }
+  }
   pmh_ctx   ctx = mg->ctx;
   pmh_mg_mv M   = new pmh_mg_mv_s();
   M->mg = mg, M->ctx = ctx, M->nrep = nrep;
@@ -200,7 +230,7 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
       rc = pmh_mv_ell_create_prefix(Lv.A, nrep, Lv.Ab->storage == PMH_BSR_F64 ? PMH_BSR_F32 : Lv.Ab->storage, &Ml.E);
       if (!rc && !Ml.E) {
         pmh_mg_mv_destroy(M);
-        pmh_mv_set_why("a level operator has rows with unsorted columns or more than 32 blocks of 3 x 3 in a block row");
+        pmh_mv_set_why("a level operator has rows with unsorted columns or more than 96 blocks of 3 x 3 in a block row");
         return PMH_EPI_UNSUPPORTED;
       }
       for (float **v : {&Ml.r, &Ml.d, &Ml.t, &Ml.xa})
@@ -255,12 +285,22 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.t, PMH_EPI_SUB, &e, halt));
   const bool cf  = l + 2 < mg->nlevels; // the coarse level is a smoothed one: its d0 rides on the restriction
   const int  ncn = Lc.n / 3 / nrep;
-  hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
-                     (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
-                     cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
+  const bool nodal = Lv.rn_rowptr != nullptr;
+  if (nodal)
+    hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
+                       (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
+                       cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
+  else
+    hipLaunchKernelGGL(k_mvg_restrict_s, mvg_grid((long long)Lc.n * MV_R), blk, 0, st, Lc.n, halt, (const int *)Lv.P->transpose->d_rowptr, (const int *)Lv.P->transpose->d_col,
+                       (const float *)Lv.rv, (const float *)Ml.t, Mc.b,
+                       cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   PMH_CHK(mvg_cycle(M, l + 1, nullptr, nullptr, cf, halt));
-  hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col,
-                     (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
+  if (nodal)
+    hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col,
+                       (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
+  else
+    hipLaunchKernelGGL(k_mvg_prolong_sub_s, mvg_grid((long long)n_l * MV_R), blk, 0, st, n_l, halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col,
+                       (const float *)Lv.pv, (const float *)Mc.x, Ml.xa);
   PMH_HIP(hipGetLastError());
   e.c0 = itheta;
   PMH_CHK(pmh_mv_spmv_f32(Ml.E, Ml.xa, Ml.x, PMH_BSR_EPI_POST1, &e, halt));

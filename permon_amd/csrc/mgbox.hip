@@ -19,14 +19,11 @@
 #include <thread>
 
 #include "pmh_internal.h"
+#include "mg_host.h"
 
-namespace {
-struct HCsr {
-  int                 nr = 0, nc = 0;
-  std::vector<int>    rp, ci;
-  std::vector<double> va;
-};
+int pmh_mg_adopt_csr(pmh_mg mg, pmh_csr A); // mg.hip: the hierarchy owns the CSR handles this builder created
 
+namespace mgh {
 HCsr transpose(const HCsr &A)
 {
   HCsr T;
@@ -104,71 +101,6 @@ HCsr symmetrize(const HCsr &A)
   }
   return S;
 }
-
-// linear interpolation onto n grid nodes from the coarse nodes {0,2,4,...} U {n-1}: per fine node <= 2 (coarse index, weight)
-struct Interp1 {
-  int                 nc;
-  std::vector<int>    c0, c1;
-  std::vector<double> w0, w1;
-  std::vector<int>    cnode; // fine index of every coarse node
-};
-Interp1 interp1d(int n)
-{
-  Interp1 I;
-  for (int i = 0; i < n; i += 2) I.cnode.push_back(i);
-  if (I.cnode.back() != n - 1) I.cnode.push_back(n - 1);
-  I.nc = (int)I.cnode.size();
-  I.c0.assign(n, 0), I.c1.assign(n, -1), I.w0.assign(n, 1.0), I.w1.assign(n, 0.0);
-  if (I.nc == n) {
-    for (int i = 0; i < n; i++) I.c0[i] = i;
-    return I;
-  }
-  for (int j = 0; j + 1 < I.nc; j++) {
-    const int a = I.cnode[j], b = I.cnode[j + 1];
-    for (int i = a; i < b; i++) {
-      const double t = (double)(i - a) / (double)(b - a);
-      I.c0[i] = j, I.w0[i] = 1.0 - t;
-      if (t > 0.0) I.c1[i] = j + 1, I.w1[i] = t;
-    }
-  }
-  I.c0[n - 1] = I.nc - 1, I.w0[n - 1] = 1.0, I.c1[n - 1] = -1;
-  return I;
-}
-
-// P = (Pz (x) Py (x) Px) (x) I_ndof for an nx x ny x nz node box (x fastest, node-major dofs)
-HCsr prolongation(const int d[3], int ndof, int dc[3], std::vector<int> &coarse_to_fine_node)
-{
-  Interp1 I[3] = {interp1d(d[0]), interp1d(d[1]), interp1d(d[2])};
-  for (int a = 0; a < 3; a++) dc[a] = I[a].nc;
-  HCsr P;
-  P.nr = d[0] * d[1] * d[2] * ndof, P.nc = dc[0] * dc[1] * dc[2] * ndof;
-  P.rp.assign((size_t)P.nr + 1, 0);
-  for (int k = 0; k < d[2]; k++)
-    for (int j = 0; j < d[1]; j++)
-      for (int i = 0; i < d[0]; i++) {
-        // node entries sorted by coarse index: z outer, y, x inner (the candidates come in ascending order along every axis)
-        int    cz[2] = {I[2].c0[k], I[2].c1[k]}, cy[2] = {I[1].c0[j], I[1].c1[j]}, cx[2] = {I[0].c0[i], I[0].c1[i]};
-        double wz[2] = {I[2].w0[k], I[2].w1[k]}, wy[2] = {I[1].w0[j], I[1].w1[j]}, wx[2] = {I[0].w0[i], I[0].w1[i]};
-        std::vector<std::pair<int, double>> ent;
-        for (int a = 0; a < 2; a++)
-          for (int b = 0; b < 2; b++)
-            for (int c = 0; c < 2; c++)
-              if (cz[a] >= 0 && cy[b] >= 0 && cx[c] >= 0) ent.push_back({(cz[a] * dc[1] + cy[b]) * dc[0] + cx[c], wz[a] * wy[b] * wx[c]});
-        std::sort(ent.begin(), ent.end());
-        const int node = (k * d[1] + j) * d[0] + i;
-        for (int q = 0; q < ndof; q++) {
-          for (auto &e : ent) P.ci.push_back(e.first * ndof + q), P.va.push_back(e.second);
-          P.rp[(size_t)node * ndof + q + 1] = (int)P.ci.size();
-        }
-      }
-  coarse_to_fine_node.clear();
-  for (int k = 0; k < dc[2]; k++)
-    for (int j = 0; j < dc[1]; j++)
-      for (int i = 0; i < dc[0]; i++) coarse_to_fine_node.push_back((I[2].cnode[k] * d[1] + I[1].cnode[j]) * d[0] + I[0].cnode[i]);
-  return P;
-}
-
-void parallel_for(int n, const std::function<void(int, int)> &f);
 
 double lambda_max_dinv_a(const HCsr &A, int its)
 {
@@ -289,9 +221,197 @@ int spd_inverse(int n, std::vector<double> &M)
     for (int j = i + 1; j < n; j++) M[(size_t)i * n + j] = M[(size_t)j * n + i];
   return 0;
 }
-} // namespace
 
-int pmh_mg_adopt_csr(pmh_mg mg, pmh_csr A); // mg.hip: the hierarchy owns the CSR handles this builder created
+// dense (pseudo-)inverse of a coarsest operator: A^+ = (A + s Q Q')^{-1} - Q Q' / s with Q the orthonormalised kernel vectors R (kd x n; kd = 0: the plain inverse);
+// 1 if A is not positive definite on the complement of span(Q)
+int coarse_pinv(const HCsr &A, int kd, const std::vector<double> &R, std::vector<double> &pinv)
+{
+  const int   n = A.nr;
+  std::vector<double> M((size_t)n * n, 0.0), Q((size_t)kd * n);
+  for (int i = 0; i < n; i++)
+    for (int k = A.rp[i]; k < A.rp[i + 1]; k++) M[(size_t)i * n + A.ci[k]] = A.va[k];
+  int kq = 0;
+  for (int k = 0; k < kd; k++) { // Gram-Schmidt (twice) of the injected kernel vectors
+    std::vector<double> v(R.begin() + (size_t)k * n, R.begin() + (size_t)(k + 1) * n);
+    double              n0 = 0.0;
+    for (double x : v) n0 += x * x;
+    for (int pass = 0; pass < 2; pass++)
+      for (int j = 0; j < kq; j++) {
+        double t = 0.0;
+        for (int i = 0; i < n; i++) t += Q[(size_t)j * n + i] * v[i];
+        for (int i = 0; i < n; i++) v[i] -= t * Q[(size_t)j * n + i];
+      }
+    double nn = 0.0;
+    for (double x : v) nn += x * x;
+    if (nn <= 1e-20 * n0) continue;
+    nn = std::sqrt(nn);
+    for (int i = 0; i < n; i++) Q[(size_t)kq * n + i] = v[i] / nn;
+    kq++;
+  }
+  // scale Q Q' to the size of A so that A + s Q Q' is well conditioned; (A + s Q Q')^{-1} = A^+ + Q Q' / s
+  double sc = 0.0;
+  for (int i = 0; i < n; i++) sc = std::max(sc, std::fabs(M[(size_t)i * n + i]));
+  if (sc == 0.0) sc = 1.0;
+  for (int k = 0; k < kq; k++)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) M[(size_t)i * n + j] += sc * Q[(size_t)k * n + i] * Q[(size_t)k * n + j];
+  if (spd_inverse(n, M)) return 1;
+  for (int k = 0; k < kq; k++)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) M[(size_t)i * n + j] -= Q[(size_t)k * n + i] * Q[(size_t)k * n + j] / sc;
+  pinv = std::move(M);
+  return 0;
+}
+
+// the classes' levels -> block-diagonal concatenation per level -> device CSRs -> pmh_mg_create (the hierarchy owns the handles created here)
+int finish(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const std::vector<int> &cls, std::vector<ClassH> &H, int nlev, int degree, int precision, bool verbose, pmh_mg *out)
+{
+  const int ncls   = (int)H.size();
+  auto      t_last = std::chrono::steady_clock::now();
+  auto      stage  = [&](const char *what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  pmh_mg hierarchy: %-40s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  // block-diagonal concatenation per level -> device CSRs -> pmh_mg_create
+  std::vector<pmh_csr> Ah(nlev), Ph(std::max(1, nlev - 1)), created;
+  std::vector<double>  lam(std::max(1, nlev - 1), 1.0);
+  Ah[0] = A_fine;
+  struct HostCat { // the concatenated host arrays stay alive until pmh_mg_create has built its block copies from them (host hint: no download of what was just uploaded)
+    std::vector<int>    rp, ci;
+    std::vector<double> va;
+  };
+  std::deque<HostCat> kept;
+  auto cat = [&](int l, int which, pmh_csr *dst) -> int { // which: 0 the level's operator, 1 its prolongation, 2 the transpose of the prolongation
+    // sized once, every block filled by its own thread (the entry-by-entry push_back of one thread was 0.2 s of the set-up for configs[2])
+    size_t nr_tot = 0, nz_tot = 0;
+    std::vector<size_t> r0(nblocks), k0(nblocks);
+    std::vector<int>    c0(nblocks);
+    int                 roff = 0, coff = 0;
+    for (int b = 0; b < nblocks; b++) {
+      const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
+      r0[b] = nr_tot, k0[b] = nz_tot, c0[b] = coff;
+      nr_tot += (size_t)M.nr, nz_tot += (size_t)M.rp[M.nr], roff += M.nr, coff += M.nc;
+    }
+    if (nz_tot > (size_t)0x7fffff00) return pmh_set_error(PMH_ERR_SUP, "pmh_mg hierarchy: level %d has %zu non-zeros (int32 row pointers)", l, nz_tot);
+    kept.emplace_back();
+    std::vector<int>    &rp = kept.back().rp, &ci = kept.back().ci;
+    std::vector<double> &va = kept.back().va;
+    rp.resize(nr_tot + 1), ci.resize(nz_tot), va.resize(nz_tot);
+    rp[0] = 0;
+    {
+      auto fillb = [&](int b) {
+        const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
+        for (int i = 0; i < M.nr; i++) rp[r0[b] + i + 1] = (int)(k0[b] + (size_t)M.rp[i + 1]);
+        const size_t nz = (size_t)M.rp[M.nr];
+        for (size_t k = 0; k < nz; k++) ci[k0[b] + k] = M.ci[k] + c0[b];
+        std::copy(M.va.begin(), M.va.begin() + nz, va.begin() + k0[b]);
+      };
+      std::vector<std::thread> th;
+      for (int b = 0; b < nblocks; b++) th.emplace_back(fillb, b);
+      for (auto &x : th) x.join();
+    }
+    PMH_CHK(pmh_csr_create(ctx, roff, coff, rp.data(), ci.data(), va.data(), dst));
+    pmh_csr_set_host_hint(*dst, rp.data(), ci.data(), va.data());
+    if (which != 2) created.push_back(*dst);
+    return PMH_SUCCESS;
+  };
+  for (int l = 0; l < nlev; l++) {
+    if (l > 0) PMH_CHK(cat(l, 0, &Ah[l]));
+    if (l + 1 < nlev) {
+      PMH_CHK(cat(l, 1, &Ph[l]));
+      pmh_csr Pt = nullptr; // the classes' own transposes, concatenated: pmh_mg_create would otherwise download P and transpose the 16 M entries on one host thread
+      PMH_CHK(cat(l, 2, &Pt));
+      PMH_CHK(pmh_csr_adopt_transpose(Ph[l], Pt));
+      for (int c = 0; c < ncls; c++) lam[l] = (c == 0) ? H[c].L[l].lam : std::max(lam[l], H[c].L[l].lam);
+    }
+  }
+  stage("level matrices -> device CSR");
+  std::vector<int>    crs(nblocks + 1, 0);
+  std::vector<double> cp;
+  for (int b = 0; b < nblocks; b++) {
+    const ClassH &C = H[cls[b]];
+    crs[b + 1]      = crs[b] + C.L[nlev - 1].A.nr;
+    cp.insert(cp.end(), C.pinv.begin(), C.pinv.end());
+  }
+  PMH_CHK(pmh_mg_create(ctx, nlev, Ah.data(), Ph.data(), degree, lam.data(), 0.1, 1.1, nblocks, crs.data(), cp.data(), precision, out));
+  stage("pmh_mg_create (block copies, transfer operators)");
+  for (pmh_csr a : created) {
+    pmh_csr_set_host_hint(a, nullptr, nullptr, nullptr); // (the host arrays go away with this function)
+    if (a->transpose) pmh_csr_set_host_hint(a->transpose, nullptr, nullptr, nullptr);
+    PMH_CHK(pmh_mg_adopt_csr(*out, a));
+  }
+  return PMH_SUCCESS;
+}
+} // namespace mgh
+
+namespace {
+using namespace mgh;
+// linear interpolation onto n grid nodes from the coarse nodes {0,2,4,...} U {n-1}: per fine node <= 2 (coarse index, weight)
+struct Interp1 {
+  int                 nc;
+  std::vector<int>    c0, c1;
+  std::vector<double> w0, w1;
+  std::vector<int>    cnode; // fine index of every coarse node
+};
+Interp1 interp1d(int n)
+{
+  Interp1 I;
+  for (int i = 0; i < n; i += 2) I.cnode.push_back(i);
+  if (I.cnode.back() != n - 1) I.cnode.push_back(n - 1);
+  I.nc = (int)I.cnode.size();
+  I.c0.assign(n, 0), I.c1.assign(n, -1), I.w0.assign(n, 1.0), I.w1.assign(n, 0.0);
+  if (I.nc == n) {
+    for (int i = 0; i < n; i++) I.c0[i] = i;
+    return I;
+  }
+  for (int j = 0; j + 1 < I.nc; j++) {
+    const int a = I.cnode[j], b = I.cnode[j + 1];
+    for (int i = a; i < b; i++) {
+      const double t = (double)(i - a) / (double)(b - a);
+      I.c0[i] = j, I.w0[i] = 1.0 - t;
+      if (t > 0.0) I.c1[i] = j + 1, I.w1[i] = t;
+    }
+  }
+  I.c0[n - 1] = I.nc - 1, I.w0[n - 1] = 1.0, I.c1[n - 1] = -1;
+  return I;
+}
+
+// P = (Pz (x) Py (x) Px) (x) I_ndof for an nx x ny x nz node box (x fastest, node-major dofs)
+HCsr prolongation(const int d[3], int ndof, int dc[3], std::vector<int> &coarse_to_fine_node)
+{
+  Interp1 I[3] = {interp1d(d[0]), interp1d(d[1]), interp1d(d[2])};
+  for (int a = 0; a < 3; a++) dc[a] = I[a].nc;
+  HCsr P;
+  P.nr = d[0] * d[1] * d[2] * ndof, P.nc = dc[0] * dc[1] * dc[2] * ndof;
+  P.rp.assign((size_t)P.nr + 1, 0);
+  for (int k = 0; k < d[2]; k++)
+    for (int j = 0; j < d[1]; j++)
+      for (int i = 0; i < d[0]; i++) {
+        // node entries sorted by coarse index: z outer, y, x inner (the candidates come in ascending order along every axis)
+        int    cz[2] = {I[2].c0[k], I[2].c1[k]}, cy[2] = {I[1].c0[j], I[1].c1[j]}, cx[2] = {I[0].c0[i], I[0].c1[i]};
+        double wz[2] = {I[2].w0[k], I[2].w1[k]}, wy[2] = {I[1].w0[j], I[1].w1[j]}, wx[2] = {I[0].w0[i], I[0].w1[i]};
+        std::vector<std::pair<int, double>> ent;
+        for (int a = 0; a < 2; a++)
+          for (int b = 0; b < 2; b++)
+            for (int c = 0; c < 2; c++)
+              if (cz[a] >= 0 && cy[b] >= 0 && cx[c] >= 0) ent.push_back({(cz[a] * dc[1] + cy[b]) * dc[0] + cx[c], wz[a] * wy[b] * wx[c]});
+        std::sort(ent.begin(), ent.end());
+        const int node = (k * d[1] + j) * d[0] + i;
+        for (int q = 0; q < ndof; q++) {
+          for (auto &e : ent) P.ci.push_back(e.first * ndof + q), P.va.push_back(e.second);
+          P.rp[(size_t)node * ndof + q + 1] = (int)P.ci.size();
+        }
+      }
+  coarse_to_fine_node.clear();
+  for (int k = 0; k < dc[2]; k++)
+    for (int j = 0; j < dc[1]; j++)
+      for (int i = 0; i < dc[0]; i++) coarse_to_fine_node.push_back((I[2].cnode[k] * d[1] + I[1].cnode[j]) * d[0] + I[0].cnode[i]);
+  return P;
+}
+
+} // namespace
 
 // dims: nblocks x 3 node counts (x fastest); rowptr / col / val: the host copy of the block-diagonal fine matrix A_fine holds on the
 // device; R_host: kdim x n kernel vectors (block-wise, zero over non-singular blocks) or NULL; coarsening stops at <= min_nodes nodes.
@@ -317,16 +437,6 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   PMH_CHK(pmh_csr_block_classes(nblocks, block_rowstart, rowptr, col, val, cls.data(), &ncls));
   stage("block classes");
   // blocks of one class must also share the box and the kernel dimension (the kernel SPACE follows from the matrix)
-  struct Level {
-    HCsr                A, P, Pt;
-    double              lam = 0.0;
-    std::vector<double> R; // kdim_b x n_l kernel vectors of this level (injected)
-  };
-  struct ClassH {
-    std::vector<Level>  L;
-    std::vector<double> pinv;
-    int                 rep, kd;
-  };
   std::vector<ClassH> H(ncls);
   std::vector<char>   seen(ncls, 0);
   int                 nlev = 1 << 30;
@@ -398,112 +508,9 @@ extern "C" int pmh_mg_create_box(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const
   }
   stage("Galerkin operators, lambda_max (host)");
   // dense (pseudo-)inverse of the level every class is cut at
-  for (int c = 0; c < ncls; c++) {
-    ClassH     &C = H[c];
-    const HCsr &A = C.L[nlev - 1].A;
-    const int   n = A.nr;
-    std::vector<double> M((size_t)n * n, 0.0), Q((size_t)C.kd * n);
-    for (int i = 0; i < n; i++)
-      for (int k = A.rp[i]; k < A.rp[i + 1]; k++) M[(size_t)i * n + A.ci[k]] = A.va[k];
-    int kq = 0;
-    for (int k = 0; k < C.kd; k++) { // Gram-Schmidt (twice) of the injected kernel vectors
-      std::vector<double> v(C.L[nlev - 1].R.begin() + (size_t)k * n, C.L[nlev - 1].R.begin() + (size_t)(k + 1) * n);
-      double              n0 = 0.0;
-      for (double x : v) n0 += x * x;
-      for (int pass = 0; pass < 2; pass++)
-        for (int j = 0; j < kq; j++) {
-          double t = 0.0;
-          for (int i = 0; i < n; i++) t += Q[(size_t)j * n + i] * v[i];
-          for (int i = 0; i < n; i++) v[i] -= t * Q[(size_t)j * n + i];
-        }
-      double nn = 0.0;
-      for (double x : v) nn += x * x;
-      if (nn <= 1e-20 * n0) continue;
-      nn = std::sqrt(nn);
-      for (int i = 0; i < n; i++) Q[(size_t)kq * n + i] = v[i] / nn;
-      kq++;
-    }
-    // scale Q Q' to the size of A so that A + s Q Q' is well conditioned; (A + s Q Q')^{-1} = A^+ + Q Q' / s
-    double sc = 0.0;
-    for (int i = 0; i < n; i++) sc = std::max(sc, std::fabs(M[(size_t)i * n + i]));
-    if (sc == 0.0) sc = 1.0;
-    for (int k = 0; k < kq; k++)
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) M[(size_t)i * n + j] += sc * Q[(size_t)k * n + i] * Q[(size_t)k * n + j];
-    if (spd_inverse(n, M)) return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_box: the coarsest operator of block class %d (n = %d) is not positive definite on the complement of the given kernel", c, n);
-    for (int k = 0; k < kq; k++)
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) M[(size_t)i * n + j] -= Q[(size_t)k * n + i] * Q[(size_t)k * n + j] / sc;
-    C.pinv = std::move(M);
-  }
+  for (int c = 0; c < ncls; c++)
+    if (coarse_pinv(H[c].L[nlev - 1].A, H[c].kd, H[c].L[nlev - 1].R, H[c].pinv)) return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_box: the coarsest operator of block class %d (n = %d) is not positive definite on the complement of the given kernel", c, H[c].L[nlev - 1].A.nr);
   stage("dense coarse pseudo-inverses");
-  // block-diagonal concatenation per level -> device CSRs -> pmh_mg_create
-  std::vector<pmh_csr> Ah(nlev), Ph(std::max(1, nlev - 1)), created;
-  std::vector<double>  lam(std::max(1, nlev - 1), 1.0);
-  Ah[0] = A_fine;
-  struct HostCat { // the concatenated host arrays stay alive until pmh_mg_create has built its block copies from them (host hint: no download of what was just uploaded)
-    std::vector<int>    rp, ci;
-    std::vector<double> va;
-  };
-  std::deque<HostCat> kept;
-  auto cat = [&](int l, int which, pmh_csr *dst) -> int { // which: 0 the level's operator, 1 its prolongation, 2 the transpose of the prolongation
-    // sized once, every block filled by its own thread (the entry-by-entry push_back of one thread was 0.2 s of the set-up for configs[2])
-    size_t nr_tot = 0, nz_tot = 0;
-    std::vector<size_t> r0(nblocks), k0(nblocks);
-    std::vector<int>    c0(nblocks);
-    int                 roff = 0, coff = 0;
-    for (int b = 0; b < nblocks; b++) {
-      const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
-      r0[b] = nr_tot, k0[b] = nz_tot, c0[b] = coff;
-      nr_tot += (size_t)M.nr, nz_tot += (size_t)M.rp[M.nr], roff += M.nr, coff += M.nc;
-    }
-    if (nz_tot > (size_t)0x7fffff00) return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create_box: level %d has %zu non-zeros (int32 row pointers)", l, nz_tot);
-    kept.emplace_back();
-    std::vector<int>    &rp = kept.back().rp, &ci = kept.back().ci;
-    std::vector<double> &va = kept.back().va;
-    rp.resize(nr_tot + 1), ci.resize(nz_tot), va.resize(nz_tot);
-    rp[0] = 0;
-    {
-      auto fillb = [&](int b) {
-        const HCsr &M = which == 1 ? H[cls[b]].L[l].P : (which == 2 ? H[cls[b]].L[l].Pt : H[cls[b]].L[l].A);
-        for (int i = 0; i < M.nr; i++) rp[r0[b] + i + 1] = (int)(k0[b] + (size_t)M.rp[i + 1]);
-        const size_t nz = (size_t)M.rp[M.nr];
-        for (size_t k = 0; k < nz; k++) ci[k0[b] + k] = M.ci[k] + c0[b];
-        std::copy(M.va.begin(), M.va.begin() + nz, va.begin() + k0[b]);
-      };
-      std::vector<std::thread> th;
-      for (int b = 0; b < nblocks; b++) th.emplace_back(fillb, b);
-      for (auto &x : th) x.join();
-    }
-    PMH_CHK(pmh_csr_create(ctx, roff, coff, rp.data(), ci.data(), va.data(), dst));
-    pmh_csr_set_host_hint(*dst, rp.data(), ci.data(), va.data());
-    if (which != 2) created.push_back(*dst);
-    return PMH_SUCCESS;
-  };
-  for (int l = 0; l < nlev; l++) {
-    if (l > 0) PMH_CHK(cat(l, 0, &Ah[l]));
-    if (l + 1 < nlev) {
-      PMH_CHK(cat(l, 1, &Ph[l]));
-      pmh_csr Pt = nullptr; // the classes' own transposes, concatenated: pmh_mg_create would otherwise download P and transpose the 16 M entries on one host thread
-      PMH_CHK(cat(l, 2, &Pt));
-      PMH_CHK(pmh_csr_adopt_transpose(Ph[l], Pt));
-      for (int c = 0; c < ncls; c++) lam[l] = (c == 0) ? H[c].L[l].lam : std::max(lam[l], H[c].L[l].lam);
-    }
-  }
-  stage("level matrices -> device CSR");
-  std::vector<int>    crs(nblocks + 1, 0);
-  std::vector<double> cp;
-  for (int b = 0; b < nblocks; b++) {
-    const ClassH &C = H[cls[b]];
-    crs[b + 1]      = crs[b] + C.L[nlev - 1].A.nr;
-    cp.insert(cp.end(), C.pinv.begin(), C.pinv.end());
-  }
-  PMH_CHK(pmh_mg_create(ctx, nlev, Ah.data(), Ph.data(), degree, lam.data(), 0.1, 1.1, nblocks, crs.data(), cp.data(), precision, out));
-  stage("pmh_mg_create (block copies, transfer operators)");
-  for (pmh_csr a : created) {
-    pmh_csr_set_host_hint(a, nullptr, nullptr, nullptr); // (the host arrays go away with this function)
-    if (a->transpose) pmh_csr_set_host_hint(a->transpose, nullptr, nullptr, nullptr);
-    PMH_CHK(pmh_mg_adopt_csr(*out, a));
-  }
+  PMH_CHK(finish(ctx, A_fine, nblocks, cls, H, nlev, degree, precision, verbose, out));
   return PMH_SUCCESS;
 }

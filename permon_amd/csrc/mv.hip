@@ -128,7 +128,7 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
                      d_info);
   int info[2];
   PMH_CHK(pmh_memcpy_d2h(ctx, info, d_info, sizeof(info)));
-  if (info[1] || info[0] < 1 || info[0] > 32) {
+  if (info[1] || info[0] < 1 || info[0] > 96) { // (32 until round 6: the coarse operators of an aggregation hierarchy couple an aggregate's two 3 x 3 block rows to ~ 27 x 2 block columns)
     pmh_free(ctx, d_info);
     return PMH_SUCCESS;
   }

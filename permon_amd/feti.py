@@ -641,3 +641,371 @@ def box_symmetries(dims, ndof, K=None, nsample=4000, tol=1e-11, seed=0):
                 nxt.append((pc, sc))
         frontier = nxt
     return np.stack([g[0] for g in group]).astype(np.int32), np.stack([g[1] for g in group]).astype(np.int8)
+
+
+# ---- irregular decompositions (subdomains that are NOT boxes) ---------------------------------------------------------------
+def irregular_partition(n, kind="staircase", w=None):
+    """Element -> subdomain map elem_sub[iz, iy, ix] of a (2n)^3-element cube cut into 8 subdomains that are not boxes (input of MeshFeti).
+    'staircase': the three cutting planes of the 2 x 2 x 2 decomposition move by one element in a checkerboard of steps w elements wide, so every interface
+    is a staircase and no subdomain has a symmetry or a congruent partner; 'lshape': the 2 x 2 x 2 cubes with a quarter-size brick handed from every cube of
+    the lower layer to its x / y neighbour and from every cube of the upper layer to the cube below it (L-shaped bodies); 'cubes': the plain 2 x 2 x 2 boxes."""
+    n = int(n)
+    m = 2 * n
+    iz, iy, ix = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+    if kind == "cubes":
+        return ((ix >= n) + 2 * (iy >= n) + 4 * (iz >= n)).astype(np.int32)
+    if kind == "staircase":
+        w = max(2, n // 3) if w is None else int(w)
+        xc = n + ((iy // w + iz // w) % 2)
+        yc = n + ((ix // w + iz // w + 1) % 2)
+        zc = n + ((ix // w + iy // w) % 2)
+        return _repair_partition(((ix >= xc) + 2 * (iy >= yc) + 4 * (iz >= zc)).astype(np.int32))
+    if kind == "lshape":
+        a = max(1, n // 2)
+        es = ((ix >= n) + 2 * (iy >= n) + 4 * (iz >= n)).astype(np.int32)
+        lo = iz < n
+        es[lo & (ix >= n) & (ix < n + a) & (iy < a)] = 0          # cube 1 -> cube 0
+        es[lo & (iy >= n) & (iy < n + a) & (ix >= m - a)] = 1     # cube 3 -> cube 1
+        es[lo & (ix >= n - a) & (ix < n) & (iy >= m - a)] = 3     # cube 2 -> cube 3
+        es[lo & (iy >= n - a) & (iy < n) & (ix < a)] = 2          # cube 0 -> cube 2
+        up = (iz >= n) & (iz < n + a)
+        es[up & (ix < a) & (iy < a)] = 0                          # cube 4 -> cube 0 ... a brick of every upper cube goes down
+        es[up & (ix >= m - a) & (iy < a)] = 1
+        es[up & (ix < a) & (iy >= m - a)] = 2
+        es[up & (ix >= m - a) & (iy >= m - a)] = 3
+        return es
+    raise ValueError("unknown partition kind %r" % kind)
+
+
+def _face_components(es, s):
+    """Face-connected components of subdomain s of an element map: (element ids, component label per element, number of components)."""
+    from scipy.sparse.csgraph import connected_components
+
+    esf = es.ravel()
+    eid = np.arange(es.size).reshape(es.shape)
+    pairs = [(eid[:, :, :-1].ravel(), eid[:, :, 1:].ravel()), (eid[:, :-1, :].ravel(), eid[:, 1:, :].ravel()), (eid[:-1, :, :].ravel(), eid[1:, :, :].ravel())]
+    el = np.nonzero(esf == s)[0]
+    loc = -np.ones(es.size, dtype=np.int64)
+    loc[el] = np.arange(el.size)
+    ii = np.concatenate([loc[a][(esf[a] == s) & (esf[b] == s)] for a, b in pairs])
+    jj = np.concatenate([loc[b][(esf[a] == s) & (esf[b] == s)] for a, b in pairs])
+    ncomp, lab = connected_components(sp.coo_matrix((np.ones(ii.size), (ii, jj)), shape=(el.size, el.size)), directed=False)
+    return el, lab, ncomp
+
+
+def _repair_partition(es):
+    """Hands every element outside the largest face-connected piece of its subdomain to the subdomain most of its face neighbours belong to (a subdomain held
+    together by an edge or a vertex would be a mechanism: more than 6 kernel vectors)."""
+    es = es.copy()
+    shp = es.shape
+    for _ in range(8):
+        changed = False
+        for s in range(int(es.max()) + 1):
+            el, lab, ncomp = _face_components(es, s)
+            if ncomp <= 1:
+                continue
+            big = np.argmax(np.bincount(lab))
+            for e in el[lab != big]:
+                k, j, i = np.unravel_index(e, shp)
+                votes = {}
+                for dk, dj, di in ((0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)):
+                    kk, jj, ii = k + dk, j + dj, i + di
+                    if 0 <= kk < shp[0] and 0 <= jj < shp[1] and 0 <= ii < shp[2] and es[kk, jj, ii] != s:
+                        votes[int(es[kk, jj, ii])] = votes.get(int(es[kk, jj, ii]), 0) + 1
+                if votes:
+                    es[k, j, i] = max(sorted(votes), key=lambda t: votes[t])
+                    changed = True
+        if not changed:
+            break
+    return es
+
+
+class MeshFeti:
+    """TFETI data for a box of nex x ney x nez Q1 elements of edge h cut into ARBITRARY (face-connected) subdomains: elem_sub[iz, iy, ix] names the subdomain of
+    every element.  Same conventions as CubeFeti (Dirichlet u = 0 on the global x = 0 face enforced by B, rigid obstacle under the global z = 0 face as
+    inequality rows, dual rows ordered [Dirichlet | gluing | contact]) but nothing is assumed about the subdomains' shape: the local numbering of a subdomain is
+    its nodes in ascending global order (node-major dofs), the gluing comes from the subdomains' local-to-global maps through QPFetiGetBgtSF's rules
+    (pmh_feti_gluing_from_l2g), the kernel basis from the node coordinates.  This is the decomposition a mesh partitioner hands the reference
+    (QPTMatISToBlockDiag + QPFetiSetUp): blocks with no box structure, no symmetry and no congruent partner."""
+
+    def __init__(self, elem_sub, h=None, physics="elasticity", gluing="full", scale=True, contact=True, gap0=0.0, gap_slope=0.05, load=-1.0, young=None):
+        es = np.asarray(elem_sub, dtype=np.int64)
+        nez, ney, nex = es.shape
+        self.elem_sub = es
+        self.physics = physics
+        nd = self.ndof = 3 if physics == "elasticity" else 1
+        self.kdim = 6 if physics == "elasticity" else 1
+        h = 2.0 / max(nex, ney, nez) if h is None else float(h)
+        self.h = h
+        self.nsub = int(es.max()) + 1
+        GX, GY, GZ = nex + 1, ney + 1, nez + 1
+        Ke = q1_elasticity_element(h) if physics == "elasticity" else q1_poisson_element(h)
+        self.young = None if young is None else np.asarray(young, dtype=np.float64)
+        ez, ey, ex = np.meshgrid(np.arange(nez), np.arange(ney), np.arange(nex), indexing="ij")
+        e0 = (ez.ravel() * GY + ey.ravel()) * GX + ex.ravel()  # lowest global node of every element
+        offs = np.array([(c * GY + b) * GX + a for c in (0, 1) for b in (0, 1) for a in (0, 1)])
+        esf = es.ravel()
+        self.blocks, self.gnodes, self.coords, fs, Rs = [], [], [], [], []
+        for s in range(self.nsub):
+            el, _, ncomp = _face_components(es, s)  # (a subdomain hanging together by an edge or a vertex only would have more than 6 kernel vectors)
+            if el.size == 0:
+                raise ValueError("subdomain %d has no element" % s)
+            if ncomp != 1:
+                raise ValueError("subdomain %d is not face-connected (%d pieces)" % (s, ncomp))
+            gn = e0[el][:, None] + offs[None, :]
+            nodes = np.unique(gn)
+            ln = np.searchsorted(nodes, gn)
+            nl = nodes.size
+            ed = (ln[:, :, None] * nd + np.arange(nd)[None, None, :]).reshape(el.size, 8 * nd)
+            Es = 1.0 if self.young is None else float(self.young[s])
+            Ks = sp.coo_matrix((np.tile(Es * Ke.ravel(), el.size), (np.repeat(ed, 8 * nd, axis=1).ravel(), np.tile(ed, (1, 8 * nd)).ravel())), shape=(nl * nd, nl * nd)).tocsr()
+            Ks.sum_duplicates()
+            Ks.sort_indices()
+            X = np.stack([(nodes % GX) * h, ((nodes // GX) % GY) * h, (nodes // (GX * GY)) * h], axis=1)
+            wgt = np.zeros(nl)
+            np.add.at(wgt, ln.ravel(), h ** 3 / 8.0)
+            f = np.zeros(nl * nd)
+            f[(nd - 1)::nd] = load * wgt
+            if nd == 1:
+                Rb = np.ones((nl, 1))
+            else:
+                Rb = np.zeros((nl * 3, 6))
+                Rb[0::3, 0] = Rb[1::3, 1] = Rb[2::3, 2] = 1.0
+                Rb[0::3, 3], Rb[1::3, 3] = -X[:, 1], X[:, 0]
+                Rb[1::3, 4], Rb[2::3, 4] = -X[:, 2], X[:, 1]
+                Rb[0::3, 5], Rb[2::3, 5] = X[:, 2], -X[:, 0]
+            Q, _ = np.linalg.qr(Rb)
+            self.blocks.append(Ks), self.gnodes.append(nodes), self.coords.append(X), fs.append(f), Rs.append(Q.T)
+        self.block_rowstart = np.concatenate([[0], np.cumsum([K.shape[0] for K in self.blocks])]).astype(np.int32)
+        self.N = int(self.block_rowstart[-1])
+        self.f = np.concatenate(fs)
+        self.R = np.zeros((self.kdim, self.N))
+        for s, Rb in enumerate(Rs):
+            self.R[:, self.block_rowstart[s]:self.block_rowstart[s + 1]] = Rb
+        self.l2g = [(g[:, None] * nd + np.arange(nd)[None, :]).ravel() for g in self.gnodes]
+        # ---- constraints: [Dirichlet on x = 0 | gluing | contact on z = 0] ----
+        rows_l, roots_l, vals_l, c_rhs = [], [], [], []
+        nrow = 0
+        for s, g in enumerate(self.gnodes):
+            dn = np.nonzero(g % GX == 0)[0]
+            dd = (dn[:, None] * nd + np.arange(nd)[None, :]).ravel() + self.block_rowstart[s]
+            rows_l.append(dd), roots_l.append(nrow + np.arange(dd.size)), vals_l.append(np.ones(dd.size))
+            nrow += dd.size
+        self.n_dirichlet = nrow
+        gr, gt, gv, ng = gluing_from_l2g(self.l2g, gluing, scale)
+        rows_l.append(np.asarray(gr)), roots_l.append(np.asarray(gt) + nrow), vals_l.append(np.asarray(gv))
+        nrow += ng
+        self.n_eq = nrow
+        c_rhs.append(np.zeros(nrow))
+        if contact:
+            for s, g in enumerate(self.gnodes):
+                cn = np.nonzero(g // (GX * GY) == 0)[0]
+                rows_l.append(cn * nd + (nd - 1) + self.block_rowstart[s]), roots_l.append(nrow + np.arange(cn.size)), vals_l.append(-np.ones(cn.size))
+                c_rhs.append(gap0 + gap_slope * (self.coords[s][cn, 0] + self.coords[s][cn, 1]))
+                nrow += cn.size
+        self.n_lambda = nrow
+        self.n_ineq = nrow - self.n_eq
+        self.leaves_row = np.concatenate(rows_l).astype(np.int32)
+        self.leaves_root = np.concatenate(roots_l).astype(np.int32)
+        self.leaves_sign = np.concatenate(vals_l).astype(np.float64)
+        self.c = np.concatenate(c_rhs)
+        self.B = sp.csr_matrix((self.leaves_sign, (self.leaves_root, self.leaves_row)), shape=(self.n_lambda, self.N))
+        self.lb = np.concatenate([np.full(self.n_eq, -np.inf), np.zeros(self.n_ineq)])
+        self._K = None
+
+    @property
+    def K(self):
+        if self._K is None:
+            self._K = csr_block_diag(self.blocks)
+        return self._K
+
+    def block_K(self, s):
+        return self.blocks[s]
+
+    def kernel_matrix(self):
+        rs = self.block_rowstart
+        return sp.block_diag([sp.csr_matrix(self.R[:, rs[s]:rs[s + 1]].T) for s in range(self.nsub)], format="csr")
+
+    coarse = CubeFeti.coarse
+
+    def subset(self, blocks):
+        """One rank's share, in the layout FetiDualQP consumes (CubeFeti.subset)."""
+        blocks = list(blocks)
+        rs = self.block_rowstart
+        keep = np.zeros(self.N, dtype=bool)
+        newidx = -np.ones(self.N, dtype=np.int64)
+        o = 0
+        nrs = [0]
+        for s in blocks:
+            n = int(rs[s + 1] - rs[s])
+            keep[rs[s]:rs[s + 1]] = True
+            newidx[rs[s]:rs[s + 1]] = np.arange(o, o + n)
+            o += n
+            nrs.append(o)
+        sel = keep[self.leaves_row]
+        return dict(nblocks=len(blocks), block_rowstart=np.asarray(nrs, dtype=np.int32), K=csr_block_diag([self.blocks[s] for s in blocks]), f=self.f[keep], R=self.R[:, keep],
+                    leaves_row=newidx[self.leaves_row[sel]].astype(np.int32), leaves_root=self.leaves_root[sel], leaves_sign=self.leaves_sign[sel], n_x=o, n_lambda=self.n_lambda)
+
+
+# ---- algebraic multigrid hierarchy (smoothed aggregation) for blocks of ANY shape: the scipy restatement of pmh_mg_create_sa ----------------------
+def _splitmix_start(n):
+    """The fixed start vector of the library's power method (splitmix64 -> [-1, 1)), mgbox.hip lambda_max_dinv_a."""
+    with np.errstate(over="ignore"):
+        s = np.uint64(0x9E3779B97F4A7C15) * (np.arange(n, dtype=np.uint64) + np.uint64(2))
+        z = s.copy()
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) / 4503599627370496.0 - 1.0
+
+
+def _lambda_max_dinv_a_fixed(A, its=20):
+    d = A.diagonal()
+    dinv = np.where(d != 0.0, 1.0 / np.where(d != 0.0, d, 1.0), 1.0)
+    v = _splitmix_start(A.shape[0])
+    lam = 1.0
+    for _ in range(its):
+        w = dinv * (A @ v)
+        nw, nv = np.linalg.norm(w), np.linalg.norm(v)
+        lam = nw / max(nv, 1e-300)
+        v = w / max(nw, 1e-300)
+    return float(lam)
+
+
+def sa_aggregate(S):
+    """Greedy aggregation of Vanek / Mandel / Brezina on the strength graph S (CSR over nodes, no diagonal, weights = coupling strength): phase 1 -- in index
+    order, a node all of whose neighbours are still free becomes a root and takes them; phase 2 -- a free node joins the phase-1 aggregate of its strongest
+    aggregated neighbour (lowest index on ties); phase 3 -- what is left forms aggregates with its free neighbours.  Returns (aggregate of every node, count)."""
+    nn = S.shape[0]
+    ip, ix, w = S.indptr, S.indices, S.data
+    agg = -np.ones(nn, dtype=np.int64)
+    na = 0
+    for i in range(nn):
+        if agg[i] >= 0:
+            continue
+        nb = ix[ip[i]:ip[i + 1]]
+        if nb.size and np.all(agg[nb] < 0):
+            agg[i] = na
+            agg[nb] = na
+            na += 1
+    agg1 = agg.copy()
+    for i in range(nn):
+        if agg[i] >= 0:
+            continue
+        nb, ww = ix[ip[i]:ip[i + 1]], w[ip[i]:ip[i + 1]]
+        best, bw = -1, -1.0
+        for j, x in zip(nb, ww):
+            if agg1[j] >= 0 and x > bw * (1.0 + 1e-10):
+                best, bw = j, x
+        if best >= 0:
+            agg[i] = agg1[best]
+    for i in range(nn):
+        if agg[i] >= 0:
+            continue
+        agg[i] = na
+        for j in ix[ip[i]:ip[i + 1]]:
+            if agg[j] < 0:
+                agg[j] = na
+        na += 1
+    return agg, na
+
+
+def _sa_level(A, Bn, bs, theta, omega):
+    """One coarsening step: (P, A_c, B_c, lambda_max(D^-1 A))."""
+    n = A.shape[0]
+    nn, m = n // bs, Bn.shape[1]
+    A = A.tocsr()
+    # block Frobenius norms on the node graph
+    Ac = A.tocoo()
+    S2 = sp.coo_matrix((Ac.data ** 2, (Ac.row // bs, Ac.col // bs)), shape=(nn, nn)).tocsr()
+    S2.sum_duplicates()
+    S2.sort_indices()
+    dg = np.sqrt(S2.diagonal())
+    Sc = S2.tocoo()
+    sv = np.sqrt(Sc.data)
+    keep = (Sc.row != Sc.col) & (sv > theta * np.sqrt(dg[Sc.row] * dg[Sc.col])) & (sv > 0.0)
+    S = sp.csr_matrix((sv[keep], (Sc.row[keep], Sc.col[keep])), shape=(nn, nn))
+    S.sort_indices()
+    agg, na = sa_aggregate(S)
+    # tentative prolongation: per aggregate, modified Gram-Schmidt (twice) of the near-kernel restricted to it; a column that is (numerically) dependent there is dropped
+    order = np.argsort(agg, kind="stable")
+    start = np.concatenate([[0], np.cumsum(np.bincount(agg, minlength=na))])
+    rows, cols, vals = [], [], []
+    Bc = np.zeros((na * m, m))
+    for a in range(na):
+        nodes = order[start[a]:start[a + 1]]
+        dofs = (nodes[:, None] * bs + np.arange(bs)[None, :]).ravel()
+        V = Bn[dofs, :].copy()
+        for k in range(m):
+            n0 = np.linalg.norm(V[:, k])
+            for _ in range(2):
+                for j in range(k):
+                    V[:, k] -= (V[:, j] @ V[:, k]) * V[:, j]
+            nk = np.linalg.norm(V[:, k])
+            if n0 == 0.0 or nk <= 1e-8 * n0:
+                V[:, k] = 0.0  # dependent on the earlier columns over this aggregate (fewer than 3 non-collinear nodes): a dead coarse dof
+            else:
+                V[:, k] /= nk
+        Bc[a * m:(a + 1) * m, :] = V.T @ Bn[dofs, :]  # B_a = Q (Q' B_a): the coarse near-kernel
+        rr, cc = np.meshgrid(dofs, a * m + np.arange(m), indexing="ij")
+        nz = V != 0.0
+        rows.append(rr[nz]), cols.append(cc[nz]), vals.append(V[nz])
+    Pt = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, na * m))
+    lam = _lambda_max_dinv_a_fixed(A)
+    d = A.diagonal()
+    dinv = np.where(d != 0.0, 1.0 / np.where(d != 0.0, d, 1.0), 1.0)
+    P = (Pt - sp.diags(omega / lam * dinv) @ (A @ Pt)).tocsr()
+    P.sort_indices()
+    Acn = (P.T @ A @ P).tocsr()
+    Acn = (0.5 * (Acn + Acn.T)).tolil()
+    dead = np.nonzero(np.asarray(abs(Pt).sum(axis=0)).ravel() == 0.0)[0]
+    for k in dead:
+        Acn[k, k] = 1.0
+    Acn = Acn.tocsr()
+    Acn.sort_indices()
+    return P, Acn, Bc, lam
+
+
+def sa_mg_hierarchy(blocks, nns, ndof=3, max_coarse=1500, max_levels=8, theta=0.0, omega=4.0 / 3.0, singular=None):
+    """Smoothed-aggregation hierarchy (Vanek, Mandel, Brezina 1996) for a block-diagonal matrix whose blocks have NO structure to lean on: per level the node graph
+    (ndof dofs per node on the fine level, one node per aggregate with m = near-kernel dimension dofs below), greedy aggregates, the tentative prolongation that
+    reproduces the near-kernel vectors nns[b] (m x n_b: the rigid-body modes of an elasticity block -- for a floating TFETI block its kernel R_b) exactly,
+    one damped-Jacobi smoothing step P = (I - omega / lambda_max D^-1 A) P_t, Galerkin operators.  Same dict as box_mg_hierarchy (input of MatInv.set_pc_mg /
+    oracle.mg_host).  singular[b] (default: A_b nns_b' = 0 numerically): the coarsest operator of block b keeps nns as its kernel and gets a pseudo-inverse."""
+    per_block = []
+    for b, (Kb, Nb) in enumerate(zip(blocks, nns)):
+        A, P, lam = [Kb.tocsr()], [], []
+        Bn = np.asarray(Nb, dtype=np.float64).T.copy()
+        bs = ndof
+        sing = (np.abs(Kb @ Bn).max() <= 1e-9 * abs(Kb).max() * max(np.abs(Bn).max(), 1e-300)) if singular is None else bool(singular[b])
+        Bl = [Bn]
+        per_block.append([A, P, lam, Bl, sing, bs])
+    # all blocks get the SAME number of levels: that of the block that needs most
+    done = False
+    while not done:
+        done = True
+        if len(per_block[0][0]) >= max_levels:
+            break
+        if max(pb[0][-1].shape[0] for pb in per_block) <= max_coarse:
+            break
+        for pb in per_block:
+            A, P, lam, Bl, sing, bs = pb
+            Pn, Ac, Bc, lm = _sa_level(A[-1], Bl[-1], bs, theta * (0.5 ** (len(A) - 1)), omega)
+            P.append(Pn), A.append(Ac), Bl.append(Bc), lam.append(lm)
+            pb[5] = Bl[0].shape[1]  # below the fine level a node is an aggregate with m dofs
+        done = False
+    nlev = len(per_block[0][0])
+    out = dict(A=[], P=[], lambda_max=[])
+    for l in range(nlev):
+        Al = sp.block_diag([pb[0][l] for pb in per_block], format="csr")
+        Al.sort_indices()
+        out["A"].append(Al)
+        if l + 1 < nlev:
+            Pl = sp.block_diag([pb[1][l] for pb in per_block], format="csr")
+            Pl.sort_indices()
+            out["P"].append(Pl)
+            out["lambda_max"].append(max(pb[2][l] for pb in per_block))
+    sizes = [pb[0][-1].shape[0] for pb in per_block]
+    out["coarse_rowstart"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    out["coarse_pinv"] = np.concatenate([np.linalg.pinv(pb[0][-1].toarray(), rcond=1e-10, hermitian=True).ravel() for pb in per_block])
+    return out

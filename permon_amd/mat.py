@@ -200,6 +200,26 @@ class MatInv:
         check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, h))
         return self.mg
 
+    def set_pc_mg_sa(self, K, ndof, R=None, nns=None, max_coarse=1500, theta=0.08, degree=2, precision="fp64"):
+        """The V-cycle PC with an ALGEBRAIC hierarchy built inside libpermonhip (pmh_mg_create_sa, host C++: smoothed aggregation) -- blocks of any shape, no boxes,
+        no caller-supplied P.  K = the scipy CSR this MATINV works on; R = (kdim, n) kernel vectors (zero over non-singular blocks) or None; nns = (m, n)
+        near-kernel vectors for the non-singular blocks or None (the ndof translations)."""
+        K = K.tocsr()
+        K.sort_indices()
+        ip, ci, va = np.ascontiguousarray(K.indptr, dtype=np.int32), np.ascontiguousarray(K.indices, dtype=np.int32), np.ascontiguousarray(K.data, dtype=np.float64)
+        rs = np.ascontiguousarray(self._rowstart(), dtype=np.int32)
+        Rm = np.ascontiguousarray(R, dtype=np.float64) if R is not None and np.size(R) else None
+        Nm = np.ascontiguousarray(nns, dtype=np.float64) if nns is not None and np.size(nns) else None
+        h = C.c_void_p()
+        check(self.ctx.L.pmh_mg_create_sa(self.ctx.h, self.K.K.h, rs.size - 1, rs.ctypes.data_as(C.c_void_p), int(ndof), ip.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                          va.ctypes.data_as(C.c_void_p), Rm.shape[0] if Rm is not None else 0, Rm.ctypes.data_as(C.c_void_p) if Rm is not None else None,
+                                          Nm.shape[0] if Nm is not None else 0, Nm.ctypes.data_as(C.c_void_p) if Nm is not None else None, int(max_coarse), float(theta), int(degree),
+                                          {"fp64": 0, "fp32": 1, "fp16": 2}[precision], C.byref(h)))
+        self.mg = MG.__new__(MG)
+        self.mg.ctx, self.mg.h, self.mg.precision = self.ctx, h, precision
+        check(self.ctx.L.pmh_matinv_set_pc_mg(self.h, h))
+        return self.mg
+
     def _rowstart(self):
         return self.K.block_rowstart
 
