@@ -85,6 +85,10 @@ def parse():
     ap.add_argument("--general-nel", type=int, default=43, help="feti at N=1: elements per edge of the secondary 'general' block (8 subdomains of 8 different materials: no two blocks congruent; one class per block, "
                     "each on the closure of its touched set under the cube's 48 symmetries -> one K^+ solve per orbit: 43 -> ~15 s of set-up; with --no-explicit-symmetry every column of every W_b by its own "
                     "K^+ solve: 21 -> ~20 s, 43 -> minutes); 0 = skip")
+    ap.add_argument("--partition", choices=["", "staircase", "lshape"], default="", help="feti: cut the (2 nel)^3-element cube into 8 subdomains that are NOT boxes (permon_amd.feti.irregular_partition: staircase "
+                    "interfaces / L-shaped bodies) instead of the 2 x 2 x 2 cubes: no congruence, no symmetry, no box hierarchy -- K^+ on the algebraic hierarchy (pmh_mg_create_sa), per-block explicit operators (k_fx_symv)")
+    ap.add_argument("--nosym-nel", type=int, default=21, help="feti at N=1: half the elements per edge of the secondary 'general_nosym' block (the irregular 'staircase' partition of a (2 nel)^3-element cube; "
+                    "every column of every W_b by its own K^+ solve, 8 per block at a time: 21 -> seconds, 43 -> ~2 min of set-up); 0 = skip")
     ap.add_argument("--c2-steps", type=int, default=2500, help="feti at N=1: MPGP iterations of the secondary configs[1] block (from x0 = 0 the first ~hundreds of iterations are pure CG; the expansion steps start once the iterate reaches the obstacle)")
     ap.add_argument("--no-configs3", action="store_true", help="feti at N=1: skip the secondary configs[3] block (4x4x4 subdomains of 21^3 elements, dense 384 x 384 coarse problem)")
     ap.add_argument("--no-svm", action="store_true", help="feti at N=1: skip the secondary configs[4] block (5 M x 64 SVM dual)")
@@ -701,8 +705,17 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     young = None
     if getattr(a, "young", ""):
         young = [1.0 + 0.25 * i for i in range(nsub)] if a.young == "distinct" else [float(v) for v in a.young.split(",")]
-    f = pa.CubeFeti(sub, a.nel, contact=True, young=young)
-    congruent = f.congruent
+    partition = getattr(a, "partition", "")
+    if partition:  # the (2 nel)^3-element cube re-cut into 8 subdomains that are NOT boxes (staircase interfaces / L-shapes): no congruence, no symmetry, no box hierarchy
+        from permon_amd import feti as _feti
+
+        if sub != (2, 2, 2):
+            raise SystemExit("--partition cuts the 2,2,2 cube")
+        f = _feti.MeshFeti(_feti.irregular_partition(a.nel, partition), contact=True, young=young)
+        congruent = False
+    else:
+        f = pa.CubeFeti(sub, a.nel, contact=True, young=young)
+        congruent = f.congruent
     implicit = orth and a.orth_form == "implicit"
     G, e = f.coarse(orthonormalize=orth and not implicit)  # implicit: G0 = R'B', e0; the library orthonormalises (pmh_qppf_create orthonormal = 2)
     if nsub % world:
@@ -732,9 +745,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
 
     # the V-cycle hierarchy of the GPU solver is built inside the library (pmh_mg_create_box, host C++); the scipy builder is only
     # run where its output is needed on the host: the CPU baseline leg (rank 0 at N = 1) and --mg-builder python
-    need_py_hier = a.kplus_pc == "mg" and (a.mg_builder == "python" or a.regularize or (world == 1 and not a.sim_world and not a.no_cpu_baseline))
+    need_py_hier = a.kplus_pc == "mg" and not partition and (a.mg_builder == "python" or a.regularize or (world == 1 and not a.sim_world and not a.no_cpu_baseline))
     hier = make_hier(blocks, per) if need_py_hier else None
-    use_c_builder = a.kplus_pc == "mg" and a.mg_builder == "c" and not a.regularize
+    use_c_builder = a.kplus_pc == "mg" and (a.mg_builder == "c" or bool(partition)) and not a.regularize
+    mg_sa = dict(ndof=3, max_coarse=3 * (a.mg_min_nodes or 500), theta=0.08) if (partition and use_c_builder) else None  # blocks that are not boxes: the algebraic hierarchy (pmh_mg_create_sa)
 
     def mg_box(nblk):
         # (explicit K^+: the rank's own inner-Krylov solver only serves a handful of set-up products -- d = B K^+ f, the replica's columns come from the replica solver --
@@ -766,6 +780,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         explicit = dict(rtol=a.explicit_rtol, storage=a.explicit_storage, min_slots=0 if (a.regularize or not congruent) else a.explicit_slots, solver_factory=None if (a.regularize or not congruent) else solver_factory)
         if not a.no_explicit_symmetry and not a.regularize and congruent:  # used by the class-shared storages only
             explicit["symmetry"] = dict(dims=(a.nel + 1,) * 3, ndof=3, orbit=a.explicit_storage in ("auto", "class_orbit"))
+        elif partition:
+            explicit["storage"] = "sym"  # nothing to share, nothing to find by symmetry: per-block symmetric tiles (k_fx_symv), every column by its own K^+ solve (8 per block at a time)
         elif not a.no_explicit_symmetry and not a.regularize and not congruent and a.explicit_storage in ("auto", "class_orbit"):  # (several GPUs: every rank its own blocks' classes -- owner computes)
             # cubes of different materials: one class per block, each on the CLOSURE of its touched set under the cube's group (the whole boundary): all 48 operations survive, one K^+
             # solve per orbit instead of one per touched dof, and the apply is the orbit GEMM (one per class) instead of the HBM-bound stream over every full W_b
@@ -775,14 +791,16 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if nshare > 1 and a.explicit_storage != "full" and not a.regularize and not a.no_stripe and congruent:
             # every cube is congruent: each rank takes an even share of 128-row stripes of ALL W_b (the blocks' n_Gamma differ by 1.43 x)
             explicit["stripe"] = (rank, nshare, dict(n_x=f.N, block_rowstart=f.block_rowstart, leaves_row=f.leaves_row, leaves_root=f.leaves_root, leaves_sign=f.leaves_sign))
-    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal="implicit" if implicit else orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if use_c_builder else None,
+    q = FetiDualQP(ctx, local, G, e, f.c, f.lb, orthonormal="implicit" if implicit else orth, kplus_rtol=a.kplus_rtol, mg_hierarchy=None if use_c_builder else hier, mg_box=mg_box(per) if (use_c_builder and not mg_sa) else None, mg_sa=mg_sa,
                    mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3, regularize=a.regularize, explicit=explicit)
     has_mg = a.kplus_pc == "mg"
 
     def switch_mg(precision):
         """Replace the V-cycle of the inner KSP by one in another precision (same hierarchy, same builder)."""
         old = q.Kplus.mg
-        if use_c_builder:
+        if mg_sa:
+            q.Kplus.set_pc_mg_sa(local["K"], 3, R=local["R"], max_coarse=mg_sa["max_coarse"], theta=mg_sa["theta"], degree=a.mg_degree, precision=precision)
+        elif use_c_builder:
             mb = mg_box(per)
             q.Kplus.set_pc_mg_box(local["K"], mb["dims"], 3, R=local["R"], min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=precision)
         else:
@@ -850,10 +868,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         return dt, cnt
 
     want_timing = not os.environ.get("PMH_BENCH_NO_TIMING")
-    full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world and congruent)
+    full_size = (a.nel == 43 and a.sub == "2,2,2" and world == 1 and not a.sim_world and congruent and not partition)
     kreg_text = " on K_reg = MatRegularize(K, R)" if a.regularize else ""
     pc_text = ("multigrid-preconditioned CG (Galerkin V-cycle in %s built by %s, dense coarse solve at <= %d nodes per block, Chebyshev(%d)/Jacobi smoothing)"
-               % (a.mg_precision, "pmh_mg_create_box" if use_c_builder else "permon_amd.feti.box_mg_hierarchy", mg_box(per)["min_nodes"], a.mg_degree)) if has_mg else "Jacobi-CG"
+               % (a.mg_precision, ("pmh_mg_create_sa (smoothed aggregation)" if mg_sa else "pmh_mg_create_box") if use_c_builder else "permon_amd.feti.box_mg_hierarchy", (mg_sa["max_coarse"] // 3) if mg_sa else mg_box(per)["min_nodes"], a.mg_degree)) if has_mg else "Jacobi-CG"
 
     def iterative_pass(nsteps, nwarm, precision):
         """The inner-Krylov K^+ (the reference's iterative MATINV path): block-wise CG with the V-cycle PC in `precision`."""
@@ -934,7 +952,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if world == 1 and not a.sim_world:
             pmc_file = ("r04_pmc_traffic_feti_explicit.json" if (full_size and congruent) else
                         "r04_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
-                        "r04_pmc_traffic_general.json" if (a.nel == 43 and a.sub == "2,2,2" and not congruent) else None)
+                        "r04_pmc_traffic_general.json" if (a.nel == 43 and a.sub == "2,2,2" and not congruent and not partition) else None)
         traffic, tsrc = pmc_lookup(ppref, pmc_file, combine="sum") if pmc_file else (None, "not the configuration of a committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
@@ -1018,6 +1036,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             q.Kplus.mult(rhsv, uv)
         n_x, ms_x, b_x = q.Kplus.timing_get()
         q.Kplus.timing_enable(0)
+        kplus_its = q.Kplus.last_iterations()[0]
         rhsv.free(), uv.free()
         if n_x and q.Kplus.multi_rhs_active():
             gbs = b_x / (ms_x / n_x * 1e-3) / 1e9
@@ -1038,9 +1057,12 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                            "achieved/frac count what HBM delivers (the copy once + x + y); blockdiag_figure_GBs counts every K_i as SURVEY 8d does and is NOT an HBM rate. The HBM-streaming "
                            "product (distinct K_i, a copy each) is the feti_dual_spmv block" % nrep) if nrep > 1 else
                           "one device copy per block: every byte of the block-diagonal product is streamed from HBM once"}
+    if kx is not None:
+        kx["kplus_cg_iterations_random_rhs"] = int(kplus_its)
+        kx["kplus_rtol"] = a.kplus_rtol
     # the north star's "FETI dual SpMV" on HBM at this size: 8 DISTINCT K_i, one device copy each (dual_spmv_hbm)
     dual = None
-    if world == 1 and not a.sim_world and want_timing and not getattr(a, "no_dual_spmv", False) and not getattr(a, "_secondary", False):
+    if world == 1 and not a.sim_world and want_timing and not getattr(a, "no_dual_spmv", False) and not getattr(a, "_secondary", False) and not partition:
         try:
             dual = dual_spmv_hbm(ctx, f)
         except Exception as ex:  # noqa: BLE001 - never at the cost of the headline
@@ -1090,15 +1112,16 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         "value": steps / dt, "ms_per_step": dt / steps * 1e3, "full_solve": full_solve,
         "workload": "%s: 3-D elasticity TFETI, %dx%dx%d cubic subdomains of %d^3 Q1 elements (N=%d dof, K_i %d rows / %d nnz, n_lambda=%d "
                     "incl. %d contact rows), rigid obstacle, SMALXE+MPGP on the dual QP (the real solver loop, restarted when it converges), F = B K^+ B' through %s%s"
-                    % (("configs[2]-like, HETEROGENEOUS (Young's moduli %s: no two subdomain matrices are equal -- the general, non-congruent case)" % ", ".join("%g" % v for v in f.young)) if not congruent else
+                    % (("configs[2]-like, IRREGULAR PARTITION ('%s': the same body cut into 8 subdomains that are not boxes -- no congruence, no symmetry, no box hierarchy; rows per block %d-%d)" % (partition, int(np.diff(f.block_rowstart).min()), int(np.diff(f.block_rowstart).max()))) if partition else
+                       ("configs[2]-like, HETEROGENEOUS (Young's moduli %s: no two subdomain matrices are equal -- the general, non-congruent case)" % ", ".join("%g" % v for v in f.young)) if not congruent else
                        "configs[2]" if (sub == (2, 2, 2) and orth and a.nel == 43) else "configs[3]" if (nsub == 64 and a.nel == 21 and not orth) else "configs[3]-shaped" if nsub == 64 else "configs[2]-like",
-                       sub[0], sub[1], sub[2], a.nel, f.N, f.n_i, f.Ki.nnz, f.n_lambda, f.n_ineq,
+                       sub[0], sub[1], sub[2], a.nel, f.N, int(np.diff(f.block_rowstart).max()), int(max(f.block_K(s_).nnz for s_ in range(f.nsub))), f.n_lambda, f.n_ineq,
                        kplus_text, "" if orth else ", coarse problem: dense %d x %d (GG')^{-1}" % (G.shape[0], G.shape[0])),
         "parallelism": ("%d subdomain block(s) per GPU on %d GPU(s) (K_i, K^+, the set-up solves); dual vectors replicated; one RCCL all-reduce (n_lambda doubles) per F apply" % (per, world))
                        + ("; the dense local dual operators are applied in 128-row stripes dealt evenly over the GPUs (the cubes are congruent: every rank assembles its stripes of every W_b with its own K^+)" if (explicit and "stripe" in explicit) else "")
                        + (" [REHEARSAL --sim-world %d: rank 0's share only, no collective; not a result]" % a.sim_world if (a.sim_world and world == 1) else ""),
         "workload_short": "%s: 3-D elasticity TFETI contact, %dx%dx%d subdomains of %d^3 Q1 elements (N=%d dof, n_lambda=%d), SMALXE+MPGP on the dual QP, F = B K^+ B' with K^+ %s" % (
-            "configs[2]-like heterogeneous" if not congruent else "configs[2]" if (sub == (2, 2, 2) and orth and a.nel == 43) else "configs[3]" if (nsub == 64 and a.nel == 21 and not orth) else "configs[2]-like",
+            ("configs[2]-like, irregular partition '%s'" % partition) if partition else "configs[2]-like heterogeneous" if not congruent else "configs[2]" if (sub == (2, 2, 2) and orth and a.nel == 43) else "configs[3]" if (nsub == 64 and a.nel == 21 and not orth) else "configs[2]-like",
             sub[0], sub[1], sub[2], a.nel, f.N, f.n_lambda, ("explicit (dense local dual operators, storage %s)" % q.explicit_storage) if a.kplus == "explicit" else "iterative (block CG, %s PC)" % a.kplus_pc),
         "parallelism_short": "%d subdomain block(s)/GPU on %d GPU(s), strong scaling; dual vectors replicated, one RCCL all-reduce (n_lambda doubles) per F apply%s" % (
             per, world, " [REHEARSAL --sim-world %d]" % a.sim_world if (a.sim_world and world == 1) else ""),
@@ -1216,18 +1239,24 @@ def compact_line(out, details_path):
             c[k] = _num(out[k])
     if isinstance(out.get("full_solve"), dict):
         c["full_solve"] = {k: _num(out["full_solve"].get(k)) for k in ("solve_seconds", "outer_iterations", "inner_iterations", "reason", "setup_seconds")}
-    for k in ("iterative", "strict_fp64", "general", "configs1", "configs3", "configs4", "reuse_products"):
+    for k in ("iterative", "strict_fp64", "general", "general_nosym", "configs1", "configs3", "configs4", "reuse_products"):
         if k in out:
             c[k] = block(out[k])
     if isinstance(c.get("general"), dict) and isinstance(out["general"], dict) and isinstance(out["general"].get("kplus"), dict):  # the non-congruent block's set-up: K^+ solves and their time
         kp = out["general"]["kplus"]
         c["general"].update({k: kp.get(k) for k in ("storage", "assemble_seconds", "assemble_solves", "assemble_multi_rhs") if kp.get(k) is not None})
+    if isinstance(c.get("general_nosym"), dict) and isinstance(out["general_nosym"], dict) and isinstance(out["general_nosym"].get("kplus"), dict):  # blocks that are not boxes: nothing shared, nothing by symmetry
+        kp = out["general_nosym"]["kplus"]
+        c["general_nosym"].update({k: kp.get(k) for k in ("storage", "assemble_seconds", "assemble_solves", "assemble_multi_rhs") if kp.get(k) is not None})
+        kxn = out["general_nosym"].get("kplus_cg_product") or {}
+        if kxn.get("kplus_cg_iterations_random_rhs") is not None:
+            c["general_nosym"]["kplus_cg_iterations"] = kxn["kplus_cg_iterations_random_rhs"]
     if isinstance(out.get("contact_solve"), dict):
         c["contact_solve"] = {k: out["contact_solve"].get(k) for k in ("setup_seconds", "solve_seconds", "time_to_solution_seconds", "failed") if out["contact_solve"].get(k) is not None}
     c["details"] = os.path.relpath(details_path, ROOT) if details_path.startswith(ROOT) else details_path
     line = json.dumps(c, separators=(",", ":"))
     if len(line) >= 4000:  # never hand the driver a line it cannot take: drop the summaries of the secondary blocks first
-        for k in ("reuse_products", "strict_fp64", "iterative", "general", "contact_solve", "configs4", "configs3", "configs1", "full_solve", "cpu_baseline_iterative"):
+        for k in ("reuse_products", "strict_fp64", "iterative", "general_nosym", "general", "contact_solve", "configs4", "configs3", "configs1", "full_solve", "cpu_baseline_iterative"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) < 4000:
@@ -1458,7 +1487,7 @@ def main():
             import copy
 
             if a.no_c2:  # --no-c2 = the headline alone: no secondary block at all
-                a.general_nel, a.no_configs3, a.no_svm, a.no_contact_solve = 0, True, True, True
+                a.general_nel, a.nosym_nel, a.no_configs3, a.no_svm, a.no_contact_solve = 0, 0, True, True, True
 
             def secondary(name, fn):
                 """A secondary block must never cost the headline: failures are recorded, not raised."""
@@ -1485,6 +1514,10 @@ def main():
                 # the general (non-congruent) path of the explicit operators: 8 subdomains of 8 different materials -> no class sharing, no set-up by symmetry,
                 # per-block symmetric storage applied by k_fx_symv (HBM-bound); every column of every W_b by its own K^+ solve
                 secondary("general", lambda: feti_block(young="distinct", nel=a.general_nel, sub="2,2,2", dense_coarse=False, no_iterative=True, explicit_storage="auto"))
+            if a.nosym_nel and not a.young and not a.partition:
+                # blocks that are NOT boxes (round 6): the same body cut along staircases -- the set-up leans on nothing (algebraic hierarchy, one K^+ column per touched dof, 8 at a time),
+                # the apply is the HBM-bound k_fx_symv over every block's own W_b
+                secondary("general_nosym", lambda: feti_block(partition="staircase", nel=a.nosym_nel, sub="2,2,2", dense_coarse=False, no_iterative=True, explicit_storage="sym", young=""))
             if not a.no_configs3:
                 # BASELINE configs[3]: 4 x 4 x 4 subdomains (64, 8 per GPU at N = 8) of 21^3 elements, G NOT orthonormalised: the projector applies the dense 384 x 384 (G G')^{-1},
                 # G G' assembled on the fp64 matrix cores (coarse_problem.GGt_TFLOPs)

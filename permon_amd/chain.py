@@ -212,6 +212,11 @@ class FetiDualQP:
             except PermonHipError as ex:
                 if getattr(ex, "code", 0) != 4:  # PMH_ERR_SUP: the multi-right-hand-side solver does not apply here
                     raise
+                import os
+                import sys
+
+                if os.environ.get("PMH_MV_VERBOSE") or os.environ.get("PMH_PROGRESS"):
+                    sys.stderr.write("assemble_explicit: one column per block and application (%s)\n" % ex)
                 run(False)
         else:
             run(bool(multi_rhs))

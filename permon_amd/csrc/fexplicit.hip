@@ -823,7 +823,14 @@ extern "C" int pmh_fexplicit_assemble(pmh_fexplicit E, pmh_matinv solver, int ns
   PMH_CHK(pmh_matinv_set_tolerances(solver, rtol, 1e-300, max_it > 0 ? max_it : old_maxit));
   int        rc = PMH_SUCCESS;
   std::vector<int> col(nslots);
+  const bool progress = getenv("PMH_PROGRESS") != nullptr || getenv("PMH_CONTACT_TIMING") != nullptr; // (set-up only: a long assembly says where it is every ~ 20 s)
+  auto       t_prog   = std::chrono::steady_clock::now();
   for (int k = 0; k < nbatch && !rc; k++) {
+    if (progress && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 20.0) {
+      t_prog = std::chrono::steady_clock::now();
+      fprintf(stderr, "  pmh_fexplicit_assemble: batch %d of %d (%d columns per batch), %.0f s\n", k, nbatch, nslots, std::chrono::duration<double>(t_prog - t0).count());
+      fflush(stderr);
+    }
     int *hh = h_idx + (k & 1) * nslots; // pinned staging, alternating halves (every K^+ application synchronises the stream at least once)
     for (int s = 0; s < nslots; s++) hh[s] = -1, col[s] = -1;
     for (int c = 0; c < ncls; c++) {

@@ -143,6 +143,42 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub(int n, const int *
   if (first && hlt) return;
 }
 
+// The same two transfers for prolongations with LONG rows (smoothed aggregation, mgsa.hip: ~ 30 entries per row of P, hundreds per row of P'): a wavefront per coarse
+// row / 8 lanes per fine row, sums by butterfly steps in a fixed order.  Chosen at pmh_mg_create by the average row length of P.
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_restrict_w(int nc, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ t, TV *__restrict__ bc,
+                                                           const TV *__restrict__ dinv_c, TV itheta_c, TV *__restrict__ d_c)
+{
+  if (halt && *halt) return;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * (PMH_BLOCK / 64) + (threadIdx.x >> 6); i < nc; i += gridDim.x * (PMH_BLOCK / 64)) {
+    TV s = (TV)0;
+    for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) s += (TV)val[k] * t[col[k]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+      bc[i] = s;
+      if (dinv_c) d_c[i] = dinv_c[i] * s * itheta_c;
+    }
+  }
+}
+template <typename TV>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mg_prolong_sub8(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col, const TV *__restrict__ val, const TV *__restrict__ xc, TV *__restrict__ x)
+{
+  if (halt && *halt) return;
+  const int lane = threadIdx.x & 7;
+  for (int i0 = blockIdx.x * (PMH_BLOCK / 8); i0 < n; i0 += gridDim.x * (PMH_BLOCK / 8)) { // uniform trip count per workgroup
+    const int i = i0 + (threadIdx.x >> 3);
+    TV        s = (TV)0;
+    if (i < n)
+      for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 8) s += (TV)val[k] * xc[col[k]];
+    s += __shfl_xor(s, 4, 8);
+    s += __shfl_xor(s, 2, 8);
+    s += __shfl_xor(s, 1, 8);
+    if (i < n && lane == 0) x[i] -= s;
+  }
+}
+
 // P = P_node (x) I_3 (nodal prolongation of a 3-dof-per-node problem, e.g. trilinear interpolation of elasticity blocks): one
 // node-level CSR entry serves the three components, so the transfer operators move a third of the index / value bytes.
 // Detected at pmh_mg_create from the entries of P; any other P runs on the scalar kernels above.
@@ -312,6 +348,10 @@ static void mg_restrict(pmh_mg mg, int l, const TV *t, bool with_d0)
   if (Lv.rn_rowptr) {
     const int ncn = Lc.n / 3;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict3<TV>), mg_grid(8 * ncn), dim3(PMH_BLOCK), 0, st, ncn, mg->halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col, (const TV *)Lv.rn_val, t, (TV *)Lc.b, dv, it, dc);
+  } else if (Lv.long_rows) {
+    pmh_csr R = Lv.P->transpose;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict_w<TV>), mg_grid(64LL * Lc.n > 0x7fffffff ? 0x7fffffff : 64 * Lc.n), dim3(PMH_BLOCK), 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, t,
+                       (TV *)Lc.b, dv, it, dc);
   } else {
     pmh_csr R = Lv.P->transpose;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_restrict<TV>), mg_grid(8 * (long long)Lc.n > 0x7fffffff ? 0x7fffffff : 8 * Lc.n), dim3(PMH_BLOCK), 0, st, Lc.n, mg->halt, (const int *)R->d_rowptr, (const int *)R->d_col, (const TV *)Lv.rv, t,
@@ -326,6 +366,8 @@ static void mg_prolong_sub(pmh_mg mg, int l, TV *x)
   hipStream_t st = mg->ctx->stream;
   if (Lv.pn_rowptr)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub3<TV>), mg_grid(Lv.n / 3), dim3(PMH_BLOCK), 0, st, Lv.n / 3, mg->halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col, (const TV *)Lv.pn_val, (const TV *)Lc.x, x);
+  else if (Lv.long_rows)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub8<TV>), mg_grid(8LL * Lv.n > 0x7fffffff ? 0x7fffffff : 8 * Lv.n), dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, x);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mg_prolong_sub<TV>), mg_grid(Lv.n), dim3(PMH_BLOCK), 0, st, Lv.n, mg->halt, (const int *)Lv.P->d_rowptr, (const int *)Lv.P->d_col, (const TV *)Lv.pv, (const TV *)Lc.x, x);
 }
@@ -603,6 +645,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32/FP16 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
       }
       if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches only
+      Lv.long_rows = P[l]->nrows > 0 && (double)P[l]->nnz / P[l]->nrows > 12.0;
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
       stage("transpose of the prolongation", l);
       Lv.pv = P[l]->d_val, Lv.rv = P[l]->transpose->d_val;

@@ -12,6 +12,7 @@ struct mg_level {
   void    *pv, *rv;       // values of P and P' in the cycle's precision (fp32 copies: 8 instead of 12 bytes per entry; the
                           // trilinear weights 1, 1/2, 1/4, 1/8 are exact in any precision), or the CSR's own fp64 arrays
   bool     pv_owned;
+  bool     long_rows = false; // P has > 12 entries per row on average (an aggregation hierarchy): the wavefront-per-row transfer kernels
   // node-level copies of P and P' when P = P_node (x) I_3 (cycle precision values), else NULL
   int     *pn_rowptr, *pn_col, *rn_rowptr, *rn_col;
   void    *pn_val, *rn_val;

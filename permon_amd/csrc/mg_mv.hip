@@ -12,9 +12,11 @@
 
 #define MV_R PMH_MV_R
 typedef float mvg_flt4 __attribute__((ext_vector_type(4)));
+static_assert(MV_R == 8, "k_mvg_restrict_s: 8 entry groups x 8 columns per wavefront");
 
 struct mg_mv_level {
   pmh_mv_ell E = nullptr;
+  pmh_mv_ell EP = nullptr, ER = nullptr; // a prolongation that is not node-wise as 3 x 3 blocks: -P and P' (fp32 entries), else NULL (node-wise / scalar kernels)
   float     *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xa = nullptr;
 };
 struct pmh_mg_mv_s {
@@ -98,13 +100,20 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict_s(int nc, const int 
                         const float *__restrict__ val, const float *__restrict__ t, float *__restrict__ bc, const float *__restrict__ dinv_c, float itheta_c,
                         float *__restrict__ d_c)
 {
+  // a row of P' has hundreds of entries (the dofs of an aggregate and of its neighbours' rims): ONE wavefront per coarse row, lane (entry group g, column r), the 8 groups
+  // summed by three butterfly steps (a fixed order) -- one lane per (row, column) walked the row alone: 330 us per launch where the operator products take 55
   if (halt && *halt) return;
-  const int r = threadIdx.x % MV_R;
-  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < nc; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+  const int lane = threadIdx.x & 63, r = lane % MV_R, g = lane / MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / 64) + (threadIdx.x >> 6); i < nc; i += gridDim.x * (PMH_BLOCK / 64)) {
     float s = 0.f;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) s += val[k] * t[(size_t)col[k] * MV_R + r];
-    bc[(size_t)i * MV_R + r] = s;
-    if (dinv_c) d_c[(size_t)i * MV_R + r] = dinv_c[i] * s * itheta_c;
+    for (int k = rowptr[i] + g; k < rowptr[i + 1]; k += 64 / MV_R) s += val[k] * t[(size_t)col[k] * MV_R + r];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0) {
+      bc[(size_t)i * MV_R + r] = s;
+      if (dinv_c) d_c[(size_t)i * MV_R + r] = dinv_c[i] * s * itheta_c;
+    }
   }
 }
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_prolong_sub_s(int n, const int *__restrict__ halt, const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -169,7 +178,7 @@ int pmh_mg_mv_destroy(pmh_mg_mv M)
   if (!M) return PMH_SUCCESS;
   pmh_ctx ctx = M->ctx;
   for (auto &l : M->L) {
-    pmh_mv_ell_destroy(l.E);
+    pmh_mv_ell_destroy(l.E), pmh_mv_ell_destroy(l.EP), pmh_mv_ell_destroy(l.ER);
     pmh_free(ctx, l.x), pmh_free(ctx, l.b), pmh_free(ctx, l.r), pmh_free(ctx, l.d), pmh_free(ctx, l.t), pmh_free(ctx, l.xa);
   }
   delete M;
@@ -230,8 +239,13 @@ int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep)
       rc = pmh_mv_ell_create_prefix(Lv.A, nrep, Lv.Ab->storage == PMH_BSR_F64 ? PMH_BSR_F32 : Lv.Ab->storage, &Ml.E);
       if (!rc && !Ml.E) {
         pmh_mg_mv_destroy(M);
-        pmh_mv_set_why("a level operator has rows with unsorted columns or more than 96 blocks of 3 x 3 in a block row");
+        pmh_mv_set_why("a level operator has rows with unsorted columns or more than 2048 blocks of 3 x 3 in a block row");
         return PMH_EPI_UNSUPPORTED;
+      }
+      if (!rc && !(Lv.pn_rowptr && Lv.rn_rowptr) && Lv.P->ncols % 3 == 0) { // aggregation hierarchy: P couples a fine node to the 6 dofs of a few aggregates -- two 3 x 3 blocks each
+        rc = pmh_mv_ell_create_rect(Lv.P, PMH_BSR_F32, 1, &Ml.EP);
+        if (!rc && Ml.EP) rc = pmh_mv_ell_create_rect(Lv.P->transpose, PMH_BSR_F32, 0, &Ml.ER);
+        if (!rc && !Ml.ER) pmh_mv_ell_destroy(Ml.EP), Ml.EP = nullptr; // (both or none: the scalar kernels otherwise)
       }
       for (float **v : {&Ml.r, &Ml.d, &Ml.t, &Ml.xa})
         if (!rc) rc = pmh_malloc(ctx, sizeof(float) * nR, (void **)v);
@@ -286,16 +300,26 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   const bool cf  = l + 2 < mg->nlevels; // the coarse level is a smoothed one: its d0 rides on the restriction
   const int  ncn = Lc.n / 3 / nrep;
   const bool nodal = Lv.rn_rowptr != nullptr;
-  if (nodal)
+  if (Ml.ER) {
+    pmh_mv_epi<float> er;
+    memset(&er, 0, sizeof(er));
+    if (cf) er.dinv = (const float *)Lc.dinv, er.d = Mc.d, er.c0 = (float)(1.0 / Lc.theta);
+    PMH_CHK(pmh_mv_spmv_f32(Ml.ER, Ml.t, Mc.b, PMH_MV_EPI_RESTRICT, &er, halt));
+  } else if (nodal)
     hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
                        (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
                        cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   else
-    hipLaunchKernelGGL(k_mvg_restrict_s, mvg_grid((long long)Lc.n * MV_R), blk, 0, st, Lc.n, halt, (const int *)Lv.P->transpose->d_rowptr, (const int *)Lv.P->transpose->d_col,
+    hipLaunchKernelGGL(k_mvg_restrict_s, mvg_grid((long long)Lc.n * 64), blk, 0, st, Lc.n, halt, (const int *)Lv.P->transpose->d_rowptr, (const int *)Lv.P->transpose->d_col,
                        (const float *)Lv.rv, (const float *)Ml.t, Mc.b,
                        cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   PMH_CHK(mvg_cycle(M, l + 1, nullptr, nullptr, cf, halt));
-  if (nodal)
+  if (Ml.EP) {
+    pmh_mv_epi<float> ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.y1 = Ml.xa;
+    PMH_CHK(pmh_mv_spmv_f32(Ml.EP, Mc.x, Ml.xa, PMH_EPI_ADD, &ep, halt)); // xa += (-P) x_c
+  } else if (nodal)
     hipLaunchKernelGGL(k_mvg_prolong_sub, mvg_grid((long long)(n_l / 3) * MV_R), blk, 0, st, n_l / 3, halt, (const int *)Lv.pn_rowptr, (const int *)Lv.pn_col,
                        (const float *)Lv.pn_val, (const float *)Mc.x, Ml.xa);
   else

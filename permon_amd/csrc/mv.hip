@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_absmax(long long nnz, const do
 
 template <typename TM>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
-                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval)
+                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval, int rect)
 {
   const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (br >= nbr) return;
@@ -86,11 +86,11 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const
   };
   const int    n = mv_walk(br, rowptr, col, val, put);
   const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = n; s < W; s++) put(s, br, z); // padding: the row's own block column, zero entries
+  for (int s = n; s < W; s++) put(s, rect ? 0 : br, z); // padding: the row's own block column (a rectangular matrix: block column 0), zero entries
 }
 // fp16: one vector of 4 halves per block row q (the 4th is zero)
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
-                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval)
+                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval, int rect)
 {
   const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (br >= nbr) return;
@@ -105,19 +105,22 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, con
   };
   const int    n = mv_walk(br, rowptr, col, val, put);
   const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = n; s < W; s++) put(s, br, z);
+  for (int s = n; s < W; s++) put(s, rect ? 0 : br, z);
 }
 
+static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, pmh_mv_ell *out);
 int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out) { return pmh_mv_ell_create_prefix(A, 1, storage, out); }
+int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out) { return mv_ell_build(A, nrep, storage, 0, 0, out); }
+int pmh_mv_ell_create_rect(pmh_csr A, int storage, int negate, pmh_mv_ell *out) { return mv_ell_build(A, 1, storage, 1, negate, out); }
 
 // nrep > 1: A is block diagonal with nrep congruent blocks (the caller has verified it): the ELL copy of its FIRST block (rows / columns [0, n / nrep), nnz /
-// nrep entries)
-int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
+// nrep entries).  rect: A may be rectangular (3 | rows, 3 | columns).  negate: the copy holds -A
+static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, pmh_mv_ell *out)
 {
-  PMH_ARG(A && out && nrep >= 1 && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16));
+  PMH_ARG(A && out && nrep >= 1 && (storage == PMH_BSR_F64 || storage == PMH_BSR_F32 || storage == PMH_BSR_F16) && !(rect && nrep > 1));
   *out        = nullptr;
   pmh_ctx ctx = A->ctx;
-  if (A->nrows != A->ncols || A->nrows % (3 * nrep) || A->nrows == 0 || A->nnz % nrep) return PMH_SUCCESS;
+  if ((!rect && A->nrows != A->ncols) || A->ncols % 3 || A->nrows % (3 * nrep) || A->nrows == 0 || A->nnz % nrep) return PMH_SUCCESS;
   const int       nbr  = A->nrows / 3 / nrep;
   const long long nnzb = A->nnz / nrep;
   hipStream_t st  = ctx->stream;
@@ -128,12 +131,16 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
                      d_info);
   int info[2];
   PMH_CHK(pmh_memcpy_d2h(ctx, info, d_info, sizeof(info)));
-  if (info[1] || info[0] < 1 || info[0] > 96) { // (32 until round 6: the coarse operators of an aggregation hierarchy couple an aggregate's two 3 x 3 block rows to ~ 27 x 2 block columns)
+  // (32 slots until round 6: the coarse operators of an aggregation hierarchy couple an aggregate's two 3 x 3 block rows to 50 ... 150 block columns, and the small levels
+  // near the bottom of such a hierarchy are almost dense: up to 2048 slots, as long as the padded copy stays under 2 GB)
+  if (info[1] || info[0] < 1 || info[0] > 2048 || (double)((info[0] + 15) / 16 * 16) * nbr * 76.0 > 2.0e9) {
     pmh_free(ctx, d_info);
     return PMH_SUCCESS;
   }
   pmh_mv_ell E = new pmh_mv_ell_s();
-  E->ctx = ctx, E->nbr = nbr, E->W = (info[0] + 3) / 4 * 4, E->storage = storage, E->scale = 1.0, E->col = nullptr, E->val = nullptr;
+  E->ctx = ctx, E->nbr = nbr, E->storage = storage, E->scale = 1.0, E->col = nullptr, E->val = nullptr;
+  E->lpr = info[0] > 48 ? 16 : 4;
+  E->W   = (info[0] + E->lpr - 1) / E->lpr * E->lpr;
   double inv_scale = 1.0;
   if (storage == PMH_BSR_F16) { // power-of-two scale that brings the largest entry to [1, 2) (as pmh_bsr3_from_csr)
     PMH_HIP(hipMemsetAsync(d_info, 0, sizeof(unsigned long long) * 2, st));
@@ -144,7 +151,8 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
     if (amax > 0.0) frexp(amax, &ex);
     E->scale  = ldexp(1.0, ex - 1);
     inv_scale = 1.0 / E->scale;
-  }
+    if (negate) E->scale = -E->scale;
+  } else if (negate) inv_scale = -1.0;
   pmh_free(ctx, d_info);
   const size_t nslot = (size_t)E->W * nbr;
   const dim3   g((nbr + PMH_BLOCK - 1) / PMH_BLOCK), blk(PMH_BLOCK);
@@ -156,11 +164,11 @@ int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out)
     return rc;
   }
   if (storage == PMH_BSR_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<double>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
-                          (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (double *)E->val);
+                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (double *)E->val, rect);
   else if (storage == PMH_BSR_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<float>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
-                          (const int *)A->d_col, (const double *)A->d_val, 1.0, E->col, (float *)E->val);
+                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (float *)E->val, rect);
   else hipLaunchKernelGGL(k_mv_ell_fill_h, g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale,
-                          E->col, (mv_half4 *)E->val);
+                          E->col, (mv_half4 *)E->val, rect);
   PMH_HIP(hipGetLastError());
   *out = E;
   return PMH_SUCCESS;
@@ -209,7 +217,7 @@ template <int N> struct mv_vec<float, N> {
 };
 
 template <typename TM, typename T> struct mv_blk { // the 9 entries of slot 4 g + l, block row br
-  static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9])
+  static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9]) // g: plane (slot >> 2), l: slot & 3
   {
 #pragma unroll
     for (int e = 0; e < 9; e++) a[e] = (T)__builtin_nontemporal_load((const TM *)val + ((g * 9 + e) * nbr + br) * 4 + l);
@@ -226,23 +234,26 @@ template <typename T> struct mv_blk<_Float16, T> {
   }
 };
 
-template <typename TM, typename T, int R, int EPI>
+// LPR lanes per block row (4; 16 for the long rows of an aggregation hierarchy's coarse operators: 7 500 block rows of ~ 80 ... 150 blocks left the chip idle with 4):
+// lane l takes the slots LPR g + l, i.e. plane (LPR / 4) g + (l >> 2), entry l & 3 of the plane
+template <typename TM, typename T, int R, int EPI, int LPR = 4>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale,
                         const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt)
 {
   const int hlt = halt ? *halt : 0;
-  const int tg  = blockIdx.x * PMH_BLOCK + threadIdx.x, br = tg >> 2, l = tg & 3;
-  if (br >= nbr) return; // whole quads
-  int cn = col[(size_t)br * 4 + l];
+  const int tg  = blockIdx.x * PMH_BLOCK + threadIdx.x, br = tg / LPR, lw = tg % LPR, l = lw & 3, pl = lw >> 2;
+  constexpr int PS = LPR / 4; // planes per trip
+  if (br >= nbr) return; // whole groups of LPR lanes
+  int cn = col[((size_t)pl * nbr + br) * 4 + l];
   if (hlt) return;
   T acc[3][R];
 #pragma unroll
   for (int q = 0; q < 3; q++)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[q][r] = (T)0;
-  for (int g = 0; g < W4; g++) {
+  for (int g = pl; g < W4; g += PS) {
     const int c = cn;
-    if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l]; // the next slot's index travels during this slot's products
+    if (g + PS < W4) cn = col[((size_t)(g + PS) * nbr + br) * 4 + l]; // the next slot's index travels during this slot's products
     T a[9], xv[3 * R];
     mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
     mv_vec<T, 3 * R>::load(x + (size_t)3 * c * R, xv);
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
 #pragma unroll
       for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
   }
-  // the quad's four partial sums: (l0 + l1) + (l2 + l3) on every lane
+  // the group's partial sums: (l0 + l1) + (l2 + l3) [+ the other planes' quads] on every lane
 #pragma unroll
   for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -259,9 +270,11 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
       T v = acc[q][r];
       v += __shfl_xor(v, 1, 64);
       v += __shfl_xor(v, 2, 64);
+      if (LPR > 4) v += __shfl_xor(v, 4, 64);
+      if (LPR > 8) v += __shfl_xor(v, 8, 64);
       acc[q][r] = v;
     }
-  if (l == 3) return;
+  if (lw >= 3) return;
   // lane l finishes row 3 br + l: R contiguous values
   const size_t o = ((size_t)3 * br + l) * R;
   T            out[R], t1[R], t2[R];
@@ -274,6 +287,14 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
     mv_vec<T, R>::load(e.y1 + o, t1);
 #pragma unroll
     for (int k = 0; k < R; k++) out[k] = (EPI == PMH_EPI_ADD) ? t1[k] + out[k] : out[k] - t1[k];
+  }
+  if (EPI == PMH_MV_EPI_RESTRICT) { // the coarse level's first smoothing direction d = dinv y c0
+    if (e.d) {
+      const T di = e.dinv[3 * br + l] * e.c0;
+#pragma unroll
+      for (int k = 0; k < R; k++) t1[k] = di * out[k];
+      mv_vec<T, R>::store(e.d + o, t1);
+    }
   }
   if (EPI == PMH_BSR_EPI_PRE) { // y = c0 d0 + c2 dinv (b - A d0)
     mv_vec<T, R>::load(e.y1 + o, t1);
@@ -315,13 +336,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
 template <typename TM, typename T>
 static int mv_launch(pmh_mv_ell E, const T *x, T *y, int epi, const pmh_mv_epi<T> *ep, const int *halt)
 {
-  const dim3    g((unsigned)(((long long)E->nbr * 4 + PMH_BLOCK - 1) / PMH_BLOCK)), blk(PMH_BLOCK);
+  const dim3    g((unsigned)(((long long)E->nbr * E->lpr + PMH_BLOCK - 1) / PMH_BLOCK)), blk(PMH_BLOCK);
   hipStream_t   st = E->ctx->stream;
   pmh_mv_epi<T> e;
   if (ep) e = *ep;
   else memset(&e, 0, sizeof(e));
   const T sc = (T)E->scale;
-#define MV_LAUNCH(EPI) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt)
+#define MV_LAUNCH(EPI) \
+  do { \
+    if (E->lpr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 16>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 4>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt); \
+  } while (0)
   switch (epi) {
   case PMH_EPI_NONE: MV_LAUNCH(PMH_EPI_NONE); break;
   case PMH_EPI_ADD: MV_LAUNCH(PMH_EPI_ADD); break;
@@ -329,6 +354,7 @@ static int mv_launch(pmh_mv_ell E, const T *x, T *y, int epi, const pmh_mv_epi<T
   case PMH_BSR_EPI_PRE: MV_LAUNCH(PMH_BSR_EPI_PRE); break;
   case PMH_BSR_EPI_POST1: MV_LAUNCH(PMH_BSR_EPI_POST1); break;
   case PMH_BSR_EPI_POST2: MV_LAUNCH(PMH_BSR_EPI_POST2); break;
+  case PMH_MV_EPI_RESTRICT: MV_LAUNCH(PMH_MV_EPI_RESTRICT); break;
   default: return pmh_set_error(PMH_ERR_ARG, "mv: unsupported epilogue %d", epi);
   }
 #undef MV_LAUNCH

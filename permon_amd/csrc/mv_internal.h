@@ -19,6 +19,7 @@
 struct pmh_mv_ell_s {
   pmh_ctx ctx;
   int     nbr, W, storage; // PMH_BSR_F64 / F32 / F16
+  int     lpr = 4;         // lanes per block row of the product: 4, or 16 where the rows are long (W > 48: the coarse operators of an aggregation hierarchy); W is a multiple of it
   int    *col;
   void   *val;
   double  scale;
@@ -32,10 +33,13 @@ template <typename T> struct pmh_mv_epi {
   T        c0, c1, c2;
 };
 
-// *out = NULL without error when A has no regular 3 x 3 block structure (unsorted rows, or more than 32 blocks in a block row)
+// *out = NULL without error when A has no regular 3 x 3 block structure (unsorted rows, or more than 2048 blocks in a block row)
 int pmh_mv_ell_create(pmh_csr A, int storage, pmh_mv_ell *out);
 int pmh_mv_ell_create_prefix(pmh_csr A, int nrep, int storage, pmh_mv_ell *out); // the first of nrep congruent diagonal blocks of A
+// the same copy of a RECTANGULAR matrix of 3 x 3 blocks (a prolongation of an aggregation hierarchy or its transpose: 3 | rows, 3 | columns); negate: the copy holds -A
+int pmh_mv_ell_create_rect(pmh_csr A, int storage, int negate, pmh_mv_ell *out);
 int pmh_mv_ell_destroy(pmh_mv_ell E);
+#define PMH_MV_EPI_RESTRICT 20 // y = A x and, where e.d != NULL, e.d = e.dinv[row] * y * e.c0 (the coarse level's first smoothing direction rides on the restriction)
 // y = A x on multivectors of R = PMH_MV_R columns (x, y: 3 nbr R entries) with the epilogues of k_bsr3 (PMH_EPI_NONE / ADD / SUB, PMH_BSR_EPI_PRE / POST1 /
 // POST2)
 int pmh_mv_spmv_f64(pmh_mv_ell E, const double *x, double *y, int epi, const pmh_mv_epi<double> *e, const int *halt);

@@ -58,10 +58,31 @@ def test_mv_product_against_scipy(ctx, nn, extra, storage):
 
 
 def test_mv_wide_rows_are_refused(ctx):
-    A = sp.csr_matrix(np.ones((3 * 40, 3 * 40)))  # 40 blocks in a block row: more than the 32 slots
-    Ad = pa.CsrMat(ctx, 120, 120, A.indptr, A.indices, A.data)
-    xd, yd = ctx.vec(120 * R), ctx.vec(120 * R)
+    n = 3 * 2050
+    A = sp.csr_matrix(np.ones((n, n)))  # 2050 blocks in a block row: more than the 2048 slots (32 until round 6: an aggregation hierarchy's coarse rows hold 50 ... 600)
+    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+    xd, yd = ctx.vec(n * R), ctx.vec(n * R)
     assert ctx.L.pmh_mv_test_spmv(Ad.h, 0, xd.p, yd.p, 1, None) != 0
+
+
+@pytest.mark.parametrize("storage", [0, 1, 2])
+def test_mv_long_rows_take_16_lanes_per_block_row(ctx, storage):
+    """Block rows of more than 48 blocks (the coarse operators of an aggregation hierarchy) run with 16 lanes per block row (k_mv_spmv<..., 16>): same product."""
+    rng = np.random.default_rng(40 + storage)
+    nb = 90
+    M = rng.standard_normal((3 * nb, 3 * nb)) * (rng.random((3 * nb, 3 * nb)) < 0.8)
+    keep = np.kron((rng.random((nb, nb)) < 0.75).astype(float), np.ones((3, 3)))
+    A = sp.csr_matrix(M * keep + np.eye(3 * nb))
+    A.sort_indices()
+    n = A.shape[0]
+    X = rng.standard_normal((n, R))
+    Ad = pa.CsrMat(ctx, n, n, A.indptr, A.indices, A.data)
+    xd, yd = ctx.vec_from(X.reshape(-1)), ctx.vec(n * R)
+    check(ctx.L.pmh_mv_test_spmv(Ad.h, storage, xd.p, yd.p, 1, None))
+    ref = A @ X
+    tol = {0: 1e-13, 1: 2e-6, 2: 3e-3}[storage]
+    scale = np.abs(A).dot(np.abs(X)).max()
+    assert np.abs(yd.to_numpy().reshape(n, R) - ref).max() <= tol * scale
 
 
 @pytest.mark.parametrize("case", ["floating", "regularized", "odd_box", "jacobi"])
