@@ -62,6 +62,7 @@ static int *knob_by_name(const char *name)
   if (!strcmp(name, "smalxe_prefetch")) return &pmh_knobs().smalxe_prefetch;
   if (!strcmp(name, "mg_d0_fusion")) return &pmh_knobs().mg_d0_fusion;
   if (!strcmp(name, "mpgp_spec")) return &pmh_knobs().mpgp_spec;
+  if (!strcmp(name, "vec_epi")) return &pmh_knobs().vec_epi;
   return nullptr;
 }
 extern "C" int pmh_set_knob(const char *name, int value)

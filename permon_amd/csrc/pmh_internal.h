@@ -21,12 +21,12 @@ int pmh_set_error(int code, const char *fmt, ...);
 // process-wide run-time switches (pmh_set_knob; initial values from the environment, read ONCE)
 struct pmh_knobs_s {
   int chain; // the five-launch dual-space chain (dualchain.hip)
-  // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and the launches they took, the middle stage's included
+  // counters (pmh_get_knob; pmh_set_knob resets them): applications of the chain and its OWN launches (the middle stage's are not counted)
   int chain_applies = 0, chain_launches = 0;
   // A/B switches that sit on per-product / per-iteration paths: the environment is read ONCE (ctx.hip pmh_knobs), never inside a solver loop
   int gt_fusion = 1;       // PMH_NO_GT_FUSION: the projector's v - G'(...) epilogue folded into the G' kernel (qppf.hip)
   int smalxe_prefetch = 1; // PMH_SMALXE_NO_PREFETCH: ||B u|| enqueued before the inner solver's host wait (smalxe.hip)
-  int vec_epi = 1;         // PMH_NO_VEC_EPI: MPGP's vector phase in the operator's last kernel (mpgp.hip; qppf.hip reads the variable itself, once)
+  int vec_epi = 1;         // PMH_NO_VEC_EPI: MPGP's vector phase in the operator's last kernel (mpgp.hip, qppf.hip)
   int mpgp_spec = 1;       // PMH_MPGP_NO_SPEC: batches of device-side CG steps for CSR operators (mpgp.hip)
   int mg_d0_fusion = 1;    // PMH_MG_NO_D0_FUSION: the first smoothing step written by the producer of the right-hand side (feti.hip)
   int kplus_mv = 1;        // PMH_NO_KPLUS_MV: pmh_matinv_mult on 8 congruent blocks runs them as the 8 columns of one block on the multi-right-hand-side kernels (feti.hip)

@@ -780,9 +780,11 @@ struct PenalizedOp : pmh_op_s {
   }
   int mult_epi(const double *x, double *y, const pmh_vec_epi &e) override
   {
-    if (chain()) return pmh_dc_apply(dc, x, y, rho, &e);
-    static const bool off = getenv("PMH_NO_VEC_EPI") != nullptr; // A/B: the separate vector kernels
-    if (off || !fused_dense() || n > PMH_MAX_VEC_BLOCKS * PMH_BLOCK || pmh_vec_grid(n) != (n + PMH_BLOCK - 1) / PMH_BLOCK) return PMH_EPI_UNSUPPORTED;
+    // (the chain leaves its block partials per 1024-entry tile for the HOST to sum: a caller that finalises on the device -- row-distributed scalars, e.hosted == NULL --
+    // counts on one partial per workgroup of the streaming Vec kernels' grid, so it gets the separate vector kernels behind the chain's plain product instead)
+    if (chain()) return e.hosted ? pmh_dc_apply(dc, x, y, rho, &e) : PMH_EPI_UNSUPPORTED;
+    if (!pmh_knobs().vec_epi) return PMH_EPI_UNSUPPORTED; // A/B: the separate vector kernels
+    if (!fused_dense() || n > PMH_MAX_VEC_BLOCKS * PMH_BLOCK || pmh_vec_grid(n) != (n + PMH_BLOCK - 1) / PMH_BLOCK) return PMH_EPI_UNSUPPORTED;
     return mult_fused_dense(x, y, &e);
   }
   ~PenalizedOp() override

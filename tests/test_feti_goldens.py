@@ -217,7 +217,11 @@ def test_gpu_ex71_elasticity_iteration_goldens(ctx, goldens, lumped):
     dq = _dual_qp(ctx, prob)
     st = dq.solve_ksp(rtol=1e-6, lumped=lumped)
     assert st.reason == 2
-    assert abs(st.iteration - _golden_its(goldens, ELAST[lumped])) <= 5
+    # exactly 64 / 26 on this chain (the Moore-Penrose form P_R K^- P_R; the library's arithmetic is deterministic); pmh_kspfeti_solve's default, the LEFT generalised
+    # inverse, takes 64 / 27 (test_gpu_kspfeti.py, = the CPU oracle).  The golden's 66 / 26 ran on MUMPS' null pivots and lies within the +-2 that rounding at the
+    # stopping iteration moves this count by (profiles/r04_ex71_2_residual_history.txt)
+    assert st.iteration == {False: 64, True: 26}[lumped], st.iteration
+    assert abs(st.iteration - _golden_its(goldens, ELAST[lumped])) <= 2
     assert abs(np.linalg.norm(dq.b.to_numpy()) - 204.3) < 0.5
     # solution check: primal residual of the recovered u as the reference's last KKT line (r/||b|| ~ 2e-05)
     u, Fl = dq.primal_solution(None)

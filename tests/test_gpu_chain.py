@@ -111,7 +111,7 @@ def test_chain_smalxe_vs_round4_and_oracle(ctx, oracle, kplus, sub, nel):
     q.qps.Destroy()
     check(ctx.L.pmh_set_knob(b"chain", 1))
     assert (st.reason, st.iteration, st.M1_updates, st.rho_updates) == (st0.reason, st0.iteration, st0.M1_updates, st0.rho_updates)
-    assert abs(st.inner_iter_accu - st0.inner_iter_accu) <= max(2, st0.inner_iter_accu // 50), (inner1, inner0)
+    assert (st.inner_iter_accu,) + inner1 == (st0.inner_iter_accu,) + inner0  # the same steps, one by one (round 6: equality, as in the random sweep)
     assert np.linalg.norm(lam1 - lam0) <= 1e-4 * np.linalg.norm(lam0)
     if nel > 4:
         return
@@ -126,5 +126,30 @@ def test_chain_smalxe_vs_round4_and_oracle(ctx, oracle, kplus, sub, nel):
     A_or = oracle.Op(n, fn=lambda x: pfo.P(F @ pfo.P(x)))
     ref = oracle.smalxe(A_or, q.b.to_numpy(), np.zeros(n), oracle.Box(n, lb=q.lb_new.to_numpy()), pfo)
     assert (st.reason, st.iteration, st.M1_updates, st.rho_updates) == (ref["reason"], ref["iteration"], ref["M1_updates"], ref["rho_updates"])
-    assert abs(st.inner_iter_accu - ref["inner_iter_accu"]) <= max(2, ref["inner_iter_accu"] // 50)
+    assert st.inner_iter_accu == ref["inner_iter_accu"]
     assert np.linalg.norm(lam1 - ref["u"]) <= 1e-4 * np.linalg.norm(ref["u"])
+
+
+def test_chain_with_device_finalised_scalars():
+    """MPGP with row-distributed scalars (`distributed` = 1: every reduction finalised on the DEVICE and all-reduced) on a chained operator: the chain leaves its block
+    partials per 1024-entry tile for the host, so the operator must NOT take the vector phase into its last kernel for such a caller (PenalizedOp::mult_epi answers
+    'unsupported' and MPGP runs its own vector kernels behind the chain's plain product).  On a 1-rank communicator the solve must take exactly the steps of the local mode."""
+    import os
+
+    os.environ["PMH_COMM_FORCE"] = "1"
+    try:
+        c = pa.Context(0)
+        check(c.L.pmh_set_knob(b"chain", 1))
+        c.comm_init(0, 1, c.comm_unique_id())
+        f, G0, q = _problem(c, "orbit")
+        res = []
+        for dist in (0, 1):
+            q.lam.set(0.0)
+            st = q.solve_smalxe(inner=dict(distributed=dist))
+            res.append(((st.reason, st.iteration, st.inner_iter_accu, st.inner.ncg, st.inner.nexp, st.inner.nprop, st.inner.nmv), q.lam.to_numpy().copy()))
+            q.qps.Destroy()
+        assert res[0][0] == res[1][0] and res[0][0][0] > 0
+        assert np.linalg.norm(res[0][1] - res[1][1]) <= 1e-9 * np.linalg.norm(res[0][1])
+        c.close()
+    finally:
+        os.environ.pop("PMH_COMM_FORCE", None)
