@@ -96,11 +96,13 @@ def parse():
     ap.add_argument("--cpu-direct-nel", type=int, default=21, help="feti: subdomain size at which the CPU baseline factors K_reg with scipy's SuperLU (the reference's direct K^+); the 43^3 block itself would take ~20 min and ~10 GB")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="where rank 0 writes the full result object (the stdout line is the compact summary)")
     ap.add_argument("--dry-launch", action="store_true", help="testing: with --gpus N > 1 start the N ranks as usual, but every rank only reports its rendezvous environment and exits (no GPU, no torch)")
+    ap.add_argument("--no-cpu-pool", action="store_true", help="feti at N=1: do not start the worker processes of the configs[3] CPU leg (the reference's op sequence with a direct K^+, timed live)")
     ap.add_argument("--no-dual-spmv", action="store_true", help="feti at N=1: skip the HBM-streaming measurement of MatMult_BlockDiag (8 DISTINCT K_i, one device copy each) at the headline size")
     return ap.parse_args()
 
 
 _HOST_THREADS = None
+CPU_POOL = None  # oracle.direct_pool.DirectPool of the configs[3] CPU leg (started in main() before the GPU is initialised)
 _DIRECT_ROWS = []  # cpu_baseline_direct's measured (nel, n, factor_s, solve_s) rows: the configs[3] block re-uses the measured 21^3 solve
 
 
@@ -480,6 +482,67 @@ def cpu_baseline_feti(f, G, hier, b_dual, lb_dual, its, rtol, orth=True, budget_
     }
 
 
+def cpu_baseline_whole_iteration(pool, ctx, f, G0, b_dual, lb_dual, budget_s=25.0, its_cap=40):
+    """The reference's op sequence for a TFETI contact QP timed LIVE on the host cores, whole iteration: the oracle's SMALXE + MPGP in the
+    reference's unfused operation order (oracle/permon_oracle.c: mpgp.c:511-641, smalxe.c:893-997) on A = P F P (qptransform.c:273-284), F = B K^+ B'
+    (qptransform.c:1103-1128) with B / B' as CSR products (gluing.c:47-159), the projector with the dense (G G')^{-1} (qppf.c:454-605) and the reference's DEFAULT K^+:
+    a sparse direct factorisation of K_reg = MatRegularize(K, R) per block and one forward / backward substitution per block and application (matinv.c:481-580,
+    :734-743) -- SuperLU standing in for PETSc Cholesky / MUMPS, the blocks dealt to `pool.nw` worker processes (the ranks of the reference's run), each holding its own
+    factors.  The blocks are congruent: every worker factors the ONE block matrix.  Sample: ONE outer SMALXE iteration with the inner solve capped so that it fits the budget;
+    value = inner iterations / wall time of the solve call (factorisation reported separately)."""
+    import scipy.sparse as sp
+
+    import permon_amd as pa
+    from oracle import oracle as O
+
+    if not f.congruent:
+        raise ValueError("the live CPU leg factors ONE block matrix: congruent blocks only")
+    nb, n_i, n = f.nsub, f.n_i, f.n_lambda
+    Kreg, _piv, _rho = pa.MatRegularize(ctx, f.Ki, f.R[:, :n_i])
+    t0 = time.perf_counter()
+    fnnz = pool.factor(Kreg)
+    t_fac = time.perf_counter() - t0
+    pool.attach(n_i, nb)
+    B = f.B.tocsr()
+    Bt = B.T.tocsr()
+    G = G0.tocsr()
+    pf = O.Qppf(O.Csr.from_scipy(G), orthonormal=False)
+    stamps = {"kplus": 0.0, "applies": 0}
+
+    def F(v):
+        pool.X[:, :] = (Bt @ v).reshape(nb, n_i)
+        t1 = time.perf_counter()
+        pool.solve()
+        stamps["kplus"] += time.perf_counter() - t1
+        stamps["applies"] += 1
+        return B @ pool.Y.reshape(-1)
+
+    def A(v):
+        return pf.P(F(pf.P(v)))
+
+    op = O.Op(n, fn=A)
+    A(b_dual)  # warm-up (page faults, worker caches)
+    t0 = time.perf_counter()
+    A(b_dual)
+    t_probe = time.perf_counter() - t0
+    its = int(max(3, min(its_cap, budget_s / (2.2 * t_probe))))
+    stamps["kplus"], stamps["applies"] = 0.0, 0
+    t0 = time.perf_counter()
+    ref = O.smalxe(op, b_dual, np.zeros(n), O.Box(n, lb=lb_dual), pf, max_it=1, inner_opts=dict(max_it=its))
+    wall = time.perf_counter() - t0
+    inner = max(1, int(ref["inner_iter_accu"]))
+    return {
+        "value": inner / wall, "unit": "QPS iterations/s", "cores": pool.nw, "kind": "port", "extrapolated": False, "cpu_model": cpu_model(), "measured": "live, this run",
+        "kplus": "sparse direct (the reference's algorithm): SuperLU of K_reg per worker process", "inner_iterations": inner, "operator_applies": stamps["applies"], "wall_seconds": wall,
+        "kplus_share_of_wall": stamps["kplus"] / wall, "factor_seconds_per_worker": t_fac, "factor_entries": int(fnnz),
+        "sample": "WHOLE iteration, measured live: the oracle's SMALXE + MPGP (oracle/permon_oracle.c, the reference's unfused op order) for %d inner iterations (%d applications of A = P F P, one outer update) "
+                  "of this block's dual QP on the host: F = B K^+ B' with CSR B / B' (scipy), the projector with the dense (G G')^{-1} (%d x %d), K^+ = the reference's direct solve -- SuperLU (scipy splu, stand-in "
+                  "for PCCHOLESKY / MUMPS, matinv.c:481-580, :734-743) of K_reg, %d blocks dealt to %d worker processes (one factorisation each, %.1f s, not in the figure), vectors through shared memory; "
+                  "%.2f s wall, %.0f %% of it inside the K^+ solves; %s" % (inner, stamps["applies"], G.shape[0], G.shape[0], nb, pool.nw, t_fac, wall, 100.0 * stamps["kplus"] / wall, cpu_model()),
+        "sample_short": "live: oracle SMALXE+MPGP, %d inner its, direct K^+ (SuperLU) on %d worker processes, B/B'/projector included" % (inner, pool.nw),
+    }
+
+
 def cpu_baseline_direct(ctx, nel_full, nel_factor, applies_per_step, nblocks=8):
     """The reference's own K^+ on the host: MATINV factors K_reg = MatRegularize(K, R) once per block (PCCHOLESKY / MUMPS, src/mat/impls/inv/matinv.c:481-580)
     and every F = B K^+ B' application is one forward / backward substitution per block (MatMult_Inv -> KSPSolve with KSPPREONLY, matinv.c:734-743), one block
@@ -536,8 +599,11 @@ def cpu_baseline_direct(ctx, nel_full, nel_factor, applies_per_step, nblocks=8):
     if once is not None:
         fm, cm = once["full"], once["cal"]
         return {
-            "value": 1.0 / (applies_per_step * once["t_solve_full"]), "unit": "QPS iterations/s", "cores": nblocks, "kind": "port", "cpu_model": cpu_model(), "kplus": "sparse direct (the reference's algorithm)",
-            "extrapolated": False, "measured_once": "profiles/r05_splu_%d.json" % nel_full, "sizes_measured": [r["nel"] for r in rows] + [nel_full],
+            "value": 1.0 / (applies_per_step * once["t_solve_full"] * math.ceil(nblocks / max(1, min(nblocks, host_threads())))), "unit": "QPS iterations/s", "cores": min(nblocks, host_threads()), "kind": "port", "cpu_model": cpu_model(),
+            "kplus": "sparse direct (the reference's algorithm)",
+            # NOT a same-run measurement: the full-size solve time was measured once on another box of this pool and is carried here by a calibration ratio; only the K^+ solves are counted
+            "extrapolated": True, "calibrated_from": "profiles/r05_splu_%d.json x (this run's %d^3 solve / the committed %d^3 solve)" % (nel_full, b["nel"], b["nel"]), "counts": "K+ solves only (B / B', projector and vector work not counted; perfect concurrency of the blocks assumed)",
+            "measured_once": "profiles/r05_splu_%d.json" % nel_full, "sizes_measured": [r["nel"] for r in rows] + [nel_full],
             "solve_seconds_per_block_full_size": once["t_solve_full"], "solve_seconds_per_block_full_size_as_measured": fm["solve_seconds_median"], "factor_seconds_full_size_measured": fm["factor_seconds"],
             "factor_entries_full_size": fm["factor_nnz"], "factor_max_rss_GB": fm["max_rss_GB"], "calibration_ratio_this_host": once["ratio"],
             "solve_seconds_per_block_measured": {("%d^3" % r["nel"]): round(r["solve_s"], 4) for r in rows}, "factor_seconds_measured": {("%d^3" % r["nel"]): round(r["factor_s"], 2) for r in rows},
@@ -553,7 +619,8 @@ def cpu_baseline_direct(ctx, nel_full, nel_factor, applies_per_step, nblocks=8):
                          once["ratio"], once["t_solve_full"], "; ".join("%d^3 (n = %d): factor %.1f s, solve %.4f s" % (r["nel"], r["n"], r["factor_s"], r["solve_s"]) for r in rows), applies_per_step, nblocks, nblocks),
         }
     return {
-        "value": 1.0 / (applies_per_step * t_solve_full), "unit": "QPS iterations/s", "cores": nblocks, "kind": "port", "cpu_model": cpu_model(),
+        "value": 1.0 / (applies_per_step * t_solve_full * math.ceil(nblocks / max(1, min(nblocks, host_threads())))), "unit": "QPS iterations/s", "cores": min(nblocks, host_threads()), "kind": "port", "cpu_model": cpu_model(),
+        "counts": "K+ solves only (B / B', projector and vector work not counted; perfect concurrency of the blocks assumed)",
         "solve_seconds_per_block_measured": {("%d^3" % r["nel"]): round(r["solve_s"], 4) for r in rows}, "factor_seconds_measured": {("%d^3" % r["nel"]): round(r["factor_s"], 2) for r in rows},
         "solve_seconds_per_block_full_size": t_solve_full, "factor_seconds_full_size_extrapolated": t_fac_full, "growth_exponent_solve": expo, "growth_exponent_factor": expo_f,
         "extrapolated": nel_full != b["nel"], "sizes_measured": [r["nel"] for r in rows],
@@ -977,6 +1044,10 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                 "avg_launch_ms": ms_gemm / n_k if n_k else None, "dense_apply_ms": ms_k / n_k if n_k else None, "finishing_kernel_ms": (ms_k - ms_gemm) / n_k if n_k else None,
                 "share_of_step_time": (ms_gemm * 1e-3) / dt if n_k else None, "dense_apply_share_of_step_time": (ms_k * 1e-3) / dt if n_k else None,
                 "frac_dense_apply": (fl_issued / (ms_k / n_k * 1e-3) / 1e12 / 78.6) if n_k else None,
+                # USEFUL flops: what the dense symmetric product y_b = W_b x_b of every block would take, 2 sum_b n_Gamma_b^2 -- the GEMM executes more (padded row tiles, the columns of
+                # operations a row tile lists for only some of its rows) to move 48 x fewer bytes; frac_useful prices the launch on that basis
+                "flops_useful": 2.0 * float(np.sum(np.asarray(E.n_gamma, dtype=np.float64) ** 2)),
+                "frac_useful": (2.0 * float(np.sum(np.asarray(E.n_gamma, dtype=np.float64) ** 2)) / (ms_gemm / n_k * 1e-3) / 1e12 / 78.6) if n_k else None,
                 "flops_listed_legacy": flops_k, "frac_legacy_r02": tf_legacy / 78.6, "flops_unpruned_product": fl_dense,
                 "flops_note": "flops_per_launch = what the matrix cores execute: every chunk of the padded 120 x 128 tiles the workgroups multiply, the k segments a unit skips (structurally zero B) "
                               "not counted.  flops_listed_legacy = rounds 2-3's count (rows x listed columns x ALL of n_c: the skipped segments still in it, the padding not): frac_legacy_r02 is on that. "
@@ -1172,7 +1243,7 @@ def compact_line(out, details_path):
             keep["hbm_bytes_algorithmic"] = _num(r.get("hbm_bytes_algorithmic"), 6)
         else:
             keep["algorithmic_bytes_per_launch"] = _num(r.get("algorithmic_bytes_per_launch"), 6)
-        for k in ("share_of_step_time", "whole_iteration_frac", "frac_streamed", "frac_legacy_r02"):
+        for k in ("share_of_step_time", "whole_iteration_frac", "frac_streamed", "frac_legacy_r02", "frac_useful"):
             if r.get(k) is not None:
                 keep[k] = _num(r[k], 4)
         return keep
@@ -1189,6 +1260,9 @@ def compact_line(out, details_path):
                 o["frac_streamed"] = _num(b["roofline"]["frac_streamed"], 4)
             if b["roofline"].get("whole_iteration_frac") is not None:
                 o["whole_iteration_frac"] = _num(b["roofline"]["whole_iteration_frac"], 4)
+        if isinstance(b.get("cpu_baseline"), dict) and b["cpu_baseline"].get("value") is not None:  # a block with its own CPU leg (configs[3]: the reference's op sequence, live)
+            cbb = b["cpu_baseline"]
+            o["cpu_baseline"] = {"value": _num(cbb.get("value")), "cores": cbb.get("cores"), "kind": cbb.get("kind"), "extrapolated": bool(cbb.get("extrapolated", False)), "sample": str(cbb.get("sample_short") or cbb.get("sample", ""))[:140]}
         return o
 
     cfg = out.get("config", {})
@@ -1216,7 +1290,7 @@ def compact_line(out, details_path):
         c["roofline"]["measured_ceiling"] = {k: _num(v, 4) for k, v in mc.items()}
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
-        c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "extrapolated": bool(cb.get("extrapolated", False)),
+        c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "extrapolated": bool(cb.get("extrapolated", False)), "counts": cb.get("counts"), "calibrated_from": cb.get("calibrated_from"),
                              "cpu_model": str(cb.get("cpu_model") or cpu_model())[:64], "sample": cb.get("sample_short") or str(cb.get("sample", ""))[:200]}
     if isinstance(cb, dict) and cb.get("kplus"):
         c["cpu_baseline"]["kplus"] = cb["kplus"]
@@ -1389,6 +1463,19 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    global CPU_POOL
+    if (rank == 0 and world == 1 and not force_dist and a.workload == "feti" and not a.sim_world and not a.no_cpu_baseline and not a.no_c2 and not a.no_configs3 and not a.no_cpu_pool
+            and a.kplus == "explicit" and not a.young and not a.partition):
+        # the worker processes of the configs[3] CPU leg (the reference's direct K^+, one factorisation per worker: oracle/direct_pool.py) are started HERE, before this
+        # process initialises the GPU -- they import numpy / scipy only and idle until that leg runs
+        try:
+            from oracle.direct_pool import DirectPool
+
+            CPU_POOL = DirectPool(host_threads())
+        except Exception as ex:  # noqa: BLE001 - the CPU leg then says why it is missing
+            sys.stderr.write("bench.py: no CPU worker pool: %r\n" % (ex,))
+            CPU_POOL = None
+
     import permon_amd as pa
 
     ctx = pa.Context(local_rank)
@@ -1504,7 +1591,10 @@ def main():
                 a2._secondary = True
                 for k_, v_ in over.items():
                     setattr(a2, k_, v_)
-                r2 = run_feti(ctx, a2, over.get("_steps", 108), 8, 0, 1, None)[0]
+                full = run_feti(ctx, a2, over.get("_steps", 108), 8, 0, 1, None)
+                r2 = full[0]
+                if over.get("_keep") is not None:  # (the block's generated problem and dual QP, for its CPU leg)
+                    over["_keep"].update(f=full[1], G=full[2], b_dual=full[4], lb_dual=full[5])
                 sb = r2["steps_by_type"]
                 return {"value": r2["value"], "unit": "QPS iterations/s", "ms_per_step": r2["ms_per_step"], "steps": over.get("_steps", 108), "warmup": 8, "workload": r2["workload"],
                         "applies_per_step": sb["operator_applies"] / over.get("_steps", 108) if sb.get("operator_applies") else None, "ms_per_operator_apply": sb.get("ms_per_operator_apply"),
@@ -1521,13 +1611,24 @@ def main():
             if not a.no_configs3:
                 # BASELINE configs[3]: 4 x 4 x 4 subdomains (64, 8 per GPU at N = 8) of 21^3 elements, G NOT orthonormalised: the projector applies the dense 384 x 384 (G G')^{-1},
                 # G G' assembled on the fp64 matrix cores (coarse_problem.GGt_TFLOPs)
-                secondary("configs3", lambda: feti_block(sub="4,4,4", nel=21, dense_coarse=True, no_iterative=True, young="", explicit_storage="auto"))
+                keep3 = {}
+                secondary("configs3", lambda: feti_block(sub="4,4,4", nel=21, dense_coarse=True, no_iterative=True, young="", explicit_storage="auto", _keep=keep3))
                 row = next((r_ for r_ in _DIRECT_ROWS if r_["nel"] == 21), None)
-                if row and out["configs3"].get("applies_per_step"):
+                if CPU_POOL is not None and keep3.get("f") is not None and out["configs3"].get("value"):
+                    # the reference's op sequence timed LIVE on this host, whole iteration: oracle SMALXE + MPGP, direct K^+ on worker processes, B / B' / projector included
+                    try:
+                        out["configs3"]["cpu_baseline"] = cpu_baseline_whole_iteration(CPU_POOL, ctx, keep3["f"], keep3["G"], keep3["b_dual"], keep3["lb_dual"])
+                    except Exception as ex:  # noqa: BLE001
+                        out["configs3"]["cpu_baseline"] = {"value": None, "unit": "QPS iterations/s", "kind": "port", "sample": "failed: %r" % (ex,)}
+                    finally:
+                        CPU_POOL.close()
+                    keep3.clear()
+                elif row and out["configs3"].get("applies_per_step"):
                     # the reference's direct K^+ for THIS block size was measured by cpu_baseline_direct (SuperLU forward/backward solve of one 21^3 block): no extrapolation here
                     cores = host_threads()
                     t_apply = math.ceil(64 / cores) * row["solve_s"]
-                    out["configs3"]["cpu_baseline"] = {"value": 1.0 / (out["configs3"]["applies_per_step"] * t_apply), "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": False, "cpu_model": cpu_model(),
+                    out["configs3"]["cpu_baseline"] = {"value": 1.0 / (out["configs3"]["applies_per_step"] * t_apply), "unit": "QPS iterations/s", "cores": cores, "kind": "port", "extrapolated": True, "cpu_model": cpu_model(),
+                                                       "counts": "K+ solves only (a model: measured solve time x rounds; the live whole-iteration leg needs the worker pool, --no-cpu-pool was given or it failed to start)",
                                                        "sample": "measured: SuperLU (scipy splu, stand-in for the reference's PCCHOLESKY / MUMPS K^+, matinv.c:734-743) forward/backward solve of one 21^3 block = %.4f s; 64 blocks over %d cores "
                                                                  "(%d rounds per F application, perfect parallelism assumed) x %.2f F applications per iteration; B / B' and dual-space work not counted" % (row["solve_s"], cores, math.ceil(64 / cores), out["configs3"]["applies_per_step"])}
             if not a.no_svm:

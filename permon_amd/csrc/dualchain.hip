@@ -37,6 +37,7 @@ struct pmh_dualchain_s {
   unsigned char *d_ec = nullptr;
   // the rows of the gather matrix that have entries (built for the gather matrix / mid_in pair in use: the other rows of mid_in are zeroed once)
   pmh_csr  list_for = nullptr;
+  unsigned long long list_uid = 0, sc_uid = 0; // (the matrices' uids: an operator rebuilt at the same address is another matrix)
   double  *zeroed   = nullptr;
   int      nlist = 0, *d_reci = nullptr; // per listed row 8 ints (row, partner row or -1, first entry, one past the last, the first three columns, 0) ...
   double  *d_recd = nullptr;            // ... and 4 doubles (the first three values, 0)
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(PMH_EMIT_TILE) void k_dc_final(int n, const double 
 // ---- set-up ------------------------------------------------------------------------------------------------------------------------
 static bool dc_off() { return pmh_knobs().chain == 0; } // A/B (pmh_set_knob("chain", 0), PMH_NO_CHAIN): the round-4 launch sequence
 
+void pmh_dc_destroy(pmh_dualchain dc);
 int pmh_dc_create(pmh_qppf pf, pmh_op F, pmh_dualchain *out)
 {
   *out = nullptr;
@@ -387,23 +389,31 @@ int pmh_dc_create(pmh_qppf pf, pmh_op F, pmh_dualchain *out)
       ev[(size_t)j * W + e] = va[k], ec[(size_t)j * W + e] = (unsigned char)r;
     }
   pmh_dualchain dc = new pmh_dualchain_s();
+#define DC_CHK(call) \
+  do { \
+    if (int rc_ = (call)) { \
+      pmh_dc_destroy(dc); \
+      return rc_; \
+    } \
+  } while (0)
   dc->ctx = ctx, dc->pf = pf, dc->F = F, dc->n = n, dc->m = m, dc->nwg = nwg, dc->nseg = nseg, dc->W = W;
-  PMH_CHK(pmh_malloc(ctx, sizeof(int) * (seg.size() + 3), (void **)&dc->d_seg));
-  PMH_CHK(pmh_malloc(ctx, sizeof(int) * lrow.size(), (void **)&dc->d_lrow));
-  PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_seg, seg.data(), sizeof(int) * seg.size()));
-  PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_lrow, lrow.data(), sizeof(int) * lrow.size()));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * ev.size(), (void **)&dc->d_ev));
-  PMH_CHK(pmh_malloc(ctx, ec.size(), (void **)&dc->d_ec));
-  PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_ev, ev.data(), sizeof(double) * ev.size()));
-  PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_ec, ec.data(), ec.size()));
+  DC_CHK(pmh_malloc(ctx, sizeof(int) * (seg.size() + 3), (void **)&dc->d_seg));
+  DC_CHK(pmh_malloc(ctx, sizeof(int) * lrow.size(), (void **)&dc->d_lrow));
+  DC_CHK(pmh_memcpy_h2d(ctx, dc->d_seg, seg.data(), sizeof(int) * seg.size()));
+  DC_CHK(pmh_memcpy_h2d(ctx, dc->d_lrow, lrow.data(), sizeof(int) * lrow.size()));
+  DC_CHK(pmh_malloc(ctx, sizeof(double) * ev.size(), (void **)&dc->d_ev));
+  DC_CHK(pmh_malloc(ctx, ec.size(), (void **)&dc->d_ec));
+  DC_CHK(pmh_memcpy_h2d(ctx, dc->d_ev, ev.data(), sizeof(double) * ev.size()));
+  DC_CHK(pmh_memcpy_h2d(ctx, dc->d_ec, ec.data(), ec.size()));
   for (int s = 0; s < 3; s++) {
-    PMH_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(nseg + 1), (void **)&dc->part[s]));
-    PMH_CHK(pmh_memset(ctx, dc->part[s], 0, sizeof(double) * (size_t)(nseg + 1)));
+    DC_CHK(pmh_malloc(ctx, sizeof(double) * (size_t)(nseg + 1), (void **)&dc->part[s]));
+    DC_CHK(pmh_memset(ctx, dc->part[s], 0, sizeof(double) * (size_t)(nseg + 1)));
   }
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * 64, (void **)&dc->c_cur));
-  PMH_CHK(pmh_memset(ctx, dc->c_cur, 0, sizeof(double) * 64));
-  PMH_CHK(pmh_malloc(ctx, sizeof(double) * ((size_t)n + nseg + 1), (void **)&dc->w));
-  PMH_CHK(pmh_memset(ctx, dc->w, 0, sizeof(double) * ((size_t)n + nseg + 1)));
+  DC_CHK(pmh_malloc(ctx, sizeof(double) * 64, (void **)&dc->c_cur));
+  DC_CHK(pmh_memset(ctx, dc->c_cur, 0, sizeof(double) * 64));
+  DC_CHK(pmh_malloc(ctx, sizeof(double) * ((size_t)n + nseg + 1), (void **)&dc->w));
+  DC_CHK(pmh_memset(ctx, dc->w, 0, sizeof(double) * ((size_t)n + nseg + 1)));
+#undef DC_CHK
   *out = dc;
   return PMH_SUCCESS;
 }
@@ -413,7 +423,7 @@ int pmh_dc_create(pmh_qppf pf, pmh_op F, pmh_dualchain *out)
 static int dc_prepare_stages(pmh_dualchain dc)
 {
   pmh_ctx ctx = dc->ctx;
-  if (!(dc->list_for == dc->gather && dc->zeroed == dc->mid_in)) {
+  if (!(dc->list_for == dc->gather && dc->list_uid == dc->gather->uid && dc->zeroed == dc->mid_in)) {
     const pmh_csr       Bg = dc->gather;
     std::vector<int>    rp((size_t)Bg->nrows + 1), ci((size_t)Bg->nnz);
     std::vector<double> va((size_t)Bg->nnz);
@@ -478,9 +488,9 @@ static int dc_prepare_stages(pmh_dualchain dc)
     PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_reci, reci.data(), sizeof(int) * reci.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_recd, recd.data(), sizeof(double) * recd.size()));
     PMH_CHK(pmh_memset(ctx, dc->mid_in, 0, sizeof(double) * (size_t)Bg->nrows));
-    dc->nlist = (int)(reci.size() / 8), dc->list_for = Bg, dc->zeroed = dc->mid_in;
+    dc->nlist = (int)(reci.size() / 8), dc->list_for = Bg, dc->list_uid = Bg->uid, dc->zeroed = dc->mid_in;
   }
-  if (dc->sc_for != dc->scatter) {
+  if (dc->sc_for != dc->scatter || dc->sc_uid != dc->scatter->uid) {
     const pmh_csr       Bs = dc->scatter;
     const int           n  = dc->n;
     std::vector<int>    rp((size_t)n + 1), ci((size_t)Bs->nnz);
@@ -504,7 +514,7 @@ static int dc_prepare_stages(pmh_dualchain dc)
     PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_sc2, sc2.data(), sizeof(int) * sc2.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_sv2, sv2.data(), sizeof(double) * sv2.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, dc->d_scnt, cnt.data(), cnt.size()));
-    dc->sc_for = Bs;
+    dc->sc_for = Bs, dc->sc_uid = Bs->uid;
   }
   return PMH_SUCCESS;
 }

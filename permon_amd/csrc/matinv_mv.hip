@@ -307,6 +307,18 @@ int pmh_matinv_mv_destroy(pmh_matinv_mv V)
 static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out);
 int        pmh_matinv_mv_create(pmh_matinv M, pmh_matinv_mv *out) { return mvc_create(M, 1, out); }
 
+// *differs = 1 if the kernel vectors of block b > 0 are not those of block 0 entry by entry, to rounding: |difference| <= tol (R: kdim x ldR, the blocks' rows one after the
+// other, nb rows each; bases computed from shifted coordinates agree to ~ 1e-16 but not to the bit)
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_kernel_differs(int kdim, int nrep, int nb, size_t ldR, const double *__restrict__ R, double tol, int *__restrict__ differs)
+{
+  for (long long t = (long long)blockIdx.x * PMH_BLOCK + threadIdx.x; t < (long long)kdim * nb; t += (long long)gridDim.x * PMH_BLOCK) {
+    const int    k = (int)(t / nb), i = (int)(t % nb);
+    const double r0 = R[(size_t)k * ldR + i];
+    for (int b = 1; b < nrep; b++)
+      if (!(fabs(R[(size_t)k * ldR + (size_t)b * nb + i] - r0) <= tol)) *differs = 1;
+  }
+}
+
 int pmh_matinv_mv_create_congruent(pmh_matinv M, pmh_matinv_mv *out)
 {
   PMH_ARG(M && out);
@@ -314,6 +326,21 @@ int pmh_matinv_mv_create_congruent(pmh_matinv M, pmh_matinv_mv *out)
   if (M->nblocks != MV_R || !M->Kb || M->Kb->nrep != MV_R || !M->mg) {
     pmh_mv_set_why("not 8 congruent blocks with a V-cycle (pmh_matinv_enable_bsr3 verifies the congruence)");
     return PMH_EPI_UNSUPPORTED;
+  }
+  if (M->kdim && M->d_R) {
+    // the 8 columns are projected with block 0's kernel vectors: the caller's bases must be the same vectors block after block (the kernel SPACE follows from the
+    // matrix, the basis does not: another basis, scaling or zero-padded column per block would silently give another K^+ than the one-column path)
+    int *d_diff, h_diff = 0;
+    PMH_CHK(pmh_malloc(M->ctx, sizeof(int), (void **)&d_diff));
+    PMH_HIP(hipMemsetAsync(d_diff, 0, sizeof(int), M->ctx->stream));
+    const int nb = M->n / MV_R;
+    hipLaunchKernelGGL(k_mvc_kernel_differs, dim3(256), dim3(PMH_BLOCK), 0, M->ctx->stream, M->kdim, MV_R, nb, (size_t)M->n, (const double *)M->d_R, 1e-9 / sqrt((double)nb), d_diff); // (entries of an orthonormal basis are ~ 1 / sqrt(nb))
+    PMH_CHK(pmh_memcpy_d2h(M->ctx, &h_diff, d_diff, sizeof(int)));
+    pmh_free(M->ctx, d_diff);
+    if (h_diff) {
+      pmh_mv_set_why("the congruent blocks come with different kernel bases");
+      return PMH_EPI_UNSUPPORTED;
+    }
   }
   return mvc_create(M, MV_R, out);
 }

@@ -115,6 +115,7 @@ struct pmh_csr_s {
   // borrowed host copy of the arrays (set-up builders only: pmh_csr_set_host_hint; the caller keeps them alive and unchanged until it clears the hint)
   const int    *h_rowptr, *h_col;
   const double *h_val;
+  unsigned long long uid = 0;   // unique per created matrix (spmv.hip pmh_csr_create): caches keyed on a matrix compare this, not the address a later matrix may reuse
   int           congruent_nrep = 0; // > 1: pmh_bsr3_from_csr has compared the nrep diagonal blocks entry by entry and found them equal (the values never change after creation: a second conversion skips the comparison)
   // very long rows (G of the coarse problem: a few dozen rows of ~10^4 non-zeros): rows split into chunks, see spmv.hip
   int      *d_lchunks, *d_lrow; // [3*l_nchunks] (row, k0, k1) and [nrows+1] first chunk of each row

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <climits>
 
+#include <atomic>
+
 #include "pmh_internal.h"
 #include "reduce.h"
 
@@ -494,6 +496,10 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
     if (col[k] < 0 || col[k] >= ncols) return pmh_set_error(PMH_ERR_ARG, "pmh_csr_create: column index %d out of range [0,%d) at nnz %lld", col[k], ncols, k);
   PMH_HIP(hipSetDevice(ctx->device));
   pmh_csr A = new pmh_csr_s();
+  {
+    static std::atomic<unsigned long long> next_uid{1};
+    A->uid = next_uid++;
+  }
   memset(A, 0, sizeof(*A));
   A->ctx   = ctx;
   A->nrows = nrows;
