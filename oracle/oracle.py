@@ -322,8 +322,9 @@ class Qppf:
         return y
 
 
-def smalxe(op, b, u0, box, pf, omp=False, inner_opts=None, trace_cap=0, **opts):
-    """QPSSolve_SMALXE restatement (outer AL loop + inner MPGP with the injected convergence test)."""
+def smalxe(op, b, u0, box, pf, omp=False, inner_opts=None, trace_cap=0, timing=None, **opts):
+    """QPSSolve_SMALXE restatement (outer AL loop + inner MPGP with the injected convergence test).
+    timing: a dict that receives the seconds of QPSSetUp (power method for the largest eigenvalue, rho, M1) and of QPSSolve separately."""
     L = lib(omp)
     b = _f64(b)
     u = _f64(u0).copy()
@@ -336,8 +337,14 @@ def smalxe(op, b, u0, box, pf, omp=False, inner_opts=None, trace_cap=0, **opts):
             _apply_opts(L, L.orc_qps_set, inner, inner_opts)
         if trace_cap:
             L.orc_qps_enable_trace(C.c_void_p(inner), C.c_int(trace_cap))
+        import time as _time
+
+        t0 = _time.perf_counter()
         L.orc_smalxe_setup(C.c_void_p(s))
+        t1 = _time.perf_counter()
         L.orc_smalxe_solve(C.c_void_p(s))
+        if timing is not None:
+            timing["setup_seconds"], timing["solve_seconds"] = t1 - t0, _time.perf_counter() - t1
         keys = ["M1", "M1_initial", "eta", "rho", "rho_current", "M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "normBu", "enorm", "rnorm", "iteration", "reason", "maxeig", "gtol", "lag_neval", "lag_niter"]
         res = {k: L.orc_smalxe_get(C.c_void_p(s), k.encode()) for k in keys}
         for k in ("M1_updates", "M1_hits", "eta_hits", "rho_updates", "state", "inner_iter_accu", "iteration", "reason", "lag_neval", "lag_niter"):

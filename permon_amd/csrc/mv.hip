@@ -139,7 +139,9 @@ static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, 
   }
   pmh_mv_ell E = new pmh_mv_ell_s();
   E->ctx = ctx, E->nbr = nbr, E->storage = storage, E->scale = 1.0, E->col = nullptr, E->val = nullptr;
-  E->lpr = info[0] > 48 ? 16 : 4;
+  // long rows (W > 48: the coarse operators of an aggregation hierarchy) and small levels (fewer block rows than fill the chip with 4 lanes each: the trips of a row are a
+  // serial chain -- 7 of them for a 27-point operator) take 16 lanes per block row
+  E->lpr = (info[0] > 48 || (nbr < 16384 && !getenv("PMH_MV_NO_LPR16"))) ? 16 : 4;
   E->W   = (info[0] + E->lpr - 1) / E->lpr * E->lpr;
   double inv_scale = 1.0;
   if (storage == PMH_BSR_F16) { // power-of-two scale that brings the largest entry to [1, 2) (as pmh_bsr3_from_csr)
@@ -184,6 +186,10 @@ int pmh_mv_ell_destroy(pmh_mv_ell E)
 }
 
 // ---- the product --------------------------------------------------------------------------------------------------------------------------------------------
+// (Round 6, built, measured, dropped: a lane map with four COLUMN-PAIR lanes per slot -- 16 lanes per block row, every lane 2 of the 8 columns, the operand of a slot read
+// as 4 adjacent 8 / 16-byte pieces instead of 6 / 12 loads of 16 bytes per lane.  Same bits; 78 / 39 / 38 us per product of one 43^3 block with fp64 / fp32 / fp16 entries
+// against 58 / 28 / 25.5 us of the map below: the four lanes of a slot each issue the loads of the 3 x 3 block, and the texture addresser's cost is per quad of lanes,
+// not per distinct address.  What bounds the product is that rate -- one cache line per clock and CU; a 16-byte piece of a gathered operand costs a line access of its own.)
 template <typename T, int N> struct mv_vec;
 template <int N> struct mv_vec<double, N> { // N doubles = N / 2 loads of 16 bytes
   static __device__ __forceinline__ void load(const double *p, double (&v)[N])
@@ -238,10 +244,18 @@ template <typename T> struct mv_blk<_Float16, T> {
 // lane l takes the slots LPR g + l, i.e. plane (LPR / 4) g + (l >> 2), entry l & 3 of the plane
 template <typename TM, typename T, int R, int EPI, int LPR = 4>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale,
-                        const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt)
+                        const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt, int xcd_map)
 {
   const int hlt = halt ? *halt : 0;
-  const int tg  = blockIdx.x * PMH_BLOCK + threadIdx.x, br = tg / LPR, lw = tg % LPR, l = lw & 3, pl = lw >> 2;
+  // XCD-aware order of the workgroups: consecutive workgroup ids land on different XCDs (8 private L2s), so with the natural order every XCD walks the WHOLE operand
+  // multivector through its 4 MB L2 -- the gathers of a block row reach +- one plane of nodes, ~ 30 workgroups away.  Workgroup b takes the b / 8-th tile of the (b % 8)-th
+  // contiguous eighth of the block rows: an XCD's gathers stay inside its own slab (+ a halo).  Same bits; 5 - 7 % of the product (round 6)
+  int wg = blockIdx.x;
+  if (xcd_map) {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xc = wg & 7, j = wg >> 3;
+    wg = xc * q + min(xc, rr) + j;
+  }
+  const int tg  = wg * PMH_BLOCK + threadIdx.x, br = tg / LPR, lw = tg % LPR, l = lw & 3, pl = lw >> 2;
   constexpr int PS = LPR / 4; // planes per trip
   if (br >= nbr) return; // whole groups of LPR lanes
   int cn = col[((size_t)pl * nbr + br) * 4 + l];
@@ -251,16 +265,45 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
   for (int q = 0; q < 3; q++)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[q][r] = (T)0;
-  for (int g = pl; g < W4; g += PS) {
-    const int c = cn;
-    if (g + PS < W4) cn = col[((size_t)(g + PS) * nbr + br) * 4 + l]; // the next slot's index travels during this slot's products
+  if constexpr (sizeof(T) == 4) {
+    // software pipeline (fp32 vectors: the V-cycle): the entries and the operand values of trip g + 1 are loaded before the products of trip g (the index of trip g + 2 with
+    // them).  Measured on one 43^3 block, 8 columns: fp32 entries 34.6 -> 29.5 us, fp16 entries unchanged (27 us); with fp64 vectors the second operand set costs
+    // the occupancy more than the chain costs (57 -> 62 us): the plain loop below
     T a[9], xv[3 * R];
-    mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
-    mv_vec<T, 3 * R>::load(x + (size_t)3 * c * R, xv);
+    mv_blk<TM, T>::load(val, (size_t)pl, nbr, br, l, a);
+    mv_vec<T, 3 * R>::load(x + (size_t)3 * cn * R, xv);
+    if (pl + PS < W4) cn = col[((size_t)(pl + PS) * nbr + br) * 4 + l];
+    for (int g = pl; g < W4; g += PS) {
+      T          an[9], xn[3 * R];
+      const bool more = g + PS < W4;
+      if (more) {
+        mv_blk<TM, T>::load(val, (size_t)(g + PS), nbr, br, l, an);
+        mv_vec<T, 3 * R>::load(x + (size_t)3 * cn * R, xn);
+        if (g + 2 * PS < W4) cn = col[((size_t)(g + 2 * PS) * nbr + br) * 4 + l];
+      }
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+      for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
+        for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) a[i] = an[i];
+#pragma unroll
+        for (int i = 0; i < 3 * R; i++) xv[i] = xn[i];
+      }
+    }
+  } else {
+    for (int g = pl; g < W4; g += PS) {
+      const int c = cn;
+      if (g + PS < W4) cn = col[((size_t)(g + PS) * nbr + br) * 4 + l]; // the next slot's index travels during this slot's products
+      T a[9], xv[3 * R];
+      mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
+      mv_vec<T, 3 * R>::load(x + (size_t)3 * c * R, xv);
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
+    }
   }
   // the group's partial sums: (l0 + l1) + (l2 + l3) [+ the other planes' quads] on every lane
 #pragma unroll
@@ -342,10 +385,12 @@ static int mv_launch(pmh_mv_ell E, const T *x, T *y, int epi, const pmh_mv_epi<T
   if (ep) e = *ep;
   else memset(&e, 0, sizeof(e));
   const T sc = (T)E->scale;
+  static const int xmap_on = getenv("PMH_MV_NO_XCDMAP") ? 0 : 1; // A/B
+  const int        xmap    = (xmap_on && g.x >= 64) ? 1 : 0;
 #define MV_LAUNCH(EPI) \
   do { \
-    if (E->lpr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 16>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 4>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt); \
+    if (E->lpr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 16>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt, xmap); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 4>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt, xmap); \
   } while (0)
   switch (epi) {
   case PMH_EPI_NONE: MV_LAUNCH(PMH_EPI_NONE); break;
