@@ -1076,10 +1076,12 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         kplus_text = "the explicit local dual operators W_b = (K_b^+)[Gamma_b, Gamma_b] (dense fp64, n_Gamma %d-%d, %s%.1f GB on this rank; assembled once by %d K^+ solves at rtol %.0e in %.0f s)" % (
             int(E.n_gamma.min()), int(E.n_gamma.max()), "the congruent blocks share ONE matrix on the union of their Gamma, " if storage_used in ("class", "class_sym", "class_orbit") else "", E.dense_bytes / 1e9, n_solves, a.explicit_rtol, asm_s)
         precision_note = "fp64 throughout: the dense blocks, the GEMV and everything in the dual space are fp64; reduced precision exists only inside the V-cycle that preconditions the SET-UP solves (their CG, residual test at rtol %.0e and solutions are fp64)" % a.explicit_rtol
-        if world == 1 and not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and strict fp64
+        if not a.sim_world and not a.no_iterative:  # the inner-Krylov path next to it: fp16-PC default and (one GPU) strict fp64
+            # N > 1 (round 6): every rank runs this pass too -- the strong-scaling figure of the path that shards one subdomain per GPU and streams every K_i from HBM at
+            # every N stands next to the explicit one in the same line (at N = 1 its like-for-like partner is `iterative_distinct_blocks`: 8 different K_i, nothing shared)
             q.Kplus.attach_explicit(None)
             extra["iterative"] = iterative_pass(min(steps, 108), 4, a.mg_precision)
-            if has_mg and a.mg_precision != "fp64":
+            if world == 1 and has_mg and a.mg_precision != "fp64" and not getattr(a, "_no_strict", False):
                 switch_mg("fp64")
                 extra["strict_fp64"] = iterative_pass(min(steps, 108), 2, "fp64")
                 extra["strict_fp64"]["note"] = "every operator, vector and the V-cycle in fp64 (the reference's arithmetic throughout)"
@@ -1238,7 +1240,7 @@ def compact_line(out, details_path):
         keep = {"bound": r.get("bound"), "kernel": kernel_name_only(r.get("kernel")), "achieved": _num(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _num(r.get("frac"), 4),
                 "traffic": _num(r.get("traffic"), 6), "avg_launch_ms": _num(r.get("avg_launch_ms")), "launches_timed": r.get("launches_timed")}
         if r.get("traffic") is not None:  # where the HBM bytes come from: a committed rocprofv3 --pmc pass of this kernel (not measured in this run), with the state it measured
-            keep["traffic_source"] = str(r.get("traffic_source") or "")[:60]
+            keep["traffic_source"] = str(r.get("traffic_source") or "")[:44]
         if r.get("bound") == "mfma":
             keep["flops_per_launch"] = _num(r.get("flops_per_launch"), 6)
             keep["hbm_bytes_algorithmic"] = _num(r.get("hbm_bytes_algorithmic"), 6)
@@ -1254,7 +1256,7 @@ def compact_line(out, details_path):
             return None
         if b.get("failed"):
             return {"value": None, "failed": str(b["failed"])[:120]}
-        o = {"value": _num(b.get("value")), "ms_per_step": _num(b.get("ms_per_step")), "steps": b.get("steps")}
+        o = {"value": _num(b.get("value")), "ms_per_step": _num(b.get("ms_per_step"))}
         if isinstance(b.get("roofline"), dict):
             o["roofline_bound"], o["roofline_frac"], o["kernel"] = b["roofline"].get("bound"), _num(b["roofline"].get("frac"), 4), kernel_name_only(b["roofline"].get("kernel"))
             if b["roofline"].get("frac_streamed") is not None:
@@ -1263,7 +1265,7 @@ def compact_line(out, details_path):
                 o["whole_iteration_frac"] = _num(b["roofline"]["whole_iteration_frac"], 4)
         if isinstance(b.get("cpu_baseline"), dict) and b["cpu_baseline"].get("value") is not None:  # a block with its own CPU leg (configs[3]: the reference's op sequence, live)
             cbb = b["cpu_baseline"]
-            o["cpu_baseline"] = {"value": _num(cbb.get("value")), "cores": cbb.get("cores"), "kind": cbb.get("kind"), "extrapolated": bool(cbb.get("extrapolated", False)), "sample": str(cbb.get("sample_short") or cbb.get("sample", ""))[:70]}
+            o["cpu_baseline"] = {"value": _num(cbb.get("value")), "cores": cbb.get("cores"), "kind": cbb.get("kind"), "extrapolated": bool(cbb.get("extrapolated", False)), "measured": cbb.get("measured")}
         return o
 
     cfg = out.get("config", {})
@@ -1292,7 +1294,7 @@ def compact_line(out, details_path):
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "extrapolated": bool(cb.get("extrapolated", False)), "counts": (str(cb.get("counts")).split(" (")[0] if cb.get("counts") else None), "calibrated_from": (str(cb.get("calibrated_from")).split(" x ")[0] if cb.get("calibrated_from") else None),
-                             "cpu_model": str(cb.get("cpu_model") or cpu_model())[:40], "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:110]}
+                             "cpu_model": str(cb.get("cpu_model") or cpu_model())[:40], "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:90]}
     if isinstance(cb, dict) and cb.get("kplus"):
         c["cpu_baseline"]["kplus"] = cb["kplus"]
         if cb.get("measured_once"):
@@ -1314,7 +1316,7 @@ def compact_line(out, details_path):
             c[k] = _num(out[k])
     if isinstance(out.get("full_solve"), dict):
         c["full_solve"] = {k: _num(out["full_solve"].get(k)) for k in ("solve_seconds", "outer_iterations", "inner_iterations", "reason", "setup_seconds")}
-    for k in ("iterative", "strict_fp64", "general", "general_nosym", "configs1", "configs3", "configs4", "reuse_products"):
+    for k in ("iterative", "iterative_distinct_blocks", "strict_fp64", "general", "general_nosym", "configs1", "configs3", "configs4", "reuse_products"):
         if k in out:
             c[k] = block(out[k])
     if isinstance(c.get("general"), dict) and isinstance(out["general"], dict) and isinstance(out["general"].get("kplus"), dict):  # the non-congruent block's set-up: K^+ solves and their time
@@ -1331,7 +1333,7 @@ def compact_line(out, details_path):
     c["details"] = os.path.relpath(details_path, ROOT) if details_path.startswith(ROOT) else details_path
     line = json.dumps(c, separators=(",", ":"))
     if len(line) >= 4000:  # never hand the driver a line it cannot take: drop the summaries of the secondary blocks first
-        for k in ("reuse_products", "cpu_baseline_iterative", "contact_solve", "full_solve", "strict_fp64", "general", "iterative", "general_nosym", "configs4", "configs3", "configs1", "full_solve", "cpu_baseline_iterative"):
+        for k in ("reuse_products", "contact_solve", "full_solve", "cpu_baseline_iterative", "strict_fp64", "iterative_distinct_blocks", "general", "iterative", "general_nosym", "configs4", "configs3", "configs1", "full_solve", "cpu_baseline_iterative"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) < 4000:
@@ -1599,12 +1601,17 @@ def main():
                 sb = r2["steps_by_type"]
                 return {"value": r2["value"], "unit": "QPS iterations/s", "ms_per_step": r2["ms_per_step"], "steps": over.get("_steps", 108), "warmup": 8, "workload": r2["workload"],
                         "applies_per_step": sb["operator_applies"] / over.get("_steps", 108) if sb.get("operator_applies") else None, "ms_per_operator_apply": sb.get("ms_per_operator_apply"),
-                        "steps_by_type": sb, "kplus": r2["kplus"], "coarse_problem": r2["coarse_problem"], "full_solve": r2["full_solve"], "setup_seconds": r2["setup_seconds"], "roofline": r2["roofline"], "kplus_cg_product": r2["kplus_cg_product"]}
+                        "steps_by_type": sb, "kplus": r2["kplus"], "coarse_problem": r2["coarse_problem"], "full_solve": r2["full_solve"], "setup_seconds": r2["setup_seconds"], "roofline": r2["roofline"], "kplus_cg_product": r2["kplus_cg_product"],
+                        **({"iterative": r2["iterative"]} if "iterative" in r2 else {})}
 
             if a.general_nel and not a.young:
                 # the general (non-congruent) path of the explicit operators: 8 subdomains of 8 different materials -> no class sharing, no set-up by symmetry,
                 # per-block symmetric storage applied by k_fx_symv (HBM-bound); every column of every W_b by its own K^+ solve
-                secondary("general", lambda: feti_block(young="distinct", nel=a.general_nel, sub="2,2,2", dense_coarse=False, no_iterative=True, explicit_storage="auto"))
+                # its inner-Krylov pass = MatMult_Inv on 8 DISTINCT K_i: one device copy per block, every byte from HBM (no congruence to lean on) -- the 1-GPU partner of the
+                # N > 1 runs' `iterative` figure (one block per GPU at N = 8)
+                secondary("general", lambda: feti_block(young="distinct", nel=a.general_nel, sub="2,2,2", dense_coarse=False, no_iterative=False, _no_strict=True, explicit_storage="auto"))
+                if isinstance(out.get("general"), dict) and isinstance(out["general"].get("iterative"), dict):
+                    out["iterative_distinct_blocks"] = dict(out["general"].pop("iterative"), workload="the `general` block's problem: 8 subdomains of 8 different materials, K^+ by the inner Krylov solver on 8 distinct K_i (every byte from HBM)")
             if a.nosym_nel and not a.young and not a.partition:
                 # blocks that are NOT boxes (round 6): the same body cut along staircases -- the set-up leans on nothing (algebraic hierarchy, one K^+ column per touched dof, 8 at a time),
                 # the apply is the HBM-bound k_fx_symv over every block's own W_b

@@ -189,7 +189,10 @@ int pmh_mv_ell_destroy(pmh_mv_ell E)
 // (Round 6, built, measured, dropped: a lane map with four COLUMN-PAIR lanes per slot -- 16 lanes per block row, every lane 2 of the 8 columns, the operand of a slot read
 // as 4 adjacent 8 / 16-byte pieces instead of 6 / 12 loads of 16 bytes per lane.  Same bits; 78 / 39 / 38 us per product of one 43^3 block with fp64 / fp32 / fp16 entries
 // against 58 / 28 / 25.5 us of the map below: the four lanes of a slot each issue the loads of the 3 x 3 block, and the texture addresser's cost is per quad of lanes,
-// not per distinct address.  What bounds the product is that rate -- one cache line per clock and CU; a 16-byte piece of a gathered operand costs a line access of its own.)
+// not per distinct address.  What bounds the product is that rate -- one cache line per clock and CU; a 16-byte piece of a gathered operand costs a line access of its own.
+// Also built, measured, dropped: the operand STAGED in LDS per tile of 64 (fp64: 32) block rows -- the tile's distinct block columns copied with coalesced 16-byte loads,
+// the slots addressing them by 16-bit local indices (tables built on the host).  Same bits; 81 / 31 / 30 us: 45 ... 90 KB of LDS per workgroup leave 1 - 3 workgroups per
+// CU, and their copy phases do not overlap anybody's products.)
 template <typename T, int N> struct mv_vec;
 template <int N> struct mv_vec<double, N> { // N doubles = N / 2 loads of 16 bytes
   static __device__ __forceinline__ void load(const double *p, double (&v)[N])
