@@ -1014,7 +1014,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         n_solves, asm_s = E.assemble_stats()
         storage_used = q.explicit_storage
         flops_k = E.apply_flops()
-        ppref = {"class_orbit": (("k_fxo_gemm", "void k_fxo_gemm4<", "void k_fxo_gemm16<"), "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
+        ppref = {"class_orbit": (("void k_fxo_gemm16<",), "k_fxo_fin"), "class_sym": ("k_fxs_symm8", "k_fxs_symfin"), "class": ("k_fxs_gemm8", "k_fxs_fin"), "sym": ("void k_fx_symv<", "k_fx_symv_fin"), "full": ("void k_fx_gemv<",)}[storage_used]
         # the committed PMC passes (scripts/gpu_final_r04.sh): the headline, the configs[3] block, the general (non-congruent) block
         pmc_file = None
         if world == 1 and not a.sim_world:
@@ -1053,7 +1053,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                 "flops_note": "flops_per_launch = what the matrix cores execute: every chunk of the padded 120 x 128 tiles the workgroups multiply, the k segments a unit skips (structurally zero B) "
                               "not counted.  flops_listed_legacy = rounds 2-3's count (rows x listed columns x ALL of n_c: the skipped segments still in it, the padding not): frac_legacy_r02 is on that. "
                               "flops_unpruned_product = every (representative, operation, block) (%.2f of it is listed)" % (flops_k / max(fl_dense, 1.0)),
-                "kernel": "k_fxo_gemm16<NI, NWM> (+ k_fxo_fin) (v_mfma_f64_16x16x4_f64; workgroup tile 144 / 112 / 80 rows with 1 x 4 waves or 128 / 96 with 2 x 2, whichever pads the representatives' rows least: 715 -> 5 x 144; PMH_FXO_MFMA4=1: the 4x4x4_4b kernels k_fxo_gemm / k_fxo_gemm4<NA> of rounds 2-3): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of %.2f GB of symmetric tiles) and "
+                "kernel": "k_fxo_gemm16<NI, NWM> (+ k_fxo_fin) (v_mfma_f64_16x16x4_f64; workgroup tile 144 / 112 / 80 rows with 1 x 4 waves or 128 / 96 with 2 x 2, whichever pads the representatives' rows least: 715 -> 5 x 144): W_c is invariant under the %d signed coordinate permutations of the cube, so only the rows of the %d orbit representatives are stored (%.2f GB instead of %.2f GB of symmetric tiles) and "
                           "Y = W_c X becomes the GEMM (representatives) x (operations x 8 right-hand sides) over n_c on the fp64 matrix instruction: %.0f flop per stored byte, compute-bound; B is gathered from the L2-resident SIGNED multivector "
                           "(+x and -x per entry: one index per (operation, dof) addresses the signed value, nothing touches a loaded value before the products), the chunk loop is one basic block with the next chunk's loads placed between the products, split-K partial tiles summed in a fixed order; the representatives are ordered by which (operation, block) columns their rows are needed for and "
                           "every row tile multiplies its own column list only (the FETI dual operator apply, SURVEY 8d dense path)"

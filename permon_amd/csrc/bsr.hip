@@ -126,24 +126,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_bsr3(const int4 *__restrict__ til
 
 static int bsr_tile(int storage)
 {
-  int tb = 1024; // measured on MI355X (profiles/r01_bsr3_tune.txt)
-  if (const char *e = getenv("PMH_BSR_TB")) { // tuning knob: "tb64,tb32,tb16"
-    int t64 = 1024, t32 = 1024, t16 = 1024;
-    sscanf(e, "%d,%d,%d", &t64, &t32, &t16);
-    tb = (storage == PMH_BSR_F64) ? t64 : (storage == PMH_BSR_F32 ? t32 : t16);
-  }
-  return (tb == 512 || tb == 1024 || tb == 2048) ? tb : 512;
+  (void)storage;
+  return 1024; // measured on MI355X for every entry type (profiles/r01_bsr3_tune.txt; the tuning knobs PMH_BSR_TB / PMH_BSR_W went at the end of round 6)
 }
 
 static int bsr_width(int storage)
 {
-  int w = (storage == PMH_BSR_F64) ? 2 : 4; // 16-byte loads for fp64 / fp32, 8-byte for fp16
-  if (const char *e = getenv("PMH_BSR_W")) { // tuning knob: "w64,w32,w16"
-    int w64 = 2, w32 = 4, w16 = 4;
-    sscanf(e, "%d,%d,%d", &w64, &w32, &w16);
-    w = (storage == PMH_BSR_F64) ? w64 : (storage == PMH_BSR_F32 ? w32 : w16);
-  }
-  return (w == 1 || w == 2 || w == 4 || (w == 8 && storage == PMH_BSR_F16)) ? w : 1;
+  return (storage == PMH_BSR_F64) ? 2 : 4; // 16-byte loads for fp64 / fp32, 8-byte for fp16
 }
 
 // Build from a resident CSR (downloaded once); *out = NULL without error when the matrix has no 3x3 block structure that

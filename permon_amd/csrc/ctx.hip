@@ -154,16 +154,9 @@ extern "C" int pmh_mem_info(pmh_ctx c, size_t *free_bytes, size_t *total_bytes)
   return PMH_SUCCESS;
 }
 
-// the host waits for the launch stream several times per MPGP step (step decisions on a shell operator); PMH_SYNC_SPIN=1 polls the stream instead of
-// blocking in hipStreamSynchronize (tuning knob)
-static inline hipError_t ctx_wait(pmh_ctx c)
-{
-  static const int spin = getenv("PMH_SYNC_SPIN") ? atoi(getenv("PMH_SYNC_SPIN")) : 0;
-  if (!spin) return hipStreamSynchronize(c->stream);
-  hipError_t e;
-  while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
-  return e;
-}
+// the host waits for the launch stream once per MPGP step (step decisions on a shell operator).  (Polling the stream instead of blocking in hipStreamSynchronize was a
+// knob until round 6: measured, noise.)
+static inline hipError_t ctx_wait(pmh_ctx c) { return hipStreamSynchronize(c->stream); }
 
 extern "C" int pmh_sync(pmh_ctx c)
 {

@@ -304,9 +304,7 @@ static int fx_build_launch(pmh_fexplicit E)
   int       maxsb = 0;
   for (int b = 0; b < nb; b++) maxsb = std::max(maxsb, E->ld[b] / FX_TC);
   int seg = FX_SEG_MAX;
-  if (const char *e = getenv("PMH_FX_SEG")) seg = std::max(FX_SEG_MIN, std::min(FX_SEG_MAX, atoi(e)));
-  else
-    for (; seg > FX_SEG_MIN; seg /= 2) {
+  for (; seg > FX_SEG_MIN; seg /= 2) {
       long long n = 0;
       for (int b = 0; b < nb; b++)
         for (int sb = 0; sb < E->ld[b] / FX_TC; sb++)
@@ -458,8 +456,7 @@ static int fx_create(pmh_gluing B, pmh_blockdiag K, int storage, const int *bloc
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * nb, (void **)&E->d_ngam));
   PMH_CHK(pmh_memcpy_h2d(ctx, E->d_ngam, E->ngam.data(), sizeof(int) * nb));
   // GEMV launch table
-  E->rw = 4;
-  if (const char *s = getenv("PMH_FX_RW")) E->rw = (atoi(s) == 8) ? 8 : (atoi(s) == 2 ? 2 : 4);
+  E->rw = 4; // rows per wave of the full-matrix GEMV (2 / 4 / 8 measured in round 2: profiles/r02_symv_tune.txt)
   const int        rows_per_wg = 4 * E->rw;
   std::vector<int> wb, wr;
   for (int b = 0; b < nb; b++)
@@ -973,10 +970,8 @@ static int fx_gemv(pmh_fexplicit E)
       timed = true;
       PMH_HIP(hipEventRecord(E->ev[2 * E->ev_used], st));
     }
-    static const int var = getenv("PMH_FX_SYMV_VARIANT") ? atoi(getenv("PMH_FX_SYMV_VARIANT")) : 0;
 #define SYMV_LAUNCH(V) hipLaunchKernelGGL(k_fx_symv<V>, dim3(E->nsw), dim3(PMH_BLOCK), 0, st, (const int *)E->d_sw_block, (const int *)E->d_sw_band, (const int *)E->d_sw_seg, (const int *)E->d_gstart, (const int *)E->d_ld, (const long long *)E->d_woff, (const long long *)E->d_poff, (const long long *)E->d_doff, (const double *)E->Wbase, (const double *)E->xh, E->ydir, E->partial, E->seg)
-    if (var == 1) SYMV_LAUNCH(1);
-    else SYMV_LAUNCH(0);
+    SYMV_LAUNCH(0);
 #undef SYMV_LAUNCH
     if (timed) PMH_HIP(hipEventRecord(E->ev_mid[E->ev_used], st));
     if (E->nfw)

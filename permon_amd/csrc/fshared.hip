@@ -16,7 +16,7 @@
 //   0  PMH_FX_CLASS        the full matrix, k_fxs_gemm8: 8 n_c^2 bytes per apply, HBM-bound
 //   1 PMH_FX_CLASS_SYM its lower block-triangle in 16 x 16 tiles, k_fxs_symm8 (both products of a tile on the fp64 matrix instruction): 4 n_c^2 bytes,
 //     HBM-bound
-//   2 PMH_FX_CLASS_ORBIT only the rows of the orbit representatives under the class's symmetries, k_fxo_gemm / k_fxo_gemm4: a GEMM on the fp64 matrix
+//   2 PMH_FX_CLASS_ORBIT only the rows of the orbit representatives under the class's symmetries, k_fxo_gemm16: a GEMM on the fp64 matrix
 //     instruction,
 //                          4 n_c^2 / 24 bytes for the cube's 48 operations, compute-bound (the default for congruent cubes)
 // and the set-up by symmetry (fxs_set_symmetry: one K^+ solve per orbit of rows, self-checked against direct solves) serves 1 and 2.
@@ -130,7 +130,6 @@ static int fxs_build_launch(fx_shared *S)
   for (auto &C : S->C) maxrows = std::max(maxrows, C.r1 - C.r0), chunks += C.ngroups * (C.ld / 128);
   int nseg = std::max(1, std::min(32, (4096 + std::max(1, chunks) - 1) / std::max(1, chunks)));
   nseg     = std::max(1, std::min(nseg, maxrows / FXS_U));
-  if (const char *e = getenv("PMH_FXS_NSEG")) nseg = std::max(1, atoi(e));
   S->nseg = nseg;
   std::vector<int> wg;
   S->bytes = 0.0;
@@ -183,8 +182,7 @@ int fxs_create(pmh_gluing B, pmh_blockdiag K, const int *block_class, int sym, f
     slot[b] = (int)C.blocks.size() % FXS_S, group[b] = (int)C.blocks.size() / FXS_S;
     C.blocks.push_back(b);
   }
-  S->mfma16 = fxo_mfma16();
-  if (sym == 2 && S->mfma16 && !getenv("PMH_FXO_SLOTS8"))
+  if (sym == 2)
     for (auto &C : S->C) {
       C.S = 1;
       while (C.S < FXS_S && C.S < (int)C.blocks.size()) C.S *= 2;
@@ -471,7 +469,7 @@ static int fxo_gemm(fx_shared *S)
 #endif
     if (merged) {
       // (the class's products were part of the launch above)
-    } else if (S->mfma16 && C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
+    } else if (C.S != FXS_S) { // records of fewer than 8 slots: the table-driven kernel on this class's slice of the items
 #define FXO_LAUNCH_T(NI, NWM, TNW)                                                                                                                                                                             \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fxo_gemm16<NI, NWM, true, TNW>), dim3(count), dim3(256), 0, st, (const int *)(S->d_items + 8 * first), (const long long *)(S->d_wgl + 4 * first), (const int *)S->d_wg, \
                      (const int *)(S->d_wg + S->ncls), (const int *)nullptr, 0, (const double *)S->Afund, (const int *)nullptr, (const double *)S->X2, S->cpart, (const int *)(S->d_wgfirst + C.wgf_first),     \
@@ -493,7 +491,7 @@ static int fxo_gemm(fx_shared *S)
       default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
       }
 #undef FXO_LAUNCH_T
-    } else if (S->mfma16) {
+    } else {
       switch (C.tm) {
       case 144: FXO_LAUNCH((k_fxo_gemm16<9, 1>)); break;
       case 128: FXO_LAUNCH((k_fxo_gemm16<4, 2>)); break;
@@ -502,14 +500,6 @@ static int fxo_gemm(fx_shared *S)
       case 80: FXO_LAUNCH((k_fxo_gemm16<5, 1>)); break;
       default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no 16x16x4 kernel", C.tm);
       }
-    } else
-    switch (C.tm) {
-    case 128: FXO_LAUNCH(k_fxo_gemm); break;
-    case 120: FXO_LAUNCH(k_fxo_gemm4<15>); break;
-    case 112: FXO_LAUNCH(k_fxo_gemm4<14>); break;
-    case 104: FXO_LAUNCH(k_fxo_gemm4<13>); break;
-    case 96: FXO_LAUNCH(k_fxo_gemm4<12>); break;
-    default: return pmh_set_error(PMH_ERR_STATE, "PMH_FX_CLASS_ORBIT: row tile %d has no kernel", C.tm);
     }
 #undef FXO_LAUNCH
     // (one class: configs[2] / [3]; several classes: after the last class's GEMM)

@@ -1,5 +1,5 @@
 // Device kernels of the class-shared explicit local dual operators (included by fshared.hip only): the full-matrix product k_fxs_gemm8, the symmetric tile product
-// k_fxs_symm8 / k_fxs_symfin, the orbit GEMM k_fxo_gemm / k_fxo_gemm4 / k_fxo_gemm16 with its finishing kernel k_fxo_fin, and the set-up helpers.
+// k_fxs_symm8 / k_fxs_symfin, the orbit GEMM k_fxo_gemm16 with its finishing kernel k_fxo_fin, and the set-up helpers.
 #pragma once
 #include "fshared_types.h"
 #include "reduce.h"
@@ -338,217 +338,13 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_fxs_check_row(int r, const int *_
 // 64 x 64 (4 x 16 accumulators per lane), A pre-tiled in the order of its LDS image ([k][row] per (row tile, chunk): coalesced 16-byte loads),
 // both operands double-buffered in LDS, split-K partial tiles summed in a fixed order by k_fxo_fin, which also applies s_g(p) and scatters row g p.
 // (FXO_TM / FXO_TN / FXO_TK: fshared_types.h)
-#define FXO_LDA (FXO_TM + 16)
-#define FXO_LDB (FXO_TN + 4)
 // items: (class, group, row tile, column tile (16 operations), first chunk, one-past-last chunk, split, 0); iteml: A offset of the class, X offset of
-// the group, C offset of (class, group, split)
-__global__ __launch_bounds__(256, 2) void k_fxo_gemm(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
-                                                     const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                     const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
-{
-  __shared__ double As[2][FXO_TK][FXO_LDA];
-  __shared__ double Bs[2][FXO_TK][FXO_LDB];
-  // the workgroup's items one after the other (a piece of the k range may end one unit and begin the next: fxo_prepare)
-  for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
-  __builtin_amdgcn_sched_barrier(0);
-  const int *w8 = items + 8 * it;
-  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
-  const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
-  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
-  const double *__restrict__ Ab = A + iteml[4 * it];
-  const double *__restrict__ x  = X + iteml[4 * it + 1];
-  double *__restrict__ C        = cpart + iteml[4 * it + 2]; // the (group, row tile, split) block: tile rows x ncol
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  constexpr int NEA = FXO_TK * FXO_TM / 2 / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB;
-  const int  col = t % FXO_TN, kb = t / FXO_TN;
-  const int  ct  = coltab[iteml[4 * it + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
-  const int  sl  = ct < 0 ? 0 : (ct & 7);
-  const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
-  double     acc[4][16];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 16; j++) acc[i][j] = 0.0;
-  dbl2   ar[NEA];
-  double br[NEB];
-  int    gn[NEB];
-  auto loadA = [&](int kc) {
-    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * FXO_TM);
-#pragma unroll
-    // default cache policy: the workgroups of the other column tiles read the same chunk from the XCD's L2 (work-item order below)
-    for (int e = 0; e < NEA; e++) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e));
-  };
-  auto loadG = [&](int kc) {
-#pragma unroll
-    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
-  };
-  // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
-  auto gatherB = [&]() {
-                         // put the wait for all of the chunk's global loads in front of the products)
-#pragma unroll
-    for (int e = 0; e < NEB; e++) {
-      br[e] = x[(long long)gn[e] * FXS_S + sl];
-    }
-  };
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < NEA; e++) {
-      const int q = t + 256 * e, k = q / (FXO_TM / 2), r2 = (q % (FXO_TM / 2)) * 2;
-      *(dbl2 *)&As[buf][k][r2] = ar[e];
-    }
-#pragma unroll
-    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
-  };
-  if (kc0 < kc1) {
-    loadG(kc0);
-    loadA(kc0);
-    gatherB();
-    if (kc0 + 1 < kc1) loadG(kc0 + 1);
-    store(0);
-  }
-  __syncthreads();
-  const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
-  for (int kc = kc0; kc < kc1; kc++) {
-    const int buf = (kc - kc0) & 1;
-    // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
-    if (kc + 1 < kc1) {
-                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order,
-                        // and the compiler counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
-      gatherB();
-      if (kc + 2 < kc1) loadG(kc + 2);
-      loadA(kc + 1);
-    }
-#pragma unroll
-    for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
-      double a[4], b[16];
-#pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[buf][4 * k4 + ka][wm * 64 + i * 16 + ra];
-#pragma unroll
-      for (int j = 0; j < 16; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 4 + cb];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) acc[i][j] = fxm_mfma(a[i], b[j], acc[i][j]);
-    }
-    if (kc + 1 < kc1) store(buf ^ 1);
-    __syncthreads();
-  }
-  // D lane l: row 4 ((l >> 2) & 3) + (l >> 4) of the 16, column l & 3 of the 4
-  const int rr = 4 * ((lane >> 2) & 3) + (lane >> 4);
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 16; j++) C[(long long)(wm * 64 + i * 16 + rr) * ncol + nt * FXO_TN + wn * 64 + j * 4 + cb] = acc[i][j];
-  }
-}
+// the group, C offset of (class, group, split).
+// (Rounds 2-3 ran this GEMM on v_mfma_f64_4x4x4_4b_f64 -- k_fxo_gemm, workgroup tile 128 x 128, and k_fxo_gemm4<NA> with row tiles 8 NA = 96 ... 120; removed at the end
+// of round 6, the ladder is in docs/LAB_NOTEBOOK.md.)
 
-// The same GEMM with the instruction's operands the other way round: the SAME 4 rows of A in its 4 blocks, 16 columns of B (4 per block) -- rows come in
-// units of 4 instead of 16, so the row tile can be 8 NA = 96 ... 120 and 715 representatives pad to 720 rows (6 x 120) instead of 768.  At equal tile
-// this orientation is ~2 % slower than k_fxo_gemm (scripts/micro/orbit_gemm.hip), so it is used when it saves more than that in padding (fxo_row_tile).
-// Wave tile 4 NA x 64: NA x 4 accumulators; D lane l = row l >> 4 of the 4, column l & 15 of the 16.
-#define FXO_LDB4 (FXO_TN + 16) // 16 consecutive columns x 4 k per read: rows of B 32 banks apart
-template <int NA>
-__global__ __launch_bounds__(256, 2) void k_fxo_gemm4(const int *__restrict__ items, const long long *__restrict__ iteml, const int *__restrict__ c_nkc, const int *__restrict__ c_ldk,
-                                                      const int *__restrict__ coltab /* of this launch's class */, int zrow, const double *__restrict__ A, const int *__restrict__ gidx /* of this launch's class */,
-                                                      const double *__restrict__ X, double *__restrict__ cpart, const int *__restrict__ wgfirst)
-{
-  constexpr int TM = 8 * NA, WR = 4 * NA, LDA = TM + 16;
-  __shared__ double As[2][FXO_TK][LDA];
-  __shared__ double Bs[2][FXO_TK][FXO_LDB4];
-  // the workgroup's items one after the other (a piece of the k range may end one unit and begin the next: fxo_prepare)
-  for (int it = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x]), ite = __builtin_amdgcn_readfirstlane(wgfirst[blockIdx.x + 1]); it < ite; it++) {
-  __builtin_amdgcn_sched_barrier(0);
-  const int *w8 = items + 8 * it;
-  const int  c = __builtin_amdgcn_readfirstlane(w8[0]), mt = __builtin_amdgcn_readfirstlane(w8[2]), nt = __builtin_amdgcn_readfirstlane(w8[3]);
-  const int  kc0 = __builtin_amdgcn_readfirstlane(w8[4]), kc1 = __builtin_amdgcn_readfirstlane(w8[5]);
-  const int  nkc = c_nkc[c], ldk = c_ldk[c], ncol = __builtin_amdgcn_readfirstlane(w8[7]); // ncol: padded columns of this (group, row tile)
-  const double *__restrict__ Ab = A + iteml[4 * it];
-  const double *__restrict__ x  = X + iteml[4 * it + 1];
-  double *__restrict__ C        = cpart + iteml[4 * it + 2]; // the (group, row tile, split) block: tile rows x ncol
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  constexpr int NQ = FXO_TK * TM / 2, NEA = (NQ + 255) / 256, KPB = 256 / FXO_TN, NEB = FXO_TK / KPB; // NQ 16-byte pieces of A per chunk
-  const int  col = t % FXO_TN, kb = t / FXO_TN;
-  const int  ct  = coltab[iteml[4 * it + 3] + col]; // this column: operation << 3 | slot, -1 = padding (gathers the zero row)
-  const int  sl  = ct < 0 ? 0 : (ct & 7);
-  const int *gp  = gidx + (long long)(ct < 0 ? zrow : (ct >> 3)) * ldk;
-  double     acc[NA][4];
-#pragma unroll
-  for (int i = 0; i < NA; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-  dbl2   ar[NEA];
-  double br[NEB];
-  int    gn[NEB];
-  auto loadA = [&](int kc) {
-    const double *blk = Ab + ((long long)mt * nkc + kc) * (FXO_TK * TM);
-#pragma unroll
-    for (int e = 0; e < NEA; e++)
-      if (NQ % 256 == 0 || t + 256 * e < NQ) ar[e] = *(const dbl2 *)(blk + 2 * (t + 256 * e)); // default cache policy, see k_fxo_gemm
-  };
-  auto loadG = [&](int kc) {
-#pragma unroll
-    for (int e = 0; e < NEB; e++) gn[e] = gp[kc * FXO_TK + kb + KPB * e];
-  };
-  // X holds +x and -x per (position, slot): the index (position << 1 | negative) addresses the signed value; nothing here may USE a loaded value (that would
-  auto gatherB = [&]() {
-                         // put the wait for all of the chunk's global loads in front of the products)
-#pragma unroll
-    for (int e = 0; e < NEB; e++) {
-      br[e] = x[(long long)gn[e] * FXS_S + sl];
-    }
-  };
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < NEA; e++) {
-      const int q = t + 256 * e, k = q / (TM / 2), r2 = (q % (TM / 2)) * 2;
-      if (NQ % 256 == 0 || q < NQ) *(dbl2 *)&As[buf][k][r2] = ar[e];
-    }
-#pragma unroll
-    for (int e = 0; e < NEB; e++) Bs[buf][kb + KPB * e][col] = br[e];
-  };
-  if (kc0 < kc1) {
-    loadG(kc0);
-    loadA(kc0);
-    gatherB();
-    if (kc0 + 1 < kc1) loadG(kc0 + 1);
-    store(0);
-  }
-  __syncthreads();
-  const int ka = lane >> 4, ra = lane & 15, cb = lane & 3;
-  for (int kc = kc0; kc < kc1; kc++) {
-    const int buf = (kc - kc0) & 1;
-    // the next chunk's operands travel while this chunk is multiplied.  Order matters: the gathers need the indices asked for one chunk ago -- the only loads
-    if (kc + 1 < kc1) {
-                        // outstanding here --, so they go first; with the loads of A in front of them the wait for those indices (s_waitcnt vmcnt is in order,
-                        // and the compiler counts conservatively across A's exec-masked load blocks) became a wait for A itself, in front of the products
-      gatherB();
-      if (kc + 2 < kc1) loadG(kc + 2);
-      loadA(kc + 1);
-    }
-#pragma unroll
-    for (int k4 = 0; k4 < FXO_TK / 4; k4++) {
-      double a[NA], b[4];
-#pragma unroll
-      for (int i = 0; i < NA; i++) a[i] = As[buf][4 * k4 + ka][wm * WR + i * 4 + cb];
-#pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[buf][4 * k4 + ka][wn * 64 + j * 16 + ra];
-#pragma unroll
-      for (int i = 0; i < NA; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = fxm_mfma(a[i], b[j], acc[i][j]);
-    }
-    if (kc + 1 < kc1) store(buf ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < NA; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) C[(long long)(wm * WR + i * 4 + ka) * ncol + nt * FXO_TN + wn * 64 + j * 16 + ra] = acc[i][j];
-  }
-}
-
-// The same GEMM on the other fp64 shape of the matrix pipe, v_mfma_f64_16x16x4_f64: one instruction = a 16 x 16 tile over 4 k (2048 flop, 16 passes) where the
-// 4x4x4_4b form needs four (4 x 512 flop, 4 passes each).  Same flop rate, but a quarter of the instructions and half of the operand registers read per flop:
+// The GEMM on v_mfma_f64_16x16x4_f64: one instruction = a 16 x 16 tile over 4 k (2048 flop, 16 passes) where the 4x4x4_4b form of rounds 2-3 needed four (4 x 512
+// flop, 4 passes each).  Same flop rate, but a quarter of the instructions and half of the operand registers read per flop:
 // A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15], D column l & 15, rows (l >> 4) + 4 r in the 4 registers (scripts/micro/mfma_f64.hip).  Wave tile 16 NI
 // x 64 (NI x 4 instruction tiles, 4 NI x 4 accumulator doubles per lane), workgroup tile 32 NI x 128 (2 x 2 waves); the LDS images are the ones of k_fxo_gemm
 // (A) and k_fxo_gemm4 (B): per k step of 4 a lane reads NI + 4 operands for 4 NI instructions of 64 cycles (k_fxo_gemm4<15>: 19 operands for 60 instructions of
@@ -734,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void k_fxo_gemm16(const int *__restrict__ i
 }
 
 // row tile of a class with M representatives: the padded row count decides; 128 (the faster orientation) unless a smaller tile saves more than 2.5 %
-// the orbit GEMM runs on v_mfma_f64_16x16x4_f64 (k_fxo_gemm16); PMH_FXO_MFMA4=1: the 4x4x4_4b kernels of rounds 2-3 (k_fxo_gemm / k_fxo_gemm4<NA>) for the A/B
+// the orbit GEMM runs on v_mfma_f64_16x16x4_f64 (k_fxo_gemm16)
 
 // Y[g p][slot] = s_g(p) * (sum over the row tile's units (k segments) in unit order, over a unit's splits in split order) for the (row, operation) pairs that
 // own their row (use = +-1: the operation the row was assigned to; rows fixed by several operations are written once), over the columns the (group, row tile)

@@ -7,29 +7,17 @@
 
 #include "fshared_types.h"
 
-bool fxo_mfma16() { return getenv("PMH_FXO_MFMA4") == nullptr; }
+// 16-row instruction tiles (v_mfma_f64_16x16x4): the workgroup tile that pads least among 144, 128, 112, 96, 80 (ties: the larger tile).  (The 4x4x4_4b kernels of rounds
+// 2-3, row tiles 128 ... 96, went at the end of round 6: docs/LAB_NOTEBOOK.md.)
 int fxo_row_tile(int M)
 {
-  if (fxo_mfma16()) { // 16-row instruction tiles: the workgroup tile that pads least among 144, 128, 112, 96, 80 (ties: the larger tile)
-    if (const char *e = getenv("PMH_FXO_TM")) {
-      const int v = atoi(e);
-      if (v == 144 || v == 128 || v == 112 || v == 96 || v == 80) return v;
-    }
-    int best = 144, pad = (M + 143) / 144 * 144;
-    for (int tm : {128, 112, 96, 80})
-      if ((M + tm - 1) / tm * tm < pad) pad = (M + tm - 1) / tm * tm, best = tm;
-    return best;
-  }
-  if (const char *e = getenv("PMH_FXO_TM")) {
+  if (const char *e = getenv("PMH_FXO_TM")) { // tests: every row tile
     const int v = atoi(e);
-    if (v == 128 || v == 120 || v == 112 || v == 104 || v == 96) return v;
+    if (v == 144 || v == 128 || v == 112 || v == 96 || v == 80) return v;
   }
-  int    best = 128;
-  double cost = (double)((M + 127) / 128 * 128);
-  for (int tm : {120, 112, 104, 96}) {
-    const double cst = 1.025 * (double)((M + tm - 1) / tm * tm);
-    if (cst < cost) cost = cst, best = tm;
-  }
+  int best = 144, pad = (M + 143) / 144 * 144;
+  for (int tm : {128, 112, 96, 80})
+    if ((M + tm - 1) / tm * tm < pad) pad = (M + tm - 1) / tm * tm, best = tm;
   return best;
 }
 
@@ -82,7 +70,7 @@ int fxo_prepare(fx_shared *S)
     const int M = C.m1 - C.m0;
     C.tm   = fxo_row_tile(M);
     C.tnw  = 0;
-    if (S->mfma16 && C.S == 1 && C.nsym * C.S <= 48 && !getenv("PMH_FXO_NO_TN48")) {
+    if (C.S == 1 && C.nsym * C.S <= 48) {
       // a class of ONE block lists at most 48 columns: the 64-wide tile multiplies a quarter of zeros.  48 columns x (4 waves x NI x 16 rows): 192 rows unless
       // fewer pad less
       C.tnw = 48, C.tm = 192;
@@ -165,9 +153,8 @@ int fxo_prepare(fx_shared *S)
           }
           most = std::max(most, n);
         }
-      const char *e = getenv("PMH_FXO_TN");
       // (only classes on the table-driven kernel: the single-class kernel of 8-block classes is left as it is)
-      C.tn = (S->mfma16 && C.S != FXS_S && most <= 64 && !(e && atoi(e) == 128)) ? 64 : 128;
+      C.tn = (C.S != FXS_S && most <= 64) ? 64 : 128;
     }
     for (int gr = 0; gr < C.ngroups; gr++) {
       int elems = 0;
@@ -335,7 +322,7 @@ int fxo_prepare(fx_shared *S)
   const int minch = getenv("PMH_FXO_MINCH") ? std::max(1, atoi(getenv("PMH_FXO_MINCH"))) : 8;
   // several classes on one row tile share ONE launch (fxo_gemm): the resident workgroups are divided among them
   int nplanned = 0, tm_first = 0, tn_first = 128, tnw_first = 0;
-  bool one_tile = S->mfma16 && !getenv("PMH_FXO_NO_MERGE");
+  bool one_tile = true;
   for (int c = 0; c < S->ncls; c++)
     if (tab_of[c] >= 0) {
       if (!nplanned) tm_first = S->C[c].tm, tn_first = S->C[c].tn, tnw_first = S->C[c].tnw;
@@ -508,7 +495,7 @@ int fxo_prepare(fx_shared *S)
       // scripts/micro/orbit_gemm.hip -DAPLAIN, OG_MAP=2: -8 % per GEMM).  The pieces are grouped by their number of column tiles, so that the groups of 8 are
       // uniform.  The partial sums stay indexed by (unit, split): the order of the workgroups changes nothing in the result.  PMH_FXO_NO_XCDMAP=1: piece after
       // piece, all column tiles each.
-      static const bool xcdmap = !getenv("PMH_FXO_NO_XCDMAP");
+      const bool xcdmap = true;
       C.wgf_first = (int)wgfirst.size();
       auto emit = [&](const piece &pc, int nt) {
         wgfirst.push_back((int)(items.size() / 8) - C.item_first);
@@ -629,7 +616,7 @@ int fxo_prepare(fx_shared *S)
   }
   if (S->d_fin_args) pmh_free(ctx, S->d_fin_args), S->d_fin_args = nullptr;
   S->fin_nbx = S->fin_ngroups = 0;
-  if (S->ncls > 1 && !getenv("PMH_FXO_NO_MERGE")) { // the classes' finishing kernels in one launch
+  if (S->ncls > 1) { // the classes' finishing kernels in one launch
     std::vector<fxo_fin_args> fa((size_t)S->ncls);
     for (int c = 0; c < S->ncls; c++) {
       const fxs_class &C = S->C[c];

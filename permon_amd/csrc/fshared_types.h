@@ -111,8 +111,6 @@ struct fx_shared {
   double                *Afund = nullptr, *cpart = nullptr;
   long long              afund_tot = 0, cpart_cap = 0;
   int                    fxo_ready = 0, fxo_S = 1, stripe_rank = 0, stripe_size = 0;
-  // the orbit GEMM on v_mfma_f64_16x16x4 (PMH_FXO_MFMA4 read ONCE, when the operator is created: nothing on the apply path asks the environment)
-  bool                   mfma16 = true;
   // listed columns x valid rows; padded tiles; every (representative, operation, block)
   double                 flops = 0.0, flops_issued = 0.0, flops_dense = 0.0;
 };
@@ -132,6 +130,5 @@ struct fxo_fin_args {
 };
 
 // fshared_plan.hip (host only)
-bool fxo_mfma16();       // PMH_FXO_MFMA4 unset: the orbit GEMM on v_mfma_f64_16x16x4 (asked once per operator, fxs_create)
 int  fxo_row_tile(int M); // row tile of a class with M orbit representatives
 int  fxo_prepare(fx_shared *S);

@@ -442,32 +442,9 @@ int pmh_mg_fine_d0_slots(pmh_mg mg, const float **dinv, float *itheta, float **d
   return 1;
 }
 
-int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready)
-{
-  if (!mg->use_graph || mg->timing_on) return mg_apply_body(mg, b, x, halt, d0_ready);
-  hipStream_t st = mg->ctx->stream;
-  for (auto &g : mg->graphs)
-    if (g.b == b && g.x == x && g.halt == halt && g.d0_ready == d0_ready) {
-      PMH_HIP(hipGraphLaunch(g.exec, st));
-      mg->fine_spmv += g.fine_spmv;
-      return PMH_SUCCESS;
-    }
-  if (mg->graphs.size() >= 8) return mg_apply_body(mg, b, x, halt, d0_ready); // callers with ever-changing vectors: plain launches
-  const long long f0 = mg->fine_spmv;
-  hipGraph_t      graph;
-  PMH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = mg_apply_body(mg, b, x, halt, d0_ready);
-  hipError_t e = hipStreamEndCapture(st, &graph);
-  if (rc) return rc;
-  if (e != hipSuccess) return pmh_set_error(PMH_ERR_HIP, "pmh_mg: stream capture of the V-cycle failed: %s", hipGetErrorString(e));
-  pmh_mg_s::cached_graph g;
-  g.b = b, g.x = x, g.halt = halt, g.d0_ready = d0_ready, g.fine_spmv = mg->fine_spmv - f0;
-  PMH_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-  PMH_HIP(hipGraphDestroy(graph));
-  mg->graphs.push_back(g);
-  PMH_HIP(hipGraphLaunch(g.exec, st)); // the capture recorded the launches without running them
-  return PMH_SUCCESS;
-}
+// (A hipGraph replay of the cycle -- captured once per (b, x, halt) triple -- was opt-in until round 6: slower or equal in every configuration measured, and rocprofv3's
+// kernel tracing crashes on graph launches on this ROCm; docs/LAB_NOTEBOOK.md.)
+int pmh_mg_apply_halt(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready) { return mg_apply_body(mg, b, x, halt, d0_ready); }
 
 static int mg_apply_body(pmh_mg mg, const double *b, double *x, const int *halt, bool d0_ready)
 {
@@ -598,12 +575,6 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   mg->halt      = nullptr;
   mg->fine_spmv = 0;
   mg->timing_on = 0;
-  // hipGraph replay of the cycle is opt-in (PMH_MG_GRAPH=1).  Measured: nil at 8 blocks per GPU (the host runs far ahead of the
-  // GPU), and nil at 1 block per GPU too once the bench stopped recording event pairs inside the timed region (4.85 ms/step with
-  // replay, 4.71 without): the ~5 us floor of the small launches is GPU-side (dependent loads), not host launch overhead.
-  // rocprofv3's kernel tracing crashes on graph launches on this ROCm.
-  mg->use_graph = 0;
-  if (const char *e = getenv("PMH_MG_GRAPH")) mg->use_graph = atoi(e);
   mg->fused = (degree == 2);
   if (const char *e = getenv("PMH_MG_FUSED")) mg->fused = mg->fused && atoi(e); // testing knob: 0 = separate smoothing kernels
   mg->L.resize(nlevels);
@@ -631,11 +602,11 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
     }
     if (l + 1 < nlevels) {
       // FP16: the fine-level operator (almost all of the cycle's bytes) stores fp16 entries; arithmetic and vectors stay fp32
-      static const int f16_levels = getenv("PMH_MG_FP16_LEVELS") ? atoi(getenv("PMH_MG_FP16_LEVELS")) : 2; // fp16 entries on the two finest levels (measured: 22.2 -> 20.6 ms per step, same CG count; a third level gains nothing)
+      const int f16_levels = 2; // fp16 entries on the two finest levels (measured: 22.2 -> 20.6 ms per step, same CG count; a third level gains nothing)
       const int storage = !fl ? PMH_BSR_F64 : ((precision == PMH_MG_FP16 && l < f16_levels) ? PMH_BSR_F16 : PMH_BSR_F32);
       // coarser levels use 512-block tiles: twice the workgroups on operators that are too small to fill the chip, and a kernel
       // instantiation of their own, so that profiler averages of the fine-level operator are not mixed with the coarse launches
-      static const int coarse_tile = getenv("PMH_MG_COARSE_TILE") ? atoi(getenv("PMH_MG_COARSE_TILE")) : 512;
+      const int coarse_tile = 512;
       // congruent blocks (every cube of a structured decomposition): nb_coarse is the number of diagonal blocks on every level; pmh_bsr3_from_csr keeps ONE device copy of the
       // block when all of them turn out to be bit-identical (it compares them), applied to the nb_coarse vector segments
       if (!no_bsr || fl) PMH_CHK(pmh_bsr3_from_csr(A[l], storage, &Lv.Ab, l == 0 ? 0 : coarse_tile, (nb_coarse > 1 && Lv.n % nb_coarse == 0) ? nb_coarse : 1));
@@ -644,7 +615,6 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         pmh_mg_destroy(mg);
         return pmh_set_error(PMH_ERR_SUP, "pmh_mg_create: PMH_MG_FP32/FP16 needs 3x3-block operators on every smoothed level (level %d of size %d is not)", l, Lv.n);
       }
-      if (!Lv.Ab) mg->use_graph = 0; // the CSR launcher keeps host-side launch state (event timing): plain launches only
       Lv.long_rows = P[l]->nrows > 0 && (double)P[l]->nnz / P[l]->nrows > 12.0;
       PMH_CHK(pmh_csr_ensure_transpose(P[l]));
       stage("transpose of the prolongation", l);
@@ -669,7 +639,7 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
         PMH_HIP(hipGetLastError());
       }
       stage("value conversion, diagonal, work vectors", l);
-      if (!getenv("PMH_MG_NO_NODAL_P")) PMH_CHK(mg_build_nodal_transfer(mg, l, fl));
+      PMH_CHK(mg_build_nodal_transfer(mg, l, fl));
       stage("node-wise transfer operators", l);
       // KSPChebyshev recurrence on the window [lo, hi] x lambda_max
       const double a = lo_frac * lambda_max[l], b = hi_frac * lambda_max[l];
@@ -696,7 +666,6 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
   PMH_CHK(pmh_malloc(ctx, sizeof(long long) * (size_t)nb_coarse, (void **)&mg->d_cofs));
   mg->cp_half  = (precision == PMH_MG_FP16 && nlevels > 1) ? 1 : 0;
   mg->cp_scale = 1.0;
-  if (const char *e = getenv("PMH_MG_COARSE_HALF")) mg->cp_half = mg->cp_half && atoi(e); // testing knob
   PMH_CHK(pmh_malloc(ctx, (mg->cp_half ? 2 : w) * (size_t)(tot ? tot : 1), &mg->d_cpinv));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_crs, coarse_rowstart, sizeof(int) * (size_t)(nb_coarse + 1)));
   PMH_CHK(pmh_memcpy_h2d(ctx, mg->d_cofs, ofs.data(), sizeof(long long) * (size_t)nb_coarse));
@@ -745,7 +714,6 @@ extern "C" int pmh_mg_destroy(pmh_mg mg)
     pmh_free(ctx, Lv.pn_rowptr), pmh_free(ctx, Lv.pn_col), pmh_free(ctx, Lv.pn_val), pmh_free(ctx, Lv.rn_rowptr), pmh_free(ctx, Lv.rn_col), pmh_free(ctx, Lv.rn_val);
     pmh_bsr3_destroy(Lv.Ab);
   }
-  for (auto &g : mg->graphs) (void)hipGraphExecDestroy(g.exec);
   pmh_free(ctx, mg->d_crs);
   pmh_free(ctx, mg->d_cofs);
   pmh_free(ctx, mg->d_cpinv);
@@ -765,7 +733,7 @@ extern "C" int pmh_mg_timing_enable(pmh_mg mg, int max_launches)
 {
   PMH_ARG(mg);
   if (!mg->L[0].Ab) return max_launches ? pmh_set_error(PMH_ERR_SUP, "pmh_mg_timing_enable: the fine level runs on the CSR kernel; use pmh_csr_timing_enable") : PMH_SUCCESS;
-  mg->timing_on = max_launches > 0; // event pairs cannot be replayed from a graph: timed applications use plain launches
+  mg->timing_on = max_launches > 0;
   return pmh_bsr3_timing_enable(mg->L[0].Ab, max_launches);
 }
 

@@ -32,17 +32,7 @@ struct pmh_mg_s {
   double                cp_scale;
   const int            *halt;
   long long             fine_spmv; // fine-level SpMVs issued (statistics)
-  // the cycle is a fixed launch sequence: it is captured once per (b, x, halt) triple into a hipGraph and replayed
-  struct cached_graph {
-    const double   *b;
-    double         *x;
-    const int      *halt;
-    bool            d0_ready;
-    hipGraphExec_t  exec;
-    long long       fine_spmv;
-  };
-  std::vector<cached_graph> graphs;
-  int                       use_graph, timing_on;
+  int                       timing_on;
   int                       fused; // degree 2 + block operators: smoothing steps finished inside the operator kernel
   std::vector<pmh_csr>      owned; // CSR handles created for this hierarchy by pmh_mg_create_box (destroyed with it)
 };

@@ -1164,9 +1164,8 @@ static int solve_fused(pmh_mpgp s)
     // driver's 20-step window were such orphans). Nothing numerical depends on it: the product is then enqueued after the test, by the `!spec` branch above.
     bool orphan_risk = false;
     {
-      static const bool always = getenv("PMH_MPGP_ALWAYS_SPEC") != nullptr;
-      const double      m      = s->cvg_margin;
-      if (!always && m > 0.0) {
+      const double m = s->cvg_margin;
+      if (m > 0.0) {
         const double red = (prev_margin > 0.0 && m < prev_margin) ? m / prev_margin : 1.0;
         orphan_risk      = (m < 3.0) || (m * red < 2.0);
       }

@@ -141,7 +141,7 @@ static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, 
   E->ctx = ctx, E->nbr = nbr, E->storage = storage, E->scale = 1.0, E->col = nullptr, E->val = nullptr;
   // long rows (W > 48: the coarse operators of an aggregation hierarchy) and small levels (fewer block rows than fill the chip with 4 lanes each: the trips of a row are a
   // serial chain -- 7 of them for a 27-point operator) take 16 lanes per block row
-  E->lpr = (info[0] > 48 || (nbr < 16384 && !getenv("PMH_MV_NO_LPR16"))) ? 16 : 4;
+  E->lpr = (info[0] > 48 || nbr < 16384) ? 16 : 4;
   E->W   = (info[0] + E->lpr - 1) / E->lpr * E->lpr;
   double inv_scale = 1.0;
   if (storage == PMH_BSR_F16) { // power-of-two scale that brings the largest entry to [1, 2) (as pmh_bsr3_from_csr)
@@ -388,8 +388,7 @@ static int mv_launch(pmh_mv_ell E, const T *x, T *y, int epi, const pmh_mv_epi<T
   if (ep) e = *ep;
   else memset(&e, 0, sizeof(e));
   const T sc = (T)E->scale;
-  static const int xmap_on = getenv("PMH_MV_NO_XCDMAP") ? 0 : 1; // A/B
-  const int        xmap    = (xmap_on && g.x >= 64) ? 1 : 0;
+  const int xmap = g.x >= 64 ? 1 : 0;
 #define MV_LAUNCH(EPI) \
   do { \
     if (E->lpr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_spmv<TM, T, PMH_MV_R, EPI, 16>), g, blk, 0, st, E->nbr, E->W / 4, (const int *)E->col, (const void *)E->val, sc, x, y, e, halt, xmap); \

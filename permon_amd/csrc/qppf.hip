@@ -636,8 +636,7 @@ static int qppf_left(pmh_qppf pf, const double *v);
 // the one-launch form (k_gt_fused1d) applies: implicit orthonormalisation, long-row G0, one-lane-per-row G0', m <= 64
 static bool q_fused_dense(pmh_qppf pf)
 {
-  static const bool off = getenv("PMH_NO_GT_DENSE_FUSION") != nullptr;
-  return pf->implicit_orth && pf->G->l_nchunks > 0 && pf->m <= 64 && pf->G->transpose && pf->G->transpose->st_rl == 1 && !off;
+  return pf->implicit_orth && pf->G->l_nchunks > 0 && pf->m <= 64 && pf->G->transpose && pf->G->transpose->st_rl == 1;
 }
 // aux_u != nullptr (one-launch form only): G0 aux_u shares the pass over G0, T G0 aux_u -> aux_Gu and its squared norm -> scalar slot aux_slot by workgroup 0.
 // epi (mode 1, one-launch form only): the vector phase folded into the kernel, pin = the operator's input vector.
@@ -893,9 +892,8 @@ int pmh_op_penalized_arm_aux_normG(pmh_op op, const double *u, double *Gu, int s
 {
   PenalizedOp *o = dynamic_cast<PenalizedOp *>(op);
   PMH_ARG(o && u && Gu && slot >= 0 && slot < PMH_NSCAL);
-  static const bool off = getenv("PMH_NO_AUX_NORMG") != nullptr; // A/B: ||G u|| by its own two launches
   o->aux_done = 0;
-  if (off || o->dc || !o->fused_dense()) return PMH_SUCCESS; // not armed: the caller's own launches follow
+  if (o->dc || !o->fused_dense()) return PMH_SUCCESS; // not armed: the caller's own launches follow
   o->aux_u = u, o->aux_Gu = Gu, o->aux_slot = slot;
   return PMH_SUCCESS;
 }

@@ -516,23 +516,18 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
 
   const double avg = nrows ? (double)nnz / nrows : 0.0;
   int medium_stream = 1, m_nnzb = 2048, m_mode = 0, m_nt = 3; // measured best on 81 nnz/row K_i (round 4 sweep at 43^3 x 8 distinct blocks: nt 3 = non-temporal 16-byte value / 8-byte column loads 0.391 ms, nt 1 0.406; 1024 / 4096 entries per row block 0.41 / 0.43)
-  if (const char *t = getenv("PMH_SPMV_MTUNE")) sscanf(t, "%d,%d,%d,%d", &medium_stream, &m_nnzb, &m_mode, &m_nt); // medium-row tuning knob
   const bool medium = avg > 24.0 && avg <= 256.0 && medium_stream;
   if (avg <= 24.0 || avg > 1024.0 || medium) { // short rows: LDS-staged row blocks; very long rows (G of the coarse problem): one workgroup per row
     A->kind = PMH_SPMV_STREAM;
-    // tuning knobs (defaults chosen from measurements on MI355X, see profiles/): PMH_SPMV_TUNE="nnzb,mode,nt"
+    // tile (entries per row block), mode (0 one row block per workgroup / 2 persistent grid), non-temporal mask: chosen from the sweeps of rounds 1-4 (profiles/r01_spmv_tune_*.txt;
+    // the tuning knobs PMH_SPMV_TUNE / _MTUNE / _VTUNE went at the end of round 6)
     A->st_nnzb = 1024, A->st_mode = 2, A->st_nt = 1, A->st_rl = 1;
     if (medium) A->st_nnzb = m_nnzb, A->st_mode = m_mode, A->st_nt = m_nt, A->st_rl = 8;
-    if (const char *t = getenv("PMH_SPMV_TUNE")) {
-      if (!medium) sscanf(t, "%d,%d,%d", &A->st_nnzb, &A->st_mode, &A->st_nt);
-    }
-    if (A->st_nnzb != 512 && A->st_nnzb != 1024 && A->st_nnzb != 2048 && A->st_nnzb != 4096) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: nnzb must be 512, 1024, 2048 or 4096");
-    if (A->st_mode != 0 && A->st_mode != 2) return pmh_set_error(PMH_ERR_ARG, "PMH_SPMV_TUNE: mode must be 0 (one row block per workgroup) or 2 (persistent grid); the double-buffered mode 1 was measured slower and is not instantiated");
     std::vector<int> rb;
     A->n_rowblocks = build_rowblocks(nrows, rowptr, A->st_nnzb - 1, rb); // -1: room for the aligned-down start of the 16-byte load variant
     PMH_HIP(hipMalloc((void **)&A->d_rowblocks, sizeof(int) * rb.size()));
     PMH_CHK(pmh_memcpy_h2d(ctx, A->d_rowblocks, rb.data(), sizeof(int) * rb.size()));
-    if (A->st_rl == 1 && !(A->st_nt & 2) && A->st_nnzb <= 2048 && !getenv("PMH_SPMV_NO_COL16")) {
+    if (A->st_rl == 1 && !(A->st_nt & 2) && A->st_nnzb <= 2048) {
       // 16-bit column offsets per row block where every block spans < 65 536 columns (device-private copy next to the int32 indices)
       std::vector<int>            cb((size_t)A->n_rowblocks, 0);
       std::vector<unsigned short> c16((size_t)nnz + 8, 0);
@@ -552,7 +547,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
         PMH_CHK(pmh_memcpy_h2d(ctx, A->d_cbase, cb.data(), sizeof(int) * cb.size()));
       }
     }
-    if (A->st_rl == 1 && A->st_mode == 2 && nrows > 0 && !getenv("PMH_SPMV_NO_ELL")) {
+    if (A->st_rl == 1 && A->st_mode == 2 && nrows > 0) {
       // slot-major copy for uniformly short rows (k_spmv_ell): <= 8 non-zeros per row and at most 25 % padding
       int wmax = 0;
       for (int r = 0; r < nrows; r++) wmax = std::max(wmax, rowptr[r + 1] - rowptr[r]);
@@ -606,7 +601,6 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
     A->kind          = PMH_SPMV_VECTOR;
     A->lanes_per_row = (avg <= 48.0) ? 8 : (avg <= 160.0 ? 16 : (avg <= 512.0 ? 32 : 64));
     A->st_nt         = 1;
-    if (const char *t = getenv("PMH_SPMV_VTUNE")) sscanf(t, "%d,%d", &A->lanes_per_row, &A->st_nt); // tuning knob: "lanes,nt"
     const int rpb    = PMH_BLOCK / A->lanes_per_row;
     A->n_rowblocks   = (nrows + rpb - 1) / rpb;
     A->n_launch_blocks = ((A->n_rowblocks + 7) / 8) * 8;
@@ -614,7 +608,7 @@ extern "C" int pmh_csr_create(pmh_ctx ctx, int nrows, int ncols, const int *rowp
   PMH_HIP(hipMalloc((void **)&A->d_blockpart, sizeof(double) * 3 * (size_t)(A->n_launch_blocks ? A->n_launch_blocks : 8)));
   if (avg > 1024.0 && !getenv("PMH_SPMV_NO_LONG")) { // chunk table of the long-row kernels (plain / ADD / SUB epilogues)
     std::vector<int> ch, lrow((size_t)nrows + 1, 0);
-    const int        long_chunk = getenv("PMH_LONG_CHUNK") ? std::max(256, atoi(getenv("PMH_LONG_CHUNK"))) : PMH_LONG_CHUNK;
+    const int        long_chunk = PMH_LONG_CHUNK;
     for (int r = 0; r < nrows; r++) {
       for (int k = rowptr[r]; k < rowptr[r + 1]; k += long_chunk) {
         ch.push_back(r), ch.push_back(k), ch.push_back(std::min(k + long_chunk, rowptr[r + 1]));
@@ -680,7 +674,7 @@ static int launch(pmh_csr A, const double *x, double *y, const EpiArgs &a)
   const int nl  = A->n_launch_blocks;
   if (A->nrows == 0) return PMH_SUCCESS;
   if (A->l_nchunks && EPI != PMH_EPI_MPGP) {
-    static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+    const bool long_nt = true; // (non-temporal matrix stream of the long-row kernels)
     if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
     else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, a.halt, A->d_lpart);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_long_fin<EPI>), dim3((A->nrows + PMH_BLOCK - 1) / PMH_BLOCK), dim3(PMH_BLOCK), 0, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, x, y, a);
@@ -877,7 +871,7 @@ extern "C" int pmh_csr_mult(pmh_csr A, const double *x, double *y)
 int pmh_csr_mult_partials(pmh_csr A, const double *x, const int **lrow, const double **part)
 {
   PMH_ARG(A && x && lrow && part && A->l_nchunks > 0);
-  static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+  const bool long_nt = true; // (non-temporal matrix stream of the long-row kernels)
   if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
   else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
   PMH_HIP(hipGetLastError());
@@ -889,7 +883,7 @@ int pmh_csr_mult_partials2(pmh_csr A, const double *x, const double *x2, const i
 {
   PMH_ARG(A && x && x2 && lrow && part && part2 && A->l_nchunks > 0);
   if (!A->d_lpart2) PMH_CHK(pmh_malloc(A->ctx, sizeof(double) * (size_t)A->l_nchunks, (void **)&A->d_lpart2));
-  static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+  const bool long_nt = true; // (non-temporal matrix stream of the long-row kernels)
   if (long_nt) hipLaunchKernelGGL(k_spmv_long_part2<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, x2, A->d_lpart, A->d_lpart2);
   else hipLaunchKernelGGL(k_spmv_long_part2<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, A->ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, x2, A->d_lpart, A->d_lpart2);
   PMH_HIP(hipGetLastError());
@@ -905,7 +899,7 @@ int pmh_csr_mult_then_dense(pmh_csr A, const double *x, const double *Mt, double
   pmh_ctx      ctx = A->ctx;
   const size_t lds = sizeof(double) * (size_t)A->nrows;
   if (A->l_nchunks) {
-    static const bool long_nt = getenv("PMH_LONG_NT") ? atoi(getenv("PMH_LONG_NT")) != 0 : true;
+    const bool long_nt = true; // (non-temporal matrix stream of the long-row kernels)
     if (long_nt) hipLaunchKernelGGL(k_spmv_long_part<true>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
     else hipLaunchKernelGGL(k_spmv_long_part<false>, dim3(A->l_nchunks), dim3(PMH_BLOCK), 0, ctx->stream, (const int *)A->d_lchunks, (const int *)A->d_col, (const double *)A->d_val, x, (const int *)nullptr, A->d_lpart);
     hipLaunchKernelGGL(k_rows_then_dense, dim3(1), dim3(PMH_BLOCK), lds, ctx->stream, A->nrows, (const int *)A->d_lrow, (const double *)A->d_lpart, Mt, y, nd, nh);

@@ -436,7 +436,7 @@ int SvmDualOp::mult(const double *a, double *Ha)
     // rows in flight per wave-instruction group: 2 x UNR rows of 512 B (16-byte loads, UNR of them outstanding per lane).  UNR decides which wave visits which
     // rows, i.e. the summation order of pass 1 (last-digit differences between UNR values; fixed for a given UNR).  Measured 4 / 8 / 12 / 16 on configs[4]: 464
     // / 452-488 / 433 / 487 iterations per second -- inside the run-to-run spread of the box (the two passes already stream X at the box's copy rate): 4 stays
-    static const int unr = getenv("PMH_SVM_UNR") ? atoi(getenv("PMH_SVM_UNR")) : 4;
+    const int unr = 4; // rows in flight per wave of the two passes (4 / 8 / 12 / 16 measured: inside the run-to-run spread)
 #define SVM_GO(U)                                                                                                                          \
   do {                                                                                                                                     \
     SVM_PASS(k_svm_xt64<U>, dim3(nblocks), dim3(PMH_BLOCK), 0, ctx->stream, n, X, y, a, part);                                   \

@@ -8,7 +8,7 @@
 
 int pmh_vec_grid(int n)
 {
-  static const int epb = getenv("PMH_VEC_EPB") ? std::max(256, atoi(getenv("PMH_VEC_EPB"))) : 256; // elements per workgroup of the streaming Vec kernels (grid capped at PMH_MAX_VEC_BLOCKS): one element per thread up to 524 288 entries -- dual vectors of ~1e5 entries ran on 50 workgroups with 2048 each, 4-5 us above the launch floor for the five-operand kernels
+  const int epb = 256; // elements per workgroup of the streaming Vec kernels (grid capped at PMH_MAX_VEC_BLOCKS): one element per thread up to 524 288 entries -- dual vectors of ~1e5 entries ran on 50 workgroups with 2048 each, 4-5 us above the launch floor for the five-operand kernels
   long long b = ((long long)n + epb - 1) / epb;
   if (b < 1) b = 1;
   if (b > PMH_MAX_VEC_BLOCKS) b = PMH_MAX_VEC_BLOCKS;

@@ -195,16 +195,12 @@ def test_explicit_orbit_storage(ctx, sub, nel, nsym):
     assert np.linalg.norm(tot - Fref @ lam) <= 1e-10 * np.linalg.norm(Fref @ lam)
 
 
-@pytest.mark.parametrize("mfma4,tm", [(0, 144), (0, 128), (0, 112), (0, 96), (0, 80), (1, 128), (1, 120), (1, 112), (1, 104), (1, 96)])
-def test_explicit_orbit_row_tiles(ctx, mfma4, tm, monkeypatch):
-    """Every row tile of the orbit GEMM -- the default kernel k_fxo_gemm16<NI, NWM> (v_mfma_f64_16x16x4: tiles 144 / 112 / 80 with 1 x 4 waves, 128 / 96 with 2 x 2) and, behind
-    PMH_FXO_MFMA4=1, the 4x4x4_4b kernels of rounds 2-3 (k_fxo_gemm: tile 128; k_fxo_gemm4<NA>: tiles 8 NA = 96 ... 120) -- forced through PMH_FXO_TM, two or more row tiles
-    per class (nel = 20: n_c = 7206, ~165 representatives), F = B pinv(K) B' through each and the blocks rebuilt from the pre-tiled rows."""
+@pytest.mark.parametrize("tm", [144, 128, 112, 96, 80])
+def test_explicit_orbit_row_tiles(ctx, tm, monkeypatch):
+    """Every row tile of the orbit GEMM k_fxo_gemm16<NI, NWM> (v_mfma_f64_16x16x4: tiles 144 / 112 / 80 with 1 x 4 waves, 128 / 96 with 2 x 2), forced through PMH_FXO_TM,
+    two or more row tiles per class (nel = 20: n_c = 7206, ~165 representatives), F = B pinv(K) B' through each and the blocks rebuilt from the pre-tiled rows.  (The
+    4x4x4_4b kernels of rounds 2-3 went at the end of round 6.)"""
     monkeypatch.setenv("PMH_FXO_TM", str(tm))
-    if mfma4:
-        monkeypatch.setenv("PMH_FXO_MFMA4", "1")
-    else:
-        monkeypatch.delenv("PMH_FXO_MFMA4", raising=False)
     nel = 20
     f = pa.CubeFeti((2, 2, 2), nel, contact=True)
     G, e = f.coarse()

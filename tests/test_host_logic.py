@@ -247,15 +247,13 @@ def test_class_sym_plan_balances_the_tile_bytes():
 
 def test_orbit_row_tile_rule(monkeypatch):
     """PMH_FX_CLASS_ORBIT (host helper, no GPU): the row tile of the orbit GEMM.  Default kernel (k_fxo_gemm16, v_mfma_f64_16x16x4: 16 rows per instruction tile): the tile among
-    144, 128, 112, 96, 80 that pads the representatives' rows least (ties: the larger): configs[2]'s 715 -> 5 x 144 = 720.  PMH_FXO_MFMA4=1 (the 4x4x4_4b kernels of rounds 2-3):
-    128 unless a tile of 8 NA = 96 ... 120 rows pads by more than 2.5 % less: 715 -> 6 x 120."""
+    144, 128, 112, 96, 80 that pads the representatives' rows least (ties: the larger): configs[2]'s 715 -> 5 x 144 = 720."""
     import ctypes as C
 
     import permon_amd as pa
 
     L = pa.load()
     monkeypatch.delenv("PMH_FXO_TM", raising=False)
-    monkeypatch.delenv("PMH_FXO_MFMA4", raising=False)
 
     def rule(M):
         tm, Mp = C.c_int(), C.c_int()
@@ -272,17 +270,7 @@ def test_orbit_row_tile_rule(monkeypatch):
     monkeypatch.setenv("PMH_FXO_TM", "112")
     assert rule(715) == (112, 784)
     monkeypatch.delenv("PMH_FXO_TM")
-    monkeypatch.setenv("PMH_FXO_MFMA4", "1")
-    assert rule(715) == (120, 720)
-    assert rule(128) == (128, 128) and rule(1024) == (128, 1024) and rule(256) == (128, 256)
-    assert rule(96) == (96, 96) and rule(1) == (96, 96)
-    assert rule(176) == (96, 192)
-    for M in range(1, 2000, 7):
-        tm, Mp = rule(M)
-        assert tm in (128, 120, 112, 104, 96) and Mp % tm == 0 and M <= Mp < M + tm
-        assert Mp <= -(-M // 128) * 128  # never more padding than the 128-row tile
-    monkeypatch.setenv("PMH_FXO_TM", "112")
-    assert rule(715) == (112, 784)
+    assert rule(715) == (144, 720)
 
 
 def test_box_symmetries_c_vs_numpy():
