@@ -816,7 +816,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     need_py_hier = a.kplus_pc == "mg" and not partition and (a.mg_builder == "python" or a.regularize or (world == 1 and not a.sim_world and not a.no_cpu_baseline))
     hier = make_hier(blocks, per) if need_py_hier else None
     use_c_builder = a.kplus_pc == "mg" and (a.mg_builder == "c" or bool(partition)) and not a.regularize
-    mg_sa = dict(ndof=3, max_coarse=3 * (a.mg_min_nodes or 500), theta=0.08) if (partition and use_c_builder) else None  # blocks that are not boxes: the algebraic hierarchy (pmh_mg_create_sa)
+    # blocks that are not boxes: the algebraic hierarchy (pmh_mg_create_sa); tiny test problems: at least one smoothed level
+    mg_sa = dict(ndof=3, max_coarse=min(3 * (a.mg_min_nodes or 500), max(6, int(np.diff(f.block_rowstart).min()) // 4)), theta=0.08) if (partition and use_c_builder) else None
 
     def mg_box(nblk):
         # (explicit K^+: the rank's own inner-Krylov solver only serves a handful of set-up products -- d = B K^+ f, the replica's columns come from the replica solver --

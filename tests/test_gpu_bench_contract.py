@@ -168,9 +168,16 @@ def test_two_ranks_on_one_gpu_host_transport():
     for args, key in ((("--nel", "7", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),
                       (("--nel", "7", "--young", "distinct", "--steps", "40", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),  # 8 materials: every rank the closed orbit classes of its own 4 blocks
                       (("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"), "norm_lambda_child_after_last_step"),
-                      (("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2"), "norm_x_after_last_step")):
+                      (("--workload", "svm", "--svm-n", "200000", "--steps", "10", "--warmup", "2"), "norm_x_after_last_step"),
+                      # round 6: an IRREGULAR partition (8 staircase-bounded subdomains, 4 per rank: algebraic hierarchy, per-block explicit operators / the inner-Krylov K^+ on it) ...
+                      (("--partition", "staircase", "--nel", "6", "--steps", "30", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--no-iterative"), "norm_lambda_child_after_last_step"),
+                      (("--partition", "staircase", "--nel", "6", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-c2", "--kplus", "iterative", "--no-iterative"), "norm_lambda_child_after_last_step"),
+                      # ... and the explicit headline WITH its inner-Krylov pass: every N > 1 line carries `iterative` next to the headline
+                      (("--nel", "7", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-c2"), "norm_lambda_child_after_last_step")):
         one = _run(*args)[1]
         two = _run("--gpus", "2", *args, env=env)[1]
+        if "--no-iterative" not in args and "--workload" not in args:
+            assert two["iterative"]["value"] > 0 and "k_bsr3<double>" in two["iterative"]["roofline"]["kernel"], two.get("iterative")  # (4 blocks per rank: the one-column kernel)
         assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and "host" in two["config"]["transport"]
         a, b = float(one["config"]["checksum"][key]), float(two["config"]["checksum"][key])
         assert abs(a - b) <= 1e-9 * abs(a), (args, a, b)  # (the FETI paths reproduce the one-rank iterate bit for bit: replicated dual arithmetic, the split sums added in a fixed order)
