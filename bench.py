@@ -641,7 +641,7 @@ def pmc_lookup(prefix, fname, combine="mean", contains=None):
     scripts/gpu_pmc*.sh with the git state it measured).  (None, reason) when the file or the kernel is missing: the line then
     carries no traffic figure rather than a stale one."""
     # the newest committed pass of that name wins (profiles/r05_* over r04_*: the callers name the round-4 file the figure first came from)
-    for newer in ("r05_" + fname[4:],) if fname.startswith("r04_") else ():
+    for newer in ("r05_" + fname[4:], "r06_" + fname[4:]) if fname.startswith("r04_") else ():
         if os.path.exists(os.path.join(ROOT, "profiles", newer)):
             fname = newer
     path = os.path.join(ROOT, "profiles", fname)
