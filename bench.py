@@ -1021,7 +1021,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if world == 1 and not a.sim_world:
             pmc_file = ("r04_pmc_traffic_feti_explicit.json" if (full_size and congruent) else
                         "r04_pmc_traffic_configs3.json" if (a.nel == 21 and a.sub == "4,4,4" and congruent) else
-                        "r04_pmc_traffic_general.json" if (a.nel == 43 and a.sub == "2,2,2" and not congruent and not partition) else None)
+                        "r04_pmc_traffic_general.json" if (a.nel == 43 and a.sub == "2,2,2" and not congruent and not partition) else
+                        "r06_pmc_traffic_nosym21.json" if (partition == "staircase" and a.nel == 21) else None)
         traffic, tsrc = pmc_lookup(ppref, pmc_file, combine="sum") if pmc_file else (None, "not the configuration of a committed PMC pass")
         roofline = {
             "bound": "hbm", "kernel": ("k_fxs_symm8 (+ k_fxs_symfin): Y = W_c X, ONE symmetric dense fp64 matrix W_c = (K^+)[U_c, U_c] per class of congruent blocks, kept as its lower block-triangle in 16x16 tiles "
