@@ -602,6 +602,9 @@ typedef struct {
                                 side effect on the two QPs printed after it when the Dirichlet dofs are enforced by B (see pmh_kspfeti_solve in kspfeti.hip) */
   char  *view_buf; int view_cap; /* the text (full PETSc viewer lines, '\n'-separated, NUL-terminated, truncated to view_cap) goes here; NULL: to stdout */
   pmh_smalxe_opts smalxe;    /* -qps_smalxe_* / -qps_smalxe_qps_* of the SMALXE solve taken with project == 0 (its outer tolerances are rtol / atol / divtol / max_it above) */
+  int    kplus_pc;           /* -dual_mat_inv_pc_type: 0 jacobi (default: what the golden tests pin), 1 gamg = the algebraic V-cycle built inside the library (pmh_mg_create_sa) on the
+                                matrix MATINV inverts, near-kernel = the kernel vectors R -- subdomains of any shape, any of the three generalised inverses */
+  int    kplus_pc_ndof;      /* dofs per node of the aggregation's node graph; 0: 3 where the blocks come with 6 kernel vectors and 3 | their sizes, else 1 */
 } pmh_kspfeti_opts;
 typedef struct {
   int    iteration, reason;  /* CG iterations on P F; with project == 0 SMALXE's outer iterations */
@@ -621,7 +624,7 @@ int pmh_qpt_matis_to_blockdiag(int nsub, const int *l2g_start, const int *l2g, i
                                int *rowptr, int *col, double *val, int *counter, int *is_interface, int *n_i2g, int *i2g);
 int pmh_kspfeti_default_opts(pmh_kspfeti_opts *o);
 /* the options-database keys of the FETI chain (-feti_gluing_type, -feti_gluing_exclude_dirichlet, -SCALE_ON, -regularize,
-   -qpt_dualize_Kplus_mp, -dual_pc_dual_type, -qps_rtol/-qps_atol/-qps_divtol/-qps_max_it, -dual_mat_inv_ksp_rtol/_max_it) */
+   -qpt_dualize_Kplus_mp, -dual_pc_dual_type, -qps_rtol/-qps_atol/-qps_divtol/-qps_max_it, -dual_mat_inv_ksp_rtol/_max_it, -dual_mat_inv_pc_type jacobi | gamg) */
 int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opts *o, char *unknown, int unknown_cap);
 int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstart, const int *rowptr, const int *col, const double *val, const double *f, const int *l2g, int n_dir,
                       const int *dir_local, int kdim, const double *R, const pmh_kspfeti_opts *o, double *u_host, double *lambda_host /* or NULL */, int lambda_cap,

@@ -76,7 +76,7 @@ class KspFetiOpts(C.Structure):
                 ("E_orth_type", C.c_int), ("lumped_pc", C.c_int), ("regularize_rho", C.c_double),
                 ("kplus_rtol", C.c_double), ("kplus_max_it", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("divtol", C.c_double), ("max_it", C.c_int), ("max_it_set", C.c_int),
                 ("explicit_dual", C.c_int), ("explicit_rtol", C.c_double), ("view_convergence", C.c_int), ("view_kkt", C.c_int), ("matis_to_diag_norm", C.c_int),
-                ("view_buf", C.c_char_p), ("view_cap", C.c_int), ("smalxe", SmalxeOpts)]
+                ("view_buf", C.c_char_p), ("view_cap", C.c_int), ("smalxe", SmalxeOpts), ("kplus_pc", C.c_int), ("kplus_pc_ndof", C.c_int)]
 
 
 class KspFetiStats(C.Structure):

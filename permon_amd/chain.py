@@ -322,7 +322,7 @@ class FetiDualQP:
 
 
 def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, gluing="full", scale=True, exclude_dirichlet=False, regularize=None, lumped=False,
-                 rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000, options=None, regularize_rho=0.0, explicit=False):
+                 rtol=1e-5, atol=1e-50, divtol=1e4, max_it=10000, kplus_rtol=1e-12, kplus_max_it=20000, options=None, regularize_rho=0.0, explicit=False, kplus_pc="jacobi"):
     """KSPFETI (src/ksp/impls/feti/feti.c:71-156) for a decomposed linear problem, one call into pmh_kspfeti_solve (C++):
     K block-diagonal scipy CSR, f split among copies, l2g global dof of every local dof, dirichlet_local = local dofs enforced
     by B (TFETI) or None, R = (kdim, N) kernel vectors (zero over non-floating blocks) or None.
@@ -349,6 +349,7 @@ def KSPFETISolve(ctx, block_rowstart, K, f, l2g, dirichlet_local=None, R=None, g
     o.lumped_pc, o.regularize_rho = int(bool(lumped)), float(regularize_rho)
     o.kplus_rtol, o.kplus_max_it, o.rtol, o.atol, o.divtol, o.max_it = kplus_rtol, kplus_max_it, rtol, atol, divtol, max_it
     o.explicit_dual = int(bool(explicit))  # F through the explicit local dual operators (pmh_fexplicit_*)
+    o.kplus_pc = {"jacobi": 0, "gamg": 1, "mg": 1}[kplus_pc]  # -dual_mat_inv_pc_type: the algebraic V-cycle (pmh_mg_create_sa) as the PC of MATINV's inner KSP
     if options:  # the reference's command line on top of the keyword arguments (pmh_kspfeti_set_from_options)
         left = C.create_string_buffer(2048)
         check(ctx.L.pmh_kspfeti_set_from_options(options.encode(), C.byref(o), left, len(left)))

@@ -367,6 +367,7 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
   pmh_csr        Kc = nullptr, Kregc = nullptr, Gc = nullptr;
   pmh_blockdiag  Kb = nullptr, Kregb = nullptr;
   pmh_matinv     Kp = nullptr;
+  pmh_mg         mg = nullptr; // -dual_mat_inv_pc_type gamg
   pmh_gluing     B  = nullptr;
   pmh_qppf       pf = nullptr, pfo = nullptr; // of G = R'B'; of the orthonormalised G (-dual_qp_E_orth_type)
   pmh_csr        Goc = nullptr;
@@ -456,6 +457,36 @@ extern "C" int pmh_kspfeti_solve(pmh_ctx ctx, int nsub, const int *block_rowstar
     } else {
       GO(pmh_matinv_create(Kb, o->kplus_rtol, 1e-50, o->kplus_max_it, 1, &Kp));
       if (any_kernel) GO(pmh_matinv_set_nullspace(Kp, kdim, Rn.data()));
+    }
+    if (o->kplus_pc == 1) {
+      // -dual_mat_inv_pc_type gamg: the algebraic V-cycle on the matrix this MATINV inverts.  The regularised / fixed matrices are non-singular: the rigid-body modes go in
+      // as the near-kernel of non-singular blocks; the Moore-Penrose form keeps them as the kernel.  Single precision cycles where the levels have 3 x 3 blocks
+      int ndof = o->kplus_pc_ndof;
+      if (ndof <= 0) {
+        ndof = (kdim == 6) ? 3 : 1;
+        for (int s = 0; s < nsub && ndof == 3; s++)
+          if ((block_rowstart[s + 1] - block_rowstart[s]) % 3 || (bdim[s] != 6 && bdim[s] != 0)) ndof = 1;
+      }
+      const bool    singular = !Kregc;
+      const pmh_csr Kpc      = Kregc ? Kregc : Kc;
+      std::vector<int>    hrp, hci;
+      std::vector<double> hva;
+      const int          *prp = rowptr, *pci = col;
+      const double       *pva = val;
+      if (Kregc) { // (host copy of the matrix the PC is built on: the regularised / fixed one was assembled above and lives on the device)
+        hrp.resize((size_t)N + 1), hci.resize((size_t)Kregc->nnz), hva.resize((size_t)Kregc->nnz);
+        GO(pmh_memcpy_d2h(ctx, hrp.data(), Kregc->d_rowptr, sizeof(int) * hrp.size()));
+        GO(pmh_memcpy_d2h(ctx, hci.data(), Kregc->d_col, sizeof(int) * hci.size()));
+        GO(pmh_memcpy_d2h(ctx, hva.data(), Kregc->d_val, sizeof(double) * hva.size()));
+        prp = hrp.data(), pci = hci.data(), pva = hva.data();
+      }
+      bool blocks3 = ndof == 3;
+      if (blocks3 && pmh_matinv_enable_bsr3(Kp)) blocks3 = false; // (no 3 x 3 block structure: the fp64 cycle on the CSR kernels)
+      const int prec = blocks3 ? PMH_MG_FP16 : PMH_MG_FP64;
+      rc = pmh_mg_create_sa(ctx, Kpc, nsub, block_rowstart, ndof, prp, pci, pva, singular ? kdim : 0, singular ? Rn.data() : nullptr, singular ? 0 : kdim, singular ? nullptr : Rn.data(), 1500, 0.08, 2, prec, &mg);
+      if (rc && prec != PMH_MG_FP64) rc = pmh_mg_create_sa(ctx, Kpc, nsub, block_rowstart, ndof, prp, pci, pva, singular ? kdim : 0, singular ? Rn.data() : nullptr, singular ? 0 : kdim, singular ? nullptr : Rn.data(), 1500, 0.08, 2, PMH_MG_FP64, &mg);
+      if (rc) goto done;
+      GO(pmh_matinv_set_pc_mg(Kp, mg));
     }
     GO(pmh_gluing_create(ctx, N, nl, (int)lrow.size(), lrow.data(), lroot.data(), lval.data(), &B));
     if (o->explicit_dual) { // the exact K^+ path: W_b = (K_b^+)[Gamma_b, Gamma_b] by one K^+ solve per column, then F = Bhat W Bhat'
@@ -613,6 +644,7 @@ done:
   pmh_qppf_destroy(pfo), pmh_qppf_destroy(pf);
   pmh_gluing_destroy(B);
   pmh_matinv_destroy(Kp);
+  pmh_mg_destroy(mg);
   pmh_blockdiag_destroy(Kregb), pmh_blockdiag_destroy(Kb);
   pmh_csr_destroy(Goc), pmh_csr_destroy(Gc), pmh_csr_destroy(Kregc), pmh_csr_destroy(Kc);
   return rc;

@@ -371,6 +371,12 @@ extern "C" int pmh_kspfeti_set_from_options(const char *options, pmh_kspfeti_opt
     } else if (k == "dual_pc_dual_type") rc = get_enum(t, pctypes, 2, &o->lumped_pc) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_rtol") rc = get_real(t, &o->kplus_rtol) ? -1 : 1;
     else if (k == "dual_mat_inv_ksp_max_it") rc = get_int(t, &o->kplus_max_it) ? -1 : 1;
+    else if (k == "dual_mat_inv_pc_type") { // the PC of MATINV's inner KSP (MatInvGetKSP; PETSc's PCType names): jacobi | gamg (mg: the same algebraic hierarchy)
+      static const char *const pcs[] = {"jacobi", "gamg", "mg"};
+      int v = 0;
+      rc = get_enum(t, pcs, 3, &v) ? -1 : 1;
+      if (rc == 1) o->kplus_pc = v ? 1 : 0;
+    }
     else if (k == "feti") rc = get_bool(t, &b) ? -1 : 1; // the combination this driver always performs
     else if (k == "qp_chain_view_kkt") rc = get_bool(t, &o->view_kkt) ? -1 : 1;
     else if (k == "qps_view_convergence") rc = get_bool(t, &o->view_convergence) ? -1 : 1;

@@ -205,3 +205,42 @@ def test_irregular_partition_contact_solution_equals_box_decomposition(ctx, stai
     assert sq.reason > 0
     lq = q.dual_solution()
     assert np.linalg.norm(lq - lam) <= 1e-4 * np.linalg.norm(lam)
+
+
+@pytest.mark.parametrize("regularize", [None, True, False])
+def test_kspfeti_on_an_irregular_partition_with_the_algebraic_pc(ctx, regularize):
+    """KSPFETI (src/ksp/impls/feti/feti.c:71-156) on a decomposition into subdomains that are not boxes, `-dual_mat_inv_pc_type gamg`: MATINV's inner KSP preconditioned by the
+    algebraic V-cycle, on each of the three generalised inverses (the left inverse K^- P_R that KSPFETI takes by itself, K_reg^{-1}, the Moore-Penrose form).  The outer CG
+    count (to +-1) and u as with the Jacobi-preconditioned inner KSP, u equal to the direct solve of the assembled problem."""
+    from scipy.sparse.linalg import spsolve
+
+    from permon_amd.chain import KSPFETISolve
+
+    f = feti.MeshFeti(feti.irregular_partition(5, "staircase"), contact=False)
+    l2g = np.concatenate(f.l2g).astype(np.int32)
+    rs = f.block_rowstart
+    GX = f.elem_sub.shape[2] + 1
+    dl = np.concatenate([(np.nonzero(g % GX == 0)[0][:, None] * 3 + np.arange(3)[None, :]).ravel() + rs[s] for s, g in enumerate(f.gnodes)]).astype(np.int32)
+    res = {}
+    for pc in ("jacobi", "gamg"):
+        u, lam, st = KSPFETISolve(ctx, rs, f.K, f.f, l2g, dirichlet_local=dl, R=f.R, regularize=regularize, rtol=1e-8, kplus_rtol=1e-12, kplus_pc=pc)
+        assert st.reason > 0
+        res[pc] = (u, st.iteration)
+    assert abs(res["jacobi"][1] - res["gamg"][1]) <= 1  # (two inner solvers at rtol 1e-12: the outer count may move by one at the stopping iteration)
+    assert np.linalg.norm(res["jacobi"][0] - res["gamg"][0]) <= 1e-6 * np.linalg.norm(res["jacobi"][0])
+    # the assembled problem: K_glob u = f_glob with u = 0 on x = 0
+    nglob = int(l2g.max()) + 1
+    A = sp.csr_matrix((np.ones(f.N), (np.arange(f.N), l2g)), shape=(f.N, nglob))
+    Kg = (A.T @ f.K @ A).tocsr()
+    fg = A.T @ f.f
+    fixed = np.zeros(nglob, dtype=bool)
+    fixed[np.unique(l2g[dl])] = True
+    free = np.nonzero(~fixed)[0]
+    ug = np.zeros(nglob)
+    ug[free] = spsolve(Kg[free][:, free].tocsc(), fg[free])
+    ua = np.zeros(nglob)
+    ua[l2g] = res["gamg"][0]  # (INSERT_VALUES assembly of the copies, as QPTPostSolve_QPTMatISToBlockDiag)
+    assert np.linalg.norm(ua - ug) <= 1e-5 * np.linalg.norm(ug)
+    # and through the options database key
+    u2, _, st2 = KSPFETISolve(ctx, rs, f.K, f.f, l2g, dirichlet_local=dl, R=f.R, regularize=regularize, rtol=1e-8, kplus_rtol=1e-12, options="-dual_mat_inv_pc_type gamg")
+    assert st2.iteration == res["gamg"][1] and np.array_equal(u2, res["gamg"][0])
