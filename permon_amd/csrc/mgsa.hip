@@ -11,7 +11,8 @@
 //     coarse operators keep their m x m (hence 3 x 3) block structure;
 //   * one damped-Jacobi step P = (I - 4/3 / lambda_max(D^-1 A) D^-1 A) P_t, Galerkin operators A_{l+1} = P' A P (symmetrised) -- a floating block stays
 //     consistently singular down the hierarchy (A B = 0 => P B_c = B and A_c B_c = 0), and its coarsest operator gets the pseudo-inverse of mgbox.hip;
-//   * every block is coarsened the SAME number of times (that of the block that needs most to get under max_coarse dofs); congruent blocks are processed once.
+//   * every block is coarsened the SAME number of times (that of the block that needs most to get under max_coarse dofs; a block that is down to <= 8 nodes meanwhile is
+//     carried to the next level by P = I); congruent blocks are processed once.
 // The scipy restatement the tests compare with: permon_amd/feti.py sa_mg_hierarchy.
 #include <algorithm>
 #include <chrono>
@@ -23,6 +24,7 @@
 
 namespace {
 using namespace mgh;
+#define SA_MIN_NODES 8 // a level of a class with at most this many nodes is not aggregated any further
 
 // strength graph of the level over its nodes (bs dofs each): CSR without the diagonal, weights = Frobenius norms of the bs x bs blocks, kept where
 // w_ij > theta sqrt(w_ii w_jj); columns ascending
@@ -281,6 +283,7 @@ extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const 
     std::vector<double> B; // near-kernel of the current coarsest level, m x n_l
     int                 m = 0, bs = 0;
     bool                singular = false;
+    bool                stalled = false; // its level cannot be aggregated any further (one aggregate): it does not ask for more levels
   };
   std::vector<ClassH> H(ncls);
   std::vector<ClassX> X(ncls);
@@ -332,7 +335,8 @@ extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const 
   int nlev = 1;
   for (;;) {
     int big = 0;
-    for (int c = 0; c < ncls; c++) big = std::max(big, H[c].L.back().A.nr);
+    for (int c = 0; c < ncls; c++)
+      if (!X[c].stalled) big = std::max(big, H[c].L.back().A.nr);
     if (big <= max_coarse || nlev >= 10) break;
     for (int c = 0; c < ncls; c++) {
       ClassH   &C = H[c];
@@ -340,10 +344,34 @@ extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const 
       Level    &F = C.L.back();
       const int n = F.A.nr, m = Xc.m;
       if (n % Xc.bs) return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_sa: level %d of block class %d has %d rows, not a multiple of its node size %d", nlev - 1, c, n, Xc.bs);
+      auto carry_as_is = [&]() { // the class goes to the next level AS IT IS (P = I)
+        Level Cn;
+        HCsr  I;
+        I.nr = I.nc = n;
+        I.rp.resize((size_t)n + 1), I.ci.resize((size_t)n), I.va.assign((size_t)n, 1.0);
+        for (int i = 0; i <= n; i++) I.rp[i] = i;
+        for (int i = 0; i < n; i++) I.ci[i] = i;
+        F.lam = lambda_max_dinv_a(F.A, 20);
+        F.P = I, F.Pt = I;
+        Cn.A = F.A;
+        if (Xc.singular) Cn.R = Xc.B;
+        C.L.push_back(std::move(Cn));
+      };
+      // a class that is already down to a handful of nodes while a larger one still coarsens, or whose (small, almost dense) level would collapse into ONE aggregate -- a
+      // coarse operator that is zero on a floating block and a coarse correction that does nothing -- is carried over unchanged
+      if (n / Xc.bs <= SA_MIN_NODES) {
+        carry_as_is();
+        continue;
+      }
       const NodeGraph  G = strength_graph(F.A, Xc.bs, theta * std::pow(0.5, nlev - 1));
       std::vector<int> agg;
       const int        na = aggregate(G, agg);
       stage("  (class) strength graph, aggregates");
+      if (na < 2) {
+        Xc.stalled = true;
+        carry_as_is();
+        continue;
+      }
       HCsr                Ptent;
       std::vector<double> Bc;
       std::vector<char>   dead;

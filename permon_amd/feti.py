@@ -986,11 +986,18 @@ def sa_mg_hierarchy(blocks, nns, ndof=3, max_coarse=1500, max_levels=8, theta=0.
         done = True
         if len(per_block[0][0]) >= max_levels:
             break
-        if max(pb[0][-1].shape[0] for pb in per_block) <= max_coarse:
+        if max([pb[0][-1].shape[0] for pb in per_block if len(pb) < 7] + [0]) <= max_coarse:  # (a block whose level cannot be aggregated any further does not ask for more levels)
             break
         for pb in per_block:
-            A, P, lam, Bl, sing, bs = pb
-            Pn, Ac, Bc, lm = _sa_level(A[-1], Bl[-1], bs, theta * (0.5 ** (len(A) - 1)), omega)
+            A, P, lam, Bl, sing, bs = pb[:6]
+            lvl = None if A[-1].shape[0] // bs <= 8 else _sa_level(A[-1], Bl[-1], bs, theta * (0.5 ** (len(A) - 1)), omega)
+            if lvl is not None and lvl[1].shape[0] < 2 * Bl[0].shape[1] and len(pb) < 7:
+                pb.append("stalled")
+            if lvl is None or lvl[1].shape[0] < 2 * Bl[0].shape[1]:
+                # down to a handful of nodes while a larger block still coarsens, or a small dense level that would collapse into ONE aggregate: carried over as it is (P = I)
+                P.append(sp.identity(A[-1].shape[0], format="csr")), lam.append(_lambda_max_dinv_a_fixed(A[-1])), A.append(A[-1]), Bl.append(Bl[-1])
+                continue
+            Pn, Ac, Bc, lm = lvl
             P.append(Pn), A.append(Ac), Bl.append(Bc), lam.append(lm)
             pb[5] = Bl[0].shape[1]  # below the fine level a node is an aggregate with m dofs
         done = False

@@ -244,3 +244,30 @@ def test_kspfeti_on_an_irregular_partition_with_the_algebraic_pc(ctx, regularize
     # and through the options database key
     u2, _, st2 = KSPFETISolve(ctx, rs, f.K, f.f, l2g, dirichlet_local=dl, R=f.R, regularize=regularize, rtol=1e-8, kplus_rtol=1e-12, options="-dual_mat_inv_pc_type gamg")
     assert st2.iteration == res["gamg"][1] and np.array_equal(u2, res["gamg"][0])
+
+
+def test_sa_scalar_problem_poisson_blocks(ctx):
+    """The same builder on a SCALAR problem (Poisson, one dof per node, kernel = the constant): aggregates of nodes, one coarse dof each, fp64 cycle on the CSR kernels (no 3 x 3
+    blocks anywhere) -- K^+ = pinv(K) on the 8 staircase blocks, and the one-call contact solve (obstacle under the z = 0 face) takes the same path."""
+    from permon_amd.chain import FETIContactSolve
+
+    f = feti.MeshFeti(feti.irregular_partition(6, "staircase"), physics="poisson", contact=True)
+    assert f.ndof == 1 and f.kdim == 1
+    loc = _local(f)
+    Kd = pa.MatBlockDiag.from_scipy(ctx, loc["block_rowstart"], loc["K"])
+    Mi = pa.MatInv(Kd, rtol=1e-12, nullspace=loc["R"])
+    Mi.set_pc_mg_sa(loc["K"], 1, R=loc["R"], max_coarse=60, precision="fp64")
+    rhs = np.random.default_rng(9).standard_normal(f.N)
+    u = ctx.vec(f.N)
+    Mi.mult(ctx.vec_from(rhs), u)
+    assert Mi.last_iterations()[0] <= 25
+    rs = f.block_rowstart
+    for s in range(f.nsub):
+        ref = np.linalg.pinv(f.blocks[s].toarray(), rcond=1e-10, hermitian=True) @ rhs[rs[s]:rs[s + 1]]
+        assert np.linalg.norm(u.to_numpy()[rs[s]:rs[s + 1]] - ref) <= 1e-9 * np.linalg.norm(ref)
+    Mi.destroy()
+    Kd.destroy()
+    uu, lam, st = FETIContactSolve(ctx, f, rtol=1e-7, kplus_rtol=1e-11, mg_min_nodes=20, dims=None)
+    assert st.smalxe.reason > 0
+    Bu = f.B @ uu
+    assert np.abs(Bu[:f.n_eq]).max() <= 1e-5 * np.abs(uu).max() and (Bu[f.n_eq:] - f.c[f.n_eq:]).max() <= 1e-5 * np.abs(uu).max()
