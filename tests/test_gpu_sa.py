@@ -271,3 +271,32 @@ def test_sa_scalar_problem_poisson_blocks(ctx):
     assert st.smalxe.reason > 0
     Bu = f.B @ uu
     assert np.abs(Bu[:f.n_eq]).max() <= 1e-5 * np.abs(uu).max() and (Bu[f.n_eq:] - f.c[f.n_eq:]).max() <= 1e-5 * np.abs(uu).max()
+
+
+def test_sa_on_congruent_blocks_is_built_once_and_falls_back_politely(ctx):
+    """8 congruent cubes through the ALGEBRAIC builder: one class, its hierarchy built once and replicated; pmh_matinv_mult's 8-columns-of-one-block mode needs a node-wise P
+    for congruent blocks and is refused without an error (the one-column cycle with the scalar transfers runs); K^+ = pinv(K), and the 8-column set-up solver applies."""
+    f = pa.CubeFeti((2, 2, 2), 6, contact=False)
+    loc = f.subset(range(8))
+    Kd = pa.MatBlockDiag.from_scipy(ctx, loc["block_rowstart"], loc["K"])
+    Mi = pa.MatInv(Kd, rtol=1e-12, nullspace=loc["R"])
+    Mi.enable_bsr3()
+    Mi.set_pc_mg_sa(loc["K"], 3, R=loc["R"], max_coarse=150, precision="fp16")
+    assert Mi.bsr3_replicas() == 8 and not Mi.multi_rhs_active()
+    rhs = np.random.default_rng(10).standard_normal(f.N)
+    u = ctx.vec(f.N)
+    Mi.mult(ctx.vec_from(rhs), u)
+    assert Mi.last_iterations()[0] <= 20
+    Kp = np.linalg.pinv(f.Ki.toarray(), rcond=1e-10, hermitian=True)
+    got = u.to_numpy()
+    for s in range(8):
+        ref = Kp @ rhs[s * f.n_i:(s + 1) * f.n_i]
+        assert np.linalg.norm(got[s * f.n_i:(s + 1) * f.n_i] - ref) <= 1e-9 * np.linalg.norm(ref)
+    F8, U8 = ctx.vec_from(np.random.default_rng(11).standard_normal(8 * f.N)), ctx.vec(8 * f.N)
+    assert Mi.mult_multi(F8, U8) <= 20
+    X = U8.to_numpy().reshape(f.N, 8)
+    B8 = F8.to_numpy().reshape(f.N, 8)
+    ref = Kp @ B8[:f.n_i, 3]
+    assert np.linalg.norm(X[:f.n_i, 3] - ref) <= 1e-9 * np.linalg.norm(ref)
+    Mi.destroy()
+    Kd.destroy()
