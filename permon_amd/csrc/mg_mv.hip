@@ -58,20 +58,26 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_restrict(int ncn, const int *
                         const float *__restrict__ val, const float *__restrict__ t,
                                                            float *__restrict__ bc, const float *__restrict__ dinv_c, float itheta_c, float *__restrict__ d_c)
 {
+  // 32 lanes per coarse node: 4 entry groups x 8 columns, the groups summed by two butterfly steps (a fixed order).  (Until round 6 one lane per (node, column) walked the up
+  // to 27 entries alone: 14 us per launch on every level of the 43^3 hierarchy -- three of them per cycle, 10 % of an inner-Krylov step.)
   if (halt && *halt) return;
-  const int r = threadIdx.x % MV_R;
-  for (int i = blockIdx.x * (PMH_BLOCK / MV_R) + threadIdx.x / MV_R; i < ncn; i += gridDim.x * (PMH_BLOCK / MV_R)) {
+  const int lane = threadIdx.x & 31, r = lane % MV_R, g = lane / MV_R;
+  for (int i = blockIdx.x * (PMH_BLOCK / 32) + (threadIdx.x >> 5); i < ncn; i += gridDim.x * (PMH_BLOCK / 32)) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) {
+    for (int k = rowptr[i] + g; k < rowptr[i + 1]; k += 4) {
       const float  w = val[k];
       const float *p = t + (size_t)3 * col[k] * MV_R + r;
       s0 += w * p[0], s1 += w * p[MV_R], s2 += w * p[2 * MV_R];
     }
-    float *o = bc + (size_t)3 * i * MV_R + r;
-    o[0] = s0, o[MV_R] = s1, o[2 * MV_R] = s2;
-    if (dinv_c) {
-      float *dd = d_c + (size_t)3 * i * MV_R + r;
-      dd[0] = dinv_c[3 * i] * s0 * itheta_c, dd[MV_R] = dinv_c[3 * i + 1] * s1 * itheta_c, dd[2 * MV_R] = dinv_c[3 * i + 2] * s2 * itheta_c;
+#pragma unroll
+    for (int o = 8; o < 32; o <<= 1) s0 += __shfl_xor(s0, o, 32), s1 += __shfl_xor(s1, o, 32), s2 += __shfl_xor(s2, o, 32);
+    if (g == 0) {
+      float *o = bc + (size_t)3 * i * MV_R + r;
+      o[0] = s0, o[MV_R] = s1, o[2 * MV_R] = s2;
+      if (dinv_c) {
+        float *dd = d_c + (size_t)3 * i * MV_R + r;
+        dd[0] = dinv_c[3 * i] * s0 * itheta_c, dd[MV_R] = dinv_c[3 * i + 1] * s1 * itheta_c, dd[2 * MV_R] = dinv_c[3 * i + 2] * s2 * itheta_c;
+      }
     }
   }
 }
@@ -306,7 +312,7 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
     if (cf) er.dinv = (const float *)Lc.dinv, er.d = Mc.d, er.c0 = (float)(1.0 / Lc.theta);
     PMH_CHK(pmh_mv_spmv_f32(Ml.ER, Ml.t, Mc.b, PMH_MV_EPI_RESTRICT, &er, halt));
   } else if (nodal)
-    hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * MV_R), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
+    hipLaunchKernelGGL(k_mvg_restrict, mvg_grid((long long)ncn * 32), blk, 0, st, ncn, halt, (const int *)Lv.rn_rowptr, (const int *)Lv.rn_col,
                        (const float *)Lv.rn_val, (const float *)Ml.t, Mc.b,
                        cf ? (const float *)Lc.dinv : (const float *)nullptr, cf ? (float)(1.0 / Lc.theta) : 0.f, cf ? Mc.d : (float *)nullptr);
   else
