@@ -542,6 +542,10 @@ int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_
                      int nns, const double *nns_host, int max_coarse, double theta, int degree, int precision, pmh_mg *mg);
 /* host routine (tests, diagnostics): the aggregates pmh_mg_create_sa forms on ONE level of one block -- A: n x n host CSR with bs dofs per node; agg_out[n / bs] */
 int pmh_sa_aggregate(int n, int bs, const int *rowptr, const int *col, const double *val, double theta, int *agg_out, int *n_agg);
+/* host routine (tests, sanitizer runs; no device): the whole hierarchy pmh_mg_create_sa builds for ONE block (R: kdim x n kernel vectors; kdim = 0: a non-singular block, near-kernel = the
+   ndof translations).  level_rows[0 .. *nlevels): rows per level (room for 16); defect[0] = max_l max|A_l B_l| / max|A_l|, defect[1] = max_l max|P_l B_{l+1} - B_l| (both 0 for kdim = 0),
+   defect[2] = max|A_c A_c^+ A_c - A_c| / max|A_c| of the coarsest operator and its dense (pseudo-)inverse */
+int pmh_sa_hierarchy_host(int n, int ndof, const int *rowptr, const int *col, const double *val, int kdim, const double *R, int max_coarse, double theta, int *nlevels, int *level_rows, double *defect);
 int pmh_mg_apply(pmh_mg mg, const double *b_dev, double *x_dev); /* x = V(b), zero initial guess (PCApply) */
 int pmh_mg_stats(pmh_mg mg, long long *fine_spmv);
 int pmh_mg_timing_enable(pmh_mg mg, int max_launches); /* HIP-event pairs around the fine-level operator launches */

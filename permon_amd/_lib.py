@@ -247,6 +247,7 @@ _PROTOS = {
     "pmh_mg_create": [vp, C.c_int, vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.c_int, C.POINTER(vp)],
     "pmh_mg_create_box": [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_sa_aggregate": [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, C.POINTER(C.c_int)],
+    "pmh_sa_hierarchy_host": [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.POINTER(C.c_int), vp, vp],
     "pmh_mg_create_sa": [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(vp)],
     "pmh_mg_timing_enable": [vp, C.c_int],
     "pmh_mg_timing_get": [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],

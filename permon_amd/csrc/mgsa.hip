@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <thread>
 
 #include "mg_host.h"
@@ -237,101 +238,17 @@ HCsr smooth_prolongation(const HCsr &A, const HCsr &Pt, double s)
   });
   return P;
 }
-} // namespace
+struct ClassX { // what the coarsening of a class carries besides its levels
+  std::vector<double> B; // near-kernel of the current coarsest level, m x n_l
+  int                 m = 0, bs = 0;
+  bool                singular = false;
+  bool                stalled = false; // its level cannot be aggregated any further (one aggregate): it does not ask for more levels
+};
 
-// host routine (tests, diagnostics): the aggregates of ONE level of one block -- A (n x n host CSR, bs dofs per node), threshold theta; agg_out[n / bs], *n_agg
-extern "C" int pmh_sa_aggregate(int n, int bs, const int *rowptr, const int *col, const double *val, double theta, int *agg_out, int *n_agg)
+// the coarsening proper: every class the same number of times, until every class that still aggregates has at most max_coarse dofs
+int sa_coarsen(std::vector<ClassH> &H, std::vector<ClassX> &X, int max_coarse, double theta, int *nlev_out, const std::function<void(const char *)> &stage)
 {
-  PMH_ARG(n >= 1 && bs >= 1 && n % bs == 0 && rowptr && col && val && theta >= 0.0 && agg_out && n_agg);
-  HCsr A;
-  A.nr = A.nc = n;
-  A.rp.assign(rowptr, rowptr + n + 1);
-  A.ci.assign(col, col + rowptr[n]);
-  A.va.assign(val, val + rowptr[n]);
-  const NodeGraph  G = strength_graph(A, bs, theta);
-  std::vector<int> agg;
-  *n_agg = aggregate(G, agg);
-  std::copy(agg.begin(), agg.end(), agg_out);
-  return PMH_SUCCESS;
-}
-
-// nns_host: nns x N near-kernel vectors for the NON-singular blocks (NULL / zero over a block: the ndof translations); a block over which R_host (kdim x N) is
-// non-zero is singular with exactly that kernel, which is then its near-kernel as well.  max_coarse: coarsening stops when every block has at most that many dofs.
-extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_rowstart, int ndof, const int *rowptr, const int *col, const double *val, int kdim, const double *R_host,
-                                int nns, const double *nns_host, int max_coarse, double theta, int degree, int precision, pmh_mg *out)
-{
-  PMH_ARG(ctx && A_fine && out && nblocks >= 1 && block_rowstart && ndof >= 1 && rowptr && col && val && kdim >= 0 && kdim <= 8 && (kdim == 0 || R_host) && nns >= 0 && nns <= 8 && (nns == 0 || nns_host));
-  PMH_ARG(max_coarse >= 1 && theta >= 0.0 && theta < 1.0 && degree >= 1);
-  const int N = block_rowstart[nblocks];
-  PMH_ARG(A_fine->nrows == N && block_rowstart[0] == 0);
-  for (int b = 0; b < nblocks; b++)
-    if ((block_rowstart[b + 1] - block_rowstart[b]) % ndof || block_rowstart[b + 1] <= block_rowstart[b])
-      return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_sa: block %d has %d rows, not a positive multiple of ndof = %d", b, block_rowstart[b + 1] - block_rowstart[b], ndof);
-  const bool verbose = getenv("PMH_CONTACT_TIMING") != nullptr;
-  auto       t_last  = std::chrono::steady_clock::now();
-  auto       stage   = [&](const char *what) {
-    if (!verbose) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "  pmh_mg_create_sa: %-40s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-    t_last = now;
-  };
-  std::vector<int> cls(nblocks);
-  int              ncls = 0;
-  PMH_CHK(pmh_csr_block_classes(nblocks, block_rowstart, rowptr, col, val, cls.data(), &ncls));
-  stage("block classes");
-  struct ClassX { // what the coarsening of a class carries besides its levels
-    std::vector<double> B; // near-kernel of the current coarsest level, m x n_l
-    int                 m = 0, bs = 0;
-    bool                singular = false;
-    bool                stalled = false; // its level cannot be aggregated any further (one aggregate): it does not ask for more levels
-  };
-  std::vector<ClassH> H(ncls);
-  std::vector<ClassX> X(ncls);
-  std::vector<char>   seen(ncls, 0);
-  for (int b = 0; b < nblocks; b++) {
-    const int c = cls[b];
-    if (seen[c]) continue;
-    seen[c]     = 1;
-    ClassH &C   = H[c];
-    C.rep       = b;
-    const int r0 = block_rowstart[b], n = block_rowstart[b + 1] - r0, k0 = rowptr[r0];
-    Level     L0;
-    L0.A.nr = L0.A.nc = n;
-    L0.A.rp.resize((size_t)n + 1);
-    for (int i = 0; i <= n; i++) L0.A.rp[i] = rowptr[r0 + i] - k0;
-    const size_t nz = (size_t)L0.A.rp[n];
-    L0.A.ci.resize(nz), L0.A.va.resize(nz);
-    parallel_for(n, [&](int i0, int i1) {
-      for (int i = i0; i < i1; i++)
-        for (int k = L0.A.rp[i]; k < L0.A.rp[i + 1]; k++) L0.A.ci[k] = col[k0 + k] - r0, L0.A.va[k] = val[k0 + k];
-    });
-    for (size_t k = 0; k < nz; k++)
-      if (L0.A.ci[k] < 0 || L0.A.ci[k] >= n) return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_sa: block %d couples to a column outside itself", b);
-    // the block's near-kernel: its kernel vectors if it has any, else the caller's vectors, else the translations
-    ClassX &Xc = X[c];
-    auto    take = [&](int nv, const double *V) {
-      for (int k = 0; k < nv; k++) {
-        const double *r  = V + (size_t)k * N + r0;
-        bool          nzv = false;
-        for (int i = 0; i < n && !nzv; i++) nzv = r[i] != 0.0;
-        if (nzv) Xc.B.insert(Xc.B.end(), r, r + n), Xc.m++;
-      }
-    };
-    take(kdim, R_host);
-    Xc.singular = Xc.m > 0;
-    C.kd        = Xc.m;
-    if (!Xc.m && nns) take(nns, nns_host);
-    if (!Xc.m) {
-      Xc.m = ndof;
-      Xc.B.assign((size_t)ndof * n, 0.0);
-      for (int i = 0; i < n; i++) Xc.B[(size_t)(i % ndof) * n + i] = 1.0;
-    }
-    Xc.bs = ndof;
-    if (Xc.singular) L0.R = Xc.B;
-    C.L.push_back(std::move(L0));
-  }
-  stage("class representatives, near-kernels");
-  // every class is coarsened the same number of times
+  const int ncls = (int)H.size();
   int nlev = 1;
   for (;;) {
     int big = 0;
@@ -426,6 +343,178 @@ extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const 
     }
     nlev++;
   }
+  *nlev_out = nlev;
+  return PMH_SUCCESS;
+}
+} // namespace
+
+// host routine (tests, diagnostics): the aggregates of ONE level of one block -- A (n x n host CSR, bs dofs per node), threshold theta; agg_out[n / bs], *n_agg
+extern "C" int pmh_sa_aggregate(int n, int bs, const int *rowptr, const int *col, const double *val, double theta, int *agg_out, int *n_agg)
+{
+  PMH_ARG(n >= 1 && bs >= 1 && n % bs == 0 && rowptr && col && val && theta >= 0.0 && agg_out && n_agg);
+  HCsr A;
+  A.nr = A.nc = n;
+  A.rp.assign(rowptr, rowptr + n + 1);
+  A.ci.assign(col, col + rowptr[n]);
+  A.va.assign(val, val + rowptr[n]);
+  const NodeGraph  G = strength_graph(A, bs, theta);
+  std::vector<int> agg;
+  *n_agg = aggregate(G, agg);
+  std::copy(agg.begin(), agg.end(), agg_out);
+  return PMH_SUCCESS;
+}
+
+// host routine (tests, sanitizer runs, diagnostics; no device): the whole hierarchy of ONE block -- A: n x n host CSR with ndof dofs per node, R: kdim x n kernel vectors
+// (kdim = 0: the ndof translations as near-kernel of a non-singular block).  level_rows[0 .. *nlevels): rows per level (cap 16); defect[0]: max over the levels of
+// max |A_l B_l| / max |A_l| (a floating block stays consistently singular), defect[1]: max over the levels of max |P_l B_{l+1} - B_l| (the prolongations reproduce the
+// near-kernel), defect[2]: max |A_c A_c^+ A_c - A_c| / max |A_c| of the coarsest operator and its dense pseudo-inverse
+extern "C" int pmh_sa_hierarchy_host(int n, int ndof, const int *rowptr, const int *col, const double *val, int kdim, const double *R, int max_coarse, double theta, int *nlevels, int *level_rows,
+                                     double *defect)
+{
+  PMH_ARG(n >= 1 && ndof >= 1 && n % ndof == 0 && rowptr && col && val && kdim >= 0 && kdim <= 8 && (kdim == 0 || R) && max_coarse >= 1 && theta >= 0.0 && nlevels && level_rows && defect);
+  std::vector<ClassH> H(1);
+  std::vector<ClassX> X(1);
+  Level               L0;
+  L0.A.nr = L0.A.nc = n;
+  L0.A.rp.assign(rowptr, rowptr + n + 1);
+  L0.A.ci.assign(col, col + rowptr[n]);
+  L0.A.va.assign(val, val + rowptr[n]);
+  X[0].bs = ndof;
+  if (kdim) {
+    X[0].B.assign(R, R + (size_t)kdim * n), X[0].m = kdim, X[0].singular = true, H[0].kd = kdim;
+    L0.R = X[0].B;
+  } else {
+    X[0].m = ndof;
+    X[0].B.assign((size_t)ndof * n, 0.0);
+    for (int i = 0; i < n; i++) X[0].B[(size_t)(i % ndof) * n + i] = 1.0;
+  }
+  H[0].L.push_back(std::move(L0));
+  int nlev = 1;
+  PMH_CHK(sa_coarsen(H, X, max_coarse, theta, &nlev, [](const char *) {}));
+  if (nlev > 16) return pmh_set_error(PMH_ERR_STATE, "pmh_sa_hierarchy_host: more than 16 levels");
+  *nlevels = nlev;
+  const int m = X[0].m;
+  double    d_ab = 0.0, d_pb = 0.0;
+  // (for a singular block the level's kernel vectors L[l].R ARE its near-kernel B_l; for a non-singular block only the sizes are reported)
+  for (int l = 0; l < nlev; l++) {
+    const Level &Lv = H[0].L[l];
+    level_rows[l]   = Lv.A.nr;
+    if (!X[0].singular) continue;
+    double amax = 0.0;
+    for (double v : Lv.A.va) amax = std::max(amax, std::fabs(v));
+    for (int k = 0; k < m; k++)
+      for (int i = 0; i < Lv.A.nr; i++) {
+        double t = 0.0;
+        for (int q = Lv.A.rp[i]; q < Lv.A.rp[i + 1]; q++) t += Lv.A.va[q] * Lv.R[(size_t)k * Lv.A.nr + Lv.A.ci[q]];
+        d_ab = std::max(d_ab, std::fabs(t) / std::max(amax, 1e-300));
+      }
+    if (l + 1 < nlev) {
+      const Level &Lc = H[0].L[l + 1];
+      for (int k = 0; k < m; k++)
+        for (int i = 0; i < Lv.P.nr; i++) {
+          double t = 0.0;
+          for (int q = Lv.P.rp[i]; q < Lv.P.rp[i + 1]; q++) t += Lv.P.va[q] * Lc.R[(size_t)k * Lc.A.nr + Lv.P.ci[q]];
+          d_pb = std::max(d_pb, std::fabs(t - Lv.R[(size_t)k * Lv.A.nr + i]));
+        }
+    }
+  }
+  std::vector<double> pinv;
+  if (coarse_pinv(H[0].L[nlev - 1].A, H[0].kd, H[0].L[nlev - 1].R, pinv)) return pmh_set_error(PMH_ERR_ARG, "pmh_sa_hierarchy_host: the coarsest operator is not positive definite on the complement of the kernel");
+  const HCsr &Ac = H[0].L[nlev - 1].A;
+  const int   nc = Ac.nr;
+  std::vector<double> Ad((size_t)nc * nc, 0.0), T((size_t)nc * nc, 0.0);
+  double              amax = 0.0;
+  for (int i = 0; i < nc; i++)
+    for (int q = Ac.rp[i]; q < Ac.rp[i + 1]; q++) Ad[(size_t)i * nc + Ac.ci[q]] = Ac.va[q], amax = std::max(amax, std::fabs(Ac.va[q]));
+  for (int i = 0; i < nc; i++) // T = A pinv
+    for (int k = 0; k < nc; k++) {
+      const double a = Ad[(size_t)i * nc + k];
+      if (a != 0.0)
+        for (int j = 0; j < nc; j++) T[(size_t)i * nc + j] += a * pinv[(size_t)k * nc + j];
+    }
+  double d_pi = 0.0;
+  for (int i = 0; i < nc; i++)
+    for (int j = 0; j < nc; j++) {
+      double t = 0.0;
+      for (int k = 0; k < nc; k++) t += T[(size_t)i * nc + k] * Ad[(size_t)k * nc + j];
+      d_pi = std::max(d_pi, std::fabs(t - Ad[(size_t)i * nc + j]) / std::max(amax, 1e-300));
+    }
+  defect[0] = d_ab, defect[1] = d_pb, defect[2] = d_pi;
+  return PMH_SUCCESS;
+}
+
+// nns_host: nns x N near-kernel vectors for the NON-singular blocks (NULL / zero over a block: the ndof translations); a block over which R_host (kdim x N) is
+// non-zero is singular with exactly that kernel, which is then its near-kernel as well.  max_coarse: coarsening stops when every block has at most that many dofs.
+extern "C" int pmh_mg_create_sa(pmh_ctx ctx, pmh_csr A_fine, int nblocks, const int *block_rowstart, int ndof, const int *rowptr, const int *col, const double *val, int kdim, const double *R_host,
+                                int nns, const double *nns_host, int max_coarse, double theta, int degree, int precision, pmh_mg *out)
+{
+  PMH_ARG(ctx && A_fine && out && nblocks >= 1 && block_rowstart && ndof >= 1 && rowptr && col && val && kdim >= 0 && kdim <= 8 && (kdim == 0 || R_host) && nns >= 0 && nns <= 8 && (nns == 0 || nns_host));
+  PMH_ARG(max_coarse >= 1 && theta >= 0.0 && theta < 1.0 && degree >= 1);
+  const int N = block_rowstart[nblocks];
+  PMH_ARG(A_fine->nrows == N && block_rowstart[0] == 0);
+  for (int b = 0; b < nblocks; b++)
+    if ((block_rowstart[b + 1] - block_rowstart[b]) % ndof || block_rowstart[b + 1] <= block_rowstart[b])
+      return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_sa: block %d has %d rows, not a positive multiple of ndof = %d", b, block_rowstart[b + 1] - block_rowstart[b], ndof);
+  const bool verbose = getenv("PMH_CONTACT_TIMING") != nullptr;
+  auto       t_last  = std::chrono::steady_clock::now();
+  auto       stage   = [&](const char *what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  pmh_mg_create_sa: %-40s %7.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  std::vector<int> cls(nblocks);
+  int              ncls = 0;
+  PMH_CHK(pmh_csr_block_classes(nblocks, block_rowstart, rowptr, col, val, cls.data(), &ncls));
+  stage("block classes");
+  std::vector<ClassH> H(ncls);
+  std::vector<ClassX> X(ncls);
+  std::vector<char>   seen(ncls, 0);
+  for (int b = 0; b < nblocks; b++) {
+    const int c = cls[b];
+    if (seen[c]) continue;
+    seen[c]     = 1;
+    ClassH &C   = H[c];
+    C.rep       = b;
+    const int r0 = block_rowstart[b], n = block_rowstart[b + 1] - r0, k0 = rowptr[r0];
+    Level     L0;
+    L0.A.nr = L0.A.nc = n;
+    L0.A.rp.resize((size_t)n + 1);
+    for (int i = 0; i <= n; i++) L0.A.rp[i] = rowptr[r0 + i] - k0;
+    const size_t nz = (size_t)L0.A.rp[n];
+    L0.A.ci.resize(nz), L0.A.va.resize(nz);
+    parallel_for(n, [&](int i0, int i1) {
+      for (int i = i0; i < i1; i++)
+        for (int k = L0.A.rp[i]; k < L0.A.rp[i + 1]; k++) L0.A.ci[k] = col[k0 + k] - r0, L0.A.va[k] = val[k0 + k];
+    });
+    for (size_t k = 0; k < nz; k++)
+      if (L0.A.ci[k] < 0 || L0.A.ci[k] >= n) return pmh_set_error(PMH_ERR_ARG, "pmh_mg_create_sa: block %d couples to a column outside itself", b);
+    // the block's near-kernel: its kernel vectors if it has any, else the caller's vectors, else the translations
+    ClassX &Xc = X[c];
+    auto    take = [&](int nv, const double *V) {
+      for (int k = 0; k < nv; k++) {
+        const double *r  = V + (size_t)k * N + r0;
+        bool          nzv = false;
+        for (int i = 0; i < n && !nzv; i++) nzv = r[i] != 0.0;
+        if (nzv) Xc.B.insert(Xc.B.end(), r, r + n), Xc.m++;
+      }
+    };
+    take(kdim, R_host);
+    Xc.singular = Xc.m > 0;
+    C.kd        = Xc.m;
+    if (!Xc.m && nns) take(nns, nns_host);
+    if (!Xc.m) {
+      Xc.m = ndof;
+      Xc.B.assign((size_t)ndof * n, 0.0);
+      for (int i = 0; i < n; i++) Xc.B[(size_t)(i % ndof) * n + i] = 1.0;
+    }
+    Xc.bs = ndof;
+    if (Xc.singular) L0.R = Xc.B;
+    C.L.push_back(std::move(L0));
+  }
+  stage("class representatives, near-kernels");
+  int nlev = 1;
+  PMH_CHK(sa_coarsen(H, X, max_coarse, theta, &nlev, stage));
   stage("hierarchies (host)");
   for (int c = 0; c < ncls; c++)
     if (coarse_pinv(H[c].L[nlev - 1].A, H[c].kd, H[c].L[nlev - 1].R, H[c].pinv))

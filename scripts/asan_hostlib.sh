@@ -1,5 +1,5 @@
 #!/bin/bash
-# AddressSanitizer pass over the HOST side of libpermonhip.so (set-up producers, planners, converters: everything tests/test_host_logic.py reaches without a GPU).
+# AddressSanitizer pass over the HOST side of libpermonhip.so (set-up producers, planners, converters: everything tests/test_host_logic.py and tests/test_sa_host.py reach without a GPU).
 # CPU only: device code is NOT instrumented (-fno-gpu-sanitize; GPU ASan / xnack+ is not available on the pool).  Builds into /tmp/asanlib, swaps the library
 # in for the run and restores the plain one.  tests/test_abi.py is left out: it links the plain-C examples against the library, which then needs the ASan runtime.
 set -e
@@ -13,6 +13,6 @@ SRCS=$(sed -n 's/^SRCS *= *//p' permon_amd/csrc/Makefile)
 cp permon_amd/libpermonhip.so /tmp/asanlib/libpermonhip.plain.so
 cp /tmp/asanlib/libpermonhip.so permon_amd/libpermonhip.so
 rc=0
-LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python -m pytest tests/test_host_logic.py -x -q -m "not gpu" -p no:cacheprovider || rc=$?
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python -m pytest tests/test_host_logic.py tests/test_sa_host.py -x -q -m "not gpu" -p no:cacheprovider || rc=$?
 cp /tmp/asanlib/libpermonhip.plain.so permon_amd/libpermonhip.so
 exit $rc

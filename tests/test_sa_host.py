@@ -92,3 +92,41 @@ def test_restated_hierarchy_preconditions_the_oracle_block_cg():
     for k, s in enumerate(sel):
         ref = np.linalg.pinv(f.blocks[s].toarray(), rcond=1e-10, hermitian=True) @ rhs[brs[k]:brs[k + 1]]
         assert np.linalg.norm(u[brs[k]:brs[k + 1]] - ref) <= 1e-9 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("physics,ndof,kind,n", [("elasticity", 3, "staircase", 6), ("elasticity", 3, "lshape", 5), ("poisson", 1, "staircase", 6)])
+def test_library_hierarchy_on_the_host_vs_restatement(physics, ndof, kind, n):
+    """pmh_sa_hierarchy_host (the whole host builder of pmh_mg_create_sa for one block, no device): the levels have the sizes of the scipy restatement, a floating block stays
+    consistently singular down the hierarchy (A_l B_l = 0), every prolongation reproduces the kernel vectors (P_l B_{l+1} = B_l) and the coarsest operator's dense pseudo-inverse
+    is one (A A^+ A = A).  Also what scripts/asan_hostlib.sh runs the builder's index arithmetic through."""
+    L = _lib.load()
+    f = feti.MeshFeti(feti.irregular_partition(n, kind), physics=physics, contact=False)
+    rs = f.block_rowstart
+    for s in (0, 3, 7):
+        A = f.blocks[s].tocsr()
+        A.sort_indices()
+        nb = A.shape[0]
+        Rb = np.ascontiguousarray(f.R[:, rs[s]:rs[s + 1]])
+        ip, ci = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)
+        for maxc in (200, 40):
+            nl = C.c_int()
+            rows = np.zeros(16, dtype=np.int32)
+            defect = np.zeros(3)
+            _lib.check(L.pmh_sa_hierarchy_host(nb, ndof, ip.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), A.data.ctypes.data_as(C.c_void_p), Rb.shape[0], Rb.ctypes.data_as(C.c_void_p), maxc, 0.08,
+                                               C.byref(nl), rows.ctypes.data_as(C.c_void_p), defect.ctypes.data_as(C.c_void_p)))
+            H = feti.sa_mg_hierarchy([A], [Rb], ndof=ndof, max_coarse=maxc, theta=0.08)
+            assert rows[:nl.value].tolist() == [a.shape[0] for a in H["A"]], (s, maxc, rows[:nl.value], [a.shape[0] for a in H["A"]])
+            assert defect[0] <= 1e-12 and defect[1] <= 1e-12 and defect[2] <= 1e-9, defect
+    # a non-singular block (Dirichlet dofs as identity rows): translations as near-kernel, plain inverse at the bottom
+    Kb = f.blocks[0].tolil()
+    fix = np.arange(0, 3 * ndof)
+    keep = np.ones(Kb.shape[0])
+    keep[fix] = 0.0
+    Kn = (sp.diags(keep) @ f.blocks[0] @ sp.diags(keep) + sp.diags(1.0 - keep)).tocsr()
+    Kn.eliminate_zeros()
+    Kn.sort_indices()
+    ip, ci = np.ascontiguousarray(Kn.indptr, dtype=np.int32), np.ascontiguousarray(Kn.indices, dtype=np.int32)
+    nl, rows, defect = C.c_int(), np.zeros(16, dtype=np.int32), np.zeros(3)
+    _lib.check(L.pmh_sa_hierarchy_host(Kn.shape[0], ndof, ip.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), Kn.data.ctypes.data_as(C.c_void_p), 0, None, 40, 0.08, C.byref(nl),
+                                       rows.ctypes.data_as(C.c_void_p), defect.ctypes.data_as(C.c_void_p)))
+    assert nl.value >= 2 and rows[0] == Kn.shape[0] and all(rows[l + 1] < rows[l] for l in range(nl.value - 1)) and defect[2] <= 1e-9
