@@ -819,10 +819,15 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
     # blocks that are not boxes: the algebraic hierarchy (pmh_mg_create_sa); tiny test problems: at least one smoothed level
     mg_sa = dict(ndof=3, max_coarse=min(3 * (a.mg_min_nodes or 500), max(6, int(np.diff(f.block_rowstart).min()) // 4)), theta=0.08) if (partition and use_c_builder) else None
 
-    def mg_box(nblk):
+    def mg_box(nblk, for_iterative=None, precision=None):
         # (explicit K^+: the rank's own inner-Krylov solver only serves a handful of set-up products -- d = B K^+ f, the replica's columns come from the replica solver --
         # so it does not pay for the 5000-dof dense coarse pseudo-inverse that makes the cycle of a 1-4 block rank faster: 6 s of host set-up at the 1/8 share)
-        auto_nodes = 2000 if (nblk <= (4 if a.mg_precision == "fp16" else 1) and a.kplus != "explicit") else 400
+        # Round 6: 8 CONGRUENT blocks run as the 8 columns of ONE block (matinv_mv.hip): the cycle then walks one block's levels, the 1-4 block regime -- the hierarchy stops a level
+        # earlier there too (measured on the driver's window: 71.1 -> 76.0 it/s, one CG iteration less per application; +8 s of host set-up for the one dense pseudo-inverse)
+        it = (a.kplus != "explicit") if for_iterative is None else for_iterative
+        prec = precision or a.mg_precision
+        one_block_regime = nblk <= (4 if prec == "fp16" else 1) or (nblk == 8 and congruent and prec != "fp64" and not a.no_bsr3)  # (the strict fp64 cycle runs on the one-column kernels: 8 blocks)
+        auto_nodes = 2000 if (one_block_regime and it) else 400
         return dict(dims=[(nn, nn, nn)] * nblk, ndof=3, min_nodes=a.mg_min_nodes or min(auto_nodes, nn ** 3 // 8))
     explicit = None
     replica = {}
@@ -864,13 +869,13 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
                    mg_degree=a.mg_degree, mg_precision=a.mg_precision, bsr3=not a.no_bsr3, regularize=a.regularize, explicit=explicit)
     has_mg = a.kplus_pc == "mg"
 
-    def switch_mg(precision):
-        """Replace the V-cycle of the inner KSP by one in another precision (same hierarchy, same builder)."""
+    def switch_mg(precision, for_iterative=None):
+        """Replace the V-cycle of the inner KSP by one in another precision (same builder; for_iterative: the depth the inner-Krylov path takes, see mg_box)."""
         old = q.Kplus.mg
         if mg_sa:
             q.Kplus.set_pc_mg_sa(local["K"], 3, R=local["R"], max_coarse=mg_sa["max_coarse"], theta=mg_sa["theta"], degree=a.mg_degree, precision=precision)
         elif use_c_builder:
-            mb = mg_box(per)
+            mb = mg_box(per, for_iterative, precision)
             q.Kplus.set_pc_mg_box(local["K"], mb["dims"], 3, R=local["R"], min_nodes=mb["min_nodes"], degree=a.mg_degree, precision=precision)
         else:
             q.Kplus.set_pc_mg(hier, degree=a.mg_degree, precision=precision)
@@ -991,7 +996,7 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
         if has_mg:
             q.Kplus.mg.timing_enable(0)
         return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "steps": nsteps, "warmup": nwarm, "steps_by_type": cnt,
-                "kplus": "block-wise %s%s (rtol %.0e)" % (pc_text.replace(a.mg_precision, precision), kreg_text, a.kplus_rtol),
+                "kplus": "block-wise %s%s (rtol %.0e)" % ((pc_text.replace("<= %d nodes" % mg_box(per)["min_nodes"], "<= %d nodes" % mg_box(per, True, precision)["min_nodes"]) if (has_mg and use_c_builder and not mg_sa) else pc_text).replace(a.mg_precision, precision), kreg_text, a.kplus_rtol),
                 "cg_spmv_per_step": (spmv2 - spmv1) / max(nsteps + nwarm, 1), "vcycle_fine_spmv_per_step": (mgs2 - mgs1) / max(nsteps + nwarm, 1), "last_block_cg_iterations": kits,
                 "roofline": roof}
 
@@ -1082,6 +1087,8 @@ def run_feti(ctx, a, steps, warmup, rank, world, dist):
             # N > 1 (round 6): every rank runs this pass too -- the strong-scaling figure of the path that shards one subdomain per GPU and streams every K_i from HBM at
             # every N stands next to the explicit one in the same line (at N = 1 its like-for-like partner is `iterative_distinct_blocks`: 8 different K_i, nothing shared)
             q.Kplus.attach_explicit(None)
+            if has_mg and use_c_builder and not mg_sa and not getattr(a, "_secondary", False) and mg_box(per, True)["min_nodes"] != mg_box(per)["min_nodes"]:
+                switch_mg(a.mg_precision, for_iterative=True)  # the set-up solves of the explicit operators ran on the shallow-coarse hierarchy; the inner-Krylov pass takes its own depth
             extra["iterative"] = iterative_pass(min(steps, 108), 4, a.mg_precision)
             if world == 1 and has_mg and a.mg_precision != "fp64" and not getattr(a, "_no_strict", False):
                 switch_mg("fp64")
