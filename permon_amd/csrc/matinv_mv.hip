@@ -35,7 +35,7 @@ struct pmh_matinv_mv_s {
 #define MV_ROW_LOOP(i, b, rs, wgs)                                                                                                                                \
   const int b = blockIdx.x / (wgs), w_ = blockIdx.x % (wgs), cr_ = (int)threadIdx.x % MV_R;                                                                      \
   const int lo_ = (rs)[b], hi_ = (rs)[b + 1];                                                                                                                    \
-  for (long long i = ((long long)lo_ + w_ * MVC_ROWS + (int)threadIdx.x / MV_R) * MV_R + cr_; i < (long long)hi_ * MV_R; i += (long long)(wgs)*MVC_ROWS * MV_R)
+  _Pragma("unroll 4") for (long long i = ((long long)lo_ + w_ * MVC_ROWS + (int)threadIdx.x / MV_R) * MV_R + cr_; i < (long long)hi_ * MV_R; i += (long long)(wgs)*MVC_ROWS * MV_R)
 
 // sum over the threads that work on the same column (t % 8): every thread gets its column's total.  lds: 32 doubles
 static __device__ __forceinline__ double mvc_red8(double v, double *lds)
@@ -221,9 +221,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_rt_dot(const int *__restrict_
   {
     const double vi = v[i];
     vv += vi * vi;
+    // the row's kdim <= 8 kernel entries: ONE load per lane (lane c of the row's 8 brings R_c) handed round by lane index -- every lane loading all of them itself was
+    // 6 loads of 64 useful bytes per wavefront, 57 us for the 28 MB of a 43^3 cube (round 6)
+    const double rk = (cr_ < kdim) ? R[(size_t)cr_ * n + i / MV_R] : 0.0;
 #pragma unroll
     for (int k = 0; k < MVC_MAX_KDIM; k++)
-      if (k < kdim) acc[k] += R[(size_t)k * n + i / MV_R] * vi;
+      if (k < kdim) acc[k] += __shfl(rk, ((int)threadIdx.x & 56) + k, 64) * vi;
   }
   const size_t o = ((size_t)b * MV_R + threadIdx.x % MV_R) * wgs + w_;
   vv             = mvc_red8(vv, lds);
@@ -238,27 +241,29 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_rt_dot(const int *__restrict_
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_coef(int wgs, int kdim, size_t ld, const double *__restrict__ part, double *__restrict__ coef,
                         double *__restrict__ vnorm2)
 {
+  // grid (blocks, kdim + 1): workgroup (b, k) sums the partials of R_k' v, (b, kdim) those of |v|^2 (one workgroup per block doing the 7 sums in turn took 18 us)
   __shared__ double lds[32];
-  const int         b = blockIdx.x, c = b * MV_R + (int)threadIdx.x % MV_R;
-  if (vnorm2) {
+  const int         b = blockIdx.x, k = blockIdx.y, c = b * MV_R + (int)threadIdx.x % MV_R;
+  if (k == kdim) {
+    if (!vnorm2) return;
     const double v = mvc_total(part + (size_t)MVC_MAX_KDIM * ld, b, wgs, lds);
     if (threadIdx.x < MV_R) vnorm2[c] = v;
+    return;
   }
-  for (int k = 0; k < kdim; k++) {
-    const double v = mvc_total(part + (size_t)k * ld, b, wgs, lds);
-    if (threadIdx.x < MV_R) coef[(size_t)c * MVC_MAX_KDIM + k] = v;
-  }
+  const double v = mvc_total(part + (size_t)k * ld, b, wgs, lds);
+  if (threadIdx.x < MV_R) coef[(size_t)c * MVC_MAX_KDIM + k] = v;
 }
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_project(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R,
                         const double *__restrict__ coef, const double *__restrict__ v, double *__restrict__ out)
 {
   MV_ROW_LOOP(i, b, rs, wgs)
   {
-    const int c = b * MV_R + cr_;
-    double    s = v[i];
+    const int    c  = b * MV_R + cr_;
+    double       s  = v[i];
+    const double rk = (cr_ < kdim) ? R[(size_t)cr_ * n + i / MV_R] : 0.0; // (as in k_mvc_rt_dot)
 #pragma unroll
     for (int k = 0; k < MVC_MAX_KDIM; k++)
-      if (k < kdim) s -= coef[(size_t)c * MVC_MAX_KDIM + k] * R[(size_t)k * n + i / MV_R];
+      if (k < kdim) s -= coef[(size_t)c * MVC_MAX_KDIM + k] * __shfl(rk, ((int)threadIdx.x & 56) + k, 64);
     out[i] = s;
   }
 }
@@ -398,7 +403,7 @@ static int mvc_project(pmh_matinv_mv V, const double *v, double *out, double *vn
   hipStream_t  st   = V->ctx->stream;
   hipLaunchKernelGGL(k_mvc_rt_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, ld, (const double *)M->d_R, v,
                      V->d_kpart);
-  hipLaunchKernelGGL(k_mvc_coef, dim3(V->nb), dim3(PMH_BLOCK), 0, st, V->wgs, M->kdim, ld, (const double *)V->d_kpart, V->d_coef, vnorm2);
+  hipLaunchKernelGGL(k_mvc_coef, dim3(V->nb, M->kdim + 1), dim3(PMH_BLOCK), 0, st, V->wgs, M->kdim, ld, (const double *)V->d_kpart, V->d_coef, vnorm2);
   hipLaunchKernelGGL(k_mvc_project, dim3(grid), dim3(PMH_BLOCK), 0, st, (const int *)M->K->d_rowstart, V->wgs, V->ldR, M->kdim, (const double *)M->d_R,
                      (const double *)V->d_coef, v, out);
   PMH_HIP(hipGetLastError());

@@ -654,12 +654,14 @@ extern "C" int pmh_mg_create(pmh_ctx ctx, int nlevels, const pmh_csr *A, const p
       }
     }
   }
-  mg->nb_coarse = nb_coarse;
+  mg->nb_coarse  = nb_coarse;
+  mg->coarse_m16 = 1;
   std::vector<long long> ofs(nb_coarse);
   long long              tot = 0;
   for (int b = 0; b < nb_coarse; b++) {
     const long long m = coarse_rowstart[b + 1] - coarse_rowstart[b];
     PMH_ARG(m >= 0);
+    if (m % 16 || m < 512) mg->coarse_m16 = 0;
     ofs[b] = tot, tot += m * m;
   }
   PMH_CHK(pmh_malloc(ctx, sizeof(int) * (size_t)(nb_coarse + 1), (void **)&mg->d_crs));

@@ -29,6 +29,7 @@ struct pmh_mg_s {
   long long            *d_cofs;  // offsets of the dense blocks [nb_coarse]
   void                 *d_cpinv; // concatenated dense pseudo-inverses, row-major, cycle precision (fp16 entries / cp_scale with PMH_MG_FP16)
   int                   cp_half;
+  int                   coarse_m16; // every dense block has a multiple of 16 rows, at least 512 (the 8-column cycle's matrix-core coarse solve, mg_mv.hip)
   double                cp_scale;
   const int            *halt;
   long long             fine_spmv; // fine-level SpMVs issued (statistics)

@@ -173,6 +173,102 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const i
   }
 }
 
+// The same on the matrix cores (round 6), for the LARGE dense coarse blocks of the one-block regime (5 184 rows on the 43^3 cube: 54 MB of fp16 entries per solve).  The form
+// above reads the 32 bytes of B's row j once per ROW of pinv -- 860 MB through the L1s per solve, 35.6 us (1.5 TB/s on the matrix) -- and sums over k with 48 butterfly steps
+// per row.  Here a workgroup of 8 wavefronts owns 16 rows, wavefront w the steps [w per, (w+1) per) of 32 k's: lane (i, q) = (l & 15, l >> 4) loads the 8 entries
+// pinv[row0 + i][k0 + 8 q ... + 8) in one 16-byte load and feeds them to 8 v_mfma_f32_16x16x4_f32 (exact fp32 FMAs; A[i][k = q] / B[k = q][j = l & 15], k taken as 8 q + e for
+// the e-th one: any assignment of k's to the 4 k-slots is a permutation of the sum) against B[k0 + 8 q + e][j & 7] -- the 8 columns twice, half of the instruction's N = 16 is
+// idle, which costs nothing at 0.9 GFLOP.  The sum over k happens inside the instruction; the 8 wavefronts' 16 x 8 partials are added through LDS in wave order (fixed).
+// Needs every block's size to be a multiple of 16 (rows of a workgroup in ONE block, 16-byte aligned rows); else the form above.
+typedef float    mvg_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 mvg_h8 __attribute__((ext_vector_type(8)));
+template <int MVG_CU> struct mvg_cstage {
+  mvg_h8   a[MVG_CU];
+  mvg_flt4 b[MVG_CU];
+};
+template <int MVG_CW, int MVG_CU> __global__ __launch_bounds__(64 * MVG_CW) void k_mvg_coarse_mfma(int nb, const int *__restrict__ halt, const int *__restrict__ rs, const long long *__restrict__ ofs,
+                        const _Float16 *__restrict__ pinv, float scale, const float *__restrict__ b, float *__restrict__ x)
+{
+  if (halt && *halt) return;
+  __shared__ float part[MVG_CW][16][MV_R];
+  __shared__ float tr[MVG_CW][MVG_CU][4 * 8 * 8]; // per wavefront and step: the 32 x 8 entries of B, [q][column][k & 7]
+  const int        row0 = blockIdx.x * 16;
+  int              lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rs[mid] <= row0) lo = mid;
+    else hi = mid;
+  }
+  const int       r0 = rs[lo], m = rs[lo + 1] - r0;
+  const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4, jr = i & 7, h = i >> 3;
+  const _Float16 *a  = pinv + ofs[lo] + (size_t)(row0 - r0 + i) * m + 8 * q;
+  // B[k0 + 8 q ... + 8)[0 ... 8) is 256 contiguous bytes: lane (jr, h) of the 16 with this q brings 16 of them (row jr, columns 4 h ... 4 h + 3) -- ONE coalesced load per
+  // step where every lane fetching its own 8 operands (column jr of the 8 rows) took 8 and left the kernel bound by the address rate of those (26 us)
+  const float *bb = b + ((size_t)r0 + 8 * q + jr) * MV_R + 4 * h;
+  const int    nsteps = (m + 31) / 32, per = (nsteps + MVG_CW - 1) / MVG_CW;
+  const int    s0 = wave * per, s1 = min(nsteps, s0 + per);
+  auto         load = [&](mvg_cstage<MVG_CU> &S, int s) {
+#pragma unroll
+    for (int u = 0; u < MVG_CU; u++) {
+      const int  k0 = 32 * (s + u);
+      const bool ok = (s + u < s1) && (k0 + 8 * q < m); // (m % 8 == 0: the 8 entries are in the row or not)
+      if (ok) {
+        S.a[u] = *(const mvg_h8 *)(a + k0);
+        S.b[u] = *(const mvg_flt4 *)(bb + (size_t)k0 * MV_R);
+      } else {
+        S.a[u] = mvg_h8{0, 0, 0, 0, 0, 0, 0, 0};
+        S.b[u] = mvg_flt4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  mvg_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f}; // two chains: the instruction's dependent latency (40 cycles) is above its issue time (32)
+  auto      mults = [&](const mvg_cstage<MVG_CU> &S) {
+    // the 8 x 8 blocks transposed through the wavefront's own LDS lines (its LDS operations execute in order: no barrier, the compiler is only kept from reordering them)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < MVG_CU; u++) {
+      float *t = &tr[wave][u][(q * 8 + 4 * h) * 8 + jr];
+      t[0] = S.b[u].x, t[8] = S.b[u].y, t[16] = S.b[u].z, t[24] = S.b[u].w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < MVG_CU; u++) {
+      const mvg_flt4 v0 = *(const mvg_flt4 *)&tr[wave][u][(q * 8 + jr) * 8], v1 = *(const mvg_flt4 *)&tr[wave][u][(q * 8 + jr) * 8 + 4];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][0], v0.x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][1], v0.y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][2], v0.z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][3], v0.w, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][4], v1.x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][5], v1.y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][6], v1.z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.a[u][7], v1.w, c1, 0, 0, 0);
+    }
+  };
+  mvg_cstage<MVG_CU> S0, S1;
+  load(S0, s0);
+  for (int s = s0; s < s1; s += 2 * MVG_CU) { // (the loads of the next stage are in flight while this one's products issue)
+    load(S1, s + MVG_CU);
+    mults(S0);
+    load(S0, s + 2 * MVG_CU);
+    mults(S1);
+  }
+  // C[row = 4 q + v][col = i]: columns 8 ... 15 repeat 0 ... 7
+  if (i < MV_R) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) part[wave][4 * q + v][i] = c0[v] + c1[v];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 * MV_R) {
+    const int rr = threadIdx.x / MV_R, cc = threadIdx.x % MV_R;
+    float     sum = part[0][rr][cc];
+#pragma unroll
+    for (int w = 1; w < MVG_CW; w++) sum += part[w][rr][cc];
+    x[(size_t)(row0 + rr) * MV_R + cc] = sum * scale;
+  }
+}
+
 static inline dim3 mvg_grid(long long work_items)
 {
   long long g = (work_items + PMH_BLOCK - 1) / PMH_BLOCK;
@@ -277,7 +373,16 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   const int    nrep = M->nrep, n_l = Lv.n / nrep; // (congruent blocks: the first block's share of every level)
   if (l == mg->nlevels - 1) {
     const int nbc = mg->nb_coarse / nrep;
-    if (mg->cp_half)
+    if (mg->cp_half && mg->coarse_m16) {
+      static int dev = -1;
+      if (dev < 0) dev = getenv("PMH_DEV_COARSE") ? atoi(getenv("PMH_DEV_COARSE")) : 0;
+#define CL(CW, CU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse_mfma<CW, CU>), dim3(n_l / 16), dim3(64 * CW), 0, st, nbc, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale, (const float *)Ml.b, Ml.x)
+      switch (dev) {
+      case 1: CL(16, 1); break;
+      default: CL(16, 2);
+      }
+    }
+    else if (mg->cp_half)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs,
                          (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
                          (const float *)Ml.b, Ml.x);

@@ -169,6 +169,46 @@ def test_eight_congruent_blocks_run_as_eight_columns(ctx, prec):
         assert np.linalg.norm(ua[sl] - ref) <= 1e-8 * np.linalg.norm(ref), b
 
 
+@pytest.mark.parametrize("nel", [14, 22])
+def test_large_dense_coarse_block_is_solved_on_the_matrix_cores(ctx, nel):
+    """The one-block regime of bench.py's inner-Krylov pass in small: 15^3- (23^3-) node cubes coarsened ONCE, dense coarse blocks of 8^3 (12^3) nodes = 1 536 (5 184, bench.py's)
+    rows in fp16 -- multiples of 16 and >= 512, so the 8-column cycle takes k_mvg_coarse_mfma (v_mfma_f32_16x16x4_f32, 16 rows per workgroup, the k range split over its 8
+    wavefronts: 48 steps of 32 k's = 6 per wavefront, whole pipeline stages; 162 steps = 21 per wavefront, 15 for the last one: the guarded tails) -- against the one-column
+    cycle's k_mg_coarse on 8 replicas: the same K^+ to 1e-8, iteration counts within 2."""
+    from permon_amd.feti import CubeFeti
+
+    f = CubeFeti((2, 2, 2), nel, "elasticity", contact=False)
+    nn, n_i, N = f.nel + 1, f.n_i, f.N
+    Ksp = f.K
+    rhs = np.random.default_rng(5).standard_normal(N) * np.repeat(10.0 ** np.arange(-3, 5), n_i)
+    out = []
+    try:
+        for knob in (1, 0):
+            check(ctx.L.pmh_set_knob(b"kplus_mv", knob))
+            K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Ksp)
+            M = pa.MatInv(K, rtol=1e-11, nullspace=f.R)
+            M.enable_bsr3()
+            M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=f.R, min_nodes=512, degree=2, precision="fp16")
+            u = ctx.vec(N)
+            M.mult(ctx.vec_from(rhs), u)
+            out.append((u.to_numpy(), M.last_iterations()[0]))
+    finally:
+        ctx.L.pmh_set_knob(b"kplus_mv", 1)
+    (ua, ia), (ub, ib) = out
+    for b in range(8):
+        sl = slice(b * n_i, (b + 1) * n_i)
+        assert np.linalg.norm(ua[sl] - ub[sl]) <= 1e-8 * np.linalg.norm(ub[sl]), b
+    assert abs(ia - ib) <= 2 and ia < 30, (ia, ib)
+    # K K^+ f = P_R f: the solution is one, whatever the path
+    r = Ksp @ ua - rhs
+    Rb = f.R[:, :n_i]
+    G = np.linalg.inv(Rb @ Rb.T)
+    for b in range(8):
+        sl = slice(b * n_i, (b + 1) * n_i)
+        rb = r[sl] + Rb.T @ (G @ (Rb @ rhs[sl]))
+        assert np.linalg.norm(rb) <= 1e-9 * np.linalg.norm(rhs[sl]), b
+
+
 def test_multi_rhs_kplus_on_blocks_of_different_sizes(ctx):
     """ex71's elasticity slabs (DmdaFeti): 7 blocks of two different sizes, one of them non-singular (Dirichlet in the matrix), thin in x, a hierarchy built by the Python
     builder and handed in (pmh_mg_create with node-wise P) -- the 8-column solver against the one-column solver on every column, and the explicit operators assembled
