@@ -140,6 +140,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_ur(const int *__restri
                                                             const double *__restrict__ partA, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap, double *__restrict__ u,
                                                             double *__restrict__ r, double *__restrict__ z, double *__restrict__ partB, double *__restrict__ partC)
 {
+  // (the V-cycle's first smoothing direction D^-1 r / theta and its fp32 copy of r written from here, round 6: this kernel 27 -> 36 us for the 6.5 us of k_mvg_d0 -- these
+  // passes run at the latency of their few wavefronts, two more store streams cost more than the launch they save)
   __shared__ double lds[32];
   if (*done) return;
   const int    bb  = blockIdx.x / wgs, c = bb * MV_R + (int)threadIdx.x % MV_R;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_coef(int wgs, int kdim, size_
   if (threadIdx.x < MV_R) coef[(size_t)c * MVC_MAX_KDIM + k] = v;
 }
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_project(const int *__restrict__ rs, int wgs, int n, int kdim, const double *__restrict__ R,
-                        const double *__restrict__ coef, const double *__restrict__ v, double *__restrict__ out)
+                        const double *__restrict__ coef, const double *v, double *out) // (v == out is allowed)
 {
   MV_ROW_LOOP(i, b, rs, wgs)
   {
@@ -363,7 +365,10 @@ static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out)
   V->M = M, V->ctx = ctx, V->nrep = nrep, V->nb = M->nblocks / nrep, V->n = M->n / nrep, V->ncol = V->nb * MV_R, V->ldR = M->n;
   int maxrows = 1;
   for (int b = 0; b < V->nb; b++) maxrows = std::max(maxrows, M->K->rowstart[b + 1] - M->K->rowstart[b]);
-  V->wgs = std::max(1, std::min({PMH_BLOCK, (maxrows + 4 * MVC_ROWS - 1) / (4 * MVC_ROWS), std::max(1, 4 * ctx->num_cus / std::max(1, V->nb))}));
+  // workgroups per block of the vector kernels = partial sums per column: 8 per CU over all blocks, at most 512 a block.  (Measured on the 43^3 cube, one block: 256 -> 512:
+  // k_mvc_rt_dot 28.8 -> 17.4 us, k_mvc_project 29.8 -> 20.7, k_mvc_update_ur 28.0 -> 24.1, k_mvc_update_p 17.9 -> 19.4; at 1 024 the consumers' prologue -- every workgroup
+  // sums all the partials of its block -- takes the gain back: update_p 35 us, 85 at 2 048.)
+  V->wgs = std::max(1, std::min({2 * PMH_BLOCK, (maxrows + 4 * MVC_ROWS - 1) / (4 * MVC_ROWS), std::max(1, 8 * ctx->num_cus / std::max(1, V->nb))}));
   int rc = pmh_mv_ell_create_prefix(M->K->K, nrep, PMH_BSR_F64, &V->K64);
   if (!rc && !V->K64) pmh_mv_set_why("K has rows with unsorted columns or more than 32 blocks of 3 x 3 in a block row"), rc = PMH_EPI_UNSUPPORTED;
   if (!rc && M->mg) rc = pmh_mg_mv_create(M->mg, &V->mgmv, nrep);
@@ -468,10 +473,7 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
     }
   }
   V->last_max_its = V->h_state[1];
-  if (M->kdim) { // U <- P_R U (in place through the scratch multivector)
-    PMH_CHK(mvc_project(V, u, V->fproj, nullptr));
-    PMH_CHK(pmh_memcpy_d2d(ctx, u, V->fproj, sizeof(double) * (size_t)V->n * MV_R));
-  }
+  if (M->kdim) PMH_CHK(mvc_project(V, u, u, nullptr)); // U <- P_R U, in place: the coefficients are complete before k_mvc_project starts, which reads and writes entry by entry
   return PMH_SUCCESS;
 }
 

@@ -175,10 +175,12 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const i
 
 // The same on the matrix cores (round 6), for the LARGE dense coarse blocks of the one-block regime (5 184 rows on the 43^3 cube: 54 MB of fp16 entries per solve).  The form
 // above reads the 32 bytes of B's row j once per ROW of pinv -- 860 MB through the L1s per solve, 35.6 us (1.5 TB/s on the matrix) -- and sums over k with 48 butterfly steps
-// per row.  Here a workgroup of 8 wavefronts owns 16 rows, wavefront w the steps [w per, (w+1) per) of 32 k's: lane (i, q) = (l & 15, l >> 4) loads the 8 entries
+// per row.  Here a workgroup of MVG_CW wavefronts owns 16 rows, wavefront w the steps [w per, (w+1) per) of 32 k's: lane (i, q) = (l & 15, l >> 4) loads the 8 entries
 // pinv[row0 + i][k0 + 8 q ... + 8) in one 16-byte load and feeds them to 8 v_mfma_f32_16x16x4_f32 (exact fp32 FMAs; A[i][k = q] / B[k = q][j = l & 15], k taken as 8 q + e for
-// the e-th one: any assignment of k's to the 4 k-slots is a permutation of the sum) against B[k0 + 8 q + e][j & 7] -- the 8 columns twice, half of the instruction's N = 16 is
-// idle, which costs nothing at 0.9 GFLOP.  The sum over k happens inside the instruction; the 8 wavefronts' 16 x 8 partials are added through LDS in wave order (fixed).
+// the e-th one: any assignment of k's to the 4 k-slots is a permutation of the sum) against B[k0 + 8 q + e][j & 7] -- the 8 columns twice: half of the instruction's N = 16 is
+// idle.  The sum over k happens inside the instruction; the wavefronts' 16 x 8 partials are added through LDS in wave order (fixed).  21.4 us = 2.5 TB/s on the matrix: 324
+// workgroups on 256 CUs leave 68 CUs with two, whose 32 wavefronts x 12 steps x 8 instructions x 32 cycles / 4 SIMDs are 10 us of matrix-core time alone -- the next steps
+// would be the 4x4x1 16-block form (no idle half, 4-row granularity) and are not taken: the solve is 6 % of an inner-Krylov step now.
 // Needs every block's size to be a multiple of 16 (rows of a workgroup in ONE block, 16-byte aligned rows); else the form above.
 typedef float    mvg_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 mvg_h8 __attribute__((ext_vector_type(8)));
@@ -373,15 +375,10 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
   const int    nrep = M->nrep, n_l = Lv.n / nrep; // (congruent blocks: the first block's share of every level)
   if (l == mg->nlevels - 1) {
     const int nbc = mg->nb_coarse / nrep;
-    if (mg->cp_half && mg->coarse_m16) {
-      static int dev = -1;
-      if (dev < 0) dev = getenv("PMH_DEV_COARSE") ? atoi(getenv("PMH_DEV_COARSE")) : 0;
-#define CL(CW, CU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse_mfma<CW, CU>), dim3(n_l / 16), dim3(64 * CW), 0, st, nbc, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale, (const float *)Ml.b, Ml.x)
-      switch (dev) {
-      case 1: CL(16, 1); break;
-      default: CL(16, 2);
-      }
-    }
+    if (mg->cp_half && mg->coarse_m16)
+      // (16 wavefronts x 2 steps per stage: 21.4 us on the 5 184-row block; 8 x 3: 23.2, 8 x 6: 26.9, 16 x 3: 25.3, 4 x 6: 26.6)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse_mfma<16, 2>), dim3(n_l / 16), dim3(64 * 16), 0, st, nbc, halt, (const int *)mg->d_crs, (const long long *)mg->d_cofs,
+                         (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale, (const float *)Ml.b, Ml.x);
     else if (mg->cp_half)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvg_coarse<_Float16>), dim3((n_l + 3) / 4), blk, 0, st, nbc, n_l, halt, (const int *)mg->d_crs,
                          (const long long *)mg->d_cofs, (const _Float16 *)mg->d_cpinv, (float)mg->cp_scale,
