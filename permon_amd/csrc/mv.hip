@@ -245,6 +245,9 @@ template <typename T> struct mv_blk<_Float16, T> {
 
 // LPR lanes per block row (4; 16 for the long rows of an aggregation hierarchy's coarse operators: 7 500 block rows of ~ 80 ... 150 blocks left the chip idle with 4):
 // lane l takes the slots LPR g + l, i.e. plane (LPR / 4) g + (l >> 2), entry l & 3 of the plane
+#ifndef MV_STAGED
+#define MV_STAGED 1
+#endif
 template <typename TM, typename T, int R, int EPI, int LPR = 4>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale,
                         const T *__restrict__ x, T *__restrict__ y, pmh_mv_epi<T> e, const int *__restrict__ halt, int xcd_map)
@@ -268,7 +271,60 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
   for (int q = 0; q < 3; q++)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[q][r] = (T)0;
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (LPR == 4 && MV_STAGED) {
+    // Round 6, the operand through LDS.  A lane's slot needs the 3 R operand values of ITS block column -- NP = 6 (fp64: 12) pieces of 16 bytes, each lane of a quad from
+    // another block column: four cache-line accesses per quad and load instruction, the rate that bounds the product (header comment).  Here the quad loads its trip's four
+    // pieces of 3 R values TOGETHER: lane l of the quad takes the pieces p = 4 j + l, j < NP, of their concatenation, four adjacent pieces = 64 contiguous bytes of one
+    // (or two) block columns per instruction -- one or two line accesses, the same number of instructions; the pieces go to the quad's own 64 bytes x NP of LDS and every lane
+    // reads its block column's NP pieces back.  A wavefront's LDS operations execute in order and a quad exchanges with nobody else: no barrier.  Same values into the same
+    // FMAs: the same bits.
+    constexpr int NP = 3 * R * (int)sizeof(T) / 16, QS = 4 * NP * 16 + (NP == 6 ? 64 : 16); // bytes per quad (the padding that leaves the 16-byte stores of a lane group of 8 / the loads of one of 16 the fewest bank conflicts)
+    __shared__ __attribute__((aligned(16))) char stage_[PMH_BLOCK / 4 * QS];
+    char *const  sq = stage_ + (threadIdx.x >> 2) * QS;
+    // piece p = 4 j + l lies in the chunk of quad lane p / NP at 16 (p % NP) bytes
+    auto gather = [&](int c, mv_flt4(&pc)[NP]) {
+      int cq[4];
+      cq[0] = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, true), cq[1] = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, true);
+      cq[2] = __builtin_amdgcn_update_dpp(0, c, 0xAA, 0xf, 0xf, true), cq[3] = __builtin_amdgcn_update_dpp(0, c, 0xFF, 0xf, 0xf, true);
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        const int lo = (4 * j) / NP, hi = (4 * j + 3) / NP; // the chunks this instruction touches (compile-time: at most two)
+        const int p  = 4 * j + l;
+        const int cc = (lo == hi || p / NP == lo) ? cq[lo] : cq[hi];
+        pc[j]        = *(const mv_flt4 *)((const char *)(x + (size_t)3 * cc * R) + 16 * (p % NP));
+      }
+    };
+    auto exchange = [&](const mv_flt4(&pc)[NP], T(&xv)[3 * R]) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NP; j++) *(mv_flt4 *)(sq + 16 * (4 * j + l)) = pc[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int o = 0; o < NP; o++) {
+        const mv_flt4 t = *(const mv_flt4 *)(sq + 16 * (NP * l + o));
+        __builtin_memcpy(&xv[o * (16 / (int)sizeof(T))], &t, 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    mv_flt4 pc[NP];
+    gather(cn, pc);
+    if (1 < W4) cn = col[((size_t)1 * nbr + br) * 4 + l];
+    for (int g = 0; g < W4; g++) {
+      T a[9], xv[3 * R];
+      mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
+      exchange(pc, xv);
+      if (g + 1 < W4) { // the next trip's pieces travel during this trip's products
+        gather(cn, pc);
+        if (g + 2 < W4) cn = col[((size_t)(g + 2) * nbr + br) * 4 + l];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[q][r] += a[3 * q] * xv[r] + a[3 * q + 1] * xv[R + r] + a[3 * q + 2] * xv[2 * R + r];
+    }
+  } else if constexpr (sizeof(T) == 4) {
     // software pipeline (fp32 vectors: the V-cycle): the entries and the operand values of trip g + 1 are loaded before the products of trip g (the index of trip g + 2 with
     // them).  Measured on one 43^3 block, 8 columns: fp32 entries 34.6 -> 29.5 us, fp16 entries unchanged (27 us); with fp64 vectors the second operand set costs
     // the occupancy more than the chain costs (57 -> 62 us): the plain loop below
