@@ -192,7 +192,10 @@ int pmh_mv_ell_destroy(pmh_mv_ell E)
 // not per distinct address.  What bounds the product is that rate -- one cache line per clock and CU; a 16-byte piece of a gathered operand costs a line access of its own.
 // Also built, measured, dropped: the operand STAGED in LDS per tile of 64 (fp64: 32) block rows -- the tile's distinct block columns copied with coalesced 16-byte loads,
 // the slots addressing them by 16-bit local indices (tables built on the host).  Same bits; 81 / 31 / 30 us: 45 ... 90 KB of LDS per workgroup leave 1 - 3 workgroups per
-// CU, and their copy phases do not overlap anybody's products.)
+// CU, and their copy phases do not overlap anybody's products.
+// Built, measured, KEPT (later in round 6): the quad of a block row loads its trip's four operand pieces together and exchanges them through its own LDS lines -- the
+// MV_STAGED branch of the kernel below; 57.8 / 27.3 / 25.4 -> 51.0 / 26.1 / 23.8 us.  Control experiment behind it: the operand loads replaced by same-sized loads from
+// contiguous addresses (wrong results, timing only) 35.9 / 18.5 / 15.6 us.)
 template <typename T, int N> struct mv_vec;
 template <int N> struct mv_vec<double, N> { // N doubles = N / 2 loads of 16 bytes
   static __device__ __forceinline__ void load(const double *p, double (&v)[N])
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
     // (or two) block columns per instruction -- one or two line accesses, the same number of instructions; the pieces go to the quad's own 64 bytes x NP of LDS and every lane
     // reads its block column's NP pieces back.  A wavefront's LDS operations execute in order and a quad exchanges with nobody else: no barrier.  Same values into the same
     // FMAs: the same bits.
+    constexpr bool MV_PREF = sizeof(T) == 4;
     constexpr int NP = 3 * R * (int)sizeof(T) / 16, QS = 4 * NP * 16 + (NP == 6 ? 64 : 16); // bytes per quad (the padding that leaves the 16-byte stores of a lane group of 8 / the loads of one of 16 the fewest bank conflicts)
     __shared__ __attribute__((aligned(16))) char stage_[PMH_BLOCK / 4 * QS];
     char *const  sq = stage_ + (threadIdx.x >> 2) * QS;
@@ -309,13 +313,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
       __builtin_amdgcn_wave_barrier();
     };
     mv_flt4 pc[NP];
-    gather(cn, pc);
-    if (1 < W4) cn = col[((size_t)1 * nbr + br) * 4 + l];
+    if (MV_PREF) gather(cn, pc);
+    if (MV_PREF && 1 < W4) cn = col[((size_t)1 * nbr + br) * 4 + l];
     for (int g = 0; g < W4; g++) {
       T a[9], xv[3 * R];
+      if (!MV_PREF) {
+        gather(cn, pc);
+        if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l];
+      }
       mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
       exchange(pc, xv);
-      if (g + 1 < W4) { // the next trip's pieces travel during this trip's products
+      if (MV_PREF && g + 1 < W4) { // the next trip's pieces travel during this trip's products
         gather(cn, pc);
         if (g + 2 < W4) cn = col[((size_t)(g + 2) * nbr + br) * 4 + l];
       }
