@@ -42,6 +42,7 @@ if [[ $PART == *c* ]]; then
   export PMH_BENCH_NO_TIMING=1
   run() { # name, program, regex, args...
     name=$1; prog=$2; rx=$3; shift; shift; shift
+    if [[ -n "$PMC_ONLY" && "$PMC_ONLY" != *$name* ]]; then return; fi # PMC_ONLY="feti_iterative nosym21": a subset
     mkdir -p $O/pmc_$name
     for C in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --pmc $C --kernel-include-regex "$rx" --output-format csv -d $O/pmc_$name/pmc_$C -- python3 $R/$prog "$@" > $O/pmc_${name}_$C.log 2>&1
