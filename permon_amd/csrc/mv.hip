@@ -313,24 +313,20 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
       __builtin_amdgcn_wave_barrier();
     };
     mv_flt4 pc[NP];
-    T       an[9]; // the next trip's entries: asked for one trip ahead, behind that trip's operand pieces (loads return in order: the exchange waits for the pieces only)
     if (MV_PREF) gather(cn, pc);
     if (MV_PREF && 1 < W4) cn = col[((size_t)1 * nbr + br) * 4 + l];
-    mv_blk<TM, T>::load(val, (size_t)0, nbr, br, l, an);
     for (int g = 0; g < W4; g++) {
       T a[9], xv[3 * R];
       if (!MV_PREF) {
         gather(cn, pc);
         if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l];
       }
-#pragma unroll
-      for (int i = 0; i < 9; i++) a[i] = an[i];
+      mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
       exchange(pc, xv);
       if (MV_PREF && g + 1 < W4) { // the next trip's pieces travel during this trip's products
         gather(cn, pc);
         if (g + 2 < W4) cn = col[((size_t)(g + 2) * nbr + br) * 4 + l];
       }
-      if (g + 1 < W4) mv_blk<TM, T>::load(val, (size_t)(g + 1), nbr, br, l, an);
 #pragma unroll
       for (int q = 0; q < 3; q++)
 #pragma unroll
