@@ -281,7 +281,6 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
     // (or two) block columns per instruction -- one or two line accesses, the same number of instructions; the pieces go to the quad's own 64 bytes x NP of LDS and every lane
     // reads its block column's NP pieces back.  A wavefront's LDS operations execute in order and a quad exchanges with nobody else: no barrier.  Same values into the same
     // FMAs: the same bits.
-    constexpr bool MV_PREF = sizeof(T) == 4;
     constexpr int NP = 3 * R * (int)sizeof(T) / 16, QS = 4 * NP * 16 + (NP == 6 ? 64 : 16); // bytes per quad (the padding that leaves the 16-byte stores of a lane group of 8 / the loads of one of 16 the fewest bank conflicts)
     __shared__ __attribute__((aligned(16))) char stage_[PMH_BLOCK / 4 * QS];
     char *const  sq = stage_ + (threadIdx.x >> 2) * QS;
@@ -312,21 +311,15 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
       }
       __builtin_amdgcn_wave_barrier();
     };
-    mv_flt4 pc[NP];
-    if (MV_PREF) gather(cn, pc);
-    if (MV_PREF && 1 < W4) cn = col[((size_t)1 * nbr + br) * 4 + l];
+    // (No operand prefetch across trips: the pieces of trip g + 1 asked for during the products of trip g cost 24 / 48 registers -- fp16 entries 124 -> 100 VGPRs = 5 instead of
+    // 4 wavefronts per SIMD, 23.8 -> 23.1 us; fp64 192 -> 146, 52.0 -> 51.0 us.  Forcing 6 per SIMD spills 21 registers: 46 us.  The entries one trip ahead: 51.0 -> 55.8 us.)
     for (int g = 0; g < W4; g++) {
-      T a[9], xv[3 * R];
-      if (!MV_PREF) {
-        gather(cn, pc);
-        if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l];
-      }
+      T       a[9], xv[3 * R];
+      mv_flt4 pc[NP];
+      gather(cn, pc);
+      if (g + 1 < W4) cn = col[((size_t)(g + 1) * nbr + br) * 4 + l];
       mv_blk<TM, T>::load(val, (size_t)g, nbr, br, l, a);
       exchange(pc, xv);
-      if (MV_PREF && g + 1 < W4) { // the next trip's pieces travel during this trip's products
-        gather(cn, pc);
-        if (g + 2 < W4) cn = col[((size_t)(g + 2) * nbr + br) * 4 + l];
-      }
 #pragma unroll
       for (int q = 0; q < 3; q++)
 #pragma unroll
