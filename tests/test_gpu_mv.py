@@ -85,15 +85,17 @@ def test_mv_long_rows_take_16_lanes_per_block_row(ctx, storage):
     assert np.abs(yd.to_numpy().reshape(n, R) - ref).max() <= tol * scale
 
 
-@pytest.mark.parametrize("case", ["floating", "regularized", "odd_box", "jacobi"])
+@pytest.mark.parametrize("case", ["floating", "regularized", "odd_box", "jacobi", "mfma_coarse"])
 def test_multi_rhs_kplus_against_the_one_column_solver(ctx, case):
     """U = K^+ F for 8 columns per block (matinv_mv.hip: interleaved multivectors, the V-cycle of mg_mv.hip) against pmh_matinv_mult column by column and against the dense
     pseudo-inverse: floating blocks (K^+ = P_R K^- P_R), regularised blocks (no kernel), a box with a short last coarse interval, and Jacobi-CG without a hierarchy; two
-    DIFFERENT blocks (the second one twice as stiff) so that nothing leans on congruence.  Columns of very different size, one of them zero, one in the kernel."""
+    DIFFERENT blocks (the second one twice as stiff) so that nothing leans on congruence.  Columns of very different size, one of them zero, one in the kernel.
+    "mfma_coarse": 15^3-node blocks coarsened once, TWO dense fp16 coarse blocks of 1 536 rows each -- k_mvg_coarse_mfma with more than one block (a workgroup finds its block by its
+    first row); against the one-column solver only (the dense pseudo-inverse of 10 125 dofs is not formed)."""
     from permon_amd.feti import CubeFeti
     import scipy.sparse as sp
 
-    nel = 9 if case == "odd_box" else 6
+    nel = {"odd_box": 9, "mfma_coarse": 14}.get(case, 6)
     f = CubeFeti((2, 1, 1), nel, "elasticity", contact=False)
     nn, n_i, N = f.nel + 1, f.n_i, f.N
     Ksp = sp.block_diag([f.K[:n_i, :n_i], 2.0 * f.K[n_i:, n_i:]]).tocsr()
@@ -105,7 +107,7 @@ def test_multi_rhs_kplus_against_the_one_column_solver(ctx, case):
     K = pa.MatBlockDiag.from_scipy(ctx, f.block_rowstart, Ksp)
     M = pa.MatInv(K, rtol=1e-11, nullspace=R)
     if case != "jacobi":
-        M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=R, min_nodes=27, degree=2, precision="fp32")
+        M.set_pc_mg_box(Ksp, [(nn, nn, nn)] * f.nsub, 3, R=R, min_nodes=512 if case == "mfma_coarse" else 27, degree=2, precision="fp16" if case == "mfma_coarse" else "fp32")
     rng = np.random.default_rng(5)
     F = rng.standard_normal((N, 8)) * (10.0 ** rng.integers(-3, 4, size=8))
     F[:, 3] = 0.0
@@ -125,7 +127,7 @@ def test_multi_rhs_kplus_against_the_one_column_solver(ctx, case):
     assert np.all(U[:, 3] == 0.0)
     if R is not None:
         assert np.linalg.norm(U[:n_i, 5]) <= 1e-10
-        for b in range(2):
+        for b in range(2 if case != "mfma_coarse" else 0):
             Kd = Ksp[b * n_i:(b + 1) * n_i, b * n_i:(b + 1) * n_i].toarray()
             ref = np.linalg.pinv(Kd, rcond=1e-10, hermitian=True) @ F[b * n_i:(b + 1) * n_i]
             for r in (0, 1, 2, 4, 6, 7):
