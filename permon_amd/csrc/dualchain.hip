@@ -586,8 +586,8 @@ int pmh_dc_apply(pmh_dualchain dc, const double *x, double *y, double rho, const
 {
   pmh_ctx     ctx = dc->ctx;
   hipStream_t st  = ctx->stream;
-  const int   n = dc->n, m = dc->m;
-  const dim3  vgrid((unsigned)dc->nwg), blk(PMH_BLOCK), eblk(PMH_EMIT_TILE);
+  const int   n = dc->n;
+  const dim3  vgrid((unsigned)dc->nwg), eblk(PMH_EMIT_TILE);
   const int   kind = epi ? epi->kind : 0;
   dc->launches     = 0;
   const pmh_emit_tab tab = dc_tab(dc);
