@@ -73,39 +73,37 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_absmax(long long nnz, const do
   if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m)); // non-negative doubles order as their bit patterns
 }
 
+// Layout of the entries (round 6: until then one plane per entry -- 9 loads of 8 / 4 bytes per slot, fp16 three of 8 with every fourth half unused; the product is bound by
+// the number of vector-memory instructions its wavefronts can issue, ~ 41 cycles each (SQ counters, profiles/r06_mv_spmv_pmc.txt)).  Per plane g of 4 slots x nbr block rows:
+// the entries 0 ... 7 of a slot as NW = 8 / VW vectors of 16 bytes (VW = 2 / 4 / 8 entries), vector k of (br, l) at 16-byte index (k nbr + br) 4 + l, then entry 8 of (br, l) as
+// one element at index 4 br + l behind them; a plane starts at a multiple of 16 bytes.  5 / 3 / 2 loads per slot instead of 9 / 9 / 3, fp16 18 instead of 24 bytes.
+template <typename TM> struct mv_lay {
+  static constexpr int VW = 16 / (int)sizeof(TM), NW = 8 / VW;
+  static __host__ __device__ __forceinline__ size_t plane_bytes(int nbr) { return ((size_t)nbr * 4 * 9 * sizeof(TM) + 15) & ~(size_t)15; }
+};
+template <typename TM> static __device__ __forceinline__ TM mv_entry(double v);
+template <> __device__ __forceinline__ double mv_entry<double>(double v) { return v; }
+template <> __device__ __forceinline__ float mv_entry<float>(double v) { return (float)v; }
+template <> __device__ __forceinline__ _Float16 mv_entry<_Float16>(double v) { return (_Float16)(float)v; }
+
 template <typename TM>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
-                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, TM *__restrict__ eval, int rect)
+                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, char *__restrict__ eval, int rect)
 {
   const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
   if (br >= nbr) return;
+  constexpr int VW = mv_lay<TM>::VW, NW = mv_lay<TM>::NW;
+  const size_t  pb = mv_lay<TM>::plane_bytes(nbr);
   auto put = [&](int s, int cb, const double *a) {
     ecol[((size_t)(s >> 2) * nbr + br) * 4 + (s & 3)] = cb;
+    char *p = eval + (size_t)(s >> 2) * pb;
 #pragma unroll
-    for (int i = 0; i < 9; i++) eval[(((size_t)(s >> 2) * 9 + i) * nbr + br) * 4 + (s & 3)] = (TM)(a[i] * inv_scale);
+    for (int i = 0; i < 8; i++) ((TM *)(p + (((size_t)(i / VW) * nbr + br) * 4 + (s & 3)) * 16))[i % VW] = mv_entry<TM>(a[i] * inv_scale);
+    ((TM *)(p + (size_t)NW * nbr * 64))[br * 4 + (s & 3)] = mv_entry<TM>(a[8] * inv_scale);
   };
   const int    n = mv_walk(br, rowptr, col, val, put);
   const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int s = n; s < W; s++) put(s, rect ? 0 : br, z); // padding: the row's own block column (a rectangular matrix: block column 0), zero entries
-}
-// fp16: one vector of 4 halves per block row q (the 4th is zero)
-__global__ __launch_bounds__(PMH_BLOCK) void k_mv_ell_fill_h(int nbr, int W, const int *__restrict__ rowptr, const int *__restrict__ col,
-                        const double *__restrict__ val, double inv_scale, int *__restrict__ ecol, mv_half4 *__restrict__ eval, int rect)
-{
-  const int br = blockIdx.x * PMH_BLOCK + threadIdx.x;
-  if (br >= nbr) return;
-  auto put = [&](int s, int cb, const double *a) {
-    ecol[((size_t)(s >> 2) * nbr + br) * 4 + (s & 3)] = cb;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      mv_half4 h;
-      h.x = (_Float16)(float)(a[3 * q] * inv_scale), h.y = (_Float16)(float)(a[3 * q + 1] * inv_scale), h.z = (_Float16)(float)(a[3 * q + 2] * inv_scale), h.w = (_Float16)0.f;
-      eval[(((size_t)(s >> 2) * 3 + q) * nbr + br) * 4 + (s & 3)] = h;
-    }
-  };
-  const int    n = mv_walk(br, rowptr, col, val, put);
-  const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = n; s < W; s++) put(s, rect ? 0 : br, z);
 }
 
 static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, pmh_mv_ell *out);
@@ -159,18 +157,18 @@ static int mv_ell_build(pmh_csr A, int nrep, int storage, int rect, int negate, 
   const size_t nslot = (size_t)E->W * nbr;
   const dim3   g((nbr + PMH_BLOCK - 1) / PMH_BLOCK), blk(PMH_BLOCK);
   int          rc = pmh_malloc(ctx, sizeof(int) * nslot, (void **)&E->col);
-  if (!rc) rc = pmh_malloc(ctx, (storage == PMH_BSR_F64 ? sizeof(double) * 9 : (storage == PMH_BSR_F32 ? sizeof(float) * 9 : sizeof(mv_half4) * 3)) * nslot,
-                          &E->val);
+  const size_t planeb = storage == PMH_BSR_F64 ? mv_lay<double>::plane_bytes(nbr) : (storage == PMH_BSR_F32 ? mv_lay<float>::plane_bytes(nbr) : mv_lay<_Float16>::plane_bytes(nbr));
+  if (!rc) rc = pmh_malloc(ctx, planeb * (size_t)(E->W / 4), &E->val);
   if (rc) {
     pmh_mv_ell_destroy(E);
     return rc;
   }
   if (storage == PMH_BSR_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<double>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
-                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (double *)E->val, rect);
+                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (char *)E->val, rect);
   else if (storage == PMH_BSR_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<float>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr,
-                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (float *)E->val, rect);
-  else hipLaunchKernelGGL(k_mv_ell_fill_h, g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale,
-                          E->col, (mv_half4 *)E->val, rect);
+                          (const int *)A->d_col, (const double *)A->d_val, inv_scale, E->col, (char *)E->val, rect);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mv_ell_fill<_Float16>), g, blk, 0, st, nbr, E->W, (const int *)A->d_rowptr, (const int *)A->d_col, (const double *)A->d_val, inv_scale,
+                          E->col, (char *)E->val, rect);
   PMH_HIP(hipGetLastError());
   *out = E;
   return PMH_SUCCESS;
@@ -228,21 +226,20 @@ template <int N> struct mv_vec<float, N> {
   }
 };
 
-template <typename TM, typename T> struct mv_blk { // the 9 entries of slot 4 g + l, block row br
+template <typename TM, typename T> struct mv_blk { // the 9 entries of slot 4 g + l, block row br (layout: mv_lay)
   static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9]) // g: plane (slot >> 2), l: slot & 3
   {
+    constexpr int VW = mv_lay<TM>::VW, NW = mv_lay<TM>::NW;
+    const char   *p  = (const char *)val + g * mv_lay<TM>::plane_bytes(nbr);
 #pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = (T)__builtin_nontemporal_load((const TM *)val + ((g * 9 + e) * nbr + br) * 4 + l);
-  }
-};
-template <typename T> struct mv_blk<_Float16, T> {
-  static __device__ __forceinline__ void load(const void *val, size_t g, int nbr, int br, int l, T (&a)[9])
-  {
+    for (int k = 0; k < NW; k++) {
+      const mv_flt4 w = __builtin_nontemporal_load((const mv_flt4 *)p + ((size_t)k * nbr + br) * 4 + l);
+      TM            t[VW];
+      __builtin_memcpy(t, &w, 16);
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const mv_half4 h = __builtin_nontemporal_load((const mv_half4 *)val + ((g * 3 + q) * nbr + br) * 4 + l);
-      a[3 * q] = (T)h.x, a[3 * q + 1] = (T)h.y, a[3 * q + 2] = (T)h.z;
+      for (int j = 0; j < VW; j++) a[k * VW + j] = (T)t[j];
     }
+    a[8] = (T)__builtin_nontemporal_load((const TM *)(p + (size_t)NW * nbr * 64) + br * 4 + l);
   }
 };
 
@@ -250,6 +247,9 @@ template <typename T> struct mv_blk<_Float16, T> {
 // lane l takes the slots LPR g + l, i.e. plane (LPR / 4) g + (l >> 2), entry l & 3 of the plane
 #ifndef MV_STAGED
 #define MV_STAGED 1
+#endif
+#ifndef MV_EARLY_EPI
+#define MV_EARLY_EPI 1
 #endif
 template <typename TM, typename T, int R, int EPI, int LPR = 4>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const int *__restrict__ col, const void *__restrict__ val, T scale,
@@ -274,6 +274,25 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
   for (int q = 0; q < 3; q++)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[q][r] = (T)0;
+  // the epilogue's operands asked for BEFORE the slots (fp32 vectors, 4 lanes per block row): the wavefronts of a launch are all resident and reach their epilogues together --
+  // a streaming phase behind the gather phase instead of under it
+  constexpr bool EARLY = MV_EARLY_EPI && sizeof(T) == 4 && LPR == 4;
+  T              t1[R], t2[R], t3[R], di0 = (T)0;
+  if (EARLY && lw < 3) {
+    const size_t o0 = ((size_t)3 * br + l) * R;
+    if (EPI == PMH_EPI_ADD || EPI == PMH_EPI_SUB) mv_vec<T, R>::load(e.y1 + o0, t1);
+    if (EPI == PMH_BSR_EPI_PRE || EPI == PMH_BSR_EPI_POST1) {
+      mv_vec<T, R>::load(e.y1 + o0, t1);
+      mv_vec<T, R>::load(x + o0, t2);
+      di0 = e.dinv[3 * br + l];
+    }
+    if (EPI == PMH_BSR_EPI_POST2) {
+      mv_vec<T, R>::load(y + o0, t1);
+      mv_vec<T, R>::load(x + o0, t2);
+      mv_vec<T, R>::load(e.r + o0, t3);
+      di0 = e.dinv[3 * br + l];
+    }
+  }
   if constexpr (LPR == 4 && MV_STAGED) {
     // Round 6, the operand through LDS.  A lane's slot needs the 3 R operand values of ITS block column -- NP = 6 (fp64: 12) pieces of 16 bytes, each lane of a quad from
     // another block column: four cache-line accesses per quad and load instruction, the rate that bounds the product (header comment).  Here the quad loads its trip's four
@@ -380,14 +399,14 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
   if (lw >= 3) return;
   // lane l finishes row 3 br + l: R contiguous values
   const size_t o = ((size_t)3 * br + l) * R;
-  T            out[R], t1[R], t2[R];
+  T            out[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const T v = (l == 0) ? acc[0][r] : (l == 1 ? acc[1][r] : acc[2][r]);
     out[r]    = (sizeof(TM) == 2) ? v * scale : v; // fp16 storage keeps A / scale
   }
   if (EPI == PMH_EPI_ADD || EPI == PMH_EPI_SUB) {
-    mv_vec<T, R>::load(e.y1 + o, t1);
+    if (!EARLY) mv_vec<T, R>::load(e.y1 + o, t1);
 #pragma unroll
     for (int k = 0; k < R; k++) out[k] = (EPI == PMH_EPI_ADD) ? t1[k] + out[k] : out[k] - t1[k];
   }
@@ -400,16 +419,14 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
     }
   }
   if (EPI == PMH_BSR_EPI_PRE) { // y = c0 d0 + c2 dinv (b - A d0)
-    mv_vec<T, R>::load(e.y1 + o, t1);
-    mv_vec<T, R>::load(x + o, t2);
-    const T di = e.dinv[3 * br + l];
+    if (!EARLY) mv_vec<T, R>::load(e.y1 + o, t1), mv_vec<T, R>::load(x + o, t2);
+    const T di = EARLY ? di0 : e.dinv[3 * br + l];
 #pragma unroll
     for (int k = 0; k < R; k++) out[k] = e.c0 * t2[k] + e.c2 * di * (t1[k] - out[k]);
   }
   if (EPI == PMH_BSR_EPI_POST1) { // r = dinv (b - A x); d = c0 r; y = x + d
-    mv_vec<T, R>::load(e.y1 + o, t1);
-    mv_vec<T, R>::load(x + o, t2);
-    const T di = e.dinv[3 * br + l];
+    if (!EARLY) mv_vec<T, R>::load(e.y1 + o, t1), mv_vec<T, R>::load(x + o, t2);
+    const T di = EARLY ? di0 : e.dinv[3 * br + l];
     T       rr[R], dd[R];
 #pragma unroll
     for (int k = 0; k < R; k++) {
@@ -421,13 +438,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mv_spmv(int nbr, int W4, const in
     mv_vec<T, R>::store(e.d + o, dd);
   }
   if (EPI == PMH_BSR_EPI_POST2) { // y += c1 d + c2 (r - dinv A d)
-    mv_vec<T, R>::load(y + o, t1);
-    mv_vec<T, R>::load(x + o, t2);
-    const T di = e.dinv[3 * br + l];
-    T       rr[R];
-    mv_vec<T, R>::load(e.r + o, rr);
+    if (!EARLY) mv_vec<T, R>::load(y + o, t1), mv_vec<T, R>::load(x + o, t2), mv_vec<T, R>::load(e.r + o, t3);
+    const T di = EARLY ? di0 : e.dinv[3 * br + l];
 #pragma unroll
-    for (int k = 0; k < R; k++) out[k] = t1[k] + e.c1 * t2[k] + e.c2 * (rr[k] - di * out[k]);
+    for (int k = 0; k < R; k++) out[k] = t1[k] + e.c1 * t2[k] + e.c2 * (t3[k] - di * out[k]);
     if (e.z64) {
 #pragma unroll
       for (int k = 0; k < R; k++) e.z64[o + k] = (double)out[k];

@@ -14,8 +14,8 @@
 #define PMH_MV_R 8
 
 // ELL copy of a matrix of 3 x 3 blocks, W slots per block row (a multiple of 4; padding: the row's own block column with zero values), slot planes interleaved
-// by 4 for the four lanes of a block row: col[((s / 4) * nbr + br) * 4 + s % 4]; val fp64 / fp32 at [(((s / 4) * 9 + e) * nbr + br) * 4 + s % 4] (e = 3 q + c),
-// fp16 at [(((s / 4) * 3 + q) * nbr + br) * 4 + s % 4] as vectors of 4 halves (row q of the block, entries / scale, the 4th zero)
+// by 4 for the four lanes of a block row: col[((s / 4) * nbr + br) * 4 + s % 4]; the entries (fp64 / fp32 / fp16 = entries / scale) per plane s / 4 as 16-byte vectors of the
+// entries 0 ... 7 and one element for entry 8 (e = 3 q + c): struct mv_lay in mv.hip
 struct pmh_mv_ell_s {
   pmh_ctx ctx;
   int     nbr, W, storage; // PMH_BSR_F64 / F32 / F16
