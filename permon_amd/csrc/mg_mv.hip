@@ -179,8 +179,8 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvg_coarse(int nb, int n, const i
 // pinv[row0 + i][k0 + 8 q ... + 8) in one 16-byte load and feeds them to 8 v_mfma_f32_16x16x4_f32 (exact fp32 FMAs; A[i][k = q] / B[k = q][j = l & 15], k taken as 8 q + e for
 // the e-th one: any assignment of k's to the 4 k-slots is a permutation of the sum) against B[k0 + 8 q + e][j & 7] -- the 8 columns twice: half of the instruction's N = 16 is
 // idle.  The sum over k happens inside the instruction; the wavefronts' 16 x 8 partials are added through LDS in wave order (fixed).  21.4 us = 2.5 TB/s on the matrix: 324
-// workgroups on 256 CUs leave 68 CUs with two, whose 32 wavefronts x 12 steps x 8 instructions x 32 cycles / 4 SIMDs are 10 us of matrix-core time alone -- the next steps
-// would be the 4x4x1 16-block form (no idle half, 4-row granularity) and are not taken: the solve is 6 % of an inner-Krylov step now.
+// workgroups on 256 CUs leave 68 CUs with two.  (The 4x4x1 16-block form -- no idle half, 8- or 4-row workgroups -- was built too: 18.7 - 20.1 us, removed again;
+// docs/LAB_NOTEBOOK.md "Round 6" 5, lane maps in scripts/micro/mfma_f32_4x4.hip.)
 // Needs every block's size to be a multiple of 16 (rows of a workgroup in ONE block, 16-byte aligned rows); else the form above.
 typedef float    mvg_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 mvg_h8 __attribute__((ext_vector_type(8)));
