@@ -88,14 +88,17 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start(const int *__restrict__
   }
 }
 
-__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start_pz(const int *__restrict__ rs, int wgs, const double *__restrict__ r, const double *__restrict__ z,
+// (TZ = float: z is the V-cycle's own fp32 result, read where it lies -- the fp64 copy the cycle used to leave for the three readers below was 16 MB written and 2 x 16 MB
+// read per iteration for the same values, round 6)
+template <typename TZ>
+__global__ __launch_bounds__(PMH_BLOCK) void k_mvc_start_pz(const int *__restrict__ rs, int wgs, const double *__restrict__ r, const TZ *__restrict__ z,
                         double *__restrict__ p, double *__restrict__ partB)
 {
   __shared__ double lds[32];
   double            s0 = 0.0;
   MV_ROW_LOOP(i, b, rs, wgs)
   {
-    const double zi = z[i];
+    const double zi = (double)z[i];
     p[i] = zi;
     s0 += r[i] * zi;
   }
@@ -122,13 +125,14 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_init(int ncol, int wgs, const
 }
 __global__ void k_mvc_init_done(const int *nactive, int *done) { *done = (*nactive == 0) ? 1 : 0; }
 
+template <typename TY>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_dot(const int *__restrict__ rs, int wgs, const int *__restrict__ done, const double *__restrict__ x,
-                        const double *__restrict__ y, double *__restrict__ part)
+                        const TY *__restrict__ y, double *__restrict__ part)
 {
   __shared__ double lds[32];
   if (*done) return;
   double s = 0.0;
-  MV_ROW_LOOP(i, b, rs, wgs) s += x[i] * y[i];
+  MV_ROW_LOOP(i, b, rs, wgs) s += x[i] * (double)y[i];
   s = mvc_red8(s, lds);
   if (threadIdx.x < MV_R) part[((size_t)b * MV_R + threadIdx.x) * wgs + w_] = s;
 }
@@ -174,9 +178,10 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_ur(const int *__restri
 }
 
 // beta_c = rz_new / rz; convergence of column c; p = z + beta p; the block's first workgroup publishes the next state
+template <typename TZ>
 __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_p(const int *__restrict__ rs, int ncol, int wgs, int q, int it, int max_it, double *__restrict__ cs,
                         int *__restrict__ ci, int *__restrict__ nactive, int *__restrict__ done,
-                                                           const double *__restrict__ partB, const double *__restrict__ partC, const double *__restrict__ z, double *__restrict__ p)
+                                                           const double *__restrict__ partB, const double *__restrict__ partC, const TZ *__restrict__ z, double *__restrict__ p)
 {
   __shared__ double lds[32];
   if (*done) return;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(PMH_BLOCK) void k_mvc_update_p(const int *__restric
   const double beta = rzn / CSQ(cs, q, c, 0);
   const bool   conv = (sqrt(rr) <= CSQ(cs, q, c, 1)) || (it + 1 >= max_it) || !(rr == rr);
   if (act && !conv) {
-    MV_ROW_LOOP(i, b, rs, wgs) p[i] = z[i] + beta * p[i];
+    MV_ROW_LOOP(i, b, rs, wgs) p[i] = (double)z[i] + beta * p[i];
   }
   if (blockIdx.x % wgs == 0 && threadIdx.x < MV_R) {
     if (!act) { // carry the frozen state to the other parity
@@ -374,7 +379,7 @@ static int mvc_create(pmh_matinv M, int nrep, pmh_matinv_mv *out)
   if (!rc && M->mg) rc = pmh_mg_mv_create(M->mg, &V->mgmv, nrep);
   const size_t nR = (size_t)V->n * MV_R, np = (size_t)V->ncol * V->wgs;
   for (double **v : {&V->r, &V->z, &V->p, &V->Ap, &V->fproj})
-    if (!rc) rc = pmh_malloc(ctx, sizeof(double) * nR, (void **)v);
+    if (!rc && !(v == &V->z && V->mgmv)) rc = pmh_malloc(ctx, sizeof(double) * nR, (void **)v); // (z: with a V-cycle the block CG reads the cycle's own fp32 result)
   if (nrep > 1)
     for (double **v : {&V->fin, &V->uout})
       if (!rc) rc = pmh_malloc(ctx, sizeof(double) * nR, (void **)v);
@@ -430,11 +435,12 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
   }
   PMH_HIP(hipMemsetAsync(V->d_nactive, 0, sizeof(int), st));
   PMH_HIP(hipMemsetAsync(V->d_done, 0, sizeof(int), st));
-  const int extpc = V->mgmv ? 1 : 0;
+  const int    extpc = V->mgmv ? 1 : 0;
+  const float *zf    = extpc ? pmh_mg_mv_result(V->mgmv) : nullptr;
   hipLaunchKernelGGL(k_mvc_start, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, extpc, f, (const double *)M->dinv, u, V->r, V->z, V->p, V->partB, V->partC);
   if (extpc) {
-    PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, V->z, V->d_done));
-    hipLaunchKernelGGL(k_mvc_start_pz, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const double *)V->r, (const double *)V->z, V->p, V->partB);
+    PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, nullptr, V->d_done));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvc_start_pz<float>), dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const double *)V->r, zf, V->p, V->partB);
   }
   hipLaunchKernelGGL(k_mvc_init, dim3(nb), dim3(PMH_BLOCK), 0, st, ncol, wgs, (const double *)V->partB, (const double *)V->partC, V->cs, V->ci, V->d_nactive,
                      M->rtol, M->atol, (const double *)(M->kdim ? V->d_fnorm2 : nullptr), M->kernel_tol);
@@ -453,16 +459,18 @@ int pmh_matinv_mv_mult(pmh_matinv_mv V, const double *f, double *u)
       V->ev_used += 2;
     }
     V->products++;
-    hipLaunchKernelGGL(k_mvc_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->p, (const double *)V->Ap, V->partA);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvc_dot<double>), dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->p, (const double *)V->Ap, V->partA);
     hipLaunchKernelGGL(k_mvc_update_ur, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, extpc, (const int *)V->d_done, (const double *)V->cs,
                        (const int *)V->ci, (const double *)V->partA, (const double *)M->dinv, (const double *)V->p,
                        (const double *)V->Ap, u, V->r, V->z, V->partB, V->partC);
     if (extpc) {
-      PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, V->z, V->d_done));
-      hipLaunchKernelGGL(k_mvc_dot, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->r, (const double *)V->z, V->partB);
-    }
-    hipLaunchKernelGGL(k_mvc_update_p, dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, it, M->max_it, V->cs, V->ci, V->d_nactive, V->d_done,
-                       (const double *)V->partB, (const double *)V->partC, (const double *)V->z, V->p);
+      PMH_CHK(pmh_mg_mv_apply(V->mgmv, V->r, nullptr, V->d_done));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvc_dot<float>), dim3(grid), dim3(PMH_BLOCK), 0, st, rs, wgs, (const int *)V->d_done, (const double *)V->r, zf, V->partB);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvc_update_p<float>), dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, it, M->max_it, V->cs, V->ci, V->d_nactive, V->d_done,
+                         (const double *)V->partB, (const double *)V->partC, zf, V->p);
+    } else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mvc_update_p<double>), dim3(grid), dim3(PMH_BLOCK), 0, st, rs, ncol, wgs, q, it, M->max_it, V->cs, V->ci, V->d_nactive, V->d_done,
+                         (const double *)V->partB, (const double *)V->partC, (const double *)V->z, V->p);
     PMH_HIP(hipGetLastError());
     it++;
     if (it >= next_check || it >= M->max_it) {

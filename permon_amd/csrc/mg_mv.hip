@@ -443,6 +443,7 @@ static int mvg_cycle(pmh_mg_mv M, int l, const double *b64, double *z64, bool d0
 // Z = V(B) for R columns: b, z are fp64 multivectors of n_0 R entries
 int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt)
 {
-  PMH_ARG(M && b && z);
+  PMH_ARG(M && b);
   return mvg_cycle(M, 0, b, z, false, halt);
 }
+const float *pmh_mg_mv_result(pmh_mg_mv M) { return M->L[0].x; }

@@ -52,7 +52,8 @@ typedef pmh_mg_mv_s *pmh_mg_mv;
 // nrep > 1: the hierarchy of the FIRST of nrep congruent blocks (every level is block diagonal with nrep equal blocks)
 int pmh_mg_mv_create(pmh_mg mg, pmh_mg_mv *out, int nrep = 1);
 int pmh_mg_mv_destroy(pmh_mg_mv M);
-int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt);
+int pmh_mg_mv_apply(pmh_mg_mv M, const double *b, double *z, const int *halt); // z == NULL: no fp64 copy of the result, the caller reads pmh_mg_mv_result()
+const float *pmh_mg_mv_result(pmh_mg_mv M); // the cycle's own (fp32) result multivector: valid until the next apply
 
 // the block CG of MATINV for R columns per block (matinv_mv.hip) on top of a one-column solver's K, V-cycle, kernel basis and tolerances
 struct pmh_matinv_mv_s;
